@@ -1,0 +1,507 @@
+/* oracle/chz_oracle.c -- TEST INFRASTRUCTURE (CPU oracle), not a product path.
+ * Plain-C restatement of the reference algorithm; see chz_oracle.h for scope
+ * and pinning.  Every function cites the reference lines it follows.
+ */
+#define _GNU_SOURCE 1
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <stdint.h>
+#include <pthread.h>
+#include "chz_oracle.h"
+#include "dft.h"
+
+/* Plans are cached per (length, real?) so repeated blocks do not rebuild the
+   twiddle tables; tables are built under the lock, execution is lock-free. */
+#define PLAN_CACHE 16
+static struct { int n, real; odft_plan *pl; } Cache[PLAN_CACHE];
+static pthread_mutex_t Cache_lock = PTHREAD_MUTEX_INITIALIZER;
+static odft_plan *cached_plan(int n, int real) {
+  pthread_mutex_lock(&Cache_lock);
+  int freeslot = -1;
+  for (int i = 0; i < PLAN_CACHE; i++) {
+    if (Cache[i].pl && Cache[i].n == n && Cache[i].real == real) {
+      odft_plan *p = Cache[i].pl; pthread_mutex_unlock(&Cache_lock); return p;
+    }
+    if (!Cache[i].pl && freeslot < 0) freeslot = i;
+  }
+  if (freeslot < 0) { freeslot = 0; odft_destroy(Cache[0].pl); }
+  odft_plan *p = odft_create(n, ODFT_F64);
+  if (p) odft_warm(p, real);
+  Cache[freeslot].n = n; Cache[freeslot].real = real; Cache[freeslot].pl = p;
+  pthread_mutex_unlock(&Cache_lock);
+  return p;
+}
+
+/* ------------------------------------------------------------------ */
+/* small helpers                                                       */
+/* ------------------------------------------------------------------ */
+
+/* sin(pi x), cos(pi x) with the argument reduced in units of half-turns so the
+   result does not lose accuracy for large |x| (role of src/sincospi.c:24-65). */
+static void sincos_pi(double x, double *s, double *c) {
+  if (!isfinite(x)) { *s = *c = NAN; return; }
+  double y = fmod(x, 2.0);
+  if (y < 0) y += 2.0;                 /* [0,2) */
+  int q = (int)floor(2.0 * y);         /* quarter-turn index 0..3 */
+  if (q > 3) q = 3;
+  double r = y - 0.5 * q;              /* [0,0.5) */
+  double sr, cr;
+  if (r > 0.25) { sr = cos(M_PI * (0.5 - r)); cr = sin(M_PI * (0.5 - r)); }
+  else          { sr = sin(M_PI * r);         cr = cos(M_PI * r); }
+  switch (q) {
+  case 0: *s =  sr; *c =  cr; break;
+  case 1: *s =  cr; *c = -sr; break;
+  case 2: *s = -sr; *c = -cr; break;
+  default:*s = -cr; *c =  sr; break;
+  }
+}
+
+static double sinc_pi(double x) {      /* src/misc.h:217-221 */
+  return x == 0 ? 1.0 : sin(M_PI * x) / (M_PI * x);
+}
+
+/* ------------------------------------------------------------------ */
+/* filter design                                                       */
+/* ------------------------------------------------------------------ */
+
+/* Modified Bessel function I0 by its power series, stopping when a term falls
+   below 1e-12 of the running sum, at most 40 terms (src/misc.c:416-427). */
+double chzo_i0(double z) {
+  const double t = 0.25 * z * z;
+  double term = t, sum = 1.0 + t;
+  for (int k = 2; k < 40; k++) {
+    term *= t / ((double)k * (double)k);
+    sum += term;
+    if (term < 1e-12 * sum) break;
+  }
+  return sum;
+}
+
+/* Kaiser window, float32 storage, computed symmetric from both ends; the middle
+   tap of an odd-length window is exactly 1 (src/window.c:217-237). */
+int chzo_make_kaiser(float *w, int M, double beta) {
+  if (!w || M < 2 || !isfinite(beta)) return -1;
+  const double inv = 1.0 / chzo_i0(beta);
+  const double step = 2.0 / (M - 1);
+  for (int n = 0; n < M / 2; n++) {
+    double p = step * n - 1.0;
+    float v = (float)(chzo_i0(beta * sqrt(1.0 - p * p)) * inv);
+    w[n] = v; w[M - 1 - n] = v;
+  }
+  if (M & 1) w[(M - 1) / 2] = 1.0f;
+  return 0;
+}
+
+/* scale so the taps sum to M (src/window.c:240-254) */
+int chzo_normalize_window(float *w, int M) {
+  if (!w || M == 0) return -1;
+  double g = 0;
+  for (int i = 0; i < M; i++) g += w[i];
+  if (g == 0 || !isfinite(g)) return -1;
+  g = M / g;
+  for (int i = 0; i < M; i++) w[i] *= (float)g;
+  return 0;
+}
+
+/* src/filter.c:968-1045.  Taps: h[i] = kaiser[i] * 2 bw2 sinc(2 bw2 n) * e^{j 2 pi center n},
+   n = i - (M-1)/2, M = P - olen + 1; gain = (sqrt2 if master real) / (sum_i r_i * N_master);
+   zero-pad to P, forward P-point transform. */
+int chzo_set_filter(int P, int olen, int master_points, int master_real, int out_type,
+                    double low, double high, double beta, float *response) {
+  if (!response || isnan(low) || isnan(high) || isnan(beta)) return -1;
+  if (out_type == CHZO_REAL) { low = fabs(low); high = fabs(high); }   /* :971-975 */
+  if (low > high) { double t = low; low = high; high = t; }            /* :977-981 */
+  low  = low  < -0.5 ? -0.5 : low  > 0.5 ? 0.5 : low;                  /* :983-984 */
+  high = high < -0.5 ? -0.5 : high > 0.5 ? 0.5 : high;
+  const int M = P - olen + 1;                                          /* :986-988 */
+  if (M < 2) return -1;
+  const double bw2 = (high == low) ? 0.0001 : fabs(high - low) / 2;    /* :992 */
+  const double center = (high + low) / 2;                              /* :993 */
+
+  float *win = (float *)malloc(sizeof(float) * (size_t)M);
+  float *taps = (float *)calloc((size_t)P * 2, sizeof(float));
+  if (!win || !taps) { free(win); free(taps); return -1; }
+  chzo_make_kaiser(win, M, beta);
+  chzo_normalize_window(win, M);
+
+  double wsum = 0;
+  for (int i = 0; i < M; i++) {                                        /* :1011-1019 */
+    double n = i - (double)(M - 1) / 2;
+    double r = win[i] * 2 * bw2 * sinc_pi(2 * bw2 * n);
+    wsum += r;
+    double s, c;
+    sincos_pi(2 * center * n, &s, &c);
+    taps[2 * i] = (float)(c * r);
+    taps[2 * i + 1] = (float)(s * r);
+  }
+  const double gain = (master_real ? M_SQRT2 : 1.0) / (wsum * master_points);  /* :1024-1025 */
+  for (int i = 0; i < M; i++) {                                        /* :1027-1028 */
+    taps[2 * i] = (float)(taps[2 * i] * gain);
+    taps[2 * i + 1] = (float)(taps[2 * i + 1] * gain);
+  }
+  odft_plan *pl = cached_plan(P, 0);
+  if (!pl) { free(win); free(taps); return -1; }
+  odft_c2c(pl, taps, response, -1);                                    /* :1030 */
+  free(win); free(taps);
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* forward transform                                                   */
+/* ------------------------------------------------------------------ */
+
+int chzo_forward_f64(const float *window, int N, int in_type, double *spectrum) {
+  odft_plan *pl = cached_plan(N, in_type == CHZO_REAL);
+  if (!pl) return -1;
+  if (in_type == CHZO_REAL) {
+    double *x = (double *)malloc(sizeof(double) * (size_t)N);
+    for (int i = 0; i < N; i++) x[i] = window[i];
+    odft_r2c_f64(pl, x, spectrum);                                     /* src/filter.c:508,582 */
+    free(x);
+  } else {
+    double *x = (double *)malloc(sizeof(double) * 2 * (size_t)N);
+    for (long i = 0; i < 2L * N; i++) x[i] = window[i];
+    odft_c2c_f64(pl, x, spectrum, -1);                                 /* src/filter.c:505,573 */
+    free(x);
+  }
+  return 0;
+}
+
+int chzo_forward(const float *window, int N, int in_type, float *spectrum) {
+  int bins = in_type == CHZO_REAL ? N / 2 + 1 : N;
+  double *s = (double *)malloc(sizeof(double) * 2 * (size_t)bins);
+  if (!s) return -1;
+  int r = chzo_forward_f64(window, N, in_type, s);
+  for (long i = 0; i < 2L * bins; i++) spectrum[i] = (float)s[i];
+  free(s);
+  return r;
+}
+
+/* src/filter.c:464-474: state += alpha (X[bin] - state); X[bin] -= state;
+   list ends with the DC entry. */
+void chzo_notch(double *state, const int *bins, int n, double alpha, float *spectrum) {
+  for (int i = 0; i < n; i++) {
+    int b = bins[i];
+    state[2 * i]     += alpha * ((double)spectrum[2 * b]     - state[2 * i]);
+    state[2 * i + 1] += alpha * ((double)spectrum[2 * b + 1] - state[2 * i + 1]);
+    spectrum[2 * b]     = (float)((double)spectrum[2 * b]     - state[2 * i]);
+    spectrum[2 * b + 1] = (float)((double)spectrum[2 * b + 1] - state[2 * i + 1]);
+    if (b == 0) break;
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* per-channel gather                                                  */
+/* ------------------------------------------------------------------ */
+
+/* Source descriptor for one output bin: master index, or -1 for "zero";
+   conj != 0 means the master bin is conjugated (inverted spectrum). */
+struct src { int idx; int conj; };
+
+/* Output bins are visited from the most negative frequency upward; the t-th
+   visited bin lives at FFT-order index ((s_bins+1)/2 + t) mod s_bins
+   (src/filter.c:730,818: "wp = (s_bins+1)/2"). */
+
+/* REAL master, COMPLEX slave (src/filter.c:810-893) */
+static struct src map_real_to_complex(int t, int m_bins, int s_bins, int shift) {
+  struct src s = { -1, 0 };
+  if (shift >= 0) {                       /* upright spectrum, :819-855 */
+    long r = (long)shift - s_bins / 2 + t;
+    if (r >= 0 && r < m_bins) s.idx = (int)r;
+  } else {                                /* inverted spectrum, read downward, :856-892 */
+    long r = -((long)shift - s_bins / 2) - t;
+    if (r >= 0 && r < m_bins) { s.idx = (int)r; s.conj = 1; }
+  }
+  return s;
+}
+
+/* COMPLEX master, COMPLEX slave (src/filter.c:728-793, non-beam).  The walk is
+   stateful: leading zeros while below -(m_bins+1)/2, one wrap of a negative
+   start into the upper half of the array, then an upward copy that ends for
+   good when the read index arrives at (m_bins+1)/2. */
+static void map_complex_to_complex(struct src *map, int m_bins, int s_bins, int shift) {
+  long r = (long)shift - s_bins / 2;
+  int started = 0, ended = 0;
+  long rp = 0;
+  for (int t = 0; t < s_bins; t++, r++) {
+    map[t].idx = -1; map[t].conj = 0;
+    if (!started) {
+      if (r < -(long)((m_bins + 1) / 2)) continue;        /* :733-741 */
+      started = 1;
+      rp = r < 0 ? r + m_bins : r;                         /* :742-743 */
+      if (rp < 0 || rp >= m_bins) ended = 1;               /* :744-754 */
+    }
+    if (ended) continue;
+    map[t].idx = (int)rp;                                  /* :780 */
+    if (++rp == m_bins) rp = 0;                            /* :781-782 */
+    if (rp == (m_bins + 1) / 2) ended = 1;                 /* :785 */
+  }
+}
+
+static inline int imod(long x, int m) { long r = x % m; return (int)(r < 0 ? r + m : r); }
+
+/* fd (float32, the reference's arithmetic) and/or fd64 (from a float64 spectrum) */
+static int gather_core(const float *sp, const double *sp64, int m_bins, int in_type,
+                       int s_bins, int out_type, int shift, int isb,
+                       const float *H, float *fd, double *fd64) {
+  if (m_bins <= 0 || s_bins <= 0 || !H) return -1;
+#define X_RE(i) (sp ? (double)sp[2 * (i)] : sp64[2 * (i)])
+#define X_IM(i) (sp ? (double)sp[2 * (i)+1] : sp64[2 * (i)+1])
+#define PUT(w, re, im) do { if (fd) { fd[2*(w)] = (float)(re); fd[2*(w)+1] = (float)(im); } \
+                            if (fd64) { fd64[2*(w)] = (re); fd64[2*(w)+1] = (im); } } while (0)
+  /* float32 products when reproducing the reference, float64 otherwise */
+#define MUL_PUT(w, xr, xi) do { \
+    if (fd) { float a = (float)(xr), b = (float)(xi), hr = H[2*(w)], hi = H[2*(w)+1]; \
+              fd[2*(w)] = a*hr - b*hi; fd[2*(w)+1] = a*hi + b*hr; } \
+    if (fd64) { double hr = H[2*(w)], hi = H[2*(w)+1]; \
+              fd64[2*(w)] = (xr)*hr - (xi)*hi; fd64[2*(w)+1] = (xr)*hi + (xi)*hr; } } while (0)
+
+  if (out_type == CHZO_COMPLEX) {
+    struct src *map = (struct src *)malloc(sizeof(struct src) * (size_t)s_bins);
+    if (!map) return -1;
+    if (in_type == CHZO_COMPLEX) map_complex_to_complex(map, m_bins, s_bins, shift);
+    else for (int t = 0; t < s_bins; t++) map[t] = map_real_to_complex(t, m_bins, s_bins, shift);
+    for (int t = 0; t < s_bins; t++) {
+      int w = ((s_bins + 1) / 2 + t) % s_bins;
+      if (map[t].idx < 0) { PUT(w, 0.0, 0.0); continue; }
+      double xr = X_RE(map[t].idx), xi = X_IM(map[t].idx);
+      if (map[t].conj) xi = -xi;
+      MUL_PUT(w, xr, xi);
+    }
+    free(map);
+  } else if (out_type == CHZO_REAL && in_type == CHZO_REAL) {
+    for (int si = 0; si < s_bins; si++) {                  /* src/filter.c:803-809 */
+      long mi = (long)si + shift;
+      if (mi >= 0 && mi < m_bins) { double xr = X_RE(mi), xi = X_IM(mi); MUL_PUT(si, xr, xi); }
+      else PUT(si, 0.0, 0.0);
+    }
+  } else if (out_type == CHZO_REAL && in_type == CHZO_COMPLEX) {
+    for (int si = 0; si < s_bins; si++) {                  /* src/filter.c:794-802 */
+      long mi = (long)si + shift;
+      if (mi >= -(m_bins / 2) && mi < m_bins / 2) {
+        int a = imod(mi, m_bins), b = imod((long)m_bins - mi, m_bins);
+        double xr = X_RE(a) + X_RE(b), xi = X_IM(a) - X_IM(b);
+        if (fd) { /* reference sums in float32 first, then multiplies */
+          float fr = (float)X_RE(a) + (float)X_RE(b), fi = (float)X_IM(a) - (float)X_IM(b);
+          float hr = H[2*si], hi = H[2*si+1];
+          fd[2*si] = hr*fr - hi*fi; fd[2*si+1] = hr*fi + hi*fr;
+        }
+        if (fd64) { double hr = H[2*si], hi = H[2*si+1];
+          fd64[2*si] = hr*xr - hi*xi; fd64[2*si+1] = hr*xi + hi*xr; }
+      } else PUT(si, 0.0, 0.0);
+    }
+  } else return -1;
+
+  if (isb && out_type == CHZO_COMPLEX) {                   /* src/filter.c:895-909 */
+    for (int p = 1, dn = s_bins - 1; p < s_bins / 2; p++, dn--) {
+      if (fd) {
+        float pr = fd[2*p], pi = fd[2*p+1], nr = fd[2*dn], ni = fd[2*dn+1];
+        fd[2*p] = pr + nr;  fd[2*p+1] = pi - ni;           /* pos + conj(neg) */
+        fd[2*dn] = nr - pr; fd[2*dn+1] = ni + pi;          /* neg - conj(pos) */
+      }
+      if (fd64) {
+        double pr = fd64[2*p], pi = fd64[2*p+1], nr = fd64[2*dn], ni = fd64[2*dn+1];
+        fd64[2*p] = pr + nr;  fd64[2*p+1] = pi - ni;
+        fd64[2*dn] = nr - pr; fd64[2*dn+1] = ni + pi;
+      }
+    }
+    PUT(0, 0.0, 0.0);
+  }
+  PUT((s_bins + 1) / 2, 0.0, 0.0);                         /* src/filter.c:911 */
+  return 0;
+#undef X_RE
+#undef X_IM
+#undef PUT
+#undef MUL_PUT
+}
+
+int chzo_gather(const float *spectrum, int m_bins, int in_type, int s_bins, int out_type,
+                int shift, int isb, const float *response, float *fdomain) {
+  return gather_core(spectrum, NULL, m_bins, in_type, s_bins, out_type, shift, isb, response, fdomain, NULL);
+}
+
+int chzo_channel(const float *spectrum, int m_bins, int in_type, int P, int olen, int out_type,
+                 int shift, int isb, const float *response, float *out) {
+  int s_bins = out_type == CHZO_REAL ? P / 2 + 1 : P;      /* src/filter.c:346,374 */
+  float *fd = (float *)malloc(sizeof(float) * 2 * (size_t)(s_bins + 1));
+  float *td = (float *)malloc(sizeof(float) * 2 * (size_t)P);
+  if (!fd || !td) { free(fd); free(td); return -1; }
+  int r = gather_core(spectrum, NULL, m_bins, in_type, s_bins, out_type, shift, isb, response, fd, NULL);
+  if (r == 0) {
+    odft_plan *pl = cached_plan(P, 0);
+    if (out_type == CHZO_COMPLEX) {
+      odft_c2c(pl, fd, td, +1);                            /* src/filter.c:914 via :359 */
+      memcpy(out, td + 2 * (size_t)(P - olen), sizeof(float) * 2 * (size_t)olen);   /* :357 */
+    } else {
+      odft_c2r(pl, fd, td);                                /* :387 */
+      memcpy(out, td + (P - olen), sizeof(float) * (size_t)olen);                  /* :385 */
+    }
+  }
+  free(fd); free(td);
+  return r;
+}
+
+int chzo_channel_f64(const double *spectrum, int m_bins, int in_type, int P, int olen, int out_type,
+                     int shift, int isb, const float *response, double *out) {
+  if (out_type != CHZO_COMPLEX) return -1;                 /* demodulators only use COMPLEX out */
+  double *fd = (double *)malloc(sizeof(double) * 2 * (size_t)P);
+  double *td = (double *)malloc(sizeof(double) * 2 * (size_t)P);
+  if (!fd || !td) { free(fd); free(td); return -1; }
+  int r = gather_core(NULL, spectrum, m_bins, in_type, P, out_type, shift, isb, response, NULL, fd);
+  if (r == 0) {
+    odft_plan *pl = cached_plan(P, 0);
+    odft_c2c_f64(pl, fd, td, +1);
+    memcpy(out, td + 2 * (size_t)(P - olen), sizeof(double) * 2 * (size_t)olen);
+  }
+  free(fd); free(td);
+  return r;
+}
+
+/* ------------------------------------------------------------------ */
+/* sig_gen stream                                                      */
+/* ------------------------------------------------------------------ */
+
+struct chzo_siggen {
+  /* rotator, src/osc.c:28-70 */
+  double ph_re, ph_im, st_re, st_im;
+  int steps;
+  /* xoshiro256**, src/gauss.c:19-61 */
+  uint64_t s[4];
+  double amplitude, noise, scale;
+  int isreal;
+};
+
+static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+static uint64_t splitmix(uint64_t *x) {                    /* src/gauss.c:25-30 */
+  uint64_t z = (*x += 0x9E3779B97F4A7C15ULL);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+static uint64_t xo_next(uint64_t s[4]) {                   /* src/gauss.c:47-61 */
+  uint64_t out = rotl(s[1] * 5, 7) * 9;
+  uint64_t t = s[1] << 17;
+  s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+  s[2] ^= t;
+  s[3] = rotl(s[3], 45);
+  return out;
+}
+
+/* popcount-based near-Gaussian, unit variance (src/gauss.c:102-111) */
+static double gauss1(uint64_t s[4]) {
+  uint64_t u = xo_next(s);
+  double x = (double)(__builtin_popcountll(u * 0x2c1b3c6dULL) + __builtin_popcountll(u * 0x297a2d39ULL) - 64);
+  x += (double)(int64_t)u * (1.0 / 9223372036854775808.0);
+  return x * 0.1765469659009499;
+}
+
+chzo_siggen *chzo_siggen_create(double cycles_per_sample, double amplitude, double noise,
+                                double scale, int isreal, uint64_t seed) {
+  chzo_siggen *g = (chzo_siggen *)calloc(1, sizeof *g);
+  if (!g) return NULL;
+  g->ph_re = 1; g->ph_im = 0; g->steps = 16384;            /* src/osc.c:18,30-32 */
+  double s, c;
+  if (cycles_per_sample != 0) { sincos_pi(2 * cycles_per_sample, &s, &c); g->st_re = c; g->st_im = s; }
+  else { g->st_re = 1; g->st_im = 0; }                      /* src/osc.c:37-40 */
+  uint64_t x = seed;                                        /* src/gauss.c:33-45 */
+  for (int i = 0; i < 4; i++) g->s[i] = splitmix(&x);
+  if ((g->s[0] | g->s[1] | g->s[2] | g->s[3]) == 0) g->s[0] = 1;
+  g->amplitude = amplitude; g->noise = noise; g->scale = scale; g->isreal = isreal;
+  return g;
+}
+void chzo_siggen_delete(chzo_siggen *g) { free(g); }
+
+/* one rotator step; returns the phasor BEFORE stepping (src/osc.c:60-70),
+   renormalising every 16384 steps (src/osc.c:47-57) */
+static void osc_step(chzo_siggen *g, double *re, double *im) {
+  if (--g->steps <= 0) {
+    g->steps = 16384;
+    double a = hypot(g->ph_re, g->ph_im);
+    g->ph_re /= a; g->ph_im /= a;
+  }
+  *re = g->ph_re; *im = g->ph_im;
+  double nr = g->ph_re * g->st_re - g->ph_im * g->st_im;
+  double ni = g->ph_re * g->st_im + g->ph_im * g->st_re;
+  g->ph_re = nr; g->ph_im = ni;
+}
+
+void chzo_siggen_generate(chzo_siggen *g, float *out, long n) {
+  if (g->isreal) {                                          /* src/sig_gen.c:291-296 */
+    for (long i = 0; i < n; i++) {
+      double cr, ci; osc_step(g, &cr, &ci);
+      double samp = g->amplitude * cr + g->noise * gauss1(g->s);
+      out[i] = (float)(samp * g->scale);
+    }
+  } else {                                                  /* src/sig_gen.c:321-326 */
+    for (long i = 0; i < n; i++) {
+      double cr, ci; osc_step(g, &cr, &ci);
+      double nr = gauss1(g->s), ni = gauss1(g->s);          /* src/misc.h:399-403 */
+      double sr = g->amplitude * cr + g->noise * nr, si = g->amplitude * ci + g->noise * ni;
+      out[2 * i] = (float)(sr * g->scale);
+      out[2 * i + 1] = (float)(si * g->scale);
+    }
+  }
+}
+
+/* src/radio.c:1630-1650: 10^(-gain/20) * 2^(1-bits), real front ends get -3 dB of gain */
+double chzo_scale_ad(double rf_gain_db, double rf_atten_db, double level_cal_db, int isreal, int bitspersample) {
+  double g = 0;
+  if (isfinite(rf_gain_db)) g += rf_gain_db;
+  if (isfinite(rf_atten_db)) g -= rf_atten_db;
+  if (isfinite(level_cal_db)) g -= level_cal_db;
+  if (isreal) g -= 3.0;
+  return ldexp(pow(10.0, -g / 20.0), 1 - bitspersample);
+}
+
+/* src/radio.c:1175-1199 */
+int chzo_compute_tuning(int N, double samprate, double freq, int *shift, double *remainder) {
+  double hzperbin = samprate / N;
+  long r = lrint(freq / hzperbin);
+  if (shift) *shift = (int)r;
+  if (remainder) *remainder = fma(-(double)r, hzperbin, freq);
+  return labs(r) >= N / 2 ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* overlap-save stream                                                 */
+/* ------------------------------------------------------------------ */
+
+struct chzo_stream {
+  int L, M, N, in_type, bins, per;
+  float *win;       /* N samples: M-1 of history followed by the L newest */
+};
+
+chzo_stream *chzo_stream_create(int L, int M, int in_type) {
+  if (L < 1 || M < 1 || (in_type != CHZO_REAL && in_type != CHZO_COMPLEX)) return NULL;
+  chzo_stream *s = (chzo_stream *)calloc(1, sizeof *s);
+  if (!s) return NULL;
+  s->L = L; s->M = M; s->N = L + M - 1; s->in_type = in_type;         /* src/filter.c:196 */
+  s->per = in_type == CHZO_REAL ? 1 : 2;
+  s->bins = in_type == CHZO_REAL ? s->N / 2 + 1 : s->N;               /* src/filter.c:197 */
+  if (s->bins < 2) { free(s); return NULL; }                          /* src/filter.c:198-199 */
+  s->win = (float *)calloc((size_t)s->N * s->per, sizeof(float));     /* ring starts zeroed, :242,257 */
+  if (!s->win) { free(s); return NULL; }
+  return s;
+}
+void chzo_stream_delete(chzo_stream *s) { if (s) { free(s->win); free(s); } }
+int chzo_stream_bins(const chzo_stream *s) { return s->bins; }
+int chzo_stream_points(const chzo_stream *s) { return s->N; }
+
+static void stream_advance(chzo_stream *s, const float *samples) {
+  /* the read pointer advances by L per block while the write pointer leads it
+     by M-1 (src/filter.c:244,259,628-635): window k = stream[kL-(M-1), kL+L) */
+  size_t keep = (size_t)(s->M - 1) * s->per, fresh = (size_t)s->L * s->per;
+  memmove(s->win, s->win + fresh, sizeof(float) * keep);
+  memcpy(s->win + keep, samples, sizeof(float) * fresh);
+}
+int chzo_stream_push(chzo_stream *s, const float *samples, float *spectrum) {
+  stream_advance(s, samples);
+  return chzo_forward(s->win, s->N, s->in_type, spectrum);
+}
+int chzo_stream_push_f64(chzo_stream *s, const float *samples, double *spectrum) {
+  stream_advance(s, samples);
+  return chzo_forward_f64(s->win, s->N, s->in_type, spectrum);
+}

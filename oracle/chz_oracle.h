@@ -1,0 +1,87 @@
+/* oracle/chz_oracle.h -- TEST INFRASTRUCTURE (CPU oracle), not a product path.
+ *
+ * Plain-C restatement of ka9q-radio's overlap-save channelizer (the path behind
+ * src/filter.h).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this; the shipped HIP path never does.
+ *
+ * Pinning: the reference has NO golden vectors or tests for this path
+ * (SURVEY.md section 4), so this restatement is pinned against the reference
+ * ITSELF: oracle/_ref/libka9q_ref.so is the reference's own filter.c, window.c,
+ * misc.c, osc.c, gauss.c compiled unmodified (oracle/Makefile), and
+ * tests/test_oracle_vs_reference.py checks every function below against it on
+ * seeded inputs; tests/golden/ holds vectors generated from it.  The FFT
+ * butterflies themselves come from FFTW3 in the reference (third-party, absent
+ * from /root/reference and from this image); they are restated from the DFT
+ * definition in oracle/dft.c and cross-checked against numpy's pocketfft.
+ *
+ * Type codes follow the reference's enum filtertype (src/filter.h:29-34):
+ *   1 COMPLEX, 2 REAL, 3 SPECTRUM.
+ */
+#ifndef CHZ_ORACLE_H
+#define CHZ_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { CHZO_COMPLEX = 1, CHZO_REAL = 2, CHZO_SPECTRUM = 3 };
+
+/* ---- filter design (host side of the path; src/filter.c:968-1045) ---- */
+double chzo_i0(double z);                                   /* src/misc.c:416-427 */
+int chzo_make_kaiser(float *w, int M, double beta);         /* src/window.c:217-237 */
+int chzo_normalize_window(float *w, int M);                 /* src/window.c:240-254 */
+/* response[2*P] <- frequency response exactly as set_filter builds it.
+   master_points = N of the master, master_real != 0 adds the +3 dB. */
+int chzo_set_filter(int P, int olen, int master_points, int master_real, int out_type,
+                    double low, double high, double beta, float *response);
+
+/* ---- forward transform of one N-sample window (src/filter.c:505-508,573-582) ---- */
+int chzo_forward(const float *window, int N, int in_type, float *spectrum);        /* float32 result */
+int chzo_forward_f64(const float *window, int N, int in_type, double *spectrum);   /* unrounded */
+
+/* ---- spur notches (src/filter.c:464-474); state = 2 doubles per notch; the
+        list must end with bin 0 ---- */
+void chzo_notch(double *state, const int *bins, int n, double alpha, float *spectrum);
+
+/* ---- per-channel: gather x response (src/filter.c:728-911) ---- */
+int chzo_gather(const float *spectrum, int m_bins, int in_type,
+                int s_bins, int out_type, int shift, int isb,
+                const float *response, float *fdomain);
+/* gather + backward transform + keep the last olen samples (src/filter.c:357,914).
+   out: 2*olen floats (COMPLEX) or olen floats (REAL). */
+int chzo_channel(const float *spectrum, int m_bins, int in_type,
+                 int P, int olen, int out_type, int shift, int isb,
+                 const float *response, float *out);
+/* the same carried in float64 from an unrounded spectrum: the "exact" answer
+   used to measure both the GPU's and the reference's float32 error */
+int chzo_channel_f64(const double *spectrum, int m_bins, int in_type,
+                     int P, int olen, int out_type, int shift, int isb,
+                     const float *response, double *out);
+
+/* ---- deterministic sig_gen stream (src/sig_gen.c:291-296,321-326; src/osc.c:28-70;
+        src/gauss.c:32-61,95-111) ---- */
+typedef struct chzo_siggen chzo_siggen;
+chzo_siggen *chzo_siggen_create(double cycles_per_sample, double amplitude, double noise,
+                                double scale, int isreal, uint64_t seed);
+void chzo_siggen_delete(chzo_siggen *s);
+void chzo_siggen_generate(chzo_siggen *s, float *out, long n);
+double chzo_scale_ad(double rf_gain_db, double rf_atten_db, double level_cal_db,
+                     int isreal, int bitspersample);        /* src/radio.c:1630-1650 */
+/* shift/remainder split of a tuning frequency (src/radio.c:1175-1199) */
+int chzo_compute_tuning(int N, double samprate, double freq, int *shift, double *remainder);
+
+/* ---- whole overlap-save stream driver (src/filter.c:186-269,558-651,1093-1134):
+        keeps the M-1 sample history, first block is preceded by M-1 zeros ---- */
+typedef struct chzo_stream chzo_stream;
+chzo_stream *chzo_stream_create(int L, int M, int in_type);
+void chzo_stream_delete(chzo_stream *s);
+int chzo_stream_bins(const chzo_stream *s);
+int chzo_stream_points(const chzo_stream *s);
+/* push exactly L new samples; fills spectrum (2*bins floats) of the new block */
+int chzo_stream_push(chzo_stream *s, const float *samples, float *spectrum);
+int chzo_stream_push_f64(chzo_stream *s, const float *samples, double *spectrum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

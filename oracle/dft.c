@@ -1,0 +1,219 @@
+/* oracle/dft.c -- TEST INFRASTRUCTURE (CPU oracle), not a product path.
+ * See dft.h / dft_core.h.  Restates the DFT definition FFTW3 implements for the
+ * reference's call sites src/filter.c:106,127,148,505,508,573,582,914,1007,1030.
+ */
+#define _GNU_SOURCE 1
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <alloca.h>
+#include "dft.h"
+
+#define DFT_REAL double
+#define DFT_NAME(x) d64_##x
+#include "dft_core.h"
+#undef DFT_REAL
+#undef DFT_NAME
+
+#define DFT_REAL float
+#define DFT_NAME(x) f32_##x
+#include "dft_core.h"
+#undef DFT_REAL
+#undef DFT_NAME
+
+struct odft_plan {
+  int n;
+  int precision;
+  d64_plan *full64;   /* length n   (lazily built) */
+  d64_plan *half64;   /* length n/2 (lazily built, even n only) */
+  f32_plan *full32;
+  f32_plan *half32;
+  double *rtw;        /* W_n^k, k = 0..n/2, interleaved (re,im), forward sign; lazily built */
+};
+
+odft_plan *odft_create(int n, int precision) {
+  if (n < 1) return NULL;
+  odft_plan *p = (odft_plan *)calloc(1, sizeof *p);
+  if (!p) return NULL;
+  p->n = n;
+  p->precision = precision;
+  return p;
+}
+
+void odft_destroy(odft_plan *p) {
+  if (!p) return;
+  d64_plan_destroy(p->full64); d64_plan_destroy(p->half64);
+  f32_plan_destroy(p->full32); f32_plan_destroy(p->half32);
+  free(p->rtw);
+  free(p);
+}
+
+int odft_length(const odft_plan *p) { return p ? p->n : 0; }
+
+/* Plans are built lazily; callers (the FFTW shim) create them under the
+   reference's own planning mutex (src/filter.c:50-51), and the bench/test
+   drivers touch each plan once from one thread before going parallel. */
+static d64_plan *need_full64(odft_plan *p) { if (!p->full64) p->full64 = d64_plan_create(p->n); return p->full64; }
+static d64_plan *need_half64(odft_plan *p) { if (!p->half64) p->half64 = d64_plan_create(p->n / 2); return p->half64; }
+static f32_plan *need_full32(odft_plan *p) { if (!p->full32) p->full32 = f32_plan_create(p->n); return p->full32; }
+static f32_plan *need_half32(odft_plan *p) { if (!p->half32) p->half32 = f32_plan_create(p->n / 2); return p->half32; }
+
+static const double *need_rtw(odft_plan *p) {
+  if (p->rtw) return p->rtw;
+  int h = p->n / 2;
+  double *t = (double *)malloc(sizeof(double) * 2 * (size_t)(h + 1));
+  for (int k = 0; k <= h; k++) {
+    double s, c;
+    sincos(2.0 * M_PI * (double)k / (double)p->n, &s, &c);
+    t[2 * k] = c; t[2 * k + 1] = -s;
+  }
+  p->rtw = t;
+  return t;
+}
+
+void odft_warm(odft_plan *p, int real) {
+  /* force table construction from a single thread */
+  if (p->precision == ODFT_F64) { if (real && !(p->n & 1)) { need_half64(p); need_rtw(p); } else need_full64(p); }
+  else { if (real && !(p->n & 1)) { need_half32(p); need_rtw(p); } else need_full32(p); }
+}
+
+void odft_c2c_f64(odft_plan *p, const double *in, double *out, int sign) {
+  d64_plan *pl = need_full64(p);
+  size_t n = (size_t)p->n;
+  if (in == out) {
+    d64_cpx *tmp = (d64_cpx *)malloc(sizeof(d64_cpx) * n);
+    memcpy(tmp, in, sizeof(d64_cpx) * n);
+    d64_execute(pl, tmp, (d64_cpx *)out, sign);
+    free(tmp);
+  } else {
+    d64_execute(pl, (const d64_cpx *)in, (d64_cpx *)out, sign);
+  }
+}
+
+void odft_c2c(odft_plan *p, const float *in, float *out, int sign) {
+  size_t n = (size_t)p->n;
+  if (p->precision == ODFT_F64) {
+    d64_plan *pl = need_full64(p);
+    d64_cpx *a = (d64_cpx *)malloc(sizeof(d64_cpx) * n * 2);
+    d64_cpx *b = a + n;
+    for (size_t i = 0; i < n; i++) { a[i].re = in[2 * i]; a[i].im = in[2 * i + 1]; }
+    d64_execute(pl, a, b, sign);
+    for (size_t i = 0; i < n; i++) { out[2 * i] = (float)b[i].re; out[2 * i + 1] = (float)b[i].im; }
+    free(a);
+  } else {
+    f32_plan *pl = need_full32(p);
+    if (in == out) {
+      f32_cpx *tmp = (f32_cpx *)malloc(sizeof(f32_cpx) * n);
+      memcpy(tmp, in, sizeof(f32_cpx) * n);
+      f32_execute(pl, tmp, (f32_cpx *)out, sign);
+      free(tmp);
+    } else {
+      f32_execute(pl, (const f32_cpx *)in, (f32_cpx *)out, sign);
+    }
+  }
+}
+
+/* Real-input transform of even length through the half-length complex
+   transform of z[j] = x[2j] + i x[2j+1]:
+     X[k] = (Z[k] + conj Z[h-k])/2  -  (i/2) W_n^k (Z[k] - conj Z[h-k]),  k = 0..h, Z[h] := Z[0]
+   (the standard packing identity; odd n falls back to a full complex transform). */
+void odft_r2c_f64(odft_plan *p, const double *in, double *out) {
+  int n = p->n;
+  if (n & 1) {
+    d64_plan *pl = need_full64(p);
+    d64_cpx *a = (d64_cpx *)malloc(sizeof(d64_cpx) * (size_t)n * 2);
+    d64_cpx *b = a + n;
+    for (int i = 0; i < n; i++) { a[i].re = in[i]; a[i].im = 0; }
+    d64_execute(pl, a, b, -1);
+    for (int k = 0; k <= n / 2; k++) { out[2 * k] = b[k].re; out[2 * k + 1] = b[k].im; }
+    free(a);
+    return;
+  }
+  int h = n / 2;
+  d64_plan *pl = need_half64(p);
+  const double *tw = need_rtw(p);
+  d64_cpx *z = (d64_cpx *)malloc(sizeof(d64_cpx) * (size_t)h);
+  d64_execute(pl, (const d64_cpx *)in, z, -1);
+  for (int k = 0; k <= h; k++) {
+    d64_cpx a = z[k == h ? 0 : k];
+    d64_cpx b = z[k == 0 ? 0 : h - k];   /* conj applied below */
+    double er = 0.5 * (a.re + b.re), ei = 0.5 * (a.im - b.im);   /* even part  */
+    double orr = 0.5 * (a.re - b.re), oi = 0.5 * (a.im + b.im);  /* (Z - conj Z')/2 */
+    /* -i * W * (orr + i oi) */
+    double wr = tw[2 * k], wi = tw[2 * k + 1];
+    double tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
+    out[2 * k] = er + ti;
+    out[2 * k + 1] = ei - tr;
+  }
+  free(z);
+}
+
+void odft_r2c(odft_plan *p, const float *in, float *out) {
+  int n = p->n;
+  int h = n / 2;
+  if (p->precision == ODFT_F64) {
+    double *a = (double *)malloc(sizeof(double) * ((size_t)n + 2 * (size_t)(h + 1)));
+    double *b = a + n;
+    for (int i = 0; i < n; i++) a[i] = in[i];
+    odft_r2c_f64(p, a, b);
+    for (int i = 0; i < 2 * (h + 1); i++) out[i] = (float)b[i];
+    free(a);
+    return;
+  }
+  if (n & 1) {
+    f32_plan *pl = need_full32(p);
+    f32_cpx *a = (f32_cpx *)malloc(sizeof(f32_cpx) * (size_t)n * 2);
+    f32_cpx *b = a + n;
+    for (int i = 0; i < n; i++) { a[i].re = in[i]; a[i].im = 0; }
+    f32_execute(pl, a, b, -1);
+    for (int k = 0; k <= h; k++) { out[2 * k] = b[k].re; out[2 * k + 1] = b[k].im; }
+    free(a);
+    return;
+  }
+  f32_plan *pl = need_half32(p);
+  const double *tw = need_rtw(p);
+  f32_cpx *z = (f32_cpx *)malloc(sizeof(f32_cpx) * (size_t)h);
+  f32_execute(pl, (const f32_cpx *)in, z, -1);
+  for (int k = 0; k <= h; k++) {
+    f32_cpx a = z[k == h ? 0 : k];
+    f32_cpx b = z[k == 0 ? 0 : h - k];
+    float er = 0.5f * (a.re + b.re), ei = 0.5f * (a.im - b.im);
+    float orr = 0.5f * (a.re - b.re), oi = 0.5f * (a.im + b.im);
+    float wr = (float)tw[2 * k], wi = (float)tw[2 * k + 1];
+    float tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
+    out[2 * k] = er + ti;
+    out[2 * k + 1] = ei - tr;
+  }
+  free(z);
+}
+
+/* Hermitian-input backward transform: extend to the full spectrum and run the
+   complex transform; only the small per-channel REAL-output case uses it
+   (src/filter.c:387), so simplicity beats speed. */
+void odft_c2r(odft_plan *p, const float *in, float *out) {
+  int n = p->n;
+  int h = n / 2;
+  if (p->precision == ODFT_F64) {
+    d64_plan *pl = need_full64(p);
+    d64_cpx *a = (d64_cpx *)malloc(sizeof(d64_cpx) * (size_t)n * 2);
+    d64_cpx *b = a + n;
+    for (int k = 0; k <= h; k++) { a[k].re = in[2 * k]; a[k].im = in[2 * k + 1]; }
+    a[0].im = 0;                                  /* c2r ignores the imaginary part of DC */
+    if (!(n & 1)) a[h].im = 0;                    /* ... and of Nyquist */
+    for (int k = h + 1; k < n; k++) { a[k].re = a[n - k].re; a[k].im = -a[n - k].im; }
+    d64_execute(pl, a, b, +1);
+    for (int i = 0; i < n; i++) out[i] = (float)b[i].re;
+    free(a);
+  } else {
+    f32_plan *pl = need_full32(p);
+    f32_cpx *a = (f32_cpx *)malloc(sizeof(f32_cpx) * (size_t)n * 2);
+    f32_cpx *b = a + n;
+    for (int k = 0; k <= h; k++) { a[k].re = in[2 * k]; a[k].im = in[2 * k + 1]; }
+    a[0].im = 0;
+    if (!(n & 1)) a[h].im = 0;
+    for (int k = h + 1; k < n; k++) { a[k].re = a[n - k].re; a[k].im = -a[n - k].im; }
+    f32_execute(pl, a, b, +1);
+    for (int i = 0; i < n; i++) out[i] = b[i].re;
+    free(a);
+  }
+}

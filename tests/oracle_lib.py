@@ -1,0 +1,335 @@
+"""ctypes bindings for the CPU oracle (TEST INFRASTRUCTURE).
+
+Two libraries live under oracle/:
+  liboracle.so          project restatement (oracle/chz_oracle.c, oracle/dft.c)
+  _ref/libka9q_ref.so   the reference's own filter.c & friends, compiled unmodified
+                        from /root/reference/src by oracle/Makefile (prebuilt file
+                        travels to the GPU box; /root/reference itself does not)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+COMPLEX, REAL, SPECTRUM = 1, 2, 3
+
+_vp, _i, _d, _u64 = C.c_void_p, C.c_int, C.c_double, C.c_uint64
+
+
+def build(force=False):
+    """(Re)build liboracle.so always-if-stale, and _ref when /root/reference exists."""
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR, "all"] + (["-B"] if force else []),
+                   check=True, stdout=subprocess.DEVNULL)
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_oracle = None
+_ref = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.chzo_i0.restype = _d; L.chzo_i0.argtypes = [_d]
+        L.chzo_make_kaiser.argtypes = [_vp, _i, _d]
+        L.chzo_set_filter.argtypes = [_i, _i, _i, _i, _i, _d, _d, _d, _vp]
+        L.chzo_forward.argtypes = [_vp, _i, _i, _vp]
+        L.chzo_forward_f64.argtypes = [_vp, _i, _i, _vp]
+        L.chzo_notch.argtypes = [_vp, _vp, _i, _d, _vp]
+        L.chzo_gather.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]
+        L.chzo_channel.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]
+        L.chzo_channel_f64.argtypes = [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]
+        L.chzo_siggen_create.restype = _vp
+        L.chzo_siggen_create.argtypes = [_d, _d, _d, _d, _i, _u64]
+        L.chzo_siggen_delete.argtypes = [_vp]
+        L.chzo_siggen_generate.argtypes = [_vp, _vp, C.c_long]
+        L.chzo_scale_ad.restype = _d; L.chzo_scale_ad.argtypes = [_d, _d, _d, _i, _i]
+        L.chzo_compute_tuning.argtypes = [_i, _d, _d, _vp, _vp]
+        L.chzo_stream_create.restype = _vp; L.chzo_stream_create.argtypes = [_i, _i, _i]
+        L.chzo_stream_delete.argtypes = [_vp]
+        L.chzo_stream_bins.argtypes = [_vp]
+        L.chzo_stream_push.argtypes = [_vp, _vp, _vp]
+        L.chzo_stream_push_f64.argtypes = [_vp, _vp, _vp]
+        _oracle = L
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libka9q_ref.so"))
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        L = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libka9q_ref.so"))
+        L.refchz_master_create.restype = _vp; L.refchz_master_create.argtypes = [_i, _i, _i, _i]
+        L.refchz_master_delete.argtypes = [_vp]
+        L.refchz_master_bins.argtypes = [_vp]
+        L.refchz_master_points.argtypes = [_vp]
+        L.refchz_master_next_jobnum.restype = C.c_uint; L.refchz_master_next_jobnum.argtypes = [_vp]
+        L.refchz_master_set_notches.argtypes = [_vp, _vp, _i, _d]
+        L.refchz_master_write.argtypes = [_vp, _vp, _i]
+        L.refchz_master_spectrum.argtypes = [_vp, C.c_uint, _vp]
+        L.refchz_chan_create.restype = _vp; L.refchz_chan_create.argtypes = [_vp, _i, _i]
+        L.refchz_chan_delete.argtypes = [_vp]
+        L.refchz_chan_points.argtypes = [_vp]
+        L.refchz_chan_bins.argtypes = [_vp]
+        L.refchz_chan_drops.restype = C.c_uint; L.refchz_chan_drops.argtypes = [_vp]
+        L.refchz_chan_set_isb.argtypes = [_vp, _i]
+        L.refchz_chan_set_filter.argtypes = [_vp, _d, _d, _d]
+        L.refchz_chan_response.argtypes = [_vp, _vp]
+        L.refchz_chan_set_response.argtypes = [_vp, _vp]
+        L.refchz_chan_execute.argtypes = [_vp, _i, _vp]
+        L.refchz_chan_fdomain.argtypes = [_vp, _vp]
+        L.refchz_make_kaiserf.argtypes = [_vp, _i, _d]
+        L.refchz_i0.restype = _d; L.refchz_i0.argtypes = [_d]
+        L.refchz_bench.restype = _d
+        L.refchz_bench.argtypes = [_vp, _vp, _vp, _i, _vp, _i, _i, _i]
+        L.refchz_fft_times.argtypes = [_vp, _vp, _vp]
+        L.refsig_create.restype = _vp; L.refsig_create.argtypes = [_d, _d, _d, _d, _i, C.c_ulonglong]
+        L.refsig_delete.argtypes = [_vp]
+        L.refsig_generate.argtypes = [_vp, _vp, C.c_long]
+        L.oracle_fft_set_precision.argtypes = [_i]
+        _ref = L
+    return _ref
+
+
+# ----------------------------------------------------------------------------
+# numpy-level conveniences over the restatement
+# ----------------------------------------------------------------------------
+
+def set_filter(P, olen, master_points, master_real, low, high, beta, out_type=COMPLEX):
+    resp = np.zeros(P, np.complex64)
+    r = oracle().chzo_set_filter(P, olen, master_points, int(master_real), out_type,
+                                 low, high, beta, _fptr(resp))
+    if r != 0:
+        raise ValueError("chzo_set_filter failed")
+    return resp
+
+
+def forward(window, in_type, f64=False):
+    window = np.ascontiguousarray(window, np.float32 if in_type == REAL else np.complex64)
+    N = window.shape[0]
+    bins = N // 2 + 1 if in_type == REAL else N
+    if f64:
+        out = np.zeros(bins, np.complex128)
+        oracle().chzo_forward_f64(_fptr(window), N, in_type, _fptr(out))
+    else:
+        out = np.zeros(bins, np.complex64)
+        oracle().chzo_forward(_fptr(window), N, in_type, _fptr(out))
+    return out
+
+
+def channel(spectrum, in_type, P, olen, shift, response, out_type=COMPLEX, isb=False):
+    response = np.ascontiguousarray(response, np.complex64)
+    if spectrum.dtype == np.complex128:
+        out = np.zeros(olen, np.complex128)
+        r = oracle().chzo_channel_f64(_fptr(spectrum), spectrum.shape[0], in_type, P, olen, out_type,
+                                      int(shift), int(isb), _fptr(response), _fptr(out))
+    else:
+        spectrum = np.ascontiguousarray(spectrum, np.complex64)
+        out = np.zeros(olen, np.complex64 if out_type == COMPLEX else np.float32)
+        r = oracle().chzo_channel(_fptr(spectrum), spectrum.shape[0], in_type, P, olen, out_type,
+                                  int(shift), int(isb), _fptr(response), _fptr(out))
+    if r != 0:
+        raise ValueError("chzo_channel failed")
+    return out
+
+
+def gather(spectrum, in_type, s_bins, shift, response, out_type=COMPLEX, isb=False):
+    spectrum = np.ascontiguousarray(spectrum, np.complex64)
+    response = np.ascontiguousarray(response, np.complex64)
+    fd = np.zeros(s_bins + 1, np.complex64)
+    r = oracle().chzo_gather(_fptr(spectrum), spectrum.shape[0], in_type, s_bins, out_type,
+                             int(shift), int(isb), _fptr(response), _fptr(fd))
+    if r != 0:
+        raise ValueError("chzo_gather failed")
+    return fd[:s_bins]
+
+
+class SigGen:
+    """Deterministic sig_gen stream (restatement)."""
+
+    def __init__(self, cycles_per_sample, amplitude, noise, scale, isreal=True, seed=1):
+        self.isreal = isreal
+        self.h = oracle().chzo_siggen_create(cycles_per_sample, amplitude, noise, scale, int(isreal), seed)
+
+    def generate(self, n):
+        out = np.zeros(n, np.float32 if self.isreal else np.complex64)
+        oracle().chzo_siggen_generate(self.h, _fptr(out), n)
+        return out
+
+    def __del__(self):
+        try:
+            oracle().chzo_siggen_delete(self.h)
+        except Exception:
+            pass
+
+
+class Stream:
+    """Overlap-save master restatement: push L samples, get the block spectrum."""
+
+    def __init__(self, L, M, in_type):
+        self.L, self.M, self.in_type = L, M, in_type
+        self.h = oracle().chzo_stream_create(L, M, in_type)
+        if not self.h:
+            raise ValueError("bad stream parameters")
+        self.bins = oracle().chzo_stream_bins(self.h)
+        self.N = L + M - 1
+
+    def push(self, samples, f64=False):
+        samples = np.ascontiguousarray(samples, np.float32 if self.in_type == REAL else np.complex64)
+        assert samples.shape[0] == self.L
+        if f64:
+            out = np.zeros(self.bins, np.complex128)
+            oracle().chzo_stream_push_f64(self.h, _fptr(samples), _fptr(out))
+        else:
+            out = np.zeros(self.bins, np.complex64)
+            oracle().chzo_stream_push(self.h, _fptr(samples), _fptr(out))
+        return out
+
+    def __del__(self):
+        try:
+            oracle().chzo_stream_delete(self.h)
+        except Exception:
+            pass
+
+
+def notch(state, bins, alpha, spectrum):
+    bins = np.ascontiguousarray(bins, np.int32)
+    oracle().chzo_notch(_fptr(state), _fptr(bins), len(bins), alpha, _fptr(spectrum))
+
+
+def scale_ad(isreal=True, bitspersample=1, rf_gain=float("nan"), rf_atten=float("nan"), cal=float("nan")):
+    return oracle().chzo_scale_ad(rf_gain, rf_atten, cal, int(isreal), bitspersample)
+
+
+def compute_tuning(N, samprate, freq):
+    s = C.c_int(0); rem = C.c_double(0)
+    r = oracle().chzo_compute_tuning(N, samprate, freq, C.byref(s), C.byref(rem))
+    return r, s.value, rem.value
+
+
+# ----------------------------------------------------------------------------
+# the reference itself (oracle/_ref)
+# ----------------------------------------------------------------------------
+
+class RefMaster:
+    def __init__(self, L, M, in_type, worker_threads=0):
+        self.lib = ref()
+        self.L, self.M, self.in_type = L, M, in_type
+        self.h = self.lib.refchz_master_create(L, M, in_type, worker_threads)
+        if not self.h:
+            raise ValueError("create_filter_input failed")
+        self.bins = self.lib.refchz_master_bins(self.h)
+        self.N = self.lib.refchz_master_points(self.h)
+        self.chans = []
+
+    def write(self, samples):
+        samples = np.ascontiguousarray(samples, np.float32 if self.in_type == REAL else np.complex64)
+        return self.lib.refchz_master_write(self.h, _fptr(samples), samples.shape[0])
+
+    def jobnum(self):
+        return self.lib.refchz_master_next_jobnum(self.h)
+
+    def spectrum(self, jobnum=None):
+        if jobnum is None:
+            jobnum = self.jobnum() - 1
+        out = np.zeros(self.bins, np.complex64)
+        self.lib.refchz_master_spectrum(self.h, jobnum & 0xFFFFFFFF, _fptr(out))
+        return out
+
+    def set_notches(self, bins, alpha=0.01):
+        bins = np.ascontiguousarray(bins, np.int32)
+        self.lib.refchz_master_set_notches(self.h, _fptr(bins), len(bins), alpha)
+
+    def channel(self, olen, out_type=COMPLEX):
+        c = RefChan(self, olen, out_type)
+        self.chans.append(c)
+        return c
+
+    def close(self):
+        for c in self.chans:
+            c.close()
+        self.chans = []
+        if self.h:
+            self.lib.refchz_master_delete(self.h)
+            self.h = None
+
+
+class RefChan:
+    def __init__(self, master, olen, out_type):
+        self.lib = master.lib
+        self.olen, self.out_type = olen, out_type
+        self.h = self.lib.refchz_chan_create(master.h, olen, out_type)
+        if not self.h:
+            raise ValueError("create_filter_output failed")
+        self.points = self.lib.refchz_chan_points(self.h)
+        self.bins = self.lib.refchz_chan_bins(self.h)
+
+    def set_filter(self, low, high, beta):
+        return self.lib.refchz_chan_set_filter(self.h, low, high, beta)
+
+    def set_isb(self, isb):
+        self.lib.refchz_chan_set_isb(self.h, int(isb))
+
+    def response(self):
+        out = np.zeros(self.points, np.complex64)
+        if self.lib.refchz_chan_response(self.h, _fptr(out)) < 0:
+            return None
+        return out
+
+    def set_response(self, resp):
+        resp = np.ascontiguousarray(resp, np.complex64)
+        assert resp.shape[0] == self.points
+        self.lib.refchz_chan_set_response(self.h, _fptr(resp))
+
+    def execute(self, shift):
+        out = np.zeros(self.olen, np.complex64 if self.out_type == COMPLEX else np.float32)
+        r = self.lib.refchz_chan_execute(self.h, int(shift), _fptr(out))
+        if r != 0:
+            raise RuntimeError("execute_filter_output returned %d" % r)
+        return out
+
+    def fdomain(self):
+        out = np.zeros(self.bins, np.complex64)
+        self.lib.refchz_chan_fdomain(self.h, _fptr(out))
+        return out
+
+    def drops(self):
+        return self.lib.refchz_chan_drops(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.refchz_chan_delete(self.h)
+            self.h = None
+
+
+class RefSigGen:
+    def __init__(self, cycles_per_sample, amplitude, noise, scale, isreal=True, seed=1):
+        self.lib = ref()
+        self.isreal = isreal
+        self.h = self.lib.refsig_create(cycles_per_sample, amplitude, noise, scale, int(isreal), seed)
+
+    def generate(self, n):
+        out = np.zeros(n, np.float32 if self.isreal else np.complex64)
+        self.lib.refsig_generate(self.h, _fptr(out), n)
+        return out
+
+    def __del__(self):
+        try:
+            self.lib.refsig_delete(self.h)
+        except Exception:
+            pass
