@@ -1,0 +1,363 @@
+// chz_kernels.h -- hand-written CDNA4 (gfx950) kernels of the overlap-save channelizer.
+//
+// What the reference does on CPU threads with FFTW3 (src/filter.c):
+//   K1  forward transform of the N-sample window          src/filter.c:505-508,573-582
+//   K2  spur notches on a handful of bins                  src/filter.c:464-474
+//   K3  per-channel bin gather x frequency response        src/filter.c:728-911
+//   K4  per-channel small backward transform, keep olen    src/filter.c:914, :357
+// is done here by five kernels.  The large transform is a three-axis Cooley-Tukey
+// decomposition N = Na*Nb*Nc (n = na*Nb*Nc + nb*Nc + nc, k = ka + Na*kb + Na*Nb*kc):
+//
+//   fwd_first_real   axis a.  Real input: two adjacent real columns travel as one
+//                    complex column, the Hermitian split happens inside the tile, so
+//                    only rows ka = 0..Na/2 are ever written.  Reads the input ring.
+//   fwd_cols         axis b (and axis a of a complex-input master): column FFTs in
+//                    place, T adjacent columns per workgroup.
+//   fwd_rows         axis c.  Row FFTs; the tile is transposed through LDS so the
+//                    digit-reversed store k = ka + Na*(kb + Nb*kc) is contiguous in ka,
+//                    and the upper half of each row lands conjugated at N-k.
+//
+// Each workgroup keeps its tile in VGPRs, does one radix-R1 and one radix-R2
+// butterfly layer (regfft.h) with a single LDS exchange between them ("LDS-staged
+// radix butterflies"); inter-axis twiddles W^(k*m) are factored as
+// W^(k*tile_base) * W^(k*offset_in_tile), two tiny L2-resident tables built in
+// float64 on the host.  No MFMA: this is an HBM/L2-bound permutation-heavy
+// transform, not a dense contraction.
+//
+// The file is plain HIP, gfx950 only; tests/hipemu can also run it on the CPU as
+// test infrastructure (it is NOT a fallback: the product library is hipcc-built).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "regfft.h"
+
+namespace chz {
+
+// ------------------------------------------------------------------------------
+// parameter blocks (plain data; filled by chz_engine.hip)
+// ------------------------------------------------------------------------------
+struct FirstRealParams {
+  const float* ring;      // input sample ring (device), float32
+  long ring_len;          // ring length in floats (even)
+  long start;             // window start inside the ring (even)
+  float2* buf;            // out: [Ra][inner] complex
+  int inner;              // Nb*Nc  (even)
+  int T;                  // packed (complex) columns per tile; inner/2 % T == 0
+  int Ra;                 // Na/2 + 1 rows kept
+  int padk;               // LDS padding (float2) after each k1 group
+  const float2* tw_sub;   // [R2][R1]   W_Na^(j*k1)
+  const float2* tw_tile;  // [tiles][Ra] W_N^(ka * 2*c0)
+  const float2* tw_col;   // [Ra][2T]   0.5 * W_N^(ka*cc) (even cc) or -0.5i * W_N^(ka*cc) (odd cc)
+};
+
+struct ColsParams {
+  const float2* in;       // in[(row*NP + n)*inner + col]  (+ ring wrap when in_len != 0)
+  long in_len;            // 0, or ring length in float2 (input then starts at in_start)
+  long in_start;
+  float2* out;            // out[(row*NP + k)*inner + col]; may alias in when in_len == 0
+  int rows;               // independent row blocks (ka values)
+  int inner;              // contiguous inner length (columns per row block)
+  int T;                  // columns per tile; inner % T == 0
+  int padk;
+  const float2* tw_sub;   // [R2][R1]      W_NP^(j*k1)
+  const float2* tw_tile;  // [inner/T][NP] W_(NP*inner)^(k * c0)
+  const float2* tw_col;   // [NP][T]       W_(NP*inner)^(k * t)
+};
+
+struct RowsParams {
+  const float2* buf;      // [Ra][Nb][Nc]
+  float2* spec;           // out: master spectrum, `bins` complex
+  int Ra, Na, Nb;         // rows kept, axis-a length, axis-b length
+  int Ta;                 // ka values per tile
+  int ld, padg;           // LDS leading dimension (Ta+1) and per-group padding
+  long N;                 // full transform length
+  int mirror;             // 1: real master (bins N/2+1, conj-mirror store); 0: complex master
+  const float2* tw_sub;   // [R2][R1] W_Nc^(j*k1)
+};
+
+struct NotchParams {
+  float2* spec;
+  const int* bins;        // n entries
+  double* state;          // 2 doubles per entry, persistent across blocks
+  int n;
+  double alpha;
+};
+
+// One channel's gather, precomputed on the host from `shift`
+// (restating the index walk of src/filter.c:728-911):
+// the t-th output bin counted from the most negative frequency takes master bin
+//   src0 + dir*(t - t0)   (mod wrap if wrap != 0)     for t0 <= t < t0 + cnt
+// and is zero otherwise; conj != 0 conjugates the master bin (inverted spectrum).
+struct ChanDesc { int t0, cnt, src0, dir, conj, wrap; };
+
+struct ChanParams {
+  const float2* spec;     // master spectrum of this block
+  const float2* resp;     // [nch][P] frequency responses
+  const ChanDesc* desc;   // [nch]
+  float2* out;            // [nch][olen]
+  int nch, olen;
+  const float2* tw_sub;   // [R2][R1]  W_P^(-j*k1)  (backward)
+};
+
+// ------------------------------------------------------------------------------
+// K1a: first axis of a REAL master.  grid = inner/2/T tiles.
+// ------------------------------------------------------------------------------
+template <int R1, int R2>
+__global__ void fwd_first_real(FirstRealParams p) {
+  constexpr int NA = R1 * R2;
+  HIP_DYNAMIC_SHARED(float2, lds)
+  const int tid = threadIdx.x, nthr = blockDim.x, tile = blockIdx.x;
+  const int T = p.T;
+  const int c0 = tile * T;                       // first packed column of the tile
+  const float2* ring2 = reinterpret_cast<const float2*>(p.ring);
+  const long ring2_len = p.ring_len >> 1, start2 = p.start >> 1, inner2 = p.inner >> 1;
+
+  // layer 1: radix R1 over na = j + q*R2, one (j, column) pair per thread
+  if (tid < R2 * T) {
+    const int j = tid / T, t = tid - j * T;
+    float2 v[R1];
+    static_for<R1>([&](auto q) {
+      constexpr int Q = decltype(q)::value;
+      long idx = start2 + (long)(j + Q * R2) * inner2 + c0 + t;
+      if (idx >= ring2_len) idx -= ring2_len;
+      v[Q] = ring2[idx];
+    });
+    reg_dft<R1, -1>(v);
+    static_for<R1>([&](auto k1) {
+      constexpr int K1 = decltype(k1)::value;
+      float2 x = v[K1];
+      if constexpr (K1 > 0) x = cmul(x, p.tw_sub[j * R1 + K1]);
+      lds[(K1 * R2 + j) * T + K1 * p.padk + t] = x;
+    });
+  }
+  __syncthreads();
+  // layer 2: radix R2 over j, one (k1, column) pair per thread
+  float2 u[R2];
+  const int k1 = tid / T, t2 = tid - k1 * T;
+  const bool act2 = tid < R1 * T;
+  if (act2) {
+    static_for<R2>([&](auto j) {
+      constexpr int J = decltype(j)::value;
+      u[J] = lds[(k1 * R2 + J) * T + k1 * p.padk + t2];
+    });
+    reg_dft<R2, -1>(u);
+  }
+  __syncthreads();
+  // Z[k1 + R1*k2] back to LDS in natural row order for the Hermitian split
+  if (act2) {
+    static_for<R2>([&](auto k2) {
+      constexpr int K2 = decltype(k2)::value;
+      lds[(k1 + R1 * K2) * T + t2] = u[K2];
+    });
+  }
+  __syncthreads();
+  // split + twiddle + store:  real column 2p   -> (Z[k] + conj Z[Na-k]) / 2
+  //                           real column 2p+1 -> (Z[k] - conj Z[Na-k]) / 2i
+  const int W2 = 2 * T;
+  const int total = p.Ra * W2;
+  for (int idx = tid; idx < total; idx += nthr) {
+    const int k = idx / W2, cc = idx - k * W2;
+    const int pc = cc >> 1;
+    const float2 a = lds[k * T + pc];
+    const int km = (k == 0) ? 0 : NA - k;
+    const float2 b = lds[km * T + pc];
+    float2 d;
+    if (cc & 1) d = make_float2(a.x - b.x, a.y + b.y);   // a - conj(b)
+    else        d = make_float2(a.x + b.x, a.y - b.y);   // a + conj(b)
+    const float2 w = cmul(p.tw_tile[tile * p.Ra + k], p.tw_col[k * W2 + cc]);
+    p.buf[(long)k * p.inner + 2 * c0 + cc] = cmul(d, w);
+  }
+}
+
+// ------------------------------------------------------------------------------
+// K1b: column FFTs along a strided axis, T adjacent columns per workgroup.
+// grid = rows * inner/T.
+// ------------------------------------------------------------------------------
+template <int R1, int R2>
+__global__ void fwd_cols(ColsParams p) {
+  constexpr int NP = R1 * R2;
+  HIP_DYNAMIC_SHARED(float2, lds)
+  const int tid = threadIdx.x;
+  const int T = p.T;
+  const int tpr = p.inner / T;
+  const int row = blockIdx.x / tpr, ct = blockIdx.x - row * tpr;
+  const int c0 = ct * T;
+  const long base = (long)row * NP * p.inner + c0;
+
+  if (tid < R2 * T) {
+    const int j = tid / T, t = tid - j * T;
+    float2 v[R1];
+    static_for<R1>([&](auto q) {
+      constexpr int Q = decltype(q)::value;
+      long idx = base + (long)(j + Q * R2) * p.inner + t;
+      if (p.in_len) { idx += p.in_start; if (idx >= p.in_len) idx -= p.in_len; }
+      v[Q] = p.in[idx];
+    });
+    reg_dft<R1, -1>(v);
+    static_for<R1>([&](auto k1) {
+      constexpr int K1 = decltype(k1)::value;
+      float2 x = v[K1];
+      if constexpr (K1 > 0) x = cmul(x, p.tw_sub[j * R1 + K1]);
+      lds[(K1 * R2 + j) * T + K1 * p.padk + t] = x;
+    });
+  }
+  __syncthreads();
+  if (tid < R1 * T) {
+    const int k1 = tid / T, t = tid - k1 * T;
+    float2 u[R2];
+    static_for<R2>([&](auto j) {
+      constexpr int J = decltype(j)::value;
+      u[J] = lds[(k1 * R2 + J) * T + k1 * p.padk + t];
+    });
+    reg_dft<R2, -1>(u);
+    static_for<R2>([&](auto k2) {
+      constexpr int K2 = decltype(k2)::value;
+      const int k = k1 + R1 * K2;
+      const float2 w = cmul(p.tw_tile[ct * NP + k], p.tw_col[k * T + t]);
+      p.out[base + (long)k * p.inner + t] = cmul(u[K2], w);
+    });
+  }
+}
+
+// ------------------------------------------------------------------------------
+// K1c: last axis.  grid = Nb * ceil(Ra/Ta); tile = Ta consecutive ka at one kb.
+// ------------------------------------------------------------------------------
+template <int R1, int R2>
+__global__ void fwd_rows(RowsParams p) {
+  constexpr int NC = R1 * R2;
+  HIP_DYNAMIC_SHARED(float2, lds)
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int Ta = p.Ta, ld = p.ld, padg = p.padg;
+  const int kb = blockIdx.x % p.Nb, at = blockIdx.x / p.Nb;
+  const int a0 = at * Ta;
+  const long rowstride = (long)p.Nb * NC;
+
+  // coalesced row loads, transposed into LDS as [nc][r]
+  for (int e = tid; e < Ta * NC; e += nthr) {
+    const int r = e / NC, nc = e - r * NC;
+    const int ka = a0 + r;
+    float2 x = make_float2(0.f, 0.f);
+    if (ka < p.Ra) x = p.buf[(long)ka * rowstride + (long)kb * NC + nc];
+    lds[nc * ld + (nc / R2) * padg + r] = x;
+  }
+  __syncthreads();
+  if (tid < R2 * Ta) {
+    const int j = tid / Ta, r = tid - j * Ta;
+    float2 v[R1];
+    static_for<R1>([&](auto q) {
+      constexpr int Q = decltype(q)::value;
+      const int row = j + Q * R2;
+      v[Q] = lds[row * ld + (row / R2) * padg + r];
+    });
+    reg_dft<R1, -1>(v);
+    static_for<R1>([&](auto k1) {
+      constexpr int K1 = decltype(k1)::value;
+      float2 x = v[K1];
+      if constexpr (K1 > 0) x = cmul(x, p.tw_sub[j * R1 + K1]);
+      lds[(K1 * R2 + j) * ld + K1 * padg + r] = x;       // row K1*R2+j belongs to group K1
+    });
+  }
+  __syncthreads();
+  if (tid < R1 * Ta) {
+    const int k1 = tid / Ta, r = tid - k1 * Ta;
+    const int ka = a0 + r;
+    float2 u[R2];
+    static_for<R2>([&](auto j) {
+      constexpr int J = decltype(j)::value;
+      u[J] = lds[(k1 * R2 + J) * ld + k1 * padg + r];
+    });
+    reg_dft<R2, -1>(u);
+    if (ka < p.Ra) {
+      const bool selfconj = (ka == 0) || (2 * ka == p.Na);
+      const long half = p.N >> 1;
+      static_for<R2>([&](auto k2) {
+        constexpr int K2 = decltype(k2)::value;
+        const long k = ka + (long)p.Na * (kb + (long)p.Nb * (k1 + R1 * K2));
+        if (!p.mirror || k <= half) p.spec[k] = u[K2];
+        else if (!selfconj) p.spec[p.N - k] = cconj(u[K2]);
+      });
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------
+// K2: spur notches (src/filter.c:464-474).  One lane per listed bin; state is
+// float64 and lives on the device across blocks.
+// ------------------------------------------------------------------------------
+__global__ void notch_bins(NotchParams p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.n) return;
+  const int b = p.bins[i];
+  float2 x = p.spec[b];
+  double sr = p.state[2 * i], si = p.state[2 * i + 1];
+  sr += p.alpha * ((double)x.x - sr);
+  si += p.alpha * ((double)x.y - si);
+  p.state[2 * i] = sr; p.state[2 * i + 1] = si;
+  p.spec[b] = make_float2((float)((double)x.x - sr), (float)((double)x.y - si));
+}
+
+// ------------------------------------------------------------------------------
+// K3+K4: per-channel gather x response, P-point backward FFT, keep last olen.
+// LPC = max(R1,R2) lanes serve one channel, 64/LPC channels share a wavefront.
+// ------------------------------------------------------------------------------
+template <int R1, int R2>
+__global__ void chan_ifft(ChanParams p) {
+  constexpr int P = R1 * R2;
+  constexpr int LPC = R1 > R2 ? R1 : R2;
+  constexpr int CPW = 64 / LPC;
+  constexpr int LDC = R2 + 1;                    // padded row of the exchange buffer
+  static_assert(CPW >= 1, "radix too wide for one wavefront");
+  HIP_DYNAMIC_SHARED(float2, lds)
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wpb = blockDim.x >> 6;
+  const int cw = lane / LPC, jl = lane - cw * LPC;
+  const int ch = (blockIdx.x * wpb + wave) * CPW + cw;
+  const bool live = (cw < CPW) && (ch < p.nch);
+  float2* my = lds + ((wave * CPW + (cw < CPW ? cw : 0)) * (R1 * LDC));
+
+  if (live && jl < R2) {
+    const ChanDesc d = p.desc[ch];
+    const float2* H = p.resp + (long)ch * P;
+    float2 v[R1];
+    static_for<R1>([&](auto q) {
+      constexpr int Q = decltype(q)::value;
+      const int i = jl + Q * R2;                           // FFT-order bin index
+      int t = i - (P + 1) / 2; if (t < 0) t += P;          // rank from most negative bin
+      const int u = t - d.t0;
+      float2 x = make_float2(0.f, 0.f);
+      if (u >= 0 && u < d.cnt && i != (P + 1) / 2) {       // Nyquist bin forced to zero (:911)
+        int src = d.src0 + d.dir * u;
+        if (d.wrap && src >= d.wrap) src -= d.wrap;
+        x = p.spec[src];
+        if (d.conj) x.y = -x.y;
+        x = cmul(x, H[i]);
+      }
+      v[Q] = x;
+    });
+    reg_dft<R1, +1>(v);
+    static_for<R1>([&](auto k1) {
+      constexpr int K1 = decltype(k1)::value;
+      float2 x = v[K1];
+      if constexpr (K1 > 0) x = cmul(x, p.tw_sub[jl * R1 + K1]);
+      my[K1 * LDC + jl] = x;
+    });
+  }
+  __syncthreads();
+  if (live && jl < R1) {
+    float2 u[R2];
+    static_for<R2>([&](auto j) {
+      constexpr int J = decltype(j)::value;
+      u[J] = my[jl * LDC + J];
+    });
+    reg_dft<R2, +1>(u);
+    const int drop = P - p.olen;                           // first M-1 samples are discarded (:357)
+    float2* o = p.out + (long)ch * p.olen;
+    static_for<R2>([&](auto k2) {
+      constexpr int K2 = decltype(k2)::value;
+      const int n = jl + R1 * K2;
+      if (n >= drop) o[n - drop] = u[K2];
+    });
+  }
+}
+
+}  // namespace chz

@@ -1,0 +1,291 @@
+// chz_plan.h -- host-side planning for the forward transform and channel banks:
+// choice of the axis lengths N = Na*Nb*Nc, tile widths, LDS geometry, and the
+// float64-accurate twiddle tables the kernels in chz_kernels.h consume.
+// Pure host C++ (no HIP runtime calls) so chz_engine.hip and the CPU test
+// harness build the very same plan.
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace chz {
+
+// (R1,R2) pairs with a compiled kernel instantiation.  Sub-transform length = R1*R2.
+#define CHZ_FWD_MENU(X) \
+  X(4, 4) X(5, 5) X(6, 6) X(5, 10) X(8, 8) X(8, 9) X(9, 9) X(10, 10) X(10, 12) X(12, 12) \
+  X(10, 15) X(12, 15) X(15, 15) X(16, 16) X(20, 20)
+// per-channel backward transform lengths P = R1*R2 (reference sizes: docs/FFTW3.md:51-68)
+#define CHZ_CHAN_MENU(X) \
+  X(4, 5) X(5, 6) X(10, 15) X(10, 16) X(10, 20) X(15, 20) X(16, 20) X(20, 20) X(20, 24) \
+  X(24, 25) X(25, 32) X(30, 32) X(30, 40)
+
+struct Radix2 { int r1, r2; };
+
+inline bool fwd_menu_lookup(int np, Radix2* out) {
+#define X(a, b) if ((a) * (b) == np) { if (out) { out->r1 = a; out->r2 = b; } return true; }
+  CHZ_FWD_MENU(X)
+#undef X
+  return false;
+}
+inline bool chan_menu_lookup(int p, Radix2* out) {
+#define X(a, b) if ((a) * (b) == p) { if (out) { out->r1 = a; out->r2 = b; } return true; }
+  CHZ_CHAN_MENU(X)
+#undef X
+  return false;
+}
+
+struct f2 { float x, y; };   // layout-identical to HIP's float2
+
+// e^{sign * 2 pi i num/den} rounded once from float64, angle folded into an octant
+inline f2 root_of_unity(long long num, long long den, int sign, double scale_re = 1.0, double scale_im = 0.0) {
+  num %= den; if (num < 0) num += den;
+  long long k8 = 8 * num, oct = k8 / den, rem = k8 - oct * den;
+  double a = (M_PI / 4.0) * ((double)rem / (double)den), c, s;
+  if (oct & 1) { a = M_PI / 4.0 - a; s = std::cos(a); c = std::sin(a); }
+  else { c = std::cos(a); s = std::sin(a); }
+  double cc, ss;
+  switch (oct >> 1) {
+    case 0: cc = c; ss = s; break;
+    case 1: cc = -s; ss = c; break;
+    case 2: cc = -c; ss = -s; break;
+    default: cc = s; ss = -c; break;
+  }
+  ss *= sign;
+  // multiply by the optional complex scale (used to fold 1/2 and -i/2 into a table)
+  double re = cc * scale_re - ss * scale_im, im = cc * scale_im + ss * scale_re;
+  return f2{(float)re, (float)im};
+}
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// W_NP^(sign*j*k1) laid out [R2][R1] as the first butterfly layer indexes it
+inline std::vector<f2> make_tw_sub(int r1, int r2, int sign) {
+  std::vector<f2> t((size_t)r1 * r2);
+  for (int j = 0; j < r2; j++)
+    for (int k1 = 0; k1 < r1; k1++) t[(size_t)j * r1 + k1] = root_of_unity((long long)j * k1, (long long)r1 * r2, sign);
+  return t;
+}
+
+enum { CHZ_IN_COMPLEX = 1, CHZ_IN_REAL = 2 };   // enum filtertype values, src/filter.h:29-34
+
+struct FwdPlan {
+  int N = 0, in_type = 0, bins = 0;
+  int Na = 0, Nb = 1, Nc = 0;         // Nb == 1: two-axis plan (no fwd_cols for axis b)
+  Radix2 ra{}, rb{}, rc{};
+  int Ra = 0;                          // rows of the intermediate buffer (Na/2+1 real, Na complex)
+  int inner = 0;                       // Nb*Nc
+  int T1 = 0, T2 = 0, Ta = 0;          // tile widths: first axis (packed cols if real), axis b, last axis
+  int padk1 = 0, padk2 = 0, ld3 = 0, padg3 = 0;
+  int grid1 = 0, block1 = 0, grid2 = 0, block2 = 0, grid3 = 0, block3 = 0;
+  size_t lds1 = 0, lds2 = 0, lds3 = 0;
+  std::vector<f2> tw_sub_a, tw_sub_b, tw_sub_c, tw1_tile, tw1_col, tw2_tile, tw2_col;
+  std::string desc;
+};
+
+inline int padk_for(int r2, int T) { int v = (T - r2 * T) % 32; if (v < 0) v += 32; return v; }
+
+// choose a divisor of `n` as tile width: closest to `want`, within [lo,hi], limited by thread count
+inline int pick_tile(int n, int want, int lo, int hi, int lanes_per_col, int max_threads) {
+  int best = 0; double bestscore = 1e30;
+  for (int t = 1; t <= n && t <= hi; t++) {
+    if (n % t) continue;
+    if (t * lanes_per_col > max_threads) continue;
+    double score = std::fabs(std::log((double)t / want)) + (t < lo ? 1.0 : 0.0);
+    if (score < bestscore) { bestscore = score; best = t; }
+  }
+  return best;
+}
+
+inline bool finish_fwd_plan(FwdPlan& p, int T1_over, int T2_over, int Ta_over) {
+  const bool real = p.in_type == CHZ_IN_REAL;
+  p.inner = p.Nb * p.Nc;
+  p.Ra = real ? p.Na / 2 + 1 : p.Na;
+  p.bins = real ? p.N / 2 + 1 : p.N;
+  const int la = p.ra.r1 > p.ra.r2 ? p.ra.r1 : p.ra.r2;
+  // ---- first axis
+  if (real) {
+    if (p.inner & 1) return false;
+    const int cols_p = p.inner / 2;
+    p.T1 = T1_over > 0 ? T1_over : pick_tile(cols_p, 16, 8, 64, la, 1024);
+    if (p.T1 <= 0 || cols_p % p.T1) return false;
+    p.grid1 = cols_p / p.T1;
+    p.tw1_tile.resize((size_t)p.grid1 * p.Ra);
+    for (int tile = 0; tile < p.grid1; tile++)
+      for (int k = 0; k < p.Ra; k++)
+        p.tw1_tile[(size_t)tile * p.Ra + k] = root_of_unity((long long)k * 2 * tile * p.T1, p.N, -1);
+    p.tw1_col.resize((size_t)p.Ra * 2 * p.T1);
+    for (int k = 0; k < p.Ra; k++)
+      for (int cc = 0; cc < 2 * p.T1; cc++)   // 1/2 for even columns, 1/(2i) = -i/2 for odd ones
+        p.tw1_col[(size_t)k * 2 * p.T1 + cc] =
+            (cc & 1) ? root_of_unity((long long)k * cc, p.N, -1, 0.0, -0.5) : root_of_unity((long long)k * cc, p.N, -1, 0.5, 0.0);
+  } else {
+    p.T1 = T1_over > 0 ? T1_over : pick_tile(p.inner, 16, 8, 64, la, 1024);
+    if (p.T1 <= 0 || p.inner % p.T1) return false;
+    p.grid1 = p.inner / p.T1;
+    p.tw1_tile.resize((size_t)p.grid1 * p.Na);
+    for (int tile = 0; tile < p.grid1; tile++)
+      for (int k = 0; k < p.Na; k++)
+        p.tw1_tile[(size_t)tile * p.Na + k] = root_of_unity((long long)k * tile * p.T1, p.N, -1);
+    p.tw1_col.resize((size_t)p.Na * p.T1);
+    for (int k = 0; k < p.Na; k++)
+      for (int t = 0; t < p.T1; t++) p.tw1_col[(size_t)k * p.T1 + t] = root_of_unity((long long)k * t, p.N, -1);
+  }
+  p.padk1 = padk_for(p.ra.r2, p.T1);
+  p.block1 = round_up(la * p.T1, 64);
+  p.lds1 = sizeof(f2) * ((size_t)p.Na * p.T1 + (size_t)p.ra.r1 * p.padk1);
+  p.tw_sub_a = make_tw_sub(p.ra.r1, p.ra.r2, -1);
+  // ---- axis b
+  if (p.Nb > 1) {
+    const int lb = p.rb.r1 > p.rb.r2 ? p.rb.r1 : p.rb.r2;
+    p.T2 = T2_over > 0 ? T2_over : pick_tile(p.Nc, 24, 8, 64, lb, 1024);
+    if (p.T2 <= 0 || p.Nc % p.T2) return false;
+    const int tpr = p.Nc / p.T2;
+    p.grid2 = p.Ra * tpr;
+    p.block2 = round_up(lb * p.T2, 64);
+    p.padk2 = padk_for(p.rb.r2, p.T2);
+    p.lds2 = sizeof(f2) * ((size_t)p.Nb * p.T2 + (size_t)p.rb.r1 * p.padk2);
+    const long long D = (long long)p.Nb * p.Nc;
+    p.tw2_tile.resize((size_t)tpr * p.Nb);
+    for (int ct = 0; ct < tpr; ct++)
+      for (int k = 0; k < p.Nb; k++) p.tw2_tile[(size_t)ct * p.Nb + k] = root_of_unity((long long)k * ct * p.T2, D, -1);
+    p.tw2_col.resize((size_t)p.Nb * p.T2);
+    for (int k = 0; k < p.Nb; k++)
+      for (int t = 0; t < p.T2; t++) p.tw2_col[(size_t)k * p.T2 + t] = root_of_unity((long long)k * t, D, -1);
+    p.tw_sub_b = make_tw_sub(p.rb.r1, p.rb.r2, -1);
+  }
+  // ---- last axis
+  const int lc = p.rc.r1 > p.rc.r2 ? p.rc.r1 : p.rc.r2;
+  p.Ta = Ta_over > 0 ? Ta_over : 16;
+  if (p.Ta > p.Ra) p.Ta = p.Ra;
+  while (lc * p.Ta > 1024) p.Ta--;
+  p.ld3 = p.Ta + 1 + (p.Ta & 1);                 // odd leading dimension
+  if (!(p.ld3 & 1)) p.ld3++;
+  p.padg3 = (16 - (p.rc.r2 * p.ld3) % 32 + 32) % 32;
+  p.grid3 = p.Nb * ((p.Ra + p.Ta - 1) / p.Ta);
+  p.block3 = round_up(lc * p.Ta, 64);
+  p.lds3 = sizeof(f2) * ((size_t)p.Nc * p.ld3 + (size_t)p.rc.r1 * p.padg3 + 8);
+  p.tw_sub_c = make_tw_sub(p.rc.r1, p.rc.r2, -1);
+  char b[256];
+  snprintf(b, sizeof b, "N=%d %s axes %dx%dx%d radices (%d,%d)(%d,%d)(%d,%d) tiles T1=%d T2=%d Ta=%d grids %d/%d/%d blocks %d/%d/%d",
+           p.N, real ? "real" : "complex", p.Na, p.Nb, p.Nc, p.ra.r1, p.ra.r2, p.rb.r1, p.rb.r2, p.rc.r1, p.rc.r2,
+           p.T1, p.T2, p.Ta, p.grid1, p.grid2, p.grid3, p.block1, p.block2, p.block3);
+  p.desc = b;
+  return true;
+}
+
+// spec: "" (automatic) or "NaxNbxNc[:T1,T2,Ta]" / "NaxNc[:T1,Ta]"
+inline bool build_fwd_plan(int N, int in_type, const char* spec, FwdPlan& out) {
+  if (N < 4 || (in_type != CHZ_IN_REAL && in_type != CHZ_IN_COMPLEX)) return false;
+  const bool real = in_type == CHZ_IN_REAL;
+  int T1o = 0, T2o = 0, Tao = 0;
+  if (spec && *spec) {
+    int a = 0, b = 0, c = 0;
+    int n = sscanf(spec, "%dx%dx%d", &a, &b, &c);
+    if (n == 2) { c = b; b = 1; }
+    else if (n != 3) return false;
+    const char* colon = strchr(spec, ':');
+    if (colon) {
+      int t[3] = {0, 0, 0};
+      int m = sscanf(colon + 1, "%d,%d,%d", &t[0], &t[1], &t[2]);
+      if (b == 1) { T1o = t[0]; Tao = m >= 2 ? t[1] : 0; }
+      else { T1o = t[0]; T2o = m >= 2 ? t[1] : 0; Tao = m >= 3 ? t[2] : 0; }
+    }
+    if ((long long)a * b * c != N) return false;
+    FwdPlan p; p.N = N; p.in_type = in_type; p.Na = a; p.Nb = b; p.Nc = c;
+    if (!fwd_menu_lookup(a, &p.ra) || !fwd_menu_lookup(c, &p.rc)) return false;
+    if (b > 1 && !fwd_menu_lookup(b, &p.rb)) return false;
+    if (!finish_fwd_plan(p, T1o, T2o, Tao)) return false;
+    out = p;
+    return true;
+  }
+  // automatic: enumerate menu triples whose product is N, prefer balanced axes with enough tiles
+  static const int menu[] = {
+#define X(a, b) (a) * (b),
+      CHZ_FWD_MENU(X)
+#undef X
+  };
+  const int nm = (int)(sizeof menu / sizeof menu[0]);
+  double best = 1e300; FwdPlan bestp; bool found = false;
+  for (int ia = 0; ia < nm; ia++) {
+    const int a = menu[ia];
+    if (N % a) continue;
+    for (int ib = -1; ib < nm; ib++) {
+      const int b = ib < 0 ? 1 : menu[ib];
+      if ((N / a) % b) continue;
+      const int c = N / a / b;
+      if (!fwd_menu_lookup(c, nullptr)) continue;
+      if (real && ((long long)b * c) % 2) continue;
+      FwdPlan p; p.N = N; p.in_type = in_type; p.Na = a; p.Nb = b; p.Nc = c;
+      fwd_menu_lookup(a, &p.ra); fwd_menu_lookup(c, &p.rc);
+      if (b > 1) fwd_menu_lookup(b, &p.rb);
+      if (!finish_fwd_plan(p, 0, 0, 0)) continue;
+      // cost model: passes over memory + penalty for too few workgroups + misaligned stores
+      double passes = b > 1 ? 3.0 : 2.0;
+      int mingrid = p.grid1 < p.grid3 ? p.grid1 : p.grid3;
+      if (b > 1 && p.grid2 < mingrid) mingrid = p.grid2;
+      double score = passes + (mingrid < 512 ? 512.0 / (mingrid + 1) : 0.0) + (a % 16 ? 0.15 : 0.0) +
+                     (p.T1 < 8 ? 0.5 : 0.0) + (b > 1 && p.T2 < 8 ? 0.5 : 0.0);
+      if (score < best) { best = score; bestp = p; found = true; }
+    }
+  }
+  if (!found) return false;
+  out = bestp;
+  return true;
+}
+
+// ---- channel banks -------------------------------------------------------------
+struct ChanGeom {
+  int P = 0; Radix2 r{}; int lpc = 0, cpw = 0, wpb = 4;
+  size_t lds = 0;
+  std::vector<f2> tw_sub;   // backward sign
+};
+inline bool build_chan_geom(int P, ChanGeom& g) {
+  if (!chan_menu_lookup(P, &g.r)) return false;
+  g.P = P;
+  g.lpc = g.r.r1 > g.r.r2 ? g.r.r1 : g.r.r2;
+  g.cpw = 64 / g.lpc;
+  g.wpb = 4;
+  g.lds = sizeof(f2) * (size_t)g.wpb * g.cpw * g.r.r1 * (g.r.r2 + 1);
+  g.tw_sub = make_tw_sub(g.r.r1, g.r.r2, +1);
+  return true;
+}
+
+// Host restatement of the gather index walk (src/filter.c:728-911, COMPLEX
+// output) as a closed-form descriptor; mirrors struct ChanDesc in chz_kernels.h.
+struct ChanDescH { int t0, cnt, src0, dir, conj, wrap; };
+inline ChanDescH make_chan_desc(int in_type, int m_bins, int P, int shift) {
+  ChanDescH d{0, 0, 0, 1, 0, 0};
+  const long long r0 = (long long)shift - P / 2;      // master index of the most negative output bin
+  if (in_type == CHZ_IN_REAL) {
+    if (shift >= 0) {                                 // src/filter.c:819-855
+      long long t0 = r0 < 0 ? -r0 : 0;
+      long long src0 = r0 + t0;
+      long long cnt = (long long)P - t0; if (cnt > m_bins - src0) cnt = m_bins - src0;
+      if (t0 >= P || cnt <= 0) return d;
+      d.t0 = (int)t0; d.src0 = (int)src0; d.cnt = (int)cnt; d.dir = 1;
+    } else {                                          // src/filter.c:856-892: read downward, conjugated
+      long long top = -r0;                            // master index feeding t = 0
+      long long t0 = top > m_bins - 1 ? top - (m_bins - 1) : 0;
+      long long src0 = top - t0;
+      long long cnt = (long long)P - t0; if (cnt > src0 + 1) cnt = src0 + 1;
+      if (t0 >= P || src0 < 0 || cnt <= 0) return d;
+      d.t0 = (int)t0; d.src0 = (int)src0; d.cnt = (int)cnt; d.dir = -1; d.conj = 1;
+    }
+  } else {                                            // src/filter.c:728-793
+    const long long hb = (m_bins + 1) / 2;
+    long long t0 = r0 < -hb ? -hb - r0 : 0;
+    if (t0 >= P) return d;
+    long long r = r0 + t0;
+    long long rp = r < 0 ? r + m_bins : r;
+    if (rp < 0 || rp >= m_bins) return d;
+    long long cnt = rp < hb ? hb - rp : (long long)m_bins - rp + hb;   // until the read index arrives at hb
+    if (cnt > P - t0) cnt = P - t0;
+    d.t0 = (int)t0; d.src0 = (int)rp; d.cnt = (int)cnt; d.dir = 1; d.wrap = m_bins;
+  }
+  return d;
+}
+
+}  // namespace chz

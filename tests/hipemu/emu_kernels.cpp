@@ -1,0 +1,82 @@
+// tests/hipemu/emu_kernels.cpp -- TEST INFRASTRUCTURE ONLY.
+// Runs the unmodified kernels of ka9q-radio_amd/csrc/chz_kernels.h on the CPU
+// through the fiber emulator, behind a flat C API for ctypes.  Used by
+// tests/test_kernels_emulated.py (-m "not gpu") to check butterfly wiring and
+// index math against the oracle before the kernels ever see a GPU.
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <cstring>
+#include "chz_launch.h"
+
+using namespace chz;
+
+static const float2* F2(const std::vector<f2>& v) { return reinterpret_cast<const float2*>(v.data()); }
+
+extern "C" {
+
+// ring: input ring on the host (floats for REAL, float pairs for COMPLEX); ring_len in floats
+int emu_forward(const float* ring, long ring_len, long start, int N, int in_type, const char* spec,
+                float* spectrum, char* desc, int desc_len) {
+  FwdPlan p;
+  if (!build_fwd_plan(N, in_type, spec, p)) return -1;
+  if (desc) { strncpy(desc, p.desc.c_str(), (size_t)desc_len - 1); desc[desc_len - 1] = 0; }
+  std::vector<float2> buf((size_t)p.Ra * p.inner);
+  if (in_type == CHZ_IN_REAL) {
+    FirstRealParams a{};
+    a.ring = ring; a.ring_len = ring_len; a.start = start; a.buf = buf.data(); a.inner = p.inner;
+    a.T = p.T1; a.Ra = p.Ra; a.padk = p.padk1;
+    a.tw_sub = F2(p.tw_sub_a); a.tw_tile = F2(p.tw1_tile); a.tw_col = F2(p.tw1_col);
+    if (launch_first_real(p.ra, p.grid1, p.block1, p.lds1, nullptr, a)) return -2;
+  } else {
+    ColsParams a{};
+    a.in = reinterpret_cast<const float2*>(ring); a.in_len = ring_len / 2; a.in_start = start / 2;
+    a.out = buf.data(); a.rows = 1; a.inner = p.inner; a.T = p.T1; a.padk = p.padk1;
+    a.tw_sub = F2(p.tw_sub_a); a.tw_tile = F2(p.tw1_tile); a.tw_col = F2(p.tw1_col);
+    if (launch_cols(p.ra, p.grid1, p.block1, p.lds1, nullptr, a)) return -2;
+  }
+  if (p.Nb > 1) {
+    ColsParams b{};
+    b.in = buf.data(); b.in_len = 0; b.in_start = 0; b.out = buf.data();
+    b.rows = p.Ra; b.inner = p.Nc; b.T = p.T2; b.padk = p.padk2;
+    b.tw_sub = F2(p.tw_sub_b); b.tw_tile = F2(p.tw2_tile); b.tw_col = F2(p.tw2_col);
+    if (launch_cols(p.rb, p.grid2, p.block2, p.lds2, nullptr, b)) return -3;
+  }
+  RowsParams c{};
+  c.buf = buf.data(); c.spec = reinterpret_cast<float2*>(spectrum);
+  c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3; c.padg = p.padg3; c.N = p.N;
+  c.mirror = in_type == CHZ_IN_REAL; c.tw_sub = F2(p.tw_sub_c);
+  if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, nullptr, c)) return -4;
+  return 0;
+}
+
+int emu_chan_desc(int in_type, int m_bins, int P, int shift, int* out6) {
+  ChanDescH d = make_chan_desc(in_type, m_bins, P, shift);
+  out6[0] = d.t0; out6[1] = d.cnt; out6[2] = d.src0; out6[3] = d.dir; out6[4] = d.conj; out6[5] = d.wrap;
+  return 0;
+}
+
+int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, int nch,
+                 const float* resp, const int* shifts, float* out) {
+  ChanGeom g;
+  if (!build_chan_geom(P, g)) return -1;
+  std::vector<ChanDesc> desc((size_t)nch);
+  for (int i = 0; i < nch; i++) {
+    ChanDescH h = make_chan_desc(in_type, m_bins, P, shifts[i]);
+    desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
+  }
+  ChanParams c{};
+  c.spec = reinterpret_cast<const float2*>(spec); c.resp = reinterpret_cast<const float2*>(resp);
+  c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.nch = nch; c.olen = olen;
+  c.tw_sub = F2(g.tw_sub);
+  const int per_block = g.wpb * g.cpw;
+  const int grid = (nch + per_block - 1) / per_block;
+  return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
+}
+
+int emu_notch(float* spec, const int* bins, double* state, int n, double alpha) {
+  NotchParams q{reinterpret_cast<float2*>(spec), bins, state, n, alpha};
+  launch_notch(n, nullptr, q);
+  return 0;
+}
+
+}  // extern "C"
