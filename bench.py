@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py -- free-running throughput of the MI355X overlap-save channelizer.
+
+A "step" is one 20 ms block of the hot path: the shared forward transform of the
+N = 3,240,000-sample window (129.6 MS/s real input) plus the gather x response +
+backward transform of every channel, inputs already resident in HBM (an 8-block
+sig_gen stream pre-generated into the device ring and replayed cyclically).
+
+  N = 1   BASELINE config 3: 1024 mixed usb/cw/iq channels, 12 kHz (P = 300), one GPU.
+  N > 1   BASELINE config 4: rank 0 owns the front end and transforms; the block
+          spectrum (12.96 MB) is RCCL-broadcast; every rank runs its own 1024 x 24 kHz
+          channels (P = 600) -> weak scaling in channels.
+
+metric: channels sustained at 129.6 MS/s = channel-blocks per second / 50 blocks/s
+(real-time-equivalent channels: how many channels of this configuration the measured
+block rate could serve in real time).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FS = 129.6e6
+BLOCKTIME = 0.02
+L = int(round(FS * BLOCKTIME))          # 2,592,000
+M = L // 4 + 1                          # 648,001  (overlap 5, src/radio.c:582-586)
+N = L + M - 1                           # 3,240,000
+BINS = N // 2 + 1
+RING_BLOCKS = 8
+HBM_PEAK_GBS = 8000.0                   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:35
+FWD_BYTES = 4 * N + 8 * BINS            # 25,920,008  
+
+
+def chan_bytes(P, olen):
+    return 8 * P + 8 * P + 8 * olen     # 6,720 (P=300) / 13,440 (P=600)
+
+
+def channel_plan_config3(nch):
+    """1024 mixed channels: thirds usb / cw / iq, f_i = 1 MHz + i*60 kHz + (i mod 40) Hz."""
+    kinds = [(50 / 12000, 3000 / 12000), (-200 / 12000, 200 / 12000), (-5000 / 12000, 5000 / 12000)]
+    hz_per_bin = FS / N
+    plan = []
+    for i in range(nch):
+        f = 1e6 + (i % 1040) * 60e3 + (i % 40)
+        plan.append((int(round(f / hz_per_bin)),) + kinds[i % 3])
+    return plan
+
+
+def channel_plan_config4(nch, rank):
+    """8192 x 24 kHz channels, f_i = 0.5 MHz + i*7.8 kHz, 1024 per GPU, +-10 kHz."""
+    hz_per_bin = FS / N
+    plan = []
+    for j in range(nch):
+        i = rank * nch + j
+        f = 0.5e6 + i * 7.8e3
+        plan.append((int(round(f / hz_per_bin)), -10000 / 24000, 10000 / 24000))
+    return plan
+
+
+def siggen_ring(oracle_lib, seed=1):
+    """8 blocks of the deterministic sig_gen stream (CW carrier 10.00002 MHz, -20 dBFS, noise -40 dBFS).
+    The generator is test infrastructure (oracle/); it only produces INPUT, outside the timed region."""
+    g = oracle_lib.SigGen(10.00002e6 / FS, 10 ** (-20 / 20), 10 ** (-40 / 20),
+                          oracle_lib.scale_ad(True, 1), True, seed=seed)
+    return g.generate(RING_BLOCKS * L)
+
+
+def cpu_baseline(oracle_lib, ring, plan, P, olen, seconds=12.0):
+    """Reference filter.c (oracle/_ref, FFT butterflies from the project's float32 provider, NOT FFTW)
+    timed on this host's cores: 1 forward-FFT worker thread + a pool of channel threads, radiod style."""
+    if not oracle_lib.have_ref():
+        return None
+    R = oracle_lib.ref()
+    R.oracle_fft_set_precision(1)          # float32 arithmetic for a fair CPU timing
+    cores = os.cpu_count() or 1
+    pool = max(1, min(cores - 1, 16))
+    m = oracle_lib.RefMaster(L, M, oracle_lib.REAL, worker_threads=1)
+    chans = []
+    for shift, low, high in plan:
+        c = m.channel(olen, oracle_lib.COMPLEX)
+        c.set_filter(low, high, 11.0)
+        chans.append(c)
+    harr = (ctypes.c_void_p * len(chans))(*[c.h for c in chans])
+    sarr = np.array([p[0] for p in plan], np.int32)
+    ring = np.ascontiguousarray(ring, np.float32)
+    # calibrate with 2 blocks, then run a bounded sample
+    t = R.refchz_bench(m.h, harr, sarr.ctypes.data, len(chans), ring.ctypes.data, RING_BLOCKS, 2, pool)
+    nblk = int(max(3, min(200, seconds / max(t / 2, 1e-3))))
+    t = R.refchz_bench(m.h, harr, sarr.ctypes.data, len(chans), ring.ctypes.data, RING_BLOCKS, nblk, pool)
+    mn, mx, avg = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+    R.refchz_fft_times(ctypes.byref(mn), ctypes.byref(mx), ctypes.byref(avg))
+    m.close()
+    R.oracle_fft_set_precision(0)
+    per_block = t / nblk
+    return {
+        "value": len(plan) * BLOCKTIME / per_block, "unit": "channels",
+        "cores": 1 + pool, "kind": "reference",
+        "sample": "%d blocks of the same workload (%d channels P=%d), reference filter.c with the project's "
+                  "portable float32 FFT provider (FFTW3 is not installed on this image), 1 FFT worker + %d channel threads"
+                  % (nblk, len(plan), P, pool),
+        "ms_per_block": per_block * 1e3, "fwd_fft_ms_avg": avg.value / 1e6, "host_cores": cores,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
+    ap.add_argument("--plan", default="", help="forward plan override, e.g. 144x100x225")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    import oracle_lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    pkg = ge.load()
+    eng = pkg.engine.Engine(L, M, pkg.engine.REAL, device=local_rank, plan=args.plan, ring_blocks=RING_BLOCKS)
+
+    nch = args.channels
+    if world == 1:
+        P, olen, workload = 300, 240, "config3: sig_gen real 129.6 MS/s, %d mixed usb/cw/iq 12 kHz channels (P=300), 1 MI355X" % nch
+        plan = channel_plan_config3(nch)
+    else:
+        P, olen = 600, 480
+        workload = ("config4: sig_gen real 129.6 MS/s, %d x 24 kHz channels (P=600) sharded over %d MI355X, "
+                    "spectrum RCCL-broadcast from rank 0" % (nch * world, world))
+        plan = channel_plan_config4(nch, rank)
+
+    # ---- inputs resident in HBM before anything is timed
+    ring_host = siggen_ring(oracle_lib)
+    # the device ring starts with the write position M-1 ahead (zeros before time 0); fill it to the brim
+    eng.write(ring_host[:RING_BLOCKS * L - (M - 1)])
+    eng.write(ring_host[RING_BLOCKS * L - (M - 1):])       # wraps: ring now holds the cyclic 8-block stream
+    bank = eng.bank(P, olen, nch)
+    resp = np.stack([pkg.filterapi.design_response(P, olen, N, True, lo, hi, 11.0) for _, lo, hi in plan])
+    bank.set_responses(0, resp)
+    bank.set_shifts(0, np.array([p[0] for p in plan], np.int32))
+    bank.set_active(nch)
+    eng.set_notches([0], 0.01)                               # DC notch is always present (src/radio.c:601-620)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        graph = not args.eager
+        eng.run_blocks(0, args.warmup, graph=graph)
+        barrier()
+        t0 = time.perf_counter()
+        timing = eng.run_blocks(args.warmup, args.steps, graph=graph)   # returns after the stream drained
+        barrier()
+        elapsed = time.perf_counter() - t0
+        gpu_ms = timing.total_ms
+    else:
+        # spectrum slots are torch tensors so RCCL can broadcast into them
+        slots = [torch.zeros(2 * BINS, dtype=torch.float32, device="cuda") for _ in range(4)]
+        for i, t in enumerate(slots):
+            eng.attach_spectrum(i, t.data_ptr())
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+        def run(job0, n):
+            # block j's broadcast (RCCL stream) overlaps block j+1's forward transform (compute stream)
+            pkg.sharding.pipelined_blocks(
+                range(job0, job0 + n), rank == 0, eng.forward,
+                lambda j: dist.broadcast(slots[j % 4], src=0, async_op=True),
+                lambda j: bank.execute(j % 4))
+
+        run(0, args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run(args.warmup, args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        gpu_ms = elapsed * 1e3
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- per-kernel durations with HIP events on the launch stream (eager, instrumented)
+    roof = None
+    if rank == 0:
+        eng_t = eng
+        it = eng_t.run_blocks(0, min(args.steps, 200), graph=False, instrument=True)
+        kern = {}
+        for name, ms, n in (("fwd_first_real", it.first_ms, it.first_n), ("fwd_cols", it.cols_ms, it.cols_n),
+                            ("fwd_rows", it.rows_ms, it.rows_n), ("notch_bins", it.notch_ms, it.notch_n),
+                            ("chan_ifft", it.chan_ms, it.chan_n)):
+            if n:
+                kern[name] = ms / n * 1e3       # microseconds per launch
+        Ra = eng.axes[0] // 2 + 1
+        inner_bytes = Ra * eng.axes[1] * eng.axes[2] * 8
+        own = {"fwd_first_real": 4 * N + inner_bytes, "fwd_cols": 2 * inner_bytes,
+               "fwd_rows": inner_bytes + 8 * BINS, "chan_ifft": nch * chan_bytes(P, olen)}
+        fwd_us = sum(kern.get(k, 0.0) for k in ("fwd_first_real", "fwd_cols", "fwd_rows"))
+        achieved = FWD_BYTES / (fwd_us * 1e-6) / 1e9 if fwd_us else 0.0
+        roof = {
+            "bound": "hbm", "kernel": "forward transform = fwd_first_real + fwd_cols + fwd_rows (one launch each per block)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_block": FWD_BYTES, "forward_us_per_block": fwd_us,
+            "kernels_us": kern,
+            "kernels_own_GBps": {k: own[k] / (kern[k] * 1e-6) / 1e9 for k in own if k in kern and kern[k] > 0},
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(oracle_lib, ring_host, plan, P, olen)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        total_ch = nch * world
+        value = total_ch * BLOCKTIME / (elapsed / args.steps)
+        step_bytes = FWD_BYTES + total_ch * chan_bytes(P, olen) + (world - 1) * 8 * BINS
+        out = {
+            "metric": "channels sustained @129.6 MS/s input (real-time-equivalent: channel-blocks/s / 50)",
+            "value": value, "unit": "channels", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "channels_total": total_ch, "P": P, "olen": olen, "N": N, "L": L, "M": M,
+                       "launch": "eager" if (args.eager or world > 1) else "hipGraph(8 blocks)", "plan": eng.plan},
+            "blocks_per_s": args.steps / elapsed, "realtime_margin": BLOCKTIME / (elapsed / args.steps),
+            "step_algorithmic_GBps": step_bytes / (elapsed / args.steps) / 1e9,
+            "gpu_event_ms_per_step": gpu_ms / args.steps,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

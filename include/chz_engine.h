@@ -1,0 +1,117 @@
+/* chz_engine.h -- C ABI of the MI355X overlap-save channelizer engine
+ * (libchz_hip.so, built from ka9q-radio_amd/csrc/chz_engine.hip).
+ *
+ * Plain pointers and sizes only; no torch, no C++ types.  This is the layer a
+ * foreign host (C, ctypes, cgo ...) binds.  Each entry point states which piece
+ * of the reference's filter.c it replaces; the struct-compatible drop-in for the
+ * reference's own filter.h (create_filter_input & co.) is layered on top of it in
+ * ka9q-radio_amd/csrc/filter_hip.c and declared in include/ka9q_filter_abi.h.
+ *
+ * All functions return 0 on success and a negative value on error (the message
+ * is available from chz_last_error()); there is NO CPU fallback: without a HIP
+ * device chz_engine_create() fails.
+ *
+ * Sample/stream conventions are the reference's: blocks of L new samples, impulse
+ * length M, N = L+M-1 point transform, window k = stream[kL-(M-1), kL+L) with
+ * zeros before time 0 (src/filter.c:196,244,259); unnormalised transforms both ways
+ * with all gain folded into the per-channel response (src/filter.c:1020-1028);
+ * ND = 4 spectrum slots indexed job % 4 (src/filter.h:48).
+ */
+#ifndef CHZ_ENGINE_H
+#define CHZ_ENGINE_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHZ_COMPLEX 1   /* enum filtertype COMPLEX, src/filter.h:31 */
+#define CHZ_REAL    2   /* enum filtertype REAL,    src/filter.h:32 */
+#define CHZ_ND      4   /* spectrum slots,          src/filter.h:48 */
+
+typedef struct chz_engine chz_engine;
+
+typedef struct chz_info {
+  int L, M, N, in_type, bins;
+  int ring_blocks;          /* device input ring holds ring_blocks*L samples */
+  int Na, Nb, Nc;           /* axis lengths of the forward transform */
+  int n_banks;
+  char plan[256];           /* human-readable plan description */
+} chz_info;
+
+typedef struct chz_timing {
+  double total_ms;          /* HIP-event time of the whole run on the engine's stream */
+  int blocks;
+  /* per-kernel HIP-event time, accumulated over the run (only when instrumented) */
+  double first_ms, cols_ms, rows_ms, notch_ms, chan_ms;
+  int first_n, cols_n, rows_n, notch_n, chan_n;
+} chz_timing;
+
+const char *chz_last_error(void);
+int chz_device_count(void);
+
+/* replaces create_filter_input (src/filter.c:186-269): allocates the device input
+ * ring (zeroed, write position M-1 ahead of the read position), the ND spectrum
+ * slots and the transform plan ("" / NULL = automatic, or "NaxNbxNc[:T1,T2,Ta]"). */
+int chz_engine_create(chz_engine **out, int L, int M, int in_type, int device,
+                      const char *plan_spec, int ring_blocks);
+/* replaces delete_filter_input (src/filter.c:930-942) */
+void chz_engine_destroy(chz_engine *e);
+int chz_engine_info(const chz_engine *e, chz_info *info);
+/* run all engine work on a caller-owned hipStream_t (e.g. torch's current stream) */
+int chz_engine_set_stream(chz_engine *e, void *hip_stream);
+int chz_sync(chz_engine *e);
+
+/* replaces the sample hand-over of write_rfilter/write_cfilter
+ * (src/filter.c:1093-1134): append n samples (floats; re,im pairs for COMPLEX) from
+ * host memory at the ring's write position. */
+int chz_input_write(chz_engine *e, const float *host_samples, long n);
+/* same, but the samples already live in device memory */
+int chz_input_write_device(chz_engine *e, const float *dev_samples, long n);
+/* direct access to the device ring for HBM-resident benchmarks */
+int chz_input_ring(chz_engine *e, float **dev_ring, long *ring_len_floats);
+
+/* replaces the body of execute_filter_input / run_fft (src/filter.c:485-651):
+ * forward transform of the window of job `job` (window start = job*L in ring
+ * coordinates) into slot job % 4, then the spur notches. */
+int chz_forward(chz_engine *e, unsigned job);
+/* notch list as radio.c builds it (src/radio.c:601-620): last entry is bin 0;
+ * replaces apply_notch_filters' state (src/filter.c:464-474).  n = 0 clears. */
+int chz_set_notches(chz_engine *e, const int *bins, int n, double alpha);
+int chz_spectrum_read(chz_engine *e, int slot, float *host);     /* 2*bins floats, synchronous */
+int chz_spectrum_device(chz_engine *e, int slot, float **dev);
+/* point a slot at caller-owned device memory (2*bins floats), e.g. a torch tensor
+ * that RCCL broadcasts into */
+int chz_spectrum_attach(chz_engine *e, int slot, float *dev);
+
+/* A bank = all channels sharing one (P, olen); replaces create_filter_output's
+ * allocations (src/filter.c:298-415) for COMPLEX output channels. */
+int chz_bank_create(chz_engine *e, int P, int olen, int capacity);          /* returns bank id */
+/* response[P] complex as set_filter leaves it (src/filter.c:968-1045) */
+int chz_bank_set_responses(chz_engine *e, int bank, int ch0, int n, const float *resp);
+/* `shift` of execute_filter_output(slave, shift) (src/filter.c:663) */
+int chz_bank_set_shifts(chz_engine *e, int bank, int ch0, int n, const int *shifts);
+int chz_bank_set_active(chz_engine *e, int bank, int n);                    /* channels [0,n) run */
+/* replaces execute_filter_output's gather x response + backward transform
+ * (src/filter.c:728-914) for every active channel of the bank at once */
+int chz_bank_execute(chz_engine *e, int bank, int slot);
+int chz_bank_read(chz_engine *e, int bank, int ch0, int n, float *host);    /* n*olen complex, synchronous */
+int chz_bank_output_device(chz_engine *e, int bank, float **dev);
+
+/* one whole block: chz_forward(job) then every bank on slot job % 4 */
+int chz_step(chz_engine *e, unsigned job);
+
+/* Run `nblocks` consecutive blocks starting at `job0` and time them with HIP
+ * events on the engine's stream.
+ *   mode 0: eager launches          mode 1: one hipGraph per ring cycle, replayed
+ *   instrument != 0 (eager only): HIP events around every kernel -> per-kernel ms */
+int chz_run_blocks(chz_engine *e, unsigned job0, int nblocks, int mode, int instrument,
+                   chz_timing *timing);
+
+/* host-side helper exposed for tests: the closed-form gather descriptor
+ * {t0,cnt,src0,dir,conj,wrap} that restates src/filter.c:728-911 */
+int chz_gather_descriptor(int in_type, int master_bins, int P, int shift, int out6[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

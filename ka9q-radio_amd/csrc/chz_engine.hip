@@ -1,0 +1,450 @@
+// chz_engine.hip -- device-side engine behind include/chz_engine.h.
+//
+// Owns the HBM-resident state of one master (input ring, intermediate buffer,
+// ND spectrum slots, twiddle tables) and of its channel banks, and launches the
+// kernels of chz_kernels.h on one HIP stream.  Everything per block is enqueued
+// asynchronously; a ring cycle of blocks can be captured into a hipGraph so the
+// launch-bound inner loop costs one graph replay.  gfx950 only, no fallback.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "chz_launch.h"
+#include "../../include/chz_engine.h"
+
+using namespace chz;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+  return code;
+}
+#define HIPOK(call) do { hipError_t _e = (call); if (_e != hipSuccess) \
+  return fail(-10, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+
+struct Bank {
+  int P = 0, olen = 0, cap = 0, active = 0;
+  ChanGeom g;
+  float2* resp = nullptr;       // [cap][P]
+  ChanDesc* desc = nullptr;     // [cap]
+  float2* out = nullptr;        // [cap][olen]
+  float2* tw_sub = nullptr;
+};
+
+struct chz_engine {
+  int L = 0, M = 0, N = 0, in_type = 0, bins = 0, per = 1, device = 0, ring_blocks = 0;
+  FwdPlan plan;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  float* ring = nullptr; long ring_len = 0;   // floats
+  long wpos = 0;                              // write position (floats)
+  float2* buf = nullptr;
+  float2* spec[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};
+  bool spec_owned[CHZ_ND] = {false, false, false, false};
+  float2 *tw_sub_a = nullptr, *tw_sub_b = nullptr, *tw_sub_c = nullptr;
+  float2 *tw1_tile = nullptr, *tw1_col = nullptr, *tw2_tile = nullptr, *tw2_col = nullptr;
+  int n_notch = 0; int* notch_bins = nullptr; double* notch_state = nullptr; double notch_alpha = 0;
+  std::vector<Bank> banks;
+  hipGraphExec_t graph = nullptr; unsigned graph_job0 = 0; int graph_blocks = 0; size_t graph_sig = 0;
+};
+
+template <class T> static int upload(T** dst, const std::vector<f2>& v) {
+  *dst = nullptr;
+  if (v.empty()) return 0;
+  HIPOK(hipMalloc((void**)dst, v.size() * sizeof(f2)));
+  HIPOK(hipMemcpy(*dst, v.data(), v.size() * sizeof(f2), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" {
+
+const char* chz_last_error(void) { return g_err; }
+
+int chz_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int chz_gather_descriptor(int in_type, int master_bins, int P, int shift, int out6[6]) {
+  ChanDescH d = make_chan_desc(in_type, master_bins, P, shift);
+  out6[0] = d.t0; out6[1] = d.cnt; out6[2] = d.src0; out6[3] = d.dir; out6[4] = d.conj; out6[5] = d.wrap;
+  return 0;
+}
+
+int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, const char* plan_spec, int ring_blocks) {
+  if (!out) return fail(-1, "null out pointer");
+  *out = nullptr;
+  if (L < 1 || M < 1) return fail(-1, "bad L/M");
+  if (in_type != CHZ_REAL && in_type != CHZ_COMPLEX) return fail(-1, "in_type must be REAL or COMPLEX");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(-2, "no HIP device: the channelizer engine has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(-2, "device %d out of range (%d devices)", device, ndev);
+  HIPOK(hipSetDevice(device));
+  const int N = L + M - 1;                                  // src/filter.c:196
+  const int bins = in_type == CHZ_COMPLEX ? N : N / 2 + 1;  // src/filter.c:197
+  if (bins < 2) return fail(-1, "transform too small");     // src/filter.c:198-199
+  if (in_type == CHZ_REAL && (L & 1)) return fail(-1, "real input needs an even block length L");
+  chz_engine* e = new chz_engine();
+  e->L = L; e->M = M; e->N = N; e->in_type = in_type; e->bins = bins; e->device = device;
+  e->per = in_type == CHZ_REAL ? 1 : 2;
+  const char* envspec = getenv("CHZ_PLAN");
+  if ((!plan_spec || !*plan_spec) && envspec && *envspec) plan_spec = envspec;
+  if (!build_fwd_plan(N, in_type, plan_spec, e->plan)) {
+    delete e;
+    return fail(-3, "no transform plan for N=%d (spec '%s'): N must factor into the compiled axis lengths", N, plan_spec ? plan_spec : "");
+  }
+  const int minblocks = (N + L - 1) / L + 1;
+  if (ring_blocks < minblocks) ring_blocks = minblocks < 8 ? 8 : minblocks;
+  e->ring_blocks = ring_blocks;
+  e->ring_len = (long)ring_blocks * L * e->per;
+  HIPOK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  e->own_stream = true;
+  HIPOK(hipMalloc((void**)&e->ring, sizeof(float) * (size_t)e->ring_len));
+  HIPOK(hipMemset(e->ring, 0, sizeof(float) * (size_t)e->ring_len));       // src/filter.c:242,257
+  e->wpos = (long)(M - 1) * e->per;                                          // src/filter.c:244,259
+  HIPOK(hipMalloc((void**)&e->buf, sizeof(float2) * (size_t)e->plan.Ra * e->plan.inner));
+  for (int i = 0; i < CHZ_ND; i++) {
+    HIPOK(hipMalloc((void**)&e->spec[i], sizeof(float2) * (size_t)bins));
+    HIPOK(hipMemset(e->spec[i], 0, sizeof(float2) * (size_t)bins));
+    e->spec_owned[i] = true;
+  }
+  int r;
+  if ((r = upload(&e->tw_sub_a, e->plan.tw_sub_a)) || (r = upload(&e->tw_sub_b, e->plan.tw_sub_b)) ||
+      (r = upload(&e->tw_sub_c, e->plan.tw_sub_c)) || (r = upload(&e->tw1_tile, e->plan.tw1_tile)) ||
+      (r = upload(&e->tw1_col, e->plan.tw1_col)) || (r = upload(&e->tw2_tile, e->plan.tw2_tile)) ||
+      (r = upload(&e->tw2_col, e->plan.tw2_col)))
+    return r;
+  // kernels may need more than the default 64 KiB of dynamic LDS
+  *out = e;
+  return 0;
+}
+
+static void drop_graph(chz_engine* e) {
+  if (e->graph) { hipGraphExecDestroy(e->graph); e->graph = nullptr; }
+}
+
+void chz_engine_destroy(chz_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  hipStreamSynchronize(e->stream);
+  drop_graph(e);
+  for (auto& b : e->banks) { hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); }
+  hipFree(e->ring); hipFree(e->buf);
+  for (int i = 0; i < CHZ_ND; i++) if (e->spec_owned[i]) hipFree(e->spec[i]);
+  hipFree(e->tw_sub_a); hipFree(e->tw_sub_b); hipFree(e->tw_sub_c);
+  hipFree(e->tw1_tile); hipFree(e->tw1_col); hipFree(e->tw2_tile); hipFree(e->tw2_col);
+  hipFree(e->notch_bins); hipFree(e->notch_state);
+  if (e->own_stream) hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int chz_engine_info(const chz_engine* e, chz_info* info) {
+  if (!e || !info) return fail(-1, "null argument");
+  memset(info, 0, sizeof *info);
+  info->L = e->L; info->M = e->M; info->N = e->N; info->in_type = e->in_type; info->bins = e->bins;
+  info->ring_blocks = e->ring_blocks; info->Na = e->plan.Na; info->Nb = e->plan.Nb; info->Nc = e->plan.Nc;
+  info->n_banks = (int)e->banks.size();
+  snprintf(info->plan, sizeof info->plan, "%s", e->plan.desc.c_str());
+  return 0;
+}
+
+int chz_engine_set_stream(chz_engine* e, void* hip_stream) {
+  if (!e) return fail(-1, "null engine");
+  HIPOK(hipStreamSynchronize(e->stream));
+  drop_graph(e);
+  if (e->own_stream) { hipStreamDestroy(e->stream); e->own_stream = false; }
+  e->stream = (hipStream_t)hip_stream;
+  return 0;
+}
+
+int chz_sync(chz_engine* e) {
+  if (!e) return fail(-1, "null engine");
+  HIPOK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+
+static int ring_write(chz_engine* e, const float* src, long n, hipMemcpyKind kind) {
+  const long nf = n * e->per;
+  if (nf < 0 || nf > e->ring_len) return fail(-1, "write of %ld samples does not fit the ring", n);
+  const long first = (e->wpos + nf <= e->ring_len) ? nf : e->ring_len - e->wpos;
+  if (first > 0) HIPOK(hipMemcpyAsync(e->ring + e->wpos, src, sizeof(float) * (size_t)first, kind, e->stream));
+  if (nf > first) HIPOK(hipMemcpyAsync(e->ring, src + first, sizeof(float) * (size_t)(nf - first), kind, e->stream));
+  e->wpos = (e->wpos + nf) % e->ring_len;
+  return 0;
+}
+int chz_input_write(chz_engine* e, const float* host, long n) {
+  if (!e || !host) return fail(-1, "null argument");
+  return ring_write(e, host, n, hipMemcpyHostToDevice);
+}
+int chz_input_write_device(chz_engine* e, const float* dev, long n) {
+  if (!e || !dev) return fail(-1, "null argument");
+  return ring_write(e, dev, n, hipMemcpyDeviceToDevice);
+}
+int chz_input_ring(chz_engine* e, float** dev_ring, long* ring_len_floats) {
+  if (!e) return fail(-1, "null engine");
+  if (dev_ring) *dev_ring = e->ring;
+  if (ring_len_floats) *ring_len_floats = e->ring_len;
+  return 0;
+}
+
+// ---- kernel launches ---------------------------------------------------------
+struct Instr {      // optional per-kernel HIP-event instrumentation
+  bool on = false;
+  std::vector<hipEvent_t> ev;   // pairs
+  std::vector<int> kind;        // 0 first, 1 cols, 2 rows, 3 notch, 4 chan
+};
+static void mark(Instr* in, hipStream_t s, int kind, bool begin) {
+  if (!in || !in->on) return;
+  hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s);
+  in->ev.push_back(e);
+  if (begin) in->kind.push_back(kind);
+}
+
+static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
+  const FwdPlan& p = e->plan;
+  const int slot = job % CHZ_ND;
+  const long start = (long)(((unsigned long long)job * (unsigned long long)e->L) % (unsigned long long)((long)e->ring_blocks * e->L)) * e->per;
+  if (e->in_type == CHZ_REAL) {
+    FirstRealParams a{};
+    a.ring = e->ring; a.ring_len = e->ring_len; a.start = start; a.buf = e->buf; a.inner = p.inner;
+    a.T = p.T1; a.Ra = p.Ra; a.padk = p.padk1; a.tw_sub = e->tw_sub_a; a.tw_tile = e->tw1_tile; a.tw_col = e->tw1_col;
+    mark(in, e->stream, 0, true);
+    if (launch_first_real(p.ra, p.grid1, p.block1, p.lds1, e->stream, a)) return fail(-4, "no kernel for axis a");
+    mark(in, e->stream, 0, false);
+  } else {
+    ColsParams a{};
+    a.in = reinterpret_cast<const float2*>(e->ring); a.in_len = e->ring_len / 2; a.in_start = start / 2;
+    a.out = e->buf; a.rows = 1; a.inner = p.inner; a.T = p.T1; a.padk = p.padk1;
+    a.tw_sub = e->tw_sub_a; a.tw_tile = e->tw1_tile; a.tw_col = e->tw1_col;
+    mark(in, e->stream, 0, true);
+    if (launch_cols(p.ra, p.grid1, p.block1, p.lds1, e->stream, a)) return fail(-4, "no kernel for axis a");
+    mark(in, e->stream, 0, false);
+  }
+  if (p.Nb > 1) {
+    ColsParams b{};
+    b.in = e->buf; b.in_len = 0; b.in_start = 0; b.out = e->buf; b.rows = p.Ra; b.inner = p.Nc; b.T = p.T2;
+    b.padk = p.padk2; b.tw_sub = e->tw_sub_b; b.tw_tile = e->tw2_tile; b.tw_col = e->tw2_col;
+    mark(in, e->stream, 1, true);
+    if (launch_cols(p.rb, p.grid2, p.block2, p.lds2, e->stream, b)) return fail(-4, "no kernel for axis b");
+    mark(in, e->stream, 1, false);
+  }
+  RowsParams c{};
+  c.buf = e->buf; c.spec = e->spec[slot]; c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3;
+  c.padg = p.padg3; c.N = p.N; c.mirror = e->in_type == CHZ_REAL; c.tw_sub = e->tw_sub_c;
+  mark(in, e->stream, 2, true);
+  if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, e->stream, c)) return fail(-4, "no kernel for axis c");
+  mark(in, e->stream, 2, false);
+  if (e->n_notch > 0) {
+    NotchParams q{e->spec[slot], e->notch_bins, e->notch_state, e->n_notch, e->notch_alpha};
+    mark(in, e->stream, 3, true);
+    launch_notch(e->n_notch, e->stream, q);
+    mark(in, e->stream, 3, false);
+  }
+  return 0;
+}
+
+static int enqueue_bank(chz_engine* e, int bank, int slot, Instr* in) {
+  Bank& b = e->banks[(size_t)bank];
+  if (b.active <= 0) return 0;
+  ChanParams c{};
+  c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc; c.out = b.out; c.nch = b.active; c.olen = b.olen;
+  c.tw_sub = b.tw_sub;
+  const int per_block = b.g.wpb * b.g.cpw;
+  const int grid = (b.active + per_block - 1) / per_block;
+  mark(in, e->stream, 4, true);
+  if (launch_chan(b.g.r, grid, b.g.wpb * 64, b.g.lds, e->stream, c)) return fail(-4, "no kernel for P=%d", b.P);
+  mark(in, e->stream, 4, false);
+  return 0;
+}
+
+int chz_forward(chz_engine* e, unsigned job) {
+  if (!e) return fail(-1, "null engine");
+  HIPOK(hipSetDevice(e->device));
+  int r = enqueue_forward(e, job, nullptr);
+  if (r) return r;
+  HIPOK(hipGetLastError());
+  return 0;
+}
+
+int chz_set_notches(chz_engine* e, const int* bins, int n, double alpha) {
+  if (!e) return fail(-1, "null engine");
+  HIPOK(hipStreamSynchronize(e->stream));
+  drop_graph(e);
+  hipFree(e->notch_bins); hipFree(e->notch_state); e->notch_bins = nullptr; e->notch_state = nullptr; e->n_notch = 0;
+  if (n <= 0 || !bins) return 0;
+  for (int i = 0; i < n; i++) if (bins[i] < 0 || bins[i] >= e->bins) return fail(-1, "notch bin %d out of range", bins[i]);
+  HIPOK(hipMalloc((void**)&e->notch_bins, sizeof(int) * (size_t)n));
+  HIPOK(hipMalloc((void**)&e->notch_state, sizeof(double) * 2 * (size_t)n));
+  HIPOK(hipMemcpy(e->notch_bins, bins, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  HIPOK(hipMemset(e->notch_state, 0, sizeof(double) * 2 * (size_t)n));
+  e->n_notch = n; e->notch_alpha = alpha;
+  return 0;
+}
+
+int chz_spectrum_read(chz_engine* e, int slot, float* host) {
+  if (!e || !host || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
+  HIPOK(hipMemcpyAsync(host, e->spec[slot], sizeof(float2) * (size_t)e->bins, hipMemcpyDeviceToHost, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+int chz_spectrum_device(chz_engine* e, int slot, float** dev) {
+  if (!e || !dev || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
+  *dev = reinterpret_cast<float*>(e->spec[slot]);
+  return 0;
+}
+int chz_spectrum_attach(chz_engine* e, int slot, float* dev) {
+  if (!e || !dev || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
+  HIPOK(hipStreamSynchronize(e->stream));
+  drop_graph(e);
+  if (e->spec_owned[slot]) hipFree(e->spec[slot]);
+  e->spec[slot] = reinterpret_cast<float2*>(dev); e->spec_owned[slot] = false;
+  return 0;
+}
+
+int chz_bank_create(chz_engine* e, int P, int olen, int capacity) {
+  if (!e) return fail(-1, "null engine");
+  if (capacity < 1 || olen < 1 || olen > P) return fail(-1, "bad bank geometry");
+  // P = olen*N/L must divide exactly (src/filter.c:312-316)
+  if ((long long)olen * e->N % e->L != 0 || (long long)olen * e->N / e->L != P)
+    return fail(-1, "P=%d is not olen*N/L for olen=%d N=%d L=%d", P, olen, e->N, e->L);
+  Bank b;
+  if (!build_chan_geom(P, b.g)) return fail(-3, "no channel kernel compiled for P=%d", P);
+  HIPOK(hipSetDevice(e->device));
+  b.P = P; b.olen = olen; b.cap = capacity; b.active = 0;
+  HIPOK(hipMalloc((void**)&b.resp, sizeof(float2) * (size_t)capacity * P));
+  HIPOK(hipMemset(b.resp, 0, sizeof(float2) * (size_t)capacity * P));
+  HIPOK(hipMalloc((void**)&b.desc, sizeof(ChanDesc) * (size_t)capacity));
+  HIPOK(hipMemset(b.desc, 0, sizeof(ChanDesc) * (size_t)capacity));
+  HIPOK(hipMalloc((void**)&b.out, sizeof(float2) * (size_t)capacity * olen));
+  HIPOK(hipMemset(b.out, 0, sizeof(float2) * (size_t)capacity * olen));
+  int r = upload(&b.tw_sub, b.g.tw_sub);
+  if (r) return r;
+  drop_graph(e);
+  e->banks.push_back(b);
+  return (int)e->banks.size() - 1;
+}
+
+#define BANK_CHECK(e, bank, ch0, n) \
+  if (!(e) || (bank) < 0 || (bank) >= (int)(e)->banks.size()) return fail(-1, "bad bank"); \
+  if ((ch0) < 0 || (n) < 0 || (ch0) + (n) > (e)->banks[(size_t)(bank)].cap) return fail(-1, "channel range out of bank capacity")
+
+int chz_bank_set_responses(chz_engine* e, int bank, int ch0, int n, const float* resp) {
+  BANK_CHECK(e, bank, ch0, n);
+  Bank& b = e->banks[(size_t)bank];
+  HIPOK(hipMemcpyAsync(b.resp + (size_t)ch0 * b.P, resp, sizeof(float2) * (size_t)n * b.P, hipMemcpyHostToDevice, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));   // caller's buffer may be pageable / reused
+  return 0;
+}
+int chz_bank_set_shifts(chz_engine* e, int bank, int ch0, int n, const int* shifts) {
+  BANK_CHECK(e, bank, ch0, n);
+  Bank& b = e->banks[(size_t)bank];
+  std::vector<ChanDesc> d((size_t)n);
+  for (int i = 0; i < n; i++) {
+    ChanDescH h = make_chan_desc(e->in_type, e->bins, b.P, shifts[i]);
+    d[(size_t)i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
+  }
+  HIPOK(hipMemcpyAsync(b.desc + ch0, d.data(), sizeof(ChanDesc) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+int chz_bank_set_active(chz_engine* e, int bank, int n) {
+  BANK_CHECK(e, bank, 0, n);
+  if (e->banks[(size_t)bank].active != n) drop_graph(e);
+  e->banks[(size_t)bank].active = n;
+  return 0;
+}
+int chz_bank_execute(chz_engine* e, int bank, int slot) {
+  BANK_CHECK(e, bank, 0, 0);
+  if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
+  HIPOK(hipSetDevice(e->device));
+  int r = enqueue_bank(e, bank, slot, nullptr);
+  if (r) return r;
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int chz_bank_read(chz_engine* e, int bank, int ch0, int n, float* host) {
+  BANK_CHECK(e, bank, ch0, n);
+  Bank& b = e->banks[(size_t)bank];
+  HIPOK(hipMemcpyAsync(host, b.out + (size_t)ch0 * b.olen, sizeof(float2) * (size_t)n * b.olen, hipMemcpyDeviceToHost, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+int chz_bank_output_device(chz_engine* e, int bank, float** dev) {
+  BANK_CHECK(e, bank, 0, 0);
+  *dev = reinterpret_cast<float*>(e->banks[(size_t)bank].out);
+  return 0;
+}
+
+static int enqueue_step(chz_engine* e, unsigned job, Instr* in) {
+  int r = enqueue_forward(e, job, in);
+  if (r) return r;
+  for (int b = 0; b < (int)e->banks.size(); b++)
+    if ((r = enqueue_bank(e, b, job % CHZ_ND, in))) return r;
+  return 0;
+}
+
+int chz_step(chz_engine* e, unsigned job) {
+  if (!e) return fail(-1, "null engine");
+  HIPOK(hipSetDevice(e->device));
+  int r = enqueue_step(e, job, nullptr);
+  if (r) return r;
+  HIPOK(hipGetLastError());
+  return 0;
+}
+
+int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int instrument, chz_timing* timing) {
+  if (!e || nblocks < 0) return fail(-1, "bad argument");
+  HIPOK(hipSetDevice(e->device));
+  hipEvent_t t0, t1;
+  HIPOK(hipEventCreate(&t0)); HIPOK(hipEventCreate(&t1));
+  Instr in; in.on = instrument != 0 && mode == 0;
+  int done = 0;
+  if (mode == 1) {
+    // one graph = one ring cycle of blocks (a multiple of ND so slots line up too)
+    int cycle = e->ring_blocks;
+    while (cycle % CHZ_ND) cycle += e->ring_blocks;
+    const unsigned phase = job0 % (unsigned)cycle;
+    if (!e->graph || e->graph_blocks != cycle || e->graph_job0 != phase) {
+      drop_graph(e);
+      hipGraph_t g = nullptr;
+      HIPOK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+      int r = 0;
+      for (int i = 0; i < cycle && !r; i++) r = enqueue_step(e, phase + (unsigned)i, nullptr);
+      hipError_t ce = hipStreamEndCapture(e->stream, &g);
+      if (r) { if (g) hipGraphDestroy(g); return r; }
+      if (ce != hipSuccess) return fail(-10, "graph capture failed: %s", hipGetErrorString(ce));
+      HIPOK(hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0));
+      hipGraphDestroy(g);
+      e->graph_blocks = cycle; e->graph_job0 = phase;
+    }
+    HIPOK(hipEventRecord(t0, e->stream));
+    while (nblocks - done >= cycle) { HIPOK(hipGraphLaunch(e->graph, e->stream)); done += cycle; }
+    for (; done < nblocks; done++) { int r = enqueue_step(e, job0 + (unsigned)done, nullptr); if (r) return r; }
+  } else {
+    HIPOK(hipEventRecord(t0, e->stream));
+    for (; done < nblocks; done++) { int r = enqueue_step(e, job0 + (unsigned)done, &in); if (r) return r; }
+  }
+  HIPOK(hipEventRecord(t1, e->stream));
+  HIPOK(hipEventSynchronize(t1));
+  HIPOK(hipGetLastError());
+  if (timing) {
+    memset(timing, 0, sizeof *timing);
+    float ms = 0; HIPOK(hipEventElapsedTime(&ms, t0, t1));
+    timing->total_ms = ms; timing->blocks = nblocks;
+    double* acc[5] = {&timing->first_ms, &timing->cols_ms, &timing->rows_ms, &timing->notch_ms, &timing->chan_ms};
+    int* cnt[5] = {&timing->first_n, &timing->cols_n, &timing->rows_n, &timing->notch_n, &timing->chan_n};
+    for (size_t i = 0; i < in.kind.size(); i++) {
+      float k = 0; hipEventElapsedTime(&k, in.ev[2 * i], in.ev[2 * i + 1]);
+      *acc[in.kind[i]] += k; *cnt[in.kind[i]] += 1;
+    }
+  }
+  for (auto ev : in.ev) hipEventDestroy(ev);
+  hipEventDestroy(t0); hipEventDestroy(t1);
+  return 0;
+}
+
+}  // extern "C"

@@ -300,7 +300,7 @@ __global__ void notch_bins(NotchParams p) {
 // LPC = max(R1,R2) lanes serve one channel, 64/LPC channels share a wavefront.
 // ------------------------------------------------------------------------------
 template <int R1, int R2>
-__global__ void chan_ifft(ChanParams p) {
+__global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
   constexpr int P = R1 * R2;
   constexpr int LPC = R1 > R2 ? R1 : R2;
   constexpr int CPW = 64 / LPC;

@@ -1,0 +1,212 @@
+"""ctypes binding of include/chz_engine.h (libchz_hip.so).
+
+There is deliberately no CPU fallback here: if the HIP library is missing or no
+MI355X is visible, loading / engine creation raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libchz_hip.so")
+
+COMPLEX, REAL = 1, 2
+ND = 4
+
+_vp, _i, _u, _d, _l = C.c_void_p, C.c_int, C.c_uint, C.c_double, C.c_long
+
+
+class ChzInfo(C.Structure):
+    _fields_ = [("L", _i), ("M", _i), ("N", _i), ("in_type", _i), ("bins", _i), ("ring_blocks", _i),
+                ("Na", _i), ("Nb", _i), ("Nc", _i), ("n_banks", _i), ("plan", C.c_char * 256)]
+
+
+class ChzTiming(C.Structure):
+    _fields_ = [("total_ms", _d), ("blocks", _i),
+                ("first_ms", _d), ("cols_ms", _d), ("rows_ms", _d), ("notch_ms", _d), ("chan_ms", _d),
+                ("first_n", _i), ("cols_n", _i), ("rows_n", _i), ("notch_n", _i), ("chan_n", _i)]
+
+
+# every symbol include/chz_engine.h declares (checked by tests/test_abi_symbols.py)
+SYMBOLS = [
+    "chz_last_error", "chz_device_count", "chz_engine_create", "chz_engine_destroy", "chz_engine_info",
+    "chz_engine_set_stream", "chz_sync", "chz_input_write", "chz_input_write_device", "chz_input_ring",
+    "chz_forward", "chz_set_notches", "chz_spectrum_read", "chz_spectrum_device", "chz_spectrum_attach",
+    "chz_bank_create", "chz_bank_set_responses", "chz_bank_set_shifts", "chz_bank_set_active",
+    "chz_bank_execute", "chz_bank_read", "chz_bank_output_device", "chz_step", "chz_run_blocks",
+    "chz_gather_descriptor",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libchz_hip.so (raises if it has not been built: run __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libchz_hip.so is missing: build it with `make -C ka9q-radio_amd/csrc` "
+                               "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.chz_last_error.restype = C.c_char_p
+        L.chz_device_count.restype = _i
+        L.chz_engine_create.argtypes = [C.POINTER(_vp), _i, _i, _i, _i, C.c_char_p, _i]
+        L.chz_engine_destroy.argtypes = [_vp]; L.chz_engine_destroy.restype = None
+        L.chz_engine_info.argtypes = [_vp, C.POINTER(ChzInfo)]
+        L.chz_engine_set_stream.argtypes = [_vp, _vp]
+        L.chz_sync.argtypes = [_vp]
+        L.chz_input_write.argtypes = [_vp, _vp, _l]
+        L.chz_input_write_device.argtypes = [_vp, _vp, _l]
+        L.chz_input_ring.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_l)]
+        L.chz_forward.argtypes = [_vp, _u]
+        L.chz_set_notches.argtypes = [_vp, _vp, _i, _d]
+        L.chz_spectrum_read.argtypes = [_vp, _i, _vp]
+        L.chz_spectrum_device.argtypes = [_vp, _i, C.POINTER(_vp)]
+        L.chz_spectrum_attach.argtypes = [_vp, _i, _vp]
+        L.chz_bank_create.argtypes = [_vp, _i, _i, _i]
+        L.chz_bank_set_responses.argtypes = [_vp, _i, _i, _i, _vp]
+        L.chz_bank_set_shifts.argtypes = [_vp, _i, _i, _i, _vp]
+        L.chz_bank_set_active.argtypes = [_vp, _i, _i]
+        L.chz_bank_execute.argtypes = [_vp, _i, _i]
+        L.chz_bank_read.argtypes = [_vp, _i, _i, _i, _vp]
+        L.chz_bank_output_device.argtypes = [_vp, _i, C.POINTER(_vp)]
+        L.chz_step.argtypes = [_vp, _u]
+        L.chz_run_blocks.argtypes = [_vp, _u, _i, _i, _i, C.POINTER(ChzTiming)]
+        L.chz_gather_descriptor.argtypes = [_i, _i, _i, _i, C.POINTER(_i * 6)]
+        _lib = L
+    return _lib
+
+
+class ChzError(RuntimeError):
+    pass
+
+
+def _check(r):
+    if r < 0:
+        raise ChzError(lib().chz_last_error().decode())
+    return r
+
+
+def gather_descriptor(in_type, master_bins, P, shift):
+    out = (_i * 6)()
+    lib().chz_gather_descriptor(in_type, master_bins, P, int(shift), C.byref(out))
+    return tuple(out)
+
+
+class Engine:
+    """One master (input half) on one GPU."""
+
+    def __init__(self, L, M, in_type, device=0, plan="", ring_blocks=0):
+        self._h = _vp()
+        _check(lib().chz_engine_create(C.byref(self._h), L, M, in_type, device,
+                                       plan.encode() if plan else None, ring_blocks))
+        info = ChzInfo()
+        _check(lib().chz_engine_info(self._h, C.byref(info)))
+        self.L, self.M, self.N, self.in_type, self.bins = info.L, info.M, info.N, info.in_type, info.bins
+        self.ring_blocks = info.ring_blocks
+        self.plan = info.plan.decode()
+        self.axes = (info.Na, info.Nb, info.Nc)
+        self.banks = []
+
+    def close(self):
+        if self._h:
+            lib().chz_engine_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- input ---------------------------------------------------------------
+    def write(self, samples):
+        dt = np.float32 if self.in_type == REAL else np.complex64
+        samples = np.ascontiguousarray(samples, dt)
+        _check(lib().chz_input_write(self._h, samples.ctypes.data, samples.shape[0]))
+        _check(lib().chz_sync(self._h))   # numpy buffer may be freed by the caller
+
+    def write_device(self, dev_ptr, n):
+        _check(lib().chz_input_write_device(self._h, dev_ptr, n))
+
+    def ring(self):
+        p, n = _vp(), _l()
+        _check(lib().chz_input_ring(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def set_stream(self, hip_stream):
+        _check(lib().chz_engine_set_stream(self._h, hip_stream))
+
+    # -- forward ---------------------------------------------------------------
+    def forward(self, job):
+        _check(lib().chz_forward(self._h, job & 0xFFFFFFFF))
+
+    def set_notches(self, bins, alpha=0.01):
+        bins = np.ascontiguousarray(bins, np.int32)
+        _check(lib().chz_set_notches(self._h, bins.ctypes.data if len(bins) else None, len(bins), alpha))
+
+    def spectrum(self, slot):
+        out = np.zeros(self.bins, np.complex64)
+        _check(lib().chz_spectrum_read(self._h, slot, out.ctypes.data))
+        return out
+
+    def spectrum_ptr(self, slot):
+        p = _vp()
+        _check(lib().chz_spectrum_device(self._h, slot, C.byref(p)))
+        return p.value
+
+    def attach_spectrum(self, slot, dev_ptr):
+        _check(lib().chz_spectrum_attach(self._h, slot, dev_ptr))
+
+    # -- banks -----------------------------------------------------------------
+    def bank(self, P, olen, capacity):
+        b = Bank(self, P, olen, capacity)
+        self.banks.append(b)
+        return b
+
+    def step(self, job):
+        _check(lib().chz_step(self._h, job & 0xFFFFFFFF))
+
+    def sync(self):
+        _check(lib().chz_sync(self._h))
+
+    def run_blocks(self, job0, nblocks, graph=False, instrument=False):
+        t = ChzTiming()
+        _check(lib().chz_run_blocks(self._h, job0 & 0xFFFFFFFF, nblocks, 1 if graph else 0,
+                                    1 if instrument else 0, C.byref(t)))
+        return t
+
+
+class Bank:
+    def __init__(self, eng, P, olen, capacity):
+        self.eng, self.P, self.olen, self.capacity = eng, P, olen, capacity
+        self.id = _check(lib().chz_bank_create(eng._h, P, olen, capacity))
+        self.active = 0
+
+    def set_responses(self, ch0, resp):
+        resp = np.ascontiguousarray(resp, np.complex64).reshape(-1, self.P)
+        _check(lib().chz_bank_set_responses(self.eng._h, self.id, ch0, resp.shape[0], resp.ctypes.data))
+
+    def set_shifts(self, ch0, shifts):
+        shifts = np.ascontiguousarray(shifts, np.int32).reshape(-1)
+        _check(lib().chz_bank_set_shifts(self.eng._h, self.id, ch0, shifts.shape[0], shifts.ctypes.data))
+
+    def set_active(self, n):
+        _check(lib().chz_bank_set_active(self.eng._h, self.id, n))
+        self.active = n
+
+    def execute(self, slot):
+        _check(lib().chz_bank_execute(self.eng._h, self.id, slot))
+
+    def read(self, ch0=0, n=None):
+        if n is None:
+            n = self.active - ch0
+        out = np.zeros((n, self.olen), np.complex64)
+        _check(lib().chz_bank_read(self.eng._h, self.id, ch0, n, out.ctypes.data))
+        return out
+
+    def output_ptr(self):
+        p = _vp()
+        _check(lib().chz_bank_output_device(self.eng._h, self.id, C.byref(p)))
+        return p.value

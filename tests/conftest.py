@@ -15,3 +15,9 @@ def oracle_built():
     import oracle_lib
     oracle_lib.build()
     return oracle_lib
+
+
+def load_pkg():
+    """Import ka9q-radio_amd (hyphenated directory) through the loader in __graft_entry__."""
+    import __graft_entry__ as ge
+    return ge.load()

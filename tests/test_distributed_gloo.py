@@ -1,0 +1,93 @@
+"""world_size-2 gloo test of the multi-GPU orchestration (CPU only).
+
+The sharding / pipelining logic bench.py uses at N > 1 (ka9q-radio_amd/sharding.py) is
+exercised with the oracle standing in for the device kernels: rank 0 "owns the front
+end", the block spectrum is broadcast over gloo, each rank runs its channel shard, and
+the concatenated result must equal the single-process answer.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as ol
+from conftest import load_pkg
+
+L, M, OLEN, P, NCH, NBLK = 11520, 2881, 240, 300, 11, 3
+
+
+def _inputs():
+    rng = np.random.default_rng(2024)
+    x = rng.standard_normal(NBLK * L).astype(np.float32)
+    shifts = [int(s) for s in rng.integers(-7000, 7000, NCH)]
+    resp = [ol.set_filter(P, OLEN, L + M - 1, True, -0.3, 0.3, 11.0) for _ in range(NCH)]
+    return x, shifts, resp
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_pkg()
+    x, shifts, resp = _inputs()
+    first, last = pkg.sharding.shard_channels(NCH, rank, world)
+    bins = (L + M - 1) // 2 + 1
+    slots = [torch.zeros(2 * bins, dtype=torch.float32) for _ in range(4)]
+    stream = ol.Stream(L, M, ol.REAL) if rank == 0 else None
+    outs = {}
+
+    def forward(job):
+        spec = stream.push(x[job * L:(job + 1) * L])
+        slots[job % 4].copy_(torch.from_numpy(spec.view(np.float32)))
+
+    def broadcast(job):
+        return dist.broadcast(slots[job % 4], src=0, async_op=True)
+
+    def channels(job):
+        spec = slots[job % 4].numpy().view(np.complex64)
+        outs[job] = [ol.channel(spec, ol.REAL, P, OLEN, shifts[c], resp[c]) for c in range(first, last)]
+
+    pkg.sharding.pipelined_blocks(range(NBLK), rank == 0, forward, broadcast, channels)
+    q.put((rank, first, last, {j: np.stack(v) if v else np.zeros((0, OLEN), np.complex64) for j, v in outs.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_tile_exactly():
+    pkg = load_pkg()
+    for total in (0, 1, 7, 1024, 8192, 8191):
+        for world in (1, 2, 3, 8):
+            edges = [pkg.sharding.shard_channels(total, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        pkg.sharding.shard_channels(4, 2, 2)
+
+
+def test_two_rank_broadcast_pipeline_matches_single_process(oracle_built):
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results.sort(key=lambda r: r[0])
+    assert results[0][1] == 0 and results[-1][2] == NCH and results[0][2] == results[1][1]
+    x, shifts, resp = _inputs()
+    st = ol.Stream(L, M, ol.REAL)
+    for job in range(NBLK):
+        spec = st.push(x[job * L:(job + 1) * L])
+        want = np.stack([ol.channel(spec, ol.REAL, P, OLEN, shifts[c], resp[c]) for c in range(NCH)])
+        got = np.concatenate([r[3][job] for r in results])
+        np.testing.assert_array_equal(got, want)

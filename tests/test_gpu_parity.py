@@ -1,0 +1,416 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Everything here needs a real MI355X (`-m gpu`).  The HIP path is compared with
+  * oracle/chz_oracle.c carried in float64 (the "exact" answer), and
+  * oracle/_ref = the reference's own filter.c (prebuilt .so travels with the repo)
+on identical seeded / sig_gen inputs.  Tolerances (float32 path):
+per-channel relative L2 <= 1e-5 and max-abs <= 1e-4 x rms of the oracle block; the
+forward spectrum itself is held to relative L2 <= 1e-6.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+REL_L2 = 1e-5
+MAXABS_RMS = 1e-4
+SPEC_REL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_pkg()
+    if p.engine.lib().chz_device_count() < 1:
+        pytest.fail("no HIP device visible: GPU tests cannot run (there is no CPU fallback)")
+    ol.build()
+    return p
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def check_channel(got, want):
+    want = np.asarray(want)
+    rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+    if rms == 0:
+        assert np.abs(got).max() == 0
+        return 0.0
+    e = rel(got, want)
+    assert e <= REL_L2, "relative L2 %g" % e
+    assert np.abs(got - want).max() <= MAXABS_RMS * rms
+    return e
+
+
+# ------------------------------------------------------------------------------
+# forward transform
+# ------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,M,in_type,plan", [
+    (25920, 6481, ol.REAL, ""),               # N = 32400
+    (25920, 6481, ol.REAL, "81x400"),         # two-axis plan
+    (25920, 6481, ol.REAL, "225x144"),        # odd first axis
+    (11520, 2881, ol.REAL, "16x25x36"),       # N = 14400
+    (48000, 12001, ol.COMPLEX, ""),           # config 1: N = 60000 complex
+    (11520, 2881, ol.COMPLEX, "16x25x36"),
+    (1296000, 324001, ol.REAL, ""),           # config 2: N = 1,620,000
+    (2592000, 648001, ol.REAL, ""),           # config 3: N = 3,240,000
+])
+def test_forward_matches_oracle(pkg, L, M, in_type, plan):
+    rng = np.random.default_rng(L + in_type)
+    eng = pkg.engine.Engine(L, M, in_type, plan=plan)
+    st = ol.Stream(L, M, in_type)
+    try:
+        for job in range(3):
+            if in_type == ol.REAL:
+                x = rng.standard_normal(L).astype(np.float32)
+            else:
+                x = (rng.standard_normal(L) + 1j * rng.standard_normal(L)).astype(np.complex64)
+            eng.write(x)
+            eng.forward(job)
+            got = eng.spectrum(job % 4)
+            want = st.push(x, f64=True)
+            assert rel(got, want) <= SPEC_REL, eng.plan
+            # element-wise: no bin may be off by more than a few float32 ulps of the spectrum scale
+            assert np.abs(got - want).max() <= 2e-5 * np.sqrt(np.mean(np.abs(want) ** 2)) * np.sqrt(np.log2(eng.N))
+    finally:
+        eng.close()
+
+
+def test_forward_ring_wraps_over_many_blocks(pkg):
+    # 11 blocks through an 8-block device ring: every window straddles the wrap at some point
+    L, M = 25920, 6481
+    rng = np.random.default_rng(5)
+    eng = pkg.engine.Engine(L, M, ol.REAL)
+    st = ol.Stream(L, M, ol.REAL)
+    try:
+        for job in range(11):
+            x = rng.standard_normal(L).astype(np.float32)
+            eng.write(x)
+            eng.forward(job)
+            assert rel(eng.spectrum(job % 4), st.push(x, f64=True)) <= SPEC_REL, job
+    finally:
+        eng.close()
+
+
+def test_forward_linearity_full_size(pkg):
+    # size-independent property at BASELINE's full size: F(a x + b y) = a F(x) + b F(y)
+    L, M = 2592000, 648001
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(L).astype(np.float32)
+    y = rng.standard_normal(L).astype(np.float32)
+    z = (0.5 * x - 0.25 * y).astype(np.float32)     # exact in float32
+    specs = []
+    for v in (x, y, z):
+        eng = pkg.engine.Engine(L, M, ol.REAL)
+        eng.write(v); eng.forward(0)
+        specs.append(eng.spectrum(0))
+        eng.close()
+    assert rel(specs[2], 0.5 * specs[0] - 0.25 * specs[1]) <= 2e-6
+    # Parseval on the first window (M-1 zeros then x): sum|x|^2 = (|X0|^2 + |X_N/2|^2 + 2 sum|X_k|^2)/N
+    N = L + M - 1
+    X = specs[0].astype(np.complex128)
+    e_f = (abs(X[0]) ** 2 + abs(X[-1]) ** 2 + 2 * np.sum(np.abs(X[1:-1]) ** 2)) / N
+    e_t = float(np.sum(x.astype(np.float64) ** 2))
+    assert abs(e_f - e_t) <= 1e-5 * e_t
+
+
+def test_notch_state_carries_across_blocks(pkg):
+    L, M = 25920, 6481
+    rng = np.random.default_rng(11)
+    eng = pkg.engine.Engine(L, M, ol.REAL)
+    st = ol.Stream(L, M, ol.REAL)
+    bins = [125, 4000, 0]
+    eng.set_notches(bins, 0.01)
+    state = np.zeros(2 * len(bins))
+    try:
+        for job in range(6):
+            x = (rng.standard_normal(L) + 0.3).astype(np.float32)
+            eng.write(x); eng.forward(job)
+            want = st.push(x)
+            ol.notch(state, bins, 0.01, want)
+            got = eng.spectrum(job % 4)
+            for b in bins:
+                assert abs(got[b] - want[b]) <= 2e-6 * abs(want[b]) + 2e-3, (job, b)
+            assert rel(got, want) <= SPEC_REL
+    finally:
+        eng.close()
+
+
+# ------------------------------------------------------------------------------
+# channels
+# ------------------------------------------------------------------------------
+def _mixed_plan(n, fs_in, N, rng):
+    """Config-3 style channel plan: thirds usb / cw / iq (share/presets.conf), P = 300."""
+    kinds = [(50 / 12000, 3000 / 12000), (-200 / 12000, 200 / 12000), (-5000 / 12000, 5000 / 12000)]
+    plan = []
+    for i in range(n):
+        if 1e6 + n * 60e3 < fs_in / 2:       # SURVEY section 8d, config 3 raster
+            f = 1e6 + i * 60e3 + (i % 40)
+        else:                                # same idea scaled to a smaller master
+            f = 0.02 * fs_in + i * (0.46 * fs_in / n) + (i % 40)
+        _, shift, _ = ol.compute_tuning(N, fs_in, f)
+        low, high = kinds[i % 3]
+        plan.append((shift, low, high))
+    return plan
+
+
+@pytest.mark.parametrize("P,olen", [(300, 240), (600, 480), (200, 160), (400, 320), (1200, 960),
+                                    (150, 120), (160, 128), (320, 256), (480, 384), (800, 640), (960, 768)])
+def test_channel_sizes_random_spectrum(pkg, P, olen):
+    # every compiled backward-transform size, random responses, edge + random shifts, both signs
+    L, M = 25920, 6481
+    fa = pkg.filterapi
+    rng = np.random.default_rng(P)
+    master = fa.create_filter_input(L, M, fa.REAL)
+    st = ol.Stream(L, M, ol.REAL)
+    B = master.bins
+    shifts = [0, 1, -1, 5000, -5000, P // 2, -(P // 2), B - 1, -(B - 1), B - P // 2, B + 10, -(B + 10),
+              B + P, -(B + P)] + [int(s) for s in rng.integers(-B - P, B + P, 34)]
+    slaves = []
+    for _ in shifts:
+        s = fa.create_filter_output(master, olen, fa.COMPLEX)
+        assert s is not None and s.points == P
+        fa.set_response(s, (rng.standard_normal(P) + 1j * rng.standard_normal(P)).astype(np.complex64))
+        slaves.append(s)
+    try:
+        for blk in range(2):
+            x = rng.standard_normal(L).astype(np.float32)
+            assert fa.write_rfilter(master, x) == 1
+            spec64 = st.push(x, f64=True)
+            for s, sh in zip(slaves, shifts):
+                assert fa.execute_filter_output(s, sh) == 0
+                check_channel(s.output, ol.channel(spec64, ol.REAL, P, olen, sh, s.response))
+    finally:
+        fa.delete_filter_input(master)
+
+
+def test_complex_master_channels(pkg):
+    # config 1 geometry (2.4 MS/s complex, N = 60000): wrap through DC, both Nyquist seams
+    L, M = 48000, 12001
+    fa = pkg.filterapi
+    rng = np.random.default_rng(21)
+    master = fa.create_filter_input(L, M, fa.COMPLEX)
+    st = ol.Stream(L, M, ol.COMPLEX)
+    B = master.bins
+    shifts = [0, 2500, -2500, B // 2, -(B // 2), B // 2 - 100, -(B // 2) + 100, B // 2 + 100, B - 1, -(B - 1),
+              B, -B, B + 200] + [int(s) for s in rng.integers(-B, B, 30)]
+    slaves = []
+    for _ in shifts:
+        s = fa.create_filter_output(master, 240, fa.COMPLEX)
+        assert fa.set_filter(s, -5000 / 12000, 5000 / 12000, 11.0) == 0
+        slaves.append(s)
+    try:
+        for blk in range(2):
+            x = (rng.standard_normal(L) + 1j * rng.standard_normal(L)).astype(np.complex64)
+            assert fa.write_cfilter(master, x) == 1
+            spec64 = st.push(x, f64=True)
+            for s, sh in zip(slaves, shifts):
+                assert fa.execute_filter_output(s, sh) == 0
+                check_channel(s.output, ol.channel(spec64, ol.COMPLEX, 300, 240, sh, s.response))
+    finally:
+        fa.delete_filter_input(master)
+
+
+def test_bin_centred_carrier_known_answer(pkg):
+    # SURVEY section 8c known answer (1): a cos(2 pi k0 n / N), channel at shift k0, symmetric filter
+    #  -> every output sample = a / sqrt(2); blocks rotate by 2 pi (k0 mod 5) 4/5.
+    L, M = 25920, 6481
+    N = L + M - 1
+    fa = pkg.filterapi
+    master = fa.create_filter_input(L, M, fa.REAL)
+    s = fa.create_filter_output(master, 240, fa.COMPLEX)
+    fa.set_filter(s, -5000 / 12000, 5000 / 12000, 11.0)
+    k0, a = 2501, 0.1
+    n = np.arange(4 * L)
+    x = (a * np.cos(2 * np.pi * k0 * n / N)).astype(np.float32)
+    outs = []
+    try:
+        for blk in range(4):
+            fa.write_rfilter(master, x[blk * L:(blk + 1) * L])
+            fa.execute_filter_output(s, k0)
+            outs.append(s.output.copy())
+        for blk in range(1, 4):          # block 0 still contains the start-up transient
+            assert np.allclose(np.abs(outs[blk]), a / np.sqrt(2), rtol=2e-5)
+            step = outs[blk][0] / outs[blk - 1][0] if blk > 1 else None
+            if step is not None:
+                assert np.angle(step) == pytest.approx(np.angle(np.exp(2j * np.pi * (k0 % 5) * 4 / 5)), abs=1e-4)
+    finally:
+        fa.delete_filter_input(master)
+
+
+def _siggen_run(pkg, L, M, fs, nch, P, olen, nblocks, ref_check, carrier_hz=10.00002e6):
+    """sig_gen input, config-style channel plan; compare with float64 oracle (and the reference)."""
+    fa = pkg.filterapi
+    N = L + M - 1
+    rng = np.random.default_rng(77)
+    master = fa.create_filter_input(L, M, fa.REAL)
+    fa.set_notches(master, [0], 0.01)
+    plan = _mixed_plan(nch, fs, N, rng)
+    slaves = []
+    for shift, low, high in plan:
+        s = fa.create_filter_output(master, olen, fa.COMPLEX)
+        assert fa.set_filter(s, low, high, 11.0) == 0
+        slaves.append(s)
+    gen = ol.SigGen(carrier_hz / fs, 10 ** (-20 / 20), 10 ** (-40 / 20), ol.scale_ad(True, 1), True, seed=1)
+    st = ol.Stream(L, M, ol.REAL)
+    state = np.zeros(2)
+    refm = refc = None
+    if ref_check and ol.have_ref():
+        refm = ol.RefMaster(L, M, ol.REAL)
+        refm.set_notches([0], 0.01)
+        refc = []
+        for (shift, low, high) in plan[:ref_check]:
+            c = refm.channel(olen, ol.COMPLEX)
+            c.set_filter(low, high, 11.0)
+            refc.append(c)
+    worst = 0.0
+    try:
+        for blk in range(nblocks):
+            x = gen.generate(L)
+            assert fa.write_rfilter(master, x) == 1
+            spec64 = st.push(x, f64=True)
+            dc = spec64[:1].astype(np.complex64)
+            ol.notch(state, [0], 0.01, dc)
+            spec64[0] = dc[0]
+            if refm is not None:
+                refm.write(x)
+            for i, (s, (shift, low, high)) in enumerate(zip(slaves, plan)):
+                assert fa.execute_filter_output(s, shift) == 0
+                worst = max(worst, check_channel(s.output, ol.channel(spec64, ol.REAL, P, olen, shift, s.response)))
+                if refc is not None and i < len(refc):
+                    # against the reference's own float32 pipeline: both sit ~1e-7 from the exact answer
+                    want = refc[i].execute(shift)
+                    assert rel(s.output, want) <= REL_L2
+                    assert np.abs(refc[i].response() - s.response).max() <= 2e-7 * np.abs(s.response).max()
+    finally:
+        fa.delete_filter_input(master)
+        if refm is not None:
+            refm.close()
+    return worst
+
+
+def test_siggen_scaled_down_vs_reference(pkg):
+    # 1.296 MS/s real (RX888 geometry / 100): N = 32400, 48 channels, every one checked against the
+    # reference's own filter.c as well as the float64 oracle
+    _siggen_run(pkg, 25920, 6481, 1.296e6, 48, 300, 240, 4, ref_check=48, carrier_hz=100020.0)
+
+
+def test_siggen_config2_halfrate_256_channels(pkg):
+    # BASELINE config 2: 64.8 MS/s real, 256 x 12 kHz channels (P = 300)
+    w = _siggen_run(pkg, 1296000, 324001, 64.8e6, 256, 300, 240, 2, ref_check=8)
+    assert w <= REL_L2
+
+
+def test_siggen_config3_fullrate_1024_channels(pkg):
+    # BASELINE config 3: 129.6 MS/s real, 1024 mixed usb/cw/iq channels (P = 300)
+    w = _siggen_run(pkg, 2592000, 648001, 129.6e6, 1024, 300, 240, 2, ref_check=8)
+    assert w <= REL_L2
+
+
+def test_config4_style_p600(pkg):
+    # BASELINE config 4 per-GPU share: 1024 x 24 kHz channels (P = 600) at 129.6 MS/s
+    L, M, fs = 2592000, 648001, 129.6e6
+    fa = pkg.filterapi
+    N = L + M - 1
+    master = fa.create_filter_input(L, M, fa.REAL)
+    gen = ol.SigGen(10.00002e6 / fs, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    st = ol.Stream(L, M, ol.REAL)
+    slaves, shifts = [], []
+    for i in range(1024):
+        s = fa.create_filter_output(master, 480, fa.COMPLEX)
+        fa.set_filter(s, -10000 / 24000, 10000 / 24000, 11.0)
+        slaves.append(s)
+        shifts.append(ol.compute_tuning(N, fs, 0.5e6 + i * 7.8e3)[1])
+    try:
+        x = gen.generate(L)
+        fa.write_rfilter(master, x)
+        spec64 = st.push(x, f64=True)
+        for s, sh in zip(slaves, shifts):
+            fa.execute_filter_output(s, sh)
+        for i in list(range(0, 1024, 37)) + [1023]:
+            check_channel(slaves[i].output, ol.channel(spec64, ol.REAL, 600, 480, shifts[i], slaves[i].response))
+    finally:
+        fa.delete_filter_input(master)
+
+
+# ------------------------------------------------------------------------------
+# filter.h semantics of the host mirror
+# ------------------------------------------------------------------------------
+def test_api_errors_and_drop_semantics(pkg):
+    fa = pkg.filterapi
+    assert fa.create_filter_input(25920, 6481, fa.SPECTRUM) is None        # src/filter.c:228-230
+    assert fa.create_filter_input(1, 1, fa.REAL) is None                   # bins < 2 (:198-199)
+    master = fa.create_filter_input(25920, 6481, fa.REAL)
+    assert fa.create_filter_input(25920, 6481, fa.REAL, master=master) is master   # idempotent (:191-192)
+    assert fa.create_filter_output(master, 250, fa.COMPLEX) is None        # 250*32400 % 25920 != 0 (:313-316)
+    assert fa.create_filter_output(None, 240, fa.COMPLEX) is None
+    s = fa.create_filter_output(master, 240, fa.COMPLEX)
+    spec = fa.create_filter_output(master, 0, fa.SPECTRUM)
+    assert spec is not None
+    assert fa.set_filter(None, 0.1, 0.2, 11.0) == -1                        # (:969-970)
+    assert fa.set_filter(s, float("nan"), 0.2, 11.0) == -1
+    assert fa.execute_filter_output(None, 0) == -1
+    x = np.random.default_rng(1).standard_normal(25920).astype(np.float32)
+    assert fa.write_rfilter(master, x[:1000]) == 0                           # no full block yet
+    assert fa.write_rfilter(master, x[1000:]) == 1
+    # response not set yet: returns 0 without touching the output (:715-718)
+    assert fa.execute_filter_output(s, 100) == 0 and s.output is None
+    assert fa.set_filter(s, -0.4, 0.4, 11.0) == 0
+    assert fa.execute_filter_output(spec, 0) == 0 and spec.next_jobnum == 1   # block clock only
+    # fall ND blocks behind -> zeros + block_drops (:690-701)
+    for _ in range(5):
+        fa.write_rfilter(master, x)
+    assert fa.execute_filter_output(s, 100) == 0
+    assert s.block_drops == 1 and not s.output.any()
+    assert fa.write_rfilter(master, np.zeros(25920 * 9, np.float32)) == -1   # overrun guard (:1117-1118)
+    fa.delete_filter_output(s)
+    fa.delete_filter_input(master)
+    assert master.init is False
+
+
+def test_retune_and_new_filter_between_blocks(pkg):
+    # a shift change or set_filter between blocks must take effect on the next execute
+    L, M = 25920, 6481
+    fa = pkg.filterapi
+    rng = np.random.default_rng(31)
+    master = fa.create_filter_input(L, M, fa.REAL)
+    st = ol.Stream(L, M, ol.REAL)
+    a = fa.create_filter_output(master, 240, fa.COMPLEX)
+    b = fa.create_filter_output(master, 240, fa.COMPLEX)
+    fa.set_filter(a, -0.4, 0.4, 11.0); fa.set_filter(b, 0.01, 0.25, 11.0)
+    try:
+        for blk, (sa, sb) in enumerate([(1000, 2000), (1000, 2000), (1500, 2000), (1500, -2000)]):
+            x = rng.standard_normal(L).astype(np.float32)
+            fa.write_rfilter(master, x)
+            spec64 = st.push(x, f64=True)
+            if blk == 3:
+                fa.set_filter(a, -0.1, 0.1, 5.0)
+            fa.execute_filter_output(a, sa); fa.execute_filter_output(b, sb)
+            check_channel(a.output, ol.channel(spec64, ol.REAL, 300, 240, sa, a.response))
+            check_channel(b.output, ol.channel(spec64, ol.REAL, 300, 240, sb, b.response))
+    finally:
+        fa.delete_filter_input(master)
+
+
+def test_run_blocks_graph_equals_eager(pkg):
+    # the hipGraph replay of a ring cycle must produce exactly what eager launches produce
+    L, M = 25920, 6481
+    rng = np.random.default_rng(41)
+    outs = []
+    for graph in (False, True):
+        eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+        bank = eng.bank(300, 240, 16)
+        bank.set_responses(0, (np.random.default_rng(3).standard_normal((16, 300)) + 0j).astype(np.complex64))
+        bank.set_shifts(0, np.arange(16) * 700 + 200)
+        bank.set_active(16)
+        x = np.random.default_rng(4).standard_normal(8 * L).astype(np.float32)
+        eng.write(x[:8 * L - (M - 1)])     # fill the ring exactly once (write position starts at M-1)
+        t = eng.run_blocks(0, 16, graph=graph)
+        assert t.blocks == 16 and t.total_ms > 0
+        outs.append((eng.spectrum(3), bank.read(0, 16)))
+        eng.close()
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])

@@ -1,0 +1,120 @@
+"""CPU-only checks of the host logic and of the C-ABI library itself (no GPU compute)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import load_pkg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as ge
+    if not os.path.exists(os.path.join(ROOT, "ka9q-radio_amd", "libchz_hip.so")):
+        ge.build()
+    ol.build()
+    return load_pkg()
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    # every function include/chz_engine.h declares must be exported by libchz_hip.so
+    hdr = open(os.path.join(ROOT, "include", "chz_engine.h")).read()
+    declared = set(re.findall(r"\b(chz_[a-z_0-9]+)\s*\(", hdr))
+    declared -= {"chz_engine", "chz_info", "chz_timing"}
+    assert declared == set(pkg.engine.SYMBOLS)
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.engine.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (chz_[a-z_0-9]+)", out))
+    assert declared <= exported, declared - exported
+    lib = ctypes.CDLL(pkg.engine.LIB_PATH)
+    for s in declared:
+        getattr(lib, s)
+
+
+def test_no_gpu_means_loud_failure_not_fallback(pkg):
+    if pkg.engine.lib().chz_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(pkg.engine.ChzError) as ei:
+        pkg.engine.Engine(25920, 6481, pkg.engine.REAL)
+    assert "no HIP device" in str(ei.value) or "fallback" in str(ei.value)
+    assert pkg.filterapi.create_filter_input(25920, 6481, pkg.filterapi.SPECTRUM) is None
+
+
+def test_product_code_never_touches_the_oracle():
+    # the shipped path must not import / link / dlopen anything under oracle/
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ka9q-radio_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".c", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in txt and "liboracle" not in txt and "libka9q_ref" not in txt, f
+                assert not re.search(r'#include\s+"[^"]*oracle', txt), f
+
+
+@pytest.mark.parametrize("P,olen,N,real", [(300, 240, 3240000, True), (600, 480, 3240000, True),
+                                           (300, 240, 60000, False), (1200, 960, 1620000, True)])
+def test_design_response_matches_oracle(pkg, P, olen, N, real):
+    fa = pkg.filterapi
+    for low, high, beta in [(-5000 / 12000, 5000 / 12000, 11.0), (50 / 12000, 3000 / 12000, 11.0),
+                            (-200 / 12000, 200 / 12000, 3.0), (0.3, -0.7, 6.0), (0.1, 0.1, 11.0), (-0.5, 0.5, 0.0)]:
+        got = fa.design_response(P, olen, N, real, low, high, beta)
+        want = ol.set_filter(P, olen, N, real, low, high, beta)
+        assert np.abs(got - want).max() <= 3e-7 * np.abs(want).max()
+    w = fa.make_kaiserf(61, 11.0)
+    ref = np.zeros(61, np.float32)
+    ol.oracle().chzo_make_kaiser(ref.ctypes.data, 61, 11.0)
+    np.testing.assert_array_equal(w, ref)
+
+
+def _expand(desc, P):
+    t0, cnt, src0, dirn, conj, wrap = desc
+    m = np.full(P, -1, np.int64)
+    for t in range(t0, t0 + cnt):
+        s = src0 + dirn * (t - t0)
+        if wrap and s >= wrap:
+            s -= wrap
+        m[t] = s
+    return m, conj
+
+
+@pytest.mark.parametrize("in_type,B", [(ol.REAL, 16201), (ol.REAL, 1620001), (ol.COMPLEX, 6000), (ol.COMPLEX, 6001)])
+@pytest.mark.parametrize("P", [20, 300, 301, 600])
+def test_gather_descriptor_equals_reference_walk(pkg, in_type, B, P):
+    # the closed-form descriptor the kernel consumes == the oracle's restated index walk
+    rng = np.random.default_rng(B + P)
+    k = np.arange(B)
+    spec = ((k + 1) + 1j * (k + 1)).astype(np.complex64) if B < 2 ** 22 else None
+    if spec is None:
+        pytest.skip("index-coded spectrum too large for float32")
+    ones = np.ones(P, np.complex64)
+    h = (B + 1) // 2
+    shifts = [0, 1, -1, P // 2, -(P // 2), P // 2 + 1, B - 1, -(B - 1), B, -B, B + P, -(B + P), h, -h, h - 1, -h + 1,
+              h + 1, -h - 1, h - P // 2, -(h - P // 2), B - P // 2, -(B - P // 2), 2 * B, -2 * B]
+    shifts += [int(s) for s in rng.integers(-B - P, B + P, 200)]
+    for sh in shifts:
+        d = pkg.engine.gather_descriptor(in_type, B, P, sh)
+        m, conj = _expand(d, P)
+        fd = ol.gather(spec, in_type, P, sh, ones)            # FFT order
+        # undo the oracle's "Nyquist bin forced to zero" for the comparison of pure index maps
+        order = [((P + 1) // 2 + t) % P for t in range(P)]
+        got = np.zeros(P, np.complex64)
+        for t in range(P):
+            if m[t] >= 0:
+                v = spec[m[t]]
+                got[order[t]] = np.conj(v) if conj else v
+        got[(P + 1) // 2] = 0
+        assert np.array_equal(got, fd), (in_type, B, P, sh, d)
+
+
+def test_plan_builder_covers_baseline_sizes(pkg):
+    # no GPU needed: descriptor helper lives in the library, plan strings are checked on the GPU;
+    # here: every per-channel size the reference documents has a compiled kernel (docs/FFTW3.md:51-68)
+    src = open(os.path.join(ROOT, "ka9q-radio_amd", "csrc", "chz_plan.h")).read()
+    menu = re.search(r"#define CHZ_CHAN_MENU\(X\)(.*?)\n\n", src, re.S).group(1)
+    sizes = {int(a) * int(b) for a, b in re.findall(r"X\((\d+),\s*(\d+)\)", menu)}
+    for p in (150, 160, 200, 300, 320, 400, 480, 600, 800, 960, 1200):
+        assert p in sizes
