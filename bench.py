@@ -213,8 +213,7 @@ def main():
         it = eng_t.run_blocks(0, min(args.steps, 200), graph=False, instrument=True)
         kern = {}
         for name, ms, n in (("fwd_first_real", it.first_ms, it.first_n), ("fwd_cols", it.cols_ms, it.cols_n),
-                            ("fwd_rows", it.rows_ms, it.rows_n), ("notch_bins", it.notch_ms, it.notch_n),
-                            ("chan_ifft", it.chan_ms, it.chan_n)):
+                            ("fwd_rows", it.rows_ms, it.rows_n), ("chan_ifft", it.chan_ms, it.chan_n)):
             if n:
                 kern[name] = ms / n * 1e3       # microseconds per launch
         Ra = eng.axes[0] // 2 + 1

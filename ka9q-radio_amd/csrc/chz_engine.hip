@@ -194,14 +194,16 @@ int chz_input_ring(chz_engine* e, float** dev_ring, long* ring_len_floats) {
 // ---- kernel launches ---------------------------------------------------------
 struct Instr {      // optional per-kernel HIP-event instrumentation
   bool on = false;
-  std::vector<hipEvent_t> ev;   // pairs
+  std::vector<hipEvent_t> ev;   // kind.size() + 1 boundaries
   std::vector<int> kind;        // 0 first, 1 cols, 2 rows, 3 notch, 4 chan
 };
+// One event per kernel boundary: kernel i's time = event[i+1] - event[i], so back-to-back
+// kernels are separated by a single event packet, not two.
 static void mark(Instr* in, hipStream_t s, int kind, bool begin) {
   if (!in || !in->on) return;
+  if (begin) { in->kind.push_back(kind); if (!in->ev.empty()) return; }
   hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s);
   in->ev.push_back(e);
-  if (begin) in->kind.push_back(kind);
 }
 
 static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
@@ -235,15 +237,10 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
   RowsParams c{};
   c.buf = e->buf; c.spec = e->spec[slot]; c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3;
   c.padg = p.padg3; c.N = p.N; c.mirror = e->in_type == CHZ_REAL; c.tw_sub = e->tw_sub_c;
+  c.n_notch = e->n_notch; c.notch_bins = e->notch_bins; c.notch_state = e->notch_state; c.notch_alpha = e->notch_alpha;
   mark(in, e->stream, 2, true);
   if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, e->stream, c)) return fail(-4, "no kernel for axis c");
   mark(in, e->stream, 2, false);
-  if (e->n_notch > 0) {
-    NotchParams q{e->spec[slot], e->notch_bins, e->notch_state, e->n_notch, e->notch_alpha};
-    mark(in, e->stream, 3, true);
-    launch_notch(e->n_notch, e->stream, q);
-    mark(in, e->stream, 3, false);
-  }
   return 0;
 }
 
@@ -438,7 +435,7 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
     double* acc[5] = {&timing->first_ms, &timing->cols_ms, &timing->rows_ms, &timing->notch_ms, &timing->chan_ms};
     int* cnt[5] = {&timing->first_n, &timing->cols_n, &timing->rows_n, &timing->notch_n, &timing->chan_n};
     for (size_t i = 0; i < in.kind.size(); i++) {
-      float k = 0; hipEventElapsedTime(&k, in.ev[2 * i], in.ev[2 * i + 1]);
+      float k = 0; hipEventElapsedTime(&k, in.ev[i], in.ev[i + 1]);
       *acc[in.kind[i]] += k; *cnt[in.kind[i]] += 1;
     }
   }

@@ -2,10 +2,10 @@
 //
 // What the reference does on CPU threads with FFTW3 (src/filter.c):
 //   K1  forward transform of the N-sample window          src/filter.c:505-508,573-582
-//   K2  spur notches on a handful of bins                  src/filter.c:464-474
+//   K2  spur notches on a handful of bins                  src/filter.c:464-474 (fused into fwd_rows)
 //   K3  per-channel bin gather x frequency response        src/filter.c:728-911
 //   K4  per-channel small backward transform, keep olen    src/filter.c:914, :357
-// is done here by five kernels.  The large transform is a three-axis Cooley-Tukey
+// is done here by four kernels.  The large transform is a three-axis Cooley-Tukey
 // decomposition N = Na*Nb*Nc (n = na*Nb*Nc + nb*Nc + nc, k = ka + Na*kb + Na*Nb*kc):
 //
 //   fwd_first_real   axis a.  Real input: two adjacent real columns travel as one
@@ -72,14 +72,12 @@ struct RowsParams {
   long N;                 // full transform length
   int mirror;             // 1: real master (bins N/2+1, conj-mirror store); 0: complex master
   const float2* tw_sub;   // [R2][R1] W_Nc^(j*k1)
-};
-
-struct NotchParams {
-  float2* spec;
-  const int* bins;        // n entries
-  double* state;          // 2 doubles per entry, persistent across blocks
-  int n;
-  double alpha;
+  // spur notches (src/filter.c:464-474), applied to the owning lane's register just before
+  // the store; state is float64 and persists on the device across blocks
+  int n_notch;
+  const int* notch_bins;  // n_notch bin indices
+  double* notch_state;    // 2 doubles per entry
+  double notch_alpha;
 };
 
 // One channel's gather, precomputed on the host from `shift`
@@ -152,19 +150,36 @@ __global__ void fwd_first_real(FirstRealParams p) {
   __syncthreads();
   // split + twiddle + store:  real column 2p   -> (Z[k] + conj Z[Na-k]) / 2
   //                           real column 2p+1 -> (Z[k] - conj Z[Na-k]) / 2i
+  // One lane owns one output column cc and walks the rows; the LDS reads and the two
+  // table loads of EPI_U rows are issued together so their latencies overlap.
+  constexpr int EPI_U = 4;
   const int W2 = 2 * T;
-  const int total = p.Ra * W2;
-  for (int idx = tid; idx < total; idx += nthr) {
-    const int k = idx / W2, cc = idx - k * W2;
-    const int pc = cc >> 1;
-    const float2 a = lds[k * T + pc];
-    const int km = (k == 0) ? 0 : NA - k;
-    const float2 b = lds[km * T + pc];
-    float2 d;
-    if (cc & 1) d = make_float2(a.x - b.x, a.y + b.y);   // a - conj(b)
-    else        d = make_float2(a.x + b.x, a.y - b.y);   // a + conj(b)
-    const float2 w = cmul(p.tw_tile[tile * p.Ra + k], p.tw_col[k * W2 + cc]);
-    p.buf[(long)k * p.inner + 2 * c0 + cc] = cmul(d, w);
+  const int rpi = nthr / W2;                     // rows covered per sweep
+  const int kr = tid / W2, cc = tid - kr * W2;
+  const int pc = cc >> 1;
+  const bool odd = cc & 1;
+  const bool lane_on = kr < rpi;
+  for (int k0 = kr; k0 < p.Ra; k0 += rpi * EPI_U) {
+    float2 a[EPI_U], b[EPI_U], w1[EPI_U], w2[EPI_U];
+    static_for<EPI_U>([&](auto u) {
+      constexpr int U = decltype(u)::value;
+      const int k = k0 + U * rpi;
+      const int kk = (lane_on && k < p.Ra) ? k : 0;
+      a[U] = lds[kk * T + pc];
+      b[U] = lds[(kk == 0 ? 0 : NA - kk) * T + pc];
+      w1[U] = p.tw_tile[tile * p.Ra + kk];
+      w2[U] = p.tw_col[kk * W2 + cc];
+    });
+    static_for<EPI_U>([&](auto u) {
+      constexpr int U = decltype(u)::value;
+      const int k = k0 + U * rpi;
+      if (lane_on && k < p.Ra) {
+        float2 d;
+        if (odd) d = make_float2(a[U].x - b[U].x, a[U].y + b[U].y);   // a - conj(b)
+        else     d = make_float2(a[U].x + b[U].x, a[U].y - b[U].y);   // a + conj(b)
+        p.buf[(long)k * p.inner + 2 * c0 + cc] = cmul(d, cmul(w1[U], w2[U]));
+      }
+    });
   }
 }
 
@@ -231,13 +246,24 @@ __global__ void fwd_rows(RowsParams p) {
   const int a0 = at * Ta;
   const long rowstride = (long)p.Nb * NC;
 
-  // coalesced row loads, transposed into LDS as [nc][r]
-  for (int e = tid; e < Ta * NC; e += nthr) {
-    const int r = e / NC, nc = e - r * NC;
-    const int ka = a0 + r;
-    float2 x = make_float2(0.f, 0.f);
-    if (ka < p.Ra) x = p.buf[(long)ka * rowstride + (long)kb * NC + nc];
-    lds[nc * ld + (nc / R2) * padg + r] = x;
+  // coalesced row loads, transposed into LDS as [nc][r]; LOAD_U loads are in flight per lane
+  constexpr int LOAD_U = 6;
+  for (int e0 = tid; e0 < Ta * NC; e0 += nthr * LOAD_U) {
+    float2 x[LOAD_U];
+    static_for<LOAD_U>([&](auto u) {
+      constexpr int U = decltype(u)::value;
+      const int e = e0 + U * nthr;
+      const int r = e / NC, nc = e - r * NC;
+      const int ka = a0 + r;
+      x[U] = make_float2(0.f, 0.f);
+      if (e < Ta * NC && ka < p.Ra) x[U] = p.buf[(long)ka * rowstride + (long)kb * NC + nc];
+    });
+    static_for<LOAD_U>([&](auto u) {
+      constexpr int U = decltype(u)::value;
+      const int e = e0 + U * nthr;
+      const int r = e / NC, nc = e - r * NC;
+      if (e < Ta * NC) lds[nc * ld + (nc / R2) * padg + r] = x[U];
+    });
   }
   __syncthreads();
   if (tid < R2 * Ta) {
@@ -266,6 +292,29 @@ __global__ void fwd_rows(RowsParams p) {
       u[J] = lds[(k1 * R2 + J) * ld + k1 * padg + r];
     });
     reg_dft<R2, -1>(u);
+    for (int i = 0; i < p.n_notch; i++) {          // uniform trip count, normally 1 (DC) .. 21
+      const int b = p.notch_bins[i];
+      long k = b; bool mir = false;
+      int qa = (int)(k % p.Na);
+      if (p.mirror && 2 * qa > p.Na) { k = p.N - b; qa = (int)(k % p.Na); mir = true; }
+      const long rest = k / p.Na;
+      const int qb = (int)(rest % p.Nb), qc = (int)(rest / p.Nb);
+      if (qb == kb && qa == ka && (qc % R1) == k1) {  // this lane holds the bin
+        const int q2 = qc / R1;
+        static_for<R2>([&](auto k2) {
+          constexpr int K2 = decltype(k2)::value;
+          if (K2 == q2) {
+            float2 x = mir ? cconj(u[K2]) : u[K2];
+            double sr = p.notch_state[2 * i], si = p.notch_state[2 * i + 1];
+            sr += p.notch_alpha * ((double)x.x - sr);
+            si += p.notch_alpha * ((double)x.y - si);
+            p.notch_state[2 * i] = sr; p.notch_state[2 * i + 1] = si;
+            x = make_float2((float)((double)x.x - sr), (float)((double)x.y - si));
+            u[K2] = mir ? cconj(x) : x;
+          }
+        });
+      }
+    }
     if (ka < p.Ra) {
       const bool selfconj = (ka == 0) || (2 * ka == p.Na);
       const long half = p.N >> 1;
@@ -277,22 +326,6 @@ __global__ void fwd_rows(RowsParams p) {
       });
     }
   }
-}
-
-// ------------------------------------------------------------------------------
-// K2: spur notches (src/filter.c:464-474).  One lane per listed bin; state is
-// float64 and lives on the device across blocks.
-// ------------------------------------------------------------------------------
-__global__ void notch_bins(NotchParams p) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.n) return;
-  const int b = p.bins[i];
-  float2 x = p.spec[b];
-  double sr = p.state[2 * i], si = p.state[2 * i + 1];
-  sr += p.alpha * ((double)x.x - sr);
-  si += p.alpha * ((double)x.y - si);
-  p.state[2 * i] = sr; p.state[2 * i + 1] = si;
-  p.spec[b] = make_float2((float)((double)x.x - sr), (float)((double)x.y - si));
 }
 
 // ------------------------------------------------------------------------------

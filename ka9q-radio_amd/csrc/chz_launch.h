@@ -31,8 +31,4 @@ inline int launch_chan(Radix2 r, int grid, int block, size_t lds, hipStream_t s,
 #undef X
   return -1;
 }
-inline void launch_notch(int n, hipStream_t s, const NotchParams& p) {
-  hipLaunchKernelGGL(notch_bins, dim3((n + 63) / 64), dim3(64), 0, s, p);
-}
-
 }  // namespace chz

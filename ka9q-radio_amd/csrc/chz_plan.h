@@ -238,7 +238,7 @@ inline bool build_fwd_plan(int N, int in_type, const char* spec, FwdPlan& out) {
 
 // ---- channel banks -------------------------------------------------------------
 struct ChanGeom {
-  int P = 0; Radix2 r{}; int lpc = 0, cpw = 0, wpb = 4;
+  int P = 0; Radix2 r{}; int lpc = 0, cpw = 0, wpb = 1;
   size_t lds = 0;
   std::vector<f2> tw_sub;   // backward sign
 };
@@ -247,7 +247,7 @@ inline bool build_chan_geom(int P, ChanGeom& g) {
   g.P = P;
   g.lpc = g.r.r1 > g.r.r2 ? g.r.r1 : g.r.r2;
   g.cpw = 64 / g.lpc;
-  g.wpb = 4;
+  g.wpb = 1;                                   // one wavefront per workgroup: most workgroups, no barrier partners
   g.lds = sizeof(f2) * (size_t)g.wpb * g.cpw * g.r.r1 * (g.r.r2 + 1);
   g.tw_sub = make_tw_sub(g.r.r1, g.r.r2, +1);
   return true;

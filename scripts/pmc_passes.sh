@@ -1,0 +1,14 @@
+#!/bin/bash
+# Collect rocprofv3 counters for the bench's kernels, one --pmc set per pass (never combined
+# with trace domains), results under gpurun_out/pmc_<tag>/.   usage: scripts/pmc_passes.sh <tag> [bench args...]
+TAG=$1; shift
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+run() { name=$1; shift; rocprofv3 --pmc "$@" -f csv -d $R/gpurun_out/pmc_$TAG/$name -o $name -- python $R/bench.py --steps 160 --warmup 16 --eager --no-cpu-baseline $BENCH_ARGS > $R/gpurun_out/pmc_$TAG/$name.log 2>&1; }
+mkdir -p $R/gpurun_out/pmc_$TAG
+BENCH_ARGS="$@"
+run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run tcc TCC_HIT_sum TCC_MISS_sum

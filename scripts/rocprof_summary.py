@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 output (rocpd sqlite .db from --kernel-trace, or the csv files of a --pmc pass)
+into the small text tables committed under profiles/.   usage: rocprof_summary.py <dir-or-db> [...]"""
+import csv, glob, os, sqlite3, sys
+from collections import defaultdict
+
+def short(n):
+    return n.replace("void chz::", "").replace("chz::", "").split("(")[0]
+
+def db_summary(path):
+    con = sqlite3.connect(path)
+    rows = list(con.execute("select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start), "
+                            "max(grid_x), max(workgroup_x), max(vgpr_count), max(lds_size) from kernels group by name order by 6 desc"))
+    tot = sum(r[5] for r in rows)
+    print("# %s" % path)
+    print("%-28s %7s %9s %9s %9s %6s %9s %6s %5s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct", "grid", "wg", "vgpr", "lds_B"))
+    for r in rows:
+        print("%-28s %7d %9.2f %9.2f %9.2f %6.1f %9d %6d %5d %7d" % (short(r[0])[:28], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3,
+                                                                   100.0 * r[5] / tot, r[6], r[7], r[8], r[9]))
+
+def csv_summary(d):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(int))
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"]); c = row["Counter_Name"]
+            acc[k][c] += float(row["Counter_Value"]); cnt[k][c] += 1
+    print("# %s (per-dispatch averages)" % d)
+    for k in sorted(acc):
+        print(k)
+        for c in sorted(acc[k]):
+            print("    %-24s %16.1f   (n=%d)" % (c, acc[k][c] / cnt[k][c], cnt[k][c]))
+
+for a in sys.argv[1:]:
+    if a.endswith(".db"):
+        db_summary(a)
+    elif os.path.isdir(a):
+        dbs = glob.glob(os.path.join(a, "**", "*.db"), recursive=True)
+        if dbs and not glob.glob(os.path.join(a, "**", "*counter_collection.csv"), recursive=True):
+            for d in dbs: db_summary(d)
+        else:
+            csv_summary(a)

@@ -16,7 +16,8 @@ extern "C" {
 
 // ring: input ring on the host (floats for REAL, float pairs for COMPLEX); ring_len in floats
 int emu_forward(const float* ring, long ring_len, long start, int N, int in_type, const char* spec,
-                float* spectrum, char* desc, int desc_len) {
+                float* spectrum, char* desc, int desc_len,
+                const int* notch_bins, double* notch_state, int n_notch, double notch_alpha) {
   FwdPlan p;
   if (!build_fwd_plan(N, in_type, spec, p)) return -1;
   if (desc) { strncpy(desc, p.desc.c_str(), (size_t)desc_len - 1); desc[desc_len - 1] = 0; }
@@ -45,6 +46,7 @@ int emu_forward(const float* ring, long ring_len, long start, int N, int in_type
   c.buf = buf.data(); c.spec = reinterpret_cast<float2*>(spectrum);
   c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3; c.padg = p.padg3; c.N = p.N;
   c.mirror = in_type == CHZ_IN_REAL; c.tw_sub = F2(p.tw_sub_c);
+  c.n_notch = n_notch; c.notch_bins = notch_bins; c.notch_state = notch_state; c.notch_alpha = notch_alpha;
   if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, nullptr, c)) return -4;
   return 0;
 }
@@ -71,12 +73,6 @@ int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, in
   const int per_block = g.wpb * g.cpw;
   const int grid = (nch + per_block - 1) / per_block;
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
-}
-
-int emu_notch(float* spec, const int* bins, double* state, int n, double alpha) {
-  NotchParams q{reinterpret_cast<float2*>(spec), bins, state, n, alpha};
-  launch_notch(n, nullptr, q);
-  return 0;
 }
 
 }  // extern "C"

@@ -28,9 +28,9 @@ def emu(oracle_built):
         subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I", EMU_DIR, "-I", CSRC,
                         srcs[0], "-o", so], check=True)
     lib = C.CDLL(so)
-    lib.emu_forward.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_int]
+    lib.emu_forward.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_int, C.c_double]
     lib.emu_channels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-    lib.emu_notch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double]
     return lib
 
 
@@ -53,7 +53,7 @@ def test_forward_kernels(emu, N, in_type, spec, start):
     bins = N // 2 + 1 if in_type == ol.REAL else N
     out = np.zeros(bins, np.complex64)
     desc = C.create_string_buffer(256)
-    assert emu.emu_forward(ring.ctypes.data, ring_len, start, N, in_type, spec, out.ctypes.data, desc, 256) == 0
+    assert emu.emu_forward(ring.ctypes.data, ring_len, start, N, in_type, spec, out.ctypes.data, desc, 256, None, None, 0, 0.0) == 0
     want = ol.forward(win if in_type == ol.REAL else win.view(np.complex64), in_type, f64=True)
     assert rel(out, want) < 5e-7, desc.value
 
@@ -82,14 +82,23 @@ def test_channel_kernel(emu, in_type, B, P, olen):
             assert rel(out[i], want) < 1e-6, (s, i)
 
 
-def test_notch_kernel(emu):
-    rng = np.random.default_rng(3)
-    spec = (rng.standard_normal(500) + 1j * rng.standard_normal(500)).astype(np.complex64)
-    want = spec.copy()
-    bins = np.array([17, 400, 0], np.int32)
-    st_a, st_b = np.zeros(6), np.zeros(6)
-    for _ in range(3):
-        emu.emu_notch(spec.ctypes.data, bins.ctypes.data, st_a.ctypes.data, 3, 0.01)
-        ol.notch(st_b, bins, 0.01, want)
-    np.testing.assert_allclose(st_a, st_b, rtol=1e-12)
-    np.testing.assert_array_equal(spec, want)
+@pytest.mark.parametrize("N,in_type,spec", [(32400, ol.REAL, b""), (14400, ol.REAL, b"36x400"), (14400, ol.COMPLEX, b"")])
+def test_fused_notch(emu, N, in_type, spec):
+    # notches ride in the last forward kernel: direct bins, mirrored bins, DC, Nyquist; state persists
+    rng = np.random.default_rng(N)
+    per = 1 if in_type == ol.REAL else 2
+    bins_n = N // 2 + 1 if in_type == ol.REAL else N
+    nb = np.array([17, 4001, 5000, 123, bins_n - 1, bins_n // 2 + 7, 0], np.int32)
+    st_a, st_b = np.zeros(2 * len(nb)), np.zeros(2 * len(nb))
+    desc = C.create_string_buffer(256)
+    for blk in range(3):
+        ring = (rng.standard_normal(N * per) + 0.25).astype(np.float32)
+        out = np.zeros(bins_n, np.complex64)
+        assert emu.emu_forward(ring.ctypes.data, N * per, 0, N, in_type, spec, out.ctypes.data, desc, 256,
+                               nb.ctypes.data, st_a.ctypes.data, len(nb), 0.01) == 0
+        want = ol.forward(ring if in_type == ol.REAL else ring.view(np.complex64), in_type)
+        ol.notch(st_b, nb, 0.01, want)
+        assert rel(out, want) < 5e-7
+        for b in nb:
+            assert abs(out[b] - want[b]) <= 3e-6 * abs(want[b]) + 2e-3
+    np.testing.assert_allclose(st_a, st_b, rtol=1e-4, atol=1e-2)
