@@ -37,7 +37,7 @@ def run(L,M,fs,nch):
             fa.execute_filter_output(s,p[0])
             want=ol.channel(spec64,ol.REAL,300,240,p[0],s.response)
             nr=np.linalg.norm(want); rmsl.append(nr/np.sqrt(240))
-            fl=2e-6*np.sqrt(np.mean(abs(spec64)**2))*np.linalg.norm(s.response); mar.append((np.linalg.norm(s.output-want)/np.sqrt(240))/(1e-5*nr/np.sqrt(240)+fl))
+            fl=2e-8*np.abs(spec64).max()*np.linalg.norm(s.response); mar.append((np.linalg.norm(s.output-want)/np.sqrt(240))/(1e-5*nr/np.sqrt(240)+fl))
             eg.append(np.linalg.norm(s.output-want)/nr); e0.append(np.linalg.norm(res[0][b][i]-want)/nr); e1.append(np.linalg.norm(res[1][b][i]-want)/nr)
     eg,e0,e1,rmsl=map(np.array,(eg,e0,e1,rmsl))
     for name,e in (('gpu',eg),('ref f64fft',e0),('ref f32fft',e1)):

@@ -18,11 +18,15 @@ pytestmark = pytest.mark.gpu
 REL_L2 = 1e-5          # per-channel relative L2
 MAXABS_RMS = 1e-4      # per-channel max-abs, in units of the oracle block's rms
 SPEC_REL = 1e-6        # forward spectrum relative L2
-# float32 dynamic-range floor: the forward transform's rounding noise is ~2e-7 x the rms
-# spectrum magnitude in EVERY bin (measured 1.8-2.0e-7), whatever that bin holds, so a weak
-# channel next to a strong carrier sees an absolute error ~ delta * ||H||_2.  The reference
-# run with a float32 CPU FFT shows the same floor (scripts/diag_accuracy.py).  10x margin:
-FLOOR = 2e-6
+# float32 dynamic-range floor.  A float32 transform's rounding error in a bin is not
+# proportional to what that bin holds: it is set by the strongest line of the window (the
+# partial sums of the sig_gen carrier are large in every butterfly layer that still contains
+# it), so a weak narrow channel far from the carrier carries an ABSOLUTE error.  Measured on
+# config 2/3 (scripts/diag_accuracy.py): worst per-bin error in a channel passband
+# 2.3e-9 x max|X|, for this HIP path and for the reference's filter.c on a float32 CPU FFT
+# alike.  Allowed: FLOOR x max|X| per bin, i.e. a third of a float32 ulp of the strongest
+# line, propagated through the response as ||H||_2.
+FLOOR = 2e-8
 
 
 @pytest.fixture(scope="module")
@@ -39,8 +43,8 @@ def rel(a, b):
 
 
 def noise_floor(spec64, resp):
-    """FLOOR x rms(|X|) x ||H||_2 : absolute rms error allowance from float32 forward-transform noise."""
-    return FLOOR * float(np.sqrt(np.mean(np.abs(spec64) ** 2))) * float(np.linalg.norm(resp))
+    """FLOOR x max|X| x ||H||_2 : absolute rms error allowance from float32 forward-transform noise."""
+    return FLOOR * float(np.abs(spec64).max()) * float(np.linalg.norm(resp))
 
 
 def check_channel(got, want, floor=0.0):
