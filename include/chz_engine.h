@@ -94,7 +94,20 @@ int chz_bank_set_active(chz_engine *e, int bank, int n);                    /* c
 /* replaces execute_filter_output's gather x response + backward transform
  * (src/filter.c:728-914) for every active channel of the bank at once */
 int chz_bank_execute(chz_engine *e, int bank, int slot);
+/* the same for channels [ch0, ch0+n) only: the slow path of one retuned channel */
+int chz_bank_execute_range(chz_engine *e, int bank, int slot, int ch0, int n);
+int chz_bank_destroy(chz_engine *e, int bank);                              /* frees the bank's device arrays */
 int chz_bank_read(chz_engine *e, int bank, int ch0, int n, float *host);    /* n*olen complex, synchronous */
+/* asynchronous device-to-host copies on the engine's stream (host memory should come from
+ * chz_host_alloc); completion is observed through chz_host_callback or chz_sync */
+int chz_bank_read_async(chz_engine *e, int bank, int ch0, int n, float *host);
+int chz_spectrum_read_async(chz_engine *e, int slot, float *host);
+/* run fn(arg) on a runtime thread once everything enqueued so far has finished: replaces
+ * run_fft's completion broadcast (src/filter.c:522-539) */
+int chz_host_callback(chz_engine *e, void (*fn)(void *), void *arg);
+/* page-locked host memory for the buffers the device copies into */
+int chz_host_alloc(void **p, size_t bytes);
+void chz_host_free(void *p);
 int chz_bank_output_device(chz_engine *e, int bank, float **dev);
 
 /* one whole block: chz_forward(job) then every bank on slot job % 4 */

@@ -244,14 +244,15 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
   return 0;
 }
 
-static int enqueue_bank(chz_engine* e, int bank, int slot, Instr* in) {
+static int enqueue_bank(chz_engine* e, int bank, int slot, Instr* in, int ch0 = 0, int n = -1) {
   Bank& b = e->banks[(size_t)bank];
-  if (b.active <= 0) return 0;
+  if (n < 0) n = b.active;
+  if (n <= 0 || !b.resp) return 0;
   ChanParams c{};
-  c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc; c.out = b.out; c.nch = b.active; c.olen = b.olen;
+  c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc; c.out = b.out; c.ch0 = ch0; c.nch = n; c.olen = b.olen;
   c.tw_sub = b.tw_sub;
   const int per_block = b.g.wpb * b.g.cpw;
-  const int grid = (b.active + per_block - 1) / per_block;
+  const int grid = (n + per_block - 1) / per_block;
   mark(in, e->stream, 4, true);
   if (launch_chan(b.g.r, grid, b.g.wpb * 64, b.g.lds, e->stream, c)) return fail(-4, "no kernel for P=%d", b.P);
   mark(in, e->stream, 4, false);
@@ -363,6 +364,47 @@ int chz_bank_execute(chz_engine* e, int bank, int slot) {
   HIPOK(hipGetLastError());
   return 0;
 }
+int chz_bank_execute_range(chz_engine* e, int bank, int slot, int ch0, int n) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
+  HIPOK(hipSetDevice(e->device));
+  int r = enqueue_bank(e, bank, slot, nullptr, ch0, n);
+  if (r) return r;
+  HIPOK(hipGetLastError());
+  return 0;
+}
+int chz_bank_destroy(chz_engine* e, int bank) {
+  BANK_CHECK(e, bank, 0, 0);
+  Bank& b = e->banks[(size_t)bank];
+  HIPOK(hipStreamSynchronize(e->stream));
+  drop_graph(e);
+  hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub);
+  b.resp = nullptr; b.desc = nullptr; b.out = nullptr; b.tw_sub = nullptr; b.active = 0; b.cap = 0;
+  return 0;
+}
+int chz_bank_read_async(chz_engine* e, int bank, int ch0, int n, float* host) {
+  BANK_CHECK(e, bank, ch0, n);
+  Bank& b = e->banks[(size_t)bank];
+  if (n == 0) return 0;
+  HIPOK(hipMemcpyAsync(host, b.out + (size_t)ch0 * b.olen, sizeof(float2) * (size_t)n * b.olen, hipMemcpyDeviceToHost, e->stream));
+  return 0;
+}
+int chz_spectrum_read_async(chz_engine* e, int slot, float* host) {
+  if (!e || !host || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
+  HIPOK(hipMemcpyAsync(host, e->spec[slot], sizeof(float2) * (size_t)e->bins, hipMemcpyDeviceToHost, e->stream));
+  return 0;
+}
+int chz_host_callback(chz_engine* e, void (*fn)(void*), void* arg) {
+  if (!e || !fn) return fail(-1, "bad argument");
+  HIPOK(hipLaunchHostFunc(e->stream, fn, arg));
+  return 0;
+}
+int chz_host_alloc(void** p, size_t bytes) {
+  if (!p) return fail(-1, "null pointer");
+  HIPOK(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+  return 0;
+}
+void chz_host_free(void* p) { if (p) (void)hipHostFree(p); }
 int chz_bank_read(chz_engine* e, int bank, int ch0, int n, float* host) {
   BANK_CHECK(e, bank, ch0, n);
   Bank& b = e->banks[(size_t)bank];

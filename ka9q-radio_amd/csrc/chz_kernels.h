@@ -92,7 +92,7 @@ struct ChanParams {
   const float2* resp;     // [nch][P] frequency responses
   const ChanDesc* desc;   // [nch]
   float2* out;            // [nch][olen]
-  int nch, olen;
+  int ch0, nch, olen;     // channels [ch0, ch0+nch) of the bank are processed
   const float2* tw_sub;   // [R2][R1]  W_P^(-j*k1)  (backward)
 };
 
@@ -344,8 +344,9 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
   const int wave = tid >> 6, lane = tid & 63;
   const int wpb = blockDim.x >> 6;
   const int cw = lane / LPC, jl = lane - cw * LPC;
-  const int ch = (blockIdx.x * wpb + wave) * CPW + cw;
-  const bool live = (cw < CPW) && (ch < p.nch);
+  const int lc = (blockIdx.x * wpb + wave) * CPW + cw;
+  const int ch = p.ch0 + lc;
+  const bool live = (cw < CPW) && (lc < p.nch);
   float2* my = lds + ((wave * CPW + (cw < CPW ? cw : 0)) * (R1 * LDC));
 
   if (live && jl < R2) {

@@ -1,0 +1,683 @@
+/* filter_hip.c -- drop-in replacement for ka9q-radio's filter.o, host side in C.
+ *
+ * Exports exactly what src/filter.h:99-118 declares, on the struct layout callers
+ * already compile against (include/ka9q_filter_abi.h pins it), and runs the hot path --
+ * forward transform, notches, per-channel gather x response, backward transform -- on
+ * the MI355X through the C ABI of libchz_hip.so (include/chz_engine.h).  radiod,
+ * linear.c, fm.c and the front-end plugins stay untouched:
+ *
+ *   front end thread   writes floats through in.input_write_pointer, calls
+ *                      write_rfilter(&in, NULL, n)             (src/rx888.c:800-826)
+ *     -> execute_filter_input(): H2D of the L new samples, forward transform into slot
+ *        job%ND, spectrum back to the host fdomain[] (estimate_noise reads it,
+ *        src/radio.c:1801), then ONE batched launch per (P,olen) bank for every
+ *        registered slave with its last-known shift (speculation), outputs staged in
+ *        pinned memory; a stream callback publishes completed_jobs[] and broadcasts
+ *        filter_cond exactly like run_fft did (src/filter.c:522-539).
+ *   channel threads    execute_filter_output(slave, shift): same wait / lap / drop logic
+ *                      as src/filter.c:680-707; if the staged result was computed with this
+ *                      shift and this response it is copied out, otherwise that one channel is
+ *                      re-run on the device (retunes are rare).
+ *   set_filter()       Kaiser design on the host in float64 as before (src/filter.c:968-1045),
+ *                      response uploaded to the bank.
+ *
+ * There is no CPU signal path here: REAL-output slaves and transform sizes the device
+ * kernels are not compiled for fail loudly with -1.
+ */
+#define _GNU_SOURCE 1
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <limits.h>
+#include <time.h>
+#include <unistd.h>
+#include <errno.h>
+#include <sys/mman.h>
+#include "../../include/ka9q_filter_abi.h"
+#include "../../include/chz_engine.h"
+
+/* ---- globals the rest of radiod sets or reads (src/filter.c:40-48,476-479) ---- */
+const char *Wisdom_file;
+char const *System_wisdom_file = "/etc/fftw/wisdomf";
+int N_worker_threads = 1;
+int N_internal_threads = 1;
+int FFTW_planning_level = 0;
+int64_t Min_fft_time = INT64_MAX;
+int64_t Max_fft_time = 0;
+int64_t Avg_fft_time = 0;
+int64_t Mean_dev = 0;
+
+#define FREE(p) do { free(p); (p) = NULL; } while (0)
+
+/* ------------------------------------------------------------------------- */
+/* per-master / per-slave private state, hung off the opaque plan slots        */
+/* ------------------------------------------------------------------------- */
+struct hbank {
+  int P, olen, id, cap, n;
+  struct filter_out **slaves;       /* [cap] */
+  int *shift;                       /* [cap] shift the device descriptor currently holds */
+  float complex *stage[ND];         /* pinned [cap][olen]: staged outputs per job slot */
+  int *stage_shift[ND];             /* [cap] shift each staged output was computed with */
+  unsigned *stage_epoch[ND];        /* [cap] response epoch it was computed with (0 = invalid) */
+  unsigned stage_job[ND];
+  int stage_n[ND];
+};
+
+struct done_note { struct mctx *ctx; unsigned job; struct timespec t0; };
+
+struct mctx {
+  chz_engine *eng;
+  struct filter_in *master;
+  pthread_mutex_t lock;             /* serialises engine calls and bank bookkeeping */
+  struct hbank *banks;
+  int nbanks;
+  struct notch_state *notch_ptr;    /* list last uploaded to the device */
+  int notch_n;
+  int notch_bins[64];
+  struct done_note note[ND];
+};
+
+struct sctx {
+  int bank;                         /* index into mctx.banks */
+  int idx;                          /* channel index inside the bank */
+  unsigned epoch;                   /* bumped whenever the response changes */
+};
+
+static struct mctx *MCTX(struct filter_in *m) { return (struct mctx *)(void *)m->fwd_plan; }
+static struct sctx *SCTX(struct filter_out *s) { return (struct sctx *)(void *)s->rev_plan; }
+
+static void *lmalloc(size_t size) {           /* cache-line aligned, like src/filter.c:1163 */
+  void *p = NULL;
+  if (posix_memalign(&p, 64, size ? size : 64) != 0) return NULL;
+  return p;
+}
+
+/* ------------------------------------------------------------------------- */
+/* mirrored host ring: two adjacent mappings of one memfd, so an N-sample window */
+/* is always contiguous (role of mirror_alloc, src/misc.c:635-682)              */
+/* ------------------------------------------------------------------------- */
+static size_t page_round(size_t n) {
+  size_t pg = (size_t)sysconf(_SC_PAGESIZE);
+  return (n + pg - 1) / pg * pg;
+}
+static void *ring_map(size_t size) {
+  int fd = memfd_create("ka9q_hip_ring", 0);
+  if (fd < 0) return NULL;
+  if (ftruncate(fd, (off_t)size) != 0) { close(fd); return NULL; }
+  unsigned char *base = mmap(NULL, 2 * size, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (base == MAP_FAILED) { close(fd); return NULL; }
+  if (mmap(base, size, PROT_READ | PROT_WRITE, MAP_FIXED | MAP_SHARED, fd, 0) != (void *)base ||
+      mmap(base + size, size, PROT_READ | PROT_WRITE, MAP_FIXED | MAP_SHARED, fd, 0) != (void *)(base + size)) {
+    munmap(base, 2 * size); close(fd); return NULL;
+  }
+  close(fd);
+  return base;
+}
+static void ring_unmap(void **p, size_t size) { if (p && *p) { munmap(*p, 2 * size); *p = NULL; } }
+static inline void ring_wrap(void **p, void *base, size_t size) {      /* src/misc.h:372-378 */
+  if ((unsigned char *)*p >= (unsigned char *)base + size) *p = (unsigned char *)*p - size;
+}
+
+/* ------------------------------------------------------------------------- */
+/* small host DFT for set_filter's P-point transform (P <= a few thousand)      */
+/* ------------------------------------------------------------------------- */
+static void host_dft_rec(int n, int stride, const double complex *in, double complex *out, const double complex *w, int wn) {
+  if (n == 1) { out[0] = in[0]; return; }
+  int p = 2;
+  while (p * p <= n && n % p) p++;
+  if (n % p) p = n;                       /* n itself is prime */
+  int m = n / p;
+  for (int r = 0; r < p; r++) host_dft_rec(m, stride * p, in + (size_t)r * stride, out + (size_t)r * m, w, wn);
+  double complex t[64], *tt = p <= 64 ? t : malloc(sizeof(double complex) * (size_t)p);
+  double complex u[64], *uu = p <= 64 ? u : malloc(sizeof(double complex) * (size_t)p);
+  for (int k = 0; k < m; k++) {
+    for (int r = 0; r < p; r++) tt[r] = out[k + (size_t)r * m] * w[((long)k * r * (wn / n)) % wn];
+    for (int q = 0; q < p; q++) {
+      double complex a = 0;
+      for (int r = 0; r < p; r++) a += tt[r] * w[((long)q * r % p) * (wn / p)];
+      uu[q] = a;
+    }
+    for (int q = 0; q < p; q++) out[k + (size_t)q * m] = uu[q];
+  }
+  if (p > 64) { free(tt); free(uu); }
+}
+/* forward unnormalised DFT, float complex in place via float64 */
+static int host_dft_forward(int n, float complex *x) {
+  double complex *w = malloc(sizeof(double complex) * (size_t)n * 3);
+  if (!w) return -1;
+  double complex *a = w + n, *b = a + n;
+  for (int k = 0; k < n; k++) { double s, c; sincos(-2.0 * M_PI * k / n, &s, &c); w[k] = c + I * s; }
+  for (int i = 0; i < n; i++) a[i] = x[i];
+  host_dft_rec(n, 1, a, b, w, n);
+  for (int i = 0; i < n; i++) x[i] = (float complex)b[i];
+  free(w);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Kaiser window pieces (src/misc.c:416-427, src/window.c:217-254, src/misc.h:217) */
+/* ------------------------------------------------------------------------- */
+static double bessel_i0(double z) {
+  double t = 0.25 * z * z, term = t, sum = 1 + t;
+  for (int k = 2; k < 40; k++) { term *= t / ((double)k * k); sum += term; if (term < 1e-12 * sum) break; }
+  return sum;
+}
+static void kaiser_f(float *w, int M, double beta) {
+  double inv = 1.0 / bessel_i0(beta), pc = 2.0 / (M - 1);
+  for (int n = 0; n < M / 2; n++) {
+    double p = pc * n - 1;
+    w[n] = w[M - 1 - n] = (float)(bessel_i0(beta * sqrt(1 - p * p)) * inv);
+  }
+  if (M & 1) w[(M - 1) / 2] = 1;
+}
+static double sinc_pi(double x) { return x == 0 ? 1.0 : sin(M_PI * x) / (M_PI * x); }
+static double complex cis_pi(double x) {       /* e^{i pi x}, argument reduced in half-turns */
+  double y = fmod(x, 2.0); if (y < 0) y += 2.0;
+  double s, c; sincos(M_PI * (y > 1.0 ? y - 2.0 : y), &s, &c);
+  return c + I * s;
+}
+
+/* ------------------------------------------------------------------------- */
+/* completion: runs on a HIP runtime thread after the block's work has drained   */
+/* ------------------------------------------------------------------------- */
+static void block_done(void *arg) {
+  struct done_note *n = arg;
+  struct filter_in *f = n->ctx->master;
+  struct timespec t1;
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  pthread_mutex_lock(&f->filter_mutex);
+  f->owner = pthread_self();
+  f->completed_jobs[n->job % ND] = n->job;              /* src/filter.c:526-529 */
+  pthread_cond_broadcast(&f->filter_cond);              /* src/filter.c:532-535 */
+  pthread_mutex_unlock(&f->filter_mutex);
+  int64_t ns = (t1.tv_nsec - n->t0.tv_nsec) + 1000000000LL * (t1.tv_sec - n->t0.tv_sec);
+  if (ns > Max_fft_time) Max_fft_time = ns;             /* src/filter.c:544-552 */
+  if (ns < Min_fft_time) Min_fft_time = ns;
+  int64_t dev = ns - Avg_fft_time;
+  Avg_fft_time += dev >> 4;
+  Mean_dev += (llabs(dev) - Mean_dev) >> 4;
+}
+
+/* ------------------------------------------------------------------------- */
+/* banks                                                                        */
+/* ------------------------------------------------------------------------- */
+static void bank_free_host(struct hbank *b) {
+  for (int s = 0; s < ND; s++) { chz_host_free(b->stage[s]); b->stage[s] = NULL; FREE(b->stage_shift[s]); FREE(b->stage_epoch[s]); }
+  FREE(b->slaves); FREE(b->shift);
+}
+static int bank_alloc_host(struct hbank *b, int cap) {
+  b->cap = cap;
+  b->slaves = calloc((size_t)cap, sizeof *b->slaves);
+  b->shift = calloc((size_t)cap, sizeof *b->shift);
+  if (!b->slaves || !b->shift) return -1;
+  for (int s = 0; s < ND; s++) {
+    void *p = NULL;
+    if (chz_host_alloc(&p, sizeof(float complex) * (size_t)cap * b->olen) != 0) return -1;
+    b->stage[s] = p;
+    b->stage_shift[s] = calloc((size_t)cap, sizeof(int));
+    b->stage_epoch[s] = calloc((size_t)cap, sizeof(unsigned));
+    if (!b->stage_shift[s] || !b->stage_epoch[s]) return -1;
+    b->stage_job[s] = UINT_MAX; b->stage_n[s] = 0;
+  }
+  return 0;
+}
+/* find (or create, or grow) the bank for (P, olen); caller holds ctx->lock */
+static int bank_for(struct mctx *c, int P, int olen) {
+  for (int i = 0; i < c->nbanks; i++) {
+    struct hbank *b = &c->banks[i];
+    if (b->P != P || b->olen != olen) continue;
+    if (b->n < b->cap) return i;
+    /* grow: a new, larger device bank; move responses and shifts over */
+    struct hbank nb = {.P = P, .olen = olen, .n = b->n};
+    nb.id = chz_bank_create(c->eng, P, olen, b->cap * 2);
+    if (nb.id < 0 || bank_alloc_host(&nb, b->cap * 2) != 0) { fprintf(stderr, "filter_hip: cannot grow bank: %s\n", chz_last_error()); return -1; }
+    for (int k = 0; k < b->n; k++) {
+      nb.slaves[k] = b->slaves[k]; nb.shift[k] = b->shift[k];
+      if (nb.slaves[k]->response) chz_bank_set_responses(c->eng, nb.id, k, 1, (const float *)nb.slaves[k]->response);
+    }
+    chz_bank_set_shifts(c->eng, nb.id, 0, nb.n, nb.shift);
+    chz_bank_destroy(c->eng, b->id);
+    bank_free_host(b);
+    *b = nb;
+    return i;
+  }
+  struct hbank *nbanks = realloc(c->banks, sizeof *nbanks * (size_t)(c->nbanks + 1));
+  if (!nbanks) return -1;
+  c->banks = nbanks;
+  struct hbank *b = &c->banks[c->nbanks];
+  memset(b, 0, sizeof *b);
+  b->P = P; b->olen = olen;
+  b->id = chz_bank_create(c->eng, P, olen, 64);
+  if (b->id < 0) { fprintf(stderr, "filter_hip: %s\n", chz_last_error()); return -1; }
+  if (bank_alloc_host(b, 64) != 0) return -1;
+  return c->nbanks++;
+}
+
+/* ------------------------------------------------------------------------- */
+/* create / delete                                                               */
+/* ------------------------------------------------------------------------- */
+int create_filter_input(struct filter_in *master, int const L, int const M, enum filtertype const in_type) {
+  if (master == NULL) return -1;
+  if (master->init && master->ilen == L && master->impulse_length == M && in_type == master->in_type)
+    return 0;                                                      /* src/filter.c:191-192 */
+  if (in_type != REAL && in_type != COMPLEX) return -1;            /* src/filter.c:228-234 */
+  if (L <= 0 || M <= 0) return -1;
+  int const N = L + M - 1;
+  int const bins = (in_type == COMPLEX) ? N : (N / 2 + 1);
+  if (bins < 2) return -1;                                         /* src/filter.c:198-199 */
+
+  if (master->init && master->fwd_plan) {                          /* re-create with new geometry */
+    struct mctx *old = MCTX(master);
+    chz_engine_destroy(old->eng);
+    for (int i = 0; i < old->nbanks; i++) bank_free_host(&old->banks[i]);
+    free(old->banks); pthread_mutex_destroy(&old->lock); free(old);
+    master->fwd_plan = NULL;
+    for (int i = 0; i < ND; i++) { chz_host_free(master->fdomain[i]); master->fdomain[i] = NULL; }
+    ring_unmap(&master->input_buffer, master->input_buffer_size);
+  }
+  struct mctx *c = calloc(1, sizeof *c);
+  if (!c) return -1;
+  const char *dev = getenv("KA9Q_HIP_DEVICE");
+  if (chz_engine_create(&c->eng, L, M, in_type == REAL ? CHZ_REAL : CHZ_COMPLEX, dev ? atoi(dev) : 0, NULL, 0) != 0) {
+    fprintf(stderr, "create_filter_input(L=%d M=%d): %s\n", L, M, chz_last_error());
+    free(c);
+    return -1;
+  }
+  c->master = master;
+  pthread_mutex_init(&c->lock, NULL);
+  master->points = N;
+  master->perform_inline = (N_worker_threads == 0);               /* src/filter.c:205 */
+  for (int i = 0; i < ND; i++) {
+    void *p = NULL;
+    if (chz_host_alloc(&p, sizeof(float complex) * (size_t)bins) != 0) { fprintf(stderr, "create_filter_input: %s\n", chz_last_error()); return -1; }
+    master->fdomain[i] = p;                                        /* pinned: the device copies spectra here */
+    memset(p, 0, sizeof(float complex) * (size_t)bins);
+    master->completed_jobs[i] = UINT_MAX;                         /* src/filter.c:214 */
+  }
+  master->bins = bins; master->ilen = L; master->impulse_length = M;
+  if (!master->init) {
+    pthread_mutex_init(&master->filter_mutex, NULL);
+    pthread_cond_init(&master->filter_cond, NULL);
+    master->init = true;
+  }
+  master->owner = pthread_self();
+  master->in_type = in_type;
+  size_t const ssz = in_type == COMPLEX ? sizeof(float complex) : sizeof(float);
+  master->input_buffer_size = page_round((size_t)ND * N * ssz);   /* src/filter.c:237,253 */
+  master->input_buffer = ring_map(master->input_buffer_size);
+  if (!master->input_buffer) { perror("create_filter_input: ring"); return -1; }
+  memset(master->input_buffer, 0, master->input_buffer_size);
+  if (in_type == COMPLEX) {                                        /* src/filter.c:243-246 */
+    master->input_read_pointer.c = master->input_buffer;
+    master->input_write_pointer.c = master->input_read_pointer.c + (M - 1);
+    master->input_read_pointer.r = NULL; master->input_write_pointer.r = NULL;
+  } else {                                                         /* src/filter.c:258-261 */
+    master->input_read_pointer.r = master->input_buffer;
+    master->input_write_pointer.r = master->input_read_pointer.r + (M - 1);
+    master->input_read_pointer.c = NULL; master->input_write_pointer.c = NULL;
+  }
+  master->wcnt = 0;
+  master->next_jobnum = 0;
+  master->fwd_plan = (fftwf_plan)(void *)c;
+  return 0;
+}
+
+int delete_filter_input(struct filter_in *master) {
+  if (master == NULL) return -1;
+  if (master->fwd_plan) {
+    struct mctx *c = MCTX(master);
+    chz_sync(c->eng);
+    chz_engine_destroy(c->eng);
+    for (int i = 0; i < c->nbanks; i++) bank_free_host(&c->banks[i]);
+    free(c->banks);
+    pthread_mutex_destroy(&c->lock);
+    free(c);
+  }
+  if (master->init) { pthread_mutex_destroy(&master->filter_mutex); pthread_cond_destroy(&master->filter_cond); }
+  ring_unmap(&master->input_buffer, master->input_buffer_size);
+  for (int i = 0; i < ND; i++) chz_host_free(master->fdomain[i]);
+  memset(master, 0, sizeof *master);                               /* src/filter.c:940 */
+  return 0;
+}
+
+int create_filter_output(struct filter_out *slave, struct filter_in *master, int len, enum filtertype out_type) {
+  if (master == NULL || slave == NULL || (out_type != SPECTRUM && len <= 0)) return -1;
+  if (slave->master == master && slave->olen == len && slave->out_type == out_type && slave->init)
+    goto done;                                                     /* src/filter.c:303-304 */
+  if (out_type == SPECTRUM) len = 0;
+  int const N = master->ilen + master->impulse_length - 1;
+  int const L = master->ilen;
+  if (((long)len * N % L) != 0) {                                  /* src/filter.c:313-316 */
+    fprintf(stderr, "Invalid filter output length %d (fft size %d) for input N=%d, L=%d\n", len, (int)((long)len * N / L), N, L);
+    return -1;
+  }
+  if (out_type == REAL) {
+    fprintf(stderr, "create_filter_output: REAL output is not part of the MI355X channelizer path (no CPU fallback)\n");
+    return -1;
+  }
+  if (slave->init && slave->rev_plan) delete_filter_output(slave);  /* geometry changed: start over */
+  slave->olen = len;
+  slave->points = (int)((long)len * N / L);
+  if (!slave->init) { pthread_mutex_init(&slave->response_mutex, NULL); slave->init = true; }
+  slave->master = master;
+  slave->out_type = out_type;
+  set_filter_weights(slave, 1.0, 0.0);
+  if (out_type == COMPLEX) {
+    struct mctx *c = MCTX(master);
+    slave->bins = slave->points;
+    slave->fdomain = lmalloc(sizeof(float complex) * (size_t)slave->bins);
+    slave->output_buffer.c = lmalloc(sizeof(float complex) * (size_t)slave->points);
+    struct sctx *sc = calloc(1, sizeof *sc);
+    if (!slave->fdomain || !slave->output_buffer.c || !sc) { FREE(slave->fdomain); FREE(slave->output_buffer.c); free(sc); return -1; }
+    memset(slave->output_buffer.c, 0, sizeof(float complex) * (size_t)slave->points);
+    slave->output.c = slave->output_buffer.c + slave->bins - len;   /* src/filter.c:357 */
+    pthread_mutex_lock(&c->lock);
+    int bi = bank_for(c, slave->points, len);
+    if (bi < 0) {
+      pthread_mutex_unlock(&c->lock);
+      fprintf(stderr, "create_filter_output: no device kernel for P=%d\n", slave->points);
+      FREE(slave->fdomain); FREE(slave->output_buffer.c); free(sc);
+      return -1;
+    }
+    struct hbank *b = &c->banks[bi];
+    sc->bank = bi; sc->idx = b->n; sc->epoch = 1;
+    b->slaves[b->n] = slave; b->shift[b->n] = 0;
+    for (int s = 0; s < ND; s++) b->stage_epoch[s][b->n] = 0;
+    b->n++;
+    slave->rev_plan = (fftwf_plan)(void *)sc;
+    pthread_mutex_unlock(&c->lock);
+  }
+  /* SPECTRUM: no buffers, no plan: a block clock only (src/filter.c:368-371) */
+done:;
+  slave->next_jobnum = master->next_jobnum;                        /* src/filter.c:413 */
+  return 0;
+}
+
+int delete_filter_output(struct filter_out *slave) {
+  if (slave == NULL) return -1;
+  if (slave->rev_plan && slave->master && slave->master->fwd_plan) {
+    struct mctx *c = MCTX(slave->master);
+    struct sctx *sc = SCTX(slave);
+    pthread_mutex_lock(&c->lock);
+    struct hbank *b = &c->banks[sc->bank];
+    int last = b->n - 1;
+    if (sc->idx != last) {                 /* the last channel moves into the freed index */
+      struct filter_out *mv = b->slaves[last];
+      struct sctx *ms = SCTX(mv);
+      b->slaves[sc->idx] = mv; ms->idx = sc->idx; ms->epoch++;
+      b->shift[sc->idx] = b->shift[last];
+      if (mv->response) chz_bank_set_responses(c->eng, b->id, ms->idx, 1, (const float *)mv->response);
+      chz_bank_set_shifts(c->eng, b->id, ms->idx, 1, &b->shift[ms->idx]);
+      for (int s = 0; s < ND; s++) b->stage_epoch[s][ms->idx] = 0;
+    }
+    b->slaves[last] = NULL; b->n--;
+    pthread_mutex_unlock(&c->lock);
+    free(sc);
+  }
+  if (slave->init) pthread_mutex_destroy(&slave->response_mutex);
+  FREE(slave->output_buffer.c); FREE(slave->output_buffer.r);
+  FREE(slave->response); FREE(slave->fdomain);
+  memset(slave, 0, sizeof *slave);                                 /* src/filter.c:955 */
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* input side                                                                    */
+/* ------------------------------------------------------------------------- */
+static void sync_notches(struct mctx *c, struct filter_in *f) {
+  /* radio.c installs f->notches after create_filter_input (src/radio.c:601-620) */
+  struct notch_state *ns = f->notches;
+  int n = 0;
+  if (ns) { while (n < 63 && ns[n].bin != 0) n++; n++; }           /* list ends with the DC entry */
+  bool same = (ns == c->notch_ptr && n == c->notch_n);
+  for (int i = 0; same && i < n; i++) same = (ns[i].bin == c->notch_bins[i]);
+  if (same) return;
+  for (int i = 0; i < n; i++) c->notch_bins[i] = ns[i].bin;
+  chz_set_notches(c->eng, c->notch_bins, n, n ? ns[0].alpha : 0.0);
+  c->notch_ptr = ns; c->notch_n = n;
+}
+
+int execute_filter_input(struct filter_in *const f) {
+  if (f == NULL || f->fwd_plan == NULL) return -1;
+  struct mctx *c = MCTX(f);
+  pthread_mutex_lock(&c->lock);
+  unsigned const job = f->next_jobnum++;                           /* src/filter.c:607 */
+  int const slot = (int)(job % ND);
+  f->samples_by_job[slot] = f->sample_index;                       /* src/filter.c:614-615 */
+  f->sample_index += (uint64_t)f->ilen;
+  struct done_note *note = &c->note[slot];
+  note->ctx = c; note->job = job;
+  clock_gettime(CLOCK_MONOTONIC, &note->t0);
+  sync_notches(c, f);
+
+  /* the window is [read, read+N); its last L samples are the new ones (the mirror keeps
+     them contiguous).  Advance the read pointer by L (src/filter.c:626-636). */
+  int rc = 0;
+  if (f->in_type == COMPLEX) {
+    float complex *win = f->input_read_pointer.c;
+    rc = chz_input_write(c->eng, (const float *)(win + (f->impulse_length - 1)), f->ilen);
+    f->input_read_pointer.c += f->ilen;
+    ring_wrap((void **)&f->input_read_pointer.c, f->input_buffer, f->input_buffer_size);
+  } else {
+    float *win = f->input_read_pointer.r;
+    rc = chz_input_write(c->eng, win + (f->impulse_length - 1), f->ilen);
+    f->input_read_pointer.r += f->ilen;
+    ring_wrap((void **)&f->input_read_pointer.r, f->input_buffer, f->input_buffer_size);
+  }
+  if (rc == 0) rc = chz_forward(c->eng, job);
+  if (rc == 0) rc = chz_spectrum_read_async(c->eng, slot, (float *)f->fdomain[slot]);
+  /* speculative batched channel launches: every slave with its last-known shift */
+  for (int i = 0; rc == 0 && i < c->nbanks; i++) {
+    struct hbank *b = &c->banks[i];
+    b->stage_job[slot] = job; b->stage_n[slot] = b->n;
+    if (b->n == 0) continue;
+    for (int k = 0; k < b->n; k++) {
+      b->stage_shift[slot][k] = b->shift[k];
+      b->stage_epoch[slot][k] = b->slaves[k]->response ? SCTX(b->slaves[k])->epoch : 0;
+    }
+    chz_bank_set_active(c->eng, b->id, b->n);
+    rc = chz_bank_execute(c->eng, b->id, slot);
+    if (rc == 0) rc = chz_bank_read_async(c->eng, b->id, 0, b->n, (float *)b->stage[slot]);
+  }
+  if (rc == 0) rc = chz_host_callback(c->eng, block_done, note);
+  if (rc != 0) fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
+  pthread_mutex_unlock(&c->lock);
+  if (rc == 0 && f->perform_inline) {      /* inline masters hand the block over before returning (src/filter.c:562-600) */
+    chz_sync(c->eng);
+    pthread_mutex_lock(&f->filter_mutex);
+    f->owner = pthread_self();
+    pthread_mutex_unlock(&f->filter_mutex);
+  }
+  return rc == 0 ? 0 : -1;
+}
+
+int write_cfilter(struct filter_in *f, float complex const *buffer, int size) {   /* src/filter.c:1093-1113 */
+  if (f == NULL) return -1;
+  if ((f->wcnt + size) * sizeof *buffer >= f->input_buffer_size) return -1;
+  if (buffer != NULL) memcpy(f->input_write_pointer.c, buffer, (size_t)size * sizeof *buffer);
+  f->input_write_pointer.c += size;
+  ring_wrap((void **)&f->input_write_pointer.c, f->input_buffer, f->input_buffer_size);
+  f->wcnt += size;
+  bool executed = false;
+  while (f->wcnt >= f->ilen) { f->wcnt -= f->ilen; execute_filter_input(f); executed = true; }
+  return executed;
+}
+int write_rfilter(struct filter_in *f, float const *buffer, int size) {           /* src/filter.c:1114-1134 */
+  if (f == NULL) return -1;
+  if ((f->wcnt + size) * sizeof *buffer >= f->input_buffer_size) return -1;
+  if (buffer != NULL) memcpy(f->input_write_pointer.r, buffer, (size_t)size * sizeof *buffer);
+  f->input_write_pointer.r += size;
+  ring_wrap((void **)&f->input_write_pointer.r, f->input_buffer, f->input_buffer_size);
+  f->wcnt += size;
+  bool executed = false;
+  while (f->wcnt >= f->ilen) { f->wcnt -= f->ilen; execute_filter_input(f); executed = true; }
+  return executed;
+}
+
+/* ------------------------------------------------------------------------- */
+/* output side                                                                   */
+/* ------------------------------------------------------------------------- */
+int execute_filter_output(struct filter_out *const slave, int const shift) {
+  if (slave == NULL) return -1;
+  struct filter_in *const master = slave->master;
+  if (master == NULL) return -1;
+
+  pthread_mutex_lock(&master->filter_mutex);
+  if (master->owner == pthread_self()) {
+    slave->next_jobnum = master->next_jobnum - 1;                  /* src/filter.c:681-683 */
+    while ((int)(slave->next_jobnum - master->completed_jobs[slave->next_jobnum % ND]) > 0)
+      pthread_cond_wait(&master->filter_cond, &master->filter_mutex);   /* device may still be running */
+  } else {
+    while ((int)(slave->next_jobnum - master->completed_jobs[slave->next_jobnum % ND]) > 0)
+      pthread_cond_wait(&master->filter_cond, &master->filter_mutex);   /* src/filter.c:686-687 */
+    int blocks_behind = (int)(master->completed_jobs[slave->next_jobnum % ND] - slave->next_jobnum);
+    if (blocks_behind >= ND) {                                     /* lapped: zeros + drop (src/filter.c:690-701) */
+      pthread_mutex_unlock(&master->filter_mutex);
+      slave->block_drops++;
+      slave->next_jobnum++;
+      if (slave->output_buffer.c != NULL) memset(slave->output_buffer.c, 0, (size_t)slave->points * sizeof *slave->output_buffer.c);
+      return 0;
+    }
+  }
+  unsigned const job = slave->next_jobnum;
+  int const slot = (int)(job % ND);
+  slave->sample_index = master->samples_by_job[slot];              /* src/filter.c:705 */
+  slave->next_jobnum++;
+  pthread_mutex_unlock(&master->filter_mutex);
+
+  if (slave->out_type == SPECTRUM || slave->rev_plan == NULL) return 0;   /* block clock only */
+  pthread_mutex_lock(&slave->response_mutex);
+  bool const ready = slave->response != NULL && slave->output.c != NULL;
+  pthread_mutex_unlock(&slave->response_mutex);
+  if (!ready) return 0;                                            /* src/filter.c:715-718 */
+
+  struct mctx *c = MCTX(master);
+  struct sctx *sc = SCTX(slave);
+  int rc = 0;
+  pthread_mutex_lock(&c->lock);
+  struct hbank *b = &c->banks[sc->bank];
+  int const k = sc->idx;
+  if (b->stage_job[slot] == job && k < b->stage_n[slot] && b->stage_shift[slot][k] == shift &&
+      b->stage_epoch[slot][k] == sc->epoch) {
+    /* the speculative batch already computed exactly this */
+    memcpy(slave->output.c, b->stage[slot] + (size_t)k * b->olen, sizeof(float complex) * (size_t)b->olen);
+  } else {
+    /* retuned / new filter / newly created: run this one channel on the block's spectrum */
+    if (b->shift[k] != shift) { b->shift[k] = shift; rc = chz_bank_set_shifts(c->eng, b->id, k, 1, &b->shift[k]); }
+    if (rc == 0) rc = chz_bank_execute_range(c->eng, b->id, slot, k, 1);
+    if (rc == 0) rc = chz_bank_read(c->eng, b->id, k, 1, (float *)slave->output.c);
+    if (rc != 0) fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
+  }
+  pthread_mutex_unlock(&c->lock);
+  return rc == 0 ? 0 : -1;
+}
+
+int set_filter_weights(struct filter_out *out, double complex i_weight, double complex q_weight) {  /* src/filter.c:922-929 */
+  if (out == NULL) return -1;
+  out->alpha = 0.5 * i_weight - I * q_weight;
+  out->beta = 0.5 * i_weight + I * q_weight;
+  return 0;
+}
+
+int set_filter(struct filter_out *const slave, double low, double high, double const kaiser_beta) {  /* src/filter.c:968-1045 */
+  if (slave == NULL || isnan(low) || isnan(high) || isnan(kaiser_beta) || slave->master == NULL) return -1;
+  if (slave->out_type == REAL) { low = fabs(low); high = fabs(high); }
+  if (low > high) { double t = low; low = high; high = t; }
+  low = low < -0.5 ? -0.5 : low > +0.5 ? +0.5 : low;
+  high = high < -0.5 ? -0.5 : high > +0.5 ? +0.5 : high;
+  int const N = slave->points, L = slave->olen, M = N - L + 1;
+  if (M < 2) return -1;
+  double const bw2 = (high == low) ? .0001 : fabs(high - low) / 2;
+  double const center = (high + low) / 2;
+  float *win = malloc(sizeof(float) * (size_t)M);
+  float complex *response = lmalloc((size_t)N * sizeof *response);
+  if (!win || !response) { free(win); free(response); return -1; }
+  kaiser_f(win, M, kaiser_beta);
+  double g = 0;
+  for (int i = 0; i < M; i++) g += win[i];
+  g = M / g;
+  for (int i = 0; i < M; i++) win[i] *= (float)g;                  /* normalize_windowf */
+  memset(response, 0, (size_t)N * sizeof *response);
+  double window_gain = 0;
+  for (int i = 0; i < M; i++) {
+    double n = i - (double)(M - 1) / 2;
+    double r = win[i] * 2 * bw2 * sinc_pi(2 * bw2 * n);
+    window_gain += r;
+    response[i] = (float complex)(cis_pi(2 * center * n) * r);
+  }
+  double const gain = (slave->master->in_type == REAL ? M_SQRT2 : 1.0) / (window_gain * slave->master->points);
+  for (int i = 0; i < M; i++) response[i] *= gain;
+  free(win);
+  if (host_dft_forward(N, response) != 0) { free(response); return -1; }
+  pthread_mutex_lock(&slave->response_mutex);                      /* hot swap, src/filter.c:1039-1043 */
+  float complex *old = slave->response;
+  slave->response = response;
+  pthread_mutex_unlock(&slave->response_mutex);
+  free(old);
+  if (slave->rev_plan && slave->master->fwd_plan) {
+    struct mctx *c = MCTX(slave->master);
+    struct sctx *sc = SCTX(slave);
+    pthread_mutex_lock(&c->lock);
+    sc->epoch++;
+    int rc = chz_bank_set_responses(c->eng, c->banks[sc->bank].id, sc->idx, 1, (const float *)response);
+    pthread_mutex_unlock(&c->lock);
+    if (rc != 0) { fprintf(stderr, "set_filter: %s\n", chz_last_error()); return -1; }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* helpers other parts of ka9q-radio use                                         */
+/* ------------------------------------------------------------------------- */
+/* spectrum.c plans and runs its own analysis FFTs through these (src/spectrum.c:198,265);
+   they stay FFTW-backed when the final link provides FFTW (radiod does), and return NULL
+   otherwise -- never a silent substitute. */
+extern fftwf_plan fftwf_plan_dft_1d(int, float complex *, float complex *, int, unsigned) __attribute__((weak));
+extern fftwf_plan fftwf_plan_dft_r2c_1d(int, float *, float complex *, unsigned) __attribute__((weak));
+extern fftwf_plan fftwf_plan_dft_c2r_1d(int, float complex *, float *, unsigned) __attribute__((weak));
+extern void fftwf_destroy_plan(fftwf_plan) __attribute__((weak));
+static pthread_mutex_t Planning_mutex = PTHREAD_MUTEX_INITIALIZER;
+#define FFTW_ESTIMATE_FLAG (1U << 6)
+fftwf_plan plan_complex(int N, float complex *in, float complex *out, int direction) {
+  if (!fftwf_plan_dft_1d) return NULL;
+  pthread_mutex_lock(&Planning_mutex);
+  fftwf_plan p = fftwf_plan_dft_1d(N, in, out, direction, FFTW_ESTIMATE_FLAG);
+  pthread_mutex_unlock(&Planning_mutex);
+  return p;
+}
+fftwf_plan plan_r2c(int N, float *in, float complex *out) {
+  if (!fftwf_plan_dft_r2c_1d) return NULL;
+  pthread_mutex_lock(&Planning_mutex);
+  fftwf_plan p = fftwf_plan_dft_r2c_1d(N, in, out, FFTW_ESTIMATE_FLAG);
+  pthread_mutex_unlock(&Planning_mutex);
+  return p;
+}
+fftwf_plan plan_c2r(int N, float complex *in, float *out) {
+  if (!fftwf_plan_dft_c2r_1d) return NULL;
+  pthread_mutex_lock(&Planning_mutex);
+  fftwf_plan p = fftwf_plan_dft_c2r_1d(N, in, out, FFTW_ESTIMATE_FLAG);
+  pthread_mutex_unlock(&Planning_mutex);
+  return p;
+}
+void destroy_plan(fftwf_plan *plan) {
+  if (plan == NULL || *plan == NULL) return;
+  if (fftwf_destroy_plan) { pthread_mutex_lock(&Planning_mutex); fftwf_destroy_plan(*plan); pthread_mutex_unlock(&Planning_mutex); }
+  *plan = NULL;
+}
+void *run_fft(void *p) { (void)p; return NULL; }     /* no CPU FFT workers exist in this build */
+void suggest(int size, int dir, int clex) { (void)size; (void)dir; (void)clex; }   /* FFTW wisdom hint: nothing to log */
+long gcd(long a, long b) { while (b != 0) { long t = b; b = a % b; a = t; } return a; }
+long lcm(long a, long b) { if (a <= 0 || b <= 0) return 0; return (a / gcd(a, b)) * b; }
+bool goodchoice(long n) {                              /* 2,3,5,7-smooth with at most one factor 11 or 13 (src/filter.c:444-451) */
+  if (n <= 0) return false;
+  static const int pr[6] = {2, 3, 5, 7, 11, 13};
+  int big = 0;
+  for (int i = 0; i < 6; i++) while (n % pr[i] == 0) { n /= pr[i]; if (i >= 4) big++; }
+  return n == 1 && big <= 1;
+}
+int ceil_pow2(uint32_t x) {
+  if (x <= 1) return 1;
+  x--; x |= x >> 1; x |= x >> 2; x |= x >> 4; x |= x >> 8; x |= x >> 16;
+  return (int)(x + 1);
+}

@@ -34,8 +34,9 @@ SYMBOLS = [
     "chz_engine_set_stream", "chz_sync", "chz_input_write", "chz_input_write_device", "chz_input_ring",
     "chz_forward", "chz_set_notches", "chz_spectrum_read", "chz_spectrum_device", "chz_spectrum_attach",
     "chz_bank_create", "chz_bank_set_responses", "chz_bank_set_shifts", "chz_bank_set_active",
-    "chz_bank_execute", "chz_bank_read", "chz_bank_output_device", "chz_step", "chz_run_blocks",
-    "chz_gather_descriptor",
+    "chz_bank_execute", "chz_bank_execute_range", "chz_bank_destroy", "chz_bank_read", "chz_bank_read_async",
+    "chz_spectrum_read_async", "chz_host_callback", "chz_host_alloc", "chz_host_free",
+    "chz_bank_output_device", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
 ]
 
 _lib = None
@@ -70,6 +71,8 @@ def lib():
         L.chz_bank_set_active.argtypes = [_vp, _i, _i]
         L.chz_bank_execute.argtypes = [_vp, _i, _i]
         L.chz_bank_read.argtypes = [_vp, _i, _i, _i, _vp]
+        L.chz_bank_execute_range.argtypes = [_vp, _i, _i, _i, _i]
+        L.chz_bank_destroy.argtypes = [_vp, _i]
         L.chz_bank_output_device.argtypes = [_vp, _i, C.POINTER(_vp)]
         L.chz_step.argtypes = [_vp, _u]
         L.chz_run_blocks.argtypes = [_vp, _u, _i, _i, _i, C.POINTER(ChzTiming)]

@@ -1,0 +1,140 @@
+/* tests/c/dropin_harness.c -- drives the filter.h API the way radiod does (TEST CODE).
+ *
+ * One front-end thread writes samples in place through in.input_write_pointer and calls
+ * write_rfilter/write_cfilter(&in, NULL, n) like the SDR drivers (src/rx888.c:800-826,
+ * src/sig_gen.c:290-320); one thread per channel loops execute_filter_output(&out, shift)
+ * like demod_linear/demod_fm via downconvert() (src/radio.c:1460); one SPECTRUM slave acts
+ * as a block clock (src/spectrum.c).  Results go to files for tests/test_dropin.py.
+ *
+ * Built twice: against include/ka9q_filter_abi.h (default) and, where /root/reference
+ * exists, against the reference's OWN src/filter.h (-DKA9Q_FILTER_HEADER='"filter.h"') to
+ * prove the drop-in is source- and layout-compatible with unmodified callers.
+ */
+#define _GNU_SOURCE 1
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdatomic.h>
+#include <pthread.h>
+#include <complex.h>
+#include <unistd.h>
+#ifndef KA9Q_FILTER_HEADER
+#define KA9Q_FILTER_HEADER "ka9q_filter_abi.h"
+#endif
+#include KA9Q_FILTER_HEADER
+
+struct chanplan { int shift, shift2, retune_block, refilter_block; double low, high, beta, low2, high2; };
+
+static struct filter_in Master;
+static int L, M, In_type, Olen, Nch, Nblocks, Chunk;
+static struct chanplan *Plan;
+static float complex *Result;          /* [Nblocks][Nch][Olen] */
+static unsigned *Drops;
+static _Atomic int *Progress;          /* blocks consumed per channel */
+static float *Input;
+
+struct chanarg { int idx; };
+
+static void *channel_thread(void *a) {
+  int const i = ((struct chanarg *)a)->idx;
+  struct filter_out out;
+  memset(&out, 0, sizeof out);
+  if (create_filter_output(&out, &Master, Olen, COMPLEX) != 0) { fprintf(stderr, "create_filter_output failed\n"); exit(2); }
+  if (set_filter(&out, Plan[i].low, Plan[i].high, Plan[i].beta) != 0) { fprintf(stderr, "set_filter failed\n"); exit(2); }
+  atomic_store(&Progress[i], 0);       /* registered: the producer may start */
+  for (int b = 0; b < Nblocks; b++) {
+    if (b == Plan[i].refilter_block) set_filter(&out, Plan[i].low2, Plan[i].high2, Plan[i].beta);
+    int shift = (b >= Plan[i].retune_block) ? Plan[i].shift2 : Plan[i].shift;
+    if (execute_filter_output(&out, shift) != 0) { fprintf(stderr, "execute_filter_output failed\n"); exit(2); }
+    memcpy(Result + ((size_t)b * Nch + i) * Olen, out.output.c, sizeof(float complex) * (size_t)Olen);
+    atomic_store(&Progress[i], b + 1);
+  }
+  Drops[i] = out.block_drops;
+  delete_filter_output(&out);
+  return NULL;
+}
+
+static _Atomic int Clock_blocks;
+static void *clock_thread(void *a) {
+  (void)a;
+  struct filter_out sp;
+  memset(&sp, 0, sizeof sp);
+  if (create_filter_output(&sp, &Master, 0, SPECTRUM) != 0) { fprintf(stderr, "SPECTRUM slave failed\n"); exit(2); }
+  for (int b = 0; b < Nblocks; b++) { execute_filter_output(&sp, 0); atomic_fetch_add(&Clock_blocks, 1); }
+  delete_filter_output(&sp);
+  return NULL;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) { fprintf(stderr, "usage: %s <dir>\n", argv[0]); return 1; }
+  char path[512];
+  snprintf(path, sizeof path, "%s/cfg.txt", argv[1]);
+  FILE *f = fopen(path, "r");
+  if (!f || fscanf(f, "%d %d %d %d %d %d %d", &L, &M, &In_type, &Olen, &Nch, &Nblocks, &Chunk) != 7) { perror("cfg"); return 1; }
+  fclose(f);
+  int const per = In_type == REAL ? 1 : 2;
+  Plan = calloc((size_t)Nch, sizeof *Plan);
+  snprintf(path, sizeof path, "%s/plan.bin", argv[1]);
+  f = fopen(path, "rb");
+  if (!f || fread(Plan, sizeof *Plan, (size_t)Nch, f) != (size_t)Nch) { perror("plan"); return 1; }
+  fclose(f);
+  Input = malloc(sizeof(float) * (size_t)Nblocks * L * per);
+  snprintf(path, sizeof path, "%s/in.bin", argv[1]);
+  f = fopen(path, "rb");
+  if (!f || fread(Input, sizeof(float) * per, (size_t)Nblocks * L, f) != (size_t)Nblocks * L) { perror("input"); return 1; }
+  fclose(f);
+  Result = calloc((size_t)Nblocks * Nch * Olen, sizeof *Result);
+  Drops = calloc((size_t)Nch, sizeof *Drops);
+  Progress = calloc((size_t)Nch, sizeof *Progress);
+  for (int i = 0; i < Nch; i++) atomic_store(&Progress[i], -1);
+
+  memset(&Master, 0, sizeof Master);
+  if (create_filter_input(&Master, L, M, (enum filtertype)In_type) != 0) { fprintf(stderr, "create_filter_input failed\n"); return 3; }
+  if (create_filter_input(&Master, L, M, (enum filtertype)In_type) != 0) return 3;      /* idempotent (src/filter.c:191) */
+  /* DC notch, installed after create exactly as radio.c does (src/radio.c:601-620) */
+  struct notch_state *notch = calloc(1, sizeof *notch);
+  notch[0].bin = 0; notch[0].alpha = 0.01;
+  Master.notches = notch;
+
+  pthread_t *th = calloc((size_t)Nch, sizeof *th), clk;
+  struct chanarg *args = calloc((size_t)Nch, sizeof *args);
+  for (int i = 0; i < Nch; i++) { args[i].idx = i; pthread_create(&th[i], NULL, channel_thread, &args[i]); }
+  pthread_create(&clk, NULL, clock_thread, NULL);
+  for (int i = 0; i < Nch; i++) while (atomic_load(&Progress[i]) < 0) usleep(200);      /* all slaves registered */
+
+  /* front end: write in place, then tell the filter how much arrived */
+  long total = (long)Nblocks * L, pos = 0;
+  while (pos < total) {
+    int blk = (int)(pos / L);
+    for (;;) {   /* never run more than 2 blocks ahead of the slowest channel: no drops wanted here */
+      int slow = Nblocks;
+      for (int i = 0; i < Nch; i++) { int p = atomic_load(&Progress[i]); if (p < slow) slow = p; }
+      if (blk - slow < 2) break;
+      usleep(100);
+    }
+    int n = Chunk; if (pos + n > total) n = (int)(total - pos);
+    if (In_type == REAL) {
+      memcpy(Master.input_write_pointer.r, Input + pos, sizeof(float) * (size_t)n);
+      if (write_rfilter(&Master, NULL, n) < 0) { fprintf(stderr, "write_rfilter overrun\n"); return 4; }
+    } else {
+      memcpy(Master.input_write_pointer.c, Input + 2 * pos, sizeof(float complex) * (size_t)n);
+      if (write_cfilter(&Master, NULL, n) < 0) { fprintf(stderr, "write_cfilter overrun\n"); return 4; }
+    }
+    pos += n;
+  }
+  for (int i = 0; i < Nch; i++) pthread_join(th[i], NULL);
+  pthread_join(clk, NULL);
+
+  snprintf(path, sizeof path, "%s/out.bin", argv[1]);
+  f = fopen(path, "wb"); fwrite(Result, sizeof *Result, (size_t)Nblocks * Nch * Olen, f); fclose(f);
+  snprintf(path, sizeof path, "%s/spec.bin", argv[1]);   /* host-visible spectrum of the last block (estimate_noise reads it) */
+  f = fopen(path, "wb"); fwrite(Master.fdomain[(Nblocks - 1) % ND], sizeof(float complex), (size_t)Master.bins, f); fclose(f);
+  snprintf(path, sizeof path, "%s/meta.txt", argv[1]);
+  f = fopen(path, "w");
+  unsigned drops = 0; for (int i = 0; i < Nch; i++) drops += Drops[i];
+  fprintf(f, "drops %u clock %d next_jobnum %u bins %d points %d sample_index %llu\n", drops, atomic_load(&Clock_blocks),
+          Master.next_jobnum, Master.bins, Master.points, (unsigned long long)Master.sample_index);
+  fclose(f);
+  delete_filter_input(&Master);
+  return 0;
+}

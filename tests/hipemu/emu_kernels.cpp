@@ -68,7 +68,7 @@ int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, in
   }
   ChanParams c{};
   c.spec = reinterpret_cast<const float2*>(spec); c.resp = reinterpret_cast<const float2*>(resp);
-  c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.nch = nch; c.olen = olen;
+  c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub);
   const int per_block = g.wpb * g.cpw;
   const int grid = (nch + per_block - 1) / per_block;
