@@ -97,18 +97,22 @@ int chz_bank_execute(chz_engine *e, int bank, int slot);
 /* the same for channels [ch0, ch0+n) only: the slow path of one retuned channel */
 int chz_bank_execute_range(chz_engine *e, int bank, int slot, int ch0, int n);
 int chz_bank_destroy(chz_engine *e, int bank);                              /* frees the bank's device arrays */
-int chz_bank_read(chz_engine *e, int bank, int ch0, int n, float *host);    /* n*olen complex, synchronous */
-/* asynchronous device-to-host copies on the engine's stream (host memory should come from
- * chz_host_alloc); completion is observed through chz_host_callback or chz_sync */
-int chz_bank_read_async(chz_engine *e, int bank, int ch0, int n, float *host);
+int chz_bank_read(chz_engine *e, int bank, int ch0, int n, float *host);    /* n*olen complex of the most recent execute, synchronous */
+/* Blocks are pipelined over 1, 2 or 4 HIP streams ("lanes", env CHZ_STREAMS, default 2): block j
+ * runs on lane j % lanes with its own intermediate buffer, so block j+1's forward transform overlaps
+ * block j's tail.  Bank outputs exist once per spectrum slot.  Everything addressed by `slot` below is
+ * enqueued on the lane that owns that slot, in call order.
+ * Asynchronous device-to-host copies (host memory should come from chz_host_alloc); completion is
+ * observed through chz_host_callback or chz_sync */
+int chz_bank_read_async(chz_engine *e, int bank, int slot, int ch0, int n, float *host);
 int chz_spectrum_read_async(chz_engine *e, int slot, float *host);
-/* run fn(arg) on a runtime thread once everything enqueued so far has finished: replaces
+/* run fn(arg) on a runtime thread once everything enqueued so far on `slot`'s lane has finished: replaces
  * run_fft's completion broadcast (src/filter.c:522-539) */
-int chz_host_callback(chz_engine *e, void (*fn)(void *), void *arg);
+int chz_host_callback(chz_engine *e, int slot, void (*fn)(void *), void *arg);
 /* page-locked host memory for the buffers the device copies into */
 int chz_host_alloc(void **p, size_t bytes);
 void chz_host_free(void *p);
-int chz_bank_output_device(chz_engine *e, int bank, float **dev);
+int chz_bank_output_device(chz_engine *e, int bank, int slot, float **dev);
 
 /* one whole block: chz_forward(job) then every bank on slot job % 4 */
 int chz_step(chz_engine *e, unsigned job);

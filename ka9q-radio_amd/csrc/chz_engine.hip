@@ -29,18 +29,32 @@ struct Bank {
   ChanGeom g;
   float2* resp = nullptr;       // [cap][P]
   ChanDesc* desc = nullptr;     // [cap]
-  float2* out = nullptr;        // [cap][olen]
+  float2* out = nullptr;        // [ND][cap][olen]: one output image per spectrum slot
   float2* tw_sub = nullptr;
+  int last_slot = 0;            // slot of the most recent execute (what chz_bank_read returns)
+};
+
+// A lane = one HIP stream + its own intermediate buffer.  Consecutive blocks go to
+// consecutive lanes, so block j+1's forward transform overlaps block j's tail and channel
+// kernel (the "second HIP stream" of the north star).
+#define CHZ_MAX_LANES 4
+struct Lane {
+  hipStream_t s = nullptr;
+  float2* buf = nullptr;
+  hipEvent_t rows_done = nullptr;   // after this lane's latest fwd_rows (orders the notch state)
 };
 
 struct chz_engine {
   int L = 0, M = 0, N = 0, in_type = 0, bins = 0, per = 1, device = 0, ring_blocks = 0;
   FwdPlan plan;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;     // == lanes[0].s: copies and anything not tied to a block
   bool own_stream = false;
+  Lane lanes[CHZ_MAX_LANES];
+  int nlanes = 1;
+  hipEvent_t input_ready = nullptr; // after the latest ring write
+  bool input_pending = false;
   float* ring = nullptr; long ring_len = 0;   // floats
   long wpos = 0;                              // write position (floats)
-  float2* buf = nullptr;
   float2* spec[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};
   bool spec_owned[CHZ_ND] = {false, false, false, false};
   float2 *tw_sub_a = nullptr, *tw_sub_b = nullptr, *tw_sub_c = nullptr;
@@ -49,6 +63,8 @@ struct chz_engine {
   std::vector<Bank> banks;
   hipGraphExec_t graph = nullptr; unsigned graph_job0 = 0; int graph_blocks = 0; size_t graph_sig = 0;
 };
+
+static int sync_all(chz_engine* e);
 
 template <class T> static int upload(T** dst, const std::vector<f2>& v) {
   *dst = nullptr;
@@ -103,10 +119,19 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   e->ring_len = (long)ring_blocks * L * e->per;
   HIPOK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   e->own_stream = true;
+  const char* envl = getenv("CHZ_STREAMS");
+  int nl = envl ? atoi(envl) : 2;
+  e->nlanes = (nl >= 4) ? 4 : (nl >= 2) ? 2 : 1;             // must divide ND so slot and lane stay aligned
+  HIPOK(hipEventCreateWithFlags(&e->input_ready, hipEventDisableTiming));
+  for (int i = 0; i < e->nlanes; i++) {
+    if (i == 0) e->lanes[i].s = e->stream;
+    else HIPOK(hipStreamCreateWithFlags(&e->lanes[i].s, hipStreamNonBlocking));
+    HIPOK(hipEventCreateWithFlags(&e->lanes[i].rows_done, hipEventDisableTiming));
+    HIPOK(hipMalloc((void**)&e->lanes[i].buf, sizeof(float2) * (size_t)e->plan.Ra * e->plan.inner));
+  }
   HIPOK(hipMalloc((void**)&e->ring, sizeof(float) * (size_t)e->ring_len));
   HIPOK(hipMemset(e->ring, 0, sizeof(float) * (size_t)e->ring_len));       // src/filter.c:242,257
   e->wpos = (long)(M - 1) * e->per;                                          // src/filter.c:244,259
-  HIPOK(hipMalloc((void**)&e->buf, sizeof(float2) * (size_t)e->plan.Ra * e->plan.inner));
   for (int i = 0; i < CHZ_ND; i++) {
     HIPOK(hipMalloc((void**)&e->spec[i], sizeof(float2) * (size_t)bins));
     HIPOK(hipMemset(e->spec[i], 0, sizeof(float2) * (size_t)bins));
@@ -130,10 +155,15 @@ static void drop_graph(chz_engine* e) {
 void chz_engine_destroy(chz_engine* e) {
   if (!e) return;
   hipSetDevice(e->device);
-  hipStreamSynchronize(e->stream);
+  for (int i = 0; i < e->nlanes; i++) hipStreamSynchronize(e->lanes[i].s);
   drop_graph(e);
+  for (int i = 0; i < e->nlanes; i++) {
+    hipFree(e->lanes[i].buf); hipEventDestroy(e->lanes[i].rows_done);
+    if (i > 0) hipStreamDestroy(e->lanes[i].s);
+  }
+  hipEventDestroy(e->input_ready);
   for (auto& b : e->banks) { hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); }
-  hipFree(e->ring); hipFree(e->buf);
+  hipFree(e->ring);
   for (int i = 0; i < CHZ_ND; i++) if (e->spec_owned[i]) hipFree(e->spec[i]);
   hipFree(e->tw_sub_a); hipFree(e->tw_sub_b); hipFree(e->tw_sub_c);
   hipFree(e->tw1_tile); hipFree(e->tw1_col); hipFree(e->tw2_tile); hipFree(e->tw2_col);
@@ -154,17 +184,25 @@ int chz_engine_info(const chz_engine* e, chz_info* info) {
 
 int chz_engine_set_stream(chz_engine* e, void* hip_stream) {
   if (!e) return fail(-1, "null engine");
-  HIPOK(hipStreamSynchronize(e->stream));
+  int r = sync_all(e);
+  if (r) return r;
   drop_graph(e);
+  // a caller-owned stream means the caller does the ordering: collapse to one lane
+  for (int i = 1; i < e->nlanes; i++) { hipFree(e->lanes[i].buf); hipEventDestroy(e->lanes[i].rows_done); hipStreamDestroy(e->lanes[i].s); e->lanes[i] = Lane(); }
+  e->nlanes = 1;
   if (e->own_stream) { hipStreamDestroy(e->stream); e->own_stream = false; }
   e->stream = (hipStream_t)hip_stream;
+  e->lanes[0].s = e->stream;
   return 0;
 }
 
+static int sync_all(chz_engine* e) {
+  for (int i = 0; i < e->nlanes; i++) HIPOK(hipStreamSynchronize(e->lanes[i].s));
+  return 0;
+}
 int chz_sync(chz_engine* e) {
   if (!e) return fail(-1, "null engine");
-  HIPOK(hipStreamSynchronize(e->stream));
-  return 0;
+  return sync_all(e);
 }
 
 static int ring_write(chz_engine* e, const float* src, long n, hipMemcpyKind kind) {
@@ -174,6 +212,7 @@ static int ring_write(chz_engine* e, const float* src, long n, hipMemcpyKind kin
   if (first > 0) HIPOK(hipMemcpyAsync(e->ring + e->wpos, src, sizeof(float) * (size_t)first, kind, e->stream));
   if (nf > first) HIPOK(hipMemcpyAsync(e->ring, src + first, sizeof(float) * (size_t)(nf - first), kind, e->stream));
   e->wpos = (e->wpos + nf) % e->ring_len;
+  if (e->nlanes > 1) { HIPOK(hipEventRecord(e->input_ready, e->stream)); e->input_pending = true; }
   return 0;
 }
 int chz_input_write(chz_engine* e, const float* host, long n) {
@@ -206,56 +245,74 @@ static void mark(Instr* in, hipStream_t s, int kind, bool begin) {
   in->ev.push_back(e);
 }
 
+static inline int lane_of(const chz_engine* e, unsigned job, const Instr* in) {
+  return (in && in->on) ? 0 : (int)(job % (unsigned)e->nlanes);
+}
+
 static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
   const FwdPlan& p = e->plan;
   const int slot = job % CHZ_ND;
+  const int ln = lane_of(e, job, in);
+  hipStream_t st = e->lanes[ln].s;
+  float2* lbuf = e->lanes[ln].buf;
+  if (ln != 0 && e->input_pending) HIPOK(hipStreamWaitEvent(st, e->input_ready, 0));
   const long start = (long)(((unsigned long long)job * (unsigned long long)e->L) % (unsigned long long)((long)e->ring_blocks * e->L)) * e->per;
   if (e->in_type == CHZ_REAL) {
     FirstRealParams a{};
-    a.ring = e->ring; a.ring_len = e->ring_len; a.start = start; a.buf = e->buf; a.inner = p.inner;
+    a.ring = e->ring; a.ring_len = e->ring_len; a.start = start; a.buf = lbuf; a.inner = p.inner;
     a.T = p.T1; a.Ra = p.Ra; a.padk = p.padk1; a.tw_sub = e->tw_sub_a; a.tw_tile = e->tw1_tile; a.tw_col = e->tw1_col;
-    mark(in, e->stream, 0, true);
-    if (launch_first_real(p.ra, p.grid1, p.block1, p.lds1, e->stream, a)) return fail(-4, "no kernel for axis a");
-    mark(in, e->stream, 0, false);
+    mark(in, st, 0, true);
+    if (launch_first_real(p.ra, p.grid1, p.block1, p.lds1, st, a)) return fail(-4, "no kernel for axis a");
+    mark(in, st, 0, false);
   } else {
     ColsParams a{};
     a.in = reinterpret_cast<const float2*>(e->ring); a.in_len = e->ring_len / 2; a.in_start = start / 2;
-    a.out = e->buf; a.rows = 1; a.inner = p.inner; a.T = p.T1; a.padk = p.padk1;
+    a.out = lbuf; a.rows = 1; a.inner = p.inner; a.T = p.T1; a.padk = p.padk1;
     a.tw_sub = e->tw_sub_a; a.tw_tile = e->tw1_tile; a.tw_col = e->tw1_col;
-    mark(in, e->stream, 0, true);
-    if (launch_cols(p.ra, p.grid1, p.block1, p.lds1, e->stream, a)) return fail(-4, "no kernel for axis a");
-    mark(in, e->stream, 0, false);
+    mark(in, st, 0, true);
+    if (launch_cols(p.ra, p.grid1, p.block1, p.lds1, st, a)) return fail(-4, "no kernel for axis a");
+    mark(in, st, 0, false);
   }
   if (p.Nb > 1) {
     ColsParams b{};
-    b.in = e->buf; b.in_len = 0; b.in_start = 0; b.out = e->buf; b.rows = p.Ra; b.inner = p.Nc; b.T = p.T2;
+    b.in = lbuf; b.in_len = 0; b.in_start = 0; b.out = lbuf; b.rows = p.Ra; b.inner = p.Nc; b.T = p.T2;
     b.padk = p.padk2; b.tw_sub = e->tw_sub_b; b.tw_tile = e->tw2_tile; b.tw_col = e->tw2_col;
-    mark(in, e->stream, 1, true);
-    if (launch_cols(p.rb, p.grid2, p.block2, p.lds2, e->stream, b)) return fail(-4, "no kernel for axis b");
-    mark(in, e->stream, 1, false);
+    mark(in, st, 1, true);
+    if (launch_cols(p.rb, p.grid2, p.block2, p.lds2, st, b)) return fail(-4, "no kernel for axis b");
+    mark(in, st, 1, false);
   }
   RowsParams c{};
-  c.buf = e->buf; c.spec = e->spec[slot]; c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3;
+  c.buf = lbuf; c.spec = e->spec[slot]; c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3;
   c.padg = p.padg3; c.N = p.N; c.mirror = e->in_type == CHZ_REAL; c.tw_sub = e->tw_sub_c;
   c.n_notch = e->n_notch; c.notch_bins = e->notch_bins; c.notch_state = e->notch_state; c.notch_alpha = e->notch_alpha;
-  mark(in, e->stream, 2, true);
-  if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, e->stream, c)) return fail(-4, "no kernel for axis c");
-  mark(in, e->stream, 2, false);
+  if (e->n_notch > 0 && e->nlanes > 1 && !(in && in->on)) {
+    // the notch state is sequential across blocks: this block's fwd_rows after the previous block's
+    const int prev = (int)((job + (unsigned)e->nlanes - 1u) % (unsigned)e->nlanes);
+    if (prev != ln) HIPOK(hipStreamWaitEvent(st, e->lanes[prev].rows_done, 0));
+  }
+  mark(in, st, 2, true);
+  if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, st, c)) return fail(-4, "no kernel for axis c");
+  mark(in, st, 2, false);
+  if (e->n_notch > 0 && e->nlanes > 1 && !(in && in->on)) HIPOK(hipEventRecord(e->lanes[ln].rows_done, st));
   return 0;
 }
+
+static inline float2* bank_out(const Bank& b, int slot) { return b.out + (size_t)slot * b.cap * b.olen; }
 
 static int enqueue_bank(chz_engine* e, int bank, int slot, Instr* in, int ch0 = 0, int n = -1) {
   Bank& b = e->banks[(size_t)bank];
   if (n < 0) n = b.active;
   if (n <= 0 || !b.resp) return 0;
+  hipStream_t st = e->lanes[lane_of(e, (unsigned)slot, in)].s;
+  b.last_slot = slot;
   ChanParams c{};
-  c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc; c.out = b.out; c.ch0 = ch0; c.nch = n; c.olen = b.olen;
+  c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc; c.out = bank_out(b, slot); c.ch0 = ch0; c.nch = n; c.olen = b.olen;
   c.tw_sub = b.tw_sub;
   const int per_block = b.g.wpb * b.g.cpw;
   const int grid = (n + per_block - 1) / per_block;
-  mark(in, e->stream, 4, true);
-  if (launch_chan(b.g.r, grid, b.g.wpb * 64, b.g.lds, e->stream, c)) return fail(-4, "no kernel for P=%d", b.P);
-  mark(in, e->stream, 4, false);
+  mark(in, st, 4, true);
+  if (launch_chan(b.g.r, grid, b.g.wpb * 64, b.g.lds, st, c)) return fail(-4, "no kernel for P=%d", b.P);
+  mark(in, st, 4, false);
   return 0;
 }
 
@@ -270,7 +327,7 @@ int chz_forward(chz_engine* e, unsigned job) {
 
 int chz_set_notches(chz_engine* e, const int* bins, int n, double alpha) {
   if (!e) return fail(-1, "null engine");
-  HIPOK(hipStreamSynchronize(e->stream));
+  { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
   hipFree(e->notch_bins); hipFree(e->notch_state); e->notch_bins = nullptr; e->notch_state = nullptr; e->n_notch = 0;
   if (n <= 0 || !bins) return 0;
@@ -283,10 +340,13 @@ int chz_set_notches(chz_engine* e, const int* bins, int n, double alpha) {
   return 0;
 }
 
+static inline hipStream_t slot_stream(chz_engine* e, int slot) { return e->lanes[slot % e->nlanes].s; }
+
 int chz_spectrum_read(chz_engine* e, int slot, float* host) {
   if (!e || !host || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
-  HIPOK(hipMemcpyAsync(host, e->spec[slot], sizeof(float2) * (size_t)e->bins, hipMemcpyDeviceToHost, e->stream));
-  HIPOK(hipStreamSynchronize(e->stream));
+  hipStream_t st = slot_stream(e, slot);          // the lane that produced this slot
+  HIPOK(hipMemcpyAsync(host, e->spec[slot], sizeof(float2) * (size_t)e->bins, hipMemcpyDeviceToHost, st));
+  HIPOK(hipStreamSynchronize(st));
   return 0;
 }
 int chz_spectrum_device(chz_engine* e, int slot, float** dev) {
@@ -296,7 +356,7 @@ int chz_spectrum_device(chz_engine* e, int slot, float** dev) {
 }
 int chz_spectrum_attach(chz_engine* e, int slot, float* dev) {
   if (!e || !dev || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
-  HIPOK(hipStreamSynchronize(e->stream));
+  { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
   if (e->spec_owned[slot]) hipFree(e->spec[slot]);
   e->spec[slot] = reinterpret_cast<float2*>(dev); e->spec_owned[slot] = false;
@@ -317,8 +377,8 @@ int chz_bank_create(chz_engine* e, int P, int olen, int capacity) {
   HIPOK(hipMemset(b.resp, 0, sizeof(float2) * (size_t)capacity * P));
   HIPOK(hipMalloc((void**)&b.desc, sizeof(ChanDesc) * (size_t)capacity));
   HIPOK(hipMemset(b.desc, 0, sizeof(ChanDesc) * (size_t)capacity));
-  HIPOK(hipMalloc((void**)&b.out, sizeof(float2) * (size_t)capacity * olen));
-  HIPOK(hipMemset(b.out, 0, sizeof(float2) * (size_t)capacity * olen));
+  HIPOK(hipMalloc((void**)&b.out, sizeof(float2) * (size_t)CHZ_ND * capacity * olen));
+  HIPOK(hipMemset(b.out, 0, sizeof(float2) * (size_t)CHZ_ND * capacity * olen));
   int r = upload(&b.tw_sub, b.g.tw_sub);
   if (r) return r;
   drop_graph(e);
@@ -333,6 +393,7 @@ int chz_bank_create(chz_engine* e, int P, int olen, int capacity) {
 int chz_bank_set_responses(chz_engine* e, int bank, int ch0, int n, const float* resp) {
   BANK_CHECK(e, bank, ch0, n);
   Bank& b = e->banks[(size_t)bank];
+  { int r = sync_all(e); if (r) return r; }   // no block may be using the old response
   HIPOK(hipMemcpyAsync(b.resp + (size_t)ch0 * b.P, resp, sizeof(float2) * (size_t)n * b.P, hipMemcpyHostToDevice, e->stream));
   HIPOK(hipStreamSynchronize(e->stream));   // caller's buffer may be pageable / reused
   return 0;
@@ -345,6 +406,7 @@ int chz_bank_set_shifts(chz_engine* e, int bank, int ch0, int n, const int* shif
     ChanDescH h = make_chan_desc(e->in_type, e->bins, b.P, shifts[i]);
     d[(size_t)i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
   }
+  { int r = sync_all(e); if (r) return r; }
   HIPOK(hipMemcpyAsync(b.desc + ch0, d.data(), sizeof(ChanDesc) * (size_t)n, hipMemcpyHostToDevice, e->stream));
   HIPOK(hipStreamSynchronize(e->stream));
   return 0;
@@ -376,27 +438,29 @@ int chz_bank_execute_range(chz_engine* e, int bank, int slot, int ch0, int n) {
 int chz_bank_destroy(chz_engine* e, int bank) {
   BANK_CHECK(e, bank, 0, 0);
   Bank& b = e->banks[(size_t)bank];
-  HIPOK(hipStreamSynchronize(e->stream));
+  { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
   hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub);
   b.resp = nullptr; b.desc = nullptr; b.out = nullptr; b.tw_sub = nullptr; b.active = 0; b.cap = 0;
   return 0;
 }
-int chz_bank_read_async(chz_engine* e, int bank, int ch0, int n, float* host) {
+int chz_bank_read_async(chz_engine* e, int bank, int slot, int ch0, int n, float* host) {
   BANK_CHECK(e, bank, ch0, n);
+  if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
   Bank& b = e->banks[(size_t)bank];
   if (n == 0) return 0;
-  HIPOK(hipMemcpyAsync(host, b.out + (size_t)ch0 * b.olen, sizeof(float2) * (size_t)n * b.olen, hipMemcpyDeviceToHost, e->stream));
+  HIPOK(hipMemcpyAsync(host, bank_out(b, slot) + (size_t)ch0 * b.olen, sizeof(float2) * (size_t)n * b.olen,
+                       hipMemcpyDeviceToHost, slot_stream(e, slot)));
   return 0;
 }
 int chz_spectrum_read_async(chz_engine* e, int slot, float* host) {
   if (!e || !host || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
-  HIPOK(hipMemcpyAsync(host, e->spec[slot], sizeof(float2) * (size_t)e->bins, hipMemcpyDeviceToHost, e->stream));
+  HIPOK(hipMemcpyAsync(host, e->spec[slot], sizeof(float2) * (size_t)e->bins, hipMemcpyDeviceToHost, slot_stream(e, slot)));
   return 0;
 }
-int chz_host_callback(chz_engine* e, void (*fn)(void*), void* arg) {
-  if (!e || !fn) return fail(-1, "bad argument");
-  HIPOK(hipLaunchHostFunc(e->stream, fn, arg));
+int chz_host_callback(chz_engine* e, int slot, void (*fn)(void*), void* arg) {
+  if (!e || !fn || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
+  HIPOK(hipLaunchHostFunc(slot_stream(e, slot), fn, arg));
   return 0;
 }
 int chz_host_alloc(void** p, size_t bytes) {
@@ -408,13 +472,15 @@ void chz_host_free(void* p) { if (p) (void)hipHostFree(p); }
 int chz_bank_read(chz_engine* e, int bank, int ch0, int n, float* host) {
   BANK_CHECK(e, bank, ch0, n);
   Bank& b = e->banks[(size_t)bank];
-  HIPOK(hipMemcpyAsync(host, b.out + (size_t)ch0 * b.olen, sizeof(float2) * (size_t)n * b.olen, hipMemcpyDeviceToHost, e->stream));
-  HIPOK(hipStreamSynchronize(e->stream));
+  hipStream_t st = slot_stream(e, b.last_slot);
+  HIPOK(hipMemcpyAsync(host, bank_out(b, b.last_slot) + (size_t)ch0 * b.olen, sizeof(float2) * (size_t)n * b.olen, hipMemcpyDeviceToHost, st));
+  HIPOK(hipStreamSynchronize(st));
   return 0;
 }
-int chz_bank_output_device(chz_engine* e, int bank, float** dev) {
+int chz_bank_output_device(chz_engine* e, int bank, int slot, float** dev) {
   BANK_CHECK(e, bank, 0, 0);
-  *dev = reinterpret_cast<float*>(e->banks[(size_t)bank].out);
+  if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
+  *dev = reinterpret_cast<float*>(bank_out(e->banks[(size_t)bank], slot));
   return 0;
 }
 
@@ -435,39 +501,67 @@ int chz_step(chz_engine* e, unsigned job) {
   return 0;
 }
 
+// fork: every other lane's stream waits on an event recorded on lane 0 (inside a capture this
+// pulls the lane into the capture); join: lane 0 waits for every other lane's tail.
+static int lanes_fork(chz_engine* e, hipEvent_t ev) {
+  if (e->nlanes < 2) return 0;
+  HIPOK(hipEventRecord(ev, e->lanes[0].s));
+  for (int i = 1; i < e->nlanes; i++) HIPOK(hipStreamWaitEvent(e->lanes[i].s, ev, 0));
+  return 0;
+}
+static int lanes_join(chz_engine* e, hipEvent_t* evs) {
+  for (int i = 1; i < e->nlanes; i++) {
+    HIPOK(hipEventRecord(evs[i], e->lanes[i].s));
+    HIPOK(hipStreamWaitEvent(e->lanes[0].s, evs[i], 0));
+  }
+  return 0;
+}
+
 int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int instrument, chz_timing* timing) {
   if (!e || nblocks < 0) return fail(-1, "bad argument");
   HIPOK(hipSetDevice(e->device));
-  hipEvent_t t0, t1;
+  { int r = sync_all(e); if (r) return r; }
+  e->input_pending = false;                       // everything written so far is visible to every lane now
+  hipEvent_t t0, t1, fork_ev, join_ev[CHZ_MAX_LANES];
   HIPOK(hipEventCreate(&t0)); HIPOK(hipEventCreate(&t1));
+  HIPOK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+  for (int i = 0; i < CHZ_MAX_LANES; i++) HIPOK(hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming));
   Instr in; in.on = instrument != 0 && mode == 0;
-  int done = 0;
+  hipStream_t s0 = e->lanes[0].s;
+  int done = 0, rc = 0;
   if (mode == 1) {
-    // one graph = one ring cycle of blocks (a multiple of ND so slots line up too)
+    // one graph = one ring cycle of blocks (a multiple of ND so slots and lanes line up too)
     int cycle = e->ring_blocks;
     while (cycle % CHZ_ND) cycle += e->ring_blocks;
     const unsigned phase = job0 % (unsigned)cycle;
     if (!e->graph || e->graph_blocks != cycle || e->graph_job0 != phase) {
       drop_graph(e);
       hipGraph_t g = nullptr;
-      HIPOK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-      int r = 0;
-      for (int i = 0; i < cycle && !r; i++) r = enqueue_step(e, phase + (unsigned)i, nullptr);
-      hipError_t ce = hipStreamEndCapture(e->stream, &g);
-      if (r) { if (g) hipGraphDestroy(g); return r; }
+      HIPOK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
+      rc = lanes_fork(e, fork_ev);
+      for (int i = 0; i < cycle && !rc; i++) rc = enqueue_step(e, phase + (unsigned)i, nullptr);
+      if (!rc) rc = lanes_join(e, join_ev);
+      hipError_t ce = hipStreamEndCapture(s0, &g);
+      if (rc) { if (g) hipGraphDestroy(g); return rc; }
       if (ce != hipSuccess) return fail(-10, "graph capture failed: %s", hipGetErrorString(ce));
       HIPOK(hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0));
       hipGraphDestroy(g);
       e->graph_blocks = cycle; e->graph_job0 = phase;
     }
-    HIPOK(hipEventRecord(t0, e->stream));
-    while (nblocks - done >= cycle) { HIPOK(hipGraphLaunch(e->graph, e->stream)); done += cycle; }
-    for (; done < nblocks; done++) { int r = enqueue_step(e, job0 + (unsigned)done, nullptr); if (r) return r; }
+    HIPOK(hipEventRecord(t0, s0));
+    while (nblocks - done >= cycle) { HIPOK(hipGraphLaunch(e->graph, s0)); done += cycle; }
+    if (done < nblocks) {
+      if ((rc = lanes_fork(e, fork_ev))) return rc;
+      for (; done < nblocks; done++) if ((rc = enqueue_step(e, job0 + (unsigned)done, nullptr))) return rc;
+      if ((rc = lanes_join(e, join_ev))) return rc;
+    }
   } else {
-    HIPOK(hipEventRecord(t0, e->stream));
-    for (; done < nblocks; done++) { int r = enqueue_step(e, job0 + (unsigned)done, &in); if (r) return r; }
+    HIPOK(hipEventRecord(t0, s0));
+    if (!in.on && (rc = lanes_fork(e, fork_ev))) return rc;
+    for (; done < nblocks; done++) if ((rc = enqueue_step(e, job0 + (unsigned)done, &in))) return rc;
+    if (!in.on && (rc = lanes_join(e, join_ev))) return rc;
   }
-  HIPOK(hipEventRecord(t1, e->stream));
+  HIPOK(hipEventRecord(t1, s0));
   HIPOK(hipEventSynchronize(t1));
   HIPOK(hipGetLastError());
   if (timing) {
@@ -482,7 +576,8 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
     }
   }
   for (auto ev : in.ev) hipEventDestroy(ev);
-  hipEventDestroy(t0); hipEventDestroy(t1);
+  hipEventDestroy(t0); hipEventDestroy(t1); hipEventDestroy(fork_ev);
+  for (int i = 0; i < CHZ_MAX_LANES; i++) hipEventDestroy(join_ev[i]);
   return 0;
 }
 

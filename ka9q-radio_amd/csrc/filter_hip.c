@@ -478,9 +478,9 @@ int execute_filter_input(struct filter_in *const f) {
     }
     chz_bank_set_active(c->eng, b->id, b->n);
     rc = chz_bank_execute(c->eng, b->id, slot);
-    if (rc == 0) rc = chz_bank_read_async(c->eng, b->id, 0, b->n, (float *)b->stage[slot]);
+    if (rc == 0) rc = chz_bank_read_async(c->eng, b->id, slot, 0, b->n, (float *)b->stage[slot]);
   }
-  if (rc == 0) rc = chz_host_callback(c->eng, block_done, note);
+  if (rc == 0) rc = chz_host_callback(c->eng, slot, block_done, note);
   if (rc != 0) fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
   pthread_mutex_unlock(&c->lock);
   if (rc == 0 && f->perform_inline) {      /* inline masters hand the block over before returning (src/filter.c:562-600) */

@@ -73,7 +73,7 @@ def lib():
         L.chz_bank_read.argtypes = [_vp, _i, _i, _i, _vp]
         L.chz_bank_execute_range.argtypes = [_vp, _i, _i, _i, _i]
         L.chz_bank_destroy.argtypes = [_vp, _i]
-        L.chz_bank_output_device.argtypes = [_vp, _i, C.POINTER(_vp)]
+        L.chz_bank_output_device.argtypes = [_vp, _i, _i, C.POINTER(_vp)]
         L.chz_step.argtypes = [_vp, _u]
         L.chz_run_blocks.argtypes = [_vp, _u, _i, _i, _i, C.POINTER(ChzTiming)]
         L.chz_gather_descriptor.argtypes = [_i, _i, _i, _i, C.POINTER(_i * 6)]
@@ -209,7 +209,7 @@ class Bank:
         _check(lib().chz_bank_read(self.eng._h, self.id, ch0, n, out.ctypes.data))
         return out
 
-    def output_ptr(self):
+    def output_ptr(self, slot=0):
         p = _vp()
-        _check(lib().chz_bank_output_device(self.eng._h, self.id, C.byref(p)))
+        _check(lib().chz_bank_output_device(self.eng._h, self.id, slot, C.byref(p)))
         return p.value
