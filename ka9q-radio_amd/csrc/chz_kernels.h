@@ -102,28 +102,51 @@ struct ChanParams {
 template <int R1, int R2>
 __global__ void fwd_first_real(FirstRealParams p) {
   constexpr int NA = R1 * R2;
+  constexpr int LA = R1 > R2 ? R1 : R2;
+  // rows one lane walks in the split epilogue: ceil(Ra / rows-per-sweep), rows-per-sweep >= LA/2
+  constexpr int NE = (NA / 2 + 1 + LA / 2 - 1) / (LA / 2);
   HIP_DYNAMIC_SHARED(float2, lds)
   const int tid = threadIdx.x, nthr = blockDim.x, tile = blockIdx.x;
   const int T = p.T;
   const int c0 = tile * T;                       // first packed column of the tile
-  const float2* ring2 = reinterpret_cast<const float2*>(p.ring);
+  const float2* __restrict__ ring2 = reinterpret_cast<const float2*>(p.ring);
   const long ring2_len = p.ring_len >> 1, start2 = p.start >> 1, inner2 = p.inner >> 1;
+  const float2* __restrict__ tws = p.tw_sub;
+  const float2* __restrict__ twt = p.tw_tile;
+  const float2* __restrict__ twc = p.tw_col;
+  float2* __restrict__ gout = p.buf;
+
+  // Epilogue geometry is known up front: one lane owns one output column cc and walks rows
+  // kr, kr+rpi, ...  Fetch its twiddle factors now; they are consumed at the very end.
+  const int W2 = 2 * T;
+  const int rpi = nthr / W2;                     // rows covered per sweep
+  const int kr = tid / W2, cc = tid - kr * W2;
+  const bool lane_on = kr < rpi;
+  float2 we1[NE], we2[NE];
+  static_for<NE>([&](auto u) {
+    constexpr int U = decltype(u)::value;
+    const int k = kr + U * rpi;
+    const int kk = (lane_on && k < p.Ra) ? k : 0;
+    we1[U] = twt[tile * p.Ra + kk];
+    we2[U] = twc[kk * W2 + cc];
+  });
 
   // layer 1: radix R1 over na = j + q*R2, one (j, column) pair per thread
   if (tid < R2 * T) {
     const int j = tid / T, t = tid - j * T;
-    float2 v[R1];
+    float2 v[R1], w1[R1];
     static_for<R1>([&](auto q) {
       constexpr int Q = decltype(q)::value;
       long idx = start2 + (long)(j + Q * R2) * inner2 + c0 + t;
       if (idx >= ring2_len) idx -= ring2_len;
       v[Q] = ring2[idx];
+      if constexpr (Q > 0) w1[Q] = tws[j * R1 + Q];
     });
     reg_dft<R1, -1>(v);
     static_for<R1>([&](auto k1) {
       constexpr int K1 = decltype(k1)::value;
       float2 x = v[K1];
-      if constexpr (K1 > 0) x = cmul(x, p.tw_sub[j * R1 + K1]);
+      if constexpr (K1 > 0) x = cmul(x, w1[K1]);
       lds[(K1 * R2 + j) * T + K1 * p.padk + t] = x;
     });
   }
@@ -150,37 +173,20 @@ __global__ void fwd_first_real(FirstRealParams p) {
   __syncthreads();
   // split + twiddle + store:  real column 2p   -> (Z[k] + conj Z[Na-k]) / 2
   //                           real column 2p+1 -> (Z[k] - conj Z[Na-k]) / 2i
-  // One lane owns one output column cc and walks the rows; the LDS reads and the two
-  // table loads of EPI_U rows are issued together so their latencies overlap.
-  constexpr int EPI_U = 4;
-  const int W2 = 2 * T;
-  const int rpi = nthr / W2;                     // rows covered per sweep
-  const int kr = tid / W2, cc = tid - kr * W2;
   const int pc = cc >> 1;
   const bool odd = cc & 1;
-  const bool lane_on = kr < rpi;
-  for (int k0 = kr; k0 < p.Ra; k0 += rpi * EPI_U) {
-    float2 a[EPI_U], b[EPI_U], w1[EPI_U], w2[EPI_U];
-    static_for<EPI_U>([&](auto u) {
-      constexpr int U = decltype(u)::value;
-      const int k = k0 + U * rpi;
-      const int kk = (lane_on && k < p.Ra) ? k : 0;
-      a[U] = lds[kk * T + pc];
-      b[U] = lds[(kk == 0 ? 0 : NA - kk) * T + pc];
-      w1[U] = p.tw_tile[tile * p.Ra + kk];
-      w2[U] = p.tw_col[kk * W2 + cc];
-    });
-    static_for<EPI_U>([&](auto u) {
-      constexpr int U = decltype(u)::value;
-      const int k = k0 + U * rpi;
-      if (lane_on && k < p.Ra) {
-        float2 d;
-        if (odd) d = make_float2(a[U].x - b[U].x, a[U].y + b[U].y);   // a - conj(b)
-        else     d = make_float2(a[U].x + b[U].x, a[U].y - b[U].y);   // a + conj(b)
-        p.buf[(long)k * p.inner + 2 * c0 + cc] = cmul(d, cmul(w1[U], w2[U]));
-      }
-    });
-  }
+  static_for<NE>([&](auto uu) {
+    constexpr int U = decltype(uu)::value;
+    const int k = kr + U * rpi;
+    if (lane_on && k < p.Ra) {
+      const float2 a = lds[k * T + pc];
+      const float2 b = lds[(k == 0 ? 0 : NA - k) * T + pc];
+      float2 d;
+      if (odd) d = make_float2(a.x - b.x, a.y + b.y);   // a - conj(b)
+      else     d = make_float2(a.x + b.x, a.y - b.y);   // a + conj(b)
+      gout[(long)k * p.inner + 2 * c0 + cc] = cmul(d, cmul(we1[U], we2[U]));
+    }
+  });
 }
 
 // ------------------------------------------------------------------------------
@@ -197,38 +203,55 @@ __global__ void fwd_cols(ColsParams p) {
   const int row = blockIdx.x / tpr, ct = blockIdx.x - row * tpr;
   const int c0 = ct * T;
   const long base = (long)row * NP * p.inner + c0;
+  const float2* __restrict__ gin = p.in;
+  float2* __restrict__ gout = p.out;
+  const float2* __restrict__ tws = p.tw_sub;
+  const float2* __restrict__ twt = p.tw_tile;
+  const float2* __restrict__ twc = p.tw_col;
 
+  // The output twiddles of the SECOND layer depend only on (k1, column): fetch them first so
+  // their latency hides under the data loads and the first butterfly layer.
+  const int k1o = tid / T, to = tid - k1o * T;
+  const bool act2 = tid < R1 * T;
+  float2 wt[R2], wc[R2];
+  if (act2) {
+    static_for<R2>([&](auto k2) {
+      constexpr int K2 = decltype(k2)::value;
+      const int k = k1o + R1 * K2;
+      wt[K2] = twt[ct * NP + k];
+      wc[K2] = twc[k * T + to];
+    });
+  }
   if (tid < R2 * T) {
     const int j = tid / T, t = tid - j * T;
-    float2 v[R1];
+    float2 v[R1], w1[R1];
     static_for<R1>([&](auto q) {
       constexpr int Q = decltype(q)::value;
       long idx = base + (long)(j + Q * R2) * p.inner + t;
       if (p.in_len) { idx += p.in_start; if (idx >= p.in_len) idx -= p.in_len; }
-      v[Q] = p.in[idx];
+      v[Q] = gin[idx];
+      if constexpr (Q > 0) w1[Q] = tws[j * R1 + Q];
     });
     reg_dft<R1, -1>(v);
     static_for<R1>([&](auto k1) {
       constexpr int K1 = decltype(k1)::value;
       float2 x = v[K1];
-      if constexpr (K1 > 0) x = cmul(x, p.tw_sub[j * R1 + K1]);
+      if constexpr (K1 > 0) x = cmul(x, w1[K1]);
       lds[(K1 * R2 + j) * T + K1 * p.padk + t] = x;
     });
   }
   __syncthreads();
-  if (tid < R1 * T) {
-    const int k1 = tid / T, t = tid - k1 * T;
+  if (act2) {
     float2 u[R2];
     static_for<R2>([&](auto j) {
       constexpr int J = decltype(j)::value;
-      u[J] = lds[(k1 * R2 + J) * T + k1 * p.padk + t];
+      u[J] = lds[(k1o * R2 + J) * T + k1o * p.padk + to];
     });
     reg_dft<R2, -1>(u);
     static_for<R2>([&](auto k2) {
       constexpr int K2 = decltype(k2)::value;
-      const int k = k1 + R1 * K2;
-      const float2 w = cmul(p.tw_tile[ct * NP + k], p.tw_col[k * T + t]);
-      p.out[base + (long)k * p.inner + t] = cmul(u[K2], w);
+      const int k = k1o + R1 * K2;
+      gout[base + (long)k * p.inner + to] = cmul(u[K2], cmul(wt[K2], wc[K2]));
     });
   }
 }
@@ -246,6 +269,15 @@ __global__ void fwd_rows(RowsParams p) {
   const int a0 = at * Ta;
   const long rowstride = (long)p.Nb * NC;
 
+  // first-layer twiddles depend only on the lane: fetch them before anything else
+  const int j1 = tid / Ta, r1 = tid - j1 * Ta;
+  const bool act1 = tid < R2 * Ta;
+  const float2* __restrict__ tws = p.tw_sub;
+  float2 w1[R1];
+  static_for<R1>([&](auto q) {
+    constexpr int Q = decltype(q)::value;
+    if constexpr (Q > 0) w1[Q] = tws[(act1 ? j1 : 0) * R1 + Q];
+  });
   // coalesced row loads, transposed into LDS as [nc][r]; LOAD_U loads are in flight per lane
   constexpr int LOAD_U = 6;
   for (int e0 = tid; e0 < Ta * NC; e0 += nthr * LOAD_U) {
@@ -266,8 +298,8 @@ __global__ void fwd_rows(RowsParams p) {
     });
   }
   __syncthreads();
-  if (tid < R2 * Ta) {
-    const int j = tid / Ta, r = tid - j * Ta;
+  if (act1) {
+    const int j = j1, r = r1;
     float2 v[R1];
     static_for<R1>([&](auto q) {
       constexpr int Q = decltype(q)::value;
@@ -278,7 +310,7 @@ __global__ void fwd_rows(RowsParams p) {
     static_for<R1>([&](auto k1) {
       constexpr int K1 = decltype(k1)::value;
       float2 x = v[K1];
-      if constexpr (K1 > 0) x = cmul(x, p.tw_sub[j * R1 + K1]);
+      if constexpr (K1 > 0) x = cmul(x, w1[K1]);
       lds[(K1 * R2 + j) * ld + K1 * padg + r] = x;       // row K1*R2+j belongs to group K1
     });
   }
@@ -348,31 +380,39 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
   const int ch = p.ch0 + lc;
   const bool live = (cw < CPW) && (lc < p.nch);
   float2* my = lds + ((wave * CPW + (cw < CPW ? cw : 0)) * (R1 * LDC));
+  const float2* __restrict__ tws = p.tw_sub;
 
   if (live && jl < R2) {
     const ChanDesc d = p.desc[ch];
-    const float2* H = p.resp + (long)ch * P;
-    float2 v[R1];
+    const float2* __restrict__ H = p.resp + (long)ch * P;
+    const float2* __restrict__ X = p.spec;
+    // All 2*R1 loads are issued unconditionally (out-of-range bins read bin 0 and are
+    // zeroed afterwards) so they overlap instead of costing one round trip per bin.
+    float2 v[R1], h[R1];
+    bool ok[R1];
     static_for<R1>([&](auto q) {
       constexpr int Q = decltype(q)::value;
       const int i = jl + Q * R2;                           // FFT-order bin index
       int t = i - (P + 1) / 2; if (t < 0) t += P;          // rank from most negative bin
       const int u = t - d.t0;
-      float2 x = make_float2(0.f, 0.f);
-      if (u >= 0 && u < d.cnt && i != (P + 1) / 2) {       // Nyquist bin forced to zero (:911)
-        int src = d.src0 + d.dir * u;
-        if (d.wrap && src >= d.wrap) src -= d.wrap;
-        x = p.spec[src];
-        if (d.conj) x.y = -x.y;
-        x = cmul(x, H[i]);
-      }
-      v[Q] = x;
+      ok[Q] = (u >= 0) && (u < d.cnt) && (i != (P + 1) / 2);   // Nyquist bin forced to zero (:911)
+      int src = d.src0 + d.dir * u;
+      if (d.wrap && src >= d.wrap) src -= d.wrap;
+      v[Q] = X[ok[Q] ? src : 0];
+      h[Q] = H[i];
+    });
+    static_for<R1>([&](auto q) {
+      constexpr int Q = decltype(q)::value;
+      float2 x = v[Q];
+      if (d.conj) x.y = -x.y;
+      x = cmul(x, h[Q]);
+      v[Q] = ok[Q] ? x : make_float2(0.f, 0.f);
     });
     reg_dft<R1, +1>(v);
     static_for<R1>([&](auto k1) {
       constexpr int K1 = decltype(k1)::value;
       float2 x = v[K1];
-      if constexpr (K1 > 0) x = cmul(x, p.tw_sub[jl * R1 + K1]);
+      if constexpr (K1 > 0) x = cmul(x, tws[jl * R1 + K1]);
       my[K1 * LDC + jl] = x;
     });
   }
