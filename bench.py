@@ -181,7 +181,7 @@ def main():
         gpu_ms = timing.total_ms
     else:
         # spectrum slots are torch tensors so RCCL can broadcast into them
-        slots = [torch.zeros(2 * BINS, dtype=torch.float32, device="cuda") for _ in range(4)]
+        slots = [torch.zeros(2 * eng.spec_elems, dtype=torch.float32, device="cuda") for _ in range(4)]
         for i, t in enumerate(slots):
             eng.attach_spectrum(i, t.data_ptr())
         eng.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -35,7 +35,14 @@ typedef struct chz_info {
   int ring_blocks;          /* device input ring holds ring_blocks*L samples */
   int Na, Nb, Nc;           /* axis lengths of the forward transform */
   int n_banks;
-  char plan[256];           /* human-readable plan description */
+  int lanes;                /* HIP streams blocks are pipelined over */
+  /* device storage order of a spectrum slot: bin k at [(k / spec_na) * spec_pitch + spec_off + k % spec_na];
+   * natural order when spec_pitch == spec_na and spec_off == 0.  chz_spectrum_read returns natural
+   * order; code that touches the device buffer directly (chz_spectrum_device / _attach, e.g. an RCCL
+   * broadcast) must treat it as spec_elems opaque complex values. */
+  long spec_elems;
+  int spec_na, spec_pitch, spec_off;
+  char plan[320];           /* human-readable plan description */
 } chz_info;
 
 typedef struct chz_timing {
@@ -79,8 +86,8 @@ int chz_forward(chz_engine *e, unsigned job);
 int chz_set_notches(chz_engine *e, const int *bins, int n, double alpha);
 int chz_spectrum_read(chz_engine *e, int slot, float *host);     /* 2*bins floats, synchronous */
 int chz_spectrum_device(chz_engine *e, int slot, float **dev);
-/* point a slot at caller-owned device memory (2*bins floats), e.g. a torch tensor
- * that RCCL broadcasts into */
+/* point a slot at caller-owned device memory (2*spec_elems floats, see chz_info), e.g. a torch
+ * tensor that RCCL broadcasts into */
 int chz_spectrum_attach(chz_engine *e, int slot, float *dev);
 
 /* A bank = all channels sharing one (P, olen); replaces create_filter_output's

@@ -133,8 +133,8 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   HIPOK(hipMemset(e->ring, 0, sizeof(float) * (size_t)e->ring_len));       // src/filter.c:242,257
   e->wpos = (long)(M - 1) * e->per;                                          // src/filter.c:244,259
   for (int i = 0; i < CHZ_ND; i++) {
-    HIPOK(hipMalloc((void**)&e->spec[i], sizeof(float2) * (size_t)bins));
-    HIPOK(hipMemset(e->spec[i], 0, sizeof(float2) * (size_t)bins));
+    HIPOK(hipMalloc((void**)&e->spec[i], sizeof(float2) * (size_t)e->plan.spec_elems));
+    HIPOK(hipMemset(e->spec[i], 0, sizeof(float2) * (size_t)e->plan.spec_elems));
     e->spec_owned[i] = true;
   }
   int r;
@@ -178,6 +178,8 @@ int chz_engine_info(const chz_engine* e, chz_info* info) {
   info->L = e->L; info->M = e->M; info->N = e->N; info->in_type = e->in_type; info->bins = e->bins;
   info->ring_blocks = e->ring_blocks; info->Na = e->plan.Na; info->Nb = e->plan.Nb; info->Nc = e->plan.Nc;
   info->n_banks = (int)e->banks.size();
+  info->spec_elems = e->plan.spec_elems; info->spec_na = e->plan.Na; info->spec_pitch = e->plan.spec_pitch; info->spec_off = e->plan.spec_off;
+  info->lanes = e->nlanes;
   snprintf(info->plan, sizeof info->plan, "%s", e->plan.desc.c_str());
   return 0;
 }
@@ -282,6 +284,7 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
     mark(in, st, 1, false);
   }
   RowsParams c{};
+  c.lay = SpecLayout{p.Na, p.spec_pitch, p.spec_off}; c.ka_shift = p.ka_shift;
   c.buf = lbuf; c.spec = e->spec[slot]; c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3;
   c.padg = p.padg3; c.N = p.N; c.mirror = e->in_type == CHZ_REAL; c.tw_sub = e->tw_sub_c;
   c.n_notch = e->n_notch; c.notch_bins = e->notch_bins; c.notch_state = e->notch_state; c.notch_alpha = e->notch_alpha;
@@ -306,6 +309,7 @@ static int enqueue_bank(chz_engine* e, int bank, int slot, Instr* in, int ch0 = 
   hipStream_t st = e->lanes[lane_of(e, (unsigned)slot, in)].s;
   b.last_slot = slot;
   ChanParams c{};
+  c.lay = SpecLayout{e->plan.Na, e->plan.spec_pitch, e->plan.spec_off}; c.inv_na = 1.0f / (float)e->plan.Na;
   c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc; c.out = bank_out(b, slot); c.ch0 = ch0; c.nch = n; c.olen = b.olen;
   c.tw_sub = b.tw_sub;
   const int per_block = b.g.wpb * b.g.cpw;
@@ -342,10 +346,30 @@ int chz_set_notches(chz_engine* e, const int* bins, int n, double alpha) {
 
 static inline hipStream_t slot_stream(chz_engine* e, int slot) { return e->lanes[slot % e->nlanes].s; }
 
+// device spectrum (SpecLayout order) -> host, natural bin order: whole rows as one 2-D copy, then
+// the partial last row
+static int copy_spectrum(chz_engine* e, int slot, float* host, hipStream_t st) {
+  const FwdPlan& p = e->plan;
+  const float2* src = e->spec[slot];
+  if (p.spec_pitch == p.Na && p.spec_off == 0) {
+    HIPOK(hipMemcpyAsync(host, src, sizeof(float2) * (size_t)e->bins, hipMemcpyDeviceToHost, st));
+    return 0;
+  }
+  const long full = e->bins / p.Na, rest = e->bins - full * p.Na;
+  if (full > 0)
+    HIPOK(hipMemcpy2DAsync(host, sizeof(float2) * (size_t)p.Na, src + p.spec_off, sizeof(float2) * (size_t)p.spec_pitch,
+                           sizeof(float2) * (size_t)p.Na, (size_t)full, hipMemcpyDeviceToHost, st));
+  if (rest > 0)
+    HIPOK(hipMemcpyAsync(host + 2 * full * p.Na, src + full * p.spec_pitch + p.spec_off, sizeof(float2) * (size_t)rest,
+                         hipMemcpyDeviceToHost, st));
+  return 0;
+}
+
 int chz_spectrum_read(chz_engine* e, int slot, float* host) {
   if (!e || !host || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   hipStream_t st = slot_stream(e, slot);          // the lane that produced this slot
-  HIPOK(hipMemcpyAsync(host, e->spec[slot], sizeof(float2) * (size_t)e->bins, hipMemcpyDeviceToHost, st));
+  int r = copy_spectrum(e, slot, host, st);
+  if (r) return r;
   HIPOK(hipStreamSynchronize(st));
   return 0;
 }
@@ -455,8 +479,7 @@ int chz_bank_read_async(chz_engine* e, int bank, int slot, int ch0, int n, float
 }
 int chz_spectrum_read_async(chz_engine* e, int slot, float* host) {
   if (!e || !host || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
-  HIPOK(hipMemcpyAsync(host, e->spec[slot], sizeof(float2) * (size_t)e->bins, hipMemcpyDeviceToHost, slot_stream(e, slot)));
-  return 0;
+  return copy_spectrum(e, slot, host, slot_stream(e, slot));
 }
 int chz_host_callback(chz_engine* e, int slot, void (*fn)(void*), void* arg) {
   if (!e || !fn || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");

@@ -63,11 +63,23 @@ struct ColsParams {
   const float2* tw_col;   // [NP][T]       W_(NP*inner)^(k * t)
 };
 
+// Spectrum storage: bin k = ka + Na*x lives at  spec[x*pitch + off + ka].  pitch = Na, off = 0 is
+// the natural order.  For a real master with odd Na the planner picks pitch = a multiple of 16 and
+// an offset such that BOTH the direct 16-bin store segments and the conjugate-mirrored ones start on
+// 128-byte lines (misaligned 128-byte segments cost ~2x on this chip).
+struct SpecLayout { int na, pitch, off; };
+__host__ __device__ __forceinline__ long spec_addr(const SpecLayout& l, long k) {
+  const long x = k / l.na;
+  return x * l.pitch + l.off + (k - x * l.na);
+}
+
 struct RowsParams {
   const float2* buf;      // [Ra][Nb][Nc]
-  float2* spec;           // out: master spectrum, `bins` complex
+  float2* spec;           // out: master spectrum in SpecLayout order
+  SpecLayout lay;
   int Ra, Na, Nb;         // rows kept, axis-a length, axis-b length
   int Ta;                 // ka values per tile
+  int ka_shift;           // tile t covers ka in [t*Ta - ka_shift, (t+1)*Ta - ka_shift)
   int ld, padg;           // LDS leading dimension (Ta+1) and per-group padding
   long N;                 // full transform length
   int mirror;             // 1: real master (bins N/2+1, conj-mirror store); 0: complex master
@@ -88,7 +100,9 @@ struct RowsParams {
 struct ChanDesc { int t0, cnt, src0, dir, conj, wrap; };
 
 struct ChanParams {
-  const float2* spec;     // master spectrum of this block
+  const float2* spec;     // master spectrum of this block (SpecLayout order)
+  SpecLayout lay;
+  float inv_na;           // 1/na, for the bin -> (row, column) split
   const float2* resp;     // [nch][P] frequency responses
   const ChanDesc* desc;   // [nch]
   float2* out;            // [nch][olen]
@@ -266,7 +280,7 @@ __global__ void fwd_rows(RowsParams p) {
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int Ta = p.Ta, ld = p.ld, padg = p.padg;
   const int kb = blockIdx.x % p.Nb, at = blockIdx.x / p.Nb;
-  const int a0 = at * Ta;
+  const int a0 = at * Ta - p.ka_shift;           // may be negative for the first (ragged) tile
   const long rowstride = (long)p.Nb * NC;
 
   // first-layer twiddles depend only on the lane: fetch them before anything else
@@ -288,7 +302,7 @@ __global__ void fwd_rows(RowsParams p) {
       const int r = e / NC, nc = e - r * NC;
       const int ka = a0 + r;
       x[U] = make_float2(0.f, 0.f);
-      if (e < Ta * NC && ka < p.Ra) x[U] = p.buf[(long)ka * rowstride + (long)kb * NC + nc];
+      if (e < Ta * NC && ka >= 0 && ka < p.Ra) x[U] = p.buf[(long)ka * rowstride + (long)kb * NC + nc];
     });
     static_for<LOAD_U>([&](auto u) {
       constexpr int U = decltype(u)::value;
@@ -331,7 +345,7 @@ __global__ void fwd_rows(RowsParams p) {
       if (p.mirror && 2 * qa > p.Na) { k = p.N - b; qa = (int)(k % p.Na); mir = true; }
       const long rest = k / p.Na;
       const int qb = (int)(rest % p.Nb), qc = (int)(rest / p.Nb);
-      if (qb == kb && qa == ka && (qc % R1) == k1) {  // this lane holds the bin
+      if (qb == kb && qa == ka && ka >= 0 && (qc % R1) == k1) {  // this lane holds the bin
         const int q2 = qc / R1;
         static_for<R2>([&](auto k2) {
           constexpr int K2 = decltype(k2)::value;
@@ -347,14 +361,17 @@ __global__ void fwd_rows(RowsParams p) {
         });
       }
     }
-    if (ka < p.Ra) {
+    if (ka >= 0 && ka < p.Ra) {
       const bool selfconj = (ka == 0) || (2 * ka == p.Na);
       const long half = p.N >> 1;
+      const long xrows = p.N / p.Na;               // = Nb*Nc
+      float2* __restrict__ sp = p.spec;
       static_for<R2>([&](auto k2) {
         constexpr int K2 = decltype(k2)::value;
-        const long k = ka + (long)p.Na * (kb + (long)p.Nb * (k1 + R1 * K2));
-        if (!p.mirror || k <= half) p.spec[k] = u[K2];
-        else if (!selfconj) p.spec[p.N - k] = cconj(u[K2]);
+        const long x = kb + (long)p.Nb * (k1 + R1 * K2);
+        const long k = ka + (long)p.Na * x;
+        if (!p.mirror || k <= half) sp[x * p.lay.pitch + p.lay.off + ka] = u[K2];
+        else if (!selfconj) sp[(xrows - 1 - x) * p.lay.pitch + p.lay.off + (p.Na - ka)] = cconj(u[K2]);   // bin N-k
       });
     }
   }
@@ -398,7 +415,11 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
       ok[Q] = (u >= 0) && (u < d.cnt) && (i != (P + 1) / 2);   // Nyquist bin forced to zero (:911)
       int src = d.src0 + d.dir * u;
       if (d.wrap && src >= d.wrap) src -= d.wrap;
-      v[Q] = X[ok[Q] ? src : 0];
+      if (!ok[Q]) src = 0;
+      int row = (int)((float)src * p.inv_na);               // src < 2^24: the estimate is off by at most one
+      int col = src - row * p.lay.na;
+      if (col < 0) { row--; col += p.lay.na; } else if (col >= p.lay.na) { row++; col -= p.lay.na; }
+      v[Q] = X[(long)row * p.lay.pitch + p.lay.off + col];
       h[Q] = H[i];
     });
     static_for<R1>([&](auto q) {

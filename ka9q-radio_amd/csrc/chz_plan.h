@@ -15,8 +15,8 @@ namespace chz {
 
 // (R1,R2) pairs with a compiled kernel instantiation.  Sub-transform length = R1*R2.
 #define CHZ_FWD_MENU(X) \
-  X(4, 4) X(5, 5) X(6, 6) X(5, 10) X(8, 8) X(8, 9) X(9, 9) X(10, 10) X(10, 12) X(12, 12) \
-  X(10, 15) X(12, 15) X(15, 15) X(16, 16) X(20, 20)
+  X(4, 4) X(5, 5) X(6, 6) X(5, 9) X(5, 10) X(8, 8) X(8, 9) X(9, 9) X(10, 10) X(10, 12) X(5, 25) X(9, 15) \
+  X(12, 12) X(10, 15) X(10, 16) X(12, 15) X(12, 16) X(15, 15) X(15, 16) X(16, 16) X(16, 20) X(20, 20)
 // per-channel backward transform lengths P = R1*R2 (reference sizes: docs/FFTW3.md:51-68)
 #define CHZ_CHAN_MENU(X) \
   X(4, 5) X(5, 6) X(10, 15) X(10, 16) X(10, 20) X(15, 20) X(16, 20) X(20, 20) X(20, 24) \
@@ -79,6 +79,8 @@ struct FwdPlan {
   int inner = 0;                       // Nb*Nc
   int T1 = 0, T2 = 0, Ta = 0;          // tile widths: first axis (packed cols if real), axis b, last axis
   int padk1 = 0, padk2 = 0, ld3 = 0, padg3 = 0;
+  int spec_pitch = 0, spec_off = 0, ka_shift = 0;   // spectrum storage (see SpecLayout in chz_kernels.h)
+  long spec_elems = 0;                              // float2 elements of one spectrum slot
   int grid1 = 0, block1 = 0, grid2 = 0, block2 = 0, grid3 = 0, block3 = 0;
   size_t lds1 = 0, lds2 = 0, lds3 = 0;
   std::vector<f2> tw_sub_a, tw_sub_b, tw_sub_c, tw1_tile, tw1_col, tw2_tile, tw2_col;
@@ -93,7 +95,8 @@ inline int pick_tile(int n, int want, int lo, int hi, int lanes_per_col, int max
   for (int t = 1; t <= n && t <= hi; t++) {
     if (n % t) continue;
     if (t * lanes_per_col > max_threads) continue;
-    double score = std::fabs(std::log((double)t / want)) + (t < lo ? 1.0 : 0.0);
+    // 16 float2 = one 128-byte line: aligned whole-line tiles are worth a lot
+    double score = std::fabs(std::log((double)t / want)) + (t < lo ? 1.0 : 0.0) - (t % 16 == 0 ? 0.75 : 0.0);
     if (score < bestscore) { bestscore = score; best = t; }
   }
   return best;
@@ -140,7 +143,7 @@ inline bool finish_fwd_plan(FwdPlan& p, int T1_over, int T2_over, int Ta_over) {
   // ---- axis b
   if (p.Nb > 1) {
     const int lb = p.rb.r1 > p.rb.r2 ? p.rb.r1 : p.rb.r2;
-    p.T2 = T2_over > 0 ? T2_over : pick_tile(p.Nc, 24, 8, 64, lb, 1024);
+    p.T2 = T2_over > 0 ? T2_over : pick_tile(p.Nc, 16, 8, 64, lb, 1024);
     if (p.T2 <= 0 || p.Nc % p.T2) return false;
     const int tpr = p.Nc / p.T2;
     p.grid2 = p.Ra * tpr;
@@ -161,17 +164,32 @@ inline bool finish_fwd_plan(FwdPlan& p, int T1_over, int T2_over, int Ta_over) {
   p.Ta = Ta_over > 0 ? Ta_over : 16;
   if (p.Ta > p.Ra) p.Ta = p.Ra;
   while (lc * p.Ta > 1024) p.Ta--;
+  // spectrum storage: natural order unless a real master with odd Na lets both the direct and the
+  // conjugate-mirrored 16-bin store segments start on 128-byte lines:
+  //   direct segment of tile [a0, a0+16) starts at off + a0, mirrored one at off + Na - a0 - 15
+  //   => off = s with 2s = 15 - Na (mod 16), tiles start at a0 = -s (mod 16)
+  p.spec_pitch = p.Na; p.spec_off = 0; p.ka_shift = 0;
+  if (real && (p.Na & 1) && p.Ta == 16 && p.Nc % 16 == 0) {
+    int s2 = ((15 - p.Na) % 16 + 16) % 16;          // even because Na is odd
+    p.spec_off = s2 / 2;
+    p.ka_shift = p.spec_off;
+    p.spec_pitch = round_up(p.spec_off + p.Na, 16);
+  }
+  {
+    const long xrows = real ? ((long)p.N / 2) / p.Na + 1 : (long)p.N / p.Na;
+    p.spec_elems = xrows * p.spec_pitch + 16;
+  }
   p.ld3 = p.Ta + 1 + (p.Ta & 1);                 // odd leading dimension
   if (!(p.ld3 & 1)) p.ld3++;
   p.padg3 = (16 - (p.rc.r2 * p.ld3) % 32 + 32) % 32;
-  p.grid3 = p.Nb * ((p.Ra + p.Ta - 1) / p.Ta);
+  p.grid3 = p.Nb * ((p.Ra + p.ka_shift + p.Ta - 1) / p.Ta);
   p.block3 = round_up(lc * p.Ta, 64);
   p.lds3 = sizeof(f2) * ((size_t)p.Nc * p.ld3 + (size_t)p.rc.r1 * p.padg3 + 8);
   p.tw_sub_c = make_tw_sub(p.rc.r1, p.rc.r2, -1);
   char b[256];
-  snprintf(b, sizeof b, "N=%d %s axes %dx%dx%d radices (%d,%d)(%d,%d)(%d,%d) tiles T1=%d T2=%d Ta=%d grids %d/%d/%d blocks %d/%d/%d",
+  snprintf(b, sizeof b, "N=%d %s axes %dx%dx%d radices (%d,%d)(%d,%d)(%d,%d) tiles T1=%d T2=%d Ta=%d grids %d/%d/%d blocks %d/%d/%d spec pitch %d off %d",
            p.N, real ? "real" : "complex", p.Na, p.Nb, p.Nc, p.ra.r1, p.ra.r2, p.rb.r1, p.rb.r2, p.rc.r1, p.rc.r2,
-           p.T1, p.T2, p.Ta, p.grid1, p.grid2, p.grid3, p.block1, p.block2, p.block3);
+           p.T1, p.T2, p.Ta, p.grid1, p.grid2, p.grid3, p.block1, p.block2, p.block3, p.spec_pitch, p.spec_off);
   p.desc = b;
   return true;
 }
@@ -226,7 +244,12 @@ inline bool build_fwd_plan(int N, int in_type, const char* spec, FwdPlan& out) {
       double passes = b > 1 ? 3.0 : 2.0;
       int mingrid = p.grid1 < p.grid3 ? p.grid1 : p.grid3;
       if (b > 1 && p.grid2 < mingrid) mingrid = p.grid2;
-      double score = passes + (mingrid < 512 ? 512.0 / (mingrid + 1) : 0.0) + (a % 16 ? 0.15 : 0.0) +
+      // 128-byte aligned 16-column tiles run at copy speed, misaligned ones at about half of it
+      const bool al1 = real ? (p.T1 % 16 == 0) : (p.T1 % 16 == 0);
+      const bool al2 = (b == 1) || (p.T2 % 16 == 0 && c % 16 == 0);
+      const bool al3 = real ? (p.spec_off != 0 || (a % 16 == 0)) : (a % 16 == 0);
+      double score = passes + (mingrid < 400 ? 400.0 / (mingrid + 1) : 0.0) +
+                     (al1 ? 0.0 : 0.6) + (al2 ? 0.0 : 0.6) + (al3 ? 0.0 : 0.4) +
                      (p.T1 < 8 ? 0.5 : 0.0) + (b > 1 && p.T2 < 8 ? 0.5 : 0.0);
       if (score < best) { best = score; bestp = p; found = true; }
     }

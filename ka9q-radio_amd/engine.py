@@ -19,7 +19,8 @@ _vp, _i, _u, _d, _l = C.c_void_p, C.c_int, C.c_uint, C.c_double, C.c_long
 
 class ChzInfo(C.Structure):
     _fields_ = [("L", _i), ("M", _i), ("N", _i), ("in_type", _i), ("bins", _i), ("ring_blocks", _i),
-                ("Na", _i), ("Nb", _i), ("Nc", _i), ("n_banks", _i), ("plan", C.c_char * 256)]
+                ("Na", _i), ("Nb", _i), ("Nc", _i), ("n_banks", _i), ("lanes", _i), ("spec_elems", _l),
+                ("spec_na", _i), ("spec_pitch", _i), ("spec_off", _i), ("plan", C.c_char * 320)]
 
 
 class ChzTiming(C.Structure):
@@ -110,6 +111,9 @@ class Engine:
         self.ring_blocks = info.ring_blocks
         self.plan = info.plan.decode()
         self.axes = (info.Na, info.Nb, info.Nc)
+        self.lanes = info.lanes
+        self.spec_elems = info.spec_elems
+        self.spec_layout = (info.spec_na, info.spec_pitch, info.spec_off)
         self.banks = []
 
     def close(self):

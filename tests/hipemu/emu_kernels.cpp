@@ -43,11 +43,15 @@ int emu_forward(const float* ring, long ring_len, long start, int N, int in_type
     if (launch_cols(p.rb, p.grid2, p.block2, p.lds2, nullptr, b)) return -3;
   }
   RowsParams c{};
-  c.buf = buf.data(); c.spec = reinterpret_cast<float2*>(spectrum);
+  std::vector<float2> spec_dev((size_t)p.spec_elems, make_float2(0.f, 0.f));
+  c.lay = SpecLayout{p.Na, p.spec_pitch, p.spec_off}; c.ka_shift = p.ka_shift;
+  c.buf = buf.data(); c.spec = spec_dev.data();
   c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3; c.padg = p.padg3; c.N = p.N;
   c.mirror = in_type == CHZ_IN_REAL; c.tw_sub = F2(p.tw_sub_c);
   c.n_notch = n_notch; c.notch_bins = notch_bins; c.notch_state = notch_state; c.notch_alpha = notch_alpha;
   if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, nullptr, c)) return -4;
+  float2* out = reinterpret_cast<float2*>(spectrum);
+  for (long k = 0; k < p.bins; k++) out[k] = spec_dev[(size_t)spec_addr(c.lay, k)];   // back to natural order
   return 0;
 }
 
@@ -58,16 +62,20 @@ int emu_chan_desc(int in_type, int m_bins, int P, int shift, int* out6) {
 }
 
 int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, int nch,
-                 const float* resp, const int* shifts, float* out) {
+                 const float* resp, const int* shifts, float* out, int lay_na, int lay_pitch, int lay_off) {
   ChanGeom g;
   if (!build_chan_geom(P, g)) return -1;
+  SpecLayout lay{lay_na > 0 ? lay_na : m_bins, lay_na > 0 ? lay_pitch : m_bins, lay_na > 0 ? lay_off : 0};
+  std::vector<float2> spec_dev((size_t)((long)(m_bins / lay.na + 2) * lay.pitch + 16), make_float2(0.f, 0.f));
+  for (long k = 0; k < m_bins; k++) spec_dev[(size_t)spec_addr(lay, k)] = reinterpret_cast<const float2*>(spec)[k];
   std::vector<ChanDesc> desc((size_t)nch);
   for (int i = 0; i < nch; i++) {
     ChanDescH h = make_chan_desc(in_type, m_bins, P, shifts[i]);
     desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
   }
   ChanParams c{};
-  c.spec = reinterpret_cast<const float2*>(spec); c.resp = reinterpret_cast<const float2*>(resp);
+  c.spec = spec_dev.data(); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
+  c.resp = reinterpret_cast<const float2*>(resp);
   c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub);
   const int per_block = g.wpb * g.cpw;

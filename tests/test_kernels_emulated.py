@@ -30,7 +30,7 @@ def emu(oracle_built):
     lib = C.CDLL(so)
     lib.emu_forward.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_double]
-    lib.emu_channels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emu_channels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     return lib
 
 
@@ -43,6 +43,7 @@ def rel(a, b):
     (32400, ol.REAL, b"81x400", 0), (32400, ol.REAL, b"225x144", 100), (14400, ol.REAL, b"36x400", 15002),
     (14400, ol.COMPLEX, b"", 0), (14400, ol.COMPLEX, b"16x25x36", 3000), (60000, ol.COMPLEX, b"", 0),
     (162000, ol.REAL, b"", 0), (64800, ol.REAL, b"72x25x36", 65000),
+    (86400, ol.REAL, b"135x640"[:0] + b"45x16x120", 0), (162000, ol.REAL, b"81x2000"[:0] + b"45x25x144", 1024), (57600, ol.REAL, b"25x16x144", 0),
 ])
 def test_forward_kernels(emu, N, in_type, spec, start):
     rng = np.random.default_rng(N + start)
@@ -71,7 +72,8 @@ def test_channel_kernel(emu, in_type, B, P, olen):
     resp = (rng.standard_normal((nch, P)) + 1j * rng.standard_normal((nch, P))).astype(np.complex64)
     sh = np.array(shifts, np.int32)
     out = np.zeros((nch, olen), np.complex64)
-    assert emu.emu_channels(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, out.ctypes.data) == 0
+    lay = (0, 0, 0) if P % 2 else (135, 144, 4)      # natural order, or the padded layout of a 135-point first axis
+    assert emu.emu_channels(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, out.ctypes.data, *lay) == 0
     s64 = spec.astype(np.complex128)
     for i, s in enumerate(shifts):
         want = ol.channel(s64, in_type, P, olen, s, resp[i])
