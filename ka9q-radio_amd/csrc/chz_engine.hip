@@ -59,7 +59,7 @@ struct chz_engine {
   bool spec_owned[CHZ_ND] = {false, false, false, false};
   float2 *tw_sub_a = nullptr, *tw_sub_b = nullptr, *tw_sub_c = nullptr;
   float2 *tw1_tile = nullptr, *tw1_col = nullptr, *tw2_tile = nullptr, *tw2_col = nullptr;
-  int n_notch = 0; int* notch_bins = nullptr; double* notch_state = nullptr; double notch_alpha = 0;
+  int n_notch = 0; NotchLoc* notch_loc = nullptr; double* notch_state = nullptr; double notch_alpha = 0;
   std::vector<Bank> banks;
   hipGraphExec_t graph = nullptr; unsigned graph_job0 = 0; int graph_blocks = 0; size_t graph_sig = 0;
 };
@@ -167,7 +167,7 @@ void chz_engine_destroy(chz_engine* e) {
   for (int i = 0; i < CHZ_ND; i++) if (e->spec_owned[i]) hipFree(e->spec[i]);
   hipFree(e->tw_sub_a); hipFree(e->tw_sub_b); hipFree(e->tw_sub_c);
   hipFree(e->tw1_tile); hipFree(e->tw1_col); hipFree(e->tw2_tile); hipFree(e->tw2_col);
-  hipFree(e->notch_bins); hipFree(e->notch_state);
+  hipFree(e->notch_loc); hipFree(e->notch_state);
   if (e->own_stream) hipStreamDestroy(e->stream);
   delete e;
 }
@@ -287,7 +287,7 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
   c.lay = SpecLayout{p.Na, p.spec_pitch, p.spec_off}; c.ka_shift = p.ka_shift;
   c.buf = lbuf; c.spec = e->spec[slot]; c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3;
   c.padg = p.padg3; c.N = p.N; c.mirror = e->in_type == CHZ_REAL; c.tw_sub = e->tw_sub_c;
-  c.n_notch = e->n_notch; c.notch_bins = e->notch_bins; c.notch_state = e->notch_state; c.notch_alpha = e->notch_alpha;
+  c.n_notch = e->n_notch; c.notch_loc = e->notch_loc; c.notch_state = e->notch_state; c.notch_alpha = e->notch_alpha;
   if (e->n_notch > 0 && e->nlanes > 1 && !(in && in->on)) {
     // the notch state is sequential across blocks: this block's fwd_rows after the previous block's
     const int prev = (int)((job + (unsigned)e->nlanes - 1u) % (unsigned)e->nlanes);
@@ -333,12 +333,24 @@ int chz_set_notches(chz_engine* e, const int* bins, int n, double alpha) {
   if (!e) return fail(-1, "null engine");
   { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
-  hipFree(e->notch_bins); hipFree(e->notch_state); e->notch_bins = nullptr; e->notch_state = nullptr; e->n_notch = 0;
+  hipFree(e->notch_loc); hipFree(e->notch_state); e->notch_loc = nullptr; e->notch_state = nullptr; e->n_notch = 0;
   if (n <= 0 || !bins) return 0;
-  for (int i = 0; i < n; i++) if (bins[i] < 0 || bins[i] >= e->bins) return fail(-1, "notch bin %d out of range", bins[i]);
-  HIPOK(hipMalloc((void**)&e->notch_bins, sizeof(int) * (size_t)n));
+  const FwdPlan& p = e->plan;
+  std::vector<NotchLoc> loc((size_t)n);
+  for (int i = 0; i < n; i++) {
+    if (bins[i] < 0 || bins[i] >= e->bins) return fail(-1, "notch bin %d out of range", bins[i]);
+    // which row / register of fwd_rows produces this bin (k = ka + Na*(kb + Nb*kc); the upper half
+    // of a real master's row lands conjugated at N-k)
+    long k = bins[i]; int mir = 0;
+    int qa = (int)(k % p.Na);
+    if (e->in_type == CHZ_REAL && 2 * qa > p.Na) { k = (long)p.N - bins[i]; qa = (int)(k % p.Na); mir = 1; }
+    const long rest = k / p.Na;
+    const int qb = (int)(rest % p.Nb), qc = (int)(rest / p.Nb);
+    loc[(size_t)i] = NotchLoc{qa, qb, qc % p.rc.r1, qc / p.rc.r1, mir};
+  }
+  HIPOK(hipMalloc((void**)&e->notch_loc, sizeof(NotchLoc) * (size_t)n));
   HIPOK(hipMalloc((void**)&e->notch_state, sizeof(double) * 2 * (size_t)n));
-  HIPOK(hipMemcpy(e->notch_bins, bins, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(e->notch_loc, loc.data(), sizeof(NotchLoc) * (size_t)n, hipMemcpyHostToDevice));
   HIPOK(hipMemset(e->notch_state, 0, sizeof(double) * 2 * (size_t)n));
   e->n_notch = n; e->notch_alpha = alpha;
   return 0;

@@ -73,6 +73,11 @@ __host__ __device__ __forceinline__ long spec_addr(const SpecLayout& l, long k) 
   return x * l.pitch + l.off + (k - x * l.na);
 }
 
+// Where a notched bin is produced inside fwd_rows (computed on the host from the plan):
+// row (ka, kb) of the intermediate buffer, output index kc = k1 + R1*k2 of that row's transform,
+// mir != 0 if the bin is stored through the conjugate mirror (bin N-k of that row).
+struct NotchLoc { int ka, kb, k1, k2, mir; };
+
 struct RowsParams {
   const float2* buf;      // [Ra][Nb][Nc]
   float2* spec;           // out: master spectrum in SpecLayout order
@@ -87,8 +92,8 @@ struct RowsParams {
   // spur notches (src/filter.c:464-474), applied to the owning lane's register just before
   // the store; state is float64 and persists on the device across blocks
   int n_notch;
-  const int* notch_bins;  // n_notch bin indices
-  double* notch_state;    // 2 doubles per entry
+  const NotchLoc* notch_loc;  // n_notch entries: which lane/register of which workgroup holds the bin
+  double* notch_state;        // 2 doubles per entry
   double notch_alpha;
 };
 
@@ -149,10 +154,13 @@ __global__ void fwd_first_real(FirstRealParams p) {
   if (tid < R2 * T) {
     const int j = tid / T, t = tid - j * T;
     float2 v[R1], w1[R1];
+    long f64 = start2 + (long)j * inner2 + c0 + t;
+    if (f64 >= ring2_len) f64 -= ring2_len;
+    const int first = (int)f64, len = (int)ring2_len, qstep = R2 * (int)inner2;   // 32-bit from here on
     static_for<R1>([&](auto q) {
       constexpr int Q = decltype(q)::value;
-      long idx = start2 + (long)(j + Q * R2) * inner2 + c0 + t;
-      if (idx >= ring2_len) idx -= ring2_len;
+      int idx = first + Q * qstep;                 // < 2*len: the window is shorter than the ring
+      if (idx >= len) idx -= len;
       v[Q] = ring2[idx];
       if constexpr (Q > 0) w1[Q] = tws[j * R1 + Q];
     });
@@ -161,7 +169,7 @@ __global__ void fwd_first_real(FirstRealParams p) {
       constexpr int K1 = decltype(k1)::value;
       float2 x = v[K1];
       if constexpr (K1 > 0) x = cmul(x, w1[K1]);
-      lds[(K1 * R2 + j) * T + K1 * p.padk + t] = x;
+      lds[j * T + t + K1 * (R2 * T + p.padk)] = x;
     });
   }
   __syncthreads();
@@ -172,7 +180,7 @@ __global__ void fwd_first_real(FirstRealParams p) {
   if (act2) {
     static_for<R2>([&](auto j) {
       constexpr int J = decltype(j)::value;
-      u[J] = lds[(k1 * R2 + J) * T + k1 * p.padk + t2];
+      u[J] = lds[k1 * (R2 * T + p.padk) + t2 + J * T];
     });
     reg_dft<R2, -1>(u);
   }
@@ -181,7 +189,7 @@ __global__ void fwd_first_real(FirstRealParams p) {
   if (act2) {
     static_for<R2>([&](auto k2) {
       constexpr int K2 = decltype(k2)::value;
-      lds[(k1 + R1 * K2) * T + t2] = u[K2];
+      lds[k1 * T + t2 + K2 * (R1 * T)] = u[K2];
     });
   }
   __syncthreads();
@@ -236,36 +244,53 @@ __global__ void fwd_cols(ColsParams p) {
       wc[K2] = twc[k * T + to];
     });
   }
+  const int gstep = R2 * T + p.padk;             // LDS distance between butterfly groups
   if (tid < R2 * T) {
     const int j = tid / T, t = tid - j * T;
     float2 v[R1], w1[R1];
-    static_for<R1>([&](auto q) {
-      constexpr int Q = decltype(q)::value;
-      long idx = base + (long)(j + Q * R2) * p.inner + t;
-      if (p.in_len) { idx += p.in_start; if (idx >= p.in_len) idx -= p.in_len; }
-      v[Q] = gin[idx];
-      if constexpr (Q > 0) w1[Q] = tws[j * R1 + Q];
-    });
+    // 32-bit offsets from one 64-bit base; the ring wrap (complex masters) is a compare per row
+    const int qstep = R2 * p.inner;
+    if (p.in_len) {
+      const int first = (int)((base + p.in_start + (long)j * p.inner + t) % p.in_len);
+      const int len = (int)p.in_len;
+      static_for<R1>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        int idx = first + Q * qstep;               // first < len and Q*qstep < N <= len: one wrap at most
+        if (idx >= len) idx -= len;
+        v[Q] = gin[idx];
+        if constexpr (Q > 0) w1[Q] = tws[j * R1 + Q];
+      });
+    } else {
+      const float2* __restrict__ g0 = gin + base + (long)j * p.inner + t;
+      static_for<R1>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        v[Q] = g0[Q * qstep];
+        if constexpr (Q > 0) w1[Q] = tws[j * R1 + Q];
+      });
+    }
     reg_dft<R1, -1>(v);
+    const int l1 = j * T + t;
     static_for<R1>([&](auto k1) {
       constexpr int K1 = decltype(k1)::value;
       float2 x = v[K1];
       if constexpr (K1 > 0) x = cmul(x, w1[K1]);
-      lds[(K1 * R2 + j) * T + K1 * p.padk + t] = x;
+      lds[l1 + K1 * gstep] = x;
     });
   }
   __syncthreads();
   if (act2) {
     float2 u[R2];
+    const int l2 = k1o * gstep + to;
     static_for<R2>([&](auto j) {
       constexpr int J = decltype(j)::value;
-      u[J] = lds[(k1o * R2 + J) * T + k1o * p.padk + to];
+      u[J] = lds[l2 + J * T];
     });
     reg_dft<R2, -1>(u);
+    float2* __restrict__ o0 = gout + base + (long)k1o * p.inner + to;
+    const int ostep = R1 * p.inner;
     static_for<R2>([&](auto k2) {
       constexpr int K2 = decltype(k2)::value;
-      const int k = k1o + R1 * K2;
-      gout[base + (long)k * p.inner + to] = cmul(u[K2], cmul(wt[K2], wc[K2]));
+      o0[K2 * ostep] = cmul(u[K2], cmul(wt[K2], wc[K2]));
     });
   }
 }
@@ -281,7 +306,8 @@ __global__ void fwd_rows(RowsParams p) {
   const int Ta = p.Ta, ld = p.ld, padg = p.padg;
   const int kb = blockIdx.x % p.Nb, at = blockIdx.x / p.Nb;
   const int a0 = at * Ta - p.ka_shift;           // may be negative for the first (ragged) tile
-  const long rowstride = (long)p.Nb * NC;
+  const int rowstride = p.Nb * NC;               // all index math below is 32-bit: N < 2^31
+  const int gstep = R2 * ld + padg;              // LDS distance between butterfly groups
 
   // first-layer twiddles depend only on the lane: fetch them before anything else
   const int j1 = tid / Ta, r1 = tid - j1 * Ta;
@@ -294,84 +320,81 @@ __global__ void fwd_rows(RowsParams p) {
   });
   // coalesced row loads, transposed into LDS as [nc][r]; LOAD_U loads are in flight per lane
   constexpr int LOAD_U = 6;
+  const float2* __restrict__ gin = p.buf + (long)kb * NC;
   for (int e0 = tid; e0 < Ta * NC; e0 += nthr * LOAD_U) {
     float2 x[LOAD_U];
+    int la[LOAD_U];
     static_for<LOAD_U>([&](auto u) {
       constexpr int U = decltype(u)::value;
       const int e = e0 + U * nthr;
-      const int r = e / NC, nc = e - r * NC;
+      const int r = e / NC, nc = e - r * NC;       // NC is a compile-time constant
       const int ka = a0 + r;
+      la[U] = (e < Ta * NC) ? nc * ld + (nc / R2) * padg + r : -1;
       x[U] = make_float2(0.f, 0.f);
-      if (e < Ta * NC && ka >= 0 && ka < p.Ra) x[U] = p.buf[(long)ka * rowstride + (long)kb * NC + nc];
+      if (la[U] >= 0 && ka >= 0 && ka < p.Ra) x[U] = gin[ka * rowstride + nc];
     });
     static_for<LOAD_U>([&](auto u) {
       constexpr int U = decltype(u)::value;
-      const int e = e0 + U * nthr;
-      const int r = e / NC, nc = e - r * NC;
-      if (e < Ta * NC) lds[nc * ld + (nc / R2) * padg + r] = x[U];
+      if (la[U] >= 0) lds[la[U]] = x[U];
     });
   }
   __syncthreads();
   if (act1) {
-    const int j = j1, r = r1;
+    const int b1 = j1 * ld + r1;                   // row j1 + Q*R2 sits at b1 + Q*gstep
     float2 v[R1];
     static_for<R1>([&](auto q) {
       constexpr int Q = decltype(q)::value;
-      const int row = j + Q * R2;
-      v[Q] = lds[row * ld + (row / R2) * padg + r];
+      v[Q] = lds[b1 + Q * gstep];
     });
     reg_dft<R1, -1>(v);
     static_for<R1>([&](auto k1) {
       constexpr int K1 = decltype(k1)::value;
       float2 x = v[K1];
       if constexpr (K1 > 0) x = cmul(x, w1[K1]);
-      lds[(K1 * R2 + j) * ld + K1 * padg + r] = x;       // row K1*R2+j belongs to group K1
+      lds[b1 + K1 * gstep] = x;                    // in place: row K1*R2 + j1 (group K1)
     });
   }
   __syncthreads();
   if (tid < R1 * Ta) {
     const int k1 = tid / Ta, r = tid - k1 * Ta;
     const int ka = a0 + r;
+    const int b2 = k1 * gstep + r;
     float2 u[R2];
     static_for<R2>([&](auto j) {
       constexpr int J = decltype(j)::value;
-      u[J] = lds[(k1 * R2 + J) * ld + k1 * padg + r];
+      u[J] = lds[b2 + J * ld];
     });
     reg_dft<R2, -1>(u);
     for (int i = 0; i < p.n_notch; i++) {          // uniform trip count, normally 1 (DC) .. 21
-      const int b = p.notch_bins[i];
-      long k = b; bool mir = false;
-      int qa = (int)(k % p.Na);
-      if (p.mirror && 2 * qa > p.Na) { k = p.N - b; qa = (int)(k % p.Na); mir = true; }
-      const long rest = k / p.Na;
-      const int qb = (int)(rest % p.Nb), qc = (int)(rest / p.Nb);
-      if (qb == kb && qa == ka && ka >= 0 && (qc % R1) == k1) {  // this lane holds the bin
-        const int q2 = qc / R1;
+      const NotchLoc nl = p.notch_loc[i];
+      if (nl.kb == kb && nl.ka == ka && nl.k1 == k1) {   // this lane holds the bin
         static_for<R2>([&](auto k2) {
           constexpr int K2 = decltype(k2)::value;
-          if (K2 == q2) {
-            float2 x = mir ? cconj(u[K2]) : u[K2];
+          if (K2 == nl.k2) {
+            float2 x = nl.mir ? cconj(u[K2]) : u[K2];
             double sr = p.notch_state[2 * i], si = p.notch_state[2 * i + 1];
             sr += p.notch_alpha * ((double)x.x - sr);
             si += p.notch_alpha * ((double)x.y - si);
             p.notch_state[2 * i] = sr; p.notch_state[2 * i + 1] = si;
             x = make_float2((float)((double)x.x - sr), (float)((double)x.y - si));
-            u[K2] = mir ? cconj(x) : x;
+            u[K2] = nl.mir ? cconj(x) : x;
           }
         });
       }
     }
     if (ka >= 0 && ka < p.Ra) {
       const bool selfconj = (ka == 0) || (2 * ka == p.Na);
-      const long half = p.N >> 1;
-      const long xrows = p.N / p.Na;               // = Nb*Nc
+      const int half = (int)(p.N >> 1);
+      const int xrows = (int)(p.N / p.Na);         // = Nb*Nc
+      const int x0 = kb + p.Nb * k1, xs = p.Nb * R1;              // x = x0 + K2*xs
+      const int kk0 = ka + p.Na * x0, kks = p.Na * xs;            // bin index k = kk0 + K2*kks
+      const int d0 = x0 * p.lay.pitch + p.lay.off + ka, ds = xs * p.lay.pitch;
+      const int m0 = (xrows - 1 - x0) * p.lay.pitch + p.lay.off + (p.Na - ka);
       float2* __restrict__ sp = p.spec;
       static_for<R2>([&](auto k2) {
         constexpr int K2 = decltype(k2)::value;
-        const long x = kb + (long)p.Nb * (k1 + R1 * K2);
-        const long k = ka + (long)p.Na * x;
-        if (!p.mirror || k <= half) sp[x * p.lay.pitch + p.lay.off + ka] = u[K2];
-        else if (!selfconj) sp[(xrows - 1 - x) * p.lay.pitch + p.lay.off + (p.Na - ka)] = cconj(u[K2]);   // bin N-k
+        if (!p.mirror || kk0 + K2 * kks <= half) sp[d0 + K2 * ds] = u[K2];
+        else if (!selfconj) sp[m0 - K2 * ds] = cconj(u[K2]);      // bin N-k
       });
     }
   }

@@ -48,7 +48,15 @@ int emu_forward(const float* ring, long ring_len, long start, int N, int in_type
   c.buf = buf.data(); c.spec = spec_dev.data();
   c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3; c.padg = p.padg3; c.N = p.N;
   c.mirror = in_type == CHZ_IN_REAL; c.tw_sub = F2(p.tw_sub_c);
-  c.n_notch = n_notch; c.notch_bins = notch_bins; c.notch_state = notch_state; c.notch_alpha = notch_alpha;
+  std::vector<NotchLoc> loc((size_t)(n_notch > 0 ? n_notch : 0));
+  for (int i = 0; i < n_notch; i++) {
+    long k = notch_bins[i]; int mir = 0;
+    int qa = (int)(k % p.Na);
+    if (in_type == CHZ_IN_REAL && 2 * qa > p.Na) { k = (long)p.N - notch_bins[i]; qa = (int)(k % p.Na); mir = 1; }
+    const long rest = k / p.Na;
+    loc[(size_t)i] = NotchLoc{qa, (int)(rest % p.Nb), (int)(rest / p.Nb) % p.rc.r1, (int)(rest / p.Nb) / p.rc.r1, mir};
+  }
+  c.n_notch = n_notch; c.notch_loc = loc.data(); c.notch_state = notch_state; c.notch_alpha = notch_alpha;
   if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, nullptr, c)) return -4;
   float2* out = reinterpret_cast<float2*>(spectrum);
   for (long k = 0; k < p.bins; k++) out[k] = spec_dev[(size_t)spec_addr(c.lay, k)];   // back to natural order
