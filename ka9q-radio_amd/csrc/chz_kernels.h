@@ -134,6 +134,7 @@ __global__ void fwd_first_real(FirstRealParams p) {
   const float2* __restrict__ twt = p.tw_tile;
   const float2* __restrict__ twc = p.tw_col;
   float2* __restrict__ gout = p.buf;
+  float2* zl = lds + NA * T + R1 * p.padk;         // second LDS region (see layer 2)
 
   // Epilogue geometry is known up front: one lane owns one output column cc and walks rows
   // kr, kr+rpi, ...  Fetch its twiddle factors now; they are consumed at the very end.
@@ -183,13 +184,11 @@ __global__ void fwd_first_real(FirstRealParams p) {
       u[J] = lds[k1 * (R2 * T + p.padk) + t2 + J * T];
     });
     reg_dft<R2, -1>(u);
-  }
-  __syncthreads();
-  // Z[k1 + R1*k2] back to LDS in natural row order for the Hermitian split
-  if (act2) {
+    // Z[k1 + R1*k2] goes to a SECOND LDS region in natural row order for the Hermitian split,
+    // so no barrier is needed between the layer-2 reads above and these writes
     static_for<R2>([&](auto k2) {
       constexpr int K2 = decltype(k2)::value;
-      lds[k1 * T + t2 + K2 * (R1 * T)] = u[K2];
+      zl[k1 * T + t2 + K2 * (R1 * T)] = u[K2];
     });
   }
   __syncthreads();
@@ -201,8 +200,8 @@ __global__ void fwd_first_real(FirstRealParams p) {
     constexpr int U = decltype(uu)::value;
     const int k = kr + U * rpi;
     if (lane_on && k < p.Ra) {
-      const float2 a = lds[k * T + pc];
-      const float2 b = lds[(k == 0 ? 0 : NA - k) * T + pc];
+      const float2 a = zl[k * T + pc];
+      const float2 b = zl[(k == 0 ? 0 : NA - k) * T + pc];
       float2 d;
       if (odd) d = make_float2(a.x - b.x, a.y + b.y);   // a - conj(b)
       else     d = make_float2(a.x + b.x, a.y - b.y);   // a + conj(b)

@@ -15,7 +15,7 @@ namespace chz {
 
 // (R1,R2) pairs with a compiled kernel instantiation.  Sub-transform length = R1*R2.
 #define CHZ_FWD_MENU(X) \
-  X(4, 4) X(5, 5) X(6, 6) X(5, 9) X(5, 10) X(8, 8) X(8, 9) X(9, 9) X(10, 10) X(10, 12) X(5, 25) X(9, 15) \
+  X(4, 4) X(5, 5) X(6, 6) X(5, 9) X(5, 10) X(5, 15) X(8, 8) X(8, 9) X(9, 9) X(10, 10) X(10, 12) X(5, 25) X(9, 15) \
   X(12, 12) X(10, 15) X(10, 16) X(12, 15) X(12, 16) X(15, 15) X(15, 16) X(16, 16) X(16, 20) X(20, 20)
 // per-channel backward transform lengths P = R1*R2 (reference sizes: docs/FFTW3.md:51-68)
 #define CHZ_CHAN_MENU(X) \
@@ -139,6 +139,7 @@ inline bool finish_fwd_plan(FwdPlan& p, int T1_over, int T2_over, int Ta_over) {
   p.padk1 = padk_for(p.ra.r2, p.T1);
   p.block1 = round_up(la * p.T1, 64);
   p.lds1 = sizeof(f2) * ((size_t)p.Na * p.T1 + (size_t)p.ra.r1 * p.padk1);
+  if (real) p.lds1 += sizeof(f2) * (size_t)p.Na * p.T1;      // second region for the Hermitian split
   p.tw_sub_a = make_tw_sub(p.ra.r1, p.ra.r2, -1);
   // ---- axis b
   if (p.Nb > 1) {
@@ -240,17 +241,20 @@ inline bool build_fwd_plan(int N, int in_type, const char* spec, FwdPlan& out) {
       fwd_menu_lookup(a, &p.ra); fwd_menu_lookup(c, &p.rc);
       if (b > 1) fwd_menu_lookup(b, &p.rb);
       if (!finish_fwd_plan(p, 0, 0, 0)) continue;
-      // cost model: passes over memory + penalty for too few workgroups + misaligned stores
-      double passes = b > 1 ? 3.0 : 2.0;
-      int mingrid = p.grid1 < p.grid3 ? p.grid1 : p.grid3;
-      if (b > 1 && p.grid2 < mingrid) mingrid = p.grid2;
-      // 128-byte aligned 16-column tiles run at copy speed, misaligned ones at about half of it
-      const bool al1 = real ? (p.T1 % 16 == 0) : (p.T1 % 16 == 0);
+      // cost model (fitted to scripts/plan_sweep.py runs on MI355X): every pass moves the whole
+      // data set once; 128-byte aligned 16-column tiles run at copy speed and misaligned ones at
+      // about half of it; a pass wants >= ~600 workgroups; long or lopsided butterflies cost VALU time
+      auto grid_pen = [](int g) { return g < 600 ? (600.0 - g) / 600.0 : 0.0; };
+      auto shape_pen = [](Radix2 r) {
+        const int hi = r.r1 > r.r2 ? r.r1 : r.r2, lo = r.r1 > r.r2 ? r.r2 : r.r1;
+        return 0.08 * ((double)hi / lo - 1.0) + (hi * lo > 256 ? 0.3 : 0.0) + (hi > 16 ? 0.15 : 0.0);
+      };
+      const bool al1 = p.T1 % 16 == 0;
       const bool al2 = (b == 1) || (p.T2 % 16 == 0 && c % 16 == 0);
       const bool al3 = real ? (p.spec_off != 0 || (a % 16 == 0)) : (a % 16 == 0);
-      double score = passes + (mingrid < 400 ? 400.0 / (mingrid + 1) : 0.0) +
-                     (al1 ? 0.0 : 0.6) + (al2 ? 0.0 : 0.6) + (al3 ? 0.0 : 0.4) +
-                     (p.T1 < 8 ? 0.5 : 0.0) + (b > 1 && p.T2 < 8 ? 0.5 : 0.0);
+      double score = (b > 1 ? 3.0 : 2.0) + grid_pen(p.grid1) + grid_pen(p.grid3) + (b > 1 ? grid_pen(p.grid2) : 0.0) +
+                     shape_pen(p.ra) + shape_pen(p.rc) + (b > 1 ? shape_pen(p.rb) : 0.0) +
+                     (al1 ? 0.0 : 0.5) + (al2 ? 0.0 : 0.5) + (al3 ? 0.0 : 0.25);
       if (score < best) { best = score; bestp = p; found = true; }
     }
   }
