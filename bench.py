@@ -120,7 +120,8 @@ def main():
     ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
     ap.add_argument("--plan", default="", help="forward plan override, e.g. 144x100x225")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--graph", action="store_true", help="replay one hipGraph per ring cycle instead of eager launches")
+    ap.add_argument("--eager", action="store_true", help="(default) eager launches; kept for compatibility")
     args = ap.parse_args()
 
     import torch
@@ -171,7 +172,7 @@ def main():
         torch.cuda.synchronize()
 
     if world == 1:
-        graph = not args.eager
+        graph = bool(args.graph)
         eng.run_blocks(0, args.warmup, graph=graph)
         barrier()
         t0 = time.perf_counter()
@@ -246,7 +247,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "channels_total": total_ch, "P": P, "olen": olen, "N": N, "L": L, "M": M,
-                       "launch": "eager" if (args.eager or world > 1) else "hipGraph(8 blocks)", "plan": eng.plan},
+                       "launch": ("hipGraph(8 blocks)" if (args.graph and world == 1) else "eager") + ", %d HIP streams" % eng.lanes,
+                       "plan": eng.plan},
             "blocks_per_s": args.steps / elapsed, "realtime_margin": BLOCKTIME / (elapsed / args.steps),
             "step_algorithmic_GBps": step_bytes / (elapsed / args.steps) / 1e9,
             "gpu_event_ms_per_step": gpu_ms / args.steps,

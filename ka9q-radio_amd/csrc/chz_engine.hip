@@ -6,6 +6,7 @@
 // asynchronously; a ring cycle of blocks can be captured into a hipGraph so the
 // launch-bound inner loop costs one graph replay.  gfx950 only, no fallback.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -233,19 +234,22 @@ int chz_input_ring(chz_engine* e, float** dev_ring, long* ring_len_floats) {
 }
 
 // ---- kernel launches ---------------------------------------------------------
-struct Instr {      // optional per-kernel HIP-event instrumentation
+struct Instr {      // optional per-kernel timing: one (begin, end) event pair per launch
   bool on = false;
-  std::vector<hipEvent_t> ev;   // kind.size() + 1 boundaries
-  std::vector<int> kind;        // 0 first, 1 cols, 2 rows, 3 notch, 4 chan
+  std::vector<hipEvent_t> ev;   // 2 per launch: dispatch begin / end timestamps
+  std::vector<int> kind;        // 0 first, 1 cols, 2 rows, 3 (unused), 4 chan
+  hipEvent_t e0 = nullptr, e1 = nullptr;   // pair for the launch being issued
 };
-// One event per kernel boundary: kernel i's time = event[i+1] - event[i], so back-to-back
-// kernels are separated by a single event packet, not two.
-static void mark(Instr* in, hipStream_t s, int kind, bool begin) {
+// begin=true: allocate the pair the next launch will carry; begin=false: nothing (kept for symmetry)
+static void mark(Instr* in, hipStream_t, int kind, bool begin) {
   if (!in || !in->on) return;
-  if (begin) { in->kind.push_back(kind); if (!in->ev.empty()) return; }
-  hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s);
-  in->ev.push_back(e);
+  if (begin) {
+    hipEventCreate(&in->e0); hipEventCreate(&in->e1);
+    in->ev.push_back(in->e0); in->ev.push_back(in->e1); in->kind.push_back(kind);
+  } else { in->e0 = nullptr; in->e1 = nullptr; }
 }
+#define IN_E0(in) ((in) && (in)->on ? (in)->e0 : nullptr)
+#define IN_E1(in) ((in) && (in)->on ? (in)->e1 : nullptr)
 
 static inline int lane_of(const chz_engine* e, unsigned job, const Instr* in) {
   return (in && in->on) ? 0 : (int)(job % (unsigned)e->nlanes);
@@ -264,7 +268,7 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
     a.ring = e->ring; a.ring_len = e->ring_len; a.start = start; a.buf = lbuf; a.inner = p.inner;
     a.T = p.T1; a.Ra = p.Ra; a.padk = p.padk1; a.tw_sub = e->tw_sub_a; a.tw_tile = e->tw1_tile; a.tw_col = e->tw1_col;
     mark(in, st, 0, true);
-    if (launch_first_real(p.ra, p.grid1, p.block1, p.lds1, st, a)) return fail(-4, "no kernel for axis a");
+    if (launch_first_real(p.ra, p.grid1, p.block1, p.lds1, st, a, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis a");
     mark(in, st, 0, false);
   } else {
     ColsParams a{};
@@ -272,7 +276,7 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
     a.out = lbuf; a.rows = 1; a.inner = p.inner; a.T = p.T1; a.padk = p.padk1;
     a.tw_sub = e->tw_sub_a; a.tw_tile = e->tw1_tile; a.tw_col = e->tw1_col;
     mark(in, st, 0, true);
-    if (launch_cols(p.ra, p.grid1, p.block1, p.lds1, st, a)) return fail(-4, "no kernel for axis a");
+    if (launch_cols(p.ra, p.grid1, p.block1, p.lds1, st, a, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis a");
     mark(in, st, 0, false);
   }
   if (p.Nb > 1) {
@@ -280,7 +284,7 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
     b.in = lbuf; b.in_len = 0; b.in_start = 0; b.out = lbuf; b.rows = p.Ra; b.inner = p.Nc; b.T = p.T2;
     b.padk = p.padk2; b.tw_sub = e->tw_sub_b; b.tw_tile = e->tw2_tile; b.tw_col = e->tw2_col;
     mark(in, st, 1, true);
-    if (launch_cols(p.rb, p.grid2, p.block2, p.lds2, st, b)) return fail(-4, "no kernel for axis b");
+    if (launch_cols(p.rb, p.grid2, p.block2, p.lds2, st, b, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis b");
     mark(in, st, 1, false);
   }
   RowsParams c{};
@@ -294,7 +298,7 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
     if (prev != ln) HIPOK(hipStreamWaitEvent(st, e->lanes[prev].rows_done, 0));
   }
   mark(in, st, 2, true);
-  if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, st, c)) return fail(-4, "no kernel for axis c");
+  if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis c");
   mark(in, st, 2, false);
   if (e->n_notch > 0 && e->nlanes > 1 && !(in && in->on)) HIPOK(hipEventRecord(e->lanes[ln].rows_done, st));
   return 0;
@@ -315,7 +319,7 @@ static int enqueue_bank(chz_engine* e, int bank, int slot, Instr* in, int ch0 = 
   const int per_block = b.g.wpb * b.g.cpw;
   const int grid = (n + per_block - 1) / per_block;
   mark(in, st, 4, true);
-  if (launch_chan(b.g.r, grid, b.g.wpb * 64, b.g.lds, st, c)) return fail(-4, "no kernel for P=%d", b.P);
+  if (launch_chan(b.g.r, grid, b.g.wpb * 64, b.g.lds, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for P=%d", b.P);
   mark(in, st, 4, false);
   return 0;
 }
@@ -606,7 +610,7 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
     double* acc[5] = {&timing->first_ms, &timing->cols_ms, &timing->rows_ms, &timing->notch_ms, &timing->chan_ms};
     int* cnt[5] = {&timing->first_n, &timing->cols_n, &timing->rows_n, &timing->notch_n, &timing->chan_n};
     for (size_t i = 0; i < in.kind.size(); i++) {
-      float k = 0; hipEventElapsedTime(&k, in.ev[i], in.ev[i + 1]);
+      float k = 0; hipEventElapsedTime(&k, in.ev[2 * i], in.ev[2 * i + 1]);
       *acc[in.kind[i]] += k; *cnt[in.kind[i]] += 1;
     }
   }

@@ -195,3 +195,6 @@ static inline int __lane_id() { return hipemu_linear_tid() & 63; }
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
 
 typedef void* hipStream_t;
+typedef void* hipEvent_t;
+#define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, e0, e1, flags, ...) \
+  hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__)
