@@ -41,6 +41,18 @@ HBM_PEAK_GBS = 8000.0                   # MI355X spec, /opt/skills/guides/MI355X
 FWD_BYTES = 4 * N + 8 * BINS            # 25,920,008  
 
 
+def pmc_traffic_bytes():
+    """HBM-side bytes per block of the three forward kernels from the committed rocprofv3 PMC passes
+    (profiles/pmc_forward.json, written by scripts/rocprof_summary.py --json from separate FETCH_SIZE and
+    WRITE_SIZE passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on
+    gfx950).  None if no profile has been committed for this plan."""
+    path = os.path.join(ROOT, "profiles", "pmc_forward.json")
+    try:
+        return json.load(open(path))["forward_traffic_bytes_per_block"]
+    except Exception:
+        return None
+
+
 def chan_bytes(P, olen):
     return 8 * P + 8 * P + 8 * olen     # 6,720 (P=300) / 13,440 (P=600)
 
@@ -226,7 +238,7 @@ def main():
         roof = {
             "bound": "hbm", "kernel": "forward transform = fwd_first_real + fwd_cols + fwd_rows (one launch each per block)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic_bytes(),
             "algorithmic_bytes_per_block": FWD_BYTES, "forward_us_per_block": fwd_us,
             "kernels_us": kern,
             "kernels_own_GBps": {k: own[k] / (kern[k] * 1e-6) / 1e9 for k in own if k in kern and kern[k] > 0},

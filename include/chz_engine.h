@@ -105,7 +105,7 @@ int chz_bank_execute(chz_engine *e, int bank, int slot);
 int chz_bank_execute_range(chz_engine *e, int bank, int slot, int ch0, int n);
 int chz_bank_destroy(chz_engine *e, int bank);                              /* frees the bank's device arrays */
 int chz_bank_read(chz_engine *e, int bank, int ch0, int n, float *host);    /* n*olen complex of the most recent execute, synchronous */
-/* Blocks are pipelined over 1, 2 or 4 HIP streams ("lanes", env CHZ_STREAMS, default 2): block j
+/* Blocks are pipelined over 1, 2 or 4 HIP streams ("lanes", env CHZ_STREAMS, default 4): block j
  * runs on lane j % lanes with its own intermediate buffer, so block j+1's forward transform overlaps
  * block j's tail.  Bank outputs exist once per spectrum slot.  Everything addressed by `slot` below is
  * enqueued on the lane that owns that slot, in call order.

@@ -121,7 +121,7 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   HIPOK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   e->own_stream = true;
   const char* envl = getenv("CHZ_STREAMS");
-  int nl = envl ? atoi(envl) : 2;
+  int nl = envl ? atoi(envl) : 4;
   e->nlanes = (nl >= 4) ? 4 : (nl >= 2) ? 2 : 1;             // must divide ND so slot and lane stay aligned
   HIPOK(hipEventCreateWithFlags(&e->input_ready, hipEventDisableTiming));
   for (int i = 0; i < e->nlanes; i++) {
