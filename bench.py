@@ -149,15 +149,19 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1 exercises the multi-GPU code path (RCCL broadcast, torch-owned spectrum slots)
+    # with a single rank, so it can be smoke-tested on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     pkg = ge.load()
     eng = pkg.engine.Engine(L, M, pkg.engine.REAL, device=local_rank, plan=args.plan, ring_blocks=RING_BLOCKS)
 
     nch = args.channels
-    if world == 1:
+    if not use_dist:
         P, olen, workload = 300, 240, "config3: sig_gen real 129.6 MS/s, %d mixed usb/cw/iq 12 kHz channels (P=300), 1 MI355X" % nch
         plan = channel_plan_config3(nch)
     else:
@@ -179,11 +183,11 @@ def main():
     eng.set_notches([0], 0.01)                               # DC notch is always present (src/radio.c:601-620)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    if not use_dist:
         graph = bool(args.graph)
         eng.run_blocks(0, args.warmup, graph=graph)
         barrier()
@@ -214,7 +218,7 @@ def main():
         elapsed = time.perf_counter() - t0
         gpu_ms = elapsed * 1e3
 
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -245,7 +249,7 @@ def main():
         }
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not use_dist and not args.no_cpu_baseline:
         cpu = cpu_baseline(oracle_lib, ring_host, plan, P, olen)
 
     if rank == 0:
@@ -259,7 +263,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "channels_total": total_ch, "P": P, "olen": olen, "N": N, "L": L, "M": M,
-                       "launch": ("hipGraph(8 blocks)" if (args.graph and world == 1) else "eager") + ", %d HIP streams" % eng.lanes,
+                       "launch": ("hipGraph(8 blocks)" if (args.graph and not use_dist) else "eager") + ", %d HIP streams" % eng.lanes,
                        "plan": eng.plan},
             "blocks_per_s": args.steps / elapsed, "realtime_margin": BLOCKTIME / (elapsed / args.steps),
             "step_algorithmic_GBps": step_bytes / (elapsed / args.steps) / 1e9,
@@ -268,7 +272,7 @@ def main():
         }
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

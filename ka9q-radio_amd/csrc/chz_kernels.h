@@ -122,8 +122,8 @@ template <int R1, int R2>
 __global__ void fwd_first_real(FirstRealParams p) {
   constexpr int NA = R1 * R2;
   constexpr int LA = R1 > R2 ? R1 : R2;
-  // rows one lane walks in the split epilogue: ceil(Ra / rows-per-sweep), rows-per-sweep >= LA/2
-  constexpr int NE = (NA / 2 + 1 + LA / 2 - 1) / (LA / 2);
+  // rows one lane walks in the split epilogue: ceil(Ra / rows-per-sweep), rows-per-sweep >= LA
+  constexpr int NE = (NA / 2 + 1 + LA - 1) / LA;
   HIP_DYNAMIC_SHARED(float2, lds)
   const int tid = threadIdx.x, nthr = blockDim.x, tile = blockIdx.x;
   const int T = p.T;
@@ -136,19 +136,20 @@ __global__ void fwd_first_real(FirstRealParams p) {
   float2* __restrict__ gout = p.buf;
   float2* zl = lds + NA * T + R1 * p.padk;         // second LDS region (see layer 2)
 
-  // Epilogue geometry is known up front: one lane owns one output column cc and walks rows
-  // kr, kr+rpi, ...  Fetch its twiddle factors now; they are consumed at the very end.
-  const int W2 = 2 * T;
-  const int rpi = nthr / W2;                     // rows covered per sweep
-  const int kr = tid / W2, cc = tid - kr * W2;
+  // Epilogue geometry is known up front: one lane owns one PACKED column pc (= two adjacent real
+  // columns 2pc, 2pc+1) and walks rows kr, kr+rpi, ...  Its twiddle factors are fetched now as one
+  // 16-byte load per row; they are consumed at the very end, where each row becomes one 16-byte store.
+  const int rpi = nthr / T;                      // rows covered per sweep (>= LA)
+  const int kr = tid / T, pc = tid - kr * T;
   const bool lane_on = kr < rpi;
-  float2 we1[NE], we2[NE];
+  float2 we1[NE];
+  float4 we2[NE];
   static_for<NE>([&](auto u) {
     constexpr int U = decltype(u)::value;
     const int k = kr + U * rpi;
     const int kk = (lane_on && k < p.Ra) ? k : 0;
     we1[U] = twt[tile * p.Ra + kk];
-    we2[U] = twc[kk * W2 + cc];
+    we2[U] = reinterpret_cast<const float4*>(twc)[kk * T + pc];   // columns 2pc (even) and 2pc+1 (odd)
   });
 
   // layer 1: radix R1 over na = j + q*R2, one (j, column) pair per thread
@@ -194,18 +195,20 @@ __global__ void fwd_first_real(FirstRealParams p) {
   __syncthreads();
   // split + twiddle + store:  real column 2p   -> (Z[k] + conj Z[Na-k]) / 2
   //                           real column 2p+1 -> (Z[k] - conj Z[Na-k]) / 2i
-  const int pc = cc >> 1;
-  const bool odd = cc & 1;
+  // (the factors 1/2 and 1/2i live in the column twiddle table)
+  float4* __restrict__ gout4 = reinterpret_cast<float4*>(gout);
+  const int orow = p.inner >> 1;                   // row pitch of buf in float4 units
   static_for<NE>([&](auto uu) {
     constexpr int U = decltype(uu)::value;
     const int k = kr + U * rpi;
     if (lane_on && k < p.Ra) {
       const float2 a = zl[k * T + pc];
       const float2 b = zl[(k == 0 ? 0 : NA - k) * T + pc];
-      float2 d;
-      if (odd) d = make_float2(a.x - b.x, a.y + b.y);   // a - conj(b)
-      else     d = make_float2(a.x + b.x, a.y - b.y);   // a + conj(b)
-      gout[(long)k * p.inner + 2 * c0 + cc] = cmul(d, cmul(we1[U], we2[U]));
+      const float2 de = make_float2(a.x + b.x, a.y - b.y);   // a + conj(b)
+      const float2 dd = make_float2(a.x - b.x, a.y + b.y);   // a - conj(b)
+      const float2 oe = cmul(de, cmul(we1[U], make_float2(we2[U].x, we2[U].y)));
+      const float2 oo = cmul(dd, cmul(we1[U], make_float2(we2[U].z, we2[U].w)));
+      gout4[(long)k * orow + c0 + pc] = make_float4(oe.x, oe.y, oo.x, oo.y);
     }
   });
 }

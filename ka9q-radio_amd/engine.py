@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libchz_hip.so")
+LIB_PATH = os.environ.get("CHZ_LIB") or os.path.join(HERE, "libchz_hip.so")   # CHZ_LIB: A/B builds only
 
 COMPLEX, REAL = 1, 2
 ND = 4
