@@ -270,10 +270,17 @@ def main():
             "gpu_event_ms_per_step": gpu_ms / args.steps,
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
     eng.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a banner through C stdio: flush it first so the JSON is the LAST line of stdout
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.write(json.dumps(out) + "\n")
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -144,6 +144,9 @@ class Engine:
 
     def set_stream(self, hip_stream):
         _check(lib().chz_engine_set_stream(self._h, hip_stream))
+        info = ChzInfo()
+        _check(lib().chz_engine_info(self._h, C.byref(info)))
+        self.lanes = info.lanes
 
     # -- forward ---------------------------------------------------------------
     def forward(self, job):
