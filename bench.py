@@ -268,6 +268,7 @@ def main():
             "blocks_per_s": args.steps / elapsed, "realtime_margin": BLOCKTIME / (elapsed / args.steps),
             "step_algorithmic_GBps": step_bytes / (elapsed / args.steps) / 1e9,
             "gpu_event_ms_per_step": gpu_ms / args.steps,
+            "host_enqueue_ms_per_step": (timing.enqueue_ms / args.steps) if not use_dist else None,
             "roofline": roof, "cpu_baseline": cpu,
         }
     eng.close()

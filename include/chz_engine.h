@@ -51,6 +51,7 @@ typedef struct chz_timing {
   /* per-kernel HIP-event time, accumulated over the run (only when instrumented) */
   double first_ms, cols_ms, rows_ms, notch_ms, chan_ms;
   int first_n, cols_n, rows_n, notch_n, chan_n;
+  double enqueue_ms;        /* host wall time spent issuing the launches (close to total_ms = host-bound) */
 } chz_timing;
 
 const char *chz_last_error(void);

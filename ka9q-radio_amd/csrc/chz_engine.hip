@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <vector>
 #include "chz_launch.h"
@@ -61,6 +62,7 @@ struct chz_engine {
   float2 *tw_sub_a = nullptr, *tw_sub_b = nullptr, *tw_sub_c = nullptr;
   float2 *tw1_tile = nullptr, *tw1_col = nullptr, *tw2_tile = nullptr, *tw2_col = nullptr;
   int n_notch = 0; NotchLoc* notch_loc = nullptr; double* notch_state = nullptr; double notch_alpha = 0;
+  unsigned* notch_ver = nullptr; bool notch_armed = false; unsigned notch_next = 0;   // ticket counters; first job after (re)arming
   std::vector<Bank> banks;
   hipGraphExec_t graph = nullptr; unsigned graph_job0 = 0; int graph_blocks = 0; size_t graph_sig = 0;
 };
@@ -168,7 +170,7 @@ void chz_engine_destroy(chz_engine* e) {
   for (int i = 0; i < CHZ_ND; i++) if (e->spec_owned[i]) hipFree(e->spec[i]);
   hipFree(e->tw_sub_a); hipFree(e->tw_sub_b); hipFree(e->tw_sub_c);
   hipFree(e->tw1_tile); hipFree(e->tw1_col); hipFree(e->tw2_tile); hipFree(e->tw2_col);
-  hipFree(e->notch_loc); hipFree(e->notch_state);
+  hipFree(e->notch_loc); hipFree(e->notch_state); hipFree(e->notch_ver);
   if (e->own_stream) hipStreamDestroy(e->stream);
   delete e;
 }
@@ -255,6 +257,20 @@ static inline int lane_of(const chz_engine* e, unsigned job, const Instr* in) {
   return (in && in->on) ? 0 : (int)(job % (unsigned)e->nlanes);
 }
 
+// The ticket counters must read `job` when block `job` arrives.  They count on their own as long as
+// jobs are consecutive; after set_notches, or when the caller jumps to another job number (tests,
+// run_blocks restarts), they are re-seeded -- which needs the device to be idle.
+static int arm_notch_tickets(chz_engine* e, unsigned job) {
+  if (e->n_notch <= 0) return 0;
+  if (e->notch_armed && e->notch_next == job) { e->notch_next = job + 1; return 0; }
+  int r = sync_all(e);
+  if (r) return r;
+  std::vector<unsigned> v((size_t)e->n_notch, job);
+  HIPOK(hipMemcpy(e->notch_ver, v.data(), sizeof(unsigned) * v.size(), hipMemcpyHostToDevice));
+  e->notch_armed = true; e->notch_next = job + 1;
+  return 0;
+}
+
 static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
   const FwdPlan& p = e->plan;
   const int slot = job % CHZ_ND;
@@ -292,15 +308,10 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
   c.buf = lbuf; c.spec = e->spec[slot]; c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3;
   c.padg = p.padg3; c.N = p.N; c.mirror = e->in_type == CHZ_REAL; c.tw_sub = e->tw_sub_c;
   c.n_notch = e->n_notch; c.notch_loc = e->notch_loc; c.notch_state = e->notch_state; c.notch_alpha = e->notch_alpha;
-  if (e->n_notch > 0 && e->nlanes > 1 && !(in && in->on)) {
-    // the notch state is sequential across blocks: this block's fwd_rows after the previous block's
-    const int prev = (int)((job + (unsigned)e->nlanes - 1u) % (unsigned)e->nlanes);
-    if (prev != ln) HIPOK(hipStreamWaitEvent(st, e->lanes[prev].rows_done, 0));
-  }
+  c.notch_ver = e->notch_ver; c.job = job;
   mark(in, st, 2, true);
   if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis c");
   mark(in, st, 2, false);
-  if (e->n_notch > 0 && e->nlanes > 1 && !(in && in->on)) HIPOK(hipEventRecord(e->lanes[ln].rows_done, st));
   return 0;
 }
 
@@ -327,7 +338,9 @@ static int enqueue_bank(chz_engine* e, int bank, int slot, Instr* in, int ch0 = 
 int chz_forward(chz_engine* e, unsigned job) {
   if (!e) return fail(-1, "null engine");
   HIPOK(hipSetDevice(e->device));
-  int r = enqueue_forward(e, job, nullptr);
+  int r = arm_notch_tickets(e, job);
+  if (r) return r;
+  r = enqueue_forward(e, job, nullptr);
   if (r) return r;
   HIPOK(hipGetLastError());
   return 0;
@@ -337,7 +350,8 @@ int chz_set_notches(chz_engine* e, const int* bins, int n, double alpha) {
   if (!e) return fail(-1, "null engine");
   { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
-  hipFree(e->notch_loc); hipFree(e->notch_state); e->notch_loc = nullptr; e->notch_state = nullptr; e->n_notch = 0;
+  hipFree(e->notch_loc); hipFree(e->notch_state); hipFree(e->notch_ver);
+  e->notch_loc = nullptr; e->notch_state = nullptr; e->notch_ver = nullptr; e->n_notch = 0;
   if (n <= 0 || !bins) return 0;
   const FwdPlan& p = e->plan;
   std::vector<NotchLoc> loc((size_t)n);
@@ -356,6 +370,9 @@ int chz_set_notches(chz_engine* e, const int* bins, int n, double alpha) {
   HIPOK(hipMalloc((void**)&e->notch_state, sizeof(double) * 2 * (size_t)n));
   HIPOK(hipMemcpy(e->notch_loc, loc.data(), sizeof(NotchLoc) * (size_t)n, hipMemcpyHostToDevice));
   HIPOK(hipMemset(e->notch_state, 0, sizeof(double) * 2 * (size_t)n));
+  HIPOK(hipMalloc((void**)&e->notch_ver, sizeof(unsigned) * (size_t)n));
+  HIPOK(hipMemset(e->notch_ver, 0, sizeof(unsigned) * (size_t)n));   // re-armed for the next job by arm_notch_tickets()
+  e->notch_armed = false;
   e->n_notch = n; e->notch_alpha = alpha;
   return 0;
 }
@@ -534,7 +551,9 @@ static int enqueue_step(chz_engine* e, unsigned job, Instr* in) {
 int chz_step(chz_engine* e, unsigned job) {
   if (!e) return fail(-1, "null engine");
   HIPOK(hipSetDevice(e->device));
-  int r = enqueue_step(e, job, nullptr);
+  int r = arm_notch_tickets(e, job);
+  if (r) return r;
+  r = enqueue_step(e, job, nullptr);
   if (r) return r;
   HIPOK(hipGetLastError());
   return 0;
@@ -561,6 +580,11 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
   HIPOK(hipSetDevice(e->device));
   { int r = sync_all(e); if (r) return r; }
   e->input_pending = false;                       // everything written so far is visible to every lane now
+  if (nblocks > 0) {                              // notch tickets: seed for job0, they then count on their own
+    int r = arm_notch_tickets(e, job0);
+    if (r) return r;
+    e->notch_next = job0 + (unsigned)nblocks;
+  }
   hipEvent_t t0, t1, fork_ev, join_ev[CHZ_MAX_LANES];
   HIPOK(hipEventCreate(&t0)); HIPOK(hipEventCreate(&t1));
   HIPOK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
@@ -568,6 +592,7 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
   Instr in; in.on = instrument != 0 && mode == 0;
   hipStream_t s0 = e->lanes[0].s;
   int done = 0, rc = 0;
+  const auto host_t0 = std::chrono::steady_clock::now();
   if (mode == 1) {
     // one graph = one ring cycle of blocks (a multiple of ND so slots and lanes line up too)
     int cycle = e->ring_blocks;
@@ -601,10 +626,12 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
     if (!in.on && (rc = lanes_join(e, join_ev))) return rc;
   }
   HIPOK(hipEventRecord(t1, s0));
+  const double enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   HIPOK(hipEventSynchronize(t1));
   HIPOK(hipGetLastError());
   if (timing) {
     memset(timing, 0, sizeof *timing);
+    timing->enqueue_ms = enqueue_ms;
     float ms = 0; HIPOK(hipEventElapsedTime(&ms, t0, t1));
     timing->total_ms = ms; timing->blocks = nblocks;
     double* acc[5] = {&timing->first_ms, &timing->cols_ms, &timing->rows_ms, &timing->notch_ms, &timing->chan_ms};

@@ -95,6 +95,13 @@ struct RowsParams {
   const NotchLoc* notch_loc;  // n_notch entries: which lane/register of which workgroup holds the bin
   double* notch_state;        // 2 doubles per entry
   double notch_alpha;
+  // The notch state is a recurrence over blocks, but blocks of different HIP streams run
+  // concurrently.  Instead of serialising whole kernels with stream events, the ONE lane that owns
+  // a notched bin takes a ticket: it waits until notch_ver[i] (count of updates applied so far,
+  // mod 4) equals this block's job number mod 4, updates, and publishes ver+1.  At most 4 blocks
+  // are in flight and blocks j and j+4 share a stream, so the ticket is unambiguous.
+  unsigned* notch_ver;        // n_notch counters
+  unsigned job;               // this block's job number
 };
 
 // One channel's gather, precomputed on the host from `shift`
@@ -374,10 +381,18 @@ __global__ void fwd_rows(RowsParams p) {
           constexpr int K2 = decltype(k2)::value;
           if (K2 == nl.k2) {
             float2 x = nl.mir ? cconj(u[K2]) : u[K2];
-            double sr = p.notch_state[2 * i], si = p.notch_state[2 * i + 1];
+            // wait for every earlier block's update of this notch (bounded: never hang the GPU)
+            for (int spin = 0; spin < (1 << 22); spin++) {
+              if ((__hip_atomic_load(&p.notch_ver[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) & 3u) == (p.job & 3u)) break;
+              __builtin_amdgcn_s_sleep(2);
+            }
+            double sr = __hip_atomic_load(&p.notch_state[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double si = __hip_atomic_load(&p.notch_state[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             sr += p.notch_alpha * ((double)x.x - sr);
             si += p.notch_alpha * ((double)x.y - si);
-            p.notch_state[2 * i] = sr; p.notch_state[2 * i + 1] = si;
+            __hip_atomic_store(&p.notch_state[2 * i], sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&p.notch_state[2 * i + 1], si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&p.notch_ver[i], p.job + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             x = make_float2((float)((double)x.x - sr), (float)((double)x.y - si));
             u[K2] = nl.mir ? cconj(x) : x;
           }

@@ -26,7 +26,7 @@ class ChzInfo(C.Structure):
 class ChzTiming(C.Structure):
     _fields_ = [("total_ms", _d), ("blocks", _i),
                 ("first_ms", _d), ("cols_ms", _d), ("rows_ms", _d), ("notch_ms", _d), ("chan_ms", _d),
-                ("first_n", _i), ("cols_n", _i), ("rows_n", _i), ("notch_n", _i), ("chan_n", _i)]
+                ("first_n", _i), ("cols_n", _i), ("rows_n", _i), ("notch_n", _i), ("chan_n", _i), ("enqueue_ms", _d)]
 
 
 # every symbol include/chz_engine.h declares (checked by tests/test_abi_symbols.py)

@@ -56,7 +56,10 @@ int emu_forward(const float* ring, long ring_len, long start, int N, int in_type
     const long rest = k / p.Na;
     loc[(size_t)i] = NotchLoc{qa, (int)(rest % p.Nb), (int)(rest / p.Nb) % p.rc.r1, (int)(rest / p.Nb) / p.rc.r1, mir};
   }
+  static std::vector<unsigned> ver;           // the harness runs blocks one at a time: job 0 every call
+  ver.assign((size_t)(n_notch > 0 ? n_notch : 1), 0u);
   c.n_notch = n_notch; c.notch_loc = loc.data(); c.notch_state = notch_state; c.notch_alpha = notch_alpha;
+  c.notch_ver = ver.data(); c.job = 0;
   if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, nullptr, c)) return -4;
   float2* out = reinterpret_cast<float2*>(spectrum);
   for (long k = 0; k < p.bins; k++) out[k] = spec_dev[(size_t)spec_addr(c.lay, k)];   // back to natural order

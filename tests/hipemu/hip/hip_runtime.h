@@ -198,3 +198,10 @@ typedef void* hipStream_t;
 typedef void* hipEvent_t;
 #define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, e0, e1, flags, ...) \
   hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__)
+// single-threaded fibers: agent-scope atomics degrade to plain accesses
+#define __ATOMIC_RELAXED_EMU 0
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <class T> static inline T __hip_atomic_load(T* p, int, int) { return *p; }
+template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <class T, class V> static inline void __hip_atomic_store(T* p, V v, int, int) { *p = (T)v; }
+static inline void __builtin_amdgcn_s_sleep(int) {}
