@@ -227,6 +227,9 @@ def main():
     roof = None
     if rank == 0:
         eng_t = eng
+        # one kernel at a time on one stream; the first pass after the multi-stream run is discarded
+        # (the clocks need a few ms to settle after the load change: scripts/data_probe.py)
+        eng_t.run_blocks(0, min(args.steps, 200), graph=False, instrument=True)
         it = eng_t.run_blocks(0, min(args.steps, 200), graph=False, instrument=True)
         kern = {}
         for name, ms, n in (("fwd_first_real", it.first_ms, it.first_n), ("fwd_cols", it.cols_ms, it.cols_n),

@@ -410,6 +410,33 @@ def test_retune_and_new_filter_between_blocks(pkg):
         fa.delete_filter_input(master)
 
 
+def test_notch_recurrence_is_ordered_across_streams(pkg):
+    # 4 HIP streams run consecutive blocks concurrently; the notch state must still be the sequential
+    # recurrence of src/filter.c:464-474 (ordered by the device-side ticket, not by stream events)
+    L, M = 25920, 6481
+    nblk = 37
+    rng = np.random.default_rng(51)
+    ring = (rng.standard_normal(8 * L) + 0.4).astype(np.float32)
+    bins = [125, 4000, 16000, 0]
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    assert eng.lanes >= 1
+    eng.set_notches(bins, 0.05)
+    eng.write(ring[:8 * L - (M - 1)]); eng.write(ring[8 * L - (M - 1):])
+    eng.run_blocks(0, nblk, graph=False)
+    got = eng.spectrum((nblk - 1) % 4)
+    eng.close()
+    # oracle: the same cyclic stream, block by block (the first window starts with the ring's last M-1 samples)
+    st = ol.Stream(L, M, ol.REAL)
+    st.push(ring[7 * L:8 * L])                     # primes the history with the samples before block 0
+    state = np.zeros(2 * len(bins))
+    for j in range(nblk):
+        want = st.push(ring[(j % 8) * L:(j % 8 + 1) * L])
+        ol.notch(state, bins, 0.05, want)
+    for b in bins:
+        assert abs(got[b] - want[b]) <= 5e-6 * abs(want[b]) + 5e-3, b
+    assert rel(got, want) <= SPEC_REL
+
+
 def test_run_blocks_graph_equals_eager(pkg):
     # the hipGraph replay of a ring cycle must produce exactly what eager launches produce
     L, M = 25920, 6481
