@@ -79,6 +79,19 @@ def channel_plan_config4(nch, rank):
     return plan
 
 
+def channel_plan_sharded(nch, rank, world):
+    """nch*world mixed channels on an even raster over 1..62.4 MHz; rank r owns channels [r*nch, (r+1)*nch)."""
+    kinds = [(50 / 12000, 3000 / 12000), (-200 / 12000, 200 / 12000), (-5000 / 12000, 5000 / 12000)]
+    hz_per_bin = FS / N
+    step = 61.4e6 / (nch * world)
+    plan = []
+    for j in range(nch):
+        i = rank * nch + j
+        f = 1e6 + i * step + (i % 40)
+        plan.append((int(round(f / hz_per_bin)),) + kinds[i % 3])
+    return plan
+
+
 def siggen_ring(oracle_lib, seed=1):
     """8 blocks of the deterministic sig_gen stream (CW carrier 10.00002 MHz, -20 dBFS, noise -40 dBFS).
     The generator is test infrastructure (oracle/); it only produces INPUT, outside the timed region."""
@@ -161,14 +174,17 @@ def main():
     eng = pkg.engine.Engine(L, M, pkg.engine.REAL, device=local_rank, plan=args.plan, ring_blocks=RING_BLOCKS)
 
     nch = args.channels
+    P, olen = 300, 240
     if not use_dist:
-        P, olen, workload = 300, 240, "config3: sig_gen real 129.6 MS/s, %d mixed usb/cw/iq 12 kHz channels (P=300), 1 MI355X" % nch
+        workload = "config3: sig_gen real 129.6 MS/s, %d mixed usb/cw/iq 12 kHz channels (P=300), 1 MI355X" % nch
         plan = channel_plan_config3(nch)
     else:
-        P, olen = 600, 480
-        workload = ("config4: sig_gen real 129.6 MS/s, %d x 24 kHz channels (P=600) sharded over %d MI355X, "
-                    "spectrum RCCL-broadcast from rank 0" % (nch * world, world))
-        plan = channel_plan_config4(nch, rank)
+        # weak scaling: every GPU runs the SAME per-GPU workload as N=1 (1024 mixed 12 kHz channels); the
+        # node's channels cover 1..62.4 MHz and rank r owns a contiguous slice of that raster (config 4's
+        # architecture: rank 0 owns the front end, the spectrum travels over xGMI)
+        workload = ("config3 per GPU x %d (config-4 architecture): sig_gen real 129.6 MS/s on rank 0, %d mixed usb/cw/iq "
+                    "12 kHz channels (P=300) sharded by frequency over %d MI355X, spectrum over xGMI via RCCL" % (world, nch * world, world))
+        plan = channel_plan_sharded(nch, rank, world)
 
     # ---- inputs resident in HBM before anything is timed
     ring_host = siggen_ring(oracle_lib)
@@ -184,7 +200,7 @@ def main():
 
     def barrier():
         if use_dist:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     if not use_dist:
@@ -197,18 +213,43 @@ def main():
         elapsed = time.perf_counter() - t0
         gpu_ms = timing.total_ms
     else:
-        # spectrum slots are torch tensors so RCCL can broadcast into them
+        # spectrum slots are torch tensors so RCCL can move them; each block's exchange is enqueued on the
+        # engine's own per-slot HIP stream (wrapped as a torch ExternalStream), so block j's exchange and
+        # channels overlap block j+1's forward transform on another stream
         slots = [torch.zeros(2 * eng.spec_elems, dtype=torch.float32, device="cuda") for _ in range(4)]
         for i, t in enumerate(slots):
             eng.attach_spectrum(i, t.data_ptr())
-        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        streams = [torch.cuda.ExternalStream(eng.slot_stream(i)) for i in range(4)]
+        na, pitch, _off = eng.spec_layout
+        nrows = (BINS + na - 1) // na
+        mine = pkg.sharding.needed_rows([p[0] for p in plan], P, BINS, na)
+        all_rows = [None] * world
+        dist.all_gather_object(all_rows, mine)
+        mode = os.environ.get("BENCH_EXCHANGE") or pkg.sharding.plan_exchange(all_rows, nrows)
+        if os.environ.get("BENCH_FORCE_DIST") == "1" and world == 1:
+            mode = os.environ.get("BENCH_EXCHANGE", "broadcast")          # single-rank smoke test of the collective
+
+        def exchange(j):
+            s = j % 4
+            with torch.cuda.stream(streams[s]):
+                if mode == "broadcast":
+                    dist.broadcast(slots[s], src=0, async_op=True).wait()   # stream-level wait, host does not block
+                elif mode == "subband":
+                    if rank == 0:
+                        ops = [dist.P2POp(dist.isend, slots[s][2 * pitch * lo:2 * pitch * hi], r)
+                               for r, (lo, hi) in enumerate(all_rows) if r != 0 and hi > lo]
+                    else:
+                        lo, hi = mine
+                        ops = [dist.P2POp(dist.irecv, slots[s][2 * pitch * lo:2 * pitch * hi], 0)] if hi > lo else []
+                    for w in (dist.batch_isend_irecv(ops) if ops else []):
+                        w.wait()
 
         def run(job0, n):
-            # block j's broadcast (RCCL stream) overlaps block j+1's forward transform (compute stream)
-            pkg.sharding.pipelined_blocks(
-                range(job0, job0 + n), rank == 0, eng.forward,
-                lambda j: dist.broadcast(slots[j % 4], src=0, async_op=True),
-                lambda j: bank.execute(j % 4))
+            for j in range(job0, job0 + n):
+                if rank == 0:
+                    eng.forward(j)
+                exchange(j)
+                bank.execute(j % 4)
 
         run(0, args.warmup)
         barrier()
@@ -217,6 +258,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         gpu_ms = elapsed * 1e3
+        exchange_mode = mode
 
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -268,6 +310,7 @@ def main():
             "config": {"workload": workload, "channels_total": total_ch, "P": P, "olen": olen, "N": N, "L": L, "M": M,
                        "launch": ("hipGraph(8 blocks)" if (args.graph and not use_dist) else "eager") + ", %d HIP streams" % eng.lanes,
                        "plan": eng.plan},
+            "exchange": (exchange_mode if use_dist else None),
             "blocks_per_s": args.steps / elapsed, "realtime_margin": BLOCKTIME / (elapsed / args.steps),
             "step_algorithmic_GBps": step_bytes / (elapsed / args.steps) / 1e9,
             "gpu_event_ms_per_step": gpu_ms / args.steps,

@@ -87,6 +87,9 @@ int chz_forward(chz_engine *e, unsigned job);
 int chz_set_notches(chz_engine *e, const int *bins, int n, double alpha);
 int chz_spectrum_read(chz_engine *e, int slot, float *host);     /* 2*bins floats, synchronous */
 int chz_spectrum_device(chz_engine *e, int slot, float **dev);
+/* the hipStream_t everything addressed by `slot` is enqueued on; lets a caller order foreign work
+ * (an RCCL collective on the slot's spectrum) between chz_forward(job) and chz_bank_execute(.., slot) */
+int chz_slot_stream(chz_engine *e, int slot, void **hip_stream);
 /* point a slot at caller-owned device memory (2*spec_elems floats, see chz_info), e.g. a torch
  * tensor that RCCL broadcasts into */
 int chz_spectrum_attach(chz_engine *e, int slot, float *dev);

@@ -406,6 +406,11 @@ int chz_spectrum_read(chz_engine* e, int slot, float* host) {
   HIPOK(hipStreamSynchronize(st));
   return 0;
 }
+int chz_slot_stream(chz_engine* e, int slot, void** hip_stream) {
+  if (!e || !hip_stream || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
+  *hip_stream = (void*)slot_stream(e, slot);
+  return 0;
+}
 int chz_spectrum_device(chz_engine* e, int slot, float** dev) {
   if (!e || !dev || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   *dev = reinterpret_cast<float*>(e->spec[slot]);

@@ -33,7 +33,7 @@ class ChzTiming(C.Structure):
 SYMBOLS = [
     "chz_last_error", "chz_device_count", "chz_engine_create", "chz_engine_destroy", "chz_engine_info",
     "chz_engine_set_stream", "chz_sync", "chz_input_write", "chz_input_write_device", "chz_input_ring",
-    "chz_forward", "chz_set_notches", "chz_spectrum_read", "chz_spectrum_device", "chz_spectrum_attach",
+    "chz_forward", "chz_slot_stream", "chz_set_notches", "chz_spectrum_read", "chz_spectrum_device", "chz_spectrum_attach",
     "chz_bank_create", "chz_bank_set_responses", "chz_bank_set_shifts", "chz_bank_set_active",
     "chz_bank_execute", "chz_bank_execute_range", "chz_bank_destroy", "chz_bank_read", "chz_bank_read_async",
     "chz_spectrum_read_async", "chz_host_callback", "chz_host_alloc", "chz_host_free",
@@ -65,6 +65,7 @@ def lib():
         L.chz_set_notches.argtypes = [_vp, _vp, _i, _d]
         L.chz_spectrum_read.argtypes = [_vp, _i, _vp]
         L.chz_spectrum_device.argtypes = [_vp, _i, C.POINTER(_vp)]
+        L.chz_slot_stream.argtypes = [_vp, _i, C.POINTER(_vp)]
         L.chz_spectrum_attach.argtypes = [_vp, _i, _vp]
         L.chz_bank_create.argtypes = [_vp, _i, _i, _i]
         L.chz_bank_set_responses.argtypes = [_vp, _i, _i, _i, _vp]
@@ -165,6 +166,11 @@ class Engine:
         p = _vp()
         _check(lib().chz_spectrum_device(self._h, slot, C.byref(p)))
         return p.value
+
+    def slot_stream(self, slot):
+        p = _vp()
+        _check(lib().chz_slot_stream(self._h, slot, C.byref(p)))
+        return p.value or 0
 
     def attach_spectrum(self, slot, dev_ptr):
         _check(lib().chz_spectrum_attach(self._h, slot, dev_ptr))

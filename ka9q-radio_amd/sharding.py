@@ -39,3 +39,26 @@ def pipelined_blocks(jobs, is_root, forward, broadcast, channels):
     if pending is not None:
         pending[0].wait()
         channels(pending[1])
+
+
+def needed_rows(shifts, P, master_bins, na, margin_rows=1):
+    """Rows [lo, hi) of the spectrum (rows of `na` bins, see SpecLayout) that the channels with these
+    shifts read: bins shift-P/2 .. shift+P/2 for an upright spectrum, mirrored for negative shifts."""
+    lo_bin, hi_bin = master_bins, 0
+    for s in shifts:
+        a, b = abs(int(s)) - P // 2 - 1, abs(int(s)) + (P + 1) // 2 + 1
+        lo_bin, hi_bin = min(lo_bin, a), max(hi_bin, b)
+    lo_bin, hi_bin = max(lo_bin, 0), min(hi_bin, master_bins)
+    if hi_bin <= lo_bin:
+        return 0, 0
+    nrows = (master_bins + na - 1) // na
+    return max(lo_bin // na - margin_rows, 0), min((hi_bin + na - 1) // na + margin_rows, nrows)
+
+
+def plan_exchange(all_rows, nrows, threshold=0.6):
+    """'subband' if every peer needs less than `threshold` of the spectrum rows, else 'broadcast'.
+    all_rows: list over ranks of (lo, hi)."""
+    if len(all_rows) <= 1:
+        return "none"
+    worst = max((hi - lo) for lo, hi in all_rows[1:]) if len(all_rows) > 1 else 0
+    return "subband" if worst < threshold * nrows else "broadcast"

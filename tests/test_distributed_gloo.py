@@ -57,6 +57,72 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _subband_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_pkg()
+    x, _, resp = _inputs()
+    bins = (L + M - 1) // 2 + 1
+    na = 45                                             # rows of 45 bins, natural pitch
+    # channels sharded by frequency: rank r owns a contiguous band (one negative-shift channel each to
+    # exercise the mirrored read)
+    shifts = [[300 + 40 * c for c in range(5)] + [-250], [4000 + 55 * c for c in range(4)] + [-5100, bins - 200]][rank]
+    mine = pkg.sharding.needed_rows(shifts, P, bins, na)
+    all_rows = [None] * world
+    dist.all_gather_object(all_rows, mine)
+    nrows = (bins + na - 1) // na
+    assert pkg.sharding.plan_exchange(all_rows, nrows) == "subband"
+    slot = torch.zeros(2 * nrows * na, dtype=torch.float32)
+    if rank == 0:
+        spec = ol.Stream(L, M, ol.REAL).push(x[:L])
+        slot[:2 * bins].copy_(torch.from_numpy(spec.view(np.float32)))
+        ops = [dist.P2POp(dist.isend, slot[2 * na * lo:2 * na * hi], r) for r, (lo, hi) in enumerate(all_rows) if r != 0]
+    else:
+        lo, hi = mine
+        ops = [dist.P2POp(dist.irecv, slot[2 * na * lo:2 * na * hi], 0)]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    got = slot.numpy().view(np.complex64)[:bins]
+    outs = np.stack([ol.channel(got, ol.REAL, P, OLEN, s, resp[0]) for s in shifts])
+    q.put((rank, shifts, outs, mine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_subband_exchange_delivers_every_bin_a_rank_reads(oracle_built):
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_subband_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, _, resp = _inputs()
+    spec = ol.Stream(L, M, ol.REAL).push(x[:L])
+    for rank, shifts, outs, mine in results:
+        want = np.stack([ol.channel(spec, ol.REAL, P, OLEN, s, resp[0]) for s in shifts])
+        np.testing.assert_array_equal(outs, want)
+        if rank == 1:
+            assert mine[1] - mine[0] < ((L + M - 1) // 2 + 1) // 45      # really a sub-band
+
+
+def test_needed_rows_and_exchange_plan():
+    pkg = load_pkg()
+    nr = pkg.sharding.needed_rows
+    assert nr([1000], 300, 16201, 45) == (max((1000 - 151) // 45 - 1, 0), (1000 + 151 + 44) // 45 + 1)
+    assert nr([-1000], 300, 16201, 45) == nr([1000], 300, 16201, 45)           # inverted spectrum reads the same bins
+    assert nr([10, 16190], 300, 16201, 45) == (0, (16201 + 44) // 45)           # clipped to the spectrum
+    assert nr([], 300, 16201, 45) == (0, 0)
+    assert pkg.sharding.plan_exchange([(0, 100)], 100) == "none"
+    assert pkg.sharding.plan_exchange([(0, 100), (0, 30), (40, 80)], 100) == "subband"
+    assert pkg.sharding.plan_exchange([(0, 100), (0, 30), (10, 90)], 100) == "broadcast"
+
+
 def test_shard_ranges_tile_exactly():
     pkg = load_pkg()
     for total in (0, 1, 7, 1024, 8192, 8191):
