@@ -43,7 +43,6 @@ struct Bank {
 struct Lane {
   hipStream_t s = nullptr;
   float2* buf = nullptr;
-  hipEvent_t rows_done = nullptr;   // after this lane's latest fwd_rows (orders the notch state)
 };
 
 struct chz_engine {
@@ -64,7 +63,7 @@ struct chz_engine {
   int n_notch = 0; NotchLoc* notch_loc = nullptr; double* notch_state = nullptr; double notch_alpha = 0;
   unsigned* notch_ver = nullptr; bool notch_armed = false; unsigned notch_next = 0;   // ticket counters; first job after (re)arming
   std::vector<Bank> banks;
-  hipGraphExec_t graph = nullptr; unsigned graph_job0 = 0; int graph_blocks = 0; size_t graph_sig = 0;
+  hipGraphExec_t graph = nullptr; unsigned graph_job0 = 0; int graph_blocks = 0;
 };
 
 static int sync_all(chz_engine* e);
@@ -129,7 +128,6 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   for (int i = 0; i < e->nlanes; i++) {
     if (i == 0) e->lanes[i].s = e->stream;
     else HIPOK(hipStreamCreateWithFlags(&e->lanes[i].s, hipStreamNonBlocking));
-    HIPOK(hipEventCreateWithFlags(&e->lanes[i].rows_done, hipEventDisableTiming));
     HIPOK(hipMalloc((void**)&e->lanes[i].buf, sizeof(float2) * (size_t)e->plan.Ra * e->plan.inner));
   }
   HIPOK(hipMalloc((void**)&e->ring, sizeof(float) * (size_t)e->ring_len));
@@ -146,7 +144,6 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
       (r = upload(&e->tw1_col, e->plan.tw1_col)) || (r = upload(&e->tw2_tile, e->plan.tw2_tile)) ||
       (r = upload(&e->tw2_col, e->plan.tw2_col)))
     return r;
-  // kernels may need more than the default 64 KiB of dynamic LDS
   *out = e;
   return 0;
 }
@@ -161,7 +158,7 @@ void chz_engine_destroy(chz_engine* e) {
   for (int i = 0; i < e->nlanes; i++) hipStreamSynchronize(e->lanes[i].s);
   drop_graph(e);
   for (int i = 0; i < e->nlanes; i++) {
-    hipFree(e->lanes[i].buf); hipEventDestroy(e->lanes[i].rows_done);
+    hipFree(e->lanes[i].buf);
     if (i > 0) hipStreamDestroy(e->lanes[i].s);
   }
   hipEventDestroy(e->input_ready);
@@ -193,7 +190,7 @@ int chz_engine_set_stream(chz_engine* e, void* hip_stream) {
   if (r) return r;
   drop_graph(e);
   // a caller-owned stream means the caller does the ordering: collapse to one lane
-  for (int i = 1; i < e->nlanes; i++) { hipFree(e->lanes[i].buf); hipEventDestroy(e->lanes[i].rows_done); hipStreamDestroy(e->lanes[i].s); e->lanes[i] = Lane(); }
+  for (int i = 1; i < e->nlanes; i++) { hipFree(e->lanes[i].buf); hipStreamDestroy(e->lanes[i].s); e->lanes[i] = Lane(); }
   e->nlanes = 1;
   if (e->own_stream) { hipStreamDestroy(e->stream); e->own_stream = false; }
   e->stream = (hipStream_t)hip_stream;

@@ -18,6 +18,8 @@
 #include <pthread.h>
 #include <complex.h>
 #include <unistd.h>
+#include <time.h>
+#include <stdint.h>
 #ifndef KA9Q_FILTER_HEADER
 #define KA9Q_FILTER_HEADER "ka9q_filter_abi.h"
 #endif
@@ -25,6 +27,7 @@
 
 struct chanplan { int shift, shift2, retune_block, refilter_block; double low, high, beta, low2, high2; };
 
+extern int64_t Avg_fft_time, Max_fft_time;   /* exported by filter.o (src/filter.c:476-479) */
 static struct filter_in Master;
 static int L, M, In_type, Olen, Nch, Nblocks, Chunk;
 static struct chanplan *Plan;
@@ -103,6 +106,8 @@ int main(int argc, char **argv) {
   for (int i = 0; i < Nch; i++) while (atomic_load(&Progress[i]) < 0) usleep(200);      /* all slaves registered */
 
   /* front end: write in place, then tell the filter how much arrived */
+  struct timespec ts0, ts1;
+  clock_gettime(CLOCK_MONOTONIC, &ts0);
   long total = (long)Nblocks * L, pos = 0;
   while (pos < total) {
     int blk = (int)(pos / L);
@@ -124,6 +129,8 @@ int main(int argc, char **argv) {
   }
   for (int i = 0; i < Nch; i++) pthread_join(th[i], NULL);
   pthread_join(clk, NULL);
+  clock_gettime(CLOCK_MONOTONIC, &ts1);
+  double elapsed = (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
 
   snprintf(path, sizeof path, "%s/out.bin", argv[1]);
   f = fopen(path, "wb"); fwrite(Result, sizeof *Result, (size_t)Nblocks * Nch * Olen, f); fclose(f);
@@ -132,8 +139,9 @@ int main(int argc, char **argv) {
   snprintf(path, sizeof path, "%s/meta.txt", argv[1]);
   f = fopen(path, "w");
   unsigned drops = 0; for (int i = 0; i < Nch; i++) drops += Drops[i];
-  fprintf(f, "drops %u clock %d next_jobnum %u bins %d points %d sample_index %llu\n", drops, atomic_load(&Clock_blocks),
-          Master.next_jobnum, Master.bins, Master.points, (unsigned long long)Master.sample_index);
+  fprintf(f, "drops %u clock %d next_jobnum %u bins %d points %d sample_index %llu elapsed_s %.6f avg_block_ns %lld max_block_ns %lld\n",
+          drops, atomic_load(&Clock_blocks), Master.next_jobnum, Master.bins, Master.points,
+          (unsigned long long)Master.sample_index, elapsed, (long long)Avg_fft_time, (long long)Max_fft_time);
   fclose(f);
   delete_filter_input(&Master);
   return 0;

@@ -64,10 +64,9 @@ static void trampoline() {
   s.fibers[s.cur].done = true;
   swapcontext(&s.fibers[s.cur].ctx, &s.sched);
 }
-// Run one workgroup: all fibers advance to their next yield point, repeatedly,
-// until every fiber has finished.  Because every fiber yields only at barriers
-// (workgroup or wave), lock-step rounds reproduce barrier semantics exactly as
-// long as the kernel is barrier-uniform (which HIP requires anyway).
+// Run one workgroup: fibers are resumed round-robin; each runs until it blocks in a counting
+// barrier (workgroup or wave) or finishes.  A kernel whose threads do not all reach a barrier
+// would spin here forever -- exactly the kernels that hang on hardware.
 inline void run_block() {
   State& s = st();
   size_t n = (size_t)s.bdim.x * s.bdim.y * s.bdim.z;
@@ -110,9 +109,6 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t shmem, A... args) {
       for (unsigned x = 0; x < grid.x; x++) { s.bid = uint3{x, y, z}; run_block(); }
   s.dyn_smem = nullptr;
 }
-struct TidProxy { operator uint3() const { return st().fibers[st().cur].tid; }
-  struct C { int which; operator unsigned() const { const uint3& t = st().fibers[st().cur].tid; return which == 0 ? t.x : which == 1 ? t.y : t.z; } };
-};
 }  // namespace hipemu
 
 // threadIdx.x etc. as expressions evaluated at use time
@@ -199,7 +195,6 @@ typedef void* hipEvent_t;
 #define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, e0, e1, flags, ...) \
   hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__)
 // single-threaded fibers: agent-scope atomics degrade to plain accesses
-#define __ATOMIC_RELAXED_EMU 0
 #define __HIP_MEMORY_SCOPE_AGENT 4
 template <class T> static inline T __hip_atomic_load(T* p, int, int) { return *p; }
 template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return *p; }
