@@ -34,6 +34,8 @@
 #include <unistd.h>
 #include <errno.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
+#include <linux/futex.h>
 #include "../../include/ka9q_filter_abi.h"
 #include "../../include/chz_engine.h"
 
@@ -70,6 +72,7 @@ struct mctx {
   chz_engine *eng;
   struct filter_in *master;
   pthread_mutex_t lock;             /* serialises engine calls and bank bookkeeping */
+  pthread_rwlock_t stage_lock;      /* staged outputs: many channel threads read, the launcher / bank edits write */
   struct hbank *banks;
   int nbanks;
   struct notch_state *notch_ptr;    /* list last uploaded to the device */
@@ -86,6 +89,16 @@ struct sctx {
 
 static struct mctx *MCTX(struct filter_in *m) { return (struct mctx *)(void *)m->fwd_plan; }
 static struct sctx *SCTX(struct filter_out *s) { return (struct sctx *)(void *)s->rev_plan; }
+
+/* Block completion is published through completed_jobs[] itself with a futex: the ~1000 channel
+   threads of a big radiod all sleep on the same word and are released TOGETHER, instead of being
+   handed filter_mutex one by one as pthread_cond_broadcast does (a 5-10 ms convoy per block at 1024
+   threads).  Nothing outside filter.c touches filter_mutex / filter_cond / completed_jobs in the
+   reference, so the waiting primitive is an implementation detail; the condvar is still signalled. */
+static void futex_wait_u32(unsigned *addr, unsigned expected) {
+  syscall(SYS_futex, addr, FUTEX_WAIT_PRIVATE, expected, NULL, NULL, 0);
+}
+static void futex_wake_all(unsigned *addr) { syscall(SYS_futex, addr, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0); }
 
 static void *lmalloc(size_t size) {           /* cache-line aligned, like src/filter.c:1163 */
   void *p = NULL;
@@ -188,9 +201,10 @@ static void block_done(void *arg) {
   clock_gettime(CLOCK_MONOTONIC, &t1);
   pthread_mutex_lock(&f->filter_mutex);
   f->owner = pthread_self();
-  f->completed_jobs[n->job % ND] = n->job;              /* src/filter.c:526-529 */
-  pthread_cond_broadcast(&f->filter_cond);              /* src/filter.c:532-535 */
+  __atomic_store_n(&f->completed_jobs[n->job % ND], n->job, __ATOMIC_RELEASE);   /* src/filter.c:526-529 */
+  pthread_cond_broadcast(&f->filter_cond);              /* src/filter.c:532-535 (kept; nobody in this build waits on it) */
   pthread_mutex_unlock(&f->filter_mutex);
+  futex_wake_all(&f->completed_jobs[n->job % ND]);
   int64_t ns = (t1.tv_nsec - n->t0.tv_nsec) + 1000000000LL * (t1.tv_sec - n->t0.tv_sec);
   if (ns > Max_fft_time) Max_fft_time = ns;             /* src/filter.c:544-552 */
   if (ns < Min_fft_time) Min_fft_time = ns;
@@ -271,7 +285,7 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
     struct mctx *old = MCTX(master);
     chz_engine_destroy(old->eng);
     for (int i = 0; i < old->nbanks; i++) bank_free_host(&old->banks[i]);
-    free(old->banks); pthread_mutex_destroy(&old->lock); free(old);
+    free(old->banks); pthread_mutex_destroy(&old->lock); pthread_rwlock_destroy(&old->stage_lock); free(old);
     master->fwd_plan = NULL;
     for (int i = 0; i < ND; i++) { chz_host_free(master->fdomain[i]); master->fdomain[i] = NULL; }
     ring_unmap(&master->input_buffer, master->input_buffer_size);
@@ -286,6 +300,7 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   }
   c->master = master;
   pthread_mutex_init(&c->lock, NULL);
+  pthread_rwlock_init(&c->stage_lock, NULL);
   master->points = N;
   master->perform_inline = (N_worker_threads == 0);               /* src/filter.c:205 */
   for (int i = 0; i < ND; i++) {
@@ -332,6 +347,7 @@ int delete_filter_input(struct filter_in *master) {
     for (int i = 0; i < c->nbanks; i++) bank_free_host(&c->banks[i]);
     free(c->banks);
     pthread_mutex_destroy(&c->lock);
+    pthread_rwlock_destroy(&c->stage_lock);
     free(c);
   }
   if (master->init) { pthread_mutex_destroy(&master->filter_mutex); pthread_cond_destroy(&master->filter_cond); }
@@ -373,8 +389,10 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
     memset(slave->output_buffer.c, 0, sizeof(float complex) * (size_t)slave->points);
     slave->output.c = slave->output_buffer.c + slave->bins - len;   /* src/filter.c:357 */
     pthread_mutex_lock(&c->lock);
+    pthread_rwlock_wrlock(&c->stage_lock);
     int bi = bank_for(c, slave->points, len);
     if (bi < 0) {
+      pthread_rwlock_unlock(&c->stage_lock);
       pthread_mutex_unlock(&c->lock);
       fprintf(stderr, "create_filter_output: no device kernel for P=%d\n", slave->points);
       FREE(slave->fdomain); FREE(slave->output_buffer.c); free(sc);
@@ -386,6 +404,7 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
     for (int s = 0; s < ND; s++) b->stage_epoch[s][b->n] = 0;
     b->n++;
     slave->rev_plan = (fftwf_plan)(void *)sc;
+    pthread_rwlock_unlock(&c->stage_lock);
     pthread_mutex_unlock(&c->lock);
   }
   /* SPECTRUM: no buffers, no plan: a block clock only (src/filter.c:368-371) */
@@ -400,6 +419,7 @@ int delete_filter_output(struct filter_out *slave) {
     struct mctx *c = MCTX(slave->master);
     struct sctx *sc = SCTX(slave);
     pthread_mutex_lock(&c->lock);
+    pthread_rwlock_wrlock(&c->stage_lock);
     struct hbank *b = &c->banks[sc->bank];
     int last = b->n - 1;
     if (sc->idx != last) {                 /* the last channel moves into the freed index */
@@ -412,6 +432,7 @@ int delete_filter_output(struct filter_out *slave) {
       for (int s = 0; s < ND; s++) b->stage_epoch[s][ms->idx] = 0;
     }
     b->slaves[last] = NULL; b->n--;
+    pthread_rwlock_unlock(&c->stage_lock);
     pthread_mutex_unlock(&c->lock);
     free(sc);
   }
@@ -470,12 +491,14 @@ int execute_filter_input(struct filter_in *const f) {
   /* speculative batched channel launches: every slave with its last-known shift */
   for (int i = 0; rc == 0 && i < c->nbanks; i++) {
     struct hbank *b = &c->banks[i];
+    pthread_rwlock_wrlock(&c->stage_lock);
     b->stage_job[slot] = job; b->stage_n[slot] = b->n;
-    if (b->n == 0) continue;
     for (int k = 0; k < b->n; k++) {
       b->stage_shift[slot][k] = b->shift[k];
       b->stage_epoch[slot][k] = b->slaves[k]->response ? SCTX(b->slaves[k])->epoch : 0;
     }
+    pthread_rwlock_unlock(&c->stage_lock);
+    if (b->n == 0) continue;
     chz_bank_set_active(c->eng, b->id, b->n);
     rc = chz_bank_execute(c->eng, b->id, slot);
     if (rc == 0) rc = chz_bank_read_async(c->eng, b->id, slot, 0, b->n, (float *)b->stage[slot]);
@@ -523,28 +546,26 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
   struct filter_in *const master = slave->master;
   if (master == NULL) return -1;
 
-  pthread_mutex_lock(&master->filter_mutex);
-  if (master->owner == pthread_self()) {
+  /* same wait / lap arithmetic as src/filter.c:680-702, on a futex instead of filter_cond */
+  if (pthread_equal(__atomic_load_n(&master->owner, __ATOMIC_ACQUIRE), pthread_self()))
     slave->next_jobnum = master->next_jobnum - 1;                  /* src/filter.c:681-683 */
-    while ((int)(slave->next_jobnum - master->completed_jobs[slave->next_jobnum % ND]) > 0)
-      pthread_cond_wait(&master->filter_cond, &master->filter_mutex);   /* device may still be running */
-  } else {
-    while ((int)(slave->next_jobnum - master->completed_jobs[slave->next_jobnum % ND]) > 0)
-      pthread_cond_wait(&master->filter_cond, &master->filter_mutex);   /* src/filter.c:686-687 */
-    int blocks_behind = (int)(master->completed_jobs[slave->next_jobnum % ND] - slave->next_jobnum);
-    if (blocks_behind >= ND) {                                     /* lapped: zeros + drop (src/filter.c:690-701) */
-      pthread_mutex_unlock(&master->filter_mutex);
-      slave->block_drops++;
-      slave->next_jobnum++;
-      if (slave->output_buffer.c != NULL) memset(slave->output_buffer.c, 0, (size_t)slave->points * sizeof *slave->output_buffer.c);
-      return 0;
-    }
-  }
   unsigned const job = slave->next_jobnum;
   int const slot = (int)(job % ND);
+  for (;;) {
+    unsigned done = __atomic_load_n(&master->completed_jobs[slot], __ATOMIC_ACQUIRE);
+    if ((int)(job - done) <= 0) {
+      if ((int)(done - job) >= ND) {                               /* lapped: zeros + drop (src/filter.c:690-701) */
+        slave->block_drops++;
+        slave->next_jobnum++;
+        if (slave->output_buffer.c != NULL) memset(slave->output_buffer.c, 0, (size_t)slave->points * sizeof *slave->output_buffer.c);
+        return 0;
+      }
+      break;
+    }
+    futex_wait_u32(&master->completed_jobs[slot], done);           /* src/filter.c:686-687 */
+  }
   slave->sample_index = master->samples_by_job[slot];              /* src/filter.c:705 */
   slave->next_jobnum++;
-  pthread_mutex_unlock(&master->filter_mutex);
 
   if (slave->out_type == SPECTRUM || slave->rev_plan == NULL) return 0;   /* block clock only */
   pthread_mutex_lock(&slave->response_mutex);
@@ -554,21 +575,30 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
 
   struct mctx *c = MCTX(master);
   struct sctx *sc = SCTX(slave);
+  bool hit = false;
+  pthread_rwlock_rdlock(&c->stage_lock);
+  {
+    struct hbank *b = &c->banks[sc->bank];
+    int const k = sc->idx;
+    if (b->stage_job[slot] == job && k < b->stage_n[slot] && b->stage_shift[slot][k] == shift &&
+        b->stage_epoch[slot][k] == sc->epoch) {
+      /* the speculative batch already computed exactly this */
+      memcpy(slave->output.c, b->stage[slot] + (size_t)k * b->olen, sizeof(float complex) * (size_t)b->olen);
+      hit = true;
+    }
+  }
+  pthread_rwlock_unlock(&c->stage_lock);
+  if (hit) return 0;
+
+  /* retuned / new filter / newly created: run this one channel on the block's spectrum */
   int rc = 0;
   pthread_mutex_lock(&c->lock);
   struct hbank *b = &c->banks[sc->bank];
   int const k = sc->idx;
-  if (b->stage_job[slot] == job && k < b->stage_n[slot] && b->stage_shift[slot][k] == shift &&
-      b->stage_epoch[slot][k] == sc->epoch) {
-    /* the speculative batch already computed exactly this */
-    memcpy(slave->output.c, b->stage[slot] + (size_t)k * b->olen, sizeof(float complex) * (size_t)b->olen);
-  } else {
-    /* retuned / new filter / newly created: run this one channel on the block's spectrum */
-    if (b->shift[k] != shift) { b->shift[k] = shift; rc = chz_bank_set_shifts(c->eng, b->id, k, 1, &b->shift[k]); }
-    if (rc == 0) rc = chz_bank_execute_range(c->eng, b->id, slot, k, 1);
-    if (rc == 0) rc = chz_bank_read(c->eng, b->id, k, 1, (float *)slave->output.c);
-    if (rc != 0) fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
-  }
+  if (b->shift[k] != shift) { b->shift[k] = shift; rc = chz_bank_set_shifts(c->eng, b->id, k, 1, &b->shift[k]); }
+  if (rc == 0) rc = chz_bank_execute_range(c->eng, b->id, slot, k, 1);
+  if (rc == 0) rc = chz_bank_read(c->eng, b->id, k, 1, (float *)slave->output.c);
+  if (rc != 0) fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
   pthread_mutex_unlock(&c->lock);
   return rc == 0 ? 0 : -1;
 }
@@ -619,7 +649,9 @@ int set_filter(struct filter_out *const slave, double low, double high, double c
     struct mctx *c = MCTX(slave->master);
     struct sctx *sc = SCTX(slave);
     pthread_mutex_lock(&c->lock);
+    pthread_rwlock_wrlock(&c->stage_lock);
     sc->epoch++;
+    pthread_rwlock_unlock(&c->stage_lock);
     int rc = chz_bank_set_responses(c->eng, c->banks[sc->bank].id, sc->idx, 1, (const float *)response);
     pthread_mutex_unlock(&c->lock);
     if (rc != 0) { fprintf(stderr, "set_filter: %s\n", chz_last_error()); return -1; }
