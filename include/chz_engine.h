@@ -123,6 +123,10 @@ int chz_host_callback(chz_engine *e, int slot, void (*fn)(void *), void *arg);
 /* page-locked host memory for the buffers the device copies into */
 int chz_host_alloc(void **p, size_t bytes);
 void chz_host_free(void *p);
+/* page-lock memory the caller already owns (the mirrored host input ring) so chz_input_write DMAs
+ * straight out of it; failure is not fatal, copies then go through the runtime's staging buffer */
+int chz_host_register(void *p, size_t bytes);
+void chz_host_unregister(void *p);
 int chz_bank_output_device(chz_engine *e, int bank, int slot, float **dev);
 
 /* one whole block: chz_forward(job) then every bank on slot job % 4 */

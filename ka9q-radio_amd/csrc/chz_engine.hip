@@ -527,6 +527,13 @@ int chz_host_alloc(void** p, size_t bytes) {
   return 0;
 }
 void chz_host_free(void* p) { if (p) (void)hipHostFree(p); }
+int chz_host_register(void* p, size_t bytes) {
+  if (!p || !bytes) return fail(-1, "bad argument");
+  hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); return fail(-10, "hipHostRegister failed: %s", hipGetErrorString(e)); }
+  return 0;
+}
+void chz_host_unregister(void* p) { if (p) (void)hipHostUnregister(p); }
 int chz_bank_read(chz_engine* e, int bank, int ch0, int n, float* host) {
   BANK_CHECK(e, bank, ch0, n);
   Bank& b = e->banks[(size_t)bank];

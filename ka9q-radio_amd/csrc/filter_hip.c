@@ -75,6 +75,7 @@ struct mctx {
   pthread_rwlock_t stage_lock;      /* staged outputs: many channel threads read, the launcher / bank edits write */
   struct hbank *banks;
   int nbanks;
+  bool ring_pinned;                 /* host ring registered with the HIP runtime */
   struct notch_state *notch_ptr;    /* list last uploaded to the device */
   int notch_n;
   int notch_bins[64];
@@ -283,6 +284,7 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
 
   if (master->init && master->fwd_plan) {                          /* re-create with new geometry */
     struct mctx *old = MCTX(master);
+    if (old->ring_pinned) chz_host_unregister(master->input_buffer);
     chz_engine_destroy(old->eng);
     for (int i = 0; i < old->nbanks; i++) bank_free_host(&old->banks[i]);
     free(old->banks); pthread_mutex_destroy(&old->lock); pthread_rwlock_destroy(&old->stage_lock); free(old);
@@ -323,6 +325,8 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   master->input_buffer = ring_map(master->input_buffer_size);
   if (!master->input_buffer) { perror("create_filter_input: ring"); return -1; }
   memset(master->input_buffer, 0, master->input_buffer_size);
+  /* both mappings of the ring, so a window that runs into the mirror is still DMA-able */
+  c->ring_pinned = chz_host_register(master->input_buffer, 2 * master->input_buffer_size) == 0;
   if (in_type == COMPLEX) {                                        /* src/filter.c:243-246 */
     master->input_read_pointer.c = master->input_buffer;
     master->input_write_pointer.c = master->input_read_pointer.c + (M - 1);
@@ -343,6 +347,7 @@ int delete_filter_input(struct filter_in *master) {
   if (master->fwd_plan) {
     struct mctx *c = MCTX(master);
     chz_sync(c->eng);
+    if (c->ring_pinned) chz_host_unregister(master->input_buffer);
     chz_engine_destroy(c->eng);
     for (int i = 0; i < c->nbanks; i++) bank_free_host(&c->banks[i]);
     free(c->banks);

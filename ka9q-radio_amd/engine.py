@@ -36,7 +36,7 @@ SYMBOLS = [
     "chz_forward", "chz_slot_stream", "chz_set_notches", "chz_spectrum_read", "chz_spectrum_device", "chz_spectrum_attach",
     "chz_bank_create", "chz_bank_set_responses", "chz_bank_set_shifts", "chz_bank_set_active",
     "chz_bank_execute", "chz_bank_execute_range", "chz_bank_destroy", "chz_bank_read", "chz_bank_read_async",
-    "chz_spectrum_read_async", "chz_host_callback", "chz_host_alloc", "chz_host_free",
+    "chz_spectrum_read_async", "chz_host_callback", "chz_host_alloc", "chz_host_free", "chz_host_register", "chz_host_unregister",
     "chz_bank_output_device", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
 ]
 
