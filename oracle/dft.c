@@ -21,15 +21,79 @@
 #undef DFT_REAL
 #undef DFT_NAME
 
+/* Cache-friendly "four-step" path for the float32 CPU baseline: a long transform of length
+   h = n1*n2 becomes n2 column transforms of length n1 (gathered 8 columns at a time so every cache
+   line fetched is used), a twiddle, and n1 contiguous row transforms of length n2 written back
+   transposed in blocks of 8.  Only the timing leg uses it; the float64 oracle stays on the plain
+   recursion. */
+struct four_step {
+  int h, n1, n2;
+  f32_plan *p1, *p2;
+  double *wstep;     /* W_h^{j2} (re,im), j2 = 0..n2-1: the per-column twiddle step */
+};
+
 struct odft_plan {
   int n;
   int precision;
+  struct four_step *fs;   /* for the length-n/2 complex transform behind the float32 r2c, when n is large */
   d64_plan *full64;   /* length n   (lazily built) */
   d64_plan *half64;   /* length n/2 (lazily built, even n only) */
   f32_plan *full32;
   f32_plan *half32;
   double *rtw;        /* W_n^k, k = 0..n/2, interleaved (re,im), forward sign; lazily built */
 };
+
+static struct four_step *four_step_create(int h) {
+  if (h < 65536) return NULL;
+  int best = 0;
+  for (int a = 2; (long)a * a <= h; a++) if (h % a == 0) best = a;     /* n2 = largest divisor <= sqrt(h) */
+  if (best < 64) return NULL;
+  struct four_step *fs = (struct four_step *)calloc(1, sizeof *fs);
+  fs->h = h; fs->n2 = best; fs->n1 = h / best;
+  fs->p1 = f32_plan_create(fs->n1); fs->p2 = f32_plan_create(fs->n2);
+  fs->wstep = (double *)malloc(sizeof(double) * 2 * (size_t)fs->n2);
+  for (int j = 0; j < fs->n2; j++) { double s, c; sincos(-2.0 * M_PI * j / h, &s, &c); fs->wstep[2 * j] = c; fs->wstep[2 * j + 1] = s; }
+  return fs;
+}
+static void four_step_destroy(struct four_step *fs) {
+  if (!fs) return;
+  f32_plan_destroy(fs->p1); f32_plan_destroy(fs->p2); free(fs->wstep); free(fs);
+}
+/* forward transform of h complex points, out-of-place */
+static void four_step_forward(const struct four_step *fs, const f32_cpx *in, f32_cpx *out) {
+  const int n1 = fs->n1, n2 = fs->n2, TB = 8;
+  f32_cpx *T = (f32_cpx *)malloc(sizeof(f32_cpx) * (size_t)fs->h);
+  f32_cpx *col = (f32_cpx *)malloc(sizeof(f32_cpx) * (size_t)TB * (n1 > n2 ? n1 : n2) * 2);
+  f32_cpx *res = col + (size_t)TB * (n1 > n2 ? n1 : n2);
+  /* columns: Y[k1][j2] = sum_j1 x[j1*n2 + j2] W_n1^(j1 k1), then times W_h^(j2 k1) */
+  for (int j0 = 0; j0 < n2; j0 += TB) {
+    const int tb = n2 - j0 < TB ? n2 - j0 : TB;
+    for (int j1 = 0; j1 < n1; j1++)
+      for (int t = 0; t < tb; t++) col[(size_t)t * n1 + j1] = in[(size_t)j1 * n2 + j0 + t];
+    for (int t = 0; t < tb; t++) {
+      f32_execute(fs->p1, col + (size_t)t * n1, res + (size_t)t * n1, -1);
+      /* twiddle by recurrence in double: w_{k1} = W_h^{(j0+t) k1} */
+      const double sr = fs->wstep[2 * (j0 + t)], si = fs->wstep[2 * (j0 + t) + 1];
+      double wr = 1.0, wi = 0.0;
+      f32_cpx *r = res + (size_t)t * n1;
+      for (int k1 = 0; k1 < n1; k1++) {
+        const float a = r[k1].re, b = r[k1].im;
+        r[k1].re = (float)(a * wr - b * wi); r[k1].im = (float)(a * wi + b * wr);
+        const double nr = wr * sr - wi * si; wi = wr * si + wi * sr; wr = nr;
+      }
+    }
+    for (int k1 = 0; k1 < n1; k1++)
+      for (int t = 0; t < tb; t++) T[(size_t)k1 * n2 + j0 + t] = res[(size_t)t * n1 + k1];
+  }
+  /* rows: Z[k1][k2] = sum_j2 T[k1][j2] W_n2^(j2 k2), out[k1 + n1*k2] */
+  for (int k0 = 0; k0 < n1; k0 += TB) {
+    const int tb = n1 - k0 < TB ? n1 - k0 : TB;
+    for (int t = 0; t < tb; t++) f32_execute(fs->p2, T + (size_t)(k0 + t) * n2, res + (size_t)t * n2, -1);
+    for (int k2 = 0; k2 < n2; k2++)
+      for (int t = 0; t < tb; t++) out[(size_t)k0 + t + (size_t)n1 * k2] = res[(size_t)t * n2 + k2];
+  }
+  free(T); free(col);
+}
 
 odft_plan *odft_create(int n, int precision) {
   if (n < 1) return NULL;
@@ -44,6 +108,7 @@ void odft_destroy(odft_plan *p) {
   if (!p) return;
   d64_plan_destroy(p->full64); d64_plan_destroy(p->half64);
   f32_plan_destroy(p->full32); f32_plan_destroy(p->half32);
+  four_step_destroy(p->fs);
   free(p->rtw);
   free(p);
 }
@@ -74,7 +139,13 @@ static const double *need_rtw(odft_plan *p) {
 void odft_warm(odft_plan *p, int real) {
   /* force table construction from a single thread */
   if (p->precision == ODFT_F64) { if (real && !(p->n & 1)) { need_half64(p); need_rtw(p); } else need_full64(p); }
-  else { if (real && !(p->n & 1)) { need_half32(p); need_rtw(p); } else need_full32(p); }
+  else {
+    if (real && !(p->n & 1)) {
+      if (!p->fs) p->fs = four_step_create(p->n / 2);
+      if (!p->fs) need_half32(p);
+      need_rtw(p);
+    } else need_full32(p);
+  }
 }
 
 void odft_c2c_f64(odft_plan *p, const double *in, double *out, int sign) {
@@ -170,10 +241,10 @@ void odft_r2c(odft_plan *p, const float *in, float *out) {
     free(a);
     return;
   }
-  f32_plan *pl = need_half32(p);
   const double *tw = need_rtw(p);
   f32_cpx *z = (f32_cpx *)malloc(sizeof(f32_cpx) * (size_t)h);
-  f32_execute(pl, (const f32_cpx *)in, z, -1);
+  if (p->fs) four_step_forward(p->fs, (const f32_cpx *)in, z);
+  else f32_execute(need_half32(p), (const f32_cpx *)in, z, -1);
   for (int k = 0; k <= h; k++) {
     f32_cpx a = z[k == h ? 0 : k];
     f32_cpx b = z[k == 0 ? 0 : h - k];
