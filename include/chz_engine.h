@@ -75,6 +75,16 @@ int chz_sync(chz_engine *e);
 int chz_input_write(chz_engine *e, const float *host_samples, long n);
 /* same, but the samples already live in device memory */
 int chz_input_write_device(chz_engine *e, const float *dev_samples, long n);
+/* SURVEY 8(f) rank 3 -- raw A/D samples: replaces rx888.c's convert() + write_rfilter(.., NULL, n)
+ * (src/rx888.c:753-767,800-829).  The int16 samples go to HBM as they are (half the PCIe bytes, half the
+ * first pass's reads); x -> (float)x * scale, the LTC2208 de-randomiser (randomize != 0: if bit 0 is set,
+ * flip bits 1..15, src/rx888.c:711-716) and the per-block statistics happen where the first transform
+ * pass loads the samples.  REAL masters only; an engine takes either float or int16 input, not both. */
+int chz_input_write_i16(chz_engine *e, const short *host_samples, long n, float scale, int randomize);
+int chz_input_write_i16_device(chz_engine *e, const short *dev_samples, long n, float scale, int randomize);
+/* sum of x*x and count of |x| > 32766 over the L new samples of the block last transformed into `slot`
+ * (what rx_callback accumulates into frontend->if_power / overranges, src/rx888.c:780-795); synchronous */
+int chz_input_stats(chz_engine *e, int slot, unsigned long long *energy, unsigned *clips);
 /* direct access to the device ring for HBM-resident benchmarks */
 int chz_input_ring(chz_engine *e, float **dev_ring, long *ring_len_floats);
 
@@ -104,9 +114,27 @@ int chz_bank_set_shifts(chz_engine *e, int bank, int ch0, int n, const int *shif
 int chz_bank_set_active(chz_engine *e, int bank, int n);                    /* channels [0,n) run */
 /* replaces execute_filter_output's gather x response + backward transform
  * (src/filter.c:728-914) for every active channel of the bank at once */
-int chz_bank_execute(chz_engine *e, int bank, int slot);
+/* the bank runs on the spectrum of block `job` (slot job % 4); for a bank without tuning only the slot
+ * matters, so passing a slot number 0..3 is equivalent */
+int chz_bank_execute(chz_engine *e, int bank, unsigned job);
 /* the same for channels [ch0, ch0+n) only: the slow path of one retuned channel */
-int chz_bank_execute_range(chz_engine *e, int bank, int slot, int ch0, int n);
+int chz_bank_execute_range(chz_engine *e, int bank, unsigned job, int ch0, int n);
+
+/* SURVEY 8(f) rank 1 -- the tail of radiod's downconvert() fused into the channel kernel's epilogue
+ * (src/radio.c:1476-1520): every output sample is multiplied by the channel's fine-tuning rotator
+ * (set_osc/step_osc, src/osc.c:28-70) including the per-block phase_adjust for bin shifts that are not a
+ * multiple of the overlap factor V = 1 + L/(M-1) and the one-time phase kick on a shift change, and the
+ * block's mean |sample|^2 (chan->sig.bb_power) is left in a per-slot array.
+ *   shifts[i]  as for chz_bank_set_shifts (this call replaces it for tuned channels)
+ *   freq[i]    cycles per OUTPUT sample, = -remainder / output samprate   (first argument of set_osc)
+ *   rate[i]    cycles per sample^2,       = doppler_rate / samprate^2     (second argument; NULL = 0)
+ * The update takes effect at block `job`, which must not have been enqueued yet; call it when shift,
+ * remainder or sweep rate change (it synchronises the engine), not every block.  The rotation is a closed
+ * form in the block number, so tuned banks run eagerly (chz_run_blocks mode 0), any number in flight. */
+int chz_bank_set_tuning(chz_engine *e, int bank, unsigned job, int ch0, int n, const int *shifts,
+                        const double *freq, const double *rate);
+int chz_bank_read_power(chz_engine *e, int bank, int slot, int ch0, int n, double *host);        /* synchronous */
+int chz_bank_read_power_async(chz_engine *e, int bank, int slot, int ch0, int n, double *host);
 int chz_bank_destroy(chz_engine *e, int bank);                              /* frees the bank's device arrays */
 int chz_bank_read(chz_engine *e, int bank, int ch0, int n, float *host);    /* n*olen complex of the most recent execute, synchronous */
 /* Blocks are pipelined over 1, 2 or 4 HIP streams ("lanes", env CHZ_STREAMS, default 4): block j

@@ -13,7 +13,9 @@
 #include <chrono>
 #include <string>
 #include <vector>
+#include <cmath>
 #include "chz_launch.h"
+#include "chz_finetune.h"
 #include "../../include/chz_engine.h"
 
 using namespace chz;
@@ -34,6 +36,10 @@ struct Bank {
   float2* out = nullptr;        // [ND][cap][olen]: one output image per spectrum slot
   float2* tw_sub = nullptr;
   int last_slot = 0;            // slot of the most recent execute (what chz_bank_read returns)
+  // fine tuning (tail of downconvert(), src/radio.c:1476-1520); allocated by the first chz_bank_set_tuning
+  std::vector<FineHost> fine_h; // [cap]
+  FineDesc* fine = nullptr;     // [cap]
+  double* power = nullptr;      // [ND][cap]
 };
 
 // A lane = one HIP stream + its own intermediate buffer.  Consecutive blocks go to
@@ -55,6 +61,9 @@ struct chz_engine {
   hipEvent_t input_ready = nullptr; // after the latest ring write
   bool input_pending = false;
   float* ring = nullptr; long ring_len = 0;   // floats
+  // raw A/D input: the ring holds int16 and fwd_first_real converts on load
+  short* ring16 = nullptr; float scale16 = 1.0f; int derand = 0;
+  unsigned long long* energy_part = nullptr; unsigned* clip_part = nullptr; int stat_n = 0;   // [ND][stat_n] per-wave partials
   long wpos = 0;                              // write position (floats)
   float2* spec[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};
   bool spec_owned[CHZ_ND] = {false, false, false, false};
@@ -163,7 +172,7 @@ void chz_engine_destroy(chz_engine* e) {
   }
   hipEventDestroy(e->input_ready);
   for (auto& b : e->banks) { hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); }
-  hipFree(e->ring);
+  hipFree(e->ring); hipFree(e->ring16); hipFree(e->energy_part); hipFree(e->clip_part);
   for (int i = 0; i < CHZ_ND; i++) if (e->spec_owned[i]) hipFree(e->spec[i]);
   hipFree(e->tw_sub_a); hipFree(e->tw_sub_b); hipFree(e->tw_sub_c);
   hipFree(e->tw1_tile); hipFree(e->tw1_col); hipFree(e->tw2_tile); hipFree(e->tw2_col);
@@ -208,6 +217,7 @@ int chz_sync(chz_engine* e) {
 }
 
 static int ring_write(chz_engine* e, const float* src, long n, hipMemcpyKind kind) {
+  if (e->ring16) return fail(-1, "int16 and float input cannot be mixed on one engine");
   const long nf = n * e->per;
   if (nf < 0 || nf > e->ring_len) return fail(-1, "write of %ld samples does not fit the ring", n);
   const long first = (e->wpos + nf <= e->ring_len) ? nf : e->ring_len - e->wpos;
@@ -224,6 +234,56 @@ int chz_input_write(chz_engine* e, const float* host, long n) {
 int chz_input_write_device(chz_engine* e, const float* dev, long n) {
   if (!e || !dev) return fail(-1, "null argument");
   return ring_write(e, dev, n, hipMemcpyDeviceToDevice);
+}
+// rx888.c's convert() + write_rfilter(.., NULL, n) (src/rx888.c:753-767,800-829): the samples stay int16
+// all the way into HBM (half the PCIe and half the first pass's read bytes); scaling, de-randomising,
+// the energy sum and the clip count happen where the first transform pass loads them.
+static int ring16_write(chz_engine* e, const short* src, long n, float scale, int randomize, hipMemcpyKind kind) {
+  if (e->in_type != CHZ_REAL) return fail(-1, "int16 input is a real A/D stream");
+  if (n < 0 || n > e->ring_len) return fail(-1, "write of %ld samples does not fit the ring", n);
+  HIPOK(hipSetDevice(e->device));
+  if (!e->ring16) {
+    if (e->wpos != (long)(e->M - 1)) return fail(-1, "int16 and float input cannot be mixed on one engine");
+    HIPOK(hipMalloc((void**)&e->ring16, sizeof(short) * (size_t)e->ring_len));
+    HIPOK(hipMemset(e->ring16, 0, sizeof(short) * (size_t)e->ring_len));
+    e->stat_n = e->plan.grid1 * (e->plan.block1 / 64);
+    HIPOK(hipMalloc((void**)&e->energy_part, sizeof(unsigned long long) * (size_t)CHZ_ND * e->stat_n));
+    HIPOK(hipMalloc((void**)&e->clip_part, sizeof(unsigned) * (size_t)CHZ_ND * e->stat_n));
+    HIPOK(hipMemset(e->energy_part, 0, sizeof(unsigned long long) * (size_t)CHZ_ND * e->stat_n));
+    HIPOK(hipMemset(e->clip_part, 0, sizeof(unsigned) * (size_t)CHZ_ND * e->stat_n));
+    drop_graph(e);
+  }
+  if (scale != e->scale16 || (randomize != 0) != (e->derand != 0)) drop_graph(e);   // baked into captured launches
+  e->scale16 = scale; e->derand = randomize != 0;
+  const long first = (e->wpos + n <= e->ring_len) ? n : e->ring_len - e->wpos;
+  if (first > 0) HIPOK(hipMemcpyAsync(e->ring16 + e->wpos, src, sizeof(short) * (size_t)first, kind, e->stream));
+  if (n > first) HIPOK(hipMemcpyAsync(e->ring16, src + first, sizeof(short) * (size_t)(n - first), kind, e->stream));
+  e->wpos = (e->wpos + n) % e->ring_len;
+  if (e->nlanes > 1) { HIPOK(hipEventRecord(e->input_ready, e->stream)); e->input_pending = true; }
+  return 0;
+}
+int chz_input_write_i16(chz_engine* e, const short* host, long n, float scale, int randomize) {
+  if (!e || !host) return fail(-1, "null argument");
+  return ring16_write(e, host, n, scale, randomize, hipMemcpyHostToDevice);
+}
+int chz_input_write_i16_device(chz_engine* e, const short* dev, long n, float scale, int randomize) {
+  if (!e || !dev) return fail(-1, "null argument");
+  return ring16_write(e, dev, n, scale, randomize, hipMemcpyDeviceToDevice);
+}
+// sum of x^2 and number of clipped samples over the L new samples of the block last transformed into `slot`
+int chz_input_stats(chz_engine* e, int slot, unsigned long long* energy, unsigned* clips) {
+  if (!e || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
+  if (!e->ring16) return fail(-1, "input statistics exist for int16 input only");
+  std::vector<unsigned long long> en((size_t)e->stat_n); std::vector<unsigned> cl((size_t)e->stat_n);
+  hipStream_t st = e->lanes[slot % e->nlanes].s;
+  HIPOK(hipMemcpyAsync(en.data(), e->energy_part + (size_t)slot * e->stat_n, sizeof(unsigned long long) * en.size(), hipMemcpyDeviceToHost, st));
+  HIPOK(hipMemcpyAsync(cl.data(), e->clip_part + (size_t)slot * e->stat_n, sizeof(unsigned) * cl.size(), hipMemcpyDeviceToHost, st));
+  HIPOK(hipStreamSynchronize(st));
+  unsigned long long se = 0; unsigned sc = 0;
+  for (size_t i = 0; i < en.size(); i++) { se += en[i]; sc += cl[i]; }
+  if (energy) *energy = se;
+  if (clips) *clips = sc;
+  return 0;
 }
 int chz_input_ring(chz_engine* e, float** dev_ring, long* ring_len_floats) {
   if (!e) return fail(-1, "null engine");
@@ -280,6 +340,10 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
     FirstRealParams a{};
     a.ring = e->ring; a.ring_len = e->ring_len; a.start = start; a.buf = lbuf; a.inner = p.inner;
     a.T = p.T1; a.Ra = p.Ra; a.padk = p.padk1; a.tw_sub = e->tw_sub_a; a.tw_tile = e->tw1_tile; a.tw_col = e->tw1_col;
+    if (e->ring16) {
+      a.ring16 = e->ring16; a.scale16 = e->scale16; a.derand = e->derand; a.new_from = e->M - 1;
+      a.energy_part = e->energy_part + (size_t)slot * e->stat_n; a.clip_part = e->clip_part + (size_t)slot * e->stat_n;
+    }
     mark(in, st, 0, true);
     if (launch_first_real(p.ra, p.grid1, p.block1, p.lds1, st, a, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis a");
     mark(in, st, 0, false);
@@ -314,16 +378,18 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
 
 static inline float2* bank_out(const Bank& b, int slot) { return b.out + (size_t)slot * b.cap * b.olen; }
 
-static int enqueue_bank(chz_engine* e, int bank, int slot, Instr* in, int ch0 = 0, int n = -1) {
+static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch0 = 0, int n = -1) {
   Bank& b = e->banks[(size_t)bank];
   if (n < 0) n = b.active;
   if (n <= 0 || !b.resp) return 0;
+  const int slot = (int)(job % CHZ_ND);
   hipStream_t st = e->lanes[lane_of(e, (unsigned)slot, in)].s;
   b.last_slot = slot;
   ChanParams c{};
   c.lay = SpecLayout{e->plan.Na, e->plan.spec_pitch, e->plan.spec_off}; c.inv_na = 1.0f / (float)e->plan.Na;
   c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc; c.out = bank_out(b, slot); c.ch0 = ch0; c.nch = n; c.olen = b.olen;
   c.tw_sub = b.tw_sub;
+  c.fine = b.fine; c.power = b.power ? b.power + (size_t)slot * b.cap : nullptr; c.job = job;
   const int per_block = b.g.wpb * b.g.cpw;
   const int grid = (n + per_block - 1) / per_block;
   mark(in, st, 4, true);
@@ -470,26 +536,77 @@ int chz_bank_set_shifts(chz_engine* e, int bank, int ch0, int n, const int* shif
   HIPOK(hipStreamSynchronize(e->stream));
   return 0;
 }
+// The tuning half of downconvert() (src/radio.c:1440-1441,1479-1497): bin shift for the gather plus the fine
+// oscillator.  Takes effect at block `job`; blocks before it must already have been enqueued.
+int chz_bank_set_tuning(chz_engine* e, int bank, unsigned job, int ch0, int n, const int* shifts,
+                        const double* freq, const double* rate) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (!shifts || !freq) return fail(-1, "null argument");
+  Bank& b = e->banks[(size_t)bank];
+  if (e->M < 2) return fail(-1, "impulse length %d has no overlap factor", e->M);
+  const int V = 1 + e->L / (e->M - 1);
+  HIPOK(hipSetDevice(e->device));
+  if (!b.fine) {
+    b.fine_h.assign((size_t)b.cap, FineHost());
+    HIPOK(hipMalloc((void**)&b.fine, sizeof(FineDesc) * (size_t)b.cap));
+    HIPOK(hipMemset(b.fine, 0, sizeof(FineDesc) * (size_t)b.cap));
+    HIPOK(hipMalloc((void**)&b.power, sizeof(double) * (size_t)CHZ_ND * b.cap));
+    HIPOK(hipMemset(b.power, 0, sizeof(double) * (size_t)CHZ_ND * b.cap));
+    drop_graph(e);
+  }
+  std::vector<ChanDesc> d((size_t)n);
+  std::vector<FineDesc> f((size_t)n);
+  for (int i = 0; i < n; i++) {
+    if (!std::isfinite(freq[i]) || (rate && !std::isfinite(rate[i]))) return fail(-1, "non-finite tuning for channel %d", ch0 + i);
+    ChanDescH h = make_chan_desc(e->in_type, e->bins, b.P, shifts[i]);
+    d[(size_t)i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
+    FineHost& fh = b.fine_h[(size_t)(ch0 + i)];
+    fine_retune(fh, job, b.olen, V, shifts[i], freq[i], rate ? rate[i] : 0.0);
+    f[(size_t)i] = fine_desc(fh, V);
+  }
+  { int r = sync_all(e); if (r) return r; }   // earlier blocks still read the old descriptors
+  HIPOK(hipMemcpyAsync(b.desc + ch0, d.data(), sizeof(ChanDesc) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+  HIPOK(hipMemcpyAsync(b.fine + ch0, f.data(), sizeof(FineDesc) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+// chan->sig.bb_power of channels [ch0, ch0+n) for the block last executed on `slot` (src/radio.c:1516-1520)
+int chz_bank_read_power(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (slot < 0 || slot >= CHZ_ND || !host) return fail(-1, "bad argument");
+  Bank& b = e->banks[(size_t)bank];
+  if (!b.power) return fail(-1, "bank has no tuning: call chz_bank_set_tuning first");
+  hipStream_t st = slot_stream(e, slot);
+  HIPOK(hipMemcpyAsync(host, b.power + (size_t)slot * b.cap + ch0, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+  HIPOK(hipStreamSynchronize(st));
+  return 0;
+}
+int chz_bank_read_power_async(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (slot < 0 || slot >= CHZ_ND || !host) return fail(-1, "bad argument");
+  Bank& b = e->banks[(size_t)bank];
+  if (!b.power) return fail(-1, "bank has no tuning: call chz_bank_set_tuning first");
+  HIPOK(hipMemcpyAsync(host, b.power + (size_t)slot * b.cap + ch0, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, slot_stream(e, slot)));
+  return 0;
+}
 int chz_bank_set_active(chz_engine* e, int bank, int n) {
   BANK_CHECK(e, bank, 0, n);
   if (e->banks[(size_t)bank].active != n) drop_graph(e);
   e->banks[(size_t)bank].active = n;
   return 0;
 }
-int chz_bank_execute(chz_engine* e, int bank, int slot) {
+int chz_bank_execute(chz_engine* e, int bank, unsigned job) {
   BANK_CHECK(e, bank, 0, 0);
-  if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
   HIPOK(hipSetDevice(e->device));
-  int r = enqueue_bank(e, bank, slot, nullptr);
+  int r = enqueue_bank(e, bank, job, nullptr);
   if (r) return r;
   HIPOK(hipGetLastError());
   return 0;
 }
-int chz_bank_execute_range(chz_engine* e, int bank, int slot, int ch0, int n) {
+int chz_bank_execute_range(chz_engine* e, int bank, unsigned job, int ch0, int n) {
   BANK_CHECK(e, bank, ch0, n);
-  if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
   HIPOK(hipSetDevice(e->device));
-  int r = enqueue_bank(e, bank, slot, nullptr, ch0, n);
+  int r = enqueue_bank(e, bank, job, nullptr, ch0, n);
   if (r) return r;
   HIPOK(hipGetLastError());
   return 0;
@@ -499,8 +616,9 @@ int chz_bank_destroy(chz_engine* e, int bank) {
   Bank& b = e->banks[(size_t)bank];
   { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
-  hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub);
-  b.resp = nullptr; b.desc = nullptr; b.out = nullptr; b.tw_sub = nullptr; b.active = 0; b.cap = 0;
+  hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); hipFree(b.fine); hipFree(b.power);
+  b.resp = nullptr; b.desc = nullptr; b.out = nullptr; b.tw_sub = nullptr; b.fine = nullptr; b.power = nullptr;
+  b.fine_h.clear(); b.active = 0; b.cap = 0;
   return 0;
 }
 int chz_bank_read_async(chz_engine* e, int bank, int slot, int ch0, int n, float* host) {
@@ -553,7 +671,7 @@ static int enqueue_step(chz_engine* e, unsigned job, Instr* in) {
   int r = enqueue_forward(e, job, in);
   if (r) return r;
   for (int b = 0; b < (int)e->banks.size(); b++)
-    if ((r = enqueue_bank(e, b, job % CHZ_ND, in))) return r;
+    if ((r = enqueue_bank(e, b, job, in))) return r;
   return 0;
 }
 
@@ -603,6 +721,8 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
   int done = 0, rc = 0;
   const auto host_t0 = std::chrono::steady_clock::now();
   if (mode == 1) {
+    for (const Bank& b : e->banks)
+      if (b.fine) return fail(-5, "graph replay bakes the block number into the captured launches; fine-tuned banks need eager mode");
     // one graph = one ring cycle of blocks (a multiple of ND so slots and lanes line up too)
     int cycle = e->ring_blocks;
     while (cycle % CHZ_ND) cycle += e->ring_blocks;

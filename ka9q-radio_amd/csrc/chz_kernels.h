@@ -47,6 +47,17 @@ struct FirstRealParams {
   const float2* tw_sub;   // [R2][R1]   W_Na^(j*k1)
   const float2* tw_tile;  // [tiles][Ra] W_N^(ka * 2*c0)
   const float2* tw_col;   // [Ra][2T]   0.5 * W_N^(ka*cc) (even cc) or -0.5i * W_N^(ka*cc) (odd cc)
+  // raw A/D samples.  When ring16 != nullptr the ring holds int16 (same index space as
+  // `ring`) and each sample becomes (float)x * scale16 on load -- the reference's convert(),
+  // src/rx888.c:753-767, incl. the LTC2208 de-randomiser (if bit 0 is set flip bits 1..15, :711-716).
+  const short* ring16;
+  float scale16;
+  int derand;
+  // per-wavefront partial sums over the block's NEW samples (window index >= new_from = M-1):
+  // sum of x*x (frontend->if_power, :780-795) and the count of |x| > 32766 (frontend->overranges)
+  unsigned long long* energy_part;   // [grid * waves] or nullptr
+  unsigned* clip_part;               // [grid * waves]
+  int new_from;
 };
 
 struct ColsParams {
@@ -111,7 +122,19 @@ struct RowsParams {
 // and is zero otherwise; conj != 0 conjugates the master bin (inverted spectrum).
 struct ChanDesc { int t0, cnt, src0, dir, conj, wrap; };
 
+// Fine tuning of one channel (the tail of downconvert(), src/radio.c:1476-1520), stateless in the block
+// number so blocks in flight on different streams cannot race on an oscillator state.  With
+// kb = job - job0 blocks and g = kb*olen + m samples since the base, output sample m of block `job` is
+// rotated by  phase0 + ((kb+1)*adj_num mod V)/V + g*freq + rate*g*(g+1)/2   cycles:
+//   freq/rate  = what set_osc() was given (cycles/sample, cycles/sample^2; src/osc.c:28-47, :60-70),
+//   adj_num/V  = the per-block phase_adjust = cispi(2*(shift % V)/V)   (src/radio.c:1493,1497),
+//   phase0     = everything accumulated before the base, including the shift-change kick (src/radio.c:1494).
+struct FineDesc { double phase0, freq, rate; unsigned job0; int adj_num, V, on; };
+
 struct ChanParams {
+  const FineDesc* fine;   // [nch] or nullptr: plain execute_filter_output semantics
+  double* power;          // [nch] mean |sample|^2 of the block after rotation (chan->sig.bb_power, :1516-1520)
+  unsigned job;
   const float2* spec;     // master spectrum of this block (SpecLayout order)
   SpecLayout lay;
   float inv_na;           // 1/na, for the bin -> (row, column) split
@@ -159,6 +182,7 @@ __global__ void fwd_first_real(FirstRealParams p) {
     we2[U] = reinterpret_cast<const float4*>(twc)[kk * T + pc];   // columns 2pc (even) and 2pc+1 (odd)
   });
 
+  unsigned long long energy = 0; unsigned clips = 0;        // int16 input only
   // layer 1: radix R1 over na = j + q*R2, one (j, column) pair per thread
   if (tid < R2 * T) {
     const int j = tid / T, t = tid - j * T;
@@ -166,13 +190,35 @@ __global__ void fwd_first_real(FirstRealParams p) {
     long f64 = start2 + (long)j * inner2 + c0 + t;
     if (f64 >= ring2_len) f64 -= ring2_len;
     const int first = (int)f64, len = (int)ring2_len, qstep = R2 * (int)inner2;   // 32-bit from here on
-    static_for<R1>([&](auto q) {
-      constexpr int Q = decltype(q)::value;
-      int idx = first + Q * qstep;                 // < 2*len: the window is shorter than the ring
-      if (idx >= len) idx -= len;
-      v[Q] = ring2[idx];
-      if constexpr (Q > 0) w1[Q] = tws[j * R1 + Q];
-    });
+    if (p.ring16 == nullptr) {
+      static_for<R1>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        int idx = first + Q * qstep;                 // < 2*len: the window is shorter than the ring
+        if (idx >= len) idx -= len;
+        v[Q] = ring2[idx];
+        if constexpr (Q > 0) w1[Q] = tws[j * R1 + Q];
+      });
+    } else {
+      const unsigned* __restrict__ ring16 = reinterpret_cast<const unsigned*>(p.ring16);   // two samples per word
+      unsigned raw[R1];
+      static_for<R1>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        int idx = first + Q * qstep;
+        if (idx >= len) idx -= len;
+        raw[Q] = ring16[idx];
+        if constexpr (Q > 0) w1[Q] = tws[j * R1 + Q];
+      });
+      const int n0 = 2 * (j * (int)inner2 + c0 + t);          // window index of the pair's first sample (Q = 0)
+      static_for<R1>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        int a = (int)(short)(raw[Q] & 0xffffu), b = (int)(short)(raw[Q] >> 16);
+        if (p.derand) { a ^= -(a & 1) & 0xfffe; a = (int)(short)a; b ^= -(b & 1) & 0xfffe; b = (int)(short)b; }
+        v[Q] = make_float2((float)a * p.scale16, (float)b * p.scale16);
+        const int n = n0 + 2 * Q * qstep;
+        if (n >= p.new_from) { energy += (unsigned)(a * a); clips += (a > 32766 || a < -32766); }
+        if (n + 1 >= p.new_from) { energy += (unsigned)(b * b); clips += (b > 32766 || b < -32766); }
+      });
+    }
     reg_dft<R1, -1>(v);
     static_for<R1>([&](auto k1) {
       constexpr int K1 = decltype(k1)::value;
@@ -180,6 +226,14 @@ __global__ void fwd_first_real(FirstRealParams p) {
       if constexpr (K1 > 0) x = cmul(x, w1[K1]);
       lds[j * T + t + K1 * (R2 * T + p.padk)] = x;
     });
+  }
+  if (p.energy_part != nullptr) {     // workgroup-uniform; every lane takes part in the shuffles
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { energy += __shfl_xor(energy, d); clips += __shfl_xor(clips, d); }
+    if ((tid & 63) == 0) {
+      const int w = tile * ((nthr + 63) >> 6) + (tid >> 6);
+      p.energy_part[w] = energy; p.clip_part[w] = clips;
+    }
   }
   __syncthreads();
   // layer 2: radix R2 over j, one (k1, column) pair per thread
@@ -478,6 +532,7 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
     });
   }
   __syncthreads();
+  double part = 0.0;                                       // this lane's share of the block energy
   if (live && jl < R1) {
     float2 u[R2];
     static_for<R2>([&](auto j) {
@@ -487,11 +542,54 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
     reg_dft<R2, +1>(u);
     const int drop = P - p.olen;                           // first M-1 samples are discarded (:357)
     float2* o = p.out + (long)ch * p.olen;
+    if (p.fine != nullptr) {
+      const FineDesc f = p.fine[ch];
+      if (f.on) {
+        // phase (cycles) of output sample m = jl - drop of this block; later samples step by R1
+        const double kb = (double)(p.job - f.job0);
+        const int m0 = jl - drop;
+        const double g0 = kb * (double)p.olen + (double)m0;
+        const unsigned r = (unsigned)(((unsigned long long)((p.job - f.job0) % (unsigned)f.V + 1u) * (unsigned)f.adj_num) % (unsigned)f.V);
+        const double base = f.phase0 + (double)r / (double)f.V;
+        if (f.rate == 0.0) {
+          double hi = g0 * f.freq, lo = fma(g0, f.freq, -hi);          // exact product, reduced mod 1
+          hi -= rint(hi);
+          double s0, c0, s1, c1;
+          sincospi(2.0 * (base + hi + lo), &s0, &c0);
+          sincospi(2.0 * ((double)R1 * f.freq), &s1, &c1);
+          static_for<R2>([&](auto k2) {
+            constexpr int K2 = decltype(k2)::value;
+            const double xr = u[K2].x, xi = u[K2].y;
+            u[K2] = make_float2((float)(xr * c0 - xi * s0), (float)(xr * s0 + xi * c0));
+            const double nc = c0 * c1 - s0 * s1; s0 = c0 * s1 + s0 * c1; c0 = nc;
+          });
+        } else {
+          static_for<R2>([&](auto k2) {
+            constexpr int K2 = decltype(k2)::value;
+            const double g = g0 + (double)(R1 * K2);
+            double hi = g * f.freq, lo = fma(g, f.freq, -hi);
+            hi -= rint(hi);
+            double q = 0.5 * f.rate * g * (g + 1.0);
+            q -= rint(q);
+            double sn, cs;
+            sincospi(2.0 * (base + hi + lo + q), &sn, &cs);
+            const double xr = u[K2].x, xi = u[K2].y;
+            u[K2] = make_float2((float)(xr * cs - xi * sn), (float)(xr * sn + xi * cs));
+          });
+        }
+      }
+    }
     static_for<R2>([&](auto k2) {
       constexpr int K2 = decltype(k2)::value;
       const int n = jl + R1 * K2;
-      if (n >= drop) o[n - drop] = u[K2];
+      if (n >= drop) { o[n - drop] = u[K2]; part += (double)(u[K2].x * u[K2].x + u[K2].y * u[K2].y); }
     });
+  }
+  if (p.power != nullptr) {            // wave-uniform: every lane takes part in the shuffles
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < R1; i++) tot += __shfl(part, (cw < CPW ? cw : 0) * LPC + i);
+    if (live && jl == 0) p.power[ch] = tot / (double)p.olen;
   }
 }
 

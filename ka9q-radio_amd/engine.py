@@ -38,6 +38,8 @@ SYMBOLS = [
     "chz_bank_execute", "chz_bank_execute_range", "chz_bank_destroy", "chz_bank_read", "chz_bank_read_async",
     "chz_spectrum_read_async", "chz_host_callback", "chz_host_alloc", "chz_host_free", "chz_host_register", "chz_host_unregister",
     "chz_bank_output_device", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
+    "chz_bank_set_tuning", "chz_bank_read_power", "chz_bank_read_power_async",
+    "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
 ]
 
 _lib = None
@@ -61,6 +63,9 @@ def lib():
         L.chz_input_write.argtypes = [_vp, _vp, _l]
         L.chz_input_write_device.argtypes = [_vp, _vp, _l]
         L.chz_input_ring.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_l)]
+        L.chz_input_write_i16.argtypes = [_vp, _vp, _l, C.c_float, _i]
+        L.chz_input_write_i16_device.argtypes = [_vp, _vp, _l, C.c_float, _i]
+        L.chz_input_stats.argtypes = [_vp, _i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
         L.chz_forward.argtypes = [_vp, _u]
         L.chz_set_notches.argtypes = [_vp, _vp, _i, _d]
         L.chz_spectrum_read.argtypes = [_vp, _i, _vp]
@@ -71,10 +76,14 @@ def lib():
         L.chz_bank_set_responses.argtypes = [_vp, _i, _i, _i, _vp]
         L.chz_bank_set_shifts.argtypes = [_vp, _i, _i, _i, _vp]
         L.chz_bank_set_active.argtypes = [_vp, _i, _i]
-        L.chz_bank_execute.argtypes = [_vp, _i, _i]
+        L.chz_bank_execute.argtypes = [_vp, _i, _u]
         L.chz_bank_read.argtypes = [_vp, _i, _i, _i, _vp]
-        L.chz_bank_execute_range.argtypes = [_vp, _i, _i, _i, _i]
+        L.chz_bank_execute_range.argtypes = [_vp, _i, _u, _i, _i]
+        L.chz_bank_set_tuning.argtypes = [_vp, _i, _u, _i, _i, _vp, _vp, _vp]
+        L.chz_bank_read_power.argtypes = [_vp, _i, _i, _i, _i, _vp]
+        L.chz_bank_read_power_async.argtypes = [_vp, _i, _i, _i, _i, _vp]
         L.chz_bank_destroy.argtypes = [_vp, _i]
+        L.chz_bank_read_async.argtypes = [_vp, _i, _i, _i, _i, _vp]
         L.chz_bank_output_device.argtypes = [_vp, _i, _i, C.POINTER(_vp)]
         L.chz_step.argtypes = [_vp, _u]
         L.chz_run_blocks.argtypes = [_vp, _u, _i, _i, _i, C.POINTER(ChzTiming)]
@@ -134,6 +143,18 @@ class Engine:
         samples = np.ascontiguousarray(samples, dt)
         _check(lib().chz_input_write(self._h, samples.ctypes.data, samples.shape[0]))
         _check(lib().chz_sync(self._h))   # numpy buffer may be freed by the caller
+
+    def write_i16(self, samples, scale, randomize=False):
+        """Raw A/D samples (rx888.c's convert() + write_rfilter): int16, scaled on the device."""
+        s = np.ascontiguousarray(samples, np.int16).reshape(-1)
+        _check(lib().chz_input_write_i16(self._h, s.ctypes.data, s.size, float(scale), 1 if randomize else 0))
+        self.sync()       # the caller's buffer may be pageable / reused
+
+    def input_stats(self, slot):
+        """(sum x^2, clipped samples) over the new samples of the block last transformed into `slot`."""
+        en, cl = C.c_ulonglong(0), C.c_uint(0)
+        _check(lib().chz_input_stats(self._h, slot, C.byref(en), C.byref(cl)))
+        return en.value, cl.value
 
     def write_device(self, dev_ptr, n):
         _check(lib().chz_input_write_device(self._h, dev_ptr, n))
@@ -212,14 +233,46 @@ class Bank:
         _check(lib().chz_bank_set_active(self.eng._h, self.id, n))
         self.active = n
 
-    def execute(self, slot):
-        _check(lib().chz_bank_execute(self.eng._h, self.id, slot))
+    def execute(self, job):
+        """Run the bank on the spectrum of block `job` (slot job % 4; a bare slot number is fine for an untuned bank)."""
+        _check(lib().chz_bank_execute(self.eng._h, self.id, job & 0xFFFFFFFF))
+
+    def set_tuning(self, job, ch0, shifts, freq, rate=None):
+        """downconvert()'s tuning update (src/radio.c:1479-1497) taking effect at block `job`:
+        shifts[i] bins, freq[i] = -remainder/samprate cycles/sample, rate[i] = doppler_rate/samprate^2."""
+        shifts = np.ascontiguousarray(shifts, np.int32).reshape(-1)
+        freq = np.ascontiguousarray(freq, np.float64).reshape(-1)
+        assert freq.shape == shifts.shape
+        rp = None
+        if rate is not None:
+            rate = np.ascontiguousarray(rate, np.float64).reshape(-1)
+            assert rate.shape == shifts.shape
+            rp = rate.ctypes.data
+        _check(lib().chz_bank_set_tuning(self.eng._h, self.id, job & 0xFFFFFFFF, ch0, shifts.shape[0],
+                                         shifts.ctypes.data, freq.ctypes.data, rp))
+
+    def read_power(self, slot, ch0=0, n=None):
+        """chan->sig.bb_power of the block last executed on `slot` (src/radio.c:1516-1520)."""
+        if n is None:
+            n = self.active - ch0
+        out = np.zeros(n, np.float64)
+        _check(lib().chz_bank_read_power(self.eng._h, self.id, slot, ch0, n, out.ctypes.data))
+        return out
 
     def read(self, ch0=0, n=None):
         if n is None:
             n = self.active - ch0
         out = np.zeros((n, self.olen), np.complex64)
         _check(lib().chz_bank_read(self.eng._h, self.id, ch0, n, out.ctypes.data))
+        return out
+
+    def read_slot(self, slot, ch0=0, n=None):
+        """Outputs of the block last executed on spectrum slot `slot` (every slot keeps its own image)."""
+        if n is None:
+            n = self.active - ch0
+        out = np.zeros((n, self.olen), np.complex64)
+        _check(lib().chz_bank_read_async(self.eng._h, self.id, slot, ch0, n, out.ctypes.data))
+        self.eng.sync()
         return out
 
     def output_ptr(self, slot=0):

@@ -466,6 +466,114 @@ int chzo_compute_tuning(int N, double samprate, double freq, int *shift, double 
 }
 
 /* ------------------------------------------------------------------ */
+/* RX888 sample conversion (src/rx888.c:697-767)     */
+/* ------------------------------------------------------------------ */
+
+/* int16 A/D samples -> scaled float32, with the energy sum and the clip count rx_callback keeps
+   (src/rx888.c:753-767 portable, :697-751 AVX2).  rx888.c itself cannot be compiled here (libusb.h),
+   so this is a restatement only.  The de-randomiser follows the AVX2 routine, which is the one an
+   x86-64 host runs and which does what its comment says -- "if lsb == 1, flip all other bits", 16-bit
+   shifts (:711-716).  (The portable fallback's `(x << 15) >> 14` is evaluated in int and does
+   something else; it is not followed.) */
+int chzo_convert_i16(const int16_t *samples, int n, float scale, int randomize, float *out, uint64_t *energy) {
+  int clips = 0;
+  uint64_t e = 0;
+  for (int i = 0; i < n; i++) {
+    int16_t x = samples[i];
+    if (randomize) {
+      int16_t mask = (int16_t)((int16_t)((uint16_t)x << 15) >> 14);   /* 0xFFFE if bit 0 set, else 0 */
+      x ^= mask;
+    }
+    e += (uint64_t)((int32_t)x * x);
+    if (x > 32766 || x < -32766) clips++;
+    out[i] = (float)x * scale;
+  }
+  if (energy) *energy += e;
+  return clips;
+}
+
+/* ------------------------------------------------------------------ */
+/* downconvert() tail: fine tuning, block phase correction, baseband power
+   (src/radio.c:1476-1520, src/osc.c:28-70, src/modes.c:265-266) */
+/* ------------------------------------------------------------------ */
+
+struct chzo_downconv {
+  /* struct osc fine (src/osc.h:12-19) */
+  double freq, rate;
+  double ph_re, ph_im, st_re, st_im, ss_re, ss_im;
+  int steps;
+  /* chan->filter.{bin_shift,remainder,phase_adjust} (src/radio.h:179-181) */
+  int bin_shift;
+  double remainder;
+  double pa_re, pa_im;
+};
+
+chzo_downconv *chzo_downconv_create(void) {
+  chzo_downconv *d = (chzo_downconv *)calloc(1, sizeof *d);    /* struct channel starts zeroed: osc not initialised */
+  if (!d) return NULL;
+  d->remainder = NAN;          /* src/modes.c:265 */
+  d->bin_shift = -1000999;     /* src/modes.c:266 */
+  return d;
+}
+void chzo_downconv_delete(chzo_downconv *d) { free(d); }
+
+static int dc_phasor_init(double re, double im) {               /* src/osc.c:20-24 */
+  if (isnan(re) || isnan(im) || re * re + im * im < 0.9) return 0;
+  return 1;
+}
+static void dc_cmul(double *ar, double *ai, double br, double bi) {
+  double r = *ar * br - *ai * bi, i = *ar * bi + *ai * br; *ar = r; *ai = i;
+}
+static void dc_set_osc(chzo_downconv *d, double f, double r) {  /* src/osc.c:28-47 */
+  if (!dc_phasor_init(d->ph_re, d->ph_im)) {
+    d->ph_re = 1; d->ph_im = 0; d->steps = 16384; d->freq = 0; d->rate = 0;
+    d->st_re = 1; d->st_im = 0; d->ss_re = 1; d->ss_im = 0;
+  }
+  if (f != d->freq) { d->freq = f; sincos_pi(2 * f, &d->st_im, &d->st_re); }
+  if (r != d->rate) { d->rate = r; sincos_pi(2 * r, &d->ss_im, &d->ss_re); }
+}
+static void dc_step_osc(chzo_downconv *d, double *re, double *im) {   /* src/osc.c:49-70 */
+  if (--d->steps <= 0) {
+    if (!dc_phasor_init(d->ph_re, d->ph_im)) { d->ph_re = 1; d->ph_im = 0; }
+    d->steps = 16384;
+    double a = hypot(d->ph_re, d->ph_im); d->ph_re /= a; d->ph_im /= a;
+    if (d->rate != 0) { double b = hypot(d->st_re, d->st_im); d->st_re /= b; d->st_im /= b; }
+  }
+  *re = d->ph_re; *im = d->ph_im;
+  if (d->rate != 0) dc_cmul(&d->st_re, &d->st_im, d->ss_re, d->ss_im);
+  dc_cmul(&d->ph_re, &d->ph_im, d->st_re, d->st_im);
+}
+
+/* One block of one channel after execute_filter_output(): buf holds olen complex samples and is
+   rotated in place; returns bb_power.  L, M are the MASTER's block and impulse lengths
+   (V = 1 + L/(M-1), src/radio.c:1492). */
+double chzo_downconv_block(chzo_downconv *d, int shift, double remainder, double out_samprate,
+                           double doppler_rate, int L, int M, float *buf, int olen) {
+  if (shift != d->bin_shift || isnan(d->remainder) || remainder != d->remainder) {      /* :1479-1483 */
+    dc_set_osc(d, -remainder / out_samprate, doppler_rate / (out_samprate * out_samprate));
+    d->remainder = remainder;
+  }
+  if (shift != d->bin_shift) {                                                           /* :1491-1496 */
+    const int V = 1 + L / (M - 1);
+    sincos_pi(2.0 * (shift % V) / (double)V, &d->pa_im, &d->pa_re);
+    double kr, ki; sincos_pi((shift - d->bin_shift) / (-2.0 * (V - 1)), &ki, &kr);
+    dc_cmul(&d->ph_re, &d->ph_im, kr, ki);
+    d->bin_shift = shift;
+  }
+  dc_cmul(&d->ph_re, &d->ph_im, d->pa_re, d->pa_im);                                     /* :1497 */
+  double energy = 0;
+  for (int n = 0; n < olen; n++) {                                                       /* :1500-1501 */
+    double wr, wi; dc_step_osc(d, &wr, &wi);
+    /* float complex * double complex, product rounded to float complex on store */
+    const double xr = buf[2 * n], xi = buf[2 * n + 1];
+    const float yr = (float)(xr * wr - xi * wi), yi = (float)(xr * wi + xi * wr);
+    buf[2 * n] = yr; buf[2 * n + 1] = yi;
+    energy += (double)(yr * yr + yi * yi);                                               /* cnrmf, :1516-1519 */
+  }
+  return olen ? energy / olen : 0.0;
+}
+
+/* ------------------------------------------------------------------ */
 /* overlap-save stream                                                 */
 /* ------------------------------------------------------------------ */
 

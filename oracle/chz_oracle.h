@@ -70,6 +70,18 @@ double chzo_scale_ad(double rf_gain_db, double rf_atten_db, double level_cal_db,
 /* shift/remainder split of a tuning frequency (src/radio.c:1175-1199) */
 int chzo_compute_tuning(int N, double samprate, double freq, int *shift, double *remainder);
 
+/* rx888.c convert(): int16 A/D samples -> float32 * scale, energy += sum x^2, returns the clip count */
+int chzo_convert_i16(const int16_t *samples, int n, float scale, int randomize, float *out, uint64_t *energy);
+
+/* tail of downconvert() (src/radio.c:1476-1520): fine-tuning rotator stepped per output sample, per-block
+   phase correction for bin shifts not divisible by the overlap factor, phase continuity across shift
+   changes, and the baseband power average.  One object per channel. */
+typedef struct chzo_downconv chzo_downconv;
+chzo_downconv *chzo_downconv_create(void);
+void chzo_downconv_delete(chzo_downconv *d);
+double chzo_downconv_block(chzo_downconv *d, int shift, double remainder, double out_samprate,
+                           double doppler_rate, int L, int M, float *buf, int olen);
+
 /* ---- whole overlap-save stream driver (src/filter.c:186-269,558-651,1093-1134):
         keeps the M-1 sample history, first block is preceded by M-1 zeros ---- */
 typedef struct chzo_stream chzo_stream;

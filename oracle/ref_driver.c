@@ -273,3 +273,43 @@ void refsig_generate(void *h, float *out, long n) {
   }
   s->rng = Rand_state;
 }
+
+/* ---------------------------------------------------------------------------
+ * downconvert() tail.  radio.c cannot be built here (iniparser, opus, libusb ...), so the dozen
+ * statements of src/radio.c:1476-1520 that follow execute_filter_output() are restated around the
+ * reference's OWN oscillator and cispi (src/osc.c:28-70, src/sincospi.c), both compiled unmodified.
+ * ------------------------------------------------------------------------ */
+struct refdc {
+  struct osc fine;
+  int bin_shift;
+  double remainder;
+  double complex phase_adjust;
+};
+void *refdc_create(void) {
+  struct refdc *d = calloc(1, sizeof *d);
+  if (!d) return NULL;
+  d->remainder = NAN;        /* src/modes.c:265 */
+  d->bin_shift = -1000999;   /* src/modes.c:266 */
+  return d;
+}
+void refdc_delete(void *h) { free(h); }
+double refdc_block(void *h, int shift, double remainder, double out_samprate, double doppler_rate,
+                   int L, int M, float *buf, int olen) {
+  struct refdc *d = h;
+  float complex *x = (float complex *)buf;
+  if (shift != d->bin_shift || isnan(d->remainder) || remainder != d->remainder) {
+    set_osc(&d->fine, -remainder / out_samprate, doppler_rate / (out_samprate * out_samprate));
+    d->remainder = remainder;
+  }
+  if (shift != d->bin_shift) {
+    const int V = 1 + (L / (M - 1));
+    d->phase_adjust = cispi(2.0 * (shift % V) / (double)V);
+    d->fine.phasor *= cispi((shift - d->bin_shift) / (-2.0 * (V - 1)));
+    d->bin_shift = shift;
+  }
+  d->fine.phasor *= d->phase_adjust;
+  for (int n = 0; n < olen; n++) x[n] *= step_osc(&d->fine);
+  double energy = 0;
+  for (int n = 0; n < olen; n++) energy += cnrmf(x[n]);
+  return olen ? energy / olen : 0;
+}

@@ -7,6 +7,7 @@
 #include <vector>
 #include <cstring>
 #include "chz_launch.h"
+#include "chz_finetune.h"
 
 using namespace chz;
 
@@ -15,9 +16,28 @@ static const float2* F2(const std::vector<f2>& v) { return reinterpret_cast<cons
 extern "C" {
 
 // ring: input ring on the host (floats for REAL, float pairs for COMPLEX); ring_len in floats
+static int emu_forward_impl(const float* ring, const short* ring16, float scale16, int derand, int new_from,
+                            unsigned long long* energy, unsigned* clips,
+                            long ring_len, long start, int N, int in_type, const char* spec,
+                            float* spectrum, char* desc, int desc_len,
+                            const int* notch_bins, double* notch_state, int n_notch, double notch_alpha);
 int emu_forward(const float* ring, long ring_len, long start, int N, int in_type, const char* spec,
                 float* spectrum, char* desc, int desc_len,
                 const int* notch_bins, double* notch_state, int n_notch, double notch_alpha) {
+  return emu_forward_impl(ring, nullptr, 1.f, 0, 0, nullptr, nullptr, ring_len, start, N, in_type, spec, spectrum, desc, desc_len,
+                          notch_bins, notch_state, n_notch, notch_alpha);
+}
+// int16 ring (REAL masters): energy/clips = sums over window indices >= new_from
+int emu_forward_i16(const short* ring16, float scale, int derand, int new_from, long ring_len, long start, int N, const char* spec,
+                    float* spectrum, unsigned long long* energy, unsigned* clips) {
+  return emu_forward_impl(nullptr, ring16, scale, derand, new_from, energy, clips, ring_len, start, N, CHZ_IN_REAL, spec, spectrum,
+                          nullptr, 0, nullptr, nullptr, 0, 0.0);
+}
+static int emu_forward_impl(const float* ring, const short* ring16, float scale16, int derand, int new_from,
+                            unsigned long long* energy, unsigned* clips,
+                            long ring_len, long start, int N, int in_type, const char* spec,
+                            float* spectrum, char* desc, int desc_len,
+                            const int* notch_bins, double* notch_state, int n_notch, double notch_alpha) {
   FwdPlan p;
   if (!build_fwd_plan(N, in_type, spec, p)) return -1;
   if (desc) { strncpy(desc, p.desc.c_str(), (size_t)desc_len - 1); desc[desc_len - 1] = 0; }
@@ -27,7 +47,19 @@ int emu_forward(const float* ring, long ring_len, long start, int N, int in_type
     a.ring = ring; a.ring_len = ring_len; a.start = start; a.buf = buf.data(); a.inner = p.inner;
     a.T = p.T1; a.Ra = p.Ra; a.padk = p.padk1;
     a.tw_sub = F2(p.tw_sub_a); a.tw_tile = F2(p.tw1_tile); a.tw_col = F2(p.tw1_col);
+    std::vector<unsigned long long> en((size_t)p.grid1 * (p.block1 / 64), 0ull);
+    std::vector<unsigned> cl(en.size(), 0u);
+    if (ring16) {
+      a.ring16 = ring16; a.scale16 = scale16; a.derand = derand; a.new_from = new_from;
+      a.energy_part = en.data(); a.clip_part = cl.data();
+    }
     if (launch_first_real(p.ra, p.grid1, p.block1, p.lds1, nullptr, a)) return -2;
+    if (ring16) {
+      unsigned long long se = 0; unsigned sc = 0;
+      for (size_t i = 0; i < en.size(); i++) { se += en[i]; sc += cl[i]; }
+      if (energy) *energy = se;
+      if (clips) *clips = sc;
+    }
   } else {
     ColsParams a{};
     a.in = reinterpret_cast<const float2*>(ring); a.in_len = ring_len / 2; a.in_start = start / 2;
@@ -89,6 +121,37 @@ int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, in
   c.resp = reinterpret_cast<const float2*>(resp);
   c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub);
+  const int per_block = g.wpb * g.cpw;
+  const int grid = (nch + per_block - 1) / per_block;
+  return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
+}
+
+// --- fine tuning: host bookkeeping (chz_finetune.h) + the channel kernel's epilogue -----------------
+void* emu_fine_create(int nch) { return new std::vector<FineHost>((size_t)nch); }
+void emu_fine_delete(void* h) { delete static_cast<std::vector<FineHost>*>(h); }
+void emu_fine_retune(void* h, int ch, unsigned job, int olen, int V, int shift, double freq, double rate) {
+  fine_retune((*static_cast<std::vector<FineHost>*>(h))[(size_t)ch], job, olen, V, shift, freq, rate);
+}
+// like emu_channels for block `job`, every channel rotated by its oscillator; power[nch] = mean |y|^2
+int emu_channels_tuned(const float* spec, int m_bins, int in_type, int P, int olen, int nch,
+                       const float* resp, const int* shifts, float* out, void* fine, int V, unsigned job, double* power) {
+  ChanGeom g;
+  if (!build_chan_geom(P, g)) return -1;
+  SpecLayout lay{m_bins, m_bins, 0};
+  std::vector<ChanDesc> desc((size_t)nch);
+  std::vector<FineDesc> fd((size_t)nch);
+  const std::vector<FineHost>& fh = *static_cast<std::vector<FineHost>*>(fine);
+  for (int i = 0; i < nch; i++) {
+    ChanDescH h = make_chan_desc(in_type, m_bins, P, shifts[i]);
+    desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
+    fd[(size_t)i] = fine_desc(fh[(size_t)i], V);
+  }
+  ChanParams c{};
+  c.spec = reinterpret_cast<const float2*>(spec); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
+  c.resp = reinterpret_cast<const float2*>(resp);
+  c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
+  c.tw_sub = F2(g.tw_sub);
+  c.fine = fd.data(); c.power = power; c.job = job;
   const int per_block = g.wpb * g.cpw;
   const int grid = (nch + per_block - 1) / per_block;
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);

@@ -189,6 +189,15 @@ static inline int __lane_id() { return hipemu_linear_tid() & 63; }
   hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__)
 
 static inline float __fmaf_rn(float a, float b, float c) { return fmaf(a, b, c); }
+// sin(pi x), cos(pi x) in double with exact argument reduction (device: ocml sincospi)
+static inline void sincospi(double x, double* s, double* c) {
+  double y = fmod(x, 2.0); if (y < 0) y += 2.0;
+  int q = (int)floor(2.0 * y); if (q > 3) q = 3;
+  const double r = y - 0.5 * q, pi = 3.14159265358979323846;
+  double sr, cr;
+  if (r > 0.25) { sr = cos(pi * (0.5 - r)); cr = sin(pi * (0.5 - r)); } else { sr = sin(pi * r); cr = cos(pi * r); }
+  switch (q) { case 0: *s = sr; *c = cr; break; case 1: *s = cr; *c = -sr; break; case 2: *s = -sr; *c = -cr; break; default: *s = -cr; *c = sr; }
+}
 
 typedef void* hipStream_t;
 typedef void* hipEvent_t;

@@ -62,6 +62,11 @@ def oracle():
         L.chzo_stream_bins.argtypes = [_vp]
         L.chzo_stream_push.argtypes = [_vp, _vp, _vp]
         L.chzo_stream_push_f64.argtypes = [_vp, _vp, _vp]
+        L.chzo_convert_i16.argtypes = [_vp, _i, C.c_float, _i, _vp, _vp]
+        L.chzo_downconv_create.restype = _vp
+        L.chzo_downconv_delete.argtypes = [_vp]
+        L.chzo_downconv_block.restype = _d
+        L.chzo_downconv_block.argtypes = [_vp, _i, _d, _d, _d, _i, _i, _vp, _i]
         _oracle = L
     return _oracle
 
@@ -102,6 +107,10 @@ def ref():
         L.refsig_delete.argtypes = [_vp]
         L.refsig_generate.argtypes = [_vp, _vp, C.c_long]
         L.oracle_fft_set_precision.argtypes = [_i]
+        L.refdc_create.restype = _vp
+        L.refdc_delete.argtypes = [_vp]
+        L.refdc_block.restype = _d
+        L.refdc_block.argtypes = [_vp, _i, _d, _d, _d, _i, _i, _vp, _i]
         _ref = L
     return _ref
 
@@ -333,3 +342,38 @@ class RefSigGen:
             self.lib.refsig_delete(self.h)
         except Exception:
             pass
+
+
+def convert_i16(samples, scale, randomize=False):
+    """rx888.c convert(): returns (float32 samples, energy, clips)."""
+    s = np.ascontiguousarray(samples, np.int16)
+    out = np.zeros(s.size, np.float32)
+    en = C.c_uint64(0)
+    clips = oracle().chzo_convert_i16(_fptr(s), s.size, float(scale), 1 if randomize else 0, _fptr(out), C.byref(en))
+    return out, en.value, clips
+
+
+class Downconv:
+    """Per-channel tail of downconvert() (src/radio.c:1476-1520).  which = "oracle" (restatement) or
+    "ref" (the reference's own osc.c / cispi with the glue statements restated in ref_driver.c)."""
+
+    def __init__(self, L, M, out_samprate, which="oracle"):
+        self.L, self.M, self.fs = L, M, float(out_samprate)
+        self.which = which
+        self._lib = oracle() if which == "oracle" else ref()
+        self._h = self._lib.chzo_downconv_create() if which == "oracle" else self._lib.refdc_create()
+
+    def block(self, samples, shift, remainder, doppler_rate=0.0):
+        """samples: complex64[olen] as execute_filter_output leaves them; returns (rotated, bb_power)."""
+        buf = np.ascontiguousarray(samples, dtype=np.complex64).copy()
+        fn = self._lib.chzo_downconv_block if self.which == "oracle" else self._lib.refdc_block
+        pw = fn(self._h, int(shift), float(remainder), self.fs, float(doppler_rate), self.L, self.M,
+                _fptr(buf), buf.size)
+        return buf, pw
+
+    def close(self):
+        if self._h:
+            (self._lib.chzo_downconv_delete if self.which == "oracle" else self._lib.refdc_delete)(self._h)
+            self._h = None
+
+    __del__ = close

@@ -456,3 +456,138 @@ def test_run_blocks_graph_equals_eager(pkg):
         eng.close()
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
+
+
+# ------------------------------------------------------------------------------
+# the tail of downconvert() fused into the channel kernel
+# ------------------------------------------------------------------------------
+def _ulp_close(got, want):
+    ulp = np.spacing(np.maximum(np.abs(want.real), np.abs(want.imag)).astype(np.float32))
+    d = got - want
+    worst = float((np.maximum(np.abs(d.real), np.abs(d.imag)) / ulp).max())
+    return worst, float((got == want).mean())
+
+
+def test_tuned_bank_follows_downconvert(pkg):
+    # per-channel fine oscillator, block phase correction, shift-change kick and bb_power
+    # (src/radio.c:1476-1520) against the restated tail AND the reference's own osc.c, block by block
+    L, M, fs_in, fs_out, P, olen = 25920, 6481, 1.296e6, 12000.0, 300, 240
+    N = L + M - 1
+    nch = 24
+    rng = np.random.default_rng(71)
+    f_hz = 50e3 + rng.uniform(0, 500e3, nch)
+    f_hz[0] = 40.0 * 2500                      # exactly on a bin whose shift is a multiple of V: no rotation at all
+    f_hz[1] = 40.0 * 2501                      # on a bin, shift % V = 1: block phase correction only
+    sweep = np.zeros(nch); sweep[5] = 35.0; sweep[6] = -120.0     # Hz/s
+    resp = np.stack([ol.set_filter(P, olen, N, True, -0.35, 0.35, 9.0)] * nch).astype(np.complex64)
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    tuned = eng.bank(P, olen, nch); plain = eng.bank(P, olen, nch)
+    for b in (tuned, plain):
+        b.set_responses(0, resp); b.set_active(nch)
+    st = ol.Stream(L, M, ol.REAL)
+    dco = [ol.Downconv(L, M, fs_out, "oracle") for _ in range(nch)]
+    dcr = [ol.Downconv(L, M, fs_out, "ref") for _ in range(nch)] if ol.have_ref() else None
+    dce = [ol.Downconv(L, M, fs_out, "oracle") for _ in range(nch)]       # end-to-end chain on the float64 oracle
+    job0 = 0xFFFFFFF8                          # ring-aligned (multiple of 8); the block counter wraps during the run
+    shifts = np.zeros(nch, np.int32); rems = np.zeros(nch)
+    try:
+        for blk in range(11):
+            job = (job0 + blk) & 0xFFFFFFFF
+            if blk in (0, 3, 5, 9):               # retune: everything at 0, a few channels later
+                sel = range(nch) if blk == 0 else ([2, 3, 6] if blk == 3 else ([3, 9] if blk == 5 else [1, 2]))
+                for ch in sel:
+                    if blk:
+                        f_hz[ch] += rng.uniform(-3e3, 3e3)
+                    _, sh, rem = ol.compute_tuning(N, fs_in, f_hz[ch])
+                    shifts[ch], rems[ch] = sh, rem
+                sel = np.array(list(sel))
+                lo, hi = int(sel.min()), int(sel.max()) + 1
+                tuned.set_tuning(job, lo, shifts[lo:hi], -rems[lo:hi] / fs_out, sweep[lo:hi] / fs_out ** 2)
+                plain.set_shifts(0, shifts)
+            x = rng.standard_normal(L).astype(np.float32)
+            eng.write(x)
+            spec64 = st.push(x, f64=True)
+            eng.step(job)
+            got = tuned.read_slot(job % 4); raw = plain.read_slot(job % 4)
+            pw = tuned.read_power(job % 4)
+            for ch in range(nch):
+                # (1) the rotation itself, applied to the GPU's own un-rotated samples: float-exact
+                want, wpw = dco[ch].block(raw[ch], shifts[ch], rems[ch], sweep[ch])
+                worst, same = _ulp_close(got[ch], want)
+                assert worst <= 1.0 and same >= 0.97, (blk, ch, worst, same)
+                assert abs(pw[ch] - wpw) <= 1e-6 * wpw
+                if dcr is not None:
+                    want_r, rpw = dcr[ch].block(raw[ch], shifts[ch], rems[ch], sweep[ch])
+                    assert _ulp_close(want_r, want)[0] <= 1.0 and abs(rpw - wpw) <= 1e-9 * wpw
+                # (2) end to end against the float64 oracle chain
+                ideal = ol.channel(spec64, ol.REAL, P, olen, int(shifts[ch]), resp[ch])
+                ideal, ipw = dce[ch].block(ideal, shifts[ch], rems[ch], sweep[ch])
+                check_channel(got[ch], ideal, noise_floor(spec64, resp[ch]))
+                assert abs(pw[ch] - ipw) <= 1e-4 * ipw
+            if blk == 0:
+                assert np.array_equal(got[0], raw[0])      # shift % V == 0 and zero remainder: identity
+    finally:
+        eng.close()
+
+
+def test_tuned_bank_pipelined_over_streams(pkg):
+    # the rotation is a closed form in the block number: many blocks in flight on 4 streams must give
+    # exactly what block-at-a-time stepping gives
+    L, M, fs_out, P, olen = 25920, 6481, 12000.0, 300, 240
+    nch, nblk = 64, 23
+    rng = np.random.default_rng(72)
+    shifts = rng.integers(300, 16000, nch).astype(np.int32)
+    freq = rng.uniform(-20, 20, nch) / fs_out
+    rate = np.where(np.arange(nch) % 7 == 0, 50.0 / fs_out ** 2, 0.0)
+    resp = (rng.standard_normal((nch, P)) + 1j * rng.standard_normal((nch, P))).astype(np.complex64) / P
+    ring = rng.standard_normal(8 * L).astype(np.float32)
+    outs = []
+    for pipelined in (False, True):
+        eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+        b = eng.bank(P, olen, nch); b.set_responses(0, resp); b.set_active(nch)
+        b.set_tuning(5, 0, shifts, freq, rate)
+        eng.write(ring[:8 * L - (M - 1)])
+        if pipelined:
+            eng.run_blocks(5, nblk, graph=False)
+            with pytest.raises(pkg.engine.ChzError):
+                eng.run_blocks(5, 8, graph=True)        # graph replay would freeze the block number
+        else:
+            for j in range(nblk):
+                eng.step(5 + j)
+        eng.sync()
+        outs.append([(b.read_slot(s), b.read_power(s)) for s in range(4)])
+        eng.close()
+    for (a, pa), (c, pc) in zip(*outs):
+        assert np.array_equal(a, c) and np.array_equal(pa, pc)
+        assert np.abs(a).max() > 0
+
+
+# ------------------------------------------------------------------------------
+# raw int16 A/D samples converted where the first pass loads them
+# ------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,M,randomize", [(25920, 6481, False), (1296000, 324001, True), (2592000, 648001, False)])
+def test_int16_input_matches_convert_then_float_path(pkg, L, M, randomize):
+    rng = np.random.default_rng(L)
+    scale = np.float32(ol.scale_ad(True, 16, 0.0, 0.0, 0.0))
+    e16 = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    ef = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    st = ol.Stream(L, M, ol.REAL)
+    try:
+        for blk in range(3):
+            x16 = np.clip(rng.normal(0, 9000, L), -32768, 32767).astype(np.int16)
+            x16[rng.integers(0, L, 17)] = 32767
+            xf, energy, clips = ol.convert_i16(x16, scale, randomize)
+            # written in the odd-sized chunks a USB callback delivers
+            for a in range(0, L, 16384 * 3 + 2):
+                e16.write_i16(x16[a:a + 16384 * 3 + 2], scale, randomize)
+            ef.write(xf)
+            e16.forward(blk); ef.forward(blk)
+            got, ref = e16.spectrum(blk % 4), ef.spectrum(blk % 4)
+            assert np.array_equal(got, ref)               # same arithmetic, conversion is exact
+            assert e16.input_stats(blk % 4) == (energy, clips)
+            want = st.push(xf, f64=True)
+            assert rel(got, want) <= SPEC_REL
+        with pytest.raises(pkg.engine.ChzError):
+            e16.write(np.zeros(16, np.float32))           # one engine, one sample format
+    finally:
+        e16.close(); ef.close()

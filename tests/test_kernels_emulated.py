@@ -23,7 +23,7 @@ CSRC = os.path.join(ROOT, "ka9q-radio_amd", "csrc")
 def emu(oracle_built):
     so = os.path.join(EMU_DIR, "libchz_emu.so")
     srcs = [os.path.join(EMU_DIR, "emu_kernels.cpp"), os.path.join(EMU_DIR, "hip", "hip_runtime.h")] + \
-           [os.path.join(CSRC, f) for f in ("chz_kernels.h", "chz_launch.h", "chz_plan.h", "regfft.h")]
+           [os.path.join(CSRC, f) for f in ("chz_kernels.h", "chz_launch.h", "chz_plan.h", "regfft.h", "chz_finetune.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I", EMU_DIR, "-I", CSRC,
                         srcs[0], "-o", so], check=True)
@@ -31,6 +31,14 @@ def emu(oracle_built):
     lib.emu_forward.argtypes = [C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_char_p, C.c_void_p, C.c_char_p, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_int, C.c_double]
     lib.emu_channels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.emu_forward_i16.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_char_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emu_fine_create.restype = C.c_void_p
+    lib.emu_fine_create.argtypes = [C.c_int]
+    lib.emu_fine_delete.argtypes = [C.c_void_p]
+    lib.emu_fine_retune.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+    lib.emu_channels_tuned.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_uint, C.c_void_p]
     return lib
 
 
@@ -104,3 +112,79 @@ def test_fused_notch(emu, N, in_type, spec):
         for b in nb:
             assert abs(out[b] - want[b]) <= 3e-6 * abs(want[b]) + 2e-3
     np.testing.assert_allclose(st_a, st_b, rtol=1e-4, atol=1e-2)
+
+
+def test_tuned_channel_epilogue_follows_downconvert(emu):
+    """Channel kernel + fine-tuning epilogue + host re-basing (chz_finetune.h) against the oracle's
+    execute_filter_output followed by the restated downconvert() tail, over a tuning history with shift
+    changes, remainder changes, a frequency sweep, and a wrapped job counter."""
+    L, M, N, P, olen, fs = 11520, 2881, 14400, 300, 240, 12000.0     # V = 5 like the real configurations
+    V = 1 + L // (M - 1)
+    B = N // 2 + 1
+    nch = 5
+    rng = np.random.default_rng(17)
+    resp = np.stack([ol.set_filter(P, olen, N, True, -0.3, 0.3, 9.0) for _ in range(nch)]).astype(np.complex64)
+    # per channel tuning plans: (first block, shift, remainder Hz, doppler rate Hz/s)
+    plans = {
+        0: [(0, 1000, 3.25, 0.0)],
+        1: [(0, 1001, -17.5, 0.0), (3, 1002, -17.5, 0.0), (5, 1002, 4.0, 0.0)],
+        2: [(0, -2003, 0.0, 0.0), (4, -2004, 11.0, 0.0)],
+        3: [(0, 3004, 5.5, 40.0), (6, 3004, 6.5, -25.0)],     # set_osc runs only when shift/remainder change (:1479)
+        4: [(0, 7, 19.999, 0.0), (2, 8, -19.999, 0.0), (7, 6, 1e-3, 0.0)],
+    }
+    job0 = 0xFFFFFFFD                                   # the unsigned block counter wraps inside the run
+    fine = emu.emu_fine_create(nch)
+    dcs = [ol.Downconv(L, M, fs, "oracle") for _ in range(nch)]
+    cur = [None] * nch
+    worst_ulp, same, total = 0.0, 0, 0
+    for blk in range(9):
+        job = (job0 + blk) & 0xFFFFFFFF
+        for ch in range(nch):
+            for (b0, sh, rem, dr) in plans[ch]:
+                if b0 == blk:
+                    cur[ch] = (sh, rem, dr)
+                    emu.emu_fine_retune(fine, ch, job, olen, V, sh, -rem / fs, dr / (fs * fs))
+        spec = (rng.standard_normal(B) + 1j * rng.standard_normal(B)).astype(np.complex64)
+        shifts = np.array([c[0] for c in cur], np.int32)
+        got = np.zeros((nch, olen), np.complex64)
+        power = np.zeros(nch)
+        assert emu.emu_channels_tuned(spec.ctypes.data, B, ol.REAL, P, olen, nch, resp.ctypes.data, shifts.ctypes.data,
+                                      got.ctypes.data, fine, V, job, power.ctypes.data) == 0
+        for ch in range(nch):
+            plain = np.zeros(olen, np.complex64)
+            assert emu.emu_channels(spec.ctypes.data, B, ol.REAL, P, olen, 1, resp[ch].ctypes.data, shifts[ch:ch + 1].ctypes.data,
+                                    plain.ctypes.data, 0, 0, 0) == 0
+            want, pw = dcs[ch].block(plain, *cur[ch])
+            ulp = np.spacing(np.maximum(np.abs(want.real), np.abs(want.imag)).astype(np.float32))
+            d = got[ch] - want
+            worst_ulp = max(worst_ulp, float((np.maximum(np.abs(d.real), np.abs(d.imag)) / ulp).max()))
+            same += int((got[ch] == want).sum()); total += olen
+            assert abs(power[ch] - pw) <= 1e-6 * pw
+    emu.emu_fine_delete(fine)
+    assert worst_ulp <= 1.0 and same >= 0.98 * total, (worst_ulp, same, total)
+
+
+@pytest.mark.parametrize("N,M,spec,start,randomize", [(14400, 2881, b"", 0, False), (14400, 2881, b"16x25x36", 15002, True),
+                                                       (32400, 6481, b"", 100, True)])
+def test_int16_input_is_converted_on_load(emu, N, M, spec, start, randomize):
+    """First pass fed with raw int16 A/D samples: identical spectrum to converting with the restated
+    rx888.c convert() first, and the energy / clip statistics cover exactly the L new samples."""
+    rng = np.random.default_rng(N + start)
+    ring_len = N + 1000
+    ring16 = rng.integers(-32768, 32768, ring_len).astype(np.int16)
+    ring16[rng.integers(0, ring_len, 40)] = 32767
+    ring16[rng.integers(0, ring_len, 40)] = -32768
+    scale = np.float32(3.7e-5)
+    win16 = ring16[(start + np.arange(N)) % ring_len]
+    conv, _, _ = ol.convert_i16(win16, scale, randomize)
+    _, energy, clips = ol.convert_i16(win16[M - 1:], scale, randomize)
+    ringf, _, _ = ol.convert_i16(ring16, scale, randomize)
+    bins = N // 2 + 1
+    out = np.zeros(bins, np.complex64); ref = np.zeros(bins, np.complex64)
+    en = C.c_ulonglong(0); cl = C.c_uint(0)
+    assert emu.emu_forward_i16(ring16.ctypes.data, scale, int(randomize), M - 1, ring_len, start, N, spec, out.ctypes.data,
+                               C.byref(en), C.byref(cl)) == 0
+    assert emu.emu_forward(ringf.ctypes.data, ring_len, start, N, ol.REAL, spec, ref.ctypes.data, None, 0, None, None, 0, 0.0) == 0
+    assert np.array_equal(out, ref)                       # conversion on load is bit-exact
+    assert (en.value, cl.value) == (energy, clips)
+    assert rel(out, ol.forward(conv, ol.REAL, f64=True)) < 5e-7

@@ -182,3 +182,34 @@ def test_first_block_is_preceded_by_zeros_and_overlap_carries(oracle_built):
             assert rel(m.spectrum(), want) < 1e-6
     finally:
         m.close()
+
+
+def test_downconvert_tail_matches_reference_oscillator(oracle_built):
+    """Restated downconvert() tail (oracle/chz_oracle.c) against the same statements wrapped around the
+    reference's OWN set_osc/step_osc/cispi (src/osc.c, src/sincospi.c compiled unmodified) over shift
+    changes, remainder changes, sweeps and several oscillator renormalisations.  The phasors agree to
+    double rounding (the reference is built with -funsafe-math-optimizations), so the float32 products are
+    identical except for a rare last-bit flip."""
+    L, M, fs, olen = 2592000, 648001, 12000.0, 240
+    rng = np.random.default_rng(5)
+    a, b = ol.Downconv(L, M, fs, "oracle"), ol.Downconv(L, M, fs, "ref")
+    history = [(25000, 13.7, 0.0)] * 3 + [(25001, 13.7, 0.0)] * 2 + [(25001, -7.25, 0.5)] * 150 + \
+              [(-31234, 3.0, 0.0)] * 3 + [(-31234, 0.0, 0.0)] * 2 + [(12345, 19.99, -3.0)] * 80
+    flips = 0
+    for sh, rem, dr in history:
+        x = (rng.standard_normal(olen) + 1j * rng.standard_normal(olen)).astype(np.complex64)
+        ya, pa = a.block(x, sh, rem, dr)
+        yb, pb = b.block(x, sh, rem, dr)
+        d = ya - yb
+        ulp = np.spacing(np.maximum(np.abs(yb.real), np.abs(yb.imag)).astype(np.float32))
+        assert (np.maximum(np.abs(d.real), np.abs(d.imag)) <= ulp).all()
+        flips += int((ya != yb).sum())
+        assert abs(pa - pb) <= 1e-9 * pb
+    assert flips <= 1e-3 * olen * len(history)
+    # a shift that is a multiple of V with zero remainder leaves the samples untouched apart from the
+    # constant start-up phase; |y| is preserved in every case
+    c = ol.Downconv(L, M, fs, "oracle")
+    x = (rng.standard_normal(olen) + 1j * rng.standard_normal(olen)).astype(np.complex64)
+    y0, _ = c.block(x, 25000, 0.0, 0.0)
+    y1, _ = c.block(x, 25000, 0.0, 0.0)
+    assert np.allclose(np.abs(y0), np.abs(x), rtol=1e-6) and np.array_equal(y0, y1)
