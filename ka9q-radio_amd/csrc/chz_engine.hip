@@ -153,6 +153,7 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
       (r = upload(&e->tw1_col, e->plan.tw1_col)) || (r = upload(&e->tw2_tile, e->plan.tw2_tile)) ||
       (r = upload(&e->tw2_col, e->plan.tw2_col)))
     return r;
+  HIPOK(hipDeviceSynchronize());       // null-stream memsets vs the engine's non-blocking streams
   *out = e;
   return 0;
 }
@@ -251,6 +252,7 @@ static int ring16_write(chz_engine* e, const short* src, long n, float scale, in
     HIPOK(hipMalloc((void**)&e->clip_part, sizeof(unsigned) * (size_t)CHZ_ND * e->stat_n));
     HIPOK(hipMemset(e->energy_part, 0, sizeof(unsigned long long) * (size_t)CHZ_ND * e->stat_n));
     HIPOK(hipMemset(e->clip_part, 0, sizeof(unsigned) * (size_t)CHZ_ND * e->stat_n));
+    HIPOK(hipDeviceSynchronize());     // the memsets run on the null stream, which the engine's non-blocking streams do not wait for
     drop_graph(e);
   }
   if (scale != e->scale16 || (randomize != 0) != (e->derand != 0)) drop_graph(e);   // baked into captured launches
@@ -435,6 +437,7 @@ int chz_set_notches(chz_engine* e, const int* bins, int n, double alpha) {
   HIPOK(hipMemset(e->notch_state, 0, sizeof(double) * 2 * (size_t)n));
   HIPOK(hipMalloc((void**)&e->notch_ver, sizeof(unsigned) * (size_t)n));
   HIPOK(hipMemset(e->notch_ver, 0, sizeof(unsigned) * (size_t)n));   // re-armed for the next job by arm_notch_tickets()
+  HIPOK(hipDeviceSynchronize());
   e->notch_armed = false;
   e->n_notch = n; e->notch_alpha = alpha;
   return 0;
@@ -506,6 +509,7 @@ int chz_bank_create(chz_engine* e, int P, int olen, int capacity) {
   HIPOK(hipMemset(b.out, 0, sizeof(float2) * (size_t)CHZ_ND * capacity * olen));
   int r = upload(&b.tw_sub, b.g.tw_sub);
   if (r) return r;
+  HIPOK(hipDeviceSynchronize());       // null-stream memsets vs the engine's non-blocking streams
   drop_graph(e);
   e->banks.push_back(b);
   return (int)e->banks.size() - 1;
@@ -552,6 +556,7 @@ int chz_bank_set_tuning(chz_engine* e, int bank, unsigned job, int ch0, int n, c
     HIPOK(hipMemset(b.fine, 0, sizeof(FineDesc) * (size_t)b.cap));
     HIPOK(hipMalloc((void**)&b.power, sizeof(double) * (size_t)CHZ_ND * b.cap));
     HIPOK(hipMemset(b.power, 0, sizeof(double) * (size_t)CHZ_ND * b.cap));
+    HIPOK(hipDeviceSynchronize());     // null-stream memsets vs the engine's non-blocking streams
     drop_graph(e);
   }
   std::vector<ChanDesc> d((size_t)n);
