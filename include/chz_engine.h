@@ -49,7 +49,7 @@ typedef struct chz_timing {
   double total_ms;          /* HIP-event time of the whole run on the engine's stream */
   int blocks;
   /* per-kernel HIP-event time, accumulated over the run (only when instrumented) */
-  double first_ms, cols_ms, rows_ms, notch_ms, chan_ms;
+  double first_ms, cols_ms, rows_ms, notch_ms, chan_ms;   /* notch_ms/notch_n: the noise-estimate kernel (the spur notch is fused into fwd_rows) */
   int first_n, cols_n, rows_n, notch_n, chan_n;
   double enqueue_ms;        /* host wall time spent issuing the launches (close to total_ms = host-bound) */
 } chz_timing;
@@ -135,6 +135,16 @@ int chz_bank_set_tuning(chz_engine *e, int bank, unsigned job, int ch0, int n, c
                         const double *freq, const double *rate);
 int chz_bank_read_power(chz_engine *e, int bank, int slot, int ch0, int n, double *host);        /* synchronous */
 int chz_bank_read_power_async(chz_engine *e, int bank, int slot, int ch0, int n, double *host);
+
+/* SURVEY 8(f) rank 2 -- estimate_noise() (src/radio.c:1783-1866) on the device, run for every channel of
+ * the bank right after its channel kernel: energies of max(P, 1000) master bins around |shift|, their 0.10
+ * quantile, the mean of the energies below 1.5 x that, bias correction, per Hz.  It is the one reader of
+ * the whole block spectrum outside filter.c (src/radio.c:1787-1836): with it on the device the 13 MB
+ * spectrum no longer has to travel to the host every block.  samprate = front-end sample rate (Hz), 0 = off.
+ * The exponential smoothing of chan->sig.n0 (src/radio.c:1466-1473) stays with the caller. */
+int chz_bank_enable_noise(chz_engine *e, int bank, double samprate);
+int chz_bank_read_noise(chz_engine *e, int bank, int slot, int ch0, int n, double *host);        /* synchronous */
+int chz_bank_read_noise_async(chz_engine *e, int bank, int slot, int ch0, int n, double *host);
 int chz_bank_destroy(chz_engine *e, int bank);                              /* frees the bank's device arrays */
 int chz_bank_read(chz_engine *e, int bank, int ch0, int n, float *host);    /* n*olen complex of the most recent execute, synchronous */
 /* Blocks are pipelined over 1, 2 or 4 HIP streams ("lanes", env CHZ_STREAMS, default 4): block j

@@ -40,6 +40,10 @@ struct Bank {
   std::vector<FineHost> fine_h; // [cap]
   FineDesc* fine = nullptr;     // [cap]
   double* power = nullptr;      // [ND][cap]
+  // estimate_noise() on the device (src/radio.c:1783-1866); allocated by chz_bank_enable_noise
+  int* shifts = nullptr;        // [cap] the channels' bin shifts
+  double* n0 = nullptr;         // [ND][cap]
+  double noise_samprate = 0.0;  // front-end sample rate; 0 = off
 };
 
 // A lane = one HIP stream + its own intermediate buffer.  Consecutive blocks go to
@@ -397,6 +401,13 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   mark(in, st, 4, true);
   if (launch_chan(b.g.r, grid, b.g.wpb * 64, b.g.lds, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for P=%d", b.P);
   mark(in, st, 4, false);
+  if (b.n0 && b.noise_samprate > 0.0) {
+    NoiseParams q = noise_params(e->bins, e->in_type == CHZ_REAL, b.P, b.noise_samprate);
+    q.spec = e->spec[slot]; q.lay = c.lay; q.shift = b.shifts; q.n0 = b.n0 + (size_t)slot * b.cap; q.ch0 = ch0; q.nch = n;
+    mark(in, st, 3, true);
+    if (launch_noise(n, st, q, IN_E0(in), IN_E1(in))) return fail(-4, "no noise kernel for a %d-bin window", q.nbins);
+    mark(in, st, 3, false);
+  }
   return 0;
 }
 
@@ -505,6 +516,8 @@ int chz_bank_create(chz_engine* e, int P, int olen, int capacity) {
   HIPOK(hipMemset(b.resp, 0, sizeof(float2) * (size_t)capacity * P));
   HIPOK(hipMalloc((void**)&b.desc, sizeof(ChanDesc) * (size_t)capacity));
   HIPOK(hipMemset(b.desc, 0, sizeof(ChanDesc) * (size_t)capacity));
+  HIPOK(hipMalloc((void**)&b.shifts, sizeof(int) * (size_t)capacity));
+  HIPOK(hipMemset(b.shifts, 0, sizeof(int) * (size_t)capacity));
   HIPOK(hipMalloc((void**)&b.out, sizeof(float2) * (size_t)CHZ_ND * capacity * olen));
   HIPOK(hipMemset(b.out, 0, sizeof(float2) * (size_t)CHZ_ND * capacity * olen));
   int r = upload(&b.tw_sub, b.g.tw_sub);
@@ -537,6 +550,7 @@ int chz_bank_set_shifts(chz_engine* e, int bank, int ch0, int n, const int* shif
   }
   { int r = sync_all(e); if (r) return r; }
   HIPOK(hipMemcpyAsync(b.desc + ch0, d.data(), sizeof(ChanDesc) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+  HIPOK(hipMemcpyAsync(b.shifts + ch0, shifts, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
   HIPOK(hipStreamSynchronize(e->stream));
   return 0;
 }
@@ -572,7 +586,46 @@ int chz_bank_set_tuning(chz_engine* e, int bank, unsigned job, int ch0, int n, c
   { int r = sync_all(e); if (r) return r; }   // earlier blocks still read the old descriptors
   HIPOK(hipMemcpyAsync(b.desc + ch0, d.data(), sizeof(ChanDesc) * (size_t)n, hipMemcpyHostToDevice, e->stream));
   HIPOK(hipMemcpyAsync(b.fine + ch0, f.data(), sizeof(FineDesc) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+  HIPOK(hipMemcpyAsync(b.shifts + ch0, shifts, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
   HIPOK(hipStreamSynchronize(e->stream));
+  return 0;
+}
+// estimate_noise() (src/radio.c:1783-1866) for every channel of the bank right after its channel kernel;
+// samprate = front-end sample rate in Hz (Frontend.samprate, :1865), 0 switches it off again
+int chz_bank_enable_noise(chz_engine* e, int bank, double samprate) {
+  BANK_CHECK(e, bank, 0, 0);
+  Bank& b = e->banks[(size_t)bank];
+  if (!(samprate >= 0.0)) return fail(-1, "bad sample rate");
+  const int nb = b.P < 1000 ? 1000 : b.P;
+  if (samprate > 0.0 && nb > e->bins) return fail(-1, "master has %d bins, fewer than the %d-bin noise window", e->bins, nb);
+  if (samprate > 0.0 && nb > 2048) return fail(-3, "no noise kernel compiled for a %d-bin window", nb);
+  HIPOK(hipSetDevice(e->device));
+  { int r = sync_all(e); if (r) return r; }
+  if (!b.n0 && samprate > 0.0) {
+    HIPOK(hipMalloc((void**)&b.n0, sizeof(double) * (size_t)CHZ_ND * b.cap));
+    HIPOK(hipMemset(b.n0, 0, sizeof(double) * (size_t)CHZ_ND * b.cap));
+    HIPOK(hipDeviceSynchronize());
+  }
+  b.noise_samprate = samprate;
+  drop_graph(e);
+  return 0;
+}
+int chz_bank_read_noise(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (slot < 0 || slot >= CHZ_ND || !host) return fail(-1, "bad argument");
+  Bank& b = e->banks[(size_t)bank];
+  if (!b.n0) return fail(-1, "noise estimation is off: call chz_bank_enable_noise first");
+  hipStream_t st = slot_stream(e, slot);
+  HIPOK(hipMemcpyAsync(host, b.n0 + (size_t)slot * b.cap + ch0, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+  HIPOK(hipStreamSynchronize(st));
+  return 0;
+}
+int chz_bank_read_noise_async(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (slot < 0 || slot >= CHZ_ND || !host) return fail(-1, "bad argument");
+  Bank& b = e->banks[(size_t)bank];
+  if (!b.n0) return fail(-1, "noise estimation is off: call chz_bank_enable_noise first");
+  HIPOK(hipMemcpyAsync(host, b.n0 + (size_t)slot * b.cap + ch0, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, slot_stream(e, slot)));
   return 0;
 }
 // chan->sig.bb_power of channels [ch0, ch0+n) for the block last executed on `slot` (src/radio.c:1516-1520)
@@ -622,6 +675,7 @@ int chz_bank_destroy(chz_engine* e, int bank) {
   { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
   hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); hipFree(b.fine); hipFree(b.power);
+  hipFree(b.shifts); hipFree(b.n0); b.shifts = nullptr; b.n0 = nullptr; b.noise_samprate = 0.0;
   b.resp = nullptr; b.desc = nullptr; b.out = nullptr; b.tw_sub = nullptr; b.fine = nullptr; b.power = nullptr;
   b.fine_h.clear(); b.active = 0; b.cap = 0;
   return 0;

@@ -30,6 +30,17 @@
 #include <hip/hip_runtime.h>
 #include "regfft.h"
 
+// Rounding fences.  The library is built with -ffp-contract=fast, which lets the backend fuse ANY multiply
+// with a following add, pragmas notwithstanding; where a result must round like the reference's x86-64
+// build (no FMA) the product goes through an empty asm so the two operations cannot be combined.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CHZ_ROUNDED_F32(x) asm volatile("" : "+v"(x))
+#define CHZ_ROUNDED_F64(x) asm volatile("" : "+v"(x))
+#else
+#define CHZ_ROUNDED_F32(x) ((void)0)
+#define CHZ_ROUNDED_F64(x) ((void)0)
+#endif
+
 namespace chz {
 
 // ------------------------------------------------------------------------------
@@ -213,7 +224,9 @@ __global__ void fwd_first_real(FirstRealParams p) {
         constexpr int Q = decltype(q)::value;
         int a = (int)(short)(raw[Q] & 0xffffu), b = (int)(short)(raw[Q] >> 16);
         if (p.derand) { a ^= -(a & 1) & 0xfffe; a = (int)(short)a; b ^= -(b & 1) & 0xfffe; b = (int)(short)b; }
-        v[Q] = make_float2((float)a * p.scale16, (float)b * p.scale16);
+        float fa = (float)a * p.scale16, fb = (float)b * p.scale16;   // rounded products, as convert() stores them
+        CHZ_ROUNDED_F32(fa); CHZ_ROUNDED_F32(fb);
+        v[Q] = make_float2(fa, fb);
         const int n = n0 + 2 * Q * qstep;
         if (n >= p.new_from) { energy += (unsigned)(a * a); clips += (a > 32766 || a < -32766); }
         if (n + 1 >= p.new_from) { energy += (unsigned)(b * b); clips += (b > 32766 || b < -32766); }
@@ -591,6 +604,122 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
     for (int i = 0; i < R1; i++) tot += __shfl(part, (cw < CPW ? cw : 0) * LPC + i);
     if (live && jl == 0) p.power[ch] = tot / (double)p.olen;
   }
+}
+
+// ------------------------------------------------------------------------------
+// K5: estimate_noise() of src/radio.c:1783-1866, one workgroup per channel.
+// |X|^2 of nbins master bins around |shift| -> LDS, bitonic sort, the 0.10 quantile with linear
+// interpolation, mean of the energies <= 1.5 x quantile, times the truncated-exponential correction,
+// per Hz.  Keeps the one consumer of the whole spectrum (src/radio.c:1787-1836) on the device.
+// ------------------------------------------------------------------------------
+// cnrmf(): two products and a sum, each rounded to float
+__device__ __forceinline__ float cnrm_unfused(float2 x) {
+  float a = x.x * x.x;
+  float b = x.y * x.y;
+  CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
+  return a + b;
+}
+
+struct NoiseParams {
+  const float2* spec; SpecLayout lay;
+  const int* shift;       // [nch] the channels' bin shifts
+  double* n0;             // [nch] out: noise density estimate
+  int ch0, nch;
+  int m_bins, real;       // master bins; real != 0 for a REAL master
+  int nbins;              // max(slave bins, Min_noise_bins = 1000)   (:1794-1796)
+  int nsort;              // 1024 or 2048: values sorted per channel (64 lanes x 16 or 32 registers)
+  double scale;           // correction / (master bins * front-end sample rate)   (:1840-1844,1863-1865)
+};
+
+// One wavefront per channel; the window lives in registers, VPL values per lane.
+template <int VPL>
+__global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
+  const int lane = threadIdx.x & 63;
+  // the channel index is the same in every lane: telling the compiler keeps the window arithmetic scalar
+  const int lc = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+  if (lc >= p.nch) return;                                           // wave-uniform
+  const int ch = p.ch0 + lc;
+  const int shift = p.shift[ch];
+  // first master bin of the window and how many entries the reference fills
+  int mbin, n = p.nbins, wrap = 0;
+  if (p.real) {
+    mbin = (shift < 0 ? -shift : shift) - p.nbins / 2;               // :1812-1816
+    if (mbin < 0) mbin = 0; else if (mbin + p.nbins > p.m_bins) mbin = p.m_bins - p.nbins;
+  } else {
+    mbin = shift - p.nbins / 2;                                      // :1822-1836
+    if (mbin < 0) mbin += p.m_bins; else if (mbin >= p.m_bins) mbin -= p.m_bins;
+    if (mbin < 0 || mbin >= p.m_bins) { if (lane == 0) p.n0[ch] = 0.0; return; }
+    wrap = p.m_bins;
+    // the fill stops once the walk arrives at bin m_bins/2 (the +Nyquist seam)
+    const int half = p.m_bins / 2;
+    const int to_seam = mbin < half ? half - mbin : half + p.m_bins - mbin;
+    if (to_seam < n) n = to_seam;
+  }
+  const float inf = __builtin_huge_valf();
+  float v[VPL];
+  // Coalesced loads (which register a bin lands in does not matter to a selection), all issued before
+  // any is consumed: entries past n read the window's first bin and are replaced by +inf afterwards.
+  const float2* __restrict__ sp = p.spec;
+  const int row0 = mbin / p.lay.na, col0 = mbin - row0 * p.lay.na;
+  float2 x[VPL];
+  static_for<VPL>([&](auto rr) {
+    constexpr int R = decltype(rr)::value;
+    int i = R * 64 + lane;
+    if (i >= n) i = 0;
+    int col = col0 + i, row = row0;
+    if (wrap) { int k = mbin + i; if (k >= wrap) k -= wrap; row = 0; col = k; }
+    const int dr = col / p.lay.na;
+    row += dr; col -= dr * p.lay.na;
+    x[R] = sp[(long)row * p.lay.pitch + p.lay.off + col];
+  });
+  static_for<VPL>([&](auto rr) {
+    constexpr int R = decltype(rr)::value;
+    v[R] = (R * 64 + lane < n) ? cnrm_unfused(x[R]) : inf;
+  });
+  // quantile(energies, n, 0.10) (:1760-1775): the qi-th and (qi+1)-th smallest energies.  Non-negative
+  // floats order like their bit patterns, so the qi-th smallest is built bit by bit from the top: keep a
+  // bit whenever no more than qi values lie strictly below the candidate.  Counting is one compare per
+  // register, a ballot and a scalar popcount -- no sort, no LDS, no cross-lane data movement.
+  const double pos = 0.10 * (double)(n - 1);
+  const int qi = (int)floor(pos);
+  const double frac = pos - (double)qi;
+  unsigned bits[VPL];
+  static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; bits[R] = __float_as_uint(v[R]); });
+  unsigned ans = 0;
+  for (int bit = 30; bit >= 0; --bit) {
+    const unsigned t = ans | (1u << bit);
+    int c = 0;
+    static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; c += __popcll(__ballot(bits[R] < t)); });
+    if (c <= qi) ans = t;                                            // wave-uniform
+  }
+  const double q1 = (double)__uint_as_float(ans);
+  double q = q1;
+  if (frac != 0.0) {
+    // the next order statistic: q1 again if it occurs more than once beyond rank qi, else the smallest value above it
+    int c_le = 0;
+    unsigned above = 0x7f800000u;
+    static_for<VPL>([&](auto rr) {
+      constexpr int R = decltype(rr)::value;
+      c_le += __popcll(__ballot(bits[R] <= ans));
+      if (bits[R] > ans && bits[R] < above) above = bits[R];
+    });
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned o = __shfl_xor(above, d); above = o < above ? o : above; }
+    const double q2 = c_le >= qi + 2 ? q1 : (double)__uint_as_float(above);
+    double fq = frac * (q2 - q1);                                    // :1773, product rounded before the sum
+    CHZ_ROUNDED_F64(fq);
+    q = q1 + fq;
+  }
+  const double cut = 1.5 * q;
+  double e = 0.0; int cnt = 0;
+  static_for<VPL>([&](auto rr) {
+    constexpr int R = decltype(rr)::value;
+    const double x = (double)v[R];
+    if (x <= cut) { e += x; cnt++; }                                 // the +inf padding never qualifies
+  });
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { e += __shfl_xor(e, d); cnt += __shfl_xor(cnt, d); }
+  if (lane == 0) p.n0[ch] = cnt ? e / (double)cnt * p.scale : 0.0;
 }
 
 }  // namespace chz

@@ -2,6 +2,7 @@
 // Shared by chz_engine.hip (hipcc, real launches on a HIP stream) and the CPU
 // test harness (tests/hipemu), so both exercise the same template instances.
 #pragma once
+#include <cmath>
 #include "chz_kernels.h"
 #include "chz_plan.h"
 
@@ -39,5 +40,23 @@ inline int launch_chan(Radix2 r, int grid, int block, size_t lds, hipStream_t s,
   CHZ_CHAN_MENU(X)
 #undef X
   return -1;
+}
+inline int launch_noise(int nch, hipStream_t s, const NoiseParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+  const int grid = (nch + 3) / 4;          // four wavefronts = four channels per workgroup
+  if (p.nsort == 1024) { CHZ_LAUNCH((noise_est<16>), grid, 256, 0, s, e0, e1, p); return 0; }
+  if (p.nsort == 2048) { CHZ_LAUNCH((noise_est<32>), grid, 256, 0, s, e0, e1, p); return 0; }
+  return -1;
+}
+// host side of K5: window size, sort size and the constant factor of estimate_noise() (src/radio.c:73-76,1840-1865)
+inline NoiseParams noise_params(int m_bins, bool real, int s_bins, double samprate) {
+  NoiseParams p{};
+  p.m_bins = m_bins; p.real = real ? 1 : 0;
+  p.nbins = s_bins < 1000 ? 1000 : s_bins;
+  p.nsort = p.nbins <= 1024 ? 1024 : (p.nbins <= 2048 ? 2048 : 0);   // 0: no kernel (launch_noise fails)
+  const double NQ = 0.10, N_cutoff = 1.5;
+  const double z = N_cutoff * (-std::log(1.0 - NQ));
+  const double correction = 1.0 / (1.0 - z * std::exp(-z) / (1.0 - std::exp(-z)));
+  p.scale = correction / ((double)m_bins * samprate);
+  return p;
 }
 }  // namespace chz

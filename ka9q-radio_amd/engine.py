@@ -40,6 +40,7 @@ SYMBOLS = [
     "chz_bank_output_device", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
     "chz_bank_set_tuning", "chz_bank_read_power", "chz_bank_read_power_async",
     "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
+    "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async",
 ]
 
 _lib = None
@@ -82,6 +83,9 @@ def lib():
         L.chz_bank_set_tuning.argtypes = [_vp, _i, _u, _i, _i, _vp, _vp, _vp]
         L.chz_bank_read_power.argtypes = [_vp, _i, _i, _i, _i, _vp]
         L.chz_bank_read_power_async.argtypes = [_vp, _i, _i, _i, _i, _vp]
+        L.chz_bank_enable_noise.argtypes = [_vp, _i, _d]
+        L.chz_bank_read_noise.argtypes = [_vp, _i, _i, _i, _i, _vp]
+        L.chz_bank_read_noise_async.argtypes = [_vp, _i, _i, _i, _i, _vp]
         L.chz_bank_destroy.argtypes = [_vp, _i]
         L.chz_bank_read_async.argtypes = [_vp, _i, _i, _i, _i, _vp]
         L.chz_bank_output_device.argtypes = [_vp, _i, _i, C.POINTER(_vp)]
@@ -250,6 +254,17 @@ class Bank:
             rp = rate.ctypes.data
         _check(lib().chz_bank_set_tuning(self.eng._h, self.id, job & 0xFFFFFFFF, ch0, shifts.shape[0],
                                          shifts.ctypes.data, freq.ctypes.data, rp))
+
+    def enable_noise(self, samprate):
+        """estimate_noise() (src/radio.c:1783-1866) on the device after every block; samprate = front-end rate in Hz."""
+        _check(lib().chz_bank_enable_noise(self.eng._h, self.id, float(samprate)))
+
+    def read_noise(self, slot, ch0=0, n=None):
+        if n is None:
+            n = self.active - ch0
+        out = np.zeros(n, np.float64)
+        _check(lib().chz_bank_read_noise(self.eng._h, self.id, slot, ch0, n, out.ctypes.data))
+        return out
 
     def read_power(self, slot, ch0=0, n=None):
         """chan->sig.bb_power of the block last executed on `slot` (src/radio.c:1516-1520)."""

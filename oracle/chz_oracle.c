@@ -466,6 +466,68 @@ int chzo_compute_tuning(int N, double samprate, double freq, int *shift, double 
 }
 
 /* ------------------------------------------------------------------ */
+/* estimate_noise() (src/radio.c:1719-1866)          */
+/* ------------------------------------------------------------------ */
+
+static int cmp_double(const void *a, const void *b) {
+  double x = *(const double *)a, y = *(const double *)b;
+  return (x > y) - (x < y);
+}
+
+/* Noise density estimate around one channel from the master spectrum of the block it just consumed:
+   energies of nbins = max(slave bins, 1000) master bins centred on |shift| (:1794-1820), the
+   p = 0.10 quantile with linear interpolation (:1760-1775), the mean of the energies not above
+   1.5 x that quantile (:1846-1857), times the truncated-exponential correction (:1840-1844), divided
+   by master bins x front-end sample rate (:1863-1865).  The k-th smallest value does not depend on
+   how it is found, so the quickselect of :1722-1757 is replaced by a sort.
+   Complex masters (:1821-1837): the reference stops filling energies[] at the +Nyquist seam and
+   then reads the uninitialised remainder; here the remainder does not exist (n = entries filled). */
+double chzo_estimate_noise(const float *spectrum, int m_bins, int in_type, int s_bins, int shift, double samprate) {
+  if (s_bins <= 0) return 0;
+  int nbins = s_bins < 1000 ? 1000 : s_bins;
+  if (nbins > m_bins) return NAN;              /* the reference would index outside fdomain */
+  double *en = (double *)malloc(sizeof(double) * (size_t)nbins);
+  int n = 0;
+  if (in_type == CHZO_REAL) {
+    int mbin = abs(shift) - nbins / 2;
+    if (mbin < 0) mbin = 0;
+    else if (mbin + nbins > m_bins) mbin = m_bins - nbins;
+    for (int i = 0; i < nbins; i++, mbin++) {
+      float re = spectrum[2 * mbin], im = spectrum[2 * mbin + 1];
+      en[n++] = (double)(re * re + im * im);   /* cnrmf, float arithmetic */
+    }
+  } else {
+    int mbin = shift - nbins / 2;
+    if (mbin < 0) mbin += m_bins; else if (mbin >= m_bins) mbin -= m_bins;
+    if (mbin < 0 || mbin >= m_bins) { free(en); return 0; }
+    for (int i = 0; i < nbins; i++) {
+      float re = spectrum[2 * mbin], im = spectrum[2 * mbin + 1];
+      en[n++] = (double)(re * re + im * im);
+      if (++mbin == m_bins) mbin = 0;
+      if (mbin == m_bins / 2) break;
+    }
+  }
+  double *sorted = (double *)malloc(sizeof(double) * (size_t)n);
+  memcpy(sorted, en, sizeof(double) * (size_t)n);
+  qsort(sorted, (size_t)n, sizeof(double), cmp_double);
+  const double NQ = 0.10, N_cutoff = 1.5;      /* src/radio.c:73-74 */
+  double pos = NQ * (n - 1);
+  int i = (int)floor(pos);
+  double frac = pos - i;
+  double q = sorted[i];
+  if (frac != 0.0) q = sorted[i] + frac * (sorted[i + 1] - sorted[i]);
+  const double cut = N_cutoff * q;
+  double energy = 0; int noisebins = 0;
+  for (int k = 0; k < n; k++) if (en[k] <= cut) { energy += en[k]; noisebins++; }
+  free(en); free(sorted);
+  if (noisebins == 0) return 0;
+  energy /= noisebins;
+  const double z = N_cutoff * (-log(1 - NQ));
+  const double correction = 1 / (1 - z * exp(-z) / (1 - exp(-z)));
+  return energy * correction / ((double)m_bins * samprate);
+}
+
+/* ------------------------------------------------------------------ */
 /* RX888 sample conversion (src/rx888.c:697-767)     */
 /* ------------------------------------------------------------------ */
 

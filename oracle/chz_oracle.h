@@ -70,6 +70,9 @@ double chzo_scale_ad(double rf_gain_db, double rf_atten_db, double level_cal_db,
 /* shift/remainder split of a tuning frequency (src/radio.c:1175-1199) */
 int chzo_compute_tuning(int N, double samprate, double freq, int *shift, double *remainder);
 
+/* estimate_noise() of src/radio.c:1783-1866: noise density (per Hz) around a channel from the master spectrum */
+double chzo_estimate_noise(const float *spectrum, int m_bins, int in_type, int s_bins, int shift, double samprate);
+
 /* rx888.c convert(): int16 A/D samples -> float32 * scale, energy += sum x^2, returns the clip count */
 int chzo_convert_i16(const int16_t *samples, int n, float scale, int randomize, float *out, uint64_t *energy);
 

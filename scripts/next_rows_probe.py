@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Cost of the SURVEY 8(f) rows on config 3 (129.6 MS/s real, 1024 x P=300): the fine-tuning epilogue in
-chan_ifft (rank 1) and raw int16 input converted in fwd_first_real (rank 3), each against the plain path.
+chan_ifft (rank 1) and raw int16 input converted in fwd_first_real (rank 3), and estimate_noise() on the device (rank 2), each against the plain path.
 Prints pipelined us/block and per-kernel us (HIP dispatch timestamps, one kernel at a time)."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,8 +17,8 @@ shifts = (25000 + np.arange(nch) * 1500).astype(np.int32)
 freq = rng.uniform(-20, 20, nch) / 12000.0
 resp = np.ones((nch, 300), np.complex64) / 300
 res = {}
-for tuned in (False, True):
-    for i16 in (False, True):
+for tuned, i16, noise in ((False, False, False), (True, False, False), (False, True, False), (False, False, True), (True, True, True)):
+    if True:
         eng = pkg.engine.Engine(L, M, pkg.engine.REAL, ring_blocks=8)
         if i16:
             eng.write_i16(x16[:8 * L - (M - 1)], scale); eng.write_i16(x16[8 * L - (M - 1):], scale)
@@ -30,14 +30,17 @@ for tuned in (False, True):
             b.set_tuning(0, 0, shifts, freq)
         else:
             b.set_shifts(0, shifts)
+        if noise:
+            b.enable_noise(129.6e6)
         eng.set_notches([0], 0.01)
         eng.run_blocks(0, 160)
         t = eng.run_blocks(160, 1600)
         eng.run_blocks(0, 200, instrument=True)
         it = eng.run_blocks(0, 200, instrument=True)
-        key = "tuned=%d int16=%d" % (tuned, i16)
+        key = "tuned=%d int16=%d noise=%d" % (tuned, i16, noise)
         res[key] = {"us_per_block": t.total_ms / 1600 * 1e3, "first_us": it.first_ms / it.first_n * 1e3, "cols_us": it.cols_ms / it.cols_n * 1e3,
-                    "rows_us": it.rows_ms / it.rows_n * 1e3, "chan_us": it.chan_ms / it.chan_n * 1e3}
+                    "rows_us": it.rows_ms / it.rows_n * 1e3, "chan_us": it.chan_ms / it.chan_n * 1e3,
+                    "noise_us": (it.notch_ms / it.notch_n * 1e3) if it.notch_n else None}
         print(key, json.dumps(res[key]))
         eng.close()
 print(json.dumps(res))

@@ -126,6 +126,18 @@ int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, in
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
 }
 
+// --- estimate_noise() kernel ------------------------------------------------------------------------
+int emu_noise(const float* spec, int m_bins, int in_type, int s_bins, int nch, const int* shifts, double samprate, double* n0,
+              int lay_na, int lay_pitch, int lay_off) {
+  SpecLayout lay{lay_na > 0 ? lay_na : m_bins, lay_na > 0 ? lay_pitch : m_bins, lay_na > 0 ? lay_off : 0};
+  std::vector<float2> spec_dev((size_t)((long)(m_bins / lay.na + 2) * lay.pitch + 16), make_float2(0.f, 0.f));
+  for (long k = 0; k < m_bins; k++) spec_dev[(size_t)spec_addr(lay, k)] = reinterpret_cast<const float2*>(spec)[k];
+  NoiseParams q = noise_params(m_bins, in_type == CHZ_IN_REAL, s_bins, samprate);
+  if (q.nbins > m_bins) return -1;
+  q.spec = spec_dev.data(); q.lay = lay; q.shift = shifts; q.n0 = n0; q.ch0 = 0; q.nch = nch;
+  return launch_noise(nch, nullptr, q);   // -1: window larger than the compiled sorts
+}
+
 // --- fine tuning: host bookkeeping (chz_finetune.h) + the channel kernel's epilogue -----------------
 void* emu_fine_create(int nch) { return new std::vector<FineHost>((size_t)nch); }
 void emu_fine_delete(void* h) { delete static_cast<std::vector<FineHost>*>(h); }

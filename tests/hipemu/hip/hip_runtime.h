@@ -183,6 +183,24 @@ template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) 
   int s = lane + (int)d; if (s > 63) s = lane;
   return hipemu_shfl_idx(v, s);
 }
+static inline unsigned long long __ballot(int pred) {
+  hipemu::State& s = hipemu::st();
+  unsigned me = hipemu_linear_tid();
+  s.slots[me] = pred ? 1u : 0u;
+  hipemu_wave_barrier(me);
+  unsigned base = me & ~63u;
+  size_t n = (size_t)s.bdim.x * s.bdim.y * s.bdim.z;
+  unsigned long long m = 0;
+  for (unsigned l = 0; l < 64; l++) if (base + l < n && s.slots[base + l]) m |= 1ull << l;
+  hipemu_wave_barrier(me);
+  return m;
+}
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline int __lane_id() { return hipemu_linear_tid() & 63; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \

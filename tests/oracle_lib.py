@@ -62,6 +62,8 @@ def oracle():
         L.chzo_stream_bins.argtypes = [_vp]
         L.chzo_stream_push.argtypes = [_vp, _vp, _vp]
         L.chzo_stream_push_f64.argtypes = [_vp, _vp, _vp]
+        L.chzo_estimate_noise.restype = _d
+        L.chzo_estimate_noise.argtypes = [_vp, _i, _i, _i, _i, _d]
         L.chzo_convert_i16.argtypes = [_vp, _i, C.c_float, _i, _vp, _vp]
         L.chzo_downconv_create.restype = _vp
         L.chzo_downconv_delete.argtypes = [_vp]
@@ -342,6 +344,12 @@ class RefSigGen:
             self.lib.refsig_delete(self.h)
         except Exception:
             pass
+
+
+def estimate_noise(spectrum, in_type, s_bins, shift, samprate):
+    """estimate_noise() of src/radio.c:1783-1866 on a complex64 master spectrum."""
+    sp = np.ascontiguousarray(spectrum, np.complex64)
+    return oracle().chzo_estimate_noise(_fptr(sp), sp.size, in_type, int(s_bins), int(shift), float(samprate))
 
 
 def convert_i16(samples, scale, randomize=False):

@@ -593,3 +593,42 @@ def test_int16_input_matches_convert_then_float_path(pkg, L, M, randomize):
             e16.write(np.zeros(16, np.float32))           # one engine, one sample format
     finally:
         e16.close(); ef.close()
+
+
+# ------------------------------------------------------------------------------
+# estimate_noise() on the device
+# ------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,M,P,olen,nch", [(25920, 6481, 300, 240, 40), (2592000, 648001, 300, 240, 1024), (1296000, 324001, 600, 480, 128)])
+def test_noise_estimate_matches_radio_c(pkg, L, M, P, olen, nch):
+    N = L + M - 1
+    B = N // 2 + 1
+    fs = 50.0 * L
+    rng = np.random.default_rng(P + nch)
+    x = rng.standard_normal(L).astype(np.float32)
+    t = np.arange(L)
+    for f in rng.uniform(0.02, 0.45, 6):
+        x += (30 * np.cos(2 * np.pi * f * t)).astype(np.float32)          # carriers inside some of the windows
+    shifts = rng.integers(-(B - 2), B - 1, nch).astype(np.int32)
+    shifts[:6] = [0, 3, B - 1, -(B - 1), 500, -499]
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    try:
+        b = eng.bank(P, olen, nch)
+        b.set_responses(0, np.ones((nch, P), np.complex64) / P); b.set_shifts(0, shifts); b.set_active(nch)
+        with pytest.raises(pkg.engine.ChzError):
+            b.read_noise(0)
+        b.enable_noise(fs)
+        st = ol.Stream(L, M, ol.REAL)
+        for job in range(2):
+            eng.write(x); eng.step(job)
+            spec64 = st.push(x, f64=True)
+        got = b.read_noise(1)
+        spec = eng.spectrum(1)
+        want = np.array([ol.estimate_noise(spec, ol.REAL, P, int(s), fs) for s in shifts])
+        assert np.all(want > 0) and np.allclose(got, want, rtol=1e-12, atol=0)      # same spectrum: same estimate
+        ideal = np.array([ol.estimate_noise(spec64.astype(np.complex64), ol.REAL, P, int(s), fs) for s in shifts])
+        assert np.allclose(got, ideal, rtol=2e-4)                                    # float32 transform noise only
+        b.enable_noise(0.0)
+        eng.step(2)
+        assert np.array_equal(b.read_noise(1), got)                                  # switched off: nothing new written
+    finally:
+        eng.close()

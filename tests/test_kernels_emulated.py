@@ -33,6 +33,7 @@ def emu(oracle_built):
     lib.emu_channels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.emu_forward_i16.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_char_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emu_noise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.emu_fine_create.restype = C.c_void_p
     lib.emu_fine_create.argtypes = [C.c_int]
     lib.emu_fine_delete.argtypes = [C.c_void_p]
@@ -188,3 +189,23 @@ def test_int16_input_is_converted_on_load(emu, N, M, spec, start, randomize):
     assert np.array_equal(out, ref)                       # conversion on load is bit-exact
     assert (en.value, cl.value) == (energy, clips)
     assert rel(out, ol.forward(conv, ol.REAL, f64=True)) < 5e-7
+
+
+@pytest.mark.parametrize("in_type,B,s_bins,lay", [(ol.REAL, 16201, 300, (0, 0, 0)), (ol.REAL, 16201, 1200, (135, 144, 4)),
+                                                  (ol.REAL, 7201, 600, (75, 80, 2)), (ol.COMPLEX, 14400, 300, (0, 0, 0))])
+def test_noise_estimate_kernel(emu, in_type, B, s_bins, lay):
+    """estimate_noise() (src/radio.c:1783-1866) as a kernel: window placement incl. the clamps at DC and
+    Nyquist, inverted spectra, the quantile and the thresholded mean -- against the restatement."""
+    rng = np.random.default_rng(B + s_bins)
+    spec = ((rng.standard_normal(B) + 1j * rng.standard_normal(B)) * 2.5).astype(np.complex64)
+    for c in rng.integers(0, B, 12):
+        spec[c:c + 30] *= 40.0                                   # carriers the estimator must step over
+    if in_type == ol.REAL:
+        shifts = np.array([0, 17, 499, 500, 501, 4000, -4000, B - 700, B - 1, -(B - 1), 2500, -2501], np.int32)
+    else:
+        shifts = np.array([0, 600, -600, 3000, -3000, B // 2 - 200, -(B // 2) + 100, 6000], np.int32)
+    n0 = np.zeros(shifts.size)
+    assert emu.emu_noise(spec.ctypes.data, B, in_type, s_bins, shifts.size, shifts.ctypes.data, 1.296e6, n0.ctypes.data, *lay) == 0
+    want = np.array([ol.estimate_noise(spec, in_type, s_bins, int(s), 1.296e6) for s in shifts])
+    assert np.all(want > 0)
+    assert np.allclose(n0, want, rtol=1e-12, atol=0)
