@@ -43,6 +43,33 @@
 
 namespace chz {
 
+// Store flavour of the forward passes, fixed at build time: 0 plain (default), 1 non-temporal, 2 agent-scope
+// write-through.  Measured on MI355X (config 3): non-temporal stores in pass a shorten that kernel alone
+// (10.6 -> 8.5 us: no dirty lines left for the end-of-kernel L2 write-back) but the next pass then misses the
+// cache (+0.9 us) and the pipelined block time gets WORSE (17.9 -> 19.3 us); write-through behaves alike.
+// The intermediate buffers want to stay cache-resident, so the default is plain stores.
+#ifndef CHZ_NT
+#define CHZ_NT 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && CHZ_NT == 1
+typedef float chz_v2f __attribute__((ext_vector_type(2)));
+typedef float chz_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(float2* p, float2 v) { __builtin_nontemporal_store(chz_v2f{v.x, v.y}, reinterpret_cast<chz_v2f*>(p)); }
+__device__ __forceinline__ void store_stream(float4* p, float4 v) { __builtin_nontemporal_store(chz_v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<chz_v4f*>(p)); }
+#elif defined(__HIP_DEVICE_COMPILE__) && CHZ_NT == 2
+__device__ __forceinline__ void store_stream(float2* p, float2 v) {
+  unsigned long long b = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_stream(float4* p, float4 v) {
+  store_stream(reinterpret_cast<float2*>(p), make_float2(v.x, v.y));
+  store_stream(reinterpret_cast<float2*>(p) + 1, make_float2(v.z, v.w));
+}
+#else
+__device__ __forceinline__ void store_stream(float2* p, float2 v) { *p = v; }
+__device__ __forceinline__ void store_stream(float4* p, float4 v) { *p = v; }
+#endif
+
 // ------------------------------------------------------------------------------
 // parameter blocks (plain data; filled by chz_engine.hip)
 // ------------------------------------------------------------------------------
@@ -282,7 +309,7 @@ __global__ void fwd_first_real(FirstRealParams p) {
       const float2 dd = make_float2(a.x - b.x, a.y + b.y);   // a - conj(b)
       const float2 oe = cmul(de, cmul(we1[U], make_float2(we2[U].x, we2[U].y)));
       const float2 oo = cmul(dd, cmul(we1[U], make_float2(we2[U].z, we2[U].w)));
-      gout4[(long)k * orow + c0 + pc] = make_float4(oe.x, oe.y, oo.x, oo.y);
+      store_stream(&gout4[(long)k * orow + c0 + pc], make_float4(oe.x, oe.y, oo.x, oo.y));
     }
   });
 }
@@ -366,7 +393,7 @@ __global__ void fwd_cols(ColsParams p) {
     const int ostep = R1 * p.inner;
     static_for<R2>([&](auto k2) {
       constexpr int K2 = decltype(k2)::value;
-      o0[K2 * ostep] = cmul(u[K2], cmul(wt[K2], wc[K2]));
+      store_stream(&o0[K2 * ostep], cmul(u[K2], cmul(wt[K2], wc[K2])));
     });
   }
 }
@@ -477,8 +504,8 @@ __global__ void fwd_rows(RowsParams p) {
       float2* __restrict__ sp = p.spec;
       static_for<R2>([&](auto k2) {
         constexpr int K2 = decltype(k2)::value;
-        if (!p.mirror || kk0 + K2 * kks <= half) sp[d0 + K2 * ds] = u[K2];
-        else if (!selfconj) sp[m0 - K2 * ds] = cconj(u[K2]);      // bin N-k
+        if (!p.mirror || kk0 + K2 * kks <= half) store_stream(&sp[d0 + K2 * ds], u[K2]);
+        else if (!selfconj) store_stream(&sp[m0 - K2 * ds], cconj(u[K2]));      // bin N-k
       });
     }
   }
@@ -488,7 +515,8 @@ __global__ void fwd_rows(RowsParams p) {
 // K3+K4: per-channel gather x response, P-point backward FFT, keep last olen.
 // LPC = max(R1,R2) lanes serve one channel, 64/LPC channels share a wavefront.
 // ------------------------------------------------------------------------------
-template <int R1, int R2>
+// EPI: compiled with the downconvert() epilogue (fine tuning + power); the plain variant carries none of it.
+template <int R1, int R2, bool EPI>
 __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
   constexpr int P = R1 * R2;
   constexpr int LPC = R1 > R2 ? R1 : R2;
@@ -555,7 +583,7 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
     reg_dft<R2, +1>(u);
     const int drop = P - p.olen;                           // first M-1 samples are discarded (:357)
     float2* o = p.out + (long)ch * p.olen;
-    if (p.fine != nullptr) {
+    if (EPI && p.fine != nullptr) {
       const FineDesc f = p.fine[ch];
       if (f.on) {
         // phase (cycles) of output sample m = jl - drop of this block; later samples step by R1
@@ -595,10 +623,13 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
     static_for<R2>([&](auto k2) {
       constexpr int K2 = decltype(k2)::value;
       const int n = jl + R1 * K2;
-      if (n >= drop) { o[n - drop] = u[K2]; part += (double)(u[K2].x * u[K2].x + u[K2].y * u[K2].y); }
+      if (n >= drop) {
+        o[n - drop] = u[K2];
+        if constexpr (EPI) part += (double)(u[K2].x * u[K2].x + u[K2].y * u[K2].y);
+      }
     });
   }
-  if (p.power != nullptr) {            // wave-uniform: every lane takes part in the shuffles
+  if (EPI && p.power != nullptr) {     // wave-uniform: every lane takes part in the shuffles
     double tot = 0.0;
 #pragma unroll
     for (int i = 0; i < R1; i++) tot += __shfl(part, (cw < CPW ? cw : 0) * LPC + i);

@@ -36,7 +36,10 @@ inline int launch_rows(Radix2 r, int grid, int block, size_t lds, hipStream_t s,
   return -1;
 }
 inline int launch_chan(Radix2 r, int grid, int block, size_t lds, hipStream_t s, const ChanParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-#define X(a, b) if (r.r1 == a && r.r2 == b) { CHZ_LAUNCH((chan_ifft<a, b>), grid, block, lds, s, e0, e1, p); return 0; }
+#define X(a, b) if (r.r1 == a && r.r2 == b) { \
+    if (p.fine || p.power) { CHZ_LAUNCH((chan_ifft<a, b, true>), grid, block, lds, s, e0, e1, p); } \
+    else { CHZ_LAUNCH((chan_ifft<a, b, false>), grid, block, lds, s, e0, e1, p); } \
+    return 0; }
   CHZ_CHAN_MENU(X)
 #undef X
   return -1;
