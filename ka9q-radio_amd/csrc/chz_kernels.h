@@ -65,9 +65,12 @@ __device__ __forceinline__ void store_stream(float4* p, float4 v) {
   store_stream(reinterpret_cast<float2*>(p), make_float2(v.x, v.y));
   store_stream(reinterpret_cast<float2*>(p) + 1, make_float2(v.z, v.w));
 }
+#endif
+// the default is a plain assignment, so the compiler keeps the destination's __restrict__ knowledge
+#if defined(__HIP_DEVICE_COMPILE__) && CHZ_NT != 0
+#define CHZ_STORE(lvalue, value) store_stream(&(lvalue), (value))
 #else
-__device__ __forceinline__ void store_stream(float2* p, float2 v) { *p = v; }
-__device__ __forceinline__ void store_stream(float4* p, float4 v) { *p = v; }
+#define CHZ_STORE(lvalue, value) ((lvalue) = (value))
 #endif
 
 // ------------------------------------------------------------------------------
@@ -309,7 +312,7 @@ __global__ void fwd_first_real(FirstRealParams p) {
       const float2 dd = make_float2(a.x - b.x, a.y + b.y);   // a - conj(b)
       const float2 oe = cmul(de, cmul(we1[U], make_float2(we2[U].x, we2[U].y)));
       const float2 oo = cmul(dd, cmul(we1[U], make_float2(we2[U].z, we2[U].w)));
-      store_stream(&gout4[(long)k * orow + c0 + pc], make_float4(oe.x, oe.y, oo.x, oo.y));
+      CHZ_STORE(gout4[(long)k * orow + c0 + pc], make_float4(oe.x, oe.y, oo.x, oo.y));
     }
   });
 }
@@ -393,7 +396,7 @@ __global__ void fwd_cols(ColsParams p) {
     const int ostep = R1 * p.inner;
     static_for<R2>([&](auto k2) {
       constexpr int K2 = decltype(k2)::value;
-      store_stream(&o0[K2 * ostep], cmul(u[K2], cmul(wt[K2], wc[K2])));
+      CHZ_STORE(o0[K2 * ostep], cmul(u[K2], cmul(wt[K2], wc[K2])));
     });
   }
 }
@@ -504,8 +507,8 @@ __global__ void fwd_rows(RowsParams p) {
       float2* __restrict__ sp = p.spec;
       static_for<R2>([&](auto k2) {
         constexpr int K2 = decltype(k2)::value;
-        if (!p.mirror || kk0 + K2 * kks <= half) store_stream(&sp[d0 + K2 * ds], u[K2]);
-        else if (!selfconj) store_stream(&sp[m0 - K2 * ds], cconj(u[K2]));      // bin N-k
+        if (!p.mirror || kk0 + K2 * kks <= half) CHZ_STORE(sp[d0 + K2 * ds], u[K2]);
+        else if (!selfconj) CHZ_STORE(sp[m0 - K2 * ds], cconj(u[K2]));      // bin N-k
       });
     }
   }
