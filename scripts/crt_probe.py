@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""C_rt: the largest number of simultaneous 12 kHz channels (P = 300) one MI355X carries at
+129.6 MS/s with EVERY block done inside its 20 ms slot, inputs and outputs resident in HBM.
+
+One bank of `cap` channels is filled by tiling the config-3 plan (mixed usb/cw/iq filters, 60 kHz raster); the
+active count n is bisected.  Criterion for n: 500 consecutive blocks, each run to completion on its own
+(chz_run_blocks(job, 1): forward transform + all n channels, then a device synchronise), slowest block <= 20 ms;
+the pipelined free-running rate over the same 500 blocks is reported next to it.
+usage: crt_probe.py [cap_millions=10]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as ge
+import bench
+
+pkg = ge.load()
+L, M, N = bench.L, bench.M, bench.N
+P, olen = 300, 240
+cap = int(float(sys.argv[1]) * 1e6) if len(sys.argv) > 1 else 10_000_000
+cap -= cap % 3072
+nblk = int(os.environ.get("CRT_BLOCKS", "500"))
+
+eng = pkg.engine.Engine(L, M, pkg.engine.REAL, ring_blocks=bench.RING_BLOCKS)
+x = np.random.default_rng(1).standard_normal(bench.RING_BLOCKS * L).astype(np.float32) * 0.05
+eng.write(x[:bench.RING_BLOCKS * L - (M - 1)]); eng.write(x[bench.RING_BLOCKS * L - (M - 1):])
+t0 = time.time()
+bank = eng.bank(P, olen, cap)
+tile = 3072
+plan = bench.channel_plan_config3(tile)
+resp = np.stack([pkg.filterapi.design_response(P, olen, N, True, lo, hi, 11.0) for _, lo, hi in plan[:3]])
+resp = np.ascontiguousarray(np.tile(resp, (tile // 3, 1)))
+shifts = np.array([p[0] for p in plan], np.int32)
+for c0 in range(0, cap, tile):
+    bank.set_responses(c0, resp)
+    bank.set_shifts(c0, shifts + (c0 // tile) % 7)
+eng.set_notches([0], 0.01)
+print("bank of %d channels ready in %.1f s (responses %.1f GB, outputs %.1f GB)" % (cap, time.time() - t0, cap * P * 8 / 1e9, 4 * cap * olen * 8 / 1e9), flush=True)
+
+def measure(n):
+    bank.set_active(n)
+    eng.run_blocks(0, 8)
+    worst = 0.0; tot = 0.0
+    for j in range(nblk):
+        t = eng.run_blocks(8 + j, 1)
+        worst = max(worst, t.total_ms); tot += t.total_ms
+    tp = eng.run_blocks(8 + nblk, nblk)
+    return worst, tot / nblk, tp.total_ms / nblk
+
+lo, hi = 0, cap
+res = []
+w, a, p = measure(cap)
+res.append({"channels": cap, "worst_block_ms": w, "mean_block_ms": a, "pipelined_ms_per_block": p})
+print(json.dumps(res[-1]), flush=True)
+if w > 20.0:
+    while hi - lo > cap // 64:
+        mid = (lo + hi) // 2; mid -= mid % 3
+        w, a, p = measure(mid)
+        res.append({"channels": mid, "worst_block_ms": w, "mean_block_ms": a, "pipelined_ms_per_block": p})
+        print(json.dumps(res[-1]), flush=True)
+        if w <= 20.0: lo = mid
+        else: hi = mid
+else:
+    lo = cap
+ok = [r for r in res if r["worst_block_ms"] <= 20.0]
+best = max(ok, key=lambda r: r["channels"]) if ok else None
+out = {"metric": "C_rt: channels sustained @129.6 MS/s, every block <= 20 ms", "P": P, "olen": olen, "blocks": nblk, "capacity_tested": cap,
+       "c_rt": best, "capacity_limited": best is not None and best["channels"] == cap, "probes": res,
+       "algorithmic_GBps_at_c_rt": (bench.FWD_BYTES + best["channels"] * bench.chan_bytes(P, olen)) / (best["mean_block_ms"] * 1e-3) / 1e9 if best else None}
+print(json.dumps(out))
+eng.close()
