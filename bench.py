@@ -198,6 +198,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
+    # N > 1: channels shard across ranks.  How the shared spectrum gets to every rank:
+    #   replicate (default)  every rank runs the forward transform on its own HBM-resident copy of the samples
+    #   subband | broadcast  rank 0 transforms, the needed spectrum rows / the whole slot travel over xGMI (RCCL)
+    #   auto                 subband or broadcast, whichever moves fewer bytes (sharding.plan_exchange)
+    exch = os.environ.get("BENCH_EXCHANGE", "replicate") if use_dist else None
     pkg = ge.load()
     eng = pkg.engine.Engine(L, M, pkg.engine.REAL, device=local_rank, plan=args.plan, ring_blocks=RING_BLOCKS)
 
@@ -210,8 +215,13 @@ def main():
         # weak scaling: every GPU runs the SAME per-GPU workload as N=1 (1024 mixed 12 kHz channels); the
         # node's channels cover 1..62.4 MHz and rank r owns a contiguous slice of that raster (config 4's
         # architecture: rank 0 owns the front end, the spectrum travels over xGMI)
-        workload = ("config3 per GPU x %d (config-4 architecture): sig_gen real 129.6 MS/s on rank 0, %d mixed usb/cw/iq "
-                    "12 kHz channels (P=300) sharded by frequency over %d MI355X, spectrum over xGMI via RCCL" % (world, nch * world, world))
+        if exch == "replicate":
+            how = ("the sample stream is resident in every GPU's HBM (the bench's input rule; in service the host feeds each GPU over its "
+                   "own PCIe link) and each GPU transforms it itself (17 us per 20 ms block): no data-path collective")
+        else:
+            how = "rank 0 owns the front end and the forward transform, the spectrum travels over xGMI via RCCL (%s)" % exch
+        workload = ("config3 per GPU x %d: sig_gen real 129.6 MS/s, %d mixed usb/cw/iq 12 kHz channels (P=300) sharded by "
+                    "frequency over %d MI355X; %s" % (world, nch * world, world, how))
         plan = channel_plan_sharded(nch, rank, world)
 
     # ---- inputs resident in HBM before anything is timed
@@ -231,8 +241,8 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    if not use_dist:
-        graph = bool(args.graph)
+    if not use_dist or exch == "replicate":
+        graph = bool(args.graph) and not use_dist
         eng.run_blocks(0, args.warmup, graph=graph)
         barrier()
         t0 = time.perf_counter()
@@ -240,6 +250,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         gpu_ms = timing.total_ms
+        exchange_mode = "none (forward transform replicated on every rank)" if use_dist else None
     else:
         # spectrum slots are torch tensors so RCCL can move them; each block's exchange is enqueued on the
         # engine's own per-slot HIP stream (wrapped as a torch ExternalStream), so block j's exchange and
@@ -253,9 +264,9 @@ def main():
         mine = pkg.sharding.needed_rows([p[0] for p in plan], P, BINS, na)
         all_rows = [None] * world
         dist.all_gather_object(all_rows, mine)
-        mode = os.environ.get("BENCH_EXCHANGE") or pkg.sharding.plan_exchange(all_rows, nrows)
-        if os.environ.get("BENCH_FORCE_DIST") == "1" and world == 1:
-            mode = os.environ.get("BENCH_EXCHANGE", "broadcast")          # single-rank smoke test of the collective
+        mode = pkg.sharding.plan_exchange(all_rows, nrows) if exch == "auto" else exch
+        if mode not in ("broadcast", "subband"):
+            raise SystemExit("BENCH_EXCHANGE must be replicate, auto, subband or broadcast")
 
         def exchange(j):
             s = j % 4
@@ -339,7 +350,8 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         total_ch = nch * world
         value = total_ch * BLOCKTIME / (elapsed / args.steps)
-        step_bytes = FWD_BYTES + total_ch * chan_bytes(P, olen) + (world - 1) * 8 * BINS
+        replicated = use_dist and exch == "replicate"
+        step_bytes = (world if replicated else 1) * FWD_BYTES + total_ch * chan_bytes(P, olen) + (0 if (replicated or not use_dist) else (world - 1) * 8 * BINS)
         out = {
             "metric": "channels sustained @129.6 MS/s input (real-time-equivalent: channel-blocks/s / 50)",
             "value": value, "unit": "channels", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -352,7 +364,7 @@ def main():
             "blocks_per_s": args.steps / elapsed, "realtime_margin": BLOCKTIME / (elapsed / args.steps),
             "step_algorithmic_GBps": step_bytes / (elapsed / args.steps) / 1e9,
             "gpu_event_ms_per_step": gpu_ms / args.steps,
-            "host_enqueue_ms_per_step": (timing.enqueue_ms / args.steps) if not use_dist else None,
+            "host_enqueue_ms_per_step": (timing.enqueue_ms / args.steps) if (not use_dist or exch == "replicate") else None,
             "roofline": roof, "cpu_baseline": cpu, "c_rt": crt,
         }
     eng.close()
