@@ -76,6 +76,7 @@ struct mctx {
   struct hbank *banks;
   int nbanks;
   bool ring_pinned;                 /* host ring registered with the HIP runtime */
+  bool host_spectrum;               /* copy every block's spectrum into master->fdomain[] (KA9Q_HIP_FDOMAIN, default on) */
   struct notch_state *notch_ptr;    /* list last uploaded to the device */
   int notch_n;
   int notch_bins[64];
@@ -301,6 +302,9 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
     return -1;
   }
   c->master = master;
+  /* master->fdomain[] is read by radiod's estimate_noise() (src/radio.c:1801) and by nothing else outside filter.c;
+     a host that takes the noise estimate from the device (chz_bank_enable_noise) can switch the 13 MB per-block copy off */
+  { const char *fd = getenv("KA9Q_HIP_FDOMAIN"); c->host_spectrum = !(fd && fd[0] == '0'); }
   pthread_mutex_init(&c->lock, NULL);
   pthread_rwlock_init(&c->stage_lock, NULL);
   master->points = N;
@@ -492,7 +496,7 @@ int execute_filter_input(struct filter_in *const f) {
     ring_wrap((void **)&f->input_read_pointer.r, f->input_buffer, f->input_buffer_size);
   }
   if (rc == 0) rc = chz_forward(c->eng, job);
-  if (rc == 0) rc = chz_spectrum_read_async(c->eng, slot, (float *)f->fdomain[slot]);
+  if (rc == 0 && c->host_spectrum) rc = chz_spectrum_read_async(c->eng, slot, (float *)f->fdomain[slot]);
   /* speculative batched channel launches: every slave with its last-known shift */
   for (int i = 0; rc == 0 && i < c->nbanks; i++) {
     struct hbank *b = &c->banks[i];
