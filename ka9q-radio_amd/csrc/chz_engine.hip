@@ -58,6 +58,7 @@ struct Lane {
 struct chz_engine {
   int L = 0, M = 0, N = 0, in_type = 0, bins = 0, per = 1, device = 0, ring_blocks = 0;
   FwdPlan plan;
+  int chan_stage = -1;              // output staging of chan_ifft: -1 by launch size, 0 never, 1 always (env CHZ_CHAN_STAGE)
   hipStream_t stream = nullptr;     // == lanes[0].s: copies and anything not tied to a block
   bool own_stream = false;
   Lane lanes[CHZ_MAX_LANES];
@@ -120,12 +121,12 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   if (bins < 2) return fail(-1, "transform too small");     // src/filter.c:198-199
   if (in_type == CHZ_REAL && (L & 1)) return fail(-1, "real input needs an even block length L");
   chz_engine* e = new chz_engine();
+  struct Guard { chz_engine* e; ~Guard() { if (e) chz_engine_destroy(e); } } guard{e};   // frees everything on an early return
   e->L = L; e->M = M; e->N = N; e->in_type = in_type; e->bins = bins; e->device = device;
   e->per = in_type == CHZ_REAL ? 1 : 2;
   const char* envspec = getenv("CHZ_PLAN");
   if ((!plan_spec || !*plan_spec) && envspec && *envspec) plan_spec = envspec;
   if (!build_fwd_plan(N, in_type, plan_spec, e->plan)) {
-    delete e;
     return fail(-3, "no transform plan for N=%d (spec '%s'): N must factor into the compiled axis lengths", N, plan_spec ? plan_spec : "");
   }
   const int minblocks = (N + L - 1) / L + 1;
@@ -134,6 +135,7 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   e->ring_len = (long)ring_blocks * L * e->per;
   HIPOK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   e->own_stream = true;
+  if (const char* cs = getenv("CHZ_CHAN_STAGE")) e->chan_stage = atoi(cs) != 0;
   const char* envl = getenv("CHZ_STREAMS");
   int nl = envl ? atoi(envl) : 4;
   e->nlanes = (nl >= 4) ? 4 : (nl >= 2) ? 2 : 1;             // must divide ND so slot and lane stay aligned
@@ -158,6 +160,7 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
       (r = upload(&e->tw2_col, e->plan.tw2_col)))
     return r;
   HIPOK(hipDeviceSynchronize());       // null-stream memsets vs the engine's non-blocking streams
+  guard.e = nullptr;
   *out = e;
   return 0;
 }
@@ -169,20 +172,23 @@ static void drop_graph(chz_engine* e) {
 void chz_engine_destroy(chz_engine* e) {
   if (!e) return;
   hipSetDevice(e->device);
-  for (int i = 0; i < e->nlanes; i++) hipStreamSynchronize(e->lanes[i].s);
+  for (int i = 0; i < e->nlanes; i++) if (e->lanes[i].s) hipStreamSynchronize(e->lanes[i].s);
   drop_graph(e);
   for (int i = 0; i < e->nlanes; i++) {
     hipFree(e->lanes[i].buf);
-    if (i > 0) hipStreamDestroy(e->lanes[i].s);
+    if (i > 0 && e->lanes[i].s) hipStreamDestroy(e->lanes[i].s);
   }
-  hipEventDestroy(e->input_ready);
-  for (auto& b : e->banks) { hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); }
+  if (e->input_ready) hipEventDestroy(e->input_ready);
+  for (auto& b : e->banks) {
+    hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub);
+    hipFree(b.fine); hipFree(b.power); hipFree(b.shifts); hipFree(b.n0);
+  }
   hipFree(e->ring); hipFree(e->ring16); hipFree(e->energy_part); hipFree(e->clip_part);
   for (int i = 0; i < CHZ_ND; i++) if (e->spec_owned[i]) hipFree(e->spec[i]);
   hipFree(e->tw_sub_a); hipFree(e->tw_sub_b); hipFree(e->tw_sub_c);
   hipFree(e->tw1_tile); hipFree(e->tw1_col); hipFree(e->tw2_tile); hipFree(e->tw2_col);
   hipFree(e->notch_loc); hipFree(e->notch_state); hipFree(e->notch_ver);
-  if (e->own_stream) hipStreamDestroy(e->stream);
+  if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
 }
 
@@ -395,6 +401,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   c.lay = SpecLayout{e->plan.Na, e->plan.spec_pitch, e->plan.spec_off}; c.inv_na = 1.0f / (float)e->plan.Na;
   c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc; c.out = bank_out(b, slot); c.ch0 = ch0; c.nch = n; c.olen = b.olen;
   c.tw_sub = b.tw_sub;
+  c.stage = e->chan_stage >= 0 ? e->chan_stage : (n >= 16384);
   c.fine = b.fine; c.power = b.power ? b.power + (size_t)slot * b.cap : nullptr; c.job = job;
   const int per_block = b.g.wpb * b.g.cpw;
   const int grid = (n + per_block - 1) / per_block;
@@ -511,6 +518,8 @@ int chz_bank_create(chz_engine* e, int P, int olen, int capacity) {
   Bank b;
   if (!build_chan_geom(P, b.g)) return fail(-3, "no channel kernel compiled for P=%d", P);
   HIPOK(hipSetDevice(e->device));
+  // a failed allocation (the C_rt-sized banks take > 100 GB) must not leak the earlier ones
+  struct Guard { Bank* b; ~Guard() { if (b) { hipFree(b->resp); hipFree(b->desc); hipFree(b->shifts); hipFree(b->out); hipFree(b->tw_sub); } } } guard{&b};
   b.P = P; b.olen = olen; b.cap = capacity; b.active = 0;
   HIPOK(hipMalloc((void**)&b.resp, sizeof(float2) * (size_t)capacity * P));
   HIPOK(hipMemset(b.resp, 0, sizeof(float2) * (size_t)capacity * P));
@@ -524,6 +533,7 @@ int chz_bank_create(chz_engine* e, int P, int olen, int capacity) {
   if (r) return r;
   HIPOK(hipDeviceSynchronize());       // null-stream memsets vs the engine's non-blocking streams
   drop_graph(e);
+  guard.b = nullptr;
   e->banks.push_back(b);
   return (int)e->banks.size() - 1;
 }

@@ -241,6 +241,10 @@ class Bank:
         """Run the bank on the spectrum of block `job` (slot job % 4; a bare slot number is fine for an untuned bank)."""
         _check(lib().chz_bank_execute(self.eng._h, self.id, job & 0xFFFFFFFF))
 
+    def execute_range(self, job, ch0, n):
+        """The same for channels [ch0, ch0+n) only (the slow path of one retuned channel)."""
+        _check(lib().chz_bank_execute_range(self.eng._h, self.id, job & 0xFFFFFFFF, ch0, n))
+
     def set_tuning(self, job, ch0, shifts, freq, rate=None):
         """downconvert()'s tuning update (src/radio.c:1479-1497) taking effect at block `job`:
         shifts[i] bins, freq[i] = -remainder/samprate cycles/sample, rate[i] = doppler_rate/samprate^2."""

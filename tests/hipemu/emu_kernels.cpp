@@ -123,6 +123,7 @@ int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, in
   c.tw_sub = F2(g.tw_sub);
   const int per_block = g.wpb * g.cpw;
   const int grid = (nch + per_block - 1) / per_block;
+  c.stage = getenv("CHZ_CHAN_STAGE") ? atoi(getenv("CHZ_CHAN_STAGE")) : 0;
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
 }
 
@@ -164,6 +165,7 @@ int emu_channels_tuned(const float* spec, int m_bins, int in_type, int P, int ol
   c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub);
   c.fine = fd.data(); c.power = power; c.job = job;
+  c.stage = getenv("CHZ_CHAN_STAGE") ? atoi(getenv("CHZ_CHAN_STAGE")) : 0;
   const int per_block = g.wpb * g.cpw;
   const int grid = (nch + per_block - 1) / per_block;
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);

@@ -8,6 +8,7 @@
 // the product library, which is built by hipcc from the same sources and fails
 // loudly without a GPU.  Nothing here is a "CPU fallback".
 #pragma once
+#define HIPEMU 1   /* lets kernel sources tell this emulator from hipcc's host pass */
 #include <ucontext.h>
 #include <cstdint>
 #include <cstdlib>

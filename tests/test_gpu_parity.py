@@ -632,3 +632,32 @@ def test_noise_estimate_matches_radio_c(pkg, L, M, P, olen, nch):
         assert np.array_equal(b.read_noise(1), got)                                  # switched off: nothing new written
     finally:
         eng.close()
+
+
+def test_staged_output_path_is_bit_identical(pkg, monkeypatch):
+    # large launches send the output rows through LDS as full-line stores (chz_kernels.h: p.stage); forced on here for a
+    # small bank, incl. a channel count that is not a multiple of the channels per wavefront and range launches at odd offsets
+    L, M = 25920, 6481
+    rng = np.random.default_rng(91)
+    x = rng.standard_normal(L).astype(np.float32)
+    outs = {}
+    for stage in ("0", "1"):
+        monkeypatch.setenv("CHZ_CHAN_STAGE", stage)
+        eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+        res = []
+        for P, olen, nch in ((300, 240, 1024), (300, 240, 7), (600, 480, 65), (200, 160, 10), (1200, 960, 5)):
+            b = eng.bank(P, olen, nch)
+            r2 = np.random.default_rng(P + nch)
+            b.set_responses(0, (r2.standard_normal((nch, P)) + 1j * r2.standard_normal((nch, P))).astype(np.complex64) / P)
+            b.set_shifts(0, r2.integers(-16000, 16000, nch)); b.set_active(nch)
+        eng.write(x); eng.step(0)
+        for b in eng.banks:
+            res.append(b.read_slot(0))
+        b = eng.banks[0]
+        b.execute_range(0, 5, 11) if hasattr(b, "execute_range") else None
+        eng.sync()
+        res.append(b.read_slot(0))
+        outs[stage] = res
+        eng.close()
+    for a, c in zip(outs["0"], outs["1"]):
+        assert np.array_equal(a, c) and np.abs(a).max() > 0

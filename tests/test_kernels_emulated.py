@@ -68,10 +68,12 @@ def test_forward_kernels(emu, N, in_type, spec, start):
     assert rel(out, want) < 5e-7, desc.value
 
 
+@pytest.mark.parametrize("stage", [0, 1])
 @pytest.mark.parametrize("in_type,B", [(ol.REAL, 16201), (ol.COMPLEX, 6000), (ol.COMPLEX, 6001)])
 @pytest.mark.parametrize("P,olen", [(300, 240), (600, 480), (200, 160), (400, 320), (1200, 960), (150, 120),
                                     (20, 16), (30, 24), (160, 128), (320, 256), (480, 384), (800, 640), (960, 768)])
-def test_channel_kernel(emu, in_type, B, P, olen):
+def test_channel_kernel(emu, in_type, B, P, olen, stage, monkeypatch):
+    monkeypatch.setenv("CHZ_CHAN_STAGE", str(stage))     # output rows straight from the lanes / staged through LDS
     rng = np.random.default_rng(B * 7 + P)
     spec = (rng.standard_normal(B) + 1j * rng.standard_normal(B)).astype(np.complex64)
     h = (B + 1) // 2
