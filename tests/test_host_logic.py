@@ -118,3 +118,46 @@ def test_plan_builder_covers_baseline_sizes(pkg):
     sizes = {int(a) * int(b) for a, b in re.findall(r"X\((\d+),\s*(\d+)\)", menu)}
     for p in (150, 160, 200, 300, 320, 400, 480, 600, 800, 960, 1200):
         assert p in sizes
+
+
+# ------------------------------------------------------------------------------
+# property tests (hypothesis): the closed forms the kernels consume against the restated reference logic
+# ------------------------------------------------------------------------------
+from hypothesis import given, settings, strategies as st, HealthCheck
+
+
+@settings(max_examples=300, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(real=st.booleans(), B=st.integers(40, 5000), P=st.integers(4, 64), frac=st.floats(-1.3, 1.3))
+def test_gather_descriptor_property(pkg, real, B, P, frac):
+    """Any master size, any channel size, any shift (in range, at the edges, far outside): the closed-form descriptor
+    names exactly the master bin the restated index walk of src/filter.c:728-911 reads for every output bin."""
+    if P > B:
+        P = B
+    in_type = ol.REAL if real else ol.COMPLEX
+    sh = int(round(frac * B))
+    k = np.arange(B)
+    spec = ((k + 1) + 1j * (k + 1)).astype(np.complex64)
+    d = pkg.engine.gather_descriptor(in_type, B, P, sh)
+    m, conj = _expand(d, P)
+    fd = ol.gather(spec, in_type, P, sh, np.ones(P, np.complex64))
+    order = [((P + 1) // 2 + t) % P for t in range(P)]
+    got = np.zeros(P, np.complex64)
+    for t in range(P):
+        if m[t] >= 0:
+            v = spec[m[t]]
+            got[order[t]] = np.conj(v) if conj else v
+    got[(P + 1) // 2] = 0
+    assert np.array_equal(got, fd), (in_type, B, P, sh, d)
+
+
+@settings(max_examples=200, deadline=None)
+@given(N=st.sampled_from([60000, 1620000, 3240000, 32400]), fs=st.sampled_from([2.4e6, 64.8e6, 129.6e6, 1.296e6]),
+       f=st.floats(-70e6, 70e6, allow_nan=False))
+def test_compute_tuning_property(N, fs, f):
+    """compute_tuning (src/radio.c:1175-1199): shift is the nearest bin, the remainder is what is left, |remainder| <= half a bin,
+    and frequencies beyond +-fs/2 are refused."""
+    r, shift, rem = ol.compute_tuning(N, fs, f)
+    hz = fs / N
+    assert abs(shift * hz + rem - f) <= 1e-9 * max(1.0, abs(f))
+    assert abs(rem) <= hz / 2 * (1 + 1e-12)
+    assert (r != 0) == (abs(shift) >= N // 2)
