@@ -43,9 +43,31 @@ def make(name, L, M, in_type, olen, fs, carrier_hz, chans, nblocks, notch_bins):
     print(name, "written")
 
 
+def make_downconvert(name):
+    """Tail of downconvert() (src/radio.c:1476-1520) around the reference's OWN oscillator (src/osc.c, src/sincospi.c
+    compiled unmodified; the dozen glue statements are restated in oracle/ref_driver.c): a tuning history with shift
+    changes, remainder changes and a sweep, applied to seeded channel samples."""
+    L, M, fs_out, olen = 11520, 2881, 12000.0, 240
+    rng = np.random.default_rng(2026)
+    history = [(2500, 13.7, 0.0)] * 2 + [(2501, 13.7, 0.0)] * 2 + [(2501, -7.25, 0.5)] * 70 + [(-3123, 3.0, 0.0)] * 2 + \
+              [(-3123, 0.0, 0.0)] + [(1234, 19.99, -3.0)] * 3
+    d = ol.Downconv(L, M, fs_out, "ref")
+    xs, ys, pw = [], [], []
+    for sh, rem, dr in history:
+        x = (rng.standard_normal(olen) + 1j * rng.standard_normal(olen)).astype(np.complex64)
+        y, p = d.block(x, sh, rem, dr)
+        xs.append(x); ys.append(y); pw.append(p)
+    keep = list(range(6)) + list(range(68, len(history)))          # the sweep's middle only advances the oscillator
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), L=L, M=M, fs_out=fs_out, olen=olen,
+                        history=np.array(history, np.float64), keep=np.array(keep, np.int32),
+                        x=np.stack(xs), y=np.stack(ys)[keep], power=np.array(pw)[keep])
+    print(name, "written")
+
+
 if __name__ == "__main__":
     if not ol.have_ref():
         raise SystemExit("oracle/_ref/libka9q_ref.so missing: run `make -C oracle` where /root/reference exists")
+    make_downconvert("downconvert_tail")
     # scaled-down RX888 geometry (real input, N = 14400, 40 Hz bins), P = 300: usb / cw / iq / inverted / edge channels
     make("real_n14400_p300", 11520, 2881, ol.REAL, 240, 576e3, 100020.0,
          [(2500, 50 / 12000, 3000 / 12000, 11.0), (2501, -200 / 12000, 200 / 12000, 11.0), (2500, -5000 / 12000, 5000 / 12000, 11.0),
