@@ -174,7 +174,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph per ring cycle instead of eager launches")
     ap.add_argument("--eager", action="store_true", help="(default) eager launches; kept for compatibility")
     ap.add_argument("--no-crt", action="store_true", help="skip the C_rt leg (one large bank, every block inside 20 ms)")
-    ap.add_argument("--crt-channels", type=int, default=18_000_000, help="channels of the C_rt leg's bank")
+    ap.add_argument("--crt-channels", type=int, default=17_000_000, help="channels of the C_rt leg's bank")
     args = ap.parse_args()
 
     import torch
