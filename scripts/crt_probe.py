@@ -15,7 +15,7 @@ import bench
 
 pkg = ge.load()
 L, M, N = bench.L, bench.M, bench.N
-P, olen = 300, 240
+P = int(os.environ.get("CRT_P", "300")); olen = P * 4 // 5      # 12 kHz channels (P=300) or 24 kHz (P=600, config 4)
 cap = int(float(sys.argv[1]) * 1e6) if len(sys.argv) > 1 else 10_000_000
 cap -= cap % 3072
 nblk = int(os.environ.get("CRT_BLOCKS", "500"))
@@ -27,6 +27,8 @@ t0 = time.time()
 bank = eng.bank(P, olen, cap)
 tile = 3072
 plan = bench.channel_plan_config3(tile)
+if P == 600:
+    plan = [(sh, -10000 / 24000, 10000 / 24000) for sh, _, _ in plan]          # config 4: 24 kHz channels, +-10 kHz
 resp = np.stack([pkg.filterapi.design_response(P, olen, N, True, lo, hi, 11.0) for _, lo, hi in plan[:3]])
 resp = np.ascontiguousarray(np.tile(resp, (tile // 3, 1)))
 shifts = np.array([p[0] for p in plan], np.int32)
