@@ -109,31 +109,39 @@ def cpu_baseline(oracle_lib, ring, plan, P, olen, seconds=12.0):
     R.oracle_fft_set_precision(1)          # float32 arithmetic for a fair CPU timing
     cores = os.cpu_count() or 1
     pool = max(1, min(cores - 1, 16))
-    m = oracle_lib.RefMaster(L, M, oracle_lib.REAL, worker_threads=1)
-    chans = []
-    for shift, low, high in plan:
-        c = m.channel(olen, oracle_lib.COMPLEX)
-        c.set_filter(low, high, 11.0)
-        chans.append(c)
-    harr = (ctypes.c_void_p * len(chans))(*[c.h for c in chans])
-    sarr = np.array([p[0] for p in plan], np.int32)
     ring = np.ascontiguousarray(ring, np.float32)
-    # calibrate with 2 blocks, then run a bounded sample
-    t = R.refchz_bench(m.h, harr, sarr.ctypes.data, len(chans), ring.ctypes.data, RING_BLOCKS, 2, pool)
-    nblk = int(max(3, min(200, seconds / max(t / 2, 1e-3))))
-    t = R.refchz_bench(m.h, harr, sarr.ctypes.data, len(chans), ring.ctypes.data, RING_BLOCKS, nblk, pool)
-    mn, mx, avg = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
-    R.refchz_fft_times(ctypes.byref(mn), ctypes.byref(mx), ctypes.byref(avg))
-    m.close()
+    sarr = np.array([p[0] for p in plan], np.int32)
+
+    def run(workers, budget):
+        m = oracle_lib.RefMaster(L, M, oracle_lib.REAL, worker_threads=workers)
+        chans = []
+        for shift, low, high in plan:
+            c = m.channel(olen, oracle_lib.COMPLEX)
+            c.set_filter(low, high, 11.0)
+            chans.append(c)
+        harr = (ctypes.c_void_p * len(chans))(*[c.h for c in chans])
+        # calibrate with 2 blocks, then run a bounded sample
+        t = R.refchz_bench(m.h, harr, sarr.ctypes.data, len(chans), ring.ctypes.data, RING_BLOCKS, 2, pool)
+        nblk = int(max(3, min(200, budget / max(t / 2, 1e-3))))
+        t = R.refchz_bench(m.h, harr, sarr.ctypes.data, len(chans), ring.ctypes.data, RING_BLOCKS, nblk, pool)
+        mn, mx, avg = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+        R.refchz_fft_times(ctypes.byref(mn), ctypes.byref(mx), ctypes.byref(avg))
+        m.close()
+        return nblk, t / nblk, avg.value / 1e6
+
+    nblk, per_block, fft_ms = run(1, seconds)
+    nblk2, per_block2, fft_ms2 = run(2, seconds / 2)        # fft-threads = 2, the reference's advice for this rate (docs/ka9q-radio.md:232)
     R.oracle_fft_set_precision(0)
-    per_block = t / nblk
     return {
         "value": len(plan) * BLOCKTIME / per_block, "unit": "channels",
         "cores": 1 + pool, "kind": "reference",
         "sample": "%d blocks of the same workload (%d channels P=%d), reference filter.c with the project's "
                   "portable float32 FFT provider (FFTW3 is not installed on this image), 1 FFT worker + %d channel threads"
                   % (nblk, len(plan), P, pool),
-        "ms_per_block": per_block * 1e3, "fwd_fft_ms_avg": avg.value / 1e6, "host_cores": cores,
+        "ms_per_block": per_block * 1e3, "fwd_fft_ms_avg": fft_ms, "host_cores": cores,
+        "two_fft_workers": {"value": len(plan) * BLOCKTIME / per_block2, "cores": 2 + pool, "blocks": nblk2,
+                            "ms_per_block": per_block2 * 1e3, "fwd_fft_ms_avg": fft_ms2},
+        "real_time": bool(min(per_block, per_block2) <= BLOCKTIME),
     }
 
 
