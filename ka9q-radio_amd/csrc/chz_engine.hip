@@ -306,6 +306,9 @@ int chz_input_ring(chz_engine* e, float** dev_ring, long* ring_len_floats) {
 
 // ---- kernel launches ---------------------------------------------------------
 struct Instr {      // optional per-kernel timing: one (begin, end) event pair per launch
+  Instr() = default;
+  Instr(const Instr&) = delete;
+  ~Instr() { for (auto e : ev) hipEventDestroy(e); }
   bool on = false;
   std::vector<hipEvent_t> ev;   // 2 per launch: dispatch begin / end timestamps
   std::vector<int> kind;        // 0 first, 1 cols, 2 rows, 3 (unused), 4 chan
@@ -773,6 +776,9 @@ static int lanes_join(chz_engine* e, hipEvent_t* evs) {
 
 int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int instrument, chz_timing* timing) {
   if (!e || nblocks < 0) return fail(-1, "bad argument");
+  if (mode == 1)
+    for (const Bank& b : e->banks)
+      if (b.fine) return fail(-5, "graph replay bakes the block number into the captured launches; fine-tuned banks need eager mode");
   HIPOK(hipSetDevice(e->device));
   { int r = sync_all(e); if (r) return r; }
   e->input_pending = false;                       // everything written so far is visible to every lane now
@@ -781,17 +787,25 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
     if (r) return r;
     e->notch_next = job0 + (unsigned)nblocks;
   }
-  hipEvent_t t0, t1, fork_ev, join_ev[CHZ_MAX_LANES];
-  HIPOK(hipEventCreate(&t0)); HIPOK(hipEventCreate(&t1));
-  HIPOK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
-  for (int i = 0; i < CHZ_MAX_LANES; i++) HIPOK(hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming));
+  struct Events {      // destroyed on every return path
+    hipEvent_t t0 = nullptr, t1 = nullptr, fork_ev = nullptr, join_ev[CHZ_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    ~Events() {
+      if (t0) hipEventDestroy(t0);
+      if (t1) hipEventDestroy(t1);
+      if (fork_ev) hipEventDestroy(fork_ev);
+      for (auto ev : join_ev) if (ev) hipEventDestroy(ev);
+    }
+  } evs;
+  HIPOK(hipEventCreate(&evs.t0)); HIPOK(hipEventCreate(&evs.t1));
+  HIPOK(hipEventCreateWithFlags(&evs.fork_ev, hipEventDisableTiming));
+  for (int i = 0; i < CHZ_MAX_LANES; i++) HIPOK(hipEventCreateWithFlags(&evs.join_ev[i], hipEventDisableTiming));
+  hipEvent_t t0 = evs.t0, t1 = evs.t1, fork_ev = evs.fork_ev;
+  hipEvent_t* join_ev = evs.join_ev;
   Instr in; in.on = instrument != 0 && mode == 0;
   hipStream_t s0 = e->lanes[0].s;
   int done = 0, rc = 0;
   const auto host_t0 = std::chrono::steady_clock::now();
   if (mode == 1) {
-    for (const Bank& b : e->banks)
-      if (b.fine) return fail(-5, "graph replay bakes the block number into the captured launches; fine-tuned banks need eager mode");
     // one graph = one ring cycle of blocks (a multiple of ND so slots and lanes line up too)
     int cycle = e->ring_blocks;
     while (cycle % CHZ_ND) cycle += e->ring_blocks;
@@ -839,9 +853,6 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
       *acc[in.kind[i]] += k; *cnt[in.kind[i]] += 1;
     }
   }
-  for (auto ev : in.ev) hipEventDestroy(ev);
-  hipEventDestroy(t0); hipEventDestroy(t1); hipEventDestroy(fork_ev);
-  for (int i = 0; i < CHZ_MAX_LANES; i++) hipEventDestroy(join_ev[i]);
   return 0;
 }
 
