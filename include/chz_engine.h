@@ -107,6 +107,10 @@ int chz_spectrum_attach(chz_engine *e, int slot, float *dev);
 /* A bank = all channels sharing one (P, olen); replaces create_filter_output's
  * allocations (src/filter.c:298-415) for COMPLEX output channels. */
 int chz_bank_create(chz_engine *e, int P, int olen, int capacity);          /* returns bank id */
+/* the same for REAL-output slaves (create_filter_output(.., REAL), src/filter.c:372-395; gather :794-809, c2r :914):
+ * responses are still P complex values per channel (set_filter's array, of which bins 0..P/2 are used), outputs are
+ * olen floats per channel; P must be even */
+int chz_bank_create_real(chz_engine *e, int P, int olen, int capacity);
 /* response[P] complex as set_filter leaves it (src/filter.c:968-1045) */
 int chz_bank_set_responses(chz_engine *e, int bank, int ch0, int n, const float *resp);
 /* `shift` of execute_filter_output(slave, shift) (src/filter.c:663) */
@@ -146,7 +150,7 @@ int chz_bank_enable_noise(chz_engine *e, int bank, double samprate);
 int chz_bank_read_noise(chz_engine *e, int bank, int slot, int ch0, int n, double *host);        /* synchronous */
 int chz_bank_read_noise_async(chz_engine *e, int bank, int slot, int ch0, int n, double *host);
 int chz_bank_destroy(chz_engine *e, int bank);                              /* frees the bank's device arrays */
-int chz_bank_read(chz_engine *e, int bank, int ch0, int n, float *host);    /* n*olen complex of the most recent execute, synchronous */
+int chz_bank_read(chz_engine *e, int bank, int ch0, int n, float *host);    /* n*olen complex (REAL banks: n*olen floats) of the most recent execute, synchronous */
 /* Blocks are pipelined over 1, 2 or 4 HIP streams ("lanes", env CHZ_STREAMS, default 4): block j
  * runs on lane j % lanes with its own intermediate buffer, so block j+1's forward transform overlaps
  * block j's tail.  Bank outputs exist once per spectrum slot.  Everything addressed by `slot` below is

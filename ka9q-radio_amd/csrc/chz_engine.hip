@@ -30,6 +30,7 @@ static int fail(int code, const char* fmt, ...) {
 
 struct Bank {
   int P = 0, olen = 0, cap = 0, active = 0;
+  int out_real = 0;             // 1: REAL-output slaves (olen floats per channel, chan_c2r); 0: COMPLEX
   ChanGeom g;
   float2* resp = nullptr;       // [cap][P]
   ChanDesc* desc = nullptr;     // [cap]
@@ -391,7 +392,14 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
   return 0;
 }
 
-static inline float2* bank_out(const Bank& b, int slot) { return b.out + (size_t)slot * b.cap * b.olen; }
+// output image of one slot; a sample is one float (REAL banks) or one float2
+static inline size_t bank_sample_bytes(const Bank& b) { return b.out_real ? sizeof(float) : sizeof(float2); }
+static inline float2* bank_out(const Bank& b, int slot) {
+  return reinterpret_cast<float2*>(reinterpret_cast<char*>(b.out) + (size_t)slot * b.cap * b.olen * bank_sample_bytes(b));
+}
+static inline char* bank_out_at(const Bank& b, int slot, int ch) {
+  return reinterpret_cast<char*>(bank_out(b, slot)) + (size_t)ch * b.olen * bank_sample_bytes(b);
+}
 
 static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch0 = 0, int n = -1) {
   Bank& b = e->banks[(size_t)bank];
@@ -409,10 +417,13 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   const int per_block = b.g.wpb * b.g.cpw;
   const int grid = (n + per_block - 1) / per_block;
   mark(in, st, 4, true);
-  if (launch_chan(b.g.r, grid, b.g.wpb * 64, b.g.lds, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for P=%d", b.P);
+  if (b.out_real) {
+    c.shifts = b.shifts; c.m_bins = e->bins; c.m_real = e->in_type == CHZ_REAL; c.fine = nullptr; c.power = nullptr; c.stage = 0;
+    if (launch_chan_real(b.g.r, grid, b.g.wpb * 64, b.g.lds, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no real-output kernel for P=%d", b.P);
+  } else if (launch_chan(b.g.r, grid, b.g.wpb * 64, b.g.lds, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for P=%d", b.P);
   mark(in, st, 4, false);
   if (b.n0 && b.noise_samprate > 0.0) {
-    NoiseParams q = noise_params(e->bins, e->in_type == CHZ_REAL, b.P, b.noise_samprate);
+    NoiseParams q = noise_params(e->bins, e->in_type == CHZ_REAL, b.out_real ? b.P / 2 + 1 : b.P, b.noise_samprate);   // slave->bins
     q.spec = e->spec[slot]; q.lay = c.lay; q.shift = b.shifts; q.n0 = b.n0 + (size_t)slot * b.cap; q.ch0 = ch0; q.nch = n;
     mark(in, st, 3, true);
     if (launch_noise(n, st, q, IN_E0(in), IN_E1(in))) return fail(-4, "no noise kernel for a %d-bin window", q.nbins);
@@ -512,7 +523,7 @@ int chz_spectrum_attach(chz_engine* e, int slot, float* dev) {
   return 0;
 }
 
-int chz_bank_create(chz_engine* e, int P, int olen, int capacity) {
+static int bank_create(chz_engine* e, int P, int olen, int capacity, int out_real) {
   if (!e) return fail(-1, "null engine");
   if (capacity < 1 || olen < 1 || olen > P) return fail(-1, "bad bank geometry");
   // P = olen*N/L must divide exactly (src/filter.c:312-316)
@@ -523,15 +534,16 @@ int chz_bank_create(chz_engine* e, int P, int olen, int capacity) {
   HIPOK(hipSetDevice(e->device));
   // a failed allocation (the C_rt-sized banks take > 100 GB) must not leak the earlier ones
   struct Guard { Bank* b; ~Guard() { if (b) { hipFree(b->resp); hipFree(b->desc); hipFree(b->shifts); hipFree(b->out); hipFree(b->tw_sub); } } } guard{&b};
-  b.P = P; b.olen = olen; b.cap = capacity; b.active = 0;
+  b.P = P; b.olen = olen; b.cap = capacity; b.active = 0; b.out_real = out_real;
+  if (out_real && (P & 1)) return fail(-3, "real-output channels need an even P (got %d)", P);
   HIPOK(hipMalloc((void**)&b.resp, sizeof(float2) * (size_t)capacity * P));
   HIPOK(hipMemset(b.resp, 0, sizeof(float2) * (size_t)capacity * P));
   HIPOK(hipMalloc((void**)&b.desc, sizeof(ChanDesc) * (size_t)capacity));
   HIPOK(hipMemset(b.desc, 0, sizeof(ChanDesc) * (size_t)capacity));
   HIPOK(hipMalloc((void**)&b.shifts, sizeof(int) * (size_t)capacity));
   HIPOK(hipMemset(b.shifts, 0, sizeof(int) * (size_t)capacity));
-  HIPOK(hipMalloc((void**)&b.out, sizeof(float2) * (size_t)CHZ_ND * capacity * olen));
-  HIPOK(hipMemset(b.out, 0, sizeof(float2) * (size_t)CHZ_ND * capacity * olen));
+  HIPOK(hipMalloc((void**)&b.out, bank_sample_bytes(b) * (size_t)CHZ_ND * capacity * olen));
+  HIPOK(hipMemset(b.out, 0, bank_sample_bytes(b) * (size_t)CHZ_ND * capacity * olen));
   int r = upload(&b.tw_sub, b.g.tw_sub);
   if (r) return r;
   HIPOK(hipDeviceSynchronize());       // null-stream memsets vs the engine's non-blocking streams
@@ -540,6 +552,10 @@ int chz_bank_create(chz_engine* e, int P, int olen, int capacity) {
   e->banks.push_back(b);
   return (int)e->banks.size() - 1;
 }
+
+int chz_bank_create(chz_engine* e, int P, int olen, int capacity) { return bank_create(e, P, olen, capacity, 0); }
+// create_filter_output(.., REAL) (src/filter.c:372-395): olen real samples per channel and block
+int chz_bank_create_real(chz_engine* e, int P, int olen, int capacity) { return bank_create(e, P, olen, capacity, 1); }
 
 #define BANK_CHECK(e, bank, ch0, n) \
   if (!(e) || (bank) < 0 || (bank) >= (int)(e)->banks.size()) return fail(-1, "bad bank"); \
@@ -574,6 +590,7 @@ int chz_bank_set_tuning(chz_engine* e, int bank, unsigned job, int ch0, int n, c
   BANK_CHECK(e, bank, ch0, n);
   if (!shifts || !freq) return fail(-1, "null argument");
   Bank& b = e->banks[(size_t)bank];
+  if (b.out_real) return fail(-1, "fine tuning applies to COMPLEX-output banks");
   if (e->M < 2) return fail(-1, "impulse length %d has no overlap factor", e->M);
   const int V = 1 + e->L / (e->M - 1);
   HIPOK(hipSetDevice(e->device));
@@ -609,7 +626,8 @@ int chz_bank_enable_noise(chz_engine* e, int bank, double samprate) {
   BANK_CHECK(e, bank, 0, 0);
   Bank& b = e->banks[(size_t)bank];
   if (!(samprate >= 0.0)) return fail(-1, "bad sample rate");
-  const int nb = b.P < 1000 ? 1000 : b.P;
+  const int sb = b.out_real ? b.P / 2 + 1 : b.P;     // slave->bins (src/radio.c:1794)
+  const int nb = sb < 1000 ? 1000 : sb;
   if (samprate > 0.0 && nb > e->bins) return fail(-1, "master has %d bins, fewer than the %d-bin noise window", e->bins, nb);
   if (samprate > 0.0 && nb > 2048) return fail(-3, "no noise kernel compiled for a %d-bin window", nb);
   HIPOK(hipSetDevice(e->device));
@@ -698,7 +716,7 @@ int chz_bank_read_async(chz_engine* e, int bank, int slot, int ch0, int n, float
   if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
   Bank& b = e->banks[(size_t)bank];
   if (n == 0) return 0;
-  HIPOK(hipMemcpyAsync(host, bank_out(b, slot) + (size_t)ch0 * b.olen, sizeof(float2) * (size_t)n * b.olen,
+  HIPOK(hipMemcpyAsync(host, bank_out_at(b, slot, ch0), bank_sample_bytes(b) * (size_t)n * b.olen,
                        hipMemcpyDeviceToHost, slot_stream(e, slot)));
   return 0;
 }
@@ -728,7 +746,7 @@ int chz_bank_read(chz_engine* e, int bank, int ch0, int n, float* host) {
   BANK_CHECK(e, bank, ch0, n);
   Bank& b = e->banks[(size_t)bank];
   hipStream_t st = slot_stream(e, b.last_slot);
-  HIPOK(hipMemcpyAsync(host, bank_out(b, b.last_slot) + (size_t)ch0 * b.olen, sizeof(float2) * (size_t)n * b.olen, hipMemcpyDeviceToHost, st));
+  HIPOK(hipMemcpyAsync(host, bank_out_at(b, b.last_slot, ch0), bank_sample_bytes(b) * (size_t)n * b.olen, hipMemcpyDeviceToHost, st));
   HIPOK(hipStreamSynchronize(st));
   return 0;
 }

@@ -184,6 +184,9 @@ struct ChanDesc { int t0, cnt, src0, dir, conj, wrap; };
 struct FineDesc { double phase0, freq, rate; unsigned job0; int adj_num, V, on; };
 
 struct ChanParams {
+  // REAL-output banks (chan_c2r) take the shift itself instead of a descriptor
+  const int* shifts;      // [nch]
+  int m_bins, m_real;     // master bins; master is REAL (else COMPLEX)
   int stage;              // 1: output rows leave through LDS as full-line stores (throughput); 0: straight from the lanes (latency)
   const FineDesc* fine;   // [nch] or nullptr: plain execute_filter_output semantics
   double* power;          // [nch] mean |sample|^2 of the block after rotation (chan->sig.bb_power, :1516-1520)
@@ -680,6 +683,102 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
 #pragma unroll
     for (int i = 0; i < R1; i++) tot += __shfl(part, (cw < CPW ? cw : 0) * LPC + i);
     if (live && jl == 0) p.power[ch] = tot / (double)p.olen;
+  }
+}
+
+// ------------------------------------------------------------------------------
+// K3+K4 for REAL-output slaves (create_filter_output(.., REAL): wfm's composite filters): the gather of
+// src/filter.c:803-809 (REAL master) / :794-802 (COMPLEX master) fills bins 0..P/2, bin (bins+1)/2 is zeroed
+// (:911), and the c2r transform of src/filter.c:914 via :387 is a backward transform of the Hermitian
+// extension Y[P-k] = conj(Y[k]) with the imaginary parts of DC and Nyquist ignored, as FFTW's c2r does.
+// Output: the last olen of P real samples (:385).  Same lane layout as chan_ifft; P even.
+// ------------------------------------------------------------------------------
+template <int R1, int R2>
+__global__ void __launch_bounds__(256) chan_c2r(ChanParams p) {
+  constexpr int P = R1 * R2;
+  constexpr int LPC = R1 > R2 ? R1 : R2;
+  constexpr int CPW = 64 / LPC;
+  constexpr int LDC = R2 + 1;
+  static_assert(CPW >= 1, "radix too wide for one wavefront");
+  static_assert(P % 2 == 0, "real-output channels need an even P");
+  HIP_DYNAMIC_SHARED(float2, lds)
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wpb = blockDim.x >> 6;
+  const int cw = lane / LPC, jl = lane - cw * LPC;
+  const int lc = (blockIdx.x * wpb + wave) * CPW + cw;
+  const int ch = p.ch0 + lc;
+  const bool live = (cw < CPW) && (lc < p.nch);
+  float2* my = lds + ((wave * CPW + (cw < CPW ? cw : 0)) * (R1 * LDC));
+  const float2* __restrict__ tws = p.tw_sub;
+
+  if (live && jl < R2) {
+    const int shift = p.shifts[ch];
+    const float2* __restrict__ H = p.resp + (long)ch * P;
+    const float2* __restrict__ X = p.spec;
+    constexpr int SB = P / 2 + 1;                          // slave bins (:374)
+    float2 v[R1], w[R1], h[R1];
+    bool ok[R1];
+    static_for<R1>([&](auto q) {
+      constexpr int Q = decltype(q)::value;
+      const int i = jl + Q * R2;                           // index into the Hermitian-extended spectrum
+      const int k = i <= P / 2 ? i : P - i;                // the slave bin it comes from
+      const int mi = k + shift;
+      int a, b = 0;
+      if (p.m_real) {
+        ok[Q] = mi >= 0 && mi < p.m_bins;                                           // :808
+        a = ok[Q] ? mi : 0;
+      } else {
+        ok[Q] = mi >= -(p.m_bins / 2) && mi < p.m_bins / 2;                         // :798
+        a = mi % p.m_bins; if (a < 0) a += p.m_bins;
+        b = (p.m_bins - mi) % p.m_bins; if (b < 0) b += p.m_bins;
+        if (!ok[Q]) { a = 0; b = 0; }
+      }
+      if (k == (SB + 1) / 2) ok[Q] = false;                                         // :911
+      int row = (int)((float)a * p.inv_na), col = a - row * p.lay.na;
+      if (col < 0) { row--; col += p.lay.na; } else if (col >= p.lay.na) { row++; col -= p.lay.na; }
+      v[Q] = X[(long)row * p.lay.pitch + p.lay.off + col];
+      if (!p.m_real) {
+        int rowb = (int)((float)b * p.inv_na), colb = b - rowb * p.lay.na;
+        if (colb < 0) { rowb--; colb += p.lay.na; } else if (colb >= p.lay.na) { rowb++; colb -= p.lay.na; }
+        w[Q] = X[(long)rowb * p.lay.pitch + p.lay.off + colb];
+      }
+      h[Q] = H[k];
+    });
+    static_for<R1>([&](auto q) {
+      constexpr int Q = decltype(q)::value;
+      const int i = jl + Q * R2;
+      const int k = i <= P / 2 ? i : P - i;
+      float2 x = v[Q];
+      if (!p.m_real) x = make_float2(x.x + w[Q].x, x.y - w[Q].y);                   // X[a] + conj(X[b]), :800
+      x = cmul(x, h[Q]);
+      if (k == 0 || 2 * k == P) x.y = 0.f;                                          // c2r ignores these imaginary parts
+      if (i > P / 2) x.y = -x.y;                                                    // Hermitian extension
+      v[Q] = ok[Q] ? x : make_float2(0.f, 0.f);
+    });
+    reg_dft<R1, +1>(v);
+    static_for<R1>([&](auto k1) {
+      constexpr int K1 = decltype(k1)::value;
+      float2 x = v[K1];
+      if constexpr (K1 > 0) x = cmul(x, tws[jl * R1 + K1]);
+      my[K1 * LDC + jl] = x;
+    });
+  }
+  __syncthreads();
+  if (live && jl < R1) {
+    float2 u[R2];
+    static_for<R2>([&](auto j) {
+      constexpr int J = decltype(j)::value;
+      u[J] = my[jl * LDC + J];
+    });
+    reg_dft<R2, +1>(u);
+    const int drop = P - p.olen;
+    float* __restrict__ o = reinterpret_cast<float*>(p.out) + (long)ch * p.olen;
+    static_for<R2>([&](auto k2) {
+      constexpr int K2 = decltype(k2)::value;
+      const int n = jl + R1 * K2;
+      if (n >= drop) o[n - drop] = u[K2].x;
+    });
   }
 }
 

@@ -44,6 +44,12 @@ inline int launch_chan(Radix2 r, int grid, int block, size_t lds, hipStream_t s,
 #undef X
   return -1;
 }
+inline int launch_chan_real(Radix2 r, int grid, int block, size_t lds, hipStream_t s, const ChanParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+#define X(a, b) if (r.r1 == a && r.r2 == b) { if constexpr ((a * b) % 2 == 0) { CHZ_LAUNCH((chan_c2r<a, b>), grid, block, lds, s, e0, e1, p); return 0; } }
+  CHZ_CHAN_MENU(X)
+#undef X
+  return -1;
+}
 inline int launch_noise(int nch, hipStream_t s, const NoiseParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   const int grid = (nch + 3) / 4;          // four wavefronts = four channels per workgroup
   if (p.nsort == 1024) { CHZ_LAUNCH((noise_est<16>), grid, 256, 0, s, e0, e1, p); return 0; }

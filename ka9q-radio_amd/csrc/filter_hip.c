@@ -57,9 +57,10 @@ int64_t Mean_dev = 0;
 /* ------------------------------------------------------------------------- */
 struct hbank {
   int P, olen, id, cap, n;
+  bool real;                        /* REAL-output slaves: olen floats per channel (else olen float complex) */
   struct filter_out **slaves;       /* [cap] */
   int *shift;                       /* [cap] shift the device descriptor currently holds */
-  float complex *stage[ND];         /* pinned [cap][olen]: staged outputs per job slot */
+  void *stage[ND];                  /* pinned [cap][olen] samples: staged outputs per job slot */
   int *stage_shift[ND];             /* [cap] shift each staged output was computed with */
   unsigned *stage_epoch[ND];        /* [cap] response epoch it was computed with (0 = invalid) */
   unsigned stage_job[ND];
@@ -218,6 +219,8 @@ static void block_done(void *arg) {
 /* ------------------------------------------------------------------------- */
 /* banks                                                                        */
 /* ------------------------------------------------------------------------- */
+static size_t bank_sample_bytes(const struct hbank *b) { return b->real ? sizeof(float) : sizeof(float complex); }
+static int bank_create_dev(struct mctx *c, const struct hbank *b, int cap);
 static void bank_free_host(struct hbank *b) {
   for (int s = 0; s < ND; s++) { chz_host_free(b->stage[s]); b->stage[s] = NULL; FREE(b->stage_shift[s]); FREE(b->stage_epoch[s]); }
   FREE(b->slaves); FREE(b->shift);
@@ -229,7 +232,7 @@ static int bank_alloc_host(struct hbank *b, int cap) {
   if (!b->slaves || !b->shift) return -1;
   for (int s = 0; s < ND; s++) {
     void *p = NULL;
-    if (chz_host_alloc(&p, sizeof(float complex) * (size_t)cap * b->olen) != 0) return -1;
+    if (chz_host_alloc(&p, bank_sample_bytes(b) * (size_t)cap * b->olen) != 0) return -1;
     b->stage[s] = p;
     b->stage_shift[s] = calloc((size_t)cap, sizeof(int));
     b->stage_epoch[s] = calloc((size_t)cap, sizeof(unsigned));
@@ -238,15 +241,18 @@ static int bank_alloc_host(struct hbank *b, int cap) {
   }
   return 0;
 }
-/* find (or create, or grow) the bank for (P, olen); caller holds ctx->lock */
-static int bank_for(struct mctx *c, int P, int olen) {
+static int bank_create_dev(struct mctx *c, const struct hbank *b, int cap) {
+  return b->real ? chz_bank_create_real(c->eng, b->P, b->olen, cap) : chz_bank_create(c->eng, b->P, b->olen, cap);
+}
+/* find (or create, or grow) the bank for (P, olen, output type); caller holds ctx->lock */
+static int bank_for(struct mctx *c, int P, int olen, bool real) {
   for (int i = 0; i < c->nbanks; i++) {
     struct hbank *b = &c->banks[i];
-    if (b->P != P || b->olen != olen) continue;
+    if (b->P != P || b->olen != olen || b->real != real) continue;
     if (b->n < b->cap) return i;
     /* grow: a new, larger device bank; move responses and shifts over */
-    struct hbank nb = {.P = P, .olen = olen, .n = b->n};
-    nb.id = chz_bank_create(c->eng, P, olen, b->cap * 2);
+    struct hbank nb = {.P = P, .olen = olen, .n = b->n, .real = real};
+    nb.id = bank_create_dev(c, &nb, b->cap * 2);
     if (nb.id < 0 || bank_alloc_host(&nb, b->cap * 2) != 0) { fprintf(stderr, "filter_hip: cannot grow bank: %s\n", chz_last_error()); return -1; }
     for (int k = 0; k < b->n; k++) {
       nb.slaves[k] = b->slaves[k]; nb.shift[k] = b->shift[k];
@@ -263,8 +269,8 @@ static int bank_for(struct mctx *c, int P, int olen) {
   c->banks = nbanks;
   struct hbank *b = &c->banks[c->nbanks];
   memset(b, 0, sizeof *b);
-  b->P = P; b->olen = olen;
-  b->id = chz_bank_create(c->eng, P, olen, 64);
+  b->P = P; b->olen = olen; b->real = real;
+  b->id = bank_create_dev(c, b, 64);
   if (b->id < 0) { fprintf(stderr, "filter_hip: %s\n", chz_last_error()); return -1; }
   if (bank_alloc_host(b, 64) != 0) return -1;
   return c->nbanks++;
@@ -377,8 +383,8 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
     fprintf(stderr, "Invalid filter output length %d (fft size %d) for input N=%d, L=%d\n", len, (int)((long)len * N / L), N, L);
     return -1;
   }
-  if (out_type == REAL) {
-    fprintf(stderr, "create_filter_output: REAL output is not part of the MI355X channelizer path (no CPU fallback)\n");
+  if (out_type == REAL && (((long)len * N / L) & 1)) {
+    fprintf(stderr, "create_filter_output: REAL output needs an even block size (got %d)\n", (int)((long)len * N / L));
     return -1;
   }
   if (slave->init && slave->rev_plan) delete_filter_output(slave);  /* geometry changed: start over */
@@ -388,23 +394,28 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
   slave->master = master;
   slave->out_type = out_type;
   set_filter_weights(slave, 1.0, 0.0);
-  if (out_type == COMPLEX) {
+  if (out_type == COMPLEX || out_type == REAL) {
     struct mctx *c = MCTX(master);
-    slave->bins = slave->points;
+    bool const real = out_type == REAL;
+    slave->bins = real ? slave->points / 2 + 1 : slave->points;    /* src/filter.c:346,374 */
     slave->fdomain = lmalloc(sizeof(float complex) * (size_t)slave->bins);
-    slave->output_buffer.c = lmalloc(sizeof(float complex) * (size_t)slave->points);
     struct sctx *sc = calloc(1, sizeof *sc);
-    if (!slave->fdomain || !slave->output_buffer.c || !sc) { FREE(slave->fdomain); FREE(slave->output_buffer.c); free(sc); return -1; }
-    memset(slave->output_buffer.c, 0, sizeof(float complex) * (size_t)slave->points);
-    slave->output.c = slave->output_buffer.c + slave->bins - len;   /* src/filter.c:357 */
+    if (real) {
+      slave->output_buffer.r = lmalloc(sizeof(float) * (size_t)slave->points);
+      if (slave->output_buffer.r) { memset(slave->output_buffer.r, 0, sizeof(float) * (size_t)slave->points); slave->output.r = slave->output_buffer.r + slave->points - len; }   /* src/filter.c:385 */
+    } else {
+      slave->output_buffer.c = lmalloc(sizeof(float complex) * (size_t)slave->points);
+      if (slave->output_buffer.c) { memset(slave->output_buffer.c, 0, sizeof(float complex) * (size_t)slave->points); slave->output.c = slave->output_buffer.c + slave->bins - len; }  /* src/filter.c:357 */
+    }
+    if (!slave->fdomain || (!slave->output_buffer.c && !slave->output_buffer.r) || !sc) { FREE(slave->fdomain); FREE(slave->output_buffer.c); FREE(slave->output_buffer.r); free(sc); return -1; }
     pthread_mutex_lock(&c->lock);
     pthread_rwlock_wrlock(&c->stage_lock);
-    int bi = bank_for(c, slave->points, len);
+    int bi = bank_for(c, slave->points, len, real);
     if (bi < 0) {
       pthread_rwlock_unlock(&c->stage_lock);
       pthread_mutex_unlock(&c->lock);
       fprintf(stderr, "create_filter_output: no device kernel for P=%d\n", slave->points);
-      FREE(slave->fdomain); FREE(slave->output_buffer.c); free(sc);
+      FREE(slave->fdomain); FREE(slave->output_buffer.c); FREE(slave->output_buffer.r); free(sc);
       return -1;
     }
     struct hbank *b = &c->banks[bi];
@@ -567,6 +578,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
         slave->block_drops++;
         slave->next_jobnum++;
         if (slave->output_buffer.c != NULL) memset(slave->output_buffer.c, 0, (size_t)slave->points * sizeof *slave->output_buffer.c);
+        if (slave->output_buffer.r != NULL) memset(slave->output_buffer.r, 0, (size_t)slave->points * sizeof *slave->output_buffer.r);
         return 0;
       }
       break;
@@ -578,7 +590,9 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
 
   if (slave->out_type == SPECTRUM || slave->rev_plan == NULL) return 0;   /* block clock only */
   pthread_mutex_lock(&slave->response_mutex);
-  bool const ready = slave->response != NULL && slave->output.c != NULL;
+  bool const real_out = slave->out_type == REAL;
+  void *const dst = real_out ? (void *)slave->output.r : (void *)slave->output.c;
+  bool const ready = slave->response != NULL && dst != NULL;
   pthread_mutex_unlock(&slave->response_mutex);
   if (!ready) return 0;                                            /* src/filter.c:715-718 */
 
@@ -592,7 +606,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
     if (b->stage_job[slot] == job && k < b->stage_n[slot] && b->stage_shift[slot][k] == shift &&
         b->stage_epoch[slot][k] == sc->epoch) {
       /* the speculative batch already computed exactly this */
-      memcpy(slave->output.c, b->stage[slot] + (size_t)k * b->olen, sizeof(float complex) * (size_t)b->olen);
+      memcpy(dst, (char *)b->stage[slot] + (size_t)k * b->olen * bank_sample_bytes(b), bank_sample_bytes(b) * (size_t)b->olen);
       hit = true;
     }
   }
@@ -606,7 +620,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
   int const k = sc->idx;
   if (b->shift[k] != shift) { b->shift[k] = shift; rc = chz_bank_set_shifts(c->eng, b->id, k, 1, &b->shift[k]); }
   if (rc == 0) rc = chz_bank_execute_range(c->eng, b->id, slot, k, 1);
-  if (rc == 0) rc = chz_bank_read(c->eng, b->id, k, 1, (float *)slave->output.c);
+  if (rc == 0) rc = chz_bank_read(c->eng, b->id, k, 1, (float *)dst);
   if (rc != 0) fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
   pthread_mutex_unlock(&c->lock);
   return rc == 0 ? 0 : -1;

@@ -40,7 +40,7 @@ SYMBOLS = [
     "chz_bank_output_device", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
     "chz_bank_set_tuning", "chz_bank_read_power", "chz_bank_read_power_async",
     "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
-    "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async",
+    "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real",
 ]
 
 _lib = None
@@ -74,6 +74,7 @@ def lib():
         L.chz_slot_stream.argtypes = [_vp, _i, C.POINTER(_vp)]
         L.chz_spectrum_attach.argtypes = [_vp, _i, _vp]
         L.chz_bank_create.argtypes = [_vp, _i, _i, _i]
+        L.chz_bank_create_real.argtypes = [_vp, _i, _i, _i]
         L.chz_bank_set_responses.argtypes = [_vp, _i, _i, _i, _vp]
         L.chz_bank_set_shifts.argtypes = [_vp, _i, _i, _i, _vp]
         L.chz_bank_set_active.argtypes = [_vp, _i, _i]
@@ -201,8 +202,8 @@ class Engine:
         _check(lib().chz_spectrum_attach(self._h, slot, dev_ptr))
 
     # -- banks -----------------------------------------------------------------
-    def bank(self, P, olen, capacity):
-        b = Bank(self, P, olen, capacity)
+    def bank(self, P, olen, capacity, real=False):
+        b = Bank(self, P, olen, capacity, real)
         self.banks.append(b)
         return b
 
@@ -220,9 +221,11 @@ class Engine:
 
 
 class Bank:
-    def __init__(self, eng, P, olen, capacity):
-        self.eng, self.P, self.olen, self.capacity = eng, P, olen, capacity
-        self.id = _check(lib().chz_bank_create(eng._h, P, olen, capacity))
+    def __init__(self, eng, P, olen, capacity, real=False):
+        self.eng, self.P, self.olen, self.capacity, self.real = eng, P, olen, capacity, bool(real)
+        make = lib().chz_bank_create_real if real else lib().chz_bank_create      # REAL- or COMPLEX-output slaves
+        self.id = _check(make(eng._h, P, olen, capacity))
+        self._dtype = np.float32 if real else np.complex64
         self.active = 0
 
     def set_responses(self, ch0, resp):
@@ -281,7 +284,7 @@ class Bank:
     def read(self, ch0=0, n=None):
         if n is None:
             n = self.active - ch0
-        out = np.zeros((n, self.olen), np.complex64)
+        out = np.zeros((n, self.olen), self._dtype)
         _check(lib().chz_bank_read(self.eng._h, self.id, ch0, n, out.ctypes.data))
         return out
 
@@ -289,7 +292,7 @@ class Bank:
         """Outputs of the block last executed on spectrum slot `slot` (every slot keeps its own image)."""
         if n is None:
             n = self.active - ch0
-        out = np.zeros((n, self.olen), np.complex64)
+        out = np.zeros((n, self.olen), self._dtype)
         _check(lib().chz_bank_read_async(self.eng._h, self.id, slot, ch0, n, out.ctypes.data))
         self.eng.sync()
         return out

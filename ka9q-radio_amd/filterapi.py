@@ -220,13 +220,16 @@ def create_filter_output(master, olen, out_type, slave=None):
     s.output = None
     s.isb = False
     s.beam = False
-    if out_type == COMPLEX:
-        s.bins = s.points
-        key = (s.points, olen)
+    if out_type in (COMPLEX, REAL):
+        real = out_type == REAL
+        if real and s.points % 2:
+            return None                  # the c2r kernels need an even block size
+        s.bins = s.points // 2 + 1 if real else s.points          # (:346,374)
+        key = (s.points, olen, real)
         st = master._banks.get(key)
         if st is None or len(st.slaves) >= st.bank.capacity:
             cap = 64 if st is None else st.bank.capacity * 2
-            new = _BankState(master._engine.bank(s.points, olen, cap))
+            new = _BankState(master._engine.bank(s.points, olen, cap, real=real))
             if st is not None:            # grow: move the existing slaves over
                 for old in st.slaves:
                     old._bank, old._index = new, len(new.slaves)
@@ -243,9 +246,7 @@ def create_filter_output(master, olen, out_type, slave=None):
         s.bins = 0                        # block clock only, no buffers (:368-371)
         s._bank = None
     else:
-        # REAL output (wfm composite / filter2 style small inline filters) is outside
-        # the accelerated path; fail loudly rather than fall back to a CPU path.
-        raise NotImplementedError("REAL-output slaves are not part of the MI355X channelizer path")
+        return None
     s.next_jobnum = master.next_jobnum
     s.init = True
     return s
@@ -314,6 +315,8 @@ def execute_filter_output(slave, shift):
         slave.next_jobnum = (slave.next_jobnum + 1) & 0xFFFFFFFF
         if slave.out_type == COMPLEX:
             slave.output = np.zeros(slave.olen, np.complex64)
+        elif slave.out_type == REAL:
+            slave.output = np.zeros(slave.olen, np.float32)
         return 0
     job = slave.next_jobnum
     slave.sample_index = master.samples_by_job[job % ND]

@@ -57,6 +57,24 @@ static void *channel_thread(void *a) {
   return NULL;
 }
 
+/* optional REAL-output slave (wfm's composite filters use these, src/wfm.c): env HARNESS_REAL="shift low high beta" */
+static int Real_on, Real_shift; static double Real_low, Real_high, Real_beta;
+static float *Real_result;             /* [Nblocks][Olen] */
+static void *real_thread(void *a) {
+  (void)a;
+  struct filter_out out;
+  memset(&out, 0, sizeof out);
+  if (create_filter_output(&out, &Master, Olen, REAL) != 0) { fprintf(stderr, "create_filter_output(REAL) failed\n"); exit(2); }
+  if (out.bins != out.points / 2 + 1 || out.output.r != out.output_buffer.r + out.points - Olen) { fprintf(stderr, "REAL slave geometry\n"); exit(2); }
+  if (set_filter(&out, Real_low, Real_high, Real_beta) != 0) { fprintf(stderr, "set_filter(REAL) failed\n"); exit(2); }
+  for (int b = 0; b < Nblocks; b++) {
+    if (execute_filter_output(&out, Real_shift) != 0) { fprintf(stderr, "execute_filter_output(REAL) failed\n"); exit(2); }
+    memcpy(Real_result + (size_t)b * Olen, out.output.r, sizeof(float) * (size_t)Olen);
+  }
+  delete_filter_output(&out);
+  return NULL;
+}
+
 static _Atomic int Clock_blocks;
 static void *clock_thread(void *a) {
   (void)a;
@@ -103,6 +121,12 @@ int main(int argc, char **argv) {
   struct chanarg *args = calloc((size_t)Nch, sizeof *args);
   for (int i = 0; i < Nch; i++) { args[i].idx = i; pthread_create(&th[i], NULL, channel_thread, &args[i]); }
   pthread_create(&clk, NULL, clock_thread, NULL);
+  pthread_t rth;
+  if (getenv("HARNESS_REAL") && sscanf(getenv("HARNESS_REAL"), "%d %lf %lf %lf", &Real_shift, &Real_low, &Real_high, &Real_beta) == 4) {
+    Real_on = 1;
+    Real_result = calloc((size_t)Nblocks * Olen, sizeof *Real_result);
+    pthread_create(&rth, NULL, real_thread, NULL);
+  }
   for (int i = 0; i < Nch; i++) while (atomic_load(&Progress[i]) < 0) usleep(200);      /* all slaves registered */
 
   /* front end: write in place, then tell the filter how much arrived */
@@ -129,11 +153,16 @@ int main(int argc, char **argv) {
   }
   for (int i = 0; i < Nch; i++) pthread_join(th[i], NULL);
   pthread_join(clk, NULL);
+  if (Real_on) pthread_join(rth, NULL);
   clock_gettime(CLOCK_MONOTONIC, &ts1);
   double elapsed = (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
 
   snprintf(path, sizeof path, "%s/out.bin", argv[1]);
   f = fopen(path, "wb"); fwrite(Result, sizeof *Result, (size_t)Nblocks * Nch * Olen, f); fclose(f);
+  if (Real_on) {
+    snprintf(path, sizeof path, "%s/real.bin", argv[1]);
+    f = fopen(path, "wb"); fwrite(Real_result, sizeof *Real_result, (size_t)Nblocks * Olen, f); fclose(f);
+  }
   snprintf(path, sizeof path, "%s/spec.bin", argv[1]);   /* host-visible spectrum of the last block (estimate_noise reads it) */
   f = fopen(path, "wb"); fwrite(Master.fdomain[(Nblocks - 1) % ND], sizeof(float complex), (size_t)Master.bins, f); fclose(f);
   snprintf(path, sizeof path, "%s/meta.txt", argv[1]);

@@ -127,6 +127,25 @@ int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, in
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
 }
 
+// REAL-output slaves: out = [nch][olen] floats
+int emu_channels_real(const float* spec, int m_bins, int in_type, int P, int olen, int nch,
+                      const float* resp, const int* shifts, float* out, int lay_na, int lay_pitch, int lay_off) {
+  ChanGeom g;
+  if (!build_chan_geom(P, g)) return -1;
+  SpecLayout lay{lay_na > 0 ? lay_na : m_bins, lay_na > 0 ? lay_pitch : m_bins, lay_na > 0 ? lay_off : 0};
+  std::vector<float2> spec_dev((size_t)((long)(m_bins / lay.na + 2) * lay.pitch + 16), make_float2(0.f, 0.f));
+  for (long k = 0; k < m_bins; k++) spec_dev[(size_t)spec_addr(lay, k)] = reinterpret_cast<const float2*>(spec)[k];
+  ChanParams c{};
+  c.spec = spec_dev.data(); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
+  c.resp = reinterpret_cast<const float2*>(resp);
+  c.shifts = shifts; c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL;
+  c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
+  c.tw_sub = F2(g.tw_sub);
+  const int per_block = g.wpb * g.cpw;
+  const int grid = (nch + per_block - 1) / per_block;
+  return launch_chan_real(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
+}
+
 // --- estimate_noise() kernel ------------------------------------------------------------------------
 int emu_noise(const float* spec, int m_bins, int in_type, int s_bins, int nch, const int* shifts, double samprate, double* n0,
               int lay_na, int lay_pitch, int lay_off) {

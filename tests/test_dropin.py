@@ -62,7 +62,7 @@ def test_caller_compiled_against_reference_header_links(tmp_path):
     _build_harness(str(tmp_path / "h_abi"), ref_header=False)     # also checks the _Static_assert layout pins
 
 
-def _run_harness(tmp, L, M, in_type, olen, plan, nblocks, chunk, x):
+def _run_harness(tmp, L, M, in_type, olen, plan, nblocks, chunk, x, env=None):
     """plan rows: (shift, shift2, retune_block, refilter_block, low, high, beta, low2, high2)"""
     exe = os.path.join(tmp, "harness")
     _build_harness(exe)
@@ -71,7 +71,7 @@ def _run_harness(tmp, L, M, in_type, olen, plan, nblocks, chunk, x):
         for p in plan:
             f.write(struct.pack("iiiiddddd", *p))
     x.tofile(os.path.join(tmp, "in.bin"))
-    r = subprocess.run([exe, tmp], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, tmp], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr[-2000:]
     out = np.fromfile(os.path.join(tmp, "out.bin"), np.complex64).reshape(nblocks, len(plan), olen)
     spec = np.fromfile(os.path.join(tmp, "spec.bin"), np.complex64)
@@ -142,3 +142,33 @@ def test_dropin_radiod_style_config3():
         out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 16384, x)
     sub = list(range(0, 1024, 41)) + [1023]
     _check(L, M, olen, P, [plan[i] for i in sub], nblocks, out[:, sub], spec, meta, x)
+
+
+@pytest.mark.gpu
+def test_dropin_real_output_slave():
+    """create_filter_output(.., REAL) through the drop-in (src/filter.c:372-395 buffers, :803-809 gather, c2r): the kind of
+    slave wfm's composite filters use, next to ordinary COMPLEX slaves on the same master."""
+    _build_lib(); ol.build()
+    L, M, olen, P = 7680, 1921, 960, 1200          # wfm's composite geometry: 384 kHz real, 48 kHz audio
+    N = L + M - 1
+    nblocks = 5
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(nblocks * L).astype(np.float32)
+    plan = [(300, 300, 10 ** 6, 10 ** 6, -0.2, 0.2, 7.0, -0.2, 0.2), (-900, -900, 10 ** 6, 10 ** 6, 0.05, 0.3, 7.0, 0.05, 0.3)]
+    shift, lo, hi, beta = 0, 0.0, 15000.0 / 48000.0, 3.5            # the mono audio filter of src/wfm.c
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x,
+                                       env={"HARNESS_REAL": "%d %r %r %r" % (shift, lo, hi, beta)})
+        real = np.fromfile(os.path.join(tmp, "real.bin"), np.float32).reshape(nblocks, olen)
+    assert meta["drops"] == "0"
+    st = ol.Stream(L, M, ol.REAL)
+    state = np.zeros(2)
+    resp = ol.set_filter(P, olen, N, True, lo, hi, beta, out_type=ol.REAL)
+    for b in range(nblocks):
+        s = st.push(x[b * L:(b + 1) * L])
+        ol.notch(state, [0], 0.01, s)
+        want = ol.channel(s, ol.REAL, P, olen, shift, resp, out_type=ol.REAL)
+        assert np.linalg.norm(real[b] - want) <= 1e-5 * np.linalg.norm(want), b
+        for i, p in enumerate(plan):
+            wc = ol.channel(s, ol.REAL, P, olen, p[0], ol.set_filter(P, olen, N, True, p[4], p[5], p[6]))
+            assert np.linalg.norm(out[b, i] - wc) <= 1e-5 * np.linalg.norm(wc)

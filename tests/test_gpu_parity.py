@@ -661,3 +661,48 @@ def test_staged_output_path_is_bit_identical(pkg, monkeypatch):
         eng.close()
     for a, c in zip(outs["0"], outs["1"]):
         assert np.array_equal(a, c) and np.abs(a).max() > 0
+
+
+# ------------------------------------------------------------------------------
+# REAL-output slaves (src/filter.c:372-395, gather :794-809, c2r :914)
+# ------------------------------------------------------------------------------
+@pytest.mark.parametrize("in_type,L,M,P,olen", [(2, 7680, 1921, 1200, 960), (2, 25920, 6481, 300, 240), (1, 11520, 2881, 600, 480),
+                                                (2, 2592000, 648001, 1200, 960)])
+def test_real_output_slaves(pkg, in_type, L, M, P, olen):
+    fa = pkg.filterapi
+    rng = np.random.default_rng(P + L)
+    master = fa.create_filter_input(L, M, in_type)
+    N = L + M - 1
+    B = N // 2 + 1 if in_type == ol.REAL else N
+    st = ol.Stream(L, M, in_type)
+    plan = [(0, 0.0, 0.31), (17, 0.02, 0.4), (-5, 0.1, 0.1), (B - P // 4, 0.0, 0.45), (B // 3, 0.2, 0.05), (-(B // 3), 0.0, 0.5)]
+    slaves = []
+    try:
+        for sh, lo, hi in plan:
+            s = fa.create_filter_output(master, olen, fa.REAL)
+            assert s is not None and s.bins == P // 2 + 1 and s.points == P
+            assert fa.set_filter(s, lo, hi, 5.0) == 0
+            ref = ol.set_filter(P, olen, N, in_type == ol.REAL, lo, hi, 5.0, out_type=ol.REAL)
+            assert np.abs(s.response - ref).max() <= 3e-7 * np.abs(ref).max()
+            slaves.append(s)
+        cplx = fa.create_filter_output(master, olen, fa.COMPLEX)        # a COMPLEX slave of the same size shares the master
+        fa.set_filter(cplx, -0.3, 0.3, 5.0)
+        for blk in range(3):
+            if in_type == ol.REAL:
+                x = rng.standard_normal(L).astype(np.float32); fa.write_rfilter(master, x)
+            else:
+                x = (rng.standard_normal(L) + 1j * rng.standard_normal(L)).astype(np.complex64); fa.write_cfilter(master, x)
+            spec = st.push(x)
+            for s, (sh, lo, hi) in zip(slaves, plan):
+                assert fa.execute_filter_output(s, sh) == 0
+                assert s.output.dtype == np.float32 and s.output.shape == (olen,)
+                want = ol.channel(spec, in_type, P, olen, sh, s.response, out_type=ol.REAL)
+                nrm = float(np.linalg.norm(want))
+                if nrm == 0:
+                    assert not s.output.any()
+                else:
+                    assert np.linalg.norm(s.output - want) <= 1e-5 * nrm + 2e-8 * float(np.abs(spec).max()) * float(np.linalg.norm(s.response)) * np.sqrt(olen)
+            assert fa.execute_filter_output(cplx, 40) == 0
+            check_channel(cplx.output, ol.channel(spec.astype(np.complex128), in_type, P, olen, 40, cplx.response))
+    finally:
+        fa.delete_filter_input(master)

@@ -33,6 +33,7 @@ def emu(oracle_built):
     lib.emu_channels.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.emu_forward_i16.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_char_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.emu_channels_real.argtypes = lib.emu_channels.argtypes
     lib.emu_noise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.emu_fine_create.restype = C.c_void_p
     lib.emu_fine_create.argtypes = [C.c_int]
@@ -211,3 +212,26 @@ def test_noise_estimate_kernel(emu, in_type, B, s_bins, lay):
     want = np.array([ol.estimate_noise(spec, in_type, s_bins, int(s), 1.296e6) for s in shifts])
     assert np.all(want > 0)
     assert np.allclose(n0, want, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("in_type,B", [(ol.REAL, 4801), (ol.COMPLEX, 6000), (ol.COMPLEX, 6001)])
+@pytest.mark.parametrize("P,olen", [(1200, 960), (300, 240), (20, 16), (600, 480)])
+def test_real_output_channel_kernel(emu, in_type, B, P, olen):
+    """REAL-output slaves (create_filter_output(.., REAL): src/filter.c:794-809 gather, bin (bins+1)/2 zeroed, c2r):
+    wfm's composite filters.  Kernel against the restatement, REAL and COMPLEX masters, shifts in and out of range."""
+    rng = np.random.default_rng(B + P)
+    spec = (rng.standard_normal(B) + 1j * rng.standard_normal(B)).astype(np.complex64)
+    shifts = [0, 1, -1, 7, -7, B - P // 2, B - 3, B + 5, -(B // 2), B // 2 - P // 4, -P // 4, P] + [int(s) for s in rng.integers(-B, B, 8)]
+    nch = len(shifts)
+    resp = (rng.standard_normal((nch, P)) + 1j * rng.standard_normal((nch, P))).astype(np.complex64)
+    sh = np.array(shifts, np.int32)
+    out = np.zeros((nch, olen), np.float32)
+    lay = (0, 0, 0) if B % 2 == 0 else (75, 80, 2)
+    assert emu.emu_channels_real(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, out.ctypes.data, *lay) == 0
+    for i, s in enumerate(shifts):
+        want = ol.channel(spec, in_type, P, olen, s, resp[i], out_type=ol.REAL)
+        nrm = np.linalg.norm(want)
+        if nrm == 0:
+            assert not out[i].any()
+        else:
+            assert rel(out[i], want) < 1e-6, (s, i)
