@@ -115,6 +115,9 @@ int chz_bank_create_real(chz_engine *e, int P, int olen, int capacity);
 int chz_bank_set_responses(chz_engine *e, int bank, int ch0, int n, const float *resp);
 /* `shift` of execute_filter_output(slave, shift) (src/filter.c:663) */
 int chz_bank_set_shifts(chz_engine *e, int bank, int ch0, int n, const int *shifts);
+/* slave->isb (src/filter.c:895-909, filter2 of the linear demodulator in ISB mode): LSB and USB are unpacked to I and Q
+ * after the gather.  One flag byte per channel, non-zero = on.  COMPLEX-output banks only. */
+int chz_bank_set_isb(chz_engine *e, int bank, int ch0, int n, const unsigned char *flags);
 int chz_bank_set_active(chz_engine *e, int bank, int n);                    /* channels [0,n) run */
 /* replaces execute_filter_output's gather x response + backward transform
  * (src/filter.c:728-914) for every active channel of the bank at once */

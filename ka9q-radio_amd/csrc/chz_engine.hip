@@ -45,6 +45,7 @@ struct Bank {
   int* shifts = nullptr;        // [cap] the channels' bin shifts
   double* n0 = nullptr;         // [ND][cap]
   double noise_samprate = 0.0;  // front-end sample rate; 0 = off
+  unsigned char* isb = nullptr; // [cap] slave->isb flags (src/filter.c:895-909); allocated by chz_bank_set_isb
 };
 
 // A lane = one HIP stream + its own intermediate buffer.  Consecutive blocks go to
@@ -182,7 +183,7 @@ void chz_engine_destroy(chz_engine* e) {
   if (e->input_ready) hipEventDestroy(e->input_ready);
   for (auto& b : e->banks) {
     hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub);
-    hipFree(b.fine); hipFree(b.power); hipFree(b.shifts); hipFree(b.n0);
+    hipFree(b.fine); hipFree(b.power); hipFree(b.shifts); hipFree(b.n0); hipFree(b.isb);
   }
   hipFree(e->ring); hipFree(e->ring16); hipFree(e->energy_part); hipFree(e->clip_part);
   for (int i = 0; i < CHZ_ND; i++) if (e->spec_owned[i]) hipFree(e->spec[i]);
@@ -413,6 +414,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc; c.out = bank_out(b, slot); c.ch0 = ch0; c.nch = n; c.olen = b.olen;
   c.tw_sub = b.tw_sub;
   c.stage = e->chan_stage >= 0 ? e->chan_stage : (n >= 16384);
+  c.isb = b.isb;
   c.fine = b.fine; c.power = b.power ? b.power + (size_t)slot * b.cap : nullptr; c.job = job;
   const int per_block = b.g.wpb * b.g.cpw;
   const int grid = (n + per_block - 1) / per_block;
@@ -678,6 +680,27 @@ int chz_bank_read_power_async(chz_engine* e, int bank, int slot, int ch0, int n,
   HIPOK(hipMemcpyAsync(host, b.power + (size_t)slot * b.cap + ch0, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, slot_stream(e, slot)));
   return 0;
 }
+// slave->isb (src/filter.c:895-909): unpack LSB/USB to I/Q after the gather; flags != 0 switch it on per channel
+int chz_bank_set_isb(chz_engine* e, int bank, int ch0, int n, const unsigned char* flags) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (!flags) return fail(-1, "null argument");
+  Bank& b = e->banks[(size_t)bank];
+  if (b.out_real) return fail(-1, "ISB unpacking applies to COMPLEX-output banks");
+  HIPOK(hipSetDevice(e->device));
+  { int r = sync_all(e); if (r) return r; }
+  if (!b.isb) {
+    bool any = false;
+    for (int i = 0; i < n; i++) any = any || flags[i] != 0;
+    if (!any) return 0;                          // nothing to switch on: keep the plain kernel variant
+    HIPOK(hipMalloc((void**)&b.isb, (size_t)b.cap));
+    HIPOK(hipMemset(b.isb, 0, (size_t)b.cap));
+    HIPOK(hipDeviceSynchronize());
+    drop_graph(e);
+  }
+  HIPOK(hipMemcpyAsync(b.isb + ch0, flags, (size_t)n, hipMemcpyHostToDevice, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  return 0;
+}
 int chz_bank_set_active(chz_engine* e, int bank, int n) {
   BANK_CHECK(e, bank, 0, n);
   if (e->banks[(size_t)bank].active != n) drop_graph(e);
@@ -706,7 +729,7 @@ int chz_bank_destroy(chz_engine* e, int bank) {
   { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
   hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); hipFree(b.fine); hipFree(b.power);
-  hipFree(b.shifts); hipFree(b.n0); b.shifts = nullptr; b.n0 = nullptr; b.noise_samprate = 0.0;
+  hipFree(b.shifts); hipFree(b.n0); hipFree(b.isb); b.shifts = nullptr; b.n0 = nullptr; b.isb = nullptr; b.noise_samprate = 0.0;
   b.resp = nullptr; b.desc = nullptr; b.out = nullptr; b.tw_sub = nullptr; b.fine = nullptr; b.power = nullptr;
   b.fine_h.clear(); b.active = 0; b.cap = 0;
   return 0;

@@ -188,6 +188,7 @@ struct ChanParams {
   const int* shifts;      // [nch]
   int m_bins, m_real;     // master bins; master is REAL (else COMPLEX)
   int stage;              // 1: output rows leave through LDS as full-line stores (throughput); 0: straight from the lanes (latency)
+  const unsigned char* isb; // [nch] or nullptr: per-channel slave->isb flags (EPI variant only)
   const FineDesc* fine;   // [nch] or nullptr: plain execute_filter_output semantics
   double* power;          // [nch] mean |sample|^2 of the block after rotation (chan->sig.bb_power, :1516-1520)
   unsigned job;
@@ -552,13 +553,15 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
   float2* my = lds + ((wave * CPW + (cw < CPW ? cw : 0)) * (R1 * LDC));
   const float2* __restrict__ tws = p.tw_sub;
 
-  if (live && jl < R2) {
+  float2 v[R1];
+  const bool act1 = live && jl < R2;
+  if (act1) {
     const ChanDesc d = p.desc[ch];
     const float2* __restrict__ H = p.resp + (long)ch * P;
     const float2* __restrict__ X = p.spec;
     // All 2*R1 loads are issued unconditionally (out-of-range bins read bin 0 and are
     // zeroed afterwards) so they overlap instead of costing one round trip per bin.
-    float2 v[R1], h[R1];
+    float2 h[R1];
     bool ok[R1];
     static_for<R1>([&](auto q) {
       constexpr int Q = decltype(q)::value;
@@ -582,6 +585,37 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
       x = cmul(x, h[Q]);
       v[Q] = ok[Q] ? x : make_float2(0.f, 0.f);
     });
+  }
+  if constexpr (EPI) {
+    // ISB mode (slave->isb, src/filter.c:895-909, filter2 of the linear demodulator): LSB and USB are unpacked to
+    // I and Q -- Y[p] += conj(Y[P-p]), Y[P-p] -= conj(Y[p]) for 0 < p < P/2, Y[0] = 0.  Bin P-i of lane jl, register Q
+    // sits in lane R2-jl, register R1-1-Q (lane 0: its own register R1-Q): one cross-lane fetch per register.
+    if (p.isb != nullptr) {                                // wave-uniform
+      const bool mine = act1 && p.isb[ch] != 0;
+      const int src_lane = (cw < CPW ? cw : 0) * LPC + (jl == 0 || jl >= R2 ? 0 : R2 - jl);
+      float2 part2[R1];
+      static_for<R1>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        const float2 mine_v = act1 ? v[R1 - 1 - Q] : make_float2(0.f, 0.f);
+        part2[Q] = make_float2(__shfl(mine_v.x, src_lane), __shfl(mine_v.y, src_lane));
+      });
+      if (mine) {
+        float2 orig[R1];
+        static_for<R1>([&](auto q) { constexpr int Q = decltype(q)::value; orig[Q] = v[Q]; });
+        static_for<R1>([&](auto q) {
+          constexpr int Q = decltype(q)::value;
+          const int i = jl + Q * R2;
+          float2 partner = part2[Q];                       // Y[P-i] for jl >= 1
+          if (jl == 0) { if constexpr (Q >= 1) partner = orig[R1 - Q]; else partner = make_float2(0.f, 0.f); }
+          if (i == 0) v[Q] = make_float2(0.f, 0.f);
+          else if (2 * i < P) v[Q] = make_float2(orig[Q].x + partner.x, orig[Q].y - partner.y);        // pos + conj(neg)
+          else if (2 * i > P) v[Q] = make_float2(orig[Q].x - partner.x, orig[Q].y + partner.y);        // neg - conj(pos)
+          if (i == (P + 1) / 2) v[Q] = make_float2(0.f, 0.f);                                          // :911 comes after the unpack
+        });
+      }
+    }
+  }
+  if (act1) {
     reg_dft<R1, +1>(v);
     static_for<R1>([&](auto k1) {
       constexpr int K1 = decltype(k1)::value;

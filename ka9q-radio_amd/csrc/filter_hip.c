@@ -60,6 +60,7 @@ struct hbank {
   bool real;                        /* REAL-output slaves: olen floats per channel (else olen float complex) */
   struct filter_out **slaves;       /* [cap] */
   int *shift;                       /* [cap] shift the device descriptor currently holds */
+  unsigned char *isb;               /* [cap] slave->isb as the device currently holds it */
   void *stage[ND];                  /* pinned [cap][olen] samples: staged outputs per job slot */
   int *stage_shift[ND];             /* [cap] shift each staged output was computed with */
   unsigned *stage_epoch[ND];        /* [cap] response epoch it was computed with (0 = invalid) */
@@ -223,13 +224,14 @@ static size_t bank_sample_bytes(const struct hbank *b) { return b->real ? sizeof
 static int bank_create_dev(struct mctx *c, const struct hbank *b, int cap);
 static void bank_free_host(struct hbank *b) {
   for (int s = 0; s < ND; s++) { chz_host_free(b->stage[s]); b->stage[s] = NULL; FREE(b->stage_shift[s]); FREE(b->stage_epoch[s]); }
-  FREE(b->slaves); FREE(b->shift);
+  FREE(b->slaves); FREE(b->shift); FREE(b->isb);
 }
 static int bank_alloc_host(struct hbank *b, int cap) {
   b->cap = cap;
   b->slaves = calloc((size_t)cap, sizeof *b->slaves);
   b->shift = calloc((size_t)cap, sizeof *b->shift);
-  if (!b->slaves || !b->shift) return -1;
+  b->isb = calloc((size_t)cap, 1);
+  if (!b->slaves || !b->shift || !b->isb) return -1;
   for (int s = 0; s < ND; s++) {
     void *p = NULL;
     if (chz_host_alloc(&p, bank_sample_bytes(b) * (size_t)cap * b->olen) != 0) return -1;
@@ -255,10 +257,11 @@ static int bank_for(struct mctx *c, int P, int olen, bool real) {
     nb.id = bank_create_dev(c, &nb, b->cap * 2);
     if (nb.id < 0 || bank_alloc_host(&nb, b->cap * 2) != 0) { fprintf(stderr, "filter_hip: cannot grow bank: %s\n", chz_last_error()); return -1; }
     for (int k = 0; k < b->n; k++) {
-      nb.slaves[k] = b->slaves[k]; nb.shift[k] = b->shift[k];
+      nb.slaves[k] = b->slaves[k]; nb.shift[k] = b->shift[k]; nb.isb[k] = b->isb[k];
       if (nb.slaves[k]->response) chz_bank_set_responses(c->eng, nb.id, k, 1, (const float *)nb.slaves[k]->response);
     }
     chz_bank_set_shifts(c->eng, nb.id, 0, nb.n, nb.shift);
+    if (!real) chz_bank_set_isb(c->eng, nb.id, 0, nb.n, nb.isb);
     chz_bank_destroy(c->eng, b->id);
     bank_free_host(b);
     *b = nb;
@@ -447,6 +450,7 @@ int delete_filter_output(struct filter_out *slave) {
       struct sctx *ms = SCTX(mv);
       b->slaves[sc->idx] = mv; ms->idx = sc->idx; ms->epoch++;
       b->shift[sc->idx] = b->shift[last];
+      if (!b->real && b->isb[sc->idx] != b->isb[last]) { b->isb[sc->idx] = b->isb[last]; chz_bank_set_isb(c->eng, b->id, sc->idx, 1, &b->isb[sc->idx]); }
       if (mv->response) chz_bank_set_responses(c->eng, b->id, ms->idx, 1, (const float *)mv->response);
       chz_bank_set_shifts(c->eng, b->id, ms->idx, 1, &b->shift[ms->idx]);
       for (int s = 0; s < ND; s++) b->stage_epoch[s][ms->idx] = 0;
@@ -519,6 +523,14 @@ int execute_filter_input(struct filter_in *const f) {
     }
     pthread_rwlock_unlock(&c->stage_lock);
     if (b->n == 0) continue;
+    if (!b->real) {                 /* callers flip slave->isb directly (src/radio.c:1586, src/radio_status.c:326) */
+      bool changed = false;
+      for (int k = 0; k < b->n; k++) {
+        unsigned char f = b->slaves[k]->isb ? 1 : 0;
+        if (f != b->isb[k]) { b->isb[k] = f; changed = true; }
+      }
+      if (changed) chz_bank_set_isb(c->eng, b->id, 0, b->n, b->isb);
+    }
     chz_bank_set_active(c->eng, b->id, b->n);
     rc = chz_bank_execute(c->eng, b->id, slot);
     if (rc == 0) rc = chz_bank_read_async(c->eng, b->id, slot, 0, b->n, (float *)b->stage[slot]);
@@ -604,7 +616,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
     struct hbank *b = &c->banks[sc->bank];
     int const k = sc->idx;
     if (b->stage_job[slot] == job && k < b->stage_n[slot] && b->stage_shift[slot][k] == shift &&
-        b->stage_epoch[slot][k] == sc->epoch) {
+        b->stage_epoch[slot][k] == sc->epoch && (b->real || b->isb[k] == (slave->isb ? 1 : 0))) {
       /* the speculative batch already computed exactly this */
       memcpy(dst, (char *)b->stage[slot] + (size_t)k * b->olen * bank_sample_bytes(b), bank_sample_bytes(b) * (size_t)b->olen);
       hit = true;
@@ -619,6 +631,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
   struct hbank *b = &c->banks[sc->bank];
   int const k = sc->idx;
   if (b->shift[k] != shift) { b->shift[k] = shift; rc = chz_bank_set_shifts(c->eng, b->id, k, 1, &b->shift[k]); }
+  if (rc == 0 && !b->real && b->isb[k] != (slave->isb ? 1 : 0)) { b->isb[k] = slave->isb ? 1 : 0; rc = chz_bank_set_isb(c->eng, b->id, k, 1, &b->isb[k]); }
   if (rc == 0) rc = chz_bank_execute_range(c->eng, b->id, slot, k, 1);
   if (rc == 0) rc = chz_bank_read(c->eng, b->id, k, 1, (float *)dst);
   if (rc != 0) fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());

@@ -40,7 +40,7 @@ SYMBOLS = [
     "chz_bank_output_device", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
     "chz_bank_set_tuning", "chz_bank_read_power", "chz_bank_read_power_async",
     "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
-    "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real",
+    "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real", "chz_bank_set_isb",
 ]
 
 _lib = None
@@ -75,6 +75,7 @@ def lib():
         L.chz_spectrum_attach.argtypes = [_vp, _i, _vp]
         L.chz_bank_create.argtypes = [_vp, _i, _i, _i]
         L.chz_bank_create_real.argtypes = [_vp, _i, _i, _i]
+        L.chz_bank_set_isb.argtypes = [_vp, _i, _i, _i, _vp]
         L.chz_bank_set_responses.argtypes = [_vp, _i, _i, _i, _vp]
         L.chz_bank_set_shifts.argtypes = [_vp, _i, _i, _i, _vp]
         L.chz_bank_set_active.argtypes = [_vp, _i, _i]
@@ -235,6 +236,11 @@ class Bank:
     def set_shifts(self, ch0, shifts):
         shifts = np.ascontiguousarray(shifts, np.int32).reshape(-1)
         _check(lib().chz_bank_set_shifts(self.eng._h, self.id, ch0, shifts.shape[0], shifts.ctypes.data))
+
+    def set_isb(self, ch0, flags):
+        """slave->isb per channel (src/filter.c:895-909)."""
+        f = np.ascontiguousarray(flags, np.uint8).reshape(-1)
+        _check(lib().chz_bank_set_isb(self.eng._h, self.id, ch0, f.shape[0], f.ctypes.data))
 
     def set_active(self, n):
         _check(lib().chz_bank_set_active(self.eng._h, self.id, n))

@@ -108,6 +108,7 @@ class _BankState:
         self.result_job = None
         self.results = None
         self.dirty_shifts = True
+        self.isb = np.zeros(bank.capacity, np.uint8)          # slave->isb flags as uploaded
 
 
 def create_filter_input(L, M, in_type, device=0, plan="", master=None):
@@ -237,6 +238,9 @@ def create_filter_output(master, olen, out_type, slave=None):
                     if old.response is not None:
                         new.bank.set_responses(old._index, old.response)
                 new.shifts[:len(st.slaves)] = st.shifts[:len(st.slaves)]
+                new.isb[:len(st.slaves)] = st.isb[:len(st.slaves)]
+                if new.isb.any():
+                    new.bank.set_isb(0, new.isb[:len(st.slaves)])
             master._banks[key] = st = new
         s._bank, s._index = st, len(st.slaves)
         st.slaves.append(s)
@@ -267,6 +271,9 @@ def delete_filter_output(slave):
                 st.bank.set_responses(idx, last.response)
             st.shifts[idx] = st.shifts[len(st.slaves) - 1]
             st.dirty_shifts = True
+            st.isb[idx] = st.isb[len(st.slaves) - 1]
+            if st.isb.any():
+                st.bank.set_isb(0, st.isb[:len(st.slaves)])
         st.slaves.pop()
         st.bank.set_active(len(st.slaves))
         st.result_job = None
@@ -328,6 +335,10 @@ def execute_filter_output(slave, shift):
     if st.shifts[slave._index] != shift:
         st.shifts[slave._index] = shift
         st.dirty_shifts = True
+        st.result_job = None
+    if slave.out_type == COMPLEX and bool(getattr(slave, "isb", False)) != bool(st.isb[slave._index]):   # callers set slave->isb directly (src/radio.c:1586)
+        st.isb[slave._index] = 1 if slave.isb else 0
+        st.bank.set_isb(0, st.isb[:len(st.slaves)])
         st.result_job = None
     if st.result_job != job:
         if st.dirty_shifts:

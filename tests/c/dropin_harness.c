@@ -44,6 +44,7 @@ static void *channel_thread(void *a) {
   memset(&out, 0, sizeof out);
   if (create_filter_output(&out, &Master, Olen, COMPLEX) != 0) { fprintf(stderr, "create_filter_output failed\n"); exit(2); }
   if (set_filter(&out, Plan[i].low, Plan[i].high, Plan[i].beta) != 0) { fprintf(stderr, "set_filter failed\n"); exit(2); }
+  if (getenv("HARNESS_ISB") && atoi(getenv("HARNESS_ISB")) == i) out.isb = true;   /* set by the caller after create (src/radio.c:1586) */
   atomic_store(&Progress[i], 0);       /* registered: the producer may start */
   for (int b = 0; b < Nblocks; b++) {
     if (b == Plan[i].refilter_block) set_filter(&out, Plan[i].low2, Plan[i].high2, Plan[i].beta);

@@ -127,6 +127,27 @@ int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, in
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
 }
 
+// COMPLEX slaves with per-channel ISB flags (src/filter.c:895-909)
+int emu_channels_isb(const float* spec, int m_bins, int in_type, int P, int olen, int nch,
+                     const float* resp, const int* shifts, const unsigned char* isb, float* out) {
+  ChanGeom g;
+  if (!build_chan_geom(P, g)) return -1;
+  SpecLayout lay{m_bins, m_bins, 0};
+  std::vector<ChanDesc> desc((size_t)nch);
+  for (int i = 0; i < nch; i++) {
+    ChanDescH h = make_chan_desc(in_type, m_bins, P, shifts[i]);
+    desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
+  }
+  ChanParams c{};
+  c.spec = reinterpret_cast<const float2*>(spec); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
+  c.resp = reinterpret_cast<const float2*>(resp);
+  c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
+  c.tw_sub = F2(g.tw_sub); c.isb = isb;
+  const int per_block = g.wpb * g.cpw;
+  const int grid = (nch + per_block - 1) / per_block;
+  return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
+}
+
 // REAL-output slaves: out = [nch][olen] floats
 int emu_channels_real(const float* spec, int m_bins, int in_type, int P, int olen, int nch,
                       const float* resp, const int* shifts, float* out, int lay_na, int lay_pitch, int lay_off) {

@@ -172,3 +172,29 @@ def test_dropin_real_output_slave():
         for i, p in enumerate(plan):
             wc = ol.channel(s, ol.REAL, P, olen, p[0], ol.set_filter(P, olen, N, True, p[4], p[5], p[6]))
             assert np.linalg.norm(out[b, i] - wc) <= 1e-5 * np.linalg.norm(wc)
+
+
+@pytest.mark.gpu
+def test_dropin_isb_slave():
+    """A caller sets slave->isb after create_filter_output (src/radio.c:1586): the drop-in picks the flag up per block."""
+    _build_lib(); ol.build()
+    L, M, olen, P = 25920, 6481, 240, 300
+    N = L + M - 1
+    nblocks = 4
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal(nblocks * L).astype(np.float32)
+    plan = [(1500, 1500, 10 ** 6, 10 ** 6, -0.4, 0.4, 9.0, -0.4, 0.4), (1500, 1500, 10 ** 6, 10 ** 6, -0.4, 0.4, 9.0, -0.4, 0.4),
+            (-7000, -7000, 10 ** 6, 10 ** 6, -0.2, 0.3, 9.0, -0.2, 0.3)]
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 8192, x, env={"HARNESS_ISB": "1"})
+    assert meta["drops"] == "0"
+    st = ol.Stream(L, M, ol.REAL)
+    state = np.zeros(2)
+    for b in range(nblocks):
+        s = st.push(x[b * L:(b + 1) * L])
+        ol.notch(state, [0], 0.01, s)
+        for i, p in enumerate(plan):
+            resp = ol.set_filter(P, olen, N, True, p[4], p[5], p[6])
+            want = ol.channel(s, ol.REAL, P, olen, p[0], resp, isb=(i == 1))
+            assert np.linalg.norm(out[b, i] - want) <= 2e-5 * np.linalg.norm(want), (b, i)
+    assert not np.allclose(out[:, 0], out[:, 1])       # same tuning and filter, only the flag differs

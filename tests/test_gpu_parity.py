@@ -706,3 +706,30 @@ def test_real_output_slaves(pkg, in_type, L, M, P, olen):
             check_channel(cplx.output, ol.channel(spec.astype(np.complex128), in_type, P, olen, 40, cplx.response))
     finally:
         fa.delete_filter_input(master)
+
+
+def test_isb_slaves(pkg):
+    # slave->isb set by the caller after create (src/radio.c:1586): LSB/USB unpacked to I/Q (src/filter.c:895-909)
+    L, M, P, olen = 25920, 6481, 300, 240
+    fa = pkg.filterapi
+    rng = np.random.default_rng(77)
+    master = fa.create_filter_input(L, M, fa.REAL)
+    st = ol.Stream(L, M, ol.REAL)
+    slaves = [fa.create_filter_output(master, olen, fa.COMPLEX) for _ in range(5)]
+    shifts = [1200, -3000, 40, 9000, 1200]
+    try:
+        for s in slaves:
+            fa.set_filter(s, -0.45, 0.45, 9.0)
+        for blk in range(4):
+            x = rng.standard_normal(L).astype(np.float32)
+            fa.write_rfilter(master, x)
+            spec64 = st.push(x, f64=True)
+            spec32 = spec64.astype(np.complex64)
+            for i, (s, sh) in enumerate(zip(slaves, shifts)):
+                s.isb = (i != 4) and (blk != 2 or i != 0)          # flags flip between blocks; one channel stays plain
+                assert fa.execute_filter_output(s, sh) == 0
+                want = ol.channel(spec32, ol.REAL, P, olen, sh, s.response, isb=bool(s.isb))
+                assert np.linalg.norm(s.output - want) <= 1e-5 * np.linalg.norm(want) + noise_floor(spec64, s.response) * np.sqrt(olen) * 2, (blk, i)
+            assert not np.array_equal(slaves[1].output, slaves[4].output)
+    finally:
+        fa.delete_filter_input(master)

@@ -34,6 +34,7 @@ def emu(oracle_built):
     lib.emu_forward_i16.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_char_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emu_channels_real.argtypes = lib.emu_channels.argtypes
+    lib.emu_channels_isb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emu_noise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.emu_fine_create.restype = C.c_void_p
     lib.emu_fine_create.argtypes = [C.c_int]
@@ -235,3 +236,26 @@ def test_real_output_channel_kernel(emu, in_type, B, P, olen):
             assert not out[i].any()
         else:
             assert rel(out[i], want) < 1e-6, (s, i)
+
+
+@pytest.mark.parametrize("in_type,B", [(ol.REAL, 4801), (ol.COMPLEX, 6000)])
+@pytest.mark.parametrize("P,olen", [(300, 240), (20, 16), (1200, 960), (600, 480)])
+def test_isb_unpack_in_channel_kernel(emu, in_type, B, P, olen):
+    """slave->isb (src/filter.c:895-909): LSB/USB unpacked to I/Q between gather and transform; mixed with plain channels
+    in one launch (the partner bin of every register comes from another lane of the channel)."""
+    rng = np.random.default_rng(B + P + 1)
+    spec = (rng.standard_normal(B) + 1j * rng.standard_normal(B)).astype(np.complex64)
+    shifts = [0, 5, -5, P, B // 3, -(B // 4), B - 3, 11]
+    flags = np.array([1, 1, 0, 1, 1, 1, 1, 0], np.uint8)
+    nch = len(shifts)
+    resp = (rng.standard_normal((nch, P)) + 1j * rng.standard_normal((nch, P))).astype(np.complex64)
+    sh = np.array(shifts, np.int32)
+    out = np.zeros((nch, olen), np.complex64)
+    assert emu.emu_channels_isb(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, flags.ctypes.data, out.ctypes.data) == 0
+    for i, s in enumerate(shifts):
+        want = ol.channel(spec, in_type, P, olen, s, resp[i], isb=bool(flags[i]))
+        nrm = np.linalg.norm(want)
+        if nrm == 0:
+            assert not out[i].any()
+        else:
+            assert rel(out[i], want) < 1e-6, (s, i, flags[i])
