@@ -118,6 +118,11 @@ int chz_bank_set_shifts(chz_engine *e, int bank, int ch0, int n, const int *shif
 /* slave->isb (src/filter.c:895-909, filter2 of the linear demodulator in ISB mode): LSB and USB are unpacked to I and Q
  * after the gather.  One flag byte per channel, non-zero = on.  COMPLEX-output banks only. */
 int chz_bank_set_isb(chz_engine *e, int bank, int ch0, int n, const unsigned char *flags);
+/* slave->beam (src/filter.c:756-775; set by radio.c:938-940): two antennas on I and Q of a COMPLEX master are selected or
+ * combined with the weights set_filter_weights left in slave->alpha / ->beta.  ab = 4 doubles per channel (Re alpha,
+ * Im alpha, Re beta, Im beta), on = one flag byte per channel.  Bins past the end of the master walk are zero (the
+ * reference leaves them unwritten). */
+int chz_bank_set_beam(chz_engine *e, int bank, int ch0, int n, const double *ab, const unsigned char *on);
 int chz_bank_set_active(chz_engine *e, int bank, int n);                    /* channels [0,n) run */
 /* replaces execute_filter_output's gather x response + backward transform
  * (src/filter.c:728-914) for every active channel of the bank at once */

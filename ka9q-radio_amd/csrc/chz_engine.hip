@@ -46,6 +46,7 @@ struct Bank {
   double* n0 = nullptr;         // [ND][cap]
   double noise_samprate = 0.0;  // front-end sample rate; 0 = off
   unsigned char* isb = nullptr; // [cap] slave->isb flags (src/filter.c:895-909); allocated by chz_bank_set_isb
+  BeamDesc* beam = nullptr;     // [cap] slave->beam + weights (src/filter.c:756-775); allocated by chz_bank_set_beam
 };
 
 // A lane = one HIP stream + its own intermediate buffer.  Consecutive blocks go to
@@ -183,7 +184,7 @@ void chz_engine_destroy(chz_engine* e) {
   if (e->input_ready) hipEventDestroy(e->input_ready);
   for (auto& b : e->banks) {
     hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub);
-    hipFree(b.fine); hipFree(b.power); hipFree(b.shifts); hipFree(b.n0); hipFree(b.isb);
+    hipFree(b.fine); hipFree(b.power); hipFree(b.shifts); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam);
   }
   hipFree(e->ring); hipFree(e->ring16); hipFree(e->energy_part); hipFree(e->clip_part);
   for (int i = 0; i < CHZ_ND; i++) if (e->spec_owned[i]) hipFree(e->spec[i]);
@@ -414,7 +415,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc; c.out = bank_out(b, slot); c.ch0 = ch0; c.nch = n; c.olen = b.olen;
   c.tw_sub = b.tw_sub;
   c.stage = e->chan_stage >= 0 ? e->chan_stage : (n >= 16384);
-  c.isb = b.isb;
+  c.isb = b.isb; c.beam = b.beam;
   c.fine = b.fine; c.power = b.power ? b.power + (size_t)slot * b.cap : nullptr; c.job = job;
   const int per_block = b.g.wpb * b.g.cpw;
   const int grid = (n + per_block - 1) / per_block;
@@ -701,6 +702,30 @@ int chz_bank_set_isb(chz_engine* e, int bank, int ch0, int n, const unsigned cha
   HIPOK(hipStreamSynchronize(e->stream));
   return 0;
 }
+// slave->beam with the weights set_filter_weights leaves in slave->alpha / ->beta (src/filter.c:756-775,922-929):
+// ab = 4 doubles per channel (Re alpha, Im alpha, Re beta, Im beta), on = one flag byte per channel
+int chz_bank_set_beam(chz_engine* e, int bank, int ch0, int n, const double* ab, const unsigned char* on) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (!ab || !on) return fail(-1, "null argument");
+  Bank& b = e->banks[(size_t)bank];
+  if (b.out_real || e->in_type != CHZ_COMPLEX) return fail(-1, "beam mode combines I and Q of a COMPLEX master into COMPLEX-output channels");
+  HIPOK(hipSetDevice(e->device));
+  { int r = sync_all(e); if (r) return r; }
+  if (!b.beam) {
+    bool any = false;
+    for (int i = 0; i < n; i++) any = any || on[i] != 0;
+    if (!any) return 0;
+    HIPOK(hipMalloc((void**)&b.beam, sizeof(BeamDesc) * (size_t)b.cap));
+    HIPOK(hipMemset(b.beam, 0, sizeof(BeamDesc) * (size_t)b.cap));
+    HIPOK(hipDeviceSynchronize());
+    drop_graph(e);
+  }
+  std::vector<BeamDesc> d((size_t)n);
+  for (int i = 0; i < n; i++) d[(size_t)i] = BeamDesc{ab[4 * i], ab[4 * i + 1], ab[4 * i + 2], ab[4 * i + 3], on[i] ? 1 : 0, 0};
+  HIPOK(hipMemcpyAsync(b.beam + ch0, d.data(), sizeof(BeamDesc) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  return 0;
+}
 int chz_bank_set_active(chz_engine* e, int bank, int n) {
   BANK_CHECK(e, bank, 0, n);
   if (e->banks[(size_t)bank].active != n) drop_graph(e);
@@ -729,7 +754,7 @@ int chz_bank_destroy(chz_engine* e, int bank) {
   { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
   hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); hipFree(b.fine); hipFree(b.power);
-  hipFree(b.shifts); hipFree(b.n0); hipFree(b.isb); b.shifts = nullptr; b.n0 = nullptr; b.isb = nullptr; b.noise_samprate = 0.0;
+  hipFree(b.shifts); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam); b.shifts = nullptr; b.n0 = nullptr; b.isb = nullptr; b.beam = nullptr; b.noise_samprate = 0.0;
   b.resp = nullptr; b.desc = nullptr; b.out = nullptr; b.tw_sub = nullptr; b.fine = nullptr; b.power = nullptr;
   b.fine_h.clear(); b.active = 0; b.cap = 0;
   return 0;

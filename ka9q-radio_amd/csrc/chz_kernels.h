@@ -183,12 +183,16 @@ struct ChanDesc { int t0, cnt, src0, dir, conj, wrap; };
 //   phase0     = everything accumulated before the base, including the shift-change kick (src/radio.c:1494).
 struct FineDesc { double phase0, freq, rate; unsigned job0; int adj_num, V, on; };
 
+// slave->beam (src/filter.c:756-775): Y = (alpha X[rp] + beta conj(X[m_bins-rp])) H, weights as set_filter_weights stores them
+struct BeamDesc { double ar, ai, br, bi; int on; int pad; };
+
 struct ChanParams {
   // REAL-output banks (chan_c2r) take the shift itself instead of a descriptor
   const int* shifts;      // [nch]
   int m_bins, m_real;     // master bins; master is REAL (else COMPLEX)
   int stage;              // 1: output rows leave through LDS as full-line stores (throughput); 0: straight from the lanes (latency)
   const unsigned char* isb; // [nch] or nullptr: per-channel slave->isb flags (EPI variant only)
+  const BeamDesc* beam;   // [nch] or nullptr: slave->beam with its weights (EPI variant only, COMPLEX masters)
   const FineDesc* fine;   // [nch] or nullptr: plain execute_filter_output semantics
   double* power;          // [nch] mean |sample|^2 of the block after rotation (chan->sig.bb_power, :1516-1520)
   unsigned job;
@@ -563,6 +567,7 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
     // zeroed afterwards) so they overlap instead of costing one round trip per bin.
     float2 h[R1];
     bool ok[R1];
+    int srcs[EPI ? R1 : 1];                               // master bin of each register (beam mode needs its mirror)
     static_for<R1>([&](auto q) {
       constexpr int Q = decltype(q)::value;
       const int i = jl + Q * R2;                           // FFT-order bin index
@@ -577,14 +582,50 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
       if (col < 0) { row--; col += p.lay.na; } else if (col >= p.lay.na) { row++; col -= p.lay.na; }
       v[Q] = X[(long)row * p.lay.pitch + p.lay.off + col];
       h[Q] = H[i];
+      if constexpr (EPI) srcs[Q] = src;
     });
-    static_for<R1>([&](auto q) {
-      constexpr int Q = decltype(q)::value;
-      float2 x = v[Q];
-      if (d.conj) x.y = -x.y;
-      x = cmul(x, h[Q]);
-      v[Q] = ok[Q] ? x : make_float2(0.f, 0.f);
-    });
+    bool beamed = false;
+    if constexpr (EPI) {
+      if (p.beam != nullptr) {                             // wave-uniform
+        const BeamDesc bd = p.beam[ch];
+        if (bd.on && d.wrap > 0) {                         // COMPLEX masters only (wrap = master bins)
+          beamed = true;
+          float2 w[R1];
+          static_for<R1>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            int mp = srcs[Q] == 0 ? 0 : d.wrap - srcs[Q];  // the mirror bin
+            int row = (int)((float)mp * p.inv_na), col = mp - row * p.lay.na;
+            if (col < 0) { row--; col += p.lay.na; } else if (col >= p.lay.na) { row++; col -= p.lay.na; }
+            w[Q] = X[(long)row * p.lay.pitch + p.lay.off + col];
+          });
+          static_for<R1>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            const double xr = v[Q].x, xi = v[Q].y, hr = h[Q].x, hi = h[Q].y;
+            double sr, si;
+            if (srcs[Q] == 0 || srcs[Q] == d.wrap / 2) {   // :766-768: Re X alpha H + Im X beta H
+              const double t1r = xr * bd.ar, t1i = xr * bd.ai, t2r = xi * bd.br, t2i = xi * bd.bi;
+              sr = (t1r * hr - t1i * hi) + (t2r * hr - t2i * hi);
+              si = (t1r * hi + t1i * hr) + (t2r * hi + t2i * hr);
+            } else {                                       // :770-771
+              const double yr = w[Q].x, yi = -(double)w[Q].y;
+              const double cr = (bd.ar * xr - bd.ai * xi) + (bd.br * yr - bd.bi * yi);
+              const double ci = (bd.ar * xi + bd.ai * xr) + (bd.br * yi + bd.bi * yr);
+              sr = cr * hr - ci * hi; si = cr * hi + ci * hr;
+            }
+            v[Q] = ok[Q] ? make_float2((float)sr, (float)si) : make_float2(0.f, 0.f);
+          });
+        }
+      }
+    }
+    if (!beamed) {
+      static_for<R1>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        float2 x = v[Q];
+        if (d.conj) x.y = -x.y;
+        x = cmul(x, h[Q]);
+        v[Q] = ok[Q] ? x : make_float2(0.f, 0.f);
+      });
+    }
   }
   if constexpr (EPI) {
     // ISB mode (slave->isb, src/filter.c:895-909, filter2 of the linear demodulator): LSB and USB are unpacked to

@@ -37,7 +37,7 @@ inline int launch_rows(Radix2 r, int grid, int block, size_t lds, hipStream_t s,
 }
 inline int launch_chan(Radix2 r, int grid, int block, size_t lds, hipStream_t s, const ChanParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
 #define X(a, b) if (r.r1 == a && r.r2 == b) { \
-    if (p.fine || p.power || p.isb) { CHZ_LAUNCH((chan_ifft<a, b, true>), grid, block, lds, s, e0, e1, p); } \
+    if (p.fine || p.power || p.isb || p.beam) { CHZ_LAUNCH((chan_ifft<a, b, true>), grid, block, lds, s, e0, e1, p); } \
     else { CHZ_LAUNCH((chan_ifft<a, b, false>), grid, block, lds, s, e0, e1, p); } \
     return 0; }
   CHZ_CHAN_MENU(X)

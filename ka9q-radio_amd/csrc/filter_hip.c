@@ -61,6 +61,8 @@ struct hbank {
   struct filter_out **slaves;       /* [cap] */
   int *shift;                       /* [cap] shift the device descriptor currently holds */
   unsigned char *isb;               /* [cap] slave->isb as the device currently holds it */
+  double *beam_ab;                  /* [cap][4] slave->alpha/beta as uploaded */
+  unsigned char *beam_on;           /* [cap] slave->beam as uploaded */
   void *stage[ND];                  /* pinned [cap][olen] samples: staged outputs per job slot */
   int *stage_shift[ND];             /* [cap] shift each staged output was computed with */
   unsigned *stage_epoch[ND];        /* [cap] response epoch it was computed with (0 = invalid) */
@@ -224,14 +226,16 @@ static size_t bank_sample_bytes(const struct hbank *b) { return b->real ? sizeof
 static int bank_create_dev(struct mctx *c, const struct hbank *b, int cap);
 static void bank_free_host(struct hbank *b) {
   for (int s = 0; s < ND; s++) { chz_host_free(b->stage[s]); b->stage[s] = NULL; FREE(b->stage_shift[s]); FREE(b->stage_epoch[s]); }
-  FREE(b->slaves); FREE(b->shift); FREE(b->isb);
+  FREE(b->slaves); FREE(b->shift); FREE(b->isb); FREE(b->beam_ab); FREE(b->beam_on);
 }
 static int bank_alloc_host(struct hbank *b, int cap) {
   b->cap = cap;
   b->slaves = calloc((size_t)cap, sizeof *b->slaves);
   b->shift = calloc((size_t)cap, sizeof *b->shift);
   b->isb = calloc((size_t)cap, 1);
-  if (!b->slaves || !b->shift || !b->isb) return -1;
+  b->beam_ab = calloc((size_t)cap * 4, sizeof(double));
+  b->beam_on = calloc((size_t)cap, 1);
+  if (!b->slaves || !b->shift || !b->isb || !b->beam_ab || !b->beam_on) return -1;
   for (int s = 0; s < ND; s++) {
     void *p = NULL;
     if (chz_host_alloc(&p, bank_sample_bytes(b) * (size_t)cap * b->olen) != 0) return -1;
@@ -530,6 +534,18 @@ int execute_filter_input(struct filter_in *const f) {
         if (f != b->isb[k]) { b->isb[k] = f; changed = true; }
       }
       if (changed) chz_bank_set_isb(c->eng, b->id, 0, b->n, b->isb);
+      if (f->in_type == COMPLEX) {   /* slave->beam and its weights (src/radio.c:938-940) */
+        for (int k = 0; k < b->n; k++) {
+          struct filter_out *s = b->slaves[k];
+          double ab[4] = {creal(s->alpha), cimag(s->alpha), creal(s->beta), cimag(s->beta)};
+          unsigned char on = s->beam ? 1 : 0;
+          if (on != b->beam_on[k] || (on && memcmp(ab, b->beam_ab + 4 * k, sizeof ab) != 0)) {
+            b->beam_on[k] = on; memcpy(b->beam_ab + 4 * k, ab, sizeof ab);
+            chz_bank_set_beam(c->eng, b->id, k, 1, ab, &on);
+            for (int s2 = 0; s2 < ND; s2++) b->stage_epoch[s2][k] = 0;      /* earlier staged results used other weights */
+          }
+        }
+      }
     }
     chz_bank_set_active(c->eng, b->id, b->n);
     rc = chz_bank_execute(c->eng, b->id, slot);

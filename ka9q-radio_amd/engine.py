@@ -40,7 +40,7 @@ SYMBOLS = [
     "chz_bank_output_device", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
     "chz_bank_set_tuning", "chz_bank_read_power", "chz_bank_read_power_async",
     "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
-    "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real", "chz_bank_set_isb",
+    "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real", "chz_bank_set_isb", "chz_bank_set_beam",
 ]
 
 _lib = None
@@ -76,6 +76,7 @@ def lib():
         L.chz_bank_create.argtypes = [_vp, _i, _i, _i]
         L.chz_bank_create_real.argtypes = [_vp, _i, _i, _i]
         L.chz_bank_set_isb.argtypes = [_vp, _i, _i, _i, _vp]
+        L.chz_bank_set_beam.argtypes = [_vp, _i, _i, _i, _vp, _vp]
         L.chz_bank_set_responses.argtypes = [_vp, _i, _i, _i, _vp]
         L.chz_bank_set_shifts.argtypes = [_vp, _i, _i, _i, _vp]
         L.chz_bank_set_active.argtypes = [_vp, _i, _i]
@@ -241,6 +242,14 @@ class Bank:
         """slave->isb per channel (src/filter.c:895-909)."""
         f = np.ascontiguousarray(flags, np.uint8).reshape(-1)
         _check(lib().chz_bank_set_isb(self.eng._h, self.id, ch0, f.shape[0], f.ctypes.data))
+
+    def set_beam(self, ch0, alpha, beta, on):
+        """slave->beam with slave->alpha / ->beta per channel (src/filter.c:756-775)."""
+        alpha = np.asarray(alpha, np.complex128).reshape(-1); beta = np.asarray(beta, np.complex128).reshape(-1)
+        ab = np.ascontiguousarray(np.stack([alpha.real, alpha.imag, beta.real, beta.imag], axis=1), np.float64)
+        f = np.ascontiguousarray(on, np.uint8).reshape(-1)
+        assert ab.shape[0] == f.shape[0]
+        _check(lib().chz_bank_set_beam(self.eng._h, self.id, ch0, f.shape[0], ab.ctypes.data, f.ctypes.data))
 
     def set_active(self, n):
         _check(lib().chz_bank_set_active(self.eng._h, self.id, n))

@@ -109,6 +109,7 @@ class _BankState:
         self.results = None
         self.dirty_shifts = True
         self.isb = np.zeros(bank.capacity, np.uint8)          # slave->isb flags as uploaded
+        self.beam = [None] * bank.capacity                    # (alpha, beta) as uploaded, None = beam off
 
 
 def create_filter_input(L, M, in_type, device=0, plan="", master=None):
@@ -221,6 +222,7 @@ def create_filter_output(master, olen, out_type, slave=None):
     s.output = None
     s.isb = False
     s.beam = False
+    set_filter_weights(s, 1.0, 0.0)                         # defaults select the A input only (:341)
     if out_type in (COMPLEX, REAL):
         real = out_type == REAL
         if real and s.points % 2:
@@ -283,6 +285,15 @@ def delete_filter_output(slave):
     return 0
 
 
+def set_filter_weights(slave, i_weight, q_weight):
+    """src/filter.c:922-929."""
+    if slave is None:
+        return -1
+    slave.alpha = 0.5 * complex(i_weight) - 1j * complex(q_weight)
+    slave.beta = 0.5 * complex(i_weight) + 1j * complex(q_weight)
+    return 0
+
+
 def set_filter(slave, low, high, kaiser_beta):
     """src/filter.c:968-1045."""
     if slave is None or not getattr(slave, "init", False) or slave.master is None:
@@ -335,6 +346,13 @@ def execute_filter_output(slave, shift):
     if st.shifts[slave._index] != shift:
         st.shifts[slave._index] = shift
         st.dirty_shifts = True
+        st.result_job = None
+    want_beam = (complex(slave.alpha), complex(slave.beta)) if (slave.out_type == COMPLEX and getattr(slave, "beam", False)
+                                                               and master.in_type == COMPLEX) else None
+    if want_beam != st.beam[slave._index]:                    # callers set slave->beam and the weights directly (src/radio.c:938-940)
+        st.beam[slave._index] = want_beam
+        a, b = want_beam if want_beam else (0j, 0j)
+        st.bank.set_beam(slave._index, [a], [b], [1 if want_beam else 0])
         st.result_job = None
     if slave.out_type == COMPLEX and bool(getattr(slave, "isb", False)) != bool(st.isb[slave._index]):   # callers set slave->isb directly (src/radio.c:1586)
         st.isb[slave._index] = 1 if slave.isb else 0

@@ -316,6 +316,58 @@ static int gather_core(const float *sp, const double *sp64, int m_bins, int in_t
 #undef MUL_PUT
 }
 
+/* Beam variant of COMPLEX master -> COMPLEX slave (slave->beam, src/filter.c:756-775): two antennas ride on I and Q of
+   the master; alpha and beta (set_filter_weights, :922-929) select or combine them,
+       Y = (alpha X[rp] + beta conj(X[m_bins - rp])) H      (double complex arithmetic, rounded to float complex)
+       Y = (Re X[rp] alpha + Im X[rp] beta) H               at rp = 0 and rp = m_bins/2.
+   Same index walk as the plain variant.  The reference has no trailing zero fill here, so bins past the end of the
+   walk keep whatever the buffer held (it is never initialised); this restatement defines them as zero. */
+int chzo_gather_beam(const float *spectrum, int m_bins, int s_bins, int shift, const float *H,
+                     double ar, double ai, double br, double bi, float *fd) {
+  if (m_bins <= 0 || s_bins <= 0 || !H) return -1;
+  struct src *map = (struct src *)malloc(sizeof(struct src) * (size_t)s_bins);
+  if (!map) return -1;
+  map_complex_to_complex(map, m_bins, s_bins, shift);
+  for (int t = 0; t < s_bins; t++) {
+    int w = ((s_bins + 1) / 2 + t) % s_bins;
+    if (map[t].idx < 0) { fd[2 * w] = 0; fd[2 * w + 1] = 0; continue; }
+    const int rp = map[t].idx;
+    const double xr = spectrum[2 * rp], xi = spectrum[2 * rp + 1];
+    const double hr = H[2 * w], hi = H[2 * w + 1];
+    double sr, si;
+    if (rp == 0 || rp == m_bins / 2) {                     /* :766-768 */
+      /* xr*alpha*H + xi*beta*H, evaluated left to right as the C expression is */
+      double t1r = xr * ar, t1i = xr * ai, t2r = xi * br, t2i = xi * bi;
+      sr = (t1r * hr - t1i * hi) + (t2r * hr - t2i * hi);
+      si = (t1r * hi + t1i * hr) + (t2r * hi + t2i * hr);
+    } else {                                               /* :770-771 */
+      const int mp = m_bins - rp;
+      const double yr = spectrum[2 * mp], yi = -(double)spectrum[2 * mp + 1];   /* conjf */
+      const double cr = (ar * xr - ai * xi) + (br * yr - bi * yi);
+      const double ci = (ar * xi + ai * xr) + (br * yi + bi * yr);
+      sr = cr * hr - ci * hi; si = cr * hi + ci * hr;
+    }
+    fd[2 * w] = (float)sr; fd[2 * w + 1] = (float)si;
+  }
+  free(map);
+  fd[2 * ((s_bins + 1) / 2)] = 0; fd[2 * ((s_bins + 1) / 2) + 1] = 0;       /* :911 */
+  return 0;
+}
+
+int chzo_channel_beam(const float *spectrum, int m_bins, int P, int olen, int shift, const float *response,
+                      double ar, double ai, double br, double bi, float *out) {
+  float *fd = (float *)malloc(sizeof(float) * 2 * (size_t)P);
+  float *td = (float *)malloc(sizeof(float) * 2 * (size_t)P);
+  if (!fd || !td) { free(fd); free(td); return -1; }
+  int r = chzo_gather_beam(spectrum, m_bins, P, shift, response, ar, ai, br, bi, fd);
+  if (r == 0) {
+    odft_c2c(cached_plan(P, 0), fd, td, +1);
+    memcpy(out, td + 2 * (size_t)(P - olen), sizeof(float) * 2 * (size_t)olen);
+  }
+  free(fd); free(td);
+  return r;
+}
+
 int chzo_gather(const float *spectrum, int m_bins, int in_type, int s_bins, int out_type,
                 int shift, int isb, const float *response, float *fdomain) {
   return gather_core(spectrum, NULL, m_bins, in_type, s_bins, out_type, shift, isb, response, fdomain, NULL);

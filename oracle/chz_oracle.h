@@ -70,6 +70,12 @@ double chzo_scale_ad(double rf_gain_db, double rf_atten_db, double level_cal_db,
 /* shift/remainder split of a tuning frequency (src/radio.c:1175-1199) */
 int chzo_compute_tuning(int N, double samprate, double freq, int *shift, double *remainder);
 
+/* slave->beam variant of the COMPLEX->COMPLEX gather (src/filter.c:756-775); alpha/beta as set_filter_weights leaves them */
+int chzo_gather_beam(const float *spectrum, int m_bins, int s_bins, int shift, const float *response,
+                     double ar, double ai, double br, double bi, float *fdomain);
+int chzo_channel_beam(const float *spectrum, int m_bins, int P, int olen, int shift, const float *response,
+                      double ar, double ai, double br, double bi, float *out);
+
 /* estimate_noise() of src/radio.c:1783-1866: noise density (per Hz) around a channel from the master spectrum */
 double chzo_estimate_noise(const float *spectrum, int m_bins, int in_type, int s_bins, int shift, double samprate);
 

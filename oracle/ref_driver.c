@@ -151,6 +151,19 @@ int refchz_chan_execute(void *h, int shift, float *out) {
   else if (c->out.out_type == REAL) memcpy(out, c->out.output.r, sizeof(float) * (size_t)c->out.olen);
   return 0;
 }
+/* beam mode (src/radio.c:938-940): the caller sets out.beam and the weights after create.  The reference never
+   initialises fdomain and its beam branch has no trailing zero fill (src/filter.c:756-775), so the scratch vector is
+   cleared once here to make the untouched bins comparable. */
+int refchz_chan_set_beam(void *h, double iw_re, double iw_im, double qw_re, double qw_im) {
+  struct refchz_chan *c = h;
+  c->out.beam = true;
+  memset(c->out.fdomain, 0, sizeof(float complex) * (size_t)c->out.bins);
+  return set_filter_weights(&c->out, iw_re + I * iw_im, qw_re + I * qw_im);
+}
+void refchz_chan_weights(void *h, double *ab) {
+  struct refchz_chan *c = h;
+  ab[0] = creal(c->out.alpha); ab[1] = cimag(c->out.alpha); ab[2] = creal(c->out.beta); ab[3] = cimag(c->out.beta);
+}
 /* the gathered & weighted frequency-domain vector that fed the last IFFT */
 int refchz_chan_fdomain(void *h, float *out) {
   struct refchz_chan *c = h;

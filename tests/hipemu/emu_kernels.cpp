@@ -148,6 +148,29 @@ int emu_channels_isb(const float* spec, int m_bins, int in_type, int P, int olen
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
 }
 
+// COMPLEX master, COMPLEX slaves in beam mode (src/filter.c:756-775): ab = 4 doubles per channel
+int emu_channels_beam(const float* spec, int m_bins, int P, int olen, int nch, const float* resp, const int* shifts,
+                      const double* ab, const unsigned char* on, float* out) {
+  ChanGeom g;
+  if (!build_chan_geom(P, g)) return -1;
+  SpecLayout lay{m_bins, m_bins, 0};
+  std::vector<ChanDesc> desc((size_t)nch);
+  std::vector<BeamDesc> bd((size_t)nch);
+  for (int i = 0; i < nch; i++) {
+    ChanDescH h = make_chan_desc(CHZ_IN_COMPLEX, m_bins, P, shifts[i]);
+    desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
+    bd[i] = BeamDesc{ab[4 * i], ab[4 * i + 1], ab[4 * i + 2], ab[4 * i + 3], on[i] ? 1 : 0, 0};
+  }
+  ChanParams c{};
+  c.spec = reinterpret_cast<const float2*>(spec); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
+  c.resp = reinterpret_cast<const float2*>(resp);
+  c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
+  c.tw_sub = F2(g.tw_sub); c.beam = bd.data();
+  const int per_block = g.wpb * g.cpw;
+  const int grid = (nch + per_block - 1) / per_block;
+  return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
+}
+
 // REAL-output slaves: out = [nch][olen] floats
 int emu_channels_real(const float* spec, int m_bins, int in_type, int P, int olen, int nch,
                       const float* resp, const int* shifts, float* out, int lay_na, int lay_pitch, int lay_off) {

@@ -62,6 +62,8 @@ def oracle():
         L.chzo_stream_bins.argtypes = [_vp]
         L.chzo_stream_push.argtypes = [_vp, _vp, _vp]
         L.chzo_stream_push_f64.argtypes = [_vp, _vp, _vp]
+        L.chzo_gather_beam.argtypes = [_vp, _i, _i, _i, _vp, _d, _d, _d, _d, _vp]
+        L.chzo_channel_beam.argtypes = [_vp, _i, _i, _i, _i, _vp, _d, _d, _d, _d, _vp]
         L.chzo_estimate_noise.restype = _d
         L.chzo_estimate_noise.argtypes = [_vp, _i, _i, _i, _i, _d]
         L.chzo_convert_i16.argtypes = [_vp, _i, C.c_float, _i, _vp, _vp]
@@ -100,6 +102,8 @@ def ref():
         L.refchz_chan_set_response.argtypes = [_vp, _vp]
         L.refchz_chan_execute.argtypes = [_vp, _i, _vp]
         L.refchz_chan_fdomain.argtypes = [_vp, _vp]
+        L.refchz_chan_set_beam.argtypes = [_vp, _d, _d, _d, _d]
+        L.refchz_chan_weights.argtypes = [_vp, _vp]
         L.refchz_make_kaiserf.argtypes = [_vp, _i, _d]
         L.refchz_i0.restype = _d; L.refchz_i0.argtypes = [_d]
         L.refchz_bench.restype = _d
@@ -296,6 +300,14 @@ class RefChan:
     def set_isb(self, isb):
         self.lib.refchz_chan_set_isb(self.h, int(isb))
 
+    def set_beam(self, i_weight, q_weight):
+        """out.beam = true + set_filter_weights (src/radio.c:938-940); returns (alpha, beta) as the reference stored them."""
+        i_weight, q_weight = complex(i_weight), complex(q_weight)
+        self.lib.refchz_chan_set_beam(self.h, i_weight.real, i_weight.imag, q_weight.real, q_weight.imag)
+        ab = np.zeros(4)
+        self.lib.refchz_chan_weights(self.h, _fptr(ab))
+        return complex(ab[0], ab[1]), complex(ab[2], ab[3])
+
     def response(self):
         out = np.zeros(self.points, np.complex64)
         if self.lib.refchz_chan_response(self.h, _fptr(out)) < 0:
@@ -344,6 +356,24 @@ class RefSigGen:
             self.lib.refsig_delete(self.h)
         except Exception:
             pass
+
+
+def beam_weights(i_weight, q_weight):
+    """set_filter_weights (src/filter.c:922-929): alpha = 0.5 i_w - j q_w, beta = 0.5 i_w + j q_w."""
+    i_weight, q_weight = complex(i_weight), complex(q_weight)
+    return 0.5 * i_weight - 1j * q_weight, 0.5 * i_weight + 1j * q_weight
+
+
+def channel_beam(spectrum, P, olen, shift, response, alpha, beta):
+    """COMPLEX master -> COMPLEX slave in beam mode (src/filter.c:756-775)."""
+    sp = np.ascontiguousarray(spectrum, np.complex64)
+    response = np.ascontiguousarray(response, np.complex64)
+    out = np.zeros(olen, np.complex64)
+    r = oracle().chzo_channel_beam(_fptr(sp), sp.size, P, olen, int(shift), _fptr(response),
+                                   alpha.real, alpha.imag, beta.real, beta.imag, _fptr(out))
+    if r != 0:
+        raise ValueError("chzo_channel_beam failed")
+    return out
 
 
 def estimate_noise(spectrum, in_type, s_bins, shift, samprate):

@@ -733,3 +733,37 @@ def test_isb_slaves(pkg):
             assert not np.array_equal(slaves[1].output, slaves[4].output)
     finally:
         fa.delete_filter_input(master)
+
+
+def test_beam_slaves(pkg):
+    # slave->beam with set_filter_weights (src/filter.c:756-775, :922-929; radio.c:938-940) on a COMPLEX master
+    L, M, P, olen = 11520, 2881, 300, 240
+    fa = pkg.filterapi
+    rng = np.random.default_rng(78)
+    master = fa.create_filter_input(L, M, fa.COMPLEX)
+    st = ol.Stream(L, M, ol.COMPLEX)
+    N = L + M - 1
+    weights = [(1.0, 0.0), (0.0, 1.0), (0.7 + 0.2j, -0.3 + 0.6j), None]
+    shifts = [0, 2000, -(N // 2) + 60, 350]
+    slaves = [fa.create_filter_output(master, olen, fa.COMPLEX) for _ in weights]
+    try:
+        for s, w in zip(slaves, weights):
+            fa.set_filter(s, -0.4, 0.4, 9.0)
+            if w is not None:
+                s.beam = True
+                assert fa.set_filter_weights(s, *w) == 0
+        for blk in range(3):
+            x = (rng.standard_normal(L) + 1j * rng.standard_normal(L)).astype(np.complex64)
+            fa.write_cfilter(master, x)
+            spec = st.push(x)
+            if blk == 2:
+                fa.set_filter_weights(slaves[0], 0.25, -0.5j)          # weights change mid-stream
+            for s, w, sh in zip(slaves, weights, shifts):
+                assert fa.execute_filter_output(s, sh) == 0
+                if w is None:
+                    want = ol.channel(spec, ol.COMPLEX, P, olen, sh, s.response)
+                else:
+                    want = ol.channel_beam(spec, P, olen, sh, s.response, s.alpha, s.beta)
+                assert np.linalg.norm(s.output - want) <= 1e-5 * np.linalg.norm(want), (blk, sh)
+    finally:
+        fa.delete_filter_input(master)

@@ -34,6 +34,7 @@ def emu(oracle_built):
     lib.emu_forward_i16.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int, C.c_char_p,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emu_channels_real.argtypes = lib.emu_channels.argtypes
+    lib.emu_channels_beam.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emu_channels_isb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.emu_noise.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int, C.c_int]
     lib.emu_fine_create.restype = C.c_void_p
@@ -259,3 +260,33 @@ def test_isb_unpack_in_channel_kernel(emu, in_type, B, P, olen):
             assert not out[i].any()
         else:
             assert rel(out[i], want) < 1e-6, (s, i, flags[i])
+
+
+@pytest.mark.parametrize("B,P,olen", [(6000, 300, 240), (6001, 20, 16), (14400, 600, 480)])
+def test_beam_mode_in_channel_kernel(emu, B, P, olen):
+    """slave->beam (src/filter.c:756-775): antenna selection / combination weights on a COMPLEX master, mixed with plain
+    channels in one launch; shifts through DC (the Re/Im special case), the band edges and the +Nyquist seam."""
+    rng = np.random.default_rng(B + P + 2)
+    spec = (rng.standard_normal(B) + 1j * rng.standard_normal(B)).astype(np.complex64)
+    h = B // 2
+    shifts = [0, 3, -3, P // 2, -(P // 2), h - 10, -h + 10, h + P // 4, 1000, -1000, h - P // 2 + 1, 7]
+    weights = [(1, 0), (0, 1), (0.7 + 0.2j, -0.3 + 0.6j), (1, 1j)]
+    nch = len(shifts)
+    on = np.array([1] * (nch - 1) + [0], np.uint8)
+    ab = np.zeros((nch, 4))
+    alphas, betas = [], []
+    for i in range(nch):
+        a, b = ol.beam_weights(*weights[i % len(weights)])
+        alphas.append(a); betas.append(b); ab[i] = [a.real, a.imag, b.real, b.imag]
+    resp = (rng.standard_normal((nch, P)) + 1j * rng.standard_normal((nch, P))).astype(np.complex64)
+    sh = np.array(shifts, np.int32)
+    out = np.zeros((nch, olen), np.complex64)
+    assert emu.emu_channels_beam(spec.ctypes.data, B, P, olen, nch, resp.ctypes.data, sh.ctypes.data, ab.ctypes.data,
+                                 on.ctypes.data, out.ctypes.data) == 0
+    for i, s in enumerate(shifts):
+        want = ol.channel_beam(spec, P, olen, s, resp[i], alphas[i], betas[i]) if on[i] else ol.channel(spec, ol.COMPLEX, P, olen, s, resp[i])
+        nrm = np.linalg.norm(want)
+        if nrm == 0:
+            assert not out[i].any()
+        else:
+            assert rel(out[i], want) < 1e-6, (s, i)

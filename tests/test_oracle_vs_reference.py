@@ -213,3 +213,42 @@ def test_downconvert_tail_matches_reference_oscillator(oracle_built):
     y0, _ = c.block(x, 25000, 0.0, 0.0)
     y1, _ = c.block(x, 25000, 0.0, 0.0)
     assert np.allclose(np.abs(y0), np.abs(x), rtol=1e-6) and np.array_equal(y0, y1)
+
+
+def test_beam_gather_matches_reference(oracle_built):
+    """slave->beam (src/filter.c:756-775) on a COMPLEX master: the restatement against the reference's own branch, for
+    antenna selections and a genuine two-antenna combination, shifts through DC, the band edges and the +Nyquist seam."""
+    L, M, olen = 11520, 2881, 240
+    rng = np.random.default_rng(8)
+    m = ol.RefMaster(L, M, ol.COMPLEX)
+    st = ol.Stream(L, M, ol.COMPLEX)
+    N = L + M - 1
+    P = olen * N // L
+    weights = [(1.0, 0.0), (0.0, 1.0), (0.7 + 0.2j, -0.3 + 0.6j)]
+    shifts = [0, 1, -1, 150, -150, 3000, -3000, N // 2 - 100, -(N // 2) + 100, N // 2 - 10, N // 2 + 40]
+    chans = []
+    for (iw, qw) in weights:
+        for sh in shifts:                       # a slave runs once per block: one slave per (weights, shift)
+            c = m.channel(olen, ol.COMPLEX)
+            assert c.set_filter(-0.4, 0.35, 7.0) == 0
+            ab = c.set_beam(iw, qw)
+            assert np.allclose(ab, ol.beam_weights(iw, qw), rtol=0, atol=1e-15)
+            chans.append((c, ab, sh))
+    for blk in range(2):
+        x = (rng.standard_normal(L) + 1j * rng.standard_normal(L)).astype(np.complex64)
+        assert m.write(x) == 1
+        spec = m.spectrum()
+        assert rel(st.push(x), spec) <= 1e-7
+        for c, (alpha, beta), sh in chans:
+            resp = c.response()
+            got = c.execute(sh)
+            fd = np.zeros(P, np.complex64); c.lib.refchz_chan_fdomain(c.h, fd.ctypes.data)
+            want_fd = np.zeros(P, np.complex64)
+            ol.oracle().chzo_gather_beam(spec.ctypes.data, spec.size, P, sh, resp.ctypes.data,
+                                         alpha.real, alpha.imag, beta.real, beta.imag, want_fd.ctypes.data)
+            # the reference's scratch vector was cleared once at set_beam (ref_driver.c); the walk of a fixed shift
+            # writes the same bins every block, so unwritten bins stay zero on both sides
+            assert np.abs(fd - want_fd).max() <= 2e-7 * max(np.abs(want_fd).max(), 1e-30), (blk, sh)
+            want = ol.channel_beam(spec, P, olen, sh, resp, alpha, beta)
+            assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1e-30), (blk, sh)
+    m.close()
