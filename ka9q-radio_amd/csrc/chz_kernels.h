@@ -435,10 +435,38 @@ __global__ void fwd_rows(RowsParams p) {
   const int rowstride = p.Nb * NC;               // all index math below is 32-bit: N < 2^31
   const int gstep = R2 * ld + padg;              // LDS distance between butterfly groups
 
+  const float2* __restrict__ tws = p.tw_sub;
+  const float2* __restrict__ gin = p.buf + (long)kb * NC;
+  if constexpr (R2 % 16 == 0) {
+    // The first layer takes its points straight from global memory: with the lanes running along nc (j1 fastest),
+    // the R2 lanes of one row read R2 consecutive complex values = whole 128-byte lines per load instruction, and
+    // the separate transposition pass through LDS (one barrier, one LDS write + read, its index arithmetic) is gone.
+    const int r1 = tid / R2, j1 = tid - r1 * R2;
+    const bool act1 = tid < R2 * Ta;
+    if (act1) {
+      const int ka = a0 + r1;
+      const bool in = ka >= 0 && ka < p.Ra;
+      const float2* __restrict__ g = gin + (in ? ka : 0) * rowstride + j1;
+      float2 v[R1], w1[R1];
+      static_for<R1>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        v[Q] = g[Q * R2];
+        if constexpr (Q > 0) w1[Q] = tws[j1 * R1 + Q];
+      });
+      if (!in) static_for<R1>([&](auto q) { constexpr int Q = decltype(q)::value; v[Q] = make_float2(0.f, 0.f); });
+      reg_dft<R1, -1>(v);
+      const int b1 = j1 * ld + r1;                 // row K1*R2 + j1 (group K1), column r1
+      static_for<R1>([&](auto k1) {
+        constexpr int K1 = decltype(k1)::value;
+        float2 x = v[K1];
+        if constexpr (K1 > 0) x = cmul(x, w1[K1]);
+        lds[b1 + K1 * gstep] = x;
+      });
+    }
+  } else {
   // first-layer twiddles depend only on the lane: fetch them before anything else
   const int j1 = tid / Ta, r1 = tid - j1 * Ta;
   const bool act1 = tid < R2 * Ta;
-  const float2* __restrict__ tws = p.tw_sub;
   float2 w1[R1];
   static_for<R1>([&](auto q) {
     constexpr int Q = decltype(q)::value;
@@ -446,7 +474,6 @@ __global__ void fwd_rows(RowsParams p) {
   });
   // coalesced row loads, transposed into LDS as [nc][r]; LOAD_U loads are in flight per lane
   constexpr int LOAD_U = 6;
-  const float2* __restrict__ gin = p.buf + (long)kb * NC;
   for (int e0 = tid; e0 < Ta * NC; e0 += nthr * LOAD_U) {
     float2 x[LOAD_U];
     int la[LOAD_U];
@@ -479,6 +506,7 @@ __global__ void fwd_rows(RowsParams p) {
       if constexpr (K1 > 0) x = cmul(x, w1[K1]);
       lds[b1 + K1 * gstep] = x;                    // in place: row K1*R2 + j1 (group K1)
     });
+  }
   }
   __syncthreads();
   if (tid < R1 * Ta) {
