@@ -16,7 +16,7 @@ namespace chz {
 // (R1,R2) pairs with a compiled kernel instantiation.  Sub-transform length = R1*R2.
 #define CHZ_FWD_MENU(X) \
   X(4, 4) X(5, 5) X(6, 6) X(5, 9) X(5, 10) X(5, 15) X(8, 8) X(8, 9) X(9, 9) X(10, 10) X(10, 12) X(5, 25) X(9, 15) \
-  X(12, 12) X(10, 15) X(10, 16) X(12, 15) X(12, 16) X(15, 15) X(15, 16) X(16, 16) X(16, 20) X(20, 20)
+  X(12, 12) X(10, 15) X(10, 16) X(12, 15) X(12, 16) X(15, 15) X(15, 16) X(16, 16) X(16, 20) X(20, 20) X(9, 16)
 // per-channel backward transform lengths P = R1*R2 (reference sizes: docs/FFTW3.md:51-68)
 #define CHZ_CHAN_MENU(X) \
   X(4, 5) X(5, 6) X(10, 15) X(10, 16) X(10, 20) X(15, 20) X(16, 20) X(20, 20) X(20, 24) \
@@ -29,6 +29,14 @@ inline bool fwd_menu_lookup(int np, Radix2* out) {
   CHZ_FWD_MENU(X)
 #undef X
   return false;
+}
+// Axis c (fwd_rows) loads whole 128-byte lines straight into its first butterfly layer when R2 is a multiple of 16:
+// prefer such a factorisation of the axis length where the menu has one.
+inline bool fwd_menu_lookup_c(int np, Radix2* out) {
+#define X(a, b) if ((a) * (b) == np && (b) % 16 == 0) { if (out) { out->r1 = a; out->r2 = b; } return true; }
+  CHZ_FWD_MENU(X)
+#undef X
+  return fwd_menu_lookup(np, out);
 }
 inline bool chan_menu_lookup(int p, Radix2* out) {
 #define X(a, b) if ((a) * (b) == p) { if (out) { out->r1 = a; out->r2 = b; } return true; }
@@ -214,7 +222,7 @@ inline bool build_fwd_plan(int N, int in_type, const char* spec, FwdPlan& out) {
     }
     if ((long long)a * b * c != N) return false;
     FwdPlan p; p.N = N; p.in_type = in_type; p.Na = a; p.Nb = b; p.Nc = c;
-    if (!fwd_menu_lookup(a, &p.ra) || !fwd_menu_lookup(c, &p.rc)) return false;
+    if (!fwd_menu_lookup(a, &p.ra) || !fwd_menu_lookup_c(c, &p.rc)) return false;
     if (b > 1 && !fwd_menu_lookup(b, &p.rb)) return false;
     if (!finish_fwd_plan(p, T1o, T2o, Tao)) return false;
     out = p;
@@ -238,7 +246,7 @@ inline bool build_fwd_plan(int N, int in_type, const char* spec, FwdPlan& out) {
       if (!fwd_menu_lookup(c, nullptr)) continue;
       if (real && ((long long)b * c) % 2) continue;
       FwdPlan p; p.N = N; p.in_type = in_type; p.Na = a; p.Nb = b; p.Nc = c;
-      fwd_menu_lookup(a, &p.ra); fwd_menu_lookup(c, &p.rc);
+      fwd_menu_lookup(a, &p.ra); fwd_menu_lookup_c(c, &p.rc);
       if (b > 1) fwd_menu_lookup(b, &p.rb);
       if (!finish_fwd_plan(p, 0, 0, 0)) continue;
       // cost model (fitted to scripts/plan_sweep.py runs on MI355X): every pass moves the whole
@@ -254,7 +262,8 @@ inline bool build_fwd_plan(int N, int in_type, const char* spec, FwdPlan& out) {
       const bool al3 = real ? (p.spec_off != 0 || (a % 16 == 0)) : (a % 16 == 0);
       double score = (b > 1 ? 3.0 : 2.0) + grid_pen(p.grid1) + grid_pen(p.grid3) + (b > 1 ? grid_pen(p.grid2) : 0.0) +
                      shape_pen(p.ra) + shape_pen(p.rc) + (b > 1 ? shape_pen(p.rb) : 0.0) +
-                     (al1 ? 0.0 : 0.5) + (al2 ? 0.0 : 0.5) + (al3 ? 0.0 : 0.25);
+                     (al1 ? 0.0 : 0.5) + (al2 ? 0.0 : 0.5) + (al3 ? 0.0 : 0.25) -
+                     (p.rc.r2 % 16 == 0 ? 0.15 : 0.0);      // direct-load first layer of fwd_rows: that pass runs 15 % faster
       if (score < best) { best = score; bestp = p; found = true; }
     }
   }
