@@ -54,32 +54,30 @@
 
 namespace chz {
 
-// Store flavour of the forward passes, fixed at build time: 0 plain (default), 1 non-temporal, 2 agent-scope
-// write-through.  Measured on MI355X (config 3): non-temporal stores in pass a shorten that kernel alone
-// (10.6 -> 8.5 us: no dirty lines left for the end-of-kernel L2 write-back) but the next pass then misses the
-// cache (+0.9 us) and the pipelined block time gets WORSE (17.9 -> 19.3 us); write-through behaves alike.
-// The intermediate buffers want to stay cache-resident, so the default is plain stores.
-#ifndef CHZ_NT
-#define CHZ_NT 0
+// Stores of the forward passes.  A pass's output is read next by another kernel on whatever XCD it lands on, so a
+// plain store only parks a dirty line in this XCD's (non-coherent) L2 until the end-of-kernel release writes all of
+// them back in one burst -- measured as ~2 us of every pass.  Stores with agent scope (the `sc1` bit) write through as
+// the kernel runs and keep the lines cacheable for the next pass:
+//     config 3, one MI355X:  fwd_first_real 10.5 -> 8.2 us, fwd_cols 8.4 -> 7.0 us, fwd_rows 7.6 -> 6.7 us,
+//     pipelined block time 16.9 -> 15.4 us.
+// Variants measured and rejected: non-temporal stores (`nt`: the next pass then misses the cache, pipelined 17.9 -> 19.3 us)
+// and relaxed agent-scope atomic stores from C++ (8-byte pieces, more instructions: pipelined worse).  CHZ_WT=0 at build
+// time restores plain stores.
+#ifndef CHZ_WT
+#define CHZ_WT 1
 #endif
-#if defined(__HIP_DEVICE_COMPILE__) && CHZ_NT == 1
-typedef float chz_v2f __attribute__((ext_vector_type(2)));
-typedef float chz_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_stream(float2* p, float2 v) { __builtin_nontemporal_store(chz_v2f{v.x, v.y}, reinterpret_cast<chz_v2f*>(p)); }
-__device__ __forceinline__ void store_stream(float4* p, float4 v) { __builtin_nontemporal_store(chz_v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<chz_v4f*>(p)); }
-#elif defined(__HIP_DEVICE_COMPILE__) && CHZ_NT == 2
-__device__ __forceinline__ void store_stream(float2* p, float2 v) {
-  unsigned long long b = ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(__HIP_DEVICE_COMPILE__) && CHZ_WT
+__device__ __forceinline__ void store_wt(float2* p, float2 v) {
+  typedef float v2 __attribute__((ext_vector_type(2)));
+  v2 d = {v.x, v.y};
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(d) : "memory");
 }
-__device__ __forceinline__ void store_stream(float4* p, float4 v) {
-  store_stream(reinterpret_cast<float2*>(p), make_float2(v.x, v.y));
-  store_stream(reinterpret_cast<float2*>(p) + 1, make_float2(v.z, v.w));
+__device__ __forceinline__ void store_wt(float4* p, float4 v) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  v4 d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(d) : "memory");
 }
-#endif
-// the default is a plain assignment, so the compiler keeps the destination's __restrict__ knowledge
-#if defined(__HIP_DEVICE_COMPILE__) && CHZ_NT != 0
-#define CHZ_STORE(lvalue, value) store_stream(&(lvalue), (value))
+#define CHZ_STORE(lvalue, value) store_wt(&(lvalue), (value))
 #else
 #define CHZ_STORE(lvalue, value) ((lvalue) = (value))
 #endif
