@@ -13,6 +13,7 @@
 #include <chrono>
 #include <string>
 #include <vector>
+#include <thread>
 #include <cmath>
 #include "chz_launch.h"
 #include "chz_finetune.h"
@@ -900,6 +901,28 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
   } else {
     HIPOK(hipEventRecord(t0, s0));
     if (!in.on && (rc = lanes_fork(e, fork_ev))) return rc;
+    // Blocks of different lanes are independent launch sequences.  A single host thread issues ~4 launches per block at
+    // ~3 us each, which bounds the small configurations (config 2: 12 us per block) -- so the lanes are split over
+    // CHZ_ENQ_THREADS host threads (default 2; 1 = issue from the caller only), each owning a subset of the lanes.
+    static const int enq_threads = [] { const char* v = getenv("CHZ_ENQ_THREADS"); int n = v ? atoi(v) : 2; return n == 2 || n == 4 ? n : 1; }();
+    if (enq_threads > 1 && !in.on && e->nlanes >= enq_threads && nblocks >= 4 * e->nlanes) {
+      std::vector<std::thread> th;
+      std::vector<int> rcs((size_t)enq_threads, 0);
+      std::vector<std::string> errs((size_t)enq_threads);
+      for (int t = 0; t < enq_threads; t++)
+        th.emplace_back([&, t] {
+          (void)hipSetDevice(e->device);
+          for (int b = 0; b < nblocks && !rcs[(size_t)t]; b++) {
+            const unsigned job = job0 + (unsigned)b;
+            if ((int)(job % (unsigned)e->nlanes) % enq_threads != t) continue;
+            if ((rcs[(size_t)t] = enqueue_step(e, job, nullptr))) errs[(size_t)t] = g_err;
+          }
+        });
+      for (auto& x : th) x.join();
+      for (size_t t = 0; t < rcs.size(); t++) if (rcs[t]) return fail(rcs[t], "%s", errs[t].c_str());   // the message lives in the worker's thread-local
+      for (Bank& b : e->banks) b.last_slot = (int)((job0 + (unsigned)nblocks - 1u) % CHZ_ND);            // what a single issuer would have left
+      done = nblocks;
+    }
     for (; done < nblocks; done++) if ((rc = enqueue_step(e, job0 + (unsigned)done, &in))) return rc;
     if (!in.on && (rc = lanes_join(e, join_ev))) return rc;
   }
