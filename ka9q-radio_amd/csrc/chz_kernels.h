@@ -66,20 +66,22 @@ namespace chz {
 #ifndef CHZ_WT
 #define CHZ_WT 1
 #endif
+// The stores go through a buffer descriptor (raw_buffer_store with aux = 16 = sc1) rather than inline asm, so the compiler
+// still counts and schedules them and pads their hazards; offsets are 32-bit bytes from the (wave-uniform) array base.
 #if defined(__HIP_DEVICE_COMPILE__) && CHZ_WT
-__device__ __forceinline__ void store_wt(float2* p, float2 v) {
-  typedef float v2 __attribute__((ext_vector_type(2)));
-  v2 d = {v.x, v.y};
-  asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(d) : "memory");
+typedef unsigned chz_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned chz_u4 __attribute__((ext_vector_type(4)));
+#define CHZ_OUT_DESC(name, base) const __amdgpu_buffer_rsrc_t name = __builtin_amdgcn_make_buffer_rsrc((void*)(base), 0, 0x7ffffffc, 0x00020000)
+__device__ __forceinline__ void store_wt(__amdgpu_buffer_rsrc_t d, int elem, float2 v) {
+  __builtin_amdgcn_raw_buffer_store_b64(chz_u2{__float_as_uint(v.x), __float_as_uint(v.y)}, d, elem * 8, 0, 16);
 }
-__device__ __forceinline__ void store_wt(float4* p, float4 v) {
-  typedef float v4 __attribute__((ext_vector_type(4)));
-  v4 d = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(d) : "memory");
+__device__ __forceinline__ void store_wt(__amdgpu_buffer_rsrc_t d, int elem, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(chz_u4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, d, elem * 16, 0, 16);
 }
-#define CHZ_STORE(lvalue, value) store_wt(&(lvalue), (value))
+#define CHZ_STORE(desc, base, elem, value) store_wt(desc, (int)(elem), (value))
 #else
-#define CHZ_STORE(lvalue, value) ((lvalue) = (value))
+#define CHZ_OUT_DESC(name, base) const int name = 0; (void)name
+#define CHZ_STORE(desc, base, elem, value) ((base)[(elem)] = (value))
 #endif
 
 // ------------------------------------------------------------------------------
@@ -319,6 +321,7 @@ __global__ void fwd_first_real(FirstRealParams p) {
   //                           real column 2p+1 -> (Z[k] - conj Z[Na-k]) / 2i
   // (the factors 1/2 and 1/2i live in the column twiddle table)
   float4* __restrict__ gout4 = reinterpret_cast<float4*>(gout);
+  CHZ_OUT_DESC(odesc, gout4);
   const int orow = p.inner >> 1;                   // row pitch of buf in float4 units
   static_for<NE>([&](auto uu) {
     constexpr int U = decltype(uu)::value;
@@ -330,7 +333,7 @@ __global__ void fwd_first_real(FirstRealParams p) {
       const float2 dd = make_float2(a.x - b.x, a.y + b.y);   // a - conj(b)
       const float2 oe = cmul(de, cmul(we1[U], make_float2(we2[U].x, we2[U].y)));
       const float2 oo = cmul(dd, cmul(we1[U], make_float2(we2[U].z, we2[U].w)));
-      CHZ_STORE(gout4[(long)k * orow + c0 + pc], make_float4(oe.x, oe.y, oo.x, oo.y));
+      CHZ_STORE(odesc, gout4, k * orow + c0 + pc, make_float4(oe.x, oe.y, oo.x, oo.y));
     }
   });
 }
@@ -410,11 +413,12 @@ __global__ void fwd_cols(ColsParams p) {
       u[J] = lds[l2 + J * T];
     });
     reg_dft<R2, -1>(u);
-    float2* __restrict__ o0 = gout + base + (long)k1o * p.inner + to;
+    CHZ_OUT_DESC(odesc, gout);
+    const int o0 = (int)base + k1o * p.inner + to;       // element index into gout: the whole buffer is < 2^31 bytes
     const int ostep = R1 * p.inner;
     static_for<R2>([&](auto k2) {
       constexpr int K2 = decltype(k2)::value;
-      CHZ_STORE(o0[K2 * ostep], cmul(u[K2], cmul(wt[K2], wc[K2])));
+      CHZ_STORE(odesc, gout, o0 + K2 * ostep, cmul(u[K2], cmul(wt[K2], wc[K2])));
     });
   }
 }
@@ -551,10 +555,11 @@ __global__ void fwd_rows(RowsParams p) {
       const int d0 = x0 * p.lay.pitch + p.lay.off + ka, ds = xs * p.lay.pitch;
       const int m0 = (xrows - 1 - x0) * p.lay.pitch + p.lay.off + (p.Na - ka);
       float2* __restrict__ sp = p.spec;
+      CHZ_OUT_DESC(sdesc, sp);
       static_for<R2>([&](auto k2) {
         constexpr int K2 = decltype(k2)::value;
-        if (!p.mirror || kk0 + K2 * kks <= half) CHZ_STORE(sp[d0 + K2 * ds], u[K2]);
-        else if (!selfconj) CHZ_STORE(sp[m0 - K2 * ds], cconj(u[K2]));      // bin N-k
+        if (!p.mirror || kk0 + K2 * kks <= half) CHZ_STORE(sdesc, sp, d0 + K2 * ds, u[K2]);
+        else if (!selfconj) CHZ_STORE(sdesc, sp, m0 - K2 * ds, cconj(u[K2]));      // bin N-k
       });
     }
   }
