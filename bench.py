@@ -204,7 +204,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm.  BENCH_DIST_BACKEND=gloo exists only to exercise the multi-rank control flow with several
+        # ranks on ONE GPU (RCCL refuses two ranks per device); the replicate mode has no data-path collective anyway.
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     # N > 1: channels shard across ranks.  How the shared spectrum gets to every rank:
     #   replicate (default)  every rank runs the forward transform on its own HBM-resident copy of the samples
@@ -225,7 +228,7 @@ def main():
         # architecture: rank 0 owns the front end, the spectrum travels over xGMI)
         if exch == "replicate":
             how = ("the sample stream is resident in every GPU's HBM (the bench's input rule; in service the host feeds each GPU over its "
-                   "own PCIe link) and each GPU transforms it itself (17 us per 20 ms block): no data-path collective")
+                   "own PCIe link) and each GPU transforms it itself (about 0.1 % of a 20 ms block): no data-path collective")
         else:
             how = "rank 0 owns the front end and the forward transform, the spectrum travels over xGMI via RCCL (%s)" % exch
         workload = ("config3 per GPU x %d: sig_gen real 129.6 MS/s, %d mixed usb/cw/iq 12 kHz channels (P=300) sharded by "
@@ -246,7 +249,10 @@ def main():
 
     def barrier():
         if use_dist:
-            dist.barrier(device_ids=[local_rank])
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     if not use_dist or exch == "replicate":
@@ -308,7 +314,7 @@ def main():
         exchange_mode = mode
 
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
