@@ -341,6 +341,8 @@ def main():
             "bound": "hbm", "kernel": "forward transform = fwd_first_real + fwd_cols + fwd_rows (one launch each per block)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic_bytes(),
+            "frac_of_measured_copy_rate": achieved / 6290.0,        # 6.29 TB/s: the chip's achievable copy rate (MI355X_MICROARCH.md)
+            "structural_cap": "three HBM passes: at most 1/3 of peak on algorithmic bytes",
             "algorithmic_bytes_per_block": FWD_BYTES, "forward_us_per_block": fwd_us,
             "kernels_us": kern,
             "kernels_own_GBps": {k: own[k] / (kern[k] * 1e-6) / 1e9 for k in own if k in kern and kern[k] > 0},
