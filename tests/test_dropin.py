@@ -198,3 +198,17 @@ def test_dropin_isb_slave():
             want = ol.channel(s, ol.REAL, P, olen, p[0], resp, isb=(i == 1))
             assert np.linalg.norm(out[b, i] - want) <= 2e-5 * np.linalg.norm(want), (b, i)
     assert not np.allclose(out[:, 0], out[:, 1])       # same tuning and filter, only the flag differs
+
+
+@pytest.mark.gpu
+def test_c_example_runs_against_the_engine_abi():
+    """examples/chz_minimal.c: include/chz_engine.h from plain C (gcc, no Python in the process), analytic known answer."""
+    _build_lib()
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "chz_minimal")
+        pkgdir = os.path.join(ROOT, "ka9q-radio_amd")
+        subprocess.run(["gcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "chz_minimal.c"),
+                        "-L", pkgdir, "-lchz_hip", "-Wl,-rpath," + pkgdir, "-lm", "-o", exe], check=True)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "within" in r.stdout
