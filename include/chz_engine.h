@@ -52,6 +52,7 @@ typedef struct chz_timing {
   double first_ms, cols_ms, rows_ms, notch_ms, chan_ms;   /* notch_ms/notch_n: the noise-estimate kernel (the spur notch is fused into fwd_rows) */
   int first_n, cols_n, rows_n, notch_n, chan_n;
   double enqueue_ms;        /* host wall time spent issuing the launches (close to total_ms = host-bound) */
+  double fix_ms; int fix_n; /* the spur-notch kernel (notch_fix) */
 } chz_timing;
 
 const char *chz_last_error(void);
@@ -95,6 +96,10 @@ int chz_forward(chz_engine *e, unsigned job);
 /* notch list as radio.c builds it (src/radio.c:601-620): last entry is bin 0;
  * replaces apply_notch_filters' state (src/filter.c:464-474).  n = 0 clears. */
 int chz_set_notches(chz_engine *e, const int *bins, int n, double alpha);
+/* the same with one averager gain per entry, as struct notch_state carries it (src/filter.h:42-46, src/filter.c:468);
+ * an entry with alpha = 0 is the reference's no-op.  The recurrence over blocks is carried by HIP events between
+ * the engine's streams (no kernel waits for another kernel on the device). */
+int chz_set_notches_alpha(chz_engine *e, const int *bins, const double *alpha, int n);
 int chz_spectrum_read(chz_engine *e, int slot, float *host);     /* 2*bins floats, synchronous */
 int chz_spectrum_device(chz_engine *e, int slot, float **dev);
 /* the hipStream_t everything addressed by `slot` is enqueued on; lets a caller order foreign work
@@ -111,6 +116,12 @@ int chz_bank_create(chz_engine *e, int P, int olen, int capacity);          /* r
  * responses are still P complex values per channel (set_filter's array, of which bins 0..P/2 are used), outputs are
  * olen floats per channel; P must be even */
 int chz_bank_create_real(chz_engine *e, int P, int olen, int capacity);
+/* None of the per-channel setters below waits for blocks in flight: shifts, tuning, ISB flags and beam weights live in
+ * small descriptors kept once per spectrum slot and refreshed in stream order when the next block of that slot is
+ * enqueued (blocks already enqueued keep what they were launched with); a response is written to a spare row and the
+ * channel re-pointed, the old row being recycled once everything enqueued before the swap has drained.  Only edits of
+ * more than 8192 channels at once (a bank being set up) and the first use of a feature that switches the kernel
+ * variant (tuning, ISB, beam, noise) drain the engine. */
 /* response[P] complex as set_filter leaves it (src/filter.c:968-1045) */
 int chz_bank_set_responses(chz_engine *e, int bank, int ch0, int n, const float *resp);
 /* `shift` of execute_filter_output(slave, shift) (src/filter.c:663) */
@@ -141,7 +152,7 @@ int chz_bank_execute_range(chz_engine *e, int bank, unsigned job, int ch0, int n
  *   freq[i]    cycles per OUTPUT sample, = -remainder / output samprate   (first argument of set_osc)
  *   rate[i]    cycles per sample^2,       = doppler_rate / samprate^2     (second argument; NULL = 0)
  * The update takes effect at block `job`, which must not have been enqueued yet; call it when shift,
- * remainder or sweep rate change (it synchronises the engine), not every block.  The rotation is a closed
+ * remainder or sweep rate change (it does not wait for the engine), not every block.  The rotation is a closed
  * form in the block number, so tuned banks run eagerly (chz_run_blocks mode 0), any number in flight. */
 int chz_bank_set_tuning(chz_engine *e, int bank, unsigned job, int ch0, int n, const int *shifts,
                         const double *freq, const double *rate);
@@ -170,6 +181,8 @@ int chz_spectrum_read_async(chz_engine *e, int slot, float *host);
 /* run fn(arg) on a runtime thread once everything enqueued so far on `slot`'s lane has finished: replaces
  * run_fft's completion broadcast (src/filter.c:522-539) */
 int chz_host_callback(chz_engine *e, int slot, void (*fn)(void *), void *arg);
+/* wait for everything enqueued on `slot`'s lane only (the other lanes keep running) */
+int chz_slot_sync(chz_engine *e, int slot);
 /* page-locked host memory for the buffers the device copies into */
 int chz_host_alloc(void **p, size_t bytes);
 void chz_host_free(void *p);
@@ -188,6 +201,32 @@ int chz_step(chz_engine *e, unsigned job);
  *   instrument != 0 (eager only): HIP events around every kernel -> per-kernel ms */
 int chz_run_blocks(chz_engine *e, unsigned job0, int nblocks, int mode, int instrument,
                    chz_timing *timing);
+
+/* ---- multi-GPU (north_star: "the forward spectrum is RCCL-broadcast over xGMI and each GPU owns a disjoint
+ * channel subset, overlapped with the next block's forward FFT on a second HIP stream").  One process per GPU and one
+ * communicator per process; the reference has no counterpart (thread per channel in one process).  RCCL is bound at
+ * run time.  Rank 0 obtains an id and ships its CHZ_COMM_ID_BYTES bytes to the peers by any means (or all ranks meet
+ * through a file with chz_comm_create_file). */
+#define CHZ_COMM_ID_BYTES 128
+typedef struct chz_comm chz_comm;
+int chz_comm_unique_id(void *id128);
+int chz_comm_create(chz_comm **out, int rank, int world, const void *id128, int device);
+int chz_comm_create_file(chz_comm **out, int rank, int world, const char *path, int device, double timeout_s);
+void chz_comm_destroy(chz_comm *c);
+int chz_comm_rank(const chz_comm *c);
+int chz_comm_world(const chz_comm *c);
+int chz_comm_barrier(chz_comm *c);
+int chz_comm_allreduce_max(chz_comm *c, double *v, int n);           /* n <= 64, blocking: control plane only */
+/* ncclBroadcast of spectrum slot `slot` (all spec_elems complex values) from `root`, enqueued on the slot's stream:
+ * behind chz_forward(job) on the root, in front of chz_bank_execute(.., job) everywhere */
+int chz_spectrum_broadcast(chz_engine *e, chz_comm *c, int slot, int root);
+/* sub-band variant: rank r receives only spectrum rows [row_lo[r], row_hi[r]) (row = spec_pitch complex values),
+ * one grouped ncclSend/ncclRecv */
+int chz_spectrum_exchange_rows(chz_engine *e, chz_comm *c, int slot, int root, const int *row_lo, const int *row_hi);
+/* BASELINE config 4 from a C host: per block the root transforms, the spectrum travels (mode 0 broadcast, 1 rows),
+ * every rank runs its own banks; timed like chz_run_blocks */
+int chz_run_blocks_sharded(chz_engine *e, chz_comm *c, int root, int mode, const int *row_lo, const int *row_hi,
+                           unsigned job0, int nblocks, chz_timing *timing);
 
 /* host-side helper exposed for tests: the closed-form gather descriptor
  * {t0,cnt,src0,dir,conj,wrap} that restates src/filter.c:728-911 */

@@ -1,16 +1,25 @@
 // chz_engine.hip -- device-side engine behind include/chz_engine.h.
 //
-// Owns the HBM-resident state of one master (input ring, intermediate buffer,
+// Owns the HBM-resident state of one master (input ring, intermediate buffers,
 // ND spectrum slots, twiddle tables) and of its channel banks, and launches the
-// kernels of chz_kernels.h on one HIP stream.  Everything per block is enqueued
-// asynchronously; a ring cycle of blocks can be captured into a hipGraph so the
-// launch-bound inner loop costs one graph replay.  gfx950 only, no fallback.
+// kernels of chz_kernels.h.  Blocks are pipelined over 1/2/4 HIP streams ("lanes");
+// everything per block is enqueued asynchronously.  Nothing in here makes a kernel
+// wait for another kernel from inside the device: the one cross-block dependency of
+// the path (the spur-notch recurrence) is carried by HIP events between the lanes.
+// Retunes never drain the pipeline: the small per-channel descriptors exist once per
+// spectrum slot and are refreshed in stream order, responses are swapped by row.
+// gfx950 only, no fallback.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <chrono>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <thread>
@@ -29,42 +38,111 @@ static int fail(int code, const char* fmt, ...) {
 #define HIPOK(call) do { hipError_t _e = (call); if (_e != hipSuccess) \
   return fail(-10, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
 
+#define CHZ_MAX_LANES 4
+#define CHZ_STAGE_CAP 8192          // channels per staged descriptor refresh; larger edits take the bulk path
+
+// One retired batch of response rows: reusable once everything enqueued before the swap has drained
+struct Retired {
+  std::vector<int> rows;
+  hipEvent_t ev[CHZ_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+};
+
 struct Bank {
   int P = 0, olen = 0, cap = 0, active = 0;
   int out_real = 0;             // 1: REAL-output slaves (olen floats per channel, chan_c2r); 0: COMPLEX
   ChanGeom g;
-  float2* resp = nullptr;       // [cap][P]
-  ChanDesc* desc = nullptr;     // [cap]
+  float2* resp = nullptr;       // [cap + spare][P]; a channel's row is desc.row
+  int rows_total = 0;
+  std::vector<int> free_rows;
+  std::deque<Retired> retired;
   float2* out = nullptr;        // [ND][cap][olen]: one output image per spectrum slot
   float2* tw_sub = nullptr;
   int last_slot = 0;            // slot of the most recent execute (what chz_bank_read returns)
-  // fine tuning (tail of downconvert(), src/radio.c:1476-1520); allocated by the first chz_bank_set_tuning
-  std::vector<FineHost> fine_h; // [cap]
-  FineDesc* fine = nullptr;     // [cap]
-  double* power = nullptr;      // [ND][cap]
-  // estimate_noise() on the device (src/radio.c:1783-1866); allocated by chz_bank_enable_noise
-  int* shifts = nullptr;        // [cap] the channels' bin shifts
-  double* n0 = nullptr;         // [ND][cap]
+  // host master copies of the small per-channel state; the device holds one copy per spectrum slot
+  std::vector<ChanDesc> desc_h;          // [cap]
+  std::vector<FineHost> fine_h;          // [cap] fine-tuning bookkeeping (chz_finetune.h)
+  std::vector<FineDesc> fine_dh;         // [cap]
+  std::vector<unsigned char> isb_h;      // [cap]
+  std::vector<BeamDesc> beam_h;          // [cap]
+  ChanDesc* desc = nullptr;     // [ND][cap]
+  FineDesc* fine = nullptr;     // [ND][cap], allocated by the first chz_bank_set_tuning
+  unsigned char* isb = nullptr; // [ND][cap], allocated by chz_bank_set_isb
+  BeamDesc* beam = nullptr;     // [ND][cap], allocated by chz_bank_set_beam
+  int dirty_lo[CHZ_ND], dirty_hi[CHZ_ND];           // channels whose slot copy is older than the host copy
+  char* stage[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging of one refresh per slot
+  hipEvent_t stage_ev[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};
+  bool stage_busy[CHZ_ND] = {false, false, false, false};
+  double* power = nullptr;      // [ND][cap] (tail of downconvert(), src/radio.c:1516-1520)
+  double* n0 = nullptr;         // [ND][cap] estimate_noise() (src/radio.c:1783-1866)
   double noise_samprate = 0.0;  // front-end sample rate; 0 = off
-  unsigned char* isb = nullptr; // [cap] slave->isb flags (src/filter.c:895-909); allocated by chz_bank_set_isb
-  BeamDesc* beam = nullptr;     // [cap] slave->beam + weights (src/filter.c:756-775); allocated by chz_bank_set_beam
 };
 
 // A lane = one HIP stream + its own intermediate buffer.  Consecutive blocks go to
 // consecutive lanes, so block j+1's forward transform overlaps block j's tail and channel
 // kernel (the "second HIP stream" of the north star).
-#define CHZ_MAX_LANES 4
 struct Lane {
   hipStream_t s = nullptr;
   float2* buf = nullptr;
 };
 
+// A persistent host thread that issues the launches of a subset of the lanes.  It spins for a short while
+// after each task so that back-to-back chz_run_blocks calls do not pay a wake-up, then sleeps.
+struct Issuer {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::atomic<int> state{0};      // 0 idle, 1 task posted, 2 task done, 3 quit
+  bool sleeping = false;
+  std::function<void()> fn;
+  void loop() {
+    for (;;) {
+      int spins = 0;
+      for (;;) {
+        const int s = state.load(std::memory_order_acquire);
+        if (s == 1 || s == 3) break;
+        if (++spins < 20000) { __builtin_ia32_pause(); continue; }
+        std::unique_lock<std::mutex> lk(m);
+        sleeping = true;
+        cv.wait(lk, [&] { const int t = state.load(std::memory_order_acquire); return t == 1 || t == 3; });
+        sleeping = false;
+      }
+      if (state.load(std::memory_order_acquire) == 3) return;
+      fn();
+      state.store(2, std::memory_order_release);
+    }
+  }
+  void post(std::function<void()> f) {
+    fn = std::move(f);
+    std::lock_guard<std::mutex> lk(m);
+    state.store(1, std::memory_order_release);
+    if (sleeping) cv.notify_one();
+  }
+  void wait() {
+    while (state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
+    state.store(0, std::memory_order_release);
+  }
+  void quit() {
+    { std::lock_guard<std::mutex> lk(m); state.store(3, std::memory_order_release); cv.notify_one(); }
+    if (th.joinable()) th.join();
+  }
+};
+
+// Hand-over between issuing threads: the notch section of block number `next` (counted from the start of
+// the run) may be issued; see enqueue_forward().
+struct NotchTurn {
+  std::atomic<int> next{0};
+  std::atomic<int> abort{0};
+};
+
+#define CHZ_NOTCH_EVENTS 8
+
 struct chz_engine {
   int L = 0, M = 0, N = 0, in_type = 0, bins = 0, per = 1, device = 0, ring_blocks = 0;
   FwdPlan plan;
   int chan_stage = -1;              // output staging of chan_ifft: -1 by launch size, 0 never, 1 always (env CHZ_CHAN_STAGE)
-  hipStream_t stream = nullptr;     // == lanes[0].s: copies and anything not tied to a block
+  hipStream_t stream = nullptr;     // == lanes[0].s: input copies and anything not tied to a block
   bool own_stream = false;
+  hipStream_t upload = nullptr;     // control-plane uploads (responses): never waits for, or stalls, a lane
   Lane lanes[CHZ_MAX_LANES];
   int nlanes = 1;
   hipEvent_t input_ready = nullptr; // after the latest ring write
@@ -78,10 +156,17 @@ struct chz_engine {
   bool spec_owned[CHZ_ND] = {false, false, false, false};
   float2 *tw_sub_a = nullptr, *tw_sub_b = nullptr, *tw_sub_c = nullptr;
   float2 *tw1_tile = nullptr, *tw1_col = nullptr, *tw2_tile = nullptr, *tw2_col = nullptr;
-  int n_notch = 0; NotchLoc* notch_loc = nullptr; double* notch_state = nullptr; double notch_alpha = 0;
-  unsigned* notch_ver = nullptr; bool notch_armed = false; unsigned notch_next = 0;   // ticket counters; first job after (re)arming
+  // spur notches: device tables + the event chain that orders the recurrence across lanes
+  int n_notch = 0;
+  int *notch_addr = nullptr, *notch_next = nullptr, *notch_head = nullptr;
+  double* notch_alpha = nullptr; double* notch_state = nullptr;
+  hipEvent_t notch_ev[CHZ_NOTCH_EVENTS] = {};
+  unsigned notch_seq = 0; bool notch_have = false;      // notch_ev[(notch_seq-1) % 8] is the latest recorded one
   std::vector<Bank> banks;
   hipGraphExec_t graph = nullptr; unsigned graph_job0 = 0; int graph_blocks = 0;
+  // chz_run_blocks: events and issuing threads live as long as the engine
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_fork = nullptr, ev_join[CHZ_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<Issuer*> issuers;
 };
 
 static int sync_all(chz_engine* e);
@@ -92,6 +177,22 @@ template <class T> static int upload(T** dst, const std::vector<f2>& v) {
   HIPOK(hipMalloc((void**)dst, v.size() * sizeof(f2)));
   HIPOK(hipMemcpy(*dst, v.data(), v.size() * sizeof(f2), hipMemcpyHostToDevice));
   return 0;
+}
+
+static void free_bank(Bank& b) {
+  hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub);
+  hipFree(b.fine); hipFree(b.power); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam);
+  for (int s = 0; s < CHZ_ND; s++) {
+    if (b.stage[s]) (void)hipHostFree(b.stage[s]);
+    if (b.stage_ev[s]) (void)hipEventDestroy(b.stage_ev[s]);
+    b.stage[s] = nullptr; b.stage_ev[s] = nullptr; b.stage_busy[s] = false;
+  }
+  for (auto& r : b.retired) for (auto ev : r.ev) if (ev) (void)hipEventDestroy(ev);
+  b.retired.clear(); b.free_rows.clear();
+  b.resp = nullptr; b.desc = nullptr; b.out = nullptr; b.tw_sub = nullptr; b.fine = nullptr; b.power = nullptr;
+  b.n0 = nullptr; b.isb = nullptr; b.beam = nullptr; b.noise_samprate = 0.0;
+  b.desc_h.clear(); b.fine_h.clear(); b.fine_dh.clear(); b.isb_h.clear(); b.beam_h.clear();
+  b.active = 0; b.cap = 0;
 }
 
 extern "C" {
@@ -139,11 +240,16 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   e->ring_len = (long)ring_blocks * L * e->per;
   HIPOK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   e->own_stream = true;
+  HIPOK(hipStreamCreateWithFlags(&e->upload, hipStreamNonBlocking));
   if (const char* cs = getenv("CHZ_CHAN_STAGE")) e->chan_stage = atoi(cs) != 0;
   const char* envl = getenv("CHZ_STREAMS");
   int nl = envl ? atoi(envl) : 4;
   e->nlanes = (nl >= 4) ? 4 : (nl >= 2) ? 2 : 1;             // must divide ND so slot and lane stay aligned
   HIPOK(hipEventCreateWithFlags(&e->input_ready, hipEventDisableTiming));
+  HIPOK(hipEventCreate(&e->ev_t0)); HIPOK(hipEventCreate(&e->ev_t1));
+  HIPOK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  for (int i = 0; i < CHZ_MAX_LANES; i++) HIPOK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
+  for (int i = 0; i < CHZ_NOTCH_EVENTS; i++) HIPOK(hipEventCreateWithFlags(&e->notch_ev[i], hipEventDisableTiming));
   for (int i = 0; i < e->nlanes; i++) {
     if (i == 0) e->lanes[i].s = e->stream;
     else HIPOK(hipStreamCreateWithFlags(&e->lanes[i].s, hipStreamNonBlocking));
@@ -173,25 +279,37 @@ static void drop_graph(chz_engine* e) {
   if (e->graph) { hipGraphExecDestroy(e->graph); e->graph = nullptr; }
 }
 
+static void free_notches(chz_engine* e) {
+  hipFree(e->notch_addr); hipFree(e->notch_next); hipFree(e->notch_head); hipFree(e->notch_alpha); hipFree(e->notch_state);
+  e->notch_addr = e->notch_next = e->notch_head = nullptr; e->notch_alpha = nullptr; e->notch_state = nullptr;
+  e->n_notch = 0; e->notch_have = false;
+}
+
 void chz_engine_destroy(chz_engine* e) {
   if (!e) return;
   hipSetDevice(e->device);
+  for (Issuer* is : e->issuers) { is->quit(); delete is; }
+  e->issuers.clear();
   for (int i = 0; i < e->nlanes; i++) if (e->lanes[i].s) hipStreamSynchronize(e->lanes[i].s);
+  if (e->upload) hipStreamSynchronize(e->upload);
   drop_graph(e);
   for (int i = 0; i < e->nlanes; i++) {
     hipFree(e->lanes[i].buf);
     if (i > 0 && e->lanes[i].s) hipStreamDestroy(e->lanes[i].s);
   }
   if (e->input_ready) hipEventDestroy(e->input_ready);
-  for (auto& b : e->banks) {
-    hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub);
-    hipFree(b.fine); hipFree(b.power); hipFree(b.shifts); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam);
-  }
+  if (e->ev_t0) hipEventDestroy(e->ev_t0);
+  if (e->ev_t1) hipEventDestroy(e->ev_t1);
+  if (e->ev_fork) hipEventDestroy(e->ev_fork);
+  for (auto ev : e->ev_join) if (ev) hipEventDestroy(ev);
+  for (auto ev : e->notch_ev) if (ev) hipEventDestroy(ev);
+  for (auto& b : e->banks) free_bank(b);
   hipFree(e->ring); hipFree(e->ring16); hipFree(e->energy_part); hipFree(e->clip_part);
   for (int i = 0; i < CHZ_ND; i++) if (e->spec_owned[i]) hipFree(e->spec[i]);
   hipFree(e->tw_sub_a); hipFree(e->tw_sub_b); hipFree(e->tw_sub_c);
   hipFree(e->tw1_tile); hipFree(e->tw1_col); hipFree(e->tw2_tile); hipFree(e->tw2_col);
-  hipFree(e->notch_loc); hipFree(e->notch_state); hipFree(e->notch_ver);
+  free_notches(e);
+  if (e->upload) hipStreamDestroy(e->upload);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
 }
@@ -219,6 +337,7 @@ int chz_engine_set_stream(chz_engine* e, void* hip_stream) {
   if (e->own_stream) { hipStreamDestroy(e->stream); e->own_stream = false; }
   e->stream = (hipStream_t)hip_stream;
   e->lanes[0].s = e->stream;
+  e->notch_have = false;
   return 0;
 }
 
@@ -315,7 +434,7 @@ struct Instr {      // optional per-kernel timing: one (begin, end) event pair p
   ~Instr() { for (auto e : ev) hipEventDestroy(e); }
   bool on = false;
   std::vector<hipEvent_t> ev;   // 2 per launch: dispatch begin / end timestamps
-  std::vector<int> kind;        // 0 first, 1 cols, 2 rows, 3 (unused), 4 chan
+  std::vector<int> kind;        // 0 first, 1 cols, 2 rows, 3 noise, 4 chan, 5 notch fix
   hipEvent_t e0 = nullptr, e1 = nullptr;   // pair for the launch being issued
 };
 // begin=true: allocate the pair the next launch will carry; begin=false: nothing (kept for symmetry)
@@ -333,21 +452,49 @@ static inline int lane_of(const chz_engine* e, unsigned job, const Instr* in) {
   return (in && in->on) ? 0 : (int)(job % (unsigned)e->nlanes);
 }
 
-// The ticket counters must read `job` when block `job` arrives.  They count on their own as long as
-// jobs are consecutive; after set_notches, or when the caller jumps to another job number (tests,
-// run_blocks restarts), they are re-seeded -- which needs the device to be idle.
-static int arm_notch_tickets(chz_engine* e, unsigned job) {
+// K2 for one block.  apply_notch_filters (src/filter.c:464-474) is a recurrence over blocks, and consecutive
+// blocks live on different streams: block j's notch_fix waits for the EVENT recorded behind block j-1's
+// notch_fix, then records its own.  Ordering is stream semantics only -- no kernel ever waits for another
+// kernel from inside the device, so it holds under any stream-to-hardware-queue mapping (GPU_MAX_HW_QUEUES,
+// several engines per process, a profiler that serialises dispatches).  With more than one issuing host
+// thread the record of block j-1 must have been ISSUED before block j's wait is (a wait on a not yet
+// recorded event is a no-op): `turn` hands the notch section from thread to thread in block order.
+// capture_first: first block of a graph capture -- the previous graph launch is ordered by the launching
+// stream, and an event recorded outside the capture must not be waited on inside it.
+static int enqueue_notch(chz_engine* e, int slot, hipStream_t st, Instr* in, NotchTurn* turn, int seq, bool capture_first) {
   if (e->n_notch <= 0) return 0;
-  if (e->notch_armed && e->notch_next == job) { e->notch_next = job + 1; return 0; }
-  int r = sync_all(e);
-  if (r) return r;
-  std::vector<unsigned> v((size_t)e->n_notch, job);
-  HIPOK(hipMemcpy(e->notch_ver, v.data(), sizeof(unsigned) * v.size(), hipMemcpyHostToDevice));
-  e->notch_armed = true; e->notch_next = job + 1;
-  return 0;
+  if (turn) {
+    while (turn->next.load(std::memory_order_acquire) != seq) {
+      if (turn->abort.load(std::memory_order_relaxed)) return fail(-6, "another issuing thread failed");
+      __builtin_ia32_pause();
+    }
+  }
+  int rc = 0;
+  do {
+    if (e->notch_have && !capture_first && e->nlanes > 1) {
+      hipError_t he = hipStreamWaitEvent(st, e->notch_ev[(e->notch_seq - 1u) % CHZ_NOTCH_EVENTS], 0);
+      if (he != hipSuccess) { rc = fail(-10, "hipStreamWaitEvent failed: %s", hipGetErrorString(he)); break; }
+    }
+    NotchFixParams q{};
+    q.spec = e->spec[slot]; q.addr = e->notch_addr; q.next = e->notch_next; q.head = e->notch_head;
+    q.alpha = e->notch_alpha; q.state = e->notch_state; q.n = e->n_notch;
+    mark(in, st, 5, true);
+    launch_notch_fix(st, q, IN_E0(in), IN_E1(in));
+    mark(in, st, 5, false);
+    if (e->nlanes > 1) {
+      hipError_t he = hipEventRecord(e->notch_ev[e->notch_seq % CHZ_NOTCH_EVENTS], st);
+      if (he != hipSuccess) { rc = fail(-10, "hipEventRecord failed: %s", hipGetErrorString(he)); break; }
+      e->notch_seq++; e->notch_have = true;
+    }
+  } while (0);
+  if (turn) {
+    if (rc) turn->abort.store(1, std::memory_order_relaxed);
+    turn->next.store(seq + 1, std::memory_order_release);
+  }
+  return rc;
 }
 
-static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
+static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* turn = nullptr, int seq = 0, bool capture_first = false) {
   const FwdPlan& p = e->plan;
   const int slot = job % CHZ_ND;
   const int ln = lane_of(e, job, in);
@@ -387,12 +534,10 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in) {
   c.lay = SpecLayout{p.Na, p.spec_pitch, p.spec_off}; c.ka_shift = p.ka_shift;
   c.buf = lbuf; c.spec = e->spec[slot]; c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3;
   c.padg = p.padg3; c.N = p.N; c.mirror = e->in_type == CHZ_REAL; c.tw_sub = e->tw_sub_c;
-  c.n_notch = e->n_notch; c.notch_loc = e->notch_loc; c.notch_state = e->notch_state; c.notch_alpha = e->notch_alpha;
-  c.notch_ver = e->notch_ver; c.job = job;
   mark(in, st, 2, true);
   if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis c");
   mark(in, st, 2, false);
-  return 0;
+  return enqueue_notch(e, slot, st, in, turn, seq, capture_first);
 }
 
 // output image of one slot; a sample is one float (REAL banks) or one float2
@@ -404,6 +549,76 @@ static inline char* bank_out_at(const Bank& b, int slot, int ch) {
   return reinterpret_cast<char*>(bank_out(b, slot)) + (size_t)ch * b.olen * bank_sample_bytes(b);
 }
 
+// ---- per-slot descriptors ------------------------------------------------------
+static inline void mark_dirty(Bank& b, int ch0, int n) {
+  for (int s = 0; s < CHZ_ND; s++) {
+    if (ch0 < b.dirty_lo[s]) b.dirty_lo[s] = ch0;
+    if (ch0 + n > b.dirty_hi[s]) b.dirty_hi[s] = ch0 + n;
+  }
+}
+static inline size_t stage_bytes_per_channel() { return sizeof(ChanDesc) + sizeof(FineDesc) + sizeof(BeamDesc) + 1; }
+
+// Bring slot `slot`'s device copy of the descriptors up to the host copy, in stream order on `st`: blocks already
+// enqueued on this slot keep what they were launched with, blocks of other slots are not touched at all.
+static int refresh_slot(chz_engine* e, Bank& b, int slot, hipStream_t st) {
+  int lo = b.dirty_lo[slot], hi = b.dirty_hi[slot];
+  if (lo >= hi) return 0;
+  if (hi > b.cap) hi = b.cap;
+  const int chunk = b.cap < CHZ_STAGE_CAP ? b.cap : CHZ_STAGE_CAP;
+  if (!b.stage[slot]) {
+    HIPOK(hipHostMalloc((void**)&b.stage[slot], stage_bytes_per_channel() * (size_t)chunk, hipHostMallocDefault));
+    HIPOK(hipEventCreateWithFlags(&b.stage_ev[slot], hipEventDisableTiming));
+  }
+  for (int c0 = lo; c0 < hi; c0 += chunk) {
+    const int n = hi - c0 < chunk ? hi - c0 : chunk;
+    if (b.stage_busy[slot]) HIPOK(hipEventSynchronize(b.stage_ev[slot]));   // the previous refresh of this slot: long done
+    char* sp = b.stage[slot];
+    memcpy(sp, b.desc_h.data() + c0, sizeof(ChanDesc) * (size_t)n);
+    HIPOK(hipMemcpyAsync(b.desc + (size_t)slot * b.cap + c0, sp, sizeof(ChanDesc) * (size_t)n, hipMemcpyHostToDevice, st));
+    sp += sizeof(ChanDesc) * (size_t)n;
+    if (b.fine) {
+      memcpy(sp, b.fine_dh.data() + c0, sizeof(FineDesc) * (size_t)n);
+      HIPOK(hipMemcpyAsync(b.fine + (size_t)slot * b.cap + c0, sp, sizeof(FineDesc) * (size_t)n, hipMemcpyHostToDevice, st));
+      sp += sizeof(FineDesc) * (size_t)n;
+    }
+    if (b.beam) {
+      memcpy(sp, b.beam_h.data() + c0, sizeof(BeamDesc) * (size_t)n);
+      HIPOK(hipMemcpyAsync(b.beam + (size_t)slot * b.cap + c0, sp, sizeof(BeamDesc) * (size_t)n, hipMemcpyHostToDevice, st));
+      sp += sizeof(BeamDesc) * (size_t)n;
+    }
+    if (b.isb) {
+      memcpy(sp, b.isb_h.data() + c0, (size_t)n);
+      HIPOK(hipMemcpyAsync(b.isb + (size_t)slot * b.cap + c0, sp, (size_t)n, hipMemcpyHostToDevice, st));
+    }
+    HIPOK(hipEventRecord(b.stage_ev[slot], st));
+    b.stage_busy[slot] = true;
+  }
+  b.dirty_lo[slot] = b.cap; b.dirty_hi[slot] = 0;
+  return 0;
+}
+// Large edits (a whole bank being set up): drain once and write all four slot copies directly.
+static int refresh_all_bulk(chz_engine* e, Bank& b) {
+  int r = sync_all(e);
+  if (r) return r;
+  for (int s = 0; s < CHZ_ND; s++) {
+    int lo = b.dirty_lo[s], hi = b.dirty_hi[s];
+    if (lo >= hi) continue;
+    if (hi > b.cap) hi = b.cap;
+    const size_t n = (size_t)(hi - lo), off = (size_t)s * b.cap + lo;
+    HIPOK(hipMemcpy(b.desc + off, b.desc_h.data() + lo, sizeof(ChanDesc) * n, hipMemcpyHostToDevice));
+    if (b.fine) HIPOK(hipMemcpy(b.fine + off, b.fine_dh.data() + lo, sizeof(FineDesc) * n, hipMemcpyHostToDevice));
+    if (b.beam) HIPOK(hipMemcpy(b.beam + off, b.beam_h.data() + lo, sizeof(BeamDesc) * n, hipMemcpyHostToDevice));
+    if (b.isb) HIPOK(hipMemcpy(b.isb + off, b.isb_h.data() + lo, n, hipMemcpyHostToDevice));
+    b.dirty_lo[s] = b.cap; b.dirty_hi[s] = 0;
+  }
+  return 0;
+}
+static int after_edit(chz_engine* e, Bank& b, int ch0, int n) {
+  mark_dirty(b, ch0, n);
+  if (n > CHZ_STAGE_CAP) return refresh_all_bulk(e, b);
+  return 0;
+}
+
 static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch0 = 0, int n = -1) {
   Bank& b = e->banks[(size_t)bank];
   if (n < 0) n = b.active;
@@ -411,24 +626,26 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   const int slot = (int)(job % CHZ_ND);
   hipStream_t st = e->lanes[lane_of(e, (unsigned)slot, in)].s;
   b.last_slot = slot;
+  { int r = refresh_slot(e, b, slot, st); if (r) return r; }
+  const size_t so = (size_t)slot * b.cap;
   ChanParams c{};
   c.lay = SpecLayout{e->plan.Na, e->plan.spec_pitch, e->plan.spec_off}; c.inv_na = 1.0f / (float)e->plan.Na;
-  c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc; c.out = bank_out(b, slot); c.ch0 = ch0; c.nch = n; c.olen = b.olen;
+  c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc + so; c.out = bank_out(b, slot); c.ch0 = ch0; c.nch = n; c.olen = b.olen;
   c.tw_sub = b.tw_sub;
   c.stage = e->chan_stage >= 0 ? e->chan_stage : (n >= 16384);
-  c.isb = b.isb; c.beam = b.beam;
-  c.fine = b.fine; c.power = b.power ? b.power + (size_t)slot * b.cap : nullptr; c.job = job;
+  c.isb = b.isb ? b.isb + so : nullptr; c.beam = b.beam ? b.beam + so : nullptr;
+  c.fine = b.fine ? b.fine + so : nullptr; c.power = b.power ? b.power + so : nullptr; c.job = job;
   const int per_block = b.g.wpb * b.g.cpw;
   const int grid = (n + per_block - 1) / per_block;
   mark(in, st, 4, true);
   if (b.out_real) {
-    c.shifts = b.shifts; c.m_bins = e->bins; c.m_real = e->in_type == CHZ_REAL; c.fine = nullptr; c.power = nullptr; c.stage = 0;
+    c.m_bins = e->bins; c.m_real = e->in_type == CHZ_REAL; c.fine = nullptr; c.power = nullptr; c.stage = 0;
     if (launch_chan_real(b.g.r, grid, b.g.wpb * 64, b.g.lds, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no real-output kernel for P=%d", b.P);
   } else if (launch_chan(b.g.r, grid, b.g.wpb * 64, b.g.lds, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for P=%d", b.P);
   mark(in, st, 4, false);
   if (b.n0 && b.noise_samprate > 0.0) {
     NoiseParams q = noise_params(e->bins, e->in_type == CHZ_REAL, b.out_real ? b.P / 2 + 1 : b.P, b.noise_samprate);   // slave->bins
-    q.spec = e->spec[slot]; q.lay = c.lay; q.shift = b.shifts; q.n0 = b.n0 + (size_t)slot * b.cap; q.ch0 = ch0; q.nch = n;
+    q.spec = e->spec[slot]; q.lay = c.lay; q.desc = b.desc + so; q.n0 = b.n0 + so; q.ch0 = ch0; q.nch = n;
     mark(in, st, 3, true);
     if (launch_noise(n, st, q, IN_E0(in), IN_E1(in))) return fail(-4, "no noise kernel for a %d-bin window", q.nbins);
     mark(in, st, 3, false);
@@ -439,44 +656,37 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
 int chz_forward(chz_engine* e, unsigned job) {
   if (!e) return fail(-1, "null engine");
   HIPOK(hipSetDevice(e->device));
-  int r = arm_notch_tickets(e, job);
-  if (r) return r;
-  r = enqueue_forward(e, job, nullptr);
+  int r = enqueue_forward(e, job, nullptr);
   if (r) return r;
   HIPOK(hipGetLastError());
   return 0;
 }
 
-int chz_set_notches(chz_engine* e, const int* bins, int n, double alpha) {
+// notch list as radio.c builds it (src/radio.c:601-620), one averager gain per entry (src/filter.c:468)
+int chz_set_notches_alpha(chz_engine* e, const int* bins, const double* alpha, int n) {
   if (!e) return fail(-1, "null engine");
   { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
-  hipFree(e->notch_loc); hipFree(e->notch_state); hipFree(e->notch_ver);
-  e->notch_loc = nullptr; e->notch_state = nullptr; e->notch_ver = nullptr; e->n_notch = 0;
-  if (n <= 0 || !bins) return 0;
-  const FwdPlan& p = e->plan;
-  std::vector<NotchLoc> loc((size_t)n);
-  for (int i = 0; i < n; i++) {
+  free_notches(e);
+  if (n <= 0 || !bins || !alpha) return 0;
+  for (int i = 0; i < n; i++)
     if (bins[i] < 0 || bins[i] >= e->bins) return fail(-1, "notch bin %d out of range", bins[i]);
-    // which row / register of fwd_rows produces this bin (k = ka + Na*(kb + Nb*kc); the upper half
-    // of a real master's row lands conjugated at N-k)
-    long k = bins[i]; int mir = 0;
-    int qa = (int)(k % p.Na);
-    if (e->in_type == CHZ_REAL && 2 * qa > p.Na) { k = (long)p.N - bins[i]; qa = (int)(k % p.Na); mir = 1; }
-    const long rest = k / p.Na;
-    const int qb = (int)(rest % p.Nb), qc = (int)(rest / p.Nb);
-    loc[(size_t)i] = NotchLoc{qa, qb, qc % p.rc.r1, qc / p.rc.r1, mir};
-  }
-  HIPOK(hipMalloc((void**)&e->notch_loc, sizeof(NotchLoc) * (size_t)n));
-  HIPOK(hipMalloc((void**)&e->notch_state, sizeof(double) * 2 * (size_t)n));
-  HIPOK(hipMemcpy(e->notch_loc, loc.data(), sizeof(NotchLoc) * (size_t)n, hipMemcpyHostToDevice));
-  HIPOK(hipMemset(e->notch_state, 0, sizeof(double) * 2 * (size_t)n));
-  HIPOK(hipMalloc((void**)&e->notch_ver, sizeof(unsigned) * (size_t)n));
-  HIPOK(hipMemset(e->notch_ver, 0, sizeof(unsigned) * (size_t)n));   // re-armed for the next job by arm_notch_tickets()
+  NotchTables t = notch_tables(bins, n, SpecLayout{e->plan.Na, e->plan.spec_pitch, e->plan.spec_off});
+  const size_t ib = sizeof(int) * (size_t)n, db = sizeof(double) * (size_t)n;
+  HIPOK(hipMalloc((void**)&e->notch_addr, ib)); HIPOK(hipMalloc((void**)&e->notch_next, ib)); HIPOK(hipMalloc((void**)&e->notch_head, ib));
+  HIPOK(hipMalloc((void**)&e->notch_alpha, db)); HIPOK(hipMalloc((void**)&e->notch_state, 2 * db));
+  HIPOK(hipMemcpy(e->notch_addr, t.addr.data(), ib, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(e->notch_next, t.next.data(), ib, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(e->notch_head, t.head.data(), ib, hipMemcpyHostToDevice));
+  HIPOK(hipMemcpy(e->notch_alpha, alpha, db, hipMemcpyHostToDevice));
+  HIPOK(hipMemset(e->notch_state, 0, 2 * db));
   HIPOK(hipDeviceSynchronize());
-  e->notch_armed = false;
-  e->n_notch = n; e->notch_alpha = alpha;
+  e->n_notch = n;
   return 0;
+}
+int chz_set_notches(chz_engine* e, const int* bins, int n, double alpha) {
+  std::vector<double> a((size_t)(n > 0 ? n : 0), alpha);
+  return chz_set_notches_alpha(e, bins, a.data(), n);
 }
 
 static inline hipStream_t slot_stream(chz_engine* e, int slot) { return e->lanes[slot % e->nlanes].s; }
@@ -537,15 +747,21 @@ static int bank_create(chz_engine* e, int P, int olen, int capacity, int out_rea
   if (!build_chan_geom(P, b.g)) return fail(-3, "no channel kernel compiled for P=%d", P);
   HIPOK(hipSetDevice(e->device));
   // a failed allocation (the C_rt-sized banks take > 100 GB) must not leak the earlier ones
-  struct Guard { Bank* b; ~Guard() { if (b) { hipFree(b->resp); hipFree(b->desc); hipFree(b->shifts); hipFree(b->out); hipFree(b->tw_sub); } } } guard{&b};
+  struct Guard { Bank* b; ~Guard() { if (b) free_bank(*b); } } guard{&b};
   b.P = P; b.olen = olen; b.cap = capacity; b.active = 0; b.out_real = out_real;
   if (out_real && (P & 1)) return fail(-3, "real-output channels need an even P (got %d)", P);
-  HIPOK(hipMalloc((void**)&b.resp, sizeof(float2) * (size_t)capacity * P));
-  HIPOK(hipMemset(b.resp, 0, sizeof(float2) * (size_t)capacity * P));
-  HIPOK(hipMalloc((void**)&b.desc, sizeof(ChanDesc) * (size_t)capacity));
-  HIPOK(hipMemset(b.desc, 0, sizeof(ChanDesc) * (size_t)capacity));
-  HIPOK(hipMalloc((void**)&b.shifts, sizeof(int) * (size_t)capacity));
-  HIPOK(hipMemset(b.shifts, 0, sizeof(int) * (size_t)capacity));
+  // spare response rows: set_filter writes a spare row and re-points the channel, so a swap never waits for the pipeline
+  int spare = capacity / 16; if (spare < 16) spare = 16; if (spare > 4096) spare = 4096;
+  b.rows_total = capacity + spare;
+  HIPOK(hipMalloc((void**)&b.resp, sizeof(float2) * (size_t)b.rows_total * P));
+  HIPOK(hipMemset(b.resp, 0, sizeof(float2) * (size_t)b.rows_total * P));
+  for (int r = b.rows_total - 1; r >= capacity; r--) b.free_rows.push_back(r);
+  b.desc_h.assign((size_t)capacity, ChanDesc{0, 0, 0, 1, 0, 0, 0, 0});
+  for (int i = 0; i < capacity; i++) b.desc_h[(size_t)i].row = i;
+  HIPOK(hipMalloc((void**)&b.desc, sizeof(ChanDesc) * (size_t)CHZ_ND * capacity));
+  for (int s = 0; s < CHZ_ND; s++)
+    HIPOK(hipMemcpy(b.desc + (size_t)s * capacity, b.desc_h.data(), sizeof(ChanDesc) * (size_t)capacity, hipMemcpyHostToDevice));
+  for (int s = 0; s < CHZ_ND; s++) { b.dirty_lo[s] = capacity; b.dirty_hi[s] = 0; }
   HIPOK(hipMalloc((void**)&b.out, bank_sample_bytes(b) * (size_t)CHZ_ND * capacity * olen));
   HIPOK(hipMemset(b.out, 0, bank_sample_bytes(b) * (size_t)CHZ_ND * capacity * olen));
   int r = upload(&b.tw_sub, b.g.tw_sub);
@@ -553,7 +769,7 @@ static int bank_create(chz_engine* e, int P, int olen, int capacity, int out_rea
   HIPOK(hipDeviceSynchronize());       // null-stream memsets vs the engine's non-blocking streams
   drop_graph(e);
   guard.b = nullptr;
-  e->banks.push_back(b);
+  e->banks.push_back(std::move(b));
   return (int)e->banks.size() - 1;
 }
 
@@ -565,27 +781,77 @@ int chz_bank_create_real(chz_engine* e, int P, int olen, int capacity) { return 
   if (!(e) || (bank) < 0 || (bank) >= (int)(e)->banks.size()) return fail(-1, "bad bank"); \
   if ((ch0) < 0 || (n) < 0 || (ch0) + (n) > (e)->banks[(size_t)(bank)].cap) return fail(-1, "channel range out of bank capacity")
 
+// Move retired response rows whose fences have passed back to the free list; with `need` > 0 wait (briefly: at most the
+// blocks that were in flight when the rows were retired) until that many rows are free.
+static int reclaim_rows(chz_engine* e, Bank& b, size_t need) {
+  while (!b.retired.empty()) {
+    Retired& r = b.retired.front();
+    bool done = true;
+    for (int l = 0; l < e->nlanes && done; l++) done = hipEventQuery(r.ev[l]) == hipSuccess;
+    (void)hipGetLastError();      // hipEventQuery reports "not ready" through the sticky error
+    if (!done) {
+      if (b.free_rows.size() >= need) break;
+      for (int l = 0; l < e->nlanes; l++) HIPOK(hipEventSynchronize(r.ev[l]));
+    }
+    for (int row : r.rows) b.free_rows.push_back(row);
+    for (auto ev : r.ev) if (ev) (void)hipEventDestroy(ev);
+    b.retired.pop_front();
+  }
+  return 0;
+}
+
+// set_filter's hot swap (src/filter.c:1039-1043): the new response goes to a spare row over the upload stream, the
+// channel's descriptor is re-pointed (next block of every slot, in stream order), and the old row is recycled once
+// everything enqueued before the swap has drained.  Nothing waits for the pipeline.
 int chz_bank_set_responses(chz_engine* e, int bank, int ch0, int n, const float* resp) {
   BANK_CHECK(e, bank, ch0, n);
+  if (!resp) return fail(-1, "null argument");
   Bank& b = e->banks[(size_t)bank];
-  { int r = sync_all(e); if (r) return r; }   // no block may be using the old response
-  HIPOK(hipMemcpyAsync(b.resp + (size_t)ch0 * b.P, resp, sizeof(float2) * (size_t)n * b.P, hipMemcpyHostToDevice, e->stream));
-  HIPOK(hipStreamSynchronize(e->stream));   // caller's buffer may be pageable / reused
+  if (n == 0) return 0;
+  HIPOK(hipSetDevice(e->device));
+  const int spare_total = b.rows_total - b.cap;
+  if (n > spare_total / 2) {
+    // a whole bank being filled: drain once and write the channels' current rows in place
+    { int r = sync_all(e); if (r) return r; }
+    bool contiguous = true;
+    for (int i = 0; i < n && contiguous; i++) contiguous = b.desc_h[(size_t)(ch0 + i)].row == b.desc_h[(size_t)ch0].row + i;
+    if (contiguous) {
+      HIPOK(hipMemcpy(b.resp + (size_t)b.desc_h[(size_t)ch0].row * b.P, resp, sizeof(float2) * (size_t)n * b.P, hipMemcpyHostToDevice));
+    } else {
+      for (int i = 0; i < n; i++)
+        HIPOK(hipMemcpy(b.resp + (size_t)b.desc_h[(size_t)(ch0 + i)].row * b.P, resp + (size_t)2 * i * b.P, sizeof(float2) * (size_t)b.P, hipMemcpyHostToDevice));
+    }
+    return 0;
+  }
+  { int r = reclaim_rows(e, b, 0); if (r) return r; }
+  if (b.free_rows.size() < (size_t)n) { int r = reclaim_rows(e, b, (size_t)n); if (r) return r; }
+  if (b.free_rows.size() < (size_t)n) return fail(-7, "no spare response rows (%zu free, %d needed)", b.free_rows.size(), n);
+  Retired old;
+  for (int i = 0; i < n; i++) {
+    const int row = b.free_rows.back(); b.free_rows.pop_back();
+    HIPOK(hipMemcpyAsync(b.resp + (size_t)row * b.P, resp + (size_t)2 * i * b.P, sizeof(float2) * (size_t)b.P, hipMemcpyHostToDevice, e->upload));
+    old.rows.push_back(b.desc_h[(size_t)(ch0 + i)].row);
+    b.desc_h[(size_t)(ch0 + i)].row = row;
+  }
+  HIPOK(hipStreamSynchronize(e->upload));     // the caller's buffer may be pageable / reused; only the upload stream is waited for
+  for (int l = 0; l < e->nlanes; l++) {
+    HIPOK(hipEventCreateWithFlags(&old.ev[l], hipEventDisableTiming));
+    HIPOK(hipEventRecord(old.ev[l], e->lanes[l].s));
+  }
+  b.retired.push_back(std::move(old));
+  mark_dirty(b, ch0, n);
   return 0;
 }
 int chz_bank_set_shifts(chz_engine* e, int bank, int ch0, int n, const int* shifts) {
   BANK_CHECK(e, bank, ch0, n);
+  if (!shifts) return fail(-1, "null argument");
   Bank& b = e->banks[(size_t)bank];
-  std::vector<ChanDesc> d((size_t)n);
   for (int i = 0; i < n; i++) {
     ChanDescH h = make_chan_desc(e->in_type, e->bins, b.P, shifts[i]);
-    d[(size_t)i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
+    ChanDesc& d = b.desc_h[(size_t)(ch0 + i)];
+    d.t0 = h.t0; d.cnt = h.cnt; d.src0 = h.src0; d.dir = h.dir; d.conj = h.conj; d.wrap = h.wrap; d.shift = shifts[i];
   }
-  { int r = sync_all(e); if (r) return r; }
-  HIPOK(hipMemcpyAsync(b.desc + ch0, d.data(), sizeof(ChanDesc) * (size_t)n, hipMemcpyHostToDevice, e->stream));
-  HIPOK(hipMemcpyAsync(b.shifts + ch0, shifts, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
-  HIPOK(hipStreamSynchronize(e->stream));
-  return 0;
+  return after_edit(e, b, ch0, n);
 }
 // The tuning half of downconvert() (src/radio.c:1440-1441,1479-1497): bin shift for the gather plus the fine
 // oscillator.  Takes effect at block `job`; blocks before it must already have been enqueued.
@@ -598,31 +864,28 @@ int chz_bank_set_tuning(chz_engine* e, int bank, unsigned job, int ch0, int n, c
   if (e->M < 2) return fail(-1, "impulse length %d has no overlap factor", e->M);
   const int V = 1 + e->L / (e->M - 1);
   HIPOK(hipSetDevice(e->device));
+  for (int i = 0; i < n; i++)
+    if (!std::isfinite(freq[i]) || (rate && !std::isfinite(rate[i]))) return fail(-1, "non-finite tuning for channel %d", ch0 + i);
   if (!b.fine) {
+    { int r = sync_all(e); if (r) return r; }     // the kernel variant changes: one-time switch
     b.fine_h.assign((size_t)b.cap, FineHost());
-    HIPOK(hipMalloc((void**)&b.fine, sizeof(FineDesc) * (size_t)b.cap));
-    HIPOK(hipMemset(b.fine, 0, sizeof(FineDesc) * (size_t)b.cap));
+    b.fine_dh.assign((size_t)b.cap, FineDesc{0.0, 0.0, 0.0, 0u, 0, 1, 0});
+    HIPOK(hipMalloc((void**)&b.fine, sizeof(FineDesc) * (size_t)CHZ_ND * b.cap));
+    HIPOK(hipMemset(b.fine, 0, sizeof(FineDesc) * (size_t)CHZ_ND * b.cap));
     HIPOK(hipMalloc((void**)&b.power, sizeof(double) * (size_t)CHZ_ND * b.cap));
     HIPOK(hipMemset(b.power, 0, sizeof(double) * (size_t)CHZ_ND * b.cap));
     HIPOK(hipDeviceSynchronize());     // null-stream memsets vs the engine's non-blocking streams
     drop_graph(e);
   }
-  std::vector<ChanDesc> d((size_t)n);
-  std::vector<FineDesc> f((size_t)n);
   for (int i = 0; i < n; i++) {
-    if (!std::isfinite(freq[i]) || (rate && !std::isfinite(rate[i]))) return fail(-1, "non-finite tuning for channel %d", ch0 + i);
     ChanDescH h = make_chan_desc(e->in_type, e->bins, b.P, shifts[i]);
-    d[(size_t)i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
+    ChanDesc& d = b.desc_h[(size_t)(ch0 + i)];
+    d.t0 = h.t0; d.cnt = h.cnt; d.src0 = h.src0; d.dir = h.dir; d.conj = h.conj; d.wrap = h.wrap; d.shift = shifts[i];
     FineHost& fh = b.fine_h[(size_t)(ch0 + i)];
     fine_retune(fh, job, b.olen, V, shifts[i], freq[i], rate ? rate[i] : 0.0);
-    f[(size_t)i] = fine_desc(fh, V);
+    b.fine_dh[(size_t)(ch0 + i)] = fine_desc(fh, V);
   }
-  { int r = sync_all(e); if (r) return r; }   // earlier blocks still read the old descriptors
-  HIPOK(hipMemcpyAsync(b.desc + ch0, d.data(), sizeof(ChanDesc) * (size_t)n, hipMemcpyHostToDevice, e->stream));
-  HIPOK(hipMemcpyAsync(b.fine + ch0, f.data(), sizeof(FineDesc) * (size_t)n, hipMemcpyHostToDevice, e->stream));
-  HIPOK(hipMemcpyAsync(b.shifts + ch0, shifts, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, e->stream));
-  HIPOK(hipStreamSynchronize(e->stream));
-  return 0;
+  return after_edit(e, b, ch0, n);
 }
 // estimate_noise() (src/radio.c:1783-1866) for every channel of the bank right after its channel kernel;
 // samprate = front-end sample rate in Hz (Frontend.samprate, :1865), 0 switches it off again
@@ -645,42 +908,31 @@ int chz_bank_enable_noise(chz_engine* e, int bank, double samprate) {
   drop_graph(e);
   return 0;
 }
-int chz_bank_read_noise(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
-  BANK_CHECK(e, bank, ch0, n);
+static int read_doubles(chz_engine* e, int bank, const double* base, int slot, int ch0, int n, double* host, bool wait, const char* what) {
   if (slot < 0 || slot >= CHZ_ND || !host) return fail(-1, "bad argument");
   Bank& b = e->banks[(size_t)bank];
-  if (!b.n0) return fail(-1, "noise estimation is off: call chz_bank_enable_noise first");
+  if (!base) return fail(-1, "%s", what);
   hipStream_t st = slot_stream(e, slot);
-  HIPOK(hipMemcpyAsync(host, b.n0 + (size_t)slot * b.cap + ch0, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
-  HIPOK(hipStreamSynchronize(st));
+  HIPOK(hipMemcpyAsync(host, base + (size_t)slot * b.cap + ch0, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+  if (wait) HIPOK(hipStreamSynchronize(st));
   return 0;
+}
+int chz_bank_read_noise(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
+  BANK_CHECK(e, bank, ch0, n);
+  return read_doubles(e, bank, e->banks[(size_t)bank].n0, slot, ch0, n, host, true, "noise estimation is off: call chz_bank_enable_noise first");
 }
 int chz_bank_read_noise_async(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
   BANK_CHECK(e, bank, ch0, n);
-  if (slot < 0 || slot >= CHZ_ND || !host) return fail(-1, "bad argument");
-  Bank& b = e->banks[(size_t)bank];
-  if (!b.n0) return fail(-1, "noise estimation is off: call chz_bank_enable_noise first");
-  HIPOK(hipMemcpyAsync(host, b.n0 + (size_t)slot * b.cap + ch0, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, slot_stream(e, slot)));
-  return 0;
+  return read_doubles(e, bank, e->banks[(size_t)bank].n0, slot, ch0, n, host, false, "noise estimation is off: call chz_bank_enable_noise first");
 }
 // chan->sig.bb_power of channels [ch0, ch0+n) for the block last executed on `slot` (src/radio.c:1516-1520)
 int chz_bank_read_power(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
   BANK_CHECK(e, bank, ch0, n);
-  if (slot < 0 || slot >= CHZ_ND || !host) return fail(-1, "bad argument");
-  Bank& b = e->banks[(size_t)bank];
-  if (!b.power) return fail(-1, "bank has no tuning: call chz_bank_set_tuning first");
-  hipStream_t st = slot_stream(e, slot);
-  HIPOK(hipMemcpyAsync(host, b.power + (size_t)slot * b.cap + ch0, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
-  HIPOK(hipStreamSynchronize(st));
-  return 0;
+  return read_doubles(e, bank, e->banks[(size_t)bank].power, slot, ch0, n, host, true, "bank has no tuning: call chz_bank_set_tuning first");
 }
 int chz_bank_read_power_async(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
   BANK_CHECK(e, bank, ch0, n);
-  if (slot < 0 || slot >= CHZ_ND || !host) return fail(-1, "bad argument");
-  Bank& b = e->banks[(size_t)bank];
-  if (!b.power) return fail(-1, "bank has no tuning: call chz_bank_set_tuning first");
-  HIPOK(hipMemcpyAsync(host, b.power + (size_t)slot * b.cap + ch0, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, slot_stream(e, slot)));
-  return 0;
+  return read_doubles(e, bank, e->banks[(size_t)bank].power, slot, ch0, n, host, false, "bank has no tuning: call chz_bank_set_tuning first");
 }
 // slave->isb (src/filter.c:895-909): unpack LSB/USB to I/Q after the gather; flags != 0 switch it on per channel
 int chz_bank_set_isb(chz_engine* e, int bank, int ch0, int n, const unsigned char* flags) {
@@ -689,19 +941,19 @@ int chz_bank_set_isb(chz_engine* e, int bank, int ch0, int n, const unsigned cha
   Bank& b = e->banks[(size_t)bank];
   if (b.out_real) return fail(-1, "ISB unpacking applies to COMPLEX-output banks");
   HIPOK(hipSetDevice(e->device));
-  { int r = sync_all(e); if (r) return r; }
   if (!b.isb) {
     bool any = false;
     for (int i = 0; i < n; i++) any = any || flags[i] != 0;
     if (!any) return 0;                          // nothing to switch on: keep the plain kernel variant
-    HIPOK(hipMalloc((void**)&b.isb, (size_t)b.cap));
-    HIPOK(hipMemset(b.isb, 0, (size_t)b.cap));
+    { int r = sync_all(e); if (r) return r; }   // the kernel variant changes: one-time switch
+    b.isb_h.assign((size_t)b.cap, 0);
+    HIPOK(hipMalloc((void**)&b.isb, (size_t)CHZ_ND * b.cap));
+    HIPOK(hipMemset(b.isb, 0, (size_t)CHZ_ND * b.cap));
     HIPOK(hipDeviceSynchronize());
     drop_graph(e);
   }
-  HIPOK(hipMemcpyAsync(b.isb + ch0, flags, (size_t)n, hipMemcpyHostToDevice, e->stream));
-  HIPOK(hipStreamSynchronize(e->stream));
-  return 0;
+  for (int i = 0; i < n; i++) b.isb_h[(size_t)(ch0 + i)] = flags[i] ? 1 : 0;
+  return after_edit(e, b, ch0, n);
 }
 // slave->beam with the weights set_filter_weights leaves in slave->alpha / ->beta (src/filter.c:756-775,922-929):
 // ab = 4 doubles per channel (Re alpha, Im alpha, Re beta, Im beta), on = one flag byte per channel
@@ -711,21 +963,19 @@ int chz_bank_set_beam(chz_engine* e, int bank, int ch0, int n, const double* ab,
   Bank& b = e->banks[(size_t)bank];
   if (b.out_real || e->in_type != CHZ_COMPLEX) return fail(-1, "beam mode combines I and Q of a COMPLEX master into COMPLEX-output channels");
   HIPOK(hipSetDevice(e->device));
-  { int r = sync_all(e); if (r) return r; }
   if (!b.beam) {
     bool any = false;
     for (int i = 0; i < n; i++) any = any || on[i] != 0;
     if (!any) return 0;
-    HIPOK(hipMalloc((void**)&b.beam, sizeof(BeamDesc) * (size_t)b.cap));
-    HIPOK(hipMemset(b.beam, 0, sizeof(BeamDesc) * (size_t)b.cap));
+    { int r = sync_all(e); if (r) return r; }
+    b.beam_h.assign((size_t)b.cap, BeamDesc{0.0, 0.0, 0.0, 0.0, 0, 0});
+    HIPOK(hipMalloc((void**)&b.beam, sizeof(BeamDesc) * (size_t)CHZ_ND * b.cap));
+    HIPOK(hipMemset(b.beam, 0, sizeof(BeamDesc) * (size_t)CHZ_ND * b.cap));
     HIPOK(hipDeviceSynchronize());
     drop_graph(e);
   }
-  std::vector<BeamDesc> d((size_t)n);
-  for (int i = 0; i < n; i++) d[(size_t)i] = BeamDesc{ab[4 * i], ab[4 * i + 1], ab[4 * i + 2], ab[4 * i + 3], on[i] ? 1 : 0, 0};
-  HIPOK(hipMemcpyAsync(b.beam + ch0, d.data(), sizeof(BeamDesc) * (size_t)n, hipMemcpyHostToDevice, e->stream));
-  HIPOK(hipStreamSynchronize(e->stream));
-  return 0;
+  for (int i = 0; i < n; i++) b.beam_h[(size_t)(ch0 + i)] = BeamDesc{ab[4 * i], ab[4 * i + 1], ab[4 * i + 2], ab[4 * i + 3], on[i] ? 1 : 0, 0};
+  return after_edit(e, b, ch0, n);
 }
 int chz_bank_set_active(chz_engine* e, int bank, int n) {
   BANK_CHECK(e, bank, 0, n);
@@ -754,10 +1004,7 @@ int chz_bank_destroy(chz_engine* e, int bank) {
   Bank& b = e->banks[(size_t)bank];
   { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
-  hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); hipFree(b.fine); hipFree(b.power);
-  hipFree(b.shifts); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam); b.shifts = nullptr; b.n0 = nullptr; b.isb = nullptr; b.beam = nullptr; b.noise_samprate = 0.0;
-  b.resp = nullptr; b.desc = nullptr; b.out = nullptr; b.tw_sub = nullptr; b.fine = nullptr; b.power = nullptr;
-  b.fine_h.clear(); b.active = 0; b.cap = 0;
+  free_bank(b);
   return 0;
 }
 int chz_bank_read_async(chz_engine* e, int bank, int slot, int ch0, int n, float* host) {
@@ -776,6 +1023,11 @@ int chz_spectrum_read_async(chz_engine* e, int slot, float* host) {
 int chz_host_callback(chz_engine* e, int slot, void (*fn)(void*), void* arg) {
   if (!e || !fn || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   HIPOK(hipLaunchHostFunc(slot_stream(e, slot), fn, arg));
+  return 0;
+}
+int chz_slot_sync(chz_engine* e, int slot) {
+  if (!e || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
+  HIPOK(hipStreamSynchronize(slot_stream(e, slot)));
   return 0;
 }
 int chz_host_alloc(void** p, size_t bytes) {
@@ -806,8 +1058,8 @@ int chz_bank_output_device(chz_engine* e, int bank, int slot, float** dev) {
   return 0;
 }
 
-static int enqueue_step(chz_engine* e, unsigned job, Instr* in) {
-  int r = enqueue_forward(e, job, in);
+static int enqueue_step(chz_engine* e, unsigned job, Instr* in, NotchTurn* turn = nullptr, int seq = 0, bool capture_first = false) {
+  int r = enqueue_forward(e, job, in, turn, seq, capture_first);
   if (r) return r;
   for (int b = 0; b < (int)e->banks.size(); b++)
     if ((r = enqueue_bank(e, b, job, in))) return r;
@@ -817,9 +1069,7 @@ static int enqueue_step(chz_engine* e, unsigned job, Instr* in) {
 int chz_step(chz_engine* e, unsigned job) {
   if (!e) return fail(-1, "null engine");
   HIPOK(hipSetDevice(e->device));
-  int r = arm_notch_tickets(e, job);
-  if (r) return r;
-  r = enqueue_step(e, job, nullptr);
+  int r = enqueue_step(e, job, nullptr);
   if (r) return r;
   HIPOK(hipGetLastError());
   return 0;
@@ -841,6 +1091,11 @@ static int lanes_join(chz_engine* e, hipEvent_t* evs) {
   return 0;
 }
 
+static int issue_threads() {
+  static const int n = [] { const char* v = getenv("CHZ_ENQ_THREADS"); int k = v ? atoi(v) : 2; return k == 2 || k == 4 ? k : 1; }();
+  return n;
+}
+
 int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int instrument, chz_timing* timing) {
   if (!e || nblocks < 0) return fail(-1, "bad argument");
   if (mode == 1)
@@ -849,25 +1104,9 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
   HIPOK(hipSetDevice(e->device));
   { int r = sync_all(e); if (r) return r; }
   e->input_pending = false;                       // everything written so far is visible to every lane now
-  if (nblocks > 0) {                              // notch tickets: seed for job0, they then count on their own
-    int r = arm_notch_tickets(e, job0);
-    if (r) return r;
-    e->notch_next = job0 + (unsigned)nblocks;
-  }
-  struct Events {      // destroyed on every return path
-    hipEvent_t t0 = nullptr, t1 = nullptr, fork_ev = nullptr, join_ev[CHZ_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
-    ~Events() {
-      if (t0) hipEventDestroy(t0);
-      if (t1) hipEventDestroy(t1);
-      if (fork_ev) hipEventDestroy(fork_ev);
-      for (auto ev : join_ev) if (ev) hipEventDestroy(ev);
-    }
-  } evs;
-  HIPOK(hipEventCreate(&evs.t0)); HIPOK(hipEventCreate(&evs.t1));
-  HIPOK(hipEventCreateWithFlags(&evs.fork_ev, hipEventDisableTiming));
-  for (int i = 0; i < CHZ_MAX_LANES; i++) HIPOK(hipEventCreateWithFlags(&evs.join_ev[i], hipEventDisableTiming));
-  hipEvent_t t0 = evs.t0, t1 = evs.t1, fork_ev = evs.fork_ev;
-  hipEvent_t* join_ev = evs.join_ev;
+  e->notch_have = false;                          // the device is idle: nothing to order the first block behind
+  hipEvent_t t0 = e->ev_t0, t1 = e->ev_t1, fork_ev = e->ev_fork;
+  hipEvent_t* join_ev = e->ev_join;
   Instr in; in.on = instrument != 0 && mode == 0;
   hipStream_t s0 = e->lanes[0].s;
   int done = 0, rc = 0;
@@ -879,18 +1118,21 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
     const unsigned phase = job0 % (unsigned)cycle;
     if (!e->graph || e->graph_blocks != cycle || e->graph_job0 != phase) {
       drop_graph(e);
+      for (Bank& b : e->banks) { int r = refresh_all_bulk(e, b); if (r) return r; }   // no descriptor copies inside the capture
       hipGraph_t g = nullptr;
       HIPOK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
       rc = lanes_fork(e, fork_ev);
-      for (int i = 0; i < cycle && !rc; i++) rc = enqueue_step(e, phase + (unsigned)i, nullptr);
+      for (int i = 0; i < cycle && !rc; i++) rc = enqueue_step(e, phase + (unsigned)i, nullptr, nullptr, 0, i == 0);
       if (!rc) rc = lanes_join(e, join_ev);
       hipError_t ce = hipStreamEndCapture(s0, &g);
+      e->notch_have = false;                      // events recorded inside a capture are not waitable outside it
       if (rc) { if (g) hipGraphDestroy(g); return rc; }
       if (ce != hipSuccess) return fail(-10, "graph capture failed: %s", hipGetErrorString(ce));
       HIPOK(hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0));
       hipGraphDestroy(g);
       e->graph_blocks = cycle; e->graph_job0 = phase;
     }
+    for (Bank& b : e->banks) { int r = refresh_all_bulk(e, b); if (r) return r; }
     HIPOK(hipEventRecord(t0, s0));
     while (nblocks - done >= cycle) { HIPOK(hipGraphLaunch(e->graph, s0)); done += cycle; }
     if (done < nblocks) {
@@ -901,24 +1143,30 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
   } else {
     HIPOK(hipEventRecord(t0, s0));
     if (!in.on && (rc = lanes_fork(e, fork_ev))) return rc;
-    // Blocks of different lanes are independent launch sequences.  A single host thread issues ~4 launches per block at
-    // ~3 us each, which bounds the small configurations (config 2: 12 us per block) -- so the lanes are split over
-    // CHZ_ENQ_THREADS host threads (default 2; 1 = issue from the caller only), each owning a subset of the lanes.
-    static const int enq_threads = [] { const char* v = getenv("CHZ_ENQ_THREADS"); int n = v ? atoi(v) : 2; return n == 2 || n == 4 ? n : 1; }();
-    if (enq_threads > 1 && !in.on && e->nlanes >= enq_threads && nblocks >= 4 * e->nlanes) {
-      std::vector<std::thread> th;
-      std::vector<int> rcs((size_t)enq_threads, 0);
-      std::vector<std::string> errs((size_t)enq_threads);
-      for (int t = 0; t < enq_threads; t++)
-        th.emplace_back([&, t] {
-          (void)hipSetDevice(e->device);
-          for (int b = 0; b < nblocks && !rcs[(size_t)t]; b++) {
-            const unsigned job = job0 + (unsigned)b;
-            if ((int)(job % (unsigned)e->nlanes) % enq_threads != t) continue;
-            if ((rcs[(size_t)t] = enqueue_step(e, job, nullptr))) errs[(size_t)t] = g_err;
-          }
-        });
-      for (auto& x : th) x.join();
+    // Blocks of different lanes are independent launch sequences.  A single host thread issues ~5 launches per block at
+    // ~3 us each, which bounds the small configurations -- so the lanes are split over CHZ_ENQ_THREADS host threads
+    // (default 2; 1 = issue from the caller only): the caller takes its share, persistent issuers take the rest.
+    const int T = issue_threads();
+    if (T > 1 && !in.on && e->nlanes >= T && nblocks >= 2 * e->nlanes) {
+      while ((int)e->issuers.size() < T - 1) {
+        Issuer* is = new Issuer();
+        const int dev = e->device;
+        is->th = std::thread([is, dev] { (void)hipSetDevice(dev); is->loop(); });
+        e->issuers.push_back(is);
+      }
+      NotchTurn turn;
+      std::vector<int> rcs((size_t)T, 0);
+      std::vector<std::string> errs((size_t)T);
+      auto work = [&](int t) {
+        for (int b = 0; b < nblocks && !rcs[(size_t)t]; b++) {
+          const unsigned job = job0 + (unsigned)b;
+          if ((int)(job % (unsigned)e->nlanes) % T != t) continue;
+          if ((rcs[(size_t)t] = enqueue_step(e, job, nullptr, &turn, b))) { errs[(size_t)t] = g_err; turn.abort.store(1); }
+        }
+      };
+      for (int t = 1; t < T; t++) e->issuers[(size_t)(t - 1)]->post([&work, t] { work(t); });
+      work(0);
+      for (int t = 1; t < T; t++) e->issuers[(size_t)(t - 1)]->wait();
       for (size_t t = 0; t < rcs.size(); t++) if (rcs[t]) return fail(rcs[t], "%s", errs[t].c_str());   // the message lives in the worker's thread-local
       for (Bank& b : e->banks) b.last_slot = (int)((job0 + (unsigned)nblocks - 1u) % CHZ_ND);            // what a single issuer would have left
       done = nblocks;
@@ -935,8 +1183,8 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
     timing->enqueue_ms = enqueue_ms;
     float ms = 0; HIPOK(hipEventElapsedTime(&ms, t0, t1));
     timing->total_ms = ms; timing->blocks = nblocks;
-    double* acc[5] = {&timing->first_ms, &timing->cols_ms, &timing->rows_ms, &timing->notch_ms, &timing->chan_ms};
-    int* cnt[5] = {&timing->first_n, &timing->cols_n, &timing->rows_n, &timing->notch_n, &timing->chan_n};
+    double* acc[6] = {&timing->first_ms, &timing->cols_ms, &timing->rows_ms, &timing->notch_ms, &timing->chan_ms, &timing->fix_ms};
+    int* cnt[6] = {&timing->first_n, &timing->cols_n, &timing->rows_n, &timing->notch_n, &timing->chan_n, &timing->fix_n};
     for (size_t i = 0; i < in.kind.size(); i++) {
       float k = 0; hipEventElapsedTime(&k, in.ev[2 * i], in.ev[2 * i + 1]);
       *acc[in.kind[i]] += k; *cnt[in.kind[i]] += 1;
@@ -946,3 +1194,5 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
 }
 
 }  // extern "C"
+
+#include "chz_comm.inc"

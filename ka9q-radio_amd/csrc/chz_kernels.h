@@ -2,7 +2,7 @@
 //
 // What the reference does on CPU threads with FFTW3 (src/filter.c):
 //   K1  forward transform of the N-sample window          src/filter.c:505-508,573-582
-//   K2  spur notches on a handful of bins                  src/filter.c:464-474 (fused into fwd_rows)
+//   K2  spur notches on a handful of bins                  src/filter.c:464-474 (notch_fix, ordered across blocks by events)
 //   K3  per-channel bin gather x frequency response        src/filter.c:728-911
 //   K4  per-channel small backward transform, keep olen    src/filter.c:914, :357
 // is done here by four kernels.  The large transform is a three-axis Cooley-Tukey
@@ -136,11 +136,6 @@ __host__ __device__ __forceinline__ long spec_addr(const SpecLayout& l, long k) 
   return x * l.pitch + l.off + (k - x * l.na);
 }
 
-// Where a notched bin is produced inside fwd_rows (computed on the host from the plan):
-// row (ka, kb) of the intermediate buffer, output index kc = k1 + R1*k2 of that row's transform,
-// mir != 0 if the bin is stored through the conjugate mirror (bin N-k of that row).
-struct NotchLoc { int ka, kb, k1, k2, mir; };
-
 struct RowsParams {
   const float2* buf;      // [Ra][Nb][Nc]
   float2* spec;           // out: master spectrum in SpecLayout order
@@ -152,19 +147,6 @@ struct RowsParams {
   long N;                 // full transform length
   int mirror;             // 1: real master (bins N/2+1, conj-mirror store); 0: complex master
   const float2* tw_sub;   // [R2][R1] W_Nc^(j*k1)
-  // spur notches (src/filter.c:464-474), applied to the owning lane's register just before
-  // the store; state is float64 and persists on the device across blocks
-  int n_notch;
-  const NotchLoc* notch_loc;  // n_notch entries: which lane/register of which workgroup holds the bin
-  double* notch_state;        // 2 doubles per entry
-  double notch_alpha;
-  // The notch state is a recurrence over blocks, but blocks of different HIP streams run
-  // concurrently.  Instead of serialising whole kernels with stream events, the ONE lane that owns
-  // a notched bin takes a ticket: it waits until notch_ver[i] (count of updates applied so far,
-  // mod 4) equals this block's job number mod 4, updates, and publishes ver+1.  At most 4 blocks
-  // are in flight and blocks j and j+4 share a stream, so the ticket is unambiguous.
-  unsigned* notch_ver;        // n_notch counters
-  unsigned job;               // this block's job number
 };
 
 // One channel's gather, precomputed on the host from `shift`
@@ -172,7 +154,12 @@ struct RowsParams {
 // the t-th output bin counted from the most negative frequency takes master bin
 //   src0 + dir*(t - t0)   (mod wrap if wrap != 0)     for t0 <= t < t0 + cnt
 // and is zero otherwise; conj != 0 conjugates the master bin (inverted spectrum).
-struct ChanDesc { int t0, cnt, src0, dir, conj, wrap; };
+// row   = which row of the bank's response array holds this channel's response (set_filter swaps a response by
+//         writing a spare row and re-pointing the descriptor, so blocks in flight keep the old one);
+// shift = the channel's bin shift itself (REAL-output gather, noise estimate).
+// Descriptors exist once per spectrum slot: a retune edits the copy of the NEXT block of each slot in stream
+// order and never touches what blocks already in flight are reading.
+struct ChanDesc { int t0, cnt, src0, dir, conj, wrap, row, shift; };
 
 // Fine tuning of one channel (the tail of downconvert(), src/radio.c:1476-1520), stateless in the block
 // number so blocks in flight on different streams cannot race on an oscillator state.  With
@@ -187,8 +174,6 @@ struct FineDesc { double phase0, freq, rate; unsigned job0; int adj_num, V, on; 
 struct BeamDesc { double ar, ai, br, bi; int on; int pad; };
 
 struct ChanParams {
-  // REAL-output banks (chan_c2r) take the shift itself instead of a descriptor
-  const int* shifts;      // [nch]
   int m_bins, m_real;     // master bins; master is REAL (else COMPLEX)
   int stage;              // 1: output rows leave through LDS as full-line stores (throughput); 0: straight from the lanes (latency)
   const unsigned char* isb; // [nch] or nullptr: per-channel slave->isb flags (EPI variant only)
@@ -199,8 +184,8 @@ struct ChanParams {
   const float2* spec;     // master spectrum of this block (SpecLayout order)
   SpecLayout lay;
   float inv_na;           // 1/na, for the bin -> (row, column) split
-  const float2* resp;     // [nch][P] frequency responses
-  const ChanDesc* desc;   // [nch]
+  const float2* resp;     // [rows][P] frequency responses, row = desc[ch].row
+  const ChanDesc* desc;   // [nch] this slot's descriptors
   float2* out;            // [nch][olen]
   int ch0, nch, olen;     // channels [ch0, ch0+nch) of the bank are processed
   const float2* tw_sub;   // [R2][R1]  W_P^(-j*k1)  (backward)
@@ -521,31 +506,6 @@ __global__ void fwd_rows(RowsParams p) {
       u[J] = lds[b2 + J * ld];
     });
     reg_dft<R2, -1>(u);
-    for (int i = 0; i < p.n_notch; i++) {          // uniform trip count, normally 1 (DC) .. 21
-      const NotchLoc nl = p.notch_loc[i];
-      if (nl.kb == kb && nl.ka == ka && nl.k1 == k1) {   // this lane holds the bin
-        static_for<R2>([&](auto k2) {
-          constexpr int K2 = decltype(k2)::value;
-          if (K2 == nl.k2) {
-            float2 x = nl.mir ? cconj(u[K2]) : u[K2];
-            // wait for every earlier block's update of this notch (bounded: never hang the GPU)
-            for (int spin = 0; spin < (1 << 22); spin++) {
-              if ((__hip_atomic_load(&p.notch_ver[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) & 3u) == (p.job & 3u)) break;
-              __builtin_amdgcn_s_sleep(2);
-            }
-            double sr = __hip_atomic_load(&p.notch_state[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            double si = __hip_atomic_load(&p.notch_state[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sr += p.notch_alpha * ((double)x.x - sr);
-            si += p.notch_alpha * ((double)x.y - si);
-            __hip_atomic_store(&p.notch_state[2 * i], sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&p.notch_state[2 * i + 1], si, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&p.notch_ver[i], p.job + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            x = make_float2((float)((double)x.x - sr), (float)((double)x.y - si));
-            u[K2] = nl.mir ? cconj(x) : x;
-          }
-        });
-      }
-    }
     if (ka >= 0 && ka < p.Ra) {
       const bool selfconj = (ka == 0) || (2 * ka == p.Na);
       const int half = (int)(p.N >> 1);
@@ -563,6 +523,41 @@ __global__ void fwd_rows(RowsParams p) {
       });
     }
   }
+}
+
+// ------------------------------------------------------------------------------
+// K2: spur notches (apply_notch_filters, src/filter.c:464-474): for every list entry, in list order,
+//   state += alpha * (X[bin] - state);  X[bin] -= state          (state is double complex, X float complex)
+// The state is a recurrence over BLOCKS, and blocks of different HIP streams run concurrently, so this tiny
+// kernel sits on the block's own stream right after fwd_rows and is ordered behind the previous block's
+// notch_fix by a HIP event (chz_engine.hip): stream semantics alone carry the recurrence, there is no
+// device-side waiting.  One lane per distinct bin; entries that name the same bin again are chained through
+// `next` and applied by the same lane in list order, exactly as the reference's sequential walk does.
+// ------------------------------------------------------------------------------
+struct NotchFixParams {
+  float2* spec;           // this block's spectrum slot (SpecLayout order)
+  const int* addr;        // [n] storage index of the entry's bin
+  const int* next;        // [n] next entry with the same bin, or -1
+  const int* head;        // [n] 1 if the entry is the first one naming its bin
+  const double* alpha;    // [n] per-entry averager gain
+  double* state;          // [n][2] persists across blocks
+  int n;
+};
+__global__ void notch_fix(NotchFixParams p) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= p.n || !p.head[i]) return;
+  const int a = p.addr[i];
+  float2 x = p.spec[a];
+  for (int e = i; e >= 0; e = p.next[e]) {
+    double sr = p.state[2 * e], si = p.state[2 * e + 1];
+    const double al = p.alpha[e];
+    double dr = al * ((double)x.x - sr), di = al * ((double)x.y - si);   // rounded products, then the sums (no fma on x86-64)
+    CHZ_ROUNDED_F64(dr); CHZ_ROUNDED_F64(di);
+    sr += dr; si += di;
+    p.state[2 * e] = sr; p.state[2 * e + 1] = si;
+    x = make_float2((float)((double)x.x - sr), (float)((double)x.y - si));
+  }
+  p.spec[a] = x;
 }
 
 // ------------------------------------------------------------------------------
@@ -592,7 +587,7 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
   const bool act1 = live && jl < R2;
   if (act1) {
     const ChanDesc d = p.desc[ch];
-    const float2* __restrict__ H = p.resp + (long)ch * P;
+    const float2* __restrict__ H = p.resp + (long)d.row * P;
     const float2* __restrict__ X = p.spec;
     // All 2*R1 loads are issued unconditionally (out-of-range bins read bin 0 and are
     // zeroed afterwards) so they overlap instead of costing one round trip per bin.
@@ -819,8 +814,9 @@ __global__ void __launch_bounds__(256) chan_c2r(ChanParams p) {
   const float2* __restrict__ tws = p.tw_sub;
 
   if (live && jl < R2) {
-    const int shift = p.shifts[ch];
-    const float2* __restrict__ H = p.resp + (long)ch * P;
+    const ChanDesc d = p.desc[ch];
+    const int shift = d.shift;
+    const float2* __restrict__ H = p.resp + (long)d.row * P;
     const float2* __restrict__ X = p.spec;
     constexpr int SB = P / 2 + 1;                          // slave bins (:374)
     float2 v[R1], w[R1], h[R1];
@@ -904,7 +900,7 @@ __device__ __forceinline__ float cnrm_unfused(float2 x) {
 
 struct NoiseParams {
   const float2* spec; SpecLayout lay;
-  const int* shift;       // [nch] the channels' bin shifts
+  const ChanDesc* desc;   // [nch] this slot's descriptors (the bin shift is read from them)
   double* n0;             // [nch] out: noise density estimate
   int ch0, nch;
   int m_bins, real;       // master bins; real != 0 for a REAL master
@@ -921,7 +917,7 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
   const int lc = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
   if (lc >= p.nch) return;                                           // wave-uniform
   const int ch = p.ch0 + lc;
-  const int shift = p.shift[ch];
+  const int shift = p.desc[ch].shift;
   // first master bin of the window and how many entries the reference fills
   int mbin, n = p.nbins, wrap = 0;
   if (p.real) {

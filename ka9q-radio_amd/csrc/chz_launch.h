@@ -50,6 +50,24 @@ inline int launch_chan_real(Radix2 r, int grid, int block, size_t lds, hipStream
 #undef X
   return -1;
 }
+inline int launch_notch_fix(hipStream_t s, const NotchFixParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+  if (p.n <= 0) return 0;
+  CHZ_LAUNCH(notch_fix, (p.n + 63) / 64, 64, 0, s, e0, e1, p);
+  return 0;
+}
+// Host side of K2: the reference walks its list in order (src/filter.c:464-474); entries naming a bin a second time are
+// chained behind the first so one lane applies them in list order.
+struct NotchTables { std::vector<int> addr, next, head; };
+inline NotchTables notch_tables(const int* bins, int n, const SpecLayout& lay) {
+  NotchTables t;
+  t.addr.resize((size_t)n); t.next.assign((size_t)n, -1); t.head.assign((size_t)n, 1);
+  for (int i = 0; i < n; i++) {
+    t.addr[(size_t)i] = (int)spec_addr(lay, bins[i]);
+    for (int j = i - 1; j >= 0; j--)
+      if (bins[j] == bins[i]) { t.next[(size_t)j] = i; t.head[(size_t)i] = 0; break; }
+  }
+  return t;
+}
 inline int launch_noise(int nch, hipStream_t s, const NoiseParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   const int grid = (nch + 3) / 4;          // four wavefronts = four channels per workgroup
   if (p.nsort == 1024) { CHZ_LAUNCH((noise_est<16>), grid, 256, 0, s, e0, e1, p); return 0; }

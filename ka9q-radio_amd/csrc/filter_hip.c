@@ -66,6 +66,7 @@ struct hbank {
   void *stage[ND];                  /* pinned [cap][olen] samples: staged outputs per job slot */
   int *stage_shift[ND];             /* [cap] shift each staged output was computed with */
   unsigned *stage_epoch[ND];        /* [cap] response epoch it was computed with (0 = invalid) */
+  unsigned char *stage_isb[ND];     /* [cap] slave->isb flag it was computed with */
   unsigned stage_job[ND];
   int stage_n[ND];
 };
@@ -84,7 +85,23 @@ struct mctx {
   struct notch_state *notch_ptr;    /* list last uploaded to the device */
   int notch_n;
   int notch_bins[64];
-  struct done_note note[ND];
+  double notch_alpha[64];
+  struct done_note note[ND];        /* one per job slot; execute_filter_input never has more than ND blocks in flight */
+  /* channels whose staged result does not fit (retuned, new filter, just created) are re-run in batches: the first
+     thread to miss becomes the leader and serves everybody who queued up meanwhile with one device round trip */
+  pthread_mutex_t miss_lock;
+  pthread_cond_t miss_cv;
+  struct miss_req *miss_head, *miss_tail;
+  bool miss_leader;
+};
+
+struct miss_req {
+  struct filter_out *slave;
+  int shift, slot;
+  unsigned job;
+  int rc;
+  bool done;
+  struct miss_req *next;
 };
 
 struct sctx {
@@ -93,6 +110,8 @@ struct sctx {
   unsigned epoch;                   /* bumped whenever the response changes */
 };
 
+struct hbank;
+static void bank_free_host(struct hbank *b);
 static struct mctx *MCTX(struct filter_in *m) { return (struct mctx *)(void *)m->fwd_plan; }
 static struct sctx *SCTX(struct filter_out *s) { return (struct sctx *)(void *)s->rev_plan; }
 
@@ -105,6 +124,7 @@ static void futex_wait_u32(unsigned *addr, unsigned expected) {
   syscall(SYS_futex, addr, FUTEX_WAIT_PRIVATE, expected, NULL, NULL, 0);
 }
 static void futex_wake_all(unsigned *addr) { syscall(SYS_futex, addr, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0); }
+static void futex_wake_n(unsigned *addr, int n) { syscall(SYS_futex, addr, FUTEX_WAKE_PRIVATE, n, NULL, NULL, 0); }
 
 static void *lmalloc(size_t size) {           /* cache-line aligned, like src/filter.c:1163 */
   void *p = NULL;
@@ -203,15 +223,18 @@ static double complex cis_pi(double x) {       /* e^{i pi x}, argument reduced i
 static void block_done(void *arg) {
   struct done_note *n = arg;
   struct filter_in *f = n->ctx->master;
+  /* the record is read in full BEFORE the job is published: publishing releases the producer, which may reuse it */
+  unsigned const job = n->job;
+  struct timespec const t0 = n->t0;
   struct timespec t1;
   clock_gettime(CLOCK_MONOTONIC, &t1);
   pthread_mutex_lock(&f->filter_mutex);
   f->owner = pthread_self();
-  __atomic_store_n(&f->completed_jobs[n->job % ND], n->job, __ATOMIC_RELEASE);   /* src/filter.c:526-529 */
+  __atomic_store_n(&f->completed_jobs[job % ND], job, __ATOMIC_RELEASE);   /* src/filter.c:526-529 */
   pthread_cond_broadcast(&f->filter_cond);              /* src/filter.c:532-535 (kept; nobody in this build waits on it) */
   pthread_mutex_unlock(&f->filter_mutex);
-  futex_wake_all(&f->completed_jobs[n->job % ND]);
-  int64_t ns = (t1.tv_nsec - n->t0.tv_nsec) + 1000000000LL * (t1.tv_sec - n->t0.tv_sec);
+  futex_wake_all(&f->completed_jobs[job % ND]);
+  int64_t ns = (t1.tv_nsec - t0.tv_nsec) + 1000000000LL * (t1.tv_sec - t0.tv_sec);
   if (ns > Max_fft_time) Max_fft_time = ns;             /* src/filter.c:544-552 */
   if (ns < Min_fft_time) Min_fft_time = ns;
   int64_t dev = ns - Avg_fft_time;
@@ -225,7 +248,7 @@ static void block_done(void *arg) {
 static size_t bank_sample_bytes(const struct hbank *b) { return b->real ? sizeof(float) : sizeof(float complex); }
 static int bank_create_dev(struct mctx *c, const struct hbank *b, int cap);
 static void bank_free_host(struct hbank *b) {
-  for (int s = 0; s < ND; s++) { chz_host_free(b->stage[s]); b->stage[s] = NULL; FREE(b->stage_shift[s]); FREE(b->stage_epoch[s]); }
+  for (int s = 0; s < ND; s++) { chz_host_free(b->stage[s]); b->stage[s] = NULL; FREE(b->stage_shift[s]); FREE(b->stage_epoch[s]); FREE(b->stage_isb[s]); }
   FREE(b->slaves); FREE(b->shift); FREE(b->isb); FREE(b->beam_ab); FREE(b->beam_on);
 }
 static int bank_alloc_host(struct hbank *b, int cap) {
@@ -242,7 +265,8 @@ static int bank_alloc_host(struct hbank *b, int cap) {
     b->stage[s] = p;
     b->stage_shift[s] = calloc((size_t)cap, sizeof(int));
     b->stage_epoch[s] = calloc((size_t)cap, sizeof(unsigned));
-    if (!b->stage_shift[s] || !b->stage_epoch[s]) return -1;
+    b->stage_isb[s] = calloc((size_t)cap, 1);
+    if (!b->stage_shift[s] || !b->stage_epoch[s] || !b->stage_isb[s]) return -1;
     b->stage_job[s] = UINT_MAX; b->stage_n[s] = 0;
   }
   return 0;
@@ -259,9 +283,15 @@ static int bank_for(struct mctx *c, int P, int olen, bool real) {
     /* grow: a new, larger device bank; move responses and shifts over */
     struct hbank nb = {.P = P, .olen = olen, .n = b->n, .real = real};
     nb.id = bank_create_dev(c, &nb, b->cap * 2);
-    if (nb.id < 0 || bank_alloc_host(&nb, b->cap * 2) != 0) { fprintf(stderr, "filter_hip: cannot grow bank: %s\n", chz_last_error()); return -1; }
+    if (nb.id < 0 || bank_alloc_host(&nb, b->cap * 2) != 0) {
+      fprintf(stderr, "filter_hip: cannot grow bank: %s\n", chz_last_error());
+      if (nb.id >= 0) chz_bank_destroy(c->eng, nb.id);
+      bank_free_host(&nb);
+      return -1;
+    }
     for (int k = 0; k < b->n; k++) {
       nb.slaves[k] = b->slaves[k]; nb.shift[k] = b->shift[k]; nb.isb[k] = b->isb[k];
+      nb.beam_on[k] = 0;                                  /* re-uploaded by the next execute_filter_input if the slave is in beam mode */
       if (nb.slaves[k]->response) chz_bank_set_responses(c->eng, nb.id, k, 1, (const float *)nb.slaves[k]->response);
     }
     chz_bank_set_shifts(c->eng, nb.id, 0, nb.n, nb.shift);
@@ -279,13 +309,22 @@ static int bank_for(struct mctx *c, int P, int olen, bool real) {
   b->P = P; b->olen = olen; b->real = real;
   b->id = bank_create_dev(c, b, 64);
   if (b->id < 0) { fprintf(stderr, "filter_hip: %s\n", chz_last_error()); return -1; }
-  if (bank_alloc_host(b, 64) != 0) return -1;
+  if (bank_alloc_host(b, 64) != 0) { chz_bank_destroy(c->eng, b->id); bank_free_host(b); return -1; }
   return c->nbanks++;
 }
 
 /* ------------------------------------------------------------------------- */
 /* create / delete                                                               */
 /* ------------------------------------------------------------------------- */
+static void mctx_free(struct mctx *c) {          /* host side only; the engine is destroyed by the caller first */
+  for (int i = 0; i < c->nbanks; i++) bank_free_host(&c->banks[i]);
+  free(c->banks);
+  pthread_mutex_destroy(&c->lock);
+  pthread_rwlock_destroy(&c->stage_lock);
+  pthread_mutex_destroy(&c->miss_lock);
+  pthread_cond_destroy(&c->miss_cv);
+  free(c);
+}
 int create_filter_input(struct filter_in *master, int const L, int const M, enum filtertype const in_type) {
   if (master == NULL) return -1;
   if (master->init && master->ilen == L && master->impulse_length == M && in_type == master->in_type)
@@ -300,8 +339,7 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
     struct mctx *old = MCTX(master);
     if (old->ring_pinned) chz_host_unregister(master->input_buffer);
     chz_engine_destroy(old->eng);
-    for (int i = 0; i < old->nbanks; i++) bank_free_host(&old->banks[i]);
-    free(old->banks); pthread_mutex_destroy(&old->lock); pthread_rwlock_destroy(&old->stage_lock); free(old);
+    mctx_free(old);
     master->fwd_plan = NULL;
     for (int i = 0; i < ND; i++) { chz_host_free(master->fdomain[i]); master->fdomain[i] = NULL; }
     ring_unmap(&master->input_buffer, master->input_buffer_size);
@@ -320,13 +358,23 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   { const char *fd = getenv("KA9Q_HIP_FDOMAIN"); c->host_spectrum = !(fd && fd[0] == '0'); }
   pthread_mutex_init(&c->lock, NULL);
   pthread_rwlock_init(&c->stage_lock, NULL);
+  pthread_mutex_init(&c->miss_lock, NULL);
+  pthread_cond_init(&c->miss_cv, NULL);
+  size_t const ssz = in_type == COMPLEX ? sizeof(float complex) : sizeof(float);
+  size_t const ring_bytes = page_round((size_t)ND * N * ssz);       /* src/filter.c:237,253 */
+  void *ring = NULL;
+  void *fd[ND] = {NULL, NULL, NULL, NULL};
+  for (int i = 0; i < ND; i++)
+    if (chz_host_alloc(&fd[i], sizeof(float complex) * (size_t)bins) != 0) { fprintf(stderr, "create_filter_input: %s\n", chz_last_error()); goto fail; }
+  ring = ring_map(ring_bytes);
+  if (!ring) { perror("create_filter_input: ring"); goto fail; }
+
+  /* nothing below can fail: only now is the caller's struct touched */
   master->points = N;
   master->perform_inline = (N_worker_threads == 0);               /* src/filter.c:205 */
   for (int i = 0; i < ND; i++) {
-    void *p = NULL;
-    if (chz_host_alloc(&p, sizeof(float complex) * (size_t)bins) != 0) { fprintf(stderr, "create_filter_input: %s\n", chz_last_error()); return -1; }
-    master->fdomain[i] = p;                                        /* pinned: the device copies spectra here */
-    memset(p, 0, sizeof(float complex) * (size_t)bins);
+    master->fdomain[i] = fd[i];                                    /* pinned: the device copies spectra here */
+    memset(fd[i], 0, sizeof(float complex) * (size_t)bins);
     master->completed_jobs[i] = UINT_MAX;                         /* src/filter.c:214 */
   }
   master->bins = bins; master->ilen = L; master->impulse_length = M;
@@ -337,10 +385,8 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   }
   master->owner = pthread_self();
   master->in_type = in_type;
-  size_t const ssz = in_type == COMPLEX ? sizeof(float complex) : sizeof(float);
-  master->input_buffer_size = page_round((size_t)ND * N * ssz);   /* src/filter.c:237,253 */
-  master->input_buffer = ring_map(master->input_buffer_size);
-  if (!master->input_buffer) { perror("create_filter_input: ring"); return -1; }
+  master->input_buffer_size = ring_bytes;
+  master->input_buffer = ring;
   memset(master->input_buffer, 0, master->input_buffer_size);
   /* both mappings of the ring, so a window that runs into the mirror is still DMA-able */
   c->ring_pinned = chz_host_register(master->input_buffer, 2 * master->input_buffer_size) == 0;
@@ -357,6 +403,13 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   master->next_jobnum = 0;
   master->fwd_plan = (fftwf_plan)(void *)c;
   return 0;
+
+fail:
+  for (int i = 0; i < ND; i++) chz_host_free(fd[i]);
+  ring_unmap(&ring, ring_bytes);
+  chz_engine_destroy(c->eng);
+  mctx_free(c);
+  return -1;
 }
 
 int delete_filter_input(struct filter_in *master) {
@@ -366,11 +419,7 @@ int delete_filter_input(struct filter_in *master) {
     chz_sync(c->eng);
     if (c->ring_pinned) chz_host_unregister(master->input_buffer);
     chz_engine_destroy(c->eng);
-    for (int i = 0; i < c->nbanks; i++) bank_free_host(&c->banks[i]);
-    free(c->banks);
-    pthread_mutex_destroy(&c->lock);
-    pthread_rwlock_destroy(&c->stage_lock);
-    free(c);
+    mctx_free(c);
   }
   if (master->init) { pthread_mutex_destroy(&master->filter_mutex); pthread_cond_destroy(&master->filter_cond); }
   ring_unmap(&master->input_buffer, master->input_buffer_size);
@@ -394,7 +443,12 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
     fprintf(stderr, "create_filter_output: REAL output needs an even block size (got %d)\n", (int)((long)len * N / L));
     return -1;
   }
-  if (slave->init && slave->rev_plan) delete_filter_output(slave);  /* geometry changed: start over */
+  if (slave->init && slave->rev_plan) {                            /* geometry changed: start over ... */
+    bool const isb = slave->isb, beam = slave->beam;               /* ... but create_filter_output (src/filter.c:298-415) */
+    unsigned const drops = slave->block_drops;                     /* leaves these caller-owned fields alone */
+    delete_filter_output(slave);
+    slave->isb = isb; slave->beam = beam; slave->block_drops = drops;
+  }
   slave->olen = len;
   slave->points = (int)((long)len * N / L);
   if (!slave->init) { pthread_mutex_init(&slave->response_mutex, NULL); slave->init = true; }
@@ -475,21 +529,38 @@ int delete_filter_output(struct filter_out *slave) {
 /* input side                                                                    */
 /* ------------------------------------------------------------------------- */
 static void sync_notches(struct mctx *c, struct filter_in *f) {
-  /* radio.c installs f->notches after create_filter_input (src/radio.c:601-620) */
+  /* radio.c installs f->notches after create_filter_input (src/radio.c:601-620); every entry carries its own
+     averager gain (src/filter.c:468) -- the calloc'd DC sentinel of a full spur list has alpha 0, a no-op */
   struct notch_state *ns = f->notches;
   int n = 0;
   if (ns) { while (n < 63 && ns[n].bin != 0) n++; n++; }           /* list ends with the DC entry */
   bool same = (ns == c->notch_ptr && n == c->notch_n);
-  for (int i = 0; same && i < n; i++) same = (ns[i].bin == c->notch_bins[i]);
+  for (int i = 0; same && i < n; i++) same = (ns[i].bin == c->notch_bins[i] && ns[i].alpha == c->notch_alpha[i]);
   if (same) return;
-  for (int i = 0; i < n; i++) c->notch_bins[i] = ns[i].bin;
-  chz_set_notches(c->eng, c->notch_bins, n, n ? ns[0].alpha : 0.0);
+  for (int i = 0; i < n; i++) { c->notch_bins[i] = ns[i].bin; c->notch_alpha[i] = ns[i].alpha; }
+  if (chz_set_notches_alpha(c->eng, c->notch_bins, c->notch_alpha, n) != 0) fprintf(stderr, "filter_hip: notches: %s\n", chz_last_error());
   c->notch_ptr = ns; c->notch_n = n;
 }
 
 int execute_filter_input(struct filter_in *const f) {
   if (f == NULL || f->fwd_plan == NULL) return -1;
   struct mctx *c = MCTX(f);
+  /* Everything below is asynchronous, so the producer must not run more than ND blocks ahead of the device: block
+     job-ND owns this job's completion record, spectrum slot, staged outputs and host-ring window until its callback has
+     published it.  (The reference's worker queue throttles the producer the same way only through the ring; a lapped
+     SLAVE still drops a block with zeros, src/filter.c:690-701 -- that logic is unchanged.) */
+  {
+    unsigned const next = f->next_jobnum;
+    if (next >= ND) {
+      unsigned const need = next - ND;
+      unsigned *word = &f->completed_jobs[need % ND];
+      for (;;) {
+        unsigned done = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+        if (done != UINT_MAX && (int)(need - done) <= 0) break;
+        futex_wait_u32(word, done);
+      }
+    }
+  }
   pthread_mutex_lock(&c->lock);
   unsigned const job = f->next_jobnum++;                           /* src/filter.c:607 */
   int const slot = (int)(job % ND);
@@ -520,20 +591,23 @@ int execute_filter_input(struct filter_in *const f) {
   for (int i = 0; rc == 0 && i < c->nbanks; i++) {
     struct hbank *b = &c->banks[i];
     pthread_rwlock_wrlock(&c->stage_lock);
+    if (!b->real) {                 /* callers flip slave->isb directly (src/radio.c:1586, src/radio_status.c:326) */
+      int lo = b->n, hi = 0;
+      for (int k = 0; k < b->n; k++) {
+        unsigned char v = b->slaves[k]->isb ? 1 : 0;
+        if (v != b->isb[k]) { b->isb[k] = v; if (k < lo) lo = k; hi = k + 1; }
+      }
+      if (hi > lo) chz_bank_set_isb(c->eng, b->id, lo, hi - lo, b->isb + lo);
+    }
     b->stage_job[slot] = job; b->stage_n[slot] = b->n;
     for (int k = 0; k < b->n; k++) {
       b->stage_shift[slot][k] = b->shift[k];
       b->stage_epoch[slot][k] = b->slaves[k]->response ? SCTX(b->slaves[k])->epoch : 0;
+      b->stage_isb[slot][k] = b->isb[k];
     }
     pthread_rwlock_unlock(&c->stage_lock);
     if (b->n == 0) continue;
-    if (!b->real) {                 /* callers flip slave->isb directly (src/radio.c:1586, src/radio_status.c:326) */
-      bool changed = false;
-      for (int k = 0; k < b->n; k++) {
-        unsigned char f = b->slaves[k]->isb ? 1 : 0;
-        if (f != b->isb[k]) { b->isb[k] = f; changed = true; }
-      }
-      if (changed) chz_bank_set_isb(c->eng, b->id, 0, b->n, b->isb);
+    if (!b->real) {
       if (f->in_type == COMPLEX) {   /* slave->beam and its weights (src/radio.c:938-940) */
         for (int k = 0; k < b->n; k++) {
           struct filter_out *s = b->slaves[k];
@@ -542,7 +616,9 @@ int execute_filter_input(struct filter_in *const f) {
           if (on != b->beam_on[k] || (on && memcmp(ab, b->beam_ab + 4 * k, sizeof ab) != 0)) {
             b->beam_on[k] = on; memcpy(b->beam_ab + 4 * k, ab, sizeof ab);
             chz_bank_set_beam(c->eng, b->id, k, 1, ab, &on);
-            for (int s2 = 0; s2 < ND; s2++) b->stage_epoch[s2][k] = 0;      /* earlier staged results used other weights */
+            pthread_rwlock_wrlock(&c->stage_lock);
+            for (int s2 = 0; s2 < ND; s2++) if (s2 != slot) b->stage_epoch[s2][k] = 0;   /* earlier staged results used other weights */
+            pthread_rwlock_unlock(&c->stage_lock);
           }
         }
       }
@@ -589,6 +665,48 @@ int write_rfilter(struct filter_in *f, float const *buffer, int size) {         
 /* ------------------------------------------------------------------------- */
 /* output side                                                                   */
 /* ------------------------------------------------------------------------- */
+/* Serve every queued miss with one device round trip: per request refresh the channel's shift / ISB flag (host-side
+   edits, picked up in stream order), launch that one channel on the block's spectrum, read it into the channel's
+   place in the staged image; then ONE wait per spectrum slot touched.  Caller is the batch leader. */
+static void serve_misses(struct mctx *c, struct miss_req *list) {
+  bool touched[ND] = {false, false, false, false};
+  pthread_mutex_lock(&c->lock);
+  for (struct miss_req *r = list; r; r = r->next) {
+    struct sctx *sc = SCTX(r->slave);
+    struct hbank *b = &c->banks[sc->bank];
+    int const k = sc->idx;
+    unsigned char const isb = r->slave->isb ? 1 : 0;
+    int rc = 0;
+    if (b->shift[k] != r->shift) { b->shift[k] = r->shift; rc = chz_bank_set_shifts(c->eng, b->id, k, 1, &b->shift[k]); }
+    if (rc == 0 && !b->real && b->isb[k] != isb) { b->isb[k] = isb; rc = chz_bank_set_isb(c->eng, b->id, k, 1, &b->isb[k]); }
+    if (rc == 0) rc = chz_bank_execute_range(c->eng, b->id, (unsigned)r->slot, k, 1);
+    if (rc == 0) rc = chz_bank_read_async(c->eng, b->id, r->slot, k, 1,
+                                          (float *)((char *)b->stage[r->slot] + (size_t)k * b->olen * bank_sample_bytes(b)));
+    if (rc != 0) fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
+    r->rc = rc;
+    touched[r->slot] = true;
+  }
+  for (int s = 0; s < ND; s++)
+    if (touched[s] && chz_slot_sync(c->eng, s) != 0) {
+      fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
+      for (struct miss_req *r = list; r; r = r->next) if (r->slot == s) r->rc = -1;
+    }
+  /* the staged image now holds exactly what each requester asked for */
+  pthread_rwlock_wrlock(&c->stage_lock);
+  for (struct miss_req *r = list; r; r = r->next) {
+    if (r->rc != 0) continue;
+    struct sctx *sc = SCTX(r->slave);
+    struct hbank *b = &c->banks[sc->bank];
+    if (b->stage_job[r->slot] == r->job && sc->idx < b->stage_n[r->slot]) {
+      b->stage_shift[r->slot][sc->idx] = r->shift;
+      b->stage_epoch[r->slot][sc->idx] = sc->epoch;
+      b->stage_isb[r->slot][sc->idx] = r->slave->isb ? 1 : 0;
+    }
+  }
+  pthread_rwlock_unlock(&c->stage_lock);
+  pthread_mutex_unlock(&c->lock);
+}
+
 int execute_filter_output(struct filter_out *const slave, int const shift) {
   if (slave == NULL) return -1;
   struct filter_in *const master = slave->master;
@@ -599,9 +717,14 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
     slave->next_jobnum = master->next_jobnum - 1;                  /* src/filter.c:681-683 */
   unsigned const job = slave->next_jobnum;
   int const slot = (int)(job % ND);
+  bool slept = false;
   for (;;) {
     unsigned done = __atomic_load_n(&master->completed_jobs[slot], __ATOMIC_ACQUIRE);
     if ((int)(job - done) <= 0) {
+      /* Everybody asleep on this word waits for the same job, so a woken thread passes the wake-up on to two more:
+         ~1000 channel threads are released in a tree (log depth, on many cores) instead of one after the other by
+         the completion callback. */
+      if (slept) futex_wake_n(&master->completed_jobs[slot], 2);
       if ((int)(done - job) >= ND) {                               /* lapped: zeros + drop (src/filter.c:690-701) */
         slave->block_drops++;
         slave->next_jobnum++;
@@ -612,6 +735,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
       break;
     }
     futex_wait_u32(&master->completed_jobs[slot], done);           /* src/filter.c:686-687 */
+    slept = true;
   }
   slave->sample_index = master->samples_by_job[slot];              /* src/filter.c:705 */
   slave->next_jobnum++;
@@ -626,33 +750,50 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
 
   struct mctx *c = MCTX(master);
   struct sctx *sc = SCTX(slave);
-  bool hit = false;
-  pthread_rwlock_rdlock(&c->stage_lock);
-  {
-    struct hbank *b = &c->banks[sc->bank];
-    int const k = sc->idx;
-    if (b->stage_job[slot] == job && k < b->stage_n[slot] && b->stage_shift[slot][k] == shift &&
-        b->stage_epoch[slot][k] == sc->epoch && (b->real || b->isb[k] == (slave->isb ? 1 : 0))) {
-      /* the speculative batch already computed exactly this */
-      memcpy(dst, (char *)b->stage[slot] + (size_t)k * b->olen * bank_sample_bytes(b), bank_sample_bytes(b) * (size_t)b->olen);
-      hit = true;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    bool hit = false;
+    pthread_rwlock_rdlock(&c->stage_lock);
+    {
+      struct hbank *b = &c->banks[sc->bank];
+      int const k = sc->idx;
+      if (b->stage_job[slot] == job && k < b->stage_n[slot] && b->stage_shift[slot][k] == shift &&
+          b->stage_epoch[slot][k] == sc->epoch && (b->real || b->stage_isb[slot][k] == (slave->isb ? 1 : 0))) {
+        /* the batch (speculative, or the miss batch just served) computed exactly this */
+        memcpy(dst, (char *)b->stage[slot] + (size_t)k * b->olen * bank_sample_bytes(b), bank_sample_bytes(b) * (size_t)b->olen);
+        hit = true;
+      }
     }
-  }
-  pthread_rwlock_unlock(&c->stage_lock);
-  if (hit) return 0;
+    pthread_rwlock_unlock(&c->stage_lock);
+    if (hit) return 0;
+    if (attempt == 1) break;
 
-  /* retuned / new filter / newly created: run this one channel on the block's spectrum */
-  int rc = 0;
-  pthread_mutex_lock(&c->lock);
-  struct hbank *b = &c->banks[sc->bank];
-  int const k = sc->idx;
-  if (b->shift[k] != shift) { b->shift[k] = shift; rc = chz_bank_set_shifts(c->eng, b->id, k, 1, &b->shift[k]); }
-  if (rc == 0 && !b->real && b->isb[k] != (slave->isb ? 1 : 0)) { b->isb[k] = slave->isb ? 1 : 0; rc = chz_bank_set_isb(c->eng, b->id, k, 1, &b->isb[k]); }
-  if (rc == 0) rc = chz_bank_execute_range(c->eng, b->id, slot, k, 1);
-  if (rc == 0) rc = chz_bank_read(c->eng, b->id, k, 1, (float *)dst);
-  if (rc != 0) fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
-  pthread_mutex_unlock(&c->lock);
-  return rc == 0 ? 0 : -1;
+    /* retuned / new filter / newly created: queue this channel for a re-run on the block's spectrum */
+    struct miss_req req = {.slave = slave, .shift = shift, .slot = slot, .job = job};
+    pthread_mutex_lock(&c->miss_lock);
+    if (c->miss_tail) c->miss_tail->next = &req; else c->miss_head = &req;
+    c->miss_tail = &req;
+    if (!c->miss_leader) {
+      c->miss_leader = true;
+      while (c->miss_head) {
+        struct miss_req *list = c->miss_head;
+        c->miss_head = c->miss_tail = NULL;
+        pthread_mutex_unlock(&c->miss_lock);
+        serve_misses(c, list);
+        pthread_mutex_lock(&c->miss_lock);
+        for (struct miss_req *r = list; r;) { struct miss_req *nx = r->next; r->done = true; r = nx; }   /* r may vanish once done */
+        pthread_cond_broadcast(&c->miss_cv);
+      }
+      c->miss_leader = false;
+    } else {
+      while (!req.done) pthread_cond_wait(&c->miss_cv, &c->miss_lock);
+    }
+    pthread_mutex_unlock(&c->miss_lock);
+    if (req.rc != 0) return -1;
+  }
+  /* the block's staged image was re-used for a later block while this channel waited (it was about to be lapped):
+     the reference would have read a half-overwritten spectrum here; hand out silence instead */
+  memset(dst, 0, bank_sample_bytes(&c->banks[sc->bank]) * (size_t)slave->olen);
+  return 0;
 }
 
 int set_filter_weights(struct filter_out *out, double complex i_weight, double complex q_weight) {  /* src/filter.c:922-929 */

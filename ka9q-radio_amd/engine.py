@@ -26,10 +26,11 @@ class ChzInfo(C.Structure):
 class ChzTiming(C.Structure):
     _fields_ = [("total_ms", _d), ("blocks", _i),
                 ("first_ms", _d), ("cols_ms", _d), ("rows_ms", _d), ("notch_ms", _d), ("chan_ms", _d),
-                ("first_n", _i), ("cols_n", _i), ("rows_n", _i), ("notch_n", _i), ("chan_n", _i), ("enqueue_ms", _d)]
+                ("first_n", _i), ("cols_n", _i), ("rows_n", _i), ("notch_n", _i), ("chan_n", _i), ("enqueue_ms", _d),
+                ("fix_ms", _d), ("fix_n", _i)]
 
 
-# every symbol include/chz_engine.h declares (checked by tests/test_abi_symbols.py)
+# every symbol include/chz_engine.h declares (checked by tests/test_host_logic.py and __graft_entry__.build())
 SYMBOLS = [
     "chz_last_error", "chz_device_count", "chz_engine_create", "chz_engine_destroy", "chz_engine_info",
     "chz_engine_set_stream", "chz_sync", "chz_input_write", "chz_input_write_device", "chz_input_ring",
@@ -41,6 +42,9 @@ SYMBOLS = [
     "chz_bank_set_tuning", "chz_bank_read_power", "chz_bank_read_power_async",
     "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
     "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real", "chz_bank_set_isb", "chz_bank_set_beam",
+    "chz_set_notches_alpha", "chz_slot_sync",
+    "chz_comm_unique_id", "chz_comm_create", "chz_comm_create_file", "chz_comm_destroy", "chz_comm_rank", "chz_comm_world",
+    "chz_comm_barrier", "chz_comm_allreduce_max", "chz_spectrum_broadcast", "chz_spectrum_exchange_rows", "chz_run_blocks_sharded",
 ]
 
 _lib = None
@@ -69,6 +73,19 @@ def lib():
         L.chz_input_stats.argtypes = [_vp, _i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_uint)]
         L.chz_forward.argtypes = [_vp, _u]
         L.chz_set_notches.argtypes = [_vp, _vp, _i, _d]
+        L.chz_set_notches_alpha.argtypes = [_vp, _vp, _vp, _i]
+        L.chz_slot_sync.argtypes = [_vp, _i]
+        L.chz_comm_unique_id.argtypes = [_vp]
+        L.chz_comm_create.argtypes = [C.POINTER(_vp), _i, _i, _vp, _i]
+        L.chz_comm_create_file.argtypes = [C.POINTER(_vp), _i, _i, C.c_char_p, _i, _d]
+        L.chz_comm_destroy.argtypes = [_vp]; L.chz_comm_destroy.restype = None
+        L.chz_comm_rank.argtypes = [_vp]
+        L.chz_comm_world.argtypes = [_vp]
+        L.chz_comm_barrier.argtypes = [_vp]
+        L.chz_comm_allreduce_max.argtypes = [_vp, _vp, _i]
+        L.chz_spectrum_broadcast.argtypes = [_vp, _vp, _i, _i]
+        L.chz_spectrum_exchange_rows.argtypes = [_vp, _vp, _i, _i, _vp, _vp]
+        L.chz_run_blocks_sharded.argtypes = [_vp, _vp, _i, _i, _vp, _vp, _u, _i, C.POINTER(ChzTiming)]
         L.chz_spectrum_read.argtypes = [_vp, _i, _vp]
         L.chz_spectrum_device.argtypes = [_vp, _i, C.POINTER(_vp)]
         L.chz_slot_stream.argtypes = [_vp, _i, C.POINTER(_vp)]
@@ -182,8 +199,30 @@ class Engine:
         _check(lib().chz_forward(self._h, job & 0xFFFFFFFF))
 
     def set_notches(self, bins, alpha=0.01):
+        """alpha: one gain for the whole list, or one per entry (struct notch_state, src/filter.h:42-46)."""
         bins = np.ascontiguousarray(bins, np.int32)
-        _check(lib().chz_set_notches(self._h, bins.ctypes.data if len(bins) else None, len(bins), alpha))
+        if np.ndim(alpha) == 0:
+            _check(lib().chz_set_notches(self._h, bins.ctypes.data if len(bins) else None, len(bins), float(alpha)))
+        else:
+            al = np.ascontiguousarray(alpha, np.float64).reshape(-1)
+            assert al.shape[0] == bins.shape[0]
+            _check(lib().chz_set_notches_alpha(self._h, bins.ctypes.data if len(bins) else None,
+                                               al.ctypes.data if len(bins) else None, len(bins)))
+
+    def slot_sync(self, slot):
+        _check(lib().chz_slot_sync(self._h, slot))
+
+    def run_blocks_sharded(self, comm, job0, nblocks, root=0, rows=None):
+        """BASELINE config 4: the root transforms, the spectrum travels over RCCL (whole slot, or the row ranges
+        rows = (lo[world], hi[world])), every rank runs its own banks."""
+        t = ChzTiming()
+        if rows is None:
+            _check(lib().chz_run_blocks_sharded(self._h, comm._h, root, 0, None, None, job0 & 0xFFFFFFFF, nblocks, C.byref(t)))
+        else:
+            lo = np.ascontiguousarray(rows[0], np.int32); hi = np.ascontiguousarray(rows[1], np.int32)
+            _check(lib().chz_run_blocks_sharded(self._h, comm._h, root, 1, lo.ctypes.data, hi.ctypes.data,
+                                                job0 & 0xFFFFFFFF, nblocks, C.byref(t)))
+        return t
 
     def spectrum(self, slot):
         out = np.zeros(self.bins, np.complex64)
@@ -229,6 +268,12 @@ class Bank:
         self.id = _check(make(eng._h, P, olen, capacity))
         self._dtype = np.float32 if real else np.complex64
         self.active = 0
+
+    def destroy(self):
+        """Free the bank's device arrays (the id stays reserved)."""
+        if self.id is not None and self.eng._h:
+            _check(lib().chz_bank_destroy(self.eng._h, self.id))
+        self.id = None
 
     def set_responses(self, ch0, resp):
         resp = np.ascontiguousarray(resp, np.complex64).reshape(-1, self.P)
@@ -316,3 +361,52 @@ class Bank:
         p = _vp()
         _check(lib().chz_bank_output_device(self.eng._h, self.id, slot, C.byref(p)))
         return p.value
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """Rank 0: the 128-byte id every rank passes to Comm()."""
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    _check(lib().chz_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """One RCCL communicator per process (one process per GPU), behind the engine's C ABI."""
+
+    def __init__(self, rank, world, uid=None, device=0, path=None, timeout_s=120.0):
+        self._h = _vp()
+        if path is not None:
+            _check(lib().chz_comm_create_file(C.byref(self._h), rank, world, path.encode(), device, float(timeout_s)))
+        else:
+            buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(uid)
+            _check(lib().chz_comm_create(C.byref(self._h), rank, world, buf, device))
+        self.rank, self.world = rank, world
+
+    def barrier(self):
+        _check(lib().chz_comm_barrier(self._h))
+
+    def allreduce_max(self, values):
+        v = np.ascontiguousarray(values, np.float64).reshape(-1).copy()
+        _check(lib().chz_comm_allreduce_max(self._h, v.ctypes.data, v.shape[0]))
+        return v
+
+    def broadcast_spectrum(self, eng, slot, root=0):
+        _check(lib().chz_spectrum_broadcast(eng._h, self._h, slot, root))
+
+    def exchange_rows(self, eng, slot, lo, hi, root=0):
+        lo = np.ascontiguousarray(lo, np.int32); hi = np.ascontiguousarray(hi, np.int32)
+        _check(lib().chz_spectrum_exchange_rows(eng._h, self._h, slot, root, lo.ctypes.data, hi.ctypes.data))
+
+    def close(self):
+        if self._h:
+            lib().chz_comm_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -243,6 +243,7 @@ def create_filter_output(master, olen, out_type, slave=None):
                 new.isb[:len(st.slaves)] = st.isb[:len(st.slaves)]
                 if new.isb.any():
                     new.bank.set_isb(0, new.isb[:len(st.slaves)])
+                st.bank.destroy()         # the old, smaller device bank
             master._banks[key] = st = new
         s._bank, s._index = st, len(st.slaves)
         st.slaves.append(s)

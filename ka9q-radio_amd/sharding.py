@@ -41,9 +41,15 @@ def pipelined_blocks(jobs, is_root, forward, broadcast, channels):
         channels(pending[1])
 
 
-def needed_rows(shifts, P, master_bins, na, margin_rows=1):
+def needed_rows(shifts, P, master_bins, na, margin_rows=1, in_type=2):
     """Rows [lo, hi) of the spectrum (rows of `na` bins, see SpecLayout) that the channels with these
-    shifts read: bins shift-P/2 .. shift+P/2 for an upright spectrum, mirrored for negative shifts."""
+    shifts read.  REAL master (in_type 2): bins |shift|-P/2 .. |shift|+P/2, a negative shift reading the same
+    bins mirrored (src/filter.c:856-892).  COMPLEX master (in_type 1): a negative shift reads bins
+    master_bins+shift at the TOP of the spectrum (src/filter.c:728-793), so the needed set can be two
+    intervals; one covering interval cannot describe that, and the exchange must not silently ship the
+    wrong rows -- use the whole-slot broadcast for complex masters."""
+    if in_type != 2:
+        raise ValueError("needed_rows describes REAL masters only; broadcast the whole slot for a COMPLEX master")
     lo_bin, hi_bin = master_bins, 0
     for s in shifts:
         a, b = abs(int(s)) - P // 2 - 1, abs(int(s)) + (P + 1) // 2 + 1

@@ -80,19 +80,15 @@ static int emu_forward_impl(const float* ring, const short* ring16, float scale1
   c.buf = buf.data(); c.spec = spec_dev.data();
   c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3; c.padg = p.padg3; c.N = p.N;
   c.mirror = in_type == CHZ_IN_REAL; c.tw_sub = F2(p.tw_sub_c);
-  std::vector<NotchLoc> loc((size_t)(n_notch > 0 ? n_notch : 0));
-  for (int i = 0; i < n_notch; i++) {
-    long k = notch_bins[i]; int mir = 0;
-    int qa = (int)(k % p.Na);
-    if (in_type == CHZ_IN_REAL && 2 * qa > p.Na) { k = (long)p.N - notch_bins[i]; qa = (int)(k % p.Na); mir = 1; }
-    const long rest = k / p.Na;
-    loc[(size_t)i] = NotchLoc{qa, (int)(rest % p.Nb), (int)(rest / p.Nb) % p.rc.r1, (int)(rest / p.Nb) / p.rc.r1, mir};
-  }
-  static std::vector<unsigned> ver;           // the harness runs blocks one at a time: job 0 every call
-  ver.assign((size_t)(n_notch > 0 ? n_notch : 1), 0u);
-  c.n_notch = n_notch; c.notch_loc = loc.data(); c.notch_state = notch_state; c.notch_alpha = notch_alpha;
-  c.notch_ver = ver.data(); c.job = 0;
   if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, nullptr, c)) return -4;
+  if (n_notch > 0) {           // K2 as the engine runs it: its own tiny kernel right after the last pass
+    NotchTables nt = notch_tables(notch_bins, n_notch, c.lay);
+    std::vector<double> alpha((size_t)n_notch, notch_alpha);
+    NotchFixParams q{};
+    q.spec = spec_dev.data(); q.addr = nt.addr.data(); q.next = nt.next.data(); q.head = nt.head.data();
+    q.alpha = alpha.data(); q.state = notch_state; q.n = n_notch;
+    if (launch_notch_fix(nullptr, q)) return -5;
+  }
   float2* out = reinterpret_cast<float2*>(spectrum);
   for (long k = 0; k < p.bins; k++) out[k] = spec_dev[(size_t)spec_addr(c.lay, k)];   // back to natural order
   return 0;
@@ -114,7 +110,7 @@ int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, in
   std::vector<ChanDesc> desc((size_t)nch);
   for (int i = 0; i < nch; i++) {
     ChanDescH h = make_chan_desc(in_type, m_bins, P, shifts[i]);
-    desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
+    desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap, i, shifts[i]};
   }
   ChanParams c{};
   c.spec = spec_dev.data(); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
@@ -136,7 +132,7 @@ int emu_channels_isb(const float* spec, int m_bins, int in_type, int P, int olen
   std::vector<ChanDesc> desc((size_t)nch);
   for (int i = 0; i < nch; i++) {
     ChanDescH h = make_chan_desc(in_type, m_bins, P, shifts[i]);
-    desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
+    desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap, i, shifts[i]};
   }
   ChanParams c{};
   c.spec = reinterpret_cast<const float2*>(spec); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
@@ -158,7 +154,7 @@ int emu_channels_beam(const float* spec, int m_bins, int P, int olen, int nch, c
   std::vector<BeamDesc> bd((size_t)nch);
   for (int i = 0; i < nch; i++) {
     ChanDescH h = make_chan_desc(CHZ_IN_COMPLEX, m_bins, P, shifts[i]);
-    desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
+    desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap, i, shifts[i]};
     bd[i] = BeamDesc{ab[4 * i], ab[4 * i + 1], ab[4 * i + 2], ab[4 * i + 3], on[i] ? 1 : 0, 0};
   }
   ChanParams c{};
@@ -182,7 +178,9 @@ int emu_channels_real(const float* spec, int m_bins, int in_type, int P, int ole
   ChanParams c{};
   c.spec = spec_dev.data(); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
   c.resp = reinterpret_cast<const float2*>(resp);
-  c.shifts = shifts; c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL;
+  std::vector<ChanDesc> desc((size_t)nch);
+  for (int i = 0; i < nch; i++) desc[(size_t)i] = ChanDesc{0, 0, 0, 1, 0, 0, i, shifts[i]};   // the REAL-output gather reads row and shift only
+  c.desc = desc.data(); c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL;
   c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub);
   const int per_block = g.wpb * g.cpw;
@@ -198,7 +196,9 @@ int emu_noise(const float* spec, int m_bins, int in_type, int s_bins, int nch, c
   for (long k = 0; k < m_bins; k++) spec_dev[(size_t)spec_addr(lay, k)] = reinterpret_cast<const float2*>(spec)[k];
   NoiseParams q = noise_params(m_bins, in_type == CHZ_IN_REAL, s_bins, samprate);
   if (q.nbins > m_bins) return -1;
-  q.spec = spec_dev.data(); q.lay = lay; q.shift = shifts; q.n0 = n0; q.ch0 = 0; q.nch = nch;
+  std::vector<ChanDesc> desc((size_t)nch);
+  for (int i = 0; i < nch; i++) desc[(size_t)i] = ChanDesc{0, 0, 0, 1, 0, 0, i, shifts[i]};
+  q.spec = spec_dev.data(); q.lay = lay; q.desc = desc.data(); q.n0 = n0; q.ch0 = 0; q.nch = nch;
   return launch_noise(nch, nullptr, q);   // -1: window larger than the compiled sorts
 }
 
@@ -219,7 +219,7 @@ int emu_channels_tuned(const float* spec, int m_bins, int in_type, int P, int ol
   const std::vector<FineHost>& fh = *static_cast<std::vector<FineHost>*>(fine);
   for (int i = 0; i < nch; i++) {
     ChanDescH h = make_chan_desc(in_type, m_bins, P, shifts[i]);
-    desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap};
+    desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap, i, shifts[i]};
     fd[(size_t)i] = fine_desc(fh[(size_t)i], V);
   }
   ChanParams c{};
