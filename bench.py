@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- free-running throughput of the MI355X overlap-save channelizer.
 
-A "step" is one 20 ms block of the hot path: the shared forward transform of the
-N = 3,240,000-sample window (129.6 MS/s real input) plus the gather x response +
-backward transform of every channel, inputs already resident in HBM (an 8-block
-sig_gen stream pre-generated into the device ring and replayed cyclically).
+A "step" is one 20 ms block of the hot path: the shared forward transform of the overlapped
+input window plus gather x response + backward transform of every channel, inputs already
+resident in HBM (an 8-block sig_gen stream in the device ring, replayed cyclically).
 
-  N = 1   BASELINE config 3: 1024 mixed usb/cw/iq channels, 12 kHz (P = 300), one GPU.
-  N > 1   BASELINE config 4: rank 0 owns the front end and transforms; the block
-          spectrum (12.96 MB) is RCCL-broadcast; every rank runs its own 1024 x 24 kHz
-          channels (P = 600) -> weak scaling in channels.
+Workloads (BASELINE.json configs; --config picks one, the default follows --gpus):
+  2  sig_gen real  64.8 MS/s, 256 x 12 kHz NBFM channels (P = 300), one GPU
+  3  sig_gen real 129.6 MS/s, 1024 mixed usb/cw/iq 12 kHz channels (P = 300), one GPU   [default at --gpus 1]
+  4  sig_gen real 129.6 MS/s, 1024 x 24 kHz channels (P = 600) PER GPU, sharded by frequency; rank 0 owns the
+     front end and the forward transform, the block spectrum travels over xGMI through RCCL (called from
+     libchz_hip.so: chz_run_blocks_sharded) on the slot's own HIP stream                 [default at --gpus > 1]
+  5  one independent 129.6 MS/s front end per GPU (sig_gen seed = rank + 1), 1024 mixed channels each,
+     no RCCL in the data path ("replicas only")
 
-metric: channels sustained at 129.6 MS/s = channel-blocks per second / 50 blocks/s
-(real-time-equivalent channels: how many channels of this configuration the measured
-block rate could serve in real time).
+Timing: after W warm-up steps, ONE region of exactly K steps is timed between device synchronisations
+(barrier across ranks on both sides) and reported as drained_k_step_region; it also sizes `reps`.  The
+headline is the steady state: `reps` back-to-back repetitions of the K-step loop (reps*K blocks, no drain in
+between) form one timed region, bracketed the same way; `regions` of them cover --min-seconds and the MEDIAN
+(max over ranks each) gives ms_per_step and value.  So the figure does not depend on how small K is.
 
-Prints ONE JSON line on rank 0.
+metric: channels sustained at the input rate = channel-blocks per second / 50 blocks/s
+(real-time-equivalent channels of the benchmarked configuration).  The c_rt object is the literal
+"simultaneous channels in real time": one huge bank, every single block inside its 20 ms slot.
+
+Prints ONE JSON line on rank 0 (the last line of stdout).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import statistics
 import sys
 import time
 
@@ -30,46 +41,56 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-FS = 129.6e6
 BLOCKTIME = 0.02
+RING_BLOCKS = 8
+HBM_PEAK_GBS = 8000.0                   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:35
+COPY_RATE_GBS = 6290.0                  # the chip's measured achievable copy rate (same guide)
+
+# the 129.6 MS/s geometry is also what tests and scripts import from here
+FS = 129.6e6
 L = int(round(FS * BLOCKTIME))          # 2,592,000
 M = L // 4 + 1                          # 648,001  (overlap 5, src/radio.c:582-586)
 N = L + M - 1                           # 3,240,000
 BINS = N // 2 + 1
-RING_BLOCKS = 8
-HBM_PEAK_GBS = 8000.0                   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:35
 FWD_BYTES = 4 * N + 8 * BINS            # 25,920,008  
 
 
-def pmc_traffic_bytes():
-    """HBM-side bytes per block of the three forward kernels from the committed rocprofv3 PMC passes
-    (profiles/pmc_forward.json, written by scripts/rocprof_summary.py --json from separate FETCH_SIZE and
-    WRITE_SIZE passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on
-    gfx950).  None if no profile has been committed for this plan."""
-    path = os.path.join(ROOT, "profiles", "pmc_forward.json")
-    try:
-        return json.load(open(path))["forward_traffic_bytes_per_block"]
-    except Exception:
-        return None
+def geometry(fs):
+    l = int(round(fs * BLOCKTIME))
+    m = l // 4 + 1
+    n = l + m - 1
+    return l, m, n, n // 2 + 1
+
+
+def fwd_bytes(n):
+    return 4 * n + 8 * (n // 2 + 1)     # read the real window once, write the half spectrum once
 
 
 def chan_bytes(P, olen):
     return 8 * P + 8 * P + 8 * olen     # 6,720 (P=300) / 13,440 (P=600)
 
 
+KINDS = [(50 / 12000, 3000 / 12000), (-200 / 12000, 200 / 12000), (-5000 / 12000, 5000 / 12000)]   # usb / cw / iq
+
+
+def channel_plan_config2(nch, fs=64.8e6):
+    """256 x 12 kHz NBFM: f_i = 10 MHz + i*12.5 kHz, +-5 kHz."""
+    hz = fs / geometry(fs)[2]
+    return [(int(round((10e6 + i * 12.5e3) / hz)), -5000 / 12000, 5000 / 12000) for i in range(nch)]
+
+
 def channel_plan_config3(nch):
     """1024 mixed channels: thirds usb / cw / iq, f_i = 1 MHz + i*60 kHz + (i mod 40) Hz."""
-    kinds = [(50 / 12000, 3000 / 12000), (-200 / 12000, 200 / 12000), (-5000 / 12000, 5000 / 12000)]
     hz_per_bin = FS / N
     plan = []
     for i in range(nch):
         f = 1e6 + (i % 1040) * 60e3 + (i % 40)
-        plan.append((int(round(f / hz_per_bin)),) + kinds[i % 3])
+        plan.append((int(round(f / hz_per_bin)),) + KINDS[i % 3])
     return plan
 
 
 def channel_plan_config4(nch, rank):
-    """8192 x 24 kHz channels, f_i = 0.5 MHz + i*7.8 kHz, 1024 per GPU, +-10 kHz."""
+    """8192 x 24 kHz channels, f_i = 0.5 MHz + i*7.8 kHz, nch per GPU (rank r owns [r*nch, (r+1)*nch)), +-10 kHz."""
     hz_per_bin = FS / N
     plan = []
     for j in range(nch):
@@ -79,28 +100,61 @@ def channel_plan_config4(nch, rank):
     return plan
 
 
-def channel_plan_sharded(nch, rank, world):
-    """nch*world mixed channels on an even raster over 1..62.4 MHz; rank r owns channels [r*nch, (r+1)*nch)."""
-    kinds = [(50 / 12000, 3000 / 12000), (-200 / 12000, 200 / 12000), (-5000 / 12000, 5000 / 12000)]
-    hz_per_bin = FS / N
-    step = 61.4e6 / (nch * world)
-    plan = []
-    for j in range(nch):
-        i = rank * nch + j
-        f = 1e6 + i * step + (i % 40)
-        plan.append((int(round(f / hz_per_bin)),) + kinds[i % 3])
-    return plan
+def workload_for(config, rank, world, nch):
+    """Everything that defines what one rank runs."""
+    if config == 2:
+        fs, P, olen = 64.8e6, 300, 240
+        nch = nch or 256
+        plan = channel_plan_config2(nch, fs)
+        name = "config2: sig_gen real 64.8 MS/s, %d x 12 kHz NBFM channels (P=300)" % nch
+        seed = 1
+    elif config == 3:
+        fs, P, olen = FS, 300, 240
+        nch = nch or 1024
+        plan = channel_plan_config3(nch)
+        name = "config3: sig_gen real 129.6 MS/s, %d mixed usb/cw/iq 12 kHz channels (P=300)" % nch
+        seed = 1
+    elif config == 4:
+        fs, P, olen = FS, 600, 480
+        nch = nch or 1024
+        plan = channel_plan_config4(nch, rank)
+        name = ("config4: sig_gen real 129.6 MS/s, %d x 24 kHz channels (P=600), %d per GPU sharded by frequency over %d MI355X"
+                % (nch * world, nch, world))
+        seed = 1
+    elif config == 5:
+        fs, P, olen = FS, 300, 240
+        nch = nch or 1024
+        plan = channel_plan_config3(nch)
+        name = ("config5: %d independent 129.6 MS/s sig_gen front ends (seed = rank+1), %d mixed 12 kHz channels each, "
+                "no RCCL in the data path" % (world, nch))
+        seed = rank + 1
+    else:
+        raise SystemExit("--config must be 2, 3, 4 or 5")
+    l, m, n, bins = geometry(fs)
+    return dict(config=config, fs=fs, L=l, M=m, N=n, bins=bins, P=P, olen=olen, nch=nch, plan=plan, name=name, seed=seed)
 
 
-def siggen_ring(oracle_lib, seed=1):
+def siggen_ring(oracle_lib, fs=FS, seed=1, l=None):
     """8 blocks of the deterministic sig_gen stream (CW carrier 10.00002 MHz, -20 dBFS, noise -40 dBFS).
     The generator is test infrastructure (oracle/); it only produces INPUT, outside the timed region."""
-    g = oracle_lib.SigGen(10.00002e6 / FS, 10 ** (-20 / 20), 10 ** (-40 / 20),
+    l = l or geometry(fs)[0]
+    g = oracle_lib.SigGen(10.00002e6 / fs, 10 ** (-20 / 20), 10 ** (-40 / 20),
                           oracle_lib.scale_ad(True, 1), True, seed=seed)
-    return g.generate(RING_BLOCKS * L)
+    return g.generate(RING_BLOCKS * l)
 
 
-def cpu_baseline(oracle_lib, ring, plan, P, olen, seconds=12.0):
+def pmc_traffic_bytes():
+    """HBM-side bytes per block of the forward kernels from the committed rocprofv3 PMC passes
+    (profiles/pmc_forward.json, written by scripts/rocprof_summary.py --json from separate FETCH_SIZE and
+    WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes).  None if no profile has been committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_forward.json")
+    try:
+        return json.load(open(path))["forward_traffic_bytes_per_block"]
+    except Exception:
+        return None
+
+
+def cpu_baseline(oracle_lib, ring, wl, seconds=12.0):
     """Reference filter.c (oracle/_ref, FFT butterflies from the project's float32 provider, NOT FFTW)
     timed on this host's cores: 1 forward-FFT worker thread + a pool of channel threads, radiod style."""
     if not oracle_lib.have_ref():
@@ -110,10 +164,11 @@ def cpu_baseline(oracle_lib, ring, plan, P, olen, seconds=12.0):
     cores = os.cpu_count() or 1
     pool = max(1, min(cores - 1, 16))
     ring = np.ascontiguousarray(ring, np.float32)
+    plan, P, olen = wl["plan"], wl["P"], wl["olen"]
     sarr = np.array([p[0] for p in plan], np.int32)
 
     def run(workers, budget):
-        m = oracle_lib.RefMaster(L, M, oracle_lib.REAL, worker_threads=workers)
+        m = oracle_lib.RefMaster(wl["L"], wl["M"], oracle_lib.REAL, worker_threads=workers)
         chans = []
         for shift, low, high in plan:
             c = m.channel(olen, oracle_lib.COMPLEX)
@@ -145,45 +200,78 @@ def cpu_baseline(oracle_lib, ring, plan, P, olen, seconds=12.0):
     }
 
 
-def crt_leg(pkg, eng, nch, blocks=60):
-    P, olen, tile = 300, 240, 3072
+def crt_leg(pkg, eng, wl, nch, blocks, run_one):
+    """C_rt: one bank of `nch` channels of the workload's kind tiled from its plan, I/O resident in
+    HBM; every block is run to completion ON ITS OWN (run_one(job) -> ms) and must take <= 20 ms."""
+    P, olen, tile = wl["P"], wl["olen"], 3072
     nch -= nch % tile
     bank = eng.bank(P, olen, nch)
-    plan = channel_plan_config3(tile)
-    resp = np.stack([pkg.filterapi.design_response(P, olen, N, True, lo, hi, 11.0) for _, lo, hi in plan[:3]])
+    if wl["config"] == 4:
+        base = channel_plan_config3(tile)
+        plan = [(sh, -10000 / 24000, 10000 / 24000) for sh, _, _ in base]
+    else:
+        plan = channel_plan_config3(tile)
+    resp = np.stack([pkg.filterapi.design_response(P, olen, wl["N"], True, lo, hi, 11.0) for _, lo, hi in plan[:3]])
     resp = np.ascontiguousarray(np.tile(resp, (tile // 3, 1)))
     shifts = np.array([p[0] for p in plan], np.int32)
     for c0 in range(0, nch, tile):
         bank.set_responses(c0, resp)
         bank.set_shifts(c0, shifts + (c0 // tile) % 7)
     bank.set_active(nch)
-    eng.run_blocks(0, 4)
+    for j in range(8):
+        run_one(j)
     worst = tot = 0.0
     for j in range(blocks):
-        t = eng.run_blocks(4 + j, 1)                 # forward + the 1024-channel bank + this bank, then a device sync
-        worst = max(worst, t.total_ms); tot += t.total_ms
+        ms = run_one(8 + j)                     # forward (root) [+ exchange] + the small bank + this bank, then a device sync
+        worst = max(worst, ms); tot += ms
     mean = tot / blocks
     bank.set_active(0)
-    alg = FWD_BYTES + (nch + 1024) * chan_bytes(P, olen)
-    return {"channels": nch + 1024, "blocks": blocks, "worst_block_ms": worst, "mean_block_ms": mean, "sustained": worst <= BLOCKTIME * 1e3,
-            "algorithmic_GBps": alg / (mean * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "every block individually <= 20 ms; I/O resident in HBM (responses %.0f GB, 4 output images %.0f GB); "
-                    "bisected C_rt over 500 blocks: profiles/r01_crt.json" % (nch * P * 8 / 1e9, 4 * nch * olen * 8 / 1e9)}
+    total_ch = nch + wl["nch"]
+    chan_alg = total_ch * chan_bytes(P, olen)
+    dram = total_ch * (8 * P + 8 * olen)         # responses in + outputs out; the gathered master bins are cache hits
+    return {"channels": total_ch, "P": P, "blocks": blocks, "worst_block_ms": worst, "mean_block_ms": mean,
+            "sustained": worst <= BLOCKTIME * 1e3,
+            "algorithmic_GBps": (fwd_bytes(wl["N"]) + chan_alg) / (mean * 1e-3) / 1e9,
+            "dram_side_GBps": dram / (mean * 1e-3) / 1e9, "dram_side_frac_of_hbm_peak": dram / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "every block individually <= 20 ms; I/O resident in HBM (responses %.0f GB, 4 output images %.0f GB); the "
+                    "algorithmic figure counts the gathered master bins, which the caches serve -- the DRAM-side figure is "
+                    "responses + outputs only" % (nch * P * 8 / 1e9, 4 * nch * olen * 8 / 1e9)}
+
+
+def self_spawn(args):
+    """--gpus N > 1 without a launcher: become `torch.distributed.run` with one rank per GPU."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; refusing to run fewer ranks than asked" % (args.gpus, have))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", type=int, default=0, help="BASELINE config 2, 3, 4 or 5 (default: 3 at --gpus 1, 4 otherwise)")
+    ap.add_argument("--exchange", default=os.environ.get("BENCH_EXCHANGE", "auto"),
+                    help="config 4, how the spectrum reaches the ranks: auto | subband | broadcast (RCCL) | replicate (no collective)")
+    ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the config's)")
     ap.add_argument("--plan", default="", help="forward plan override, e.g. 144x100x225")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="keep repeating the K-step region until this much is measured")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay one hipGraph per ring cycle instead of eager launches")
-    ap.add_argument("--eager", action="store_true", help="(default) eager launches; kept for compatibility")
+    ap.add_argument("--graph", action="store_true", help="replay one hipGraph per ring cycle instead of eager launches (N=1)")
     ap.add_argument("--no-crt", action="store_true", help="skip the C_rt leg (one large bank, every block inside 20 ms)")
-    ap.add_argument("--crt-channels", type=int, default=17_000_000, help="channels of the C_rt leg's bank")
+    ap.add_argument("--crt-channels", type=int, default=0, help="channels of the C_rt leg's bank (default 17.0 M at P=300, 8.4 M at P=600)")
+    ap.add_argument("--crt-blocks", type=int, default=500)
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        raise SystemExit("bad --gpus/--steps/--warmup")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
 
     import torch
     import torch.distributed as dist
@@ -193,177 +281,180 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    # BENCH_FORCE_DIST=1 exercises the multi-GPU code path (RCCL broadcast, torch-owned spectrum slots)
-    # with a single rank, so it can be smoke-tested on a 1-GPU box
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")     # gloo: several ranks on ONE GPU (control-flow checks only)
+    if backend == "nccl" and torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: GPU %d is not visible (%d devices)" % (rank, local_rank, torch.cuda.device_count()))
+    dev_index = local_rank if torch.cuda.device_count() > local_rank else 0
+    torch.cuda.set_device(dev_index)
+    # BENCH_FORCE_DIST=1: run the multi-rank code path (process group, RCCL exchange) with ONE rank on a 1-GPU box
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        # "nccl" is RCCL on ROCm.  BENCH_DIST_BACKEND=gloo exists only to exercise the multi-rank control flow with several
-        # ranks on ONE GPU (RCCL refuses two ranks per device); the replicate mode has no data-path collective anyway.
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)      # "nccl" IS RCCL on ROCm; control plane only
 
-    # N > 1: channels shard across ranks.  How the shared spectrum gets to every rank:
-    #   replicate (default)  every rank runs the forward transform on its own HBM-resident copy of the samples
-    #   subband | broadcast  rank 0 transforms, the needed spectrum rows / the whole slot travel over xGMI (RCCL)
-    #   auto                 subband or broadcast, whichever moves fewer bytes (sharding.plan_exchange)
-    exch = os.environ.get("BENCH_EXCHANGE", "replicate") if use_dist else None
+    config = args.config or (4 if use_dist else 3)
+    wl = workload_for(config, rank, world, args.channels)
+    exch = None
+    if config == 4:
+        exch = args.exchange
+        if exch == "auto" and not use_dist:
+            exch = "replicate"                                  # one rank: nothing to exchange (BENCH_FORCE_DIST=1 keeps the collective)
+        if exch not in ("auto", "subband", "broadcast", "replicate"):
+            raise SystemExit("--exchange must be auto, subband, broadcast or replicate")
+        if backend != "nccl" and exch != "replicate":
+            raise SystemExit("the RCCL exchange needs one GPU per rank (backend nccl)")
+
     pkg = ge.load()
-    eng = pkg.engine.Engine(L, M, pkg.engine.REAL, device=local_rank, plan=args.plan, ring_blocks=RING_BLOCKS)
-
-    nch = args.channels
-    P, olen = 300, 240
-    if not use_dist:
-        workload = "config3: sig_gen real 129.6 MS/s, %d mixed usb/cw/iq 12 kHz channels (P=300), 1 MI355X" % nch
-        plan = channel_plan_config3(nch)
-    else:
-        # weak scaling: every GPU runs the SAME per-GPU workload as N=1 (1024 mixed 12 kHz channels); the
-        # node's channels cover 1..62.4 MHz and rank r owns a contiguous slice of that raster (config 4's
-        # architecture: rank 0 owns the front end, the spectrum travels over xGMI)
-        if exch == "replicate":
-            how = ("the sample stream is resident in every GPU's HBM (the bench's input rule; in service the host feeds each GPU over its "
-                   "own PCIe link) and each GPU transforms it itself (about 0.1 % of a 20 ms block): no data-path collective")
-        else:
-            how = "rank 0 owns the front end and the forward transform, the spectrum travels over xGMI via RCCL (%s)" % exch
-        workload = ("config3 per GPU x %d: sig_gen real 129.6 MS/s, %d mixed usb/cw/iq 12 kHz channels (P=300) sharded by "
-                    "frequency over %d MI355X; %s" % (world, nch * world, world, how))
-        plan = channel_plan_sharded(nch, rank, world)
+    eng = pkg.engine.Engine(wl["L"], wl["M"], pkg.engine.REAL, device=dev_index, plan=args.plan, ring_blocks=RING_BLOCKS)
 
     # ---- inputs resident in HBM before anything is timed
-    ring_host = siggen_ring(oracle_lib)
+    ring_host = siggen_ring(oracle_lib, wl["fs"], wl["seed"], wl["L"])
     # the device ring starts with the write position M-1 ahead (zeros before time 0); fill it to the brim
-    eng.write(ring_host[:RING_BLOCKS * L - (M - 1)])
-    eng.write(ring_host[RING_BLOCKS * L - (M - 1):])       # wraps: ring now holds the cyclic 8-block stream
+    eng.write(ring_host[:RING_BLOCKS * wl["L"] - (wl["M"] - 1)])
+    eng.write(ring_host[RING_BLOCKS * wl["L"] - (wl["M"] - 1):])       # wraps: ring now holds the cyclic 8-block stream
+    nch, P, olen, plan = wl["nch"], wl["P"], wl["olen"], wl["plan"]
     bank = eng.bank(P, olen, nch)
-    resp = np.stack([pkg.filterapi.design_response(P, olen, N, True, lo, hi, 11.0) for _, lo, hi in plan])
+    resp = np.stack([pkg.filterapi.design_response(P, olen, wl["N"], True, lo, hi, 11.0) for _, lo, hi in plan])
     bank.set_responses(0, resp)
     bank.set_shifts(0, np.array([p[0] for p in plan], np.int32))
     bank.set_active(nch)
-    eng.set_notches([0], 0.01)                               # DC notch is always present (src/radio.c:601-620)
+    if os.environ.get("BENCH_NO_NOTCH") != "1":             # (A/B knob for scripts; the bench line always has the notch)
+        eng.set_notches([0], 0.01)                           # DC notch is always present (src/radio.c:601-620)
+
+    # ---- the RCCL communicator lives behind the engine's C ABI; torch.distributed only ships the id and keeps time
+    comm = None
+    rows = None
+    mode = None
+    if config == 4 and exch != "replicate":
+        uid = [pkg.engine.comm_unique_id() if rank == 0 else None]
+        if use_dist:
+            dist.broadcast_object_list(uid, src=0)
+        comm = pkg.engine.Comm(rank, world, uid[0], device=dev_index)
+        na, pitch, _off = eng.spec_layout
+        nrows = (wl["bins"] + na - 1) // na
+        mine = pkg.sharding.needed_rows([p[0] for p in plan], P, wl["bins"], na)
+        all_rows = [mine]
+        if use_dist:
+            all_rows = [None] * world
+            dist.all_gather_object(all_rows, mine)
+        mode = exch
+        if exch == "auto":
+            mode = pkg.sharding.plan_exchange(all_rows, nrows) if world > 1 else "broadcast"
+        rows = ([r[0] for r in all_rows], [r[1] for r in all_rows])
 
     def barrier():
         if use_dist:
             if dist.get_backend() == "nccl":
-                dist.barrier(device_ids=[local_rank])
+                dist.barrier(device_ids=[dev_index])
             else:
                 dist.barrier()
         torch.cuda.synchronize()
 
-    if not use_dist or exch == "replicate":
-        graph = bool(args.graph) and not use_dist
-        eng.run_blocks(0, args.warmup, graph=graph)
-        barrier()
-        t0 = time.perf_counter()
-        timing = eng.run_blocks(args.warmup, args.steps, graph=graph)   # returns after the stream drained
-        barrier()
-        elapsed = time.perf_counter() - t0
-        gpu_ms = timing.total_ms
-        exchange_mode = "none (forward transform replicated on every rank)" if use_dist else None
-    else:
-        # spectrum slots are torch tensors so RCCL can move them; each block's exchange is enqueued on the
-        # engine's own per-slot HIP stream (wrapped as a torch ExternalStream), so block j's exchange and
-        # channels overlap block j+1's forward transform on another stream
-        slots = [torch.zeros(2 * eng.spec_elems, dtype=torch.float32, device="cuda") for _ in range(4)]
-        for i, t in enumerate(slots):
-            eng.attach_spectrum(i, t.data_ptr())
-        streams = [torch.cuda.ExternalStream(eng.slot_stream(i)) for i in range(4)]
-        na, pitch, _off = eng.spec_layout
-        nrows = (BINS + na - 1) // na
-        mine = pkg.sharding.needed_rows([p[0] for p in plan], P, BINS, na)
-        all_rows = [None] * world
-        dist.all_gather_object(all_rows, mine)
-        mode = pkg.sharding.plan_exchange(all_rows, nrows) if exch == "auto" else exch
-        if mode not in ("broadcast", "subband"):
-            raise SystemExit("BENCH_EXCHANGE must be replicate, auto, subband or broadcast")
-
-        def exchange(j):
-            s = j % 4
-            with torch.cuda.stream(streams[s]):
-                if mode == "broadcast":
-                    dist.broadcast(slots[s], src=0, async_op=True).wait()   # stream-level wait, host does not block
-                elif mode == "subband":
-                    if rank == 0:
-                        ops = [dist.P2POp(dist.isend, slots[s][2 * pitch * lo:2 * pitch * hi], r)
-                               for r, (lo, hi) in enumerate(all_rows) if r != 0 and hi > lo]
-                    else:
-                        lo, hi = mine
-                        ops = [dist.P2POp(dist.irecv, slots[s][2 * pitch * lo:2 * pitch * hi], 0)] if hi > lo else []
-                    for w in (dist.batch_isend_irecv(ops) if ops else []):
-                        w.wait()
-
-        def run(job0, n):
-            for j in range(job0, job0 + n):
-                if rank == 0:
-                    eng.forward(j)
-                exchange(j)
-                bank.execute(j % 4)
-
-        run(0, args.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        run(args.warmup, args.steps)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        gpu_ms = elapsed * 1e3
-        exchange_mode = mode
-
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
 
-    # ---- per-kernel durations with HIP events on the launch stream (eager, instrumented)
+    def timed(run_k, job, nblocks):
+        barrier()
+        t0 = time.perf_counter()
+        last = run_k(job, nblocks)                            # returns after this rank's streams have drained
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        barrier()
+        return max_over_ranks(el), last
+
+    def measure(run_k):
+        """W warm-up steps; ONE drained K-step region (the literal contract); then regions of `reps` back-to-back
+        repetitions of the K-step loop (reps*K blocks issued without draining in between, each region bracketed by
+        barrier + synchronize, max over ranks), enough of them to cover --min-seconds.  The median region gives the
+        steady-state ms_per_step.  Returns (seconds per K steps, [seconds per K steps of every region], last timing
+        object, reps, seconds of the single drained K-step region)."""
+        job = 0
+        if args.warmup:
+            run_k(job, args.warmup); job += args.warmup
+        single, _ = timed(run_k, job, args.steps); job += args.steps
+        # same decisions on every rank: they are made from the reduced time
+        reps = int(min(20000, max(1, np.ceil(0.1 / max(single, 1e-6)))))          # one region ~ 0.1 s
+        nreg = int(min(50, max(5, np.ceil(args.min_seconds / 0.1))))
+        times, last = [], None
+        for _ in range(nreg):
+            el, last = timed(run_k, job, reps * args.steps)
+            times.append(el / reps)
+            job += reps * args.steps
+        return statistics.median(times), times, last, reps, single
+
+    legs = {}
+    graph = bool(args.graph) and not use_dist
+    if comm is not None:
+        def run_sharded(m):
+            return lambda job0, k: eng.run_blocks_sharded(comm, job0, k, root=0, rows=(rows if m == "subband" else None))
+        legs[mode] = measure(run_sharded(mode))
+        if world > 1:
+            other = "broadcast" if mode == "subband" else "subband"
+            legs[other] = measure(run_sharded(other))
+        legs["replicate"] = measure(lambda job0, k: eng.run_blocks(job0, k))
+        main_leg = mode
+    else:
+        main_leg = "replicate" if config == 4 else "local"
+        legs[main_leg] = measure(lambda job0, k: eng.run_blocks(job0, k, graph=graph))
+    elapsed, times, timing, reps, single = legs[main_leg]
+
+    # ---- per-kernel durations with HIP events on the launch stream (eager, instrumented; >= 200 launches whatever K is)
     roof = None
     if rank == 0:
-        eng_t = eng
-        # one kernel at a time on one stream; the first pass after the multi-stream run is discarded
-        # (the clocks need a few ms to settle after the load change: scripts/data_probe.py)
-        eng_t.run_blocks(0, min(args.steps, 200), graph=False, instrument=True)
-        it = eng_t.run_blocks(0, min(args.steps, 200), graph=False, instrument=True)
+        nk = max(200, min(args.steps, 1000))
+        eng.run_blocks(0, nk, graph=False, instrument=True)          # discarded: clocks settle after the load change
+        it = eng.run_blocks(0, nk, graph=False, instrument=True)
         kern = {}
         for name, ms, n in (("fwd_first_real", it.first_ms, it.first_n), ("fwd_cols", it.cols_ms, it.cols_n),
-                            ("fwd_rows", it.rows_ms, it.rows_n), ("chan_ifft", it.chan_ms, it.chan_n)):
+                            ("fwd_rows", it.rows_ms, it.rows_n), ("notch_fix", it.fix_ms, it.fix_n), ("chan_ifft", it.chan_ms, it.chan_n)):
             if n:
                 kern[name] = ms / n * 1e3       # microseconds per launch
         Ra = eng.axes[0] // 2 + 1
         inner_bytes = Ra * eng.axes[1] * eng.axes[2] * 8
-        own = {"fwd_first_real": 4 * N + inner_bytes, "fwd_cols": 2 * inner_bytes,
-               "fwd_rows": inner_bytes + 8 * BINS, "chan_ifft": nch * chan_bytes(P, olen)}
+        own = {"fwd_first_real": 4 * wl["N"] + inner_bytes, "fwd_cols": 2 * inner_bytes,
+               "fwd_rows": inner_bytes + 8 * wl["bins"], "chan_ifft": nch * chan_bytes(P, olen)}
         fwd_us = sum(kern.get(k, 0.0) for k in ("fwd_first_real", "fwd_cols", "fwd_rows"))
-        achieved = FWD_BYTES / (fwd_us * 1e-6) / 1e9 if fwd_us else 0.0
+        fb = fwd_bytes(wl["N"])
+        achieved = fb / (fwd_us * 1e-6) / 1e9 if fwd_us else 0.0
+        passes = 3 if eng.axes[1] > 1 else 2
         roof = {
             "bound": "hbm", "kernel": "forward transform = fwd_first_real + fwd_cols + fwd_rows (one launch each per block)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic_bytes(),
-            "frac_of_measured_copy_rate": achieved / 6290.0,        # 6.29 TB/s: the chip's achievable copy rate (MI355X_MICROARCH.md)
-            "structural_cap": "three HBM passes: at most 1/3 of peak on algorithmic bytes",
-            "algorithmic_bytes_per_block": FWD_BYTES, "forward_us_per_block": fwd_us,
+            "traffic": pmc_traffic_bytes() if config in (3, 4, 5) else None,
+            "frac_of_measured_copy_rate": achieved / COPY_RATE_GBS,
+            "structural_cap": "%d HBM passes: at most 1/%d of peak on algorithmic bytes" % (passes, passes),
+            "algorithmic_bytes_per_block": fb, "forward_us_per_block": fwd_us, "launches_timed": nk,
             "kernels_us": kern,
             "kernels_own_GBps": {k: own[k] / (kern[k] * 1e-6) / 1e9 for k in own if k in kern and kern[k] > 0},
         }
 
-    # ---- C_rt leg: ONE MI355X, one bank of millions of 12 kHz channels tiled from the same
-    # config-3 plan, inputs and outputs resident in HBM; every block is run to completion on its own and must take
-    # <= 20 ms (the literal "channels sustained in real time"; bisected value: profiles/r01_crt.json)
-    # With N > 1 (replicated forward) every rank carries its own bank of that size: the node's figure is the sum, and it
-    # holds only if the slowest block of the slowest rank stays inside 20 ms.
+    # ---- C_rt leg: one bank of millions of channels of the workload's kind; every block on its own <= 20 ms
     crt = None
-    if not args.no_crt and (not use_dist or exch == "replicate"):
+    if not args.no_crt and config in (3, 4):
+        crt_n = args.crt_channels or (17_000_000 if P == 300 else 8_400_000)
+        if comm is not None:
+            def run_one(job):
+                return eng.run_blocks_sharded(comm, job, 1, root=0, rows=(rows if mode == "subband" else None)).total_ms
+        else:
+            def run_one(job):
+                return eng.run_blocks(job, 1).total_ms
         try:
-            mine_crt = crt_leg(pkg, eng, args.crt_channels)
+            mine_crt = crt_leg(pkg, eng, wl, crt_n, args.crt_blocks, run_one)
         except Exception as ex:      # e.g. not enough free HBM: report, do not fail the bench line
             mine_crt = {"error": str(ex)[:200]}
+        every = [mine_crt]
         if use_dist:
             every = [None] * world
             dist.all_gather_object(every, mine_crt)          # reached by every rank, whatever happened above
-        else:
-            every = [mine_crt]
         if rank == 0:
             bad = [c for c in every if "error" in c]
             if bad:
@@ -375,34 +466,61 @@ def main():
                 crt["mean_block_ms"] = max(c["mean_block_ms"] for c in every)
                 crt["sustained"] = all(c["sustained"] for c in every)
                 crt["algorithmic_GBps"] = sum(c["algorithmic_GBps"] for c in every)
-                crt["frac_of_hbm_peak"] = crt["algorithmic_GBps"] / (HBM_PEAK_GBS * len(every))
+                crt["dram_side_GBps"] = sum(c["dram_side_GBps"] for c in every)
+                crt["dram_side_frac_of_hbm_peak"] = crt["dram_side_GBps"] / (HBM_PEAK_GBS * len(every))
                 crt["gpus"] = len(every)
+                crt["exchange"] = main_leg
 
     cpu = None
-    if rank == 0 and not use_dist and not args.no_cpu_baseline:
-        cpu = cpu_baseline(oracle_lib, ring_host, plan, P, olen)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(oracle_lib, ring_host, wl)
 
     if rank == 0:
+        def leg_obj(name, leg):
+            el, ts, tm, rp, sg = leg
+            return {"ms_per_step": el * 1e3 / args.steps, "value": nch * world * BLOCKTIME / (el / args.steps), "reps": rp, "regions": len(ts),
+                    "ms_per_step_min": min(ts) * 1e3 / args.steps, "ms_per_step_max": max(ts) * 1e3 / args.steps,
+                    "drained_k_step_region_ms_per_step": sg * 1e3 / args.steps,
+                    "gpu_event_ms_per_step": tm.total_ms / tm.blocks, "host_enqueue_ms_per_step": tm.enqueue_ms / tm.blocks}
         ms_per_step = elapsed * 1e3 / args.steps
         total_ch = nch * world
         value = total_ch * BLOCKTIME / (elapsed / args.steps)
-        replicated = use_dist and exch == "replicate"
-        step_bytes = (world if replicated else 1) * FWD_BYTES + total_ch * chan_bytes(P, olen) + (0 if (replicated or not use_dist) else (world - 1) * 8 * BINS)
+        fwd_copies = world if (config == 5 or main_leg == "replicate") else 1
+        step_bytes = fwd_copies * fwd_bytes(wl["N"]) + total_ch * chan_bytes(P, olen)
+        exchange_desc = None
+        if config == 4:
+            exchange_desc = {
+                "subband": "RCCL grouped ncclSend/ncclRecv of the spectrum rows each rank's channels read (chz_spectrum_exchange_rows), on the slot's HIP stream",
+                "broadcast": "RCCL ncclBroadcast of the whole spectrum slot (chz_spectrum_broadcast), on the slot's HIP stream",
+                "replicate": "none: every rank transforms its own HBM-resident copy of the samples",
+            }[main_leg] + "; %d rank(s)" % world
+        elif config == 5:
+            exchange_desc = "none (replicas only): %d independent front ends" % world
         out = {
-            "metric": "channels sustained @129.6 MS/s input (real-time-equivalent: channel-blocks/s / 50)",
+            "metric": "channels sustained @%.1f MS/s input (real-time-equivalent: channel-blocks/s / 50)" % (wl["fs"] / 1e6),
             "value": value, "unit": "channels", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "channels_total": total_ch, "P": P, "olen": olen, "N": N, "L": L, "M": M,
-                       "launch": ("hipGraph(8 blocks)" if (args.graph and not use_dist) else "eager") + ", %d HIP streams" % eng.lanes,
+            "config": {"workload": wl["name"] + (", 1 MI355X" if world == 1 else ""), "baseline_config": config,
+                       "channels_total": total_ch, "P": P, "olen": olen, "N": wl["N"], "L": wl["L"], "M": wl["M"],
+                       "launch": ("hipGraph(8 blocks)" if graph else "eager") + ", %d HIP streams, notch recurrence ordered by %s"
+                                 % (eng.lanes, "HIP events" if os.environ.get("CHZ_NOTCH_ORDER") == "event" else "device ticket"),
                        "plan": eng.plan},
-            "exchange": (exchange_mode if use_dist else None),
+            "timing": "steady state: median over `regions` timed regions, each = `reps` back-to-back repetitions of the K-step loop "
+                      "(reps*K blocks, barrier+sync on both sides, max over ranks); drained_k_step_region = ONE K-step region on its own, "
+                      "pipeline fill and drain included",
+            "reps": reps, "regions": len(times), "ms_per_step_min": min(times) * 1e3 / args.steps, "ms_per_step_max": max(times) * 1e3 / args.steps,
+            "drained_k_step_region_ms_per_step": single * 1e3 / args.steps,
+            "exchange": exchange_desc,
+            "legs": {k: leg_obj(k, v) for k, v in legs.items() if k != main_leg} or None,
             "blocks_per_s": args.steps / elapsed, "realtime_margin": BLOCKTIME / (elapsed / args.steps),
             "step_algorithmic_GBps": step_bytes / (elapsed / args.steps) / 1e9,
-            "gpu_event_ms_per_step": gpu_ms / args.steps,
-            "host_enqueue_ms_per_step": (timing.enqueue_ms / args.steps) if (not use_dist or exch == "replicate") else None,
+            "gpu_event_ms_per_step": timing.total_ms / timing.blocks,
+            "host_enqueue_ms_per_step": timing.enqueue_ms / timing.blocks,
             "roofline": roof, "cpu_baseline": cpu, "c_rt": crt,
         }
+    if comm is not None:
+        comm.close()
     eng.close()
     if use_dist:
         dist.destroy_process_group()

@@ -69,6 +69,9 @@ int chz_engine_info(const chz_engine *e, chz_info *info);
 /* run all engine work on a caller-owned hipStream_t (e.g. torch's current stream) */
 int chz_engine_set_stream(chz_engine *e, void *hip_stream);
 int chz_sync(chz_engine *e);
+/* non-blocking health check: < 0 (and chz_last_error) once a device-side consistency check has failed -- today that is
+ * the spur-notch ticket (see chz_set_notches_alpha); chz_sync and chz_run_blocks report the same condition */
+int chz_engine_check(const chz_engine *e);
 
 /* replaces the sample hand-over of write_rfilter/write_cfilter
  * (src/filter.c:1093-1134): append n samples (floats; re,im pairs for COMPLEX) from
@@ -97,8 +100,9 @@ int chz_forward(chz_engine *e, unsigned job);
  * replaces apply_notch_filters' state (src/filter.c:464-474).  n = 0 clears. */
 int chz_set_notches(chz_engine *e, const int *bins, int n, double alpha);
 /* the same with one averager gain per entry, as struct notch_state carries it (src/filter.h:42-46, src/filter.c:468);
- * an entry with alpha = 0 is the reference's no-op.  The recurrence over blocks is carried by HIP events between
- * the engine's streams (no kernel waits for another kernel on the device). */
+ * an entry with alpha = 0 is the reference's no-op.  The recurrence over blocks is ordered by a ticket the tiny notch
+ * kernels take in block order (bounded wait, loud failure, never a wrong state: chz_engine_check), or -- env
+ * CHZ_NOTCH_ORDER=event, and always inside captured graphs -- by HIP events between the engine's streams. */
 int chz_set_notches_alpha(chz_engine *e, const int *bins, const double *alpha, int n);
 int chz_spectrum_read(chz_engine *e, int slot, float *host);     /* 2*bins floats, synchronous */
 int chz_spectrum_device(chz_engine *e, int slot, float **dev);

@@ -142,7 +142,10 @@ struct chz_engine {
   int chan_stage = -1;              // output staging of chan_ifft: -1 by launch size, 0 never, 1 always (env CHZ_CHAN_STAGE)
   hipStream_t stream = nullptr;     // == lanes[0].s: input copies and anything not tied to a block
   bool own_stream = false;
-  hipStream_t upload = nullptr;     // control-plane uploads (responses): never waits for, or stalls, a lane
+  // control-plane uploads (responses): never waits for a lane.  Created on first use, AFTER the lanes: the runtime deals
+  // streams onto its (4) hardware queues round-robin in creation order, and two lanes sharing a queue serialise
+  // (measured: a fifth stream created between the lanes cost 15 -> 20 us per block).
+  hipStream_t upload = nullptr;
   Lane lanes[CHZ_MAX_LANES];
   int nlanes = 1;
   hipEvent_t input_ready = nullptr; // after the latest ring write
@@ -162,6 +165,11 @@ struct chz_engine {
   double* notch_alpha = nullptr; double* notch_state = nullptr;
   hipEvent_t notch_ev[CHZ_NOTCH_EVENTS] = {};
   unsigned notch_seq = 0; bool notch_have = false;      // notch_ev[(notch_seq-1) % 8] is the latest recorded one
+  int notch_order = 0;                                  // 0: device ticket (default), 1: HIP events (env CHZ_NOTCH_ORDER=event)
+  unsigned* notch_ver = nullptr;                        // device: tickets served so far
+  unsigned notch_tickets = 0;                           // host: tickets handed out so far
+  unsigned* notch_err = nullptr;                        // pinned host word the kernel raises when a ticket wait runs out
+  NotchTables notch_tab; std::vector<double> notch_alpha_h;
   std::vector<Bank> banks;
   hipGraphExec_t graph = nullptr; unsigned graph_job0 = 0; int graph_blocks = 0;
   // chz_run_blocks: events and issuing threads live as long as the engine
@@ -240,7 +248,6 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   e->ring_len = (long)ring_blocks * L * e->per;
   HIPOK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   e->own_stream = true;
-  HIPOK(hipStreamCreateWithFlags(&e->upload, hipStreamNonBlocking));
   if (const char* cs = getenv("CHZ_CHAN_STAGE")) e->chan_stage = atoi(cs) != 0;
   const char* envl = getenv("CHZ_STREAMS");
   int nl = envl ? atoi(envl) : 4;
@@ -249,7 +256,10 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   HIPOK(hipEventCreate(&e->ev_t0)); HIPOK(hipEventCreate(&e->ev_t1));
   HIPOK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   for (int i = 0; i < CHZ_MAX_LANES; i++) HIPOK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
-  for (int i = 0; i < CHZ_NOTCH_EVENTS; i++) HIPOK(hipEventCreateWithFlags(&e->notch_ev[i], hipEventDisableTiming));
+  for (int i = 0; i < CHZ_NOTCH_EVENTS; i++) HIPOK(hipEventCreateWithFlags(&e->notch_ev[i], hipEventDisableTiming | hipEventReleaseToDevice));
+  if (const char* no = getenv("CHZ_NOTCH_ORDER")) e->notch_order = strcmp(no, "event") == 0 ? 1 : (strcmp(no, "unordered-timing-only") == 0 ? 2 : 0);
+  HIPOK(hipHostMalloc((void**)&e->notch_err, sizeof(unsigned), hipHostMallocMapped));
+  *e->notch_err = 0;
   for (int i = 0; i < e->nlanes; i++) {
     if (i == 0) e->lanes[i].s = e->stream;
     else HIPOK(hipStreamCreateWithFlags(&e->lanes[i].s, hipStreamNonBlocking));
@@ -280,9 +290,9 @@ static void drop_graph(chz_engine* e) {
 }
 
 static void free_notches(chz_engine* e) {
-  hipFree(e->notch_addr); hipFree(e->notch_next); hipFree(e->notch_head); hipFree(e->notch_alpha); hipFree(e->notch_state);
-  e->notch_addr = e->notch_next = e->notch_head = nullptr; e->notch_alpha = nullptr; e->notch_state = nullptr;
-  e->n_notch = 0; e->notch_have = false;
+  hipFree(e->notch_addr); hipFree(e->notch_next); hipFree(e->notch_head); hipFree(e->notch_alpha); hipFree(e->notch_state); hipFree(e->notch_ver);
+  e->notch_addr = e->notch_next = e->notch_head = nullptr; e->notch_alpha = nullptr; e->notch_state = nullptr; e->notch_ver = nullptr;
+  e->n_notch = 0; e->notch_have = false; e->notch_tickets = 0;
 }
 
 void chz_engine_destroy(chz_engine* e) {
@@ -309,6 +319,7 @@ void chz_engine_destroy(chz_engine* e) {
   hipFree(e->tw_sub_a); hipFree(e->tw_sub_b); hipFree(e->tw_sub_c);
   hipFree(e->tw1_tile); hipFree(e->tw1_col); hipFree(e->tw2_tile); hipFree(e->tw2_col);
   free_notches(e);
+  if (e->notch_err) (void)hipHostFree(e->notch_err);
   if (e->upload) hipStreamDestroy(e->upload);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
@@ -341,13 +352,25 @@ int chz_engine_set_stream(chz_engine* e, void* hip_stream) {
   return 0;
 }
 
+// raised by notch_fix when its ticket never came up: the spectra of that block and of every later one are NOT notched
+static int check_device_errors(const chz_engine* e) {
+  const unsigned v = e->notch_err ? __atomic_load_n(e->notch_err, __ATOMIC_ACQUIRE) : 0u;
+  if (v) return fail(-8, "spur-notch ordering failed at ticket %u: a block's notch kernel waited for its predecessor in vain; "
+                         "the engine must be re-created (CHZ_NOTCH_ORDER=event orders by HIP events instead)", v - 1u);
+  return 0;
+}
 static int sync_all(chz_engine* e) {
   for (int i = 0; i < e->nlanes; i++) HIPOK(hipStreamSynchronize(e->lanes[i].s));
-  return 0;
+  return check_device_errors(e);
 }
 int chz_sync(chz_engine* e) {
   if (!e) return fail(-1, "null engine");
   return sync_all(e);
+}
+// non-blocking health check (the drop-in calls it from every execute_filter_input): < 0 once a device-side check failed
+int chz_engine_check(const chz_engine* e) {
+  if (!e) return fail(-1, "null engine");
+  return check_device_errors(e);
 }
 
 static int ring_write(chz_engine* e, const float* src, long n, hipMemcpyKind kind) {
@@ -453,15 +476,21 @@ static inline int lane_of(const chz_engine* e, unsigned job, const Instr* in) {
 }
 
 // K2 for one block.  apply_notch_filters (src/filter.c:464-474) is a recurrence over blocks, and consecutive
-// blocks live on different streams: block j's notch_fix waits for the EVENT recorded behind block j-1's
-// notch_fix, then records its own.  Ordering is stream semantics only -- no kernel ever waits for another
-// kernel from inside the device, so it holds under any stream-to-hardware-queue mapping (GPU_MAX_HW_QUEUES,
-// several engines per process, a profiler that serialises dispatches).  With more than one issuing host
-// thread the record of block j-1 must have been ISSUED before block j's wait is (a wait on a not yet
-// recorded event is a no-op): `turn` hands the notch section from thread to thread in block order.
-// capture_first: first block of a graph capture -- the previous graph launch is ordered by the launching
-// stream, and an event recorded outside the capture must not be waited on inside it.
-static int enqueue_notch(chz_engine* e, int slot, hipStream_t st, Instr* in, NotchTurn* turn, int seq, bool capture_first) {
+// blocks live on different streams.  Two ways to order it, both issued here in BLOCK ORDER (`turn` hands the notch
+// section from issuing thread to issuing thread):
+//   ticket (default)  notch_fix waits on the device for a counter to reach its own sequence number.  Because the
+//                     kernels are issued in block order, block j-1's notch_fix -- and everything it depends on, which
+//                     precedes it on its own stream -- sits IN FRONT of block j's on every hardware queue they might
+//                     share (GPU_MAX_HW_QUEUES, several engines per process): the kernel being waited for can always
+//                     start.  The wait is bounded anyway; if it runs out nothing is written, a host-visible error word
+//                     is raised and every later entry point fails loudly (check_device_errors).
+//   event             (CHZ_NOTCH_ORDER=event, and always inside a graph capture) a HIP event recorded behind block
+//                     j-1's notch_fix is waited for by block j's stream.  No device-side waiting at all, but on this
+//                     runtime a cross-stream event costs ~20 us of latency per link of the chain (measured: 26 us per
+//                     block instead of 16), which makes the chain the bottleneck of the free-running pipeline.
+// capture_first: first block of a graph capture -- the previous graph launch is ordered by the launching stream, and an
+// event recorded outside the capture must not be waited on inside it.
+static int enqueue_notch(chz_engine* e, int slot, hipStream_t st, Instr* in, NotchTurn* turn, int seq, bool capture_first, bool capturing) {
   if (e->n_notch <= 0) return 0;
   if (turn) {
     while (turn->next.load(std::memory_order_acquire) != seq) {
@@ -470,18 +499,22 @@ static int enqueue_notch(chz_engine* e, int slot, hipStream_t st, Instr* in, Not
     }
   }
   int rc = 0;
+  const bool by_event = e->notch_order == 1 || capturing;      // a captured launch cannot carry a running ticket number
   do {
-    if (e->notch_have && !capture_first && e->nlanes > 1) {
+    if (by_event && e->notch_have && !capture_first && e->nlanes > 1) {
       hipError_t he = hipStreamWaitEvent(st, e->notch_ev[(e->notch_seq - 1u) % CHZ_NOTCH_EVENTS], 0);
       if (he != hipSuccess) { rc = fail(-10, "hipStreamWaitEvent failed: %s", hipGetErrorString(he)); break; }
     }
     NotchFixParams q{};
     q.spec = e->spec[slot]; q.addr = e->notch_addr; q.next = e->notch_next; q.head = e->notch_head;
     q.alpha = e->notch_alpha; q.state = e->notch_state; q.n = e->n_notch;
+    e->notch_tab.fill_inline(q, e->notch_alpha_h.data());
+    q.err = e->notch_err;
+    if (!by_event && e->nlanes > 1 && e->notch_order != 2) { q.ver = e->notch_ver; q.seq = e->notch_tickets++; }   // 2: A/B timing of the bare kernel, WRONG results
     mark(in, st, 5, true);
-    launch_notch_fix(st, q, IN_E0(in), IN_E1(in));
+    if (launch_notch_fix(st, q, IN_E0(in), IN_E1(in))) { rc = fail(-4, "notch list too long"); break; }
     mark(in, st, 5, false);
-    if (e->nlanes > 1) {
+    if (by_event && e->nlanes > 1) {
       hipError_t he = hipEventRecord(e->notch_ev[e->notch_seq % CHZ_NOTCH_EVENTS], st);
       if (he != hipSuccess) { rc = fail(-10, "hipEventRecord failed: %s", hipGetErrorString(he)); break; }
       e->notch_seq++; e->notch_have = true;
@@ -494,7 +527,7 @@ static int enqueue_notch(chz_engine* e, int slot, hipStream_t st, Instr* in, Not
   return rc;
 }
 
-static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* turn = nullptr, int seq = 0, bool capture_first = false) {
+static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* turn = nullptr, int seq = 0, bool capture_first = false, bool capturing = false) {
   const FwdPlan& p = e->plan;
   const int slot = job % CHZ_ND;
   const int ln = lane_of(e, job, in);
@@ -537,7 +570,7 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* tu
   mark(in, st, 2, true);
   if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis c");
   mark(in, st, 2, false);
-  return enqueue_notch(e, slot, st, in, turn, seq, capture_first);
+  return enqueue_notch(e, slot, st, in, turn, seq, capture_first, capturing);
 }
 
 // output image of one slot; a sample is one float (REAL banks) or one float2
@@ -680,7 +713,11 @@ int chz_set_notches_alpha(chz_engine* e, const int* bins, const double* alpha, i
   HIPOK(hipMemcpy(e->notch_head, t.head.data(), ib, hipMemcpyHostToDevice));
   HIPOK(hipMemcpy(e->notch_alpha, alpha, db, hipMemcpyHostToDevice));
   HIPOK(hipMemset(e->notch_state, 0, 2 * db));
+  HIPOK(hipMalloc((void**)&e->notch_ver, sizeof(unsigned)));
+  HIPOK(hipMemset(e->notch_ver, 0, sizeof(unsigned)));
   HIPOK(hipDeviceSynchronize());
+  e->notch_tab = t; e->notch_alpha_h.assign(alpha, alpha + n);
+  e->notch_tickets = 0;
   e->n_notch = n;
   return 0;
 }
@@ -823,6 +860,7 @@ int chz_bank_set_responses(chz_engine* e, int bank, int ch0, int n, const float*
     }
     return 0;
   }
+  if (!e->upload) HIPOK(hipStreamCreateWithFlags(&e->upload, hipStreamNonBlocking));
   { int r = reclaim_rows(e, b, 0); if (r) return r; }
   if (b.free_rows.size() < (size_t)n) { int r = reclaim_rows(e, b, (size_t)n); if (r) return r; }
   if (b.free_rows.size() < (size_t)n) return fail(-7, "no spare response rows (%zu free, %d needed)", b.free_rows.size(), n);
@@ -1058,8 +1096,8 @@ int chz_bank_output_device(chz_engine* e, int bank, int slot, float** dev) {
   return 0;
 }
 
-static int enqueue_step(chz_engine* e, unsigned job, Instr* in, NotchTurn* turn = nullptr, int seq = 0, bool capture_first = false) {
-  int r = enqueue_forward(e, job, in, turn, seq, capture_first);
+static int enqueue_step(chz_engine* e, unsigned job, Instr* in, NotchTurn* turn = nullptr, int seq = 0, bool capture_first = false, bool capturing = false) {
+  int r = enqueue_forward(e, job, in, turn, seq, capture_first, capturing);
   if (r) return r;
   for (int b = 0; b < (int)e->banks.size(); b++)
     if ((r = enqueue_bank(e, b, job, in))) return r;
@@ -1122,7 +1160,7 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
       hipGraph_t g = nullptr;
       HIPOK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
       rc = lanes_fork(e, fork_ev);
-      for (int i = 0; i < cycle && !rc; i++) rc = enqueue_step(e, phase + (unsigned)i, nullptr, nullptr, 0, i == 0);
+      for (int i = 0; i < cycle && !rc; i++) rc = enqueue_step(e, phase + (unsigned)i, nullptr, nullptr, 0, i == 0, true);
       if (!rc) rc = lanes_join(e, join_ev);
       hipError_t ce = hipStreamEndCapture(s0, &g);
       e->notch_have = false;                      // events recorded inside a capture are not waitable outside it

@@ -529,11 +529,19 @@ __global__ void fwd_rows(RowsParams p) {
 // K2: spur notches (apply_notch_filters, src/filter.c:464-474): for every list entry, in list order,
 //   state += alpha * (X[bin] - state);  X[bin] -= state          (state is double complex, X float complex)
 // The state is a recurrence over BLOCKS, and blocks of different HIP streams run concurrently, so this tiny
-// kernel sits on the block's own stream right after fwd_rows and is ordered behind the previous block's
-// notch_fix by a HIP event (chz_engine.hip): stream semantics alone carry the recurrence, there is no
-// device-side waiting.  One lane per distinct bin; entries that name the same bin again are chained through
-// `next` and applied by the same lane in list order, exactly as the reference's sequential walk does.
+// kernel (one workgroup) sits on the block's own stream right after fwd_rows and takes its turn in block order:
+//   ver != nullptr   a ticket: wait until `ver` (blocks applied so far) equals this block's sequence number,
+//                    apply, publish seq+1 with release semantics.  The engine issues these kernels in block order
+//                    (chz_engine.hip: NotchTurn), so whatever a ticket waits for was enqueued BEFORE it on every
+//                    hardware queue and cannot be stuck behind it; the wait is bounded all the same, and a wait
+//                    that runs out touches nothing, raises `err` (host-visible) and leaves `ver` alone, so every
+//                    later block fails too and the host reports it -- a wrong recurrence is never published.
+//   ver == nullptr   ordering is done by the caller (HIP events between the streams, graph capture, one stream).
+// One lane per distinct bin; entries that name the same bin again are chained through `next` and applied by the
+// same lane in list order, exactly as the reference's sequential walk does.  Lists of up to CHZ_NOTCH_INLINE
+// entries (radiod's usual DC-only or few-spur lists) travel in the kernel arguments: no dependent table loads.
 // ------------------------------------------------------------------------------
+#define CHZ_NOTCH_INLINE 8
 struct NotchFixParams {
   float2* spec;           // this block's spectrum slot (SpecLayout order)
   const int* addr;        // [n] storage index of the entry's bin
@@ -542,22 +550,58 @@ struct NotchFixParams {
   const double* alpha;    // [n] per-entry averager gain
   double* state;          // [n][2] persists across blocks
   int n;
+  int inl;                // 1: the list is in the i_* arrays below
+  unsigned* ver;          // ticket counter or nullptr
+  unsigned seq;           // this block's ticket
+  unsigned* err;          // host-visible error word (0 = fine)
+  int i_addr[CHZ_NOTCH_INLINE];
+  signed char i_next[CHZ_NOTCH_INLINE], i_head[CHZ_NOTCH_INLINE];
+  double i_alpha[CHZ_NOTCH_INLINE];
 };
-__global__ void notch_fix(NotchFixParams p) {
-  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (i >= p.n || !p.head[i]) return;
-  const int a = p.addr[i];
-  float2 x = p.spec[a];
-  for (int e = i; e >= 0; e = p.next[e]) {
-    double sr = p.state[2 * e], si = p.state[2 * e + 1];
-    const double al = p.alpha[e];
-    double dr = al * ((double)x.x - sr), di = al * ((double)x.y - si);   // rounded products, then the sums (no fma on x86-64)
-    CHZ_ROUNDED_F64(dr); CHZ_ROUNDED_F64(di);
-    sr += dr; si += di;
-    p.state[2 * e] = sr; p.state[2 * e + 1] = si;
-    x = make_float2((float)((double)x.x - sr), (float)((double)x.y - si));
+__global__ void __launch_bounds__(1024) notch_fix(NotchFixParams p) {
+  const int i = (int)threadIdx.x;
+  // loads that do not depend on the previous block go out before the wait
+  bool mine = false; int a = 0;
+  if (i < p.n) {
+    if (p.inl) { mine = p.i_head[i] != 0; a = p.i_addr[i]; }
+    else { mine = p.head[i] != 0; a = p.addr[i]; }
   }
-  p.spec[a] = x;
+  float2 x = mine ? p.spec[a] : make_float2(0.f, 0.f);
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (p.ver != nullptr) {
+    // poll with relaxed loads (they bypass the non-coherent caches); ONE acquire fence once the ticket is up, so the
+    // cache invalidation that comes with it is not repeated per poll
+    unsigned v = 0; int spins = 0;
+    for (;;) {
+      v = __hip_atomic_load(p.ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v == p.seq || ++spins >= (1 << 19)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (v != p.seq) {                                   // never publish a wrong recurrence
+      if (i == 0) __hip_atomic_store(p.err, p.seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+#endif
+  if (mine) {
+    for (int e = i; e >= 0; e = p.inl ? (int)p.i_next[e] : p.next[e]) {
+      double sr = p.state[2 * e], si = p.state[2 * e + 1];
+      const double al = p.inl ? p.i_alpha[e] : p.alpha[e];
+      double dr = al * ((double)x.x - sr), di = al * ((double)x.y - si);   // rounded products, then the sums (no fma on x86-64)
+      CHZ_ROUNDED_F64(dr); CHZ_ROUNDED_F64(di);
+      sr += dr; si += di;
+      p.state[2 * e] = sr; p.state[2 * e + 1] = si;
+      x = make_float2((float)((double)x.x - sr), (float)((double)x.y - si));
+    }
+    p.spec[a] = x;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (p.ver != nullptr) {
+    __syncthreads();                                     // every lane's state and bin writes precede the release
+    if (i == 0) __hip_atomic_store(p.ver, p.seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------

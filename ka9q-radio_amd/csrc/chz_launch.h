@@ -52,12 +52,22 @@ inline int launch_chan_real(Radix2 r, int grid, int block, size_t lds, hipStream
 }
 inline int launch_notch_fix(hipStream_t s, const NotchFixParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   if (p.n <= 0) return 0;
-  CHZ_LAUNCH(notch_fix, (p.n + 63) / 64, 64, 0, s, e0, e1, p);
+  if (p.n > 1024) return -1;
+  CHZ_LAUNCH(notch_fix, 1, (p.n + 63) / 64 * 64, 0, s, e0, e1, p);
   return 0;
 }
 // Host side of K2: the reference walks its list in order (src/filter.c:464-474); entries naming a bin a second time are
 // chained behind the first so one lane applies them in list order.
-struct NotchTables { std::vector<int> addr, next, head; };
+struct NotchTables {
+  std::vector<int> addr, next, head;
+  // small lists ride in the kernel arguments
+  void fill_inline(NotchFixParams& q, const double* alpha) const {
+    const int n = (int)addr.size();
+    q.inl = n <= CHZ_NOTCH_INLINE;
+    if (!q.inl) return;
+    for (int i = 0; i < n; i++) { q.i_addr[i] = addr[(size_t)i]; q.i_next[i] = (signed char)next[(size_t)i]; q.i_head[i] = (signed char)head[(size_t)i]; q.i_alpha[i] = alpha[i]; }
+  }
+};
 inline NotchTables notch_tables(const int* bins, int n, const SpecLayout& lay) {
   NotchTables t;
   t.addr.resize((size_t)n); t.next.assign((size_t)n, -1); t.head.assign((size_t)n, 1);

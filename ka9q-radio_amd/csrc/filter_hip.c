@@ -585,6 +585,7 @@ int execute_filter_input(struct filter_in *const f) {
     f->input_read_pointer.r += f->ilen;
     ring_wrap((void **)&f->input_read_pointer.r, f->input_buffer, f->input_buffer_size);
   }
+  if (rc == 0) rc = chz_engine_check(c->eng);                      /* a failed device-side check makes every later block fail loudly */
   if (rc == 0) rc = chz_forward(c->eng, job);
   if (rc == 0 && c->host_spectrum) rc = chz_spectrum_read_async(c->eng, slot, (float *)f->fdomain[slot]);
   /* speculative batched channel launches: every slave with its last-known shift */

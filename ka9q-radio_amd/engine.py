@@ -42,7 +42,7 @@ SYMBOLS = [
     "chz_bank_set_tuning", "chz_bank_read_power", "chz_bank_read_power_async",
     "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
     "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real", "chz_bank_set_isb", "chz_bank_set_beam",
-    "chz_set_notches_alpha", "chz_slot_sync",
+    "chz_set_notches_alpha", "chz_slot_sync", "chz_engine_check",
     "chz_comm_unique_id", "chz_comm_create", "chz_comm_create_file", "chz_comm_destroy", "chz_comm_rank", "chz_comm_world",
     "chz_comm_barrier", "chz_comm_allreduce_max", "chz_spectrum_broadcast", "chz_spectrum_exchange_rows", "chz_run_blocks_sharded",
 ]
@@ -75,6 +75,7 @@ def lib():
         L.chz_set_notches.argtypes = [_vp, _vp, _i, _d]
         L.chz_set_notches_alpha.argtypes = [_vp, _vp, _vp, _i]
         L.chz_slot_sync.argtypes = [_vp, _i]
+        L.chz_engine_check.argtypes = [_vp]
         L.chz_comm_unique_id.argtypes = [_vp]
         L.chz_comm_create.argtypes = [C.POINTER(_vp), _i, _i, _vp, _i]
         L.chz_comm_create_file.argtypes = [C.POINTER(_vp), _i, _i, C.c_char_p, _i, _d]
@@ -208,6 +209,10 @@ class Engine:
             assert al.shape[0] == bins.shape[0]
             _check(lib().chz_set_notches_alpha(self._h, bins.ctypes.data if len(bins) else None,
                                                al.ctypes.data if len(bins) else None, len(bins)))
+
+    def check(self):
+        """Raises once a device-side consistency check (the notch ticket) has failed."""
+        _check(lib().chz_engine_check(self._h))
 
     def slot_sync(self, slot):
         _check(lib().chz_slot_sync(self._h, slot))

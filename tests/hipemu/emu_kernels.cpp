@@ -87,6 +87,7 @@ static int emu_forward_impl(const float* ring, const short* ring16, float scale1
     NotchFixParams q{};
     q.spec = spec_dev.data(); q.addr = nt.addr.data(); q.next = nt.next.data(); q.head = nt.head.data();
     q.alpha = alpha.data(); q.state = notch_state; q.n = n_notch;
+    if (getenv("EMU_NOTCH_INLINE")) nt.fill_inline(q, alpha.data());
     if (launch_notch_fix(nullptr, q)) return -5;
   }
   float2* out = reinterpret_cast<float2*>(spectrum);

@@ -19,7 +19,7 @@ def test_bench_cli_parses_without_a_gpu():
 @pytest.mark.gpu
 def test_bench_emits_one_json_line_with_the_contract_keys():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "64", "--warmup", "8",
-                        "--crt-channels", "3000000"], capture_output=True, text=True, timeout=600)
+                        "--crt-channels", "3000000", "--crt-blocks", "40"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
     j = json.loads(lines[-1])                                  # the JSON is the LAST line of stdout
@@ -29,6 +29,8 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
     assert j["n_gpus"] == 1 and j["steps"] == 64 and j["warmup"] == 8 and j["higher_is_better"] is True
     assert j["scaling"] == "weak" and j["vs_baseline"] is None and j["dtype"] == "f32" and j["data"] == "synthetic"
     assert "workload" in j["config"] and "model" not in j["config"]
+    assert j["reps"] >= 1 and j["regions"] >= 5 and j["drained_k_step_region_ms_per_step"] > 0 and j["ms_per_step_min"] <= j["ms_per_step"] <= j["ms_per_step_max"]
+    assert j["config"]["baseline_config"] == 3 and j["roofline"]["launches_timed"] >= 200
     assert j["value"] > 0 and abs(j["value"] - 1024 * 0.02 / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
     roof = j["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
@@ -37,4 +39,29 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
     cpu = j["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu
     crt = j["c_rt"]
-    assert crt["sustained"] is True and crt["channels"] >= 2990000 and crt["worst_block_ms"] <= 20.0
+    assert crt["sustained"] is True and crt["channels"] >= 2990000 and crt["worst_block_ms"] <= 20.0 and crt["blocks"] == 40
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,cfg", [(["--config", "2"], 2), (["--config", "4"], 4), (["--config", "5"], 5)])
+def test_bench_other_configs_run_on_one_gpu(extra, cfg):
+    env = dict(os.environ)
+    if cfg == 4:
+        env["BENCH_FORCE_DIST"] = "1"          # one rank, but through the process group and the RCCL exchange behind the C ABI
+        env["MASTER_PORT"] = "29617"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-crt",
+                        "--no-cpu-baseline", "--min-seconds", "0.05"] + extra, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.strip()][-1])
+    assert j["config"]["baseline_config"] == cfg and j["n_gpus"] == 1 and j["value"] > 0
+    if cfg == 4:
+        assert "RCCL" in j["exchange"] and "replicate" in j["legs"]
+    if cfg == 5:
+        assert "replicas only" in j["exchange"]
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    # --gpus N without a launcher self-spawns N ranks and fails LOUDLY when fewer GPUs are visible (here: none or one)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "2", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "only" in (r.stderr + r.stdout)

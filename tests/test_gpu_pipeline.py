@@ -1,0 +1,254 @@
+"""GPU tests of the engine's pipelining machinery (round 2): the event-ordered notch recurrence under hostile
+stream-to-queue mappings, retunes and filter swaps that never drain the pipeline, and RCCL behind the C ABI.
+Everything is compared with the CPU oracle (oracle/), which is pinned to the reference's own filter.c.
+"""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import load_pkg
+from test_gpu_parity import check_channel, rel, SPEC_REL
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_pkg()
+    if p.engine.lib().chz_device_count() < 1:
+        pytest.fail("no HIP device visible: GPU tests cannot run (there is no CPU fallback)")
+    ol.build()
+    return p
+
+
+def notch_per_entry(state, bins, alphas, spec):
+    """apply_notch_filters (src/filter.c:464-474) with one gain per entry: the oracle walks one entry at a time."""
+    for i, (b, a) in enumerate(zip(bins, alphas)):
+        ol.notch(state[2 * i:2 * i + 2], [b], a, spec)
+
+
+def run_cyclic(pkg, L, M, ring, bins, alphas, nblk, seed_check=True):
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    eng.set_notches(bins, alphas)
+    eng.write(ring[:8 * L - (M - 1)]); eng.write(ring[8 * L - (M - 1):])
+    eng.run_blocks(0, nblk)
+    got = eng.spectrum((nblk - 1) % 4)
+    eng.close()
+    return got
+
+
+def oracle_cyclic(L, M, ring, bins, alphas, nblk):
+    st = ol.Stream(L, M, ol.REAL)
+    st.push(ring[7 * L:8 * L])                     # primes the history with the samples before block 0
+    state = np.zeros(2 * len(bins))
+    want = None
+    for j in range(nblk):
+        want = st.push(ring[(j % 8) * L:(j % 8 + 1) * L])
+        notch_per_entry(state, bins, alphas, want)
+    return want
+
+
+def test_notch_per_entry_alpha_duplicates_and_zero_gain(pkg):
+    # struct notch_state carries its own alpha (src/filter.h:42-46); a bin named twice is filtered twice, in list
+    # order; alpha = 0 (the calloc'd DC sentinel of a full spur list, src/radio.c:601-620) is a no-op
+    L, M = 25920, 6481
+    nblk = 23
+    rng = np.random.default_rng(7)
+    ring = (rng.standard_normal(8 * L) + 0.4).astype(np.float32)
+    bins = [125, 4000, 125, 16000, 9000, 0]
+    alphas = [0.05, 0.01, 0.2, 0.003, 0.0, 0.02]
+    got = run_cyclic(pkg, L, M, ring, bins, alphas, nblk)
+    want = oracle_cyclic(L, M, ring, bins, alphas, nblk)
+    for b in set(bins):
+        assert abs(got[b] - want[b]) <= 5e-6 * abs(want[b]) + 5e-3, b
+    assert rel(got, want) <= SPEC_REL
+    # the zero-gain entry really left its bin alone
+    plain = oracle_cyclic(L, M, ring, [0], [0.0], nblk)
+    assert abs(got[9000] - plain[9000]) <= 5e-6 * abs(plain[9000]) + 5e-3
+
+
+def test_two_engines_with_notches_run_concurrently(pkg):
+    # two masters in one process (wfm composite filters, several front ends): 8 streams plus the runtime's own
+    # compete for the hardware queues; the recurrence of each engine must still be the sequential one
+    L, M = 25920, 6481
+    nblk = 61
+    rng = np.random.default_rng(8)
+    rings = [(rng.standard_normal(8 * L) + 0.3 * (i + 1)).astype(np.float32) for i in range(2)]
+    bins = [[0], [300, 0]]
+    alphas = [[0.01], [0.1, 0.02]]
+    got = [None, None]
+
+    def work(i):
+        got[i] = run_cyclic(pkg, L, M, rings[i], bins[i], alphas[i], nblk)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        want = oracle_cyclic(L, M, rings[i], bins[i], alphas[i], nblk)
+        for b in bins[i]:
+            assert abs(got[i][b] - want[b]) <= 5e-6 * abs(want[b]) + 5e-3, (i, b)
+        assert rel(got[i], want) <= SPEC_REL
+
+
+_QUEUE_SCRIPT = r"""
+import sys, os
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+import numpy as np
+import oracle_lib as ol
+from conftest import load_pkg
+from test_gpu_pipeline import run_cyclic, oracle_cyclic
+pkg = load_pkg(); ol.build()
+L, M, nblk = 25920, 6481, 45
+rng = np.random.default_rng(9)
+ring = (rng.standard_normal(8 * L) + 0.4).astype(np.float32)
+bins, alphas = [125, 16000, 0], [0.05, 0.02, 0.01]
+got = run_cyclic(pkg, L, M, ring, bins, alphas, nblk)
+want = oracle_cyclic(L, M, ring, bins, alphas, nblk)
+for b in bins:
+    assert abs(got[b] - want[b]) <= 5e-6 * abs(want[b]) + 5e-3, b
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("queues,threads", [(1, 2), (2, 2), (1, 1), (4, 4)])
+def test_notch_order_survives_any_queue_mapping(queues, threads):
+    # GPU_MAX_HW_QUEUES squeezes the engine's 4 streams into fewer hardware queues, CHZ_ENQ_THREADS changes who issues
+    # what: with ordering by events there is nothing on the device that could wait for a kernel queued behind it
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=str(queues), CHZ_ENQ_THREADS=str(threads))
+    script = _QUEUE_SCRIPT % {"tests": os.path.join(ROOT, "tests"), "root": ROOT}
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+
+
+def _engine_with_bank(pkg, L, M, P, olen, nch, rng):
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    ring = rng.standard_normal(8 * L).astype(np.float32)
+    eng.write(ring[:8 * L - (M - 1)]); eng.write(ring[8 * L - (M - 1):])
+    bank = eng.bank(P, olen, nch)
+    return eng, bank, ring
+
+
+def _spectra(L, M, ring, nblk):
+    st = ol.Stream(L, M, ol.REAL)
+    st.push(ring[7 * L:8 * L])
+    return [st.push(ring[(j % 8) * L:(j % 8 + 1) * L], f64=True) for j in range(nblk)]
+
+
+def test_retune_takes_effect_in_stream_order_without_draining(pkg):
+    # blocks are enqueued back to back with NO synchronisation; between them channels are retuned (shift), one gets a
+    # new filter, one flips to ISB.  Every block must come out with the settings that were current when IT was
+    # enqueued -- blocks in flight keep the old ones (per-slot descriptors, response rows swapped, not overwritten).
+    L, M, P, olen, nch = 25920, 6481, 300, 240, 24
+    rng = np.random.default_rng(10)
+    eng, bank, ring = _engine_with_bank(pkg, L, M, P, olen, nch, rng)
+    N = L + M - 1
+    respA = np.stack([pkg.filterapi.design_response(P, olen, N, True, -0.3, 0.3, 11.0)] * nch)
+    respB = pkg.filterapi.design_response(P, olen, N, True, 0.02, 0.2, 6.0)
+    bank.set_responses(0, respA)
+    shifts = np.array([500 + 137 * i for i in range(nch)], np.int32)
+    bank.set_shifts(0, shifts)
+    bank.set_active(nch)
+    history = []                                   # per block: (shifts, which channels use respB, isb flags)
+    cur_shift, cur_b, cur_isb = shifts.copy(), set(), np.zeros(nch, np.uint8)
+    nblk = 4                                       # one block per slot, all in flight together
+    for j in range(nblk):
+        if j == 1:
+            cur_shift = cur_shift.copy(); cur_shift[3] = -4000; cur_shift[17] = 9000
+            bank.set_shifts(3, cur_shift[3:4]); bank.set_shifts(17, cur_shift[17:18])
+        if j == 2:
+            cur_b = {5}
+            bank.set_responses(5, respB[None, :])
+            cur_isb = cur_isb.copy(); cur_isb[8] = 1
+            bank.set_isb(8, cur_isb[8:9])
+        if j == 3:
+            cur_shift = cur_shift.copy(); cur_shift[3] = 2500
+            bank.set_shifts(3, cur_shift[3:4])
+        history.append((cur_shift.copy(), set(cur_b), cur_isb.copy()))
+        eng.step(j)                                # asynchronous
+    eng.sync()
+    spectra = _spectra(L, M, ring, nblk)
+    for j in range(nblk):
+        out = bank.read_slot(j % 4)
+        sh, useb, isb = history[j]
+        for c in range(nch):
+            r = respB if c in useb else respA[c]
+            want = ol.channel(spectra[j], ol.REAL, P, olen, int(sh[c]), r, isb=bool(isb[c]))
+            check_channel(out[c], want)
+    eng.close()
+
+
+def test_response_swaps_recycle_spare_rows(pkg):
+    # more filter changes than the bank has spare rows, while blocks keep flowing: rows are recycled behind fences
+    L, M, P, olen, nch = 25920, 6481, 300, 240, 8
+    rng = np.random.default_rng(11)
+    eng, bank, ring = _engine_with_bank(pkg, L, M, P, olen, nch, rng)
+    N = L + M - 1
+    resp = [pkg.filterapi.design_response(P, olen, N, True, -0.3, 0.3, 11.0) for _ in range(nch)]
+    bank.set_responses(0, np.stack(resp))
+    shifts = np.array([700 + 211 * i for i in range(nch)], np.int32)
+    bank.set_shifts(0, shifts); bank.set_active(nch)
+    nblk = 60                                      # 60 swaps > 16 spare rows
+    for j in range(nblk):
+        c = j % nch
+        hi = 0.05 + 0.4 * ((j * 7) % 10) / 10
+        resp[c] = pkg.filterapi.design_response(P, olen, N, True, -hi, hi, 11.0)
+        bank.set_responses(c, resp[c][None, :])
+        eng.step(j)
+    eng.sync()
+    spectra = _spectra(L, M, ring, nblk)
+    out = bank.read_slot((nblk - 1) % 4)
+    for c in range(nch):
+        check_channel(out[c], ol.channel(spectra[nblk - 1], ol.REAL, P, olen, int(shifts[c]), resp[c]))
+    eng.close()
+
+
+def test_rccl_behind_the_c_abi_single_rank(pkg):
+    # chz_comm_* / chz_spectrum_broadcast / _exchange_rows / chz_run_blocks_sharded with one rank: the collective
+    # calls really go through RCCL (ncclCommInitRank, ncclBroadcast, grouped send/recv) on the slot streams and the
+    # sharded block loop gives exactly what the plain one gives.  Multi-rank data movement: tests/test_distributed_gloo.py.
+    L, M, P, olen, nch = 25920, 6481, 300, 240, 16
+    rng = np.random.default_rng(12)
+    eng, bank, ring = _engine_with_bank(pkg, L, M, P, olen, nch, rng)
+    N = L + M - 1
+    bank.set_responses(0, np.stack([pkg.filterapi.design_response(P, olen, N, True, -0.3, 0.3, 11.0)] * nch))
+    shifts = np.array([400 + 300 * i for i in range(nch)], np.int32)
+    bank.set_shifts(0, shifts); bank.set_active(nch)
+    eng.set_notches([0], 0.01)
+    comm = pkg.engine.Comm(0, 1, pkg.engine.comm_unique_id(), device=0)
+    assert comm.allreduce_max([3.5, -1.0]).tolist() == [3.5, -1.0]
+    comm.barrier()
+    eng.run_blocks(0, 9)
+    plain = [bank.read_slot(s).copy() for s in range(4)]
+    spec_plain = eng.spectrum(0)
+    eng.set_notches([0], 0.01)                     # reset the recurrence
+    t = eng.run_blocks_sharded(comm, 0, 9)
+    assert t.blocks == 9 and t.total_ms > 0
+    for s in range(4):
+        np.testing.assert_array_equal(bank.read_slot(s), plain[s])
+    np.testing.assert_array_equal(eng.spectrum(0), spec_plain)
+    na, pitch, off = eng.spec_layout
+    rows = pkg.sharding.needed_rows(shifts, P, eng.bins, na)
+    eng.set_notches([0], 0.01)
+    eng.run_blocks_sharded(comm, 0, 9, rows=([rows[0]], [rows[1]]))
+    for s in range(4):
+        np.testing.assert_array_equal(bank.read_slot(s), plain[s])
+    comm.broadcast_spectrum(eng, 2); comm.exchange_rows(eng, 1, [rows[0]], [rows[1]])
+    eng.sync()
+    comm.close()
+    eng.close()
+
+
+def test_comm_rendezvous_file_single_rank(pkg, tmp_path):
+    comm = pkg.engine.Comm(0, 1, device=0, path=str(tmp_path / "chz_id"))
+    assert os.path.getsize(tmp_path / "chz_id") == 128
+    comm.barrier()
+    comm.close()
