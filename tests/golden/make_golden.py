@@ -64,9 +64,39 @@ def make_downconvert(name):
     print(name, "written")
 
 
+def make_next_rows(name):
+    """SURVEY 8(f) ranks 2 and 3 from the reference's OWN radio.c / rx888.c (oracle/ref_radio_wrap.c, ref_rx888_wrap.c):
+    estimate_noise() (src/radio.c:1783-1866) on a seeded REAL-master spectrum for a set of shifts and slave sizes, and
+    convert_avx2() (src/rx888.c:694-751) on seeded int16 samples with and without the LTC2208 de-randomiser."""
+    r = np.random.default_rng(808)
+    bins, fs = 16201, 1.296e6
+    spec = ((r.standard_normal(bins) + 1j * r.standard_normal(bins)) * 3e-3).astype(np.complex64)
+    idx = r.integers(0, bins, 40)
+    spec[idx] += ((r.standard_normal(40) + 1j * r.standard_normal(40)) * 0.5).astype(np.complex64)
+    shifts = np.array([0, 1, -1, 300, 500, 700, -700, 5000, -5000, bins - 1, -(bins - 1), bins - 400, bins - 600, bins + 50] +
+                      [int(x) for x in r.integers(-bins, bins, 18)], np.int32)
+    s_bins = np.array([300, 600, 1200], np.int32)
+    n0 = np.array([[ol.ref_estimate_noise(spec, ol.REAL, int(sb), int(sh), fs) for sh in shifts] for sb in s_bins])
+    x = r.integers(-32768, 32768, 4096, dtype=np.int64).astype(np.int16)
+    x[:8] = [32767, -32768, 32766, -32766, -32767, 0, 1, -1]
+    scale = np.float32(ol.scale_ad(True, 1) * 1.2345)
+    conv = {}
+    for rnd in (0, 1):
+        out = ol.ref_convert_i16(x, scale, bool(rnd), avx2=True)
+        if out is None:
+            raise SystemExit("this host has no AVX2: convert_avx2 cannot be run")
+        conv["conv%d" % rnd], conv["energy%d" % rnd], conv["clips%d" % rnd] = out[0], np.uint64(out[1]), out[2]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), spectrum=spec, samprate=fs, shifts=shifts, s_bins=s_bins, n0=n0,
+                        x16=x, scale=scale, **conv)
+    print(name, "written")
+
+
 if __name__ == "__main__":
     if not ol.have_ref():
         raise SystemExit("oracle/_ref/libka9q_ref.so missing: run `make -C oracle` where /root/reference exists")
+    if not (ol.have_ref_radio() and ol.have_ref_rx888()):
+        raise SystemExit("oracle/_ref/libka9q_ref_radio.so / _rx888.so missing: run `make -C oracle` where /root/reference exists")
+    make_next_rows("next_rows")
     make_downconvert("downconvert_tail")
     # scaled-down RX888 geometry (real input, N = 14400, 40 Hz bins), P = 300: usb / cw / iq / inverted / edge channels
     make("real_n14400_p300", 11520, 2881, ol.REAL, 240, 576e3, 100020.0,

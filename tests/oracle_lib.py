@@ -391,6 +391,60 @@ def convert_i16(samples, scale, randomize=False):
     return out, en.value, clips
 
 
+_ref_radio = None
+_ref_rx888 = None
+
+
+def have_ref_radio():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libka9q_ref_radio.so"))
+
+
+def have_ref_rx888():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libka9q_ref_rx888.so"))
+
+
+def ref_radio():
+    """The reference's own radio.c (oracle/ref_radio_wrap.c): estimate_noise / quantile / quickselect."""
+    global _ref_radio
+    if _ref_radio is None:
+        L = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libka9q_ref_radio.so"))
+        L.refradio_quickselect.restype = _d; L.refradio_quickselect.argtypes = [_vp, _i, _i]
+        L.refradio_quantile.restype = _d; L.refradio_quantile.argtypes = [_vp, _i, _d]
+        L.refradio_estimate_noise.restype = _d; L.refradio_estimate_noise.argtypes = [_vp, _i, _i, _i, _i, _d]
+        _ref_radio = L
+    return _ref_radio
+
+
+def ref_estimate_noise(spectrum, in_type, s_bins, shift, samprate):
+    sp = np.ascontiguousarray(spectrum, np.complex64)
+    return ref_radio().refradio_estimate_noise(_fptr(sp), sp.size, in_type, int(s_bins), int(shift), float(samprate))
+
+
+def ref_rx888():
+    """The reference's own rx888.c (oracle/ref_rx888_wrap.c): convert / convert_avx2."""
+    global _ref_rx888
+    if _ref_rx888 is None:
+        L = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libka9q_ref_rx888.so"))
+        for f in (L.refrx_convert, L.refrx_convert_avx2):
+            f.argtypes = [_vp, _vp, _i, C.c_float, _vp, _i]
+        _ref_rx888 = L
+    return _ref_rx888
+
+
+def ref_convert_i16(samples, scale, randomize=False, avx2=False):
+    """(float32 samples, energy, clips) from the reference's convert() / convert_avx2(); None if avx2 is asked for and absent."""
+    s = np.ascontiguousarray(samples, np.int16)
+    raw = np.zeros(s.size + 16, np.float32)
+    off = (-raw.ctypes.data // 4) % 8                # 32-byte aligned output, as convert_avx2 asserts
+    out = raw[off:off + s.size]
+    en = C.c_uint64(0)
+    fn = ref_rx888().refrx_convert_avx2 if avx2 else ref_rx888().refrx_convert
+    clips = fn(_fptr(out), _fptr(s), s.size, float(scale), C.byref(en), 1 if randomize else 0)
+    if clips < 0:
+        return None
+    return out.copy(), en.value, clips
+
+
 class Downconv:
     """Per-channel tail of downconvert() (src/radio.c:1476-1520).  which = "oracle" (restatement) or
     "ref" (the reference's own osc.c / cispi with the glue statements restated in ref_driver.c)."""

@@ -12,8 +12,9 @@ import oracle_lib as ol
 from conftest import load_pkg
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(f).startswith("downconvert"))
+FILES = sorted(f for f in glob.glob(os.path.join(GOLDEN, "*.npz")) if os.path.basename(f).split("_")[0] in ("real", "complex"))
 DC_FILE = os.path.join(GOLDEN, "downconvert_tail.npz")
+NEXT_FILE = os.path.join(GOLDEN, "next_rows.npz")
 
 
 def rel(a, b):
@@ -139,3 +140,68 @@ def test_hip_reproduces_downconvert_golden():
                 assert _ulps(wr, want)[0] <= 1.0
     finally:
         eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# vectors produced by the reference's own radio.c / rx888.c
+# ------------------------------------------------------------------------------------------------
+def test_oracle_reproduces_noise_and_conversion_golden(oracle_built):
+    g = np.load(NEXT_FILE)
+    for i, sb in enumerate(g["s_bins"]):
+        got = np.array([ol.estimate_noise(g["spectrum"], ol.REAL, int(sb), int(sh), float(g["samprate"])) for sh in g["shifts"]])
+        assert np.allclose(got, g["n0"][i], rtol=1e-12, atol=0)
+    for rnd in (0, 1):
+        out, en, clips = ol.convert_i16(g["x16"], float(g["scale"]), bool(rnd))
+        assert np.array_equal(out.view(np.uint32), g["conv%d" % rnd].view(np.uint32))
+        assert en == int(g["energy%d" % rnd]) and clips == int(g["clips%d" % rnd])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_noise_and_conversion_golden():
+    """noise_est on the golden spectrum (written straight into a spectrum slot) against the reference's estimate_noise();
+    the int16 input path against the reference's convert_avx2(): the spectrum of the raw samples must be bit-identical
+    to the spectrum of the reference-converted floats, and the energy / clip statistics must match."""
+    import ctypes as C
+    pkg = load_pkg()
+    g = np.load(NEXT_FILE)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    L, M = 25920, 6481                                  # REAL master with exactly the golden spectrum's 16201 bins
+    fs = float(g["samprate"])
+    for sb in g["s_bins"]:
+        P = int(sb); olen = P * 4 // 5
+        eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+        try:
+            assert eng.bins == g["spectrum"].shape[0]
+            na, pitch, off = eng.spec_layout
+            k = np.arange(eng.bins)
+            dev = np.zeros(eng.spec_elems, np.complex64)
+            dev[(k // na) * pitch + off + k % na] = g["spectrum"]
+            assert hip.hipMemcpy(eng.spectrum_ptr(1), dev.ctypes.data, dev.nbytes, 1) == 0
+            nch = len(g["shifts"])
+            b = eng.bank(P, olen, nch)
+            b.set_responses(0, np.ones((nch, P), np.complex64) / P); b.set_shifts(0, g["shifts"]); b.set_active(nch)
+            b.enable_noise(fs)
+            b.execute(1)
+            got = b.read_noise(1)
+            want = g["n0"][list(g["s_bins"]).index(sb)]
+            assert np.allclose(got, want, rtol=1e-12, atol=0)
+        finally:
+            eng.close()
+    # rank 3: raw int16 in, converted on load
+    n = g["x16"].shape[0]
+    for rnd in (0, 1):
+        e16 = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+        ef = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+        try:
+            x16 = np.tile(g["x16"], L // n + 1)[:L]
+            xf = np.tile(g["conv%d" % rnd], L // n + 1)[:L]
+            e16.write_i16(x16, float(g["scale"]), bool(rnd)); ef.write(xf)
+            e16.forward(0); ef.forward(0)
+            assert np.array_equal(e16.spectrum(0).view(np.uint32), ef.spectrum(0).view(np.uint32))
+            en, clips = e16.input_stats(0)
+            reps, rest = divmod(L, n)
+            _, en_r, cl_r = ol.convert_i16(g["x16"][:rest], float(g["scale"]), bool(rnd)) if rest else (None, 0, 0)
+            assert en == reps * int(g["energy%d" % rnd]) + en_r and clips == reps * int(g["clips%d" % rnd]) + cl_r
+        finally:
+            e16.close(); ef.close()

@@ -252,3 +252,90 @@ def test_beam_gather_matches_reference(oracle_built):
             want = ol.channel_beam(spec, P, olen, sh, resp, alpha, beta)
             assert np.abs(got - want).max() <= 2e-6 * max(np.abs(want).max(), 1e-30), (blk, sh)
     m.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# the restatements are pinned to the reference's OWN radio.c / rx888.c
+# (oracle/ref_radio_wrap.c, oracle/ref_rx888_wrap.c include the files unmodified and export their
+# static functions; everything else is discarded at link time)
+# ------------------------------------------------------------------------------------------------
+def _noisy_spectrum(r, bins, nsig=40):
+    s = ((r.standard_normal(bins) + 1j * r.standard_normal(bins)) * 3e-3).astype(np.complex64)
+    idx = r.integers(0, bins, nsig)
+    s[idx] += ((r.standard_normal(nsig) + 1j * r.standard_normal(nsig)) * 0.5).astype(np.complex64)   # carriers
+    return s
+
+
+@pytest.mark.skipif(not ol.have_ref_radio(), reason="oracle/_ref/libka9q_ref_radio.so not built (needs /root/reference)")
+def test_quantile_and_quickselect_match_reference_radio_c(oracle_built):
+    # src/radio.c:1724-1775; the restatement finds the same order statistics (it never copies the array order)
+    R = ol.ref_radio()
+    r = np.random.default_rng(5)
+    for n in (1, 2, 3, 10, 999, 1000, 1001, 1200):
+        a = r.exponential(1.0, n)
+        for p in (0.0, 0.1, 0.5, 0.999, 1.0):
+            b = a.copy()
+            got = R.refradio_quantile(b.ctypes.data, n, p)
+            pos = p * (n - 1); i = int(np.floor(pos)); fr = pos - i
+            srt = np.sort(a)
+            want = srt[i] if fr == 0 else srt[i] + fr * (srt[i + 1] - srt[i])
+            assert got == pytest.approx(want, rel=1e-15)
+        k = int(r.integers(0, n))
+        b = a.copy()
+        assert R.refradio_quickselect(b.ctypes.data, n, k) == np.sort(a)[k]
+
+
+@pytest.mark.skipif(not ol.have_ref_radio(), reason="oracle/_ref/libka9q_ref_radio.so not built (needs /root/reference)")
+@pytest.mark.parametrize("in_type,bins", [(ol.REAL, 16201), (ol.REAL, 1620001 // 100), (ol.COMPLEX, 14400)])
+def test_estimate_noise_matches_reference_radio_c(oracle_built, in_type, bins):
+    # estimate_noise() (src/radio.c:1783-1866) run from the reference's own radio.c on the same spectrum: window placement
+    # incl. the clamps at DC / Nyquist, inverted (negative-shift) channels, slave bins below and above Min_noise_bins.
+    # The reference sums the qualifying energies in the order quickselect left them; the restatement sums in window order:
+    # the two agree to the last few bits of a double.
+    r = np.random.default_rng(bins + in_type)
+    spec = _noisy_spectrum(r, bins)
+    fs = 1.296e6
+    if in_type == ol.REAL:
+        shifts = [0, 1, -1, 300, 499, 500, 501, 700, -700, 5000, -5000, bins - 1, -(bins - 1), bins - 400, bins - 600,
+                  bins - 501, bins + 50] + [int(x) for x in r.integers(-bins, bins, 40)]
+    else:
+        # A complex master's window that reaches the +Nyquist seam is left partly UNINITIALISED by the reference
+        # (src/radio.c:1826-1836 breaks out of the fill loop and then reads all nbins entries of a VLA): those shifts
+        # have no defined answer and are not compared.  Windows through DC (the wrap) are.
+        half = bins // 2
+        shifts = [0, 1, -1, 200, -200, 600, -600, 2500, -2500, half - 800, -(half - 800)] + \
+                 [int(x) for x in r.integers(-(half - 800), half - 800, 40)]
+    for s_bins in (300, 600, 1000, 1200):
+        for sh in shifts:
+            if in_type == ol.COMPLEX:
+                nb = max(s_bins, 1000)
+                start = (sh - nb // 2) % bins
+                if start < half <= start + nb or start + nb >= bins + half:
+                    continue
+            want = ol.ref_estimate_noise(spec, in_type, s_bins, sh, fs)
+            got = ol.estimate_noise(spec, in_type, s_bins, sh, fs)
+            assert got == pytest.approx(want, rel=1e-12, abs=0.0), (s_bins, sh)
+            assert want > 0
+
+
+@pytest.mark.skipif(not ol.have_ref_rx888(), reason="oracle/_ref/libka9q_ref_rx888.so not built (needs /root/reference)")
+@pytest.mark.parametrize("randomize", [False, True])
+def test_convert_matches_reference_rx888_c(oracle_built, randomize):
+    # src/rx888.c:694-767 run from the reference's own rx888.c.  convert_avx2 is what an x86-64 radiod executes;
+    # the restatement must equal it bit for bit (samples, energy sum, clip count), de-randomiser included.
+    r = np.random.default_rng(77 + randomize)
+    x = r.integers(-32768, 32768, 64 * 1024, dtype=np.int64).astype(np.int16)
+    x[:8] = [32767, -32768, 32766, -32766, -32767, 0, 1, -1]
+    scale = ol.scale_ad(True, 1) * 1.2345
+    got, en, clips = ol.convert_i16(x, scale, randomize)
+    av = ol.ref_convert_i16(x, scale, randomize, avx2=True)
+    if av is not None:
+        assert np.array_equal(av[0].view(np.uint32), got.view(np.uint32)) and av[1] == en and av[2] == clips
+    port = ol.ref_convert_i16(x, scale, randomize, avx2=False)
+    if not randomize:
+        assert np.array_equal(port[0].view(np.uint32), got.view(np.uint32)) and port[1] == en and port[2] == clips
+    else:
+        # the portable fallback's `x ^= (x << 15) >> 14` is evaluated in int and is NOT the LTC2208 de-randomiser its
+        # comment and the AVX2 routine describe (if bit 0 is set, flip bits 1..15): the two reference routines disagree
+        # with each other here, and the restatement (and the kernel) follow the AVX2 one
+        assert av is None or not np.array_equal(port[0], av[0])
