@@ -232,6 +232,24 @@ int chz_spectrum_exchange_rows(chz_engine *e, chz_comm *c, int slot, int root, c
 int chz_run_blocks_sharded(chz_engine *e, chz_comm *c, int root, int mode, const int *row_lo, const int *row_hi,
                            unsigned job0, int nblocks, chz_timing *timing);
 
+/* ---- small inline masters: radiod's filter2 (src/radio.c:1572-1594: a private COMPLEX master of N = round2(2*blocksize)
+ * points with one same-size COMPLEX slave, run inline by the channel thread; share/presets.conf:204,223,297).  A pool holds
+ * every instance of one geometry (8 <= N = L+M-1 <= 8192, 2-3-5-smooth); ONE kernel launch serves all instances that are
+ * due (one workgroup each: forward transform, gather x response with the slave's shift, ISB unpacking, backward transform,
+ * all in LDS).  The device keeps no overlap state: a request carries its whole N-sample window, exactly what the
+ * reference's mirrored ring holds at input_read_pointer (src/filter.c:626-636). */
+typedef struct chz_mini chz_mini;
+int chz_mini_create(chz_mini **out, int L, int M, int capacity, int device);     /* replaces create_filter_input + _output */
+void chz_mini_destroy(chz_mini *m);
+int chz_mini_capacity(const chz_mini *m);
+int chz_mini_add(chz_mini *m);                                                  /* -> instance index */
+int chz_mini_release(chz_mini *m, int inst);
+int chz_mini_set_response(chz_mini *m, int inst, const float *resp);            /* N complex, as set_filter leaves it */
+/* n requests in one launch: instance inst[i], window win[i] (N complex on the host), shift[i] (NULL = 0), isb[i] (NULL = off),
+ * L output samples to out[i]; synchronous, thread-safe */
+int chz_mini_execute(chz_mini *m, int n, const int *inst, const float *const *win, const int *shift, const unsigned char *isb,
+                     float *const *out);
+
 /* host-side helper exposed for tests: the closed-form gather descriptor
  * {t0,cnt,src0,dir,conj,wrap} that restates src/filter.c:728-911 */
 int chz_gather_descriptor(int in_type, int master_bins, int P, int shift, int out6[6]);

@@ -1234,3 +1234,4 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
 }  // extern "C"
 
 #include "chz_comm.inc"
+#include "chz_mini.inc"

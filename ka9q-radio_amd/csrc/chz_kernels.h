@@ -1044,4 +1044,114 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
   if (lane == 0) p.n0[ch] = cnt ? e / (double)cnt * p.scale : 0.0;
 }
 
+// ------------------------------------------------------------------------------
+// Small inline masters (radiod's filter2, src/radio.c:1572-1594: a private COMPLEX master of
+// N = round2(2 * blocksize) points with ONE same-size COMPLEX slave, shift 0, optionally ISB, run inline by
+// each channel thread after the first filter).  Thousands of them exist, each far too small for a launch of
+// its own: ONE launch serves every instance that is due, one workgroup per instance, everything in LDS:
+//   window (N samples, history + new, as the host ring holds them contiguously; src/filter.c:626-636)
+//   -> forward N-point transform (src/filter.c:573-582)  -> gather with the slave's descriptor x response,
+//   ISB unpacking, Nyquist bin zeroed (src/filter.c:728-793,895-911)  -> backward transform (:914), keep the
+//   last olen samples (:357).
+// Stateless: the overlap lives in the caller's ring, so an instance can be re-run or served by several slaves.
+// The transform is a Stockham autosort over radix-{2,3,4,5} stages (natural order in, natural order out, two
+// LDS buffers), twiddles from a float64-rounded table W_N^k.  N <= 8192, 2-3-5-smooth.
+// ------------------------------------------------------------------------------
+#ifndef CHZ_MINI_MAX_STAGES
+#define CHZ_MINI_MAX_STAGES 14
+#endif
+struct MiniReq { ChanDesc d; int isb; int pad; };      // per request: gather descriptor (d.row = response row), ISB flag
+struct MiniParams {
+  const float2* in;       // [nreq][N] windows
+  float2* out;            // [nreq][olen]
+  const MiniReq* req;     // [nreq]
+  const float2* resp;     // [rows][N]
+  const float2* tw;       // [N]  e^{-2 pi i k / N}
+  int N, olen, nstages;
+  int radix[CHZ_MINI_MAX_STAGES];
+};
+
+template <int R, int SIGN>
+__device__ __forceinline__ void mini_stage(const float2* __restrict__ x, float2* __restrict__ y, const float2* __restrict__ tw,
+                                           int N, int Ns, int tid, int nthr) {
+  const int M = N / R;                 // butterflies in this stage
+  const int tws = N / (Ns * R);        // table stride of W_(Ns*R)
+  for (int j = tid; j < M; j += nthr) {
+    const int k = j % Ns;
+    float2 v[R];
+    static_for<R>([&](auto t) {
+      constexpr int T = decltype(t)::value;
+      float2 a = x[j + T * M];
+      if constexpr (T > 0) {
+        float2 w = tw[(T * k * tws) % N];          // < N already (T*k < Ns*R), the modulo only guards the table
+        if (SIGN > 0) w.y = -w.y;
+        a = cmul(a, w);
+      }
+      v[T] = a;
+    });
+    reg_dft<R, SIGN>(v);
+    const int j0 = (j / Ns) * Ns * R + k;
+    static_for<R>([&](auto t) { constexpr int T = decltype(t)::value; y[j0 + T * Ns] = v[T]; });
+  }
+}
+template <int SIGN>
+__device__ __forceinline__ float2* mini_fft(float2* a, float2* b, const MiniParams& p, int tid, int nthr) {
+  int Ns = 1;
+  for (int s = 0; s < p.nstages; s++) {
+    const int r = p.radix[s];
+    if (r == 2) mini_stage<2, SIGN>(a, b, p.tw, p.N, Ns, tid, nthr);
+    else if (r == 3) mini_stage<3, SIGN>(a, b, p.tw, p.N, Ns, tid, nthr);
+    else if (r == 4) mini_stage<4, SIGN>(a, b, p.tw, p.N, Ns, tid, nthr);
+    else mini_stage<5, SIGN>(a, b, p.tw, p.N, Ns, tid, nthr);
+    Ns *= r;
+    __syncthreads();
+    float2* t = a; a = b; b = t;
+  }
+  return a;        // where the result is
+}
+
+__global__ void __launch_bounds__(256) mini_ovs(MiniParams p) {
+  HIP_DYNAMIC_SHARED(float2, lds)
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int N = p.N;
+  float2* A = lds;
+  float2* B = lds + N;
+  const MiniReq rq = p.req[blockIdx.x];
+  const float2* __restrict__ win = p.in + (size_t)blockIdx.x * N;
+  for (int i = tid; i < N; i += nthr) A[i] = win[i];
+  __syncthreads();
+  float2* X = mini_fft<-1>(A, B, p, tid, nthr);            // master spectrum, natural order
+  float2* Y = (X == A) ? B : A;
+  // gather x response into the slave's bins (FFT order), exactly as chan_ifft does for a COMPLEX master
+  const float2* __restrict__ H = p.resp + (size_t)rq.d.row * N;
+  const int P = N;
+  for (int i = tid; i < P; i += nthr) {
+    int t = i - (P + 1) / 2; if (t < 0) t += P;            // rank from the most negative bin
+    const int u = t - rq.d.t0;
+    const bool ok = (u >= 0) && (u < rq.d.cnt);
+    int src = rq.d.src0 + rq.d.dir * u;
+    if (rq.d.wrap && src >= rq.d.wrap) src -= rq.d.wrap;
+    float2 v = make_float2(0.f, 0.f);
+    if (ok) { v = X[src]; if (rq.d.conj) v.y = -v.y; v = cmul(v, H[i]); }
+    Y[i] = v;
+  }
+  __syncthreads();
+  if (rq.isb) {                                            // src/filter.c:895-909
+    for (int q = tid; q <= P / 2; q += nthr) {
+      if (q == 0) { Y[0] = make_float2(0.f, 0.f); continue; }
+      if (2 * q >= P) continue;
+      const float2 pos = Y[q], neg = Y[P - q];
+      Y[q] = make_float2(pos.x + neg.x, pos.y - neg.y);          // pos + conj(neg)
+      Y[P - q] = make_float2(neg.x - pos.x, neg.y + pos.y);      // neg - conj(pos)
+    }
+    __syncthreads();
+  }
+  if (tid == 0) Y[(P + 1) / 2] = make_float2(0.f, 0.f);     // :911 comes after the unpack
+  __syncthreads();
+  float2* Z = mini_fft<+1>(Y, X, p, tid, nthr);
+  float2* __restrict__ o = p.out + (size_t)blockIdx.x * p.olen;
+  const int drop = P - p.olen;
+  for (int i = tid; i < p.olen; i += nthr) o[i] = Z[drop + i];
+}
+
 }  // namespace chz

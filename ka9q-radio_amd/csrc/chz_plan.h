@@ -20,7 +20,7 @@ namespace chz {
 // per-channel backward transform lengths P = R1*R2 (reference sizes: docs/FFTW3.md:51-68)
 #define CHZ_CHAN_MENU(X) \
   X(4, 5) X(5, 6) X(10, 15) X(10, 16) X(10, 20) X(15, 20) X(16, 20) X(20, 20) X(20, 24) \
-  X(24, 25) X(25, 32) X(30, 32) X(30, 40)
+  X(24, 25) X(25, 32) X(30, 32) X(30, 40) X(40, 48)
 
 struct Radix2 { int r1, r2; };
 
@@ -323,6 +323,18 @@ inline ChanDescH make_chan_desc(int in_type, int m_bins, int P, int shift) {
     d.t0 = (int)t0; d.src0 = (int)rp; d.cnt = (int)cnt; d.dir = 1; d.wrap = m_bins;
   }
   return d;
+}
+
+// ---- small inline masters (mini_ovs): Stockham stages of an N-point transform, radix 4 first ---------------
+#define CHZ_MINI_MAX_STAGES 14
+inline bool mini_factor(int N, int* radix, int* nstages) {
+  int n = N, k = 0;
+  while (n % 4 == 0 && k < CHZ_MINI_MAX_STAGES) { radix[k++] = 4; n /= 4; }
+  const int small[3] = {2, 3, 5};
+  for (int r : small)
+    while (n % r == 0 && k < CHZ_MINI_MAX_STAGES) { radix[k++] = r; n /= r; }
+  *nstages = k;
+  return n == 1;
 }
 
 }  // namespace chz

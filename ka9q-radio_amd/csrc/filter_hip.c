@@ -74,6 +74,7 @@ struct hbank {
 struct done_note { struct mctx *ctx; unsigned job; struct timespec t0; };
 
 struct mctx {
+  int kind;                         /* CTX_ENGINE; a small inline master carries a struct minictx instead (filter_hip_mini.h) */
   chz_engine *eng;
   struct filter_in *master;
   pthread_mutex_t lock;             /* serialises engine calls and bank bookkeeping */
@@ -217,6 +218,8 @@ static double complex cis_pi(double x) {       /* e^{i pi x}, argument reduced i
   return c + I * s;
 }
 
+#include "filter_hip_mini.h"
+
 /* ------------------------------------------------------------------------- */
 /* completion: runs on a HIP runtime thread after the block's work has drained   */
 /* ------------------------------------------------------------------------- */
@@ -335,6 +338,7 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   int const bins = (in_type == COMPLEX) ? N : (N / 2 + 1);
   if (bins < 2) return -1;                                         /* src/filter.c:198-199 */
 
+  if (master->init && master->fwd_plan && is_mini_master(master)) mini_free_input(master);
   if (master->init && master->fwd_plan) {                          /* re-create with new geometry */
     struct mctx *old = MCTX(master);
     if (old->ring_pinned) chz_host_unregister(master->input_buffer);
@@ -344,8 +348,10 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
     for (int i = 0; i < ND; i++) { chz_host_free(master->fdomain[i]); master->fdomain[i] = NULL; }
     ring_unmap(&master->input_buffer, master->input_buffer_size);
   }
+  if (mini_wanted(L, M, in_type)) return mini_create_input(master, L, M);   /* radiod's filter2 and its like */
   struct mctx *c = calloc(1, sizeof *c);
   if (!c) return -1;
+  c->kind = CTX_ENGINE;
   const char *dev = getenv("KA9Q_HIP_DEVICE");
   if (chz_engine_create(&c->eng, L, M, in_type == REAL ? CHZ_REAL : CHZ_COMPLEX, dev ? atoi(dev) : 0, NULL, 0) != 0) {
     fprintf(stderr, "create_filter_input(L=%d M=%d): %s\n", L, M, chz_last_error());
@@ -414,6 +420,12 @@ fail:
 
 int delete_filter_input(struct filter_in *master) {
   if (master == NULL) return -1;
+  if (is_mini_master(master)) {
+    mini_free_input(master);
+    if (master->init) { pthread_mutex_destroy(&master->filter_mutex); pthread_cond_destroy(&master->filter_cond); }
+    memset(master, 0, sizeof *master);                             /* src/filter.c:940 */
+    return 0;
+  }
   if (master->fwd_plan) {
     struct mctx *c = MCTX(master);
     chz_sync(c->eng);
@@ -455,7 +467,10 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
   slave->master = master;
   slave->out_type = out_type;
   set_filter_weights(slave, 1.0, 0.0);
-  if (out_type == COMPLEX || out_type == REAL) {
+  if (is_mini_master(master)) {
+    int r = mini_create_output(slave, master, len, out_type);
+    if (r < 0) { slave->init = false; slave->master = NULL; return -1; }
+  } else if (out_type == COMPLEX || out_type == REAL) {
     struct mctx *c = MCTX(master);
     bool const real = out_type == REAL;
     slave->bins = real ? slave->points / 2 + 1 : slave->points;    /* src/filter.c:346,374 */
@@ -496,6 +511,7 @@ done:;
 
 int delete_filter_output(struct filter_out *slave) {
   if (slave == NULL) return -1;
+  if (slave->rev_plan && is_mini_master(slave->master)) mini_delete_output(slave);
   if (slave->rev_plan && slave->master && slave->master->fwd_plan) {
     struct mctx *c = MCTX(slave->master);
     struct sctx *sc = SCTX(slave);
@@ -544,6 +560,7 @@ static void sync_notches(struct mctx *c, struct filter_in *f) {
 
 int execute_filter_input(struct filter_in *const f) {
   if (f == NULL || f->fwd_plan == NULL) return -1;
+  if (is_mini_master(f)) return mini_execute_input(f);
   struct mctx *c = MCTX(f);
   /* Everything below is asynchronous, so the producer must not run more than ND blocks ahead of the device: block
      job-ND owns this job's completion record, spectrum slot, staged outputs and host-ring window until its callback has
@@ -748,6 +765,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
   bool const ready = slave->response != NULL && dst != NULL;
   pthread_mutex_unlock(&slave->response_mutex);
   if (!ready) return 0;                                            /* src/filter.c:715-718 */
+  if (is_mini_master(master)) return mini_execute_output(slave, shift, slot);
 
   struct mctx *c = MCTX(master);
   struct sctx *sc = SCTX(slave);
@@ -839,6 +857,11 @@ int set_filter(struct filter_out *const slave, double low, double high, double c
   slave->response = response;
   pthread_mutex_unlock(&slave->response_mutex);
   free(old);
+  if (slave->rev_plan && is_mini_master(slave->master)) {
+    struct msctx *ms = (struct msctx *)(void *)slave->rev_plan;
+    if (chz_mini_set_response(ms->pool->h, ms->inst, (const float *)response) != 0) { fprintf(stderr, "set_filter: %s\n", chz_last_error()); return -1; }
+    return 0;
+  }
   if (slave->rev_plan && slave->master->fwd_plan) {
     struct mctx *c = MCTX(slave->master);
     struct sctx *sc = SCTX(slave);

@@ -44,6 +44,7 @@ SYMBOLS = [
     "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real", "chz_bank_set_isb", "chz_bank_set_beam",
     "chz_set_notches_alpha", "chz_slot_sync", "chz_engine_check",
     "chz_comm_unique_id", "chz_comm_create", "chz_comm_create_file", "chz_comm_destroy", "chz_comm_rank", "chz_comm_world",
+    "chz_mini_create", "chz_mini_destroy", "chz_mini_capacity", "chz_mini_add", "chz_mini_release", "chz_mini_set_response", "chz_mini_execute",
     "chz_comm_barrier", "chz_comm_allreduce_max", "chz_spectrum_broadcast", "chz_spectrum_exchange_rows", "chz_run_blocks_sharded",
 ]
 
@@ -76,6 +77,13 @@ def lib():
         L.chz_set_notches_alpha.argtypes = [_vp, _vp, _vp, _i]
         L.chz_slot_sync.argtypes = [_vp, _i]
         L.chz_engine_check.argtypes = [_vp]
+        L.chz_mini_create.argtypes = [C.POINTER(_vp), _i, _i, _i, _i]
+        L.chz_mini_destroy.argtypes = [_vp]; L.chz_mini_destroy.restype = None
+        L.chz_mini_capacity.argtypes = [_vp]
+        L.chz_mini_add.argtypes = [_vp]
+        L.chz_mini_release.argtypes = [_vp, _i]
+        L.chz_mini_set_response.argtypes = [_vp, _i, _vp]
+        L.chz_mini_execute.argtypes = [_vp, _i, _vp, _vp, _vp, _vp, _vp]
         L.chz_comm_unique_id.argtypes = [_vp]
         L.chz_comm_create.argtypes = [C.POINTER(_vp), _i, _i, _vp, _i]
         L.chz_comm_create_file.argtypes = [C.POINTER(_vp), _i, _i, C.c_char_p, _i, _d]
@@ -408,6 +416,51 @@ class Comm:
     def close(self):
         if self._h:
             lib().chz_comm_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MiniPool:
+    """Pool of small inline masters of one geometry (radiod's filter2, src/radio.c:1572-1594)."""
+
+    def __init__(self, L, M, capacity, device=0):
+        self._h = _vp()
+        _check(lib().chz_mini_create(C.byref(self._h), L, M, capacity, device))
+        self.L, self.M, self.N, self.capacity = L, M, L + M - 1, capacity
+
+    def add(self):
+        return _check(lib().chz_mini_add(self._h))
+
+    def release(self, inst):
+        _check(lib().chz_mini_release(self._h, inst))
+
+    def set_response(self, inst, resp):
+        r = np.ascontiguousarray(resp, np.complex64).reshape(-1)
+        assert r.shape[0] == self.N
+        _check(lib().chz_mini_set_response(self._h, inst, r.ctypes.data))
+
+    def execute(self, insts, windows, shifts=None, isb=None):
+        """windows: [n][N] complex64 (M-1 old + L new samples each) -> [n][L] complex64."""
+        insts = np.ascontiguousarray(insts, np.int32)
+        n = insts.shape[0]
+        win = np.ascontiguousarray(windows, np.complex64).reshape(n, self.N)
+        out = np.zeros((n, self.L), np.complex64)
+        wp = (_vp * n)(*[win[i].ctypes.data for i in range(n)])
+        op = (_vp * n)(*[out[i].ctypes.data for i in range(n)])
+        sh = np.ascontiguousarray(shifts, np.int32) if shifts is not None else None
+        fl = np.ascontiguousarray(isb, np.uint8) if isb is not None else None
+        _check(lib().chz_mini_execute(self._h, n, insts.ctypes.data, wp, sh.ctypes.data if sh is not None else None,
+                                      fl.ctypes.data if fl is not None else None, op))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().chz_mini_destroy(self._h)
             self._h = _vp()
 
     def __del__(self):

@@ -37,6 +37,9 @@ static _Atomic int *Progress;          /* blocks consumed per channel */
 static float *Input;
 
 struct chanarg { int idx; };
+/* optional second filter per channel, created and driven exactly as radio.c does (src/radio.c:1503-1513,1572-1594):
+   env HARNESS_FILTER2="blocking low high beta [isb_channel]" */
+static int F2_blocking, F2_isb = -1; static double F2_low, F2_high, F2_beta;
 
 static void *channel_thread(void *a) {
   int const i = ((struct chanarg *)a)->idx;
@@ -45,15 +48,37 @@ static void *channel_thread(void *a) {
   if (create_filter_output(&out, &Master, Olen, COMPLEX) != 0) { fprintf(stderr, "create_filter_output failed\n"); exit(2); }
   if (set_filter(&out, Plan[i].low, Plan[i].high, Plan[i].beta) != 0) { fprintf(stderr, "set_filter failed\n"); exit(2); }
   if (getenv("HARNESS_ISB") && atoi(getenv("HARNESS_ISB")) == i) out.isb = true;   /* set by the caller after create (src/radio.c:1586) */
+  struct filter_in f2in; struct filter_out f2out;
+  memset(&f2in, 0, sizeof f2in); memset(&f2out, 0, sizeof f2out);
+  if (F2_blocking > 0) {
+    int const blocksize = F2_blocking * Olen;
+    int const n = ceil_pow2((uint32_t)(2 * blocksize));        /* round2(2 * blocksize), src/radio.c:1578 */
+    int const order = n - blocksize;
+    if (create_filter_input(&f2in, blocksize, order + 1, COMPLEX) != 0) { fprintf(stderr, "filter2 create_filter_input failed\n"); exit(2); }
+    f2in.perform_inline = true;
+    if (create_filter_output(&f2out, &f2in, blocksize, COMPLEX) != 0) { fprintf(stderr, "filter2 create_filter_output failed\n"); exit(2); }
+    f2out.isb = (F2_isb == i);
+    if (set_filter(&f2out, F2_low, F2_high, F2_beta) != 0) { fprintf(stderr, "filter2 set_filter failed\n"); exit(2); }
+  }
   atomic_store(&Progress[i], 0);       /* registered: the producer may start */
   for (int b = 0; b < Nblocks; b++) {
     if (b == Plan[i].refilter_block) set_filter(&out, Plan[i].low2, Plan[i].high2, Plan[i].beta);
     int shift = (b >= Plan[i].retune_block) ? Plan[i].shift2 : Plan[i].shift;
     if (execute_filter_output(&out, shift) != 0) { fprintf(stderr, "execute_filter_output failed\n"); exit(2); }
-    memcpy(Result + ((size_t)b * Nch + i) * Olen, out.output.c, sizeof(float complex) * (size_t)Olen);
+    if (F2_blocking > 0) {
+      int r = write_cfilter(&f2in, out.output.c, Olen);          /* runs the input side once the block is full (src/radio.c:1508) */
+      if (r < 0) { fprintf(stderr, "filter2 write_cfilter failed\n"); exit(2); }
+      if (r > 0) {
+        if (execute_filter_output(&f2out, 0) != 0) { fprintf(stderr, "filter2 execute_filter_output failed\n"); exit(2); }
+        for (int q = 0; q < F2_blocking; q++)                     /* the F2_blocking*Olen samples continue the channel's stream */
+          memcpy(Result + ((size_t)(b - F2_blocking + 1 + q) * Nch + i) * Olen, f2out.output.c + (size_t)q * Olen, sizeof(float complex) * (size_t)Olen);
+      }
+    } else
+      memcpy(Result + ((size_t)b * Nch + i) * Olen, out.output.c, sizeof(float complex) * (size_t)Olen);
     atomic_store(&Progress[i], b + 1);
   }
   Drops[i] = out.block_drops;
+  if (F2_blocking > 0) { delete_filter_output(&f2out); delete_filter_input(&f2in); }
   delete_filter_output(&out);
   return NULL;
 }
@@ -118,6 +143,10 @@ int main(int argc, char **argv) {
   notch[0].bin = 0; notch[0].alpha = 0.01;
   Master.notches = notch;
 
+  if (getenv("HARNESS_FILTER2")) {
+    int k = sscanf(getenv("HARNESS_FILTER2"), "%d %lf %lf %lf %d", &F2_blocking, &F2_low, &F2_high, &F2_beta, &F2_isb);
+    if (k < 4) { fprintf(stderr, "HARNESS_FILTER2 needs: blocking low high beta [isb_channel]\n"); return 1; }
+  }
   pthread_t *th = calloc((size_t)Nch, sizeof *th), clk;
   struct chanarg *args = calloc((size_t)Nch, sizeof *args);
   for (int i = 0; i < Nch; i++) { args[i].idx = i; pthread_create(&th[i], NULL, channel_thread, &args[i]); }

@@ -235,4 +235,23 @@ int emu_channels_tuned(const float* spec, int m_bins, int in_type, int P, int ol
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
 }
 
+// --- small inline masters (filter2): one workgroup per request, window -> olen output samples --------------
+int emu_mini(const float* windows, int nreq, int N, int olen, const float* resp, const int* shifts, const unsigned char* isb, float* out) {
+  MiniParams p{};
+  if (!mini_factor(N, p.radix, &p.nstages)) return -1;
+  std::vector<f2> tw((size_t)N);
+  for (int k = 0; k < N; k++) tw[(size_t)k] = root_of_unity(k, N, -1);
+  std::vector<MiniReq> req((size_t)nreq);
+  for (int i = 0; i < nreq; i++) {
+    ChanDescH h = make_chan_desc(CHZ_IN_COMPLEX, N, N, shifts[i]);
+    req[(size_t)i].d = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap, i, shifts[i]};
+    req[(size_t)i].isb = isb[i] != 0; req[(size_t)i].pad = 0;
+  }
+  p.in = reinterpret_cast<const float2*>(windows); p.out = reinterpret_cast<float2*>(out); p.req = req.data();
+  p.resp = reinterpret_cast<const float2*>(resp); p.tw = F2(tw); p.N = N; p.olen = olen;
+  const int threads = N / 4 >= 256 ? 256 : (N / 4 >= 64 ? (N / 4 + 63) / 64 * 64 : 64);
+  hipLaunchKernelGGL(mini_ovs, dim3(nreq), dim3(threads), sizeof(float2) * 2 * (size_t)N, nullptr, p);
+  return 0;
+}
+
 }  // extern "C"

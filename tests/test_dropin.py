@@ -212,3 +212,52 @@ def test_c_example_runs_against_the_engine_abi():
         r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "within" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blocking,isb_ch", [(1, 2), (4, -1)])
+def test_dropin_filter2_inline_masters(blocking, isb_ch):
+    """radiod with `filter2 = 1` / `= 4` (share/presets.conf:204,223,297): every channel thread owns a private COMPLEX
+    master of N = round2(2*blocksize) points plus a same-size slave and drives it inline behind the first filter
+    (src/radio.c:1503-1513,1572-1594).  Through the drop-in these are pooled inline masters: one launch per block serves
+    all of them.  Oracle: the first filter's output stream filtered again by the restated overlap-save pair."""
+    _build_lib(); ol.build()
+    L, M, olen, P = 25920, 6481, 240, 300
+    nblocks = 12
+    rng = np.random.default_rng(18)
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = []
+    for i in range(40):
+        shift = int(rng.integers(-12000, 12000))
+        plan.append((shift, shift, 10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4))
+    plan[0] = (2500, 2500, 10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4)       # sits on the sig_gen carrier
+    f2lo, f2hi, f2beta = -0.2, 0.25, 7.0
+    env = {"HARNESS_FILTER2": "%d %r %r %r %d" % (blocking, f2lo, f2hi, f2beta, isb_ch)}
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x, env=env)
+    assert meta["drops"] == "0"
+    N = L + M - 1
+    bs = blocking * olen
+    n2 = 1 << (2 * bs - 1).bit_length()
+    m2 = n2 - bs + 1
+    resp2 = ol.set_filter(n2, bs, n2, False, f2lo, f2hi, f2beta)
+    st = ol.Stream(L, M, ol.REAL)
+    state = np.zeros(2)
+    first = np.zeros((nblocks, len(plan), olen), np.complex64)
+    for b in range(nblocks):
+        s64 = st.push(x[b * L:(b + 1) * L], f64=True)
+        dc = s64[:1].astype(np.complex64); ol.notch(state, [0], 0.01, dc); s64[0] = dc[0]
+        for i, p in enumerate(plan):
+            first[b, i] = ol.channel(s64, ol.REAL, P, olen, p[0], ol.set_filter(P, olen, N, True, p[4], p[5], p[6]))
+    usable = nblocks - nblocks % blocking
+    for i in range(len(plan)):
+        st2 = ol.Stream(bs, m2, ol.COMPLEX)
+        stream = first[:usable, i].reshape(-1)
+        for k in range(usable // blocking):
+            sp = st2.push(stream[k * bs:(k + 1) * bs], f64=True)
+            want = ol.channel(sp, ol.COMPLEX, n2, bs, 0, resp2, isb=(i == isb_ch))
+            got = out[k * blocking:(k + 1) * blocking, i].reshape(-1)
+            err = float(np.sqrt(np.mean(np.abs(got - want) ** 2)))
+            rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+            assert err <= 2e-5 * rms + 1e-9, (i, k, err, rms)

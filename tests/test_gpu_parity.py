@@ -173,7 +173,7 @@ def _mixed_plan(n, fs_in, N, rng):
 
 
 @pytest.mark.parametrize("P,olen", [(300, 240), (600, 480), (200, 160), (400, 320), (1200, 960),
-                                    (150, 120), (160, 128), (320, 256), (480, 384), (800, 640), (960, 768)])
+                                    (150, 120), (160, 128), (320, 256), (480, 384), (800, 640), (960, 768), (1920, 1536)])
 def test_channel_sizes_random_spectrum(pkg, P, olen):
     # every compiled backward-transform size, random responses, edge + random shifts, both signs
     L, M = 25920, 6481

@@ -252,3 +252,44 @@ def test_comm_rendezvous_file_single_rank(pkg, tmp_path):
     assert os.path.getsize(tmp_path / "chz_id") == 128
     comm.barrier()
     comm.close()
+
+
+@pytest.mark.parametrize("L,M", [(240, 273), (480, 545), (960, 1089), (1920, 2177), (300, 101)])
+def test_mini_master_pool_matches_oracle(pkg, L, M):
+    # radiod's filter2 = 1 / 4 geometries (src/radio.c:1572-1594; share/presets.conf:204,223,297): 300 independent inline
+    # masters of one pool served by ONE launch per block; per instance the overlap-save answer of the oracle
+    N = L + M - 1
+    rng = np.random.default_rng(N + 1)
+    ninst = 300
+    pool = pkg.engine.MiniPool(L, M, ninst)
+    insts = [pool.add() for _ in range(ninst)]
+    assert sorted(insts) == list(range(ninst))
+    with pytest.raises(pkg.engine.ChzError):
+        pool.add()                                        # full: loud, not silent
+    kinds = [(-0.2, 0.2), (0.01, 0.3), (-0.4, 0.1), (-0.45, 0.45), (-0.3, -0.05)]
+    resp = [ol.set_filter(N, L, N, False, lo, hi, 9.0) for lo, hi in kinds]
+    for i in insts:
+        pool.set_response(i, resp[i % 5])
+    isb = np.array([(i % 7) == 3 for i in range(ninst)], np.uint8)
+    check = [0, 3, 10, 11, 150, 299]
+    streams = {i: ol.Stream(L, M, ol.COMPLEX) for i in check}
+    hist = np.zeros((ninst, M - 1), np.complex64)
+    try:
+        for blk in range(3):
+            x = (rng.standard_normal((ninst, L)) + 1j * rng.standard_normal((ninst, L))).astype(np.complex64)
+            win = np.concatenate([hist, x], axis=1)
+            out = pool.execute(insts, win, isb=isb)
+            for i in check:
+                spec = streams[i].push(x[i], f64=True)
+                want = ol.channel(spec, ol.COMPLEX, N, L, 0, resp[i % 5], isb=bool(isb[i]))
+                check_channel(out[i], want)
+            hist = win[:, L:]
+        pool.release(insts[5]); assert pool.add() == insts[5]
+    finally:
+        pool.close()
+
+
+def test_mini_master_rejects_what_it_cannot_do(pkg):
+    for L, M in ((240, 272), (5000, 5001)):               # N = 511 (prime factor 7 x 73), N = 10000 > 8192
+        with pytest.raises(pkg.engine.ChzError):
+            pkg.engine.MiniPool(L, M, 4)

@@ -43,6 +43,7 @@ def emu(oracle_built):
     lib.emu_fine_retune.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
     lib.emu_channels_tuned.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_uint, C.c_void_p]
+    lib.emu_mini.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
 
@@ -73,7 +74,7 @@ def test_forward_kernels(emu, N, in_type, spec, start):
 
 @pytest.mark.parametrize("stage", [0, 1])
 @pytest.mark.parametrize("in_type,B", [(ol.REAL, 16201), (ol.COMPLEX, 6000), (ol.COMPLEX, 6001)])
-@pytest.mark.parametrize("P,olen", [(300, 240), (600, 480), (200, 160), (400, 320), (1200, 960), (150, 120),
+@pytest.mark.parametrize("P,olen", [(300, 240), (600, 480), (200, 160), (400, 320), (1200, 960), (1920, 1536), (150, 120),
                                     (20, 16), (30, 24), (160, 128), (320, 256), (480, 384), (800, 640), (960, 768)])
 def test_channel_kernel(emu, in_type, B, P, olen, stage, monkeypatch):
     monkeypatch.setenv("CHZ_CHAN_STAGE", str(stage))     # output rows straight from the lanes / staged through LDS
@@ -290,3 +291,28 @@ def test_beam_mode_in_channel_kernel(emu, B, P, olen):
             assert not out[i].any()
         else:
             assert rel(out[i], want) < 1e-6, (s, i)
+
+
+@pytest.mark.parametrize("L,M", [(240, 273), (480, 545), (960, 1089), (240, 61), (300, 101), (1920, 2177)])
+def test_mini_master_kernel(emu, L, M):
+    """radiod's filter2 geometry (src/radio.c:1572-1594: N = round2(2*blocksize), M = N-L+1) and two non-power-of-two
+    ones: window -> forward transform -> gather x response (+ISB) -> backward transform, one workgroup per instance,
+    against the oracle's overlap-save master + same-size slave; a non-zero shift and ISB ride along."""
+    N = L + M - 1
+    rng = np.random.default_rng(N)
+    nreq = 5
+    shifts = np.array([0, 0, 7, -(N // 3), 0], np.int32)
+    isb = np.array([0, 1, 0, 0, 1], np.uint8)
+    resp = np.stack([ol.set_filter(N, L, N, False, lo, hi, 9.0) for lo, hi in ((-0.2, 0.2), (0.01, 0.3), (-0.4, 0.1), (-0.45, 0.45), (-0.3, -0.05))])
+    streams = [ol.Stream(L, M, ol.COMPLEX) for _ in range(nreq)]
+    hist = np.zeros((nreq, M - 1), np.complex64)
+    for blk in range(3):
+        x = (rng.standard_normal((nreq, L)) + 1j * rng.standard_normal((nreq, L))).astype(np.complex64)
+        win = np.ascontiguousarray(np.concatenate([hist, x], axis=1))
+        out = np.zeros((nreq, L), np.complex64)
+        assert emu.emu_mini(win.ctypes.data, nreq, N, L, np.ascontiguousarray(resp).ctypes.data, shifts.ctypes.data, isb.ctypes.data, out.ctypes.data) == 0
+        for i in range(nreq):
+            spec = streams[i].push(x[i], f64=True)
+            want = ol.channel(spec, ol.COMPLEX, N, L, int(shifts[i]), resp[i], isb=bool(isb[i]))
+            assert rel(out[i], want) < 3e-6, (blk, i)
+        hist = win[:, L:]
