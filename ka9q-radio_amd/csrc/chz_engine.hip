@@ -158,7 +158,7 @@ struct chz_engine {
   float2* spec[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};
   bool spec_owned[CHZ_ND] = {false, false, false, false};
   float2 *tw_sub_a = nullptr, *tw_sub_b = nullptr, *tw_sub_c = nullptr;
-  float2 *tw1_tile = nullptr, *tw1_col = nullptr, *tw2_tile = nullptr, *tw2_col = nullptr;
+  float2 *tw1_tile = nullptr, *tw1_col = nullptr, *tw2_tile = nullptr, *tw2_col = nullptr, *tw2_full = nullptr;
   // spur notches: device tables + the event chain that orders the recurrence across lanes
   int n_notch = 0;
   int *notch_addr = nullptr, *notch_next = nullptr, *notch_head = nullptr;
@@ -277,7 +277,7 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   if ((r = upload(&e->tw_sub_a, e->plan.tw_sub_a)) || (r = upload(&e->tw_sub_b, e->plan.tw_sub_b)) ||
       (r = upload(&e->tw_sub_c, e->plan.tw_sub_c)) || (r = upload(&e->tw1_tile, e->plan.tw1_tile)) ||
       (r = upload(&e->tw1_col, e->plan.tw1_col)) || (r = upload(&e->tw2_tile, e->plan.tw2_tile)) ||
-      (r = upload(&e->tw2_col, e->plan.tw2_col)))
+      (r = upload(&e->tw2_col, e->plan.tw2_col)) || (r = upload(&e->tw2_full, e->plan.tw2_full)))
     return r;
   HIPOK(hipDeviceSynchronize());       // null-stream memsets vs the engine's non-blocking streams
   guard.e = nullptr;
@@ -317,7 +317,7 @@ void chz_engine_destroy(chz_engine* e) {
   hipFree(e->ring); hipFree(e->ring16); hipFree(e->energy_part); hipFree(e->clip_part);
   for (int i = 0; i < CHZ_ND; i++) if (e->spec_owned[i]) hipFree(e->spec[i]);
   hipFree(e->tw_sub_a); hipFree(e->tw_sub_b); hipFree(e->tw_sub_c);
-  hipFree(e->tw1_tile); hipFree(e->tw1_col); hipFree(e->tw2_tile); hipFree(e->tw2_col);
+  hipFree(e->tw1_tile); hipFree(e->tw1_col); hipFree(e->tw2_tile); hipFree(e->tw2_col); hipFree(e->tw2_full);
   free_notches(e);
   if (e->notch_err) (void)hipHostFree(e->notch_err);
   if (e->upload) hipStreamDestroy(e->upload);
@@ -559,6 +559,7 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* tu
     ColsParams b{};
     b.in = lbuf; b.in_len = 0; b.in_start = 0; b.out = lbuf; b.rows = p.Ra; b.inner = p.Nc; b.T = p.T2;
     b.padk = p.padk2; b.tw_sub = e->tw_sub_b; b.tw_tile = e->tw2_tile; b.tw_col = e->tw2_col;
+    if (!getenv("CHZ_NO_TWFULL")) b.tw_full = e->tw2_full;
     mark(in, st, 1, true);
     if (launch_cols(p.rb, p.grid2, p.block2, p.lds2, st, b, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis b");
     mark(in, st, 1, false);

@@ -79,9 +79,12 @@ __device__ __forceinline__ void store_wt(__amdgpu_buffer_rsrc_t d, int elem, flo
   __builtin_amdgcn_raw_buffer_store_b128(chz_u4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, d, elem * 16, 0, 16);
 }
 #define CHZ_STORE(desc, base, elem, value) store_wt(desc, (int)(elem), (value))
+// predicated store without a branch: a raw buffer access past num_records is dropped by the hardware
+#define CHZ_STORE_IF(desc, base, elem, value, cond) store_wt(desc, (cond) ? (int)(elem) : 0x10000000, (value))
 #else
 #define CHZ_OUT_DESC(name, base) const int name = 0; (void)name
 #define CHZ_STORE(desc, base, elem, value) ((base)[(elem)] = (value))
+#define CHZ_STORE_IF(desc, base, elem, value, cond) do { if (cond) (base)[(elem)] = (value); } while (0)
 #endif
 
 // ------------------------------------------------------------------------------
@@ -124,6 +127,8 @@ struct ColsParams {
   const float2* tw_sub;   // [R2][R1]      W_NP^(j*k1)
   const float2* tw_tile;  // [inner/T][NP] W_(NP*inner)^(k * c0)
   const float2* tw_col;   // [NP][T]       W_(NP*inner)^(k * t)
+  const float2* tw_full;  // [NP][inner] W_(NP*inner)^(k * col), or nullptr: one load and no product per output (axis b: the table
+                          // is Nb*Nc entries and L2-resident; axis a of a complex master would need N entries and keeps the two factors)
 };
 
 // Spectrum storage: bin k = ka + Na*x lives at  spec[x*pitch + off + ka].  pitch = Na, off = 0 is
@@ -348,13 +353,19 @@ __global__ void fwd_cols(ColsParams p) {
   const int k1o = tid / T, to = tid - k1o * T;
   const bool act2 = tid < R1 * T;
   float2 wt[R2], wc[R2];
+  const bool full = p.tw_full != nullptr;                 // uniform
   if (act2) {
-    static_for<R2>([&](auto k2) {
-      constexpr int K2 = decltype(k2)::value;
-      const int k = k1o + R1 * K2;
-      wt[K2] = twt[ct * NP + k];
-      wc[K2] = twc[k * T + to];
-    });
+    if (full) {
+      const float2* __restrict__ twf = p.tw_full + c0 + to;
+      static_for<R2>([&](auto k2) { constexpr int K2 = decltype(k2)::value; wt[K2] = twf[(k1o + R1 * K2) * p.inner]; });
+    } else {
+      static_for<R2>([&](auto k2) {
+        constexpr int K2 = decltype(k2)::value;
+        const int k = k1o + R1 * K2;
+        wt[K2] = twt[ct * NP + k];
+        wc[K2] = twc[k * T + to];
+      });
+    }
   }
   const int gstep = R2 * T + p.padk;             // LDS distance between butterfly groups
   if (tid < R2 * T) {
@@ -403,7 +414,7 @@ __global__ void fwd_cols(ColsParams p) {
     const int ostep = R1 * p.inner;
     static_for<R2>([&](auto k2) {
       constexpr int K2 = decltype(k2)::value;
-      CHZ_STORE(odesc, gout, o0 + K2 * ostep, cmul(u[K2], cmul(wt[K2], wc[K2])));
+      CHZ_STORE(odesc, gout, o0 + K2 * ostep, cmul(u[K2], full ? wt[K2] : cmul(wt[K2], wc[K2])));
     });
   }
 }
@@ -516,10 +527,15 @@ __global__ void fwd_rows(RowsParams p) {
       const int m0 = (xrows - 1 - x0) * p.lay.pitch + p.lay.off + (p.Na - ka);
       float2* __restrict__ sp = p.spec;
       CHZ_OUT_DESC(sdesc, sp);
+      // one store per output, no branches: bins up to N/2 go out as they are, the rest conjugated to bin N-k; the
+      // self-conjugate rows (ka = 0, Na/2) have no mirror image to write
       static_for<R2>([&](auto k2) {
         constexpr int K2 = decltype(k2)::value;
-        if (!p.mirror || kk0 + K2 * kks <= half) CHZ_STORE(sdesc, sp, d0 + K2 * ds, u[K2]);
-        else if (!selfconj) CHZ_STORE(sdesc, sp, m0 - K2 * ds, cconj(u[K2]));      // bin N-k
+        const bool direct = !p.mirror || kk0 + K2 * kks <= half;
+        const int at = direct ? d0 + K2 * ds : m0 - K2 * ds;
+        float2 x = u[K2];
+        if (!direct) x.y = -x.y;
+        CHZ_STORE_IF(sdesc, sp, at, x, direct || !selfconj);
       });
     }
   }

@@ -91,7 +91,7 @@ struct FwdPlan {
   long spec_elems = 0;                              // float2 elements of one spectrum slot
   int grid1 = 0, block1 = 0, grid2 = 0, block2 = 0, grid3 = 0, block3 = 0;
   size_t lds1 = 0, lds2 = 0, lds3 = 0;
-  std::vector<f2> tw_sub_a, tw_sub_b, tw_sub_c, tw1_tile, tw1_col, tw2_tile, tw2_col;
+  std::vector<f2> tw_sub_a, tw_sub_b, tw_sub_c, tw1_tile, tw1_col, tw2_tile, tw2_col, tw2_full;
   std::string desc;
 };
 
@@ -166,6 +166,9 @@ inline bool finish_fwd_plan(FwdPlan& p, int T1_over, int T2_over, int Ta_over) {
     p.tw2_col.resize((size_t)p.Nb * p.T2);
     for (int k = 0; k < p.Nb; k++)
       for (int t = 0; t < p.T2; t++) p.tw2_col[(size_t)k * p.T2 + t] = root_of_unity((long long)k * t, D, -1);
+    p.tw2_full.resize((size_t)p.Nb * p.Nc);                 // W_D^(k*col): tile and column factor in one, rounded once
+    for (int k = 0; k < p.Nb; k++)
+      for (int c = 0; c < p.Nc; c++) p.tw2_full[(size_t)k * p.Nc + c] = root_of_unity((long long)k * c, D, -1);
     p.tw_sub_b = make_tw_sub(p.rb.r1, p.rb.r2, -1);
   }
   // ---- last axis

@@ -72,6 +72,7 @@ static int emu_forward_impl(const float* ring, const short* ring16, float scale1
     b.in = buf.data(); b.in_len = 0; b.in_start = 0; b.out = buf.data();
     b.rows = p.Ra; b.inner = p.Nc; b.T = p.T2; b.padk = p.padk2;
     b.tw_sub = F2(p.tw_sub_b); b.tw_tile = F2(p.tw2_tile); b.tw_col = F2(p.tw2_col);
+    if (!getenv("EMU_NO_TWFULL")) b.tw_full = F2(p.tw2_full);
     if (launch_cols(p.rb, p.grid2, p.block2, p.lds2, nullptr, b)) return -3;
   }
   RowsParams c{};
