@@ -241,7 +241,16 @@ __global__ void fwd_first_real(FirstRealParams p) {
     long f64 = start2 + (long)j * inner2 + c0 + t;
     if (f64 >= ring2_len) f64 -= ring2_len;
     const int first = (int)f64, len = (int)ring2_len, qstep = R2 * (int)inner2;   // 32-bit from here on
-    if (p.ring16 == nullptr) {
+    // only the windows that straddle the end of the ring need the wrap test (uniform per workgroup)
+    const bool nowrap = start2 + c0 + T - 1 + (long)(NA - 1) * inner2 < ring2_len;
+    if (p.ring16 == nullptr && nowrap) {
+      const float2* __restrict__ g0 = ring2 + first;
+      static_for<R1>([&](auto q) {
+        constexpr int Q = decltype(q)::value;
+        v[Q] = g0[Q * qstep];
+        if constexpr (Q > 0) w1[Q] = tws[j * R1 + Q];
+      });
+    } else if (p.ring16 == nullptr) {
       static_for<R1>([&](auto q) {
         constexpr int Q = decltype(q)::value;
         int idx = first + Q * qstep;                 // < 2*len: the window is shorter than the ring
