@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <complex.h>
 #include <stdint.h>
 #include <pthread.h>
 #include "chz_oracle.h"
@@ -686,6 +687,189 @@ double chzo_downconv_block(chzo_downconv *d, int shift, double remainder, double
   }
   return olen ? energy / olen : 0.0;
 }
+
+/* ------------------------------------------------------------------ */
+/* the linear demodulator's per-block work            */
+/* (src/linear.c:56-375 without the PLL branch) and PCM packing         */
+/* (src/import.h:88-118, called from send_output, src/audio.c:117-133)  */
+/* ------------------------------------------------------------------ */
+
+struct chzo_lindemod {
+  chzo_lindemod_params p;
+  /* demod_linear's locals and the chan_t fields it updates */
+  double gain;             /* chan->output.gain */
+  int hangcount;           /* chan->linear.hangcount */
+  double am_dc;            /* carrier removal filter state (src/linear.c:42) */
+  double n0;               /* chan->sig.n0, NaN until the first estimate (src/radio.c:1467-1473) */
+  int squelch_state;       /* src/linear.c:46 */
+  int squelch_open;        /* src/linear.c:47 */
+  chzo_downconv shift;     /* only the oscillator part is used: chan->shift (src/linear.c:168-172) */
+};
+
+chzo_lindemod *chzo_lindemod_create(const chzo_lindemod_params *p) {
+  chzo_lindemod *d = (chzo_lindemod *)calloc(1, sizeof *d);
+  if (!d) return NULL;
+  d->p = *p;
+  d->gain = p->gain;
+  d->n0 = NAN;
+  d->squelch_state = (!p->snr_squelch) ? p->squelch_tail + 4 : 0;          /* src/linear.c:46 (no PLL here) */
+  d->squelch_open = 1;                                                      /* :47 */
+  return d;
+}
+void chzo_lindemod_delete(chzo_lindemod *d) { free(d); }
+void chzo_lindemod_set_params(chzo_lindemod *d, const chzo_lindemod_params *p) { double g = d->gain; d->p = *p; d->p.gain = g; }
+
+static int pcm_bytes_per_sample(int enc) { return (enc == CHZO_PCM_S16BE || enc == CHZO_PCM_S16LE) ? 2 : 4; }
+
+/* export_s16_swap / _noswap and export_f32_* (src/import.h:88-118,176-183) on a little-endian host */
+static void pcm_pack(int enc, const float *in, int count, unsigned char *out) {
+  for (int i = 0; i < count; i++) {
+    if (enc == CHZO_PCM_S16BE || enc == CHZO_PCM_S16LE) {
+      float t = ldexpf(in[i], 15);
+      t = t > 32767.0f ? 32767.0f : t < -32767.0f ? -32767.0f : t;
+      int16_t v = (int16_t)lrintf(t);
+      uint16_t u = (uint16_t)v;
+      if (enc == CHZO_PCM_S16BE) u = (uint16_t)((u >> 8) | (u << 8));
+      memcpy(out + 2 * i, &u, 2);
+    } else {
+      uint32_t u; memcpy(&u, &in[i], 4);
+      if (enc == CHZO_PCM_F32BE) u = __builtin_bswap32(u);
+      memcpy(out + 4 * i, &u, 4);
+    }
+  }
+}
+
+/* One block: buf = N complex samples as downconvert() leaves them (rotated in place by the shift oscillator),
+   bb_power = chan->sig.bb_power, n0_est = this block's estimate_noise().  pcm receives N*channels samples in the
+   channel's encoding when st->frame == CHZO_FRAME_DATA.  Returns 0. */
+int chzo_lindemod_block(chzo_lindemod *d, float *buf, int N, double bb_power, double n0_est, double blocktime,
+                        unsigned char *pcm, chzo_lindemod_status *st) {
+  const chzo_lindemod_params *c = &d->p;
+  const double samprate = c->samprate;
+  /* src/radio.c:1466-1473 (Power_alpha = 0.10, :72) */
+  if (isnan(d->n0)) d->n0 = n0_est;
+  else { double diff = n0_est - d->n0; d->n0 += 0.10 * diff; }
+  /* src/linear.c:168-172: post-downconversion shift */
+  dc_set_osc(&d->shift, c->shift / samprate, 0);
+  if (d->shift.freq != 0) {
+    for (int n = 0; n < N; n++) {
+      double wr, wi; dc_step_osc(&d->shift, &wr, &wi);
+      const double xr = buf[2 * n], xi = buf[2 * n + 1];
+      buf[2 * n] = (float)(xr * wr - xi * wi); buf[2 * n + 1] = (float)(xr * wi + xi * wr);
+    }
+  }
+  /* src/linear.c:177-234: AGC */
+  double gain_change = 1;
+  if (c->agc) {
+    const double bw = c->bandwidth;
+    const double bn = sqrt(bw * d->n0);
+    const double ampl = sqrt(bb_power);
+    double peak_level = 0;
+    {
+      int sps = (int)lrint(N * .002 / blocktime);
+      sps = sps < 1 ? 1 : sps;
+      int n = 0;
+      while (n + sps < N) {
+        double energy = 0;
+        for (int i = 0; i < sps; i++) { const float re = buf[2 * n], im = buf[2 * n + 1]; n++; energy += (double)(re * re + im * im); }
+        if (energy > peak_level) peak_level = energy;
+      }
+      peak_level = sqrt(peak_level / sps);
+    }
+    if (peak_level * d->gain > M_SQRT2 * c->headroom) {
+      d->gain = M_SQRT2 * c->headroom / peak_level;
+      gain_change = 1;
+      d->hangcount = (int)lrint(0.08 * samprate);
+    } else if (ampl * d->gain > c->headroom) {
+      const double newgain = c->headroom / ampl;
+      if (newgain > 0) gain_change = pow(newgain / d->gain, 1.0 / N);
+      d->hangcount = (int)lrint(c->hangtime * samprate);
+    } else if (bn * d->gain > c->threshold * c->headroom) {
+      const double newgain = c->threshold * c->headroom / bn;
+      if (newgain > 0) gain_change = pow(newgain / d->gain, 1.0 / N);
+    } else if (d->hangcount > 0) {
+      d->hangcount -= N;
+    } else {
+      gain_change = pow(c->recovery_rate, 1.0 / samprate);
+    }
+  }
+  /* src/linear.c:236-311: final pass */
+  double output_power = 0;
+  float *samples = buf;                    /* real output overlays the complex input, index low to high */
+  if (c->channels == 1) {
+    if (c->env) {
+      double gain = d->gain;
+      for (int n = 0; n < N; n++) {
+        double s = gain * M_SQRT1_2 * (double)cabsf(buf[2 * n] + I * buf[2 * n + 1]);
+        gain *= gain_change;
+        output_power += s * s;
+        if (c->dc_alpha != 0) { d->am_dc += c->dc_alpha * (s - d->am_dc); s -= d->am_dc; }
+        samples[n] = (float)s;
+      }
+      d->gain = gain;
+    } else {
+      double gain = d->gain;
+      for (int n = 0; n < N; n++) {
+        const double s = gain * buf[2 * n];
+        gain *= gain_change;
+        output_power += s * s;
+        samples[n] = (float)s;
+      }
+      d->gain = gain;
+    }
+  } else {
+    if (c->env) {
+      double gain = d->gain;
+      for (int n = 0; n < N; n++) {
+        double sr = gain * M_SQRT1_2 * (double)buf[2 * n];
+        double si = gain * M_SQRT1_2 * (double)cabsf(buf[2 * n] + I * buf[2 * n + 1]);
+        gain *= gain_change;
+        output_power += sr * sr + si * si;
+        if (c->dc_alpha != 0) { d->am_dc += c->dc_alpha * (si - d->am_dc); si -= d->am_dc; }
+        buf[2 * n] = (float)sr; buf[2 * n + 1] = (float)si;
+      }
+      d->gain = gain;
+    } else {
+      double gain = d->gain;
+      for (int n = 0; n < N; n++) {
+        const double sr = gain * buf[2 * n], si = gain * buf[2 * n + 1];
+        gain *= gain_change;
+        output_power += sr * sr + si * si;
+        buf[2 * n] = (float)sr; buf[2 * n + 1] = (float)si;
+      }
+      d->gain = gain;
+    }
+  }
+  output_power /= N;
+  if (c->channels == 1) output_power *= 2;
+  st->output_power = output_power;
+  /* src/linear.c:313-352: squelch */
+  double snr = INFINITY;
+  if (c->snr_squelch) snr = (bb_power / (d->n0 * c->bandwidth)) - 1.0;
+  const int squelch_state_max = c->squelch_tail + 4;
+  if (!c->snr_squelch || snr >= c->squelch_open) d->squelch_state = squelch_state_max;
+  else if (d->squelch_state > 0 && snr < c->squelch_close) d->squelch_state--;
+  st->gain = d->gain; st->n0 = d->n0; st->snr = snr; st->squelch_state = d->squelch_state;
+  switch (d->squelch_state) {
+  case 3: st->output_power = 0; /* fallthrough */
+  case 2: case 1:
+    st->frame = CHZO_FRAME_SILENCE; st->mute = 0;           /* send_output(chan, NULL, N, false) */
+    return 0;
+  case 0:
+    st->output_power = 0; st->frame = CHZO_FRAME_SILENCE; st->mute = 1;   /* send_output(chan, NULL, N, true) */
+    return 0;
+  default: break;
+  }
+  if (c->snr_squelch) {
+    if (snr < c->squelch_close) d->squelch_open = 0;
+    else if (!d->squelch_open && snr > c->squelch_open) { d->squelch_open = 1; d->am_dc = 0; }
+  } else d->squelch_open = 1;
+  st->mute = (output_power == 0 || !d->squelch_open || !c->tuned);     /* src/linear.c:366 */
+  st->frame = CHZO_FRAME_DATA;
+  pcm_pack(c->encoding, samples, N * c->channels, pcm);                  /* send_output -> export_* (src/audio.c:117-133) */
+  return 0;
+}
+int chzo_pcm_bytes(int encoding, int nsamples) { return pcm_bytes_per_sample(encoding) * nsamples; }
 
 /* ------------------------------------------------------------------ */
 /* overlap-save stream                                                 */

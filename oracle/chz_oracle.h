@@ -102,6 +102,26 @@ int chzo_stream_points(const chzo_stream *s);
 int chzo_stream_push(chzo_stream *s, const float *samples, float *spectrum);
 int chzo_stream_push_f64(chzo_stream *s, const float *samples, double *spectrum);
 
+/* ---- the linear demodulator's per-block work (src/linear.c:56-375 without the PLL) and PCM
+   packing (src/import.h:88-118).  Field names follow the chan_t members linear.c reads. */
+enum { CHZO_PCM_S16BE = 0, CHZO_PCM_S16LE = 1, CHZO_PCM_F32LE = 2, CHZO_PCM_F32BE = 3 };
+enum { CHZO_FRAME_DATA = 0, CHZO_FRAME_SILENCE = 1 };
+typedef struct chzo_lindemod_params {
+  int channels, env, agc, encoding, snr_squelch, squelch_tail, tuned, pad;
+  double samprate, headroom, threshold, recovery_rate, hangtime, dc_alpha, bandwidth, shift, squelch_open, squelch_close, gain;
+} chzo_lindemod_params;
+typedef struct chzo_lindemod_status {
+  int frame, mute, squelch_state, pad;
+  double output_power, gain, n0, snr;
+} chzo_lindemod_status;
+typedef struct chzo_lindemod chzo_lindemod;
+chzo_lindemod *chzo_lindemod_create(const chzo_lindemod_params *p);
+void chzo_lindemod_delete(chzo_lindemod *d);
+void chzo_lindemod_set_params(chzo_lindemod *d, const chzo_lindemod_params *p);      /* everything but the running gain */
+int chzo_lindemod_block(chzo_lindemod *d, float *buf, int N, double bb_power, double n0_est, double blocktime,
+                        unsigned char *pcm, chzo_lindemod_status *st);
+int chzo_pcm_bytes(int encoding, int nsamples);
+
 #ifdef __cplusplus
 }
 #endif

@@ -445,6 +445,97 @@ def ref_convert_i16(samples, scale, randomize=False, avx2=False):
     return out.copy(), en.value, clips
 
 
+# ---- linear demodulator + PCM packing -------------------------------------------------------------
+PCM_S16BE, PCM_S16LE, PCM_F32LE, PCM_F32BE = 0, 1, 2, 3
+FRAME_DATA, FRAME_SILENCE = 0, 1
+
+
+class LinParams(C.Structure):
+    """chzo_lindemod_params (oracle/chz_oracle.h); the names are the chan_t members src/linear.c reads."""
+    _fields_ = [("channels", _i), ("env", _i), ("agc", _i), ("encoding", _i), ("snr_squelch", _i), ("squelch_tail", _i),
+                ("tuned", _i), ("pad", _i),
+                ("samprate", _d), ("headroom", _d), ("threshold", _d), ("recovery_rate", _d), ("hangtime", _d), ("dc_alpha", _d),
+                ("bandwidth", _d), ("shift", _d), ("squelch_open", _d), ("squelch_close", _d), ("gain", _d)]
+
+
+class LinStatus(C.Structure):
+    _fields_ = [("frame", _i), ("mute", _i), ("squelch_state", _i), ("pad", _i),
+                ("output_power", _d), ("gain", _d), ("n0", _d), ("snr", _d)]
+
+
+def lin_params(channels=1, env=False, agc=True, encoding=PCM_S16BE, snr_squelch=False, squelch_tail=1, tuned=True, samprate=12000.0,
+               headroom_db=-15.0, threshold_db=-15.0, recovery_db_per_s=20.0, hangtime=1.1, dc_alpha=0.0, bandwidth=2950.0, shift=0.0,
+               squelch_open_db=8.0, squelch_close_db=7.0, gain_db=50.0):
+    """Defaults follow src/modes.c:40-60,224-246 (dB2voltage / dB2power as there)."""
+    v = lambda db: 10 ** (db / 20.0)
+    return LinParams(channels, int(env), int(agc), encoding, int(snr_squelch), squelch_tail, int(tuned), 0, float(samprate), v(headroom_db),
+                     v(threshold_db), v(recovery_db_per_s), float(hangtime), float(dc_alpha), float(bandwidth), float(shift),
+                     10 ** (squelch_open_db / 10.0), 10 ** (squelch_close_db / 10.0), v(gain_db))
+
+
+def pcm_bytes(encoding, nsamples):
+    return (2 if encoding in (PCM_S16BE, PCM_S16LE) else 4) * nsamples
+
+
+class LinDemod:
+    """Restated per-block work of demod_linear() (oracle/chz_oracle.c:chzo_lindemod_block)."""
+
+    def __init__(self, params):
+        L = oracle()
+        L.chzo_lindemod_create.restype = _vp; L.chzo_lindemod_create.argtypes = [C.POINTER(LinParams)]
+        L.chzo_lindemod_delete.argtypes = [_vp]
+        L.chzo_lindemod_set_params.argtypes = [_vp, C.POINTER(LinParams)]
+        L.chzo_lindemod_block.argtypes = [_vp, _vp, _i, _d, _d, _d, _vp, C.POINTER(LinStatus)]
+        self.p = params
+        self._h = L.chzo_lindemod_create(C.byref(params))
+
+    def set_params(self, params):
+        self.p = params
+        oracle().chzo_lindemod_set_params(self._h, C.byref(params))
+
+    def block(self, samples, bb_power, n0_est, blocktime=0.02):
+        """samples: complex64[N] from downconvert(); returns (pcm bytes or None, LinStatus)."""
+        buf = np.ascontiguousarray(samples, np.complex64).copy()
+        n = buf.shape[0]
+        pcm = np.zeros(pcm_bytes(self.p.encoding, n * self.p.channels), np.uint8)
+        st = LinStatus()
+        oracle().chzo_lindemod_block(self._h, _fptr(buf), n, float(bb_power), float(n0_est), float(blocktime), _fptr(pcm), C.byref(st))
+        return (pcm if st.frame == FRAME_DATA else None), st
+
+    def __del__(self):
+        try:
+            oracle().chzo_lindemod_delete(self._h)
+        except Exception:
+            pass
+
+
+def have_ref_linear():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libka9q_ref_linear.so"))
+
+
+_ref_linear = None
+
+
+def ref_linear_run(params, baseband, bb_power, n0_smoothed, blocktime=0.02):
+    """The reference's OWN demod_linear() (oracle/ref_linear_wrap.c) over nblocks blocks of baseband[nblocks][N];
+    n0_smoothed = chan->sig.n0 as downconvert() leaves it.  Returns (pcm[nblocks][bytes], frame, mute, out_power, gain)."""
+    global _ref_linear
+    if _ref_linear is None:
+        _ref_linear = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libka9q_ref_linear.so"))
+        _ref_linear.reflin_run.argtypes = [C.POINTER(LinParams), _d, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]
+    bb = np.ascontiguousarray(baseband, np.complex64)
+    nb, n = bb.shape
+    stride = pcm_bytes(params.encoding, n * params.channels)
+    pcm = np.zeros((nb, stride), np.uint8)
+    frame = np.zeros(nb, np.int32); mute = np.zeros(nb, np.int32)
+    power = np.zeros(nb); gain = np.zeros(nb)
+    bp = np.ascontiguousarray(bb_power, np.float64); n0 = np.ascontiguousarray(n0_smoothed, np.float64)
+    r = _ref_linear.reflin_run(C.byref(params), float(blocktime), nb, n, _fptr(bb), _fptr(bp), _fptr(n0), _fptr(pcm), stride,
+                               _fptr(frame), _fptr(mute), _fptr(power), _fptr(gain))
+    assert r == 0
+    return pcm, frame, mute, power, gain
+
+
 class Downconv:
     """Per-channel tail of downconvert() (src/radio.c:1476-1520).  which = "oracle" (restatement) or
     "ref" (the reference's own osc.c / cispi with the glue statements restated in ref_driver.c)."""

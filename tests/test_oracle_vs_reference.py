@@ -339,3 +339,69 @@ def test_convert_matches_reference_rx888_c(oracle_built, randomize):
         # comment and the AVX2 routine describe (if bit 0 is set, flip bits 1..15): the two reference routines disagree
         # with each other here, and the restatement (and the kernel) follow the AVX2 one
         assert av is None or not np.array_equal(port[0], av[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# the linear demodulator.  The reference's OWN demod_linear() (src/linear.c, included unmodified by
+# oracle/ref_linear_wrap.c, oscillator = its osc.c, PCM packed by its import.h) is run block after block on seeded
+# baseband; the restatement must reproduce its frames.
+# ------------------------------------------------------------------------------------------------
+def _demod_case(r, nblk, N, bursts=True):
+    """baseband with level changes that drive every AGC branch: quiet noise, a strong carrier fading in, a loud burst"""
+    t = np.arange(nblk * N)
+    x = (r.standard_normal(nblk * N) + 1j * r.standard_normal(nblk * N)) * 1e-4
+    x += 0.02 * np.exp(2j * np.pi * 0.031 * t) * np.clip((t - 3 * N) / (2.0 * N), 0, 1)          # carrier fades in over blocks 3..5
+    if bursts:
+        x[9 * N + 50:9 * N + 120] += 0.9 * np.exp(2j * np.pi * 0.11 * t[9 * N + 50:9 * N + 120])  # loud 6 ms burst: peak-level branch
+        x[14 * N:] *= 0.01                                                                        # signal drops: hang, then recovery
+    bb = x.astype(np.complex64).reshape(nblk, N)
+    power = np.array([np.mean(np.abs(b.astype(np.complex128)) ** 2) for b in bb])
+    return bb, power
+
+
+@pytest.mark.skipif(not ol.have_ref_linear(), reason="oracle/_ref/libka9q_ref_linear.so not built (needs /root/reference)")
+@pytest.mark.parametrize("kw", [
+    dict(),                                                          # usb-like: mono, AGC, S16BE
+    dict(channels=2, encoding=ol.PCM_F32LE),                         # iq: stereo float
+    dict(env=True, dc_alpha=0.002, encoding=ol.PCM_S16LE),           # am: envelope + carrier removal
+    dict(channels=2, env=True, dc_alpha=0.01, encoding=ol.PCM_F32BE),
+    dict(agc=False, gain_db=30.0, shift=500.0),                      # cw: fixed gain, post-detection shift oscillator
+    dict(snr_squelch=True, squelch_tail=2, bandwidth=2950.0),        # SNR squelch closing and re-opening
+    dict(tuned=False),
+])
+def test_linear_demodulator_matches_reference_linear_c(oracle_built, kw):
+    r = np.random.default_rng(len(kw) * 7 + 3)
+    nblk, N, bt = 40, 240, 0.02
+    bb, power = _demod_case(r, nblk, N)
+    n0_est = 1e-8 * (1 + 0.3 * r.standard_normal(nblk)) / 2950.0 * 2950.0 / 12000.0
+    if kw.get("snr_squelch"):
+        power = power.copy(); power[20:28] = 1e-12                   # SNR collapses for 8 blocks, then comes back
+    p = ol.lin_params(**kw)
+    n0s = np.zeros(nblk); s = np.nan
+    for b in range(nblk):                                            # src/radio.c:1466-1473, Power_alpha = 0.10
+        s = n0_est[b] if np.isnan(s) else s + 0.10 * (n0_est[b] - s)
+        n0s[b] = s
+    pcm_r, frame_r, mute_r, pow_r, gain_r = ol.ref_linear_run(p, bb, power, n0s, bt)
+    d = ol.LinDemod(p)
+    seen = set()
+    for b in range(nblk):
+        pcm, st = d.block(bb[b], power[b], n0_est[b], bt)
+        assert st.frame == frame_r[b] and st.mute == mute_r[b], (b, st.frame, frame_r[b], st.mute, mute_r[b])
+        # envelope modes go through cabsf(), which the reference's -funsafe-math-optimizations build inlines as
+        # sqrtf(re*re + im*im) (<= 1 float ulp from the library's hypotf the restatement calls); everything else is the same
+        # double arithmetic in the same order
+        tol = 2e-7 if kw.get("env") else 1e-12
+        assert st.gain == pytest.approx(gain_r[b], rel=1e-12)
+        assert st.output_power == pytest.approx(pow_r[b], rel=tol, abs=1e-300)
+        seen.add((st.frame, st.mute))
+        if st.frame == ol.FRAME_DATA:
+            if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+                a = pcm.view(">i2" if p.encoding == ol.PCM_S16BE else "<i2").astype(np.int32)
+                w = pcm_r[b].view(">i2" if p.encoding == ol.PCM_S16BE else "<i2").astype(np.int32)
+                assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.01          # the reference is built with -funsafe-math...
+            else:
+                a = pcm.view(">f4" if p.encoding == ol.PCM_F32BE else "<f4").astype(np.float64)
+                w = pcm_r[b].view(">f4" if p.encoding == ol.PCM_F32BE else "<f4").astype(np.float64)
+                assert np.abs(a - w).max() <= 2e-7 * max(np.abs(w).max(), 1e-30)
+    if kw.get("snr_squelch"):
+        assert (ol.FRAME_SILENCE, 0) in seen and (ol.FRAME_SILENCE, 1) in seen and (ol.FRAME_DATA, 0) in seen
