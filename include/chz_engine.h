@@ -53,6 +53,7 @@ typedef struct chz_timing {
   int first_n, cols_n, rows_n, notch_n, chan_n;
   double enqueue_ms;        /* host wall time spent issuing the launches (close to total_ms = host-bound) */
   double fix_ms; int fix_n; /* the spur-notch kernel (notch_fix) */
+  double demod_ms; int demod_n; /* the linear demodulator kernel */
 } chz_timing;
 
 const char *chz_last_error(void);
@@ -231,6 +232,54 @@ int chz_spectrum_exchange_rows(chz_engine *e, chz_comm *c, int slot, int root, c
  * every rank runs its own banks; timed like chz_run_blocks */
 int chz_run_blocks_sharded(chz_engine *e, chz_comm *c, int root, int mode, const int *row_lo, const int *row_hi,
                            unsigned job0, int nblocks, chz_timing *timing);
+
+/* ---- SURVEY 8(f) rank 4 -- the linear demodulator behind the fine-tuned channel outputs (demod_linear, src/linear.c:56-375,
+ * without the PLL branch): noise smoothing (src/radio.c:1466-1473), post-detection shift oscillator, block AGC, the final
+ * demodulation pass with its per-sample gain ramp, the SNR squelch sequencer, and PCM packing (src/import.h:88-118 via
+ * send_output, src/audio.c:117-133).  Runs for every channel of a COMPLEX-output bank that has tuning (chz_bank_set_tuning:
+ * bb_power) and the noise estimate (chz_bank_enable_noise) switched on, in block order on a stream of its own behind the
+ * bank's channel kernel.  What leaves the device per channel and block is packed PCM plus a status record instead of the
+ * complex baseband -- for a 12 kHz mono S16 channel 480 B instead of 1920 B.  RTP framing and the sockets stay with the host.
+ * The fields are the chan_t members src/linear.c reads (linear amplitudes / power ratios, not dB). */
+#define CHZ_PCM_S16BE 0
+#define CHZ_PCM_S16LE 1
+#define CHZ_PCM_F32LE 2
+#define CHZ_PCM_F32BE 3
+typedef struct chz_demod_params {
+  int channels;         /* chan->output.channels: 1 mono, 2 stereo; 0 switches the channel's demodulator off */
+  int env;              /* chan->linear.env: envelope (AM) detection */
+  int agc;              /* chan->linear.agc */
+  int encoding;         /* CHZ_PCM_* (chan->output.encoding) */
+  int snr_squelch;      /* chan->squelch.snr_enable */
+  int squelch_tail;     /* chan->squelch.tail */
+  int tuned;            /* chan->tune.freq != 0 */
+  int pad;
+  double samprate;      /* chan->output.samprate */
+  double headroom;      /* chan->output.headroom */
+  double threshold, recovery_rate, hangtime, dc_alpha;   /* chan->linear.* */
+  double bandwidth;     /* |chan->filter.min_IF - chan->filter.max_IF| */
+  double shift;         /* chan->tune.shift, Hz */
+  double squelch_open, squelch_close;                     /* chan->squelch.open / .close, power ratios */
+  double gain;          /* chan->output.gain when the demodulator starts (the AGC owns it afterwards) */
+} chz_demod_params;
+typedef struct chz_demod_status {
+  int frame;            /* 0: PCM present (send_output(chan, samples, N, mute)); 1: no samples (send_output(chan, NULL, N, mute)) */
+  int mute;
+  int squelch_state, pad;
+  double output_power;  /* chan->output.power */
+  double gain;          /* chan->output.gain after the block */
+  double n0;            /* chan->sig.n0 (smoothed) */
+  double snr;
+} chz_demod_status;
+/* parameters of channels [ch0, ch0+n) from block `job` on (it must not have been enqueued yet); blocktime = radiod's Blocktime.
+ * Waits for the demodulator stream only, never for the transform lanes. */
+int chz_bank_set_demod(chz_engine *e, int bank, unsigned job, int ch0, int n, const chz_demod_params *p, double blocktime);
+/* bytes one channel's PCM of one block can take (olen frames, stereo float32): the stride of chz_bank_read_pcm's buffer */
+int chz_bank_pcm_stride(chz_engine *e, int bank);
+/* PCM (pcm_stride bytes per channel, the encoding's N*channels samples first) and status of the block last demodulated
+ * on `slot`; synchronous / asynchronous on the demodulator stream (completion: chz_sync) */
+int chz_bank_read_pcm(chz_engine *e, int bank, int slot, int ch0, int n, void *pcm, chz_demod_status *status);
+int chz_bank_read_pcm_async(chz_engine *e, int bank, int slot, int ch0, int n, void *pcm, chz_demod_status *status);
 
 /* ---- small inline masters: radiod's filter2 (src/radio.c:1572-1594: a private COMPLEX master of N = round2(2*blocksize)
  * points with one same-size COMPLEX slave, run inline by the channel thread; share/presets.conf:204,223,297).  A pool holds

@@ -72,6 +72,19 @@ struct Bank {
   char* stage[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging of one refresh per slot
   hipEvent_t stage_ev[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};
   bool stage_busy[CHZ_ND] = {false, false, false, false};
+  // the linear demodulator behind the channel outputs; allocated by the first chz_bank_set_demod
+  DemodChan* dm_chan = nullptr;          // [cap]
+  DemodState* dm_state = nullptr;        // [cap]
+  DemodStatus* dm_status = nullptr;      // [ND][cap]
+  unsigned char* dm_pcm = nullptr;       // [ND][cap][pcm_stride]
+  std::vector<DemodChan> dm_chan_h;      // [cap]
+  struct OscHost { bool init = false; double freq = 0.0, phase0 = 0.0; unsigned job0 = 0; };
+  std::vector<OscHost> dm_osc;           // [cap] chan->shift with set_osc's phase continuity
+  int dm_on = 0;                         // channels with a demodulator
+  double dm_blocktime = 0.02;
+  hipEvent_t ev_bank[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // behind the slot's channel (+ noise) kernel
+  hipEvent_t ev_tail[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // behind the slot's demodulator kernel
+  bool tail_used[CHZ_ND] = {false, false, false, false};
   double* power = nullptr;      // [ND][cap] (tail of downconvert(), src/radio.c:1516-1520)
   double* n0 = nullptr;         // [ND][cap] estimate_noise() (src/radio.c:1783-1866)
   double noise_samprate = 0.0;  // front-end sample rate; 0 = off
@@ -131,6 +144,7 @@ struct Issuer {
 // the run) may be issued; see enqueue_forward().
 struct NotchTurn {
   std::atomic<int> next{0};
+  std::atomic<int> next_tail{0};   // the same hand-over for what is issued to the demodulator stream
   std::atomic<int> abort{0};
 };
 
@@ -146,6 +160,7 @@ struct chz_engine {
   // streams onto its (4) hardware queues round-robin in creation order, and two lanes sharing a queue serialise
   // (measured: a fifth stream created between the lanes cost 15 -> 20 us per block).
   hipStream_t upload = nullptr;
+  hipStream_t tail = nullptr;       // the demodulators' stream: one in-order queue carries their block-to-block state (created on first use)
   Lane lanes[CHZ_MAX_LANES];
   int nlanes = 1;
   hipEvent_t input_ready = nullptr; // after the latest ring write
@@ -190,6 +205,13 @@ template <class T> static int upload(T** dst, const std::vector<f2>& v) {
 static void free_bank(Bank& b) {
   hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub);
   hipFree(b.fine); hipFree(b.power); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam);
+  hipFree(b.dm_chan); hipFree(b.dm_state); hipFree(b.dm_status); hipFree(b.dm_pcm);
+  b.dm_chan = nullptr; b.dm_state = nullptr; b.dm_status = nullptr; b.dm_pcm = nullptr; b.dm_on = 0; b.dm_chan_h.clear(); b.dm_osc.clear();
+  for (int s = 0; s < CHZ_ND; s++) {
+    if (b.ev_bank[s]) (void)hipEventDestroy(b.ev_bank[s]);
+    if (b.ev_tail[s]) (void)hipEventDestroy(b.ev_tail[s]);
+    b.ev_bank[s] = b.ev_tail[s] = nullptr; b.tail_used[s] = false;
+  }
   for (int s = 0; s < CHZ_ND; s++) {
     if (b.stage[s]) (void)hipHostFree(b.stage[s]);
     if (b.stage_ev[s]) (void)hipEventDestroy(b.stage_ev[s]);
@@ -302,6 +324,7 @@ void chz_engine_destroy(chz_engine* e) {
   e->issuers.clear();
   for (int i = 0; i < e->nlanes; i++) if (e->lanes[i].s) hipStreamSynchronize(e->lanes[i].s);
   if (e->upload) hipStreamSynchronize(e->upload);
+  if (e->tail) hipStreamSynchronize(e->tail);
   drop_graph(e);
   for (int i = 0; i < e->nlanes; i++) {
     hipFree(e->lanes[i].buf);
@@ -321,6 +344,7 @@ void chz_engine_destroy(chz_engine* e) {
   free_notches(e);
   if (e->notch_err) (void)hipHostFree(e->notch_err);
   if (e->upload) hipStreamDestroy(e->upload);
+  if (e->tail) hipStreamDestroy(e->tail);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
 }
@@ -361,6 +385,7 @@ static int check_device_errors(const chz_engine* e) {
 }
 static int sync_all(chz_engine* e) {
   for (int i = 0; i < e->nlanes; i++) HIPOK(hipStreamSynchronize(e->lanes[i].s));
+  if (e->tail) HIPOK(hipStreamSynchronize(e->tail));
   return check_device_errors(e);
 }
 int chz_sync(chz_engine* e) {
@@ -661,6 +686,8 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   hipStream_t st = e->lanes[lane_of(e, (unsigned)slot, in)].s;
   b.last_slot = slot;
   { int r = refresh_slot(e, b, slot, st); if (r) return r; }
+  // the demodulator of the block that used this slot last (4 blocks ago) still reads the output image
+  if (b.tail_used[slot] && ch0 == 0 && !(in && in->on)) HIPOK(hipStreamWaitEvent(st, b.ev_tail[slot], 0));
   const size_t so = (size_t)slot * b.cap;
   ChanParams c{};
   c.lay = SpecLayout{e->plan.Na, e->plan.spec_pitch, e->plan.spec_off}; c.inv_na = 1.0f / (float)e->plan.Na;
@@ -683,6 +710,23 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
     mark(in, st, 3, true);
     if (launch_noise(n, st, q, IN_E0(in), IN_E1(in))) return fail(-4, "no noise kernel for a %d-bin window", q.nbins);
     mark(in, st, 3, false);
+  }
+  // the linear demodulators of this bank, in block order on the demodulator stream.  Only whole-bank
+  // launches feed them (a single-channel re-run of the drop-in's miss path does not advance anybody's AGC).
+  if (b.dm_on > 0 && ch0 == 0) {
+    hipStream_t ts = (in && in->on) ? st : e->tail;
+    if (ts != st) {
+      HIPOK(hipEventRecord(b.ev_bank[slot], st));
+      HIPOK(hipStreamWaitEvent(ts, b.ev_bank[slot], 0));
+    }
+    DemodParams d{};
+    d.in = bank_out(b, slot); d.power = b.power + so; d.n0 = b.n0 + so; d.chan = b.dm_chan; d.state = b.dm_state;
+    d.status = b.dm_status + so; d.pcm = b.dm_pcm + so * (size_t)(b.olen * 8); d.ch0 = 0; d.nch = n; d.olen = b.olen;
+    d.pcm_stride = b.olen * 8; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;      // Power_alpha, src/radio.c:72
+    mark(in, ts, 6, true);
+    launch_demod(ts, d, IN_E0(in), IN_E1(in));
+    mark(in, ts, 6, false);
+    if (ts != st) { HIPOK(hipEventRecord(b.ev_tail[slot], ts)); b.tail_used[slot] = true; }
   }
   return 0;
 }
@@ -1016,6 +1060,98 @@ int chz_bank_set_beam(chz_engine* e, int bank, int ch0, int n, const double* ab,
   for (int i = 0; i < n; i++) b.beam_h[(size_t)(ch0 + i)] = BeamDesc{ab[4 * i], ab[4 * i + 1], ab[4 * i + 2], ab[4 * i + 3], on[i] ? 1 : 0, 0};
   return after_edit(e, b, ch0, n);
 }
+// demod_linear()'s per-block work for channels [ch0, ch0+n) from block `job` on
+int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, const chz_demod_params* p, double blocktime) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (!p || !(blocktime > 0)) return fail(-1, "bad argument");
+  Bank& b = e->banks[(size_t)bank];
+  if (b.out_real) return fail(-1, "the linear demodulator follows COMPLEX-output channels");
+  if (!b.power || !b.n0 || b.noise_samprate <= 0.0)
+    return fail(-1, "the demodulator needs the channel's bb_power and noise estimate: call chz_bank_set_tuning and chz_bank_enable_noise first");
+  for (int i = 0; i < n; i++) {
+    const chz_demod_params& q = p[i];
+    if (q.channels < 0 || q.channels > 2 || q.encoding < CHZ_PCM_S16BE || q.encoding > CHZ_PCM_F32BE) return fail(-1, "bad demodulator parameters for channel %d", ch0 + i);
+    if (q.channels > 0 && !(q.samprate > 0 && q.headroom > 0 && q.bandwidth > 0 && std::isfinite(q.shift) && q.gain > 0))
+      return fail(-1, "bad demodulator parameters for channel %d", ch0 + i);
+  }
+  HIPOK(hipSetDevice(e->device));
+  if (!e->tail) HIPOK(hipStreamCreateWithFlags(&e->tail, hipStreamNonBlocking));
+  if (!b.dm_chan) {
+    { int r = sync_all(e); if (r) return r; }        // one-time switch
+    const size_t cap = (size_t)b.cap;
+    HIPOK(hipMalloc((void**)&b.dm_chan, sizeof(DemodChan) * cap)); HIPOK(hipMemset(b.dm_chan, 0, sizeof(DemodChan) * cap));
+    HIPOK(hipMalloc((void**)&b.dm_state, sizeof(DemodState) * cap)); HIPOK(hipMemset(b.dm_state, 0, sizeof(DemodState) * cap));
+    HIPOK(hipMalloc((void**)&b.dm_status, sizeof(DemodStatus) * cap * CHZ_ND)); HIPOK(hipMemset(b.dm_status, 0, sizeof(DemodStatus) * cap * CHZ_ND));
+    HIPOK(hipMalloc((void**)&b.dm_pcm, (size_t)b.olen * 8 * cap * CHZ_ND)); HIPOK(hipMemset(b.dm_pcm, 0, (size_t)b.olen * 8 * cap * CHZ_ND));
+    for (int s = 0; s < CHZ_ND; s++) {
+      HIPOK(hipEventCreateWithFlags(&b.ev_bank[s], hipEventDisableTiming));
+      HIPOK(hipEventCreateWithFlags(&b.ev_tail[s], hipEventDisableTiming));
+    }
+    HIPOK(hipDeviceSynchronize());
+    DemodChan z; memset(&z, 0, sizeof z);
+    b.dm_chan_h.assign(cap, z);
+    b.dm_osc.assign(cap, Bank::OscHost());
+    drop_graph(e);
+  }
+  HIPOK(hipStreamSynchronize(e->tail));      // the demodulator stream only: blocks already handed to it keep their parameters
+  std::vector<DemodState> init; std::vector<int> init_ch;
+  for (int i = 0; i < n; i++) {
+    const chz_demod_params& q = p[i];
+    DemodChan& c = b.dm_chan_h[(size_t)(ch0 + i)];
+    const bool was_on = c.on != 0;
+    if (q.channels == 0) { if (was_on) b.dm_on--; c.on = 0; continue; }
+    c.channels = q.channels; c.env = q.env != 0; c.agc = q.agc != 0; c.encoding = q.encoding; c.snr_squelch = q.snr_squelch != 0;
+    c.squelch_tail = q.squelch_tail; c.tuned = q.tuned != 0; c.on = 1;
+    c.samprate = q.samprate; c.headroom = q.headroom; c.threshold = q.threshold; c.recovery_rate = q.recovery_rate; c.hangtime = q.hangtime;
+    c.dc_alpha = q.dc_alpha; c.bandwidth = q.bandwidth; c.squelch_open = q.squelch_open; c.squelch_close = q.squelch_close;
+    // chan->shift: set_osc() keeps the phase when the frequency changes (src/osc.c:28-47); an oscillator at 0 Hz is not stepped (src/linear.c:170)
+    Bank::OscHost& o = b.dm_osc[(size_t)(ch0 + i)];
+    const double f = q.shift / q.samprate;
+    if (!o.init) { o.init = true; o.freq = 0.0; o.phase0 = 0.0; o.job0 = job; }
+    if (f != o.freq) {
+      const double g = (double)(job - o.job0) * (double)b.olen;
+      double hi = g * o.freq, lo = std::fma(g, o.freq, -hi);
+      hi -= std::rint(hi);
+      o.phase0 = frac1(o.phase0 + hi + lo); o.job0 = job; o.freq = f;
+    }
+    c.osc_phase0 = o.phase0; c.osc_freq = o.freq; c.osc_job0 = o.job0;
+    if (!was_on) {
+      b.dm_on++;
+      DemodState st; memset(&st, 0, sizeof st);
+      st.gain = q.gain; st.am_dc = 0.0; st.n0 = std::nan(""); st.hangcount = 0;
+      st.squelch_state = !c.snr_squelch ? c.squelch_tail + 4 : 0;                     // src/linear.c:46
+      st.squelch_open = 1;                                                              // :47
+      init.push_back(st); init_ch.push_back(ch0 + i);
+    }
+  }
+  HIPOK(hipMemcpy(b.dm_chan + ch0, b.dm_chan_h.data() + ch0, sizeof(DemodChan) * (size_t)n, hipMemcpyHostToDevice));
+  for (size_t k = 0; k < init.size(); k++)
+    HIPOK(hipMemcpy(b.dm_state + init_ch[k], &init[k], sizeof(DemodState), hipMemcpyHostToDevice));
+  b.dm_blocktime = blocktime;
+  return 0;
+}
+int chz_bank_pcm_stride(chz_engine* e, int bank) {
+  BANK_CHECK(e, bank, 0, 0);
+  return e->banks[(size_t)bank].olen * 8;
+}
+static int read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm, chz_demod_status* status, bool wait) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
+  Bank& b = e->banks[(size_t)bank];
+  if (!b.dm_chan) return fail(-1, "bank has no demodulator: call chz_bank_set_demod first");
+  static_assert(sizeof(chz_demod_status) == sizeof(DemodStatus), "status layouts must agree");
+  const size_t so = (size_t)slot * b.cap + ch0, stride = (size_t)b.olen * 8;
+  if (pcm) HIPOK(hipMemcpyAsync(pcm, b.dm_pcm + so * stride, stride * (size_t)n, hipMemcpyDeviceToHost, e->tail));
+  if (status) HIPOK(hipMemcpyAsync(status, b.dm_status + so, sizeof(DemodStatus) * (size_t)n, hipMemcpyDeviceToHost, e->tail));
+  if (wait) HIPOK(hipStreamSynchronize(e->tail));
+  return 0;
+}
+int chz_bank_read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm, chz_demod_status* status) {
+  return read_pcm(e, bank, slot, ch0, n, pcm, status, true);
+}
+int chz_bank_read_pcm_async(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm, chz_demod_status* status) {
+  return read_pcm(e, bank, slot, ch0, n, pcm, status, false);
+}
 int chz_bank_set_active(chz_engine* e, int bank, int n) {
   BANK_CHECK(e, bank, 0, n);
   if (e->banks[(size_t)bank].active != n) drop_graph(e);
@@ -1100,9 +1236,20 @@ int chz_bank_output_device(chz_engine* e, int bank, int slot, float** dev) {
 static int enqueue_step(chz_engine* e, unsigned job, Instr* in, NotchTurn* turn = nullptr, int seq = 0, bool capture_first = false, bool capturing = false) {
   int r = enqueue_forward(e, job, in, turn, seq, capture_first, capturing);
   if (r) return r;
-  for (int b = 0; b < (int)e->banks.size(); b++)
-    if ((r = enqueue_bank(e, b, job, in))) return r;
-  return 0;
+  bool demod = false;
+  for (const Bank& b : e->banks) demod = demod || b.dm_on > 0;
+  if (demod && turn) {                // what goes to the demodulator stream is issued in block order
+    while (turn->next_tail.load(std::memory_order_acquire) != seq) {
+      if (turn->abort.load(std::memory_order_relaxed)) return fail(-6, "another issuing thread failed");
+      __builtin_ia32_pause();
+    }
+  }
+  for (int b = 0; b < (int)e->banks.size() && !r; b++) r = enqueue_bank(e, b, job, in);
+  if (demod && turn) {
+    if (r) turn->abort.store(1, std::memory_order_relaxed);
+    turn->next_tail.store(seq + 1, std::memory_order_release);
+  }
+  return r;
 }
 
 int chz_step(chz_engine* e, unsigned job) {
@@ -1139,7 +1286,7 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
   if (!e || nblocks < 0) return fail(-1, "bad argument");
   if (mode == 1)
     for (const Bank& b : e->banks)
-      if (b.fine) return fail(-5, "graph replay bakes the block number into the captured launches; fine-tuned banks need eager mode");
+      if (b.fine || b.dm_on) return fail(-5, "graph replay bakes the block number into the captured launches; fine-tuned and demodulated banks need eager mode");
   HIPOK(hipSetDevice(e->device));
   { int r = sync_all(e); if (r) return r; }
   e->input_pending = false;                       // everything written so far is visible to every lane now
@@ -1222,8 +1369,8 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
     timing->enqueue_ms = enqueue_ms;
     float ms = 0; HIPOK(hipEventElapsedTime(&ms, t0, t1));
     timing->total_ms = ms; timing->blocks = nblocks;
-    double* acc[6] = {&timing->first_ms, &timing->cols_ms, &timing->rows_ms, &timing->notch_ms, &timing->chan_ms, &timing->fix_ms};
-    int* cnt[6] = {&timing->first_n, &timing->cols_n, &timing->rows_n, &timing->notch_n, &timing->chan_n, &timing->fix_n};
+    double* acc[7] = {&timing->first_ms, &timing->cols_ms, &timing->rows_ms, &timing->notch_ms, &timing->chan_ms, &timing->fix_ms, &timing->demod_ms};
+    int* cnt[7] = {&timing->first_n, &timing->cols_n, &timing->rows_n, &timing->notch_n, &timing->chan_n, &timing->fix_n, &timing->demod_n};
     for (size_t i = 0; i < in.kind.size(); i++) {
       float k = 0; hipEventElapsedTime(&k, in.ev[2 * i], in.ev[2 * i + 1]);
       *acc[in.kind[i]] += k; *cnt[in.kind[i]] += 1;

@@ -1070,6 +1070,200 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
 }
 
 // ------------------------------------------------------------------------------
+// the linear demodulator's per-block work behind the fine-tuned channel outputs
+// (demod_linear, src/linear.c:56-375, without the PLL branch): noise smoothing (src/radio.c:1466-1473), the
+// post-detection shift oscillator (:168-172), block AGC (:177-234), the final demodulation pass with the per-sample
+// gain ramp (:236-311), the SNR squelch sequencer (:313-366), and PCM packing (src/import.h:88-118 via send_output,
+// src/audio.c:117-133).  What leaves the device per channel and block is the packed PCM (480 B for a 12 kHz mono
+// S16 channel instead of 1920 B of complex baseband) and a small status record.
+// One lane per channel, every loop in the reference's own order: gain *= gain_change and the carrier-removal filter
+// are recurrences over the samples, and doing them as the reference does keeps the result bit-for-bit that of the
+// restatement (oracle/chz_oracle.c:chzo_lindemod_block), which is pinned to the reference's linear.c itself.
+// The state is a recurrence over BLOCKS: the engine runs these kernels on one in-order stream.
+// ------------------------------------------------------------------------------
+enum { CHZ_PCM_S16BE_K = 0, CHZ_PCM_S16LE_K = 1, CHZ_PCM_F32LE_K = 2, CHZ_PCM_F32BE_K = 3 };
+struct DemodChan {               // per channel, set by the host (names: the chan_t members src/linear.c reads)
+  int channels, env, agc, encoding, snr_squelch, squelch_tail, tuned, on;
+  double samprate, headroom, threshold, recovery_rate, hangtime, dc_alpha, bandwidth, squelch_open, squelch_close;
+  double osc_phase0, osc_freq;   // chan->shift as a closed form in the block number: phase (cycles) at sample 0 of block osc_job0
+  unsigned osc_job0; int pad;
+};
+struct DemodState { double gain, am_dc, n0; int hangcount, squelch_state, squelch_open, pad; };
+struct DemodStatus { int frame, mute, squelch_state, pad; double output_power, gain, n0, snr; };   // frame 0 = PCM present, 1 = silence
+struct DemodParams {
+  const float2* in;          // [cap][olen] this slot's channel outputs (after fine tuning)
+  const double* power;       // [cap] this slot's bb_power
+  const double* n0;          // [cap] this slot's noise estimates
+  const DemodChan* chan;     // [cap]
+  DemodState* state;         // [cap]
+  DemodStatus* status;       // [cap] this slot
+  unsigned char* pcm;        // [cap][pcm_stride] this slot
+  int ch0, nch, olen, pcm_stride;
+  unsigned job;
+  double blocktime, power_alpha;
+};
+
+__device__ __forceinline__ void demod_put(unsigned char* o, int enc, int idx, float v) {
+  if (enc == CHZ_PCM_S16BE_K || enc == CHZ_PCM_S16LE_K) {
+    float t = ldexpf(v, 15);                                           // src/import.h:90-94
+    t = t > 32767.0f ? 32767.0f : t < -32767.0f ? -32767.0f : t;
+    const int q = (int)rintf(t);                                       // lrintf: to nearest, ties to even
+    unsigned short u = (unsigned short)(short)q;
+    if (enc == CHZ_PCM_S16BE_K) u = (unsigned short)((u >> 8) | (u << 8));
+    reinterpret_cast<unsigned short*>(o)[idx] = u;
+  } else {
+    unsigned u = __float_as_uint(v);
+    if (enc == CHZ_PCM_F32BE_K) u = __builtin_bswap32(u);
+    reinterpret_cast<unsigned*>(o)[idx] = u;
+  }
+}
+__device__ __forceinline__ float demod_cabsf(float2 x) {
+  float a = x.x * x.x, b = x.y * x.y;
+  CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
+  return sqrtf(a + b);
+}
+
+__global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
+  const int lc = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (lc >= p.nch) return;
+  const int ch = p.ch0 + lc;
+  const DemodChan c = p.chan[ch];
+  if (!c.on) return;
+  DemodState st = p.state[ch];
+  const int N = p.olen;
+  const float2* __restrict__ x = p.in + (size_t)ch * N;
+  unsigned char* __restrict__ o = p.pcm + (size_t)ch * p.pcm_stride;
+  const double bb_power = p.power[ch];
+  // src/radio.c:1466-1473
+  const double est = p.n0[ch];
+  if (st.n0 != st.n0) st.n0 = est;
+  else { const double diff = est - st.n0; st.n0 += p.power_alpha * diff; }
+  // chan->shift (src/linear.c:168-172): phasor at sample 0 of this block from the closed form, then stepped in double
+  const bool rot = c.osc_freq != 0.0;
+  double c0 = 1.0, s0 = 0.0, c1 = 1.0, s1 = 0.0;
+  if (rot) {
+    const double g = (double)(p.job - c.osc_job0) * (double)N;
+    double hi = g * c.osc_freq, lo = fma(g, c.osc_freq, -hi);
+    hi -= rint(hi);
+    sincospi(2.0 * (c.osc_phase0 + hi + lo), &s0, &c0);
+    sincospi(2.0 * c.osc_freq, &s1, &c1);
+  }
+  auto sample = [&](int n, double cr, double sr) -> float2 {         // buffer[n] *= step_osc(): product rounded to float complex
+    float2 v = x[n];
+    if (rot) { const double xr = v.x, xi = v.y; v = make_float2((float)(xr * cr - xi * sr), (float)(xr * sr + xi * cr)); }
+    return v;
+  };
+  // ---- AGC (src/linear.c:177-234)
+  double gain_change = 1.0;
+  if (c.agc) {
+    const double bn = sqrt(c.bandwidth * st.n0);
+    const double ampl = sqrt(bb_power);
+    double peak_level = 0.0;
+    int sps = (int)rint(N * .002 / p.blocktime);
+    sps = sps < 1 ? 1 : sps;
+    {
+      double cr = c0, sr = s0;
+      int n = 0;
+      while (n + sps < N) {
+        double energy = 0.0;
+        for (int i = 0; i < sps; i++) {
+          const float2 v = sample(n, cr, sr); n++;
+          if (rot) { const double nc = cr * c1 - sr * s1; sr = cr * s1 + sr * c1; cr = nc; }
+          float a = v.x * v.x, b = v.y * v.y;
+          CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
+          energy += (double)(a + b);                                  // cnrmf
+        }
+        if (energy > peak_level) peak_level = energy;
+      }
+      peak_level = sqrt(peak_level / sps);
+    }
+    if (peak_level * st.gain > M_SQRT2 * c.headroom) {
+      st.gain = M_SQRT2 * c.headroom / peak_level;
+      gain_change = 1.0;
+      st.hangcount = (int)rint(0.08 * c.samprate);
+    } else if (ampl * st.gain > c.headroom) {
+      const double newgain = c.headroom / ampl;
+      if (newgain > 0) gain_change = pow(newgain / st.gain, 1.0 / N);
+      st.hangcount = (int)rint(c.hangtime * c.samprate);
+    } else if (bn * st.gain > c.threshold * c.headroom) {
+      const double newgain = c.threshold * c.headroom / bn;
+      if (newgain > 0) gain_change = pow(newgain / st.gain, 1.0 / N);
+    } else if (st.hangcount > 0) {
+      st.hangcount -= N;
+    } else {
+      gain_change = pow(c.recovery_rate, 1.0 / c.samprate);
+    }
+  }
+  // ---- squelch decision first (it depends on nothing the final pass produces except output_power == 0, handled below):
+  // the sequencer state is advanced exactly as src/linear.c:313-352 does, AFTER the final pass in program order there,
+  // but the two do not interact, and knowing the frame type up front saves packing PCM nobody will send.
+  double snr = __builtin_huge_val();
+  if (c.snr_squelch) snr = (bb_power / (st.n0 * c.bandwidth)) - 1.0;
+  const int smax = c.squelch_tail + 4;
+  if (!c.snr_squelch || snr >= c.squelch_open) st.squelch_state = smax;
+  else if (st.squelch_state > 0 && snr < c.squelch_close) st.squelch_state--;
+  const bool data = st.squelch_state >= 4;
+  // ---- final pass (src/linear.c:236-311); the gain ramp runs whether or not the frame is sent
+  double output_power = 0.0;
+  {
+    double gain = st.gain, cr = c0, sr = s0;
+    double am_dc = st.am_dc;
+    const int enc = c.encoding;
+    for (int n = 0; n < N; n++) {
+      const float2 v = sample(n, cr, sr);
+      if (rot) { const double nc = cr * c1 - sr * s1; sr = cr * s1 + sr * c1; cr = nc; }
+      if (c.channels == 1) {
+        double s;
+        if (c.env) {
+          s = gain * M_SQRT1_2 * (double)demod_cabsf(v);
+          gain *= gain_change;
+          output_power += s * s;
+          if (c.dc_alpha != 0) { am_dc += c.dc_alpha * (s - am_dc); s -= am_dc; }
+        } else {
+          s = gain * (double)v.x;
+          gain *= gain_change;
+          output_power += s * s;
+        }
+        if (data) demod_put(o, enc, n, (float)s);
+      } else {
+        double a, b;
+        if (c.env) {
+          const double k = gain * M_SQRT1_2;
+          a = k * (double)v.x; b = k * (double)demod_cabsf(v);
+          gain *= gain_change;
+          output_power += a * a + b * b;
+          if (c.dc_alpha != 0) { am_dc += c.dc_alpha * (b - am_dc); b -= am_dc; }
+        } else {
+          a = gain * (double)v.x; b = gain * (double)v.y;
+          gain *= gain_change;
+          output_power += a * a + b * b;
+        }
+        if (data) { demod_put(o, enc, 2 * n, (float)a); demod_put(o, enc, 2 * n + 1, (float)b); }
+      }
+    }
+    st.gain = gain; st.am_dc = am_dc;
+  }
+  output_power /= N;
+  if (c.channels == 1) output_power *= 2;
+  DemodStatus r;
+  r.pad = 0; r.gain = st.gain; r.n0 = st.n0; r.snr = snr; r.squelch_state = st.squelch_state;
+  r.output_power = output_power;
+  if (!data) {
+    r.frame = 1; r.mute = st.squelch_state == 0;
+    if (st.squelch_state == 3 || st.squelch_state == 0) r.output_power = 0;
+  } else {
+    if (c.snr_squelch) {
+      if (snr < c.squelch_close) st.squelch_open = 0;
+      else if (!st.squelch_open && snr > c.squelch_open) { st.squelch_open = 1; st.am_dc = 0; }
+    } else st.squelch_open = 1;
+    r.frame = 0;
+    r.mute = (output_power == 0 || !st.squelch_open || !c.tuned);
+  }
+  p.status[ch] = r;
+  p.state[ch] = st;
+}
+
+// ------------------------------------------------------------------------------
 // Small inline masters (radiod's filter2, src/radio.c:1572-1594: a private COMPLEX master of
 // N = round2(2 * blocksize) points with ONE same-size COMPLEX slave, shift 0, optionally ISB, run inline by
 // each channel thread after the first filter).  Thousands of them exist, each far too small for a launch of

@@ -78,6 +78,11 @@ inline NotchTables notch_tables(const int* bins, int n, const SpecLayout& lay) {
   }
   return t;
 }
+inline int launch_demod(hipStream_t s, const DemodParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+  if (p.nch <= 0) return 0;
+  CHZ_LAUNCH(demod_linear_tail, (p.nch + 63) / 64, 64, 0, s, e0, e1, p);
+  return 0;
+}
 inline int launch_noise(int nch, hipStream_t s, const NoiseParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   const int grid = (nch + 3) / 4;          // four wavefronts = four channels per workgroup
   if (p.nsort == 1024) { CHZ_LAUNCH((noise_est<16>), grid, 256, 0, s, e0, e1, p); return 0; }

@@ -27,7 +27,23 @@ class ChzTiming(C.Structure):
     _fields_ = [("total_ms", _d), ("blocks", _i),
                 ("first_ms", _d), ("cols_ms", _d), ("rows_ms", _d), ("notch_ms", _d), ("chan_ms", _d),
                 ("first_n", _i), ("cols_n", _i), ("rows_n", _i), ("notch_n", _i), ("chan_n", _i), ("enqueue_ms", _d),
-                ("fix_ms", _d), ("fix_n", _i)]
+                ("fix_ms", _d), ("fix_n", _i), ("demod_ms", _d), ("demod_n", _i)]
+
+
+class DemodParams(C.Structure):
+    """chz_demod_params: the chan_t members src/linear.c reads (linear amplitudes / power ratios)."""
+    _fields_ = [("channels", _i), ("env", _i), ("agc", _i), ("encoding", _i), ("snr_squelch", _i), ("squelch_tail", _i),
+                ("tuned", _i), ("pad", _i),
+                ("samprate", _d), ("headroom", _d), ("threshold", _d), ("recovery_rate", _d), ("hangtime", _d), ("dc_alpha", _d),
+                ("bandwidth", _d), ("shift", _d), ("squelch_open", _d), ("squelch_close", _d), ("gain", _d)]
+
+
+class DemodStatus(C.Structure):
+    _fields_ = [("frame", _i), ("mute", _i), ("squelch_state", _i), ("pad", _i),
+                ("output_power", _d), ("gain", _d), ("n0", _d), ("snr", _d)]
+
+
+PCM_S16BE, PCM_S16LE, PCM_F32LE, PCM_F32BE = 0, 1, 2, 3
 
 
 # every symbol include/chz_engine.h declares (checked by tests/test_host_logic.py and __graft_entry__.build())
@@ -43,6 +59,7 @@ SYMBOLS = [
     "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
     "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real", "chz_bank_set_isb", "chz_bank_set_beam",
     "chz_set_notches_alpha", "chz_slot_sync", "chz_engine_check",
+    "chz_bank_set_demod", "chz_bank_pcm_stride", "chz_bank_read_pcm", "chz_bank_read_pcm_async",
     "chz_comm_unique_id", "chz_comm_create", "chz_comm_create_file", "chz_comm_destroy", "chz_comm_rank", "chz_comm_world",
     "chz_mini_create", "chz_mini_destroy", "chz_mini_capacity", "chz_mini_add", "chz_mini_release", "chz_mini_set_response", "chz_mini_execute",
     "chz_comm_barrier", "chz_comm_allreduce_max", "chz_spectrum_broadcast", "chz_spectrum_exchange_rows", "chz_run_blocks_sharded",
@@ -77,6 +94,10 @@ def lib():
         L.chz_set_notches_alpha.argtypes = [_vp, _vp, _vp, _i]
         L.chz_slot_sync.argtypes = [_vp, _i]
         L.chz_engine_check.argtypes = [_vp]
+        L.chz_bank_set_demod.argtypes = [_vp, _i, _u, _i, _i, _vp, _d]
+        L.chz_bank_pcm_stride.argtypes = [_vp, _i]
+        L.chz_bank_read_pcm.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp]
+        L.chz_bank_read_pcm_async.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp]
         L.chz_mini_create.argtypes = [C.POINTER(_vp), _i, _i, _i, _i]
         L.chz_mini_destroy.argtypes = [_vp]; L.chz_mini_destroy.restype = None
         L.chz_mini_capacity.argtypes = [_vp]
@@ -334,6 +355,21 @@ class Bank:
             rp = rate.ctypes.data
         _check(lib().chz_bank_set_tuning(self.eng._h, self.id, job & 0xFFFFFFFF, ch0, shifts.shape[0],
                                          shifts.ctypes.data, freq.ctypes.data, rp))
+
+    def set_demod(self, job, ch0, params, blocktime=0.02):
+        """demod_linear()'s per-block work (src/linear.c) for channels ch0.. from block `job`; params: list of DemodParams."""
+        arr = (DemodParams * len(params))(*params)
+        _check(lib().chz_bank_set_demod(self.eng._h, self.id, job & 0xFFFFFFFF, ch0, len(params), arr, float(blocktime)))
+
+    def read_pcm(self, slot, ch0=0, n=None):
+        """(pcm uint8[n][stride], status DemodStatus[n]) of the block last demodulated on `slot`."""
+        if n is None:
+            n = self.active - ch0
+        stride = _check(lib().chz_bank_pcm_stride(self.eng._h, self.id))
+        pcm = np.zeros((n, stride), np.uint8)
+        st = (DemodStatus * n)()
+        _check(lib().chz_bank_read_pcm(self.eng._h, self.id, slot, ch0, n, pcm.ctypes.data, st))
+        return pcm, st
 
     def enable_noise(self, samprate):
         """estimate_noise() (src/radio.c:1783-1866) on the device after every block; samprate = front-end rate in Hz."""

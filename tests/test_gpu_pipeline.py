@@ -293,3 +293,76 @@ def test_mini_master_rejects_what_it_cannot_do(pkg):
     for L, M in ((240, 272), (5000, 5001)):               # N = 511 (prime factor 7 x 73), N = 10000 > 8192
         with pytest.raises(pkg.engine.ChzError):
             pkg.engine.MiniPool(L, M, 4)
+
+
+# ------------------------------------------------------------------------------------------------
+# the linear demodulator behind the channel outputs
+# ------------------------------------------------------------------------------------------------
+def _demod_engine(pkg, ring, L, M, P, olen, cases, fs_out):
+    from test_kernels_emulated import DEMOD_CASES                      # the seven mode combinations
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    eng.write(ring[:8 * L - (M - 1)]); eng.write(ring[8 * L - (M - 1):])
+    nch = len(cases)
+    bank = eng.bank(P, olen, nch)
+    N = L + M - 1
+    bank.set_responses(0, np.stack([pkg.filterapi.design_response(P, olen, N, True, -0.12, 0.12, 11.0)] * nch))
+    shifts = np.array([2500 + 3 * i for i in range(nch)], np.int32)      # all around the test carrier
+    bank.set_tuning(0, 0, shifts, np.array([-(3.7 + i) / fs_out for i in range(nch)]))
+    bank.set_active(nch)
+    bank.enable_noise(50.0 * L)
+    params = [ol.lin_params(**kw) for kw in cases]
+    bank.set_demod(0, 0, [pkg.engine.DemodParams(*[getattr(p, f) for f, _ in ol.LinParams._fields_]) for p in params], 0.02)
+    return eng, bank, params
+
+
+def test_linear_demodulator_on_the_device(pkg):
+    """chan_ifft (+ fine tuning, bb_power) -> noise_est -> demod_linear_tail, block after block through the C ABI.  The
+    oracle's demodulator (pinned to the reference's linear.c) is fed exactly what the device stage was fed -- the channel
+    outputs, bb_power and noise estimate read back from the same slot -- and must produce the same frames; then the same
+    40 blocks run pipelined over 4 streams and two issuing threads must end in the same AGC state."""
+    from test_kernels_emulated import DEMOD_CASES
+    L, M, P, olen, fs_out = 25920, 6481, 300, 240, 12000.0
+    nblk = 40
+    rng = np.random.default_rng(77)
+    t = np.arange(8 * L)
+    env = np.ones(8 * L); env[:3 * L] = 0.02; env[5 * L:5 * L + L // 3] = 8.0; env[6 * L:] = 0.1       # level steps walk the AGC branches
+    ring = ((0.05 * np.cos(2 * np.pi * (2501.3 / (L + M - 1)) * t) * env) + 1e-4 * rng.standard_normal(8 * L)).astype(np.float32)
+    eng, bank, params = _demod_engine(pkg, ring, L, M, P, olen, DEMOD_CASES, fs_out)
+    oracles = [ol.LinDemod(p) for p in params]
+    seen = set()
+    try:
+        for b in range(nblk):
+            eng.step(b)
+            out = bank.read_slot(b % 4); power = bank.read_power(b % 4); noise = bank.read_noise(b % 4)
+            pcm, status = bank.read_pcm(b % 4)
+            for i, p in enumerate(params):
+                want, st = oracles[i].block(out[i], power[i], noise[i], 0.02)
+                got = status[i]
+                assert (got.frame, got.mute, got.squelch_state) == (st.frame, st.mute, st.squelch_state), (b, i)
+                assert got.gain == pytest.approx(st.gain, rel=1e-9) and got.n0 == pytest.approx(st.n0, rel=1e-12)
+                assert got.output_power == pytest.approx(st.output_power, rel=1e-6, abs=1e-300)
+                seen.add((i, got.frame, got.mute))
+                if st.frame == ol.FRAME_DATA:
+                    nb = ol.pcm_bytes(p.encoding, olen * p.channels)
+                    if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+                        dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
+                        a, w = pcm[i, :nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
+                        assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02, (b, i)
+                    else:
+                        dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
+                        a, w = pcm[i, :nb].view(dt).astype(np.float64), want.view(dt).astype(np.float64)
+                        assert np.abs(a - w).max() <= 1e-6 * max(np.abs(w).max(), 1e-30), (b, i)
+        final = [(s.gain, s.n0, s.squelch_state) for s in bank.read_pcm((nblk - 1) % 4)[1]]
+    finally:
+        eng.close()
+    assert (6, ol.FRAME_DATA, 1) in seen                                  # the untuned channel is muted but still demodulated
+    eng2, bank2, _ = _demod_engine(pkg, ring, L, M, P, olen, DEMOD_CASES, fs_out)
+    try:
+        t = eng2.run_blocks(0, nblk)
+        st2 = bank2.read_pcm((nblk - 1) % 4)[1]
+        for i, (g, n0, sq) in enumerate(final):
+            assert st2[i].gain == pytest.approx(g, rel=1e-9) and st2[i].n0 == pytest.approx(n0, rel=1e-12) and st2[i].squelch_state == sq
+        it = eng2.run_blocks(nblk, 8, instrument=True)
+        assert it.demod_n == 8 and it.demod_ms > 0
+    finally:
+        eng2.close()

@@ -43,6 +43,8 @@ def emu(oracle_built):
     lib.emu_fine_retune.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
     lib.emu_channels_tuned.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_uint, C.c_void_p]
+    lib.emu_demod.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_double]
+    lib.emu_demod_sizes.argtypes = [C.c_void_p]
     lib.emu_mini.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
@@ -316,3 +318,70 @@ def test_mini_master_kernel(emu, L, M):
             want = ol.channel(spec, ol.COMPLEX, N, L, int(shifts[i]), resp[i], isb=bool(isb[i]))
             assert rel(out[i], want) < 3e-6, (blk, i)
         hist = win[:, L:]
+
+
+class _DemodChan(C.Structure):           # struct DemodChan, chz_kernels.h
+    _fields_ = [("channels", C.c_int), ("env", C.c_int), ("agc", C.c_int), ("encoding", C.c_int), ("snr_squelch", C.c_int),
+                ("squelch_tail", C.c_int), ("tuned", C.c_int), ("on", C.c_int),
+                ("samprate", C.c_double), ("headroom", C.c_double), ("threshold", C.c_double), ("recovery_rate", C.c_double),
+                ("hangtime", C.c_double), ("dc_alpha", C.c_double), ("bandwidth", C.c_double), ("squelch_open", C.c_double),
+                ("squelch_close", C.c_double), ("osc_phase0", C.c_double), ("osc_freq", C.c_double), ("osc_job0", C.c_uint), ("pad", C.c_int)]
+
+
+class _DemodState(C.Structure):
+    _fields_ = [("gain", C.c_double), ("am_dc", C.c_double), ("n0", C.c_double), ("hangcount", C.c_int), ("squelch_state", C.c_int),
+                ("squelch_open", C.c_int), ("pad", C.c_int)]
+
+
+DEMOD_CASES = [dict(), dict(channels=2, encoding=ol.PCM_F32LE), dict(env=True, dc_alpha=0.002, encoding=ol.PCM_S16LE),
+               dict(channels=2, env=True, dc_alpha=0.01, encoding=ol.PCM_F32BE), dict(agc=False, gain_db=30.0, shift=500.0),
+               dict(snr_squelch=True, squelch_tail=2), dict(tuned=False)]
+
+
+def test_linear_demodulator_kernel(emu):
+    """demod_linear_tail (one lane per channel, the reference's own loop order) against the restated demodulator over 40
+    blocks of baseband that walks every AGC branch; all seven mode combinations side by side as seven channels."""
+    sizes = (C.c_int * 3)()
+    emu.emu_demod_sizes(sizes)
+    assert list(sizes) == [C.sizeof(_DemodChan), C.sizeof(_DemodState), C.sizeof(ol.LinStatus)]
+    from test_oracle_vs_reference import _demod_case
+    nblk, N, bt = 40, 240, 0.02
+    nch = len(DEMOD_CASES)
+    r = np.random.default_rng(99)
+    bbs, powers, ests, params, oracles = [], [], [], [], []
+    for i, kw in enumerate(DEMOD_CASES):
+        bb, power = _demod_case(np.random.default_rng(100 + i), nblk, N)
+        if kw.get("snr_squelch"):
+            power = power.copy(); power[20:28] = 1e-12
+        bbs.append(bb); powers.append(power); ests.append(1e-8 * (1 + 0.3 * r.standard_normal(nblk)) / 12000.0)
+        p = ol.lin_params(**kw); params.append(p); oracles.append(ol.LinDemod(p))
+    chan = (_DemodChan * nch)(); state = (_DemodState * nch)(); status = (ol.LinStatus * nch)()
+    for i, p in enumerate(params):
+        c = chan[i]
+        for f in ("channels", "env", "agc", "encoding", "snr_squelch", "squelch_tail", "tuned", "samprate", "headroom", "threshold",
+                  "recovery_rate", "hangtime", "dc_alpha", "bandwidth", "squelch_open", "squelch_close"):
+            setattr(c, f, getattr(p, f))
+        c.on = 1; c.osc_phase0 = 0.0; c.osc_freq = p.shift / p.samprate; c.osc_job0 = 7
+        state[i].gain = p.gain; state[i].n0 = float("nan"); state[i].squelch_state = (p.squelch_tail + 4) if not p.snr_squelch else 0
+        state[i].squelch_open = 1
+    pcm = np.zeros((nch, N * 8), np.uint8)
+    for b in range(nblk):
+        x = np.ascontiguousarray(np.stack([bbs[i][b] for i in range(nch)]))
+        pw = np.array([powers[i][b] for i in range(nch)]); ne = np.array([ests[i][b] for i in range(nch)])
+        assert emu.emu_demod(x.ctypes.data, pw.ctypes.data, ne.ctypes.data, chan, state, status, pcm.ctypes.data, nch, N, 7 + b, bt) == 0
+        for i, p in enumerate(params):
+            want, st = oracles[i].block(bbs[i][b], powers[i][b], ests[i][b], bt)
+            got = status[i]
+            assert (got.frame, got.mute, got.squelch_state) == (st.frame, st.mute, st.squelch_state), (b, i)
+            assert got.gain == pytest.approx(st.gain, rel=1e-12) and got.n0 == pytest.approx(st.n0, rel=1e-14)
+            assert got.output_power == pytest.approx(st.output_power, rel=2e-7 if p.env else 1e-12, abs=1e-300)
+            if st.frame == ol.FRAME_DATA:
+                nb = ol.pcm_bytes(p.encoding, N * p.channels)
+                if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+                    dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
+                    a, w = pcm[i, :nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
+                    assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.01, (b, i)
+                else:
+                    dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
+                    a, w = pcm[i, :nb].view(dt).astype(np.float64), want.view(dt).astype(np.float64)
+                    assert np.abs(a - w).max() <= 2e-7 * max(np.abs(w).max(), 1e-30), (b, i)
