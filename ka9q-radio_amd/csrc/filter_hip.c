@@ -78,7 +78,11 @@ struct mctx {
   chz_engine *eng;
   struct filter_in *master;
   pthread_mutex_t lock;             /* serialises engine calls and bank bookkeeping */
-  pthread_rwlock_t stage_lock;      /* staged outputs: many channel threads read, the launcher / bank edits write */
+  /* staged outputs: ~1000 channel threads read after every block, the launcher / bank edits write now and then.  One
+     rwlock word shared by 1000 readers on 256 cores is a cache-line ping-pong, so the lock is split: a reader takes the
+     shard its slave hashes to, a writer takes them all. */
+#define STAGE_SHARDS 16
+  struct { pthread_rwlock_t l; char pad[64 - sizeof(pthread_rwlock_t) % 64]; } stage_lock[STAGE_SHARDS];
   struct hbank *banks;
   int nbanks;
   bool ring_pinned;                 /* host ring registered with the HIP runtime */
@@ -113,8 +117,18 @@ struct sctx {
 
 struct hbank;
 static void bank_free_host(struct hbank *b);
+static void stage_wrlock(struct mctx *c);
+static void stage_wrunlock(struct mctx *c);
+static pthread_rwlock_t *stage_rdlock(struct mctx *c, const void *who);
 static struct mctx *MCTX(struct filter_in *m) { return (struct mctx *)(void *)m->fwd_plan; }
 static struct sctx *SCTX(struct filter_out *s) { return (struct sctx *)(void *)s->rev_plan; }
+static void stage_wrlock(struct mctx *c) { for (int i = 0; i < STAGE_SHARDS; i++) pthread_rwlock_wrlock(&c->stage_lock[i].l); }
+static void stage_wrunlock(struct mctx *c) { for (int i = STAGE_SHARDS - 1; i >= 0; i--) pthread_rwlock_unlock(&c->stage_lock[i].l); }
+static pthread_rwlock_t *stage_rdlock(struct mctx *c, const void *who) {
+  pthread_rwlock_t *l = &c->stage_lock[((uintptr_t)who >> 7) % STAGE_SHARDS].l;
+  pthread_rwlock_rdlock(l);
+  return l;
+}
 
 /* Block completion is published through completed_jobs[] itself with a futex: the ~1000 channel
    threads of a big radiod all sleep on the same word and are released TOGETHER, instead of being
@@ -323,7 +337,7 @@ static void mctx_free(struct mctx *c) {          /* host side only; the engine i
   for (int i = 0; i < c->nbanks; i++) bank_free_host(&c->banks[i]);
   free(c->banks);
   pthread_mutex_destroy(&c->lock);
-  pthread_rwlock_destroy(&c->stage_lock);
+  for (int i = 0; i < STAGE_SHARDS; i++) pthread_rwlock_destroy(&c->stage_lock[i].l);
   pthread_mutex_destroy(&c->miss_lock);
   pthread_cond_destroy(&c->miss_cv);
   free(c);
@@ -363,7 +377,7 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
      a host that takes the noise estimate from the device (chz_bank_enable_noise) can switch the 13 MB per-block copy off */
   { const char *fd = getenv("KA9Q_HIP_FDOMAIN"); c->host_spectrum = !(fd && fd[0] == '0'); }
   pthread_mutex_init(&c->lock, NULL);
-  pthread_rwlock_init(&c->stage_lock, NULL);
+  for (int i = 0; i < STAGE_SHARDS; i++) pthread_rwlock_init(&c->stage_lock[i].l, NULL);
   pthread_mutex_init(&c->miss_lock, NULL);
   pthread_cond_init(&c->miss_cv, NULL);
   size_t const ssz = in_type == COMPLEX ? sizeof(float complex) : sizeof(float);
@@ -485,10 +499,10 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
     }
     if (!slave->fdomain || (!slave->output_buffer.c && !slave->output_buffer.r) || !sc) { FREE(slave->fdomain); FREE(slave->output_buffer.c); FREE(slave->output_buffer.r); free(sc); return -1; }
     pthread_mutex_lock(&c->lock);
-    pthread_rwlock_wrlock(&c->stage_lock);
+    stage_wrlock(c);
     int bi = bank_for(c, slave->points, len, real);
     if (bi < 0) {
-      pthread_rwlock_unlock(&c->stage_lock);
+      stage_wrunlock(c);
       pthread_mutex_unlock(&c->lock);
       fprintf(stderr, "create_filter_output: no device kernel for P=%d\n", slave->points);
       FREE(slave->fdomain); FREE(slave->output_buffer.c); FREE(slave->output_buffer.r); free(sc);
@@ -500,7 +514,7 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
     for (int s = 0; s < ND; s++) b->stage_epoch[s][b->n] = 0;
     b->n++;
     slave->rev_plan = (fftwf_plan)(void *)sc;
-    pthread_rwlock_unlock(&c->stage_lock);
+    stage_wrunlock(c);
     pthread_mutex_unlock(&c->lock);
   }
   /* SPECTRUM: no buffers, no plan: a block clock only (src/filter.c:368-371) */
@@ -516,7 +530,7 @@ int delete_filter_output(struct filter_out *slave) {
     struct mctx *c = MCTX(slave->master);
     struct sctx *sc = SCTX(slave);
     pthread_mutex_lock(&c->lock);
-    pthread_rwlock_wrlock(&c->stage_lock);
+    stage_wrlock(c);
     struct hbank *b = &c->banks[sc->bank];
     int last = b->n - 1;
     if (sc->idx != last) {                 /* the last channel moves into the freed index */
@@ -530,7 +544,7 @@ int delete_filter_output(struct filter_out *slave) {
       for (int s = 0; s < ND; s++) b->stage_epoch[s][ms->idx] = 0;
     }
     b->slaves[last] = NULL; b->n--;
-    pthread_rwlock_unlock(&c->stage_lock);
+    stage_wrunlock(c);
     pthread_mutex_unlock(&c->lock);
     free(sc);
   }
@@ -608,7 +622,7 @@ int execute_filter_input(struct filter_in *const f) {
   /* speculative batched channel launches: every slave with its last-known shift */
   for (int i = 0; rc == 0 && i < c->nbanks; i++) {
     struct hbank *b = &c->banks[i];
-    pthread_rwlock_wrlock(&c->stage_lock);
+    stage_wrlock(c);
     if (!b->real) {                 /* callers flip slave->isb directly (src/radio.c:1586, src/radio_status.c:326) */
       int lo = b->n, hi = 0;
       for (int k = 0; k < b->n; k++) {
@@ -623,7 +637,7 @@ int execute_filter_input(struct filter_in *const f) {
       b->stage_epoch[slot][k] = b->slaves[k]->response ? SCTX(b->slaves[k])->epoch : 0;
       b->stage_isb[slot][k] = b->isb[k];
     }
-    pthread_rwlock_unlock(&c->stage_lock);
+    stage_wrunlock(c);
     if (b->n == 0) continue;
     if (!b->real) {
       if (f->in_type == COMPLEX) {   /* slave->beam and its weights (src/radio.c:938-940) */
@@ -634,9 +648,9 @@ int execute_filter_input(struct filter_in *const f) {
           if (on != b->beam_on[k] || (on && memcmp(ab, b->beam_ab + 4 * k, sizeof ab) != 0)) {
             b->beam_on[k] = on; memcpy(b->beam_ab + 4 * k, ab, sizeof ab);
             chz_bank_set_beam(c->eng, b->id, k, 1, ab, &on);
-            pthread_rwlock_wrlock(&c->stage_lock);
+            stage_wrlock(c);
             for (int s2 = 0; s2 < ND; s2++) if (s2 != slot) b->stage_epoch[s2][k] = 0;   /* earlier staged results used other weights */
-            pthread_rwlock_unlock(&c->stage_lock);
+            stage_wrunlock(c);
           }
         }
       }
@@ -710,7 +724,7 @@ static void serve_misses(struct mctx *c, struct miss_req *list) {
       for (struct miss_req *r = list; r; r = r->next) if (r->slot == s) r->rc = -1;
     }
   /* the staged image now holds exactly what each requester asked for */
-  pthread_rwlock_wrlock(&c->stage_lock);
+  stage_wrlock(c);
   for (struct miss_req *r = list; r; r = r->next) {
     if (r->rc != 0) continue;
     struct sctx *sc = SCTX(r->slave);
@@ -721,7 +735,7 @@ static void serve_misses(struct mctx *c, struct miss_req *list) {
       b->stage_isb[r->slot][sc->idx] = r->slave->isb ? 1 : 0;
     }
   }
-  pthread_rwlock_unlock(&c->stage_lock);
+  stage_wrunlock(c);
   pthread_mutex_unlock(&c->lock);
 }
 
@@ -736,13 +750,17 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
   unsigned const job = slave->next_jobnum;
   int const slot = (int)(job % ND);
   bool slept = false;
+  /* (Measured and rejected: sleeping on 16 sharded wake words per slot with a small initial fan-out -- the tree's depth
+     times the scheduler's wake latency cost 10 ms per block at 1024 threads, against 3 ms for one FUTEX_WAKE of everybody
+     plus the pass-it-on below.) */
+  unsigned *const wake = &master->completed_jobs[slot];
   for (;;) {
     unsigned done = __atomic_load_n(&master->completed_jobs[slot], __ATOMIC_ACQUIRE);
     if ((int)(job - done) <= 0) {
       /* Everybody asleep on this word waits for the same job, so a woken thread passes the wake-up on to two more:
-         ~1000 channel threads are released in a tree (log depth, on many cores) instead of one after the other by
+         the ~1000 channel threads are released in a tree (log depth, on many cores) instead of one after the other by
          the completion callback. */
-      if (slept) futex_wake_n(&master->completed_jobs[slot], 2);
+      if (slept) futex_wake_n(wake, 2);
       if ((int)(done - job) >= ND) {                               /* lapped: zeros + drop (src/filter.c:690-701) */
         slave->block_drops++;
         slave->next_jobnum++;
@@ -752,7 +770,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
       }
       break;
     }
-    futex_wait_u32(&master->completed_jobs[slot], done);           /* src/filter.c:686-687 */
+    futex_wait_u32(wake, done);                                    /* src/filter.c:686-687 */
     slept = true;
   }
   slave->sample_index = master->samples_by_job[slot];              /* src/filter.c:705 */
@@ -769,9 +787,11 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
 
   struct mctx *c = MCTX(master);
   struct sctx *sc = SCTX(slave);
-  for (int attempt = 0; attempt < 2; attempt++) {
+  /* A served miss can still miss the re-test: another channel's delete_filter_output may move this slave to a new bank
+     index between the two (its staged result then sits at the old index).  Re-run; a bounded number of times. */
+  for (int attempt = 0; attempt < 32; attempt++) {
     bool hit = false;
-    pthread_rwlock_rdlock(&c->stage_lock);
+    pthread_rwlock_t *const rl = stage_rdlock(c, slave);
     {
       struct hbank *b = &c->banks[sc->bank];
       int const k = sc->idx;
@@ -782,9 +802,8 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
         hit = true;
       }
     }
-    pthread_rwlock_unlock(&c->stage_lock);
+    pthread_rwlock_unlock(rl);
     if (hit) return 0;
-    if (attempt == 1) break;
 
     /* retuned / new filter / newly created: queue this channel for a re-run on the block's spectrum */
     struct miss_req req = {.slave = slave, .shift = shift, .slot = slot, .job = job};
@@ -809,8 +828,9 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
     pthread_mutex_unlock(&c->miss_lock);
     if (req.rc != 0) return -1;
   }
-  /* the block's staged image was re-used for a later block while this channel waited (it was about to be lapped):
-     the reference would have read a half-overwritten spectrum here; hand out silence instead */
+  /* the block's slot was re-used for a later block while this channel waited (it was being lapped) */
+  fprintf(stderr, "execute_filter_output: block %u is gone from the device (the channel is more than %d blocks behind)\n", job, ND - 1);
+  slave->block_drops++;
   memset(dst, 0, bank_sample_bytes(&c->banks[sc->bank]) * (size_t)slave->olen);
   return 0;
 }
@@ -866,9 +886,9 @@ int set_filter(struct filter_out *const slave, double low, double high, double c
     struct mctx *c = MCTX(slave->master);
     struct sctx *sc = SCTX(slave);
     pthread_mutex_lock(&c->lock);
-    pthread_rwlock_wrlock(&c->stage_lock);
+    stage_wrlock(c);
     sc->epoch++;
-    pthread_rwlock_unlock(&c->stage_lock);
+    stage_wrunlock(c);
     int rc = chz_bank_set_responses(c->eng, c->banks[sc->bank].id, sc->idx, 1, (const float *)response);
     pthread_mutex_unlock(&c->lock);
     if (rc != 0) { fprintf(stderr, "set_filter: %s\n", chz_last_error()); return -1; }

@@ -19,10 +19,11 @@ plan = []
 for i in range(nch):
     shift = ol.compute_tuning(N, fs, 1e6 + i * 60e3 + (i % 40))[1]
     lo, hi = kinds[i % 3]
-    plan.append((shift, shift, 10 ** 6, 10 ** 6, lo, hi, 11.0, lo, hi))
+    plan.append((shift, shift + 1, 10 ** 6, 10 ** 6, lo, hi, 11.0, lo, hi))
 with tempfile.TemporaryDirectory() as tmp:
-    out, spec, meta = td._run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 16384, x)
+    env = {"HARNESS_RETUNE_MOD": os.environ["RETUNE_MOD"]} if os.environ.get("RETUNE_MOD") else None      # 1/RETUNE_MOD of the channels retune every block
+    out, spec, meta = td._run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, int(os.environ.get("CHUNK", "16384")), x, env=env)
 el = float(meta["elapsed_s"])
-print("drop-in, config 3 through filter.h (%d pthreads)" % nch + ": %d blocks in %.3f s = %.2f ms/block = %.1fx real time; "
+print("drop-in, config 3 through filter.h (%d pthreads, retune 1/%s per block)" % (nch, os.environ.get("RETUNE_MOD", "inf")) + ": %d blocks in %.3f s = %.2f ms/block = %.1fx real time; "
       "device block time avg %.1f us max %.1f us; drops %s" % (nblocks, el, el / nblocks * 1e3, 0.02 / (el / nblocks),
       int(meta["avg_block_ns"]) / 1e3, int(meta["max_block_ns"]) / 1e3, meta["drops"]))

@@ -40,6 +40,9 @@ struct chanarg { int idx; };
 /* optional second filter per channel, created and driven exactly as radio.c does (src/radio.c:1503-1513,1572-1594):
    env HARNESS_FILTER2="blocking low high beta [isb_channel]" */
 static int F2_blocking, F2_isb = -1; static double F2_low, F2_high, F2_beta;
+/* env HARNESS_RETUNE_MOD=m: channel i flips between its two shifts at every block b with (b + i) % m == 0, i.e. 1/m of
+   the channels retune EVERY block (a scanning / Doppler-tracking channel set) */
+static int Retune_mod;
 
 static void *channel_thread(void *a) {
   int const i = ((struct chanarg *)a)->idx;
@@ -64,6 +67,7 @@ static void *channel_thread(void *a) {
   for (int b = 0; b < Nblocks; b++) {
     if (b == Plan[i].refilter_block) set_filter(&out, Plan[i].low2, Plan[i].high2, Plan[i].beta);
     int shift = (b >= Plan[i].retune_block) ? Plan[i].shift2 : Plan[i].shift;
+    if (Retune_mod > 0) shift = (((b + i) / Retune_mod) & 1) ? Plan[i].shift2 : Plan[i].shift;
     if (execute_filter_output(&out, shift) != 0) { fprintf(stderr, "execute_filter_output failed\n"); exit(2); }
     if (F2_blocking > 0) {
       int r = write_cfilter(&f2in, out.output.c, Olen);          /* runs the input side once the block is full (src/radio.c:1508) */
@@ -147,6 +151,7 @@ int main(int argc, char **argv) {
     int k = sscanf(getenv("HARNESS_FILTER2"), "%d %lf %lf %lf %d", &F2_blocking, &F2_low, &F2_high, &F2_beta, &F2_isb);
     if (k < 4) { fprintf(stderr, "HARNESS_FILTER2 needs: blocking low high beta [isb_channel]\n"); return 1; }
   }
+  if (getenv("HARNESS_RETUNE_MOD")) Retune_mod = atoi(getenv("HARNESS_RETUNE_MOD"));
   pthread_t *th = calloc((size_t)Nch, sizeof *th), clk;
   struct chanarg *args = calloc((size_t)Nch, sizeof *args);
   for (int i = 0; i < Nch; i++) { args[i].idx = i; pthread_create(&th[i], NULL, channel_thread, &args[i]); }

@@ -79,7 +79,7 @@ def _run_harness(tmp, L, M, in_type, olen, plan, nblocks, chunk, x, env=None):
     return out, spec, dict(zip(meta[::2], meta[1::2]))
 
 
-def _check(L, M, olen, P, plan, nblocks, out, spec, meta, x):
+def _check(L, M, olen, P, plan, nblocks, out, spec, meta, x, retune_mod=0):
     N = L + M - 1
     assert meta["drops"] == "0" and int(meta["clock"]) == nblocks and int(meta["next_jobnum"]) == nblocks
     assert int(meta["bins"]) == N // 2 + 1 and int(meta["points"]) == N and int(meta["sample_index"]) == nblocks * L
@@ -92,6 +92,8 @@ def _check(L, M, olen, P, plan, nblocks, out, spec, meta, x):
         peak = float(np.abs(s64).max())
         for i, p in enumerate(plan):
             shift = p[1] if b >= p[2] else p[0]
+            if retune_mod:
+                shift = p[1] if ((b + i) // retune_mod) & 1 else p[0]
             lo, hi = (p[7], p[8]) if b >= p[3] else (p[4], p[5])
             resp = ol.set_filter(P, olen, N, True, lo, hi, p[6])
             want = ol.channel(s64, ol.REAL, P, olen, shift, resp)
@@ -261,3 +263,22 @@ def test_dropin_filter2_inline_masters(blocking, isb_ch):
             err = float(np.sqrt(np.mean(np.abs(got - want) ** 2)))
             rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
             assert err <= 2e-5 * rms + 1e-9, (i, k, err, rms)
+
+
+@pytest.mark.gpu
+def test_dropin_channels_retuning_every_block():
+    # 1/5 of the channels change their bin shift EVERY block (scanning receivers, Doppler tracking): each of them misses
+    # the speculative batch, the misses of one block are served together, nothing drains the pipeline, every output is exact
+    _build_lib(); ol.build()
+    L, M, olen, P = 25920, 6481, 240, 300
+    nblocks = 11
+    rng = np.random.default_rng(28)
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = []
+    for i in range(60):
+        shift = int(rng.integers(-12000, 12000))
+        plan.append((shift, shift + int(rng.integers(1, 40)), 10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4))
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x, env={"HARNESS_RETUNE_MOD": "5"})
+    _check(L, M, olen, P, plan, nblocks, out, spec, meta, x, retune_mod=5)
