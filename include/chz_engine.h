@@ -274,8 +274,11 @@ typedef struct chz_demod_status {
 /* parameters of channels [ch0, ch0+n) from block `job` on (it must not have been enqueued yet); blocktime = radiod's Blocktime.
  * Waits for the demodulator stream only, never for the transform lanes. */
 int chz_bank_set_demod(chz_engine *e, int bank, unsigned job, int ch0, int n, const chz_demod_params *p, double blocktime);
-/* bytes one channel's PCM of one block can take (olen frames, stereo float32): the stride of chz_bank_read_pcm's buffer */
+/* bytes between two channels' PCM rows = the stride of chz_bank_read_pcm's buffer.  Default olen*8 (stereo float32 fits);
+ * chz_bank_set_pcm_stride, before the first chz_bank_set_demod, shrinks the rows to what the bank's encodings need (olen*2 for
+ * mono S16), so that a block's PCM is one contiguous device-to-host copy of only the bytes that matter */
 int chz_bank_pcm_stride(chz_engine *e, int bank);
+int chz_bank_set_pcm_stride(chz_engine *e, int bank, int bytes);
 /* PCM (pcm_stride bytes per channel, the encoding's N*channels samples first) and status of the block last demodulated
  * on `slot`; synchronous / asynchronous on the demodulator stream (completion: chz_sync) */
 int chz_bank_read_pcm(chz_engine *e, int bank, int slot, int ch0, int n, void *pcm, chz_demod_status *status);

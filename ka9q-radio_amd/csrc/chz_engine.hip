@@ -81,6 +81,7 @@ struct Bank {
   struct OscHost { bool init = false; double freq = 0.0, phase0 = 0.0; unsigned job0 = 0; };
   std::vector<OscHost> dm_osc;           // [cap] chan->shift with set_osc's phase continuity
   int dm_on = 0;                         // channels with a demodulator
+  int pcm_stride = 0;                    // bytes between two channels' PCM rows (default olen*8: stereo float32)
   double dm_blocktime = 0.02;
   hipEvent_t ev_bank[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // behind the slot's channel (+ noise) kernel
   hipEvent_t ev_tail[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // behind the slot's demodulator kernel
@@ -721,8 +722,8 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
     }
     DemodParams d{};
     d.in = bank_out(b, slot); d.power = b.power + so; d.n0 = b.n0 + so; d.chan = b.dm_chan; d.state = b.dm_state;
-    d.status = b.dm_status + so; d.pcm = b.dm_pcm + so * (size_t)(b.olen * 8); d.ch0 = 0; d.nch = n; d.olen = b.olen;
-    d.pcm_stride = b.olen * 8; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;      // Power_alpha, src/radio.c:72
+    d.status = b.dm_status + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = n; d.olen = b.olen;
+    d.pcm_stride = b.pcm_stride; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;      // Power_alpha, src/radio.c:72
     mark(in, ts, 6, true);
     launch_demod(ts, d, IN_E0(in), IN_E1(in));
     mark(in, ts, 6, false);
@@ -1068,9 +1069,12 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
   if (b.out_real) return fail(-1, "the linear demodulator follows COMPLEX-output channels");
   if (!b.power || !b.n0 || b.noise_samprate <= 0.0)
     return fail(-1, "the demodulator needs the channel's bb_power and noise estimate: call chz_bank_set_tuning and chz_bank_enable_noise first");
+  if (!b.pcm_stride) b.pcm_stride = b.olen * 8;
   for (int i = 0; i < n; i++) {
     const chz_demod_params& q = p[i];
     if (q.channels < 0 || q.channels > 2 || q.encoding < CHZ_PCM_S16BE || q.encoding > CHZ_PCM_F32BE) return fail(-1, "bad demodulator parameters for channel %d", ch0 + i);
+    if (q.channels * b.olen * ((q.encoding == CHZ_PCM_S16BE || q.encoding == CHZ_PCM_S16LE) ? 2 : 4) > b.pcm_stride)
+      return fail(-1, "channel %d's PCM does not fit the bank's %d-byte rows (chz_bank_set_pcm_stride)", ch0 + i, b.pcm_stride);
     if (q.channels > 0 && !(q.samprate > 0 && q.headroom > 0 && q.bandwidth > 0 && std::isfinite(q.shift) && q.gain > 0))
       return fail(-1, "bad demodulator parameters for channel %d", ch0 + i);
   }
@@ -1082,7 +1086,7 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
     HIPOK(hipMalloc((void**)&b.dm_chan, sizeof(DemodChan) * cap)); HIPOK(hipMemset(b.dm_chan, 0, sizeof(DemodChan) * cap));
     HIPOK(hipMalloc((void**)&b.dm_state, sizeof(DemodState) * cap)); HIPOK(hipMemset(b.dm_state, 0, sizeof(DemodState) * cap));
     HIPOK(hipMalloc((void**)&b.dm_status, sizeof(DemodStatus) * cap * CHZ_ND)); HIPOK(hipMemset(b.dm_status, 0, sizeof(DemodStatus) * cap * CHZ_ND));
-    HIPOK(hipMalloc((void**)&b.dm_pcm, (size_t)b.olen * 8 * cap * CHZ_ND)); HIPOK(hipMemset(b.dm_pcm, 0, (size_t)b.olen * 8 * cap * CHZ_ND));
+    HIPOK(hipMalloc((void**)&b.dm_pcm, (size_t)b.pcm_stride * cap * CHZ_ND)); HIPOK(hipMemset(b.dm_pcm, 0, (size_t)b.pcm_stride * cap * CHZ_ND));
     for (int s = 0; s < CHZ_ND; s++) {
       HIPOK(hipEventCreateWithFlags(&b.ev_bank[s], hipEventDisableTiming));
       HIPOK(hipEventCreateWithFlags(&b.ev_tail[s], hipEventDisableTiming));
@@ -1132,7 +1136,18 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
 }
 int chz_bank_pcm_stride(chz_engine* e, int bank) {
   BANK_CHECK(e, bank, 0, 0);
-  return e->banks[(size_t)bank].olen * 8;
+  const Bank& b = e->banks[(size_t)bank];
+  return b.pcm_stride ? b.pcm_stride : b.olen * 8;
+}
+// rows of exactly the size the bank's encodings need (480 B for 12 kHz mono S16) make the device-to-host copy of a block's
+// PCM one contiguous transfer of only the bytes that matter; before the first chz_bank_set_demod
+int chz_bank_set_pcm_stride(chz_engine* e, int bank, int bytes) {
+  BANK_CHECK(e, bank, 0, 0);
+  Bank& b = e->banks[(size_t)bank];
+  if (b.dm_chan) return fail(-1, "the PCM row size is fixed once demodulators exist");
+  if (bytes < 2 * b.olen || bytes > 8 * b.olen || (bytes & 3)) return fail(-1, "PCM rows hold %d..%d bytes, a multiple of 4", 2 * b.olen, 8 * b.olen);
+  b.pcm_stride = bytes;
+  return 0;
 }
 static int read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm, chz_demod_status* status, bool wait) {
   BANK_CHECK(e, bank, ch0, n);
@@ -1140,7 +1155,7 @@ static int read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm
   Bank& b = e->banks[(size_t)bank];
   if (!b.dm_chan) return fail(-1, "bank has no demodulator: call chz_bank_set_demod first");
   static_assert(sizeof(chz_demod_status) == sizeof(DemodStatus), "status layouts must agree");
-  const size_t so = (size_t)slot * b.cap + ch0, stride = (size_t)b.olen * 8;
+  const size_t so = (size_t)slot * b.cap + ch0, stride = (size_t)b.pcm_stride;
   if (pcm) HIPOK(hipMemcpyAsync(pcm, b.dm_pcm + so * stride, stride * (size_t)n, hipMemcpyDeviceToHost, e->tail));
   if (status) HIPOK(hipMemcpyAsync(status, b.dm_status + so, sizeof(DemodStatus) * (size_t)n, hipMemcpyDeviceToHost, e->tail));
   if (wait) HIPOK(hipStreamSynchronize(e->tail));

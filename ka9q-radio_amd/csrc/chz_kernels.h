@@ -1123,14 +1123,42 @@ __device__ __forceinline__ float demod_cabsf(float2 x) {
   return sqrtf(a + b);
 }
 
+// One WAVEFRONT per channel.  Lane l owns the SEG = ceil(N/64) consecutive samples [l*SEG, (l+1)*SEG): its loads are
+// one contiguous run, a wavefront reads the channel's whole row as full cache lines and writes its PCM the same way.
+//   * 2 ms AGC slices: per-sample energies go through LDS and lane s adds up slice s in the reference's own order;
+//   * the gain ramp gain *= gain_change (src/linear.c:253,271,...) starts in lane l at gain * gain_change^(l*SEG) (one pow per
+//     lane) and is then multiplied along as the reference does; the block's final gain is the last lane's;
+//   * the carrier-removal filter am_dc += alpha (s - am_dc) (src/linear.c:257-260) is a first-order linear recurrence: each
+//     lane reduces its samples to an affine map, a wavefront scan composes the maps, and the lane replays its samples from
+//     the right starting value;
+//   * output power: per-lane sums, then a butterfly over the wavefront.
+// Against the restatement's strictly sequential loops these reorderings differ by a few ulp of a DOUBLE (1e-15 relative),
+// far below the float / int16 the samples are rounded to; everything decision-making (AGC branches, squelch sequencer,
+// packing) is the reference's statement for statement.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(v, d); v = o > v ? o : v; }
+  return v;
+}
+
 __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
-  const int lc = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  HIP_DYNAMIC_SHARED(double, esh)                          // [N] per-sample energies (AGC slices)
+  const int lane = (int)threadIdx.x;
+  const int lc = (int)blockIdx.x;
   if (lc >= p.nch) return;
   const int ch = p.ch0 + lc;
   const DemodChan c = p.chan[ch];
   if (!c.on) return;
   DemodState st = p.state[ch];
   const int N = p.olen;
+  const int SEG = (N + 63) >> 6;
+  const int n0 = lane * SEG;                               // first sample of this lane
+  const int cnt = n0 >= N ? 0 : (N - n0 < SEG ? N - n0 : SEG);
   const float2* __restrict__ x = p.in + (size_t)ch * N;
   unsigned char* __restrict__ o = p.pcm + (size_t)ch * p.pcm_stride;
   const double bb_power = p.power[ch];
@@ -1138,45 +1166,46 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   const double est = p.n0[ch];
   if (st.n0 != st.n0) st.n0 = est;
   else { const double diff = est - st.n0; st.n0 += p.power_alpha * diff; }
-  // chan->shift (src/linear.c:168-172): phasor at sample 0 of this block from the closed form, then stepped in double
+  // chan->shift (src/linear.c:168-172): this lane's phasor at its first sample from the closed form, then stepped in double
   const bool rot = c.osc_freq != 0.0;
   double c0 = 1.0, s0 = 0.0, c1 = 1.0, s1 = 0.0;
   if (rot) {
-    const double g = (double)(p.job - c.osc_job0) * (double)N;
+    const double g = (double)(p.job - c.osc_job0) * (double)N + (double)n0;
     double hi = g * c.osc_freq, lo = fma(g, c.osc_freq, -hi);
     hi -= rint(hi);
     sincospi(2.0 * (c.osc_phase0 + hi + lo), &s0, &c0);
     sincospi(2.0 * c.osc_freq, &s1, &c1);
   }
-  auto sample = [&](int n, double cr, double sr) -> float2 {         // buffer[n] *= step_osc(): product rounded to float complex
-    float2 v = x[n];
-    if (rot) { const double xr = v.x, xi = v.y; v = make_float2((float)(xr * cr - xi * sr), (float)(xr * sr + xi * cr)); }
-    return v;
-  };
   // ---- AGC (src/linear.c:177-234)
   double gain_change = 1.0;
   if (c.agc) {
     const double bn = sqrt(c.bandwidth * st.n0);
     const double ampl = sqrt(bb_power);
-    double peak_level = 0.0;
     int sps = (int)rint(N * .002 / p.blocktime);
     sps = sps < 1 ? 1 : sps;
     {
       double cr = c0, sr = s0;
-      int n = 0;
-      while (n + sps < N) {
-        double energy = 0.0;
-        for (int i = 0; i < sps; i++) {
-          const float2 v = sample(n, cr, sr); n++;
-          if (rot) { const double nc = cr * c1 - sr * s1; sr = cr * s1 + sr * c1; cr = nc; }
-          float a = v.x * v.x, b = v.y * v.y;
-          CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
-          energy += (double)(a + b);                                  // cnrmf
+      for (int i = 0; i < cnt; i++) {
+        float2 v = x[n0 + i];
+        if (rot) {
+          const double xr = v.x, xi = v.y;
+          v = make_float2((float)(xr * cr - xi * sr), (float)(xr * sr + xi * cr));
+          const double nc = cr * c1 - sr * s1; sr = cr * s1 + sr * c1; cr = nc;
         }
-        if (energy > peak_level) peak_level = energy;
+        float a = v.x * v.x, b = v.y * v.y;
+        CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
+        esh[n0 + i] = (double)(a + b);                                // cnrmf
       }
-      peak_level = sqrt(peak_level / sps);
     }
+    CHZ_WAVE_SYNC();
+    // slices [k*sps, (k+1)*sps) with (k+1)*sps < N (src/linear.c:199: `while (n + samples_per_slice < N)`), summed in order
+    double peak = 0.0;
+    for (int k = lane; (k + 1) * sps < N; k += 64) {
+      double energy = 0.0;
+      for (int i = 0; i < sps; i++) energy += esh[k * sps + i];
+      if (energy > peak) peak = energy;
+    }
+    double peak_level = sqrt(wave_max(peak) / sps);
     if (peak_level * st.gain > M_SQRT2 * c.headroom) {
       st.gain = M_SQRT2 * c.headroom / peak_level;
       gain_change = 1.0;
@@ -1194,56 +1223,94 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
       gain_change = pow(c.recovery_rate, 1.0 / c.samprate);
     }
   }
-  // ---- squelch decision first (it depends on nothing the final pass produces except output_power == 0, handled below):
-  // the sequencer state is advanced exactly as src/linear.c:313-352 does, AFTER the final pass in program order there,
-  // but the two do not interact, and knowing the frame type up front saves packing PCM nobody will send.
+  // ---- squelch sequencer (src/linear.c:313-352).  It is advanced AFTER the final pass in the reference's program order, but
+  // the two do not interact, and knowing the frame type up front saves packing PCM nobody will send.
   double snr = __builtin_huge_val();
   if (c.snr_squelch) snr = (bb_power / (st.n0 * c.bandwidth)) - 1.0;
   const int smax = c.squelch_tail + 4;
   if (!c.snr_squelch || snr >= c.squelch_open) st.squelch_state = smax;
   else if (st.squelch_state > 0 && snr < c.squelch_close) st.squelch_state--;
   const bool data = st.squelch_state >= 4;
-  // ---- final pass (src/linear.c:236-311); the gain ramp runs whether or not the frame is sent
-  double output_power = 0.0;
+  // ---- final pass (src/linear.c:236-311); the gain ramp and the carrier filter run whether or not the frame is sent
+  const double k_env = M_SQRT1_2;
+  double gain = st.gain;
+  if (gain_change != 1.0 && n0 > 0) gain *= pow(gain_change, (double)(n0 < N ? n0 : N));
+  // pass A (envelope modes with carrier removal only): this lane's samples as an affine map of the incoming filter state
+  const bool dcfilt = c.env && c.dc_alpha != 0;
+  double am_in = st.am_dc;
+  if (dcfilt) {
+    double A = 1.0, B = 0.0;                               // am_dc_out = A * am_dc_in + B over this lane's samples
+    {
+      double g = gain, cr = c0, sr = s0;
+      for (int i = 0; i < cnt; i++) {
+        float2 v = x[n0 + i];
+        if (rot) {
+          const double xr = v.x, xi = v.y;
+          v = make_float2((float)(xr * cr - xi * sr), (float)(xr * sr + xi * cr));
+          const double nc = cr * c1 - sr * s1; sr = cr * s1 + sr * c1; cr = nc;
+        }
+        const double s = g * k_env * (double)demod_cabsf(v);
+        g *= gain_change;
+        A *= (1.0 - c.dc_alpha); B = (1.0 - c.dc_alpha) * B + c.dc_alpha * s;
+      }
+    }
+    // inclusive scan of the maps over the lanes (composition: later o earlier), then shift by one lane
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double Ap = __shfl_up(A, d), Bp = __shfl_up(B, d);
+      if (lane >= d) { B = A * Bp + B; A = A * Ap; }
+    }
+    const double Ae = __shfl_up(A, 1), Be = __shfl_up(B, 1);
+    am_in = lane == 0 ? st.am_dc : Ae * st.am_dc + Be;
+    // the state after the block is the last lane's composition applied to the old state
+    st.am_dc = __shfl(A, 63) * st.am_dc + __shfl(B, 63);
+  }
+  double part = 0.0;
   {
-    double gain = st.gain, cr = c0, sr = s0;
-    double am_dc = st.am_dc;
+    double cr = c0, sr = s0, am_dc = am_in;
     const int enc = c.encoding;
-    for (int n = 0; n < N; n++) {
-      const float2 v = sample(n, cr, sr);
-      if (rot) { const double nc = cr * c1 - sr * s1; sr = cr * s1 + sr * c1; cr = nc; }
+    for (int i = 0; i < cnt; i++) {
+      const int n = n0 + i;
+      float2 v = x[n];
+      if (rot) {
+        const double xr = v.x, xi = v.y;
+        v = make_float2((float)(xr * cr - xi * sr), (float)(xr * sr + xi * cr));
+        const double nc = cr * c1 - sr * s1; sr = cr * s1 + sr * c1; cr = nc;
+      }
       if (c.channels == 1) {
         double s;
         if (c.env) {
-          s = gain * M_SQRT1_2 * (double)demod_cabsf(v);
+          s = gain * k_env * (double)demod_cabsf(v);
           gain *= gain_change;
-          output_power += s * s;
-          if (c.dc_alpha != 0) { am_dc += c.dc_alpha * (s - am_dc); s -= am_dc; }
+          part += s * s;
+          if (dcfilt) { am_dc += c.dc_alpha * (s - am_dc); s -= am_dc; }
         } else {
           s = gain * (double)v.x;
           gain *= gain_change;
-          output_power += s * s;
+          part += s * s;
         }
         if (data) demod_put(o, enc, n, (float)s);
       } else {
         double a, b;
         if (c.env) {
-          const double k = gain * M_SQRT1_2;
+          const double k = gain * k_env;
           a = k * (double)v.x; b = k * (double)demod_cabsf(v);
           gain *= gain_change;
-          output_power += a * a + b * b;
-          if (c.dc_alpha != 0) { am_dc += c.dc_alpha * (b - am_dc); b -= am_dc; }
+          part += a * a + b * b;
+          if (dcfilt) { am_dc += c.dc_alpha * (b - am_dc); b -= am_dc; }
         } else {
           a = gain * (double)v.x; b = gain * (double)v.y;
           gain *= gain_change;
-          output_power += a * a + b * b;
+          part += a * a + b * b;
         }
         if (data) { demod_put(o, enc, 2 * n, (float)a); demod_put(o, enc, 2 * n + 1, (float)b); }
       }
     }
-    st.gain = gain; st.am_dc = am_dc;
   }
-  output_power /= N;
+  // the block's final gain is what the lane holding the last sample ends with
+  const int last_lane = (N - 1) / SEG;
+  st.gain = __shfl(gain, last_lane);
+  double output_power = wave_sum(part) / N;
   if (c.channels == 1) output_power *= 2;
   DemodStatus r;
   r.pad = 0; r.gain = st.gain; r.n0 = st.n0; r.snr = snr; r.squelch_state = st.squelch_state;
@@ -1259,8 +1326,7 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
     r.frame = 0;
     r.mute = (output_power == 0 || !st.squelch_open || !c.tuned);
   }
-  p.status[ch] = r;
-  p.state[ch] = st;
+  if (lane == 0) { p.status[ch] = r; p.state[ch] = st; }
 }
 
 // ------------------------------------------------------------------------------

@@ -80,7 +80,7 @@ inline NotchTables notch_tables(const int* bins, int n, const SpecLayout& lay) {
 }
 inline int launch_demod(hipStream_t s, const DemodParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   if (p.nch <= 0) return 0;
-  CHZ_LAUNCH(demod_linear_tail, (p.nch + 63) / 64, 64, 0, s, e0, e1, p);
+  CHZ_LAUNCH(demod_linear_tail, p.nch, 64, sizeof(double) * (size_t)p.olen, s, e0, e1, p);     // one wavefront per channel
   return 0;
 }
 inline int launch_noise(int nch, hipStream_t s, const NoiseParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {

@@ -59,7 +59,7 @@ SYMBOLS = [
     "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
     "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real", "chz_bank_set_isb", "chz_bank_set_beam",
     "chz_set_notches_alpha", "chz_slot_sync", "chz_engine_check",
-    "chz_bank_set_demod", "chz_bank_pcm_stride", "chz_bank_read_pcm", "chz_bank_read_pcm_async",
+    "chz_bank_set_demod", "chz_bank_pcm_stride", "chz_bank_set_pcm_stride", "chz_bank_read_pcm", "chz_bank_read_pcm_async",
     "chz_comm_unique_id", "chz_comm_create", "chz_comm_create_file", "chz_comm_destroy", "chz_comm_rank", "chz_comm_world",
     "chz_mini_create", "chz_mini_destroy", "chz_mini_capacity", "chz_mini_add", "chz_mini_release", "chz_mini_set_response", "chz_mini_execute",
     "chz_comm_barrier", "chz_comm_allreduce_max", "chz_spectrum_broadcast", "chz_spectrum_exchange_rows", "chz_run_blocks_sharded",
@@ -96,6 +96,7 @@ def lib():
         L.chz_engine_check.argtypes = [_vp]
         L.chz_bank_set_demod.argtypes = [_vp, _i, _u, _i, _i, _vp, _d]
         L.chz_bank_pcm_stride.argtypes = [_vp, _i]
+        L.chz_bank_set_pcm_stride.argtypes = [_vp, _i, _i]
         L.chz_bank_read_pcm.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp]
         L.chz_bank_read_pcm_async.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp]
         L.chz_mini_create.argtypes = [C.POINTER(_vp), _i, _i, _i, _i]
@@ -360,6 +361,9 @@ class Bank:
         """demod_linear()'s per-block work (src/linear.c) for channels ch0.. from block `job`; params: list of DemodParams."""
         arr = (DemodParams * len(params))(*params)
         _check(lib().chz_bank_set_demod(self.eng._h, self.id, job & 0xFFFFFFFF, ch0, len(params), arr, float(blocktime)))
+
+    def set_pcm_stride(self, nbytes):
+        _check(lib().chz_bank_set_pcm_stride(self.eng._h, self.id, int(nbytes)))
 
     def read_pcm(self, slot, ch0=0, n=None):
         """(pcm uint8[n][stride], status DemodStatus[n]) of the block last demodulated on `slot`."""

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """C_rt with PCIe in the loop: like crt_probe.py, but every block also takes its L new samples from pinned host memory
 (10.4 MB H2D) and returns EVERY channel's olen output samples to pinned host memory (1920 B per 12 kHz channel) before
-it counts as done.  The host link, not HBM, sets this figure (~6.5e5 channels at 63 GB/s)."""
+it counts as done.  The host link, not HBM, sets this figure (~6.5e5 channels at 63 GB/s).
+CRT_DEMOD=1: every channel carries the linear demodulator (fine tuning, noise estimate, AGC, mono S16BE) and
+what goes back is its packed PCM + status (480 + 48 B per channel and block) instead of the complex baseband."""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -29,6 +31,21 @@ shifts = np.array([p[0] for p in plan], np.int32)
 for c0 in range(0, cap, tile):
     bank.set_responses(c0, resp); bank.set_shifts(c0, shifts + (c0 // tile) % 7)
 eng.set_notches([0], 0.01)
+DEMOD = os.environ.get("CRT_DEMOD") == "1"
+if DEMOD:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import oracle_lib as ol
+    lib.chz_bank_read_pcm_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    for c0 in range(0, cap, tile):
+        bank.set_tuning(0, c0, shifts + (c0 // tile) % 7, np.full(tile, -3.3 / 12000.0))
+    bank.enable_noise(129.6e6)
+    bank.set_pcm_stride(2 * olen)            # mono S16: 480 B per channel and block, contiguous
+    q = ol.lin_params()
+    one = pkg.engine.DemodParams(*[getattr(q, f) for f, _ in ol.LinParams._fields_])
+    for c0 in range(0, cap, 65536):
+        bank.set_demod(0, c0, [one] * min(65536, cap - c0), 0.02)
+    hst = C.c_void_p()
+    assert lib.chz_host_alloc(C.byref(hst), 48 * cap) == 0
 import time
 
 def measure(n):
@@ -38,7 +55,10 @@ def measure(n):
         t0 = time.perf_counter()
         assert lib.chz_input_write(eng._h, hin, L) == 0              # H2D of the block's new samples (pinned source)
         assert lib.chz_step(eng._h, j) == 0
-        assert lib.chz_bank_read_async(eng._h, bank.id, j % 4, 0, n, hout) == 0
+        if DEMOD:
+            assert lib.chz_bank_read_pcm_async(eng._h, bank.id, j % 4, 0, n, hout, hst) == 0
+        else:
+            assert lib.chz_bank_read_async(eng._h, bank.id, j % 4, 0, n, hout) == 0
         eng.sync()
         dt = (time.perf_counter() - t0) * 1e3
         if j >= 4:

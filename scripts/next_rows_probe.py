@@ -17,7 +17,8 @@ shifts = (25000 + np.arange(nch) * 1500).astype(np.int32)
 freq = rng.uniform(-20, 20, nch) / 12000.0
 resp = np.ones((nch, 300), np.complex64) / 300
 res = {}
-for tuned, i16, noise in ((False, False, False), (True, False, False), (False, True, False), (False, False, True), (True, True, True)):
+for tuned, i16, noise, demod in ((False, False, False, False), (True, False, False, False), (False, True, False, False), (False, False, True, False),
+                                 (True, True, True, False), (True, False, True, True), (True, True, True, True)):
     if True:
         eng = pkg.engine.Engine(L, M, pkg.engine.REAL, ring_blocks=8)
         if i16:
@@ -32,15 +33,21 @@ for tuned, i16, noise in ((False, False, False), (True, False, False), (False, T
             b.set_shifts(0, shifts)
         if noise:
             b.enable_noise(129.6e6)
+        if demod:      # rank 4: usb-like mono S16BE demodulators with AGC behind every channel
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+            import oracle_lib as ol
+            q = ol.lin_params()
+            b.set_demod(0, 0, [pkg.engine.DemodParams(*[getattr(q, f) for f, _ in ol.LinParams._fields_])] * nch, 0.02)
         eng.set_notches([0], 0.01)
         eng.run_blocks(0, 160)
         t = eng.run_blocks(160, 1600)
         eng.run_blocks(0, 200, instrument=True)
         it = eng.run_blocks(0, 200, instrument=True)
-        key = "tuned=%d int16=%d noise=%d" % (tuned, i16, noise)
+        key = "tuned=%d int16=%d noise=%d demod=%d" % (tuned, i16, noise, demod)
         res[key] = {"us_per_block": t.total_ms / 1600 * 1e3, "first_us": it.first_ms / it.first_n * 1e3, "cols_us": it.cols_ms / it.cols_n * 1e3,
                     "rows_us": it.rows_ms / it.rows_n * 1e3, "chan_us": it.chan_ms / it.chan_n * 1e3,
-                    "noise_us": (it.notch_ms / it.notch_n * 1e3) if it.notch_n else None}
+                    "noise_us": (it.notch_ms / it.notch_n * 1e3) if it.notch_n else None,
+                    "demod_us": (it.demod_ms / it.demod_n * 1e3) if it.demod_n else None}
         print(key, json.dumps(res[key]))
         eng.close()
 print(json.dumps(res))

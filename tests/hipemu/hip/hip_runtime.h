@@ -184,6 +184,11 @@ template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) 
   int s = lane + (int)d; if (s > 63) s = lane;
   return hipemu_shfl_idx(v, s);
 }
+template <class T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+  int lane = hipemu_linear_tid() & 63; (void)width;
+  int s = lane - (int)d; if (s < 0) s = lane;
+  return hipemu_shfl_idx(v, s);
+}
 static inline unsigned long long __ballot(int pred) {
   hipemu::State& s = hipemu::st();
   unsigned me = hipemu_linear_tid();
