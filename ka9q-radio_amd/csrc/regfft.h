@@ -121,16 +121,53 @@ template <int SIGN> CHZ_DEV void bfly5(float2& x0, float2& x1, float2& x2, float
   x2 = cadd(m2, r2); x3 = csub(m2, r2);
 }
 
-// smallest supported base radix of R (4 preferred over 2)
+// Odd prime lengths above 5 (7, 11, 13, 19 ...: the Airspy HF+'s N = 36,480 = 2^7*3*5*19, docs/FFTW3.md:52) by
+// definition, folded once: X[k] = x0 + sum_{n=1}^{(P-1)/2} [ (x_n + x_{P-n}) cos(2 pi n k / P) + SIGN i (x_n - x_{P-n}) sin(2 pi n k / P) ],
+// with X[P-k] sharing both sums.  (P-1)^2/2 real multiply-adds per component, all coefficients literals.
+template <int P, int SIGN, int ST> CHZ_DEV void bfly_prime(float2* v) {
+  constexpr int H = (P - 1) / 2;
+  float2 sp[H], sm[H];
+  static_for<H>([&](auto n) {
+    constexpr int N = decltype(n)::value + 1;
+    sp[N - 1] = cadd(v[N * ST], v[(P - N) * ST]);
+    sm[N - 1] = csub(v[N * ST], v[(P - N) * ST]);
+  });
+  const float2 x0 = v[0];
+  float2 acc0 = x0;
+  static_for<H>([&](auto n) { constexpr int N = decltype(n)::value; acc0 = cadd(acc0, sp[N]); });
+  v[0] = acc0;
+  static_for<H>([&](auto k) {
+    constexpr int K = decltype(k)::value + 1;
+    float2 a = x0, b = make_float2(0.f, 0.f);
+    static_for<H>([&](auto n) {
+      constexpr int N = decltype(n)::value + 1;
+      constexpr float c = static_cast<float>(Root<(N * K) % P, P>::v.c);
+      constexpr float sn = static_cast<float>(Root<(N * K) % P, P>::v.s);
+      a = make_float2(fmaf(c, sp[N - 1].x, a.x), fmaf(c, sp[N - 1].y, a.y));
+      b = make_float2(fmaf(sn, sm[N - 1].x, b.x), fmaf(sn, sm[N - 1].y, b.y));
+    });
+    const float2 r = mul_si<SIGN>(b);         // SIGN * i * b
+    v[K * ST] = cadd(a, r);
+    v[(P - K) * ST] = csub(a, r);
+  });
+}
+
+constexpr bool is_small_prime(int r) { return r == 7 || r == 11 || r == 13 || r == 17 || r == 19; }
+// smallest supported base radix of R (4 preferred over 2); an odd prime factor above 5 is taken whole
 constexpr int base_radix(int r) {
-  return (r % 4 == 0) ? 4 : (r % 2 == 0) ? 2 : (r % 3 == 0) ? 3 : (r % 5 == 0) ? 5 : 0;
+  if (r % 4 == 0) return 4;
+  if (r % 2 == 0) return 2;
+  if (r % 3 == 0) return 3;
+  if (r % 5 == 0) return 5;
+  for (int p : {7, 11, 13, 17, 19}) if (r % p == 0) return p;
+  return 0;
 }
 
 // ---- recursive Cooley-Tukey, natural order in and out ----------------------------
 // v points at element 0; logical element i lives at v[i*ST].
 template <int R, int SIGN> struct RegDFT {
   static constexpr int A = base_radix(R);
-  static_assert(R == 1 || A != 0, "RegDFT: length must be 2,3,5-smooth");
+  static_assert(R == 1 || A != 0, "RegDFT: prime factors 2, 3, 5 and one of 7..19 only");
   static constexpr int B = (R == 1) ? 1 : R / (A == 0 ? 1 : A);
 
   template <int ST = 1> static CHZ_DEV void run(float2* v) {
@@ -139,6 +176,7 @@ template <int R, int SIGN> struct RegDFT {
     else if constexpr (R == 3) { bfly3<SIGN>(v[0], v[ST], v[2 * ST]); }
     else if constexpr (R == 4) { bfly4<SIGN>(v[0], v[ST], v[2 * ST], v[3 * ST]); }
     else if constexpr (R == 5) { bfly5<SIGN>(v[0], v[ST], v[2 * ST], v[3 * ST], v[4 * ST]); }
+    else if constexpr (is_small_prime(R)) { bfly_prime<R, SIGN, ST>(v); }
     else {
       // x[n], n = A*m + n1.  (1) B-point DFT over m for each residue n1.
       static_for<A>([&](auto n1) {

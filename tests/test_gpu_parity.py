@@ -72,6 +72,8 @@ def check_channel(got, want, floor=0.0):
     (11520, 2881, ol.COMPLEX, "16x25x36"),
     (1296000, 324001, ol.REAL, ""),           # config 2: N = 1,620,000
     (2592000, 648001, ol.REAL, ""),           # config 3: N = 3,240,000
+    (400000, 100001, ol.REAL, ""),            # Airspy R2, rof500000 (docs/FFTW3.md:52,60)
+    (18240, 18241, ol.COMPLEX, ""),           # Airspy HF+, cof36480 = 2^7*3*5*19 (docs/FFTW3.md:52,62): needs the radix-19 butterfly
 ])
 def test_forward_matches_oracle(pkg, L, M, in_type, plan):
     rng = np.random.default_rng(L + in_type)

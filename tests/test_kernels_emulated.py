@@ -57,6 +57,7 @@ def rel(a, b):
     (14400, ol.REAL, b"16x25x36", 0), (14400, ol.REAL, b"", 602), (32400, ol.REAL, b"", 0),
     (32400, ol.REAL, b"81x400", 0), (32400, ol.REAL, b"225x144", 100), (14400, ol.REAL, b"36x400", 15002),
     (14400, ol.COMPLEX, b"", 0), (14400, ol.COMPLEX, b"16x25x36", 3000), (60000, ol.COMPLEX, b"", 0),
+    (36480, ol.COMPLEX, b"", 0), (36480, ol.COMPLEX, b"152x240", 20000),
     (162000, ol.REAL, b"", 0), (64800, ol.REAL, b"72x25x36", 65000),
     (86400, ol.REAL, b"135x640"[:0] + b"45x16x120", 0), (162000, ol.REAL, b"81x2000"[:0] + b"45x25x144", 1024), (57600, ol.REAL, b"25x16x144", 0),
 ])
