@@ -10,6 +10,7 @@ import os
 import re
 import struct
 import subprocess
+import sys
 import tempfile
 
 import numpy as np
@@ -282,3 +283,57 @@ def test_dropin_channels_retuning_every_block():
     with tempfile.TemporaryDirectory() as tmp:
         out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x, env={"HARNESS_RETUNE_MOD": "5"})
     _check(L, M, olen, P, plan, nblocks, out, spec, meta, x, retune_mod=5)
+
+
+_FAKE_FFTW = r"""
+#include <stdlib.h>
+/* the four FFTW entry points filter.h's plan_* helpers forward to (src/filter.c:1145-1190); a plan is a tagged record */
+struct fake_plan { int kind, n, dir; unsigned flags; void *in, *out; };
+static int Destroyed;
+static struct fake_plan *mk(int kind, int n, void *in, void *out, int dir, unsigned flags) {
+  struct fake_plan *p = malloc(sizeof *p); p->kind = kind; p->n = n; p->in = in; p->out = out; p->dir = dir; p->flags = flags; return p; }
+void *fftwf_plan_dft_1d(int n, void *in, void *out, int dir, unsigned flags) { return mk(1, n, in, out, dir, flags); }
+void *fftwf_plan_dft_r2c_1d(int n, void *in, void *out, unsigned flags) { return mk(2, n, in, out, 0, flags); }
+void *fftwf_plan_dft_c2r_1d(int n, void *in, void *out, unsigned flags) { return mk(3, n, in, out, 0, flags); }
+void fftwf_destroy_plan(void *p) { Destroyed++; free(p); }
+int fake_destroyed(void) { return Destroyed; }
+"""
+
+_PLAN_SCRIPT = r"""
+import ctypes as C, sys
+fake = C.CDLL(sys.argv[1], mode=C.RTLD_GLOBAL) if sys.argv[1] != "-" else None
+lib = C.CDLL(sys.argv[2])
+class P(C.Structure):
+    _fields_ = [("kind", C.c_int), ("n", C.c_int), ("dir", C.c_int), ("flags", C.c_uint), ("inp", C.c_void_p), ("out", C.c_void_p)]
+for f in (lib.plan_complex, lib.plan_r2c, lib.plan_c2r):
+    f.restype = C.c_void_p
+a = (C.c_float * 64)(); b = (C.c_float * 64)()
+pc = lib.plan_complex(16, a, b, -1); pr = lib.plan_r2c(32, a, b); pi = lib.plan_c2r(32, b, a)
+if fake is None:
+    assert pc is None and pr is None and pi is None          # no FFTW in the link: NULL, never a silent substitute
+    print("null-ok")
+else:
+    got = [C.cast(p, C.POINTER(P)).contents for p in (pc, pr, pi)]
+    assert [(g.kind, g.n) for g in got] == [(1, 16), (2, 32), (3, 32)] and got[0].dir == -1
+    assert got[0].inp == C.addressof(a) and got[0].out == C.addressof(b) and got[2].inp == C.addressof(b)
+    h = C.c_void_p(pc)
+    lib.destroy_plan(C.byref(h))
+    assert h.value is None and fake.fake_destroyed() == 1    # destroy_plan() clears the caller's handle (src/filter.c:1184-1190)
+    print("forward-ok")
+"""
+
+
+def test_plan_helpers_forward_to_fftw_when_the_link_has_it(tmp_path):
+    # spectrum.c plans its own analysis FFTs through plan_complex / plan_r2c / plan_c2r / destroy_plan (src/spectrum.c:198,265;
+    # src/filter.c:1145-1190).  The drop-in forwards them to whatever FFTW the final link provides (radiod links -lfftw3f) through
+    # weak symbols and returns NULL without one.  No GPU involved.
+    _build_lib()
+    src = tmp_path / "fake_fftw.c"; src.write_text(_FAKE_FFTW)
+    so = tmp_path / "libfake_fftw3f.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    script = tmp_path / "plans.py"; script.write_text(_PLAN_SCRIPT)
+    drop = os.path.join(PKG, "libka9q_filter_hip.so")
+    r = subprocess.run([sys.executable, str(script), str(so), drop], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "forward-ok" in r.stdout, r.stderr[-1500:]
+    r = subprocess.run([sys.executable, str(script), "-", drop], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "null-ok" in r.stdout, r.stderr[-1500:]
