@@ -253,7 +253,9 @@ typedef struct chz_demod_params {
   int snr_squelch;      /* chan->squelch.snr_enable */
   int squelch_tail;     /* chan->squelch.tail */
   int tuned;            /* chan->tune.freq != 0 */
-  int pad;
+  int kind;             /* CHZ_DEMOD_LINEAR (demod_linear, src/linear.c) or CHZ_DEMOD_FM (demod_fm, src/fm.c:19-345 without the PLL
+                           and PL-tone branches: both SNR estimators, squelch sequencer, discriminator with threshold extension,
+                           offset / deviation statistics, PM carrier removal and de-emphasis, gain) */
   double samprate;      /* chan->output.samprate */
   double headroom;      /* chan->output.headroom */
   double threshold, recovery_rate, hangtime, dc_alpha;   /* chan->linear.* */
@@ -261,7 +263,11 @@ typedef struct chz_demod_params {
   double shift;         /* chan->tune.shift, Hz */
   double squelch_open, squelch_close;                     /* chan->squelch.open / .close, power ratios */
   double gain;          /* chan->output.gain when the demodulator starts (the AGC owns it afterwards) */
+  double deemph_rate, deemph_gain;   /* FM: chan->fm.rate (0 = flat FM), chan->fm.gain */
+  double threshold_extend;           /* FM: chan->fm.threshold, 0 or 1 */
 } chz_demod_params;
+#define CHZ_DEMOD_LINEAR 0
+#define CHZ_DEMOD_FM 1
 typedef struct chz_demod_status {
   int frame;            /* 0: PCM present (send_output(chan, samples, N, mute)); 1: no samples (send_output(chan, NULL, N, mute)) */
   int mute;
@@ -269,7 +275,9 @@ typedef struct chz_demod_status {
   double output_power;  /* chan->output.power */
   double gain;          /* chan->output.gain after the block */
   double n0;            /* chan->sig.n0 (smoothed) */
-  double snr;
+  double snr;           /* linear: the SNR squelch's; FM: chan->fm.snr */
+  double foffset;       /* FM: chan->sig.foffset */
+  double pdeviation;    /* FM: chan->fm.pdeviation */
 } chz_demod_status;
 /* parameters of channels [ch0, ch0+n) from block `job` on (it must not have been enqueued yet); blocktime = radiod's Blocktime.
  * Waits for the demodulator stream only, never for the transform lanes. */

@@ -1077,6 +1077,8 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
       return fail(-1, "channel %d's PCM does not fit the bank's %d-byte rows (chz_bank_set_pcm_stride)", ch0 + i, b.pcm_stride);
     if (q.channels > 0 && !(q.samprate > 0 && q.headroom > 0 && q.bandwidth > 0 && std::isfinite(q.shift) && q.gain > 0))
       return fail(-1, "bad demodulator parameters for channel %d", ch0 + i);
+    if (q.kind != CHZ_DEMOD_LINEAR && q.kind != CHZ_DEMOD_FM) return fail(-1, "unknown demodulator kind for channel %d", ch0 + i);
+    if (q.channels > 1 && q.kind == CHZ_DEMOD_FM) return fail(-1, "the FM demodulator is mono (src/fm.c:37)");
   }
   HIPOK(hipSetDevice(e->device));
   if (!e->tail) HIPOK(hipStreamCreateWithFlags(&e->tail, hipStreamNonBlocking));
@@ -1108,6 +1110,7 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
     c.squelch_tail = q.squelch_tail; c.tuned = q.tuned != 0; c.on = 1;
     c.samprate = q.samprate; c.headroom = q.headroom; c.threshold = q.threshold; c.recovery_rate = q.recovery_rate; c.hangtime = q.hangtime;
     c.dc_alpha = q.dc_alpha; c.bandwidth = q.bandwidth; c.squelch_open = q.squelch_open; c.squelch_close = q.squelch_close;
+    c.kind = q.kind; c.deemph_rate = q.deemph_rate; c.deemph_gain = q.deemph_gain; c.threshold_extend = q.threshold_extend;
     // chan->shift: set_osc() keeps the phase when the frequency changes (src/osc.c:28-47); an oscillator at 0 Hz is not stepped (src/linear.c:170)
     Bank::OscHost& o = b.dm_osc[(size_t)(ch0 + i)];
     const double f = q.shift / q.samprate;
@@ -1123,8 +1126,8 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
       b.dm_on++;
       DemodState st; memset(&st, 0, sizeof st);
       st.gain = q.gain; st.am_dc = 0.0; st.n0 = std::nan(""); st.hangcount = 0;
-      st.squelch_state = !c.snr_squelch ? c.squelch_tail + 4 : 0;                     // src/linear.c:46
-      st.squelch_open = 1;                                                              // :47
+      st.squelch_state = c.kind == CHZ_DEMOD_FM ? 0 : (!c.snr_squelch ? c.squelch_tail + 4 : 0);   // src/fm.c:58, src/linear.c:46
+      st.squelch_open = 1;                                                              // src/linear.c:47
       init.push_back(st); init_ch.push_back(ch0 + i);
     }
   }

@@ -1086,10 +1086,12 @@ struct DemodChan {               // per channel, set by the host (names: the cha
   int channels, env, agc, encoding, snr_squelch, squelch_tail, tuned, on;
   double samprate, headroom, threshold, recovery_rate, hangtime, dc_alpha, bandwidth, squelch_open, squelch_close;
   double osc_phase0, osc_freq;   // chan->shift as a closed form in the block number: phase (cycles) at sample 0 of block osc_job0
-  unsigned osc_job0; int pad;
+  unsigned osc_job0; int kind;   // kind 0: linear demodulator (src/linear.c), 1: FM (src/fm.c)
+  double deemph_rate, deemph_gain, threshold_extend;      // FM: chan->fm.rate, chan->fm.gain, chan->fm.threshold
 };
-struct DemodState { double gain, am_dc, n0; int hangcount, squelch_state, squelch_open, pad; };
-struct DemodStatus { int frame, mute, squelch_state, pad; double output_power, gain, n0, snr; };   // frame 0 = PCM present, 1 = silence
+struct DemodState { double gain, am_dc, n0; int hangcount, squelch_state, squelch_open, pad;
+                    double pm_re, pm_im, deemph_state, foffset, pdeviation; };   // FM: phase_memory, de-emphasis state, chan->sig.foffset, chan->fm.pdeviation
+struct DemodStatus { int frame, mute, squelch_state, pad; double output_power, gain, n0, snr, foffset, pdeviation; };   // frame 0 = PCM present, 1 = silence
 struct DemodParams {
   const float2* in;          // [cap][olen] this slot's channel outputs (after fine tuning)
   const double* power;       // [cap] this slot's bb_power
@@ -1146,6 +1148,148 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(v, d); v = o < v ? o : v; }
+  return v;
+}
+// fm_snr() with its Bessel series (src/misc.c:414-468): amplitude mean^2/variance of a Rice process -> signal-to-noise ratio
+__device__ inline double fm_i0(double z) { double t = 0.25 * z * z, sum = 1 + t, term = t;
+  for (int k = 2; k < 40; k++) { term *= t / (double)(k * k); sum += term; if (term < 1e-12 * sum) break; } return sum; }
+__device__ inline double fm_i1(double z) { double t = 0.25 * z * z, term = 0.5 * t, sum = 1 + term;
+  for (int k = 2; k < 40; k++) { term *= t / (double)(k * (k + 1)); sum += term; if (term < 1e-12 * sum) break; } return 0.5 * z * sum; }
+__device__ inline double fm_xi(double thetasq) {
+  double t = (2 + thetasq) * fm_i0(0.25 * thetasq) + thetasq * fm_i1(0.25 * thetasq);
+  t *= t;
+  return 2 + thetasq - (0.125 * M_PI) * exp(-0.5 * thetasq) * t;
+}
+__device__ inline double fm_snr_dev(double r) {
+  if (r <= M_PI / (4 - M_PI)) return 0;
+  if (r > 100) return r;
+  double thetasq = r;
+  for (int i = 0; i < 10; i++) {
+    const double o = thetasq;
+    thetasq = fm_xi(thetasq) * (1 + r) - 2;
+    if (fabs(thetasq - o) <= 0.01) break;
+  }
+  return thetasq;
+}
+
+// demod_fm()'s per-block work (src/fm.c:19-345) without the PLL (:174-203) and PL-tone (:264-311) branches, one wavefront
+// per channel, lane l owning SEG consecutive samples.  esh[] is per-lane scratch: every lane reads only what it wrote.
+__device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodChan& c, DemodState st, int ch, int lane, double* esh) {
+  const int N = p.olen;
+  const int SEG = (N + 63) >> 6;
+  const int n0 = lane * SEG;
+  const int cnt = n0 >= N ? 0 : (N - n0 < SEG ? N - n0 : SEG);
+  const float2* __restrict__ x = p.in + (size_t)ch * N;
+  unsigned char* __restrict__ o = p.pcm + (size_t)ch * p.pcm_stride;
+  const double bb_power = p.power[ch];
+  const double samprate = c.samprate, devmax = 5000.0, beta = 0.5;             // src/fm.c:43,103
+  const double est = p.n0[ch];
+  if (st.n0 != st.n0) st.n0 = est;
+  else { const double diff = est - st.n0; st.n0 += p.power_alpha * diff; }
+  const double alpha = -expm1(-p.blocktime / 1.0);                              // :55
+  const double noise = st.n0 * c.bandwidth;                                     // :101
+  const double snr = noise == 0 ? __builtin_huge_val() : (bb_power / noise) - 1.0;
+  double fmsnr;
+  if (c.snr_squelch || (st.squelch_state <= 0 && snr < c.squelch_close)) {
+    fmsnr = snr;
+  } else {                                                                      // :110-129 amplitude variance
+    double part = 0.0;
+    for (int i = 0; i < cnt; i++) { const double a = (double)demod_cabsf(x[n0 + i]); esh[n0 + i] = a; part += a; }
+    const double avg = wave_sum(part) / N;
+    part = 0.0;
+    for (int i = 0; i < cnt; i++) { const double dlt = esh[n0 + i] - avg; part += dlt * dlt; }
+    const double var = wave_sum(part);
+    const double s2 = fm_snr_dev(avg * avg * (N - 1) / var);
+    fmsnr = s2 > 0.0 ? s2 : 0.0;
+  }
+  const int smax = c.squelch_tail + 5;                                          // :149-155
+  if (fmsnr >= c.squelch_open) st.squelch_state = smax;
+  else if (st.squelch_state > 0 && (fmsnr < c.squelch_close || st.squelch_state < smax)) st.squelch_state--;
+  DemodStatus r;
+  r.pad = 0; r.n0 = st.n0; r.snr = fmsnr; r.squelch_state = st.squelch_state; r.gain = 0.0;
+  if (st.squelch_state <= 4) {                                                  // :157-173
+    if (st.squelch_state >= 1) { st.pm_re = 0.0; st.pm_im = 0.0; }
+    r.frame = 1; r.mute = st.squelch_state == 0; r.output_power = 0.0; r.foffset = st.foffset; r.pdeviation = st.pdeviation;
+    if (lane == 0) { p.status[ch] = r; p.state[ch] = st; }
+    return;
+  }
+  // :204-231 discriminator: phase of x[n] * conj(x[n-1]); the sample before the block is phase_memory
+  double psum = 0.0, pmax = 0.0, pmin = 0.0;
+  for (int i = 0; i < cnt; i++) {
+    const int n = n0 + i;
+    const float2 v = x[n];
+    double pr, pi, p0;
+    if (n == 0) { pr = st.pm_re; pi = st.pm_im; p0 = pr * pr + pi * pi; }
+    else { const float2 w = x[n - 1]; pr = w.x; pi = w.y; float a = w.x * w.x, b = w.y * w.y; CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b); p0 = (double)(a + b); }
+    const double br = v.x, bi = v.y;
+    const double sr = br * pr + bi * pi, si = bi * pr - br * pi;
+    double phase = M_1_PI * atan2(si, sr);
+    if (c.threshold_extend != 0) {
+      if (fabs(phase) > devmax / samprate) phase = copysign(devmax / samprate, phase);
+      if (p0 > 0) p0 /= (p0 + beta * noise);
+      float a = v.x * v.x, b = v.y * v.y; CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
+      double p1 = (double)(a + b);
+      if (p1 > 0) p1 /= (p1 + beta * noise);
+      phase *= p0 * p1;
+    }
+    const float bbv = (float)phase;
+    esh[n] = (double)bbv;
+    psum += (double)bbv;
+    if ((double)bbv > pmax) pmax = (double)bbv;
+    if ((double)bbv < pmin) pmin = (double)bbv;
+  }
+  {
+    const int last_lane = (N - 1) / SEG;                                        // phase_memory = the block's last sample
+    const float2 lastv = x[N - 1];
+    st.pm_re = lastv.x; st.pm_im = lastv.y;
+    (void)last_lane;
+  }
+  if (st.squelch_state == smax) {                                               // :232-256
+    double foff = wave_sum(psum) * (samprate * 0.5 / N);
+    double ppos = wave_max(pmax), pneg = wave_min(pmin);
+    st.foffset += alpha * (foff - st.foffset);
+    ppos *= samprate * 0.5; pneg *= samprate * 0.5;
+    ppos -= st.foffset; pneg -= st.foffset;
+    st.pdeviation = ppos > -pneg ? ppos : -pneg;
+  }
+  const bool pm = c.deemph_rate != 0;
+  const float dc = (float)(2 * st.foffset / samprate);                          // :258-263
+  double y_in = st.deemph_state;
+  if (pm) {                                                                     // :312-320 as a scan of affine maps
+    double A = 1.0, B = 0.0;
+    for (int i = 0; i < cnt; i++) {
+      const float b = (float)esh[n0 + i] - dc;
+      esh[n0 + i] = (double)b;
+      A *= (1.0 - c.deemph_rate); B = (1.0 - c.deemph_rate) * B + c.deemph_rate * (c.deemph_gain * (double)b);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double Ap = __shfl_up(A, d), Bp = __shfl_up(B, d);
+      if (lane >= d) { B = A * Bp + B; A = A * Ap; }
+    }
+    const double Ae = __shfl_up(A, 1), Be = __shfl_up(B, 1);
+    y_in = lane == 0 ? st.deemph_state : Ae * st.deemph_state + Be;
+    st.deemph_state = __shfl(A, 63) * st.deemph_state + __shfl(B, 63);
+  }
+  const double gain = (2 * c.headroom * samprate) / c.bandwidth;                // :325
+  double part = 0.0;
+  {
+    double y = y_in;
+    for (int i = 0; i < cnt; i++) {
+      float b = (float)esh[n0 + i];
+      if (pm) { y += c.deemph_rate * (c.deemph_gain * (double)b - y); b = (float)y; }
+      const double s = gain * (double)b;
+      part += s * s;
+      demod_put(o, c.encoding, n0 + i, (float)s);
+    }
+  }
+  r.frame = 0; r.mute = 0; r.gain = gain; r.output_power = wave_sum(part) / N; r.foffset = st.foffset; r.pdeviation = st.pdeviation;
+  if (lane == 0) { p.status[ch] = r; p.state[ch] = st; }
+}
+
 __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   HIP_DYNAMIC_SHARED(double, esh)                          // [N] per-sample energies (AGC slices)
   const int lane = (int)threadIdx.x;
@@ -1155,6 +1299,7 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   const DemodChan c = p.chan[ch];
   if (!c.on) return;
   DemodState st = p.state[ch];
+  if (c.kind == 1) { demod_fm_wave(p, c, st, ch, lane, esh); return; }     // wave-uniform
   const int N = p.olen;
   const int SEG = (N + 63) >> 6;
   const int n0 = lane * SEG;                               // first sample of this lane
@@ -1314,7 +1459,7 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   if (c.channels == 1) output_power *= 2;
   DemodStatus r;
   r.pad = 0; r.gain = st.gain; r.n0 = st.n0; r.snr = snr; r.squelch_state = st.squelch_state;
-  r.output_power = output_power;
+  r.output_power = output_power; r.foffset = 0.0; r.pdeviation = 0.0;
   if (!data) {
     r.frame = 1; r.mute = st.squelch_state == 0;
     if (st.squelch_state == 3 || st.squelch_state == 0) r.output_power = 0;

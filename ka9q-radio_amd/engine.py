@@ -33,14 +33,15 @@ class ChzTiming(C.Structure):
 class DemodParams(C.Structure):
     """chz_demod_params: the chan_t members src/linear.c reads (linear amplitudes / power ratios)."""
     _fields_ = [("channels", _i), ("env", _i), ("agc", _i), ("encoding", _i), ("snr_squelch", _i), ("squelch_tail", _i),
-                ("tuned", _i), ("pad", _i),
+                ("tuned", _i), ("kind", _i),
                 ("samprate", _d), ("headroom", _d), ("threshold", _d), ("recovery_rate", _d), ("hangtime", _d), ("dc_alpha", _d),
-                ("bandwidth", _d), ("shift", _d), ("squelch_open", _d), ("squelch_close", _d), ("gain", _d)]
+                ("bandwidth", _d), ("shift", _d), ("squelch_open", _d), ("squelch_close", _d), ("gain", _d),
+                ("deemph_rate", _d), ("deemph_gain", _d), ("threshold_extend", _d)]
 
 
 class DemodStatus(C.Structure):
     _fields_ = [("frame", _i), ("mute", _i), ("squelch_state", _i), ("pad", _i),
-                ("output_power", _d), ("gain", _d), ("n0", _d), ("snr", _d)]
+                ("output_power", _d), ("gain", _d), ("n0", _d), ("snr", _d), ("foffset", _d), ("pdeviation", _d)]
 
 
 PCM_S16BE, PCM_S16LE, PCM_F32LE, PCM_F32BE = 0, 1, 2, 3

@@ -849,7 +849,7 @@ int chzo_lindemod_block(chzo_lindemod *d, float *buf, int N, double bb_power, do
   const int squelch_state_max = c->squelch_tail + 4;
   if (!c->snr_squelch || snr >= c->squelch_open) d->squelch_state = squelch_state_max;
   else if (d->squelch_state > 0 && snr < c->squelch_close) d->squelch_state--;
-  st->gain = d->gain; st->n0 = d->n0; st->snr = snr; st->squelch_state = d->squelch_state;
+  st->gain = d->gain; st->n0 = d->n0; st->snr = snr; st->squelch_state = d->squelch_state; st->foffset = 0; st->pdeviation = 0;
   switch (d->squelch_state) {
   case 3: st->output_power = 0; /* fallthrough */
   case 2: case 1:
@@ -870,6 +870,142 @@ int chzo_lindemod_block(chzo_lindemod *d, float *buf, int N, double bb_power, do
   return 0;
 }
 int chzo_pcm_bytes(int encoding, int nsamples) { return pcm_bytes_per_sample(encoding) * nsamples; }
+
+/* ------------------------------------------------------------------ */
+/* SURVEY 8f rank 4, second half: the FM demodulator's per-block work   */
+/* (demod_fm, src/fm.c:19-345) without the PLL (:174-203) and PL tone   */
+/* (:264-311) branches                                                  */
+/* ------------------------------------------------------------------ */
+
+/* src/misc.c:414-468 */
+static double fm_i0(double z) { double t = 0.25 * z * z, sum = 1 + t, term = t;
+  for (int k = 2; k < 40; k++) { term *= t / (k * k); sum += term; if (term < 1e-12 * sum) break; } return sum; }
+static double fm_i1(double z) { double t = 0.25 * z * z, term = 0.5 * t, sum = 1 + term;
+  for (int k = 2; k < 40; k++) { term *= t / (k * (k + 1)); sum += term; if (term < 1e-12 * sum) break; } return 0.5 * z * sum; }
+static double fm_xi(double thetasq) {
+  double t = (2 + thetasq) * fm_i0(0.25 * thetasq) + thetasq * fm_i1(0.25 * thetasq);
+  t *= t;
+  return 2 + thetasq - (0.125 * M_PI) * exp(-0.5 * thetasq) * t;
+}
+double chzo_fm_snr(double r) {
+  if (r <= M_PI / (4 - M_PI)) return 0;
+  if (r > 100) return r;
+  double thetasq = r;
+  for (int i = 0; i < 10; i++) {
+    double o = thetasq;
+    thetasq = fm_xi(thetasq) * (1 + r) - 2;
+    if (fabs(thetasq - o) <= 0.01) break;
+  }
+  return thetasq;
+}
+
+struct chzo_fmdemod {
+  chzo_lindemod_params p;
+  double n0;                  /* chan->sig.n0 */
+  double pm_re, pm_im;        /* phase_memory (src/fm.c:36) */
+  double deemph_state;        /* :57 */
+  int squelch_state;          /* :58 */
+  double foffset;             /* chan->sig.foffset */
+  double pdeviation;          /* chan->fm.pdeviation */
+};
+chzo_fmdemod *chzo_fmdemod_create(const chzo_lindemod_params *p) {
+  chzo_fmdemod *d = (chzo_fmdemod *)calloc(1, sizeof *d);
+  if (!d) return NULL;
+  d->p = *p; d->n0 = NAN;
+  return d;
+}
+void chzo_fmdemod_delete(chzo_fmdemod *d) { free(d); }
+
+int chzo_fmdemod_block(chzo_fmdemod *d, const float *buf, int N, double bb_power, double n0_est, double blocktime,
+                       unsigned char *pcm, chzo_lindemod_status *st) {
+  const chzo_lindemod_params *c = &d->p;
+  const double samprate = c->samprate, devmax = 5000.;                       /* src/fm.c:43 */
+  if (isnan(d->n0)) d->n0 = n0_est;                                          /* src/radio.c:1466-1473 */
+  else { double diff = n0_est - d->n0; d->n0 += 0.10 * diff; }
+  const double alpha = -expm1(-blocktime / 1.0);                             /* :55 */
+  double fmsnr;
+  const double noise = d->n0 * c->bandwidth;                                 /* :101 */
+  const double beta = 0.5;
+  const double snr = noise == 0 ? INFINITY : (bb_power / noise) - 1.0;       /* :105 */
+  if (c->snr_squelch || (d->squelch_state <= 0 && snr < c->squelch_close)) {
+    fmsnr = snr;
+  } else {                                                                   /* :110-129 */
+    double avg_amp = 0;
+    double *amplitudes = (double *)malloc(sizeof(double) * (size_t)N);
+    for (int n = 0; n < N; n++) avg_amp += amplitudes[n] = cabsf(buf[2 * n] + I * buf[2 * n + 1]);
+    avg_amp /= N;
+    double fm_variance = 0;
+    for (int n = 0; n < N; n++) fm_variance += (amplitudes[n] - avg_amp) * (amplitudes[n] - avg_amp);
+    free(amplitudes);
+    const double s2 = chzo_fm_snr(avg_amp * avg_amp * (N - 1) / fm_variance);
+    fmsnr = s2 > 0.0 ? s2 : 0.0;
+  }
+  st->snr = fmsnr; st->n0 = d->n0; st->gain = 0; st->foffset = d->foffset; st->pdeviation = d->pdeviation;
+  const int smax = c->squelch_tail + 5;                                      /* :149 */
+  if (fmsnr >= c->squelch_open) d->squelch_state = smax;
+  else if (d->squelch_state > 0 && (fmsnr < c->squelch_close || d->squelch_state < smax)) d->squelch_state--;
+  st->squelch_state = d->squelch_state;
+  if (d->squelch_state <= 4) {                                               /* :157-173 */
+    if (d->squelch_state >= 1) { d->pm_re = 0; d->pm_im = 0; st->output_power = 0; }
+    else st->output_power = 0;          /* closed: chan->output.power keeps its last value, which was 0 */
+    st->frame = CHZO_FRAME_SILENCE; st->mute = d->squelch_state == 0;
+    return 0;
+  }
+  float *baseband = (float *)malloc(sizeof(float) * (size_t)N);
+  {                                                                          /* :204-231 straight carg demodulation */
+    double p0 = d->pm_re * d->pm_re + d->pm_im * d->pm_im;                   /* cnrm(phase_memory) */
+    if (p0 > 0) p0 /= (p0 + beta * noise);
+    for (int n = 0; n < N; n++) {
+      const double br = buf[2 * n], bi = buf[2 * n + 1];
+      const double sr = br * d->pm_re + bi * d->pm_im, si = bi * d->pm_re - br * d->pm_im;    /* buffer[n] * conj(phase_memory) */
+      double phase = M_1_PI * atan2(si, sr);
+      if (c->threshold_extend != 0) {
+        if (fabs(phase) > devmax / samprate) phase = copysign(devmax / samprate, phase);
+        double p1 = (double)(buf[2 * n] * buf[2 * n] + buf[2 * n + 1] * buf[2 * n + 1]);    /* cnrmf */
+        if (p1 > 0) p1 /= (p1 + beta * noise);
+        phase *= p0 * p1;
+        p0 = p1;
+      }
+      baseband[n] = (float)phase;
+      d->pm_re = br; d->pm_im = bi;
+    }
+  }
+  if (d->squelch_state == smax) {                                            /* :232-256 */
+    double peak_pos = 0, peak_neg = 0, foff = 0;
+    for (int n = 0; n < N; n++) {
+      foff += baseband[n];
+      if (baseband[n] > peak_pos) peak_pos = baseband[n];
+      else if (baseband[n] < peak_neg) peak_neg = baseband[n];
+    }
+    foff *= samprate * 0.5 / N;
+    d->foffset += alpha * (foff - d->foffset);
+    peak_pos *= samprate * 0.5; peak_neg *= samprate * 0.5;
+    peak_pos -= d->foffset; peak_neg -= d->foffset;
+    d->pdeviation = peak_pos > -peak_neg ? peak_pos : -peak_neg;
+  }
+  if (c->deemph_rate != 0) {                                                 /* :258-263 PM: remove DC */
+    const float dc = (float)(2 * d->foffset / samprate);
+    for (int n = 0; n < N; n++) baseband[n] -= dc;
+  }
+  if (c->deemph_rate != 0) {                                                 /* :312-320 */
+    for (int n = 0; n < N; n++) {
+      d->deemph_state += c->deemph_rate * (c->deemph_gain * baseband[n] - d->deemph_state);
+      baseband[n] = (float)d->deemph_state;
+    }
+  }
+  const double gain = (2 * c->headroom * samprate) / c->bandwidth;           /* :325 */
+  double output_energy = 0;
+  for (int n = 0; n < N; n++) {
+    const double s = gain * baseband[n];
+    output_energy += s * s;
+    baseband[n] = (float)s;
+  }
+  st->gain = gain; st->output_power = output_energy / N; st->foffset = d->foffset; st->pdeviation = d->pdeviation;
+  st->frame = CHZO_FRAME_DATA; st->mute = 0;
+  pcm_pack(c->encoding, baseband, N, pcm);
+  free(baseband);
+  return 0;
+}
 
 /* ------------------------------------------------------------------ */
 /* overlap-save stream                                                 */

@@ -106,13 +106,16 @@ int chzo_stream_push_f64(chzo_stream *s, const float *samples, double *spectrum)
    packing (src/import.h:88-118).  Field names follow the chan_t members linear.c reads. */
 enum { CHZO_PCM_S16BE = 0, CHZO_PCM_S16LE = 1, CHZO_PCM_F32LE = 2, CHZO_PCM_F32BE = 3 };
 enum { CHZO_FRAME_DATA = 0, CHZO_FRAME_SILENCE = 1 };
+enum { CHZO_DEMOD_LINEAR = 0, CHZO_DEMOD_FM = 1 };
 typedef struct chzo_lindemod_params {
-  int channels, env, agc, encoding, snr_squelch, squelch_tail, tuned, pad;
+  int channels, env, agc, encoding, snr_squelch, squelch_tail, tuned, kind;
   double samprate, headroom, threshold, recovery_rate, hangtime, dc_alpha, bandwidth, shift, squelch_open, squelch_close, gain;
+  double deemph_rate, deemph_gain, threshold_extend;     /* FM only: chan->fm.rate, chan->fm.gain, chan->fm.threshold (0/1) */
 } chzo_lindemod_params;
 typedef struct chzo_lindemod_status {
   int frame, mute, squelch_state, pad;
   double output_power, gain, n0, snr;
+  double foffset, pdeviation;                              /* FM only: chan->sig.foffset, chan->fm.pdeviation */
 } chzo_lindemod_status;
 typedef struct chzo_lindemod chzo_lindemod;
 chzo_lindemod *chzo_lindemod_create(const chzo_lindemod_params *p);
@@ -121,6 +124,14 @@ void chzo_lindemod_set_params(chzo_lindemod *d, const chzo_lindemod_params *p); 
 int chzo_lindemod_block(chzo_lindemod *d, float *buf, int N, double bb_power, double n0_est, double blocktime,
                         unsigned char *pcm, chzo_lindemod_status *st);
 int chzo_pcm_bytes(int encoding, int nsamples);
+/* the FM demodulator's per-block work (demod_fm, src/fm.c:19-345) without the PLL and PL-tone branches: both SNR estimators,
+   the squelch sequencer, the discriminator with threshold extension, offset / deviation statistics, PM carrier removal and
+   de-emphasis, gain, PCM packing.  Same parameter / status records as the linear demodulator (kind = CHZO_DEMOD_FM). */
+typedef struct chzo_fmdemod chzo_fmdemod;
+chzo_fmdemod *chzo_fmdemod_create(const chzo_lindemod_params *p);
+void chzo_fmdemod_delete(chzo_fmdemod *d);
+int chzo_fmdemod_block(chzo_fmdemod *d, const float *buf, int N, double bb_power, double n0_est, double blocktime,
+                       unsigned char *pcm, chzo_lindemod_status *st);
 
 #ifdef __cplusplus
 }

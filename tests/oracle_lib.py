@@ -453,14 +453,18 @@ FRAME_DATA, FRAME_SILENCE = 0, 1
 class LinParams(C.Structure):
     """chzo_lindemod_params (oracle/chz_oracle.h); the names are the chan_t members src/linear.c reads."""
     _fields_ = [("channels", _i), ("env", _i), ("agc", _i), ("encoding", _i), ("snr_squelch", _i), ("squelch_tail", _i),
-                ("tuned", _i), ("pad", _i),
+                ("tuned", _i), ("kind", _i),
                 ("samprate", _d), ("headroom", _d), ("threshold", _d), ("recovery_rate", _d), ("hangtime", _d), ("dc_alpha", _d),
-                ("bandwidth", _d), ("shift", _d), ("squelch_open", _d), ("squelch_close", _d), ("gain", _d)]
+                ("bandwidth", _d), ("shift", _d), ("squelch_open", _d), ("squelch_close", _d), ("gain", _d),
+                ("deemph_rate", _d), ("deemph_gain", _d), ("threshold_extend", _d)]
 
 
 class LinStatus(C.Structure):
     _fields_ = [("frame", _i), ("mute", _i), ("squelch_state", _i), ("pad", _i),
-                ("output_power", _d), ("gain", _d), ("n0", _d), ("snr", _d)]
+                ("output_power", _d), ("gain", _d), ("n0", _d), ("snr", _d), ("foffset", _d), ("pdeviation", _d)]
+
+
+DEMOD_LINEAR, DEMOD_FM = 0, 1
 
 
 def lin_params(channels=1, env=False, agc=True, encoding=PCM_S16BE, snr_squelch=False, squelch_tail=1, tuned=True, samprate=12000.0,
@@ -468,9 +472,19 @@ def lin_params(channels=1, env=False, agc=True, encoding=PCM_S16BE, snr_squelch=
                squelch_open_db=8.0, squelch_close_db=7.0, gain_db=50.0):
     """Defaults follow src/modes.c:40-60,224-246 (dB2voltage / dB2power as there)."""
     v = lambda db: 10 ** (db / 20.0)
-    return LinParams(channels, int(env), int(agc), encoding, int(snr_squelch), squelch_tail, int(tuned), 0, float(samprate), v(headroom_db),
+    return LinParams(channels, int(env), int(agc), encoding, int(snr_squelch), squelch_tail, int(tuned), DEMOD_LINEAR, float(samprate), v(headroom_db),
                      v(threshold_db), v(recovery_db_per_s), float(hangtime), float(dc_alpha), float(bandwidth), float(shift),
-                     10 ** (squelch_open_db / 10.0), 10 ** (squelch_close_db / 10.0), v(gain_db))
+                     10 ** (squelch_open_db / 10.0), 10 ** (squelch_close_db / 10.0), v(gain_db), 0.0, 0.0, 0.0)
+
+
+def fm_params(encoding=PCM_S16BE, snr_squelch=False, squelch_tail=1, samprate=24000.0, headroom_db=-15.0, bandwidth=16000.0,
+              squelch_open=6.3, squelch_close=4.0, threshold_extend=False, deemph_tc=530.5e-6, deemph_gain_db=12.0):
+    """NBFM as src/fm.c:38-44 and src/modes.c set it up: squelch thresholds are power ratios, de-emphasis
+    rate = -expm1(-1 / (tc * samprate)) (0 = flat FM), gain from dB."""
+    rate = -np.expm1(-1.0 / (deemph_tc * samprate)) if deemph_tc else 0.0
+    return LinParams(1, 0, 0, encoding, int(snr_squelch), squelch_tail, 1, DEMOD_FM, float(samprate), 10 ** (headroom_db / 20.0),
+                     0.0, 0.0, 0.0, 0.0, float(bandwidth), 0.0, float(squelch_open), float(squelch_close), 1.0,
+                     float(rate), 10 ** (deemph_gain_db / 20.0) if deemph_tc else 0.0, 1.0 if threshold_extend else 0.0)
 
 
 def pcm_bytes(encoding, nsamples):
@@ -507,6 +521,58 @@ class LinDemod:
             oracle().chzo_lindemod_delete(self._h)
         except Exception:
             pass
+
+
+class FmDemod:
+    """Restated per-block work of demod_fm() (oracle/chz_oracle.c:chzo_fmdemod_block)."""
+
+    def __init__(self, params):
+        L = oracle()
+        L.chzo_fmdemod_create.restype = _vp; L.chzo_fmdemod_create.argtypes = [C.POINTER(LinParams)]
+        L.chzo_fmdemod_delete.argtypes = [_vp]
+        L.chzo_fmdemod_block.argtypes = [_vp, _vp, _i, _d, _d, _d, _vp, C.POINTER(LinStatus)]
+        self.p = params
+        self._h = L.chzo_fmdemod_create(C.byref(params))
+
+    def block(self, samples, bb_power, n0_est, blocktime=0.02):
+        buf = np.ascontiguousarray(samples, np.complex64)
+        n = buf.shape[0]
+        pcm = np.zeros(pcm_bytes(self.p.encoding, n), np.uint8)
+        st = LinStatus()
+        oracle().chzo_fmdemod_block(self._h, _fptr(buf), n, float(bb_power), float(n0_est), float(blocktime), _fptr(pcm), C.byref(st))
+        return (pcm if st.frame == FRAME_DATA else None), st
+
+    def __del__(self):
+        try:
+            oracle().chzo_fmdemod_delete(self._h)
+        except Exception:
+            pass
+
+
+def have_ref_fm():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libka9q_ref_fm.so"))
+
+
+_ref_fm = None
+
+
+def ref_fm_run(params, baseband, bb_power, n0_smoothed, blocktime=0.02):
+    """The reference's OWN demod_fm() (oracle/ref_fm_wrap.c).  Returns dict of per-block arrays."""
+    global _ref_fm
+    if _ref_fm is None:
+        _ref_fm = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libka9q_ref_fm.so"))
+        _ref_fm.reffm_run.argtypes = [C.POINTER(LinParams), _d, _i, _i, _vp, _vp, _vp, _vp, _i] + [_vp] * 7
+    bb = np.ascontiguousarray(baseband, np.complex64)
+    nb, n = bb.shape
+    stride = pcm_bytes(params.encoding, n)
+    out = dict(pcm=np.zeros((nb, stride), np.uint8), frame=np.zeros(nb, np.int32), mute=np.zeros(nb, np.int32), power=np.zeros(nb),
+               gain=np.zeros(nb), snr=np.zeros(nb), foffset=np.zeros(nb), pdev=np.zeros(nb))
+    bp = np.ascontiguousarray(bb_power, np.float64); n0 = np.ascontiguousarray(n0_smoothed, np.float64)
+    r = _ref_fm.reffm_run(C.byref(params), float(blocktime), nb, n, _fptr(bb), _fptr(bp), _fptr(n0), _fptr(out["pcm"]), stride,
+                          _fptr(out["frame"]), _fptr(out["mute"]), _fptr(out["power"]), _fptr(out["gain"]), _fptr(out["snr"]),
+                          _fptr(out["foffset"]), _fptr(out["pdev"]))
+    assert r == 0
+    return out
 
 
 def have_ref_linear():

@@ -366,3 +366,60 @@ def test_linear_demodulator_on_the_device(pkg):
         assert it.demod_n == 8 and it.demod_ms > 0
     finally:
         eng2.close()
+
+
+def test_fm_demodulator_on_the_device(pkg):
+    """24 kHz NBFM channels behind the channelizer: an FM carrier that comes up out of the noise, is modulated with an offset,
+    and fades out through the squelch tail.  The oracle's demod_fm restatement (pinned to the reference's fm.c) gets exactly
+    what the device stage got (channel outputs, bb_power, noise estimate read back) and must produce the same frames."""
+    from test_kernels_emulated import FM_CASES
+    L, M, P, olen, fs_in, fs_out = 25920, 6481, 600, 480, 1.296e6, 24000.0
+    nblk = 36
+    rng = np.random.default_rng(91)
+    t = np.arange(nblk * L)
+    fc, dev, fmod = 100000.0 + 350.0, 3000.0, 1000.0
+    level = np.full(nblk * L, 0.05); level[:6 * L] = 0.0; level[26 * L:] = 0.0
+    level[22 * L:26 * L] = 0.05 * np.linspace(1, 0.02, 4 * L)
+    x = (level * np.cos(2 * np.pi * fc * t / fs_in - (dev / fmod) * np.cos(2 * np.pi * fmod * t / fs_in)) +
+         2e-3 * rng.standard_normal(nblk * L)).astype(np.float32)
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    nch = len(FM_CASES)
+    bank = eng.bank(P, olen, nch)
+    N = L + M - 1
+    bank.set_responses(0, np.stack([pkg.filterapi.design_response(P, olen, N, True, -8000 / fs_out, 8000 / fs_out, 11.0)] * nch))
+    shifts = np.full(nch, 2500, np.int32)
+    bank.set_tuning(0, 0, shifts, np.zeros(nch))
+    bank.set_active(nch)
+    bank.enable_noise(fs_in)
+    params = [ol.fm_params(**kw) for kw in FM_CASES]
+    bank.set_pcm_stride(4 * olen)
+    bank.set_demod(0, 0, [pkg.engine.DemodParams(*[getattr(p, f) for f, _ in ol.LinParams._fields_]) for p in params], 0.02)
+    oracles = [ol.FmDemod(p) for p in params]
+    seen = set()
+    try:
+        for b in range(nblk):
+            eng.write(x[b * L:(b + 1) * L])
+            eng.step(b)
+            out = bank.read_slot(b % 4); power = bank.read_power(b % 4); noise = bank.read_noise(b % 4)
+            pcm, status = bank.read_pcm(b % 4)
+            for i, p in enumerate(params):
+                want, st = oracles[i].block(out[i], power[i], noise[i], 0.02)
+                got = status[i]
+                assert (got.frame, got.mute, got.squelch_state) == (st.frame, st.mute, st.squelch_state), (b, i)
+                assert got.snr == pytest.approx(st.snr, rel=1e-5, abs=1e-9)
+                seen.add((got.frame, got.mute))
+                if st.frame == ol.FRAME_DATA:
+                    assert got.output_power == pytest.approx(st.output_power, rel=1e-6)
+                    assert got.foffset == pytest.approx(st.foffset, rel=1e-6, abs=1e-6) and got.pdeviation == pytest.approx(st.pdeviation, rel=1e-5, abs=1e-3)
+                    nb = ol.pcm_bytes(p.encoding, olen)
+                    if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+                        dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
+                        a, w = pcm[i, :nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
+                        assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02, (b, i)
+                    else:
+                        dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
+                        a, w = pcm[i, :nb].view(dt).astype(np.float64), want.view(dt).astype(np.float64)
+                        assert np.abs(a - w).max() <= 2e-6 * max(np.abs(w).max(), 1e-30), (b, i)
+    finally:
+        eng.close()
+    assert (ol.FRAME_DATA, 0) in seen and (ol.FRAME_SILENCE, 0) in seen and (ol.FRAME_SILENCE, 1) in seen

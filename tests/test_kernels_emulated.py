@@ -326,12 +326,14 @@ class _DemodChan(C.Structure):           # struct DemodChan, chz_kernels.h
                 ("squelch_tail", C.c_int), ("tuned", C.c_int), ("on", C.c_int),
                 ("samprate", C.c_double), ("headroom", C.c_double), ("threshold", C.c_double), ("recovery_rate", C.c_double),
                 ("hangtime", C.c_double), ("dc_alpha", C.c_double), ("bandwidth", C.c_double), ("squelch_open", C.c_double),
-                ("squelch_close", C.c_double), ("osc_phase0", C.c_double), ("osc_freq", C.c_double), ("osc_job0", C.c_uint), ("pad", C.c_int)]
+                ("squelch_close", C.c_double), ("osc_phase0", C.c_double), ("osc_freq", C.c_double), ("osc_job0", C.c_uint), ("kind", C.c_int),
+                ("deemph_rate", C.c_double), ("deemph_gain", C.c_double), ("threshold_extend", C.c_double)]
 
 
 class _DemodState(C.Structure):
     _fields_ = [("gain", C.c_double), ("am_dc", C.c_double), ("n0", C.c_double), ("hangcount", C.c_int), ("squelch_state", C.c_int),
-                ("squelch_open", C.c_int), ("pad", C.c_int)]
+                ("squelch_open", C.c_int), ("pad", C.c_int),
+                ("pm_re", C.c_double), ("pm_im", C.c_double), ("deemph_state", C.c_double), ("foffset", C.c_double), ("pdeviation", C.c_double)]
 
 
 DEMOD_CASES = [dict(), dict(channels=2, encoding=ol.PCM_F32LE), dict(env=True, dc_alpha=0.002, encoding=ol.PCM_S16LE),
@@ -359,7 +361,7 @@ def test_linear_demodulator_kernel(emu):
     chan = (_DemodChan * nch)(); state = (_DemodState * nch)(); status = (ol.LinStatus * nch)()
     for i, p in enumerate(params):
         c = chan[i]
-        for f in ("channels", "env", "agc", "encoding", "snr_squelch", "squelch_tail", "tuned", "samprate", "headroom", "threshold",
+        for f in ("channels", "env", "agc", "encoding", "snr_squelch", "squelch_tail", "tuned", "kind", "samprate", "headroom", "threshold",
                   "recovery_rate", "hangtime", "dc_alpha", "bandwidth", "squelch_open", "squelch_close"):
             setattr(c, f, getattr(p, f))
         c.on = 1; c.osc_phase0 = 0.0; c.osc_freq = p.shift / p.samprate; c.osc_job0 = 7
@@ -386,3 +388,55 @@ def test_linear_demodulator_kernel(emu):
                     dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
                     a, w = pcm[i, :nb].view(dt).astype(np.float64), want.view(dt).astype(np.float64)
                     assert np.abs(a - w).max() <= 2e-7 * max(np.abs(w).max(), 1e-30), (b, i)
+
+
+FM_CASES = [dict(), dict(threshold_extend=True, encoding=ol.PCM_F32LE), dict(deemph_tc=0, encoding=ol.PCM_S16LE),
+            dict(snr_squelch=True, squelch_tail=3, encoding=ol.PCM_F32BE)]
+
+
+def test_fm_demodulator_kernel(emu):
+    """The FM branch of the demodulator kernel (demod_fm, src/fm.c, no PLL / PL tone) against the restated demodulator:
+    carrier coming up out of the noise, a modulated stretch with a frequency offset, fading out through the squelch tail."""
+    from test_oracle_vs_reference import _fm_case
+    nblk, N, fs, bt = 36, 480, 24000.0, 0.02
+    nch = len(FM_CASES)
+    r = np.random.default_rng(5)
+    bbs, powers, ests, params, oracles = [], [], [], [], []
+    for i, kw in enumerate(FM_CASES):
+        bb, power = _fm_case(np.random.default_rng(200 + i), nblk, N, fs)
+        bbs.append(bb); powers.append(power); ests.append((2 * 2e-3 ** 2 / fs) * (1 + 0.1 * r.standard_normal(nblk)))
+        p = ol.fm_params(**kw); params.append(p); oracles.append(ol.FmDemod(p))
+    chan = (_DemodChan * nch)(); state = (_DemodState * nch)(); status = (ol.LinStatus * nch)()
+    for i, p in enumerate(params):
+        c = chan[i]
+        for f in ("channels", "env", "agc", "encoding", "snr_squelch", "squelch_tail", "tuned", "kind", "samprate", "headroom", "threshold",
+                  "recovery_rate", "hangtime", "dc_alpha", "bandwidth", "squelch_open", "squelch_close", "deemph_rate", "deemph_gain",
+                  "threshold_extend"):
+            setattr(c, f, getattr(p, f))
+        c.on = 1
+        state[i].n0 = float("nan")
+    pcm = np.zeros((nch, N * 8), np.uint8)
+    seen = set()
+    for b in range(nblk):
+        x = np.ascontiguousarray(np.stack([bbs[i][b] for i in range(nch)]))
+        pw = np.array([powers[i][b] for i in range(nch)]); ne = np.array([ests[i][b] for i in range(nch)])
+        assert emu.emu_demod(x.ctypes.data, pw.ctypes.data, ne.ctypes.data, chan, state, status, pcm.ctypes.data, nch, N, b, bt) == 0
+        for i, p in enumerate(params):
+            want, st = oracles[i].block(bbs[i][b], powers[i][b], ests[i][b], bt)
+            got = status[i]
+            assert (got.frame, got.mute, got.squelch_state) == (st.frame, st.mute, st.squelch_state), (b, i)
+            assert got.snr == pytest.approx(st.snr, rel=1e-6, abs=1e-12)
+            seen.add((got.frame, got.mute))
+            if st.frame == ol.FRAME_DATA:
+                assert got.output_power == pytest.approx(st.output_power, rel=1e-9) and got.gain == pytest.approx(st.gain, rel=1e-14)
+                assert got.foffset == pytest.approx(st.foffset, rel=1e-9, abs=1e-9) and got.pdeviation == pytest.approx(st.pdeviation, rel=1e-9, abs=1e-6)
+                nb = ol.pcm_bytes(p.encoding, N)
+                if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+                    dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
+                    a, w = pcm[i, :nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
+                    assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.01, (b, i)
+                else:
+                    dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
+                    a, w = pcm[i, :nb].view(dt).astype(np.float64), want.view(dt).astype(np.float64)
+                    assert np.abs(a - w).max() <= 2e-7 * max(np.abs(w).max(), 1e-30), (b, i)
+    assert (ol.FRAME_DATA, 0) in seen and (ol.FRAME_SILENCE, 0) in seen and (ol.FRAME_SILENCE, 1) in seen

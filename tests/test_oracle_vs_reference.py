@@ -405,3 +405,55 @@ def test_linear_demodulator_matches_reference_linear_c(oracle_built, kw):
                 assert np.abs(a - w).max() <= 2e-7 * max(np.abs(w).max(), 1e-30)
     if kw.get("snr_squelch"):
         assert (ol.FRAME_SILENCE, 0) in seen and (ol.FRAME_SILENCE, 1) in seen and (ol.FRAME_DATA, 0) in seen
+
+
+def _fm_case(r, nblk, N, fs):
+    """NBFM baseband: a tone-modulated carrier with a frequency offset that comes up out of the noise, stays, and fades"""
+    t = np.arange(nblk * N)
+    dev, fmod, foff = 3000.0, 1000.0, 350.0
+    phase = 2 * np.pi * (foff * t / fs) - (dev / fmod) * np.cos(2 * np.pi * fmod * t / fs)
+    level = np.full(nblk * N, 0.05)
+    level[:6 * N] = 0.0; level[26 * N:] = 0.0                                     # carrier present in blocks 6..25
+    level[22 * N:26 * N] = 0.05 * np.linspace(1, 0.02, 4 * N)                     # fading out: the squelch tail sequence
+    x = level * np.exp(1j * phase) + (r.standard_normal(nblk * N) + 1j * r.standard_normal(nblk * N)) * 2e-3
+    bb = x.astype(np.complex64).reshape(nblk, N)
+    power = np.array([np.mean(np.abs(b.astype(np.complex128)) ** 2) for b in bb])
+    return bb, power
+
+
+@pytest.mark.skipif(not ol.have_ref_fm(), reason="oracle/_ref/libka9q_ref_fm.so not built (needs /root/reference)")
+@pytest.mark.parametrize("kw", [dict(), dict(threshold_extend=True, encoding=ol.PCM_F32LE), dict(deemph_tc=0, encoding=ol.PCM_S16LE),
+                                dict(snr_squelch=True, squelch_tail=3, encoding=ol.PCM_F32BE)])
+def test_fm_demodulator_matches_reference_fm_c(oracle_built, kw):
+    # demod_fm() (src/fm.c:19-345, no PLL, no PL tone) run from the reference's own fm.c / misc.c / iir.c, block after block
+    r = np.random.default_rng(len(kw) + 40)
+    nblk, N, fs, bt = 36, 480, 24000.0, 0.02
+    bb, power = _fm_case(r, nblk, N, fs)
+    p = ol.fm_params(**kw)
+    n0_est = (2 * 2e-3 ** 2 / fs) * (1 + 0.1 * r.standard_normal(nblk))         # noise density of the test signal, jittered
+    n0s = np.zeros(nblk); s = np.nan
+    for b in range(nblk):
+        s = n0_est[b] if np.isnan(s) else s + 0.10 * (n0_est[b] - s)
+        n0s[b] = s
+    ref = ol.ref_fm_run(p, bb, power, n0s, bt)
+    d = ol.FmDemod(p)
+    seen = set()
+    for b in range(nblk):
+        pcm, st = d.block(bb[b], power[b], n0_est[b], bt)
+        assert st.frame == ref["frame"][b] and st.mute == ref["mute"][b], (b, st.frame, st.mute, ref["frame"][b], ref["mute"][b])
+        assert st.snr == pytest.approx(ref["snr"][b], rel=1e-6, abs=1e-12)     # cabsf under -funsafe-math: an ulp of a float per sample
+        seen.add((st.frame, st.mute))
+        if st.frame == ol.FRAME_DATA:
+            assert st.output_power == pytest.approx(ref["power"][b], rel=1e-6)
+            assert st.gain == pytest.approx(ref["gain"][b], rel=1e-14)
+            assert st.foffset == pytest.approx(ref["foffset"][b], rel=1e-6, abs=1e-6)
+            assert st.pdeviation == pytest.approx(ref["pdev"][b], rel=1e-5, abs=1e-3)
+            if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+                dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
+                a, w = pcm.view(dt).astype(np.int32), ref["pcm"][b].view(dt).astype(np.int32)
+                assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02
+            else:
+                dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
+                a, w = pcm.view(dt).astype(np.float64), ref["pcm"][b].view(dt).astype(np.float64)
+                assert np.abs(a - w).max() <= 2e-6 * max(np.abs(w).max(), 1e-30)
+    assert (ol.FRAME_DATA, 0) in seen and (ol.FRAME_SILENCE, 0) in seen and (ol.FRAME_SILENCE, 1) in seen
