@@ -442,8 +442,9 @@ def main():
     if not args.no_crt and config in (3, 4):
         crt_n = args.crt_channels or (17_000_000 if P == 300 else 8_400_000)
         if comm is not None:
+            # the big bank's channels span the whole spectrum on every rank: whole-slot broadcast, whatever the headline leg moved
             def run_one(job):
-                return eng.run_blocks_sharded(comm, job, 1, root=0, rows=(rows if mode == "subband" else None)).total_ms
+                return eng.run_blocks_sharded(comm, job, 1, root=0, rows=None).total_ms
         else:
             def run_one(job):
                 return eng.run_blocks(job, 1).total_ms
@@ -469,7 +470,7 @@ def main():
                 crt["dram_side_GBps"] = sum(c["dram_side_GBps"] for c in every)
                 crt["dram_side_frac_of_hbm_peak"] = crt["dram_side_GBps"] / (HBM_PEAK_GBS * len(every))
                 crt["gpus"] = len(every)
-                crt["exchange"] = main_leg
+                crt["exchange"] = "broadcast" if comm is not None else main_leg
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
