@@ -36,6 +36,9 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0 < roof["frac"] < 1
     assert roof["algorithmic_bytes_per_block"] == 25920008
+    pipe = roof["pipelined"]                                   # the forward transform alone, 4 blocks in flight
+    assert pipe["blocks_timed"] == 2000 and 0 < pipe["forward_us_per_block"] < roof["forward_us_per_block"]
+    assert abs(pipe["frac"] - pipe["achieved"] / roof["peak"]) < 1e-12
     cpu = j["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu
     crt = j["c_rt"]
