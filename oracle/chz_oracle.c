@@ -690,9 +690,57 @@ double chzo_downconv_block(chzo_downconv *d, int shift, double remainder, double
 
 /* ------------------------------------------------------------------ */
 /* the linear demodulator's per-block work            */
-/* (src/linear.c:56-375 without the PLL branch) and PCM packing         */
+/* (src/linear.c:56-375) and PCM packing                                */
 /* (src/import.h:88-118, called from send_output, src/audio.c:117-133)  */
 /* ------------------------------------------------------------------ */
+
+/* ---- the PLL of the coherent modes (src/osc.h:21-32, src/osc.c:75-205) ---- */
+/* nco(): phase accumulator -> (sin, cos).  Two quadrant bits, 10 table bits, 20 fraction bits; the table holds
+   sin(pi/2 * i/1024), i = 0..1024; the cosine is read from the mirrored index; the fraction is applied as a second-order
+   Taylor step with the table's own sine/cosine as derivatives (src/osc.c:91-126). */
+static double nco_table[1025];
+static int nco_ready;
+void chzo_nco(unsigned accum, double *s, double *c) {
+  if (!nco_ready) { for (int i = 0; i <= 1024; i++) nco_table[i] = sin(M_PI * 0.5 * (double)i / 1024); nco_ready = 1; }
+  const unsigned fract = accum & ((1u << 20) - 1);
+  unsigned tab = (accum >> 20) & 1023u;
+  unsigned quad = accum >> 30;
+  tab = (quad & 1) ? 1024 - tab : tab;
+  const double sine = (quad & 2) ? -nco_table[tab] : nco_table[tab];
+  tab = 1024 - tab;
+  quad++;
+  const double cosine = (quad & 2) ? -nco_table[tab] : nco_table[tab];
+  const double diff = 2 * M_PI * ldexp((double)fract, -32);
+  const double cdiff = cosine * diff, sdiff = sine * diff;
+  if (s) *s = sine + cdiff - 0.5 * sdiff * diff;
+  if (c) *c = cosine - sdiff - 0.5 * cdiff * diff;
+}
+typedef struct o_pll { uint32_t vco_phase; int32_t vco_step; double bw, damping, lower, upper, u, phi, K1, K2; int32_t wraps; } o_pll;
+static void pll_set_limits(o_pll *q, double lo, double hi) { if (lo > hi) { double t = lo; lo = hi; hi = t; } q->lower = lo; q->upper = hi; }   /* src/osc.c:139-148 */
+static void pll_set_params(o_pll *q, double bw, double damping) {                      /* src/osc.c:152-167 */
+  if (bw == 0 || (bw == q->bw && damping == q->damping)) return;
+  const double denom = damping + 1.0 / (4.0 * damping);
+  const double wn = 4.0 * M_PI * fabs(bw) / denom;
+  q->bw = bw; q->damping = damping;
+  const double theta = wn;
+  const double D = 1.0 + 2.0 * damping * theta + theta * theta;
+  q->K1 = 4.0 * damping * theta / D;
+  q->K2 = 4.0 * theta * theta / D;
+}
+static void pll_init(o_pll *q) { memset(q, 0, sizeof *q); pll_set_limits(q, -0.5, +0.5); pll_set_params(q, 0.01, M_SQRT1_2); }   /* src/osc.c:130-136 */
+static double pll_run(o_pll *q, double phase) {                                        /* src/osc.c:174-205 */
+  double u_new = q->u + q->K2 * phase;
+  double dphi = u_new + q->K1 * phase;
+  if (dphi > q->upper) { dphi = q->upper; if (phase > 0) u_new = q->u; }
+  else if (dphi < q->lower) { dphi = q->lower; if (phase < 0) u_new = q->u; }
+  q->u = u_new;
+  q->phi += dphi;
+  if (q->phi > 1) { q->phi -= 1; q->wraps++; }
+  else if (q->phi < -1) { q->phi += 1; q->wraps--; }
+  q->vco_step = (int32_t)ldexp(dphi, +32);
+  q->vco_phase += (uint32_t)q->vco_step;
+  return q->u;
+}
 
 struct chzo_lindemod {
   chzo_lindemod_params p;
@@ -704,6 +752,9 @@ struct chzo_lindemod {
   int squelch_state;       /* src/linear.c:46 */
   int squelch_open;        /* src/linear.c:47 */
   chzo_downconv shift;     /* only the oscillator part is used: chan->shift (src/linear.c:168-172) */
+  o_pll pll;               /* chan->pll.pll */
+  int pll_lock, pll_lock_count, pll_rotations;   /* chan->pll.lock, .lock_count, .rotations */
+  double pll_snr, pll_cphase, foffset;           /* chan->pll.snr, .cphase, chan->sig.foffset */
 };
 
 chzo_lindemod *chzo_lindemod_create(const chzo_lindemod_params *p) {
@@ -712,7 +763,8 @@ chzo_lindemod *chzo_lindemod_create(const chzo_lindemod_params *p) {
   d->p = *p;
   d->gain = p->gain;
   d->n0 = NAN;
-  d->squelch_state = (!p->snr_squelch) ? p->squelch_tail + 4 : 0;          /* src/linear.c:46 (no PLL here) */
+  d->squelch_state = (!p->pll_enable && !p->snr_squelch) ? p->squelch_tail + 4 : 0;   /* src/linear.c:46 */
+  pll_init(&d->pll);                                                        /* :41 */
   d->squelch_open = 1;                                                      /* :47 */
   return d;
 }
@@ -749,6 +801,48 @@ int chzo_lindemod_block(chzo_lindemod *d, float *buf, int N, double bb_power, do
   /* src/radio.c:1466-1473 (Power_alpha = 0.10, :72) */
   if (isnan(d->n0)) d->n0 = n0_est;
   else { double diff = n0_est - d->n0; d->n0 += 0.10 * diff; }
+  /* src/linear.c:76-153: the PLL of the coherent modes runs first, on the block as downconvert() left it */
+  {
+    const int isamprate = (int)samprate;                          /* `int const samprate` (:27) */
+    const int lock_limit = (int)lrint(0.5 * isamprate);           /* DEFAULT_PLL_LOCKTIME (:6,:38-40) */
+    if (c->pll_enable) {
+      double bw = c->pll_loop_bw / isamprate;
+      if (d->pll_lock) bw *= 0.1;
+      pll_set_params(&d->pll, bw, M_SQRT1_2);                     /* DEFAULT_PLL_DAMPING (:5) */
+      double signal = 0, noise = 0;
+      for (int n = 0; n < N; n++) {
+        double sn, cs; chzo_nco(d->pll.vco_phase, &sn, &cs);
+        const double br = buf[2 * n], bi = buf[2 * n + 1];
+        const double sr = br * cs + bi * sn, si = bi * cs - br * sn;          /* buffer[n] * conj(vco) */
+        buf[2 * n] = (float)sr; buf[2 * n + 1] = (float)si;
+        double phase;
+        if (d->pll_lock) {
+          if (!c->pll_square) { const double mag = sqrt(sr * sr + si * si); phase = (mag > 0) ? si / mag : 0; }
+          else phase = sr * si / (sr * sr - si * si);
+        } else {
+          if (!c->pll_square) phase = atan2(si, sr);
+          else phase = 0.5 * atan2(sr * si + si * sr, sr * sr - si * si);     /* carg(s*s) */
+        }
+        phase /= (2 * M_PI);
+        d->foffset = isamprate * pll_run(&d->pll, phase);
+        signal += sr * sr; noise += si * si;
+      }
+      d->pll_cphase = ldexp(2 * M_PI * d->pll.vco_phase, -32);
+      d->pll_rotations = d->pll.wraps;
+      if (noise != 0) { d->pll_snr = (signal / noise) - 1; if (d->pll_snr < 0) d->pll_snr = 0; }
+      else d->pll_snr = NAN;
+      if (d->pll_snr < c->squelch_close) {
+        d->pll_lock_count -= N;
+        if (d->pll_lock_count <= -lock_limit) { d->pll_lock_count = -lock_limit; d->pll_lock = 0; }
+      } else if (d->pll_snr > c->squelch_open) {
+        d->pll_lock_count += N;
+        if (d->pll_lock_count >= lock_limit) {
+          d->pll_lock_count = lock_limit;
+          if (!d->pll_lock) { d->pll_lock = 1; d->pll_rotations = 0; }
+        }
+      }
+    } else { d->pll_rotations = 0; d->pll_lock_count = -lock_limit; d->pll_lock = 0; }
+  }
   /* src/linear.c:168-172: post-downconversion shift */
   dc_set_osc(&d->shift, c->shift / samprate, 0);
   if (d->shift.freq != 0) {
@@ -846,10 +940,13 @@ int chzo_lindemod_block(chzo_lindemod *d, float *buf, int N, double bb_power, do
   /* src/linear.c:313-352: squelch */
   double snr = INFINITY;
   if (c->snr_squelch) snr = (bb_power / (d->n0 * c->bandwidth)) - 1.0;
+  else if (c->pll_enable) snr = d->pll_snr;                                 /* :317-318 */
   const int squelch_state_max = c->squelch_tail + 4;
-  if (!c->snr_squelch || snr >= c->squelch_open) d->squelch_state = squelch_state_max;
+  if (!(c->snr_squelch || c->pll_enable) || snr >= c->squelch_open) d->squelch_state = squelch_state_max;
   else if (d->squelch_state > 0 && snr < c->squelch_close) d->squelch_state--;
-  st->gain = d->gain; st->n0 = d->n0; st->snr = snr; st->squelch_state = d->squelch_state; st->foffset = 0; st->pdeviation = 0;
+  st->gain = d->gain; st->n0 = d->n0; st->snr = snr; st->squelch_state = d->squelch_state; st->foffset = d->foffset; st->pdeviation = 0;
+  st->pll_lock = d->pll_lock; st->pll_snr = d->pll_snr; st->pll_cphase = d->pll_cphase; st->pll_rotations = d->pll_rotations;
+  st->tone_deviation = 0; st->tone_mute = 0;
   switch (d->squelch_state) {
   case 3: st->output_power = 0; /* fallthrough */
   case 2: case 1:
@@ -860,7 +957,7 @@ int chzo_lindemod_block(chzo_lindemod *d, float *buf, int N, double bb_power, do
     return 0;
   default: break;
   }
-  if (c->snr_squelch) {
+  if (c->snr_squelch || c->pll_enable) {
     if (snr < c->squelch_close) d->squelch_open = 0;
     else if (!d->squelch_open && snr > c->squelch_open) { d->squelch_open = 1; d->am_dc = 0; }
   } else d->squelch_open = 1;
@@ -873,8 +970,7 @@ int chzo_pcm_bytes(int encoding, int nsamples) { return pcm_bytes_per_sample(enc
 
 /* ------------------------------------------------------------------ */
 /* SURVEY 8f rank 4, second half: the FM demodulator's per-block work   */
-/* (demod_fm, src/fm.c:19-345) without the PLL (:174-203) and PL tone   */
-/* (:264-311) branches                                                  */
+/* (demod_fm, src/fm.c:19-345)                                          */
 /* ------------------------------------------------------------------ */
 
 /* src/misc.c:414-468 */
@@ -907,11 +1003,21 @@ struct chzo_fmdemod {
   int squelch_state;          /* :58 */
   double foffset;             /* chan->sig.foffset */
   double pdeviation;          /* chan->fm.pdeviation */
+  o_pll pll; int pll_was_on;  /* chan->pll.pll, chan->pll.was_on (:176-184) */
+  /* PL tone squelch (:46-61): Goertzel detector (src/iir.h:24-44, src/iir.c:32-47), integration counter, phase memory */
+  double g_coeff, g_cfr, g_cfi, g_s0, g_s1;
+  int pl_sample_count, tone_mute;
+  double old_pl_phase, tone_deviation;
 };
 chzo_fmdemod *chzo_fmdemod_create(const chzo_lindemod_params *p) {
   chzo_fmdemod *d = (chzo_fmdemod *)calloc(1, sizeof *d);
   if (!d) return NULL;
   d->p = *p; d->n0 = NAN;
+  d->tone_mute = 1;                                                          /* :61 muted until the tone is detected */
+  if (p->tone_freq != 0) {                                                   /* :50-53 init_goertzel(tone_freq / samprate) */
+    const double f = p->tone_freq / (int)p->samprate;
+    d->g_coeff = 2 * cos(2 * M_PI * f); d->g_cfr = cos(2 * M_PI * f); d->g_cfi = -sin(2 * M_PI * f);
+  }
   return d;
 }
 void chzo_fmdemod_delete(chzo_fmdemod *d) { free(d); }
@@ -945,14 +1051,41 @@ int chzo_fmdemod_block(chzo_fmdemod *d, const float *buf, int N, double bb_power
   if (fmsnr >= c->squelch_open) d->squelch_state = smax;
   else if (d->squelch_state > 0 && (fmsnr < c->squelch_close || d->squelch_state < smax)) d->squelch_state--;
   st->squelch_state = d->squelch_state;
+  st->pll_lock = 0; st->pll_snr = 0; st->pll_cphase = 0; st->pll_rotations = 0;
+  st->tone_deviation = d->tone_deviation; st->tone_mute = c->tone_freq != 0 ? d->tone_mute : 0;
   if (d->squelch_state <= 4) {                                               /* :157-173 */
-    if (d->squelch_state >= 1) { d->pm_re = 0; d->pm_im = 0; st->output_power = 0; }
+    if (d->squelch_state == 4) { d->g_s0 = d->g_s1 = 0; }                    /* reset_goertzel */
+    if (d->squelch_state >= 1) { d->pm_re = 0; d->pm_im = 0; d->pl_sample_count = 0; st->output_power = 0; }
     else st->output_power = 0;          /* closed: chan->output.power keeps its last value, which was 0 */
     st->frame = CHZO_FRAME_SILENCE; st->mute = d->squelch_state == 0;
     return 0;
   }
   float *baseband = (float *)malloc(sizeof(float) * (size_t)N);
-  {                                                                          /* :204-231 straight carg demodulation */
+  if (c->pll_enable) {                                                       /* :176-203 PLL demodulator */
+    const int isamprate = (int)samprate;
+    const double pdev = devmax / isamprate;
+    if (!d->pll_was_on) {
+      d->pll_was_on = 1;
+      pll_init(&d->pll);
+      pll_set_params(&d->pll, 500.0 / isamprate, M_SQRT1_2);
+      pll_set_limits(&d->pll, -pdev, +pdev);
+    }
+    for (int n = 0; n < N; n++) {
+      double sn, cs; chzo_nco(d->pll.vco_phase, &sn, &cs);
+      const double br = buf[2 * n], bi = buf[2 * n + 1];
+      const double sr = br * cs + bi * sn, si = bi * cs - br * sn;            /* buffer[n] * conj(vco) */
+      double phase = M_1_PI * atan2(si, sr);
+      if (c->threshold_extend != 0) {
+        if (fabs(phase) > devmax / isamprate) phase = copysign(devmax / isamprate, phase);
+        double pw = (double)(buf[2 * n] * buf[2 * n] + buf[2 * n + 1] * buf[2 * n + 1]);   /* cnrmf */
+        if (pw > 0) { pw /= (pw + beta * noise); phase *= pw; }
+        else phase = 0;
+      }
+      baseband[n] = (float)(2 * pll_run(&d->pll, phase));
+      d->pm_re = br; d->pm_im = bi;
+    }
+  } else {                                                                   /* :204-231 straight carg demodulation */
+    d->pll_was_on = 0;
     double p0 = d->pm_re * d->pm_re + d->pm_im * d->pm_im;                   /* cnrm(phase_memory) */
     if (p0 > 0) p0 /= (p0 + beta * noise);
     for (int n = 0; n < N; n++) {
@@ -986,6 +1119,38 @@ int chzo_fmdemod_block(chzo_fmdemod *d, const float *buf, int N, double bb_power
   if (c->deemph_rate != 0) {                                                 /* :258-263 PM: remove DC */
     const float dc = (float)(2 * d->foffset / samprate);
     for (int n = 0; n < N; n++) baseband[n] -= dc;
+  }
+  if (c->tone_freq != 0) {                                                   /* :264-311 PL / CTCSS tone squelch */
+    const int isamprate = (int)samprate;
+    const int pl_integrate_samples = (int)lrint(isamprate * 0.24);           /* :59 */
+    for (int n = 0; n < N; n++) {
+      { const double s0save = d->g_s0; d->g_s0 = (double)baseband[n] + d->g_coeff * d->g_s0 - d->g_s1; d->g_s1 = s0save; }   /* update_goertzel */
+      /* the 300 Hz low-pass (applyIIR, :269-270) only feeds lpf_energy, which only the branch behind
+         `chan->options & (1LL<1)` reads -- and 1LL<1 is 0: it has no observable effect and is not restated */
+      d->pl_sample_count++;
+      if (d->pl_sample_count >= pl_integrate_samples) {
+        { const double s0save = d->g_s0; d->g_s0 = 0 + d->g_coeff * d->g_s0 - d->g_s1; d->g_s1 = s0save; }   /* output_goertzel: one zero sample */
+        const double cre = d->g_s0 - d->g_cfr * d->g_s1, cim = -d->g_cfi * d->g_s1;
+        const double g = sqrt(cre * cre + cim * cim) / d->pl_sample_count;
+        d->tone_deviation = isamprate * g;
+        const double ph = atan2(cim, cre) / (2 * M_PI);
+        double iptr = 0;
+        d->old_pl_phase += c->tone_freq * d->pl_sample_count / isamprate;
+        double np = 2 * modf(ph - d->old_pl_phase, &iptr);
+        d->old_pl_phase = ph;
+        np = np < -1 ? np + 2 : np > 1 ? np - 2 : np;
+        d->tone_mute = d->tone_deviation < 250 || fabs(np) > .10;
+        d->g_s0 = d->g_s1 = 0;
+        d->pl_sample_count = 0;
+      }
+    }
+    st->tone_deviation = d->tone_deviation; st->tone_mute = d->tone_mute;
+    if (d->tone_mute) {                                                      /* :305-309 */
+      st->output_power = 0; st->frame = CHZO_FRAME_SILENCE; st->mute = 1;
+      st->foffset = d->foffset; st->pdeviation = d->pdeviation;
+      free(baseband);
+      return 0;
+    }
   }
   if (c->deemph_rate != 0) {                                                 /* :312-320 */
     for (int n = 0; n < N; n++) {

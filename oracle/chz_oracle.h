@@ -111,12 +111,19 @@ typedef struct chzo_lindemod_params {
   int channels, env, agc, encoding, snr_squelch, squelch_tail, tuned, kind;
   double samprate, headroom, threshold, recovery_rate, hangtime, dc_alpha, bandwidth, shift, squelch_open, squelch_close, gain;
   double deemph_rate, deemph_gain, threshold_extend;     /* FM only: chan->fm.rate, chan->fm.gain, chan->fm.threshold (0/1) */
+  int pll_enable, pll_square;                            /* chan->pll.enable, chan->pll.square (linear: src/linear.c:83-153; FM: src/fm.c:176-203) */
+  double pll_loop_bw;                                    /* chan->pll.loop_bw, Hz (linear only; FM uses 500 Hz, src/fm.c:181) */
+  double tone_freq;                                      /* FM only: chan->fm.tone_freq, Hz; 0 = no PL/CTCSS tone squelch (src/fm.c:264-311) */
 } chzo_lindemod_params;
 typedef struct chzo_lindemod_status {
-  int frame, mute, squelch_state, pad;
+  int frame, mute, squelch_state, pll_lock;              /* pll_lock: chan->pll.lock (linear) */
   double output_power, gain, n0, snr;
-  double foffset, pdeviation;                              /* FM only: chan->sig.foffset, chan->fm.pdeviation */
+  double foffset, pdeviation;                            /* chan->sig.foffset (FM; linear with PLL: src/linear.c:115), chan->fm.pdeviation */
+  double pll_snr, pll_cphase, tone_deviation;            /* chan->pll.snr, chan->pll.cphase (linear), chan->fm.tone_deviation */
+  int pll_rotations, tone_mute;                          /* chan->pll.rotations; FM: the tone squelch's mute decision */
 } chzo_lindemod_status;
+/* the PLL's oscillator (nco(), src/osc.c:91-126): sine table of 1024 entries per quadrant + second-order interpolation */
+void chzo_nco(unsigned accum, double *s, double *c);
 typedef struct chzo_lindemod chzo_lindemod;
 chzo_lindemod *chzo_lindemod_create(const chzo_lindemod_params *p);
 void chzo_lindemod_delete(chzo_lindemod *d);
@@ -124,9 +131,9 @@ void chzo_lindemod_set_params(chzo_lindemod *d, const chzo_lindemod_params *p); 
 int chzo_lindemod_block(chzo_lindemod *d, float *buf, int N, double bb_power, double n0_est, double blocktime,
                         unsigned char *pcm, chzo_lindemod_status *st);
 int chzo_pcm_bytes(int encoding, int nsamples);
-/* the FM demodulator's per-block work (demod_fm, src/fm.c:19-345) without the PLL and PL-tone branches: both SNR estimators,
-   the squelch sequencer, the discriminator with threshold extension, offset / deviation statistics, PM carrier removal and
-   de-emphasis, gain, PCM packing.  Same parameter / status records as the linear demodulator (kind = CHZO_DEMOD_FM). */
+/* the FM demodulator's per-block work (demod_fm, src/fm.c:19-345): both SNR estimators, the squelch sequencer, the
+   discriminator with threshold extension or the PLL demodulator (:176-203), offset / deviation statistics, PM carrier removal,
+   the PL-tone squelch (:264-311), de-emphasis, gain, PCM packing.  Same parameter / status records as the linear demodulator (kind = CHZO_DEMOD_FM). */
 typedef struct chzo_fmdemod chzo_fmdemod;
 chzo_fmdemod *chzo_fmdemod_create(const chzo_lindemod_params *p);
 void chzo_fmdemod_delete(chzo_fmdemod *d);

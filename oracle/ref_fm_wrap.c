@@ -17,7 +17,7 @@ static struct {
   int nblocks, cur, N;
   const float *baseband; const double *bb_power, *n0;
   float complex *work;
-  unsigned char *pcm; int pcm_stride; int *frame; int *mute; double *out_power, *gain, *fmsnr, *foffset, *pdev;
+  unsigned char *pcm; int pcm_stride; int *frame; int *mute; double *out_power, *gain, *fmsnr, *foffset, *pdev, *tonedev;
 } B;
 
 int downconvert(chan_t *chan) {
@@ -30,7 +30,7 @@ int downconvert(chan_t *chan) {
 int send_output(chan_t *restrict const chan, float const *restrict buffer, int frames, bool const mute) {
   int const b = B.cur++;
   B.mute[b] = mute; B.out_power[b] = chan->output.power; B.gain[b] = chan->output.gain;
-  B.fmsnr[b] = chan->fm.snr; B.foffset[b] = chan->sig.foffset; B.pdev[b] = chan->fm.pdeviation;
+  B.fmsnr[b] = chan->fm.snr; B.foffset[b] = chan->sig.foffset; B.pdev[b] = chan->fm.pdeviation; B.tonedev[b] = chan->fm.tone_deviation;
   if (buffer == NULL) { B.frame[b] = 1; return 0; }
   B.frame[b] = 0;
   int const samples = frames * chan->output.channels;
@@ -56,11 +56,11 @@ size_t strlcpy(char *dst, const char *src, size_t size) {          /* libbsd's, 
 
 struct dm_params { int channels, env, agc, encoding, snr_squelch, squelch_tail, tuned, kind;
   double samprate, headroom, threshold, recovery_rate, hangtime, dc_alpha, bandwidth, shift, squelch_open, squelch_close, gain;
-  double deemph_rate, deemph_gain, threshold_extend; };
+  double deemph_rate, deemph_gain, threshold_extend; int pll_enable, pll_square; double pll_loop_bw, tone_freq; };
 
 EXPORT int reffm_run(const struct dm_params *p, double blocktime, int nblocks, int N, const float *baseband, const double *bb_power,
                      const double *n0, unsigned char *pcm, int pcm_stride, int *frame, int *mute, double *out_power, double *gain,
-                     double *fmsnr, double *foffset, double *pdev) {
+                     double *fmsnr, double *foffset, double *pdev, double *tonedev) {
   static chan_t chan;
   static struct frontend fe;
   memset(&chan, 0, sizeof chan);
@@ -70,14 +70,14 @@ EXPORT int reffm_run(const struct dm_params *p, double blocktime, int nblocks, i
   chan.output.encoding = p->encoding == 0 ? S16BE : p->encoding == 1 ? S16LE : p->encoding == 3 ? F32BE : F32LE;
   chan.filter.min_IF = -p->bandwidth / 2; chan.filter.max_IF = p->bandwidth / 2;
   chan.squelch.snr_enable = p->snr_squelch; chan.squelch.open = p->squelch_open; chan.squelch.close = p->squelch_close; chan.squelch.tail = p->squelch_tail;
-  chan.fm.threshold = p->threshold_extend != 0; chan.fm.rate = p->deemph_rate; chan.fm.gain = p->deemph_gain; chan.fm.tone_freq = 0;
-  chan.pll.enable = false;
+  chan.fm.threshold = p->threshold_extend != 0; chan.fm.rate = p->deemph_rate; chan.fm.gain = p->deemph_gain; chan.fm.tone_freq = p->tone_freq;
+  chan.pll.enable = p->pll_enable != 0;
   chan.demod_type = FM_DEMOD;
   pthread_mutex_init(&chan.status.lock, NULL);
   B.nblocks = nblocks; B.cur = 0; B.N = N; B.baseband = baseband; B.bb_power = bb_power; B.n0 = n0;
   B.work = malloc(sizeof(float complex) * (size_t)N);
   B.pcm = pcm; B.pcm_stride = pcm_stride; B.frame = frame; B.mute = mute; B.out_power = out_power; B.gain = gain;
-  B.fmsnr = fmsnr; B.foffset = foffset; B.pdev = pdev;
+  B.fmsnr = fmsnr; B.foffset = foffset; B.pdev = pdev; B.tonedev = tonedev;
   int r = demod_fm(&chan);
   free(B.work);
   return r;

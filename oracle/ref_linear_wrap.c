@@ -20,6 +20,7 @@ static struct {
   const double *bb_power, *n0;  /* [nblocks]: chan->sig.bb_power and the SMOOTHED chan->sig.n0 downconvert() leaves */
   float complex *work;          /* demod_linear overwrites its input: a scratch copy per block */
   unsigned char *pcm; int pcm_stride; int *frame; int *mute; double *out_power; double *gain;
+  double *pll;                  /* [nblocks][5]: chan->pll.snr, .lock, .cphase, .rotations, chan->sig.foffset */
 } B;
 
 int downconvert(chan_t *chan) {
@@ -32,6 +33,7 @@ int downconvert(chan_t *chan) {
 int send_output(chan_t *restrict const chan, float const *restrict buffer, int frames, bool const mute) {
   int const b = B.cur++;
   B.mute[b] = mute; B.out_power[b] = chan->output.power; B.gain[b] = chan->output.gain;
+  if (B.pll) { double *q = B.pll + 5 * b; q[0] = chan->pll.snr; q[1] = chan->pll.lock; q[2] = chan->pll.cphase; q[3] = chan->pll.rotations; q[4] = chan->sig.foffset; }
   if (buffer == NULL) { B.frame[b] = 1; return 0; }
   B.frame[b] = 0;
   int const samples = frames * chan->output.channels;
@@ -52,10 +54,11 @@ void realtime(int prio) { (void)prio; }
 
 /* params: the chzo_lindemod_params layout (oracle/chz_oracle.h); encoding 0 S16BE, 1 S16LE, 2 F32LE, 3 F32BE */
 struct lin_params { int channels, env, agc, encoding, snr_squelch, squelch_tail, tuned, pad;
-  double samprate, headroom, threshold, recovery_rate, hangtime, dc_alpha, bandwidth, shift, squelch_open, squelch_close, gain; };
+  double samprate, headroom, threshold, recovery_rate, hangtime, dc_alpha, bandwidth, shift, squelch_open, squelch_close, gain;
+  double deemph_rate, deemph_gain, threshold_extend; int pll_enable, pll_square; double pll_loop_bw, tone_freq; };
 
 EXPORT int reflin_run(const struct lin_params *p, double blocktime, int nblocks, int N, const float *baseband, const double *bb_power,
-                      const double *n0, unsigned char *pcm, int pcm_stride, int *frame, int *mute, double *out_power, double *gain) {
+                      const double *n0, unsigned char *pcm, int pcm_stride, int *frame, int *mute, double *out_power, double *gain, double *pll) {
   static chan_t chan;
   static struct frontend fe;
   memset(&chan, 0, sizeof chan);
@@ -68,12 +71,12 @@ EXPORT int reflin_run(const struct lin_params *p, double blocktime, int nblocks,
   chan.filter.min_IF = -p->bandwidth / 2; chan.filter.max_IF = p->bandwidth / 2;
   chan.tune.shift = p->shift; chan.tune.freq = p->tuned ? 7.0e6 : 0;
   chan.squelch.snr_enable = p->snr_squelch; chan.squelch.open = p->squelch_open; chan.squelch.close = p->squelch_close; chan.squelch.tail = p->squelch_tail;
-  chan.pll.enable = false;
+  chan.pll.enable = p->pll_enable != 0; chan.pll.square = p->pll_square != 0; chan.pll.loop_bw = p->pll_loop_bw;
   chan.demod_type = LINEAR_DEMOD;
   pthread_mutex_init(&chan.status.lock, NULL);
   B.nblocks = nblocks; B.cur = 0; B.N = N; B.baseband = baseband; B.bb_power = bb_power; B.n0 = n0;
   B.work = malloc(sizeof(float complex) * (size_t)N);
-  B.pcm = pcm; B.pcm_stride = pcm_stride; B.frame = frame; B.mute = mute; B.out_power = out_power; B.gain = gain;
+  B.pcm = pcm; B.pcm_stride = pcm_stride; B.frame = frame; B.mute = mute; B.out_power = out_power; B.gain = gain; B.pll = pll;
   int r = demod_linear(&chan);
   free(B.work);
   return r;

@@ -456,12 +456,14 @@ class LinParams(C.Structure):
                 ("tuned", _i), ("kind", _i),
                 ("samprate", _d), ("headroom", _d), ("threshold", _d), ("recovery_rate", _d), ("hangtime", _d), ("dc_alpha", _d),
                 ("bandwidth", _d), ("shift", _d), ("squelch_open", _d), ("squelch_close", _d), ("gain", _d),
-                ("deemph_rate", _d), ("deemph_gain", _d), ("threshold_extend", _d)]
+                ("deemph_rate", _d), ("deemph_gain", _d), ("threshold_extend", _d),
+                ("pll_enable", _i), ("pll_square", _i), ("pll_loop_bw", _d), ("tone_freq", _d)]
 
 
 class LinStatus(C.Structure):
-    _fields_ = [("frame", _i), ("mute", _i), ("squelch_state", _i), ("pad", _i),
-                ("output_power", _d), ("gain", _d), ("n0", _d), ("snr", _d), ("foffset", _d), ("pdeviation", _d)]
+    _fields_ = [("frame", _i), ("mute", _i), ("squelch_state", _i), ("pll_lock", _i),
+                ("output_power", _d), ("gain", _d), ("n0", _d), ("snr", _d), ("foffset", _d), ("pdeviation", _d),
+                ("pll_snr", _d), ("pll_cphase", _d), ("tone_deviation", _d), ("pll_rotations", _i), ("tone_mute", _i)]
 
 
 DEMOD_LINEAR, DEMOD_FM = 0, 1
@@ -469,22 +471,24 @@ DEMOD_LINEAR, DEMOD_FM = 0, 1
 
 def lin_params(channels=1, env=False, agc=True, encoding=PCM_S16BE, snr_squelch=False, squelch_tail=1, tuned=True, samprate=12000.0,
                headroom_db=-15.0, threshold_db=-15.0, recovery_db_per_s=20.0, hangtime=1.1, dc_alpha=0.0, bandwidth=2950.0, shift=0.0,
-               squelch_open_db=8.0, squelch_close_db=7.0, gain_db=50.0):
+               squelch_open_db=8.0, squelch_close_db=7.0, gain_db=50.0, pll=False, square=False, pll_bw=100.0):
     """Defaults follow src/modes.c:40-60,224-246 (dB2voltage / dB2power as there)."""
     v = lambda db: 10 ** (db / 20.0)
     return LinParams(channels, int(env), int(agc), encoding, int(snr_squelch), squelch_tail, int(tuned), DEMOD_LINEAR, float(samprate), v(headroom_db),
                      v(threshold_db), v(recovery_db_per_s), float(hangtime), float(dc_alpha), float(bandwidth), float(shift),
-                     10 ** (squelch_open_db / 10.0), 10 ** (squelch_close_db / 10.0), v(gain_db), 0.0, 0.0, 0.0)
+                     10 ** (squelch_open_db / 10.0), 10 ** (squelch_close_db / 10.0), v(gain_db), 0.0, 0.0, 0.0,
+                     int(pll), int(square), float(pll_bw), 0.0)
 
 
 def fm_params(encoding=PCM_S16BE, snr_squelch=False, squelch_tail=1, samprate=24000.0, headroom_db=-15.0, bandwidth=16000.0,
-              squelch_open=6.3, squelch_close=4.0, threshold_extend=False, deemph_tc=530.5e-6, deemph_gain_db=12.0):
+              squelch_open=6.3, squelch_close=4.0, threshold_extend=False, deemph_tc=530.5e-6, deemph_gain_db=12.0, pll=False, tone_freq=0.0):
     """NBFM as src/fm.c:38-44 and src/modes.c set it up: squelch thresholds are power ratios, de-emphasis
     rate = -expm1(-1 / (tc * samprate)) (0 = flat FM), gain from dB."""
     rate = -np.expm1(-1.0 / (deemph_tc * samprate)) if deemph_tc else 0.0
     return LinParams(1, 0, 0, encoding, int(snr_squelch), squelch_tail, 1, DEMOD_FM, float(samprate), 10 ** (headroom_db / 20.0),
                      0.0, 0.0, 0.0, 0.0, float(bandwidth), 0.0, float(squelch_open), float(squelch_close), 1.0,
-                     float(rate), 10 ** (deemph_gain_db / 20.0) if deemph_tc else 0.0, 1.0 if threshold_extend else 0.0)
+                     float(rate), 10 ** (deemph_gain_db / 20.0) if deemph_tc else 0.0, 1.0 if threshold_extend else 0.0,
+                     int(pll), 0, 0.0, float(tone_freq))
 
 
 def pcm_bytes(encoding, nsamples):
@@ -561,16 +565,16 @@ def ref_fm_run(params, baseband, bb_power, n0_smoothed, blocktime=0.02):
     global _ref_fm
     if _ref_fm is None:
         _ref_fm = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libka9q_ref_fm.so"))
-        _ref_fm.reffm_run.argtypes = [C.POINTER(LinParams), _d, _i, _i, _vp, _vp, _vp, _vp, _i] + [_vp] * 7
+        _ref_fm.reffm_run.argtypes = [C.POINTER(LinParams), _d, _i, _i, _vp, _vp, _vp, _vp, _i] + [_vp] * 8
     bb = np.ascontiguousarray(baseband, np.complex64)
     nb, n = bb.shape
     stride = pcm_bytes(params.encoding, n)
     out = dict(pcm=np.zeros((nb, stride), np.uint8), frame=np.zeros(nb, np.int32), mute=np.zeros(nb, np.int32), power=np.zeros(nb),
-               gain=np.zeros(nb), snr=np.zeros(nb), foffset=np.zeros(nb), pdev=np.zeros(nb))
+               gain=np.zeros(nb), snr=np.zeros(nb), foffset=np.zeros(nb), pdev=np.zeros(nb), tonedev=np.zeros(nb))
     bp = np.ascontiguousarray(bb_power, np.float64); n0 = np.ascontiguousarray(n0_smoothed, np.float64)
     r = _ref_fm.reffm_run(C.byref(params), float(blocktime), nb, n, _fptr(bb), _fptr(bp), _fptr(n0), _fptr(out["pcm"]), stride,
                           _fptr(out["frame"]), _fptr(out["mute"]), _fptr(out["power"]), _fptr(out["gain"]), _fptr(out["snr"]),
-                          _fptr(out["foffset"]), _fptr(out["pdev"]))
+                          _fptr(out["foffset"]), _fptr(out["pdev"]), _fptr(out["tonedev"]))
     assert r == 0
     return out
 
@@ -582,13 +586,14 @@ def have_ref_linear():
 _ref_linear = None
 
 
-def ref_linear_run(params, baseband, bb_power, n0_smoothed, blocktime=0.02):
+def ref_linear_run(params, baseband, bb_power, n0_smoothed, blocktime=0.02, pll_out=None):
     """The reference's OWN demod_linear() (oracle/ref_linear_wrap.c) over nblocks blocks of baseband[nblocks][N];
-    n0_smoothed = chan->sig.n0 as downconvert() leaves it.  Returns (pcm[nblocks][bytes], frame, mute, out_power, gain)."""
+    n0_smoothed = chan->sig.n0 as downconvert() leaves it.  Returns (pcm[nblocks][bytes], frame, mute, out_power, gain);
+    pll_out (float64[nblocks][5], optional) receives chan->pll.snr, .lock, .cphase, .rotations and chan->sig.foffset per block."""
     global _ref_linear
     if _ref_linear is None:
         _ref_linear = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libka9q_ref_linear.so"))
-        _ref_linear.reflin_run.argtypes = [C.POINTER(LinParams), _d, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]
+        _ref_linear.reflin_run.argtypes = [C.POINTER(LinParams), _d, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]
     bb = np.ascontiguousarray(baseband, np.complex64)
     nb, n = bb.shape
     stride = pcm_bytes(params.encoding, n * params.channels)
@@ -597,7 +602,7 @@ def ref_linear_run(params, baseband, bb_power, n0_smoothed, blocktime=0.02):
     power = np.zeros(nb); gain = np.zeros(nb)
     bp = np.ascontiguousarray(bb_power, np.float64); n0 = np.ascontiguousarray(n0_smoothed, np.float64)
     r = _ref_linear.reflin_run(C.byref(params), float(blocktime), nb, n, _fptr(bb), _fptr(bp), _fptr(n0), _fptr(pcm), stride,
-                               _fptr(frame), _fptr(mute), _fptr(power), _fptr(gain))
+                               _fptr(frame), _fptr(mute), _fptr(power), _fptr(gain), _fptr(pll_out) if pll_out is not None else None)
     assert r == 0
     return pcm, frame, mute, power, gain
 

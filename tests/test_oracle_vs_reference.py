@@ -407,14 +407,99 @@ def test_linear_demodulator_matches_reference_linear_c(oracle_built, kw):
         assert (ol.FRAME_SILENCE, 0) in seen and (ol.FRAME_SILENCE, 1) in seen and (ol.FRAME_DATA, 0) in seen
 
 
-def _fm_case(r, nblk, N, fs):
+def test_pll_oscillator_matches_reference_osc_c(oracle_built):
+    # nco() of the reference's own osc.c (inside oracle/_ref/libka9q_ref.so) against the restatement, over the whole phase circle
+    import ctypes as C
+    R = ol.ref(); O = ol.oracle()
+    for L in (R.nco, O.chzo_nco):
+        L.argtypes = [C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]; L.restype = None
+    r = np.random.default_rng(5)
+    acc = np.concatenate([r.integers(0, 2 ** 32, 5000, dtype=np.uint64), np.array([0, 1, 2 ** 20 - 1, 2 ** 20, 2 ** 30 - 1, 2 ** 30, 2 ** 31, 2 ** 32 - 1], np.uint64)])
+    for a in acc:
+        s1, c1, s2, c2 = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+        R.nco(int(a), C.byref(s1), C.byref(c1)); O.chzo_nco(int(a), C.byref(s2), C.byref(c2))
+        assert abs(s1.value - s2.value) <= 3e-16 and abs(c1.value - c2.value) <= 3e-16      # -ffp-contract / -funsafe-math in the reference build
+        th = 2 * np.pi * int(a) / 2.0 ** 32
+        assert abs(s2.value - np.sin(th)) < 2e-9 and abs(c2.value - np.cos(th)) < 2e-9      # what the table + Taylor step is good for
+
+
+def _coherent_case(r, nblk, N, square):
+    """A carrier 30 Hz off tune (5 Hz for the squaring loop, which false-locks near fs/4 when it is left to run on noise with a
+    wide bandwidth) that comes up at block 4 and goes away at block 50; AM (or, for the squaring loop, BPSK) on it"""
+    t = np.arange(nblk * N)
+    fs = 12000.0
+    if square:
+        mod = np.sign(np.sin(2 * np.pi * 31.25 * t / fs + 0.3))                 # phase reversals: only a squaring loop locks
+    else:
+        mod = 1 + 0.5 * np.sin(2 * np.pi * 400 * t / fs)
+    lvl = np.where((t >= 4 * N) & (t < 50 * N), 0.02, 0.0)
+    x = lvl * mod * np.exp(2j * np.pi * ((5.0 if square else 30.0) * t / fs) + 0.7j)
+    x = x + (r.standard_normal(nblk * N) + 1j * r.standard_normal(nblk * N)) * 4e-4
+    bb = x.astype(np.complex64).reshape(nblk, N)
+    power = np.array([np.mean(np.abs(b.astype(np.complex128)) ** 2) for b in bb])
+    return bb, power
+
+
+@pytest.mark.skipif(not ol.have_ref_linear(), reason="oracle/_ref/libka9q_ref_linear.so not built (needs /root/reference)")
+@pytest.mark.parametrize("kw", [
+    dict(pll=True),                                                  # coherent AM: carrier tracking, I channel out
+    dict(pll=True, square=True, pll_bw=20.0, channels=2, encoding=ol.PCM_F32LE),  # squaring loop on a BPSK-like signal, I/Q out
+    dict(pll=True, env=True, dc_alpha=0.002, pll_bw=50.0, squelch_tail=0, encoding=ol.PCM_S16LE),
+])
+def test_linear_pll_matches_reference_linear_c(oracle_built, kw):
+    # the PLL branch of demod_linear() (src/linear.c:83-153) incl. the lock detector and the squelch it drives, the loop
+    # itself from the reference's osc.c
+    r = np.random.default_rng(3)             # (on some noise the wide loop runs off to a false lock near fs/4 before the carrier comes up)
+    nblk, N, bt = 90, 240, 0.02
+    bb, power = _coherent_case(r, nblk, N, kw.get("square", False))
+    n0_est = np.full(nblk, 2 * 4e-4 ** 2 / 12000.0)
+    p = ol.lin_params(**kw)
+    n0s = np.zeros(nblk); s = np.nan
+    for b in range(nblk):
+        s = n0_est[b] if np.isnan(s) else s + 0.10 * (n0_est[b] - s)
+        n0s[b] = s
+    pll_r = np.zeros((nblk, 5))
+    pcm_r, frame_r, mute_r, pow_r, gain_r = ol.ref_linear_run(p, bb, power, n0s, bt, pll_out=pll_r)
+    d = ol.LinDemod(p)
+    locked = 0
+    seen = set()
+    for b in range(nblk):
+        pcm, st = d.block(bb[b], power[b], n0_est[b], bt)
+        assert st.frame == frame_r[b] and st.mute == mute_r[b], (b, st.frame, frame_r[b], st.mute, mute_r[b])
+        assert st.pll_lock == int(pll_r[b, 1]) and st.pll_rotations == int(pll_r[b, 3]), b
+        assert st.pll_snr == pytest.approx(pll_r[b, 0], rel=1e-6, abs=1e-9)
+        dphi = (st.pll_cphase - pll_r[b, 2] + np.pi) % (2 * np.pi) - np.pi
+        assert abs(dphi) < 1e-6                                      # the VCO phase word: a truncation of a double, 2^-32 cycle per flip
+        assert st.foffset == pytest.approx(pll_r[b, 4], rel=1e-6, abs=1e-6)
+        assert st.gain == pytest.approx(gain_r[b], rel=1e-7)
+        assert st.output_power == pytest.approx(pow_r[b], rel=1e-6, abs=1e-300)
+        locked += st.pll_lock
+        seen.add((st.frame, st.mute))
+        if st.frame == ol.FRAME_DATA:
+            if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+                dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
+                a, w = pcm.view(dt).astype(np.int32), pcm_r[b].view(dt).astype(np.int32)
+                assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02
+            else:
+                dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
+                a, w = pcm.view(dt).astype(np.float64), pcm_r[b].view(dt).astype(np.float64)
+                assert np.abs(a - w).max() <= 2e-6 * max(np.abs(w).max(), 1e-30)
+    assert 10 < locked < nblk - 10                                   # it locked on the carrier and let go after it went away
+    assert (ol.FRAME_DATA, 0) in seen and (ol.FRAME_SILENCE, 1) in seen
+    # the loop really tracked the 30 Hz offset while locked
+    assert any(abs(pll_r[b, 4] - 30.0) < 1.0 for b in range(30, 48)) or kw.get("square")
+
+
+def _fm_case(r, nblk, N, fs, tone=0.0, last=26):
     """NBFM baseband: a tone-modulated carrier with a frequency offset that comes up out of the noise, stays, and fades"""
     t = np.arange(nblk * N)
     dev, fmod, foff = 3000.0, 1000.0, 350.0
     phase = 2 * np.pi * (foff * t / fs) - (dev / fmod) * np.cos(2 * np.pi * fmod * t / fs)
+    if tone:
+        phase = phase - (600.0 / tone) * np.cos(2 * np.pi * tone * t / fs)      # a PL tone with 600 Hz of deviation
     level = np.full(nblk * N, 0.05)
-    level[:6 * N] = 0.0; level[26 * N:] = 0.0                                     # carrier present in blocks 6..25
-    level[22 * N:26 * N] = 0.05 * np.linspace(1, 0.02, 4 * N)                     # fading out: the squelch tail sequence
+    level[:6 * N] = 0.0; level[last * N:] = 0.0                                   # carrier present in blocks 6..last-1
+    level[(last - 4) * N:last * N] = 0.05 * np.linspace(1, 0.02, 4 * N)           # fading out: the squelch tail sequence
     x = level * np.exp(1j * phase) + (r.standard_normal(nblk * N) + 1j * r.standard_normal(nblk * N)) * 2e-3
     bb = x.astype(np.complex64).reshape(nblk, N)
     power = np.array([np.mean(np.abs(b.astype(np.complex128)) ** 2) for b in bb])
@@ -457,3 +542,51 @@ def test_fm_demodulator_matches_reference_fm_c(oracle_built, kw):
                 a, w = pcm.view(dt).astype(np.float64), ref["pcm"][b].view(dt).astype(np.float64)
                 assert np.abs(a - w).max() <= 2e-6 * max(np.abs(w).max(), 1e-30)
     assert (ol.FRAME_DATA, 0) in seen and (ol.FRAME_SILENCE, 0) in seen and (ol.FRAME_SILENCE, 1) in seen
+
+
+@pytest.mark.skipif(not ol.have_ref_fm(), reason="oracle/_ref/libka9q_ref_fm.so not built (needs /root/reference)")
+@pytest.mark.parametrize("kw,tone_sent", [
+    (dict(pll=True, encoding=ol.PCM_F32LE), 0.0),                     # PLL demodulator (src/fm.c:176-203)
+    (dict(pll=True, threshold_extend=True), 0.0),
+    (dict(tone_freq=100.0), 100.0),                                   # PL tone squelch: the tone is there -> opens after 0.24 s
+    (dict(tone_freq=100.0, deemph_tc=0, encoding=ol.PCM_S16LE), 0.0), # ... and is not: stays muted
+    (dict(tone_freq=123.0, pll=True), 100.0),                         # the wrong tone
+])
+def test_fm_pll_and_tone_squelch_match_reference_fm_c(oracle_built, kw, tone_sent):
+    r = np.random.default_rng(len(kw) + 60 + int(tone_sent))
+    nblk, N, fs, bt = 72, 480, 24000.0, 0.02
+    bb, power = _fm_case(r, nblk, N, fs, tone=tone_sent, last=60)    # the tone detector integrates 12 blocks at a time
+    bb = bb.copy(); power = power.copy()
+    p = ol.fm_params(**kw)
+    n0_est = (2 * 2e-3 ** 2 / fs) * (1 + 0.1 * r.standard_normal(nblk))
+    n0s = np.zeros(nblk); s = np.nan
+    for b in range(nblk):
+        s = n0_est[b] if np.isnan(s) else s + 0.10 * (n0_est[b] - s)
+        n0s[b] = s
+    ref = ol.ref_fm_run(p, bb, power, n0s, bt)
+    d = ol.FmDemod(p)
+    data = 0
+    for b in range(nblk):
+        pcm, st = d.block(bb[b], power[b], n0_est[b], bt)
+        assert st.frame == ref["frame"][b] and st.mute == ref["mute"][b], (b, st.frame, st.mute, ref["frame"][b], ref["mute"][b])
+        assert st.snr == pytest.approx(ref["snr"][b], rel=1e-6, abs=1e-12)
+        assert st.tone_deviation == pytest.approx(ref["tonedev"][b], rel=1e-5, abs=1e-6)
+        if st.frame == ol.FRAME_DATA:
+            data += 1
+            assert st.output_power == pytest.approx(ref["power"][b], rel=2e-6)
+            assert st.foffset == pytest.approx(ref["foffset"][b], rel=1e-5, abs=1e-5)
+            assert st.pdeviation == pytest.approx(ref["pdev"][b], rel=1e-5, abs=1e-3)
+            if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+                dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
+                a, w = pcm.view(dt).astype(np.int32), ref["pcm"][b].view(dt).astype(np.int32)
+                assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02
+            else:
+                dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
+                a, w = pcm.view(dt).astype(np.float64), ref["pcm"][b].view(dt).astype(np.float64)
+                assert np.abs(a - w).max() <= 4e-6 * max(np.abs(w).max(), 1e-30)
+    if p.tone_freq and tone_sent != p.tone_freq:
+        assert data == 0                                             # muted throughout
+    else:
+        assert data >= 5
+    if p.tone_freq == tone_sent and tone_sent:
+        assert max(ref["tonedev"]) == pytest.approx(600.0, rel=0.1)  # the detector measures the tone's deviation
