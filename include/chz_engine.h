@@ -253,9 +253,9 @@ typedef struct chz_demod_params {
   int snr_squelch;      /* chan->squelch.snr_enable */
   int squelch_tail;     /* chan->squelch.tail */
   int tuned;            /* chan->tune.freq != 0 */
-  int kind;             /* CHZ_DEMOD_LINEAR (demod_linear, src/linear.c) or CHZ_DEMOD_FM (demod_fm, src/fm.c:19-345 without the PLL
-                           and PL-tone branches: both SNR estimators, squelch sequencer, discriminator with threshold extension,
-                           offset / deviation statistics, PM carrier removal and de-emphasis, gain) */
+  int kind;             /* CHZ_DEMOD_LINEAR (demod_linear, src/linear.c) or CHZ_DEMOD_FM (demod_fm, src/fm.c:19-345: both SNR
+                           estimators, squelch sequencer, discriminator with threshold extension or PLL demodulator, offset /
+                           deviation statistics, PM carrier removal, PL-tone squelch, de-emphasis, gain) */
   double samprate;      /* chan->output.samprate */
   double headroom;      /* chan->output.headroom */
   double threshold, recovery_rate, hangtime, dc_alpha;   /* chan->linear.* */
@@ -265,23 +265,40 @@ typedef struct chz_demod_params {
   double gain;          /* chan->output.gain when the demodulator starts (the AGC owns it afterwards) */
   double deemph_rate, deemph_gain;   /* FM: chan->fm.rate (0 = flat FM), chan->fm.gain */
   double threshold_extend;           /* FM: chan->fm.threshold, 0 or 1 */
+  int pll_enable;       /* chan->pll.enable: linear -- carrier-tracking PLL in front of the detector, lock detector, PLL squelch
+                           (src/linear.c:83-153); FM -- PLL demodulator instead of the discriminator (src/fm.c:176-203) */
+  int pll_square;       /* chan->pll.square (linear): squaring loop for suppressed-carrier signals */
+  double pll_loop_bw;   /* chan->pll.loop_bw, Hz (linear; the FM loop is 500 Hz wide, src/fm.c:181) */
+  double tone_freq;     /* FM: chan->fm.tone_freq, Hz; non-zero = PL / CTCSS tone squelch (src/fm.c:264-311) */
 } chz_demod_params;
 #define CHZ_DEMOD_LINEAR 0
 #define CHZ_DEMOD_FM 1
 typedef struct chz_demod_status {
   int frame;            /* 0: PCM present (send_output(chan, samples, N, mute)); 1: no samples (send_output(chan, NULL, N, mute)) */
   int mute;
-  int squelch_state, pad;
+  int squelch_state;
+  int pll_lock;         /* chan->pll.lock (linear) */
   double output_power;  /* chan->output.power */
   double gain;          /* chan->output.gain after the block */
   double n0;            /* chan->sig.n0 (smoothed) */
-  double snr;           /* linear: the SNR squelch's; FM: chan->fm.snr */
-  double foffset;       /* FM: chan->sig.foffset */
+  double snr;           /* linear: the squelch's SNR (the SNR squelch's, else the PLL's); FM: chan->fm.snr */
+  double foffset;       /* chan->sig.foffset (FM; linear with the PLL on) */
   double pdeviation;    /* FM: chan->fm.pdeviation */
+  double pll_snr;       /* chan->pll.snr (linear) */
+  double pll_cphase;    /* chan->pll.cphase, radians (linear) */
+  double tone_deviation;/* FM: chan->fm.tone_deviation, Hz */
+  int pll_rotations;    /* chan->pll.rotations (linear) */
+  int tone_mute;        /* FM: 1 while the tone squelch keeps the channel muted */
 } chz_demod_status;
 /* parameters of channels [ch0, ch0+n) from block `job` on (it must not have been enqueued yet); blocktime = radiod's Blocktime.
  * Waits for the demodulator stream only, never for the transform lanes. */
 int chz_bank_set_demod(chz_engine *e, int bank, unsigned job, int ch0, int n, const chz_demod_params *p, double blocktime);
+/* Demodulating blocks the caller supplies (radiod puts a channel's private second filter, filter2 -- chz_mini_* -- between the
+ * channelizer and the demodulator, src/radio.c:1572-1594): chz_bank_write_block stores n channels' olen complex samples
+ * (+ bb_power, noise estimates; NULL leaves what is there) into `slot`'s output image, chz_bank_demod runs the bank's
+ * demodulators over the slot as block `job` on the demodulator stream (results: chz_bank_read_pcm). */
+int chz_bank_write_block(chz_engine *e, int bank, int slot, int ch0, int n, const float *samples, const double *bb_power, const double *n0);
+int chz_bank_demod(chz_engine *e, int bank, unsigned job, int slot);
 /* bytes between two channels' PCM rows = the stride of chz_bank_read_pcm's buffer.  Default olen*8 (stereo float32 fits);
  * chz_bank_set_pcm_stride, before the first chz_bank_set_demod, shrinks the rows to what the bank's encodings need (olen*2 for
  * mono S16), so that a block's PCM is one contiguous device-to-host copy of only the bytes that matter */

@@ -75,6 +75,7 @@ struct Bank {
   // the linear demodulator behind the channel outputs; allocated by the first chz_bank_set_demod
   DemodChan* dm_chan = nullptr;          // [cap]
   DemodState* dm_state = nullptr;        // [cap]
+  DemodExt* dm_ext = nullptr;            // [cap] PLL / tone-squelch state; allocated when the first channel asks for either
   DemodStatus* dm_status = nullptr;      // [ND][cap]
   unsigned char* dm_pcm = nullptr;       // [ND][cap][pcm_stride]
   std::vector<DemodChan> dm_chan_h;      // [cap]
@@ -206,8 +207,8 @@ template <class T> static int upload(T** dst, const std::vector<f2>& v) {
 static void free_bank(Bank& b) {
   hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub);
   hipFree(b.fine); hipFree(b.power); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam);
-  hipFree(b.dm_chan); hipFree(b.dm_state); hipFree(b.dm_status); hipFree(b.dm_pcm);
-  b.dm_chan = nullptr; b.dm_state = nullptr; b.dm_status = nullptr; b.dm_pcm = nullptr; b.dm_on = 0; b.dm_chan_h.clear(); b.dm_osc.clear();
+  hipFree(b.dm_chan); hipFree(b.dm_state); hipFree(b.dm_ext); hipFree(b.dm_status); hipFree(b.dm_pcm);
+  b.dm_chan = nullptr; b.dm_state = nullptr; b.dm_ext = nullptr; b.dm_status = nullptr; b.dm_pcm = nullptr; b.dm_on = 0; b.dm_chan_h.clear(); b.dm_osc.clear();
   for (int s = 0; s < CHZ_ND; s++) {
     if (b.ev_bank[s]) (void)hipEventDestroy(b.ev_bank[s]);
     if (b.ev_tail[s]) (void)hipEventDestroy(b.ev_tail[s]);
@@ -721,7 +722,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
       HIPOK(hipStreamWaitEvent(ts, b.ev_bank[slot], 0));
     }
     DemodParams d{};
-    d.in = bank_out(b, slot); d.power = b.power + so; d.n0 = b.n0 + so; d.chan = b.dm_chan; d.state = b.dm_state;
+    d.in = bank_out(b, slot); d.power = b.power + so; d.n0 = b.n0 + so; d.chan = b.dm_chan; d.state = b.dm_state; d.ext = b.dm_ext;
     d.status = b.dm_status + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = n; d.olen = b.olen;
     d.pcm_stride = b.pcm_stride; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;      // Power_alpha, src/radio.c:72
     mark(in, ts, 6, true);
@@ -1070,6 +1071,7 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
   if (!b.power || !b.n0 || b.noise_samprate <= 0.0)
     return fail(-1, "the demodulator needs the channel's bb_power and noise estimate: call chz_bank_set_tuning and chz_bank_enable_noise first");
   if (!b.pcm_stride) b.pcm_stride = b.olen * 8;
+  bool need_ext = false;
   for (int i = 0; i < n; i++) {
     const chz_demod_params& q = p[i];
     if (q.channels < 0 || q.channels > 2 || q.encoding < CHZ_PCM_S16BE || q.encoding > CHZ_PCM_F32BE) return fail(-1, "bad demodulator parameters for channel %d", ch0 + i);
@@ -1079,6 +1081,10 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
       return fail(-1, "bad demodulator parameters for channel %d", ch0 + i);
     if (q.kind != CHZ_DEMOD_LINEAR && q.kind != CHZ_DEMOD_FM) return fail(-1, "unknown demodulator kind for channel %d", ch0 + i);
     if (q.channels > 1 && q.kind == CHZ_DEMOD_FM) return fail(-1, "the FM demodulator is mono (src/fm.c:37)");
+    if (q.channels > 0 && q.pll_enable && q.kind == CHZ_DEMOD_LINEAR && !(q.pll_loop_bw > 0 && std::isfinite(q.pll_loop_bw)))
+      return fail(-1, "channel %d: the PLL needs a loop bandwidth", ch0 + i);
+    if (q.channels > 0 && !(q.tone_freq >= 0 && q.tone_freq < q.samprate / 2)) return fail(-1, "bad PL tone frequency for channel %d", ch0 + i);
+    if (q.channels > 0 && (q.pll_enable || (q.kind == CHZ_DEMOD_FM && q.tone_freq != 0))) need_ext = true;
   }
   HIPOK(hipSetDevice(e->device));
   if (!e->tail) HIPOK(hipStreamCreateWithFlags(&e->tail, hipStreamNonBlocking));
@@ -1100,6 +1106,13 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
     drop_graph(e);
   }
   HIPOK(hipStreamSynchronize(e->tail));      // the demodulator stream only: blocks already handed to it keep their parameters
+  if (need_ext && !b.dm_ext) {
+    // every channel gets the record init_pll() / the tone set-up would leave, whether or not it uses it yet
+    std::vector<DemodExt> fresh((size_t)b.cap, demod_ext_init());
+    HIPOK(hipMalloc((void**)&b.dm_ext, sizeof(DemodExt) * (size_t)b.cap));
+    HIPOK(hipMemcpy(b.dm_ext, fresh.data(), sizeof(DemodExt) * (size_t)b.cap, hipMemcpyHostToDevice));
+    drop_graph(e);
+  }
   std::vector<DemodState> init; std::vector<int> init_ch;
   for (int i = 0; i < n; i++) {
     const chz_demod_params& q = p[i];
@@ -1111,6 +1124,25 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
     c.samprate = q.samprate; c.headroom = q.headroom; c.threshold = q.threshold; c.recovery_rate = q.recovery_rate; c.hangtime = q.hangtime;
     c.dc_alpha = q.dc_alpha; c.bandwidth = q.bandwidth; c.squelch_open = q.squelch_open; c.squelch_close = q.squelch_close;
     c.kind = q.kind; c.deemph_rate = q.deemph_rate; c.deemph_gain = q.deemph_gain; c.threshold_extend = q.threshold_extend;
+    const bool pll_was = was_on && c.pll_enable != 0;
+    const double tone_was = was_on ? c.tone_freq : 0.0;
+    c.pll_enable = q.pll_enable != 0; c.pll_square = q.pll_square != 0; c.pll_loop_bw = q.pll_loop_bw;
+    demod_tone_consts(q.kind == CHZ_DEMOD_FM ? q.tone_freq : 0.0, q.samprate, c);
+    if (b.dm_ext) {
+      DemodExt x;
+      if (!was_on) {                                    // a new demodulator: init_pll(), tone squelch muted
+        x = demod_ext_init();
+        HIPOK(hipMemcpy(b.dm_ext + ch0 + i, &x, sizeof x, hipMemcpyHostToDevice));
+      } else if ((c.pll_enable && !pll_was && c.kind == CHZ_DEMOD_LINEAR) || c.tone_freq != tone_was) {
+        HIPOK(hipMemcpy(&x, b.dm_ext + ch0 + i, sizeof x, hipMemcpyDeviceToHost));
+        if (c.pll_enable && !pll_was && c.kind == CHZ_DEMOD_LINEAR) {
+          // what the blocks that ran with the PLL off left behind (src/linear.c:150-154); the loop itself keeps its state
+          x.pll.lock = 0; x.pll.lock_count = -(int)std::lrint(0.5 * (int)q.samprate); x.pll_rotations = 0;
+        }
+        if (c.tone_freq != tone_was) { x.g_s0 = x.g_s1 = 0.0; x.pl_sample_count = 0; x.old_pl_phase = 0.0; x.tone_mute = 1; x.tone_deviation = 0.0; }
+        HIPOK(hipMemcpy(b.dm_ext + ch0 + i, &x, sizeof x, hipMemcpyHostToDevice));
+      }
+    }
     // chan->shift: set_osc() keeps the phase when the frequency changes (src/osc.c:28-47); an oscillator at 0 Hz is not stepped (src/linear.c:170)
     Bank::OscHost& o = b.dm_osc[(size_t)(ch0 + i)];
     const double f = q.shift / q.samprate;
@@ -1126,7 +1158,7 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
       b.dm_on++;
       DemodState st; memset(&st, 0, sizeof st);
       st.gain = q.gain; st.am_dc = 0.0; st.n0 = std::nan(""); st.hangcount = 0;
-      st.squelch_state = c.kind == CHZ_DEMOD_FM ? 0 : (!c.snr_squelch ? c.squelch_tail + 4 : 0);   // src/fm.c:58, src/linear.c:46
+      st.squelch_state = c.kind == CHZ_DEMOD_FM ? 0 : ((!c.pll_enable && !c.snr_squelch) ? c.squelch_tail + 4 : 0);   // src/fm.c:58, src/linear.c:46
       st.squelch_open = 1;                                                              // src/linear.c:47
       init.push_back(st); init_ch.push_back(ch0 + i);
     }
@@ -1135,6 +1167,39 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
   for (size_t k = 0; k < init.size(); k++)
     HIPOK(hipMemcpy(b.dm_state + init_ch[k], &init[k], sizeof(DemodState), hipMemcpyHostToDevice));
   b.dm_blocktime = blocktime;
+  return 0;
+}
+// Demodulate blocks that did not come out of this bank's channel kernel: radiod runs a channel's samples through its private
+// second filter (filter2, src/radio.c:1572-1594 -- chz_mini_* here) BEFORE the demodulator sees them, so the caller must be able
+// to hand the demodulator stage its input.  chz_bank_write_block puts n channels' olen complex samples, bb_power and noise
+// estimates into `slot`; chz_bank_demod runs the demodulators of the whole bank over what the slot holds, as block `job`.
+int chz_bank_write_block(chz_engine* e, int bank, int slot, int ch0, int n, const float* samples, const double* bb_power, const double* n0) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (slot < 0 || slot >= CHZ_ND || !samples) return fail(-1, "bad argument");
+  Bank& b = e->banks[(size_t)bank];
+  if (b.out_real) return fail(-1, "the demodulators follow COMPLEX-output channels");
+  if (!b.dm_chan) return fail(-1, "bank has no demodulator: call chz_bank_set_demod first");
+  HIPOK(hipSetDevice(e->device));
+  const size_t so = (size_t)slot * b.cap + ch0;
+  HIPOK(hipMemcpyAsync(bank_out(b, slot) + (size_t)ch0 * b.olen, samples, sizeof(float2) * (size_t)n * b.olen, hipMemcpyHostToDevice, e->tail));
+  if (bb_power) HIPOK(hipMemcpyAsync(b.power + so, bb_power, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, e->tail));
+  if (n0) HIPOK(hipMemcpyAsync(b.n0 + so, n0, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, e->tail));
+  HIPOK(hipStreamSynchronize(e->tail));            // the caller's buffers are free again
+  return 0;
+}
+int chz_bank_demod(chz_engine* e, int bank, unsigned job, int slot) {
+  BANK_CHECK(e, bank, 0, 0);
+  if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
+  Bank& b = e->banks[(size_t)bank];
+  if (!b.dm_chan || b.dm_on <= 0) return fail(-1, "bank has no demodulator: call chz_bank_set_demod first");
+  HIPOK(hipSetDevice(e->device));
+  const size_t so = (size_t)slot * b.cap;
+  DemodParams d{};
+  d.in = bank_out(b, slot); d.power = b.power + so; d.n0 = b.n0 + so; d.chan = b.dm_chan; d.state = b.dm_state; d.ext = b.dm_ext;
+  d.status = b.dm_status + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = b.active; d.olen = b.olen;
+  d.pcm_stride = b.pcm_stride; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;
+  launch_demod(e->tail, d);
+  HIPOK(hipGetLastError());
   return 0;
 }
 int chz_bank_pcm_stride(chz_engine* e, int bank) {

@@ -1088,16 +1088,28 @@ struct DemodChan {               // per channel, set by the host (names: the cha
   double osc_phase0, osc_freq;   // chan->shift as a closed form in the block number: phase (cycles) at sample 0 of block osc_job0
   unsigned osc_job0; int kind;   // kind 0: linear demodulator (src/linear.c), 1: FM (src/fm.c)
   double deemph_rate, deemph_gain, threshold_extend;      // FM: chan->fm.rate, chan->fm.gain, chan->fm.threshold
+  int pll_enable, pll_square;    // chan->pll.enable / .square (linear: src/linear.c:83-153; FM: src/fm.c:176-203)
+  double pll_loop_bw;            // chan->pll.loop_bw, Hz
+  double tone_freq;              // FM: chan->fm.tone_freq (0 = no PL tone squelch, src/fm.c:264-311)
+  double g_coeff, g_cfr, g_cfi;  // init_goertzel(tone_freq / samprate) (src/iir.c:32-39), computed by the host
 };
-struct DemodState { double gain, am_dc, n0; int hangcount, squelch_state, squelch_open, pad;
+// State of the coherent modes and of the PL-tone squelch; only channels that use them touch it (one lane, sequentially).
+struct PllState { unsigned vco_phase; int vco_step, wraps, lock, lock_count, pad;         // struct pll (src/osc.h:21-32) + chan->pll.lock / .lock_count
+                  double bw, damping, lower, upper, u, phi, K1, K2; };
+struct DemodExt { PllState pll; double pll_snr, pll_cphase, foffset;                       // chan->pll.snr / .cphase, chan->sig.foffset (linear)
+                  double g_s0, g_s1, old_pl_phase, tone_deviation;                         // Goertzel state, src/fm.c:60, chan->fm.tone_deviation
+                  int pll_rotations, pl_sample_count, tone_mute, pad; };
+struct DemodState { double gain, am_dc, n0; int hangcount, squelch_state, squelch_open, pll_was_on;   // pll_was_on: chan->pll.was_on (FM, src/fm.c:178-184,209)
                     double pm_re, pm_im, deemph_state, foffset, pdeviation; };   // FM: phase_memory, de-emphasis state, chan->sig.foffset, chan->fm.pdeviation
-struct DemodStatus { int frame, mute, squelch_state, pad; double output_power, gain, n0, snr, foffset, pdeviation; };   // frame 0 = PCM present, 1 = silence
+struct DemodStatus { int frame, mute, squelch_state, pll_lock; double output_power, gain, n0, snr, foffset, pdeviation;   // frame 0 = PCM present, 1 = silence
+                     double pll_snr, pll_cphase, tone_deviation; int pll_rotations, tone_mute; };
 struct DemodParams {
   const float2* in;          // [cap][olen] this slot's channel outputs (after fine tuning)
   const double* power;       // [cap] this slot's bb_power
   const double* n0;          // [cap] this slot's noise estimates
   const DemodChan* chan;     // [cap]
   DemodState* state;         // [cap]
+  DemodExt* ext;             // [cap] PLL / tone-squelch state (read only by channels that enable them)
   DemodStatus* status;       // [cap] this slot
   unsigned char* pcm;        // [cap][pcm_stride] this slot
   int ch0, nch, olen, pcm_stride;
@@ -1175,9 +1187,57 @@ __device__ inline double fm_snr_dev(double r) {
   return thetasq;
 }
 
-// demod_fm()'s per-block work (src/fm.c:19-345) without the PLL (:174-203) and PL-tone (:264-311) branches, one wavefront
-// per channel, lane l owning SEG consecutive samples.  esh[] is per-lane scratch: every lane reads only what it wrote.
-__device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodChan& c, DemodState st, int ch, int lane, double* esh) {
+// ---- the PLL of the coherent modes (src/osc.c:75-205).  A PLL is a recurrence through a non-linear phase detector: it runs
+// sample by sample on ONE lane of the channel's wavefront (the block sits in LDS); channels are independent, so a launch still
+// keeps one lane busy per PLL channel.  nco(): the reference indexes a table of sin(pi/2 * i/1024); the same values are
+// computed here (sincospi, within an ulp of a double of the table's), the second-order interpolation step is the reference's.
+__device__ inline void pll_nco(unsigned accum, double& s, double& c) {
+  const unsigned fract = accum & ((1u << 20) - 1);
+  unsigned tab = (accum >> 20) & 1023u;
+  unsigned quad = accum >> 30;
+  tab = (quad & 1) ? 1024 - tab : tab;
+  double ts, tc;
+  sincospi((double)tab * (1.0 / 2048.0), &ts, &tc);                        // Lookup[tab], Lookup[1024 - tab]
+  const double sine = (quad & 2) ? -ts : ts;
+  quad++;
+  const double cosine = (quad & 2) ? -tc : tc;
+  const double diff = 2 * M_PI * ldexp((double)fract, -32);
+  const double cdiff = cosine * diff, sdiff = sine * diff;
+  s = sine + cdiff - 0.5 * sdiff * diff;
+  c = cosine - sdiff - 0.5 * cdiff * diff;
+}
+__host__ __device__ inline void pll_set_params(PllState& q, double bw, double damping) {     // src/osc.c:152-167
+  if (bw == 0 || (bw == q.bw && damping == q.damping)) return;
+  const double denom = damping + 1.0 / (4.0 * damping);
+  const double theta = 4.0 * M_PI * fabs(bw) / denom;
+  q.bw = bw; q.damping = damping;
+  const double D = 1.0 + 2.0 * damping * theta + theta * theta;
+  q.K1 = 4.0 * damping * theta / D;
+  q.K2 = 4.0 * theta * theta / D;
+}
+__host__ __device__ inline void pll_init(PllState& q) {                                       // src/osc.c:130-136
+  q.vco_phase = 0; q.vco_step = 0; q.wraps = 0; q.bw = 0; q.damping = 0; q.u = 0; q.phi = 0; q.K1 = 0; q.K2 = 0;
+  q.lower = -0.5; q.upper = +0.5;
+  pll_set_params(q, 0.01, M_SQRT1_2);
+}
+__device__ inline double pll_run(PllState& q, double phase) {                                 // src/osc.c:174-205
+  double u_new = q.u + q.K2 * phase;
+  double dphi = u_new + q.K1 * phase;
+  if (dphi > q.upper) { dphi = q.upper; if (phase > 0) u_new = q.u; }
+  else if (dphi < q.lower) { dphi = q.lower; if (phase < 0) u_new = q.u; }
+  q.u = u_new;
+  q.phi += dphi;
+  if (q.phi > 1) { q.phi -= 1; q.wraps++; }
+  else if (q.phi < -1) { q.phi += 1; q.wraps--; }
+  q.vco_step = (int)ldexp(dphi, 32);
+  q.vco_phase += (unsigned)q.vco_step;
+  return q.u;
+}
+
+// demod_fm()'s per-block work (src/fm.c:19-345), one wavefront per channel, lane l owning SEG consecutive samples.  esh[] is
+// per-lane scratch (every lane reads only what it wrote) except around the two sequential stages -- the PLL demodulator
+// (:176-203) and the PL-tone detector (:264-311) -- which lane 0 runs over the whole block between wavefront syncs.
+__device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodChan& c, DemodState st, int ch, int lane, double* esh, float2* xs) {
   const int N = p.olen;
   const int SEG = (N + 63) >> 6;
   const int n0 = lane * SEG;
@@ -1186,6 +1246,7 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
   unsigned char* __restrict__ o = p.pcm + (size_t)ch * p.pcm_stride;
   const double bb_power = p.power[ch];
   const double samprate = c.samprate, devmax = 5000.0, beta = 0.5;             // src/fm.c:43,103
+  const bool tone = c.tone_freq != 0, pll = c.pll_enable != 0;                  // wave-uniform
   const double est = p.n0[ch];
   if (st.n0 != st.n0) st.n0 = est;
   else { const double diff = est - st.n0; st.n0 += p.power_alpha * diff; }
@@ -1209,43 +1270,87 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
   if (fmsnr >= c.squelch_open) st.squelch_state = smax;
   else if (st.squelch_state > 0 && (fmsnr < c.squelch_close || st.squelch_state < smax)) st.squelch_state--;
   DemodStatus r;
-  r.pad = 0; r.n0 = st.n0; r.snr = fmsnr; r.squelch_state = st.squelch_state; r.gain = 0.0;
+  r.pll_lock = 0; r.pll_snr = 0.0; r.pll_cphase = 0.0; r.pll_rotations = 0; r.tone_deviation = 0.0; r.tone_mute = 0;
+  r.n0 = st.n0; r.snr = fmsnr; r.squelch_state = st.squelch_state; r.gain = 0.0;
+  DemodExt* __restrict__ ext = p.ext + ch;                                      // touched by lane 0 only, and only with pll / tone
   if (st.squelch_state <= 4) {                                                  // :157-173
     if (st.squelch_state >= 1) { st.pm_re = 0.0; st.pm_im = 0.0; }
     r.frame = 1; r.mute = st.squelch_state == 0; r.output_power = 0.0; r.foffset = st.foffset; r.pdeviation = st.pdeviation;
-    if (lane == 0) { p.status[ch] = r; p.state[ch] = st; }
+    if (lane == 0) {
+      if (tone) {
+        if (st.squelch_state == 4) { ext->g_s0 = 0.0; ext->g_s1 = 0.0; }        // reset_goertzel
+        if (st.squelch_state >= 1) ext->pl_sample_count = 0;
+        r.tone_deviation = ext->tone_deviation; r.tone_mute = ext->tone_mute;
+      }
+      p.status[ch] = r; p.state[ch] = st;
+    }
     return;
   }
-  // :204-231 discriminator: phase of x[n] * conj(x[n-1]); the sample before the block is phase_memory
+  if (pll) {
+    // :176-203 PLL demodulator: the block goes to LDS, lane 0 walks it
+    for (int i = 0; i < cnt; i++) xs[n0 + i] = x[n0 + i];
+    CHZ_WAVE_SYNC();
+    if (lane == 0) {
+      PllState q = ext->pll;
+      const int isamprate = (int)samprate;
+      const double pdev = devmax / isamprate;
+      if (!st.pll_was_on) {
+        pll_init(q);
+        pll_set_params(q, 500.0 / isamprate, M_SQRT1_2);
+        q.lower = -pdev; q.upper = +pdev;
+      }
+      for (int n = 0; n < N; n++) {
+        double sn, cs; pll_nco(q.vco_phase, sn, cs);
+        const float2 v = xs[n];
+        const double br = v.x, bi = v.y;
+        const double sr = br * cs + bi * sn, si = bi * cs - br * sn;            // buffer[n] * conj(vco)
+        double phase = M_1_PI * atan2(si, sr);
+        if (c.threshold_extend != 0) {
+          if (fabs(phase) > pdev) phase = copysign(pdev, phase);
+          float a = v.x * v.x, b = v.y * v.y; CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
+          double pw = (double)(a + b);
+          if (pw > 0) { pw /= (pw + beta * noise); phase *= pw; }
+          else phase = 0;
+        }
+        esh[n] = (double)(float)(2 * pll_run(q, phase));
+      }
+      ext->pll = q;
+    }
+    st.pll_was_on = 1;
+    CHZ_WAVE_SYNC();
+  } else {
+    st.pll_was_on = 0;                                                          // :209
+    // :204-231 discriminator: phase of x[n] * conj(x[n-1]); the sample before the block is phase_memory
+    for (int i = 0; i < cnt; i++) {
+      const int n = n0 + i;
+      const float2 v = x[n];
+      double pr, pi, p0;
+      if (n == 0) { pr = st.pm_re; pi = st.pm_im; p0 = pr * pr + pi * pi; }
+      else { const float2 w = x[n - 1]; pr = w.x; pi = w.y; float a = w.x * w.x, b = w.y * w.y; CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b); p0 = (double)(a + b); }
+      const double br = v.x, bi = v.y;
+      const double sr = br * pr + bi * pi, si = bi * pr - br * pi;
+      double phase = M_1_PI * atan2(si, sr);
+      if (c.threshold_extend != 0) {
+        if (fabs(phase) > devmax / samprate) phase = copysign(devmax / samprate, phase);
+        if (p0 > 0) p0 /= (p0 + beta * noise);
+        float a = v.x * v.x, b = v.y * v.y; CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
+        double p1 = (double)(a + b);
+        if (p1 > 0) p1 /= (p1 + beta * noise);
+        phase *= p0 * p1;
+      }
+      esh[n] = (double)(float)phase;
+    }
+  }
   double psum = 0.0, pmax = 0.0, pmin = 0.0;
   for (int i = 0; i < cnt; i++) {
-    const int n = n0 + i;
-    const float2 v = x[n];
-    double pr, pi, p0;
-    if (n == 0) { pr = st.pm_re; pi = st.pm_im; p0 = pr * pr + pi * pi; }
-    else { const float2 w = x[n - 1]; pr = w.x; pi = w.y; float a = w.x * w.x, b = w.y * w.y; CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b); p0 = (double)(a + b); }
-    const double br = v.x, bi = v.y;
-    const double sr = br * pr + bi * pi, si = bi * pr - br * pi;
-    double phase = M_1_PI * atan2(si, sr);
-    if (c.threshold_extend != 0) {
-      if (fabs(phase) > devmax / samprate) phase = copysign(devmax / samprate, phase);
-      if (p0 > 0) p0 /= (p0 + beta * noise);
-      float a = v.x * v.x, b = v.y * v.y; CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
-      double p1 = (double)(a + b);
-      if (p1 > 0) p1 /= (p1 + beta * noise);
-      phase *= p0 * p1;
-    }
-    const float bbv = (float)phase;
-    esh[n] = (double)bbv;
-    psum += (double)bbv;
-    if ((double)bbv > pmax) pmax = (double)bbv;
-    if ((double)bbv < pmin) pmin = (double)bbv;
+    const double bbv = esh[n0 + i];
+    psum += bbv;
+    if (bbv > pmax) pmax = bbv;
+    if (bbv < pmin) pmin = bbv;
   }
   {
-    const int last_lane = (N - 1) / SEG;                                        // phase_memory = the block's last sample
-    const float2 lastv = x[N - 1];
+    const float2 lastv = x[N - 1];                                              // phase_memory = the block's last sample
     st.pm_re = lastv.x; st.pm_im = lastv.y;
-    (void)last_lane;
   }
   if (st.squelch_state == smax) {                                               // :232-256
     double foff = wave_sum(psum) * (samprate * 0.5 / N);
@@ -1257,6 +1362,7 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
   }
   const bool pm = c.deemph_rate != 0;
   const float dc = (float)(2 * st.foffset / samprate);                          // :258-263
+  const double deemph_before = st.deemph_state;
   double y_in = st.deemph_state;
   if (pm) {                                                                     // :312-320 as a scan of affine maps
     double A = 1.0, B = 0.0;
@@ -1273,6 +1379,46 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
     const double Ae = __shfl_up(A, 1), Be = __shfl_up(B, 1);
     y_in = lane == 0 ? st.deemph_state : Ae * st.deemph_state + Be;
     st.deemph_state = __shfl(A, 63) * st.deemph_state + __shfl(B, 63);
+  }
+  if (tone) {
+    // :264-311 PL / CTCSS tone squelch on the baseband after DC removal and before de-emphasis: a Goertzel detector integrated over
+    // 0.24 s (12 blocks), the decision taken where the count runs out -- sequential, lane 0.  (The 300 Hz low-pass of :269-270
+    // only feeds lpf_energy, read solely behind `chan->options & (1LL<1)`, i.e. never: it has no observable effect.)
+    CHZ_WAVE_SYNC();
+    int tmute = 0; double tdev = 0.0;
+    if (lane == 0) {
+      double s0 = ext->g_s0, s1 = ext->g_s1, old_phase = ext->old_pl_phase;
+      int count = ext->pl_sample_count; tmute = ext->tone_mute; tdev = ext->tone_deviation;
+      const int isamprate = (int)samprate;
+      const int integrate = (int)rint(isamprate * 0.24);
+      for (int n = 0; n < N; n++) {
+        { const double t = esh[n] + c.g_coeff * s0 - s1; s1 = s0; s0 = t; }     // update_goertzel
+        if (++count >= integrate) {
+          { const double t = 0.0 + c.g_coeff * s0 - s1; s1 = s0; s0 = t; }      // output_goertzel: one zero sample
+          const double cre = s0 - c.g_cfr * s1, cim = -c.g_cfi * s1;
+          const double g = sqrt(cre * cre + cim * cim) / count;
+          tdev = isamprate * g;
+          const double ph = atan2(cim, cre) / (2 * M_PI);
+          old_phase += c.tone_freq * count / isamprate;
+          double ip;
+          double np = 2 * modf(ph - old_phase, &ip);
+          old_phase = ph;
+          np = np < -1 ? np + 2 : np > 1 ? np - 2 : np;
+          tmute = tdev < 250 || fabs(np) > .10;
+          s0 = 0.0; s1 = 0.0; count = 0;
+        }
+      }
+      ext->g_s0 = s0; ext->g_s1 = s1; ext->old_pl_phase = old_phase; ext->pl_sample_count = count;
+      ext->tone_mute = tmute; ext->tone_deviation = tdev;
+    }
+    tmute = __shfl(tmute, 0); tdev = __shfl(tdev, 0);
+    r.tone_deviation = tdev; r.tone_mute = tmute;
+    if (tmute) {                                                                // :305-309: muted before de-emphasis runs
+      st.deemph_state = deemph_before;
+      r.frame = 1; r.mute = 1; r.output_power = 0.0; r.foffset = st.foffset; r.pdeviation = st.pdeviation;
+      if (lane == 0) { p.status[ch] = r; p.state[ch] = st; }
+      return;
+    }
   }
   const double gain = (2 * c.headroom * samprate) / c.bandwidth;                // :325
   double part = 0.0;
@@ -1291,7 +1437,7 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
 }
 
 __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
-  HIP_DYNAMIC_SHARED(double, esh)                          // [N] per-sample energies (AGC slices)
+  HIP_DYNAMIC_SHARED(double, esh)                          // [N] per-sample energies (AGC slices), then [N] complex samples (PLL modes)
   const int lane = (int)threadIdx.x;
   const int lc = (int)blockIdx.x;
   if (lc >= p.nch) return;
@@ -1299,7 +1445,8 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   const DemodChan c = p.chan[ch];
   if (!c.on) return;
   DemodState st = p.state[ch];
-  if (c.kind == 1) { demod_fm_wave(p, c, st, ch, lane, esh); return; }     // wave-uniform
+  float2* xs = reinterpret_cast<float2*>(esh + p.olen);
+  if (c.kind == 1) { demod_fm_wave(p, c, st, ch, lane, esh, xs); return; }     // wave-uniform
   const int N = p.olen;
   const int SEG = (N + 63) >> 6;
   const int n0 = lane * SEG;                               // first sample of this lane
@@ -1311,6 +1458,61 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   const double est = p.n0[ch];
   if (st.n0 != st.n0) st.n0 = est;
   else { const double diff = est - st.n0; st.n0 += p.power_alpha * diff; }
+  // ---- coherent modes (src/linear.c:76-153): the PLL mixes the block down with its VCO, sample by sample, before anything else
+  // looks at it.  The block goes to LDS, lane 0 walks it, the mixed samples replace it there.
+  const bool pll = c.pll_enable != 0;                      // wave-uniform
+  double pll_snr = 0.0, pll_cph = 0.0, pll_foff = 0.0; int pll_lock = 0, pll_rot = 0;
+  if (pll) {
+    DemodExt* __restrict__ ext = p.ext + ch;
+    for (int i = 0; i < cnt; i++) xs[n0 + i] = x[n0 + i];
+    CHZ_WAVE_SYNC();
+    if (lane == 0) {
+      PllState q = ext->pll;
+      const int isamprate = (int)c.samprate;
+      const int lock_limit = (int)rint(0.5 * isamprate);                      // DEFAULT_PLL_LOCKTIME (:6,:38-40)
+      double bw = c.pll_loop_bw / isamprate;
+      if (q.lock) bw *= 0.1;
+      pll_set_params(q, bw, M_SQRT1_2);                                        // DEFAULT_PLL_DAMPING (:5)
+      double signal = 0.0, noise = 0.0;
+      pll_foff = ext->foffset;
+      for (int n = 0; n < N; n++) {
+        double sn, cs; pll_nco(q.vco_phase, sn, cs);
+        const float2 v = xs[n];
+        const double br = v.x, bi = v.y;
+        const double sr = br * cs + bi * sn, si = bi * cs - br * sn;           // buffer[n] * conj(vco)
+        xs[n] = make_float2((float)sr, (float)si);
+        double phase;
+        if (q.lock) {
+          if (!c.pll_square) { const double mag = sqrt(sr * sr + si * si); phase = (mag > 0) ? si / mag : 0.0; }
+          else phase = sr * si / (sr * sr - si * si);
+        } else {
+          if (!c.pll_square) phase = atan2(si, sr);
+          else phase = 0.5 * atan2(sr * si + si * sr, sr * sr - si * si);      // carg(s*s)
+        }
+        phase /= (2 * M_PI);
+        pll_foff = isamprate * pll_run(q, phase);
+        signal += sr * sr; noise += si * si;
+      }
+      pll_cph = ldexp(2 * M_PI * (double)q.vco_phase, -32);
+      pll_rot = q.wraps;
+      if (noise != 0) { pll_snr = (signal / noise) - 1; if (pll_snr < 0) pll_snr = 0; }
+      else pll_snr = __builtin_nan("");
+      if (pll_snr < c.squelch_close) {
+        q.lock_count -= N;
+        if (q.lock_count <= -lock_limit) { q.lock_count = -lock_limit; q.lock = 0; }
+      } else if (pll_snr > c.squelch_open) {
+        q.lock_count += N;
+        if (q.lock_count >= lock_limit) {
+          q.lock_count = lock_limit;
+          if (!q.lock) { q.lock = 1; pll_rot = 0; }
+        }
+      }
+      pll_lock = q.lock;
+      ext->pll = q; ext->pll_snr = pll_snr; ext->pll_cphase = pll_cph; ext->foffset = pll_foff; ext->pll_rotations = pll_rot;
+    }
+    CHZ_WAVE_SYNC();
+    pll_snr = __shfl(pll_snr, 0);                          // the squelch decisions below are taken by every lane
+  }
   // chan->shift (src/linear.c:168-172): this lane's phasor at its first sample from the closed form, then stepped in double
   const bool rot = c.osc_freq != 0.0;
   double c0 = 1.0, s0 = 0.0, c1 = 1.0, s1 = 0.0;
@@ -1331,7 +1533,7 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
     {
       double cr = c0, sr = s0;
       for (int i = 0; i < cnt; i++) {
-        float2 v = x[n0 + i];
+        float2 v = pll ? xs[n0 + i] : x[n0 + i];
         if (rot) {
           const double xr = v.x, xi = v.y;
           v = make_float2((float)(xr * cr - xi * sr), (float)(xr * sr + xi * cr));
@@ -1372,8 +1574,9 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   // the two do not interact, and knowing the frame type up front saves packing PCM nobody will send.
   double snr = __builtin_huge_val();
   if (c.snr_squelch) snr = (bb_power / (st.n0 * c.bandwidth)) - 1.0;
+  else if (pll) snr = pll_snr;                                                 // :317-318
   const int smax = c.squelch_tail + 4;
-  if (!c.snr_squelch || snr >= c.squelch_open) st.squelch_state = smax;
+  if (!(c.snr_squelch || pll) || snr >= c.squelch_open) st.squelch_state = smax;
   else if (st.squelch_state > 0 && snr < c.squelch_close) st.squelch_state--;
   const bool data = st.squelch_state >= 4;
   // ---- final pass (src/linear.c:236-311); the gain ramp and the carrier filter run whether or not the frame is sent
@@ -1388,7 +1591,7 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
     {
       double g = gain, cr = c0, sr = s0;
       for (int i = 0; i < cnt; i++) {
-        float2 v = x[n0 + i];
+        float2 v = pll ? xs[n0 + i] : x[n0 + i];
         if (rot) {
           const double xr = v.x, xi = v.y;
           v = make_float2((float)(xr * cr - xi * sr), (float)(xr * sr + xi * cr));
@@ -1416,7 +1619,7 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
     const int enc = c.encoding;
     for (int i = 0; i < cnt; i++) {
       const int n = n0 + i;
-      float2 v = x[n];
+      float2 v = pll ? xs[n] : x[n];
       if (rot) {
         const double xr = v.x, xi = v.y;
         v = make_float2((float)(xr * cr - xi * sr), (float)(xr * sr + xi * cr));
@@ -1458,13 +1661,14 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   double output_power = wave_sum(part) / N;
   if (c.channels == 1) output_power *= 2;
   DemodStatus r;
-  r.pad = 0; r.gain = st.gain; r.n0 = st.n0; r.snr = snr; r.squelch_state = st.squelch_state;
-  r.output_power = output_power; r.foffset = 0.0; r.pdeviation = 0.0;
+  r.gain = st.gain; r.n0 = st.n0; r.snr = snr; r.squelch_state = st.squelch_state;
+  r.output_power = output_power; r.foffset = pll_foff; r.pdeviation = 0.0;
+  r.pll_lock = pll_lock; r.pll_snr = pll_snr; r.pll_cphase = pll_cph; r.pll_rotations = pll_rot; r.tone_deviation = 0.0; r.tone_mute = 0;
   if (!data) {
     r.frame = 1; r.mute = st.squelch_state == 0;
     if (st.squelch_state == 3 || st.squelch_state == 0) r.output_power = 0;
   } else {
-    if (c.snr_squelch) {
+    if (c.snr_squelch || pll) {
       if (snr < c.squelch_close) st.squelch_open = 0;
       else if (!st.squelch_open && snr > c.squelch_open) { st.squelch_open = 1; st.am_dc = 0; }
     } else st.squelch_open = 1;

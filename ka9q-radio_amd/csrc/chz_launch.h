@@ -2,6 +2,8 @@
 // Shared by chz_engine.hip (hipcc, real launches on a HIP stream) and the CPU
 // test harness (tests/hipemu), so both exercise the same template instances.
 #pragma once
+#include <cstring>
+#include <cmath>
 #include <cmath>
 #include "chz_kernels.h"
 #include "chz_plan.h"
@@ -80,8 +82,21 @@ inline NotchTables notch_tables(const int* bins, int n, const SpecLayout& lay) {
 }
 inline int launch_demod(hipStream_t s, const DemodParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   if (p.nch <= 0) return 0;
-  CHZ_LAUNCH(demod_linear_tail, p.nch, 64, sizeof(double) * (size_t)p.olen, s, e0, e1, p);     // one wavefront per channel
+  CHZ_LAUNCH(demod_linear_tail, p.nch, 64, 16 * (size_t)p.olen, s, e0, e1, p);     // one wavefront per channel; LDS: N doubles + N complex
   return 0;
+}
+// host side of the coherent modes and the PL-tone squelch: what init_pll() (src/osc.c:130-136, called once when the demodulator
+// starts, src/linear.c:41) and the tone set-up of demod_fm() (src/fm.c:50-61) leave behind
+inline DemodExt demod_ext_init() {
+  DemodExt x; std::memset(&x, 0, sizeof x);
+  pll_init(x.pll);
+  x.tone_mute = 1;                                     // muted until the tone has been seen (src/fm.c:61)
+  return x;
+}
+inline void demod_tone_consts(double tone_freq, double samprate, DemodChan& c) {          // init_goertzel(), src/iir.c:32-39
+  c.tone_freq = tone_freq;
+  const double f = tone_freq / (double)(int)samprate;
+  c.g_coeff = 2 * std::cos(2 * M_PI * f); c.g_cfr = std::cos(2 * M_PI * f); c.g_cfi = -std::sin(2 * M_PI * f);
 }
 inline int launch_noise(int nch, hipStream_t s, const NoiseParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   const int grid = (nch + 3) / 4;          // four wavefronts = four channels per workgroup

@@ -36,12 +36,14 @@ class DemodParams(C.Structure):
                 ("tuned", _i), ("kind", _i),
                 ("samprate", _d), ("headroom", _d), ("threshold", _d), ("recovery_rate", _d), ("hangtime", _d), ("dc_alpha", _d),
                 ("bandwidth", _d), ("shift", _d), ("squelch_open", _d), ("squelch_close", _d), ("gain", _d),
-                ("deemph_rate", _d), ("deemph_gain", _d), ("threshold_extend", _d)]
+                ("deemph_rate", _d), ("deemph_gain", _d), ("threshold_extend", _d),
+                ("pll_enable", _i), ("pll_square", _i), ("pll_loop_bw", _d), ("tone_freq", _d)]
 
 
 class DemodStatus(C.Structure):
-    _fields_ = [("frame", _i), ("mute", _i), ("squelch_state", _i), ("pad", _i),
-                ("output_power", _d), ("gain", _d), ("n0", _d), ("snr", _d), ("foffset", _d), ("pdeviation", _d)]
+    _fields_ = [("frame", _i), ("mute", _i), ("squelch_state", _i), ("pll_lock", _i),
+                ("output_power", _d), ("gain", _d), ("n0", _d), ("snr", _d), ("foffset", _d), ("pdeviation", _d),
+                ("pll_snr", _d), ("pll_cphase", _d), ("tone_deviation", _d), ("pll_rotations", _i), ("tone_mute", _i)]
 
 
 PCM_S16BE, PCM_S16LE, PCM_F32LE, PCM_F32BE = 0, 1, 2, 3
@@ -55,7 +57,7 @@ SYMBOLS = [
     "chz_bank_create", "chz_bank_set_responses", "chz_bank_set_shifts", "chz_bank_set_active",
     "chz_bank_execute", "chz_bank_execute_range", "chz_bank_destroy", "chz_bank_read", "chz_bank_read_async",
     "chz_spectrum_read_async", "chz_host_callback", "chz_host_alloc", "chz_host_free", "chz_host_register", "chz_host_unregister",
-    "chz_bank_output_device", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
+    "chz_bank_output_device", "chz_bank_write_block", "chz_bank_demod", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
     "chz_bank_set_tuning", "chz_bank_read_power", "chz_bank_read_power_async",
     "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
     "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real", "chz_bank_set_isb", "chz_bank_set_beam",
@@ -375,6 +377,22 @@ class Bank:
         st = (DemodStatus * n)()
         _check(lib().chz_bank_read_pcm(self.eng._h, self.id, slot, ch0, n, pcm.ctypes.data, st))
         return pcm, st
+
+    def inject(self, slot, samples, bb_power=None, n0=None, ch0=0):
+        """chz_bank_write_block: complex64[n][olen] (+ float64[n] bb_power, noise estimates) into the slot's output image."""
+        x = np.ascontiguousarray(samples, np.complex64)
+        pw = None if bb_power is None else np.ascontiguousarray(bb_power, np.float64)
+        ne = None if n0 is None else np.ascontiguousarray(n0, np.float64)
+        L = lib()
+        L.chz_bank_write_block.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp, _vp]
+        _check(L.chz_bank_write_block(self.eng._h, self.id, slot, ch0, x.shape[0], x.ctypes.data,
+                                      None if pw is None else pw.ctypes.data, None if ne is None else ne.ctypes.data))
+
+    def demod_only(self, job, slot=None):
+        """chz_bank_demod: the demodulator stage alone over what `slot` (default job % 4) holds."""
+        L = lib()
+        L.chz_bank_demod.argtypes = [_vp, _i, C.c_uint, _i]
+        _check(L.chz_bank_demod(self.eng._h, self.id, job, job % 4 if slot is None else slot))
 
     def enable_noise(self, samprate):
         """estimate_noise() (src/radio.c:1783-1866) on the device after every block; samprate = front-end rate in Hz."""

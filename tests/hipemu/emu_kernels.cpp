@@ -257,13 +257,18 @@ int emu_mini(const float* windows, int nreq, int N, int olen, const float* resp,
 
 // --- linear demodulator tail: chan/state/status are the kernel's own structs (DemodChan, DemodState, DemodStatus) ----------
 int emu_demod(const float* in, const double* power, const double* n0, const void* chan, void* state, void* status, unsigned char* pcm,
-              int nch, int olen, unsigned job, double blocktime) {
+              int nch, int olen, unsigned job, double blocktime, void* ext) {
   DemodParams d{};
   d.in = reinterpret_cast<const float2*>(in); d.power = power; d.n0 = n0;
   d.chan = static_cast<const DemodChan*>(chan); d.state = static_cast<DemodState*>(state); d.status = static_cast<DemodStatus*>(status);
+  d.ext = static_cast<DemodExt*>(ext);
   d.pcm = pcm; d.ch0 = 0; d.nch = nch; d.olen = olen; d.pcm_stride = olen * 8; d.job = job; d.blocktime = blocktime; d.power_alpha = 0.10;
   return launch_demod(nullptr, d);
 }
 int emu_demod_sizes(int* out3) { out3[0] = (int)sizeof(DemodChan); out3[1] = (int)sizeof(DemodState); out3[2] = (int)sizeof(DemodStatus); return 0; }
+// the host-side records of the coherent modes / tone squelch, as chz_bank_set_demod makes them
+int emu_demod_ext_size() { return (int)sizeof(DemodExt); }
+int emu_demod_ext_init(void* ext, int n) { DemodExt* x = static_cast<DemodExt*>(ext); for (int i = 0; i < n; i++) x[i] = demod_ext_init(); return 0; }
+int emu_demod_tone_consts(void* chan, int i, double tone_freq, double samprate) { demod_tone_consts(tone_freq, samprate, static_cast<DemodChan*>(chan)[i]); return 0; }
 
 }  // extern "C"

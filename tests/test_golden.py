@@ -205,3 +205,110 @@ def test_hip_reproduces_noise_and_conversion_golden():
             assert en == reps * int(g["energy%d" % rnd]) + en_r and clips == reps * int(g["clips%d" % rnd]) + cl_r
         finally:
             e16.close(); ef.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# frames produced by the reference's own demod_linear() / demod_fm() (linear.c, fm.c, osc.c, iir.c, misc.c)
+# ------------------------------------------------------------------------------------------------
+DEMOD_FILE = os.path.join(GOLDEN, "demod_rows.npz")
+LIN_KEYS = ["lin_usb", "lin_am", "lin_pll", "lin_pllsq"]
+FM_KEYS = ["fm_plain", "fm_thr", "fm_pll", "fm_tone"]
+
+
+def _golden_params(g, key):
+    kw = eval(str(g[key + "_kw"]), {"__builtins__": {}}, {"dict": dict})       # a literal dict written by make_golden.py
+    return ol.lin_params(**kw) if key.startswith("lin") else ol.fm_params(**kw)
+
+
+def _pcm_close(p, got, want, nsamp, tol_f):
+    if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+        dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
+        a, w = got[:2 * nsamp].view(dt).astype(np.int32), want[:2 * nsamp].view(dt).astype(np.int32)
+        return np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02
+    dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
+    a, w = got[:4 * nsamp].view(dt).astype(np.float64), want[:4 * nsamp].view(dt).astype(np.float64)
+    return np.abs(a - w).max() <= tol_f * max(np.abs(w).max(), 1e-30)
+
+
+@pytest.mark.parametrize("key", LIN_KEYS + FM_KEYS)
+def test_oracle_reproduces_demodulator_golden(oracle_built, key):
+    g = np.load(DEMOD_FILE)
+    p = _golden_params(g, key)
+    bb, power, est = g[key + "_bb"], g[key + "_bbpower"], g[key + "_est"]
+    d = ol.LinDemod(p) if key.startswith("lin") else ol.FmDemod(p)
+    ndata = 0
+    for b in range(bb.shape[0]):
+        pcm, st = d.block(bb[b], power[b], est[b], 0.02)
+        assert st.frame == g[key + "_frame"][b] and st.mute == g[key + "_mute"][b], (key, b)
+        if key.startswith("lin"):
+            assert st.gain == pytest.approx(g[key + "_gain"][b], rel=1e-7)
+            assert st.output_power == pytest.approx(g[key + "_opower"][b], rel=1e-6, abs=1e-300)
+            if p.pll_enable:
+                snr, lock, cph, rot, foff = g[key + "_pll"][b]
+                assert st.pll_lock == int(lock) and st.pll_rotations == int(rot)
+                assert st.pll_snr == pytest.approx(snr, rel=1e-6, abs=1e-9) and st.foffset == pytest.approx(foff, rel=1e-6, abs=1e-6)
+        else:
+            assert st.snr == pytest.approx(g[key + "_snr"][b], rel=1e-6, abs=1e-12)
+            assert st.tone_deviation == pytest.approx(g[key + "_tonedev"][b], rel=1e-5, abs=1e-6)
+        if st.frame == ol.FRAME_DATA:
+            ndata += 1
+            assert _pcm_close(p, pcm, g[key + "_pcm"][b], bb.shape[1] * p.channels, 4e-6), (key, b)
+    assert ndata >= 5
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_demodulator_golden():
+    """The golden baseband written straight into a bank's output image (with its bb_power and noise estimates), then ONLY the
+    demodulator stage run on the device, block after block: frames, statistics and PCM against what the reference's own
+    demod_linear() / demod_fm() produced from the same blocks."""
+    import ctypes as C
+    pkg = load_pkg()
+    g = np.load(DEMOD_FILE)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    lib = pkg.engine.lib()
+    for keys, P, olen in ((LIN_KEYS, 300, 240), (FM_KEYS, 600, 480)):
+        eng = pkg.engine.Engine(25920, 6481, ol.REAL, ring_blocks=8)
+        try:
+            nch = len(keys)
+            params = [_golden_params(g, k) for k in keys]
+            bank = eng.bank(P, olen, nch)
+            bank.set_responses(0, np.ones((nch, P), np.complex64) / P)
+            bank.set_tuning(0, 0, np.full(nch, 2500, np.int32), np.zeros(nch))
+            bank.set_active(nch); bank.enable_noise(1.296e6); bank.set_pcm_stride(8 * olen)
+            bank.set_demod(0, 0, [pkg.engine.DemodParams(*[getattr(p, f) for f, _ in ol.LinParams._fields_]) for p in params], 0.02)
+            nblk = max(g[k + "_bb"].shape[0] for k in keys)
+            ndata = np.zeros(nch, int)
+            for b in range(nblk):
+                slot = b % 4
+                x = np.zeros((nch, olen), np.complex64); pw = np.zeros(nch); ne = np.zeros(nch)
+                for i, k in enumerate(keys):
+                    bb = g[k + "_bb"]
+                    if b < bb.shape[0]:
+                        x[i] = bb[b]; pw[i] = g[k + "_bbpower"][b]; ne[i] = g[k + "_est"][b]
+                    else:
+                        pw[i] = 1e-30; ne[i] = g[k + "_est"][-1]
+                bank.inject(slot, x, pw, ne)
+                bank.demod_only(b)
+                pcm, status = bank.read_pcm(slot)
+                for i, k in enumerate(keys):
+                    if b >= g[k + "_bb"].shape[0]:
+                        continue
+                    p, got = params[i], status[i]
+                    assert got.frame == g[k + "_frame"][b] and got.mute == g[k + "_mute"][b], (k, b)
+                    if k.startswith("lin"):
+                        assert got.gain == pytest.approx(g[k + "_gain"][b], rel=1e-6)
+                        assert got.output_power == pytest.approx(g[k + "_opower"][b], rel=1e-5, abs=1e-300)
+                        if p.pll_enable and b < 50:
+                            snr, lock, cph, rot, foff = g[k + "_pll"][b]
+                            assert got.pll_lock == int(lock) and got.pll_rotations == int(rot), (k, b)
+                            assert got.pll_snr == pytest.approx(snr, rel=1e-5, abs=1e-9) and got.foffset == pytest.approx(foff, rel=1e-6, abs=1e-5)
+                    else:
+                        assert got.snr == pytest.approx(g[k + "_snr"][b], rel=1e-5, abs=1e-9)
+                        assert got.tone_deviation == pytest.approx(g[k + "_tonedev"][b], rel=1e-5, abs=1e-5)
+                    if got.frame == ol.FRAME_DATA and (b < 50 or not p.pll_enable):
+                        ndata[i] += 1
+                        assert _pcm_close(p, pcm[i], g[k + "_pcm"][b], olen * p.channels, 8e-6), (k, b)
+            assert (ndata >= 5).all()
+        finally:
+            eng.close()

@@ -423,3 +423,87 @@ def test_fm_demodulator_on_the_device(pkg):
     finally:
         eng.close()
     assert (ol.FRAME_DATA, 0) in seen and (ol.FRAME_SILENCE, 0) in seen and (ol.FRAME_SILENCE, 1) in seen
+
+
+@pytest.mark.gpu
+def test_coherent_modes_and_tone_squelch_on_the_device(pkg):
+    """The sequential stages of the demodulator kernel through the C ABI: the carrier-tracking PLL of the linear demodulator
+    (plain and squaring loop) with its lock detector and squelch, FM's PLL demodulator and the PL-tone squelch (tone present /
+    absent).  Two banks on one engine -- 12 kHz linear channels and 24 kHz FM channels -- share the demodulator stream.  The
+    restated demodulators (pinned to the reference's linear.c / fm.c / osc.c / iir.c) get exactly what the device stages got."""
+    from test_kernels_emulated import PLL_CASES, FM2_CASES, _check_pcm
+    L, M, fs_in = 25920, 6481, 1.296e6
+    N = L + M - 1
+    nblk = 90
+    rng = np.random.default_rng(123)
+    t = np.arange(nblk * L)
+    on_a = (t < 50 * L).astype(np.float64)             # there from the start: a wide loop left alone with noise can run off to a false lock
+    am = 0.05 * on_a * (1 + 0.5 * np.sin(2 * np.pi * 400 * t / fs_in)) * np.cos(2 * np.pi * (100000.0 + 30.0) * t / fs_in + 0.7)
+    bpsk = 0.05 * on_a * np.sign(np.sin(2 * np.pi * 31.25 * t / fs_in + 0.3)) * np.cos(2 * np.pi * (140000.0 + 5.0) * t / fs_in)
+    lvl = np.full(nblk * L, 0.05); lvl[:6 * L] = 0.0; lvl[60 * L:] = 0.0; lvl[56 * L:60 * L] = 0.05 * np.linspace(1, 0.02, 4 * L)
+    mod = (3000.0 / 1000.0) * np.cos(2 * np.pi * 1000.0 * t / fs_in)
+    fm_tone = lvl * np.cos(2 * np.pi * 200350.0 * t / fs_in - mod - (600.0 / 100.0) * np.cos(2 * np.pi * 100.0 * t / fs_in))
+    fm_plain = lvl * np.cos(2 * np.pi * 300350.0 * t / fs_in - mod)
+    x = (am + bpsk + fm_tone + fm_plain + 4e-4 * rng.standard_normal(nblk * L)).astype(np.float32)
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    # bank A: linear, 12 kHz; cases 0, 2, 3 listen to the AM carrier, case 1 (squaring loop) to the BPSK one
+    lin = [ol.lin_params(**kw) for kw in PLL_CASES]
+    A = eng.bank(300, 240, len(lin))
+    A.set_responses(0, np.stack([pkg.filterapi.design_response(300, 240, N, True, -2950 / 12000.0, 2950 / 12000.0, 11.0)] * len(lin)))
+    A.set_tuning(0, 0, np.array([2500, 3500, 2500, 2500], np.int32), np.zeros(len(lin)))
+    A.set_active(len(lin)); A.enable_noise(fs_in); A.set_pcm_stride(8 * 240)
+    A.set_demod(0, 0, [pkg.engine.DemodParams(*[getattr(p, f) for f, _ in ol.LinParams._fields_]) for p in lin], 0.02)
+    # bank B: FM, 24 kHz; the cases that were sent the tone listen at 200.35 kHz, the others at 300.35 kHz
+    fm = [ol.fm_params(**kw) for kw, _ in FM2_CASES]
+    B = eng.bank(600, 480, len(fm))
+    B.set_responses(0, np.stack([pkg.filterapi.design_response(600, 480, N, True, -8000 / 24000.0, 8000 / 24000.0, 11.0)] * len(fm)))
+    B.set_tuning(0, 0, np.array([5000 if sent else 7500 for _, sent in FM2_CASES], np.int32), np.zeros(len(fm)))
+    B.set_active(len(fm)); B.enable_noise(fs_in); B.set_pcm_stride(4 * 480)
+    B.set_demod(0, 0, [pkg.engine.DemodParams(*[getattr(p, f) for f, _ in ol.LinParams._fields_]) for p in fm], 0.02)
+    o_lin = [ol.LinDemod(p) for p in lin]; o_fm = [ol.FmDemod(p) for p in fm]
+    locked = np.zeros(len(lin), int); data = np.zeros(len(fm), int)
+    dev = []
+    try:
+        for b in range(nblk):
+            eng.write(x[b * L:(b + 1) * L])
+            eng.step(b)
+            s = b % 4
+            out = A.read_slot(s); power = A.read_power(s); noise = A.read_noise(s); pcm, status = A.read_pcm(s)
+            for i, p in enumerate(lin):
+                want, st = o_lin[i].block(out[i], power[i], noise[i], 0.02)
+                got = status[i]
+                # Once the carrier is gone a PLL chews on noise, where the phase detector's +-pi wrap turns an ulp of difference
+                # between two arithmetic libraries into a different cycle slip: beyond that point only what does not hang on the
+                # loop's trajectory is compared (frame type, squelch sequencer, lock detector, AGC gain).
+                strict = b < 50 or not p.pll_enable
+                locked[i] += got.pll_lock
+                assert (got.frame, got.mute, got.squelch_state, got.pll_lock) == (st.frame, st.mute, st.squelch_state, st.pll_lock), (b, i)
+                assert got.gain == pytest.approx(st.gain, rel=1e-6)
+                if not strict:
+                    continue
+                assert got.pll_rotations == st.pll_rotations, (b, i)
+                assert got.output_power == pytest.approx(st.output_power, rel=1e-5, abs=1e-300)
+                if p.pll_enable:
+                    dev.append((abs(got.pll_snr - st.pll_snr) / max(abs(st.pll_snr), 1e-3), abs(got.foffset - st.foffset),
+                                abs((got.pll_cphase - st.pll_cphase + np.pi) % (2 * np.pi) - np.pi), b, i, st.pll_snr, st.pll_lock))
+                if st.frame == ol.FRAME_DATA:
+                    _check_pcm(p, pcm[i], want, 240 * p.channels, 4e-6)
+            out = B.read_slot(s); power = B.read_power(s); noise = B.read_noise(s); pcm, status = B.read_pcm(s)
+            for i, p in enumerate(fm):
+                want, st = o_fm[i].block(out[i], power[i], noise[i], 0.02)
+                got = status[i]
+                assert (got.frame, got.mute, got.squelch_state, got.tone_mute) == (st.frame, st.mute, st.squelch_state, st.tone_mute), (b, i)
+                assert got.snr == pytest.approx(st.snr, rel=1e-5, abs=1e-9)
+                assert got.tone_deviation == pytest.approx(st.tone_deviation, rel=1e-5, abs=1e-6)
+                if st.frame == ol.FRAME_DATA:
+                    data[i] += 1
+                    assert got.output_power == pytest.approx(st.output_power, rel=4e-6)
+                    assert got.foffset == pytest.approx(st.foffset, rel=1e-5, abs=1e-5)
+                    _check_pcm(p, pcm[i], want, 480, 8e-6)
+    finally:
+        eng.close()
+    # with a carrier to hold on to, device and restatement walk the same trajectory (measured: 2e-14 relative on the SNR, 3e-13 Hz on
+    # the frequency offset, identical VCO phase words)
+    assert max(d[0] for d in dev) < 1e-9 and max(d[1] for d in dev) < 1e-9 and max(d[2] for d in dev) < 1e-6
+    assert all(10 < locked[i] < nblk - 10 for i in range(3)) and locked[3] == 0        # the loops locked on their carriers
+    assert data[0] > 5 and data[1] > 5 and data[2] > 5 and data[3] == 0 and data[4] == 0 and data[5] > 5

@@ -43,7 +43,10 @@ def emu(oracle_built):
     lib.emu_fine_retune.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
     lib.emu_channels_tuned.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_uint, C.c_void_p]
-    lib.emu_demod.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_double]
+    lib.emu_demod.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_double, C.c_void_p]
+    lib.emu_demod_ext_init.argtypes = [C.c_void_p, C.c_int]
+    lib.emu_demod_tone_consts.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+    lib.emu_demod_ext_size.restype = C.c_int
     lib.emu_demod_sizes.argtypes = [C.c_void_p]
     lib.emu_mini.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
@@ -327,12 +330,14 @@ class _DemodChan(C.Structure):           # struct DemodChan, chz_kernels.h
                 ("samprate", C.c_double), ("headroom", C.c_double), ("threshold", C.c_double), ("recovery_rate", C.c_double),
                 ("hangtime", C.c_double), ("dc_alpha", C.c_double), ("bandwidth", C.c_double), ("squelch_open", C.c_double),
                 ("squelch_close", C.c_double), ("osc_phase0", C.c_double), ("osc_freq", C.c_double), ("osc_job0", C.c_uint), ("kind", C.c_int),
-                ("deemph_rate", C.c_double), ("deemph_gain", C.c_double), ("threshold_extend", C.c_double)]
+                ("deemph_rate", C.c_double), ("deemph_gain", C.c_double), ("threshold_extend", C.c_double),
+                ("pll_enable", C.c_int), ("pll_square", C.c_int), ("pll_loop_bw", C.c_double), ("tone_freq", C.c_double),
+                ("g_coeff", C.c_double), ("g_cfr", C.c_double), ("g_cfi", C.c_double)]
 
 
 class _DemodState(C.Structure):
     _fields_ = [("gain", C.c_double), ("am_dc", C.c_double), ("n0", C.c_double), ("hangcount", C.c_int), ("squelch_state", C.c_int),
-                ("squelch_open", C.c_int), ("pad", C.c_int),
+                ("squelch_open", C.c_int), ("pll_was_on", C.c_int),
                 ("pm_re", C.c_double), ("pm_im", C.c_double), ("deemph_state", C.c_double), ("foffset", C.c_double), ("pdeviation", C.c_double)]
 
 
@@ -371,7 +376,7 @@ def test_linear_demodulator_kernel(emu):
     for b in range(nblk):
         x = np.ascontiguousarray(np.stack([bbs[i][b] for i in range(nch)]))
         pw = np.array([powers[i][b] for i in range(nch)]); ne = np.array([ests[i][b] for i in range(nch)])
-        assert emu.emu_demod(x.ctypes.data, pw.ctypes.data, ne.ctypes.data, chan, state, status, pcm.ctypes.data, nch, N, 7 + b, bt) == 0
+        assert emu.emu_demod(x.ctypes.data, pw.ctypes.data, ne.ctypes.data, chan, state, status, pcm.ctypes.data, nch, N, 7 + b, bt, None) == 0
         for i, p in enumerate(params):
             want, st = oracles[i].block(bbs[i][b], powers[i][b], ests[i][b], bt)
             got = status[i]
@@ -420,7 +425,7 @@ def test_fm_demodulator_kernel(emu):
     for b in range(nblk):
         x = np.ascontiguousarray(np.stack([bbs[i][b] for i in range(nch)]))
         pw = np.array([powers[i][b] for i in range(nch)]); ne = np.array([ests[i][b] for i in range(nch)])
-        assert emu.emu_demod(x.ctypes.data, pw.ctypes.data, ne.ctypes.data, chan, state, status, pcm.ctypes.data, nch, N, b, bt) == 0
+        assert emu.emu_demod(x.ctypes.data, pw.ctypes.data, ne.ctypes.data, chan, state, status, pcm.ctypes.data, nch, N, b, bt, None) == 0
         for i, p in enumerate(params):
             want, st = oracles[i].block(bbs[i][b], powers[i][b], ests[i][b], bt)
             got = status[i]
@@ -440,3 +445,123 @@ def test_fm_demodulator_kernel(emu):
                     a, w = pcm[i, :nb].view(dt).astype(np.float64), want.view(dt).astype(np.float64)
                     assert np.abs(a - w).max() <= 2e-7 * max(np.abs(w).max(), 1e-30), (b, i)
     assert (ol.FRAME_DATA, 0) in seen and (ol.FRAME_SILENCE, 0) in seen and (ol.FRAME_SILENCE, 1) in seen
+
+
+class _DemodExt(C.Structure):            # struct DemodExt, chz_kernels.h (PllState first)
+    _fields_ = [("vco_phase", C.c_uint), ("vco_step", C.c_int), ("wraps", C.c_int), ("lock", C.c_int), ("lock_count", C.c_int), ("pad0", C.c_int),
+                ("bw", C.c_double), ("damping", C.c_double), ("lower", C.c_double), ("upper", C.c_double), ("u", C.c_double), ("phi", C.c_double),
+                ("K1", C.c_double), ("K2", C.c_double),
+                ("pll_snr", C.c_double), ("pll_cphase", C.c_double), ("foffset", C.c_double),
+                ("g_s0", C.c_double), ("g_s1", C.c_double), ("old_pl_phase", C.c_double), ("tone_deviation", C.c_double),
+                ("pll_rotations", C.c_int), ("pl_sample_count", C.c_int), ("tone_mute", C.c_int), ("pad", C.c_int)]
+
+
+_CHAN_FIELDS = ("channels", "env", "agc", "encoding", "snr_squelch", "squelch_tail", "tuned", "kind", "samprate", "headroom", "threshold",
+                "recovery_rate", "hangtime", "dc_alpha", "bandwidth", "squelch_open", "squelch_close", "deemph_rate", "deemph_gain",
+                "threshold_extend", "pll_enable", "pll_square", "pll_loop_bw")
+
+
+def _check_pcm(p, got_row, want, n_samples, tol_f):
+    nb = ol.pcm_bytes(p.encoding, n_samples)
+    if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+        dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
+        a, w = got_row[:nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
+        assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02
+    else:
+        dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
+        a, w = got_row[:nb].view(dt).astype(np.float64), want.view(dt).astype(np.float64)
+        assert np.abs(a - w).max() <= tol_f * max(np.abs(w).max(), 1e-30)
+
+
+PLL_CASES = [dict(pll=True), dict(pll=True, square=True, pll_bw=20.0, channels=2, encoding=ol.PCM_F32LE),
+             dict(pll=True, env=True, dc_alpha=0.002, pll_bw=50.0, squelch_tail=0, encoding=ol.PCM_S16LE), dict()]
+
+
+def test_linear_pll_kernel(emu):
+    """The coherent modes of the demodulator kernel (src/linear.c:83-153: PLL on one lane, lock detector, PLL squelch) against the
+    restated demodulator, which is pinned to the reference's linear.c / osc.c; a channel without the PLL rides along.
+    The loop is a recurrence through a truncation to a 32-bit phase word: device and restatement may differ by an LSB of that
+    word now and then (2^-32 cycle), which is what the tolerances below allow."""
+    assert emu.emu_demod_ext_size() == C.sizeof(_DemodExt)
+    from test_oracle_vs_reference import _coherent_case
+    nblk, N, bt = 90, 240, 0.02
+    nch = len(PLL_CASES)
+    bbs, powers, params, oracles = [], [], [], []
+    for kw in PLL_CASES:
+        bb, power = _coherent_case(np.random.default_rng(3), nblk, N, kw.get("square", False))
+        bbs.append(bb); powers.append(power)
+        p = ol.lin_params(**kw); params.append(p); oracles.append(ol.LinDemod(p))
+    est = 2 * 4e-4 ** 2 / 12000.0
+    chan = (_DemodChan * nch)(); state = (_DemodState * nch)(); status = (ol.LinStatus * nch)(); ext = (_DemodExt * nch)()
+    emu.emu_demod_ext_init(ext, nch)
+    for i, p in enumerate(params):
+        c = chan[i]
+        for f in _CHAN_FIELDS:
+            setattr(c, f, getattr(p, f))
+        c.on = 1; c.osc_freq = 0.0
+        state[i].gain = p.gain; state[i].n0 = float("nan"); state[i].squelch_open = 1
+        state[i].squelch_state = (p.squelch_tail + 4) if not (p.snr_squelch or p.pll_enable) else 0
+    pcm = np.zeros((nch, N * 8), np.uint8)
+    locked = np.zeros(nch, int)
+    for b in range(nblk):
+        x = np.ascontiguousarray(np.stack([bbs[i][b] for i in range(nch)]))
+        pw = np.array([powers[i][b] for i in range(nch)]); ne = np.full(nch, est)
+        assert emu.emu_demod(x.ctypes.data, pw.ctypes.data, ne.ctypes.data, chan, state, status, pcm.ctypes.data, nch, N, b, bt, ext) == 0
+        for i, p in enumerate(params):
+            want, st = oracles[i].block(bbs[i][b], powers[i][b], est, bt)
+            got = status[i]
+            assert (got.frame, got.mute, got.squelch_state, got.pll_lock, got.pll_rotations) == \
+                (st.frame, st.mute, st.squelch_state, st.pll_lock, st.pll_rotations), (b, i)
+            assert got.gain == pytest.approx(st.gain, rel=1e-7) and got.output_power == pytest.approx(st.output_power, rel=1e-6, abs=1e-300)
+            if p.pll_enable:
+                assert got.pll_snr == pytest.approx(st.pll_snr, rel=1e-6, abs=1e-9) and got.foffset == pytest.approx(st.foffset, rel=1e-6, abs=1e-6)
+                assert abs((got.pll_cphase - st.pll_cphase + np.pi) % (2 * np.pi) - np.pi) < 1e-6
+            locked[i] += got.pll_lock
+            if st.frame == ol.FRAME_DATA:
+                _check_pcm(p, pcm[i], want, N * p.channels, 2e-6)
+    assert all(10 < locked[i] < nblk - 10 for i in range(3)) and locked[3] == 0
+
+
+FM2_CASES = [(dict(pll=True, encoding=ol.PCM_F32LE), 0.0), (dict(pll=True, threshold_extend=True), 0.0), (dict(tone_freq=100.0), 100.0),
+             (dict(tone_freq=100.0, deemph_tc=0, encoding=ol.PCM_S16LE), 0.0), (dict(tone_freq=123.0, pll=True), 100.0), (dict(), 100.0)]
+
+
+def test_fm_pll_and_tone_kernel(emu):
+    """The PLL demodulator (src/fm.c:176-203) and the PL-tone squelch (:264-311) of the demodulator kernel against the restatement
+    pinned to the reference's fm.c / osc.c / iir.c: the tone present, absent, the wrong one; a plain channel alongside."""
+    from test_oracle_vs_reference import _fm_case
+    nblk, N, fs, bt = 72, 480, 24000.0, 0.02
+    nch = len(FM2_CASES)
+    r = np.random.default_rng(5)
+    bbs, powers, ests, params, oracles = [], [], [], [], []
+    for i, (kw, sent) in enumerate(FM2_CASES):
+        bb, power = _fm_case(np.random.default_rng(300 + i), nblk, N, fs, tone=sent, last=60)
+        bbs.append(bb); powers.append(power); ests.append((2 * 2e-3 ** 2 / fs) * (1 + 0.1 * r.standard_normal(nblk)))
+        p = ol.fm_params(**kw); params.append(p); oracles.append(ol.FmDemod(p))
+    chan = (_DemodChan * nch)(); state = (_DemodState * nch)(); status = (ol.LinStatus * nch)(); ext = (_DemodExt * nch)()
+    emu.emu_demod_ext_init(ext, nch)
+    for i, p in enumerate(params):
+        c = chan[i]
+        for f in _CHAN_FIELDS:
+            setattr(c, f, getattr(p, f))
+        c.on = 1
+        emu.emu_demod_tone_consts(chan, i, p.tone_freq, p.samprate)
+        state[i].n0 = float("nan")
+    pcm = np.zeros((nch, N * 8), np.uint8)
+    data = np.zeros(nch, int)
+    for b in range(nblk):
+        x = np.ascontiguousarray(np.stack([bbs[i][b] for i in range(nch)]))
+        pw = np.array([powers[i][b] for i in range(nch)]); ne = np.array([ests[i][b] for i in range(nch)])
+        assert emu.emu_demod(x.ctypes.data, pw.ctypes.data, ne.ctypes.data, chan, state, status, pcm.ctypes.data, nch, N, b, bt, ext) == 0
+        for i, p in enumerate(params):
+            want, st = oracles[i].block(bbs[i][b], powers[i][b], ests[i][b], bt)
+            got = status[i]
+            assert (got.frame, got.mute, got.squelch_state, got.tone_mute) == (st.frame, st.mute, st.squelch_state, st.tone_mute), (b, i)
+            assert got.snr == pytest.approx(st.snr, rel=1e-6, abs=1e-12)
+            assert got.tone_deviation == pytest.approx(st.tone_deviation, rel=1e-6, abs=1e-9)
+            if st.frame == ol.FRAME_DATA:
+                data[i] += 1
+                assert got.output_power == pytest.approx(st.output_power, rel=2e-6)
+                assert got.foffset == pytest.approx(st.foffset, rel=1e-6, abs=1e-6) and got.pdeviation == pytest.approx(st.pdeviation, rel=1e-6, abs=1e-3)
+                _check_pcm(p, pcm[i], want, N, 4e-6)
+    assert data[0] > 5 and data[1] > 5 and data[2] > 5 and data[3] == 0 and data[4] == 0 and data[5] > 5
