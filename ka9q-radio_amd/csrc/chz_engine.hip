@@ -1123,6 +1123,10 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
     c.squelch_tail = q.squelch_tail; c.tuned = q.tuned != 0; c.on = 1;
     c.samprate = q.samprate; c.headroom = q.headroom; c.threshold = q.threshold; c.recovery_rate = q.recovery_rate; c.hangtime = q.hangtime;
     c.dc_alpha = q.dc_alpha; c.bandwidth = q.bandwidth; c.squelch_open = q.squelch_open; c.squelch_close = q.squelch_close;
+    if (q.kind == CHZ_DEMOD_FM) {                       // demod_fm()'s defaults for thresholds left unset (src/fm.c:38-41)
+      if (!std::isfinite(c.squelch_open) || c.squelch_open == 0) c.squelch_open = 6.3;
+      if (!std::isfinite(c.squelch_close) || c.squelch_close == 0) c.squelch_close = 4;
+    }
     c.kind = q.kind; c.deemph_rate = q.deemph_rate; c.deemph_gain = q.deemph_gain; c.threshold_extend = q.threshold_extend;
     const bool pll_was = was_on && c.pll_enable != 0;
     const double tone_was = was_on ? c.tone_freq : 0.0;

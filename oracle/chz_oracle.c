@@ -1013,6 +1013,8 @@ chzo_fmdemod *chzo_fmdemod_create(const chzo_lindemod_params *p) {
   chzo_fmdemod *d = (chzo_fmdemod *)calloc(1, sizeof *d);
   if (!d) return NULL;
   d->p = *p; d->n0 = NAN;
+  if (!isfinite(d->p.squelch_open) || d->p.squelch_open == 0) d->p.squelch_open = 6.3;      /* :38-41 */
+  if (!isfinite(d->p.squelch_close) || d->p.squelch_close == 0) d->p.squelch_close = 4;
   d->tone_mute = 1;                                                          /* :61 muted until the tone is detected */
   if (p->tone_freq != 0) {                                                   /* :50-53 init_goertzel(tone_freq / samprate) */
     const double f = p->tone_freq / (int)p->samprate;
