@@ -245,6 +245,8 @@ int chz_run_blocks_sharded(chz_engine *e, chz_comm *c, int root, int mode, const
 #define CHZ_PCM_S16LE 1
 #define CHZ_PCM_F32LE 2
 #define CHZ_PCM_F32BE 3
+#define CHZ_PCM_MULAW 4   /* G.711 mu-law, one byte per sample (float_to_mulaw, src/rtp.c:459-483) */
+#define CHZ_PCM_ALAW 5    /* G.711 A-law (float_to_alaw, src/rtp.c:500-533) */
 typedef struct chz_demod_params {
   int channels;         /* chan->output.channels: 1 mono, 2 stereo; 0 switches the channel's demodulator off */
   int env;              /* chan->linear.env: envelope (AM) detection */

@@ -1081,7 +1081,7 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
 // restatement (oracle/chz_oracle.c:chzo_lindemod_block), which is pinned to the reference's linear.c itself.
 // The state is a recurrence over BLOCKS: the engine runs these kernels on one in-order stream.
 // ------------------------------------------------------------------------------
-enum { CHZ_PCM_S16BE_K = 0, CHZ_PCM_S16LE_K = 1, CHZ_PCM_F32LE_K = 2, CHZ_PCM_F32BE_K = 3 };
+enum { CHZ_PCM_S16BE_K = 0, CHZ_PCM_S16LE_K = 1, CHZ_PCM_F32LE_K = 2, CHZ_PCM_F32BE_K = 3, CHZ_PCM_MULAW_K = 4, CHZ_PCM_ALAW_K = 5 };
 struct DemodChan {               // per channel, set by the host (names: the chan_t members src/linear.c reads)
   int channels, env, agc, encoding, snr_squelch, squelch_tail, tuned, on;
   double samprate, headroom, threshold, recovery_rate, hangtime, dc_alpha, bandwidth, squelch_open, squelch_close;
@@ -1117,8 +1117,25 @@ struct DemodParams {
   double blocktime, power_alpha;
 };
 
+// G.711 companding as send_output() applies it (float_to_mulaw / float_to_alaw, src/rtp.c:459-483,500-533): clamp, 16-bit
+// sign/magnitude, clip at 32635, segment = position of the leading one, 4 mantissa bits below it
+__device__ __forceinline__ unsigned char demod_g711(float v, bool alaw) {
+  v = v > 1.0f ? 1.0f : v < -1.0f ? -1.0f : v;
+  const int sample = (int)rintf(ldexpf(v, 15));
+  const int sign = sample < 0;
+  int pcm = sign ? -sample : sample;
+  if (pcm > 32635) pcm = 32635;
+  if (!alaw) pcm += 0x84;
+  int exponent = (alaw && pcm < 256) ? 0 : (31 - __builtin_clz((unsigned)pcm)) - 7;
+  exponent = exponent < 0 ? 0 : exponent > 7 ? 7 : exponent;
+  const int mantissa = (alaw && exponent == 0) ? (pcm >> 4) & 0x0F : (pcm >> (exponent + 3)) & 0x0F;
+  const unsigned char code = (unsigned char)((exponent << 4) | mantissa);
+  return alaw ? (unsigned char)(code ^ (sign ? 0xD5 : 0x55)) : (unsigned char)~(code | (sign << 7));
+}
 __device__ __forceinline__ void demod_put(unsigned char* o, int enc, int idx, float v) {
-  if (enc == CHZ_PCM_S16BE_K || enc == CHZ_PCM_S16LE_K) {
+  if (enc == CHZ_PCM_MULAW_K || enc == CHZ_PCM_ALAW_K) {
+    o[idx] = demod_g711(v, enc == CHZ_PCM_ALAW_K);
+  } else if (enc == CHZ_PCM_S16BE_K || enc == CHZ_PCM_S16LE_K) {
     float t = ldexpf(v, 15);                                           // src/import.h:90-94
     t = t > 32767.0f ? 32767.0f : t < -32767.0f ? -32767.0f : t;
     const int q = (int)rintf(t);                                       // lrintf: to nearest, ties to even

@@ -771,12 +771,44 @@ chzo_lindemod *chzo_lindemod_create(const chzo_lindemod_params *p) {
 void chzo_lindemod_delete(chzo_lindemod *d) { free(d); }
 void chzo_lindemod_set_params(chzo_lindemod *d, const chzo_lindemod_params *p) { double g = d->gain; d->p = *p; d->p.gain = g; }
 
-static int pcm_bytes_per_sample(int enc) { return (enc == CHZO_PCM_S16BE || enc == CHZO_PCM_S16LE) ? 2 : 4; }
+static int pcm_bytes_per_sample(int enc) { return (enc == CHZO_PCM_MULAW || enc == CHZO_PCM_ALAW) ? 1 : (enc == CHZO_PCM_S16BE || enc == CHZO_PCM_S16LE) ? 2 : 4; }
+
+/* src/rtp.c:459-483: clamp to +-1, to 16 bits, sign/magnitude, clip at 32635, bias 132, segment = position of the leading one,
+   4 mantissa bits below it, everything inverted */
+unsigned char chzo_float_to_mulaw(float x) {
+  if (x > 1) x = 1; else if (x < -1) x = -1;
+  int32_t sample = (int32_t)lrintf(ldexpf(x, 15));
+  const int sign = sample < 0;
+  int32_t pcm = sign ? -sample : sample;
+  if (pcm > 32635) pcm = 32635;
+  pcm += 0x84;
+  int exponent = (31 - __builtin_clz((uint32_t)pcm)) - 7;
+  exponent = exponent < 0 ? 0 : exponent > 7 ? 7 : exponent;
+  const int mantissa = (pcm >> (exponent + 3)) & 0x0F;
+  return (unsigned char)~((unsigned char)((exponent << 4) | mantissa) | (sign << 7));
+}
+/* src/rtp.c:500-533: the same without the bias; segment 0 is linear (mantissa = bits 4..7); XOR 0x55 / 0xD5 */
+unsigned char chzo_float_to_alaw(float x) {
+  if (x > 1.0f) x = 1.0f; else if (x < -1.0f) x = -1.0f;
+  int32_t sample = (int32_t)lrintf(ldexpf(x, 15));
+  const int sign = sample < 0;
+  int32_t pcm = sign ? -sample : sample;
+  if (pcm > 32635) pcm = 32635;
+  int exponent = 0;
+  if (pcm >= 256) exponent = (31 - __builtin_clz((uint32_t)pcm)) - 7;
+  exponent = exponent < 0 ? 0 : exponent > 7 ? 7 : exponent;
+  const int mantissa = exponent == 0 ? (pcm >> 4) & 0x0F : (pcm >> (exponent + 3)) & 0x0F;
+  unsigned char a = (unsigned char)((exponent << 4) | mantissa);
+  a ^= (sign ? 0xD5 : 0x55);
+  return a;
+}
 
 /* export_s16_swap / _noswap and export_f32_* (src/import.h:88-118,176-183) on a little-endian host */
 static void pcm_pack(int enc, const float *in, int count, unsigned char *out) {
   for (int i = 0; i < count; i++) {
-    if (enc == CHZO_PCM_S16BE || enc == CHZO_PCM_S16LE) {
+    if (enc == CHZO_PCM_MULAW) out[i] = chzo_float_to_mulaw(in[i]);
+    else if (enc == CHZO_PCM_ALAW) out[i] = chzo_float_to_alaw(in[i]);
+    else if (enc == CHZO_PCM_S16BE || enc == CHZO_PCM_S16LE) {
       float t = ldexpf(in[i], 15);
       t = t > 32767.0f ? 32767.0f : t < -32767.0f ? -32767.0f : t;
       int16_t v = (int16_t)lrintf(t);

@@ -36,6 +36,8 @@ int send_output(chan_t *restrict const chan, float const *restrict buffer, int f
   int const samples = frames * chan->output.channels;
   uint8_t *dp = B.pcm + (size_t)b * B.pcm_stride;
   switch (chan->output.encoding) {
+  case MULAW: export_mulaw(dp, buffer, samples); break;      /* float_to_mulaw / _alaw: the reference's rtp.c */
+  case ALAW: export_alaw(dp, buffer, samples); break;
   case S16BE: export_s16_be(dp, buffer, samples); break;
   case S16LE: export_s16_le(dp, buffer, samples); break;
   case F32BE: export_f32_be(dp, buffer, samples); break;
@@ -67,7 +69,7 @@ EXPORT int reffm_run(const struct dm_params *p, double blocktime, int nblocks, i
   Blocktime = blocktime;
   chan.frontend = &fe;
   chan.output.samprate = (int)p->samprate; chan.output.headroom = p->headroom;
-  chan.output.encoding = p->encoding == 0 ? S16BE : p->encoding == 1 ? S16LE : p->encoding == 3 ? F32BE : F32LE;
+  chan.output.encoding = p->encoding == 0 ? S16BE : p->encoding == 1 ? S16LE : p->encoding == 3 ? F32BE : p->encoding == 4 ? MULAW : p->encoding == 5 ? ALAW : F32LE;
   chan.filter.min_IF = -p->bandwidth / 2; chan.filter.max_IF = p->bandwidth / 2;
   chan.squelch.snr_enable = p->snr_squelch; chan.squelch.open = p->squelch_open; chan.squelch.close = p->squelch_close; chan.squelch.tail = p->squelch_tail;
   chan.fm.threshold = p->threshold_extend != 0; chan.fm.rate = p->deemph_rate; chan.fm.gain = p->deemph_gain; chan.fm.tone_freq = p->tone_freq;

@@ -39,6 +39,8 @@ int send_output(chan_t *restrict const chan, float const *restrict buffer, int f
   int const samples = frames * chan->output.channels;
   uint8_t *dp = B.pcm + (size_t)b * B.pcm_stride;
   switch (chan->output.encoding) {                      /* src/audio.c:117-133 */
+  case MULAW: export_mulaw(dp, buffer, samples); break;      /* float_to_mulaw / _alaw: the reference's rtp.c */
+  case ALAW: export_alaw(dp, buffer, samples); break;
   case S16BE: export_s16_be(dp, buffer, samples); break;
   case S16LE: export_s16_le(dp, buffer, samples); break;
   case F32BE: export_f32_be(dp, buffer, samples); break;
@@ -65,7 +67,7 @@ EXPORT int reflin_run(const struct lin_params *p, double blocktime, int nblocks,
   Blocktime = blocktime;
   chan.frontend = &fe;
   chan.output.samprate = (int)p->samprate; chan.output.channels = p->channels; chan.output.gain = p->gain; chan.output.headroom = p->headroom;
-  chan.output.encoding = p->encoding == 0 ? S16BE : p->encoding == 1 ? S16LE : p->encoding == 3 ? F32BE : F32LE;
+  chan.output.encoding = p->encoding == 0 ? S16BE : p->encoding == 1 ? S16LE : p->encoding == 3 ? F32BE : p->encoding == 4 ? MULAW : p->encoding == 5 ? ALAW : F32LE;
   chan.linear.env = p->env; chan.linear.agc = p->agc; chan.linear.threshold = p->threshold; chan.linear.recovery_rate = p->recovery_rate;
   chan.linear.hangtime = p->hangtime; chan.linear.dc_alpha = p->dc_alpha;
   chan.filter.min_IF = -p->bandwidth / 2; chan.filter.max_IF = p->bandwidth / 2;

@@ -446,7 +446,7 @@ def ref_convert_i16(samples, scale, randomize=False, avx2=False):
 
 
 # ---- linear demodulator + PCM packing -------------------------------------------------------------
-PCM_S16BE, PCM_S16LE, PCM_F32LE, PCM_F32BE = 0, 1, 2, 3
+PCM_S16BE, PCM_S16LE, PCM_F32LE, PCM_F32BE, PCM_MULAW, PCM_ALAW = 0, 1, 2, 3, 4, 5
 FRAME_DATA, FRAME_SILENCE = 0, 1
 
 
@@ -492,7 +492,7 @@ def fm_params(encoding=PCM_S16BE, snr_squelch=False, squelch_tail=1, samprate=24
 
 
 def pcm_bytes(encoding, nsamples):
-    return (2 if encoding in (PCM_S16BE, PCM_S16LE) else 4) * nsamples
+    return (1 if encoding in (PCM_MULAW, PCM_ALAW) else 2 if encoding in (PCM_S16BE, PCM_S16LE) else 4) * nsamples
 
 
 class LinDemod:

@@ -343,7 +343,7 @@ class _DemodState(C.Structure):
 
 DEMOD_CASES = [dict(), dict(channels=2, encoding=ol.PCM_F32LE), dict(env=True, dc_alpha=0.002, encoding=ol.PCM_S16LE),
                dict(channels=2, env=True, dc_alpha=0.01, encoding=ol.PCM_F32BE), dict(agc=False, gain_db=30.0, shift=500.0),
-               dict(snr_squelch=True, squelch_tail=2), dict(tuned=False)]
+               dict(snr_squelch=True, squelch_tail=2), dict(tuned=False), dict(encoding=ol.PCM_MULAW), dict(channels=2, encoding=ol.PCM_ALAW)]
 
 
 def test_linear_demodulator_kernel(emu):
@@ -385,7 +385,9 @@ def test_linear_demodulator_kernel(emu):
             assert got.output_power == pytest.approx(st.output_power, rel=2e-7 if p.env else 1e-12, abs=1e-300)
             if st.frame == ol.FRAME_DATA:
                 nb = ol.pcm_bytes(p.encoding, N * p.channels)
-                if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+                if p.encoding in (ol.PCM_MULAW, ol.PCM_ALAW):
+                    assert np.mean(pcm[i, :nb] != want) < 0.01, (b, i)
+                elif p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
                     dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
                     a, w = pcm[i, :nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
                     assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.01, (b, i)

@@ -368,6 +368,7 @@ def _demod_case(r, nblk, N, bursts=True):
     dict(agc=False, gain_db=30.0, shift=500.0),                      # cw: fixed gain, post-detection shift oscillator
     dict(snr_squelch=True, squelch_tail=2, bandwidth=2950.0),        # SNR squelch closing and re-opening
     dict(tuned=False),
+    dict(encoding=ol.PCM_MULAW), dict(channels=2, encoding=ol.PCM_ALAW),   # G.711 companding (src/rtp.c:459-533 via export_mulaw / _alaw)
 ])
 def test_linear_demodulator_matches_reference_linear_c(oracle_built, kw):
     r = np.random.default_rng(len(kw) * 7 + 3)
@@ -395,7 +396,9 @@ def test_linear_demodulator_matches_reference_linear_c(oracle_built, kw):
         assert st.output_power == pytest.approx(pow_r[b], rel=tol, abs=1e-300)
         seen.add((st.frame, st.mute))
         if st.frame == ol.FRAME_DATA:
-            if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+            if p.encoding in (ol.PCM_MULAW, ol.PCM_ALAW):
+                assert np.mean(pcm != pcm_r[b]) < 0.01                              # a code flips only where a sample sits on a step
+            elif p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
                 a = pcm.view(">i2" if p.encoding == ol.PCM_S16BE else "<i2").astype(np.int32)
                 w = pcm_r[b].view(">i2" if p.encoding == ol.PCM_S16BE else "<i2").astype(np.int32)
                 assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.01          # the reference is built with -funsafe-math...
@@ -405,6 +408,28 @@ def test_linear_demodulator_matches_reference_linear_c(oracle_built, kw):
                 assert np.abs(a - w).max() <= 2e-7 * max(np.abs(w).max(), 1e-30)
     if kw.get("snr_squelch"):
         assert (ol.FRAME_SILENCE, 0) in seen and (ol.FRAME_SILENCE, 1) in seen and (ol.FRAME_DATA, 0) in seen
+
+
+@pytest.mark.skipif(not ol.have_ref_linear(), reason="oracle/_ref/libka9q_ref_linear.so not built (needs /root/reference)")
+def test_g711_companding_matches_reference_rtp_c(oracle_built):
+    # float_to_mulaw / float_to_alaw of the reference's own rtp.c (through export_mulaw / export_alaw in the linear wrapper's
+    # send_output) against the restatement, for every 16-bit level and beyond the clip points: bit-exact
+    import ctypes as C
+    O = ol.oracle()
+    O.chzo_float_to_mulaw.argtypes = [C.c_float]; O.chzo_float_to_mulaw.restype = C.c_ubyte
+    O.chzo_float_to_alaw.argtypes = [C.c_float]; O.chzo_float_to_alaw.restype = C.c_ubyte
+    lv = np.concatenate([np.arange(-32768, 32769) / 32768.0, [1.5, -1.5, 3e-5, -3e-5, 0.999999, -0.999999]]).astype(np.float32)
+    N = 240
+    lv = np.concatenate([lv, np.zeros((-len(lv)) % N, np.float32)])
+    bb = (lv + 0j).astype(np.complex64).reshape(-1, N)              # real part out at unit gain: I channel, no AGC
+    for enc, fn in ((ol.PCM_MULAW, O.chzo_float_to_mulaw), (ol.PCM_ALAW, O.chzo_float_to_alaw)):
+        p = ol.lin_params(agc=False, gain_db=0.0, encoding=enc)
+        pcm_r, frame_r, _, _, _ = ol.ref_linear_run(p, bb, np.ones(len(bb)), np.full(len(bb), 1e-12), 0.02)
+        assert (frame_r == ol.FRAME_DATA).all()
+        want = pcm_r.reshape(-1)[:len(lv)]
+        got = np.array([fn(float(v)) for v in lv], np.uint8)
+        assert np.array_equal(got, want)
+    assert O.chzo_float_to_mulaw(0.0) == 0xFF and O.chzo_float_to_alaw(0.0) == 0x55       # the idle codes
 
 
 def test_pll_oscillator_matches_reference_osc_c(oracle_built):
