@@ -698,10 +698,14 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   c.stage = e->chan_stage >= 0 ? e->chan_stage : (n >= 16384);
   c.isb = b.isb ? b.isb + so : nullptr; c.beam = b.beam ? b.beam + so : nullptr;
   c.fine = b.fine ? b.fine + so : nullptr; c.power = b.power ? b.power + so : nullptr; c.job = job;
-  const int per_block = b.g.wpb * b.g.cpw;
+  const int per_block = b.g.any ? 1 : b.g.wpb * b.g.cpw;
   const int grid = (n + per_block - 1) / per_block;
   mark(in, st, 4, true);
-  if (b.out_real) {
+  if (b.g.any) {                       // a size outside the register-tiled menu: one workgroup per channel
+    c.m_bins = e->bins; c.m_real = e->in_type == CHZ_REAL;
+    if (b.out_real) { c.fine = nullptr; c.power = nullptr; }
+    launch_chan_any(b.g, n, st, c, b.tw_sub, b.out_real != 0, IN_E0(in), IN_E1(in));
+  } else if (b.out_real) {
     c.m_bins = e->bins; c.m_real = e->in_type == CHZ_REAL; c.fine = nullptr; c.power = nullptr; c.stage = 0;
     if (launch_chan_real(b.g.r, grid, b.g.wpb * 64, b.g.lds, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no real-output kernel for P=%d", b.P);
   } else if (launch_chan(b.g.r, grid, b.g.wpb * 64, b.g.lds, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for P=%d", b.P);
@@ -828,7 +832,7 @@ static int bank_create(chz_engine* e, int P, int olen, int capacity, int out_rea
   if ((long long)olen * e->N % e->L != 0 || (long long)olen * e->N / e->L != P)
     return fail(-1, "P=%d is not olen*N/L for olen=%d N=%d L=%d", P, olen, e->N, e->L);
   Bank b;
-  if (!build_chan_geom(P, b.g)) return fail(-3, "no channel kernel compiled for P=%d", P);
+  if (!build_chan_geom(P, b.g)) return fail(-3, "no channel kernel for P=%d (needs a 2-3-5-smooth size up to %d)", P, CHZ_ANY_MAX_P);
   HIPOK(hipSetDevice(e->device));
   // a failed allocation (the C_rt-sized banks take > 100 GB) must not leak the earlier ones
   struct Guard { Bank* b; ~Guard() { if (b) free_bank(*b); } } guard{&b};
@@ -848,8 +852,9 @@ static int bank_create(chz_engine* e, int P, int olen, int capacity, int out_rea
   for (int s = 0; s < CHZ_ND; s++) { b.dirty_lo[s] = capacity; b.dirty_hi[s] = 0; }
   HIPOK(hipMalloc((void**)&b.out, bank_sample_bytes(b) * (size_t)CHZ_ND * capacity * olen));
   HIPOK(hipMemset(b.out, 0, bank_sample_bytes(b) * (size_t)CHZ_ND * capacity * olen));
-  int r = upload(&b.tw_sub, b.g.tw_sub);
+  int r = upload(&b.tw_sub, b.g.any ? b.g.tw_any : b.g.tw_sub);
   if (r) return r;
+  if (b.g.any && chan_any_prepare()) return fail(-3, "the runtime refuses %zu bytes of LDS per workgroup (P=%d)", b.g.lds, P);
   HIPOK(hipDeviceSynchronize());       // null-stream memsets vs the engine's non-blocking streams
   drop_graph(e);
   guard.b = nullptr;
@@ -1047,6 +1052,7 @@ int chz_bank_set_beam(chz_engine* e, int bank, int ch0, int n, const double* ab,
   if (!ab || !on) return fail(-1, "null argument");
   Bank& b = e->banks[(size_t)bank];
   if (b.out_real || e->in_type != CHZ_COMPLEX) return fail(-1, "beam mode combines I and Q of a COMPLEX master into COMPLEX-output channels");
+  if (b.g.any) return fail(-3, "beam mode is compiled for the menu sizes only (P=%d runs through the one-workgroup-per-channel kernel)", b.P);
   HIPOK(hipSetDevice(e->device));
   if (!b.beam) {
     bool any = false;

@@ -1805,4 +1805,126 @@ __global__ void __launch_bounds__(256) mini_ovs(MiniParams p) {
   for (int i = tid; i < p.olen; i += nthr) o[i] = Z[drop + i];
 }
 
+// ------------------------------------------------------------------------------
+// K3+K4 for ANY 2-3-5-smooth P up to 10240 -- the sizes the register-tiled chan_ifft / chan_c2r menu does not hold
+// (wfm's 384 kHz channel on a 20 ms block with overlap 5 is P = 9600, src/wfm.c:37-39; odd sample rates).  One workgroup
+// per channel: the gather x response of src/filter.c:728-911 lands in LDS in FFT order (COMPLEX or REAL output, ISB
+// unpacking, Nyquist bin zeroed -- the same rules as chan_ifft / chan_c2r, bin by bin), the backward transform is the
+// Stockham stage loop of mini_ovs, the last olen samples leave with the optional downconvert() epilogue.
+// ------------------------------------------------------------------------------
+struct AnyParams { ChanParams c; MiniParams m; int real_out; };
+
+__global__ void __launch_bounds__(1024) chan_any(AnyParams q) {
+  HIP_DYNAMIC_SHARED(float2, lds)
+  const ChanParams& p = q.c;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int P = q.m.N;
+  if ((int)blockIdx.x >= p.nch) return;
+  const int ch = p.ch0 + (int)blockIdx.x;
+  float2* A = lds;
+  float2* B = lds + P;
+  const ChanDesc d = p.desc[ch];
+  const float2* __restrict__ H = p.resp + (long)d.row * P;
+  const float2* __restrict__ X = p.spec;
+  if (!q.real_out) {
+    for (int i = tid; i < P; i += nthr) {
+      int t = i - (P + 1) / 2; if (t < 0) t += P;          // rank from the most negative bin
+      const int u = t - d.t0;
+      const bool ok = (u >= 0) && (u < d.cnt) && (i != (P + 1) / 2);
+      int src = d.src0 + d.dir * u;
+      if (d.wrap && src >= d.wrap) src -= d.wrap;
+      float2 v = make_float2(0.f, 0.f);
+      if (ok) { v = X[spec_addr(p.lay, src)]; if (d.conj) v.y = -v.y; v = cmul(v, H[i]); }
+      A[i] = v;
+    }
+    __syncthreads();
+    if (p.isb != nullptr && p.isb[ch] != 0) {              // src/filter.c:895-909 (workgroup-uniform)
+      for (int k = tid; k <= P / 2; k += nthr) {
+        if (k == 0) { A[0] = make_float2(0.f, 0.f); continue; }
+        if (2 * k >= P) continue;
+        const float2 pos = A[k], neg = A[P - k];
+        A[k] = make_float2(pos.x + neg.x, pos.y - neg.y);          // pos + conj(neg)
+        A[P - k] = make_float2(neg.x - pos.x, neg.y + pos.y);      // neg - conj(pos)
+      }
+      __syncthreads();
+      if (tid == 0) A[(P + 1) / 2] = make_float2(0.f, 0.f);        // :911 comes after the unpack
+      __syncthreads();
+    }
+  } else {
+    const int SB = P / 2 + 1, shift = d.shift;
+    for (int i = tid; i < P; i += nthr) {
+      const int k = i <= P / 2 ? i : P - i;                 // the slave bin this entry of the Hermitian extension comes from
+      const int mi = k + shift;
+      bool ok; int a, b = 0;
+      if (p.m_real) { ok = mi >= 0 && mi < p.m_bins; a = ok ? mi : 0; }                         // :808
+      else {
+        ok = mi >= -(p.m_bins / 2) && mi < p.m_bins / 2;                                        // :798
+        a = mi % p.m_bins; if (a < 0) a += p.m_bins;
+        b = (p.m_bins - mi) % p.m_bins; if (b < 0) b += p.m_bins;
+      }
+      if (k == (SB + 1) / 2) ok = false;                                                        // :911
+      float2 x = make_float2(0.f, 0.f);
+      if (ok) {
+        x = X[spec_addr(p.lay, a)];
+        if (!p.m_real) { const float2 w = X[spec_addr(p.lay, b)]; x = make_float2(x.x + w.x, x.y - w.y); }   // X[a] + conj(X[b]), :800
+        x = cmul(x, H[k]);
+        if (k == 0 || 2 * k == P) x.y = 0.f;                // c2r ignores these imaginary parts
+        if (i > P / 2) x.y = -x.y;
+      }
+      A[i] = x;
+    }
+    __syncthreads();
+  }
+  float2* Y = mini_fft<+1>(A, B, q.m, tid, nthr);
+  float2* W = (Y == A) ? B : A;                             // free again: reduction scratch
+  const int drop = P - p.olen;
+  if (q.real_out) {
+    float* __restrict__ o = reinterpret_cast<float*>(p.out) + (long)ch * p.olen;
+    for (int n = tid; n < p.olen; n += nthr) o[n] = Y[drop + n].x;
+    return;
+  }
+  float2* __restrict__ o = p.out + (long)ch * p.olen;
+  const bool fine = p.fine != nullptr && p.fine[ch].on;
+  double part = 0.0;
+  if (fine) {
+    const FineDesc f = p.fine[ch];
+    const double kb = (double)(p.job - f.job0);
+    const unsigned r = (unsigned)(((unsigned long long)((p.job - f.job0) % (unsigned)f.V + 1u) * (unsigned)f.adj_num) % (unsigned)f.V);
+    const double base = f.phase0 + (double)r / (double)f.V;
+    for (int n = tid; n < p.olen; n += nthr) {
+      const double g = kb * (double)p.olen + (double)n;
+      double hi = g * f.freq, lo = fma(g, f.freq, -hi);
+      hi -= rint(hi);
+      double qd = 0.0;
+      if (f.rate != 0.0) { qd = 0.5 * f.rate * g * (g + 1.0); qd -= rint(qd); }
+      double sn, cs;
+      sincospi(2.0 * (base + hi + lo + qd), &sn, &cs);
+      const float2 v = Y[drop + n];
+      const double xr = v.x, xi = v.y;
+      const float2 w = make_float2((float)(xr * cs - xi * sn), (float)(xr * sn + xi * cs));
+      o[n] = w;
+      part += (double)(w.x * w.x + w.y * w.y);
+    }
+  } else {
+    for (int n = tid; n < p.olen; n += nthr) {
+      const float2 v = Y[drop + n];
+      o[n] = v;
+      part += (double)(v.x * v.x + v.y * v.y);
+    }
+  }
+  if (p.power != nullptr) {                                 // workgroup-uniform
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) part += __shfl_xor(part, dd);
+    double* red = reinterpret_cast<double*>(W);
+    __syncthreads();                                        // every lane is done with Y's partner buffer
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+      double tot = 0.0;
+      for (int w = 0; w < (nthr + 63) / 64; w++) tot += red[w];
+      p.power[ch] = tot / (double)p.olen;
+    }
+  }
+}
+
 }  // namespace chz

@@ -127,6 +127,23 @@ def test_dropin_radiod_style_small():
 
 
 @pytest.mark.gpu
+def test_dropin_wfm_sized_slaves():
+    # what demod_wfm() asks the front-end master for (src/wfm.c:37-39): 384 kHz channels, olen = 7680, P = 9600 -- a size
+    # outside the register-tiled menu, served by chan_any; plain C caller, channel pthreads, retune and new filter on the way
+    _build_lib(); ol.build()
+    L, M, olen, P = 25920, 6481, 7680, 9600
+    nblocks = 5
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = [(2500, 2500, 10 ** 6, 10 ** 6, -0.3, 0.3, 3.0, -0.3, 0.3),
+            (-4000, 4100, 2, 10 ** 6, -0.26, 0.26, 3.0, -0.26, 0.26),          # retune at block 2
+            (7000, 7000, 10 ** 6, 3, -0.3, 0.3, 3.0, -0.1, 0.2)]               # new filter at block 3
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x)
+    _check(L, M, olen, P, plan, nblocks, out, spec, meta, x)
+
+
+@pytest.mark.gpu
 def test_dropin_radiod_style_config3():
     # BASELINE config 3 through the unmodified-caller interface: 129.6 MS/s, 1024 channel threads
     _build_lib(); ol.build()

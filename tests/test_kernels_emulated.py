@@ -223,6 +223,44 @@ def test_noise_estimate_kernel(emu, in_type, B, s_bins, lay):
     assert np.allclose(n0, want, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("in_type,B", [(ol.REAL, 16201), (ol.COMPLEX, 12000), (ol.COMPLEX, 12001)])
+@pytest.mark.parametrize("P,olen,mode", [(64, 48, "plain"), (250, 200, "plain"), (720, 576, "isb"), (1000, 800, "real"), (2048, 1024, "plain"),
+                                         (2700, 2160, "isb"), (9600, 7680, "plain"), (9600, 7680, "real"), (4096, 2048, "real")])
+def test_generic_size_channel_kernel(emu, in_type, B, P, olen, mode):
+    """chan_any: any 2-3-5-smooth P the register-tiled menu does not hold (wfm's 384 kHz channel is P = 9600), one workgroup
+    per channel, Stockham stages in LDS -- COMPLEX output, ISB unpacking and REAL output against the restatement."""
+    src = open(os.path.join(CSRC, "chz_plan.h")).read()
+    import re
+    menu = re.search(r"#define CHZ_CHAN_MENU\(X\)(.*?)\n\n", src, re.S).group(1)
+    assert P not in {int(a) * int(b) for a, b in re.findall(r"X\((\d+),\s*(\d+)\)", menu)}      # really the generic path
+    rng = np.random.default_rng(B + 3 * P)
+    spec = (rng.standard_normal(B) + 1j * rng.standard_normal(B)).astype(np.complex64)
+    shifts = [0, -1, P // 2, -(P // 2) - 3, B - 1, B - P // 2, -(B + 10), (B + 1) // 2] + ([int(x) for x in rng.integers(-B, B, 4)] if P < 4000 else [])
+    if P >= 9600 and in_type != ol.REAL:
+        shifts = shifts[:3]                                   # the float64 DFT by definition behind the oracle is O(P^2)
+    nch = len(shifts)
+    resp = (rng.standard_normal((nch, P)) + 1j * rng.standard_normal((nch, P))).astype(np.complex64)
+    sh = np.array(shifts, np.int32)
+    lay = (0, 0, 0) if B % 2 == 0 else (135, 144, 4)
+    if mode == "real":
+        out = np.zeros((nch, olen), np.float32)
+        assert emu.emu_channels_real(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, out.ctypes.data, *lay) == 0
+    elif mode == "isb":
+        flags = (np.arange(nch) % 3 != 2).astype(np.uint8)
+        out = np.zeros((nch, olen), np.complex64)
+        assert emu.emu_channels_isb(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, flags.ctypes.data, out.ctypes.data) == 0
+    else:
+        out = np.zeros((nch, olen), np.complex64)
+        assert emu.emu_channels(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, out.ctypes.data, *lay) == 0
+    for i, sft in enumerate(shifts):
+        kw = dict(out_type=ol.REAL) if mode == "real" else dict(isb=bool(flags[i])) if mode == "isb" else {}
+        want = ol.channel(spec, in_type, P, olen, sft, resp[i], **kw)
+        if np.linalg.norm(want) == 0:
+            assert not out[i].any()
+        else:
+            assert rel(out[i], want) < 2e-6, (sft, i)
+
+
 @pytest.mark.parametrize("in_type,B", [(ol.REAL, 4801), (ol.COMPLEX, 6000), (ol.COMPLEX, 6001)])
 @pytest.mark.parametrize("P,olen", [(1200, 960), (300, 240), (20, 16), (600, 480)])
 def test_real_output_channel_kernel(emu, in_type, B, P, olen):
