@@ -39,13 +39,14 @@ if DEMOD:
     for c0 in range(0, cap, tile):
         bank.set_tuning(0, c0, shifts + (c0 // tile) % 7, np.full(tile, -3.3 / 12000.0))
     bank.enable_noise(129.6e6)
-    bank.set_pcm_stride(2 * olen)            # mono S16: 480 B per channel and block, contiguous
-    q = ol.lin_params()
+    MULAW = os.environ.get("CRT_ENC") == "mulaw"        # G.711: one byte per sample, 240 B per channel and block
+    bank.set_pcm_stride(olen if MULAW else 2 * olen)     # mono S16: 480 B per channel and block, contiguous
+    q = ol.lin_params(encoding=ol.PCM_MULAW) if MULAW else ol.lin_params()
     one = pkg.engine.DemodParams(*[getattr(q, f) for f, _ in ol.LinParams._fields_])
     for c0 in range(0, cap, 65536):
         bank.set_demod(0, c0, [one] * min(65536, cap - c0), 0.02)
     hst = C.c_void_p()
-    assert lib.chz_host_alloc(C.byref(hst), 48 * cap) == 0
+    assert lib.chz_host_alloc(C.byref(hst), C.sizeof(pkg.engine.DemodStatus) * cap) == 0
 import time
 
 def measure(n):
