@@ -310,6 +310,12 @@ int chz_bank_set_pcm_stride(chz_engine *e, int bank, int bytes);
  * on `slot`; synchronous / asynchronous on the demodulator stream (completion: chz_sync) */
 int chz_bank_read_pcm(chz_engine *e, int bank, int slot, int ch0, int n, void *pcm, chz_demod_status *status);
 int chz_bank_read_pcm_async(chz_engine *e, int bank, int slot, int ch0, int n, void *pcm, chz_demod_status *status);
+/* the same with one byte per channel instead of the 96-byte record: what the caller of send_output() needs every block */
+#define CHZ_FLAG_NO_SAMPLES 1   /* send_output(chan, NULL, N, mute) */
+#define CHZ_FLAG_MUTE 2
+#define CHZ_FLAG_PLL_LOCK 4
+#define CHZ_FLAG_TONE_MUTE 8
+int chz_bank_read_pcm_flags_async(chz_engine *e, int bank, int slot, int ch0, int n, void *pcm, unsigned char *flags);
 
 /* ---- small inline masters: radiod's filter2 (src/radio.c:1572-1594: a private COMPLEX master of N = round2(2*blocksize)
  * points with one same-size COMPLEX slave, run inline by the channel thread; share/presets.conf:204,223,297).  A pool holds

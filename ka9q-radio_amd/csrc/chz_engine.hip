@@ -77,6 +77,7 @@ struct Bank {
   DemodState* dm_state = nullptr;        // [cap]
   DemodExt* dm_ext = nullptr;            // [cap] PLL / tone-squelch state; allocated when the first channel asks for either
   DemodStatus* dm_status = nullptr;      // [ND][cap]
+  unsigned char* dm_flags = nullptr;     // [ND][cap] one status byte per channel and block
   unsigned char* dm_pcm = nullptr;       // [ND][cap][pcm_stride]
   std::vector<DemodChan> dm_chan_h;      // [cap]
   struct OscHost { bool init = false; double freq = 0.0, phase0 = 0.0; unsigned job0 = 0; };
@@ -207,8 +208,8 @@ template <class T> static int upload(T** dst, const std::vector<f2>& v) {
 static void free_bank(Bank& b) {
   hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub);
   hipFree(b.fine); hipFree(b.power); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam);
-  hipFree(b.dm_chan); hipFree(b.dm_state); hipFree(b.dm_ext); hipFree(b.dm_status); hipFree(b.dm_pcm);
-  b.dm_chan = nullptr; b.dm_state = nullptr; b.dm_ext = nullptr; b.dm_status = nullptr; b.dm_pcm = nullptr; b.dm_on = 0; b.dm_chan_h.clear(); b.dm_osc.clear();
+  hipFree(b.dm_chan); hipFree(b.dm_state); hipFree(b.dm_ext); hipFree(b.dm_status); hipFree(b.dm_flags); hipFree(b.dm_pcm);
+  b.dm_chan = nullptr; b.dm_state = nullptr; b.dm_ext = nullptr; b.dm_status = nullptr; b.dm_flags = nullptr; b.dm_pcm = nullptr; b.dm_on = 0; b.dm_chan_h.clear(); b.dm_osc.clear();
   for (int s = 0; s < CHZ_ND; s++) {
     if (b.ev_bank[s]) (void)hipEventDestroy(b.ev_bank[s]);
     if (b.ev_tail[s]) (void)hipEventDestroy(b.ev_tail[s]);
@@ -727,7 +728,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
     }
     DemodParams d{};
     d.in = bank_out(b, slot); d.power = b.power + so; d.n0 = b.n0 + so; d.chan = b.dm_chan; d.state = b.dm_state; d.ext = b.dm_ext;
-    d.status = b.dm_status + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = n; d.olen = b.olen;
+    d.status = b.dm_status + so; d.flags = b.dm_flags + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = n; d.olen = b.olen;
     d.pcm_stride = b.pcm_stride; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;      // Power_alpha, src/radio.c:72
     mark(in, ts, 6, true);
     launch_demod(ts, d, IN_E0(in), IN_E1(in));
@@ -1100,6 +1101,7 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
     HIPOK(hipMalloc((void**)&b.dm_chan, sizeof(DemodChan) * cap)); HIPOK(hipMemset(b.dm_chan, 0, sizeof(DemodChan) * cap));
     HIPOK(hipMalloc((void**)&b.dm_state, sizeof(DemodState) * cap)); HIPOK(hipMemset(b.dm_state, 0, sizeof(DemodState) * cap));
     HIPOK(hipMalloc((void**)&b.dm_status, sizeof(DemodStatus) * cap * CHZ_ND)); HIPOK(hipMemset(b.dm_status, 0, sizeof(DemodStatus) * cap * CHZ_ND));
+    HIPOK(hipMalloc((void**)&b.dm_flags, cap * CHZ_ND)); HIPOK(hipMemset(b.dm_flags, 0, cap * CHZ_ND));
     HIPOK(hipMalloc((void**)&b.dm_pcm, (size_t)b.pcm_stride * cap * CHZ_ND)); HIPOK(hipMemset(b.dm_pcm, 0, (size_t)b.pcm_stride * cap * CHZ_ND));
     for (int s = 0; s < CHZ_ND; s++) {
       HIPOK(hipEventCreateWithFlags(&b.ev_bank[s], hipEventDisableTiming));
@@ -1206,7 +1208,7 @@ int chz_bank_demod(chz_engine* e, int bank, unsigned job, int slot) {
   const size_t so = (size_t)slot * b.cap;
   DemodParams d{};
   d.in = bank_out(b, slot); d.power = b.power + so; d.n0 = b.n0 + so; d.chan = b.dm_chan; d.state = b.dm_state; d.ext = b.dm_ext;
-  d.status = b.dm_status + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = b.active; d.olen = b.olen;
+  d.status = b.dm_status + so; d.flags = b.dm_flags + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = b.active; d.olen = b.olen;
   d.pcm_stride = b.pcm_stride; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;
   launch_demod(e->tail, d);
   HIPOK(hipGetLastError());
@@ -1237,6 +1239,18 @@ static int read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm
   if (pcm) HIPOK(hipMemcpyAsync(pcm, b.dm_pcm + so * stride, stride * (size_t)n, hipMemcpyDeviceToHost, e->tail));
   if (status) HIPOK(hipMemcpyAsync(status, b.dm_status + so, sizeof(DemodStatus) * (size_t)n, hipMemcpyDeviceToHost, e->tail));
   if (wait) HIPOK(hipStreamSynchronize(e->tail));
+  return 0;
+}
+// the per-block essentials only: PCM + one flag byte per channel (the full status record is 96 bytes; a host that ships
+// audio reads it when somebody asks, not 50 times a second for every channel)
+int chz_bank_read_pcm_flags_async(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm, unsigned char* flags) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
+  Bank& b = e->banks[(size_t)bank];
+  if (!b.dm_chan) return fail(-1, "bank has no demodulator: call chz_bank_set_demod first");
+  const size_t so = (size_t)slot * b.cap + ch0, stride = (size_t)b.pcm_stride;
+  if (pcm) HIPOK(hipMemcpyAsync(pcm, b.dm_pcm + so * stride, stride * (size_t)n, hipMemcpyDeviceToHost, e->tail));
+  if (flags) HIPOK(hipMemcpyAsync(flags, b.dm_flags + so, (size_t)n, hipMemcpyDeviceToHost, e->tail));
   return 0;
 }
 int chz_bank_read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm, chz_demod_status* status) {

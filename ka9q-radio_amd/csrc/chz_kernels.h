@@ -1111,6 +1111,7 @@ struct DemodParams {
   DemodState* state;         // [cap]
   DemodExt* ext;             // [cap] PLL / tone-squelch state (read only by channels that enable them)
   DemodStatus* status;       // [cap] this slot
+  unsigned char* flags;      // [cap] this slot: the status in one byte (CHZ_FLAG_*), what send_output()'s caller needs every block
   unsigned char* pcm;        // [cap][pcm_stride] this slot
   int ch0, nch, olen, pcm_stride;
   unsigned job;
@@ -1131,6 +1132,11 @@ __device__ __forceinline__ unsigned char demod_g711(float v, bool alaw) {
   const int mantissa = (alaw && exponent == 0) ? (pcm >> 4) & 0x0F : (pcm >> (exponent + 3)) & 0x0F;
   const unsigned char code = (unsigned char)((exponent << 4) | mantissa);
   return alaw ? (unsigned char)(code ^ (sign ? 0xD5 : 0x55)) : (unsigned char)~(code | (sign << 7));
+}
+// one byte per channel and block: bit 0 frame has no samples (send_output(chan, NULL, ..)), bit 1 mute, bit 2 PLL locked, bit 3 tone squelch muting
+__device__ __forceinline__ void demod_publish(const DemodParams& p, int ch, const DemodStatus& r) {
+  p.status[ch] = r;
+  if (p.flags != nullptr) p.flags[ch] = (unsigned char)((r.frame & 1) | ((r.mute & 1) << 1) | ((r.pll_lock & 1) << 2) | ((r.tone_mute & 1) << 3));
 }
 __device__ __forceinline__ void demod_put(unsigned char* o, int enc, int idx, float v) {
   if (enc == CHZ_PCM_MULAW_K || enc == CHZ_PCM_ALAW_K) {
@@ -1299,7 +1305,7 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
         if (st.squelch_state >= 1) ext->pl_sample_count = 0;
         r.tone_deviation = ext->tone_deviation; r.tone_mute = ext->tone_mute;
       }
-      p.status[ch] = r; p.state[ch] = st;
+      demod_publish(p, ch, r); p.state[ch] = st;
     }
     return;
   }
@@ -1433,7 +1439,7 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
     if (tmute) {                                                                // :305-309: muted before de-emphasis runs
       st.deemph_state = deemph_before;
       r.frame = 1; r.mute = 1; r.output_power = 0.0; r.foffset = st.foffset; r.pdeviation = st.pdeviation;
-      if (lane == 0) { p.status[ch] = r; p.state[ch] = st; }
+      if (lane == 0) { demod_publish(p, ch, r); p.state[ch] = st; }
       return;
     }
   }
@@ -1450,7 +1456,7 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
     }
   }
   r.frame = 0; r.mute = 0; r.gain = gain; r.output_power = wave_sum(part) / N; r.foffset = st.foffset; r.pdeviation = st.pdeviation;
-  if (lane == 0) { p.status[ch] = r; p.state[ch] = st; }
+  if (lane == 0) { demod_publish(p, ch, r); p.state[ch] = st; }
 }
 
 __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
@@ -1692,7 +1698,7 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
     r.frame = 0;
     r.mute = (output_power == 0 || !st.squelch_open || !c.tuned);
   }
-  if (lane == 0) { p.status[ch] = r; p.state[ch] = st; }
+  if (lane == 0) { demod_publish(p, ch, r); p.state[ch] = st; }
 }
 
 // ------------------------------------------------------------------------------

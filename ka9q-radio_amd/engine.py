@@ -57,7 +57,7 @@ SYMBOLS = [
     "chz_bank_create", "chz_bank_set_responses", "chz_bank_set_shifts", "chz_bank_set_active",
     "chz_bank_execute", "chz_bank_execute_range", "chz_bank_destroy", "chz_bank_read", "chz_bank_read_async",
     "chz_spectrum_read_async", "chz_host_callback", "chz_host_alloc", "chz_host_free", "chz_host_register", "chz_host_unregister",
-    "chz_bank_output_device", "chz_bank_write_block", "chz_bank_demod", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
+    "chz_bank_output_device", "chz_bank_write_block", "chz_bank_demod", "chz_bank_read_pcm_flags_async", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
     "chz_bank_set_tuning", "chz_bank_read_power", "chz_bank_read_power_async",
     "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
     "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real", "chz_bank_set_isb", "chz_bank_set_beam",
@@ -393,6 +393,18 @@ class Bank:
         L = lib()
         L.chz_bank_demod.argtypes = [_vp, _i, C.c_uint, _i]
         _check(L.chz_bank_demod(self.eng._h, self.id, job, job % 4 if slot is None else slot))
+
+    def read_pcm_flags(self, slot, ch0=0, n=None):
+        """(pcm uint8[n][stride], flags uint8[n]): chz_bank_read_pcm_flags_async + chz_sync of the demodulator stream."""
+        if n is None:
+            n = self.active - ch0
+        stride = _check(lib().chz_bank_pcm_stride(self.eng._h, self.id))
+        pcm = np.zeros((n, stride), np.uint8); fl = np.zeros(n, np.uint8)
+        L = lib()
+        L.chz_bank_read_pcm_flags_async.argtypes = [_vp, _i, _i, _i, _i, _vp, _vp]
+        _check(L.chz_bank_read_pcm_flags_async(self.eng._h, self.id, slot, ch0, n, pcm.ctypes.data, fl.ctypes.data))
+        self.eng.sync()
+        return pcm, fl
 
     def enable_noise(self, samprate):
         """estimate_noise() (src/radio.c:1783-1866) on the device after every block; samprate = front-end rate in Hz."""

@@ -32,10 +32,12 @@ for c0 in range(0, cap, tile):
     bank.set_responses(c0, resp); bank.set_shifts(c0, shifts + (c0 // tile) % 7)
 eng.set_notches([0], 0.01)
 DEMOD = os.environ.get("CRT_DEMOD") == "1"
+FLAGS = os.environ.get("CRT_STATUS") == "flags"        # one status byte per channel and block instead of the 96-byte record
 if DEMOD:
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
     import oracle_lib as ol
     lib.chz_bank_read_pcm_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.chz_bank_read_pcm_flags_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     for c0 in range(0, cap, tile):
         bank.set_tuning(0, c0, shifts + (c0 // tile) % 7, np.full(tile, -3.3 / 12000.0))
     bank.enable_noise(129.6e6)
@@ -56,7 +58,9 @@ def measure(n):
         t0 = time.perf_counter()
         assert lib.chz_input_write(eng._h, hin, L) == 0              # H2D of the block's new samples (pinned source)
         assert lib.chz_step(eng._h, j) == 0
-        if DEMOD:
+        if DEMOD and FLAGS:
+            assert lib.chz_bank_read_pcm_flags_async(eng._h, bank.id, j % 4, 0, n, hout, hst) == 0
+        elif DEMOD:
             assert lib.chz_bank_read_pcm_async(eng._h, bank.id, j % 4, 0, n, hout, hst) == 0
         else:
             assert lib.chz_bank_read_async(eng._h, bank.id, j % 4, 0, n, hout) == 0

@@ -264,7 +264,7 @@ int emu_demod(const float* in, const double* power, const double* n0, const void
   DemodParams d{};
   d.in = reinterpret_cast<const float2*>(in); d.power = power; d.n0 = n0;
   d.chan = static_cast<const DemodChan*>(chan); d.state = static_cast<DemodState*>(state); d.status = static_cast<DemodStatus*>(status);
-  d.ext = static_cast<DemodExt*>(ext);
+  d.ext = static_cast<DemodExt*>(ext); d.flags = nullptr;
   d.pcm = pcm; d.ch0 = 0; d.nch = nch; d.olen = olen; d.pcm_stride = olen * 8; d.job = job; d.blocktime = blocktime; d.power_alpha = 0.10;
   return launch_demod(nullptr, d);
 }

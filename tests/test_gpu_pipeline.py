@@ -491,6 +491,9 @@ def test_coherent_modes_and_tone_squelch_on_the_device(pkg):
                 if st.frame == ol.FRAME_DATA:
                     _check_pcm(p, pcm[i], want, 240 * p.channels, 4e-6)
             out = B.read_slot(s); power = B.read_power(s); noise = B.read_noise(s); pcm, status = B.read_pcm(s)
+            pcm2, fl = B.read_pcm_flags(s)                       # the one-byte-per-channel status of the same block
+            assert np.array_equal(pcm2, pcm)
+            assert [int(f) for f in fl] == [(st_.frame & 1) | (st_.mute & 1) << 1 | (st_.pll_lock & 1) << 2 | (st_.tone_mute & 1) << 3 for st_ in status]
             for i, p in enumerate(fm):
                 want, st = o_fm[i].block(out[i], power[i], noise[i], 0.02)
                 got = status[i]
