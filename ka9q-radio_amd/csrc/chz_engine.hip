@@ -184,6 +184,7 @@ struct chz_engine {
   hipEvent_t notch_ev[CHZ_NOTCH_EVENTS] = {};
   unsigned notch_seq = 0; bool notch_have = false;      // notch_ev[(notch_seq-1) % 8] is the latest recorded one
   int notch_order = 0;                                  // 0: device ticket (default), 1: HIP events (env CHZ_NOTCH_ORDER=event)
+  long long notch_max_wait = 0;                         // ticket wait budget, counter ticks (default 20 s; env CHZ_NOTCH_WAIT_MS)
   unsigned* notch_ver = nullptr;                        // device: tickets served so far
   unsigned notch_tickets = 0;                           // host: tickets handed out so far
   unsigned* notch_err = nullptr;                        // pinned host word the kernel raises when a ticket wait runs out
@@ -282,6 +283,13 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   HIPOK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   for (int i = 0; i < CHZ_MAX_LANES; i++) HIPOK(hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming));
   for (int i = 0; i < CHZ_NOTCH_EVENTS; i++) HIPOK(hipEventCreateWithFlags(&e->notch_ev[i], hipEventDisableTiming | hipEventReleaseToDevice));
+  {
+    int khz = 0;                                        // constant-rate counter, kHz (100 MHz on this family)
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device) != hipSuccess || khz <= 0) khz = 100000;
+    double ms = 20000.0;
+    if (const char* w = getenv("CHZ_NOTCH_WAIT_MS")) { const double v = atof(w); if (v > 0) ms = v; }
+    e->notch_max_wait = (long long)(ms * (double)khz);
+  }
   if (const char* no = getenv("CHZ_NOTCH_ORDER")) e->notch_order = strcmp(no, "event") == 0 ? 1 : (strcmp(no, "unordered-timing-only") == 0 ? 2 : 0);
   HIPOK(hipHostMalloc((void**)&e->notch_err, sizeof(unsigned), hipHostMallocMapped));
   *e->notch_err = 0;
@@ -537,7 +545,7 @@ static int enqueue_notch(chz_engine* e, int slot, hipStream_t st, Instr* in, Not
     q.spec = e->spec[slot]; q.addr = e->notch_addr; q.next = e->notch_next; q.head = e->notch_head;
     q.alpha = e->notch_alpha; q.state = e->notch_state; q.n = e->n_notch;
     e->notch_tab.fill_inline(q, e->notch_alpha_h.data());
-    q.err = e->notch_err;
+    q.err = e->notch_err; q.max_wait = e->notch_max_wait;
     if (!by_event && e->nlanes > 1 && e->notch_order != 2) { q.ver = e->notch_ver; q.seq = e->notch_tickets++; }   // 2: A/B timing of the bare kernel, WRONG results
     mark(in, st, 5, true);
     if (launch_notch_fix(st, q, IN_E0(in), IN_E1(in))) { rc = fail(-4, "notch list too long"); break; }

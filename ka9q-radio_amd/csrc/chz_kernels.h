@@ -579,6 +579,7 @@ struct NotchFixParams {
   unsigned* ver;          // ticket counter or nullptr
   unsigned seq;           // this block's ticket
   unsigned* err;          // host-visible error word (0 = fine)
+  long long max_wait;     // ticket wait budget in ticks of the constant-rate counter (hipDeviceAttributeWallClockRate)
   int i_addr[CHZ_NOTCH_INLINE];
   signed char i_next[CHZ_NOTCH_INLINE], i_head[CHZ_NOTCH_INLINE];
   double i_alpha[CHZ_NOTCH_INLINE];
@@ -596,11 +597,14 @@ __global__ void __launch_bounds__(1024) notch_fix(NotchFixParams p) {
   if (p.ver != nullptr) {
     // poll with relaxed loads (they bypass the non-coherent caches); ONE acquire fence once the ticket is up, so the
     // cache invalidation that comes with it is not repeated per poll
-    unsigned v = 0; int spins = 0;
+    // bounded in TIME (constant-rate counter), not in polls: free-running over banks of millions of channels a predecessor
+    // can legitimately be tens of milliseconds away, queued behind its lane's previous channel kernels
+    unsigned v = 0;
+    const long long t0 = wall_clock64();
     for (;;) {
       v = __hip_atomic_load(p.ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (v == p.seq || ++spins >= (1 << 19)) break;
-      __builtin_amdgcn_s_sleep(1);
+      if (v == p.seq || wall_clock64() - t0 > p.max_wait) break;
+      __builtin_amdgcn_s_sleep(8);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (v != p.seq) {                                   // never publish a wrong recurrence
