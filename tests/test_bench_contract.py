@@ -68,3 +68,29 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "2", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "only" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,port", [(["--config", "5", "--no-crt"], 29581),
+                                       (["--config", "4", "--exchange", "replicate", "--crt-channels", "1500000", "--crt-blocks", "12"], 29582)])
+def test_bench_two_ranks_control_flow_on_one_gpu(args, port):
+    """The driver's N > 1 launch line with two ranks sharing this box's one GPU (gloo control plane: RCCL refuses two ranks per
+    device, so the modes without a data-path collective): rendezvous, per-rank workloads and seeds, barrier + max-over-ranks
+    timing, the gathered C_rt leg, ONE JSON line from rank 0 with the whole-job aggregate."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--min-seconds", "0.1", "--no-cpu-baseline"] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1                                          # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    per_rank = 1024
+    assert j["config"]["channels_total"] == 2 * per_rank
+    assert abs(j["value"] - 2 * per_rank * 0.02 / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
+    if "--no-crt" not in args:
+        assert j["c_rt"]["gpus"] == 2 and j["c_rt"]["channels"] >= 2 * 1490000 and j["c_rt"]["blocks"] == 12
