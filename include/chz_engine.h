@@ -233,10 +233,11 @@ int chz_spectrum_exchange_rows(chz_engine *e, chz_comm *c, int slot, int root, c
 int chz_run_blocks_sharded(chz_engine *e, chz_comm *c, int root, int mode, const int *row_lo, const int *row_hi,
                            unsigned job0, int nblocks, chz_timing *timing);
 
-/* ---- SURVEY 8(f) rank 4 -- the linear demodulator behind the fine-tuned channel outputs (demod_linear, src/linear.c:56-375,
- * without the PLL branch): noise smoothing (src/radio.c:1466-1473), post-detection shift oscillator, block AGC, the final
- * demodulation pass with its per-sample gain ramp, the SNR squelch sequencer, and PCM packing (src/import.h:88-118 via
- * send_output, src/audio.c:117-133).  Runs for every channel of a COMPLEX-output bank that has tuning (chz_bank_set_tuning:
+/* ---- SURVEY 8(f) rank 4 -- the linear and FM demodulators behind the fine-tuned channel outputs (demod_linear,
+ * src/linear.c:56-375; demod_fm, src/fm.c:19-345): the PLL of the coherent modes with its lock detector, noise smoothing
+ * (src/radio.c:1466-1473), post-detection shift oscillator, block AGC, the final demodulation pass with its per-sample gain
+ * ramp, the squelch sequencers; FM's SNR estimators, discriminator or PLL demodulator, PL-tone squelch, de-emphasis; and PCM
+ * packing (src/import.h:88-118 and G.711, src/rtp.c:459-533, via send_output, src/audio.c:117-133).  Runs for every channel of a COMPLEX-output bank that has tuning (chz_bank_set_tuning:
  * bb_power) and the noise estimate (chz_bank_enable_noise) switched on, in block order on a stream of its own behind the
  * bank's channel kernel.  What leaves the device per channel and block is packed PCM plus a status record instead of the
  * complex baseband -- for a 12 kHz mono S16 channel 480 B instead of 1920 B.  RTP framing and the sockets stay with the host.

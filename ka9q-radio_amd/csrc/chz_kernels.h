@@ -1075,7 +1075,7 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
 
 // ------------------------------------------------------------------------------
 // the linear demodulator's per-block work behind the fine-tuned channel outputs
-// (demod_linear, src/linear.c:56-375, without the PLL branch): noise smoothing (src/radio.c:1466-1473), the
+// (demod_linear, src/linear.c:56-375): the PLL of the coherent modes (:76-153), noise smoothing (src/radio.c:1466-1473), the
 // post-detection shift oscillator (:168-172), block AGC (:177-234), the final demodulation pass with the per-sample
 // gain ramp (:236-311), the SNR squelch sequencer (:313-366), and PCM packing (src/import.h:88-118 via send_output,
 // src/audio.c:117-133).  What leaves the device per channel and block is the packed PCM (480 B for a 12 kHz mono

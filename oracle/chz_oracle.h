@@ -102,7 +102,7 @@ int chzo_stream_points(const chzo_stream *s);
 int chzo_stream_push(chzo_stream *s, const float *samples, float *spectrum);
 int chzo_stream_push_f64(chzo_stream *s, const float *samples, double *spectrum);
 
-/* ---- the linear demodulator's per-block work (src/linear.c:56-375 without the PLL) and PCM
+/* ---- the linear demodulator's per-block work (src/linear.c:56-375, PLL of the coherent modes included) and PCM
    packing (src/import.h:88-118).  Field names follow the chan_t members linear.c reads. */
 enum { CHZO_PCM_S16BE = 0, CHZO_PCM_S16LE = 1, CHZO_PCM_F32LE = 2, CHZO_PCM_F32BE = 3, CHZO_PCM_MULAW = 4, CHZO_PCM_ALAW = 5 };
 /* G.711 companding as send_output() applies it (float_to_mulaw / float_to_alaw, src/rtp.c:459-483,500-533) */

@@ -3,7 +3,8 @@
 (10.4 MB H2D) and returns EVERY channel's olen output samples to pinned host memory (1920 B per 12 kHz channel) before
 it counts as done.  The host link, not HBM, sets this figure (~6.5e5 channels at 63 GB/s).
 CRT_DEMOD=1: every channel carries the linear demodulator (fine tuning, noise estimate, AGC, mono S16BE) and
-what goes back is its packed PCM + status (480 + 48 B per channel and block) instead of the complex baseband."""
+what goes back is its packed PCM + status (480 B of S16, or 240 B of G.711 with CRT_ENC=mulaw, + the 96-byte status record, or one
+flag byte with CRT_STATUS=flags, per channel and block) instead of the complex baseband."""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -440,7 +440,7 @@ FM_CASES = [dict(), dict(threshold_extend=True, encoding=ol.PCM_F32LE), dict(dee
 
 
 def test_fm_demodulator_kernel(emu):
-    """The FM branch of the demodulator kernel (demod_fm, src/fm.c, no PLL / PL tone) against the restated demodulator:
+    """The FM branch of the demodulator kernel (demod_fm, src/fm.c; PLL / PL tone: test_fm_pll_and_tone_kernel) against the restated demodulator:
     carrier coming up out of the noise, a modulated stretch with a frequency offset, fading out through the squelch tail."""
     from test_oracle_vs_reference import _fm_case
     nblk, N, fs, bt = 36, 480, 24000.0, 0.02

@@ -535,7 +535,7 @@ def _fm_case(r, nblk, N, fs, tone=0.0, last=26):
 @pytest.mark.parametrize("kw", [dict(), dict(threshold_extend=True, encoding=ol.PCM_F32LE), dict(deemph_tc=0, encoding=ol.PCM_S16LE),
                                 dict(snr_squelch=True, squelch_tail=3, encoding=ol.PCM_F32BE)])
 def test_fm_demodulator_matches_reference_fm_c(oracle_built, kw):
-    # demod_fm() (src/fm.c:19-345, no PLL, no PL tone) run from the reference's own fm.c / misc.c / iir.c, block after block
+    # demod_fm() (src/fm.c:19-345; the PLL and PL-tone branches have their own test below) run from the reference's own fm.c / misc.c / iir.c, block after block
     r = np.random.default_rng(len(kw) + 40)
     nblk, N, fs, bt = 36, 480, 24000.0, 0.02
     bb, power = _fm_case(r, nblk, N, fs)
