@@ -320,7 +320,7 @@ int chz_bank_read_pcm_flags_async(chz_engine *e, int bank, int slot, int ch0, in
 
 /* ---- small inline masters: radiod's filter2 (src/radio.c:1572-1594: a private COMPLEX master of N = round2(2*blocksize)
  * points with one same-size COMPLEX slave, run inline by the channel thread; share/presets.conf:204,223,297).  A pool holds
- * every instance of one geometry (8 <= N = L+M-1 <= 8192, 2-3-5-smooth); ONE kernel launch serves all instances that are
+ * every instance of one geometry (8 <= N = L+M-1 <= 8192, no prime factor above 13); ONE kernel launch serves all instances that are
  * due (one workgroup each: forward transform, gather x response with the slave's shift, ISB unpacking, backward transform,
  * all in LDS).  The device keeps no overlap state: a request carries its whole N-sample window, exactly what the
  * reference's mirrored ring holds at input_read_pointer (src/filter.c:626-636). */

@@ -1715,8 +1715,8 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
 //   ISB unpacking, Nyquist bin zeroed (src/filter.c:728-793,895-911)  -> backward transform (:914), keep the
 //   last olen samples (:357).
 // Stateless: the overlap lives in the caller's ring, so an instance can be re-run or served by several slaves.
-// The transform is a Stockham autosort over radix-{2,3,4,5} stages (natural order in, natural order out, two
-// LDS buffers), twiddles from a float64-rounded table W_N^k.  N <= 8192, 2-3-5-smooth.
+// The transform is a Stockham autosort over radix-{2,3,4,5,7,11,13} stages (natural order in, natural order out, two
+// LDS buffers), twiddles from a float64-rounded table W_N^k.  N <= 8192, no prime factor above 13.
 // ------------------------------------------------------------------------------
 #ifndef CHZ_MINI_MAX_STAGES
 #define CHZ_MINI_MAX_STAGES 14
@@ -1763,7 +1763,10 @@ __device__ __forceinline__ float2* mini_fft(float2* a, float2* b, const MiniPara
     if (r == 2) mini_stage<2, SIGN>(a, b, p.tw, p.N, Ns, tid, nthr);
     else if (r == 3) mini_stage<3, SIGN>(a, b, p.tw, p.N, Ns, tid, nthr);
     else if (r == 4) mini_stage<4, SIGN>(a, b, p.tw, p.N, Ns, tid, nthr);
-    else mini_stage<5, SIGN>(a, b, p.tw, p.N, Ns, tid, nthr);
+    else if (r == 5) mini_stage<5, SIGN>(a, b, p.tw, p.N, Ns, tid, nthr);
+    else if (r == 7) mini_stage<7, SIGN>(a, b, p.tw, p.N, Ns, tid, nthr);
+    else if (r == 11) mini_stage<11, SIGN>(a, b, p.tw, p.N, Ns, tid, nthr);
+    else mini_stage<13, SIGN>(a, b, p.tw, p.N, Ns, tid, nthr);
     Ns *= r;
     __syncthreads();
     float2* t = a; a = b; b = t;
@@ -1816,14 +1819,18 @@ __global__ void __launch_bounds__(256) mini_ovs(MiniParams p) {
 }
 
 // ------------------------------------------------------------------------------
-// K3+K4 for ANY 2-3-5-smooth P up to 10240 -- the sizes the register-tiled chan_ifft / chan_c2r menu does not hold
+// K3+K4 for ANY P without a prime factor above 13 -- the sizes the register-tiled chan_ifft / chan_c2r menu does not hold
 // (wfm's 384 kHz channel on a 20 ms block with overlap 5 is P = 9600, src/wfm.c:37-39; odd sample rates).  One workgroup
 // per channel: the gather x response of src/filter.c:728-911 lands in LDS in FFT order (COMPLEX or REAL output, ISB
 // unpacking, Nyquist bin zeroed -- the same rules as chan_ifft / chan_c2r, bin by bin), the backward transform is the
 // Stockham stage loop of mini_ovs, the last olen samples leave with the optional downconvert() epilogue.
 // ------------------------------------------------------------------------------
-struct AnyParams { ChanParams c; MiniParams m; int real_out; };
+// BIG: P beyond what two buffers in LDS hold (10240 < P <= 65536: 768 kHz ... 1.5 MHz channels): the two buffers live in a
+// per-workgroup piece of global scratch instead, which the L2 keeps; everything else is the same code.  (Within a workgroup
+// a barrier orders global memory as it orders LDS: the wavefronts of a workgroup share their CU's vector cache.)
+struct AnyParams { ChanParams c; MiniParams m; int real_out; float2* scratch; };
 
+template <bool BIG>
 __global__ void __launch_bounds__(1024) chan_any(AnyParams q) {
   HIP_DYNAMIC_SHARED(float2, lds)
   const ChanParams& p = q.c;
@@ -1831,8 +1838,8 @@ __global__ void __launch_bounds__(1024) chan_any(AnyParams q) {
   const int P = q.m.N;
   if ((int)blockIdx.x >= p.nch) return;
   const int ch = p.ch0 + (int)blockIdx.x;
-  float2* A = lds;
-  float2* B = lds + P;
+  float2* A = BIG ? q.scratch + (size_t)blockIdx.x * 2 * (size_t)P : lds;
+  float2* B = A + P;
   const ChanDesc d = p.desc[ch];
   const float2* __restrict__ H = p.resp + (long)d.row * P;
   const float2* __restrict__ X = p.spec;

@@ -52,23 +52,26 @@ inline int launch_chan_real(Radix2 r, int grid, int block, size_t lds, hipStream
 #undef X
   return -1;
 }
-// any 2-3-5-smooth P without a register-tiled kernel: one workgroup per channel (chan_any); needs the large-LDS attribute once
+// any P (prime factors up to 13) without a register-tiled kernel: one workgroup per channel (chan_any); needs the large-LDS attribute once
 inline int chan_any_prepare() {
 #if defined(__HIPCC__) && !defined(HIPEMU)
   static int done = -1;
-  if (done < 0) done = hipFuncSetAttribute(reinterpret_cast<const void*>(chan_any), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : 0;
+  if (done < 0) done = hipFuncSetAttribute(reinterpret_cast<const void*>(chan_any<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : 0;
   return done == 1 ? 0 : -1;
 #else
   return 0;
 #endif
 }
-inline int launch_chan_any(const ChanGeom& g, int nch, hipStream_t s, const ChanParams& p, const float2* tw, bool real_out, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+inline int launch_chan_any(const ChanGeom& g, int nch, hipStream_t s, const ChanParams& p, const float2* tw, bool real_out, float2* scratch = nullptr,
+                           hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   if (nch <= 0) return 0;
+  if (g.big && !scratch) return -1;
   AnyParams q{};
-  q.c = p; q.real_out = real_out ? 1 : 0;
+  q.c = p; q.real_out = real_out ? 1 : 0; q.scratch = scratch;
   q.m.N = g.P; q.m.olen = p.olen; q.m.nstages = g.nstages; q.m.tw = tw;
   for (int i = 0; i < g.nstages; i++) q.m.radix[i] = g.radix[i];
-  CHZ_LAUNCH(chan_any, nch, g.any_threads, g.lds, s, e0, e1, q);
+  if (g.big) { CHZ_LAUNCH(chan_any<true>, nch, g.any_threads, 0, s, e0, e1, q); }
+  else { CHZ_LAUNCH(chan_any<false>, nch, g.any_threads, g.lds, s, e0, e1, q); }
   return 0;
 }
 inline int launch_notch_fix(hipStream_t s, const NotchFixParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {

@@ -280,23 +280,25 @@ inline bool build_fwd_plan(int N, int in_type, const char* spec, FwdPlan& out) {
 #define CHZ_MINI_MAX_STAGES 14
 #endif
 inline bool mini_factor(int N, int* radix, int* nstages);
-#define CHZ_ANY_MAX_P 10240                     // two P-point complex buffers in the 160 KB of LDS
+#define CHZ_ANY_LDS_P 10240                     // two P-point complex buffers in the 160 KB of LDS
+#define CHZ_ANY_MAX_P 65536                     // beyond CHZ_ANY_LDS_P the two buffers are global scratch (L2)
 struct ChanGeom {
   int P = 0; Radix2 r{}; int lpc = 0, cpw = 0, wpb = 1;
   size_t lds = 0;
   std::vector<f2> tw_sub;   // backward sign
   // P without a register-tiled kernel in the menu (wfm's 384 kHz channel: P = 9600; odd sample rates): one workgroup per
   // channel, Stockham stages in LDS (chan_any)
-  bool any = false;
+  bool any = false, big = false;
   int any_threads = 0, nstages = 0, radix[CHZ_MINI_MAX_STAGES] = {0};
   std::vector<f2> tw_any;   // [P] e^{-2 pi i k / P}
 };
 inline bool build_chan_geom(int P, ChanGeom& g) {
   if (!chan_menu_lookup(P, &g.r)) {
-    if (P < 8 || P > CHZ_ANY_MAX_P || !mini_factor(P, g.radix, &g.nstages)) return false;     // 2-3-5-smooth sizes only
+    if (P < 8 || P > CHZ_ANY_MAX_P || !mini_factor(P, g.radix, &g.nstages)) return false;     // no prime factor above 13
     g.P = P; g.any = true;
     g.any_threads = P <= 1024 ? 128 : P <= 2048 ? 256 : P <= 4096 ? 512 : 1024;
-    g.lds = sizeof(f2) * 2 * (size_t)P;
+    g.big = P > CHZ_ANY_LDS_P;
+    g.lds = g.big ? 0 : sizeof(f2) * 2 * (size_t)P;
     g.tw_any.resize((size_t)P);
     for (int k = 0; k < P; k++) g.tw_any[(size_t)k] = root_of_unity(k, P, -1);
     return true;
@@ -350,7 +352,7 @@ inline ChanDescH make_chan_desc(int in_type, int m_bins, int P, int shift) {
 inline bool mini_factor(int N, int* radix, int* nstages) {
   int n = N, k = 0;
   while (n % 4 == 0 && k < CHZ_MINI_MAX_STAGES) { radix[k++] = 4; n /= 4; }
-  const int small[3] = {2, 3, 5};
+  const int small[6] = {2, 3, 5, 7, 11, 13};
   for (int r : small)
     while (n % r == 0 && k < CHZ_MINI_MAX_STAGES) { radix[k++] = r; n /= r; }
   *nstages = k;

@@ -96,6 +96,8 @@ static int emu_forward_impl(const float* ring, const short* ring16, float scale1
   return 0;
 }
 
+// which kernel serves a channel size: 1 register-tiled menu, 2 chan_any in LDS, 3 chan_any in global scratch, 0 none
+int emu_chan_kind(int P) { ChanGeom g; if (!build_chan_geom(P, g)) return 0; return !g.any ? 1 : (g.big ? 3 : 2); }
 int emu_chan_desc(int in_type, int m_bins, int P, int shift, int* out6) {
   ChanDescH d = make_chan_desc(in_type, m_bins, P, shift);
   out6[0] = d.t0; out6[1] = d.cnt; out6[2] = d.src0; out6[3] = d.dir; out6[4] = d.conj; out6[5] = d.wrap;
@@ -122,7 +124,7 @@ int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, in
   const int per_block = g.wpb * g.cpw;
   const int grid = (nch + per_block - 1) / per_block;
   c.stage = getenv("CHZ_CHAN_STAGE") ? atoi(getenv("CHZ_CHAN_STAGE")) : 0;
-  if (g.any) { c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL; return launch_chan_any(g, nch, nullptr, c, F2(g.tw_any), false); }
+  if (g.any) { c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL; std::vector<float2> scr(g.big ? (size_t)nch * 2 * P : 0); return launch_chan_any(g, nch, nullptr, c, F2(g.tw_any), false, g.big ? scr.data() : nullptr); }
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
 }
 
@@ -142,7 +144,7 @@ int emu_channels_isb(const float* spec, int m_bins, int in_type, int P, int olen
   c.resp = reinterpret_cast<const float2*>(resp);
   c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub); c.isb = isb;
-  if (g.any) { c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL; return launch_chan_any(g, nch, nullptr, c, F2(g.tw_any), false); }
+  if (g.any) { c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL; std::vector<float2> scr(g.big ? (size_t)nch * 2 * P : 0); return launch_chan_any(g, nch, nullptr, c, F2(g.tw_any), false, g.big ? scr.data() : nullptr); }
   const int per_block = g.wpb * g.cpw;
   const int grid = (nch + per_block - 1) / per_block;
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
@@ -187,7 +189,7 @@ int emu_channels_real(const float* spec, int m_bins, int in_type, int P, int ole
   c.desc = desc.data(); c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL;
   c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub);
-  if (g.any) return launch_chan_any(g, nch, nullptr, c, F2(g.tw_any), true);
+  if (g.any) { std::vector<float2> scr(g.big ? (size_t)nch * 2 * P : 0); return launch_chan_any(g, nch, nullptr, c, F2(g.tw_any), true, g.big ? scr.data() : nullptr); }
   const int per_block = g.wpb * g.cpw;
   const int grid = (nch + per_block - 1) / per_block;
   return launch_chan_real(g.r, grid, g.wpb * 64, g.lds, nullptr, c);

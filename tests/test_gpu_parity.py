@@ -204,7 +204,7 @@ def test_channel_sizes_random_spectrum(pkg, P, olen):
         fa.delete_filter_input(master)
 
 
-@pytest.mark.parametrize("P,olen", [(250, 200), (1000, 800), (2700, 2160), (9600, 7680)])
+@pytest.mark.parametrize("P,olen", [(250, 200), (1000, 800), (2700, 2160), (9600, 7680), (5500, 4400), (10080, 8064)])   # the last two: 220 k, 403.2 k (factors 11, 7)
 def test_channel_sizes_outside_the_menu(pkg, P, olen):
     # sizes without a register-tiled kernel run through chan_any (one workgroup per channel, Stockham stages in LDS);
     # 9600 is the WFM channel of src/wfm.c:37-39 (384 kHz x 20 ms x overlap 5/4)
@@ -231,6 +231,32 @@ def test_channel_sizes_outside_the_menu(pkg, P, olen):
                 check_channel(s.output, ol.channel(spec64, ol.REAL, P, olen, sh, s.response))
     finally:
         fa.delete_filter_input(master)
+
+
+def test_channel_sizes_beyond_the_lds(pkg):
+    # 768 kHz and 1.536 MHz channels of the full-rate master (P = 19200, 38400; share/*.conf has both): chan_any with its two
+    # transform buffers in global scratch.  The restatement's gather + float64 inverse DFT on the DEVICE's own spectrum.
+    L, M = 2592000, 648001
+    rng = np.random.default_rng(5)
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    try:
+        eng.write((rng.standard_normal(L) * 0.05).astype(np.float32))
+        eng.forward(0)
+        spec = eng.spectrum(0).astype(np.complex128)
+        B = spec.shape[0]
+        for P, olen in ((19200, 15360), (38400, 30720)):
+            shifts = np.array([250000, -(B - P // 4), B - 9000], np.int32)
+            bank = eng.bank(P, olen, len(shifts))
+            resp = (rng.standard_normal((len(shifts), P)) + 1j * rng.standard_normal((len(shifts), P))).astype(np.complex64) / P
+            bank.set_responses(0, resp); bank.set_shifts(0, shifts); bank.set_active(len(shifts))
+            bank.execute(0)
+            eng.sync()
+            got = bank.read_slot(0)
+            for i, sh in enumerate(shifts):
+                want = ol.channel(spec, ol.REAL, P, olen, int(sh), resp[i])
+                assert np.linalg.norm(got[i] - want) <= 3e-6 * np.linalg.norm(want), (P, i)
+    finally:
+        eng.close()
 
 
 def test_complex_master_channels(pkg):

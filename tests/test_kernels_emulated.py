@@ -225,7 +225,9 @@ def test_noise_estimate_kernel(emu, in_type, B, s_bins, lay):
 
 @pytest.mark.parametrize("in_type,B", [(ol.REAL, 16201), (ol.COMPLEX, 12000), (ol.COMPLEX, 12001)])
 @pytest.mark.parametrize("P,olen,mode", [(64, 48, "plain"), (250, 200, "plain"), (720, 576, "isb"), (1000, 800, "real"), (2048, 1024, "plain"),
-                                         (2700, 2160, "isb"), (9600, 7680, "plain"), (9600, 7680, "real"), (4096, 2048, "real")])
+                                         (2700, 2160, "isb"), (9600, 7680, "plain"), (9600, 7680, "real"), (4096, 2048, "real"),
+                                         (5500, 4400, "plain"), (6930, 5544, "isb"), (4032, 3200, "real"),       # 220 k / 277.2 k / 161.28 k: factors 7, 11
+                                         (19200, 15360, "plain"), (25200, 20160, "real")])                       # 768 k / 1008 k: beyond the LDS
 def test_generic_size_channel_kernel(emu, in_type, B, P, olen, mode):
     """chan_any: any 2-3-5-smooth P the register-tiled menu does not hold (wfm's 384 kHz channel is P = 9600), one workgroup
     per channel, Stockham stages in LDS -- COMPLEX output, ISB unpacking and REAL output against the restatement."""
@@ -238,6 +240,10 @@ def test_generic_size_channel_kernel(emu, in_type, B, P, olen, mode):
     shifts = [0, -1, P // 2, -(P // 2) - 3, B - 1, B - P // 2, -(B + 10), (B + 1) // 2] + ([int(x) for x in rng.integers(-B, B, 4)] if P < 4000 else [])
     if P >= 9600 and in_type != ol.REAL:
         shifts = shifts[:3]                                   # the float64 DFT by definition behind the oracle is O(P^2)
+    if P > 10240:
+        if in_type != ol.REAL:
+            pytest.skip("one master type is enough for the sizes that take seconds per channel on the CPU")
+        shifts = shifts[:3]
     nch = len(shifts)
     resp = (rng.standard_normal((nch, P)) + 1j * rng.standard_normal((nch, P))).astype(np.complex64)
     sh = np.array(shifts, np.int32)
@@ -360,6 +366,27 @@ def test_mini_master_kernel(emu, L, M):
             want = ol.channel(spec, ol.COMPLEX, N, L, int(shifts[i]), resp[i], isb=bool(isb[i]))
             assert rel(out[i], want) < 3e-6, (blk, i)
         hist = win[:, L:]
+
+
+def test_every_channel_rate_of_the_reference_configs_has_a_kernel(emu):
+    """`samprate = ...` of every channel group in the reference's share/*.conf (grep, 2025 tree) at radiod's block time of 20 ms
+    and overlap factors 5 (default) and 2: P = rate * 0.02 * N/L.  All of them must be served -- by the register-tiled menu, by
+    chan_any in LDS or by chan_any in global scratch."""
+    rates = [8000, 12000, 16000, 24000, 32000, 40000, 48000, 50000, 64000, 80000, 100000, 128000, 160000, 192000, 220000, 277200,
+             384000, 768000, 201600, 705600, 403200, 1536000, 161280, 1008000, 5040]      # (912 k / 921.6 k in those files are front ends)
+    kinds = {}
+    for fs in rates:
+        for num, den in ((5, 4), (2, 1)):
+            if fs % 50 or (fs // 50 * num) % den:
+                continue                     # the reference itself refuses a block that is not a whole number of samples / bins
+            olen = fs // 50
+            P = olen * num // den
+            if P > 65536:
+                continue                     # 1.5 MHz at overlap 2: beyond CHZ_ANY_MAX_P, the drop-in refuses it loudly
+            kinds[(fs, num, den)] = emu.emu_chan_kind(P)
+    missing = [k for k, v in kinds.items() if v == 0]
+    assert not missing, missing
+    assert kinds[(12000, 5, 4)] == 1 and kinds[(384000, 5, 4)] == 2 and kinds[(768000, 5, 4)] == 3
 
 
 class _DemodChan(C.Structure):           # struct DemodChan, chz_kernels.h
