@@ -16,7 +16,8 @@ namespace chz {
 // (R1,R2) pairs with a compiled kernel instantiation.  Sub-transform length = R1*R2.
 #define CHZ_FWD_MENU(X) \
   X(4, 4) X(5, 5) X(6, 6) X(5, 9) X(5, 10) X(5, 15) X(8, 8) X(8, 9) X(9, 9) X(10, 10) X(10, 12) X(5, 25) X(9, 15) \
-  X(12, 12) X(10, 15) X(8, 19) X(10, 16) X(12, 15) X(12, 16) X(15, 15) X(15, 16) X(16, 16) X(16, 20) X(20, 20) X(9, 16)
+  X(12, 12) X(10, 15) X(8, 19) X(10, 16) X(12, 15) X(12, 16) X(15, 15) X(15, 16) X(16, 16) X(16, 20) X(20, 20) X(9, 16) \
+  X(10, 20) X(10, 13)
 // per-channel backward transform lengths P = R1*R2 (reference sizes: docs/FFTW3.md:51-68)
 #define CHZ_CHAN_MENU(X) \
   X(4, 5) X(5, 6) X(10, 15) X(10, 16) X(10, 20) X(15, 20) X(16, 20) X(20, 20) X(20, 24) \

@@ -98,6 +98,13 @@ static int emu_forward_impl(const float* ring, const short* ring16, float scale1
 
 // which kernel serves a channel size: 1 register-tiled menu, 2 chan_any in LDS, 3 chan_any in global scratch, 0 none
 int emu_chan_kind(int P) { ChanGeom g; if (!build_chan_geom(P, g)) return 0; return !g.any ? 1 : (g.big ? 3 : 2); }
+// does the planner find axes for this master?  (desc receives the plan string)
+int emu_plan_exists(int N, int in_type, char* desc, int len) {
+  FwdPlan p;
+  if (!build_fwd_plan(N, in_type, "", p)) return 0;
+  if (desc && len > 0) { strncpy(desc, p.desc.c_str(), (size_t)len - 1); desc[len - 1] = 0; }
+  return 1;
+}
 int emu_chan_desc(int in_type, int m_bins, int P, int shift, int* out6) {
   ChanDescH d = make_chan_desc(in_type, m_bins, P, shift);
   out6[0] = d.t0; out6[1] = d.cnt; out6[2] = d.src0; out6[3] = d.dir; out6[4] = d.conj; out6[5] = d.wrap;

@@ -74,6 +74,8 @@ def check_channel(got, want, floor=0.0):
     (2592000, 648001, ol.REAL, ""),           # config 3: N = 3,240,000
     (400000, 100001, ol.REAL, ""),            # Airspy R2, rof500000 (docs/FFTW3.md:52,60)
     (18240, 18241, ol.COMPLEX, ""),           # Airspy HF+, cof36480 = 2^7*3*5*19 (docs/FFTW3.md:52,62): needs the radix-19 butterfly
+    (2600000, 650001, ol.REAL, ""),           # RX888 at its 130 MS/s ceiling: N = 3,250,000 = 2^4*5^6*13 (axes of 130 = 10x13 and 200 = 10x20)
+    (2500000, 625001, ol.REAL, ""),           # 125 MS/s: N = 3,125,000 = 2^3*5^8
 ])
 def test_forward_matches_oracle(pkg, L, M, in_type, plan):
     rng = np.random.default_rng(L + in_type)

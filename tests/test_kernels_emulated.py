@@ -63,6 +63,7 @@ def rel(a, b):
     (36480, ol.COMPLEX, b"", 0), (36480, ol.COMPLEX, b"152x240", 20000),
     (162000, ol.REAL, b"", 0), (64800, ol.REAL, b"72x25x36", 65000),
     (86400, ol.REAL, b"135x640"[:0] + b"45x16x120", 0), (162000, ol.REAL, b"81x2000"[:0] + b"45x25x144", 1024), (57600, ol.REAL, b"25x16x144", 0),
+    (26000, ol.COMPLEX, b"130x200", 8), (52000, ol.REAL, b"130x400", 0), (40000, ol.REAL, b"200x200", 34),   # axes 130 = 10x13, 200 = 10x20
 ])
 def test_forward_kernels(emu, N, in_type, spec, start):
     rng = np.random.default_rng(N + start)
@@ -387,6 +388,25 @@ def test_every_channel_rate_of_the_reference_configs_has_a_kernel(emu):
     missing = [k for k, v in kinds.items() if v == 0]
     assert not missing, missing
     assert kinds[(12000, 5, 4)] == 1 and kinds[(384000, 5, 4)] == 2 and kinds[(768000, 5, 4)] == 3
+
+
+def test_planner_covers_the_front_ends_people_run(emu):
+    """Front-end rates of the reference's hardware drivers and example configurations (RX888 at 129.6 / 64.8 / 65.536 / 32.4 MS/s
+    and its 130 / 125 / 100 MS/s options, Airspy R2 20 MS/s real, Airspy HF+ 912 k / 768 k / 384 k / 192 k, RTL-SDR 1.8 - 3.2 MS/s,
+    SDRplay / HackRF / BladeRF 2 - 20 MS/s, Funcube 192 k, sig_gen at anything) at a 20 ms block with overlap 5 and 2: the planner
+    must find axes for every one of them."""
+    emu.emu_plan_exists.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+    real = [129.6e6, 64.8e6, 65.536e6, 32.4e6, 130e6, 125e6, 100e6, 50e6, 25e6, 20e6]
+    cplx = [2.4e6, 2.048e6, 1.8e6, 1.92e6, 3.2e6, 2e6, 2.5e6, 3e6, 4e6, 5e6, 6e6, 8e6, 9.6e6, 10e6, 12.5e6, 20e6,
+            912e3, 921.6e3, 768e3, 384e3, 192e3, 250e3, 1.536e6]
+    missing = []
+    for typ, rates in ((ol.REAL, real), (ol.COMPLEX, cplx)):
+        for fs in rates:
+            L = int(round(fs * 0.02))
+            for M in (L // 4 + 1, L + 1):
+                if not emu.emu_plan_exists(L + M - 1, typ, None, 0):
+                    missing.append((fs, M))
+    assert not missing, missing
 
 
 class _DemodChan(C.Structure):           # struct DemodChan, chz_kernels.h
