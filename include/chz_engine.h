@@ -302,6 +302,9 @@ int chz_bank_set_demod(chz_engine *e, int bank, unsigned job, int ch0, int n, co
  * demodulators over the slot as block `job` on the demodulator stream (results: chz_bank_read_pcm). */
 int chz_bank_write_block(chz_engine *e, int bank, int slot, int ch0, int n, const float *samples, const double *bb_power, const double *n0);
 int chz_bank_demod(chz_engine *e, int bank, unsigned job, int slot);
+/* on = 0: the bank's demodulators run only when chz_bank_demod says so (its channels pass through filter2 on the way);
+ * on = 1 (default): behind every whole-bank channel launch */
+int chz_bank_demod_auto(chz_engine *e, int bank, int on);
 /* bytes between two channels' PCM rows = the stride of chz_bank_read_pcm's buffer.  Default olen*8 (stereo float32 fits);
  * chz_bank_set_pcm_stride, before the first chz_bank_set_demod, shrinks the rows to what the bank's encodings need (olen*2 for
  * mono S16), so that a block's PCM is one contiguous device-to-host copy of only the bytes that matter */

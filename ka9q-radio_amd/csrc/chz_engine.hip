@@ -84,6 +84,7 @@ struct Bank {
   struct OscHost { bool init = false; double freq = 0.0, phase0 = 0.0; unsigned job0 = 0; };
   std::vector<OscHost> dm_osc;           // [cap] chan->shift with set_osc's phase continuity
   int dm_on = 0;                         // channels with a demodulator
+  bool dm_auto = true;                   // demodulate behind every channel launch (false: only on chz_bank_demod)
   int pcm_stride = 0;                    // bytes between two channels' PCM rows (default olen*8: stereo float32)
   double dm_blocktime = 0.02;
   hipEvent_t ev_bank[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // behind the slot's channel (+ noise) kernel
@@ -730,7 +731,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   }
   // the linear demodulators of this bank, in block order on the demodulator stream.  Only whole-bank
   // launches feed them (a single-channel re-run of the drop-in's miss path does not advance anybody's AGC).
-  if (b.dm_on > 0 && ch0 == 0) {
+  if (b.dm_on > 0 && b.dm_auto && ch0 == 0) {
     hipStream_t ts = (in && in->on) ? st : e->tail;
     if (ts != st) {
       HIPOK(hipEventRecord(b.ev_bank[slot], st));
@@ -1212,6 +1213,14 @@ int chz_bank_write_block(chz_engine* e, int bank, int slot, int ch0, int n, cons
   if (bb_power) HIPOK(hipMemcpyAsync(b.power + so, bb_power, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, e->tail));
   if (n0) HIPOK(hipMemcpyAsync(b.n0 + so, n0, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, e->tail));
   HIPOK(hipStreamSynchronize(e->tail));            // the caller's buffers are free again
+  return 0;
+}
+// a bank whose channels go through filter2 first: the channel kernel's output is not what the demodulators should see
+int chz_bank_demod_auto(chz_engine* e, int bank, int on) {
+  BANK_CHECK(e, bank, 0, 0);
+  { int r = sync_all(e); if (r) return r; }
+  e->banks[(size_t)bank].dm_auto = on != 0;
+  drop_graph(e);
   return 0;
 }
 int chz_bank_demod(chz_engine* e, int bank, unsigned job, int slot) {

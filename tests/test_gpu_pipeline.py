@@ -512,3 +512,75 @@ def test_coherent_modes_and_tone_squelch_on_the_device(pkg):
     assert max(d[0] for d in dev) < 1e-9 and max(d[1] for d in dev) < 1e-9 and max(d[2] for d in dev) < 1e-6
     assert all(10 < locked[i] < nblk - 10 for i in range(3)) and locked[3] == 0        # the loops locked on their carriers
     assert data[0] > 5 and data[1] > 5 and data[2] > 5 and data[3] == 0 and data[4] == 0 and data[5] > 5
+
+
+@pytest.mark.gpu
+def test_filter2_between_channelizer_and_demodulator(pkg):
+    """radiod with `filter2 = 1` (src/radio.c:1572-1594): channel block -> the channel's private second filter (chz_mini_*) -> the
+    fine-tuning tail (radiod's own, here the restated one) -> demodulator.  On the device: a bank whose demodulators do NOT run
+    behind the channel kernel (chz_bank_demod_auto 0), the pooled inline masters, chz_bank_write_block + chz_bank_demod.  Against
+    the same chain on the oracle, block after block; a second, ordinary bank keeps demodulating automatically alongside."""
+    L, M, P, olen, fs_out = 25920, 6481, 300, 240, 12000.0
+    N = L + M - 1
+    nblk, nch = 14, 4
+    rng = np.random.default_rng(31)
+    t = np.arange(nblk * L)
+    x = (0.05 * np.cos(2 * np.pi * (2500.3 / N) * t) * (1 + 0.4 * np.sin(2 * np.pi * 3e-4 * t)) + 1e-4 * rng.standard_normal(nblk * L)).astype(np.float32)
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    resp = np.stack([ol.set_filter(P, olen, N, True, -0.4, 0.4, 9.0)] * nch).astype(np.complex64)
+    shifts = np.full(nch, 2500, np.int32)                      # 2500 % overlap factor == 0, no fine offset: the tuning tail is the identity
+    params = [ol.lin_params(), ol.lin_params(env=True, dc_alpha=0.002, encoding=ol.PCM_S16LE), ol.lin_params(channels=2, encoding=ol.PCM_F32LE),
+              ol.lin_params(agc=False, gain_db=30.0)]
+    dp = [pkg.engine.DemodParams(*[getattr(p, f) for f, _ in ol.LinParams._fields_]) for p in params]
+    banks = []
+    for _ in range(2):
+        b = eng.bank(P, olen, nch)
+        b.set_responses(0, resp); b.set_tuning(0, 0, shifts, np.zeros(nch)); b.set_active(nch); b.enable_noise(1.296e6); b.set_pcm_stride(8 * olen)
+        b.set_demod(0, 0, dp, 0.02)
+        banks.append(b)
+    f2bank, plain = banks
+    f2bank.demod_auto(False)
+    # filter2: L2 = 240, N2 = round2(2 * 240) = 512 -> M2 = 273; a 2.4 kHz low-pass per channel
+    L2, M2 = olen, 512 - olen + 1
+    pool = pkg.engine.MiniPool(L2, M2, nch)
+    insts = [pool.add() for _ in range(nch)]
+    r2 = ol.set_filter(512, L2, 512, False, -0.1, 0.1, 7.0)
+    for i in insts:
+        pool.set_response(i, r2)
+    hist = np.zeros((nch, M2 - 1), np.complex64)
+    st2 = [ol.Stream(L2, M2, ol.COMPLEX) for _ in range(nch)]
+    o_f2 = [ol.LinDemod(p) for p in params]; o_plain = [ol.LinDemod(p) for p in params]
+    try:
+        for b in range(nblk):
+            eng.write(x[b * L:(b + 1) * L]); eng.step(b)
+            s = b % 4
+            raw = f2bank.read_slot(s); noise = f2bank.read_noise(s)
+            win = np.concatenate([hist, raw], axis=1)
+            filt = pool.execute(insts, win)                                   # device: all four second filters in one launch
+            hist = win[:, L2:]
+            pw = np.array([np.mean(np.abs(f.astype(np.complex128)) ** 2) for f in filt])      # the power sum of the tuning tail
+            f2bank.inject(s, filt, pw, noise)
+            f2bank.demod_only(b)
+            pcm, status = f2bank.read_pcm(s)
+            pcm_p, status_p = plain.read_pcm(s)
+            raw_p = plain.read_slot(s); pw_p = plain.read_power(s); noise_p = plain.read_noise(s)
+            for i, p in enumerate(params):
+                spec2 = st2[i].push(raw[i], f64=True)
+                want_f = ol.channel(spec2, ol.COMPLEX, 512, L2, 0, r2)
+                assert np.linalg.norm(filt[i] - want_f) <= 3e-6 * max(np.linalg.norm(want_f), 1e-12)
+                for orc, got, gp, inp, ipw, ins in ((o_f2[i], status[i], pcm[i], filt[i], pw[i], noise[i]),
+                                                    (o_plain[i], status_p[i], pcm_p[i], raw_p[i], pw_p[i], noise_p[i])):
+                    want, st = orc.block(inp, ipw, ins, 0.02)
+                    assert (got.frame, got.mute, got.squelch_state) == (st.frame, st.mute, st.squelch_state), (b, i)
+                    assert got.gain == pytest.approx(st.gain, rel=1e-9) and got.output_power == pytest.approx(st.output_power, rel=1e-6, abs=1e-300)
+                    if st.frame == ol.FRAME_DATA:
+                        nb = ol.pcm_bytes(p.encoding, olen * p.channels)
+                        if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+                            dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
+                            a, w = gp[:nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
+                            assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02, (b, i)
+                        else:
+                            a, w = gp[:nb].view("<f4").astype(np.float64), want.view("<f4").astype(np.float64)
+                            assert np.abs(a - w).max() <= 1e-6 * max(np.abs(w).max(), 1e-30), (b, i)
+    finally:
+        pool.close(); eng.close()
