@@ -2,6 +2,7 @@
 stream-to-queue mappings, retunes and filter swaps that never drain the pipeline, and RCCL behind the C ABI.
 Everything is compared with the CPU oracle (oracle/), which is pinned to the reference's own filter.c.
 """
+import json
 import os
 import subprocess
 import sys
@@ -584,3 +585,13 @@ def test_filter2_between_channelizer_and_demodulator(pkg):
                             assert np.abs(a - w).max() <= 1e-6 * max(np.abs(w).max(), 1e-30), (b, i)
     finally:
         pool.close(); eng.close()
+
+
+@pytest.mark.gpu
+def test_soak_free_running_with_retunes_and_response_swaps():
+    """scripts/soak.py, short: 40,000 blocks of config 3 free-running over 4 streams with channels retuning and responses being
+    swapped all the way; the last block must equal, bit for bit, what a fresh engine with the final settings produces."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak.py"), "20"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["final_block_bit_identical_to_fresh_engine"] is True and j["blocks"] == 40008
