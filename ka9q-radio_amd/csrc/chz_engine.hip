@@ -186,7 +186,7 @@ struct chz_engine {
   hipEvent_t notch_ev[CHZ_NOTCH_EVENTS] = {};
   unsigned notch_seq = 0; bool notch_have = false;      // notch_ev[(notch_seq-1) % 8] is the latest recorded one
   int notch_order = 0;                                  // 0: device ticket (default), 1: HIP events (env CHZ_NOTCH_ORDER=event)
-  long long notch_max_wait = 0;                         // ticket wait budget, counter ticks (default 20 s; env CHZ_NOTCH_WAIT_MS)
+  long long notch_max_wait = 0;                         // ticket wait budget, counter ticks (default 3 s; env CHZ_NOTCH_WAIT_MS)
   unsigned* notch_ver = nullptr;                        // device: tickets served so far
   unsigned notch_tickets = 0;                           // host: tickets handed out so far
   unsigned* notch_err = nullptr;                        // pinned host word the kernel raises when a ticket wait runs out
@@ -288,7 +288,7 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   {
     int khz = 0;                                        // constant-rate counter, kHz (100 MHz on this family)
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device) != hipSuccess || khz <= 0) khz = 100000;
-    double ms = 20000.0;
+    double ms = 3000.0;
     if (const char* w = getenv("CHZ_NOTCH_WAIT_MS")) { const double v = atof(w); if (v > 0) ms = v; }
     e->notch_max_wait = (long long)(ms * (double)khz);
   }
@@ -776,8 +776,8 @@ int chz_set_notches_alpha(chz_engine* e, const int* bins, const double* alpha, i
   HIPOK(hipMemcpy(e->notch_head, t.head.data(), ib, hipMemcpyHostToDevice));
   HIPOK(hipMemcpy(e->notch_alpha, alpha, db, hipMemcpyHostToDevice));
   HIPOK(hipMemset(e->notch_state, 0, 2 * db));
-  HIPOK(hipMalloc((void**)&e->notch_ver, sizeof(unsigned)));
-  HIPOK(hipMemset(e->notch_ver, 0, sizeof(unsigned)));
+  HIPOK(hipMalloc((void**)&e->notch_ver, 2 * sizeof(unsigned)));      // ticket counter + tombstone
+  HIPOK(hipMemset(e->notch_ver, 0, 2 * sizeof(unsigned)));
   HIPOK(hipDeviceSynchronize());
   e->notch_tab = t; e->notch_alpha_h.assign(alpha, alpha + n);
   e->notch_tickets = 0;

@@ -576,7 +576,7 @@ struct NotchFixParams {
   double* state;          // [n][2] persists across blocks
   int n;
   int inl;                // 1: the list is in the i_* arrays below
-  unsigned* ver;          // ticket counter or nullptr
+  unsigned* ver;          // [2] ticket counter, tombstone; or nullptr
   unsigned seq;           // this block's ticket
   unsigned* err;          // host-visible error word (0 = fine)
   long long max_wait;     // ticket wait budget in ticks of the constant-rate counter (hipDeviceAttributeWallClockRate)
@@ -599,6 +599,9 @@ __global__ void __launch_bounds__(1024) notch_fix(NotchFixParams p) {
     // cache invalidation that comes with it is not repeated per poll
     // bounded in TIME (constant-rate counter), not in polls: free-running over banks of millions of channels a predecessor
     // can legitimately be tens of milliseconds away, queued behind its lane's previous channel kernels
+    // p.ver[1] is the chain's tombstone: once one wait has run out nobody behind it waits again (they would each sit out the
+    // whole budget: the counter never moves on after a failure)
+    if (__hip_atomic_load(p.ver + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     unsigned v = 0;
     const long long t0 = wall_clock64();
     for (;;) {
@@ -608,7 +611,10 @@ __global__ void __launch_bounds__(1024) notch_fix(NotchFixParams p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (v != p.seq) {                                   // never publish a wrong recurrence
-      if (i == 0) __hip_atomic_store(p.err, p.seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (i == 0) {
+        __hip_atomic_store(p.ver + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.err, p.seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       return;
     }
   }

@@ -11,7 +11,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_4streams -o t -- python $R/bench.py --steps 20 --warmup 5 --no-crt --no-cpu-baseline > $R/gpurun_out/${TAG}_prof4.json 2> $R/gpurun_out/${TAG}_prof4.err
 CHZ_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_1stream -o t -- python $R/bench.py --steps 20 --warmup 5 --no-crt --no-cpu-baseline > $R/gpurun_out/${TAG}_prof1.json 2> $R/gpurun_out/${TAG}_prof1.err
 cd $R
-bash scripts/pmc_passes.sh $TAG
+timeout 1300 bash scripts/pmc_passes.sh $TAG
 {
   echo "## rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-crt --no-cpu-baseline   (default: 4 HIP streams)"
   python scripts/rocprof_summary.py gpurun_out/prof_${TAG}_4streams
