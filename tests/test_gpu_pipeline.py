@@ -595,3 +595,39 @@ def test_soak_free_running_with_retunes_and_response_swaps():
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
     j = json.loads(r.stdout.strip().splitlines()[-1])
     assert j["final_block_bit_identical_to_fresh_engine"] is True and j["blocks"] == 40008
+
+
+_TINY_BUDGET = r"""
+import sys, os, time
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+from conftest import load_pkg
+pkg = load_pkg()
+L, M = 25920, 6481
+eng = pkg.engine.Engine(L, M, pkg.engine.REAL, ring_blocks=8)
+x = np.random.default_rng(0).standard_normal(8 * L).astype(np.float32)
+eng.write(x[:8 * L - (M - 1)]); eng.write(x[8 * L - (M - 1):])
+b = eng.bank(300, 240, 64); b.set_responses(0, np.ones((64, 300), np.complex64) / 300); b.set_shifts(0, np.arange(64, dtype=np.int32) * 50 + 100); b.set_active(64)
+eng.set_notches([0, 7], 0.01)
+t0 = time.time()
+try:
+    eng.run_blocks(0, 4000)
+    print("RESULT ok %%.2f" %% (time.time() - t0))
+except pkg.engine.ChzError as ex:
+    print("RESULT failed %%.2f %%s" %% (time.time() - t0, str(ex)[:80]))
+"""
+
+
+@pytest.mark.gpu
+def test_a_notch_wait_that_runs_out_fails_fast_and_loudly():
+    """With a wait budget of a microsecond some block's notch kernel will not see its predecessor in time: the run must then
+    END quickly (the tombstone lets everything queued behind give up at once) and SAY so -- never hang, never publish a wrong
+    recurrence.  (Should every wait happen to be shorter than the budget, the run simply succeeds.)"""
+    env = dict(os.environ, CHZ_NOTCH_WAIT_MS="0.001")
+    r = subprocess.run([sys.executable, "-c", _TINY_BUDGET % (ROOT, ROOT)], capture_output=True, text=True, timeout=120, env=env)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+    assert line, (r.stdout[-300:], r.stderr[-800:])
+    kind, secs = line[0].split()[1], float(line[0].split()[2])
+    assert secs < 20.0
+    if kind == "failed":
+        assert "ordering failed" in line[0]
