@@ -79,6 +79,85 @@ def test_forward_kernels(emu, N, in_type, spec, start):
     assert rel(out, want) < 5e-7, desc.value
 
 
+def _menu(name):
+    import re
+    src = open(os.path.join(CSRC, "chz_plan.h")).read()
+    body = re.search(r"#define %s\(X\)(.*?)\n(?://|\n)" % name, src, re.S).group(1)
+    return sorted({int(a) * int(b) for a, b in re.findall(r"X\((\d+),\s*(\d+)\)", body)})
+
+
+def test_forward_kernels_random_plans(emu):
+    """Property test over the planner's whole menu: random two- and three-axis products of compiled axis lengths (N up to 70,000),
+    REAL and COMPLEX input, a random even window start in a ring that wraps -- the automatic plan against the float64 oracle."""
+    axes = _menu("CHZ_FWD_MENU")
+    assert 130 in axes and 200 in axes and 152 in axes
+    rng = np.random.default_rng(2024)
+    done = 0
+    while done < 40:
+        k = int(rng.integers(2, 4))
+        pick = [int(a) for a in rng.choice(axes, k)]
+        N = int(np.prod(pick))
+        if N > 70000 or N < 64:
+            continue
+        in_type = ol.REAL if rng.integers(0, 2) else ol.COMPLEX
+        if in_type == ol.REAL and N % 2:
+            continue
+        per = 1 if in_type == ol.REAL else 2
+        ring_len = (N + 2 * int(rng.integers(10, 600))) * per
+        start = 2 * int(rng.integers(0, ring_len // 2))
+        ring = rng.standard_normal(ring_len).astype(np.float32)
+        win = ring[(start + np.arange(N * per)) % ring_len]
+        bins = N // 2 + 1 if in_type == ol.REAL else N
+        out = np.zeros(bins, np.complex64)
+        desc = C.create_string_buffer(256)
+        r = emu.emu_forward(ring.ctypes.data, ring_len, start, N, in_type, b"", out.ctypes.data, desc, 256, None, None, 0, 0.0)
+        assert r == 0, (N, in_type, pick)                    # a product of menu axes always has a plan
+        want = ol.forward(win if in_type == ol.REAL else win.view(np.complex64), in_type, f64=True)
+        assert rel(out, want) < 5e-7, (N, in_type, desc.value)
+        done += 1
+
+
+def test_generic_channel_sizes_random(emu):
+    """Property test for chan_any: random sizes with prime factors up to 13 (outside the register-tiled menu), random master type,
+    shifts in and out of range, COMPLEX / ISB / REAL output -- against the restatement."""
+    menu = set(_menu("CHZ_CHAN_MENU"))
+    rng = np.random.default_rng(77)
+    primes = [2, 2, 2, 3, 3, 5, 5, 7, 11, 13]
+    done = 0
+    while done < 30:
+        P = int(np.prod(rng.choice(primes, int(rng.integers(3, 8)))))
+        if P in menu or P < 16 or P > 6000:
+            continue
+        mode = ("plain", "isb", "real")[int(rng.integers(0, 3))]
+        if mode == "real" and P % 2:
+            continue
+        olen = max(1, int(P * rng.uniform(0.3, 1.0)))
+        in_type, B = [(ol.REAL, 4801), (ol.COMPLEX, 6000), (ol.COMPLEX, 6001)][int(rng.integers(0, 3))]
+        spec = (rng.standard_normal(B) + 1j * rng.standard_normal(B)).astype(np.complex64)
+        shifts = [0, -(P // 2), B - 1] + [int(x) for x in rng.integers(-B - P, B + P, 3)]
+        nch = len(shifts)
+        resp = (rng.standard_normal((nch, P)) + 1j * rng.standard_normal((nch, P))).astype(np.complex64)
+        sh = np.array(shifts, np.int32)
+        if mode == "real":
+            out = np.zeros((nch, olen), np.float32)
+            assert emu.emu_channels_real(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, out.ctypes.data, 0, 0, 0) == 0
+        elif mode == "isb":
+            flags = (np.arange(nch) % 2).astype(np.uint8)
+            out = np.zeros((nch, olen), np.complex64)
+            assert emu.emu_channels_isb(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, flags.ctypes.data, out.ctypes.data) == 0
+        else:
+            out = np.zeros((nch, olen), np.complex64)
+            assert emu.emu_channels(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, out.ctypes.data, 0, 0, 0) == 0
+        for i, sft in enumerate(shifts):
+            kw = dict(out_type=ol.REAL) if mode == "real" else dict(isb=bool(flags[i])) if mode == "isb" else {}
+            want = ol.channel(spec, in_type, P, olen, sft, resp[i], **kw)
+            if np.linalg.norm(want) == 0:
+                assert not out[i].any()
+            else:
+                assert rel(out[i], want) < 2e-6, (P, olen, mode, in_type, sft)
+        done += 1
+
+
 @pytest.mark.parametrize("stage", [0, 1])
 @pytest.mark.parametrize("in_type,B", [(ol.REAL, 16201), (ol.COMPLEX, 6000), (ol.COMPLEX, 6001)])
 @pytest.mark.parametrize("P,olen", [(300, 240), (600, 480), (200, 160), (400, 320), (1200, 960), (1920, 1536), (150, 120),
@@ -344,7 +423,8 @@ def test_beam_mode_in_channel_kernel(emu, B, P, olen):
             assert rel(out[i], want) < 1e-6, (s, i)
 
 
-@pytest.mark.parametrize("L,M", [(240, 273), (480, 545), (960, 1089), (240, 61), (300, 101), (1920, 2177)])
+@pytest.mark.parametrize("L,M", [(240, 273), (480, 545), (960, 1089), (240, 61), (300, 101), (1920, 2177),
+                                 (252, 133), (660, 441), (1001, 456), (4032, 2017)])      # N = 384, 1100 (11), 1456 (7, 13), 6048 (7)
 def test_mini_master_kernel(emu, L, M):
     """radiod's filter2 geometry (src/radio.c:1572-1594: N = round2(2*blocksize), M = N-L+1) and two non-power-of-two
     ones: window -> forward transform -> gather x response (+ISB) -> backward transform, one workgroup per instance,
