@@ -246,7 +246,7 @@ static void block_done(void *arg) {
   struct timespec t1;
   clock_gettime(CLOCK_MONOTONIC, &t1);
   pthread_mutex_lock(&f->filter_mutex);
-  f->owner = pthread_self();
+  __atomic_store_n(&f->owner, pthread_self(), __ATOMIC_RELEASE);      /* read without the mutex by execute_filter_output */
   __atomic_store_n(&f->completed_jobs[job % ND], job, __ATOMIC_RELEASE);   /* src/filter.c:526-529 */
   pthread_cond_broadcast(&f->filter_cond);              /* src/filter.c:532-535 (kept; nobody in this build waits on it) */
   pthread_mutex_unlock(&f->filter_mutex);
@@ -309,7 +309,10 @@ static int bank_for(struct mctx *c, int P, int olen, bool real) {
     for (int k = 0; k < b->n; k++) {
       nb.slaves[k] = b->slaves[k]; nb.shift[k] = b->shift[k]; nb.isb[k] = b->isb[k];
       nb.beam_on[k] = 0;                                  /* re-uploaded by the next execute_filter_input if the slave is in beam mode */
+      /* the slave's own thread may be inside set_filter right now: its swap frees the old response */
+      pthread_mutex_lock(&nb.slaves[k]->response_mutex);
       if (nb.slaves[k]->response) chz_bank_set_responses(c->eng, nb.id, k, 1, (const float *)nb.slaves[k]->response);
+      pthread_mutex_unlock(&nb.slaves[k]->response_mutex);
     }
     chz_bank_set_shifts(c->eng, nb.id, 0, nb.n, nb.shift);
     if (!real) chz_bank_set_isb(c->eng, nb.id, 0, nb.n, nb.isb);
@@ -519,7 +522,7 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
   }
   /* SPECTRUM: no buffers, no plan: a block clock only (src/filter.c:368-371) */
 done:;
-  slave->next_jobnum = master->next_jobnum;                        /* src/filter.c:413 */
+  slave->next_jobnum = __atomic_load_n(&master->next_jobnum, __ATOMIC_RELAXED);   /* src/filter.c:413 */
   return 0;
 }
 
@@ -539,7 +542,9 @@ int delete_filter_output(struct filter_out *slave) {
       b->slaves[sc->idx] = mv; ms->idx = sc->idx; ms->epoch++;
       b->shift[sc->idx] = b->shift[last];
       if (!b->real && b->isb[sc->idx] != b->isb[last]) { b->isb[sc->idx] = b->isb[last]; chz_bank_set_isb(c->eng, b->id, sc->idx, 1, &b->isb[sc->idx]); }
+      pthread_mutex_lock(&mv->response_mutex);                     /* (see bank_for) */
       if (mv->response) chz_bank_set_responses(c->eng, b->id, ms->idx, 1, (const float *)mv->response);
+      pthread_mutex_unlock(&mv->response_mutex);
       chz_bank_set_shifts(c->eng, b->id, ms->idx, 1, &b->shift[ms->idx]);
       for (int s = 0; s < ND; s++) b->stage_epoch[s][ms->idx] = 0;
     }
@@ -593,9 +598,10 @@ int execute_filter_input(struct filter_in *const f) {
     }
   }
   pthread_mutex_lock(&c->lock);
-  unsigned const job = f->next_jobnum++;                           /* src/filter.c:607 */
+  unsigned const job = __atomic_fetch_add(&f->next_jobnum, 1u, __ATOMIC_RELAXED);   /* src/filter.c:607; read lock-free by slaves being created */
   int const slot = (int)(job % ND);
-  f->samples_by_job[slot] = f->sample_index;                       /* src/filter.c:614-615 */
+  /* readers pick this up without a lock, possibly while a later lap overwrites it (as in the reference): tear-free accesses */
+  __atomic_store_n(&f->samples_by_job[slot], f->sample_index, __ATOMIC_RELAXED);   /* src/filter.c:614-615 */
   f->sample_index += (uint64_t)f->ilen;
   struct done_note *note = &c->note[slot];
   note->ctx = c; note->job = job;
@@ -634,7 +640,7 @@ int execute_filter_input(struct filter_in *const f) {
     b->stage_job[slot] = job; b->stage_n[slot] = b->n;
     for (int k = 0; k < b->n; k++) {
       b->stage_shift[slot][k] = b->shift[k];
-      b->stage_epoch[slot][k] = b->slaves[k]->response ? SCTX(b->slaves[k])->epoch : 0;
+      b->stage_epoch[slot][k] = __atomic_load_n(&b->slaves[k]->response, __ATOMIC_ACQUIRE) ? SCTX(b->slaves[k])->epoch : 0;
       b->stage_isb[slot][k] = b->isb[k];
     }
     stage_wrunlock(c);
@@ -665,7 +671,7 @@ int execute_filter_input(struct filter_in *const f) {
   if (rc == 0 && f->perform_inline) {      /* inline masters hand the block over before returning (src/filter.c:562-600) */
     chz_sync(c->eng);
     pthread_mutex_lock(&f->filter_mutex);
-    f->owner = pthread_self();
+    __atomic_store_n(&f->owner, pthread_self(), __ATOMIC_RELEASE);      /* read without the mutex by execute_filter_output */
     pthread_mutex_unlock(&f->filter_mutex);
   }
   return rc == 0 ? 0 : -1;
@@ -746,7 +752,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
 
   /* same wait / lap arithmetic as src/filter.c:680-702, on a futex instead of filter_cond */
   if (pthread_equal(__atomic_load_n(&master->owner, __ATOMIC_ACQUIRE), pthread_self()))
-    slave->next_jobnum = master->next_jobnum - 1;                  /* src/filter.c:681-683 */
+    slave->next_jobnum = __atomic_load_n(&master->next_jobnum, __ATOMIC_RELAXED) - 1;   /* src/filter.c:681-683 */
   unsigned const job = slave->next_jobnum;
   int const slot = (int)(job % ND);
   bool slept = false;
@@ -773,7 +779,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
     futex_wait_u32(wake, done);                                    /* src/filter.c:686-687 */
     slept = true;
   }
-  slave->sample_index = master->samples_by_job[slot];              /* src/filter.c:705 */
+  slave->sample_index = __atomic_load_n(&master->samples_by_job[slot], __ATOMIC_RELAXED);   /* src/filter.c:705 */
   slave->next_jobnum++;
 
   if (slave->out_type == SPECTRUM || slave->rev_plan == NULL) return 0;   /* block clock only */
@@ -874,7 +880,7 @@ int set_filter(struct filter_out *const slave, double low, double high, double c
   if (host_dft_forward(N, response) != 0) { free(response); return -1; }
   pthread_mutex_lock(&slave->response_mutex);                      /* hot swap, src/filter.c:1039-1043 */
   float complex *old = slave->response;
-  slave->response = response;
+  __atomic_store_n(&slave->response, response, __ATOMIC_RELEASE);   /* execute_filter_input tests it for NULL without this mutex */
   pthread_mutex_unlock(&slave->response_mutex);
   free(old);
   if (slave->rev_plan && is_mini_master(slave->master)) {

@@ -163,15 +163,16 @@ static void mini_delete_output(struct filter_out *slave) {
 
 static int mini_execute_input(struct filter_in *f) {
   struct minictx *c = (struct minictx *)(void *)f->fwd_plan;
-  unsigned const job = f->next_jobnum++;                           /* src/filter.c:607 */
+  unsigned const job = __atomic_fetch_add(&f->next_jobnum, 1u, __ATOMIC_RELAXED);   /* src/filter.c:607; read lock-free by slaves being created */
   int const slot = (int)(job % ND);
-  f->samples_by_job[slot] = f->sample_index;                       /* src/filter.c:614-615 */
+  /* readers pick this up without a lock, possibly while a later lap overwrites it (as in the reference): tear-free accesses */
+  __atomic_store_n(&f->samples_by_job[slot], f->sample_index, __ATOMIC_RELAXED);   /* src/filter.c:614-615 */
   f->sample_index += (uint64_t)f->ilen;
   c->job_win[slot] = f->input_read_pointer.c;                      /* N contiguous samples: the mirror sees to that */
   f->input_read_pointer.c += f->ilen;                              /* src/filter.c:626-636 */
   ring_wrap((void **)&f->input_read_pointer.c, f->input_buffer, f->input_buffer_size);
   pthread_mutex_lock(&f->filter_mutex);
-  f->owner = pthread_self();
+  __atomic_store_n(&f->owner, pthread_self(), __ATOMIC_RELEASE);      /* read without the mutex by execute_filter_output */
   __atomic_store_n(&f->completed_jobs[slot], job, __ATOMIC_RELEASE);
   pthread_cond_broadcast(&f->filter_cond);
   pthread_mutex_unlock(&f->filter_mutex);

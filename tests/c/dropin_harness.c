@@ -89,6 +89,7 @@ static void *channel_thread(void *a) {
 
 /* optional REAL-output slave (wfm's composite filters use these, src/wfm.c): env HARNESS_REAL="shift low high beta" */
 static int Real_on, Real_shift; static double Real_low, Real_high, Real_beta;
+static _Atomic int Real_ready, Clock_ready;       /* the front end starts only when every consumer has its slave (they count Nblocks from there) */
 static float *Real_result;             /* [Nblocks][Olen] */
 static void *real_thread(void *a) {
   (void)a;
@@ -97,6 +98,7 @@ static void *real_thread(void *a) {
   if (create_filter_output(&out, &Master, Olen, REAL) != 0) { fprintf(stderr, "create_filter_output(REAL) failed\n"); exit(2); }
   if (out.bins != out.points / 2 + 1 || out.output.r != out.output_buffer.r + out.points - Olen) { fprintf(stderr, "REAL slave geometry\n"); exit(2); }
   if (set_filter(&out, Real_low, Real_high, Real_beta) != 0) { fprintf(stderr, "set_filter(REAL) failed\n"); exit(2); }
+  atomic_store(&Real_ready, 1);
   for (int b = 0; b < Nblocks; b++) {
     if (execute_filter_output(&out, Real_shift) != 0) { fprintf(stderr, "execute_filter_output(REAL) failed\n"); exit(2); }
     memcpy(Real_result + (size_t)b * Olen, out.output.r, sizeof(float) * (size_t)Olen);
@@ -111,6 +113,7 @@ static void *clock_thread(void *a) {
   struct filter_out sp;
   memset(&sp, 0, sizeof sp);
   if (create_filter_output(&sp, &Master, 0, SPECTRUM) != 0) { fprintf(stderr, "SPECTRUM slave failed\n"); exit(2); }
+  atomic_store(&Clock_ready, 1);
   for (int b = 0; b < Nblocks; b++) { execute_filter_output(&sp, 0); atomic_fetch_add(&Clock_blocks, 1); }
   delete_filter_output(&sp);
   return NULL;
@@ -163,6 +166,7 @@ int main(int argc, char **argv) {
     pthread_create(&rth, NULL, real_thread, NULL);
   }
   for (int i = 0; i < Nch; i++) while (atomic_load(&Progress[i]) < 0) usleep(200);      /* all slaves registered */
+  while (!atomic_load(&Clock_ready) || (Real_on && !atomic_load(&Real_ready))) usleep(200);
 
   /* front end: write in place, then tell the filter how much arrived */
   struct timespec ts0, ts1;
@@ -208,5 +212,6 @@ int main(int argc, char **argv) {
           (unsigned long long)Master.sample_index, elapsed, (long long)Avg_fft_time, (long long)Max_fft_time);
   fclose(f);
   delete_filter_input(&Master);
+  free(th); free(args); free(notch);      /* a clean exit for the leak checker of the sanitizer runs (the caller owns the notch list) */
   return 0;
 }

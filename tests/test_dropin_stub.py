@@ -1,0 +1,119 @@
+"""The filter.h drop-in's HOST code (ka9q-radio_amd/csrc/filter_hip.c) under ThreadSanitizer and AddressSanitizer on the CPU.
+
+On the GPU box the drop-in is tested end to end (tests/test_dropin.py).  What those runs cannot do is watch its host-side
+concurrency -- job numbering, completion signalling from a foreign thread, the miss queue with its leader and followers, bank
+growth while channels run, 100+ channel pthreads against one front-end thread -- with a race detector.  Here the SAME C source
+is compiled with -fsanitize=thread (and =address) against tests/stub/chz_stub.cpp, a CPU stand-in for libchz_hip.so behind the
+same C ABI whose arithmetic is the oracle's and whose entry points are asynchronous like the device's, and driven by the same
+radiod-style harness (tests/c/dropin_harness.c).  Outputs are checked against the oracle as in the GPU test; the sanitizer must
+stay silent.  Test infrastructure only: nothing here is part of, linked into or loaded by the product."""
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from test_dropin import _check, ROOT, PKG
+import struct
+
+STUB = os.path.join(ROOT, "tests", "stub")
+CSRC = os.path.join(PKG, "csrc")
+
+
+def _have(flag):
+    src = "int main(void){return 0;}"
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        return subprocess.run(["gcc", flag, os.path.join(d, "t.c"), "-o", os.path.join(d, "t")], capture_output=True).returncode == 0
+
+
+def _build(san, out_dir):
+    ol.build()
+    os.makedirs(out_dir, exist_ok=True)
+    flag = "-fsanitize=" + san
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", flag, os.path.join(STUB, "chz_stub.cpp"), "-o", os.path.join(out_dir, "libchz_hip.so"),
+                    "-L", os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread"], check=True)
+    subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-fPIC", "-shared", flag, "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-maybe-uninitialized",
+                    os.path.join(CSRC, "filter_hip.c"), "-o", os.path.join(out_dir, "libka9q_filter_hip.so"),
+                    "-L", out_dir, "-lchz_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"], check=True)
+    exe = os.path.join(out_dir, "harness")
+    subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", flag, "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "dropin_harness.c"), "-o", exe,
+                    "-L", out_dir, "-lka9q_filter_hip", "-lchz_hip", "-Wl,-rpath," + out_dir, "-lpthread", "-lm"], check=True)
+    return exe
+
+
+def _run(exe, tmp, L, M, olen, plan, nblocks, x, env=None):
+    open(os.path.join(tmp, "cfg.txt"), "w").write("%d %d %d %d %d %d %d\n" % (L, M, ol.REAL, olen, len(plan), nblocks, 4096))
+    with open(os.path.join(tmp, "plan.bin"), "wb") as f:
+        for p in plan:
+            f.write(struct.pack("iiiiddddd", *p))
+    x.tofile(os.path.join(tmp, "in.bin"))
+    e = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=67", **(env or {}))
+    r = subprocess.run([exe, tmp], capture_output=True, text=True, timeout=int(os.environ.get("STUB_TIMEOUT", "300")), env=e)
+    return r
+
+
+def _plan(rng, n):
+    plan = []
+    for i in range(n):
+        shift = int(rng.integers(-12000, 12000))
+        plan.append((shift, shift, 10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4))
+    plan[0] = (2500, 2600, 3, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4)            # retune at block 3
+    plan[1] = (2501, 2501, 10 ** 6, 2, 0.004, 0.25, 11.0, -0.02, 0.02)         # new filter at block 2
+    plan[2] = (-7000, 7000, 5, 4, -0.4, 0.4, 11.0, 0.1, 0.3)                   # both
+    return plan
+
+
+@pytest.mark.parametrize("san", ["thread", "address"])
+@pytest.mark.parametrize("env", [None, {"HARNESS_RETUNE_MOD": "1"}], ids=["steady", "retune_every_block"])
+def test_dropin_host_code_under_sanitizers(tmp_path, san, env):
+    if not _have("-fsanitize=" + san):
+        pytest.skip("no -fsanitize=%s runtime in this image" % san)
+    exe = _build(san, str(tmp_path / "build"))
+    L, M, olen, P = 25920, 6481, 240, 300
+    nblocks, nch = 8, 96
+    rng = np.random.default_rng(8)
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = _plan(rng, nch)
+    if env:
+        plan = [(p[0], p[0] + 40 + i, 10 ** 6, 10 ** 6) + p[4:] for i, p in enumerate(plan)]      # two shifts to alternate between
+    run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
+    r = _run(exe, run_dir, L, M, olen, plan, nblocks, x, env)
+    report = r.stderr
+    assert "WARNING: ThreadSanitizer" not in report and "ERROR: AddressSanitizer" not in report and "LeakSanitizer" not in report, report[-6000:]
+    assert r.returncode == 0, (r.returncode, report[-3000:])
+    out = np.fromfile(os.path.join(run_dir, "out.bin"), np.complex64).reshape(nblocks, len(plan), olen)
+    spec = np.fromfile(os.path.join(run_dir, "spec.bin"), np.complex64)
+    meta = open(os.path.join(run_dir, "meta.txt")).read().split()
+    _check(L, M, olen, P, plan, nblocks, out, spec, dict(zip(meta[::2], meta[1::2])), x, retune_mod=1 if env else 0)
+
+
+@pytest.mark.parametrize("san", ["thread", "address"])
+@pytest.mark.parametrize("env", [{"HARNESS_FILTER2": "1 -0.1 0.1 7.0 3"}, {"HARNESS_FILTER2": "4 -0.2 0.2 7.0 -1"}, {"HARNESS_REAL": "40 0.0 0.3 5.0"},
+                                 {"HARNESS_ISB": "5", "HARNESS_RETUNE_MOD": "2"}],
+                         ids=["filter2_blocking1_isb", "filter2_blocking4", "real_slave", "isb_and_retunes"])
+def test_dropin_other_paths_are_sanitizer_clean(tmp_path, san, env):
+    """filter2's pooled inline masters (leader / follower batching), a REAL-output slave next to the COMPLEX ones, ISB flags flipped
+    by the caller, retunes every other block: the numeric side of these paths is checked on the GPU (tests/test_dropin.py); here
+    the host code must run them to the end with the race detector and the address / leak checker silent."""
+    if not _have("-fsanitize=" + san):
+        pytest.skip("no -fsanitize=%s runtime in this image" % san)
+    exe = _build(san, str(tmp_path / "build"))
+    L, M, olen = 25920, 6481, 240
+    nblocks, nch = 8, 48
+    rng = np.random.default_rng(9)
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = _plan(rng, nch)
+    run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
+    r = _run(exe, run_dir, L, M, olen, plan, nblocks, x, env)
+    report = r.stderr
+    assert "WARNING: ThreadSanitizer" not in report and "ERROR: AddressSanitizer" not in report and "LeakSanitizer" not in report, report[-6000:]
+    assert r.returncode == 0, (r.returncode, report[-3000:])
+    meta = open(os.path.join(run_dir, "meta.txt")).read().split()
+    meta = dict(zip(meta[::2], meta[1::2]))
+    assert meta["drops"] == "0" and int(meta["clock"]) == nblocks
