@@ -43,6 +43,10 @@ static int F2_blocking, F2_isb = -1; static double F2_low, F2_high, F2_beta;
 /* env HARNESS_RETUNE_MOD=m: channel i flips between its two shifts at every block b with (b + i) % m == 0, i.e. 1/m of
    the channels retune EVERY block (a scanning / Doppler-tracking channel set) */
 static int Retune_mod;
+/* env HARNESS_CHURN_MOD=m: channel i with i % m == 1 leaves half way (delete_filter_output while everybody else runs: the bank
+   closes the gap by moving its last slave) and comes back as a NEW slave a little later (create_filter_output + set_filter into
+   a running master, then delete again), as radiod's dynamic channels do */
+static int Churn_mod;
 
 static void *channel_thread(void *a) {
   int const i = ((struct chanarg *)a)->idx;
@@ -80,8 +84,19 @@ static void *channel_thread(void *a) {
     } else
       memcpy(Result + ((size_t)b * Nch + i) * Olen, out.output.c, sizeof(float complex) * (size_t)Olen);
     atomic_store(&Progress[i], b + 1);
+    if (Churn_mod > 0 && i % Churn_mod == 1 && b == Nblocks / 2 && F2_blocking == 0) {
+      Drops[i] += out.block_drops;
+      delete_filter_output(&out);
+      memset(&out, 0, sizeof out);
+      atomic_store(&Progress[i], Nblocks);                       /* the front end does not wait for somebody who is away */
+      usleep(3000);
+      if (create_filter_output(&out, &Master, Olen, COMPLEX) != 0) { fprintf(stderr, "create_filter_output (again) failed\n"); exit(2); }
+      if (set_filter(&out, Plan[i].low, Plan[i].high, Plan[i].beta) != 0) { fprintf(stderr, "set_filter (again) failed\n"); exit(2); }
+      /* (it does not wait for blocks again: the stream may end before it would get one) */
+      break;
+    }
   }
-  Drops[i] = out.block_drops;
+  Drops[i] += out.block_drops;
   if (F2_blocking > 0) { delete_filter_output(&f2out); delete_filter_input(&f2in); }
   delete_filter_output(&out);
   return NULL;
@@ -155,6 +170,7 @@ int main(int argc, char **argv) {
     if (k < 4) { fprintf(stderr, "HARNESS_FILTER2 needs: blocking low high beta [isb_channel]\n"); return 1; }
   }
   if (getenv("HARNESS_RETUNE_MOD")) Retune_mod = atoi(getenv("HARNESS_RETUNE_MOD"));
+  if (getenv("HARNESS_CHURN_MOD")) Churn_mod = atoi(getenv("HARNESS_CHURN_MOD"));
   pthread_t *th = calloc((size_t)Nch, sizeof *th), clk;
   struct chanarg *args = calloc((size_t)Nch, sizeof *args);
   for (int i = 0; i < Nch; i++) { args[i].idx = i; pthread_create(&th[i], NULL, channel_thread, &args[i]); }

@@ -94,8 +94,8 @@ def test_dropin_host_code_under_sanitizers(tmp_path, san, env):
 
 @pytest.mark.parametrize("san", ["thread", "address"])
 @pytest.mark.parametrize("env", [{"HARNESS_FILTER2": "1 -0.1 0.1 7.0 3"}, {"HARNESS_FILTER2": "4 -0.2 0.2 7.0 -1"}, {"HARNESS_REAL": "40 0.0 0.3 5.0"},
-                                 {"HARNESS_ISB": "5", "HARNESS_RETUNE_MOD": "2"}],
-                         ids=["filter2_blocking1_isb", "filter2_blocking4", "real_slave", "isb_and_retunes"])
+                                 {"HARNESS_ISB": "5", "HARNESS_RETUNE_MOD": "2"}, {"HARNESS_CHURN_MOD": "3", "HARNESS_RETUNE_MOD": "2"}],
+                         ids=["filter2_blocking1_isb", "filter2_blocking4", "real_slave", "isb_and_retunes", "channels_leaving_and_joining"])
 def test_dropin_other_paths_are_sanitizer_clean(tmp_path, san, env):
     """filter2's pooled inline masters (leader / follower batching), a REAL-output slave next to the COMPLEX ones, ISB flags flipped
     by the caller, retunes every other block: the numeric side of these paths is checked on the GPU (tests/test_dropin.py); here
@@ -116,4 +116,6 @@ def test_dropin_other_paths_are_sanitizer_clean(tmp_path, san, env):
     assert r.returncode == 0, (r.returncode, report[-3000:])
     meta = open(os.path.join(run_dir, "meta.txt")).read().split()
     meta = dict(zip(meta[::2], meta[1::2]))
-    assert meta["drops"] == "0" and int(meta["clock"]) == nblocks
+    assert int(meta["clock"]) == nblocks
+    if "HARNESS_CHURN_MOD" not in env:
+        assert meta["drops"] == "0"
