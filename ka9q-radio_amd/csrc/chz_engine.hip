@@ -703,7 +703,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   if (b.tail_used[slot] && ch0 == 0 && !(in && in->on)) HIPOK(hipStreamWaitEvent(st, b.ev_tail[slot], 0));
   const size_t so = (size_t)slot * b.cap;
   ChanParams c{};
-  c.lay = SpecLayout{e->plan.Na, e->plan.spec_pitch, e->plan.spec_off}; c.inv_na = 1.0f / (float)e->plan.Na;
+  if (!chan_layout(c, SpecLayout{e->plan.Na, e->plan.spec_pitch, e->plan.spec_off}, e->bins)) return fail(-4, "spectrum layout beyond the reach of the index reciprocal");
   c.spec = e->spec[slot]; c.resp = b.resp; c.desc = b.desc + so; c.out = bank_out(b, slot); c.ch0 = ch0; c.nch = n; c.olen = b.olen;
   c.tw_sub = b.tw_sub;
   c.stage = e->chan_stage >= 0 ? e->chan_stage : (n >= 16384);

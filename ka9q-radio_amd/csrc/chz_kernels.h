@@ -78,11 +78,20 @@ __device__ __forceinline__ void store_wt(__amdgpu_buffer_rsrc_t d, int elem, flo
 __device__ __forceinline__ void store_wt(__amdgpu_buffer_rsrc_t d, int elem, float4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(chz_u4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, d, elem * 16, 0, 16);
 }
+// gathers through a buffer descriptor: a 32-bit element offset from a wave-uniform base instead of a 64-bit address per lane
+#define CHZ_IN_DESC(name, base) const __amdgpu_buffer_rsrc_t name = __builtin_amdgcn_make_buffer_rsrc((void*)(base), 0, 0x7ffffffc, 0x00020000)
+__device__ __forceinline__ float2 load_f2(__amdgpu_buffer_rsrc_t d, int elem) {
+  const chz_u2 r = __builtin_amdgcn_raw_buffer_load_b64(d, elem * 8, 0, 0);
+  return make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+#define CHZ_LOAD2(desc, base, elem) load_f2(desc, (int)(elem))
 #define CHZ_STORE(desc, base, elem, value) store_wt(desc, (int)(elem), (value))
 // predicated store without a branch: a raw buffer access past num_records is dropped by the hardware
 #define CHZ_STORE_IF(desc, base, elem, value, cond) store_wt(desc, (cond) ? (int)(elem) : 0x10000000, (value))
 #else
 #define CHZ_OUT_DESC(name, base) const int name = 0; (void)name
+#define CHZ_IN_DESC(name, base) const int name = 0; (void)name
+#define CHZ_LOAD2(desc, base, elem) ((base)[(elem)])
 #define CHZ_STORE(desc, base, elem, value) ((base)[(elem)] = (value))
 #define CHZ_STORE_IF(desc, base, elem, value, cond) do { if (cond) (base)[(elem)] = (value); } while (0)
 #endif
@@ -141,6 +150,12 @@ __host__ __device__ __forceinline__ long spec_addr(const SpecLayout& l, long k) 
   return x * l.pitch + l.off + (k - x * l.na);
 }
 
+// storage index of master bin k without a division: k + (k / na) * (pitch - na) + off
+__device__ __forceinline__ int spec_index(int na_off, unsigned magic, int dpitch, int k) {
+  const unsigned q = __umulhi((unsigned)k, magic);
+  return k + (int)__umul24(q, (unsigned)dpitch) + na_off;
+}
+
 struct RowsParams {
   const float2* buf;      // [Ra][Nb][Nc]
   float2* spec;           // out: master spectrum in SpecLayout order
@@ -189,6 +204,8 @@ struct ChanParams {
   const float2* spec;     // master spectrum of this block (SpecLayout order)
   SpecLayout lay;
   float inv_na;           // 1/na, for the bin -> (row, column) split
+  unsigned magic;         // ceil(2^32 / na): bin / na by one multiply-high (exact for bins < 2^32 / na, checked by chan_layout)
+  int dpitch;             // pitch - na
   const float2* resp;     // [rows][P] frequency responses, row = desc[ch].row
   const ChanDesc* desc;   // [nch] this slot's descriptors
   float2* out;            // [nch][olen]
@@ -644,8 +661,9 @@ __global__ void __launch_bounds__(1024) notch_fix(NotchFixParams p) {
 // LPC = max(R1,R2) lanes serve one channel, 64/LPC channels share a wavefront.
 // ------------------------------------------------------------------------------
 // EPI: compiled with the downconvert() epilogue (fine tuning + power); the plain variant carries none of it.
+// (the small sizes are asked to fit 6 wavefronts per SIMD: without the hint the 12 kHz kernel takes 95 VGPRs and loses one)
 template <int R1, int R2, bool EPI>
-__global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
+__global__ void __launch_bounds__(256, (!EPI && R1 <= 15 && R2 <= 20) ? 6 : 1) chan_ifft(ChanParams p) {
   constexpr int P = R1 * R2;
   constexpr int LPC = R1 > R2 ? R1 : R2;
   constexpr int CPW = 64 / LPC;
@@ -673,20 +691,25 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
     float2 h[R1];
     bool ok[R1];
     int srcs[EPI ? R1 : 1];                               // master bin of each register (beam mode needs its mirror)
+    // Index arithmetic is what this kernel spends most of its instructions on (at millions of channels it is bound by them, not by
+    // memory): the +-1 direction is a sign trick, not a multiply; both range tests are one unsigned compare; bin -> storage index
+    // is a multiply-high with a host-made reciprocal instead of a float estimate with fix-ups; the gather goes through a buffer
+    // descriptor (32-bit offsets from a wave-uniform base) and the response row through one per-lane pointer with immediates.
+    CHZ_IN_DESC(xdesc, X);
+    const int dm = d.dir >> 31;                            // 0 for +1, -1 for -1
+    const float2* __restrict__ Hl = H + jl;
     static_for<R1>([&](auto q) {
       constexpr int Q = decltype(q)::value;
+      constexpr int H2 = (P + 1) / 2;
       const int i = jl + Q * R2;                           // FFT-order bin index
-      int t = i - (P + 1) / 2; if (t < 0) t += P;          // rank from most negative bin
+      int t = i - H2; if (t < 0) t += P;                   // rank from most negative bin
       const int u = t - d.t0;
-      ok[Q] = (u >= 0) && (u < d.cnt) && (i != (P + 1) / 2);   // Nyquist bin forced to zero (:911)
-      int src = d.src0 + d.dir * u;
+      ok[Q] = ((unsigned)u < (unsigned)d.cnt) && (i != H2);    // 0 <= u < cnt; Nyquist bin forced to zero (:911)
+      int src = d.src0 + ((u ^ dm) - dm);                  // src0 + dir * u
       if (d.wrap && src >= d.wrap) src -= d.wrap;
       if (!ok[Q]) src = 0;
-      int row = (int)((float)src * p.inv_na);               // src < 2^24: the estimate is off by at most one
-      int col = src - row * p.lay.na;
-      if (col < 0) { row--; col += p.lay.na; } else if (col >= p.lay.na) { row++; col -= p.lay.na; }
-      v[Q] = X[(long)row * p.lay.pitch + p.lay.off + col];
-      h[Q] = H[i];
+      v[Q] = CHZ_LOAD2(xdesc, X, spec_index(p.lay.off, p.magic, p.dpitch, src));
+      h[Q] = Hl[Q * R2];
       if constexpr (EPI) srcs[Q] = src;
     });
     bool beamed = false;
@@ -852,10 +875,15 @@ __global__ void __launch_bounds__(256) chan_ifft(ChanParams p) {
     const int tot2 = nl > 0 ? (nl * p.olen) >> 1 : 0;      // float4 = two samples; olen is even (P = olen*N/L, :312)
     const float2* wl = lds + (wave * CPW) * (R1 * LDC);
     float4* __restrict__ og = reinterpret_cast<float4*>(p.out + (long)(p.ch0 + first_lc) * p.olen);
-    for (int e = lane; e < tot2; e += 64) {
-      const int s2 = 2 * e, c = s2 / p.olen, n = s2 - c * p.olen;
-      const float2 a = wl[c * (R1 * LDC) + n], b = wl[c * (R1 * LDC) + n + 1];
-      og[e] = make_float4(a.x, a.y, b.x, b.y);
+    (void)tot2;
+    const int half = p.olen >> 1;                          // float4 = two samples; olen is even (P = olen*N/L, :312)
+    for (int c = 0; c < nl; c++) {                         // channel by channel: no division by a run-time olen per element
+      const float2* wc = wl + c * (R1 * LDC);
+      float4* __restrict__ oc = og + (long)c * half;
+      for (int e = lane; e < half; e += 64) {
+        const float2 a = wc[2 * e], b = wc[2 * e + 1];
+        oc[e] = make_float4(a.x, a.y, b.x, b.y);
+      }
     }
   }
   if (EPI && p.power != nullptr) {     // wave-uniform: every lane takes part in the shuffles

@@ -37,6 +37,19 @@ inline int launch_rows(Radix2 r, int grid, int block, size_t lds, hipStream_t s,
 #undef X
   return -1;
 }
+// the spectrum layout as the channel kernels want it: 1/na for the float split (REAL-output and beam paths), and the
+// multiply-high reciprocal of na for the division-free index of chan_ifft.  Returns false if the reciprocal would not be exact
+// over this master's bins (cannot happen for compiled axis lengths: na <= 400 and bins < 2^23).
+inline bool chan_layout(ChanParams& c, const SpecLayout& lay, long bins) {
+  c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
+  c.dpitch = lay.pitch - lay.na;
+  const unsigned long long m = ((1ull << 32) + (unsigned long long)lay.na - 1) / (unsigned long long)lay.na;      // ceil(2^32 / na)
+  c.magic = (unsigned)(m > 0xffffffffull ? 0xffffffffull : m);
+  if (c.dpitch == 0) return true;                          // natural order: the quotient is multiplied by zero
+  if (c.dpitch < 0 || c.dpitch >= (1 << 24) || bins >= (1 << 24)) return false;
+  const unsigned long long e = m * (unsigned long long)lay.na - (1ull << 32);                                        // < na
+  return e * (unsigned long long)(bins > 0 ? bins - 1 : 0) < (1ull << 32);
+}
 inline int launch_chan(Radix2 r, int grid, int block, size_t lds, hipStream_t s, const ChanParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
 #define X(a, b) if (r.r1 == a && r.r2 == b) { \
     if (p.fine || p.power || p.isb || p.beam) { CHZ_LAUNCH((chan_ifft<a, b, true>), grid, block, lds, s, e0, e1, p); } \

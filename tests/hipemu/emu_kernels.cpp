@@ -105,6 +105,16 @@ int emu_plan_exists(int N, int in_type, char* desc, int len) {
   if (desc && len > 0) { strncpy(desc, p.desc.c_str(), (size_t)len - 1); desc[len - 1] = 0; }
   return 1;
 }
+// the division-free storage index of chan_ifft against the plain definition, for EVERY bin of a master: returns the first
+// disagreeing bin or -1; -2 if chan_layout refuses the layout
+long emu_spec_index_check(int na, int pitch, int off, long bins) {
+  ChanParams c{};
+  SpecLayout lay{na, pitch, off};
+  if (!chan_layout(c, lay, bins)) return -2;
+  for (long k = 0; k < bins; k++)
+    if ((long)spec_index(lay.off, c.magic, c.dpitch, (int)k) != spec_addr(lay, k)) return k;
+  return -1;
+}
 int emu_chan_desc(int in_type, int m_bins, int P, int shift, int* out6) {
   ChanDescH d = make_chan_desc(in_type, m_bins, P, shift);
   out6[0] = d.t0; out6[1] = d.cnt; out6[2] = d.src0; out6[3] = d.dir; out6[4] = d.conj; out6[5] = d.wrap;
@@ -124,7 +134,7 @@ int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, in
     desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap, i, shifts[i]};
   }
   ChanParams c{};
-  c.spec = spec_dev.data(); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
+  c.spec = spec_dev.data(); if (!chan_layout(c, lay, m_bins)) return -9;
   c.resp = reinterpret_cast<const float2*>(resp);
   c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub);
@@ -147,7 +157,7 @@ int emu_channels_isb(const float* spec, int m_bins, int in_type, int P, int olen
     desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap, i, shifts[i]};
   }
   ChanParams c{};
-  c.spec = reinterpret_cast<const float2*>(spec); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
+  c.spec = reinterpret_cast<const float2*>(spec); if (!chan_layout(c, lay, m_bins)) return -9;
   c.resp = reinterpret_cast<const float2*>(resp);
   c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub); c.isb = isb;
@@ -171,7 +181,7 @@ int emu_channels_beam(const float* spec, int m_bins, int P, int olen, int nch, c
     bd[i] = BeamDesc{ab[4 * i], ab[4 * i + 1], ab[4 * i + 2], ab[4 * i + 3], on[i] ? 1 : 0, 0};
   }
   ChanParams c{};
-  c.spec = reinterpret_cast<const float2*>(spec); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
+  c.spec = reinterpret_cast<const float2*>(spec); if (!chan_layout(c, lay, m_bins)) return -9;
   c.resp = reinterpret_cast<const float2*>(resp);
   c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub); c.beam = bd.data();
@@ -189,7 +199,7 @@ int emu_channels_real(const float* spec, int m_bins, int in_type, int P, int ole
   std::vector<float2> spec_dev((size_t)((long)(m_bins / lay.na + 2) * lay.pitch + 16), make_float2(0.f, 0.f));
   for (long k = 0; k < m_bins; k++) spec_dev[(size_t)spec_addr(lay, k)] = reinterpret_cast<const float2*>(spec)[k];
   ChanParams c{};
-  c.spec = spec_dev.data(); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
+  c.spec = spec_dev.data(); if (!chan_layout(c, lay, m_bins)) return -9;
   c.resp = reinterpret_cast<const float2*>(resp);
   std::vector<ChanDesc> desc((size_t)nch);
   for (int i = 0; i < nch; i++) desc[(size_t)i] = ChanDesc{0, 0, 0, 1, 0, 0, i, shifts[i]};   // the REAL-output gather reads row and shift only
@@ -237,7 +247,7 @@ int emu_channels_tuned(const float* spec, int m_bins, int in_type, int P, int ol
     fd[(size_t)i] = fine_desc(fh[(size_t)i], V);
   }
   ChanParams c{};
-  c.spec = reinterpret_cast<const float2*>(spec); c.lay = lay; c.inv_na = 1.0f / (float)lay.na;
+  c.spec = reinterpret_cast<const float2*>(spec); if (!chan_layout(c, lay, m_bins)) return -9;
   c.resp = reinterpret_cast<const float2*>(resp);
   c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub);

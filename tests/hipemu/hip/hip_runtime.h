@@ -205,6 +205,8 @@ static inline float __fmul_rn(float a, float b) { volatile float r = a * b; retu
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline int __lane_id() { return hipemu_linear_tid() & 63; }

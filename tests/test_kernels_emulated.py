@@ -79,6 +79,20 @@ def test_forward_kernels(emu, N, in_type, spec, start):
     assert rel(out, want) < 5e-7, desc.value
 
 
+def test_division_free_storage_index_is_exact(emu):
+    """chan_ifft turns a master bin into its storage index with a multiply-high by ceil(2^32 / na): checked against the plain
+    k + (k / na) * (pitch - na) + off for EVERY bin of the layouts the planner produces (config 3: 135 / 144 / 4 over 1,620,001
+    bins), of every first-axis length in the menu with the largest master it can carry, and of the natural order."""
+    emu.emu_spec_index_check.restype = C.c_long
+    emu.emu_spec_index_check.argtypes = [C.c_int, C.c_int, C.c_int, C.c_long]
+    assert emu.emu_spec_index_check(135, 144, 4, 1620001) == -1
+    assert emu.emu_spec_index_check(75, 80, 2, 810001) == -1
+    for na in _menu("CHZ_FWD_MENU"):
+        pitch = (na + 15) // 16 * 16 + 16
+        assert emu.emu_spec_index_check(na, pitch, 5, 6_000_000) == -1, na
+    assert emu.emu_spec_index_check(5_200_001, 5_200_001, 0, 5_200_001) == -1      # natural order: quotient times zero
+
+
 def _menu(name):
     import re
     src = open(os.path.join(CSRC, "chz_plan.h")).read()
