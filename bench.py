@@ -45,6 +45,8 @@ BLOCKTIME = 0.02
 RING_BLOCKS = 8
 HBM_PEAK_GBS = 8000.0                   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:35
 COPY_RATE_GBS = 6290.0                  # the chip's measured achievable copy rate (same guide)
+STREAM_COPY_GBS = 4880.0                # measured here: device-to-device copies of 24-48 GB, i.e. far beyond the Infinity Cache
+                                        # (scripts/hbm_stream_probe.py, profiles/r02_hbm_stream.json): what HBM streams, reads + writes mixed
 
 # the 129.6 MS/s geometry is also what tests and scripts import from here
 FS = 129.6e6
@@ -233,6 +235,7 @@ def crt_leg(pkg, eng, wl, nch, blocks, run_one):
             "sustained": worst <= BLOCKTIME * 1e3,
             "algorithmic_GBps": (fwd_bytes(wl["N"]) + chan_alg) / (mean * 1e-3) / 1e9,
             "dram_side_GBps": dram / (mean * 1e-3) / 1e9, "dram_side_frac_of_hbm_peak": dram / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "dram_side_frac_of_measured_stream_copy": dram / (mean * 1e-3) / 1e9 / STREAM_COPY_GBS,
             "note": "every block individually <= 20 ms; I/O resident in HBM (responses %.0f GB, 4 output images %.0f GB); the "
                     "algorithmic figure counts the gathered master bins, which the caches serve -- the DRAM-side figure is "
                     "responses + outputs only" % (nch * P * 8 / 1e9, 4 * nch * olen * 8 / 1e9)}
@@ -483,6 +486,7 @@ def main():
                 crt["algorithmic_GBps"] = sum(c["algorithmic_GBps"] for c in every)
                 crt["dram_side_GBps"] = sum(c["dram_side_GBps"] for c in every)
                 crt["dram_side_frac_of_hbm_peak"] = crt["dram_side_GBps"] / (HBM_PEAK_GBS * len(every))
+                crt["dram_side_frac_of_measured_stream_copy"] = crt["dram_side_GBps"] / (STREAM_COPY_GBS * len(every))
                 crt["gpus"] = len(every)
                 crt["exchange"] = "broadcast" if comm is not None else main_leg
 
