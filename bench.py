@@ -202,12 +202,12 @@ def cpu_baseline(oracle_lib, ring, wl, seconds=12.0):
     }
 
 
-def crt_leg(pkg, eng, wl, nch, blocks, run_one):
+def crt_leg(pkg, eng, wl, nch, blocks, run_one, shared=False):
     """C_rt: one bank of `nch` channels of the workload's kind tiled from its plan, I/O resident in
     HBM; every block is run to completion ON ITS OWN (run_one(job) -> ms) and must take <= 20 ms."""
     P, olen, tile = wl["P"], wl["olen"], 3072
     nch -= nch % tile
-    bank = eng.bank(P, olen, nch)
+    bank = eng.bank(P, olen, nch, shared_rows=3 if shared else 0)
     if wl["config"] == 4:
         base = channel_plan_config3(tile)
         plan = [(sh, -10000 / 24000, 10000 / 24000) for sh, _, _ in base]
@@ -216,8 +216,14 @@ def crt_leg(pkg, eng, wl, nch, blocks, run_one):
     resp = np.stack([pkg.filterapi.design_response(P, olen, wl["N"], True, lo, hi, 11.0) for _, lo, hi in plan[:3]])
     resp = np.ascontiguousarray(np.tile(resp, (tile // 3, 1)))
     shifts = np.array([p[0] for p in plan], np.int32)
+    if shared:                                   # the three filters of the mix, ONE copy each; every channel names its row
+        bank.set_row_responses(0, resp[:3])
+        rows = (np.arange(tile) % 3).astype(np.int32)
     for c0 in range(0, nch, tile):
-        bank.set_responses(c0, resp)
+        if shared:
+            bank.set_rows(c0, rows)
+        else:
+            bank.set_responses(c0, resp)
         bank.set_shifts(c0, shifts + (c0 // tile) % 7)
     bank.set_active(nch)
     for j in range(8):
@@ -228,17 +234,19 @@ def crt_leg(pkg, eng, wl, nch, blocks, run_one):
         worst = max(worst, ms); tot += ms
     mean = tot / blocks
     bank.set_active(0)
+    bank.destroy()                               # 170+ GB: the next leg needs the room
     total_ch = nch + wl["nch"]
     chan_alg = total_ch * chan_bytes(P, olen)
-    dram = total_ch * (8 * P + 8 * olen)         # responses in + outputs out; the gathered master bins are cache hits
+    dram = total_ch * ((0 if shared else 8 * P) + 8 * olen)   # responses in + outputs out; the gathered master bins (and shared rows) are cache hits
     return {"channels": total_ch, "P": P, "blocks": blocks, "worst_block_ms": worst, "mean_block_ms": mean,
             "sustained": worst <= BLOCKTIME * 1e3,
             "algorithmic_GBps": (fwd_bytes(wl["N"]) + chan_alg) / (mean * 1e-3) / 1e9,
             "dram_side_GBps": dram / (mean * 1e-3) / 1e9, "dram_side_frac_of_hbm_peak": dram / (mean * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "dram_side_frac_of_measured_stream_copy": dram / (mean * 1e-3) / 1e9 / STREAM_COPY_GBS,
+            "responses": "3 rows shared by all channels (chz_bank_create_shared)" if shared else "one row per channel",
             "note": "every block individually <= 20 ms; I/O resident in HBM (responses %.0f GB, 4 output images %.0f GB); the "
                     "algorithmic figure counts the gathered master bins, which the caches serve -- the DRAM-side figure is "
-                    "responses + outputs only" % (nch * P * 8 / 1e9, 4 * nch * olen * 8 / 1e9)}
+                    "responses + outputs only" % ((0 if shared else nch * P * 8) / 1e9, 4 * nch * olen * 8 / 1e9)}
 
 
 def self_spawn(args):
@@ -270,6 +278,8 @@ def main():
     ap.add_argument("--no-crt", action="store_true", help="skip the C_rt leg (one large bank, every block inside 20 ms)")
     ap.add_argument("--crt-channels", type=int, default=0, help="channels of the C_rt leg's bank (default 17.0 M at P=300, 8.4 M at P=600)")
     ap.add_argument("--crt-blocks", type=int, default=500)
+    ap.add_argument("--crt-shared", type=int, default=0,
+                    help="also run the C_rt leg with this many channels SHARING their response rows (0 = skip; config 3, 1 GPU)")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         raise SystemExit("bad --gpus/--steps/--warmup")
@@ -490,6 +500,15 @@ def main():
                 crt["gpus"] = len(every)
                 crt["exchange"] = "broadcast" if comm is not None else main_leg
 
+    crt_shared = None
+    if args.crt_shared and rank == 0 and world == 1 and config == 3:
+        # the same leg with the channels SHARING the three response rows of the mix: what the card carries when channels of one mode
+        # use one filter (not the headline: the reference gives every channel its own copy)
+        try:
+            crt_shared = crt_leg(pkg, eng, wl, args.crt_shared, args.crt_blocks, lambda job: eng.run_blocks(job, 1).total_ms, shared=True)
+        except Exception as ex:
+            crt_shared = {"error": str(ex)[:200]}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(oracle_lib, ring_host, wl)
@@ -536,7 +555,7 @@ def main():
             "step_algorithmic_GBps": step_bytes / (elapsed / args.steps) / 1e9,
             "gpu_event_ms_per_step": timing.total_ms / timing.blocks,
             "host_enqueue_ms_per_step": timing.enqueue_ms / timing.blocks,
-            "roofline": roof, "cpu_baseline": cpu, "c_rt": crt,
+            "roofline": roof, "cpu_baseline": cpu, "c_rt": crt, "c_rt_shared_responses": crt_shared,
         }
     if comm is not None:
         comm.close()

@@ -121,6 +121,13 @@ int chz_bank_create(chz_engine *e, int P, int olen, int capacity);          /* r
  * responses are still P complex values per channel (set_filter's array, of which bins 0..P/2 are used), outputs are
  * olen floats per channel; P must be even */
 int chz_bank_create_real(chz_engine *e, int P, int olen, int capacity);
+/* Channels with the same filter sharing its response: `nrows` response rows in the bank, every channel names the row it reads
+ * (chz_bank_set_rows: takes effect like a retune, in stream order, no drain), rows are written by chz_bank_set_row_responses (between
+ * blocks: drains).  The reference keeps one copy per slave (src/filter.c:1039-1043); the values are the same, the HBM traffic per
+ * channel and block drops from 8P + 8*olen to 8*olen bytes.  chz_bank_set_responses is refused on such a bank. */
+int chz_bank_create_shared(chz_engine *e, int P, int olen, int capacity, int nrows);
+int chz_bank_set_rows(chz_engine *e, int bank, int ch0, int n, const int *rows);
+int chz_bank_set_row_responses(chz_engine *e, int bank, int row0, int n, const float *resp);
 /* None of the per-channel setters below waits for blocks in flight: shifts, tuning, ISB flags and beam weights live in
  * small descriptors kept once per spectrum slot and refreshed in stream order when the next block of that slot is
  * enqueued (blocks already enqueued keep what they were launched with); a response is written to a spare row and the

@@ -83,6 +83,7 @@ struct Bank {
   std::vector<DemodChan> dm_chan_h;      // [cap]
   struct OscHost { bool init = false; double freq = 0.0, phase0 = 0.0; unsigned job0 = 0; };
   std::vector<OscHost> dm_osc;           // [cap] chan->shift with set_osc's phase continuity
+  int shared_rows = 0;                   // > 0: the bank's channels share this many response rows (chz_bank_create_shared)
   int dm_on = 0;                         // channels with a demodulator
   bool dm_auto = true;                   // demodulate behind every channel launch (false: only on chz_bank_demod)
   int pcm_stride = 0;                    // bytes between two channels' PCM rows (default olen*8: stereo float32)
@@ -837,7 +838,7 @@ int chz_spectrum_attach(chz_engine* e, int slot, float* dev) {
   return 0;
 }
 
-static int bank_create(chz_engine* e, int P, int olen, int capacity, int out_real) {
+static int bank_create(chz_engine* e, int P, int olen, int capacity, int out_real, int shared_rows = 0) {
   if (!e) return fail(-1, "null engine");
   if (capacity < 1 || olen < 1 || olen > P) return fail(-1, "bad bank geometry");
   // P = olen*N/L must divide exactly (src/filter.c:312-316)
@@ -853,11 +854,12 @@ static int bank_create(chz_engine* e, int P, int olen, int capacity, int out_rea
   // spare response rows: set_filter writes a spare row and re-points the channel, so a swap never waits for the pipeline
   int spare = capacity / 16; if (spare < 16) spare = 16; if (spare > 4096) spare = 4096;
   b.rows_total = capacity + spare;
+  if (shared_rows > 0) { b.shared_rows = shared_rows; b.rows_total = shared_rows; spare = 0; }     // rows are named by the caller, not swapped
   HIPOK(hipMalloc((void**)&b.resp, sizeof(float2) * (size_t)b.rows_total * P));
   HIPOK(hipMemset(b.resp, 0, sizeof(float2) * (size_t)b.rows_total * P));
-  for (int r = b.rows_total - 1; r >= capacity; r--) b.free_rows.push_back(r);
+  if (!b.shared_rows) for (int r = b.rows_total - 1; r >= capacity; r--) b.free_rows.push_back(r);
   b.desc_h.assign((size_t)capacity, ChanDesc{0, 0, 0, 1, 0, 0, 0, 0});
-  for (int i = 0; i < capacity; i++) b.desc_h[(size_t)i].row = i;
+  for (int i = 0; i < capacity; i++) b.desc_h[(size_t)i].row = b.shared_rows ? 0 : i;
   HIPOK(hipMalloc((void**)&b.desc, sizeof(ChanDesc) * (size_t)CHZ_ND * capacity));
   for (int s = 0; s < CHZ_ND; s++)
     HIPOK(hipMemcpy(b.desc + (size_t)s * capacity, b.desc_h.data(), sizeof(ChanDesc) * (size_t)capacity, hipMemcpyHostToDevice));
@@ -882,6 +884,14 @@ static int bank_create(chz_engine* e, int P, int olen, int capacity, int out_rea
 int chz_bank_create(chz_engine* e, int P, int olen, int capacity) { return bank_create(e, P, olen, capacity, 0); }
 // create_filter_output(.., REAL) (src/filter.c:372-395): olen real samples per channel and block
 int chz_bank_create_real(chz_engine* e, int P, int olen, int capacity) { return bank_create(e, P, olen, capacity, 1); }
+// Channels that use the same filter (every USB voice channel of a band, say) can share its response: the bank holds `nrows`
+// response rows, a channel names the row it reads (chz_bank_set_rows), rows are written with chz_bank_set_row_responses.  The
+// reference gives every slave its own copy (src/filter.c:1039-1043); the values are the same, the HBM traffic per channel and block
+// drops from 8P + 8*olen to 8*olen bytes (the shared rows stay in the caches).
+int chz_bank_create_shared(chz_engine* e, int P, int olen, int capacity, int nrows) {
+  if (nrows < 1) return fail(-1, "a shared bank needs at least one response row");
+  return bank_create(e, P, olen, capacity, 0, nrows);
+}
 
 #define BANK_CHECK(e, bank, ch0, n) \
   if (!(e) || (bank) < 0 || (bank) >= (int)(e)->banks.size()) return fail(-1, "bad bank"); \
@@ -913,6 +923,7 @@ int chz_bank_set_responses(chz_engine* e, int bank, int ch0, int n, const float*
   BANK_CHECK(e, bank, ch0, n);
   if (!resp) return fail(-1, "null argument");
   Bank& b = e->banks[(size_t)bank];
+  if (b.shared_rows) return fail(-1, "this bank's channels share %d response rows: use chz_bank_set_row_responses / chz_bank_set_rows", b.shared_rows);
   if (n == 0) return 0;
   HIPOK(hipSetDevice(e->device));
   const int spare_total = b.rows_total - b.cap;
@@ -947,6 +958,26 @@ int chz_bank_set_responses(chz_engine* e, int bank, int ch0, int n, const float*
   }
   b.retired.push_back(std::move(old));
   mark_dirty(b, ch0, n);
+  return 0;
+}
+int chz_bank_set_rows(chz_engine* e, int bank, int ch0, int n, const int* rows) {
+  BANK_CHECK(e, bank, ch0, n);
+  if (!rows) return fail(-1, "null argument");
+  Bank& b = e->banks[(size_t)bank];
+  if (!b.shared_rows) return fail(-1, "bank was not created with chz_bank_create_shared");
+  for (int i = 0; i < n; i++) if (rows[i] < 0 || rows[i] >= b.shared_rows) return fail(-1, "row %d out of range (bank has %d)", rows[i], b.shared_rows);
+  for (int i = 0; i < n; i++) b.desc_h[(size_t)(ch0 + i)].row = rows[i];
+  return after_edit(e, b, ch0, n);            // with the next block of each slot, in stream order, like a retune
+}
+int chz_bank_set_row_responses(chz_engine* e, int bank, int row0, int n, const float* resp) {
+  BANK_CHECK(e, bank, 0, 0);
+  if (!resp) return fail(-1, "null argument");
+  Bank& b = e->banks[(size_t)bank];
+  if (!b.shared_rows) return fail(-1, "bank was not created with chz_bank_create_shared");
+  if (row0 < 0 || n < 0 || row0 + n > b.shared_rows) return fail(-1, "row range out of the bank's %d rows", b.shared_rows);
+  HIPOK(hipSetDevice(e->device));
+  { int r = sync_all(e); if (r) return r; }   // a shared row is read by many channels of the blocks in flight: written between blocks
+  HIPOK(hipMemcpy(b.resp + (size_t)row0 * b.P, resp, sizeof(float2) * (size_t)n * b.P, hipMemcpyHostToDevice));
   return 0;
 }
 int chz_bank_set_shifts(chz_engine* e, int bank, int ch0, int n, const int* shifts) {

@@ -54,7 +54,7 @@ SYMBOLS = [
     "chz_last_error", "chz_device_count", "chz_engine_create", "chz_engine_destroy", "chz_engine_info",
     "chz_engine_set_stream", "chz_sync", "chz_input_write", "chz_input_write_device", "chz_input_ring",
     "chz_forward", "chz_slot_stream", "chz_set_notches", "chz_spectrum_read", "chz_spectrum_device", "chz_spectrum_attach",
-    "chz_bank_create", "chz_bank_set_responses", "chz_bank_set_shifts", "chz_bank_set_active",
+    "chz_bank_create", "chz_bank_create_shared", "chz_bank_set_rows", "chz_bank_set_row_responses", "chz_bank_set_responses", "chz_bank_set_shifts", "chz_bank_set_active",
     "chz_bank_execute", "chz_bank_execute_range", "chz_bank_destroy", "chz_bank_read", "chz_bank_read_async",
     "chz_spectrum_read_async", "chz_host_callback", "chz_host_alloc", "chz_host_free", "chz_host_register", "chz_host_unregister",
     "chz_bank_output_device", "chz_bank_write_block", "chz_bank_demod", "chz_bank_demod_auto", "chz_bank_read_pcm_flags_async", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
@@ -281,8 +281,8 @@ class Engine:
         _check(lib().chz_spectrum_attach(self._h, slot, dev_ptr))
 
     # -- banks -----------------------------------------------------------------
-    def bank(self, P, olen, capacity, real=False):
-        b = Bank(self, P, olen, capacity, real)
+    def bank(self, P, olen, capacity, real=False, shared_rows=0):
+        b = Bank(self, P, olen, capacity, real, shared_rows)
         self.banks.append(b)
         return b
 
@@ -300,10 +300,17 @@ class Engine:
 
 
 class Bank:
-    def __init__(self, eng, P, olen, capacity, real=False):
+    def __init__(self, eng, P, olen, capacity, real=False, shared_rows=0):
         self.eng, self.P, self.olen, self.capacity, self.real = eng, P, olen, capacity, bool(real)
-        make = lib().chz_bank_create_real if real else lib().chz_bank_create      # REAL- or COMPLEX-output slaves
-        self.id = _check(make(eng._h, P, olen, capacity))
+        L = lib()
+        if shared_rows:                                                            # channels name one of `shared_rows` response rows
+            L.chz_bank_create_shared.argtypes = [_vp, _i, _i, _i, _i]
+            L.chz_bank_set_rows.argtypes = [_vp, _i, _i, _i, _vp]
+            L.chz_bank_set_row_responses.argtypes = [_vp, _i, _i, _i, _vp]
+            self.id = _check(L.chz_bank_create_shared(eng._h, P, olen, capacity, shared_rows))
+        else:
+            make = L.chz_bank_create_real if real else L.chz_bank_create          # REAL- or COMPLEX-output slaves
+            self.id = _check(make(eng._h, P, olen, capacity))
         self._dtype = np.float32 if real else np.complex64
         self.active = 0
 
@@ -312,6 +319,15 @@ class Bank:
         if self.id is not None and self.eng._h:
             _check(lib().chz_bank_destroy(self.eng._h, self.id))
         self.id = None
+
+    def set_rows(self, ch0, rows):
+        r = np.ascontiguousarray(rows, np.int32)
+        _check(lib().chz_bank_set_rows(self.eng._h, self.id, ch0, r.shape[0], r.ctypes.data))
+
+    def set_row_responses(self, row0, resp):
+        r = np.ascontiguousarray(resp, np.complex64)
+        assert r.ndim == 2 and r.shape[1] == self.P
+        _check(lib().chz_bank_set_row_responses(self.eng._h, self.id, row0, r.shape[0], r.ctypes.data))
 
     def set_responses(self, ch0, resp):
         resp = np.ascontiguousarray(resp, np.complex64).reshape(-1, self.P)

@@ -631,3 +631,38 @@ def test_a_notch_wait_that_runs_out_fails_fast_and_loudly():
     assert secs < 20.0
     if kind == "failed":
         assert "ordering failed" in line[0]
+
+
+@pytest.mark.gpu
+def test_channels_sharing_response_rows(pkg):
+    """chz_bank_create_shared: 3 response rows for 48 channels.  Bit-identical to an ordinary bank given the same responses
+    channel by channel; a channel re-pointed to another row (no drain) follows from its next block on; per-channel
+    chz_bank_set_responses is refused."""
+    L, M, P, olen = 25920, 6481, 300, 240
+    N = L + M - 1
+    nch = 48
+    rng = np.random.default_rng(4)
+    rows3 = np.stack([pkg.filterapi.design_response(P, olen, N, True, lo, hi, 11.0) for lo, hi in ((0.004, 0.25), (-0.02, 0.02), (-0.4, 0.4))]).astype(np.complex64)
+    which = (np.arange(nch) % 3).astype(np.int32)
+    shifts = rng.integers(-12000, 12000, nch).astype(np.int32)
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    try:
+        shared = eng.bank(P, olen, nch, shared_rows=3); plain = eng.bank(P, olen, nch)
+        shared.set_row_responses(0, rows3); shared.set_rows(0, which); shared.set_shifts(0, shifts); shared.set_active(nch)
+        plain.set_responses(0, rows3[which]); plain.set_shifts(0, shifts); plain.set_active(nch)
+        with pytest.raises(pkg.engine.ChzError):
+            shared.set_responses(0, rows3[:1])
+        with pytest.raises(pkg.engine.ChzError):
+            shared.set_rows(0, np.array([3], np.int32))
+        x = (rng.standard_normal(8 * L) * 0.05).astype(np.float32)
+        eng.write(x[:8 * L - (M - 1)]); eng.write(x[8 * L - (M - 1):])
+        eng.run_blocks(0, 6)
+        assert np.array_equal(shared.read_slot(5 % 4).view(np.uint32), plain.read_slot(5 % 4).view(np.uint32))
+        which[5] = 2; which[17] = 0
+        shared.set_rows(5, which[5:6]); shared.set_rows(17, which[17:18])          # like a retune: in stream order, nothing drains
+        plain.set_responses(5, rows3[which[5:6]]); plain.set_responses(17, rows3[which[17:18]])
+        eng.run_blocks(6, 7)
+        assert np.array_equal(shared.read_slot(12 % 4).view(np.uint32), plain.read_slot(12 % 4).view(np.uint32))
+        assert np.abs(shared.read_slot(12 % 4)).max() > 0
+    finally:
+        eng.close()
