@@ -746,3 +746,64 @@ def test_fm_pll_and_tone_kernel(emu):
                 assert got.foffset == pytest.approx(st.foffset, rel=1e-6, abs=1e-6) and got.pdeviation == pytest.approx(st.pdeviation, rel=1e-6, abs=1e-3)
                 _check_pcm(p, pcm[i], want, N, 4e-6)
     assert data[0] > 5 and data[1] > 5 and data[2] > 5 and data[3] == 0 and data[4] == 0 and data[5] > 5
+
+
+def test_demodulator_kernel_random_parameter_sweep(emu):
+    """Twenty-four channels with randomly drawn demodulator settings -- linear and FM side by side in ONE launch, every PCM encoding,
+    AGC on and off, envelope / carrier removal, squelch variants, PLLs, tone squelch -- run for 30 blocks on the emulated kernel
+    against the restated demodulators (which the same kind of sweep pins to the reference's own code)."""
+    from test_oracle_vs_reference import _demod_case, _fm_case, _coherent_case, _cmp_pcm
+    rng = np.random.default_rng(99)
+    encs = [ol.PCM_S16BE, ol.PCM_S16LE, ol.PCM_F32LE, ol.PCM_F32BE, ol.PCM_MULAW, ol.PCM_ALAW]
+    nblk, N, fs = 30, 240, 12000.0
+    params, oracles, bbs, powers, ests = [], [], [], [], []
+    for i in range(24):
+        enc = encs[int(rng.integers(0, len(encs)))]
+        if i % 2 == 0:
+            pll = bool(rng.integers(0, 4) == 0)
+            kw = dict(channels=int(rng.integers(1, 3)), env=bool(rng.integers(0, 2)), agc=bool(rng.integers(0, 4) > 0), encoding=enc,
+                      snr_squelch=bool(rng.integers(0, 3) == 0), squelch_tail=int(rng.integers(0, 4)), tuned=bool(rng.integers(0, 8) > 0),
+                      headroom_db=float(rng.uniform(-25, -5)), dc_alpha=float(rng.choice([0.0, 0.002])), bandwidth=float(rng.uniform(500, 6000)),
+                      gain_db=float(rng.uniform(20, 70)), pll=pll, pll_bw=float(rng.choice([20.0, 50.0])))
+            p = ol.lin_params(**kw)
+            bb, power = (_coherent_case(np.random.default_rng(3), 90, N, False) if pll else _demod_case(np.random.default_rng(2000 + i), nblk, N))
+            bb, power = bb[:nblk], power[:nblk].copy()
+            if kw["snr_squelch"]:
+                power[12:18] = 1e-12
+            est = 1e-8 * (1 + 0.3 * rng.standard_normal(nblk)) / fs
+            orc = ol.LinDemod(p)
+        else:
+            tone = float(rng.choice([0.0, 0.0, 100.0]))
+            kw = dict(encoding=enc, snr_squelch=bool(rng.integers(0, 3) == 0), squelch_tail=int(rng.integers(0, 4)), samprate=fs, bandwidth=8000.0,
+                      threshold_extend=bool(rng.integers(0, 2)), deemph_tc=float(rng.choice([0.0, 530.5e-6])), pll=bool(rng.integers(0, 4) == 0), tone_freq=tone)
+            p = ol.fm_params(**kw)
+            bb, power = _fm_case(np.random.default_rng(3000 + i), nblk, N, fs, tone=tone if rng.integers(0, 2) else 0.0, last=26)
+            est = (2 * 2e-3 ** 2 / fs) * (1 + 0.1 * rng.standard_normal(nblk))
+            orc = ol.FmDemod(p)
+        params.append(p); oracles.append(orc); bbs.append(bb); powers.append(power); ests.append(est)
+    nch = len(params)
+    chan = (_DemodChan * nch)(); state = (_DemodState * nch)(); status = (ol.LinStatus * nch)(); ext = (_DemodExt * nch)()
+    emu.emu_demod_ext_init(ext, nch)
+    for i, p in enumerate(params):
+        c = chan[i]
+        for f in _CHAN_FIELDS:
+            setattr(c, f, getattr(p, f))
+        c.on = 1; c.osc_freq = 0.0
+        emu.emu_demod_tone_consts(chan, i, p.tone_freq, p.samprate)
+        state[i].n0 = float("nan")
+        if p.kind == ol.DEMOD_LINEAR:
+            state[i].gain = p.gain; state[i].squelch_open = 1
+            state[i].squelch_state = (p.squelch_tail + 4) if not (p.snr_squelch or p.pll_enable) else 0
+    pcm = np.zeros((nch, N * 8), np.uint8)
+    for b in range(nblk):
+        x = np.ascontiguousarray(np.stack([bbs[i][b] for i in range(nch)]))
+        pw = np.array([powers[i][b] for i in range(nch)]); ne = np.array([ests[i][b] for i in range(nch)])
+        assert emu.emu_demod(x.ctypes.data, pw.ctypes.data, ne.ctypes.data, chan, state, status, pcm.ctypes.data, nch, N, b, 0.02, ext) == 0
+        for i, p in enumerate(params):
+            want, st = oracles[i].block(bbs[i][b], powers[i][b], ests[i][b], 0.02)
+            got = status[i]
+            assert (got.frame, got.mute, got.squelch_state, got.pll_lock, got.tone_mute) == (st.frame, st.mute, st.squelch_state, st.pll_lock, st.tone_mute), (b, i)
+            assert got.output_power == pytest.approx(st.output_power, rel=3e-6, abs=1e-300), (b, i)
+            if st.frame == ol.FRAME_DATA:
+                nb = ol.pcm_bytes(p.encoding, N * p.channels)
+                assert _cmp_pcm(p, pcm[i, :nb], want, 1e-4 if (p.env and p.dc_alpha) else 6e-6), (b, i)

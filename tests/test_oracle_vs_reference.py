@@ -615,3 +615,85 @@ def test_fm_pll_and_tone_squelch_match_reference_fm_c(oracle_built, kw, tone_sen
         assert data >= 5
     if p.tone_freq == tone_sent and tone_sent:
         assert max(ref["tonedev"]) == pytest.approx(600.0, rel=0.1)  # the detector measures the tone's deviation
+
+
+# ------------------------------------------------------------------------------------------------
+# randomised sweeps: the restated demodulators against the reference's own code over parameter combinations nobody picked by hand
+# ------------------------------------------------------------------------------------------------
+def _cmp_pcm(p, got, want, tol_f):
+    if p.encoding in (ol.PCM_MULAW, ol.PCM_ALAW):
+        return np.mean(got != want) < 0.02
+    if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+        dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
+        a, w = got.view(dt).astype(np.int32), want.view(dt).astype(np.int32)
+        return np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02
+    dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
+    a, w = got.view(dt).astype(np.float64), want.view(dt).astype(np.float64)
+    return np.abs(a - w).max() <= tol_f * max(np.abs(w).max(), 1e-30)
+
+
+@pytest.mark.skipif(not ol.have_ref_linear(), reason="oracle/_ref/libka9q_ref_linear.so not built (needs /root/reference)")
+def test_linear_demodulator_random_parameter_sweep(oracle_built):
+    rng = np.random.default_rng(20260926)
+    encs = [ol.PCM_S16BE, ol.PCM_S16LE, ol.PCM_F32LE, ol.PCM_F32BE, ol.PCM_MULAW, ol.PCM_ALAW]
+    for case in range(30):
+        kw = dict(channels=int(rng.integers(1, 3)), env=bool(rng.integers(0, 2)), agc=bool(rng.integers(0, 4) > 0),
+                  encoding=encs[int(rng.integers(0, len(encs)))], snr_squelch=bool(rng.integers(0, 3) == 0), squelch_tail=int(rng.integers(0, 4)),
+                  tuned=bool(rng.integers(0, 8) > 0), headroom_db=float(rng.uniform(-25, -5)), threshold_db=float(rng.uniform(-25, -5)),
+                  recovery_db_per_s=float(rng.uniform(5, 40)), hangtime=float(rng.uniform(0.0, 0.3)),
+                  dc_alpha=float(rng.choice([0.0, 0.002, 0.02])), bandwidth=float(rng.uniform(500, 6000)),
+                  shift=float(rng.choice([0.0, 0.0, 700.0, -431.5])), gain_db=float(rng.uniform(20, 70)))
+        nblk, N = 24, int(rng.choice([240, 160, 480]))
+        kw["samprate"] = N * 50.0
+        bb, power = _demod_case(np.random.default_rng(1000 + case), nblk, N, bursts=bool(rng.integers(0, 2))) if nblk >= 16 else (None, None)
+        if kw["snr_squelch"]:
+            power = power.copy(); power[10:15] = 1e-12
+        n0_est = 1e-8 * (1 + 0.3 * rng.standard_normal(nblk)) / kw["samprate"]
+        p = ol.lin_params(**kw)
+        n0s = np.zeros(nblk); s = np.nan
+        for b in range(nblk):
+            s = n0_est[b] if np.isnan(s) else s + 0.10 * (n0_est[b] - s)
+            n0s[b] = s
+        pcm_r, frame_r, mute_r, pow_r, gain_r = ol.ref_linear_run(p, bb, power, n0s, 0.02)
+        d = ol.LinDemod(p)
+        for b in range(nblk):
+            pcm, st = d.block(bb[b], power[b], n0_est[b], 0.02)
+            assert st.frame == frame_r[b] and st.mute == mute_r[b], (case, kw, b)
+            assert st.gain == pytest.approx(gain_r[b], rel=1e-9), (case, b)
+            assert st.output_power == pytest.approx(pow_r[b], rel=3e-7, abs=1e-300), (case, b)
+            if st.frame == ol.FRAME_DATA:
+                # (envelope detection goes through cabsf -- an ulp of a float between the two builds -- and carrier removal then subtracts
+                # nearly all of it: what is left carries that ulp at a relative size of envelope / residue)
+                assert _cmp_pcm(p, pcm, pcm_r[b][:pcm.size], 1e-4 if (kw["env"] and kw["dc_alpha"]) else 3e-7), (case, kw, b)
+
+
+@pytest.mark.skipif(not ol.have_ref_fm(), reason="oracle/_ref/libka9q_ref_fm.so not built (needs /root/reference)")
+def test_fm_demodulator_random_parameter_sweep(oracle_built):
+    rng = np.random.default_rng(7)
+    encs = [ol.PCM_S16BE, ol.PCM_S16LE, ol.PCM_F32LE, ol.PCM_F32BE, ol.PCM_MULAW, ol.PCM_ALAW]
+    for case in range(20):
+        tone = float(rng.choice([0.0, 0.0, 100.0, 88.5]))
+        kw = dict(encoding=encs[int(rng.integers(0, len(encs)))], snr_squelch=bool(rng.integers(0, 3) == 0), squelch_tail=int(rng.integers(0, 4)),
+                  threshold_extend=bool(rng.integers(0, 2)), deemph_tc=float(rng.choice([0.0, 530.5e-6, 75e-6])),
+                  headroom_db=float(rng.uniform(-20, -6)), pll=bool(rng.integers(0, 4) == 0), tone_freq=tone,
+                  squelch_open=float(rng.uniform(3.0, 8.0)))
+        kw["squelch_close"] = kw["squelch_open"] * float(rng.uniform(0.5, 0.9))
+        nblk, N, fs = 52, 480, 24000.0
+        sent = tone if rng.integers(0, 3) else 0.0
+        bb, power = _fm_case(np.random.default_rng(500 + case), nblk, N, fs, tone=sent, last=44)
+        p = ol.fm_params(**kw)
+        n0_est = (2 * 2e-3 ** 2 / fs) * (1 + 0.1 * rng.standard_normal(nblk))
+        n0s = np.zeros(nblk); s = np.nan
+        for b in range(nblk):
+            s = n0_est[b] if np.isnan(s) else s + 0.10 * (n0_est[b] - s)
+            n0s[b] = s
+        ref = ol.ref_fm_run(p, bb, power, n0s, 0.02)
+        d = ol.FmDemod(p)
+        for b in range(nblk):
+            pcm, st = d.block(bb[b], power[b], n0_est[b], 0.02)
+            assert st.frame == ref["frame"][b] and st.mute == ref["mute"][b], (case, kw, b)
+            assert st.snr == pytest.approx(ref["snr"][b], rel=1e-6, abs=1e-12)
+            assert st.tone_deviation == pytest.approx(ref["tonedev"][b], rel=1e-5, abs=1e-6)
+            if st.frame == ol.FRAME_DATA:
+                assert st.output_power == pytest.approx(ref["power"][b], rel=3e-6)
+                assert _cmp_pcm(p, pcm, ref["pcm"][b][:pcm.size], 6e-6), (case, kw, b)
