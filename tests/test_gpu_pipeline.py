@@ -666,3 +666,40 @@ def test_channels_sharing_response_rows(pkg):
         assert np.abs(shared.read_slot(12 % 4)).max() > 0
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_demodulators_random_parameter_sweep_on_the_device(pkg):
+    """The 24 randomly configured channels of tests/test_kernels_emulated.py::random_demod_channels (linear and FM mixed in one bank,
+    all encodings, PLLs, tone squelch) on the device: blocks handed to the demodulator stage through chz_bank_write_block +
+    chz_bank_demod, frames against the restated demodulators."""
+    from test_kernels_emulated import random_demod_channels
+    from test_oracle_vs_reference import _cmp_pcm
+    nblk, N = 30, 240
+    params, oracles, bbs, powers, ests = random_demod_channels(424242, nblk, N)
+    nch = len(params)
+    eng = pkg.engine.Engine(25920, 6481, ol.REAL, ring_blocks=8)
+    try:
+        bank = eng.bank(300, N, nch)
+        bank.set_responses(0, np.ones((nch, 300), np.complex64) / 300)
+        bank.set_tuning(0, 0, np.full(nch, 2500, np.int32), np.zeros(nch))
+        bank.set_active(nch); bank.enable_noise(1.296e6); bank.set_pcm_stride(8 * N)
+        bank.set_demod(0, 0, [pkg.engine.DemodParams(*[getattr(p, f) for f, _ in ol.LinParams._fields_]) for p in params], 0.02)
+        bank.demod_auto(False)
+        for b in range(nblk):
+            slot = b % 4
+            bank.inject(slot, np.stack([bbs[i][b] for i in range(nch)]), np.array([powers[i][b] for i in range(nch)]), np.array([ests[i][b] for i in range(nch)]))
+            bank.demod_only(b)
+            pcm, status = bank.read_pcm(slot)
+            for i, p in enumerate(params):
+                want, st = oracles[i].block(bbs[i][b], powers[i][b], ests[i][b], 0.02)
+                got = status[i]
+                strict = not (p.pll_enable and b >= 20)            # (a PLL without a carrier is chaotic; see test_coherent_modes...)
+                assert (got.frame, got.mute, got.squelch_state) == (st.frame, st.mute, st.squelch_state), (b, i)
+                if strict:
+                    assert got.output_power == pytest.approx(st.output_power, rel=1e-5, abs=1e-300), (b, i)
+                    if st.frame == ol.FRAME_DATA:
+                        nb = ol.pcm_bytes(p.encoding, N * p.channels)
+                        assert _cmp_pcm(p, pcm[i, :nb], want, 1e-4 if (p.env and p.dc_alpha) else 8e-6), (b, i)
+    finally:
+        eng.close()

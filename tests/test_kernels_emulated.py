@@ -748,14 +748,11 @@ def test_fm_pll_and_tone_kernel(emu):
     assert data[0] > 5 and data[1] > 5 and data[2] > 5 and data[3] == 0 and data[4] == 0 and data[5] > 5
 
 
-def test_demodulator_kernel_random_parameter_sweep(emu):
-    """Twenty-four channels with randomly drawn demodulator settings -- linear and FM side by side in ONE launch, every PCM encoding,
-    AGC on and off, envelope / carrier removal, squelch variants, PLLs, tone squelch -- run for 30 blocks on the emulated kernel
-    against the restated demodulators (which the same kind of sweep pins to the reference's own code)."""
-    from test_oracle_vs_reference import _demod_case, _fm_case, _coherent_case, _cmp_pcm
-    rng = np.random.default_rng(99)
+def random_demod_channels(seed=99, nblk=30, N=240, fs=12000.0):
+    """24 channels with randomly drawn demodulator settings (linear and FM alternating) and their test signals."""
+    from test_oracle_vs_reference import _demod_case, _fm_case, _coherent_case
+    rng = np.random.default_rng(seed)
     encs = [ol.PCM_S16BE, ol.PCM_S16LE, ol.PCM_F32LE, ol.PCM_F32BE, ol.PCM_MULAW, ol.PCM_ALAW]
-    nblk, N, fs = 30, 240, 12000.0
     params, oracles, bbs, powers, ests = [], [], [], [], []
     for i in range(24):
         enc = encs[int(rng.integers(0, len(encs)))]
@@ -781,6 +778,16 @@ def test_demodulator_kernel_random_parameter_sweep(emu):
             est = (2 * 2e-3 ** 2 / fs) * (1 + 0.1 * rng.standard_normal(nblk))
             orc = ol.FmDemod(p)
         params.append(p); oracles.append(orc); bbs.append(bb); powers.append(power); ests.append(est)
+    return params, oracles, bbs, powers, ests
+
+
+def test_demodulator_kernel_random_parameter_sweep(emu):
+    """Twenty-four channels with randomly drawn demodulator settings -- linear and FM side by side in ONE launch, every PCM encoding,
+    AGC on and off, envelope / carrier removal, squelch variants, PLLs, tone squelch -- run for 30 blocks on the emulated kernel
+    against the restated demodulators (which the same kind of sweep pins to the reference's own code)."""
+    from test_oracle_vs_reference import _cmp_pcm
+    nblk, N = 30, 240
+    params, oracles, bbs, powers, ests = random_demod_channels(99, nblk, N)
     nch = len(params)
     chan = (_DemodChan * nch)(); state = (_DemodState * nch)(); status = (ol.LinStatus * nch)(); ext = (_DemodExt * nch)()
     emu.emu_demod_ext_init(ext, nch)
