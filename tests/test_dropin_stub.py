@@ -119,3 +119,43 @@ def test_dropin_other_paths_are_sanitizer_clean(tmp_path, san, env):
     assert int(meta["clock"]) == nblocks
     if "HARNESS_CHURN_MOD" not in env:
         assert meta["drops"] == "0"
+
+
+@pytest.mark.parametrize("san", ["thread", "address"])
+def test_dropin_complex_master_under_sanitizers(tmp_path, san):
+    """BASELINE config 1's geometry (2.4 MS/s complex front end: L = 48000, M = 12001, one IQ-mode channel among others) through the
+    drop-in's host code with write_cfilter, under the sanitizers; outputs against the oracle."""
+    if not _have("-fsanitize=" + san):
+        pytest.skip("no -fsanitize=%s runtime in this image" % san)
+    exe = _build(san, str(tmp_path / "build"))
+    L, M, olen, P = 48000, 12001, 240, 300
+    N = L + M - 1
+    nblocks, nch = 6, 24
+    rng = np.random.default_rng(12)
+    g = ol.SigGen(100020.0 / 2.4e6, 0.1, 0.01, ol.scale_ad(False, 1), False, seed=1)
+    x = g.generate(nblocks * L)                                   # complex64
+    plan = [(int(rng.integers(-25000, 25000)),) * 2 + (10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4) for _ in range(nch)]
+    plan[0] = (0, 0, 10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4)               # the IQ channel at DC
+    plan[1] = (29990, -29990, 3, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4)            # across the +-Nyquist seam, retuned at block 3
+    run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
+    open(os.path.join(run_dir, "cfg.txt"), "w").write("%d %d %d %d %d %d %d\n" % (L, M, ol.COMPLEX, olen, len(plan), nblocks, 4096))
+    with open(os.path.join(run_dir, "plan.bin"), "wb") as f:
+        for p in plan:
+            f.write(struct.pack("iiiiddddd", *p))
+    np.ascontiguousarray(x, np.complex64).tofile(os.path.join(run_dir, "in.bin"))
+    e = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=67")
+    r = subprocess.run([exe, run_dir], capture_output=True, text=True, timeout=int(os.environ.get("STUB_TIMEOUT", "300")), env=e)
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-5000:]
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = np.fromfile(os.path.join(run_dir, "out.bin"), np.complex64).reshape(nblocks, nch, olen)
+    st = ol.Stream(L, M, ol.COMPLEX)
+    state = np.zeros(2)
+    for b in range(nblocks):
+        s64 = st.push(x[b * L:(b + 1) * L], f64=True)
+        dc = s64[:1].astype(np.complex64); ol.notch(state, [0], 0.01, dc); s64[0] = dc[0]
+        for i, p in enumerate(plan):
+            shift = p[1] if b >= p[2] else p[0]
+            resp = ol.set_filter(P, olen, N, False, p[4], p[5], p[6])
+            want = ol.channel(s64, ol.COMPLEX, P, olen, shift, resp)
+            err = float(np.sqrt(np.mean(np.abs(out[b, i] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+            assert err <= 1e-5 * rms + 2e-8 * float(np.abs(s64).max()) * float(np.linalg.norm(resp)), (b, i, err, rms)
