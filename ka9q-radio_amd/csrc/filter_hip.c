@@ -632,7 +632,8 @@ int execute_filter_input(struct filter_in *const f) {
     if (!b->real) {                 /* callers flip slave->isb directly (src/radio.c:1586, src/radio_status.c:326) */
       int lo = b->n, hi = 0;
       for (int k = 0; k < b->n; k++) {
-        unsigned char v = b->slaves[k]->isb ? 1 : 0;
+        /* a caller-owned bool its own thread flips at will: a relaxed one-byte load */
+        unsigned char v = __atomic_load_n((unsigned char const *)&b->slaves[k]->isb, __ATOMIC_RELAXED) ? 1 : 0;
         if (v != b->isb[k]) { b->isb[k] = v; if (k < lo) lo = k; hi = k + 1; }
       }
       if (hi > lo) chz_bank_set_isb(c->eng, b->id, lo, hi - lo, b->isb + lo);
@@ -649,8 +650,11 @@ int execute_filter_input(struct filter_in *const f) {
       if (f->in_type == COMPLEX) {   /* slave->beam and its weights (src/radio.c:938-940) */
         for (int k = 0; k < b->n; k++) {
           struct filter_out *s = b->slaves[k];
+          /* set_filter_weights() runs in the slave's own thread and writes two complex doubles: read them whole */
+          if (s->init) pthread_mutex_lock(&s->response_mutex);
           double ab[4] = {creal(s->alpha), cimag(s->alpha), creal(s->beta), cimag(s->beta)};
-          unsigned char on = s->beam ? 1 : 0;
+          if (s->init) pthread_mutex_unlock(&s->response_mutex);
+          unsigned char on = __atomic_load_n((unsigned char const *)&s->beam, __ATOMIC_RELAXED) ? 1 : 0;
           if (on != b->beam_on[k] || (on && memcmp(ab, b->beam_ab + 4 * k, sizeof ab) != 0)) {
             b->beam_on[k] = on; memcpy(b->beam_ab + 4 * k, ab, sizeof ab);
             chz_bank_set_beam(c->eng, b->id, k, 1, ab, &on);
@@ -837,14 +841,18 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
   /* the block's slot was re-used for a later block while this channel waited (it was being lapped) */
   fprintf(stderr, "execute_filter_output: block %u is gone from the device (the channel is more than %d blocks behind)\n", job, ND - 1);
   slave->block_drops++;
-  memset(dst, 0, bank_sample_bytes(&c->banks[sc->bank]) * (size_t)slave->olen);
+  /* (the size from the slave itself: c->banks may be growing under another thread's create_filter_output right now) */
+  memset(dst, 0, (real_out ? sizeof(float) : sizeof(float complex)) * (size_t)slave->olen);
   return 0;
 }
 
 int set_filter_weights(struct filter_out *out, double complex i_weight, double complex q_weight) {  /* src/filter.c:922-929 */
   if (out == NULL) return -1;
+  /* the front-end thread reads both weights when it uploads them (execute_filter_input): written under the slave's mutex */
+  if (out->init) pthread_mutex_lock(&out->response_mutex);
   out->alpha = 0.5 * i_weight - I * q_weight;
   out->beta = 0.5 * i_weight + I * q_weight;
+  if (out->init) pthread_mutex_unlock(&out->response_mutex);
   return 0;
 }
 

@@ -159,3 +159,23 @@ def test_dropin_complex_master_under_sanitizers(tmp_path, san):
             want = ol.channel(s64, ol.COMPLEX, P, olen, shift, resp)
             err = float(np.sqrt(np.mean(np.abs(out[b, i] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
             assert err <= 1e-5 * rms + 2e-8 * float(np.abs(s64).max()) * float(np.linalg.norm(resp)), (b, i, err, rms)
+
+
+@pytest.mark.parametrize("san", ["thread", "address"])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_dropin_random_traffic_under_sanitizers(tmp_path, san, seed):
+    """tests/c/dropin_fuzz.c: 24 threads doing at random what radiod's channel threads do to their slaves -- create (three output
+    types, four sizes), set_filter, execute with old and new shifts, flip isb, delete and re-create, fall behind -- against a master
+    that is being fed all the while.  It must end, every call must succeed, the sanitizers must stay silent."""
+    if not _have("-fsanitize=" + san):
+        pytest.skip("no -fsanitize=%s runtime in this image" % san)
+    out_dir = str(tmp_path / "build")
+    _build(san, out_dir)
+    exe = os.path.join(out_dir, "fuzz")
+    subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-fsanitize=" + san, "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "dropin_fuzz.c"),
+                    "-o", exe, "-L", out_dir, "-lka9q_filter_hip", "-lchz_hip", "-Wl,-rpath," + out_dir, "-lpthread", "-lm"], check=True)
+    e = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=67")
+    r = subprocess.run([exe, "24", "150", str(seed)], capture_output=True, text=True, timeout=int(os.environ.get("STUB_TIMEOUT", "600")), env=e)
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-6000:]
+    assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-2000:])
+    assert "failed 0" in r.stdout
