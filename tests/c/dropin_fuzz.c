@@ -30,6 +30,10 @@ static void *worker(void *a) {
   struct filter_out sl[NSL]; bool live[NSL] = {false, false, false}; int shift[NSL] = {0, 0, 0};
   memset(sl, 0, sizeof sl);
   static const int olens[4] = {240, 480, 160, 960};
+  /* an optional private second filter (radiod's filter2, src/radio.c:1572-1594): a pooled inline master shared-nothing per worker, but
+     the POOL behind it is shared by all of them */
+  struct filter_in f2in; struct filter_out f2out; bool f2 = false;
+  memset(&f2in, 0, sizeof f2in); memset(&f2out, 0, sizeof f2out);
   for (int step = 0; step < Steps && !atomic_load(&Failed); step++) {
     int const k = (int)(rnd(&s) % NSL);
     unsigned const op = (unsigned)(rnd(&s) % 100);
@@ -49,6 +53,20 @@ static void *worker(void *a) {
     if (op < 70) {                                   /* the common case: take the next block, sometimes retuned */
       if (op < 15) shift[k] = (int)(rnd(&s) % 40000) - 20000;
       if (execute_filter_output(&sl[k], shift[k]) != 0) { fprintf(stderr, "execute_filter_output failed\n"); atomic_store(&Failed, 1); break; }
+      if (f2 && sl[k].out_type == COMPLEX && sl[k].olen == 240) {           /* through the second filter, as radio.c:1503-1513 does */
+        int const r = write_cfilter(&f2in, sl[k].output.c, 240);
+        if (r < 0) { fprintf(stderr, "filter2 write_cfilter failed\n"); atomic_store(&Failed, 1); break; }
+        if (r > 0 && execute_filter_output(&f2out, 0) != 0) { fprintf(stderr, "filter2 execute_filter_output failed\n"); atomic_store(&Failed, 1); break; }
+      }
+    } else if (op < 74) {                              /* filter2 comes and goes */
+      if (!f2) {
+        memset(&f2in, 0, sizeof f2in); memset(&f2out, 0, sizeof f2out);
+        if (create_filter_input(&f2in, 240, 273, COMPLEX) != 0) { fprintf(stderr, "filter2 create_filter_input failed\n"); atomic_store(&Failed, 1); break; }
+        f2in.perform_inline = true;
+        if (create_filter_output(&f2out, &f2in, 240, COMPLEX) != 0) { fprintf(stderr, "filter2 create_filter_output failed\n"); atomic_store(&Failed, 1); break; }
+        if (set_filter(&f2out, -0.1, 0.1, 7.0) != 0) { fprintf(stderr, "filter2 set_filter failed\n"); atomic_store(&Failed, 1); break; }
+        f2 = true;
+      } else { delete_filter_output(&f2out); delete_filter_input(&f2in); f2 = false; }
     } else if (op < 80) {
       if (sl[k].out_type != SPECTRUM) {
         double const lo = -0.45 + 0.4 * (double)(rnd(&s) % 100) / 100.0;
@@ -65,6 +83,7 @@ static void *worker(void *a) {
     }
   }
   for (int k = 0; k < NSL; k++) if (live[k]) delete_filter_output(&sl[k]);
+  if (f2) { delete_filter_output(&f2out); delete_filter_input(&f2in); }
   atomic_fetch_add(&Done, 1);
   return NULL;
 }
