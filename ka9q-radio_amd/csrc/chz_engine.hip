@@ -199,7 +199,7 @@ struct chz_engine {
   std::vector<Issuer*> issuers;
 };
 
-static int sync_all(chz_engine* e);
+extern "C" { static int sync_all(chz_engine* e); }      // (defined inside the extern "C" block below: same linkage for every compiler)
 
 template <class T> static int upload(T** dst, const std::vector<f2>& v) {
   *dst = nullptr;

@@ -79,6 +79,11 @@ def lib():
             raise RuntimeError("libchz_hip.so is missing: build it with `make -C ka9q-radio_amd/csrc` "
                                "(there is no CPU fallback)")
         L = C.CDLL(LIB_PATH)
+        # tests/hipemu can build the engine's HOST code for the CPU (kernels on a fiber emulator) so that its orchestration is
+        # testable without a GPU; such a library carries this symbol, and nothing but a test that says so may load it
+        if hasattr(L, "chz_emulated_build") and os.environ.get("CHZ_ALLOW_EMULATED_ENGINE") != "1":
+            raise RuntimeError("%s is a CPU-emulated TEST build of the engine: refusing to use it as the product "
+                               "(there is no CPU fallback)" % LIB_PATH)
         L.chz_last_error.restype = C.c_char_p
         L.chz_device_count.restype = _i
         L.chz_engine_create.argtypes = [C.POINTER(_vp), _i, _i, _i, _i, C.c_char_p, _i]

@@ -227,8 +227,20 @@ static inline void sincospi(double x, double* s, double* c) {
 
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
+#ifdef HIPEMU_HOST
+// the engine's host code on the CPU (tests/test_engine_emulated.py): the rest of the runtime API, launches one at a time
+#include "hip_host_stub.h"
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  do { std::lock_guard<std::recursive_mutex> hipemu_lk(hipemu::launch_mutex()); \
+       hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__); } while (0)
+#define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, e0, e1, flags, ...) \
+  do { std::lock_guard<std::recursive_mutex> hipemu_lk(hipemu::launch_mutex()); \
+       hipEventRecord(e0); hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__); hipEventRecord(e1); } while (0)
+#else
 #define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, e0, e1, flags, ...) \
   hipemu::launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), __VA_ARGS__)
+#endif
 // single-threaded fibers: agent-scope atomics degrade to plain accesses
 #define __HIP_MEMORY_SCOPE_AGENT 4
 template <class T> static inline T __hip_atomic_load(T* p, int, int) { return *p; }
