@@ -20,16 +20,20 @@ import oracle_lib as ol
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "ka9q-radio_amd")
+# tests/test_engine_emulated.py re-runs the harness tests against the drop-in linked with the CPU build of the engine: the two
+# libraries are then taken from this directory instead (and not rebuilt by `make`)
+LIBDIR = os.environ.get("KA9Q_TEST_LIBDIR", PKG)
 REF_SRC = "/root/reference/src"
 
 
 def _build_lib():
-    subprocess.run(["make", "-s", "-C", os.path.join(PKG, "csrc"), "all"], check=True)
+    if LIBDIR == PKG:
+        subprocess.run(["make", "-s", "-C", os.path.join(PKG, "csrc"), "all"], check=True)
 
 
 def _build_harness(out, ref_header=False):
     cmd = ["gcc", "-O2", "-std=gnu11", "-Wall", os.path.join(ROOT, "tests", "c", "dropin_harness.c"), "-o", out,
-           "-L", PKG, "-lka9q_filter_hip", "-lchz_hip", "-Wl,-rpath," + PKG, "-lpthread", "-lm"]
+           "-L", LIBDIR, "-lka9q_filter_hip", "-lchz_hip", "-Wl,-rpath," + LIBDIR, "-lpthread", "-lm"]
     if ref_header:
         cmd[4:4] = ["-DKA9Q_FILTER_HEADER=\"filter.h\"", "-D_GNU_SOURCE=1", "-I", os.path.join(ROOT, "oracle", "shims"), "-iquote", REF_SRC]
     else:
@@ -39,7 +43,7 @@ def _build_harness(out, ref_header=False):
 
 def test_dropin_exports_the_reference_symbol_set():
     _build_lib()
-    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(PKG, "libka9q_filter_hip.so")],
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(LIBDIR, "libka9q_filter_hip.so")],
                          capture_output=True, text=True, check=True).stdout
     mine = set(re.findall(r" [TDB] (\w+)", out))
     functions = {"create_filter_input", "create_filter_output", "execute_filter_input", "execute_filter_output",
@@ -375,7 +379,7 @@ def test_plan_helpers_forward_to_fftw_when_the_link_has_it(tmp_path):
     so = tmp_path / "libfake_fftw3f.so"
     subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
     script = tmp_path / "plans.py"; script.write_text(_PLAN_SCRIPT)
-    drop = os.path.join(PKG, "libka9q_filter_hip.so")
+    drop = os.path.join(LIBDIR, "libka9q_filter_hip.so")
     r = subprocess.run([sys.executable, str(script), str(so), drop], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "forward-ok" in r.stdout, r.stderr[-1500:]
     r = subprocess.run([sys.executable, str(script), "-", drop], capture_output=True, text=True, timeout=120)

@@ -51,3 +51,23 @@ def test_engine_orchestration_on_the_emulator(emulated_engine):
     assert r.returncode == 0, (tail, r.stdout[-3000:], r.stderr[-1500:])
     m = re.search(r"(\d+) passed", tail)
     assert m and int(m.group(1)) >= 60, tail
+
+
+def test_dropin_on_the_emulated_engine(emulated_engine, tmp_path):
+    """The filter.h drop-in linked against the CPU build of the engine, driven by the radiod-style C harness (front-end thread, one
+    pthread per channel, retunes, new filters, REAL slave, ISB, filter2's pooled inline masters, WFM-sized channels): the whole host
+    path -- filter_hip.c on top of chz_engine.hip on top of the kernels -- against the oracle, without a GPU."""
+    import shutil
+    libdir = str(tmp_path / "lib")
+    os.makedirs(libdir)
+    shutil.copy(emulated_engine, os.path.join(libdir, "libchz_hip.so"))
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-maybe-uninitialized",
+                    os.path.join(CSRC, "filter_hip.c"), "-o", os.path.join(libdir, "libka9q_filter_hip.so"), "-L", libdir, "-lchz_hip",
+                    "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"], check=True)
+    env = dict(os.environ, KA9Q_TEST_LIBDIR=libdir)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_dropin.py"), "-m", "gpu", "-q", "-x", "--timeout", "300", "-p", "no:cacheprovider",
+                        "-k", "not (config3 or c_example or sharded)"], capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    assert r.returncode == 0, (tail, r.stdout[-3000:], r.stderr[-1500:])
+    m = re.search(r"(\d+) passed", tail)
+    assert m and int(m.group(1)) >= 6, tail
