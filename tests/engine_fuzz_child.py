@@ -1,0 +1,93 @@
+"""Child process of tests/test_engine_emulated.py::test_engine_random_operations: a model-based random walk over the engine's C ABI
+(on whatever library CHZ_LIB names -- the CPU build in the test, an MI355X when run by hand on the GPU box).
+
+Two banks on one REAL master.  At random: retune a range of channels, swap responses, flip ISB flags, change the active count, run a
+few blocks pipelined over the lanes or one by one, re-create a bank.  A Python-side model knows what every channel should be doing;
+after every run the LAST block's outputs are compared with the oracle (float64 spectrum of the same samples, the model's shift /
+response / isb per channel)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import oracle_lib as ol
+from conftest import load_pkg
+from test_gpu_parity import check_channel, noise_floor
+
+
+def main(seed, iters):
+    pkg = load_pkg()
+    rng = np.random.default_rng(seed)
+    L, M = 25920, 6481
+    N = L + M - 1
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    st = ol.Stream(L, M, ol.REAL)
+    notch_state = np.zeros(2)
+    eng.set_notches([0], 0.01)
+    geo = [(300, 240, 40), (600, 480, 24)]
+    lib = {P: np.stack([ol.set_filter(P, olen, N, True, lo, hi, 9.0) for lo, hi in ((-0.35, 0.35), (0.01, 0.3), (-0.3, -0.02), (-0.1, 0.1), (-0.45, 0.2))]).astype(np.complex64)
+           for P, olen, _ in geo}
+
+    def fresh(i):
+        P, olen, cap = geo[i]
+        b = eng.bank(P, olen, cap)
+        m = dict(bank=b, P=P, olen=olen, cap=cap, shift=rng.integers(-12000, 12000, cap).astype(np.int32), which=rng.integers(0, 5, cap), isb=np.zeros(cap, np.uint8), active=cap)
+        b.set_responses(0, lib[P][m["which"]]); b.set_shifts(0, m["shift"]); b.set_active(cap)
+        return m
+    models = [fresh(0), fresh(1)]
+    job = 0
+    spec = None
+    checks = 0
+    for it in range(iters):
+        op = int(rng.integers(0, 100))
+        m = models[int(rng.integers(0, 2))]
+        b, cap = m["bank"], m["cap"]
+        if op < 30:                                         # retune a range
+            c0 = int(rng.integers(0, cap)); n = int(rng.integers(1, min(12, cap - c0) + 1))
+            m["shift"][c0:c0 + n] = rng.integers(-17000, 17000, n)
+            b.set_shifts(c0, m["shift"][c0:c0 + n])
+        elif op < 48:                                       # new filters for a few channels (spare rows, fences)
+            c0 = int(rng.integers(0, cap)); n = int(rng.integers(1, min(6, cap - c0) + 1))
+            m["which"][c0:c0 + n] = rng.integers(0, 5, n)
+            b.set_responses(c0, lib[m["P"]][m["which"][c0:c0 + n]])
+        elif op < 58:                                       # ISB flags
+            c0 = int(rng.integers(0, cap)); n = int(rng.integers(1, min(8, cap - c0) + 1))
+            m["isb"][c0:c0 + n] = rng.integers(0, 2, n)
+            b.set_isb(c0, m["isb"][c0:c0 + n])
+        elif op < 64:
+            m["active"] = int(rng.integers(1, cap + 1)); b.set_active(m["active"])
+        elif op < 68:                                       # the bank goes away and comes back (new device arrays, same id space)
+            idx = models.index(m)
+            b.destroy()
+            models[idx] = fresh(idx)
+        else:                                               # run: pipelined over the lanes, or block by block
+            k = int(rng.integers(1, 7))
+            xs = (rng.standard_normal(k * L) * 0.05).astype(np.float32)
+            if rng.integers(0, 2):
+                for j in range(k):
+                    eng.write(xs[j * L:(j + 1) * L]); eng.step(job + j)
+            else:
+                # the ring holds 8 blocks: write ahead, then run them in one go
+                for j in range(k):
+                    eng.write(xs[j * L:(j + 1) * L])
+                eng.run_blocks(job, k)
+            for j in range(k):
+                spec = st.push(xs[j * L:(j + 1) * L], f64=True)
+                dc = spec[:1].astype(np.complex64); ol.notch(notch_state, [0], 0.01, dc); spec[0] = dc[0]
+            job += k
+            last = (job - 1) % 4
+            for mm in models:
+                out = mm["bank"].read_slot(last)
+                for ch in rng.choice(mm["active"], size=min(6, mm["active"]), replace=False):
+                    resp = lib[mm["P"]][mm["which"][ch]]
+                    want = ol.channel(spec, ol.REAL, mm["P"], mm["olen"], int(mm["shift"][ch]), resp, isb=bool(mm["isb"][ch]))
+                    check_channel(out[ch], want, noise_floor(spec, resp))
+                    checks += 1
+    eng.check()
+    eng.close()
+    print("FUZZ ok iterations %d blocks %d channel checks %d" % (iters, job, checks))
+
+
+if __name__ == "__main__":
+    main(int(sys.argv[1]), int(sys.argv[2]))

@@ -71,3 +71,13 @@ def test_dropin_on_the_emulated_engine(emulated_engine, tmp_path):
     assert r.returncode == 0, (tail, r.stdout[-3000:], r.stderr[-1500:])
     m = re.search(r"(\d+) passed", tail)
     assert m and int(m.group(1)) >= 6, tail
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_engine_random_operations(emulated_engine, seed):
+    """tests/engine_fuzz_child.py: a model-based random walk over the engine's C ABI -- retunes, response swaps, ISB flags, active
+    counts, banks destroyed and re-created, blocks run pipelined or one by one -- with the last block of every run checked against
+    the oracle for a sample of channels of both banks."""
+    env = dict(os.environ, CHZ_LIB=emulated_engine, CHZ_ALLOW_EMULATED_ENGINE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "engine_fuzz_child.py"), str(seed), "200"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "FUZZ ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])

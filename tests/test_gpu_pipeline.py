@@ -703,3 +703,14 @@ def test_demodulators_random_parameter_sweep_on_the_device(pkg):
                         assert _cmp_pcm(p, pcm[i, :nb], want, 1e-4 if (p.env and p.dc_alpha) else 8e-6), (b, i)
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12])
+def test_engine_random_operations_on_the_device(seed):
+    """The model-based random walk of tests/engine_fuzz_child.py on the device (there the operations really are asynchronous: retunes
+    and response swaps land between blocks in flight)."""
+    env = dict(os.environ)
+    env.pop("CHZ_LIB", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "engine_fuzz_child.py"), str(seed), "300"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "FUZZ ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
