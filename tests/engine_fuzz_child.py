@@ -36,6 +36,21 @@ def main(seed, iters):
         b.set_responses(0, lib[P][m["which"]]); b.set_shifts(0, m["shift"]); b.set_active(cap)
         return m
     models = [fresh(0), fresh(1)]
+    # a third bank with fine tuning (the tail of downconvert(): rotator, block phase, shift-change kick) and a fourth whose channels
+    # SHARE three response rows; both follow every block
+    fs_in, fs_out = 1.296e6, 12000.0
+    nt = 8
+    tuned = eng.bank(300, 240, nt)
+    t_resp = lib[300][np.zeros(nt, int)]
+    tuned.set_responses(0, t_resp); tuned.set_active(nt)
+    t_f = 50e3 + rng.uniform(0, 500e3, nt); t_shift = np.zeros(nt, np.int32); t_rem = np.zeros(nt)
+    for ch in range(nt):
+        _, t_shift[ch], t_rem[ch] = ol.compute_tuning(N, fs_in, t_f[ch])
+    tuned.set_tuning(0, 0, t_shift, -t_rem / fs_out, np.zeros(nt))
+    dcs = [ol.Downconv(L, M, fs_out, "oracle") for _ in range(nt)]
+    shared = eng.bank(300, 240, 30, shared_rows=3)
+    s_rows = rng.integers(0, 3, 30).astype(np.int32); s_shift = rng.integers(-12000, 12000, 30).astype(np.int32)
+    shared.set_row_responses(0, lib[300][:3]); shared.set_rows(0, s_rows); shared.set_shifts(0, s_shift); shared.set_active(30)
     job = 0
     spec = None
     checks = 0
@@ -61,21 +76,43 @@ def main(seed, iters):
             idx = models.index(m)
             b.destroy()
             models[idx] = fresh(idx)
+        elif op < 74:                                       # a tuned channel moves (takes effect at the next block)
+            ch = int(rng.integers(0, nt))
+            t_f[ch] += rng.uniform(-3e3, 3e3)
+            _, t_shift[ch], t_rem[ch] = ol.compute_tuning(N, fs_in, t_f[ch])
+            tuned.set_tuning(job, ch, t_shift[ch:ch + 1], -t_rem[ch:ch + 1] / fs_out, np.zeros(1))
+        elif op < 78:                                       # a sharing channel names another row / moves
+            c0 = int(rng.integers(0, 30)); n = int(rng.integers(1, min(5, 30 - c0) + 1))
+            s_rows[c0:c0 + n] = rng.integers(0, 3, n); s_shift[c0:c0 + n] = rng.integers(-12000, 12000, n)
+            shared.set_rows(c0, s_rows[c0:c0 + n]); shared.set_shifts(c0, s_shift[c0:c0 + n])
         else:                                               # run: pipelined over the lanes, or block by block
             k = int(rng.integers(1, 7))
             xs = (rng.standard_normal(k * L) * 0.05).astype(np.float32)
-            if rng.integers(0, 2):
-                for j in range(k):
-                    eng.write(xs[j * L:(j + 1) * L]); eng.step(job + j)
-            else:
+            stepped = bool(rng.integers(0, 2))
+            if not stepped:
                 # the ring holds 8 blocks: write ahead, then run them in one go
                 for j in range(k):
                     eng.write(xs[j * L:(j + 1) * L])
                 eng.run_blocks(job, k)
             for j in range(k):
+                if stepped:
+                    eng.write(xs[j * L:(j + 1) * L]); eng.step(job + j)
                 spec = st.push(xs[j * L:(j + 1) * L], f64=True)
                 dc = spec[:1].astype(np.complex64); ol.notch(notch_state, [0], 0.01, dc); spec[0] = dc[0]
+                # the tuned bank's oscillators are a recurrence over blocks in the reference: the model follows every block; its
+                # outputs can be looked at block by block when stepping, and for the last block of a pipelined run
+                look = stepped or j == k - 1
+                got = tuned.read_slot((job + j) % 4) if look else None
+                for ch in range(nt):
+                    ideal = ol.channel(spec, ol.REAL, 300, 240, int(t_shift[ch]), t_resp[ch])
+                    ideal, _ = dcs[ch].block(ideal, t_shift[ch], t_rem[ch], 0.0)
+                    if look:
+                        check_channel(got[ch], ideal, noise_floor(spec, t_resp[ch])); checks += 1
             job += k
+            sh_out = shared.read_slot((job - 1) % 4)
+            for ch in rng.choice(30, size=5, replace=False):
+                want = ol.channel(spec, ol.REAL, 300, 240, int(s_shift[ch]), lib[300][s_rows[ch]])
+                check_channel(sh_out[ch], want, noise_floor(spec, lib[300][s_rows[ch]])); checks += 1
             last = (job - 1) % 4
             for mm in models:
                 out = mm["bank"].read_slot(last)
