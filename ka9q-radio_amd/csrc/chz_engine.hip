@@ -698,7 +698,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   if (n <= 0 || !b.resp) return 0;
   const int slot = (int)(job % CHZ_ND);
   hipStream_t st = e->lanes[lane_of(e, (unsigned)slot, in)].s;
-  b.last_slot = slot;
+  __atomic_store_n(&b.last_slot, slot, __ATOMIC_RELAXED);      // two issuing threads pass here; chz_run_blocks settles the final value
   { int r = refresh_slot(e, b, slot, st); if (r) return r; }
   // the demodulator of the block that used this slot last (4 blocks ago) still reads the output image
   if (b.tail_used[slot] && ch0 == 0 && !(in && in->on)) HIPOK(hipStreamWaitEvent(st, b.ev_tail[slot], 0));

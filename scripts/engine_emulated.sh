@@ -4,6 +4,9 @@
 cd "$(dirname "$0")/.." || exit 1
 python -m pytest tests/test_engine_emulated.py -q -k refuses || exit 1        # builds tests/hipemu/libchz_hip_emu.so
 LIBEMU=$PWD/tests/hipemu/libchz_hip_emu.so
+if [ "$TSAN" = 1 ]; then     # the engine's threading under ThreadSanitizer (tests/c/engine_driver.c; ~6 min)
+  CHZ_TEST_TSAN_ENGINE=1 python -m pytest tests/test_engine_emulated.py -q -k "thread_sanitizer"; exit $?
+fi
 if [ "$ASAN" = 1 ]; then     # the engine's host code AND the kernels under AddressSanitizer (61 tests clean in round 2; leave the long ones out with -k)
   g++ -std=c++17 -O1 -g -fPIC -shared -fsanitize=address -fno-omit-frame-pointer -DHIPEMU -DHIPEMU_HOST -I tests/hipemu -I ka9q-radio_amd/csrc \
       -x c++ ka9q-radio_amd/csrc/chz_engine.hip -o /tmp/libchz_hip_emu_asan.so -lpthread -ldl || exit 1

@@ -35,15 +35,25 @@ static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 
+// ThreadSanitizer has to be told about every stack switch (scripts/engine_emulated.sh TSAN=1 builds the engine's host code with it)
+#if defined(__SANITIZE_THREAD__)
+extern "C" { void* __tsan_get_current_fiber(void); void* __tsan_create_fiber(unsigned flags); void __tsan_destroy_fiber(void* fiber);
+             void __tsan_switch_to_fiber(void* fiber, unsigned flags); }
+#define HIPEMU_TSAN 1
+#else
+#define HIPEMU_TSAN 0
+#endif
 namespace hipemu {
 struct Fiber {
   ucontext_t ctx;
   char* stack = nullptr;
   bool done = false;
   uint3 tid{0, 0, 0};
+  void* tsan = nullptr;
 };
 struct State {
   ucontext_t sched;
+  void* sched_tsan = nullptr;
   std::vector<Fiber> fibers;
   int cur = -1;
   uint3 bid{0, 0, 0};
@@ -58,12 +68,18 @@ struct State {
   std::vector<size_t> wave_count; std::vector<unsigned> wave_gen;
 };
 inline State& st() { static State s; return s; }
-inline void yield() { State& s = st(); swapcontext(&s.fibers[s.cur].ctx, &s.sched); }
+inline void to_sched(State& s) {
+#if HIPEMU_TSAN
+  __tsan_switch_to_fiber(s.sched_tsan, 0);
+#endif
+  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+inline void yield() { to_sched(st()); }
 static void trampoline() {
   State& s = st();
   s.body();
   s.fibers[s.cur].done = true;
-  swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+  to_sched(s);
 }
 // Run one workgroup: fibers are resumed round-robin; each runs until it blocks in a counting
 // barrier (workgroup or wave) or finishes.  A kernel whose threads do not all reach a barrier
@@ -83,7 +99,14 @@ inline void run_block() {
     f.ctx.uc_stack.ss_size = STK;
     f.ctx.uc_link = &s.sched;
     makecontext(&f.ctx, (void (*)())trampoline, 0);
+#if HIPEMU_TSAN
+    if (f.tsan) __tsan_destroy_fiber(f.tsan);
+    f.tsan = __tsan_create_fiber(0);
+#endif
   }
+#if HIPEMU_TSAN
+  s.sched_tsan = __tsan_get_current_fiber();
+#endif
   s.slots.assign(n, 0);
   s.nthreads = n; s.bar_count = 0; s.bar_gen = 0;
   s.wave_count.assign((n + 63) / 64, 0); s.wave_gen.assign((n + 63) / 64, 0);
@@ -93,6 +116,9 @@ inline void run_block() {
     for (size_t i = 0; i < n; i++) {
       if (s.fibers[i].done) continue;
       s.cur = (int)i;
+#if HIPEMU_TSAN
+      __tsan_switch_to_fiber(s.fibers[i].tsan, 0);
+#endif
       swapcontext(&s.sched, &s.fibers[i].ctx);
       if (!s.fibers[i].done) alive = true;
     }

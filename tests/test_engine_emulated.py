@@ -81,3 +81,37 @@ def test_engine_random_operations(emulated_engine, seed):
     env = dict(os.environ, CHZ_LIB=emulated_engine, CHZ_ALLOW_EMULATED_ENGINE="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "engine_fuzz_child.py"), str(seed), "200"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "FUZZ ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
+
+
+def _build_driver(libpath, out, san=None):
+    cmd = ["gcc", "-O1", "-g", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "engine_driver.c"), "-o", out,
+           "-L", os.path.dirname(libpath), "-l:" + os.path.basename(libpath), "-Wl,-rpath," + os.path.dirname(libpath), "-lpthread"]
+    if san:
+        cmd.insert(1, "-fsanitize=" + san)
+    subprocess.run(cmd, check=True)
+
+
+def test_engine_threading_driver(emulated_engine, tmp_path):
+    """tests/c/engine_driver.c from plain C: blocks pipelined from several issuing threads, the notch and demodulator hand-overs, a tuned
+    bank with demodulators, retunes and response swaps between runs, inline masters executed from two threads -- must run to the end."""
+    exe = str(tmp_path / "driver")
+    _build_driver(emulated_engine, exe)
+    for thr in ("1", "2", "4"):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, CHZ_ENQ_THREADS=thr))
+        assert r.returncode == 0 and "driver ok blocks 32" in r.stdout, (thr, r.stdout[-300:], r.stderr[-1500:])
+
+
+@pytest.mark.skipif(os.environ.get("CHZ_TEST_TSAN_ENGINE") != "1", reason="~6 min: set CHZ_TEST_TSAN_ENGINE=1 (TSAN=1 scripts/engine_emulated.sh does)")
+def test_engine_threading_driver_under_thread_sanitizer(tmp_path):
+    """The same driver with the ENGINE's host code (and the emulated kernels, whose fibers are announced to the race detector) built with
+    -fsanitize=thread: 2 and 4 issuing threads.  Clean in round 2 after one finding (Bank::last_slot written by two issuing threads)."""
+    lib = str(tmp_path / "libchz_hip_emu_tsan.so")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-fsanitize=thread", "-DHIPEMU", "-DHIPEMU_HOST", "-I", EMU, "-I", CSRC, "-x", "c++",
+                    os.path.join(CSRC, "chz_engine.hip"), "-o", lib, "-lpthread", "-ldl"], check=True)
+    exe = str(tmp_path / "driver_tsan")
+    _build_driver(lib, exe, "thread")
+    for thr in ("2", "4"):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=1500,
+                           env=dict(os.environ, CHZ_ENQ_THREADS=thr, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=66"))
+        assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-5000:]
+        assert r.returncode == 0 and "driver ok blocks 32" in r.stdout, (thr, r.stdout[-300:], r.stderr[-1500:])
