@@ -22,7 +22,8 @@ LIB = os.path.join(EMU, "libchz_hip_emu.so")
 # what cannot run there: sizes that take minutes on the emulator, hipGraph capture, RCCL, tests that talk to libamdhip64 themselves or
 # wait on the device-side ticket, and the two long demodulator scenarios (run by scripts/engine_emulated.sh)
 SKIP = ("full_size or config3 or config2 or 2592000 or 1296000 or soak or rccl or comm_rendezvous or graph or runs_out or config4 or "
-        "noise_and_conversion or beyond_the_lds or 400000 or 2600000 or 2500000 or coherent_modes or linear_demodulator_on_the_device")
+        "noise_and_conversion or beyond_the_lds or 400000 or 2600000 or 2500000 or coherent_modes or linear_demodulator_on_the_device or "
+        "random_operations_on_the_device")
 
 
 @pytest.fixture(scope="module")
