@@ -162,7 +162,7 @@ def test_dropin_complex_master_under_sanitizers(tmp_path, san):
 
 
 @pytest.mark.parametrize("san", ["thread", "address"])
-@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("seed", [1])
 def test_dropin_random_traffic_under_sanitizers(tmp_path, san, seed):
     """tests/c/dropin_fuzz.c: 24 threads doing at random what radiod's channel threads do to their slaves -- create (three output
     types, four sizes), set_filter, execute with old and new shifts, flip isb, delete and re-create, fall behind -- against a master

@@ -74,7 +74,7 @@ def test_dropin_on_the_emulated_engine(emulated_engine, tmp_path):
     assert m and int(m.group(1)) >= 6, tail
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2])
 def test_engine_random_operations(emulated_engine, seed):
     """tests/engine_fuzz_child.py: a model-based random walk over the engine's C ABI -- retunes, response swaps, ISB flags, active
     counts, banks destroyed and re-created, blocks run pipelined or one by one -- with the last block of every run checked against
