@@ -80,7 +80,7 @@ def test_engine_random_operations(emulated_engine, seed):
     counts, banks destroyed and re-created, blocks run pipelined or one by one -- with the last block of every run checked against
     the oracle for a sample of channels of both banks."""
     env = dict(os.environ, CHZ_LIB=emulated_engine, CHZ_ALLOW_EMULATED_ENGINE="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "engine_fuzz_child.py"), str(seed), "200"], capture_output=True, text=True, env=env, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "engine_fuzz_child.py"), str(seed), "100"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "FUZZ ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
 
 
