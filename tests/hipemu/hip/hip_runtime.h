@@ -66,6 +66,7 @@ struct State {
   size_t nthreads = 0;
   size_t bar_count = 0; unsigned bar_gen = 0;
   std::vector<size_t> wave_count; std::vector<unsigned> wave_gen;
+  ~State() { for (Fiber& f : fibers) free(f.stack); }     // the stack pool lives as long as the process; keeps LeakSanitizer quiet
 };
 inline State& st() { static State s; return s; }
 inline void to_sched(State& s) {
