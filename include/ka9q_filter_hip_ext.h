@@ -1,0 +1,28 @@
+/* ka9q_filter_hip_ext.h -- what libka9q_filter_hip.so offers BEYOND ka9q-radio's filter.h (optional; a caller that only
+ * knows filter.h never needs it).
+ *
+ * estimate_noise() (/root/reference/src/radio.c:1783-1866) reads master->fdomain[] on the host for every channel and
+ * block; it is the only reader of the block spectrum outside filter.c, and the reason the drop-in copies 13 MB per
+ * block back over PCIe by default (KA9Q_HIP_FDOMAIN=1).  The device runs the same function (kernel noise_est, pinned to
+ * radio.c's own code to 1e-12): a radiod built with the three-line patch of INTEGRATION.md section 1 takes the estimate
+ * from filter_hip_noise() and sets KA9Q_HIP_FDOMAIN=0.
+ */
+#ifndef KA9Q_FILTER_HIP_EXT_H
+#define KA9Q_FILTER_HIP_EXT_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+struct filter_in;
+struct filter_out;
+/* switch the device-side noise estimate on for every channel of `master` (samprate = Frontend.samprate, Hz; 0 = off).
+   Returns 0, 1 if some channel sizes have no noise kernel (their slaves report NaN), -1 on bad arguments.
+   Env KA9Q_HIP_NOISE_SAMPRATE=<Hz> does the same at create_filter_input time. */
+int filter_hip_enable_noise(struct filter_in *master, double samprate);
+/* N0 of the block the slave's last execute_filter_output() delivered (NaN: not available) */
+double filter_hip_noise(struct filter_out const *slave);
+/* blocks skipped by the front end because the device was ND blocks behind (only with KA9Q_HIP_INPUT_FULL=drop) */
+unsigned long filter_hip_skipped_blocks(struct filter_in const *master);
+#ifdef __cplusplus
+}
+#endif
+#endif

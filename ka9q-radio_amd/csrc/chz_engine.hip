@@ -3,9 +3,11 @@
 // Owns the HBM-resident state of one master (input ring, intermediate buffers,
 // ND spectrum slots, twiddle tables) and of its channel banks, and launches the
 // kernels of chz_kernels.h.  Blocks are pipelined over 1/2/4 HIP streams ("lanes");
-// everything per block is enqueued asynchronously.  Nothing in here makes a kernel
-// wait for another kernel from inside the device: the one cross-block dependency of
-// the path (the spur-notch recurrence) is carried by HIP events between the lanes.
+// everything per block is enqueued asynchronously.  The one cross-block dependency of
+// the path (the spur-notch recurrence) is ordered on the device: each block's notch_fix
+// kernel takes a ticket in block order and waits -- bounded in time, failing loudly -- for
+// its predecessor's (enqueue_notch below); CHZ_NOTCH_ORDER=event carries it by HIP events
+// between the lanes instead.  No other kernel ever waits for another kernel.
 // Retunes never drain the pipeline: the small per-channel descriptors exist once per
 // spectrum slot and are refreshed in stream order, responses are swapped by row.
 // gfx950 only, no fallback.
@@ -194,6 +196,9 @@ struct chz_engine {
   NotchTables notch_tab; std::vector<double> notch_alpha_h;
   std::vector<Bank> banks;
   hipGraphExec_t graph = nullptr; unsigned graph_job0 = 0; int graph_blocks = 0;
+  int capture_blocks = 0;           // blocks of the capture in progress (the last one moves the ticket base on)
+  bool graph_notch_event = false;   // env CHZ_GRAPH_NOTCH=event: order the notches of captured blocks by HIP events (round 2's way)
+  int graph_min_blocks = 32;        // env CHZ_GRAPH_BLOCKS: a replay covers at least this many blocks (drained once per replay)
   // chz_run_blocks: events and issuing threads live as long as the engine
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_fork = nullptr, ev_join[CHZ_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<Issuer*> issuers;
@@ -293,6 +298,8 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
     if (const char* w = getenv("CHZ_NOTCH_WAIT_MS")) { const double v = atof(w); if (v > 0) ms = v; }
     e->notch_max_wait = (long long)(ms * (double)khz);
   }
+  if (const char* gn = getenv("CHZ_GRAPH_NOTCH")) e->graph_notch_event = strcmp(gn, "event") == 0;
+  if (const char* gb = getenv("CHZ_GRAPH_BLOCKS")) { const int v = atoi(gb); if (v > 0 && v <= 4096) e->graph_min_blocks = v; }
   if (const char* no = getenv("CHZ_NOTCH_ORDER")) e->notch_order = strcmp(no, "event") == 0 ? 1 : (strcmp(no, "unordered-timing-only") == 0 ? 2 : 0);
   HIPOK(hipHostMalloc((void**)&e->notch_err, sizeof(unsigned), hipHostMallocMapped));
   *e->notch_err = 0;
@@ -538,7 +545,9 @@ static int enqueue_notch(chz_engine* e, int slot, hipStream_t st, Instr* in, Not
     }
   }
   int rc = 0;
-  const bool by_event = e->notch_order == 1 || capturing;      // a captured launch cannot carry a running ticket number
+  // inside a capture the ticket is relative to a device word (one captured node serves every replay); CHZ_GRAPH_NOTCH=event
+  // keeps round 2's event chain inside graphs
+  const bool by_event = e->notch_order == 1 || (capturing && e->graph_notch_event);
   do {
     if (by_event && e->notch_have && !capture_first && e->nlanes > 1) {
       hipError_t he = hipStreamWaitEvent(st, e->notch_ev[(e->notch_seq - 1u) % CHZ_NOTCH_EVENTS], 0);
@@ -549,10 +558,15 @@ static int enqueue_notch(chz_engine* e, int slot, hipStream_t st, Instr* in, Not
     q.alpha = e->notch_alpha; q.state = e->notch_state; q.n = e->n_notch;
     e->notch_tab.fill_inline(q, e->notch_alpha_h.data());
     q.err = e->notch_err; q.max_wait = e->notch_max_wait;
-    if (!by_event && e->nlanes > 1 && e->notch_order != 2) { q.ver = e->notch_ver; q.seq = e->notch_tickets++; }   // 2: A/B timing of the bare kernel, WRONG results
+    const bool ticket = !by_event && e->nlanes > 1 && e->notch_order != 2;      // 2: A/B timing of the bare kernel, WRONG results
+    if (ticket && capturing) {
+      q.ver = e->notch_ver; q.seq_base = e->notch_ver + 2; q.seq = (unsigned)seq;
+      q.adv = seq == e->capture_blocks - 1 ? (unsigned)e->capture_blocks : 0u;
+    } else if (ticket) { q.ver = e->notch_ver; q.seq = e->notch_tickets; }
     mark(in, st, 5, true);
     if (launch_notch_fix(st, q, IN_E0(in), IN_E1(in))) { rc = fail(-4, "notch list too long"); break; }
     mark(in, st, 5, false);
+    if (ticket && !capturing) e->notch_tickets++;               // taken only by a launch that went out
     if (by_event && e->nlanes > 1) {
       hipError_t he = hipEventRecord(e->notch_ev[e->notch_seq % CHZ_NOTCH_EVENTS], st);
       if (he != hipSuccess) { rc = fail(-10, "hipEventRecord failed: %s", hipGetErrorString(he)); break; }
@@ -700,8 +714,11 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   hipStream_t st = e->lanes[lane_of(e, (unsigned)slot, in)].s;
   __atomic_store_n(&b.last_slot, slot, __ATOMIC_RELAXED);      // two issuing threads pass here; chz_run_blocks settles the final value
   { int r = refresh_slot(e, b, slot, st); if (r) return r; }
+  // Only a launch over the WHOLE bank is "the block": a partial re-run (the drop-in's miss path re-runs single channels of a
+  // block that has already been demodulated) must neither step anybody's AGC / squelch / PLL a second time nor overwrite PCM.
+  const bool whole_bank = ch0 == 0 && n == b.active;
   // the demodulator of the block that used this slot last (4 blocks ago) still reads the output image
-  if (b.tail_used[slot] && ch0 == 0 && !(in && in->on)) HIPOK(hipStreamWaitEvent(st, b.ev_tail[slot], 0));
+  if (b.tail_used[slot] && !(in && in->on)) HIPOK(hipStreamWaitEvent(st, b.ev_tail[slot], 0));
   const size_t so = (size_t)slot * b.cap;
   ChanParams c{};
   if (!chan_layout(c, SpecLayout{e->plan.Na, e->plan.spec_pitch, e->plan.spec_off}, e->bins)) return fail(-4, "spectrum layout beyond the reach of the index reciprocal");
@@ -732,7 +749,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   }
   // the linear demodulators of this bank, in block order on the demodulator stream.  Only whole-bank
   // launches feed them (a single-channel re-run of the drop-in's miss path does not advance anybody's AGC).
-  if (b.dm_on > 0 && b.dm_auto && ch0 == 0) {
+  if (b.dm_on > 0 && b.dm_auto && whole_bank) {
     hipStream_t ts = (in && in->on) ? st : e->tail;
     if (ts != st) {
       HIPOK(hipEventRecord(b.ev_bank[slot], st));
@@ -743,7 +760,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
     d.status = b.dm_status + so; d.flags = b.dm_flags + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = n; d.olen = b.olen;
     d.pcm_stride = b.pcm_stride; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;      // Power_alpha, src/radio.c:72
     mark(in, ts, 6, true);
-    launch_demod(ts, d, IN_E0(in), IN_E1(in));
+    if (launch_demod(ts, d, IN_E0(in), IN_E1(in))) return fail(-4, "the demodulator kernel refuses blocks of %d samples", b.olen);
     mark(in, ts, 6, false);
     if (ts != st) { HIPOK(hipEventRecord(b.ev_tail[slot], ts)); b.tail_used[slot] = true; }
   }
@@ -766,6 +783,7 @@ int chz_set_notches_alpha(chz_engine* e, const int* bins, const double* alpha, i
   drop_graph(e);
   free_notches(e);
   if (n <= 0 || !bins || !alpha) return 0;
+  if (n > 1024) return fail(-1, "at most 1024 notch entries (got %d): the list is applied by one workgroup", n);
   for (int i = 0; i < n; i++)
     if (bins[i] < 0 || bins[i] >= e->bins) return fail(-1, "notch bin %d out of range", bins[i]);
   NotchTables t = notch_tables(bins, n, SpecLayout{e->plan.Na, e->plan.spec_pitch, e->plan.spec_off});
@@ -777,8 +795,8 @@ int chz_set_notches_alpha(chz_engine* e, const int* bins, const double* alpha, i
   HIPOK(hipMemcpy(e->notch_head, t.head.data(), ib, hipMemcpyHostToDevice));
   HIPOK(hipMemcpy(e->notch_alpha, alpha, db, hipMemcpyHostToDevice));
   HIPOK(hipMemset(e->notch_state, 0, 2 * db));
-  HIPOK(hipMalloc((void**)&e->notch_ver, 2 * sizeof(unsigned)));      // ticket counter + tombstone
-  HIPOK(hipMemset(e->notch_ver, 0, 2 * sizeof(unsigned)));
+  HIPOK(hipMalloc((void**)&e->notch_ver, 4 * sizeof(unsigned)));      // ticket counter, tombstone, base of captured tickets, spare
+  HIPOK(hipMemset(e->notch_ver, 0, 4 * sizeof(unsigned)));
   HIPOK(hipDeviceSynchronize());
   e->notch_tab = t; e->notch_alpha_h.assign(alpha, alpha + n);
   e->notch_tickets = 0;
@@ -1124,6 +1142,7 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
   if (b.out_real) return fail(-1, "the linear demodulator follows COMPLEX-output channels");
   if (!b.power || !b.n0 || b.noise_samprate <= 0.0)
     return fail(-1, "the demodulator needs the channel's bb_power and noise estimate: call chz_bank_set_tuning and chz_bank_enable_noise first");
+  if (b.olen > 10240) return fail(-3, "the demodulator kernel keeps a block in LDS: at most 10240 samples per block (bank has %d)", b.olen);
   if (!b.pcm_stride) b.pcm_stride = b.olen * 8;
   bool need_ext = false;
   for (int i = 0; i < n; i++) {
@@ -1265,7 +1284,7 @@ int chz_bank_demod(chz_engine* e, int bank, unsigned job, int slot) {
   d.in = bank_out(b, slot); d.power = b.power + so; d.n0 = b.n0 + so; d.chan = b.dm_chan; d.state = b.dm_state; d.ext = b.dm_ext;
   d.status = b.dm_status + so; d.flags = b.dm_flags + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = b.active; d.olen = b.olen;
   d.pcm_stride = b.pcm_stride; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;
-  launch_demod(e->tail, d);
+  if (launch_demod(e->tail, d)) return fail(-4, "the demodulator kernel refuses blocks of %d samples", b.olen);
   HIPOK(hipGetLastError());
   return 0;
 }
@@ -1460,19 +1479,24 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
   int done = 0, rc = 0;
   const auto host_t0 = std::chrono::steady_clock::now();
   if (mode == 1) {
-    // one graph = one ring cycle of blocks (a multiple of ND so slots and lanes line up too)
-    int cycle = e->ring_blocks;
-    while (cycle % CHZ_ND) cycle += e->ring_blocks;
-    const unsigned phase = job0 % (unsigned)cycle;
+    // one graph = whole ring cycles of blocks (a multiple of ND so slots and lanes line up too), at least graph_min_blocks
+    // of them: a replay is one stream-ordered unit, so the pipeline drains once per replay
+    int unit = e->ring_blocks;
+    while (unit % CHZ_ND) unit += e->ring_blocks;
+    int cycle = unit;
+    while (cycle < e->graph_min_blocks && cycle + unit <= nblocks) cycle += unit;
+    const unsigned phase = job0 % (unsigned)unit;
     if (!e->graph || e->graph_blocks != cycle || e->graph_job0 != phase) {
       drop_graph(e);
       for (Bank& b : e->banks) { int r = refresh_all_bulk(e, b); if (r) return r; }   // no descriptor copies inside the capture
       hipGraph_t g = nullptr;
+      e->capture_blocks = cycle;
       HIPOK(hipStreamBeginCapture(s0, hipStreamCaptureModeThreadLocal));
       rc = lanes_fork(e, fork_ev);
-      for (int i = 0; i < cycle && !rc; i++) rc = enqueue_step(e, phase + (unsigned)i, nullptr, nullptr, 0, i == 0, true);
+      for (int i = 0; i < cycle && !rc; i++) rc = enqueue_step(e, phase + (unsigned)i, nullptr, nullptr, i, i == 0, true);
       if (!rc) rc = lanes_join(e, join_ev);
       hipError_t ce = hipStreamEndCapture(s0, &g);
+      e->capture_blocks = 0;
       e->notch_have = false;                      // events recorded inside a capture are not waitable outside it
       if (rc) { if (g) hipGraphDestroy(g); return rc; }
       if (ce != hipSuccess) return fail(-10, "graph capture failed: %s", hipGetErrorString(ce));
@@ -1481,8 +1505,14 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
       e->graph_blocks = cycle; e->graph_job0 = phase;
     }
     for (Bank& b : e->banks) { int r = refresh_all_bulk(e, b); if (r) return r; }
+    const bool graph_ticket = e->n_notch > 0 && e->nlanes > 1 && e->notch_order == 0 && !e->graph_notch_event;
+    if (graph_ticket)            // captured tickets count from here (the device is idle: sync_all above)
+      HIPOK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(e->notch_ver + 2), (int)e->notch_tickets, 1, s0));
     HIPOK(hipEventRecord(t0, s0));
-    while (nblocks - done >= cycle) { HIPOK(hipGraphLaunch(e->graph, s0)); done += cycle; }
+    while (nblocks - done >= cycle) {
+      HIPOK(hipGraphLaunch(e->graph, s0)); done += cycle;
+      if (graph_ticket) e->notch_tickets += (unsigned)cycle;
+    }
     if (done < nblocks) {
       if ((rc = lanes_fork(e, fork_ev))) return rc;
       for (; done < nblocks; done++) if ((rc = enqueue_step(e, job0 + (unsigned)done, nullptr))) return rc;

@@ -593,8 +593,10 @@ struct NotchFixParams {
   double* state;          // [n][2] persists across blocks
   int n;
   int inl;                // 1: the list is in the i_* arrays below
-  unsigned* ver;          // [2] ticket counter, tombstone; or nullptr
-  unsigned seq;           // this block's ticket
+  unsigned* ver;          // [4] ticket counter, tombstone, graph base, spare; or nullptr
+  unsigned seq;           // this block's ticket (relative to *seq_base when that is set)
+  unsigned* seq_base;     // captured launches: the ticket is *seq_base + seq, so one captured kernel node serves every replay
+  unsigned adv;           // != 0: this is the last block of the captured sequence; it moves *seq_base on to its own ticket + 1
   unsigned* err;          // host-visible error word (0 = fine)
   long long max_wait;     // ticket wait budget in ticks of the constant-rate counter (hipDeviceAttributeWallClockRate)
   int i_addr[CHZ_NOTCH_INLINE];
@@ -610,6 +612,7 @@ __global__ void __launch_bounds__(1024) notch_fix(NotchFixParams p) {
     else { mine = p.head[i] != 0; a = p.addr[i]; }
   }
   float2 x = mine ? p.spec[a] : make_float2(0.f, 0.f);
+  unsigned seq = p.seq; (void)seq;
 #if defined(__HIP_DEVICE_COMPILE__)
   if (p.ver != nullptr) {
     // poll with relaxed loads (they bypass the non-coherent caches); ONE acquire fence once the ticket is up, so the
@@ -619,18 +622,22 @@ __global__ void __launch_bounds__(1024) notch_fix(NotchFixParams p) {
     // p.ver[1] is the chain's tombstone: once one wait has run out nobody behind it waits again (they would each sit out the
     // whole budget: the counter never moves on after a failure)
     if (__hip_atomic_load(p.ver + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    // A captured launch cannot carry a running number in its arguments: its ticket is relative to a base word that the
+    // last block of each replay moves on.  Every other block of the replay has read the base before the last one's
+    // turn comes (their turns precede it), and the next replay starts after this one has finished (stream order).
+    if (p.seq_base != nullptr) seq += __hip_atomic_load(p.seq_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned v = 0;
     const long long t0 = wall_clock64();
     for (;;) {
       v = __hip_atomic_load(p.ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (v == p.seq || wall_clock64() - t0 > p.max_wait) break;
+      if (v == seq || wall_clock64() - t0 > p.max_wait) break;
       __builtin_amdgcn_s_sleep(8);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (v != p.seq) {                                   // never publish a wrong recurrence
+    if (v != seq) {                                     // never publish a wrong recurrence
       if (i == 0) {
         __hip_atomic_store(p.ver + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p.err, p.seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(p.err, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
       return;
     }
@@ -651,7 +658,10 @@ __global__ void __launch_bounds__(1024) notch_fix(NotchFixParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (p.ver != nullptr) {
     __syncthreads();                                     // every lane's state and bin writes precede the release
-    if (i == 0) __hip_atomic_store(p.ver, p.seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (i == 0) {
+      if (p.adv != 0u) __hip_atomic_store(p.seq_base, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the last block's ticket + 1 = base + blocks per replay
+      __hip_atomic_store(p.ver, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 #endif
 }

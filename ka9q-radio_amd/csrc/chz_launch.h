@@ -65,6 +65,14 @@ inline int launch_chan_real(Radix2 r, int grid, int block, size_t lds, hipStream
 #undef X
   return -1;
 }
+// a kernel that wants more than the default 64 KB of dynamic LDS has to say so once (up to the CU's 160 KB)
+inline int big_lds_prepare(const void* kern) {
+#if defined(__HIPCC__) && !defined(HIPEMU)
+  return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
+#else
+  (void)kern; return 0;
+#endif
+}
 // any P (prime factors up to 13) without a register-tiled kernel: one workgroup per channel (chan_any); needs the large-LDS attribute once
 inline int chan_any_prepare() {
 #if defined(__HIPCC__) && !defined(HIPEMU)
@@ -117,7 +125,14 @@ inline NotchTables notch_tables(const int* bins, int n, const SpecLayout& lay) {
 }
 inline int launch_demod(hipStream_t s, const DemodParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   if (p.nch <= 0) return 0;
-  CHZ_LAUNCH(demod_linear_tail, p.nch, 64, 16 * (size_t)p.olen, s, e0, e1, p);     // one wavefront per channel; LDS: N doubles + N complex
+  const size_t lds = 16 * (size_t)p.olen;                                          // one wavefront per channel; LDS: N doubles + N complex
+  if (lds > 160 * 1024) return -1;                                                 // blocks of more than 10240 samples do not fit a CU
+  if (lds > 64 * 1024) {
+    static int big = -1;
+    if (big < 0) big = big_lds_prepare(reinterpret_cast<const void*>(demod_linear_tail)) == 0 ? 1 : 0;
+    if (big != 1) return -1;
+  }
+  CHZ_LAUNCH(demod_linear_tail, p.nch, 64, lds, s, e0, e1, p);
   return 0;
 }
 // host side of the coherent modes and the PL-tone squelch: what init_pll() (src/osc.c:130-136, called once when the demodulator

@@ -69,6 +69,8 @@ struct hbank {
   unsigned char *stage_isb[ND];     /* [cap] slave->isb flag it was computed with */
   unsigned stage_job[ND];
   int stage_n[ND];
+  double *stage_n0[ND];             /* pinned [cap]: the device's estimate_noise() per channel (filter_hip_enable_noise), or NULL */
+  bool noise_on;                    /* the device runs noise_est behind this bank's channel kernel */
 };
 
 struct done_note { struct mctx *ctx; unsigned job; struct timespec t0; };
@@ -92,6 +94,21 @@ struct mctx {
   int notch_bins[64];
   double notch_alpha[64];
   struct done_note note[ND];        /* one per job slot; execute_filter_input never has more than ND blocks in flight */
+  /* KA9Q_HIP_INPUT_FULL=drop: the reference's producer never waits (src/filter.c:639-649 only queues a job); with ND blocks
+     still in flight on the device this block is then NOT transformed -- its samples still travel so the overlap history stays
+     whole -- and every slave gets zeros and a counted drop for it (src/filter.c:690-701), instead of the front-end thread
+     (a USB callback, say) standing still.  Default: wait (no sample is ever lost to a momentary stall). */
+  bool drop_when_full;
+  uint64_t skipped[ND];             /* (1 << 32) | job of the last block skipped in this slot */
+  unsigned long n_skipped;
+  double noise_samprate;            /* > 0: banks run the device's estimate_noise() (filter_hip_enable_noise) */
+  /* wake-up of the channel threads: the completion callback wakes wake_first of them (0 = all), every woken thread wakes
+     wake_fan more (KA9Q_HIP_WAKE="first,fan"; default "0,2") */
+  int wake_first, wake_fan;
+  /* KA9Q_HIP_PROFILE=1: where a block's host time goes, printed by delete_filter_input */
+  bool profile;
+  struct timespec t_done[ND];       /* when the slot's completion callback ran */
+  unsigned long long prof_blocks, prof_input_ns, prof_wait_ns, prof_consume_sum_ns, prof_consume_n, prof_consume_max_ns, prof_hits, prof_misses;
   /* channels whose staged result does not fit (retuned, new filter, just created) are re-run in batches: the first
      thread to miss becomes the leader and serves everybody who queued up meanwhile with one device round trip */
   pthread_mutex_t miss_lock;
@@ -113,6 +130,7 @@ struct sctx {
   int bank;                         /* index into mctx.banks */
   int idx;                          /* channel index inside the bank */
   unsigned epoch;                   /* bumped whenever the response changes */
+  double n0;                        /* the device's noise estimate of the block this slave consumed last (NaN: none) */
 };
 
 struct hbank;
@@ -245,12 +263,18 @@ static void block_done(void *arg) {
   struct timespec const t0 = n->t0;
   struct timespec t1;
   clock_gettime(CLOCK_MONOTONIC, &t1);
+  struct mctx *const c = n->ctx;
+  if (c->profile) c->t_done[job % ND] = t1;
   pthread_mutex_lock(&f->filter_mutex);
   __atomic_store_n(&f->owner, pthread_self(), __ATOMIC_RELEASE);      /* read without the mutex by execute_filter_output */
-  __atomic_store_n(&f->completed_jobs[job % ND], job, __ATOMIC_RELEASE);   /* src/filter.c:526-529 */
+  /* (a block skipped in drop mode may have published a LATER job in this slot already: never step back) */
+  unsigned const cur = __atomic_load_n(&f->completed_jobs[job % ND], __ATOMIC_RELAXED);
+  if (cur == UINT_MAX || (int)(job - cur) > 0)
+    __atomic_store_n(&f->completed_jobs[job % ND], job, __ATOMIC_RELEASE);   /* src/filter.c:526-529 */
   pthread_cond_broadcast(&f->filter_cond);              /* src/filter.c:532-535 (kept; nobody in this build waits on it) */
   pthread_mutex_unlock(&f->filter_mutex);
-  futex_wake_all(&f->completed_jobs[job % ND]);
+  if (c->wake_first > 0) futex_wake_n(&f->completed_jobs[job % ND], c->wake_first);
+  else futex_wake_all(&f->completed_jobs[job % ND]);
   int64_t ns = (t1.tv_nsec - t0.tv_nsec) + 1000000000LL * (t1.tv_sec - t0.tv_sec);
   if (ns > Max_fft_time) Max_fft_time = ns;             /* src/filter.c:544-552 */
   if (ns < Min_fft_time) Min_fft_time = ns;
@@ -263,9 +287,9 @@ static void block_done(void *arg) {
 /* banks                                                                        */
 /* ------------------------------------------------------------------------- */
 static size_t bank_sample_bytes(const struct hbank *b) { return b->real ? sizeof(float) : sizeof(float complex); }
-static int bank_create_dev(struct mctx *c, const struct hbank *b, int cap);
+static int bank_create_dev(struct mctx *c, struct hbank *b, int cap);
 static void bank_free_host(struct hbank *b) {
-  for (int s = 0; s < ND; s++) { chz_host_free(b->stage[s]); b->stage[s] = NULL; FREE(b->stage_shift[s]); FREE(b->stage_epoch[s]); FREE(b->stage_isb[s]); }
+  for (int s = 0; s < ND; s++) { chz_host_free(b->stage[s]); b->stage[s] = NULL; chz_host_free(b->stage_n0[s]); b->stage_n0[s] = NULL; FREE(b->stage_shift[s]); FREE(b->stage_epoch[s]); FREE(b->stage_isb[s]); }
   FREE(b->slaves); FREE(b->shift); FREE(b->isb); FREE(b->beam_ab); FREE(b->beam_on);
 }
 static int bank_alloc_host(struct hbank *b, int cap) {
@@ -284,12 +308,19 @@ static int bank_alloc_host(struct hbank *b, int cap) {
     b->stage_epoch[s] = calloc((size_t)cap, sizeof(unsigned));
     b->stage_isb[s] = calloc((size_t)cap, 1);
     if (!b->stage_shift[s] || !b->stage_epoch[s] || !b->stage_isb[s]) return -1;
+    if (chz_host_alloc(&p, sizeof(double) * (size_t)cap) != 0) return -1;
+    b->stage_n0[s] = p;
+    for (int k = 0; k < cap; k++) b->stage_n0[s][k] = NAN;
     b->stage_job[s] = UINT_MAX; b->stage_n[s] = 0;
   }
   return 0;
 }
-static int bank_create_dev(struct mctx *c, const struct hbank *b, int cap) {
-  return b->real ? chz_bank_create_real(c->eng, b->P, b->olen, cap) : chz_bank_create(c->eng, b->P, b->olen, cap);
+static int bank_create_dev(struct mctx *c, struct hbank *b, int cap) {
+  int const id = b->real ? chz_bank_create_real(c->eng, b->P, b->olen, cap) : chz_bank_create(c->eng, b->P, b->olen, cap);
+  b->noise_on = false;
+  /* estimate_noise() on the device (filter_hip_enable_noise): sizes the noise kernel is not compiled for keep NaN */
+  if (id >= 0 && c->noise_samprate > 0) b->noise_on = chz_bank_enable_noise(c->eng, id, c->noise_samprate) == 0;
+  return id;
 }
 /* find (or create, or grow) the bank for (P, olen, output type); caller holds ctx->lock */
 static int bank_for(struct mctx *c, int P, int olen, bool real) {
@@ -379,6 +410,11 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   /* master->fdomain[] is read by radiod's estimate_noise() (src/radio.c:1801) and by nothing else outside filter.c;
      a host that takes the noise estimate from the device (chz_bank_enable_noise) can switch the 13 MB per-block copy off */
   { const char *fd = getenv("KA9Q_HIP_FDOMAIN"); c->host_spectrum = !(fd && fd[0] == '0'); }
+  { const char *fu = getenv("KA9Q_HIP_INPUT_FULL"); c->drop_when_full = fu && strcmp(fu, "drop") == 0; }
+  c->wake_first = 0; c->wake_fan = 2;
+  { const char *wk = getenv("KA9Q_HIP_WAKE"); int a = 0, b = 2; if (wk && sscanf(wk, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0) { c->wake_first = a; c->wake_fan = b; } }
+  { const char *pf = getenv("KA9Q_HIP_PROFILE"); c->profile = pf && pf[0] == '1'; }
+  { const char *ns = getenv("KA9Q_HIP_NOISE_SAMPRATE"); if (ns && atof(ns) > 0) c->noise_samprate = atof(ns); }
   pthread_mutex_init(&c->lock, NULL);
   for (int i = 0; i < STAGE_SHARDS; i++) pthread_rwlock_init(&c->stage_lock[i].l, NULL);
   pthread_mutex_init(&c->miss_lock, NULL);
@@ -446,6 +482,12 @@ int delete_filter_input(struct filter_in *master) {
   if (master->fwd_plan) {
     struct mctx *c = MCTX(master);
     chz_sync(c->eng);
+    if (c->profile && c->prof_blocks)
+      fprintf(stderr, "filter_hip profile: blocks %llu  execute_filter_input %.1f us/block (of which waiting for the device %.1f us)  "
+              "callback -> slave has its block: mean %.1f us, worst %.1f us over %llu reads  staged hits %llu misses %llu  skipped blocks %lu\n",
+              c->prof_blocks, c->prof_input_ns / 1e3 / c->prof_blocks, c->prof_wait_ns / 1e3 / c->prof_blocks,
+              c->prof_consume_n ? c->prof_consume_sum_ns / 1e3 / c->prof_consume_n : 0.0, c->prof_consume_max_ns / 1e3, c->prof_consume_n,
+              c->prof_hits, c->prof_misses, c->n_skipped);
     if (c->ring_pinned) chz_host_unregister(master->input_buffer);
     chz_engine_destroy(c->eng);
     mctx_free(c);
@@ -512,7 +554,7 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
       return -1;
     }
     struct hbank *b = &c->banks[bi];
-    sc->bank = bi; sc->idx = b->n; sc->epoch = 1;
+    sc->bank = bi; sc->idx = b->n; sc->epoch = 1; sc->n0 = NAN;
     b->slaves[b->n] = slave; b->shift[b->n] = 0;
     for (int s = 0; s < ND; s++) b->stage_epoch[s][b->n] = 0;
     b->n++;
@@ -583,8 +625,11 @@ int execute_filter_input(struct filter_in *const f) {
   struct mctx *c = MCTX(f);
   /* Everything below is asynchronous, so the producer must not run more than ND blocks ahead of the device: block
      job-ND owns this job's completion record, spectrum slot, staged outputs and host-ring window until its callback has
-     published it.  (The reference's worker queue throttles the producer the same way only through the ring; a lapped
-     SLAVE still drops a block with zeros, src/filter.c:690-701 -- that logic is unchanged.) */
+     published it.  Default: wait for it.  KA9Q_HIP_INPUT_FULL=drop: do not wait -- this block is skipped (below), which is
+     what a producer that only queues jobs amounts to once the slots have been lapped (src/filter.c:639-649,690-701). */
+  struct timespec tp0 = {0, 0}, tp1 = {0, 0};
+  if (c->profile) clock_gettime(CLOCK_MONOTONIC, &tp0);
+  bool skip = false;
   {
     unsigned const next = f->next_jobnum;
     if (next >= ND) {
@@ -593,16 +638,42 @@ int execute_filter_input(struct filter_in *const f) {
       for (;;) {
         unsigned done = __atomic_load_n(word, __ATOMIC_ACQUIRE);
         if (done != UINT_MAX && (int)(need - done) <= 0) break;
+        if (c->drop_when_full) { skip = true; break; }
         futex_wait_u32(word, done);
       }
     }
   }
+  if (c->profile) clock_gettime(CLOCK_MONOTONIC, &tp1);
   pthread_mutex_lock(&c->lock);
   unsigned const job = __atomic_fetch_add(&f->next_jobnum, 1u, __ATOMIC_RELAXED);   /* src/filter.c:607; read lock-free by slaves being created */
   int const slot = (int)(job % ND);
   /* readers pick this up without a lock, possibly while a later lap overwrites it (as in the reference): tear-free accesses */
   __atomic_store_n(&f->samples_by_job[slot], f->sample_index, __ATOMIC_RELAXED);   /* src/filter.c:614-615 */
   f->sample_index += (uint64_t)f->ilen;
+  if (skip) {
+    /* the samples still go to the device ring (the next block's window starts with them); nothing is transformed, the
+       slot's records stay with the block that is still in flight, and the slaves are told at once */
+    int rc = 0;
+    if (f->in_type == COMPLEX) {
+      rc = chz_input_write(c->eng, (const float *)(f->input_read_pointer.c + (f->impulse_length - 1)), f->ilen);
+      f->input_read_pointer.c += f->ilen;
+      ring_wrap((void **)&f->input_read_pointer.c, f->input_buffer, f->input_buffer_size);
+    } else {
+      rc = chz_input_write(c->eng, f->input_read_pointer.r + (f->impulse_length - 1), f->ilen);
+      f->input_read_pointer.r += f->ilen;
+      ring_wrap((void **)&f->input_read_pointer.r, f->input_buffer, f->input_buffer_size);
+    }
+    if (rc != 0) fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
+    __atomic_store_n(&c->skipped[slot], ((uint64_t)1 << 32) | job, __ATOMIC_RELEASE);
+    c->n_skipped++;
+    pthread_mutex_unlock(&c->lock);
+    pthread_mutex_lock(&f->filter_mutex);
+    __atomic_store_n(&f->completed_jobs[slot], job, __ATOMIC_RELEASE);
+    pthread_cond_broadcast(&f->filter_cond);
+    pthread_mutex_unlock(&f->filter_mutex);
+    futex_wake_all(&f->completed_jobs[slot]);
+    return rc == 0 ? 0 : -1;
+  }
   struct done_note *note = &c->note[slot];
   note->ctx = c; note->job = job;
   clock_gettime(CLOCK_MONOTONIC, &note->t0);
@@ -668,9 +739,16 @@ int execute_filter_input(struct filter_in *const f) {
     chz_bank_set_active(c->eng, b->id, b->n);
     rc = chz_bank_execute(c->eng, b->id, slot);
     if (rc == 0) rc = chz_bank_read_async(c->eng, b->id, slot, 0, b->n, (float *)b->stage[slot]);
+    if (rc == 0 && b->noise_on) rc = chz_bank_read_noise_async(c->eng, b->id, slot, 0, b->n, b->stage_n0[slot]);
   }
   if (rc == 0) rc = chz_host_callback(c->eng, slot, block_done, note);
   if (rc != 0) fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
+  if (c->profile) {
+    struct timespec tp2; clock_gettime(CLOCK_MONOTONIC, &tp2);
+    c->prof_blocks++;
+    c->prof_input_ns += (unsigned long long)((tp2.tv_sec - tp0.tv_sec) * 1000000000LL + (tp2.tv_nsec - tp0.tv_nsec));
+    c->prof_wait_ns += (unsigned long long)((tp1.tv_sec - tp0.tv_sec) * 1000000000LL + (tp1.tv_nsec - tp0.tv_nsec));
+  }
   pthread_mutex_unlock(&c->lock);
   if (rc == 0 && f->perform_inline) {      /* inline masters hand the block over before returning (src/filter.c:562-600) */
     chz_sync(c->eng);
@@ -724,6 +802,7 @@ static void serve_misses(struct mctx *c, struct miss_req *list) {
     if (rc == 0) rc = chz_bank_execute_range(c->eng, b->id, (unsigned)r->slot, k, 1);
     if (rc == 0) rc = chz_bank_read_async(c->eng, b->id, r->slot, k, 1,
                                           (float *)((char *)b->stage[r->slot] + (size_t)k * b->olen * bank_sample_bytes(b)));
+    if (rc == 0 && b->noise_on) rc = chz_bank_read_noise_async(c->eng, b->id, r->slot, k, 1, b->stage_n0[r->slot] + k);
     if (rc != 0) fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
     r->rc = rc;
     touched[r->slot] = true;
@@ -770,7 +849,10 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
       /* Everybody asleep on this word waits for the same job, so a woken thread passes the wake-up on to two more:
          the ~1000 channel threads are released in a tree (log depth, on many cores) instead of one after the other by
          the completion callback. */
-      if (slept) futex_wake_n(wake, 2);
+      if (slept) {
+        int const fan = master->fwd_plan && !is_mini_master(master) ? MCTX(master)->wake_fan : 2;
+        if (fan > 0) futex_wake_n(wake, fan);
+      }
       if ((int)(done - job) >= ND) {                               /* lapped: zeros + drop (src/filter.c:690-701) */
         slave->block_drops++;
         slave->next_jobnum++;
@@ -785,6 +867,15 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
   }
   slave->sample_index = __atomic_load_n(&master->samples_by_job[slot], __ATOMIC_RELAXED);   /* src/filter.c:705 */
   slave->next_jobnum++;
+  if (master->fwd_plan && !is_mini_master(master) &&
+      __atomic_load_n(&MCTX(master)->skipped[slot], __ATOMIC_ACQUIRE) == (((uint64_t)1 << 32) | job)) {
+    /* KA9Q_HIP_INPUT_FULL=drop: the device was ND blocks behind when this block arrived and it was never transformed:
+       zeros and a counted drop, as for a lapped slave (src/filter.c:690-701) */
+    slave->block_drops++;
+    if (slave->output_buffer.c != NULL) memset(slave->output_buffer.c, 0, (size_t)slave->points * sizeof *slave->output_buffer.c);
+    if (slave->output_buffer.r != NULL) memset(slave->output_buffer.r, 0, (size_t)slave->points * sizeof *slave->output_buffer.r);
+    return 0;
+  }
 
   if (slave->out_type == SPECTRUM || slave->rev_plan == NULL) return 0;   /* block clock only */
   pthread_mutex_lock(&slave->response_mutex);
@@ -809,10 +900,24 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
           b->stage_epoch[slot][k] == sc->epoch && (b->real || b->stage_isb[slot][k] == (slave->isb ? 1 : 0))) {
         /* the batch (speculative, or the miss batch just served) computed exactly this */
         memcpy(dst, (char *)b->stage[slot] + (size_t)k * b->olen * bank_sample_bytes(b), bank_sample_bytes(b) * (size_t)b->olen);
+        sc->n0 = b->noise_on ? b->stage_n0[slot][k] : NAN;
         hit = true;
       }
     }
     pthread_rwlock_unlock(rl);
+    if (c->profile) {
+      if (hit && attempt == 0) {
+        struct timespec tn; clock_gettime(CLOCK_MONOTONIC, &tn);
+        long long const ns = (tn.tv_sec - c->t_done[slot].tv_sec) * 1000000000LL + (tn.tv_nsec - c->t_done[slot].tv_nsec);
+        if (ns >= 0 && ns < 1000000000LL) {
+          __atomic_fetch_add(&c->prof_consume_sum_ns, (unsigned long long)ns, __ATOMIC_RELAXED);
+          __atomic_fetch_add(&c->prof_consume_n, 1ull, __ATOMIC_RELAXED);
+          unsigned long long mx = __atomic_load_n(&c->prof_consume_max_ns, __ATOMIC_RELAXED);
+          while ((unsigned long long)ns > mx && !__atomic_compare_exchange_n(&c->prof_consume_max_ns, &mx, (unsigned long long)ns, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+        }
+      }
+      __atomic_fetch_add(hit ? &c->prof_hits : &c->prof_misses, 1ull, __ATOMIC_RELAXED);
+    }
     if (hit) return 0;
 
     /* retuned / new filter / newly created: queue this channel for a re-run on the block's spectrum */
@@ -844,6 +949,40 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
   /* (the size from the slave itself: c->banks may be growing under another thread's create_filter_output right now) */
   memset(dst, 0, (real_out ? sizeof(float) : sizeof(float complex)) * (size_t)slave->olen);
   return 0;
+}
+
+/* ---- beyond filter.h (include/ka9q_filter_hip_ext.h): estimate_noise() on the device -------------------------------
+   radiod's estimate_noise() (src/radio.c:1783-1866) is the only reader of master->fdomain[] outside filter.c, and the
+   reason every block's 13 MB spectrum travels back over PCIe.  A host that takes the estimate from the device instead --
+   the same function run by the noise_est kernel right behind the channel kernel, pinned to radio.c's own code to 1e-12 --
+   can switch that copy off (KA9Q_HIP_FDOMAIN=0).  samprate = Frontend.samprate (src/radio.c:1865). */
+int filter_hip_enable_noise(struct filter_in *master, double samprate) {
+  if (master == NULL || master->fwd_plan == NULL || is_mini_master(master) || !(samprate >= 0)) return -1;
+  struct mctx *c = MCTX(master);
+  int rc = 0;
+  pthread_mutex_lock(&c->lock);
+  stage_wrlock(c);
+  c->noise_samprate = samprate;
+  for (int i = 0; i < c->nbanks; i++) {
+    struct hbank *b = &c->banks[i];
+    b->noise_on = chz_bank_enable_noise(c->eng, b->id, samprate) == 0 && samprate > 0;
+    if (samprate > 0 && !b->noise_on) rc = 1;                /* some channel size has no noise kernel: those slaves report NaN */
+    for (int s = 0; s < ND; s++) for (int k = 0; k < b->cap; k++) b->stage_n0[s][k] = NAN;
+  }
+  stage_wrunlock(c);
+  pthread_mutex_unlock(&c->lock);
+  return rc;
+}
+/* N0 (power per Hz, as estimate_noise() returns it) of the block this slave's last execute_filter_output delivered;
+   NaN when the device estimate is off, the channel size has no kernel, or no block has been delivered yet */
+double filter_hip_noise(struct filter_out const *slave) {
+  if (slave == NULL || slave->rev_plan == NULL || slave->master == NULL || is_mini_master(slave->master)) return NAN;
+  return ((struct sctx const *)(void const *)slave->rev_plan)->n0;
+}
+/* blocks the front end skipped because the device was ND blocks behind (KA9Q_HIP_INPUT_FULL=drop) */
+unsigned long filter_hip_skipped_blocks(struct filter_in const *master) {
+  if (master == NULL || master->fwd_plan == NULL || is_mini_master(master)) return 0;
+  return ((struct mctx const *)(void const *)master->fwd_plan)->n_skipped;
 }
 
 int set_filter_weights(struct filter_out *out, double complex i_weight, double complex q_weight) {  /* src/filter.c:922-929 */

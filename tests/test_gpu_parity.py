@@ -517,6 +517,36 @@ def test_run_blocks_graph_equals_eager(pkg):
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_graph_replay_keeps_the_notch_ticket(pkg):
+    # round 3: captured notch kernels take their ticket relative to a device word, so graph replays, eager runs and
+    # graph replays again continue ONE recurrence (src/filter.c:464-474), block after block, in any mix
+    L, M = 25920, 6481
+    rng = np.random.default_rng(52)
+    ring = (rng.standard_normal(8 * L) + 0.3).astype(np.float32)
+    bins = [125, 16000, 0]                          # (the reference's list ends with its DC entry, src/filter.c:464-474)
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    if eng.lanes < 2:
+        eng.close(); pytest.skip("one lane: nothing to order")
+    eng.set_notches(bins, 0.05)
+    eng.write(ring[:8 * L - (M - 1)]); eng.write(ring[8 * L - (M - 1):])
+    plan = [(True, 40), (False, 13), (True, 19), (True, 64), (False, 3)]      # (graph, blocks): replays of 32 or 8 blocks + eager tails
+    job = 0
+    for graph, n in plan:
+        eng.run_blocks(job, n, graph=graph)
+        job += n
+    got = eng.spectrum((job - 1) % 4)
+    eng.close()
+    st = ol.Stream(L, M, ol.REAL)
+    st.push(ring[7 * L:8 * L])
+    state = np.zeros(2 * len(bins))
+    for j in range(job):
+        want = st.push(ring[(j % 8) * L:(j % 8 + 1) * L])
+        ol.notch(state, bins, 0.05, want)
+    for b in bins:
+        assert abs(got[b] - want[b]) <= 5e-6 * abs(want[b]) + 5e-3, b
+    assert rel(got, want) <= SPEC_REL
+
+
 # ------------------------------------------------------------------------------
 # the tail of downconvert() fused into the channel kernel
 # ------------------------------------------------------------------------------

@@ -249,8 +249,13 @@ def test_rccl_behind_the_c_abi_single_rank(pkg):
 
 
 def test_comm_rendezvous_file_single_rank(pkg, tmp_path):
-    comm = pkg.engine.Comm(0, 1, device=0, path=str(tmp_path / "chz_id"))
-    assert os.path.getsize(tmp_path / "chz_id") == 128
+    path = tmp_path / "chz_id"
+    path.write_bytes(b"\x55" * 128)                       # a previous launch's left-over must not be taken for this launch's id
+    comm = pkg.engine.Comm(0, 1, device=0, path=str(path))
+    assert not path.exists()                               # rank 0 removes its file once every rank has joined
+    comm.barrier()
+    comm.close()
+    comm = pkg.engine.Comm(0, 1, device=0, path=str(path))   # and the path can be used again
     comm.barrier()
     comm.close()
 
@@ -369,6 +374,63 @@ def test_linear_demodulator_on_the_device(pkg):
         assert it.demod_n == 8 and it.demod_ms > 0
     finally:
         eng2.close()
+
+
+def test_partial_rerun_leaves_the_demodulators_alone(pkg):
+    """chz_bank_execute_range(bank, job, 0, n < active) -- the drop-in's miss path re-running a few channels of a block that has
+    already been demodulated -- must not step anybody's AGC / squelch / noise smoothing a second time nor touch the block's PCM:
+    only a launch over the whole bank is 'the block' (round 2 advisor finding)."""
+    from test_kernels_emulated import DEMOD_CASES
+    L, M, P, olen, fs_out = 25920, 6481, 300, 240, 12000.0
+    rng = np.random.default_rng(78)
+    t = np.arange(8 * L)
+    ring = ((0.05 * np.cos(2 * np.pi * (2501.3 / (L + M - 1)) * t)) + 1e-4 * rng.standard_normal(8 * L)).astype(np.float32)
+    finals = []
+    for rerun in (False, True):
+        eng, bank, params = _demod_engine(pkg, ring, L, M, P, olen, DEMOD_CASES[:4], fs_out)
+        try:
+            for b in range(6):
+                eng.step(b)
+                if rerun and b in (2, 5):
+                    eng.sync()
+                    pcm0, st0 = bank.read_pcm(b % 4)
+                    bank.execute_range(b, 0, 1); bank.execute_range(b, 0, 3)
+                    eng.sync()
+                    pcm1, st1 = bank.read_pcm(b % 4)
+                    assert np.array_equal(pcm0, pcm1)
+                    assert [(s.gain, s.n0, s.squelch_state, s.frame) for s in st0] == [(s.gain, s.n0, s.squelch_state, s.frame) for s in st1]
+            eng.sync()
+            pcm, st = bank.read_pcm(5 % 4)
+            finals.append((pcm.copy(), [(s.gain, s.n0, s.squelch_state, s.frame, s.output_power) for s in st]))
+        finally:
+            eng.close()
+    assert np.array_equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
+
+
+def test_mini_master_of_8192_points(pkg):
+    # two 8192-point buffers are 128 KB of LDS: the kernel has to ask for more than the default 64 KB (round 2 advisor finding)
+    L, M = 6144, 2049
+    N = L + M - 1
+    rng = np.random.default_rng(N)
+    pool = pkg.engine.MiniPool(L, M, 3)
+    insts = [pool.add() for _ in range(3)]
+    resp = ol.set_filter(N, L, N, False, -0.2, 0.3, 9.0)
+    for i in insts:
+        pool.set_response(i, resp)
+    stream = ol.Stream(L, M, ol.COMPLEX)
+    hist = np.zeros((3, M - 1), np.complex64)
+    try:
+        for blk in range(2):
+            x = (rng.standard_normal((3, L)) + 1j * rng.standard_normal((3, L))).astype(np.complex64)
+            x[1:] = x[0]
+            win = np.concatenate([hist, x], axis=1)
+            out = pool.execute(insts, win)
+            want = ol.channel(stream.push(x[0], f64=True), ol.COMPLEX, N, L, 0, resp)
+            for i in range(3):
+                check_channel(out[i], want)
+            hist = win[:, L:]
+    finally:
+        pool.close()
 
 
 def test_fm_demodulator_on_the_device(pkg):
