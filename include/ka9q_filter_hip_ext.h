@@ -20,6 +20,8 @@ struct filter_out;
 int filter_hip_enable_noise(struct filter_in *master, double samprate);
 /* N0 of the block the slave's last execute_filter_output() delivered (NaN: not available) */
 double filter_hip_noise(struct filter_out const *slave);
+/* returns once the device has finished every block handed to it so far */
+int filter_hip_drain(struct filter_in *master);
 /* blocks skipped by the front end because the device was ND blocks behind (only with KA9Q_HIP_INPUT_FULL=drop) */
 unsigned long filter_hip_skipped_blocks(struct filter_in const *master);
 #ifdef __cplusplus

@@ -73,7 +73,7 @@ struct hbank {
   bool noise_on;                    /* the device runs noise_est behind this bank's channel kernel */
 };
 
-struct done_note { struct mctx *ctx; unsigned job; struct timespec t0; };
+struct done_note { struct mctx *ctx; unsigned job, seq; struct timespec t0; };
 
 struct mctx {
   int kind;                         /* CTX_ENGINE; a small inline master carries a struct minictx instead (filter_hip_mini.h) */
@@ -99,7 +99,16 @@ struct mctx {
      whole -- and every slave gets zeros and a counted drop for it (src/filter.c:690-701), instead of the front-end thread
      (a USB callback, say) standing still.  Default: wait (no sample is ever lost to a momentary stall). */
   bool drop_when_full;
-  uint64_t skipped[ND];             /* (1 << 32) | job of the last block skipped in this slot */
+#define SKIP_RING 8
+  uint64_t skipped[ND][SKIP_RING];  /* (1 << 32) | job of the blocks skipped in this slot lately, at [(job / ND) % SKIP_RING] */
+  /* What the channel threads sleep on: a per-slot generation word, bumped after every publication in the slot (a completed
+     block: completed_jobs[slot]; a skipped one: skipped[slot][..]).  A sleeper reads it BEFORE it looks at either, so a
+     publication between its look and its sleep cannot be missed. */
+  unsigned gen[ND];
+  /* what the DEVICE holds per slot: the last job enqueued there and the last one whose completion callback has run.  The slot's
+     completion record, spectrum, staged outputs and host-ring window belong to the enqueued job until the two agree. */
+  unsigned enq_seq[ND];             /* blocks enqueued in the slot so far (producer only) */
+  unsigned dev_seq[ND];             /* of which the completion callback has run (futex word the producer sleeps on) */
   unsigned long n_skipped;
   double noise_samprate;            /* > 0: banks run the device's estimate_noise() (filter_hip_enable_noise) */
   /* wake-up of the channel threads: the completion callback wakes wake_first of them (0 = all), every woken thread wakes
@@ -108,7 +117,7 @@ struct mctx {
   /* KA9Q_HIP_PROFILE=1: where a block's host time goes, printed by delete_filter_input */
   bool profile;
   struct timespec t_done[ND];       /* when the slot's completion callback ran */
-  unsigned long long prof_blocks, prof_input_ns, prof_wait_ns, prof_consume_sum_ns, prof_consume_n, prof_consume_max_ns, prof_hits, prof_misses;
+  unsigned long long prof_blocks, prof_input_ns, prof_wait_ns, prof_consume_sum_ns, prof_consume_n, prof_consume_max_ns, prof_hits, prof_misses, prof_dev_max_ns;
   /* channels whose staged result does not fit (retuned, new filter, just created) are re-run in batches: the first
      thread to miss becomes the leader and serves everybody who queued up meanwhile with one device round trip */
   pthread_mutex_t miss_lock;
@@ -148,7 +157,7 @@ static pthread_rwlock_t *stage_rdlock(struct mctx *c, const void *who) {
   return l;
 }
 
-/* Block completion is published through completed_jobs[] itself with a futex: the ~1000 channel
+/* Block completion is published through completed_jobs[] and announced on a futex word (mctx.gen[]): the ~1000 channel
    threads of a big radiod all sleep on the same word and are released TOGETHER, instead of being
    handed filter_mutex one by one as pthread_cond_broadcast does (a 5-10 ms convoy per block at 1024
    threads).  Nothing outside filter.c touches filter_mutex / filter_cond / completed_jobs in the
@@ -259,22 +268,26 @@ static void block_done(void *arg) {
   struct done_note *n = arg;
   struct filter_in *f = n->ctx->master;
   /* the record is read in full BEFORE the job is published: publishing releases the producer, which may reuse it */
-  unsigned const job = n->job;
+  unsigned const job = n->job, seq = n->seq;
   struct timespec const t0 = n->t0;
   struct timespec t1;
   clock_gettime(CLOCK_MONOTONIC, &t1);
   struct mctx *const c = n->ctx;
-  if (c->profile) c->t_done[job % ND] = t1;
+  if (c->profile) {
+    c->t_done[job % ND] = t1;
+    long long const d = (t1.tv_nsec - t0.tv_nsec) + 1000000000LL * (t1.tv_sec - t0.tv_sec);
+    if (job >= 8 && (unsigned long long)d > c->prof_dev_max_ns) c->prof_dev_max_ns = (unsigned long long)d;   /* the first blocks carry one-time set-up */
+  }
   pthread_mutex_lock(&f->filter_mutex);
   __atomic_store_n(&f->owner, pthread_self(), __ATOMIC_RELEASE);      /* read without the mutex by execute_filter_output */
-  /* (a block skipped in drop mode may have published a LATER job in this slot already: never step back) */
-  unsigned const cur = __atomic_load_n(&f->completed_jobs[job % ND], __ATOMIC_RELAXED);
-  if (cur == UINT_MAX || (int)(job - cur) > 0)
-    __atomic_store_n(&f->completed_jobs[job % ND], job, __ATOMIC_RELEASE);   /* src/filter.c:526-529 */
+  __atomic_store_n(&f->completed_jobs[job % ND], job, __ATOMIC_RELEASE);   /* src/filter.c:526-529 */
   pthread_cond_broadcast(&f->filter_cond);              /* src/filter.c:532-535 (kept; nobody in this build waits on it) */
   pthread_mutex_unlock(&f->filter_mutex);
-  if (c->wake_first > 0) futex_wake_n(&f->completed_jobs[job % ND], c->wake_first);
-  else futex_wake_all(&f->completed_jobs[job % ND]);
+  __atomic_fetch_add(&c->gen[job % ND], 1u, __ATOMIC_RELEASE);
+  if (c->wake_first > 0) futex_wake_n(&c->gen[job % ND], c->wake_first);
+  else futex_wake_all(&c->gen[job % ND]);
+  __atomic_store_n(&c->dev_seq[job % ND], seq, __ATOMIC_RELEASE);      /* the slot is the producer's again */
+  futex_wake_n(&c->dev_seq[job % ND], 1);
   int64_t ns = (t1.tv_nsec - t0.tv_nsec) + 1000000000LL * (t1.tv_sec - t0.tv_sec);
   if (ns > Max_fft_time) Max_fft_time = ns;             /* src/filter.c:544-552 */
   if (ns < Min_fft_time) Min_fft_time = ns;
@@ -483,11 +496,11 @@ int delete_filter_input(struct filter_in *master) {
     struct mctx *c = MCTX(master);
     chz_sync(c->eng);
     if (c->profile && c->prof_blocks)
-      fprintf(stderr, "filter_hip profile: blocks %llu  execute_filter_input %.1f us/block (of which waiting for the device %.1f us)  "
-              "callback -> slave has its block: mean %.1f us, worst %.1f us over %llu reads  staged hits %llu misses %llu  skipped blocks %lu\n",
+      fprintf(stderr, "filter_hip profile: blocks=%llu input_us=%.1f input_wait_us=%.1f consume_mean_us=%.1f consume_worst_us=%.1f reads=%llu "
+              "hits=%llu misses=%llu skipped=%lu dev_block_max_us_after_8=%.1f\n",
               c->prof_blocks, c->prof_input_ns / 1e3 / c->prof_blocks, c->prof_wait_ns / 1e3 / c->prof_blocks,
               c->prof_consume_n ? c->prof_consume_sum_ns / 1e3 / c->prof_consume_n : 0.0, c->prof_consume_max_ns / 1e3, c->prof_consume_n,
-              c->prof_hits, c->prof_misses, c->n_skipped);
+              c->prof_hits, c->prof_misses, c->n_skipped, c->prof_dev_max_ns / 1e3);
     if (c->ring_pinned) chz_host_unregister(master->input_buffer);
     chz_engine_destroy(c->eng);
     mctx_free(c);
@@ -631,16 +644,12 @@ int execute_filter_input(struct filter_in *const f) {
   if (c->profile) clock_gettime(CLOCK_MONOTONIC, &tp0);
   bool skip = false;
   {
-    unsigned const next = f->next_jobnum;
-    if (next >= ND) {
-      unsigned const need = next - ND;
-      unsigned *word = &f->completed_jobs[need % ND];
-      for (;;) {
-        unsigned done = __atomic_load_n(word, __ATOMIC_ACQUIRE);
-        if (done != UINT_MAX && (int)(need - done) <= 0) break;
-        if (c->drop_when_full) { skip = true; break; }
-        futex_wait_u32(word, done);
-      }
+    int const nslot = (int)(f->next_jobnum % ND);
+    for (;;) {
+      unsigned const done = __atomic_load_n(&c->dev_seq[nslot], __ATOMIC_ACQUIRE);
+      if (done == c->enq_seq[nslot]) break;
+      if (c->drop_when_full) { skip = true; break; }
+      futex_wait_u32(&c->dev_seq[nslot], done);
     }
   }
   if (c->profile) clock_gettime(CLOCK_MONOTONIC, &tp1);
@@ -664,18 +673,18 @@ int execute_filter_input(struct filter_in *const f) {
       ring_wrap((void **)&f->input_read_pointer.r, f->input_buffer, f->input_buffer_size);
     }
     if (rc != 0) fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
-    __atomic_store_n(&c->skipped[slot], ((uint64_t)1 << 32) | job, __ATOMIC_RELEASE);
+    /* completed_jobs[slot] stays with the block still in flight there (publishing this one in it would lap that block away
+       from every slave that has not fetched it yet): a skipped block is announced on its own */
+    __atomic_store_n(&c->skipped[slot][(job / ND) % SKIP_RING], ((uint64_t)1 << 32) | job, __ATOMIC_RELEASE);
     c->n_skipped++;
     pthread_mutex_unlock(&c->lock);
-    pthread_mutex_lock(&f->filter_mutex);
-    __atomic_store_n(&f->completed_jobs[slot], job, __ATOMIC_RELEASE);
-    pthread_cond_broadcast(&f->filter_cond);
-    pthread_mutex_unlock(&f->filter_mutex);
-    futex_wake_all(&f->completed_jobs[slot]);
+    __atomic_fetch_add(&c->gen[slot], 1u, __ATOMIC_RELEASE);
+    futex_wake_all(&c->gen[slot]);
     return rc == 0 ? 0 : -1;
   }
   struct done_note *note = &c->note[slot];
   note->ctx = c; note->job = job;
+  note->seq = ++c->enq_seq[slot];
   clock_gettime(CLOCK_MONOTONIC, &note->t0);
   sync_notches(c, f);
 
@@ -742,7 +751,10 @@ int execute_filter_input(struct filter_in *const f) {
     if (rc == 0 && b->noise_on) rc = chz_bank_read_noise_async(c->eng, b->id, slot, 0, b->n, b->stage_n0[slot]);
   }
   if (rc == 0) rc = chz_host_callback(c->eng, slot, block_done, note);
-  if (rc != 0) fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
+  if (rc != 0) {
+    fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
+    c->enq_seq[slot]--;                                             /* no completion callback will come for this block */
+  }
   if (c->profile) {
     struct timespec tp2; clock_gettime(CLOCK_MONOTONIC, &tp2);
     c->prof_blocks++;
@@ -842,17 +854,17 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
   /* (Measured and rejected: sleeping on 16 sharded wake words per slot with a small initial fan-out -- the tree's depth
      times the scheduler's wake latency cost 10 ms per block at 1024 threads, against 3 ms for one FUTEX_WAKE of everybody
      plus the pass-it-on below.) */
-  unsigned *const wake = &master->completed_jobs[slot];
+  struct mctx *const mc = (master->fwd_plan && !is_mini_master(master)) ? MCTX(master) : NULL;
+  unsigned *const wake = mc ? &mc->gen[slot] : &master->completed_jobs[slot];
+  bool skipped = false;
   for (;;) {
+    unsigned const g = mc ? __atomic_load_n(wake, __ATOMIC_ACQUIRE) : 0u;          /* before looking at what it announces */
     unsigned done = __atomic_load_n(&master->completed_jobs[slot], __ATOMIC_ACQUIRE);
     if ((int)(job - done) <= 0) {
-      /* Everybody asleep on this word waits for the same job, so a woken thread passes the wake-up on to two more:
+      /* Everybody asleep on this word waits for the same job, so a woken thread passes the wake-up on to a few more:
          the ~1000 channel threads are released in a tree (log depth, on many cores) instead of one after the other by
          the completion callback. */
-      if (slept) {
-        int const fan = master->fwd_plan && !is_mini_master(master) ? MCTX(master)->wake_fan : 2;
-        if (fan > 0) futex_wake_n(wake, fan);
-      }
+      if (slept) { int const fan = mc ? mc->wake_fan : 2; if (fan > 0) futex_wake_n(wake, fan); }
       if ((int)(done - job) >= ND) {                               /* lapped: zeros + drop (src/filter.c:690-701) */
         slave->block_drops++;
         slave->next_jobnum++;
@@ -862,13 +874,17 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
       }
       break;
     }
-    futex_wait_u32(wake, done);                                    /* src/filter.c:686-687 */
+    if (mc && __atomic_load_n(&mc->skipped[slot][(job / ND) % SKIP_RING], __ATOMIC_ACQUIRE) == (((uint64_t)1 << 32) | job)) {
+      if (slept && mc->wake_fan > 0) futex_wake_n(wake, mc->wake_fan);
+      skipped = true;
+      break;
+    }
+    futex_wait_u32(wake, mc ? g : done);                           /* src/filter.c:686-687 */
     slept = true;
   }
   slave->sample_index = __atomic_load_n(&master->samples_by_job[slot], __ATOMIC_RELAXED);   /* src/filter.c:705 */
   slave->next_jobnum++;
-  if (master->fwd_plan && !is_mini_master(master) &&
-      __atomic_load_n(&MCTX(master)->skipped[slot], __ATOMIC_ACQUIRE) == (((uint64_t)1 << 32) | job)) {
+  if (skipped) {
     /* KA9Q_HIP_INPUT_FULL=drop: the device was ND blocks behind when this block arrived and it was never transformed:
        zeros and a counted drop, as for a lapped slave (src/filter.c:690-701) */
     slave->block_drops++;
@@ -978,6 +994,11 @@ int filter_hip_enable_noise(struct filter_in *master, double samprate) {
 double filter_hip_noise(struct filter_out const *slave) {
   if (slave == NULL || slave->rev_plan == NULL || slave->master == NULL || is_mini_master(slave->master)) return NAN;
   return ((struct sctx const *)(void const *)slave->rev_plan)->n0;
+}
+/* returns once the device has finished every block handed to it so far (an orderly shutdown reads its last results after this) */
+int filter_hip_drain(struct filter_in *master) {
+  if (master == NULL || master->fwd_plan == NULL || is_mini_master(master)) return -1;
+  return chz_sync(MCTX(master)->eng) == 0 ? 0 : -1;
 }
 /* blocks the front end skipped because the device was ND blocks behind (KA9Q_HIP_INPUT_FULL=drop) */
 unsigned long filter_hip_skipped_blocks(struct filter_in const *master) {

@@ -5,20 +5,21 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-TAG=${1:-r02}
-timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+TAG=${1:-r03}
+FAST="--no-crt --no-cpu-baseline --no-dropin --no-crt-pcie"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_4streams -o t -- python $R/bench.py --steps 20 --warmup 5 --no-crt --no-cpu-baseline > $R/gpurun_out/${TAG}_prof4.json 2> $R/gpurun_out/${TAG}_prof4.err
-CHZ_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_1stream -o t -- python $R/bench.py --steps 20 --warmup 5 --no-crt --no-cpu-baseline > $R/gpurun_out/${TAG}_prof1.json 2> $R/gpurun_out/${TAG}_prof1.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_4streams -o t -- python $R/bench.py --steps 20 --warmup 5 $FAST > $R/gpurun_out/${TAG}_prof4.json 2> $R/gpurun_out/${TAG}_prof4.err
+CHZ_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_1stream -o t -- python $R/bench.py --steps 20 --warmup 5 $FAST > $R/gpurun_out/${TAG}_prof1.json 2> $R/gpurun_out/${TAG}_prof1.err
 cd $R
-[ "$SKIP_PMC" = 1 ] || timeout 1300 bash scripts/pmc_passes.sh $TAG
+[ "$SKIP_PMC" = 1 ] || timeout 1300 bash scripts/pmc_passes.sh $TAG --no-dropin --no-crt-pcie
 {
-  echo "## rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-crt --no-cpu-baseline   (default: 4 HIP streams)"
+  echo "## rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 $FAST   (default: 4 HIP streams)"
   python scripts/rocprof_summary.py gpurun_out/prof_${TAG}_4streams
   echo; echo "## the same with CHZ_STREAMS=1 (one kernel at a time: solo kernel durations, comparable with roofline.kernels_us)"
   python scripts/rocprof_summary.py gpurun_out/prof_${TAG}_1stream
   echo; echo "## PMC passes (scripts/pmc_passes.sh), per-dispatch averages"
   [ "$SKIP_PMC" = 1 ] || for d in sq1 sq2 fetch write tcc; do python scripts/rocprof_summary.py gpurun_out/pmc_$TAG/$d; done
 } > gpurun_out/${TAG}_rocprofv3_summary.txt 2>&1
+python scripts/rocprof_summary.py --kernels-json gpurun_out/prof_${TAG}_4streams gpurun_out/prof_${TAG}_1stream gpurun_out/${TAG}_rocprof_kernels.json $TAG
 [ "$SKIP_PMC" = 1 ] || python scripts/rocprof_summary.py --json gpurun_out/pmc_$TAG/fetch gpurun_out/pmc_$TAG/write gpurun_out/${TAG}_pmc_forward.json
-tail -c 400 gpurun_out/${TAG}_bench.json; head -40 gpurun_out/${TAG}_rocprofv3_summary.txt
+head -40 gpurun_out/${TAG}_rocprofv3_summary.txt

@@ -56,6 +56,28 @@ def pmc_json(fetch_dir, write_dir, out):
               open(out, "w"), indent=1)
     print("wrote", out, total)
 
+def kernels_json(dir4, dir1, out, tag):
+    """average kernel durations of the bench command under rocprofv3 --kernel-trace --stats (4 streams and 1 stream)"""
+    import json
+    def avgs(d):
+        r = {}
+        for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+            con = sqlite3.connect(db)
+            for name, n, avg in con.execute("select name, count(*), avg(end-start) from kernels group by name"):
+                r[short(name)] = {"calls": n, "avg_us": avg / 1e3}
+        return r
+    k4, k1 = avgs(dir4), avgs(dir1)
+    fwd1 = sum(v["avg_us"] for k, v in k1.items() if k.startswith("fwd_"))
+    fwd4 = sum(v["avg_us"] for k, v in k4.items() if k.startswith("fwd_"))
+    json.dump({"round": tag, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-crt --no-cpu-baseline --no-dropin --no-crt-pcie",
+               "forward_us_1_stream": fwd1, "forward_us_4_streams_sum_of_overlapping_kernels": fwd4,
+               "kernels_1_stream": k1, "kernels_4_streams": k4,
+               "note": "CHZ_STREAMS=1: one kernel at a time, comparable with roofline.kernels_us; profiled runs are about 10 % slower than unprofiled ones"},
+              open(out, "w"), indent=1)
+    print("wrote", out, "forward 1 stream %.2f us" % fwd1)
+
+if len(sys.argv) > 1 and sys.argv[1] == "--kernels-json":
+    kernels_json(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else ""); sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "--json":
     pmc_json(sys.argv[2], sys.argv[3], sys.argv[4]); sys.exit(0)
 

@@ -28,6 +28,15 @@
 struct chanplan { int shift, shift2, retune_block, refilter_block; double low, high, beta, low2, high2; };
 
 extern int64_t Avg_fft_time, Max_fft_time;   /* exported by filter.o (src/filter.c:476-479) */
+/* beyond filter.h (include/ka9q_filter_hip_ext.h); weak, so the same source still links against the reference's own filter.o */
+extern int filter_hip_enable_noise(struct filter_in *, double) __attribute__((weak));
+extern double filter_hip_noise(struct filter_out const *) __attribute__((weak));
+extern unsigned long filter_hip_skipped_blocks(struct filter_in const *) __attribute__((weak));
+extern int filter_hip_drain(struct filter_in *) __attribute__((weak));
+static double Noise_samprate; static double *Noise;   /* env HARNESS_NOISE=<front-end sample rate>: [Nblocks][Nch] device-side estimate_noise() */
+static int Free_run;                                   /* env HARNESS_FREE_RUN=1: the front end does not wait for the channels (a real A/D never does); > 1: and takes that many microseconds per block */
+static unsigned char *Skipflag; static unsigned long Skips_seen;   /* [Nblocks]: the front end's block was skipped (drop mode) */
+static unsigned char *Dropped;                         /* [Nblocks][Nch]: the channel's block_drops went up in that call */
 static struct filter_in Master;
 static int L, M, In_type, Olen, Nch, Nblocks, Chunk;
 static struct chanplan *Plan;
@@ -43,6 +52,12 @@ static int F2_blocking, F2_isb = -1; static double F2_low, F2_high, F2_beta;
 /* env HARNESS_RETUNE_MOD=m: channel i flips between its two shifts at every block b with (b + i) % m == 0, i.e. 1/m of
    the channels retune EVERY block (a scanning / Doppler-tracking channel set) */
 static int Retune_mod;
+/* rate runs (bench.py's `dropin` object, scripts/dropin_rate.py): env HARNESS_INPUT_BLOCKS=k -- in.bin holds k blocks that are
+   replayed cyclically; HARNESS_KEEP=0 -- results are not kept (one block's worth of memory, overwritten) */
+static int Input_blocks, Keep = 1;
+static long long Fe_copy_ns, Fe_call_ns, Fe_wait_ns;          /* front end: copying samples in, inside write_?filter, waiting for the slowest channel */
+static long long Worst_gap_ns, Sum_gap_ns; static int N_gap;  /* block clock: time between consecutive blocks */
+static long long now_ns(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1000000000LL + t.tv_nsec; }
 /* env HARNESS_CHURN_MOD=m: channel i with i % m == 1 leaves half way (delete_filter_output while everybody else runs: the bank
    closes the gap by moving its last slave) and comes back as a NEW slave a little later (create_filter_output + set_filter into
    a running master, then delete again), as radiod's dynamic channels do */
@@ -72,7 +87,10 @@ static void *channel_thread(void *a) {
     if (b == Plan[i].refilter_block) set_filter(&out, Plan[i].low2, Plan[i].high2, Plan[i].beta);
     int shift = (b >= Plan[i].retune_block) ? Plan[i].shift2 : Plan[i].shift;
     if (Retune_mod > 0) shift = (((b + i) / Retune_mod) & 1) ? Plan[i].shift2 : Plan[i].shift;
+    unsigned const drops_before = out.block_drops;
     if (execute_filter_output(&out, shift) != 0) { fprintf(stderr, "execute_filter_output failed\n"); exit(2); }
+    if (Dropped) Dropped[(size_t)b * Nch + i] = out.block_drops != drops_before;
+    if (Noise && filter_hip_noise) Noise[(size_t)b * Nch + i] = filter_hip_noise(&out);
     if (F2_blocking > 0) {
       int r = write_cfilter(&f2in, out.output.c, Olen);          /* runs the input side once the block is full (src/radio.c:1508) */
       if (r < 0) { fprintf(stderr, "filter2 write_cfilter failed\n"); exit(2); }
@@ -82,7 +100,7 @@ static void *channel_thread(void *a) {
           memcpy(Result + ((size_t)(b - F2_blocking + 1 + q) * Nch + i) * Olen, f2out.output.c + (size_t)q * Olen, sizeof(float complex) * (size_t)Olen);
       }
     } else
-      memcpy(Result + ((size_t)b * Nch + i) * Olen, out.output.c, sizeof(float complex) * (size_t)Olen);
+      memcpy(Result + ((size_t)(Keep ? b : 0) * Nch + i) * Olen, out.output.c, sizeof(float complex) * (size_t)Olen);
     atomic_store(&Progress[i], b + 1);
     if (Churn_mod > 0 && i % Churn_mod == 1 && b == Nblocks / 2 && F2_blocking == 0) {
       Drops[i] += out.block_drops;
@@ -129,7 +147,13 @@ static void *clock_thread(void *a) {
   memset(&sp, 0, sizeof sp);
   if (create_filter_output(&sp, &Master, 0, SPECTRUM) != 0) { fprintf(stderr, "SPECTRUM slave failed\n"); exit(2); }
   atomic_store(&Clock_ready, 1);
-  for (int b = 0; b < Nblocks; b++) { execute_filter_output(&sp, 0); atomic_fetch_add(&Clock_blocks, 1); }
+  long long last = 0;
+  for (int b = 0; b < Nblocks; b++) {
+    execute_filter_output(&sp, 0); atomic_fetch_add(&Clock_blocks, 1);
+    long long const t = now_ns();
+    if (b >= 8) { long long const g = t - last; if (g > Worst_gap_ns) Worst_gap_ns = g; Sum_gap_ns += g; N_gap++; }   /* the first blocks fill the pipeline */
+    last = t;
+  }
   delete_filter_output(&sp);
   return NULL;
 }
@@ -147,12 +171,15 @@ int main(int argc, char **argv) {
   f = fopen(path, "rb");
   if (!f || fread(Plan, sizeof *Plan, (size_t)Nch, f) != (size_t)Nch) { perror("plan"); return 1; }
   fclose(f);
-  Input = malloc(sizeof(float) * (size_t)Nblocks * L * per);
+  if (getenv("HARNESS_INPUT_BLOCKS")) Input_blocks = atoi(getenv("HARNESS_INPUT_BLOCKS"));
+  if (getenv("HARNESS_KEEP")) Keep = atoi(getenv("HARNESS_KEEP")) != 0;
+  if (Input_blocks <= 0 || Input_blocks > Nblocks) Input_blocks = Nblocks;
+  Input = malloc(sizeof(float) * (size_t)Input_blocks * L * per);
   snprintf(path, sizeof path, "%s/in.bin", argv[1]);
   f = fopen(path, "rb");
-  if (!f || fread(Input, sizeof(float) * per, (size_t)Nblocks * L, f) != (size_t)Nblocks * L) { perror("input"); return 1; }
+  if (!f || fread(Input, sizeof(float) * per, (size_t)Input_blocks * L, f) != (size_t)Input_blocks * L) { perror("input"); return 1; }
   fclose(f);
-  Result = calloc((size_t)Nblocks * Nch * Olen, sizeof *Result);
+  Result = calloc((size_t)(Keep ? Nblocks : 1) * Nch * Olen, sizeof *Result);
   Drops = calloc((size_t)Nch, sizeof *Drops);
   Progress = calloc((size_t)Nch, sizeof *Progress);
   for (int i = 0; i < Nch; i++) atomic_store(&Progress[i], -1);
@@ -169,6 +196,11 @@ int main(int argc, char **argv) {
     int k = sscanf(getenv("HARNESS_FILTER2"), "%d %lf %lf %lf %d", &F2_blocking, &F2_low, &F2_high, &F2_beta, &F2_isb);
     if (k < 4) { fprintf(stderr, "HARNESS_FILTER2 needs: blocking low high beta [isb_channel]\n"); return 1; }
   }
+  if (getenv("HARNESS_NOISE") && filter_hip_enable_noise) {
+    Noise_samprate = atof(getenv("HARNESS_NOISE"));
+    Noise = calloc((size_t)Nblocks * Nch, sizeof *Noise);
+  }
+  if (getenv("HARNESS_FREE_RUN")) { Free_run = atoi(getenv("HARNESS_FREE_RUN")); Dropped = calloc((size_t)Nblocks * Nch, 1); Skipflag = calloc((size_t)Nblocks, 1); }
   if (getenv("HARNESS_RETUNE_MOD")) Retune_mod = atoi(getenv("HARNESS_RETUNE_MOD"));
   if (getenv("HARNESS_CHURN_MOD")) Churn_mod = atoi(getenv("HARNESS_CHURN_MOD"));
   pthread_t *th = calloc((size_t)Nch, sizeof *th), clk;
@@ -184,48 +216,79 @@ int main(int argc, char **argv) {
   for (int i = 0; i < Nch; i++) while (atomic_load(&Progress[i]) < 0) usleep(200);      /* all slaves registered */
   while (!atomic_load(&Clock_ready) || (Real_on && !atomic_load(&Real_ready))) usleep(200);
 
+  if (Noise && filter_hip_enable_noise(&Master, Noise_samprate) < 0) { fprintf(stderr, "filter_hip_enable_noise failed\n"); return 5; }
   /* front end: write in place, then tell the filter how much arrived */
   struct timespec ts0, ts1;
   clock_gettime(CLOCK_MONOTONIC, &ts0);
   long total = (long)Nblocks * L, pos = 0;
+  long const cyc = (long)Input_blocks * L;
   while (pos < total) {
     int blk = (int)(pos / L);
+    long long const w0 = now_ns();
     for (;;) {   /* never run more than 2 blocks ahead of the slowest channel: no drops wanted here */
       int slow = Nblocks;
       for (int i = 0; i < Nch; i++) { int p = atomic_load(&Progress[i]); if (p < slow) slow = p; }
-      if (blk - slow < 2) break;
+      if (blk - slow < 2 || Free_run) break;
       usleep(100);
     }
     int n = Chunk; if (pos + n > total) n = (int)(total - pos);
+    long const src = pos % cyc;
+    if (src + n > cyc) n = (int)(cyc - src);                    /* a chunk does not straddle the replay seam */
+    long long const w1 = now_ns();
+    long long w2;
     if (In_type == REAL) {
-      memcpy(Master.input_write_pointer.r, Input + pos, sizeof(float) * (size_t)n);
+      memcpy(Master.input_write_pointer.r, Input + src, sizeof(float) * (size_t)n);
+      w2 = now_ns();
       if (write_rfilter(&Master, NULL, n) < 0) { fprintf(stderr, "write_rfilter overrun\n"); return 4; }
     } else {
-      memcpy(Master.input_write_pointer.c, Input + 2 * pos, sizeof(float complex) * (size_t)n);
+      memcpy(Master.input_write_pointer.c, Input + 2 * src, sizeof(float complex) * (size_t)n);
+      w2 = now_ns();
       if (write_cfilter(&Master, NULL, n) < 0) { fprintf(stderr, "write_cfilter overrun\n"); return 4; }
     }
+    Fe_wait_ns += w1 - w0; Fe_copy_ns += w2 - w1; Fe_call_ns += now_ns() - w2;
     pos += n;
+    if (Skipflag && filter_hip_skipped_blocks && pos / L != (pos - n) / L) {      /* a block has just gone in: was it skipped? */
+      unsigned long const sk = filter_hip_skipped_blocks(&Master);
+      Skipflag[(pos - n) / L] = sk != Skips_seen; Skips_seen = sk;
+    }
+    if (Free_run > 1 && pos / L != (pos - n) / L) usleep((useconds_t)Free_run);   /* a front end with its own clock: this many microseconds per block */
   }
   for (int i = 0; i < Nch; i++) pthread_join(th[i], NULL);
   pthread_join(clk, NULL);
   if (Real_on) pthread_join(rth, NULL);
+  if (Free_run && filter_hip_drain) filter_hip_drain(&Master);   /* skipped blocks let the consumers finish before the device has */
   clock_gettime(CLOCK_MONOTONIC, &ts1);
   double elapsed = (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
 
   snprintf(path, sizeof path, "%s/out.bin", argv[1]);
-  f = fopen(path, "wb"); fwrite(Result, sizeof *Result, (size_t)Nblocks * Nch * Olen, f); fclose(f);
+  f = fopen(path, "wb"); fwrite(Result, sizeof *Result, (size_t)(Keep ? Nblocks : 1) * Nch * Olen, f); fclose(f);
   if (Real_on) {
     snprintf(path, sizeof path, "%s/real.bin", argv[1]);
     f = fopen(path, "wb"); fwrite(Real_result, sizeof *Real_result, (size_t)Nblocks * Olen, f); fclose(f);
+  }
+  if (Skipflag) {
+    snprintf(path, sizeof path, "%s/skipped.bin", argv[1]);
+    f = fopen(path, "wb"); fwrite(Skipflag, 1, (size_t)Nblocks, f); fclose(f);
+  }
+  if (Dropped) {
+    snprintf(path, sizeof path, "%s/dropped.bin", argv[1]);
+    f = fopen(path, "wb"); fwrite(Dropped, 1, (size_t)Nblocks * Nch, f); fclose(f);
+  }
+  if (Noise) {
+    snprintf(path, sizeof path, "%s/noise.bin", argv[1]);
+    f = fopen(path, "wb"); fwrite(Noise, sizeof *Noise, (size_t)Nblocks * Nch, f); fclose(f);
   }
   snprintf(path, sizeof path, "%s/spec.bin", argv[1]);   /* host-visible spectrum of the last block (estimate_noise reads it) */
   f = fopen(path, "wb"); fwrite(Master.fdomain[(Nblocks - 1) % ND], sizeof(float complex), (size_t)Master.bins, f); fclose(f);
   snprintf(path, sizeof path, "%s/meta.txt", argv[1]);
   f = fopen(path, "w");
   unsigned drops = 0; for (int i = 0; i < Nch; i++) drops += Drops[i];
-  fprintf(f, "drops %u clock %d next_jobnum %u bins %d points %d sample_index %llu elapsed_s %.6f avg_block_ns %lld max_block_ns %lld\n",
+  fprintf(f, "drops %u clock %d next_jobnum %u bins %d points %d sample_index %llu elapsed_s %.6f avg_block_ns %lld max_block_ns %lld "
+             "worst_gap_ns %lld mean_gap_ns %lld fe_copy_ns %lld fe_call_ns %lld fe_wait_ns %lld skipped %lu\n",
           drops, atomic_load(&Clock_blocks), Master.next_jobnum, Master.bins, Master.points,
-          (unsigned long long)Master.sample_index, elapsed, (long long)Avg_fft_time, (long long)Max_fft_time);
+          (unsigned long long)Master.sample_index, elapsed, (long long)Avg_fft_time, (long long)Max_fft_time,
+          Worst_gap_ns, N_gap ? Sum_gap_ns / N_gap : 0, Fe_copy_ns, Fe_call_ns, Fe_wait_ns,
+          filter_hip_skipped_blocks ? filter_hip_skipped_blocks(&Master) : 0ul);
   fclose(f);
   delete_filter_input(&Master);
   free(th); free(args); free(notch);      /* a clean exit for the leak checker of the sanitizer runs (the caller owns the notch list) */

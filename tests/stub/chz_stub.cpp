@@ -6,6 +6,7 @@
 // device, calls return before their work is done and the completion callback runs on a thread that is not the caller's.
 // Never built into, linked with or loaded by the product (tests/test_dropin_stub.py builds it into tests/stub/_build/).
 #include <atomic>
+#include <chrono>
 #include <complex>
 #include <condition_variable>
 #include <cstdarg>
@@ -31,6 +32,7 @@ struct Bank {
   std::vector<float> resp;                 // [cap][2P]
   std::vector<int> shift; std::vector<unsigned char> isb, beam_on; std::vector<double> ab;   // [cap], [cap], [cap], [cap][4]
   std::vector<float> out[CHZ_ND];          // [cap][olen * (real ? 1 : 2)]
+  double noise_samprate = 0.0; std::vector<double> n0[CHZ_ND];   // estimate_noise() per channel (chz_bank_enable_noise)
   size_t per() const { return (size_t)olen * (real ? 1 : 2); }
 };
 
@@ -39,6 +41,7 @@ struct chz_engine {
   chzo_stream* stream = nullptr;
   std::vector<float> spec[CHZ_ND];
   std::vector<float> pending;              // samples written and not yet transformed (worker only)
+  unsigned next_job = 0;                   // the block the stream's history is ready for (worker only)
   std::vector<int> notch_bins; std::vector<double> notch_alpha, notch_state;
   enum { MAX_BANKS = 256 };
   Bank banks[MAX_BANKS];                   // contents touched by the worker only; a new one is published through nbanks
@@ -99,7 +102,18 @@ int chz_input_write(chz_engine* e, const float* x, long n) {
 int chz_forward(chz_engine* e, unsigned job) {
   if (!e) return fail(-1, "null engine");
   e->post([e, job] {
+    static const int delay_ms = [] { const char* v = getenv("CHZ_STUB_FORWARD_DELAY_MS"); return v ? atoi(v) : 0; }();   // a slow device
+    if (delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
     const size_t need = (size_t)e->L * (e->in_type == CHZ_REAL ? 1 : 2);
+    // blocks the caller wrote but never transformed (the drop-in's drop mode): their samples are history for this one, as in
+    // the device ring, where block `job` reads the window that ends with ITS samples
+    for (; e->next_job != job; e->next_job++) {
+      if (e->pending.size() < 2 * need) { fprintf(stderr, "chz_stub: forward(%u) without its input\n", job); abort(); }
+      std::vector<float> scratch((size_t)2 * e->bins);
+      chzo_stream_push(e->stream, e->pending.data(), scratch.data());
+      e->pending.erase(e->pending.begin(), e->pending.begin() + (long)need);
+    }
+    e->next_job = job + 1;
     if (e->pending.size() < need) { fprintf(stderr, "chz_stub: forward without a block of input\n"); abort(); }
     float* sp = e->spec[job % CHZ_ND].data();
     chzo_stream_push(e->stream, e->pending.data(), sp);
@@ -204,6 +218,8 @@ static void run_channels(chz_engine* e, int id, int slot, int ch0, int n) {
       chzo_channel_beam(e->spec[slot].data(), e->bins, b.P, b.olen, b.shift[(size_t)c], r, b.ab[4 * c], b.ab[4 * c + 1], b.ab[4 * c + 2], b.ab[4 * c + 3], o);
     else
       chzo_channel(e->spec[slot].data(), e->bins, e->in_type, b.P, b.olen, b.real ? CHZO_REAL : CHZO_COMPLEX, b.shift[(size_t)c], b.isb[(size_t)c], r, o);
+    if (b.noise_samprate > 0.0)
+      b.n0[slot][(size_t)c] = chzo_estimate_noise(e->spec[slot].data(), e->bins, e->in_type, b.real ? b.P / 2 + 1 : b.P, b.shift[(size_t)c], b.noise_samprate);
   }
 }
 int chz_bank_execute(chz_engine* e, int id, unsigned job) {
@@ -222,6 +238,22 @@ int chz_bank_read_async(chz_engine* e, int id, int slot, int ch0, int n, float* 
   e->post([e, id, slot, ch0, n, host] {
     Bank& b = e->banks[(size_t)id];
     if (b.alive) memcpy(host, b.out[slot].data() + (size_t)ch0 * b.per(), sizeof(float) * (size_t)n * b.per());
+  });
+  return 0;
+}
+
+int chz_bank_enable_noise(chz_engine* e, int id, double samprate) {
+  BANK(e, id, 0, 0);
+  if (!(samprate >= 0.0)) return fail(-1, "bad sample rate");
+  e->post([e, id, samprate] { Bank& b = e->banks[(size_t)id]; b.noise_samprate = samprate; for (auto& v : b.n0) v.assign((size_t)b.cap, 0.0); });
+  return 0;
+}
+int chz_bank_read_noise_async(chz_engine* e, int id, int slot, int ch0, int n, double* host) {
+  BANK(e, id, ch0, n);
+  if (slot < 0 || slot >= CHZ_ND || !host) return fail(-1, "bad argument");
+  e->post([e, id, slot, ch0, n, host] {
+    Bank& b = e->banks[(size_t)id];
+    if (b.alive && !b.n0[slot].empty()) memcpy(host, b.n0[slot].data() + ch0, sizeof(double) * (size_t)n);
   });
   return 0;
 }

@@ -67,10 +67,11 @@ def test_caller_compiled_against_reference_header_links(tmp_path):
     _build_harness(str(tmp_path / "h_abi"), ref_header=False)     # also checks the _Static_assert layout pins
 
 
-def _run_harness(tmp, L, M, in_type, olen, plan, nblocks, chunk, x, env=None):
+def _run_harness(tmp, L, M, in_type, olen, plan, nblocks, chunk, x, env=None, exe=None):
     """plan rows: (shift, shift2, retune_block, refilter_block, low, high, beta, low2, high2)"""
-    exe = os.path.join(tmp, "harness")
-    _build_harness(exe)
+    if exe is None:
+        exe = os.path.join(tmp, "harness")
+        _build_harness(exe)
     open(os.path.join(tmp, "cfg.txt"), "w").write("%d %d %d %d %d %d %d\n" % (L, M, in_type, olen, len(plan), nblocks, chunk))
     with open(os.path.join(tmp, "plan.bin"), "wb") as f:
         for p in plan:
@@ -128,6 +129,78 @@ def test_dropin_radiod_style_small():
     with tempfile.TemporaryDirectory() as tmp:
         out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x)
     _check(L, M, olen, P, plan, nblocks, out, spec, meta, x)
+
+
+PREBUILT_REF_HARNESS = os.path.join(ROOT, "tests", "c", "_prebuilt", "harness_refhdr")
+
+
+def build_ref_header_harness():
+    """The harness compiled against the reference's OWN src/filter.h, where /root/reference exists (this container): the binary
+    travels to the GPU box with the snapshot (it is git-ignored, like the other built artefacts), so that the GPU tier can RUN a
+    caller that has never seen include/ka9q_filter_abi.h.  Called by __graft_entry__.build()."""
+    if not os.path.isdir(REF_SRC) or LIBDIR != PKG:
+        return None
+    os.makedirs(os.path.dirname(PREBUILT_REF_HARNESS), exist_ok=True)
+    _build_harness(PREBUILT_REF_HARNESS, ref_header=True)
+    return PREBUILT_REF_HARNESS
+
+
+@pytest.mark.gpu
+def test_dropin_runs_a_caller_built_against_the_reference_header():
+    """round 2 only LINKED such a caller; here it runs on the device: struct layouts, enum values and every function signature are
+    the reference's own (src/filter.h:29-118), the library underneath is the drop-in."""
+    _build_lib(); ol.build()
+    exe = PREBUILT_REF_HARNESS
+    if os.path.isdir(REF_SRC):
+        build_ref_header_harness()
+    if not os.path.exists(exe):
+        pytest.fail("tests/c/_prebuilt/harness_refhdr is missing: __graft_entry__.build() makes it where /root/reference exists")
+    L, M, olen, P = 25920, 6481, 240, 300
+    nblocks = 7
+    rng = np.random.default_rng(9)
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = []
+    for i in range(24):
+        shift = int(rng.integers(-12000, 12000))
+        plan.append((shift, shift, 10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4))
+    plan[0] = (2500, 2600, 3, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4)            # retune at block 3
+    plan[1] = (2501, 2501, 10 ** 6, 2, 0.004, 0.25, 11.0, -0.02, 0.02)         # new filter at block 2
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x, exe=exe,
+                                       env={"HARNESS_REAL": "40 0.0 0.3 5.0", "HARNESS_ISB": "5"})
+    plan_chk = [p for i, p in enumerate(plan) if i != 5]                       # (channel 5 is the ISB one: checked in its own test)
+    _check(L, M, olen, P, plan_chk, nblocks, np.delete(out, 5, axis=1), spec, meta, x)
+
+
+@pytest.mark.gpu
+def test_dropin_device_noise_estimate_and_no_spectrum_copy():
+    """include/ka9q_filter_hip_ext.h: with KA9Q_HIP_FDOMAIN=0 nothing is copied to master->fdomain[], and what estimate_noise()
+    (src/radio.c:1783-1866) would have computed from it on the host comes from the device per channel and block -- equal to the
+    oracle's estimate (pinned to radio.c itself) on the oracle's float32 spectrum to the float32 transform's noise."""
+    _build_lib(); ol.build()
+    L, M, olen, P = 25920, 6481, 240, 300
+    fs = 1.296e6
+    nblocks = 6
+    rng = np.random.default_rng(10)
+    g = ol.SigGen(100020.0 / fs, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = [(int(rng.integers(-12000, 12000)),) * 2 + (10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4) for _ in range(16)]
+    plan[3] = (2500, -6000, 3, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4)            # a retune: the miss path delivers its own estimate
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x,
+                                       env={"HARNESS_NOISE": repr(fs), "KA9Q_HIP_FDOMAIN": "0"})
+        noise = np.fromfile(os.path.join(tmp, "noise.bin"), np.float64).reshape(nblocks, len(plan))
+    assert meta["drops"] == "0" and not spec.any()                              # fdomain[] stayed untouched
+    st = ol.Stream(L, M, ol.REAL)
+    state = np.zeros(2)
+    for b in range(nblocks):
+        s = st.push(x[b * L:(b + 1) * L])
+        ol.notch(state, [0], 0.01, s)
+        for i, p in enumerate(plan):
+            shift = p[1] if b >= p[2] else p[0]
+            want = ol.estimate_noise(s, ol.REAL, P, shift, fs)
+            assert noise[b, i] == pytest.approx(want, rel=2e-4), (b, i)
 
 
 @pytest.mark.gpu

@@ -179,3 +179,59 @@ def test_dropin_random_traffic_under_sanitizers(tmp_path, san, seed):
     assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-6000:]
     assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-2000:])
     assert "failed 0" in r.stdout
+
+
+@pytest.mark.parametrize("san", ["thread", "address"])
+def test_dropin_drop_mode_and_device_noise_under_sanitizers(tmp_path, san):
+    """KA9Q_HIP_INPUT_FULL=drop with a device that takes 60 ms per block under a front end that delivers one every 10 ms and never waits: the producer must not
+    block; blocks that found their slot still busy are skipped -- every channel gets zeros and a counted drop for them, as a lapped
+    slave does in the reference (src/filter.c:690-701) -- and every block that WAS transformed is exact, because the skipped blocks'
+    samples still reached the overlap history.  The device-side estimate_noise() (include/ka9q_filter_hip_ext.h) rides along: what
+    filter_hip_noise() hands a channel is the estimate of the block it just received."""
+    if not _have("-fsanitize=" + san):
+        pytest.skip("no -fsanitize=%s runtime in this image" % san)
+    exe = _build(san, str(tmp_path / "build"))
+    L, M, olen, P = 25920, 6481, 240, 300
+    N = L + M - 1
+    nblocks, nch = 18, 20
+    fs = 1.296e6
+    rng = np.random.default_rng(31)
+    g = ol.SigGen(100020.0 / fs, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = [(int(rng.integers(-12000, 12000)),) * 2 + (10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4) for _ in range(nch)]
+    run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
+    env = {"KA9Q_HIP_INPUT_FULL": "drop", "CHZ_STUB_FORWARD_DELAY_MS": "60", "HARNESS_FREE_RUN": "10000", "HARNESS_NOISE": repr(fs)}
+    r = _run(exe, run_dir, L, M, olen, plan, nblocks, x, env)
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-6000:]
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    out = np.fromfile(os.path.join(run_dir, "out.bin"), np.complex64).reshape(nblocks, nch, olen)
+    dropped = np.fromfile(os.path.join(run_dir, "dropped.bin"), np.uint8).reshape(nblocks, nch).astype(bool)
+    noise = np.fromfile(os.path.join(run_dir, "noise.bin"), np.float64).reshape(nblocks, nch)
+    was_skipped = np.fromfile(os.path.join(run_dir, "skipped.bin"), np.uint8).astype(bool)
+    meta = open(os.path.join(run_dir, "meta.txt")).read().split()
+    meta = dict(zip(meta[::2], meta[1::2]))
+    skipped = int(meta["skipped"])
+    assert int(was_skipped.sum()) == skipped
+    assert skipped >= 2 and int(meta["next_jobnum"]) == nblocks and int(meta["clock"]) == nblocks       # the front end ran ahead and never stood still
+    assert int(meta["drops"]) == int(dropped.sum()) and dropped.sum() >= skipped * nch
+    assert not dropped.all(axis=1).all() and not was_skipped.all()                                    # some blocks did get through
+    st = ol.Stream(L, M, ol.REAL)
+    state = np.zeros(2)
+    checked = 0
+    for b in range(nblocks):
+        s64 = st.push(x[b * L:(b + 1) * L], f64=True)
+        if was_skipped[b]:
+            assert dropped[b].all() and not out[b].any()                                              # zeros and a drop for everybody
+            continue                                                                                  # (the notch state did not see this block either)
+        dc = s64[:1].astype(np.complex64); ol.notch(state, [0], 0.01, dc); s64[0] = dc[0]
+        s32 = s64.astype(np.complex64)
+        for i, p in enumerate(plan):
+            if dropped[b, i]:
+                assert not out[b, i].any()
+                continue
+            want = ol.channel(s64, ol.REAL, P, olen, p[0], ol.set_filter(P, olen, N, True, p[4], p[5], p[6]))
+            err = float(np.sqrt(np.mean(np.abs(out[b, i] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+            assert err <= 1e-5 * rms + 2e-8 * float(np.abs(s64).max()), (b, i, err, rms)
+            assert noise[b, i] == pytest.approx(ol.estimate_noise(s32, ol.REAL, P, p[0], fs), rel=1e-6), (b, i)
+            checked += 1
+    assert checked >= nch
