@@ -385,7 +385,7 @@ def dropin_leg(wl, ring_host, nthreads, nblocks, env, label):
         exe = os.path.join(tmp, "harness")
         subprocess.run(["gcc", "-O2", "-std=gnu11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "dropin_harness.c"), "-o", exe,
                         "-L", libdir, "-lka9q_filter_hip", "-lchz_hip", "-Wl,-rpath," + libdir, "-lpthread", "-lm"], check=True)
-        open(os.path.join(tmp, "cfg.txt"), "w").write("%d %d %d %d %d %d %d\n" % (wl["L"], wl["M"], 1, wl["olen"], len(plan), nblocks, 65536))
+        open(os.path.join(tmp, "cfg.txt"), "w").write("%d %d %d %d %d %d %d\n" % (wl["L"], wl["M"], 2, wl["olen"], len(plan), nblocks, 65536))   # 2 = REAL (enum filtertype)
         with open(os.path.join(tmp, "plan.bin"), "wb") as f:
             for shift, lo, hi in plan:
                 f.write(struct.pack("iiiiddddd", shift, shift, 10 ** 9, 10 ** 9, lo, hi, 11.0, lo, hi))
@@ -454,7 +454,7 @@ def main():
     ap.add_argument("--no-crt", action="store_true", help="skip the C_rt leg (one large bank, every block inside 20 ms)")
     ap.add_argument("--crt-channels", type=int, default=0, help="channels of the C_rt leg's bank (default 17.0 M at P=300, 8.4 M at P=600)")
     ap.add_argument("--crt-blocks", type=int, default=500)
-    ap.add_argument("--crt-ladder", default="", help="comma-separated channel counts (millions) of the C_rt ladder; default 17.0,18.5,19.5 at P=300 / 8.4,9.2,9.8 at P=600")
+    ap.add_argument("--crt-ladder", default="", help="comma-separated channel counts (millions) of the C_rt ladder; default 17.0,19.0,19.5,20.0 at P=300 / 8.4,9.4,9.7,10.0 at P=600")
     ap.add_argument("--no-dropin", action="store_true", help="skip the legs through the filter.h drop-in")
     ap.add_argument("--dropin-blocks", type=int, default=500)
     ap.add_argument("--no-crt-pcie", action="store_true", help="skip the C_rt probes with the host link in the loop")
@@ -658,7 +658,7 @@ def main():
         elif args.crt_channels:
             crt_n = [args.crt_channels]
         else:
-            crt_n = [17_000_000, 18_500_000, 19_500_000] if P == 300 else [8_400_000, 9_200_000, 9_800_000]
+            crt_n = [17_000_000, 19_000_000, 19_500_000, 20_000_000] if P == 300 else [8_400_000, 9_400_000, 9_700_000, 10_000_000]
         if comm is not None:
             # the big bank's channels span the whole spectrum on every rank: whole-slot broadcast, whatever the headline leg moved
             def run_one(job):

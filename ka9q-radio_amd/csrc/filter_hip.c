@@ -104,7 +104,14 @@ struct mctx {
   /* What the channel threads sleep on: a per-slot generation word, bumped after every publication in the slot (a completed
      block: completed_jobs[slot]; a skipped one: skipped[slot][..]).  A sleeper reads it BEFORE it looks at either, so a
      publication between its look and its sleep cannot be missed. */
-  unsigned gen[ND];
+#define WSHARDS_MAX 64
+  /* Every slave sleeps on the word of its shard (sctx.shard).  1000+ sleepers on ONE futex word share one kernel hash bucket
+     and one wake loop: measured on a 256-core host at 1024 channel threads (profiles/r03_dropin_wake.txt), one word 2.4 ms per block, 8 words 1.2, 32 words 0.98 (and the
+     worst block 1.2 instead of 27 ms); helper threads that wake the shards side by side were slower again (an extra scheduling
+     hop: 6 ms at 2000 threads against 2.5), as was passing the wake-up on from thread to thread in a tree (10 ms). */
+  struct { unsigned v; char pad[60]; } gen[ND][WSHARDS_MAX];
+  int wshards;                      /* words in use (KA9Q_HIP_WAKE_SHARDS, default 32) */
+  int next_shard;
   /* what the DEVICE holds per slot: the last job enqueued there and the last one whose completion callback has run.  The slot's
      completion record, spectrum, staged outputs and host-ring window belong to the enqueued job until the two agree. */
   unsigned enq_seq[ND];             /* blocks enqueued in the slot so far (producer only) */
@@ -140,6 +147,7 @@ struct sctx {
   int idx;                          /* channel index inside the bank */
   unsigned epoch;                   /* bumped whenever the response changes */
   double n0;                        /* the device's noise estimate of the block this slave consumed last (NaN: none) */
+  int shard;                        /* which of the master's wake words this slave sleeps on */
 };
 
 struct hbank;
@@ -264,6 +272,15 @@ static double complex cis_pi(double x) {       /* e^{i pi x}, argument reduced i
 /* ------------------------------------------------------------------------- */
 /* completion: runs on a HIP runtime thread after the block's work has drained   */
 /* ------------------------------------------------------------------------- */
+/* announce a publication in `slot` to every sleeper: bump the shard words, then wake them */
+static void announce(struct mctx *c, int slot, bool everybody) {
+  for (int k = 0; k < c->wshards; k++) __atomic_fetch_add(&c->gen[slot][k].v, 1u, __ATOMIC_RELEASE);
+  for (int k = 0; k < c->wshards; k++) {
+    if (c->wake_first > 0 && !everybody) futex_wake_n(&c->gen[slot][k].v, c->wake_first);
+    else futex_wake_all(&c->gen[slot][k].v);
+  }
+}
+
 static void block_done(void *arg) {
   struct done_note *n = arg;
   struct filter_in *f = n->ctx->master;
@@ -283,9 +300,7 @@ static void block_done(void *arg) {
   __atomic_store_n(&f->completed_jobs[job % ND], job, __ATOMIC_RELEASE);   /* src/filter.c:526-529 */
   pthread_cond_broadcast(&f->filter_cond);              /* src/filter.c:532-535 (kept; nobody in this build waits on it) */
   pthread_mutex_unlock(&f->filter_mutex);
-  __atomic_fetch_add(&c->gen[job % ND], 1u, __ATOMIC_RELEASE);
-  if (c->wake_first > 0) futex_wake_n(&c->gen[job % ND], c->wake_first);
-  else futex_wake_all(&c->gen[job % ND]);
+  announce(c, (int)(job % ND), false);
   __atomic_store_n(&c->dev_seq[job % ND], seq, __ATOMIC_RELEASE);      /* the slot is the producer's again */
   futex_wake_n(&c->dev_seq[job % ND], 1);
   int64_t ns = (t1.tv_nsec - t0.tv_nsec) + 1000000000LL * (t1.tv_sec - t0.tv_sec);
@@ -427,6 +442,8 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   c->wake_first = 0; c->wake_fan = 2;
   { const char *wk = getenv("KA9Q_HIP_WAKE"); int a = 0, b = 2; if (wk && sscanf(wk, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0) { c->wake_first = a; c->wake_fan = b; } }
   { const char *pf = getenv("KA9Q_HIP_PROFILE"); c->profile = pf && pf[0] == '1'; }
+  c->wshards = 32;
+  { const char *ws = getenv("KA9Q_HIP_WAKE_SHARDS"); if (ws) { int v = atoi(ws); if (v >= 1 && v <= WSHARDS_MAX) c->wshards = v; } }
   { const char *ns = getenv("KA9Q_HIP_NOISE_SAMPRATE"); if (ns && atof(ns) > 0) c->noise_samprate = atof(ns); }
   pthread_mutex_init(&c->lock, NULL);
   for (int i = 0; i < STAGE_SHARDS; i++) pthread_rwlock_init(&c->stage_lock[i].l, NULL);
@@ -568,6 +585,7 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
     }
     struct hbank *b = &c->banks[bi];
     sc->bank = bi; sc->idx = b->n; sc->epoch = 1; sc->n0 = NAN;
+    sc->shard = c->next_shard++ % c->wshards;
     b->slaves[b->n] = slave; b->shift[b->n] = 0;
     for (int s = 0; s < ND; s++) b->stage_epoch[s][b->n] = 0;
     b->n++;
@@ -678,8 +696,7 @@ int execute_filter_input(struct filter_in *const f) {
     __atomic_store_n(&c->skipped[slot][(job / ND) % SKIP_RING], ((uint64_t)1 << 32) | job, __ATOMIC_RELEASE);
     c->n_skipped++;
     pthread_mutex_unlock(&c->lock);
-    __atomic_fetch_add(&c->gen[slot], 1u, __ATOMIC_RELEASE);
-    futex_wake_all(&c->gen[slot]);
+    announce(c, slot, true);
     return rc == 0 ? 0 : -1;
   }
   struct done_note *note = &c->note[slot];
@@ -855,7 +872,8 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
      times the scheduler's wake latency cost 10 ms per block at 1024 threads, against 3 ms for one FUTEX_WAKE of everybody
      plus the pass-it-on below.) */
   struct mctx *const mc = (master->fwd_plan && !is_mini_master(master)) ? MCTX(master) : NULL;
-  unsigned *const wake = mc ? &mc->gen[slot] : &master->completed_jobs[slot];
+  int const shard = (mc && slave->rev_plan) ? SCTX(slave)->shard : 0;
+  unsigned *const wake = mc ? &mc->gen[slot][shard].v : &master->completed_jobs[slot];
   bool skipped = false;
   for (;;) {
     unsigned const g = mc ? __atomic_load_n(wake, __ATOMIC_ACQUIRE) : 0u;          /* before looking at what it announces */

@@ -68,7 +68,7 @@ def _plan(rng, n):
 
 
 @pytest.mark.parametrize("san", ["thread", "address"])
-@pytest.mark.parametrize("env", [None, {"HARNESS_RETUNE_MOD": "1"}], ids=["steady", "retune_every_block"])
+@pytest.mark.parametrize("env", [None, {"HARNESS_RETUNE_MOD": "1"}, {"KA9Q_HIP_WAKE_SHARDS": "3"}], ids=["steady", "retune_every_block", "three_wake_shards"])
 def test_dropin_host_code_under_sanitizers(tmp_path, san, env):
     if not _have("-fsanitize=" + san):
         pytest.skip("no -fsanitize=%s runtime in this image" % san)
@@ -79,7 +79,7 @@ def test_dropin_host_code_under_sanitizers(tmp_path, san, env):
     g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
     x = g.generate(nblocks * L)
     plan = _plan(rng, nch)
-    if env:
+    if env and "HARNESS_RETUNE_MOD" in env:
         plan = [(p[0], p[0] + 40 + i, 10 ** 6, 10 ** 6) + p[4:] for i, p in enumerate(plan)]      # two shifts to alternate between
     run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
     r = _run(exe, run_dir, L, M, olen, plan, nblocks, x, env)
@@ -89,7 +89,7 @@ def test_dropin_host_code_under_sanitizers(tmp_path, san, env):
     out = np.fromfile(os.path.join(run_dir, "out.bin"), np.complex64).reshape(nblocks, len(plan), olen)
     spec = np.fromfile(os.path.join(run_dir, "spec.bin"), np.complex64)
     meta = open(os.path.join(run_dir, "meta.txt")).read().split()
-    _check(L, M, olen, P, plan, nblocks, out, spec, dict(zip(meta[::2], meta[1::2])), x, retune_mod=1 if env else 0)
+    _check(L, M, olen, P, plan, nblocks, out, spec, dict(zip(meta[::2], meta[1::2])), x, retune_mod=1 if env and "HARNESS_RETUNE_MOD" in env else 0)
 
 
 @pytest.mark.parametrize("san", ["thread", "address"])
