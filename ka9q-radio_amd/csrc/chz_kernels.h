@@ -1023,10 +1023,12 @@ struct NoiseParams {
   int m_bins, real;       // master bins; real != 0 for a REAL master
   int nbins;              // max(slave bins, Min_noise_bins = 1000)   (:1794-1796)
   int nsort;              // 1024 or 2048: values sorted per channel (64 lanes x 16 or 32 registers)
+  unsigned magic; int dpitch;   // bin -> storage index without a division (chan_layout)
   double scale;           // correction / (master bins * front-end sample rate)   (:1840-1844,1863-1865)
 };
 
 // One wavefront per channel; the window lives in registers, VPL values per lane.
+#define NOISE_KC 4                    /* registers per lane for the values that share the quantile's binade (256 of them) */
 template <int VPL>
 __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
   const int lane = threadIdx.x & 63;
@@ -1054,50 +1056,113 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
   float v[VPL];
   // Coalesced loads (which register a bin lands in does not matter to a selection), all issued before
   // any is consumed: entries past n read the window's first bin and are replaced by +inf afterwards.
+  // (the storage index of a bin without a division: one multiply-high by the layout's reciprocal, as in chan_ifft)
   const float2* __restrict__ sp = p.spec;
-  const int row0 = mbin / p.lay.na, col0 = mbin - row0 * p.lay.na;
+  CHZ_IN_DESC(sdesc, sp);
   float2 x[VPL];
   static_for<VPL>([&](auto rr) {
     constexpr int R = decltype(rr)::value;
     int i = R * 64 + lane;
     if (i >= n) i = 0;
-    int col = col0 + i, row = row0;
-    if (wrap) { int k = mbin + i; if (k >= wrap) k -= wrap; row = 0; col = k; }
-    const int dr = col / p.lay.na;
-    row += dr; col -= dr * p.lay.na;
-    x[R] = sp[(long)row * p.lay.pitch + p.lay.off + col];
+    int k = mbin + i;
+    if (wrap && k >= wrap) k -= wrap;
+    x[R] = CHZ_LOAD2(sdesc, sp, spec_index(p.lay.off, p.magic, p.dpitch, k));
   });
   static_for<VPL>([&](auto rr) {
     constexpr int R = decltype(rr)::value;
     v[R] = (R * 64 + lane < n) ? cnrm_unfused(x[R]) : inf;
   });
-  // quantile(energies, n, 0.10) (:1760-1775): the qi-th and (qi+1)-th smallest energies.  Non-negative
-  // floats order like their bit patterns, so the qi-th smallest is built bit by bit from the top: keep a
-  // bit whenever no more than qi values lie strictly below the candidate.  Counting is one compare per
-  // register, a ballot and a scalar popcount -- no sort, no LDS, no cross-lane data movement.
+  // quantile(energies, n, 0.10) (:1760-1775): the qi-th and (qi+1)-th smallest energies.  Non-negative floats order like
+  // their bit patterns, so the qi-th smallest can be built bit by bit from the top: keep a bit whenever no more than qi
+  // values lie strictly below the candidate; counting is one compare per register, a ballot and a scalar popcount.
+  // Round 2 ran all 31 steps over all VPL registers: 500 vector compares and 1000 scalar instructions per channel, and the
+  // CU's ONE scalar unit was what the kernel waited for (2.4 ns per channel at 1.5 M channels).  Now only the eight exponent
+  // bits are found that way.  The values that share the answer's exponent are few -- the 0.10 quantile sits in the thin lower
+  // tail -- so they are compacted through LDS into 1..NOISE_KC registers per lane, and the 23 mantissa bits are found
+  // over those; a window with more than 64*NOISE_KC values in that one binade carries on over all registers as before.
   const double pos = 0.10 * (double)(n - 1);
   const int qi = (int)floor(pos);
   const double frac = pos - (double)qi;
   unsigned bits[VPL];
   static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; bits[R] = __float_as_uint(v[R]); });
   unsigned ans = 0;
-  for (int bit = 30; bit >= 0; --bit) {
+  int below = 0;                                                    // values strictly below `ans` (wave-uniform)
+  for (int bit = 30; bit >= 23; --bit) {
     const unsigned t = ans | (1u << bit);
     int c = 0;
     static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; c += __popcll(__ballot(bits[R] < t)); });
-    if (c <= qi) ans = t;                                            // wave-uniform
+    if (c <= qi) { ans = t; below = c; }                             // wave-uniform
   }
+  // the binade [ans, ans + 2^23): how many values, and each lane's share of them
+  const unsigned top = ans + (1u << 23);                             // (ans has exponent < 255: +inf padding and NaNs sort above every finite value)
+  int mine = 0;
+  static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; mine += (bits[R] >= ans && bits[R] < top) ? 1 : 0; });
+  int incl = mine;                                                    // inclusive scan over the lanes
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, (unsigned)d); if (lane >= d) incl += o; }
+  const int total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63));
+  const int r = qi - below;                                          // rank of the answer inside the binade, 0 <= r < total
+  unsigned cur = ans;
+  int c_le;                                                          // values <= the answer, all of the window
+  unsigned above = 0x7f800000u;                                      // the smallest value above the answer
+  if (total <= 64 * NOISE_KC) {
+    __shared__ unsigned cand_all[4][64 * NOISE_KC];
+    unsigned* cand = cand_all[(threadIdx.x >> 6) & 3];
+    int at = incl - mine;
+    static_for<VPL>([&](auto rr) {
+      constexpr int R = decltype(rr)::value;
+      if (bits[R] >= ans && bits[R] < top) { cand[at] = bits[R]; at++; }
+    });
+    CHZ_WAVE_SYNC();
+    unsigned cv[NOISE_KC];
+    static_for<NOISE_KC>([&](auto jj) {
+      constexpr int J = decltype(jj)::value;
+      cv[J] = (J * 64 + lane < total) ? cand[J * 64 + lane] : 0xffffffffu;
+    });
+    int cl = 0;
+    if (total <= 64) {                                               // the usual case: one value per lane
+      for (int bit = 22; bit >= 0; --bit) {
+        const unsigned t = cur | (1u << bit);
+        if (__popcll(__ballot(cv[0] < t)) <= r) cur = t;
+      }
+      cl = __popcll(__ballot(cv[0] <= cur));
+      if (cv[0] > cur && cv[0] < above) above = cv[0];
+    } else {
+      for (int bit = 22; bit >= 0; --bit) {
+        const unsigned t = cur | (1u << bit);
+        int c = 0;
+        static_for<NOISE_KC>([&](auto jj) { constexpr int J = decltype(jj)::value; c += __popcll(__ballot(cv[J] < t)); });   // (unused registers hold 0xffffffff)
+        if (c <= r) cur = t;
+      }
+      static_for<NOISE_KC>([&](auto jj) {
+        constexpr int J = decltype(jj)::value;
+        cl += __popcll(__ballot(cv[J] <= cur)); if (cv[J] > cur && cv[J] < above) above = cv[J];
+      });
+    }
+    c_le = below + cl;
+    if (frac != 0.0 && c_le < qi + 2 && cl == total) {
+      // the next order statistic lies beyond this binade (rare): the smallest value of the rest of the window
+      static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; if (bits[R] >= top && bits[R] < above) above = bits[R]; });
+    }
+  } else {
+    for (int bit = 22; bit >= 0; --bit) {
+      const unsigned t = cur | (1u << bit);
+      int c = 0;
+      static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; c += __popcll(__ballot(bits[R] < t)); });
+      if (c <= qi) cur = t;
+    }
+    c_le = 0;
+    static_for<VPL>([&](auto rr) {
+      constexpr int R = decltype(rr)::value;
+      c_le += __popcll(__ballot(bits[R] <= cur));
+      if (bits[R] > cur && bits[R] < above) above = bits[R];
+    });
+  }
+  ans = cur;
   const double q1 = (double)__uint_as_float(ans);
   double q = q1;
   if (frac != 0.0) {
     // the next order statistic: q1 again if it occurs more than once beyond rank qi, else the smallest value above it
-    int c_le = 0;
-    unsigned above = 0x7f800000u;
-    static_for<VPL>([&](auto rr) {
-      constexpr int R = decltype(rr)::value;
-      c_le += __popcll(__ballot(bits[R] <= ans));
-      if (bits[R] > ans && bits[R] < above) above = bits[R];
-    });
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const unsigned o = __shfl_xor(above, d); above = o < above ? o : above; }
     const double q2 = c_le >= qi + 2 ? q1 : (double)__uint_as_float(above);
@@ -1106,11 +1171,16 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
     q = q1 + fq;
   }
   const double cut = 1.5 * q;
+  // (double)x <= cut for a float x  <=>  x <= the largest float not above cut: one integer compare per value instead of a
+  // conversion and a double compare
+  float cf = (float)cut;
+  if ((double)cf > cut) cf = __uint_as_float(__float_as_uint(cf) - 1u);        // cut > 0 here, or cut == 0 == cf
+  const unsigned cb = cut >= 0.0 ? __float_as_uint(cf) : 0u;
+  const bool none = !(cut >= 0.0);
   double e = 0.0; int cnt = 0;
   static_for<VPL>([&](auto rr) {
     constexpr int R = decltype(rr)::value;
-    const double x = (double)v[R];
-    if (x <= cut) { e += x; cnt++; }                                 // the +inf padding never qualifies
+    if (!none && bits[R] <= cb) { e += (double)v[R]; cnt++; }        // the +inf padding never qualifies
   });
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { e += __shfl_xor(e, d); cnt += __shfl_xor(cnt, d); }
@@ -1164,6 +1234,8 @@ struct DemodParams {
   int ch0, nch, olen, pcm_stride;
   unsigned job;
   double blocktime, power_alpha;
+  float2* mix;               // [cap][olen] or nullptr: the coherent modes' blocks after their PLL (written by pll_lanes, one CHANNEL PER LANE);
+                             // nullptr: lane 0 of each channel's wavefront walks the block inside demod_linear_tail (round 2's way)
 };
 
 // G.711 companding as send_output() applies it (float_to_mulaw / float_to_alaw, src/rtp.c:459-483,500-533): clamp, 16-bit
@@ -1507,6 +1579,91 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
   if (lane == 0) { demod_publish(p, ch, r); p.state[ch] = st; }
 }
 
+// The carrier PLL of the coherent modes (src/linear.c:83-153, loop src/osc.c:75-205) at ONE CHANNEL PER LANE.  The loop is a
+// recurrence through a non-linear phase detector -- ~1.3 us of dependent double-precision arithmetic per sample -- so a
+// wavefront that walks one channel keeps 1 lane of 64 busy (round 2: 330 us per 1024 channels, 0.5 M channels per 20 ms).  Here
+// 64 channels' blocks are transposed through LDS, tile by tile, and the 64 lanes run their loops side by side; the mixed
+// blocks go back to memory (p.mix) the same way, the loop's results to DemodExt, and demod_linear_tail picks both up.
+// Statement for statement the loop of demod_linear_tail's lane-0 path: the results are bit-identical.
+#define PLL_TILE 32
+__global__ void __launch_bounds__(64, 4) pll_lanes(DemodParams p) {
+  HIP_DYNAMIC_SHARED(float2, tile)                         // [64][PLL_TILE + 1]
+  const int lane = (int)threadIdx.x;
+  const int base = p.ch0 + (int)blockIdx.x * 64;           // first channel of this workgroup
+  const int ch = base + lane;
+  const int N = p.olen;
+  const bool active = (int)blockIdx.x * 64 + lane < p.nch && p.chan[ch].on && p.chan[ch].kind == 0 && p.chan[ch].pll_enable != 0;
+  const unsigned long long act = __ballot(active);
+  if (act == 0ull) return;                                 // wave-uniform
+  PllState q; DemodExt* __restrict__ ext = p.ext + ch;
+  int isamprate = 1, lock_limit = 0; bool square = false;                       // (only the few members the loop reads: the record is 200 bytes)
+  double signal = 0.0, noise = 0.0, pll_foff = 0.0, sq_open = 0.0, sq_close = 0.0;
+  if (active) {
+    const DemodChan* __restrict__ c = p.chan + ch;
+    q = ext->pll;
+    isamprate = (int)c->samprate; square = c->pll_square != 0; sq_open = c->squelch_open; sq_close = c->squelch_close;
+    lock_limit = (int)rint(0.5 * isamprate);                                  // DEFAULT_PLL_LOCKTIME (src/linear.c:6,38-40)
+    double bw = c->pll_loop_bw / isamprate;
+    if (q.lock) bw *= 0.1;
+    pll_set_params(q, bw, M_SQRT1_2);                                          // DEFAULT_PLL_DAMPING (:5)
+    pll_foff = ext->foffset;
+  }
+  constexpr int LD = PLL_TILE + 1;
+  for (int t0 = 0; t0 < N; t0 += PLL_TILE) {
+    const int tn = N - t0 < PLL_TILE ? N - t0 : PLL_TILE;
+    // in: row r = channel base + r, PLL_TILE consecutive samples per row, two rows per wavefront load
+    for (int r0 = 0; r0 < 64; r0 += 64 / PLL_TILE) {
+      const int r = r0 + lane / PLL_TILE, n = lane % PLL_TILE;
+      if (((act >> r) & 1ull) && n < tn) tile[r * LD + n] = p.in[(size_t)(base + r) * N + t0 + n];
+    }
+    CHZ_WAVE_SYNC();
+    if (active) {
+      for (int n = 0; n < tn; n++) {
+        double sn, cs; pll_nco(q.vco_phase, sn, cs);
+        const float2 v = tile[lane * LD + n];
+        const double br = v.x, bi = v.y;
+        const double sr = br * cs + bi * sn, si = bi * cs - br * sn;           // buffer[n] * conj(vco)
+        tile[lane * LD + n] = make_float2((float)sr, (float)si);
+        double phase;
+        if (q.lock) {
+          if (!square) { const double mag = sqrt(sr * sr + si * si); phase = (mag > 0) ? si / mag : 0.0; }
+          else phase = sr * si / (sr * sr - si * si);
+        } else {
+          if (!square) phase = atan2(si, sr);
+          else phase = 0.5 * atan2(sr * si + si * sr, sr * sr - si * si);      // carg(s*s)
+        }
+        phase /= (2 * M_PI);
+        pll_foff = isamprate * pll_run(q, phase);
+        signal += sr * sr; noise += si * si;
+      }
+    }
+    CHZ_WAVE_SYNC();
+    for (int r0 = 0; r0 < 64; r0 += 64 / PLL_TILE) {
+      const int r = r0 + lane / PLL_TILE, n = lane % PLL_TILE;
+      if (((act >> r) & 1ull) && n < tn) p.mix[(size_t)(base + r) * N + t0 + n] = tile[r * LD + n];
+    }
+    CHZ_WAVE_SYNC();
+  }
+  if (active) {
+    double pll_snr;
+    const double pll_cph = ldexp(2 * M_PI * (double)q.vco_phase, -32);
+    int pll_rot = q.wraps;
+    if (noise != 0) { pll_snr = (signal / noise) - 1; if (pll_snr < 0) pll_snr = 0; }
+    else pll_snr = __builtin_nan("");
+    if (pll_snr < sq_close) {
+      q.lock_count -= N;
+      if (q.lock_count <= -lock_limit) { q.lock_count = -lock_limit; q.lock = 0; }
+    } else if (pll_snr > sq_open) {
+      q.lock_count += N;
+      if (q.lock_count >= lock_limit) {
+        q.lock_count = lock_limit;
+        if (!q.lock) { q.lock = 1; pll_rot = 0; }
+      }
+    }
+    ext->pll = q; ext->pll_snr = pll_snr; ext->pll_cphase = pll_cph; ext->foffset = pll_foff; ext->pll_rotations = pll_rot;
+  }
+}
+
 __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   HIP_DYNAMIC_SHARED(double, esh)                          // [N] per-sample energies (AGC slices), then [N] complex samples (PLL modes)
   const int lane = (int)threadIdx.x;
@@ -1533,7 +1690,14 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   // looks at it.  The block goes to LDS, lane 0 walks it, the mixed samples replace it there.
   const bool pll = c.pll_enable != 0;                      // wave-uniform
   double pll_snr = 0.0, pll_cph = 0.0, pll_foff = 0.0; int pll_lock = 0, pll_rot = 0;
-  if (pll) {
+  if (pll && p.mix != nullptr) {
+    // pll_lanes has run this channel's loop already (one channel per lane): the mixed block and the loop's results are in memory
+    const DemodExt* __restrict__ ext = p.ext + ch;
+    const float2* __restrict__ m = p.mix + (size_t)ch * N;
+    for (int i = 0; i < cnt; i++) xs[n0 + i] = m[n0 + i];
+    pll_snr = ext->pll_snr; pll_cph = ext->pll_cphase; pll_foff = ext->foffset; pll_lock = ext->pll.lock; pll_rot = ext->pll_rotations;
+    CHZ_WAVE_SYNC();
+  } else if (pll) {
     DemodExt* __restrict__ ext = p.ext + ch;
     for (int i = 0; i < cnt; i++) xs[n0 + i] = x[n0 + i];
     CHZ_WAVE_SYNC();

@@ -132,6 +132,17 @@ inline int launch_demod(hipStream_t s, const DemodParams& p, hipEvent_t e0 = nul
     if (big < 0) big = big_lds_prepare(reinterpret_cast<const void*>(demod_linear_tail)) == 0 ? 1 : 0;
     if (big != 1) return -1;
   }
+  // the carrier PLLs of the coherent modes first, one channel per lane (only when the caller provided the scratch block: the
+  // engine does as soon as a channel of the bank asks for a PLL)
+  if (p.mix != nullptr) {
+    const size_t tl = sizeof(float2) * 64 * (PLL_TILE + 1);
+    if (e0) {                                   // timed together: the pair's first dispatch starts the clock, its second stops it
+      hipExtLaunchKernelGGL(pll_lanes, dim3((p.nch + 63) / 64), dim3(64), (unsigned)tl, s, e0, nullptr, 0, p);
+      hipExtLaunchKernelGGL(demod_linear_tail, dim3(p.nch), dim3(64), (unsigned)lds, s, nullptr, e1, 0, p);
+      return 0;
+    }
+    hipLaunchKernelGGL(pll_lanes, dim3((p.nch + 63) / 64), dim3(64), tl, s, p);
+  }
   CHZ_LAUNCH(demod_linear_tail, p.nch, 64, lds, s, e0, e1, p);
   return 0;
 }

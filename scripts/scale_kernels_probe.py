@@ -27,7 +27,8 @@ for c0 in range(0, cap, tile):
     bank.set_tuning(0, c0, shifts + (c0 // tile) % 7, np.full(tile, -3.3 / 12000.0))
 bank.enable_noise(129.6e6)
 bank.set_pcm_stride(2 * olen)
-q = ol.lin_params()
+mode = sys.argv[2] if len(sys.argv) > 2 else "linear"       # "pll": every channel in a coherent mode (carrier PLL, src/linear.c:83-153)
+q = ol.lin_params(pll=(mode == "pll"))
 one = pkg.engine.DemodParams(*[getattr(q, f) for f, _ in ol.LinParams._fields_])
 for c0 in range(0, cap, 65536):
     bank.set_demod(0, c0, [one] * min(65536, cap - c0), 0.02)
@@ -36,7 +37,7 @@ eng.set_notches([0], 0.01)
 eng.run_blocks(0, 8)
 t = eng.run_blocks(8, 16)
 it = eng.run_blocks(0, 16, instrument=True)
-print(json.dumps({"channels": cap, "pipelined_ms_per_block": t.total_ms / 16,
+print(json.dumps({"channels": cap, "mode": mode, "pipelined_ms_per_block": t.total_ms / 16,
                   "chan_ms": it.chan_ms / it.chan_n, "noise_ms": it.notch_ms / it.notch_n if it.notch_n else None,
                   "demod_ms": it.demod_ms / it.demod_n if it.demod_n else None,
                   "ns_per_channel": {"chan": it.chan_ms / it.chan_n * 1e6 / cap, "noise": (it.notch_ms / it.notch_n * 1e6 / cap) if it.notch_n else None,

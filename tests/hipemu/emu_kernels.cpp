@@ -223,6 +223,7 @@ int emu_noise(const float* spec, int m_bins, int in_type, int s_bins, int nch, c
   std::vector<ChanDesc> desc((size_t)nch);
   for (int i = 0; i < nch; i++) desc[(size_t)i] = ChanDesc{0, 0, 0, 1, 0, 0, i, shifts[i]};
   q.spec = spec_dev.data(); q.lay = lay; q.desc = desc.data(); q.n0 = n0; q.ch0 = 0; q.nch = nch;
+  { ChanParams cp{}; if (!chan_layout(cp, lay, m_bins)) return -2; q.magic = cp.magic; q.dpitch = cp.dpitch; }
   return launch_noise(nch, nullptr, q);   // -1: window larger than the compiled sorts
 }
 
@@ -285,6 +286,10 @@ int emu_demod(const float* in, const double* power, const double* n0, const void
   d.chan = static_cast<const DemodChan*>(chan); d.state = static_cast<DemodState*>(state); d.status = static_cast<DemodStatus*>(status);
   d.ext = static_cast<DemodExt*>(ext); d.flags = nullptr;
   d.pcm = pcm; d.ch0 = 0; d.nch = nch; d.olen = olen; d.pcm_stride = olen * 8; d.job = job; d.blocktime = blocktime; d.power_alpha = 0.10;
+  // the coherent modes' PLLs run one channel per lane in a pass of their own when the scratch block exists (as in the engine);
+  // EMU_PLL_LANE0=1 keeps round 2's path (lane 0 of the channel's wavefront) for the A/B test
+  std::vector<float2> mix;
+  if (ext != nullptr && !getenv("EMU_PLL_LANE0")) { mix.assign((size_t)nch * olen, make_float2(0.f, 0.f)); d.mix = mix.data(); }
   return launch_demod(nullptr, d);
 }
 int emu_demod_sizes(int* out3) { out3[0] = (int)sizeof(DemodChan); out3[1] = (int)sizeof(DemodState); out3[2] = (int)sizeof(DemodStatus); return 0; }

@@ -317,6 +317,36 @@ def test_noise_estimate_kernel(emu, in_type, B, s_bins, lay):
     assert np.allclose(n0, want, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("kind", ["one_binade", "all_equal", "mostly_zero", "two_values", "wide_range", "quantile_at_a_binade_edge"])
+@pytest.mark.parametrize("s_bins", [300, 1500])
+def test_noise_estimate_selection_corner_cases(emu, kind, s_bins):
+    """The rank selection of round 3 (exponent bits over the whole window, mantissa bits over the values of that one binade
+    compacted through LDS, the full-width loop when the binade holds more than 256 values) on windows that stress each branch:
+    every energy in one binade (the fallback), all equal, mostly exact zeros, two distinct values, 60 orders of magnitude, and the
+    next order statistic lying in the NEXT binade."""
+    B = 16201
+    rng = np.random.default_rng(len(kind) * 7 + s_bins)
+    if kind == "one_binade":
+        mag = np.sqrt(rng.uniform(1.0, 1.999, B))
+    elif kind == "all_equal":
+        mag = np.full(B, 3.0)
+    elif kind == "mostly_zero":
+        mag = np.where(rng.random(B) < 0.85, 0.0, rng.uniform(0.5, 2.0, B))
+    elif kind == "two_values":
+        mag = np.where(rng.random(B) < 0.5, 1.0, 4.0)
+    elif kind == "wide_range":
+        mag = 10.0 ** rng.uniform(-15, 15, B)
+    else:
+        # about a tenth of the window just below 2.0 in energy, the rest just above: the two order statistics straddle the edge
+        mag = np.sqrt(np.where(rng.random(B) < 0.1, rng.uniform(1.5, 1.9999, B), rng.uniform(2.0, 2.5, B)))
+    spec = (mag * np.exp(2j * np.pi * rng.random(B))).astype(np.complex64)
+    shifts = np.array([0, 499, 700, 4000, -4000, 9000, B - 800, -(B - 1), 2500, 12000], np.int32)
+    n0 = np.zeros(shifts.size)
+    assert emu.emu_noise(spec.ctypes.data, B, ol.REAL, s_bins, shifts.size, shifts.ctypes.data, 1.296e6, n0.ctypes.data, 135, 144, 4) == 0
+    want = np.array([ol.estimate_noise(spec, ol.REAL, s_bins, int(s), 1.296e6) for s in shifts])
+    assert np.allclose(n0, want, rtol=1e-12, atol=0), (n0, want)
+
+
 @pytest.mark.parametrize("in_type,B", [(ol.REAL, 16201), (ol.COMPLEX, 12000), (ol.COMPLEX, 12001)])
 @pytest.mark.parametrize("P,olen,mode", [(64, 48, "plain"), (250, 200, "plain"), (720, 576, "isb"), (1000, 800, "real"), (2048, 1024, "plain"),
                                          (2700, 2160, "isb"), (9600, 7680, "plain"), (9600, 7680, "real"), (4096, 2048, "real"),
@@ -701,6 +731,44 @@ def test_linear_pll_kernel(emu):
             if st.frame == ol.FRAME_DATA:
                 _check_pcm(p, pcm[i], want, N * p.channels, 2e-6)
     assert all(10 < locked[i] < nblk - 10 for i in range(3)) and locked[3] == 0
+
+
+def test_pll_one_channel_per_lane_equals_one_lane_per_wavefront(emu, monkeypatch):
+    """round 3: the carrier PLLs of a launch run in a pass of their own, one CHANNEL per lane (pll_lanes: 64 channels' blocks
+    transposed through LDS tile by tile), instead of one lane of every channel's wavefront walking its block.  Same statements in
+    the same order: status records, PLL state and PCM must agree BIT FOR BIT, over 150 channels (three workgroups, the last one
+    ragged) of which every third has no PLL and some are FM or switched off."""
+    from test_oracle_vs_reference import _coherent_case
+    nblk, N, bt = 12, 240, 0.02
+    nch = 150
+    kws = [PLL_CASES[i % 4] for i in range(nch)]
+    bb0, pw0 = _coherent_case(np.random.default_rng(3), nblk, N, False)
+    bb1, pw1 = _coherent_case(np.random.default_rng(4), nblk, N, True)
+    results = []
+    for lane0 in (True, False):
+        if lane0:
+            monkeypatch.setenv("EMU_PLL_LANE0", "1")
+        else:
+            monkeypatch.delenv("EMU_PLL_LANE0", raising=False)
+        chan = (_DemodChan * nch)(); state = (_DemodState * nch)(); status = (ol.LinStatus * nch)(); ext = (_DemodExt * nch)()
+        emu.emu_demod_ext_init(ext, nch)
+        for i, kw in enumerate(kws):
+            p = ol.lin_params(**kw)
+            c = chan[i]
+            for f in _CHAN_FIELDS:
+                setattr(c, f, getattr(p, f))
+            c.on = 0 if i % 17 == 5 else 1; c.osc_freq = 0.0
+            state[i].gain = p.gain; state[i].n0 = float("nan"); state[i].squelch_open = 1
+            state[i].squelch_state = (p.squelch_tail + 4) if not (p.snr_squelch or p.pll_enable) else 0
+        pcm = np.zeros((nch, N * 8), np.uint8)
+        trace = []
+        for b in range(nblk):
+            x = np.ascontiguousarray(np.stack([(bb1 if kws[i].get("square") else bb0)[b] * (1 + 0.01 * (i % 7)) for i in range(nch)]).astype(np.complex64))
+            pw = np.array([(pw1 if kws[i].get("square") else pw0)[b] for i in range(nch)]); ne = np.full(nch, 2 * 4e-4 ** 2 / 12000.0)
+            assert emu.emu_demod(x.ctypes.data, pw.ctypes.data, ne.ctypes.data, chan, state, status, pcm.ctypes.data, nch, N, b, bt, ext) == 0
+            trace.append((bytes(status), bytes(ext), pcm.tobytes()))
+        results.append(trace)
+    assert results[0] == results[1]
 
 
 FM2_CASES = [(dict(pll=True, encoding=ol.PCM_F32LE), 0.0), (dict(pll=True, threshold_extend=True), 0.0), (dict(tone_freq=100.0), 100.0),
