@@ -1586,7 +1586,7 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
 // blocks go back to memory (p.mix) the same way, the loop's results to DemodExt, and demod_linear_tail picks both up.
 // Statement for statement the loop of demod_linear_tail's lane-0 path: the results are bit-identical.
 #define PLL_TILE 32
-__global__ void __launch_bounds__(64, 4) pll_lanes(DemodParams p) {
+__global__ void __launch_bounds__(64, 2) pll_lanes(DemodParams p) {
   HIP_DYNAMIC_SHARED(float2, tile)                         // [64][PLL_TILE + 1]
   const int lane = (int)threadIdx.x;
   const int base = p.ch0 + (int)blockIdx.x * 64;           // first channel of this workgroup
