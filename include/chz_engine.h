@@ -255,6 +255,8 @@ int chz_run_blocks_sharded(chz_engine *e, chz_comm *c, int root, int mode, const
 #define CHZ_PCM_F32BE 3
 #define CHZ_PCM_MULAW 4   /* G.711 mu-law, one byte per sample (float_to_mulaw, src/rtp.c:459-483) */
 #define CHZ_PCM_ALAW 5    /* G.711 A-law (float_to_alaw, src/rtp.c:500-533) */
+#define CHZ_PCM_F16LE 6   /* IEEE binary16, round to nearest even (export_f16_le / _be, src/import.h:140-157,207-212; src/audio.c:135-139) */
+#define CHZ_PCM_F16BE 7
 typedef struct chz_demod_params {
   int channels;         /* chan->output.channels: 1 mono, 2 stereo; 0 switches the channel's demodulator off */
   int env;              /* chan->linear.env: envelope (AM) detection */

@@ -1151,8 +1151,9 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
   bool need_ext = false;
   for (int i = 0; i < n; i++) {
     const chz_demod_params& q = p[i];
-    if (q.channels < 0 || q.channels > 2 || q.encoding < CHZ_PCM_S16BE || q.encoding > CHZ_PCM_ALAW) return fail(-1, "bad demodulator parameters for channel %d", ch0 + i);
-    if (q.channels * b.olen * ((q.encoding == CHZ_PCM_MULAW || q.encoding == CHZ_PCM_ALAW) ? 1 : (q.encoding == CHZ_PCM_S16BE || q.encoding == CHZ_PCM_S16LE) ? 2 : 4) > b.pcm_stride)
+    if (q.channels < 0 || q.channels > 2 || q.encoding < CHZ_PCM_S16BE || q.encoding > CHZ_PCM_F16BE) return fail(-1, "bad demodulator parameters for channel %d", ch0 + i);
+    if (q.channels * b.olen * ((q.encoding == CHZ_PCM_MULAW || q.encoding == CHZ_PCM_ALAW) ? 1 :
+                               (q.encoding == CHZ_PCM_S16BE || q.encoding == CHZ_PCM_S16LE || q.encoding == CHZ_PCM_F16LE || q.encoding == CHZ_PCM_F16BE) ? 2 : 4) > b.pcm_stride)
       return fail(-1, "channel %d's PCM does not fit the bank's %d-byte rows (chz_bank_set_pcm_stride)", ch0 + i, b.pcm_stride);
     if (q.channels > 0 && !(q.samprate > 0 && q.headroom > 0 && q.bandwidth > 0 && std::isfinite(q.shift) && q.gain > 0))
       return fail(-1, "bad demodulator parameters for channel %d", ch0 + i);

@@ -1199,7 +1199,7 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
 // restatement (oracle/chz_oracle.c:chzo_lindemod_block), which is pinned to the reference's linear.c itself.
 // The state is a recurrence over BLOCKS: the engine runs these kernels on one in-order stream.
 // ------------------------------------------------------------------------------
-enum { CHZ_PCM_S16BE_K = 0, CHZ_PCM_S16LE_K = 1, CHZ_PCM_F32LE_K = 2, CHZ_PCM_F32BE_K = 3, CHZ_PCM_MULAW_K = 4, CHZ_PCM_ALAW_K = 5 };
+enum { CHZ_PCM_S16BE_K = 0, CHZ_PCM_S16LE_K = 1, CHZ_PCM_F32LE_K = 2, CHZ_PCM_F32BE_K = 3, CHZ_PCM_MULAW_K = 4, CHZ_PCM_ALAW_K = 5, CHZ_PCM_F16LE_K = 6, CHZ_PCM_F16BE_K = 7 };
 struct DemodChan {               // per channel, set by the host (names: the chan_t members src/linear.c reads)
   int channels, env, agc, encoding, snr_squelch, squelch_tail, tuned, on;
   double samprate, headroom, threshold, recovery_rate, hangtime, dc_alpha, bandwidth, squelch_open, squelch_close;
@@ -1258,8 +1258,33 @@ __device__ __forceinline__ void demod_publish(const DemodParams& p, int ch, cons
   p.status[ch] = r;
   if (p.flags != nullptr) p.flags[ch] = (unsigned char)((r.frame & 1) | ((r.mute & 1) << 1) | ((r.pll_lock & 1) << 2) | ((r.tone_mute & 1) << 3));
 }
+// float -> IEEE binary16 bits, round to nearest even: what `float16_t temp_float = in[i]` of export_f16_* does (src/import.h:140-157).
+// The device has the conversion in hardware (v_cvt_f16_f32, RNE); the CPU test emulator (g++ 11: no _Float16) does it by hand.
+__device__ __forceinline__ unsigned short demod_f16_bits(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const _Float16 h = (_Float16)v;
+  unsigned short u; __builtin_memcpy(&u, &h, 2);
+  return u;
+#else
+  const unsigned x = __float_as_uint(v), sign = (x >> 16) & 0x8000u, mag = x & 0x7fffffffu;
+  if (mag >= 0x7f800000u) return (unsigned short)(sign | 0x7c00u | (mag > 0x7f800000u ? 0x200u | ((mag >> 13) & 0x3ffu) : 0u));   // inf / NaN
+  if (mag >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);                        // rounds to or beyond 65520: inf
+  if (mag < 0x33000001u) return (unsigned short)sign;                                      // at or below half the smallest subnormal: +-0
+  const int e = (int)(mag >> 23) - 127;
+  unsigned m = (mag & 0x7fffffu) | 0x800000u;                                              // 24-bit significand
+  const int shift = e < -14 ? 13 + (-14 - e) : 13;                                         // subnormal halves lose more bits
+  const unsigned keep = m >> shift, rest = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  unsigned r = keep + ((rest > half || (rest == half && (keep & 1u))) ? 1u : 0u);
+  const unsigned hb = e < -14 ? r : ((unsigned)(e + 15) << 10) + (r - 0x400u);              // a carry out of the significand lands in the exponent
+  return (unsigned short)(sign | hb);
+#endif
+}
 __device__ __forceinline__ void demod_put(unsigned char* o, int enc, int idx, float v) {
-  if (enc == CHZ_PCM_MULAW_K || enc == CHZ_PCM_ALAW_K) {
+  if (enc == CHZ_PCM_F16LE_K || enc == CHZ_PCM_F16BE_K) {
+    unsigned short u = demod_f16_bits(v);
+    if (enc == CHZ_PCM_F16BE_K) u = (unsigned short)((u >> 8) | (u << 8));
+    reinterpret_cast<unsigned short*>(o)[idx] = u;
+  } else if (enc == CHZ_PCM_MULAW_K || enc == CHZ_PCM_ALAW_K) {
     o[idx] = demod_g711(v, enc == CHZ_PCM_ALAW_K);
   } else if (enc == CHZ_PCM_S16BE_K || enc == CHZ_PCM_S16LE_K) {
     float t = ldexpf(v, 15);                                           // src/import.h:90-94

@@ -46,7 +46,7 @@ class DemodStatus(C.Structure):
                 ("pll_snr", _d), ("pll_cphase", _d), ("tone_deviation", _d), ("pll_rotations", _i), ("tone_mute", _i)]
 
 
-PCM_S16BE, PCM_S16LE, PCM_F32LE, PCM_F32BE, PCM_MULAW, PCM_ALAW = 0, 1, 2, 3, 4, 5
+PCM_S16BE, PCM_S16LE, PCM_F32LE, PCM_F32BE, PCM_MULAW, PCM_ALAW, PCM_F16LE, PCM_F16BE = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 # every symbol include/chz_engine.h declares (checked by tests/test_host_logic.py and __graft_entry__.build())

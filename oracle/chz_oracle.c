@@ -12,6 +12,17 @@
 #include "chz_oracle.h"
 #include "dft.h"
 
+/* cabsf() as the reference's release build computes it: src/Makefile:105-109 compiles with -funsafe-math-optimizations
+   -fcx-limited-range, under which gcc expands cabsf(z) inline to sqrtf(re*re + im*im) in float (two rounded products, a
+   rounded sum, sqrtss) instead of calling libm's hypotf, which works in double.  The two differ in the last bit for about
+   15 % of all arguments -- round 2's "+-1 LSB on < 2 % of the PCM samples" in the envelope modes was this restatement
+   calling libm, not the device (bisected in round 3: every other mode was already bit-exact). */
+static inline float chzo_cabsf(float re, float im) {
+  volatile float a = re * re, b = im * im;      /* (volatile: no contraction into an fma, whatever flags this file is built with) */
+  volatile float s = a + b;
+  return sqrtf(s);
+}
+
 /* Plans are cached per (length, real?) so repeated blocks do not rebuild the
    twiddle tables; tables are built under the lock, execution is lock-free. */
 #define PLAN_CACHE 16
@@ -771,7 +782,27 @@ chzo_lindemod *chzo_lindemod_create(const chzo_lindemod_params *p) {
 void chzo_lindemod_delete(chzo_lindemod *d) { free(d); }
 void chzo_lindemod_set_params(chzo_lindemod *d, const chzo_lindemod_params *p) { double g = d->gain; d->p = *p; d->p.gain = g; }
 
-static int pcm_bytes_per_sample(int enc) { return (enc == CHZO_PCM_MULAW || enc == CHZO_PCM_ALAW) ? 1 : (enc == CHZO_PCM_S16BE || enc == CHZO_PCM_S16LE) ? 2 : 4; }
+static int pcm_bytes_per_sample(int enc) {
+  return (enc == CHZO_PCM_MULAW || enc == CHZO_PCM_ALAW) ? 1 : (enc == CHZO_PCM_S16BE || enc == CHZO_PCM_S16LE || enc == CHZO_PCM_F16LE || enc == CHZO_PCM_F16BE) ? 2 : 4;
+}
+
+/* export_f16_noswap / _swap (src/import.h:140-157): `float16_t temp_float = in[i]` -- the C conversion float -> _Float16, round to
+   nearest even, subnormals kept, overflow to infinity.  Restated in integer arithmetic (the image's gcc 11 has no _Float16 on x86-64;
+   pinned against the reference's own import.h built with clang, tests/test_oracle_vs_reference.py). */
+unsigned short chzo_f32_to_f16(float x) {
+  uint32_t b; memcpy(&b, &x, 4);
+  const uint32_t sign = (b >> 16) & 0x8000u, mag = b & 0x7fffffffu;
+  if (mag >= 0x7f800000u) return (unsigned short)(sign | 0x7c00u | (mag > 0x7f800000u ? 0x200u | ((mag >> 13) & 0x3ffu) : 0u));
+  if (mag >= 0x477ff000u) return (unsigned short)(sign | 0x7c00u);            /* >= 65520: rounds to infinity */
+  if (mag < 0x33000001u) return (unsigned short)sign;                          /* <= 2^-25: rounds to zero */
+  const int e = (int)(mag >> 23) - 127;
+  const uint32_t m = (mag & 0x7fffffu) | 0x800000u;
+  const int shift = e < -14 ? 13 + (-14 - e) : 13;
+  const uint32_t keep = m >> shift, rest = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+  const uint32_t r = keep + ((rest > half || (rest == half && (keep & 1u))) ? 1u : 0u);
+  const uint32_t hb = e < -14 ? r : ((uint32_t)(e + 15) << 10) + (r - 0x400u);
+  return (unsigned short)(sign | hb);
+}
 
 /* src/rtp.c:459-483: clamp to +-1, to 16 bits, sign/magnitude, clip at 32635, bias 132, segment = position of the leading one,
    4 mantissa bits below it, everything inverted */
@@ -814,6 +845,10 @@ static void pcm_pack(int enc, const float *in, int count, unsigned char *out) {
       int16_t v = (int16_t)lrintf(t);
       uint16_t u = (uint16_t)v;
       if (enc == CHZO_PCM_S16BE) u = (uint16_t)((u >> 8) | (u << 8));
+      memcpy(out + 2 * i, &u, 2);
+    } else if (enc == CHZO_PCM_F16LE || enc == CHZO_PCM_F16BE) {
+      uint16_t u = chzo_f32_to_f16(in[i]);
+      if (enc == CHZO_PCM_F16BE) u = (uint16_t)((u >> 8) | (u << 8));
       memcpy(out + 2 * i, &u, 2);
     } else {
       uint32_t u; memcpy(&u, &in[i], 4);
@@ -926,7 +961,7 @@ int chzo_lindemod_block(chzo_lindemod *d, float *buf, int N, double bb_power, do
     if (c->env) {
       double gain = d->gain;
       for (int n = 0; n < N; n++) {
-        double s = gain * M_SQRT1_2 * (double)cabsf(buf[2 * n] + I * buf[2 * n + 1]);
+        double s = gain * M_SQRT1_2 * (double)chzo_cabsf(buf[2 * n], buf[2 * n + 1]);
         gain *= gain_change;
         output_power += s * s;
         if (c->dc_alpha != 0) { d->am_dc += c->dc_alpha * (s - d->am_dc); s -= d->am_dc; }
@@ -948,7 +983,7 @@ int chzo_lindemod_block(chzo_lindemod *d, float *buf, int N, double bb_power, do
       double gain = d->gain;
       for (int n = 0; n < N; n++) {
         double sr = gain * M_SQRT1_2 * (double)buf[2 * n];
-        double si = gain * M_SQRT1_2 * (double)cabsf(buf[2 * n] + I * buf[2 * n + 1]);
+        double si = gain * M_SQRT1_2 * (double)chzo_cabsf(buf[2 * n], buf[2 * n + 1]);
         gain *= gain_change;
         output_power += sr * sr + si * si;
         if (c->dc_alpha != 0) { d->am_dc += c->dc_alpha * (si - d->am_dc); si -= d->am_dc; }
@@ -999,6 +1034,7 @@ int chzo_lindemod_block(chzo_lindemod *d, float *buf, int N, double bb_power, do
   return 0;
 }
 int chzo_pcm_bytes(int encoding, int nsamples) { return pcm_bytes_per_sample(encoding) * nsamples; }
+void chzo_pcm_pack(int encoding, const float *in, int count, unsigned char *out) { pcm_pack(encoding, in, count, out); }
 
 /* ------------------------------------------------------------------ */
 /* SURVEY 8f rank 4, second half: the FM demodulator's per-block work   */
@@ -1072,7 +1108,7 @@ int chzo_fmdemod_block(chzo_fmdemod *d, const float *buf, int N, double bb_power
   } else {                                                                   /* :110-129 */
     double avg_amp = 0;
     double *amplitudes = (double *)malloc(sizeof(double) * (size_t)N);
-    for (int n = 0; n < N; n++) avg_amp += amplitudes[n] = cabsf(buf[2 * n] + I * buf[2 * n + 1]);
+    for (int n = 0; n < N; n++) avg_amp += amplitudes[n] = chzo_cabsf(buf[2 * n], buf[2 * n + 1]);
     avg_amp /= N;
     double fm_variance = 0;
     for (int n = 0; n < N; n++) fm_variance += (amplitudes[n] - avg_amp) * (amplitudes[n] - avg_amp);

@@ -104,7 +104,11 @@ int chzo_stream_push_f64(chzo_stream *s, const float *samples, double *spectrum)
 
 /* ---- the linear demodulator's per-block work (src/linear.c:56-375, PLL of the coherent modes included) and PCM
    packing (src/import.h:88-118).  Field names follow the chan_t members linear.c reads. */
-enum { CHZO_PCM_S16BE = 0, CHZO_PCM_S16LE = 1, CHZO_PCM_F32LE = 2, CHZO_PCM_F32BE = 3, CHZO_PCM_MULAW = 4, CHZO_PCM_ALAW = 5 };
+enum { CHZO_PCM_S16BE = 0, CHZO_PCM_S16LE = 1, CHZO_PCM_F32LE = 2, CHZO_PCM_F32BE = 3, CHZO_PCM_MULAW = 4, CHZO_PCM_ALAW = 5, CHZO_PCM_F16LE = 6, CHZO_PCM_F16BE = 7 };
+/* float -> IEEE binary16 bits, round to nearest even (`float16_t temp_float = in[i]`, src/import.h:140-157) */
+unsigned short chzo_f32_to_f16(float x);
+/* send_output()'s packing of `count` float samples in the given encoding (src/audio.c:117-139, src/import.h) */
+void chzo_pcm_pack(int encoding, const float *in, int count, unsigned char *out);
 /* G.711 companding as send_output() applies it (float_to_mulaw / float_to_alaw, src/rtp.c:459-483,500-533) */
 unsigned char chzo_float_to_mulaw(float x);
 unsigned char chzo_float_to_alaw(float x);

@@ -446,7 +446,7 @@ def ref_convert_i16(samples, scale, randomize=False, avx2=False):
 
 
 # ---- linear demodulator + PCM packing -------------------------------------------------------------
-PCM_S16BE, PCM_S16LE, PCM_F32LE, PCM_F32BE, PCM_MULAW, PCM_ALAW = 0, 1, 2, 3, 4, 5
+PCM_S16BE, PCM_S16LE, PCM_F32LE, PCM_F32BE, PCM_MULAW, PCM_ALAW, PCM_F16LE, PCM_F16BE = 0, 1, 2, 3, 4, 5, 6, 7
 FRAME_DATA, FRAME_SILENCE = 0, 1
 
 
@@ -491,8 +491,38 @@ def fm_params(encoding=PCM_S16BE, snr_squelch=False, squelch_tail=1, samprate=24
                      int(pll), 0, 0.0, float(tone_freq))
 
 
+def f32_to_f16_bits(x):
+    """chzo_f32_to_f16 over an array (the restated float -> binary16 conversion)."""
+    x = np.ascontiguousarray(x, np.float32)
+    fn = oracle().chzo_f32_to_f16
+    fn.argtypes = [C.c_float]; fn.restype = C.c_ushort
+    return np.array([fn(float(v)) for v in x], np.uint16) if x.size < 4096 else _f16_many(x)
+
+
+def _f16_many(x):
+    # through the oracle's PCM packer, which loops in C
+    lib = oracle()
+    if not hasattr(lib, "_f16_pack_ready"):
+        lib.chzo_pcm_pack.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]; lib.chzo_pcm_pack.restype = None
+        lib._f16_pack_ready = True
+    out = np.zeros(x.size, np.uint16)
+    lib.chzo_pcm_pack(PCM_F16LE, x.ctypes.data, x.size, out.ctypes.data)
+    return out
+
+
+def ref_f16():
+    """The reference's own export_f16_* / import_f16_* (oracle/_ref/libka9q_ref_f16.so), or None where it could not be built."""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libka9q_ref_f16.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    lib.ref_export_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]; lib.ref_export_f16.restype = None
+    lib.ref_import_f16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]; lib.ref_import_f16.restype = None
+    return lib
+
+
 def pcm_bytes(encoding, nsamples):
-    return (1 if encoding in (PCM_MULAW, PCM_ALAW) else 2 if encoding in (PCM_S16BE, PCM_S16LE) else 4) * nsamples
+    return (1 if encoding in (PCM_MULAW, PCM_ALAW) else 2 if encoding in (PCM_S16BE, PCM_S16LE, PCM_F16LE, PCM_F16BE) else 4) * nsamples
 
 
 class LinDemod:

@@ -224,7 +224,7 @@ def _pcm_close(p, got, want, nsamp, tol_f):
     if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
         dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
         a, w = got[:2 * nsamp].view(dt).astype(np.int32), want[:2 * nsamp].view(dt).astype(np.int32)
-        return np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02
+        return np.abs(a - w).max() <= 1 and np.mean(a != w) == 0
     dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
     a, w = got[:4 * nsamp].view(dt).astype(np.float64), want[:4 * nsamp].view(dt).astype(np.float64)
     return np.abs(a - w).max() <= tol_f * max(np.abs(w).max(), 1e-30)

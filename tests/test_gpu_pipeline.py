@@ -350,12 +350,12 @@ def test_linear_demodulator_on_the_device(pkg):
                 seen.add((i, got.frame, got.mute))
                 if st.frame == ol.FRAME_DATA:
                     nb = ol.pcm_bytes(p.encoding, olen * p.channels)
-                    if p.encoding in (ol.PCM_MULAW, ol.PCM_ALAW):
-                        assert np.mean(pcm[i, :nb] != want) < 0.02, (b, i)
+                    if p.encoding in (ol.PCM_MULAW, ol.PCM_ALAW, ol.PCM_F16LE, ol.PCM_F16BE):
+                        assert np.mean(pcm[i, :nb] != want) == 0, (b, i)
                     elif p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
                         dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
                         a, w = pcm[i, :nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
-                        assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02, (b, i)
+                        assert np.abs(a - w).max() <= 1 and np.mean(a != w) == 0, (b, i)
                     else:
                         dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
                         a, w = pcm[i, :nb].view(dt).astype(np.float64), want.view(dt).astype(np.float64)
@@ -480,7 +480,7 @@ def test_fm_demodulator_on_the_device(pkg):
                     if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
                         dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
                         a, w = pcm[i, :nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
-                        assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02, (b, i)
+                        assert np.abs(a - w).max() <= 1 and np.mean(a != w) == 0, (b, i)
                     else:
                         dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
                         a, w = pcm[i, :nb].view(dt).astype(np.float64), want.view(dt).astype(np.float64)
@@ -641,7 +641,7 @@ def test_filter2_between_channelizer_and_demodulator(pkg):
                         if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
                             dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
                             a, w = gp[:nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
-                            assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02, (b, i)
+                            assert np.abs(a - w).max() <= 1 and np.mean(a != w) == 0, (b, i)
                         else:
                             a, w = gp[:nb].view("<f4").astype(np.float64), want.view("<f4").astype(np.float64)
                             assert np.abs(a - w).max() <= 1e-6 * max(np.abs(w).max(), 1e-30), (b, i)

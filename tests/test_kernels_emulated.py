@@ -552,7 +552,8 @@ class _DemodState(C.Structure):
 
 DEMOD_CASES = [dict(), dict(channels=2, encoding=ol.PCM_F32LE), dict(env=True, dc_alpha=0.002, encoding=ol.PCM_S16LE),
                dict(channels=2, env=True, dc_alpha=0.01, encoding=ol.PCM_F32BE), dict(agc=False, gain_db=30.0, shift=500.0),
-               dict(snr_squelch=True, squelch_tail=2), dict(tuned=False), dict(encoding=ol.PCM_MULAW), dict(channels=2, encoding=ol.PCM_ALAW)]
+               dict(snr_squelch=True, squelch_tail=2), dict(tuned=False), dict(encoding=ol.PCM_MULAW), dict(channels=2, encoding=ol.PCM_ALAW),
+               dict(encoding=ol.PCM_F16LE), dict(channels=2, env=True, dc_alpha=0.01, encoding=ol.PCM_F16BE)]
 
 
 def test_linear_demodulator_kernel(emu):
@@ -594,12 +595,12 @@ def test_linear_demodulator_kernel(emu):
             assert got.output_power == pytest.approx(st.output_power, rel=2e-7 if p.env else 1e-12, abs=1e-300)
             if st.frame == ol.FRAME_DATA:
                 nb = ol.pcm_bytes(p.encoding, N * p.channels)
-                if p.encoding in (ol.PCM_MULAW, ol.PCM_ALAW):
-                    assert np.mean(pcm[i, :nb] != want) < 0.01, (b, i)
+                if p.encoding in (ol.PCM_MULAW, ol.PCM_ALAW, ol.PCM_F16LE, ol.PCM_F16BE):
+                    assert np.mean(pcm[i, :nb] != want) == 0, (b, i)
                 elif p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
                     dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
                     a, w = pcm[i, :nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
-                    assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.01, (b, i)
+                    assert np.abs(a - w).max() <= 1 and np.mean(a != w) == 0, (b, i)
                 else:
                     dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
                     a, w = pcm[i, :nb].view(dt).astype(np.float64), want.view(dt).astype(np.float64)
@@ -650,7 +651,7 @@ def test_fm_demodulator_kernel(emu):
                 if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
                     dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
                     a, w = pcm[i, :nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
-                    assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.01, (b, i)
+                    assert np.abs(a - w).max() <= 1 and np.mean(a != w) == 0, (b, i)
                 else:
                     dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
                     a, w = pcm[i, :nb].view(dt).astype(np.float64), want.view(dt).astype(np.float64)
@@ -674,10 +675,12 @@ _CHAN_FIELDS = ("channels", "env", "agc", "encoding", "snr_squelch", "squelch_ta
 
 def _check_pcm(p, got_row, want, n_samples, tol_f):
     nb = ol.pcm_bytes(p.encoding, n_samples)
-    if p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
+    if p.encoding in (ol.PCM_F16LE, ol.PCM_F16BE, ol.PCM_MULAW, ol.PCM_ALAW):
+        assert np.array_equal(got_row[:nb], want)
+    elif p.encoding in (ol.PCM_S16BE, ol.PCM_S16LE):
         dt = ">i2" if p.encoding == ol.PCM_S16BE else "<i2"
         a, w = got_row[:nb].view(dt).astype(np.int32), want.view(dt).astype(np.int32)
-        assert np.abs(a - w).max() <= 1 and np.mean(a != w) < 0.02
+        assert np.abs(a - w).max() <= 1 and np.mean(a != w) == 0
     else:
         dt = ">f4" if p.encoding == ol.PCM_F32BE else "<f4"
         a, w = got_row[:nb].view(dt).astype(np.float64), want.view(dt).astype(np.float64)
@@ -820,7 +823,7 @@ def random_demod_channels(seed=99, nblk=30, N=240, fs=12000.0):
     """24 channels with randomly drawn demodulator settings (linear and FM alternating) and their test signals."""
     from test_oracle_vs_reference import _demod_case, _fm_case, _coherent_case
     rng = np.random.default_rng(seed)
-    encs = [ol.PCM_S16BE, ol.PCM_S16LE, ol.PCM_F32LE, ol.PCM_F32BE, ol.PCM_MULAW, ol.PCM_ALAW]
+    encs = [ol.PCM_S16BE, ol.PCM_S16LE, ol.PCM_F32LE, ol.PCM_F32BE, ol.PCM_MULAW, ol.PCM_ALAW, ol.PCM_F16LE, ol.PCM_F16BE]
     params, oracles, bbs, powers, ests = [], [], [], [], []
     for i in range(24):
         enc = encs[int(rng.integers(0, len(encs)))]
