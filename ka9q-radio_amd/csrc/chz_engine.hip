@@ -595,6 +595,9 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* tu
     FirstRealParams a{};
     a.ring = e->ring; a.ring_len = e->ring_len; a.start = start; a.buf = lbuf; a.inner = p.inner;
     a.T = p.T1; a.Ra = p.Ra; a.padk = p.padk1; a.tw_sub = e->tw_sub_a; a.tw_tile = e->tw1_tile; a.tw_col = e->tw1_col;
+#if CHZ_TW_SHUFFLE
+    if (p.T1 != 16) return fail(-4, "this A/B build generates its twiddles across rows of 16 lanes: T1 must be 16");
+#endif
     if (e->ring16) {
       a.ring16 = e->ring16; a.scale16 = e->scale16; a.derand = e->derand; a.new_from = e->M - 1;
       a.energy_part = e->energy_part + (size_t)slot * e->stat_n; a.clip_part = e->clip_part + (size_t)slot * e->stat_n;

@@ -124,6 +124,22 @@ struct FirstRealParams {
   int new_from;
 };
 
+// A/B of the north star's "wavefront-shuffle twiddles" (build with -DCHZ_TW_SHUFFLE=1; tiles of T = 16 columns only): the epilogue's
+// column factors W_N^(ka*cc) are not read from tw_col per lane but generated across each row of 16 lanes -- one broadcast load of
+// the row's base factor, then powers handed from lane to lane in four DPP steps.  Measured slower (profiles/r03_twiddle_ab.jsonl: 8.0 -> 9.3 us
+// for the pass, pipelined block 14.4 -> 15.3 us); a compile-time switch, because even an untaken run-time branch around it cost the pass 1.1 us.
+#ifndef CHZ_TW_SHUFFLE
+#define CHZ_TW_SHUFFLE 0
+#endif
+// value of lane (lane - n) inside the lane's row of 16 (DPP row_shr:n on the device, a plain shuffle on the CPU test emulator)
+template <int N_> __device__ __forceinline__ float row_shr16(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x110 + N_, 0xf, 0xf, false));
+#else
+  return __shfl_up(v, (unsigned)N_);
+#endif
+}
+
 struct ColsParams {
   const float2* in;       // in[(row*NP + n)*inner + col]  (+ ring wrap when in_len != 0)
   long in_len;            // 0, or ring length in float2 (input then starts at in_start)
@@ -247,7 +263,27 @@ __global__ void fwd_first_real(FirstRealParams p) {
     const int k = kr + U * rpi;
     const int kk = (lane_on && k < p.Ra) ? k : 0;
     we1[U] = twt[tile * p.Ra + kk];
+#if !CHZ_TW_SHUFFLE
     we2[U] = reinterpret_cast<const float4*>(twc)[kk * T + pc];   // columns 2pc (even) and 2pc+1 (odd)
+#else
+    {
+      // the row's two base factors (columns 0 and 1: 1/2 and h = -i/2 W_N^ka), the same address in all 16 lanes of the row
+      const float4 b = reinterpret_cast<const float4*>(twc)[kk * T];
+      const float2 h = make_float2(b.z, b.w);
+      const float2 w = make_float2(-2.f * h.y, 2.f * h.x);          // W_N^ka = 2i h
+      float2 g = cmul(w, w);                                        // ratio between neighbouring lanes: W_N^(2 ka)
+      float2 x = make_float2(1.f, 0.f);                             // becomes g^pc
+      { const float2 q = make_float2(row_shr16<1>(x.x), row_shr16<1>(x.y)); if (pc & 1) x = cmul(q, g); }
+      g = cmul(g, g);
+      { const float2 q = make_float2(row_shr16<2>(x.x), row_shr16<2>(x.y)); if (pc & 2) x = cmul(q, g); }
+      g = cmul(g, g);
+      { const float2 q = make_float2(row_shr16<4>(x.x), row_shr16<4>(x.y)); if (pc & 4) x = cmul(q, g); }
+      g = cmul(g, g);
+      { const float2 q = make_float2(row_shr16<8>(x.x), row_shr16<8>(x.y)); if (pc & 8) x = cmul(q, g); }
+      const float2 od = cmul(h, x);
+      we2[U] = make_float4(0.5f * x.x, 0.5f * x.y, od.x, od.y);
+    }
+#endif
   });
 
   unsigned long long energy = 0; unsigned clips = 0;        // int16 input only

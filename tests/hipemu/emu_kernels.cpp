@@ -47,6 +47,9 @@ static int emu_forward_impl(const float* ring, const short* ring16, float scale1
     a.ring = ring; a.ring_len = ring_len; a.start = start; a.buf = buf.data(); a.inner = p.inner;
     a.T = p.T1; a.Ra = p.Ra; a.padk = p.padk1;
     a.tw_sub = F2(p.tw_sub_a); a.tw_tile = F2(p.tw1_tile); a.tw_col = F2(p.tw1_col);
+#if CHZ_TW_SHUFFLE
+    if (p.T1 != 16) return -3;
+#endif
     std::vector<unsigned long long> en((size_t)p.grid1 * (p.block1 / 64), 0ull);
     std::vector<unsigned> cl(en.size(), 0u);
     if (ring16) {

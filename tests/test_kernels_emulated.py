@@ -317,6 +317,28 @@ def test_noise_estimate_kernel(emu, in_type, B, s_bins, lay):
     assert np.allclose(n0, want, rtol=1e-12, atol=0)
 
 
+def test_forward_with_lane_generated_twiddles(emu, tmp_path):
+    """-DCHZ_TW_SHUFFLE=1: the first pass's column factors generated across each row of 16 lanes (base factor broadcast, powers
+    handed on in four DPP steps) instead of read from the table -- the north star's "wavefront-shuffle twiddles", kept as a
+    measured-and-rejected build variant.  Same spectrum within the stated tolerance (a few more roundings per factor)."""
+    so = str(tmp_path / "libchz_emu_twshuffle.so")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-DCHZ_TW_SHUFFLE=1", "-I", EMU_DIR, "-I", CSRC,
+                    os.path.join(EMU_DIR, "emu_kernels.cpp"), "-o", so], check=True)
+    alt = C.CDLL(so)
+    alt.emu_forward.argtypes = emu.emu_forward.argtypes
+    N = 21600                                  # 135 x 160: 80 packed columns, five tiles of 16
+    rng = np.random.default_rng(5)
+    ring = rng.standard_normal(N).astype(np.float32)
+    want = ol.forward(ring, ol.REAL, f64=True)
+    errs = []
+    for lib in (emu, alt):
+        spec = np.zeros(N // 2 + 1, np.complex64)
+        desc = C.create_string_buffer(128)
+        assert lib.emu_forward(ring.ctypes.data, N, 0, N, ol.REAL, b"135x160", spec.ctypes.data, desc, 128, None, None, 0, 0.0) == 0
+        errs.append(rel(spec, want))
+    assert errs[0] < 5e-7 and errs[1] < 1e-6 and errs[1] != errs[0], (errs, desc.value)
+
+
 @pytest.mark.parametrize("kind", ["one_binade", "all_equal", "mostly_zero", "two_values", "wide_range", "quantile_at_a_binade_edge"])
 @pytest.mark.parametrize("s_bins", [300, 1500])
 def test_noise_estimate_selection_corner_cases(emu, kind, s_bins):
