@@ -75,7 +75,7 @@ struct Bank {
   hipEvent_t stage_ev[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};
   bool stage_busy[CHZ_ND] = {false, false, false, false};
   // the linear demodulator behind the channel outputs; allocated by the first chz_bank_set_demod
-  float2* any_scratch = nullptr;         // [ND][cap][2][P]: transform buffers of channel sizes beyond the LDS (chan_any<true>)
+  float2* any_scratch = nullptr;         // [ND][cap][2][P or M]: transform buffers of channel sizes beyond the LDS (chan_any<true>)
   DemodChan* dm_chan = nullptr;          // [cap]
   DemodState* dm_state = nullptr;        // [cap]
   DemodExt* dm_ext = nullptr;            // [cap] PLL / tone-squelch state; allocated when the first channel asks for either
@@ -739,7 +739,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   if (b.g.any) {                       // a size outside the register-tiled menu: one workgroup per channel
     c.m_bins = e->bins; c.m_real = e->in_type == CHZ_REAL;
     if (b.out_real) { c.fine = nullptr; c.power = nullptr; }
-    if (launch_chan_any(b.g, n, st, c, b.tw_sub, b.out_real != 0, b.any_scratch ? b.any_scratch + (size_t)slot * b.cap * 2 * b.P + (size_t)ch0 * 2 * b.P : nullptr,
+    if (launch_chan_any(b.g, n, st, c, b.tw_sub, b.out_real != 0, b.any_scratch ? b.any_scratch + (size_t)slot * b.cap * 2 * b.g.lb + (size_t)ch0 * 2 * b.g.lb : nullptr,
                         IN_E0(in), IN_E1(in))) return fail(-4, "no scratch for P=%d", b.P);
   } else if (b.out_real) {
     c.m_bins = e->bins; c.m_real = e->in_type == CHZ_REAL; c.fine = nullptr; c.power = nullptr; c.stage = 0;
@@ -870,7 +870,7 @@ static int bank_create(chz_engine* e, int P, int olen, int capacity, int out_rea
   if ((long long)olen * e->N % e->L != 0 || (long long)olen * e->N / e->L != P)
     return fail(-1, "P=%d is not olen*N/L for olen=%d N=%d L=%d", P, olen, e->N, e->L);
   Bank b;
-  if (!build_chan_geom(P, b.g)) return fail(-3, "no channel kernel for P=%d (needs a size without a prime factor above 13, up to %d points)", P, CHZ_ANY_MAX_P);
+  if (!build_chan_geom(P, b.g)) return fail(-3, "no channel kernel for P=%d (8 to %d points)", P, CHZ_ANY_MAX_P);
   HIPOK(hipSetDevice(e->device));
   // a failed allocation (the C_rt-sized banks take > 100 GB) must not leak the earlier ones
   struct Guard { Bank* b; ~Guard() { if (b) free_bank(*b); } } guard{&b};
@@ -895,7 +895,7 @@ static int bank_create(chz_engine* e, int P, int olen, int capacity, int out_rea
   if (r) return r;
   if (b.g.any && chan_any_prepare()) return fail(-3, "the runtime refuses %zu bytes of LDS per workgroup (P=%d)", b.g.lds, P);
   if (b.g.big) {
-    const size_t bytes = sizeof(float2) * (size_t)CHZ_ND * capacity * 2 * (size_t)P;
+    const size_t bytes = sizeof(float2) * (size_t)CHZ_ND * capacity * 2 * (size_t)b.g.lb;
     if (bytes > ((size_t)16 << 30)) return fail(-2, "%d channels of %d points need %zu bytes of transform scratch", capacity, P, bytes);
     HIPOK(hipMalloc((void**)&b.any_scratch, bytes));
   }

@@ -2097,18 +2097,23 @@ __global__ void __launch_bounds__(256) mini_ovs(MiniParams p) {
 // BIG: P beyond what two buffers in LDS hold (10240 < P <= 65536: 768 kHz ... 1.5 MHz channels): the two buffers live in a
 // per-workgroup piece of global scratch instead, which the L2 keeps; everything else is the same code.  (Within a workgroup
 // a barrier orders global memory as it orders LDS: the wavefronts of a workgroup share their CU's vector cache.)
-struct AnyParams { ChanParams c; MiniParams m; int real_out; float2* scratch; };
+// Bluestein (P with a prime factor above 13): m describes the M-point transform (M = 2^k >= 2P - 1); m.tw holds W_M [M], then the chirp
+// w_n = e^{+i pi n^2 / P} [P], then F(b) [M] with b_m = conj(w_m) wrapped around M.  With a = Y w (the gathered, filtered bins
+// times the chirp), the P-point backward transform is  X_n = w_n * (a (*) b)_n : two M-point transforms with the one set of
+// backward stages (the forward one as conj B conj), a pointwise product, a second chirp.
+struct AnyParams { ChanParams c; MiniParams m; int real_out; float2* scratch; int P; };
 
 template <bool BIG>
 __global__ void __launch_bounds__(1024) chan_any(AnyParams q) {
   HIP_DYNAMIC_SHARED(float2, lds)
   const ChanParams& p = q.c;
   const int tid = threadIdx.x, nthr = blockDim.x;
-  const int P = q.m.N;
+  const int P = q.P;
+  const int LB = q.m.N;                                     // points per buffer: P, or Bluestein's M
   if ((int)blockIdx.x >= p.nch) return;
   const int ch = p.ch0 + (int)blockIdx.x;
-  float2* A = BIG ? q.scratch + (size_t)blockIdx.x * 2 * (size_t)P : lds;
-  float2* B = A + P;
+  float2* A = BIG ? q.scratch + (size_t)blockIdx.x * 2 * (size_t)LB : lds;
+  float2* B = A + LB;
   const ChanDesc d = p.desc[ch];
   const float2* __restrict__ H = p.resp + (long)d.row * P;
   const float2* __restrict__ X = p.spec;
@@ -2161,9 +2166,30 @@ __global__ void __launch_bounds__(1024) chan_any(AnyParams q) {
     }
     __syncthreads();
   }
-  float2* Y = mini_fft<+1>(A, B, q.m, tid, nthr);
-  float2* W = (Y == A) ? B : A;                             // free again: reduction scratch
+  float2* Y; float2* W;
   const int drop = P - p.olen;
+  if (LB == P) {
+    Y = mini_fft<+1>(A, B, q.m, tid, nthr);
+    W = (Y == A) ? B : A;                                   // free again: reduction scratch
+  } else {                                                  // workgroup-uniform: Bluestein
+    const float2* __restrict__ chirp = q.m.tw + LB;
+    const float2* __restrict__ fb = chirp + P;
+    for (int i = tid; i < LB; i += nthr) {                  // conj(a), zero-padded to M
+      float2 v = make_float2(0.f, 0.f);
+      if (i < P) { v = cmul(A[i], chirp[i]); v.y = -v.y; }
+      A[i] = v;
+    }
+    __syncthreads();
+    float2* X1 = mini_fft<+1>(A, B, q.m, tid, nthr);        // B(conj a) = conj F(a)
+    float2* O1 = (X1 == A) ? B : A;
+    for (int j = tid; j < LB; j += nthr) { float2 v = X1[j]; v.y = -v.y; X1[j] = cmul(v, fb[j]); }   // F(a) F(b)
+    __syncthreads();
+    float2* X2 = mini_fft<+1>(X1, O1, q.m, tid, nthr);      // M (a (*) b)
+    const float inv = 1.0f / (float)LB;
+    for (int n = drop + tid; n < P; n += nthr) { const float2 v = cmul(X2[n], chirp[n]); X2[n] = make_float2(v.x * inv, v.y * inv); }   // in place
+    __syncthreads();
+    Y = X2; W = (X2 == A) ? B : A;
+  }
   if (q.real_out) {
     float* __restrict__ o = reinterpret_cast<float*>(p.out) + (long)ch * p.olen;
     for (int n = tid; n < p.olen; n += nthr) o[n] = Y[drop + n].x;

@@ -89,7 +89,8 @@ inline int launch_chan_any(const ChanGeom& g, int nch, hipStream_t s, const Chan
   if (g.big && !scratch) return -1;
   AnyParams q{};
   q.c = p; q.real_out = real_out ? 1 : 0; q.scratch = scratch;
-  q.m.N = g.P; q.m.olen = p.olen; q.m.nstages = g.nstages; q.m.tw = tw;
+  q.P = g.P;
+  q.m.N = g.lb; q.m.olen = p.olen; q.m.nstages = g.nstages; q.m.tw = tw;
   for (int i = 0; i < g.nstages; i++) q.m.radix[i] = g.radix[i];
   if (g.big) { CHZ_LAUNCH(chan_any<true>, nch, g.any_threads, 0, s, e0, e1, q); }
   else { CHZ_LAUNCH(chan_any<false>, nch, g.any_threads, g.lds, s, e0, e1, q); }

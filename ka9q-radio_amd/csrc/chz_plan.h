@@ -10,6 +10,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <complex>
 
 namespace chz {
 
@@ -291,17 +292,63 @@ struct ChanGeom {
   // channel, Stockham stages in LDS (chan_any)
   bool any = false, big = false;
   int any_threads = 0, nstages = 0, radix[CHZ_MINI_MAX_STAGES] = {0};
-  std::vector<f2> tw_any;   // [P] e^{-2 pi i k / P}
+  std::vector<f2> tw_any;   // [P] e^{-2 pi i k / P}; Bluestein: [M] e^{-2 pi i k / M}, then the chirp [P], then F(b) [M]
+  // P WITH a prime factor above 13 (FFTW plans any size, src/filter.c:101-163; so does this): Bluestein's chirp-z identity turns
+  // the P-point backward transform into a circular convolution of M >= 2P - 1 points, M a power of two, run by the same Stockham
+  // stages -- two M-point transforms and two chirp multiplications per channel and block (chan_any).
+  int blue_M = 0;
+  int lb = 0;               // points per transform buffer: P, or M for Bluestein
 };
+// host-side double-precision radix-2 transform for Bluestein's F(b) (M a power of two, forward sign)
+inline void host_fft_pow2(std::vector<std::complex<double>>& x) {
+  const size_t n = x.size();
+  for (size_t i = 1, j = 0; i < n; i++) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) std::swap(x[i], x[j]);
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    for (size_t i = 0; i < n; i += len)
+      for (size_t k = 0; k < len / 2; k++) {
+        const double ang = -2.0 * M_PI * (double)k / (double)len;
+        const std::complex<double> w(std::cos(ang), std::sin(ang));
+        const std::complex<double> u = x[i + k], v = x[i + k + len / 2] * w;
+        x[i + k] = u + v; x[i + k + len / 2] = u - v;
+      }
+  }
+}
 inline bool build_chan_geom(int P, ChanGeom& g) {
   if (!chan_menu_lookup(P, &g.r)) {
-    if (P < 8 || P > CHZ_ANY_MAX_P || !mini_factor(P, g.radix, &g.nstages)) return false;     // no prime factor above 13
+    if (P < 8 || P > CHZ_ANY_MAX_P) return false;
     g.P = P; g.any = true;
-    g.any_threads = P <= 1024 ? 128 : P <= 2048 ? 256 : P <= 4096 ? 512 : 1024;
-    g.big = P > CHZ_ANY_LDS_P;
-    g.lds = g.big ? 0 : sizeof(f2) * 2 * (size_t)P;
-    g.tw_any.resize((size_t)P);
-    for (int k = 0; k < P; k++) g.tw_any[(size_t)k] = root_of_unity(k, P, -1);
+    if (!mini_factor(P, g.radix, &g.nstages)) {                 // a prime factor above 13: Bluestein over M = 2^k >= 2P - 1
+      int M = 16;
+      while (M < 2 * P - 1) M <<= 1;
+      if (!mini_factor(M, g.radix, &g.nstages)) return false;
+      g.blue_M = M;
+      g.tw_any.resize((size_t)M + (size_t)P + (size_t)M);
+      for (int k = 0; k < M; k++) g.tw_any[(size_t)k] = root_of_unity(k, M, -1);
+      // chirp w_n = e^{+i pi n^2 / P}, the angle reduced exactly: n^2 mod 2P over 2P
+      std::vector<std::complex<double>> b((size_t)M, std::complex<double>(0.0, 0.0));
+      for (long long n = 0; n < P; n++) {
+        const long long q = (n * n) % (2LL * P);
+        g.tw_any[(size_t)M + (size_t)n] = root_of_unity(q, 2LL * P, +1);
+        const double ang = M_PI * (double)q / (double)P;
+        const std::complex<double> cw(std::cos(ang), -std::sin(ang));       // conj(w_n)
+        b[(size_t)n] = cw;
+        if (n > 0) b[(size_t)(M - n)] = cw;
+      }
+      host_fft_pow2(b);
+      for (int k = 0; k < M; k++) g.tw_any[(size_t)M + (size_t)P + (size_t)k] = f2{(float)b[(size_t)k].real(), (float)b[(size_t)k].imag()};
+    } else {
+      g.tw_any.resize((size_t)P);
+      for (int k = 0; k < P; k++) g.tw_any[(size_t)k] = root_of_unity(k, P, -1);
+    }
+    g.lb = g.blue_M ? g.blue_M : P;
+    g.any_threads = g.lb <= 1024 ? 128 : g.lb <= 2048 ? 256 : g.lb <= 4096 ? 512 : 1024;
+    g.big = g.lb > CHZ_ANY_LDS_P;
+    g.lds = g.big ? 0 : sizeof(f2) * 2 * (size_t)g.lb;
     return true;
   }
   g.P = P;

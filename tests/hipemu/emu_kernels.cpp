@@ -144,7 +144,7 @@ int emu_channels(const float* spec, int m_bins, int in_type, int P, int olen, in
   const int per_block = g.wpb * g.cpw;
   const int grid = (nch + per_block - 1) / per_block;
   c.stage = getenv("CHZ_CHAN_STAGE") ? atoi(getenv("CHZ_CHAN_STAGE")) : 0;
-  if (g.any) { c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL; std::vector<float2> scr(g.big ? (size_t)nch * 2 * P : 0); return launch_chan_any(g, nch, nullptr, c, F2(g.tw_any), false, g.big ? scr.data() : nullptr); }
+  if (g.any) { c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL; std::vector<float2> scr(g.big ? (size_t)nch * 2 * g.lb : 0); return launch_chan_any(g, nch, nullptr, c, F2(g.tw_any), false, g.big ? scr.data() : nullptr); }
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
 }
 
@@ -164,7 +164,7 @@ int emu_channels_isb(const float* spec, int m_bins, int in_type, int P, int olen
   c.resp = reinterpret_cast<const float2*>(resp);
   c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub); c.isb = isb;
-  if (g.any) { c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL; std::vector<float2> scr(g.big ? (size_t)nch * 2 * P : 0); return launch_chan_any(g, nch, nullptr, c, F2(g.tw_any), false, g.big ? scr.data() : nullptr); }
+  if (g.any) { c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL; std::vector<float2> scr(g.big ? (size_t)nch * 2 * g.lb : 0); return launch_chan_any(g, nch, nullptr, c, F2(g.tw_any), false, g.big ? scr.data() : nullptr); }
   const int per_block = g.wpb * g.cpw;
   const int grid = (nch + per_block - 1) / per_block;
   return launch_chan(g.r, grid, g.wpb * 64, g.lds, nullptr, c);
@@ -209,7 +209,7 @@ int emu_channels_real(const float* spec, int m_bins, int in_type, int P, int ole
   c.desc = desc.data(); c.m_bins = m_bins; c.m_real = in_type == CHZ_IN_REAL;
   c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub);
-  if (g.any) { std::vector<float2> scr(g.big ? (size_t)nch * 2 * P : 0); return launch_chan_any(g, nch, nullptr, c, F2(g.tw_any), true, g.big ? scr.data() : nullptr); }
+  if (g.any) { std::vector<float2> scr(g.big ? (size_t)nch * 2 * g.lb : 0); return launch_chan_any(g, nch, nullptr, c, F2(g.tw_any), true, g.big ? scr.data() : nullptr); }
   const int per_block = g.wpb * g.cpw;
   const int grid = (nch + per_block - 1) / per_block;
   return launch_chan_real(g.r, grid, g.wpb * 64, g.lds, nullptr, c);

@@ -235,6 +235,35 @@ def test_channel_sizes_outside_the_menu(pkg, P, olen):
         fa.delete_filter_input(master)
 
 
+@pytest.mark.parametrize("P,olen", [(85, 68), (115, 92), (2495, 1996), (9995, 7996)])   # factors 17, 23, 499, 1999; the last one beyond the LDS (M = 32768)
+def test_channel_sizes_with_large_prime_factors(pkg, P, olen):
+    # round 3: FFTW plans any size (src/filter.c:101-163); a channel size with a prime factor above 13 now runs through Bluestein's
+    # chirp-z identity inside chan_any, through the filter.h mirror, against the restatement (whose transform is the DFT by definition)
+    L, M = 25920, 6481
+    fa = pkg.filterapi
+    rng = np.random.default_rng(P)
+    master = fa.create_filter_input(L, M, fa.REAL)
+    st = ol.Stream(L, M, ol.REAL)
+    B = master.bins
+    shifts = [0, -1, 5000, P // 2, -(P // 2), B - 1] + [int(s) for s in rng.integers(-B - P, B + P, 4)]
+    slaves = []
+    for _ in shifts:
+        s = fa.create_filter_output(master, olen, fa.COMPLEX)
+        assert s is not None and s.points == P
+        fa.set_response(s, (rng.standard_normal(P) + 1j * rng.standard_normal(P)).astype(np.complex64))
+        slaves.append(s)
+    try:
+        for blk in range(2):
+            x = rng.standard_normal(L).astype(np.float32)
+            assert fa.write_rfilter(master, x) == 1
+            spec64 = st.push(x, f64=True)
+            for s, sh in zip(slaves, shifts):
+                assert fa.execute_filter_output(s, sh) == 0
+                check_channel(s.output, ol.channel(spec64, ol.REAL, P, olen, sh, s.response))
+    finally:
+        fa.delete_filter_input(master)
+
+
 def test_channel_sizes_beyond_the_lds(pkg):
     # 768 kHz and 1.536 MHz channels of the full-rate master (P = 19200, 38400; share/*.conf has both): chan_any with its two
     # transform buffers in global scratch.  The restatement's gather + float64 inverse DFT on the DEVICE's own spectrum.

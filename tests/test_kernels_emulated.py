@@ -172,6 +172,39 @@ def test_generic_channel_sizes_random(emu):
         done += 1
 
 
+@pytest.mark.parametrize("P,olen", [(17, 9), (34, 20), (289, 200), (323, 150), (1999, 1200), (4099, 4000), (2 * 4099, 5000), (23 * 29 * 4, 2000)])
+def test_channel_sizes_with_large_prime_factors(emu, P, olen):
+    """round 3: a channel size with a prime factor above 13 (FFTW plans any size, src/filter.c:101-163) runs through Bluestein's
+    chirp-z identity inside chan_any -- primes, squares of primes, sizes beyond the LDS (M = 16384: global scratch), COMPLEX / ISB /
+    REAL output -- against the restatement, whose P-point transform is the DFT by definition."""
+    rng = np.random.default_rng(P)
+    for in_type, B in ((ol.REAL, 4801), (ol.COMPLEX, 9000)):
+        spec = (rng.standard_normal(B) + 1j * rng.standard_normal(B)).astype(np.complex64)
+        shifts = [0, -(P // 2), 700, -1300] if P < B else [0, 100]
+        nch = len(shifts)
+        resp = (rng.standard_normal((nch, P)) + 1j * rng.standard_normal((nch, P))).astype(np.complex64)
+        sh = np.array(shifts, np.int32)
+        modes = ["plain", "isb"] + (["real"] if P % 2 == 0 else [])
+        for mode in modes:
+            if mode == "real":
+                out = np.zeros((nch, olen), np.float32)
+                assert emu.emu_channels_real(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, out.ctypes.data, 0, 0, 0) == 0
+            elif mode == "isb":
+                flags = (np.arange(nch) % 2).astype(np.uint8)
+                out = np.zeros((nch, olen), np.complex64)
+                assert emu.emu_channels_isb(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, flags.ctypes.data, out.ctypes.data) == 0
+            else:
+                out = np.zeros((nch, olen), np.complex64)
+                assert emu.emu_channels(spec.ctypes.data, B, in_type, P, olen, nch, resp.ctypes.data, sh.ctypes.data, out.ctypes.data, 0, 0, 0) == 0
+            for i, sft in enumerate(shifts):
+                kw = dict(out_type=ol.REAL) if mode == "real" else dict(isb=bool(flags[i])) if mode == "isb" else {}
+                want = ol.channel(spec, in_type, P, olen, sft, resp[i], **kw)
+                if np.linalg.norm(want) == 0:
+                    assert not out[i].any()
+                else:
+                    assert rel(out[i], want) < 4e-6, (P, olen, mode, in_type, sft, rel(out[i], want))
+
+
 @pytest.mark.parametrize("stage", [0, 1])
 @pytest.mark.parametrize("in_type,B", [(ol.REAL, 16201), (ol.COMPLEX, 6000), (ol.COMPLEX, 6001)])
 @pytest.mark.parametrize("P,olen", [(300, 240), (600, 480), (200, 160), (400, 320), (1200, 960), (1920, 1536), (150, 120),
