@@ -22,4 +22,7 @@ cd $R
 } > gpurun_out/${TAG}_rocprofv3_summary.txt 2>&1
 python scripts/rocprof_summary.py --kernels-json gpurun_out/prof_${TAG}_4streams gpurun_out/prof_${TAG}_1stream gpurun_out/${TAG}_rocprof_kernels.json $TAG
 [ "$SKIP_PMC" = 1 ] || python scripts/rocprof_summary.py --json gpurun_out/pmc_$TAG/fetch gpurun_out/pmc_$TAG/write gpurun_out/${TAG}_pmc_forward.json
+# the raw traces are tens of MB: only the summaries travel back (gpurun merges at most 64 MiB)
+rm -rf gpurun_out/prof_${TAG}_4streams gpurun_out/prof_${TAG}_1stream
+[ "$SKIP_PMC" = 1 ] || find gpurun_out/pmc_$TAG -type f ! -name "*.log" -size +200k -delete
 head -40 gpurun_out/${TAG}_rocprofv3_summary.txt
