@@ -6,6 +6,7 @@ input window plus gather x response + backward transform of every channel, input
 resident in HBM (an 8-block sig_gen stream in the device ring, replayed cyclically).
 
 Workloads (BASELINE.json configs; --config picks one, the default follows --gpus):
+  1  sig_gen complex 2.4 MS/s, ONE IQ-mode 12 kHz channel (P = 300): the reference's own CPU-runnable plumbing case, here on one GPU
   2  sig_gen real  64.8 MS/s, 256 x 12 kHz NBFM channels (P = 300), one GPU
   3  sig_gen real 129.6 MS/s, 1024 mixed usb/cw/iq 12 kHz channels (P = 300), one GPU   [default at --gpus 1]
   4  sig_gen real 129.6 MS/s, 1024 x 24 kHz channels (P = 600) PER GPU, sharded by frequency; rank 0 owns the
@@ -57,14 +58,16 @@ BINS = N // 2 + 1
 FWD_BYTES = 4 * N + 8 * BINS            # 25,920,008  
 
 
-def geometry(fs):
+def geometry(fs, real=True):
     l = int(round(fs * BLOCKTIME))
     m = l // 4 + 1
     n = l + m - 1
-    return l, m, n, n // 2 + 1
+    return l, m, n, (n // 2 + 1 if real else n)
 
 
-def fwd_bytes(n):
+def fwd_bytes(n, real=True):
+    if not real:
+        return 8 * n + 8 * n            # complex window in, full spectrum out
     return 4 * n + 8 * (n // 2 + 1)     # read the real window once, write the half spectrum once
 
 
@@ -104,7 +107,16 @@ def channel_plan_config4(nch, rank):
 
 def workload_for(config, rank, world, nch):
     """Everything that defines what one rank runs."""
-    if config == 2:
+    real = True
+    if config == 1:
+        # BASELINE config 1: sig_gen complex 2.4 MS/s, ONE IQ-mode channel (the reference's own CPU-runnable plumbing case)
+        fs, P, olen, real = 2.4e6, 300, 240, False
+        nch = nch or 1
+        hz = fs / geometry(fs, False)[2]
+        plan = [(int(round((100e3 + i * 15e3) / hz)), -5000 / 12000, 5000 / 12000) for i in range(nch)]
+        name = "config1: sig_gen complex 2.4 MS/s, %d IQ-mode 12 kHz channel%s (P=300)" % (nch, "" if nch == 1 else "s")
+        seed = 1
+    elif config == 2:
         fs, P, olen = 64.8e6, 300, 240
         nch = nch or 256
         plan = channel_plan_config2(nch, fs)
@@ -131,17 +143,18 @@ def workload_for(config, rank, world, nch):
                 "no RCCL in the data path" % (world, nch))
         seed = rank + 1
     else:
-        raise SystemExit("--config must be 2, 3, 4 or 5")
-    l, m, n, bins = geometry(fs)
-    return dict(config=config, fs=fs, L=l, M=m, N=n, bins=bins, P=P, olen=olen, nch=nch, plan=plan, name=name, seed=seed)
+        raise SystemExit("--config must be 1, 2, 3, 4 or 5")
+    l, m, n, bins = geometry(fs, real)
+    return dict(config=config, fs=fs, L=l, M=m, N=n, bins=bins, P=P, olen=olen, nch=nch, plan=plan, name=name, seed=seed, real=real)
 
 
-def siggen_ring(oracle_lib, fs=FS, seed=1, l=None):
-    """8 blocks of the deterministic sig_gen stream (CW carrier 10.00002 MHz, -20 dBFS, noise -40 dBFS).
-    The generator is test infrastructure (oracle/); it only produces INPUT, outside the timed region."""
+def siggen_ring(oracle_lib, fs=FS, seed=1, l=None, real=True):
+    """8 blocks of the deterministic sig_gen stream (CW carrier 10.00002 MHz -- 100.02 kHz for the complex 2.4 MS/s case --,
+    -20 dBFS, noise -40 dBFS).  The generator is test infrastructure (oracle/); it only produces INPUT, outside the timed region."""
     l = l or geometry(fs)[0]
-    g = oracle_lib.SigGen(10.00002e6 / fs, 10 ** (-20 / 20), 10 ** (-40 / 20),
-                          oracle_lib.scale_ad(True, 1), True, seed=seed)
+    carrier = 10.00002e6 if fs > 2.1e7 else 100.02e3
+    g = oracle_lib.SigGen(carrier / fs, 10 ** (-20 / 20), 10 ** (-40 / 20),
+                          oracle_lib.scale_ad(real, 1), real, seed=seed)
     return g.generate(RING_BLOCKS * l)
 
 
@@ -176,12 +189,12 @@ def cpu_baseline(oracle_lib, ring, wl, seconds=12.0):
     R.oracle_fft_set_precision(1)          # float32 arithmetic for a fair CPU timing
     cores = os.cpu_count() or 1
     pool = max(1, min(cores - 1, 16))
-    ring = np.ascontiguousarray(ring, np.float32)
+    ring = np.ascontiguousarray(ring, np.float32 if wl.get("real", True) else np.complex64)
     plan, P, olen = wl["plan"], wl["P"], wl["olen"]
     sarr = np.array([p[0] for p in plan], np.int32)
 
     def run(workers, budget):
-        m = oracle_lib.RefMaster(wl["L"], wl["M"], oracle_lib.REAL, worker_threads=workers)
+        m = oracle_lib.RefMaster(wl["L"], wl["M"], oracle_lib.REAL if wl.get("real", True) else oracle_lib.COMPLEX, worker_threads=workers)
         chans = []
         for shift, low, high in plan:
             c = m.channel(olen, oracle_lib.COMPLEX)
@@ -385,11 +398,11 @@ def dropin_leg(wl, ring_host, nthreads, nblocks, env, label):
         exe = os.path.join(tmp, "harness")
         subprocess.run(["gcc", "-O2", "-std=gnu11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "dropin_harness.c"), "-o", exe,
                         "-L", libdir, "-lka9q_filter_hip", "-lchz_hip", "-Wl,-rpath," + libdir, "-lpthread", "-lm"], check=True)
-        open(os.path.join(tmp, "cfg.txt"), "w").write("%d %d %d %d %d %d %d\n" % (wl["L"], wl["M"], 2, wl["olen"], len(plan), nblocks, 65536))   # 2 = REAL (enum filtertype)
+        open(os.path.join(tmp, "cfg.txt"), "w").write("%d %d %d %d %d %d %d\n" % (wl["L"], wl["M"], 2 if wl.get("real", True) else 1, wl["olen"], len(plan), nblocks, 65536))   # enum filtertype: 2 = REAL, 1 = COMPLEX
         with open(os.path.join(tmp, "plan.bin"), "wb") as f:
             for shift, lo, hi in plan:
                 f.write(struct.pack("iiiiddddd", shift, shift, 10 ** 9, 10 ** 9, lo, hi, 11.0, lo, hi))
-        np.ascontiguousarray(ring_host, np.float32).tofile(os.path.join(tmp, "in.bin"))
+        np.ascontiguousarray(ring_host, np.float32 if wl.get("real", True) else np.complex64).tofile(os.path.join(tmp, "in.bin"))
         e = dict(os.environ, HARNESS_INPUT_BLOCKS=str(RING_BLOCKS), HARNESS_KEEP="0", KA9Q_HIP_PROFILE="1")
         e.update(env)
         t0 = time.perf_counter()
@@ -443,7 +456,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--config", type=int, default=0, help="BASELINE config 2, 3, 4 or 5 (default: 3 at --gpus 1, 4 otherwise)")
+    ap.add_argument("--config", type=int, default=0, help="BASELINE config 1, 2, 3, 4 or 5 (default: 3 at --gpus 1, 4 otherwise)")
     ap.add_argument("--exchange", default=os.environ.get("BENCH_EXCHANGE", "auto"),
                     help="config 4, how the spectrum reaches the ranks: auto | subband | broadcast (RCCL) | replicate (no collective)")
     ap.add_argument("--channels", type=int, default=0, help="channels per GPU (default: the config's)")
@@ -454,7 +467,7 @@ def main():
     ap.add_argument("--no-crt", action="store_true", help="skip the C_rt leg (one large bank, every block inside 20 ms)")
     ap.add_argument("--crt-channels", type=int, default=0, help="channels of the C_rt leg's bank (default 17.0 M at P=300, 8.4 M at P=600)")
     ap.add_argument("--crt-blocks", type=int, default=500)
-    ap.add_argument("--crt-ladder", default="", help="comma-separated channel counts (millions) of the C_rt ladder; default 17.0,19.0,19.5,20.0 at P=300 / 8.4,9.4,9.7,10.0 at P=600")
+    ap.add_argument("--crt-ladder", default="", help="comma-separated channel counts (millions) of the C_rt ladder; default 17.0,19.0,20.0,20.5 at P=300 / 8.4,9.4,9.7,10.0 at P=600")
     ap.add_argument("--no-dropin", action="store_true", help="skip the legs through the filter.h drop-in")
     ap.add_argument("--dropin-blocks", type=int, default=500)
     ap.add_argument("--no-crt-pcie", action="store_true", help="skip the C_rt probes with the host link in the loop")
@@ -504,16 +517,17 @@ def main():
             raise SystemExit("the RCCL exchange needs one GPU per rank (backend nccl)")
 
     pkg = ge.load()
-    eng = pkg.engine.Engine(wl["L"], wl["M"], pkg.engine.REAL, device=dev_index, plan=args.plan, ring_blocks=RING_BLOCKS)
+    real = wl["real"]
+    eng = pkg.engine.Engine(wl["L"], wl["M"], pkg.engine.REAL if real else pkg.engine.COMPLEX, device=dev_index, plan=args.plan, ring_blocks=RING_BLOCKS)
 
     # ---- inputs resident in HBM before anything is timed
-    ring_host = siggen_ring(oracle_lib, wl["fs"], wl["seed"], wl["L"])
+    ring_host = siggen_ring(oracle_lib, wl["fs"], wl["seed"], wl["L"], real)
     # the device ring starts with the write position M-1 ahead (zeros before time 0); fill it to the brim
     eng.write(ring_host[:RING_BLOCKS * wl["L"] - (wl["M"] - 1)])
     eng.write(ring_host[RING_BLOCKS * wl["L"] - (wl["M"] - 1):])       # wraps: ring now holds the cyclic 8-block stream
     nch, P, olen, plan = wl["nch"], wl["P"], wl["olen"], wl["plan"]
     bank = eng.bank(P, olen, nch)
-    resp = np.stack([pkg.filterapi.design_response(P, olen, wl["N"], True, lo, hi, 11.0) for _, lo, hi in plan])
+    resp = np.stack([pkg.filterapi.design_response(P, olen, wl["N"], real, lo, hi, 11.0) for _, lo, hi in plan])
     bank.set_responses(0, resp)
     bank.set_shifts(0, np.array([p[0] for p in plan], np.int32))
     bank.set_active(nch)
@@ -618,18 +632,22 @@ def main():
         fo = eng.run_blocks(400, 2000)
         bank.set_active(nch)
         fwd_pipe_us = fo.total_ms / fo.blocks * 1e3
-        Ra = eng.axes[0] // 2 + 1
+        Ra = eng.axes[0] // 2 + 1 if real else eng.axes[0]
         inner_bytes = Ra * eng.axes[1] * eng.axes[2] * 8
-        own = {"fwd_first_real": 4 * wl["N"] + inner_bytes, "fwd_cols": 2 * inner_bytes,
+        own = {"fwd_first_real": (4 if real else 8) * wl["N"] + inner_bytes, "fwd_cols": 2 * inner_bytes,
                "fwd_rows": inner_bytes + 8 * wl["bins"], "chan_ifft": nch * chan_bytes(P, olen)}
+        if eng.axes[1] <= 1:
+            own.pop("fwd_cols")                      # two-axis plan: no middle pass
         fwd_us = sum(kern.get(k, 0.0) for k in ("fwd_first_real", "fwd_cols", "fwd_rows"))
-        fb = fwd_bytes(wl["N"])
+        fb = fwd_bytes(wl["N"], real)
         achieved = fb / (fwd_us * 1e-6) / 1e9 if fwd_us else 0.0
         passes = 3 if eng.axes[1] > 1 else 2
         traffic = pmc_traffic_bytes() if config in (3, 4, 5) else None
         rp = rocprof_kernel_us() if config in (3, 4, 5) else None
         roof = {
-            "bound": "hbm", "kernel": "forward transform = fwd_first_real + fwd_cols + fwd_rows (one launch each per block)",
+            "bound": "hbm", "kernel": ("forward transform = fwd_first_real + fwd_cols + fwd_rows (one launch each per block)" if real else
+                                       "forward transform of a COMPLEX master: first axis through fwd_cols (reported under fwd_first_real) + fwd_rows%s"
+                                       % (" + fwd_cols" if passes == 3 else "")),
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": ("committed profile, not this run: profiles/pmc_forward.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate "
@@ -658,7 +676,7 @@ def main():
         elif args.crt_channels:
             crt_n = [args.crt_channels]
         else:
-            crt_n = [17_000_000, 19_000_000, 19_500_000, 20_000_000] if P == 300 else [8_400_000, 9_400_000, 9_700_000, 10_000_000]
+            crt_n = [17_000_000, 19_000_000, 20_000_000, 20_500_000] if P == 300 else [8_400_000, 9_400_000, 9_700_000, 10_000_000]
         if comm is not None:
             # the big bank's channels span the whole spectrum on every rank: whole-slot broadcast, whatever the headline leg moved
             def run_one(job):
@@ -717,15 +735,15 @@ def main():
 
     # ---- the boundary itself: the same workload through filter.h (C harness, one pthread per channel), PCIe in the loop
     dropin = None
-    if rank == 0 and world == 1 and not args.no_dropin and config in (2, 3):
+    if rank == 0 and world == 1 and not args.no_dropin and config in (1, 2, 3):
         dropin = []
         fs_arg = "%.1f" % wl["fs"]
-        for label, nthr, env in (
+        for label, nthr, env in [
                 ("filter.h as an unmodified radiod uses it (every block's spectrum copied to fdomain[] for the host's estimate_noise)", nch, {}),
                 ("radiod with the noise estimate taken from the device (INTEGRATION.md section 1 patch): no spectrum copy", nch,
                  {"KA9Q_HIP_FDOMAIN": "0", "KA9Q_HIP_NOISE_SAMPRATE": fs_arg}),
                 ("2000 channel threads (Nchannels, src/radio.h:356), noise estimate from the device", 2000,
-                 {"KA9Q_HIP_FDOMAIN": "0", "KA9Q_HIP_NOISE_SAMPRATE": fs_arg})):
+                 {"KA9Q_HIP_FDOMAIN": "0", "KA9Q_HIP_NOISE_SAMPRATE": fs_arg})][:1 if config == 1 else 3]:
             try:
                 dropin.append(dropin_leg(wl, ring_host, nthr, args.dropin_blocks, env, label))
             except Exception as ex:
@@ -749,7 +767,7 @@ def main():
         total_ch = nch * world
         value = total_ch * BLOCKTIME / (elapsed / args.steps)
         fwd_copies = world if (config == 5 or main_leg == "replicate") else 1
-        step_bytes = fwd_copies * fwd_bytes(wl["N"]) + total_ch * chan_bytes(P, olen)
+        step_bytes = fwd_copies * fwd_bytes(wl["N"], wl["real"]) + total_ch * chan_bytes(P, olen)
         exchange_desc = None
         if config == 4:
             exchange_desc = {

@@ -70,10 +70,15 @@ struct Bank {
   FineDesc* fine = nullptr;     // [ND][cap], allocated by the first chz_bank_set_tuning
   unsigned char* isb = nullptr; // [ND][cap], allocated by chz_bank_set_isb
   BeamDesc* beam = nullptr;     // [ND][cap], allocated by chz_bank_set_beam
-  int dirty_lo[CHZ_ND], dirty_hi[CHZ_ND];           // channels whose slot copy is older than the host copy
+  // channels whose slot copy is older than the host copy: a short sorted list of disjoint ranges per slot (two retunes at the two
+  // ends of a multi-million-channel bank must not re-upload everything in between); beyond CHZ_DIRTY_MAX ranges the closest two merge
+  std::vector<std::pair<int, int>> dirty[CHZ_ND];
   char* stage[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging of one refresh per slot
-  hipEvent_t stage_ev[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};
-  bool stage_busy[CHZ_ND] = {false, false, false, false};
+  // the staging area of a slot is two halves used in turn, each with its own event: filling one half never waits for the copy
+  // that is still reading the other
+  hipEvent_t stage_ev[CHZ_ND][2] = {};
+  bool stage_busy[CHZ_ND][2] = {};
+  int stage_next[CHZ_ND] = {0, 0, 0, 0};
   // the linear demodulator behind the channel outputs; allocated by the first chz_bank_set_demod
   float2* any_scratch = nullptr;         // [ND][cap][2][P or M]: transform buffers of channel sizes beyond the LDS (chan_any<true>)
   DemodChan* dm_chan = nullptr;          // [cap]
@@ -229,8 +234,8 @@ static void free_bank(Bank& b) {
   }
   for (int s = 0; s < CHZ_ND; s++) {
     if (b.stage[s]) (void)hipHostFree(b.stage[s]);
-    if (b.stage_ev[s]) (void)hipEventDestroy(b.stage_ev[s]);
-    b.stage[s] = nullptr; b.stage_ev[s] = nullptr; b.stage_busy[s] = false;
+    for (int h = 0; h < 2; h++) { if (b.stage_ev[s][h]) (void)hipEventDestroy(b.stage_ev[s][h]); b.stage_ev[s][h] = nullptr; b.stage_busy[s][h] = false; }
+    b.stage[s] = nullptr; b.stage_next[s] = 0; b.dirty[s].clear();
   }
   for (auto& r : b.retired) for (auto ev : r.ev) if (ev) (void)hipEventDestroy(ev);
   b.retired.clear(); b.free_rows.clear();
@@ -643,10 +648,25 @@ static inline char* bank_out_at(const Bank& b, int slot, int ch) {
 }
 
 // ---- per-slot descriptors ------------------------------------------------------
+#define CHZ_DIRTY_MAX 16
 static inline void mark_dirty(Bank& b, int ch0, int n) {
+  if (n <= 0) return;
   for (int s = 0; s < CHZ_ND; s++) {
-    if (ch0 < b.dirty_lo[s]) b.dirty_lo[s] = ch0;
-    if (ch0 + n > b.dirty_hi[s]) b.dirty_hi[s] = ch0 + n;
+    auto& d = b.dirty[s];
+    int lo = ch0, hi = ch0 + n;
+    // absorb every range that touches [lo, hi), keep the list sorted
+    size_t i = 0;
+    while (i < d.size() && d[i].second < lo) i++;
+    size_t j = i;
+    while (j < d.size() && d[j].first <= hi) { if (d[j].first < lo) lo = d[j].first; if (d[j].second > hi) hi = d[j].second; j++; }
+    d.erase(d.begin() + (long)i, d.begin() + (long)j);
+    d.insert(d.begin() + (long)i, std::make_pair(lo, hi));
+    while (d.size() > CHZ_DIRTY_MAX) {           // too many islands: merge the two with the smallest gap between them
+      size_t best = 0; int gap = d[1].first - d[0].second;
+      for (size_t k = 1; k + 1 < d.size(); k++) if (d[k + 1].first - d[k].second < gap) { gap = d[k + 1].first - d[k].second; best = k; }
+      d[best].second = d[best + 1].second;
+      d.erase(d.begin() + (long)best + 1);
+    }
   }
 }
 static inline size_t stage_bytes_per_channel() { return sizeof(ChanDesc) + sizeof(FineDesc) + sizeof(BeamDesc) + 1; }
@@ -654,39 +674,42 @@ static inline size_t stage_bytes_per_channel() { return sizeof(ChanDesc) + sizeo
 // Bring slot `slot`'s device copy of the descriptors up to the host copy, in stream order on `st`: blocks already
 // enqueued on this slot keep what they were launched with, blocks of other slots are not touched at all.
 static int refresh_slot(chz_engine* e, Bank& b, int slot, hipStream_t st) {
-  int lo = b.dirty_lo[slot], hi = b.dirty_hi[slot];
-  if (lo >= hi) return 0;
-  if (hi > b.cap) hi = b.cap;
+  if (b.dirty[slot].empty()) return 0;
   const int chunk = b.cap < CHZ_STAGE_CAP ? b.cap : CHZ_STAGE_CAP;
+  const size_t half_bytes = stage_bytes_per_channel() * (size_t)chunk;
   if (!b.stage[slot]) {
-    HIPOK(hipHostMalloc((void**)&b.stage[slot], stage_bytes_per_channel() * (size_t)chunk, hipHostMallocDefault));
-    HIPOK(hipEventCreateWithFlags(&b.stage_ev[slot], hipEventDisableTiming));
+    HIPOK(hipHostMalloc((void**)&b.stage[slot], 2 * half_bytes, hipHostMallocDefault));
+    for (int h = 0; h < 2; h++) HIPOK(hipEventCreateWithFlags(&b.stage_ev[slot][h], hipEventDisableTiming));
   }
-  for (int c0 = lo; c0 < hi; c0 += chunk) {
-    const int n = hi - c0 < chunk ? hi - c0 : chunk;
-    if (b.stage_busy[slot]) HIPOK(hipEventSynchronize(b.stage_ev[slot]));   // the previous refresh of this slot: long done
-    char* sp = b.stage[slot];
-    memcpy(sp, b.desc_h.data() + c0, sizeof(ChanDesc) * (size_t)n);
-    HIPOK(hipMemcpyAsync(b.desc + (size_t)slot * b.cap + c0, sp, sizeof(ChanDesc) * (size_t)n, hipMemcpyHostToDevice, st));
-    sp += sizeof(ChanDesc) * (size_t)n;
-    if (b.fine) {
-      memcpy(sp, b.fine_dh.data() + c0, sizeof(FineDesc) * (size_t)n);
-      HIPOK(hipMemcpyAsync(b.fine + (size_t)slot * b.cap + c0, sp, sizeof(FineDesc) * (size_t)n, hipMemcpyHostToDevice, st));
-      sp += sizeof(FineDesc) * (size_t)n;
+  for (const auto& range : b.dirty[slot]) {
+    const int lo = range.first, hi = range.second > b.cap ? b.cap : range.second;
+    for (int c0 = lo; c0 < hi; c0 += chunk) {
+      const int n = hi - c0 < chunk ? hi - c0 : chunk;
+      const int h = b.stage_next[slot]; b.stage_next[slot] ^= 1;
+      if (b.stage_busy[slot][h]) HIPOK(hipEventSynchronize(b.stage_ev[slot][h]));   // the copy before last out of this half: long done
+      char* sp = b.stage[slot] + (size_t)h * half_bytes;
+      memcpy(sp, b.desc_h.data() + c0, sizeof(ChanDesc) * (size_t)n);
+      HIPOK(hipMemcpyAsync(b.desc + (size_t)slot * b.cap + c0, sp, sizeof(ChanDesc) * (size_t)n, hipMemcpyHostToDevice, st));
+      sp += sizeof(ChanDesc) * (size_t)n;
+      if (b.fine) {
+        memcpy(sp, b.fine_dh.data() + c0, sizeof(FineDesc) * (size_t)n);
+        HIPOK(hipMemcpyAsync(b.fine + (size_t)slot * b.cap + c0, sp, sizeof(FineDesc) * (size_t)n, hipMemcpyHostToDevice, st));
+        sp += sizeof(FineDesc) * (size_t)n;
+      }
+      if (b.beam) {
+        memcpy(sp, b.beam_h.data() + c0, sizeof(BeamDesc) * (size_t)n);
+        HIPOK(hipMemcpyAsync(b.beam + (size_t)slot * b.cap + c0, sp, sizeof(BeamDesc) * (size_t)n, hipMemcpyHostToDevice, st));
+        sp += sizeof(BeamDesc) * (size_t)n;
+      }
+      if (b.isb) {
+        memcpy(sp, b.isb_h.data() + c0, (size_t)n);
+        HIPOK(hipMemcpyAsync(b.isb + (size_t)slot * b.cap + c0, sp, (size_t)n, hipMemcpyHostToDevice, st));
+      }
+      HIPOK(hipEventRecord(b.stage_ev[slot][h], st));
+      b.stage_busy[slot][h] = true;
     }
-    if (b.beam) {
-      memcpy(sp, b.beam_h.data() + c0, sizeof(BeamDesc) * (size_t)n);
-      HIPOK(hipMemcpyAsync(b.beam + (size_t)slot * b.cap + c0, sp, sizeof(BeamDesc) * (size_t)n, hipMemcpyHostToDevice, st));
-      sp += sizeof(BeamDesc) * (size_t)n;
-    }
-    if (b.isb) {
-      memcpy(sp, b.isb_h.data() + c0, (size_t)n);
-      HIPOK(hipMemcpyAsync(b.isb + (size_t)slot * b.cap + c0, sp, (size_t)n, hipMemcpyHostToDevice, st));
-    }
-    HIPOK(hipEventRecord(b.stage_ev[slot], st));
-    b.stage_busy[slot] = true;
   }
-  b.dirty_lo[slot] = b.cap; b.dirty_hi[slot] = 0;
+  b.dirty[slot].clear();
   return 0;
 }
 // Large edits (a whole bank being set up): drain once and write all four slot copies directly.
@@ -694,15 +717,16 @@ static int refresh_all_bulk(chz_engine* e, Bank& b) {
   int r = sync_all(e);
   if (r) return r;
   for (int s = 0; s < CHZ_ND; s++) {
-    int lo = b.dirty_lo[s], hi = b.dirty_hi[s];
-    if (lo >= hi) continue;
-    if (hi > b.cap) hi = b.cap;
-    const size_t n = (size_t)(hi - lo), off = (size_t)s * b.cap + lo;
-    HIPOK(hipMemcpy(b.desc + off, b.desc_h.data() + lo, sizeof(ChanDesc) * n, hipMemcpyHostToDevice));
-    if (b.fine) HIPOK(hipMemcpy(b.fine + off, b.fine_dh.data() + lo, sizeof(FineDesc) * n, hipMemcpyHostToDevice));
-    if (b.beam) HIPOK(hipMemcpy(b.beam + off, b.beam_h.data() + lo, sizeof(BeamDesc) * n, hipMemcpyHostToDevice));
-    if (b.isb) HIPOK(hipMemcpy(b.isb + off, b.isb_h.data() + lo, n, hipMemcpyHostToDevice));
-    b.dirty_lo[s] = b.cap; b.dirty_hi[s] = 0;
+    for (const auto& range : b.dirty[s]) {
+      const int lo = range.first, hi = range.second > b.cap ? b.cap : range.second;
+      if (lo >= hi) continue;
+      const size_t n = (size_t)(hi - lo), off = (size_t)s * b.cap + lo;
+      HIPOK(hipMemcpy(b.desc + off, b.desc_h.data() + lo, sizeof(ChanDesc) * n, hipMemcpyHostToDevice));
+      if (b.fine) HIPOK(hipMemcpy(b.fine + off, b.fine_dh.data() + lo, sizeof(FineDesc) * n, hipMemcpyHostToDevice));
+      if (b.beam) HIPOK(hipMemcpy(b.beam + off, b.beam_h.data() + lo, sizeof(BeamDesc) * n, hipMemcpyHostToDevice));
+      if (b.isb) HIPOK(hipMemcpy(b.isb + off, b.isb_h.data() + lo, n, hipMemcpyHostToDevice));
+    }
+    b.dirty[s].clear();
   }
   return 0;
 }
@@ -888,7 +912,6 @@ static int bank_create(chz_engine* e, int P, int olen, int capacity, int out_rea
   HIPOK(hipMalloc((void**)&b.desc, sizeof(ChanDesc) * (size_t)CHZ_ND * capacity));
   for (int s = 0; s < CHZ_ND; s++)
     HIPOK(hipMemcpy(b.desc + (size_t)s * capacity, b.desc_h.data(), sizeof(ChanDesc) * (size_t)capacity, hipMemcpyHostToDevice));
-  for (int s = 0; s < CHZ_ND; s++) { b.dirty_lo[s] = capacity; b.dirty_hi[s] = 0; }
   HIPOK(hipMalloc((void**)&b.out, bank_sample_bytes(b) * (size_t)CHZ_ND * capacity * olen));
   HIPOK(hipMemset(b.out, 0, bank_sample_bytes(b) * (size_t)CHZ_ND * capacity * olen));
   int r = upload(&b.tw_sub, b.g.any ? b.g.tw_any : b.g.tw_sub);

@@ -19,7 +19,8 @@ def test_bench_cli_parses_without_a_gpu():
 @pytest.mark.gpu
 def test_bench_emits_one_json_line_with_the_contract_keys():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "64", "--warmup", "8",
-                        "--crt-channels", "3000000", "--crt-blocks", "40"], capture_output=True, text=True, timeout=900)
+                        "--crt-channels", "3000000", "--crt-blocks", "40", "--dropin-blocks", "60", "--crt-pcie-blocks", "30"],
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
     j = json.loads(lines[-1])                                  # the JSON is the LAST line of stdout
@@ -43,20 +44,40 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and "sample" in cpu
     crt = j["c_rt"]
     assert crt["sustained"] is True and crt["channels"] >= 2990000 and crt["worst_block_ms"] <= 20.0 and crt["blocks"] == 40
+    assert crt["probes"] and crt["probes"][-1]["channels"] == crt["channels"]            # the ladder (one rung here)
+    # round 3: the boundary and the host link are in the driver-run line
+    assert roof["traffic_source"] is None or "committed profile" in roof["traffic_source"]
+    assert "rocprof_frac" in roof and "fft_calibration" in cpu
+    legs = j["dropin"]
+    assert len(legs) == 3 and [x["threads"] for x in legs] == [1024, 1024, 2000]
+    for x in legs:
+        assert "error" not in x, x
+        assert x["blocks"] == 60 and x["drops"] == 0 and 0 < x["ms_per_block"] < 20.0 and x["worst_block_gap_ms"] > 0
+        assert x["host_profile"]["staged_hits"] > 0
+    pc = j["c_rt_pcie"]
+    assert len(pc) == 2 and all("error" not in x for x in pc), pc
+    assert pc[0]["d2h_bytes_per_channel"] == 1920 and pc[1]["d2h_bytes_per_channel"] == 481
+    assert all(x["blocks"] == 30 and x["d2h_bytes_per_block"] == x["channels"] * x["d2h_bytes_per_channel"] for x in pc)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra,cfg", [(["--config", "2"], 2), (["--config", "4"], 4), (["--config", "5"], 5)])
+@pytest.mark.parametrize("extra,cfg", [(["--config", "1"], 1), (["--config", "2"], 2), (["--config", "4"], 4), (["--config", "5"], 5)])
 def test_bench_other_configs_run_on_one_gpu(extra, cfg):
     env = dict(os.environ)
     if cfg == 4:
         env["BENCH_FORCE_DIST"] = "1"          # one rank, but through the process group and the RCCL exchange behind the C ABI
         env["MASTER_PORT"] = "29617"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-crt",
-                        "--no-cpu-baseline", "--min-seconds", "0.05"] + extra, capture_output=True, text=True, timeout=900, env=env)
+                        "--no-cpu-baseline", "--min-seconds", "0.05", "--no-crt-pcie", "--dropin-blocks", "40"] + extra,
+                       capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.strip()][-1])
     assert j["config"]["baseline_config"] == cfg and j["n_gpus"] == 1 and j["value"] > 0
+    if cfg == 1:                                        # the reference's plumbing case: a COMPLEX 2.4 MS/s master, one IQ channel
+        assert j["config"]["channels_total"] == 1 and j["config"]["N"] == 60000 and j["roofline"]["algorithmic_bytes_per_block"] == 16 * 60000
+        assert len(j["dropin"]) == 1 and "error" not in j["dropin"][0] and j["dropin"][0]["threads"] == 1 and j["dropin"][0]["drops"] == 0
+    if cfg == 2:
+        assert len(j["dropin"]) == 3 and all("error" not in x for x in j["dropin"])
     if cfg == 4:
         assert "RCCL" in j["exchange"] and "replicate" in j["legs"]
     if cfg == 5:

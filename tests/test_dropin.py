@@ -52,6 +52,10 @@ def test_dropin_exports_the_reference_symbol_set():
                  "goodchoice", "ceil_pow2"}                                  # src/filter.h:99-118
     data = {"N_worker_threads", "N_internal_threads", "FFTW_planning_level", "Wisdom_file", "System_wisdom_file",
             "Min_fft_time", "Max_fft_time", "Avg_fft_time", "Mean_dev"}      # src/filter.c:40-48,476-479
+    # beyond filter.h: every function include/ka9q_filter_hip_ext.h declares
+    ext_hdr = open(os.path.join(ROOT, "include", "ka9q_filter_hip_ext.h")).read()
+    ext = set(re.findall(r"\b(filter_hip_\w+)\s*\(", ext_hdr))
+    assert ext == {"filter_hip_enable_noise", "filter_hip_noise", "filter_hip_drain", "filter_hip_skipped_blocks"} and ext <= mine, ext - mine
     assert functions | data <= mine, (functions | data) - mine
     ref_obj = os.path.join(ROOT, "oracle", "_build", "ref_filter.o")
     if os.path.exists(ref_obj):   # the reference's own object, compiled in place by oracle/Makefile

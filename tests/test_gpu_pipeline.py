@@ -187,6 +187,47 @@ def test_retune_takes_effect_in_stream_order_without_draining(pkg):
     eng.close()
 
 
+def test_sparse_retunes_in_a_large_bank(pkg):
+    # retunes at the two ends and in the middle of a 20,000-channel bank, a dozen scattered ones on top, between blocks that are
+    # never drained: the per-slot descriptor copies are refreshed range by range (a short list of dirty ranges per slot, merged
+    # only beyond 16 islands; round 2 kept ONE interval and re-uploaded everything in between) -- every touched channel, its
+    # neighbours and a sample of the rest must come out with the settings current when the block was enqueued
+    L, M, P, olen, nch = 25920, 6481, 20, 16, 20000
+    rng = np.random.default_rng(14)
+    eng, bank, ring = _engine_with_bank(pkg, L, M, P, olen, nch, rng)
+    N = L + M - 1
+    resp = pkg.filterapi.design_response(P, olen, N, True, -0.3, 0.3, 5.0)
+    for c0 in range(0, nch, 4000):
+        bank.set_responses(c0, np.stack([resp] * 4000))
+    shifts = (200 + (np.arange(nch) * 7) % 12000).astype(np.int32)
+    bank.set_shifts(0, shifts)
+    bank.set_active(nch)
+    cur = shifts.copy()
+    history = []
+    touched = set()
+    nblk = 6
+    for j in range(nblk):
+        if j >= 1:
+            edits = [0, nch - 1, nch // 2] if j % 2 else []
+            edits += [int(c) for c in rng.integers(0, nch, 12 if j == 3 else 2)]      # block 3: more islands than the list holds
+            cur = cur.copy()
+            for c in edits:
+                cur[c] = int(rng.integers(-12000, 12000))
+                bank.set_shifts(c, cur[c:c + 1])
+                touched.add(c)
+        history.append(cur.copy())
+        eng.step(j)                                # asynchronous: nothing is drained in between
+    eng.sync()
+    spectra = _spectra(L, M, ring, nblk)
+    check = sorted(set(list(touched) + [min(nch - 1, c + 1) for c in touched] + [max(0, c - 1) for c in touched] + list(range(0, nch, 997))))
+    for j in range(nblk - 4, nblk):                # the last block of every slot
+        out = bank.read_slot(j % 4)
+        for c in check:
+            want = ol.channel(spectra[j], ol.REAL, P, olen, int(history[j][c]), resp)
+            check_channel(out[c], want)
+    eng.close()
+
+
 def test_response_swaps_recycle_spare_rows(pkg):
     # more filter changes than the bank has spare rows, while blocks keep flowing: rows are recycled behind fences
     L, M, P, olen, nch = 25920, 6481, 300, 240, 8
