@@ -317,24 +317,33 @@ def crt_leg(pkg, eng, wl, counts, blocks, run_one, shared=False):
                     "responses + outputs only" % ((0 if shared else nmax * P * 8) / 1e9, 4 * nmax * olen * 8 / 1e9)}
 
 
-def crt_pcie_leg(pkg, wl, nch, blocks, demod, dev_index):
+def crt_pcie_leg(pkg, wl, nch, blocks, demod, dev_index, pipelined=False):
     """C_rt WITH the host link in the loop (never `value`): every block takes its L new samples from pinned host memory
     (H2D) and returns every channel's result to pinned host memory (D2H) before it counts as done, and must take <= 20 ms:
       demod=False  the channel's olen complex baseband samples (what execute_filter_output hands a channel thread)
       demod=True   fine tuning + noise estimate + linear demodulator on the device; mono S16BE PCM + one status byte go back
-    Bytes are the bytes actually shipped."""
+    Bytes are the bytes actually shipped.
+    pipelined=False  every block on its own: H2D -> kernels -> D2H -> host sync, and the whole round trip must fit 20 ms
+    pipelined=True   a double-buffered host loop: block j is handed to the device, THEN the host waits for block j-1's results
+                     (two pinned output buffers in turn); the time between two consecutive completions must stay <= 20 ms, a
+                     block's results are in host memory at most two block times after its samples were (reported as latency)"""
     lib = pkg.engine.lib()
     C = ctypes
     lib.chz_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
     lib.chz_bank_read_pcm_flags_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.chz_bank_pcm_wait.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.chz_slot_sync.argtypes = [C.c_void_p, C.c_int]
     Lw, P, olen, tile = wl["L"], wl["P"], wl["olen"], 3072
     nch -= nch % tile
     eng = pkg.engine.Engine(wl["L"], wl["M"], pkg.engine.REAL, device=dev_index, ring_blocks=RING_BLOCKS)
     try:
         per_ch = (2 * olen + 1) if demod else 8 * olen
-        hin, hout, hfl = C.c_void_p(), C.c_void_p(), C.c_void_p()
-        assert lib.chz_host_alloc(C.byref(hin), 4 * Lw) == 0 and lib.chz_host_alloc(C.byref(hout), 8 * olen * nch) == 0
-        assert lib.chz_host_alloc(C.byref(hfl), nch) == 0
+        hin = C.c_void_p()
+        houts, hfls = [C.c_void_p(), C.c_void_p()], [C.c_void_p(), C.c_void_p()]
+        assert lib.chz_host_alloc(C.byref(hin), 4 * Lw) == 0
+        for k in range(2 if pipelined else 1):
+            assert lib.chz_host_alloc(C.byref(houts[k]), (2 * olen if demod else 8 * olen) * nch) == 0
+            assert lib.chz_host_alloc(C.byref(hfls[k]), nch) == 0
         xin = np.ctypeslib.as_array(C.cast(hin, C.POINTER(C.c_float)), shape=(Lw,))
         xin[:] = (np.random.default_rng(1).standard_normal(Lw) * 0.05).astype(np.float32)
         bank = eng.bank(P, olen, nch)
@@ -358,25 +367,54 @@ def crt_pcie_leg(pkg, wl, nch, blocks, demod, dev_index):
                 bank.set_demod(0, c0, [one] * min(65536, nch - c0), BLOCKTIME)
         bank.set_active(nch)
         worst = tot = 0.0
-        for j in range(blocks + 8):
-            t0 = time.perf_counter()
-            assert lib.chz_input_write(eng._h, hin, Lw) == 0              # H2D of the block's new samples (pinned source)
-            assert lib.chz_step(eng._h, j) == 0
-            if demod:
-                assert lib.chz_bank_read_pcm_flags_async(eng._h, bank.id, j % 4, 0, nch, hout, hfl) == 0
-            else:
-                assert lib.chz_bank_read_async(eng._h, bank.id, j % 4, 0, nch, hout) == 0
+        lat_worst = 0.0
+        if not pipelined:
+            for j in range(blocks + 8):
+                t0 = time.perf_counter()
+                assert lib.chz_input_write(eng._h, hin, Lw) == 0              # H2D of the block's new samples (pinned source)
+                assert lib.chz_step(eng._h, j) == 0
+                if demod:
+                    assert lib.chz_bank_read_pcm_flags_async(eng._h, bank.id, j % 4, 0, nch, houts[0], hfls[0]) == 0
+                else:
+                    assert lib.chz_bank_read_async(eng._h, bank.id, j % 4, 0, nch, houts[0]) == 0
+                eng.sync()
+                dt = (time.perf_counter() - t0) * 1e3
+                if j >= 8:
+                    worst = max(worst, dt); tot += dt
+        else:
+            issued = {}
+            last_done = None
+            for j in range(blocks + 9):
+                if j < blocks + 8:
+                    issued[j] = time.perf_counter()
+                    assert lib.chz_input_write(eng._h, hin, Lw) == 0
+                    assert lib.chz_step(eng._h, j) == 0
+                    if demod:
+                        assert lib.chz_bank_read_pcm_flags_async(eng._h, bank.id, j % 4, 0, nch, houts[j % 2], hfls[j % 2]) == 0
+                    else:
+                        assert lib.chz_bank_read_async(eng._h, bank.id, j % 4, 0, nch, houts[j % 2]) == 0
+                if j >= 1:                                                    # block j-1's results: the other host buffer
+                    if demod:
+                        assert lib.chz_bank_pcm_wait(eng._h, bank.id, (j - 1) % 4) == 0
+                    else:
+                        assert lib.chz_slot_sync(eng._h, (j - 1) % 4) == 0
+                    now = time.perf_counter()
+                    if j - 1 >= 8:
+                        period = (now - last_done) * 1e3
+                        worst = max(worst, period); tot += period
+                        lat_worst = max(lat_worst, (now - issued[j - 1]) * 1e3)
+                    last_done = now
             eng.sync()
-            dt = (time.perf_counter() - t0) * 1e3
-            if j >= 8:
-                worst = max(worst, dt); tot += dt
         mean = tot / blocks
         return {"channels": nch, "blocks": blocks, "worst_block_ms": worst, "mean_block_ms": mean, "sustained": bool(worst <= BLOCKTIME * 1e3),
                 "returns": "mono S16BE PCM + 1 status byte per channel (tuning, noise estimate, linear demodulator on the device)" if demod
                            else "olen complex float32 baseband samples per channel",
                 "h2d_bytes_per_block": 4 * Lw, "d2h_bytes_per_block": per_ch * nch, "d2h_bytes_per_channel": per_ch,
                 "d2h_GBps": per_ch * nch / (mean * 1e-3) / 1e9, "h2d_GBps_equiv": 4 * Lw / (mean * 1e-3) / 1e9,
-                "loop": "per block: H2D samples -> forward + channels [+ demodulators] -> D2H results -> host sync (no overlap between blocks)"}
+                "loop": ("double-buffered: block j is handed to the device, then the host waits for block j-1 (two pinned output buffers); "
+                         "worst/mean_block_ms = time between two consecutive completions" if pipelined else
+                         "per block: H2D samples -> forward + channels [+ demodulators] -> D2H results -> host sync (no overlap between blocks)"),
+                "worst_latency_ms": lat_worst if pipelined else worst}
     finally:
         eng.close()
 
@@ -751,9 +789,9 @@ def main():
     crt_pcie = None
     if rank == 0 and world == 1 and not args.no_crt_pcie and config == 3:
         crt_pcie = []
-        for n, dm in ((460_800, False), (1_105_920, True)):
+        for n, dm, pipe in ((460_800, False, False), (1_105_920, True, False), (1_320_960, True, True)):
             try:
-                crt_pcie.append(crt_pcie_leg(pkg, wl, n, args.crt_pcie_blocks, dm, dev_index))
+                crt_pcie.append(crt_pcie_leg(pkg, wl, n, args.crt_pcie_blocks, dm, dev_index, pipe))
             except Exception as ex:
                 crt_pcie.append({"channels": n, "error": str(ex)[:200]})
     if rank == 0:

@@ -329,6 +329,10 @@ int chz_bank_read_pcm_async(chz_engine *e, int bank, int slot, int ch0, int n, v
 #define CHZ_FLAG_PLL_LOCK 4
 #define CHZ_FLAG_TONE_MUTE 8
 int chz_bank_read_pcm_flags_async(chz_engine *e, int bank, int slot, int ch0, int n, void *pcm, unsigned char *flags);
+/* returns once everything chz_bank_read_pcm_async / _flags_async has enqueued for `slot` so far has landed in the host buffers --
+   without waiting for later blocks already handed to the demodulator stream (a double-buffered host loop waits for block j-1
+   here while block j runs) */
+int chz_bank_pcm_wait(chz_engine *e, int bank, int slot);
 
 /* ---- small inline masters: radiod's filter2 (src/radio.c:1572-1594: a private COMPLEX master of N = round2(2*blocksize)
  * points with one same-size COMPLEX slave, run inline by the channel thread; share/presets.conf:204,223,297).  A pool holds

@@ -99,6 +99,9 @@ struct Bank {
   double dm_blocktime = 0.02;
   hipEvent_t ev_bank[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // behind the slot's channel (+ noise) kernel
   hipEvent_t ev_tail[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // behind the slot's demodulator kernel
+  hipEvent_t ev_pcm[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};    // behind the slot's latest PCM read (chz_bank_pcm_wait)
+  hipEvent_t ev_pcmgo[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};  // on the demodulator stream where a PCM read on the copy stream may start
+  bool pcm_copying[CHZ_ND] = {false, false, false, false};             // a read on the copy stream is (or was) in flight for the slot
   bool tail_used[CHZ_ND] = {false, false, false, false};
   double* power = nullptr;      // [ND][cap] (tail of downconvert(), src/radio.c:1516-1520)
   double* n0 = nullptr;         // [ND][cap] estimate_noise() (src/radio.c:1783-1866)
@@ -176,6 +179,9 @@ struct chz_engine {
   // (measured: a fifth stream created between the lanes cost 15 -> 20 us per block).
   hipStream_t upload = nullptr;
   hipStream_t tail = nullptr;       // the demodulators' stream: one in-order queue carries their block-to-block state (created on first use)
+  // chz_bank_read_pcm_flags_async copies on a stream of its own, so that block j's PCM travels to the host while block j+1 is being
+  // demodulated (on the in-order demodulator stream the copy and the next kernel would take turns); created on first use
+  hipStream_t pcmcopy = nullptr;
   Lane lanes[CHZ_MAX_LANES];
   int nlanes = 1;
   hipEvent_t input_ready = nullptr; // after the latest ring write
@@ -230,7 +236,9 @@ static void free_bank(Bank& b) {
   for (int s = 0; s < CHZ_ND; s++) {
     if (b.ev_bank[s]) (void)hipEventDestroy(b.ev_bank[s]);
     if (b.ev_tail[s]) (void)hipEventDestroy(b.ev_tail[s]);
-    b.ev_bank[s] = b.ev_tail[s] = nullptr; b.tail_used[s] = false;
+    if (b.ev_pcm[s]) (void)hipEventDestroy(b.ev_pcm[s]);
+    if (b.ev_pcmgo[s]) (void)hipEventDestroy(b.ev_pcmgo[s]);
+    b.ev_bank[s] = b.ev_tail[s] = b.ev_pcm[s] = b.ev_pcmgo[s] = nullptr; b.tail_used[s] = false; b.pcm_copying[s] = false;
   }
   for (int s = 0; s < CHZ_ND; s++) {
     if (b.stage[s]) (void)hipHostFree(b.stage[s]);
@@ -354,6 +362,7 @@ void chz_engine_destroy(chz_engine* e) {
   for (int i = 0; i < e->nlanes; i++) if (e->lanes[i].s) hipStreamSynchronize(e->lanes[i].s);
   if (e->upload) hipStreamSynchronize(e->upload);
   if (e->tail) hipStreamSynchronize(e->tail);
+  if (e->pcmcopy) hipStreamSynchronize(e->pcmcopy);
   drop_graph(e);
   for (int i = 0; i < e->nlanes; i++) {
     hipFree(e->lanes[i].buf);
@@ -374,6 +383,7 @@ void chz_engine_destroy(chz_engine* e) {
   if (e->notch_err) (void)hipHostFree(e->notch_err);
   if (e->upload) hipStreamDestroy(e->upload);
   if (e->tail) hipStreamDestroy(e->tail);
+  if (e->pcmcopy) hipStreamDestroy(e->pcmcopy);
   if (e->own_stream && e->stream) hipStreamDestroy(e->stream);
   delete e;
 }
@@ -415,6 +425,7 @@ static int check_device_errors(const chz_engine* e) {
 static int sync_all(chz_engine* e) {
   for (int i = 0; i < e->nlanes; i++) HIPOK(hipStreamSynchronize(e->lanes[i].s));
   if (e->tail) HIPOK(hipStreamSynchronize(e->tail));
+  if (e->pcmcopy) HIPOK(hipStreamSynchronize(e->pcmcopy));
   return check_device_errors(e);
 }
 int chz_sync(chz_engine* e) {
@@ -785,6 +796,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
       HIPOK(hipEventRecord(b.ev_bank[slot], st));
       HIPOK(hipStreamWaitEvent(ts, b.ev_bank[slot], 0));
     }
+    if (b.pcm_copying[slot]) HIPOK(hipStreamWaitEvent(ts, b.ev_pcm[slot], 0));      // the slot's PCM of four blocks ago is still travelling
     DemodParams d{};
     d.in = bank_out(b, slot); d.power = b.power + so; d.n0 = b.n0 + so; d.chan = b.dm_chan; d.state = b.dm_state; d.ext = b.dm_ext;
     d.status = b.dm_status + so; d.flags = b.dm_flags + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = n; d.olen = b.olen;
@@ -1203,6 +1215,8 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
     for (int s = 0; s < CHZ_ND; s++) {
       HIPOK(hipEventCreateWithFlags(&b.ev_bank[s], hipEventDisableTiming));
       HIPOK(hipEventCreateWithFlags(&b.ev_tail[s], hipEventDisableTiming));
+      HIPOK(hipEventCreateWithFlags(&b.ev_pcm[s], hipEventDisableTiming));
+      HIPOK(hipEventCreateWithFlags(&b.ev_pcmgo[s], hipEventDisableTiming));
     }
     HIPOK(hipDeviceSynchronize());
     DemodChan z; memset(&z, 0, sizeof z);
@@ -1323,6 +1337,7 @@ int chz_bank_demod(chz_engine* e, int bank, unsigned job, int slot) {
   d.status = b.dm_status + so; d.flags = b.dm_flags + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = b.active; d.olen = b.olen;
   d.pcm_stride = b.pcm_stride; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;
   d.mix = b.dm_pll_lin > 0 ? b.dm_mix : nullptr;
+  if (b.pcm_copying[slot]) HIPOK(hipStreamWaitEvent(e->tail, b.ev_pcm[slot], 0));
   if (launch_demod(e->tail, d)) return fail(-4, "the demodulator kernel refuses blocks of %d samples", b.olen);
   HIPOK(hipGetLastError());
   return 0;
@@ -1351,6 +1366,7 @@ static int read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm
   const size_t so = (size_t)slot * b.cap + ch0, stride = (size_t)b.pcm_stride;
   if (pcm) HIPOK(hipMemcpyAsync(pcm, b.dm_pcm + so * stride, stride * (size_t)n, hipMemcpyDeviceToHost, e->tail));
   if (status) HIPOK(hipMemcpyAsync(status, b.dm_status + so, sizeof(DemodStatus) * (size_t)n, hipMemcpyDeviceToHost, e->tail));
+  HIPOK(hipEventRecord(b.ev_pcm[slot], e->tail));
   if (wait) HIPOK(hipStreamSynchronize(e->tail));
   return 0;
 }
@@ -1362,9 +1378,22 @@ int chz_bank_read_pcm_flags_async(chz_engine* e, int bank, int slot, int ch0, in
   Bank& b = e->banks[(size_t)bank];
   if (!b.dm_chan) return fail(-1, "bank has no demodulator: call chz_bank_set_demod first");
   const size_t so = (size_t)slot * b.cap + ch0, stride = (size_t)b.pcm_stride;
-  if (pcm) HIPOK(hipMemcpyAsync(pcm, b.dm_pcm + so * stride, stride * (size_t)n, hipMemcpyDeviceToHost, e->tail));
-  if (flags) HIPOK(hipMemcpyAsync(flags, b.dm_flags + so, (size_t)n, hipMemcpyDeviceToHost, e->tail));
+  if (!e->pcmcopy) HIPOK(hipStreamCreateWithFlags(&e->pcmcopy, hipStreamNonBlocking));
+  HIPOK(hipEventRecord(b.ev_pcmgo[slot], e->tail));                 // behind the slot's demodulator kernel (and whatever else is queued there)
+  HIPOK(hipStreamWaitEvent(e->pcmcopy, b.ev_pcmgo[slot], 0));
+  if (pcm) HIPOK(hipMemcpyAsync(pcm, b.dm_pcm + so * stride, stride * (size_t)n, hipMemcpyDeviceToHost, e->pcmcopy));
+  if (flags) HIPOK(hipMemcpyAsync(flags, b.dm_flags + so, (size_t)n, hipMemcpyDeviceToHost, e->pcmcopy));
+  HIPOK(hipEventRecord(b.ev_pcm[slot], e->pcmcopy));
+  b.pcm_copying[slot] = true;
   return 0;
+}
+int chz_bank_pcm_wait(chz_engine* e, int bank, int slot) {
+  BANK_CHECK(e, bank, 0, 0);
+  if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
+  Bank& b = e->banks[(size_t)bank];
+  if (!b.dm_chan) return fail(-1, "bank has no demodulator: call chz_bank_set_demod first");
+  HIPOK(hipEventSynchronize(b.ev_pcm[slot]));
+  return check_device_errors(e);
 }
 int chz_bank_read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm, chz_demod_status* status) {
   return read_pcm(e, bank, slot, ch0, n, pcm, status, true);

@@ -57,7 +57,7 @@ SYMBOLS = [
     "chz_bank_create", "chz_bank_create_shared", "chz_bank_set_rows", "chz_bank_set_row_responses", "chz_bank_set_responses", "chz_bank_set_shifts", "chz_bank_set_active",
     "chz_bank_execute", "chz_bank_execute_range", "chz_bank_destroy", "chz_bank_read", "chz_bank_read_async",
     "chz_spectrum_read_async", "chz_host_callback", "chz_host_alloc", "chz_host_free", "chz_host_register", "chz_host_unregister",
-    "chz_bank_output_device", "chz_bank_write_block", "chz_bank_demod", "chz_bank_demod_auto", "chz_bank_read_pcm_flags_async", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
+    "chz_bank_output_device", "chz_bank_write_block", "chz_bank_demod", "chz_bank_demod_auto", "chz_bank_read_pcm_flags_async", "chz_bank_pcm_wait", "chz_step", "chz_run_blocks", "chz_gather_descriptor",
     "chz_bank_set_tuning", "chz_bank_read_power", "chz_bank_read_power_async",
     "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
     "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real", "chz_bank_set_isb", "chz_bank_set_beam",

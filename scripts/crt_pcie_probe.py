@@ -1,88 +1,15 @@
 #!/usr/bin/env python3
-"""C_rt with PCIe in the loop: like crt_probe.py, but every block also takes its L new samples from pinned host memory
-(10.4 MB H2D) and returns EVERY channel's olen output samples to pinned host memory (1920 B per 12 kHz channel) before
-it counts as done.  The host link, not HBM, sets this figure (~6.5e5 channels at 63 GB/s).
-CRT_DEMOD=1: every channel carries the linear demodulator (fine tuning, noise estimate, AGC, mono S16BE) and
-what goes back is its packed PCM + status (480 B of S16, or 240 B of G.711 with CRT_ENC=mulaw, + the 96-byte status record, or one
-flag byte with CRT_STATUS=flags, per channel and block) instead of the complex baseband."""
-import ctypes as C, json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
+"""C_rt with the host link in the loop: bench.py's `c_rt_pcie` leg on its own, for other channel counts.
+usage: crt_pcie_probe.py <million channels> <baseband|demod> <sync|pipelined> [blocks]"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as ge
 import bench
 pkg = ge.load()
-lib = pkg.engine.lib()
-lib.chz_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-L, M, N = bench.L, bench.M, bench.N
-P, olen = 300, 240
-cap = int(float(sys.argv[1]) * 1e6) if len(sys.argv) > 1 else 1_500_000
-cap -= cap % 3072
-nblk = int(os.environ.get("CRT_BLOCKS", "200"))
-eng = pkg.engine.Engine(L, M, pkg.engine.REAL, ring_blocks=bench.RING_BLOCKS)
-hin = C.c_void_p(); hout = C.c_void_p()
-assert lib.chz_host_alloc(C.byref(hin), 4 * L) == 0 and lib.chz_host_alloc(C.byref(hout), 8 * olen * cap) == 0
-xin = np.ctypeslib.as_array(C.cast(hin, C.POINTER(C.c_float)), shape=(L,))
-xin[:] = (np.random.default_rng(1).standard_normal(L) * 0.05).astype(np.float32)
-bank = eng.bank(P, olen, cap)
-tile = 3072
-plan = bench.channel_plan_config3(tile)
-resp = np.stack([pkg.filterapi.design_response(P, olen, N, True, lo, hi, 11.0) for _, lo, hi in plan[:3]])
-resp = np.ascontiguousarray(np.tile(resp, (tile // 3, 1)))
-shifts = np.array([p[0] for p in plan], np.int32)
-for c0 in range(0, cap, tile):
-    bank.set_responses(c0, resp); bank.set_shifts(c0, shifts + (c0 // tile) % 7)
-eng.set_notches([0], 0.01)
-DEMOD = os.environ.get("CRT_DEMOD") == "1"
-FLAGS = os.environ.get("CRT_STATUS") == "flags"        # one status byte per channel and block instead of the 96-byte record
-if DEMOD:
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-    import oracle_lib as ol
-    lib.chz_bank_read_pcm_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    lib.chz_bank_read_pcm_flags_async.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    for c0 in range(0, cap, tile):
-        bank.set_tuning(0, c0, shifts + (c0 // tile) % 7, np.full(tile, -3.3 / 12000.0))
-    bank.enable_noise(129.6e6)
-    MULAW = os.environ.get("CRT_ENC") == "mulaw"        # G.711: one byte per sample, 240 B per channel and block
-    bank.set_pcm_stride(olen if MULAW else 2 * olen)     # mono S16: 480 B per channel and block, contiguous
-    q = ol.lin_params(encoding=ol.PCM_MULAW) if MULAW else ol.lin_params()
-    one = pkg.engine.DemodParams(*[getattr(q, f) for f, _ in ol.LinParams._fields_])
-    for c0 in range(0, cap, 65536):
-        bank.set_demod(0, c0, [one] * min(65536, cap - c0), 0.02)
-    hst = C.c_void_p()
-    assert lib.chz_host_alloc(C.byref(hst), C.sizeof(pkg.engine.DemodStatus) * cap) == 0
-import time
-
-def measure(n):
-    bank.set_active(n)
-    worst = tot = 0.0
-    for j in range(nblk + 4):
-        t0 = time.perf_counter()
-        assert lib.chz_input_write(eng._h, hin, L) == 0              # H2D of the block's new samples (pinned source)
-        assert lib.chz_step(eng._h, j) == 0
-        if DEMOD and FLAGS:
-            assert lib.chz_bank_read_pcm_flags_async(eng._h, bank.id, j % 4, 0, n, hout, hst) == 0
-        elif DEMOD:
-            assert lib.chz_bank_read_pcm_async(eng._h, bank.id, j % 4, 0, n, hout, hst) == 0
-        else:
-            assert lib.chz_bank_read_async(eng._h, bank.id, j % 4, 0, n, hout) == 0
-        eng.sync()
-        dt = (time.perf_counter() - t0) * 1e3
-        if j >= 4:
-            worst = max(worst, dt); tot += dt
-    return worst, tot / nblk
-
-res = []
-lo, hi = 0, cap
-w, a = measure(cap); res.append({"channels": cap, "worst_block_ms": w, "mean_block_ms": a}); print(json.dumps(res[-1]), flush=True)
-if w > 20.0:
-    while hi - lo > cap // 32:
-        mid = (lo + hi) // 2; mid -= mid % 3
-        w, a = measure(mid); res.append({"channels": mid, "worst_block_ms": w, "mean_block_ms": a}); print(json.dumps(res[-1]), flush=True)
-        if w <= 20.0: lo = mid
-        else: hi = mid
-ok = [r for r in res if r["worst_block_ms"] <= 20.0]
-best = max(ok, key=lambda r: r["channels"]) if ok else None
-print(json.dumps({"metric": "C_rt with PCIe in the loop (H2D samples + D2H of every channel's output per block)", "blocks": nblk,
-                  "c_rt": best, "capacity_limited": bool(best and best["channels"] == cap), "probes": res,
-                  "d2h_GBps_at_c_rt": (best["channels"] * olen * 8 / (best["mean_block_ms"] * 1e-3) / 1e9) if best else None}))
-eng.close()
+n = int(float(sys.argv[1]) * 1e6)
+demod = sys.argv[2] == "demod"
+pipe = sys.argv[3] == "pipelined"
+blocks = int(sys.argv[4]) if len(sys.argv) > 4 else 200
+wl = bench.workload_for(3, 0, 1, 0)
+print(json.dumps(bench.crt_pcie_leg(pkg, wl, n, blocks, demod, 0, pipe)))

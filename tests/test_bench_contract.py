@@ -55,8 +55,9 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
         assert x["blocks"] == 60 and x["drops"] == 0 and 0 < x["ms_per_block"] < 20.0 and x["worst_block_gap_ms"] > 0
         assert x["host_profile"]["staged_hits"] > 0
     pc = j["c_rt_pcie"]
-    assert len(pc) == 2 and all("error" not in x for x in pc), pc
-    assert pc[0]["d2h_bytes_per_channel"] == 1920 and pc[1]["d2h_bytes_per_channel"] == 481
+    assert len(pc) == 3 and all("error" not in x for x in pc), pc          # baseband, demodulated PCM, the same double-buffered
+    assert pc[0]["d2h_bytes_per_channel"] == 1920 and pc[1]["d2h_bytes_per_channel"] == 481 and pc[2]["d2h_bytes_per_channel"] == 481
+    assert "double-buffered" in pc[2]["loop"] and pc[2]["worst_latency_ms"] >= pc[2]["worst_block_ms"]
     assert all(x["blocks"] == 30 and x["d2h_bytes_per_block"] == x["channels"] * x["d2h_bytes_per_channel"] for x in pc)
 
 
