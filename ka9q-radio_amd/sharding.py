@@ -41,19 +41,28 @@ def pipelined_blocks(jobs, is_root, forward, broadcast, channels):
         channels(pending[1])
 
 
-def needed_rows(shifts, P, master_bins, na, margin_rows=1, in_type=2):
+MIN_NOISE_BINS = 1000        # Min_noise_bins, src/radio.c:73
+
+
+def needed_rows(shifts, P, master_bins, na, margin_rows=1, in_type=2, noise=False):
     """Rows [lo, hi) of the spectrum (rows of `na` bins, see SpecLayout) that the channels with these
     shifts read.  REAL master (in_type 2): bins |shift|-P/2 .. |shift|+P/2, a negative shift reading the same
     bins mirrored (src/filter.c:856-892).  COMPLEX master (in_type 1): a negative shift reads bins
     master_bins+shift at the TOP of the spectrum (src/filter.c:728-793), so the needed set can be two
     intervals; one covering interval cannot describe that, and the exchange must not silently ship the
-    wrong rows -- use the whole-slot broadcast for complex masters."""
+    wrong rows -- use the whole-slot broadcast for complex masters.
+    noise=True: the rank also runs estimate_noise() on these channels, whose window of max(P, 1000) bins around
+    |shift| (clamped to the spectrum, src/radio.c:1794-1816) is usually wider than the channel itself."""
     if in_type != 2:
         raise ValueError("needed_rows describes REAL masters only; broadcast the whole slot for a COMPLEX master")
     lo_bin, hi_bin = master_bins, 0
     for s in shifts:
         a, b = abs(int(s)) - P // 2 - 1, abs(int(s)) + (P + 1) // 2 + 1
         lo_bin, hi_bin = min(lo_bin, a), max(hi_bin, b)
+        if noise:
+            nb = max(P, MIN_NOISE_BINS)
+            w = min(max(abs(int(s)) - nb // 2, 0), master_bins - nb)
+            lo_bin, hi_bin = min(lo_bin, w), max(hi_bin, w + nb)
     lo_bin, hi_bin = max(lo_bin, 0), min(hi_bin, master_bins)
     if hi_bin <= lo_bin:
         return 0, 0

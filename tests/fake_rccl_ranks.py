@@ -38,23 +38,26 @@ def main(world, nblk):
             bank = eng.bank(P, olen, max(n, 1))
             bank.set_responses(0, np.stack([resp] * max(n, 1)))
             bank.set_shifts(0, shifts_all[first:last] if n else np.zeros(1, np.int32)); bank.set_active(n)
+            bank.enable_noise(50.0 * L)
             eng.set_notches([125, 0], 0.01)
             comm = pkg.engine.Comm(rank, world, uid, device=0)
             got = comm.allreduce_max([float(rank), -float(rank)])
             assert got.tolist() == [float(world - 1), 0.0], got
             comm.barrier()
             na, pitch, off = eng.spec_layout
-            rows = [pkg.sharding.needed_rows(shifts_all[slice(*pkg.sharding.shard_channels(total, r, world))], P, eng.bins, na) for r in range(world)]
+            rows = [pkg.sharding.needed_rows(shifts_all[slice(*pkg.sharding.shard_channels(total, r, world))], P, eng.bins, na, noise=True) for r in range(world)]
             out = {}
-            t = eng.run_blocks_sharded(comm, 0, nblk)                       # whole-slot broadcast
+            # row ranges first: what a peer's kernels read outside the rows it was sent is NOT the spectrum yet
+            t = eng.run_blocks_sharded(comm, 0, nblk, rows=([r[0] for r in rows], [r[1] for r in rows]))
             assert t.blocks == nblk
-            out["broadcast"] = [bank.read_slot(s).copy() for s in range(4)]
-            spec = eng.spectrum((nblk - 1) % 4).copy()
+            out["rows"] = [bank.read_slot(s).copy() for s in range(4)]
+            out["noise"] = [bank.read_noise(s).copy() for s in range(4)] if n else [np.zeros(0)] * 4
             gate.wait()
             if rank == 0:
                 eng.set_notches([125, 0], 0.01)                             # restart the recurrence for the second run
-            eng.run_blocks_sharded(comm, 0, nblk, rows=([r[0] for r in rows], [r[1] for r in rows]))
-            out["rows"] = [bank.read_slot(s).copy() for s in range(4)]
+            eng.run_blocks_sharded(comm, 0, nblk)                           # whole-slot broadcast
+            out["broadcast"] = [bank.read_slot(s).copy() for s in range(4)]
+            spec = eng.spectrum((nblk - 1) % 4).copy()
             comm.barrier()
             comm.close(); eng.close()
             results[rank] = (first, last, out, spec)
@@ -90,6 +93,11 @@ def main(world, nblk):
                 for c in range(last - first):
                     check_channel(got[c], ol.channel(spectra[j], ol.REAL, P, olen, int(shifts_all[first + c]), resp))
                     checked += 1
+        # estimate_noise() on the peers reads its 1000-bin windows out of the rows that were shipped
+        for j in range(max(0, nblk - 4), nblk):
+            for c in range(last - first):
+                want = ol.estimate_noise(spectra[j], ol.REAL, P, int(shifts_all[first + c]), 50.0 * L)
+                assert abs(out["noise"][j % 4][c] - want) <= 1e-6 * want, (first + c, j, out["noise"][j % 4][c], want)
         # and both hand-overs give the same samples
         for s in range(4):
             np.testing.assert_array_equal(out["rows"][s][:last - first], out["broadcast"][s][:last - first])

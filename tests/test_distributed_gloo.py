@@ -118,6 +118,10 @@ def test_needed_rows_and_exchange_plan():
     assert nr([-1000], 300, 16201, 45) == nr([1000], 300, 16201, 45)           # inverted spectrum reads the same bins
     assert nr([10, 16190], 300, 16201, 45) == (0, (16201 + 44) // 45)           # clipped to the spectrum
     assert nr([], 300, 16201, 45) == (0, 0)
+    # with the noise estimator on, the rank reads max(P, 1000) bins around |shift|, clamped to the spectrum (src/radio.c:1794-1816)
+    assert nr([5000], 300, 16201, 45, noise=True) == ((5000 - 500) // 45 - 1, (5000 + 500 + 44) // 45 + 1)
+    assert nr([100], 300, 16201, 45, noise=True) == (0, (1000 + 44) // 45 + 1)
+    assert nr([16100], 300, 16201, 45, noise=True)[0] == (16201 - 1000) // 45 - 1
     assert pkg.sharding.plan_exchange([(0, 100)], 100) == "none"
     assert pkg.sharding.plan_exchange([(0, 100), (0, 30), (40, 80)], 100) == "subband"
     assert pkg.sharding.plan_exchange([(0, 100), (0, 30), (10, 90)], 100) == "broadcast"
