@@ -171,6 +171,8 @@ struct NotchTurn {
 struct chz_engine {
   int L = 0, M = 0, N = 0, in_type = 0, bins = 0, per = 1, device = 0, ring_blocks = 0;
   FwdPlan plan;
+  float* energy[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // |X|^2 image of each slot for large banks' noise windows (spec_energy), made on first need
+  int noise_energy = -1;            // -1: by launch size, 0 never, 1 always (env CHZ_NOISE_ENERGY)
   int chan_stage = -1;              // output staging of chan_ifft: -1 by launch size, 0 never, 1 always (env CHZ_CHAN_STAGE)
   hipStream_t stream = nullptr;     // == lanes[0].s: input copies and anything not tied to a block
   bool own_stream = false;
@@ -299,6 +301,7 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   HIPOK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   e->own_stream = true;
   if (const char* cs = getenv("CHZ_CHAN_STAGE")) e->chan_stage = atoi(cs) != 0;
+  if (const char* cs = getenv("CHZ_NOISE_ENERGY")) e->noise_energy = atoi(cs) != 0;
   const char* envl = getenv("CHZ_STREAMS");
   int nl = envl ? atoi(envl) : 4;
   e->nlanes = (nl >= 4) ? 4 : (nl >= 2) ? 2 : 1;             // must divide ND so slot and lane stay aligned
@@ -377,6 +380,7 @@ void chz_engine_destroy(chz_engine* e) {
   for (auto& b : e->banks) free_bank(b);
   hipFree(e->ring); hipFree(e->ring16); hipFree(e->energy_part); hipFree(e->clip_part);
   for (int i = 0; i < CHZ_ND; i++) if (e->spec_owned[i]) hipFree(e->spec[i]);
+  for (int i = 0; i < CHZ_ND; i++) if (e->energy[i]) hipFree(e->energy[i]);
   hipFree(e->tw_sub_a); hipFree(e->tw_sub_b); hipFree(e->tw_sub_c);
   hipFree(e->tw1_tile); hipFree(e->tw1_col); hipFree(e->tw2_tile); hipFree(e->tw2_col); hipFree(e->tw2_full);
   free_notches(e);
@@ -784,8 +788,14 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   if (b.n0 && b.noise_samprate > 0.0) {
     NoiseParams q = noise_params(e->bins, e->in_type == CHZ_REAL, b.out_real ? b.P / 2 + 1 : b.P, b.noise_samprate);   // slave->bins
     q.spec = e->spec[slot]; q.lay = c.lay; q.desc = b.desc + so; q.n0 = b.n0 + so; q.ch0 = ch0; q.nch = n; q.magic = c.magic; q.dpitch = c.dpitch;
+    // a launch that reads every bin many times over takes |X|^2 once per bin first (16384 channels x 1000 bins = 10 x the spectrum)
+    const bool en = e->energy[slot] && (e->noise_energy >= 0 ? e->noise_energy != 0 : n >= 16384);
     mark(in, st, 3, true);
-    if (launch_noise(n, st, q, IN_E0(in), IN_E1(in))) return fail(-4, "no noise kernel for a %d-bin window", q.nbins);
+    if (en) {
+      launch_spec_energy(e->spec[slot], e->energy[slot], e->plan.spec_elems & ~1L, st, IN_E0(in), nullptr);     // (timed together with the
+      q.energy = e->energy[slot];                                                                                 //  windows when instrumented)
+    }
+    if (launch_noise(n, st, q, en ? nullptr : IN_E0(in), IN_E1(in))) return fail(-4, "no noise kernel for a %d-bin window", q.nbins);
     mark(in, st, 3, false);
   }
   // the linear demodulators of this bank, in block order on the demodulator stream.  Only whole-bank
@@ -1100,6 +1110,10 @@ int chz_bank_enable_noise(chz_engine* e, int bank, double samprate) {
   if (!b.n0 && samprate > 0.0) {
     HIPOK(hipMalloc((void**)&b.n0, sizeof(double) * (size_t)CHZ_ND * b.cap));
     HIPOK(hipMemset(b.n0, 0, sizeof(double) * (size_t)CHZ_ND * b.cap));
+    HIPOK(hipDeviceSynchronize());
+  }
+  if (samprate > 0.0 && !e->energy[0] && e->noise_energy != 0 && (b.cap >= 16384 || e->noise_energy == 1)) {
+    for (int i = 0; i < CHZ_ND; i++) HIPOK(hipMalloc((void**)&e->energy[i], sizeof(float) * (size_t)e->plan.spec_elems));
     HIPOK(hipDeviceSynchronize());
   }
   b.noise_samprate = samprate;

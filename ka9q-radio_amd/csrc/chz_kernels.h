@@ -1061,11 +1061,95 @@ struct NoiseParams {
   int nsort;              // 1024 or 2048: values sorted per channel (64 lanes x 16 or 32 registers)
   unsigned magic; int dpitch;   // bin -> storage index without a division (chan_layout)
   double scale;           // correction / (master bins * front-end sample rate)   (:1840-1844,1863-1865)
+  const float* energy;    // EN kernels: |X|^2 of every stored bin (spec_energy), same storage index as spec
 };
+
+// Large banks read every master bin hundreds of times (1.5 M channels x 1000-bin windows over 1.62 M bins): cnrmf() is then taken
+// ONCE per bin into an image of floats, and the windows read 4 bytes per bin instead of 8 -- the same float, bit for bit, since it is
+// the same three roundings.  One elementwise pass over the slot (13 MB in, 6.5 MB out), launched by the engine only when the bank is
+// large enough to pay for it.
+struct EnergyParams { const float2* spec; float* energy; long n; };
+__global__ void __launch_bounds__(256) spec_energy(EnergyParams p) {
+  const long stride = (long)gridDim.x * blockDim.x * 2;
+  const float4* __restrict__ in = reinterpret_cast<const float4*>(p.spec);
+  float2* __restrict__ out = reinterpret_cast<float2*>(p.energy);
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < p.n; i += stride) {       // n is even (the layout's pitch is)
+    const float4 x = in[i >> 1];
+    out[i >> 1] = make_float2(cnrm_unfused(make_float2(x.x, x.y)), cnrm_unfused(make_float2(x.z, x.w)));
+  }
+}
+
+// Reductions over the wavefront for wave-uniform results: DPP inside the rows of 16 lanes, then the four row results through
+// v_readlane into scalar registers (no LDS round trips as with ds_bpermute).  On the CPU test emulator: plain shuffles.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CHZ_DPP_U32(v, ctrl) ((unsigned)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xf, 0xf, false))
+#endif
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  { const unsigned o = CHZ_DPP_U32(v, 0xB1); v = o < v ? o : v; }      // quad_perm [1,0,3,2]
+  { const unsigned o = CHZ_DPP_U32(v, 0x4E); v = o < v ? o : v; }      // quad_perm [2,3,0,1]
+  { const unsigned o = CHZ_DPP_U32(v, 0x141); v = o < v ? o : v; }     // row_half_mirror
+  { const unsigned o = CHZ_DPP_U32(v, 0x140); v = o < v ? o : v; }     // row_mirror
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  const unsigned ab = a < b ? a : b, cd = c < d ? c : d;
+  return ab < cd ? ab : cd;
+#else
+  for (int d = 32; d >= 1; d >>= 1) { const unsigned o = __shfl_xor(v, d); v = o < v ? o : v; }
+  return v;
+#endif
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~wave_min_u32(~v); }
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  v += (int)CHZ_DPP_U32(v, 0xB1); v += (int)CHZ_DPP_U32(v, 0x4E); v += (int)CHZ_DPP_U32(v, 0x141); v += (int)CHZ_DPP_U32(v, 0x140);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+#else
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+#endif
+}
+// (the order of the additions differs from a butterfly's: callers that need a fixed order do not use this)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CHZ_DPP_F64_STEP(ctrl) { const unsigned long long u = (unsigned long long)__double_as_longlong(v); \
+    const unsigned lo = CHZ_DPP_U32((unsigned)u, ctrl), hi = CHZ_DPP_U32((unsigned)(u >> 32), ctrl); \
+    v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); }
+  CHZ_DPP_F64_STEP(0xB1) CHZ_DPP_F64_STEP(0x4E) CHZ_DPP_F64_STEP(0x141) CHZ_DPP_F64_STEP(0x140)
+#undef CHZ_DPP_F64_STEP
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  double r[4];
+  for (int k = 0; k < 4; k++) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 16 * k), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 16 * k);
+    r[k] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  }
+  return (r[0] + r[1]) + (r[2] + r[3]);
+#else
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+#endif
+}
+// inclusive prefix sum over the lanes and the wavefront's total
+__device__ __forceinline__ int wave_scan_i32(int v, int lane, int& total) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // inside each row of 16: row_shr 1, 2, 4, 8 with zero fill
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true); v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  const int r0 = __builtin_amdgcn_readlane(v, 15), r1 = __builtin_amdgcn_readlane(v, 31), r2 = __builtin_amdgcn_readlane(v, 47), r3 = __builtin_amdgcn_readlane(v, 63);
+  const int row = lane >> 4;
+  v += row == 0 ? 0 : (row == 1 ? r0 : (row == 2 ? r0 + r1 : r0 + r1 + r2));
+  total = r0 + r1 + r2 + r3;
+  return v;
+#else
+  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, (unsigned)d); if (lane >= d) v += o; }
+  total = __shfl(v, 63);
+  return v;
+#endif
+}
 
 // One wavefront per channel; the window lives in registers, VPL values per lane.
 #define NOISE_KC 4                    /* registers per lane for the values that share the quantile's binade (256 of them) */
-template <int VPL>
+template <int VPL, bool EN = false>
 __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
   const int lane = threadIdx.x & 63;
   // the channel index is the same in every lane: telling the compiler keeps the window arithmetic scalar
@@ -1090,24 +1174,46 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
   }
   const float inf = __builtin_huge_valf();
   float v[VPL];
+  unsigned mx = 0;                                                   // largest energy of the window (bit pattern), per lane
   // Coalesced loads (which register a bin lands in does not matter to a selection), all issued before
   // any is consumed: entries past n read the window's first bin and are replaced by +inf afterwards.
   // (the storage index of a bin without a division: one multiply-high by the layout's reciprocal, as in chan_ifft)
-  const float2* __restrict__ sp = p.spec;
-  CHZ_IN_DESC(sdesc, sp);
-  float2 x[VPL];
-  static_for<VPL>([&](auto rr) {
-    constexpr int R = decltype(rr)::value;
-    int i = R * 64 + lane;
-    if (i >= n) i = 0;
-    int k = mbin + i;
-    if (wrap && k >= wrap) k -= wrap;
-    x[R] = CHZ_LOAD2(sdesc, sp, spec_index(p.lay.off, p.magic, p.dpitch, k));
-  });
-  static_for<VPL>([&](auto rr) {
-    constexpr int R = decltype(rr)::value;
-    v[R] = (R * 64 + lane < n) ? cnrm_unfused(x[R]) : inf;
-  });
+  if constexpr (EN) {
+    const float* __restrict__ en = p.energy;
+    static_for<VPL>([&](auto rr) {
+      constexpr int R = decltype(rr)::value;
+      int i = R * 64 + lane;
+      if (i >= n) i = 0;
+      int k = mbin + i;
+      if (wrap && k >= wrap) k -= wrap;
+      v[R] = en[spec_index(p.lay.off, p.magic, p.dpitch, k)];
+    });
+    static_for<VPL>([&](auto rr) {
+      constexpr int R = decltype(rr)::value;
+      const unsigned u = __float_as_uint(v[R]);
+      mx = u > mx ? u : mx;                                           // (a padding entry holds the window's first bin here)
+      if (R * 64 + lane >= n) v[R] = inf;
+    });
+  } else {
+    const float2* __restrict__ sp = p.spec;
+    CHZ_IN_DESC(sdesc, sp);
+    float2 x[VPL];
+    static_for<VPL>([&](auto rr) {
+      constexpr int R = decltype(rr)::value;
+      int i = R * 64 + lane;
+      if (i >= n) i = 0;
+      int k = mbin + i;
+      if (wrap && k >= wrap) k -= wrap;
+      x[R] = CHZ_LOAD2(sdesc, sp, spec_index(p.lay.off, p.magic, p.dpitch, k));
+    });
+    static_for<VPL>([&](auto rr) {
+      constexpr int R = decltype(rr)::value;
+      const float raw = cnrm_unfused(x[R]);
+      const unsigned u = __float_as_uint(raw);
+      mx = u > mx ? u : mx;
+      v[R] = (R * 64 + lane < n) ? raw : inf;
+    });
+  }
   // quantile(energies, n, 0.10) (:1760-1775): the qi-th and (qi+1)-th smallest energies.  Non-negative floats order like
   // their bit patterns, so the qi-th smallest can be built bit by bit from the top: keep a bit whenever no more than qi
   // values lie strictly below the candidate; counting is one compare per register, a ballot and a scalar popcount.
@@ -1121,22 +1227,29 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
   const double frac = pos - (double)qi;
   unsigned bits[VPL];
   static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; bits[R] = __float_as_uint(v[R]); });
-  unsigned ans = 0;
-  int below = 0;                                                    // values strictly below `ans` (wave-uniform)
-  for (int bit = 30; bit >= 23; --bit) {
-    const unsigned t = ans | (1u << bit);
+  // The exponent first, by bisection over the exponents the window actually spans (white noise: some 15 binades, four steps instead
+  // of the eight a bit-by-bit search of the field needs): the answer is the largest exponent E with no more than qi values below
+  // E << 23, it is not below the smallest value's exponent (nothing lies below that) and not above the largest's.
+  unsigned mn = bits[0];
+  static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; mn = bits[R] < mn ? bits[R] : mn; });
+  int lo = (int)(wave_min_u32(mn) >> 23), hi = (int)(wave_max_u32(mx) >> 23);
+  if (lo > 255) lo = 255;                                            // (NaNs only: they sort above +inf)
+  if (hi > 255) hi = 255;
+  int below = 0;                                                     // values strictly below lo << 23 (wave-uniform)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    const unsigned t = (unsigned)mid << 23;
     int c = 0;
     static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; c += __popcll(__ballot(bits[R] < t)); });
-    if (c <= qi) { ans = t; below = c; }                             // wave-uniform
+    if (c <= qi) { lo = mid; below = c; } else hi = mid - 1;         // wave-uniform
   }
+  unsigned ans = (unsigned)lo << 23;
   // the binade [ans, ans + 2^23): how many values, and each lane's share of them
   const unsigned top = ans + (1u << 23);                             // (ans has exponent < 255: +inf padding and NaNs sort above every finite value)
   int mine = 0;
   static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; mine += (bits[R] >= ans && bits[R] < top) ? 1 : 0; });
-  int incl = mine;                                                    // inclusive scan over the lanes
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, (unsigned)d); if (lane >= d) incl += o; }
-  const int total = __builtin_amdgcn_readfirstlane(__shfl(incl, 63));
+  int total;
+  const int incl = wave_scan_i32(mine, lane, total);                 // inclusive scan over the lanes
   const int r = qi - below;                                          // rank of the answer inside the binade, 0 <= r < total
   unsigned cur = ans;
   int c_le;                                                          // values <= the answer, all of the window
@@ -1163,6 +1276,15 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
       }
       cl = __popcll(__ballot(cv[0] <= cur));
       if (cv[0] > cur && cv[0] < above) above = cv[0];
+    } else if (total <= 128) {                                       // white noise puts 50 to 90 values into the quantile's binade
+      for (int bit = 22; bit >= 0; --bit) {
+        const unsigned t = cur | (1u << bit);
+        if (__popcll(__ballot(cv[0] < t)) + __popcll(__ballot(cv[1] < t)) <= r) cur = t;
+      }
+      static_for<2>([&](auto jj) {
+        constexpr int J = decltype(jj)::value;
+        cl += __popcll(__ballot(cv[J] <= cur)); if (cv[J] > cur && cv[J] < above) above = cv[J];
+      });
     } else {
       for (int bit = 22; bit >= 0; --bit) {
         const unsigned t = cur | (1u << bit);
@@ -1199,8 +1321,7 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
   double q = q1;
   if (frac != 0.0) {
     // the next order statistic: q1 again if it occurs more than once beyond rank qi, else the smallest value above it
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const unsigned o = __shfl_xor(above, d); above = o < above ? o : above; }
+    above = wave_min_u32(above);
     const double q2 = c_le >= qi + 2 ? q1 : (double)__uint_as_float(above);
     double fq = frac * (q2 - q1);                                    // :1773, product rounded before the sum
     CHZ_ROUNDED_F64(fq);
@@ -1218,8 +1339,7 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
     constexpr int R = decltype(rr)::value;
     if (!none && bits[R] <= cb) { e += (double)v[R]; cnt++; }        // the +inf padding never qualifies
   });
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { e += __shfl_xor(e, d); cnt += __shfl_xor(cnt, d); }
+  e = wave_sum_f64(e); cnt = wave_sum_i32(cnt);
   if (lane == 0) p.n0[ch] = cnt ? e / (double)cnt * p.scale : 0.0;
 }
 

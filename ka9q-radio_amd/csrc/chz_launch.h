@@ -15,7 +15,7 @@ namespace chz {
 // per-kernel times measured in-process agree with the profiler.
 #define CHZ_LAUNCH(kern, grid, block, lds, s, ev0, ev1, p)                                              \
   do {                                                                                                  \
-    if (ev0) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (unsigned)(lds), s, ev0, ev1, 0, p); \
+    if (ev0 || ev1) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (unsigned)(lds), s, ev0, ev1, 0, p); \
     else hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, p);                                \
   } while (0)
 
@@ -160,8 +160,19 @@ inline void demod_tone_consts(double tone_freq, double samprate, DemodChan& c) {
   const double f = tone_freq / (double)(int)samprate;
   c.g_coeff = 2 * std::cos(2 * M_PI * f); c.g_cfr = std::cos(2 * M_PI * f); c.g_cfi = -std::sin(2 * M_PI * f);
 }
+// |X|^2 of every stored bin of a slot (n = the slot's element count): the input of the EN noise kernels
+inline void launch_spec_energy(const float2* spec, float* energy, long n, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+  EnergyParams q{spec, energy, n};
+  long grid = (n / 2 + 255) / 256; if (grid > 2048) grid = 2048;
+  CHZ_LAUNCH(spec_energy, (int)grid, 256, 0, s, e0, e1, q);
+}
 inline int launch_noise(int nch, hipStream_t s, const NoiseParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   const int grid = (nch + 3) / 4;          // four wavefronts = four channels per workgroup
+  if (p.energy) {
+    if (p.nsort == 1024) { CHZ_LAUNCH((noise_est<16, true>), grid, 256, 0, s, e0, e1, p); return 0; }
+    if (p.nsort == 2048) { CHZ_LAUNCH((noise_est<32, true>), grid, 256, 0, s, e0, e1, p); return 0; }
+    return -1;
+  }
   if (p.nsort == 1024) { CHZ_LAUNCH((noise_est<16>), grid, 256, 0, s, e0, e1, p); return 0; }
   if (p.nsort == 2048) { CHZ_LAUNCH((noise_est<32>), grid, 256, 0, s, e0, e1, p); return 0; }
   return -1;

@@ -755,6 +755,41 @@ def test_noise_estimate_matches_radio_c(pkg, L, M, P, olen, nch):
         eng.close()
 
 
+@pytest.mark.parametrize("master", ["real", "complex"])
+def test_noise_windows_from_the_energy_image(pkg, monkeypatch, master):
+    # large banks take |X|^2 once per bin (spec_energy) and their noise windows read that image instead of the spectrum: the same
+    # estimate bit for bit (forced on here for a small bank) -- windows clamped at both ends of a REAL master, an inverted channel,
+    # windows that wrap or stop at the seam of a COMPLEX master -- and radio.c's arithmetic on the device's own spectrum
+    L, M, P, olen, nch = 25920, 6481, 300, 240, 40
+    in_type = ol.REAL if master == "real" else ol.COMPLEX
+    N = L + M - 1
+    B = N // 2 + 1 if master == "real" else N
+    fs = 50.0 * L
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal(L if master == "real" else 2 * L).astype(np.float32)
+    if master == "real":
+        shifts = np.array([3, 140, 499, 501, B - 100, B - 20, -700] + [900 + 371 * i for i in range(nch - 7)], np.int32)
+    else:
+        shifts = np.array([0, 3, -3, 499, -501, N // 2 - 100, N // 2 + 100 - N, -(N // 2) + 5] + [(-1) ** i * (700 + 371 * i) for i in range(nch - 8)], np.int32)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CHZ_NOISE_ENERGY", mode)
+        eng = pkg.engine.Engine(L, M, in_type, ring_blocks=8)
+        try:
+            b = eng.bank(P, olen, nch)
+            b.set_responses(0, np.ones((nch, P), np.complex64) / P); b.set_shifts(0, shifts); b.set_active(nch)
+            b.enable_noise(fs)
+            for job in range(2):
+                eng.write(x); eng.step(job)
+            got[mode] = b.read_noise(1).copy()
+            spec = eng.spectrum(1)
+        finally:
+            eng.close()
+    np.testing.assert_array_equal(got["0"], got["1"])
+    want = np.array([ol.estimate_noise(spec, in_type, P, int(s), fs) for s in shifts])
+    assert np.allclose(got["1"], want, rtol=1e-12, atol=0) and np.any(want > 0)
+
+
 def test_staged_output_path_is_bit_identical(pkg, monkeypatch):
     # large launches send the output rows through LDS as full-line stores (chz_kernels.h: p.stage); forced on here for a
     # small bank, incl. a channel count that is not a multiple of the channels per wavefront and range launches at odd offsets
