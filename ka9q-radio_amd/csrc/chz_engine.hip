@@ -86,6 +86,7 @@ struct Bank {
   DemodExt* dm_ext = nullptr;            // [cap] PLL / tone-squelch state; allocated when the first channel asks for either
   float2* dm_mix = nullptr;              // [cap][olen] the coherent modes' blocks after their PLL (pll_lanes); allocated with dm_ext
   int dm_pll_lin = 0;                    // channels of the linear demodulator with a carrier PLL
+  int dm_fm_pll = 0, dm_fm_tone = 0;     // FM channels with the PLL demodulator / a PL-tone squelch
   DemodStatus* dm_status = nullptr;      // [ND][cap]
   unsigned char* dm_flags = nullptr;     // [ND][cap] one status byte per channel and block
   unsigned char* dm_pcm = nullptr;       // [ND][cap][pcm_stride]
@@ -233,7 +234,7 @@ static void free_bank(Bank& b) {
   hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); hipFree(b.any_scratch); b.any_scratch = nullptr;
   hipFree(b.fine); hipFree(b.power); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam);
   hipFree(b.dm_chan); hipFree(b.dm_state); hipFree(b.dm_ext); hipFree(b.dm_status); hipFree(b.dm_flags); hipFree(b.dm_pcm); hipFree(b.dm_mix);
-  b.dm_mix = nullptr; b.dm_pll_lin = 0;
+  b.dm_mix = nullptr; b.dm_pll_lin = 0; b.dm_fm_pll = 0; b.dm_fm_tone = 0;
   b.dm_chan = nullptr; b.dm_state = nullptr; b.dm_ext = nullptr; b.dm_status = nullptr; b.dm_flags = nullptr; b.dm_pcm = nullptr; b.dm_on = 0; b.dm_chan_h.clear(); b.dm_osc.clear();
   for (int s = 0; s < CHZ_ND; s++) {
     if (b.ev_bank[s]) (void)hipEventDestroy(b.ev_bank[s]);
@@ -811,7 +812,8 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
     d.in = bank_out(b, slot); d.power = b.power + so; d.n0 = b.n0 + so; d.chan = b.dm_chan; d.state = b.dm_state; d.ext = b.dm_ext;
     d.status = b.dm_status + so; d.flags = b.dm_flags + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = n; d.olen = b.olen;
     d.pcm_stride = b.pcm_stride; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;      // Power_alpha, src/radio.c:72
-    d.mix = b.dm_pll_lin > 0 ? b.dm_mix : nullptr;
+    d.lin_pll = b.dm_pll_lin > 0; d.fm_pll = b.dm_fm_pll > 0; d.fm_tone = b.dm_fm_tone > 0;
+    d.mix = (d.lin_pll || d.fm_pll || d.fm_tone) ? b.dm_mix : nullptr;
     mark(in, ts, 6, true);
     if (launch_demod(ts, d, IN_E0(in), IN_E1(in))) return fail(-4, "the demodulator kernel refuses blocks of %d samples", b.olen);
     mark(in, ts, 6, false);
@@ -1305,8 +1307,13 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
       init.push_back(st); init_ch.push_back(ch0 + i);
     }
   }
-  b.dm_pll_lin = 0;
-  for (const DemodChan& dc : b.dm_chan_h) b.dm_pll_lin += (dc.on && dc.kind == CHZ_DEMOD_LINEAR && dc.pll_enable) ? 1 : 0;
+  b.dm_pll_lin = 0; b.dm_fm_pll = 0; b.dm_fm_tone = 0;
+  for (const DemodChan& dc : b.dm_chan_h) {
+    if (!dc.on) continue;
+    b.dm_pll_lin += (dc.kind == CHZ_DEMOD_LINEAR && dc.pll_enable) ? 1 : 0;
+    b.dm_fm_pll += (dc.kind == CHZ_DEMOD_FM && dc.pll_enable) ? 1 : 0;
+    b.dm_fm_tone += (dc.kind == CHZ_DEMOD_FM && dc.tone_freq != 0) ? 1 : 0;
+  }
   HIPOK(hipMemcpy(b.dm_chan + ch0, b.dm_chan_h.data() + ch0, sizeof(DemodChan) * (size_t)n, hipMemcpyHostToDevice));
   for (size_t k = 0; k < init.size(); k++)
     HIPOK(hipMemcpy(b.dm_state + init_ch[k], &init[k], sizeof(DemodState), hipMemcpyHostToDevice));
@@ -1350,7 +1357,8 @@ int chz_bank_demod(chz_engine* e, int bank, unsigned job, int slot) {
   d.in = bank_out(b, slot); d.power = b.power + so; d.n0 = b.n0 + so; d.chan = b.dm_chan; d.state = b.dm_state; d.ext = b.dm_ext;
   d.status = b.dm_status + so; d.flags = b.dm_flags + so; d.pcm = b.dm_pcm + so * (size_t)b.pcm_stride; d.ch0 = 0; d.nch = b.active; d.olen = b.olen;
   d.pcm_stride = b.pcm_stride; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;
-  d.mix = b.dm_pll_lin > 0 ? b.dm_mix : nullptr;
+  d.lin_pll = b.dm_pll_lin > 0; d.fm_pll = b.dm_fm_pll > 0; d.fm_tone = b.dm_fm_tone > 0;
+    d.mix = (d.lin_pll || d.fm_pll || d.fm_tone) ? b.dm_mix : nullptr;
   if (b.pcm_copying[slot]) HIPOK(hipStreamWaitEvent(e->tail, b.ev_pcm[slot], 0));
   if (launch_demod(e->tail, d)) return fail(-4, "the demodulator kernel refuses blocks of %d samples", b.olen);
   HIPOK(hipGetLastError());

@@ -1372,7 +1372,10 @@ struct PllState { unsigned vco_phase; int vco_step, wraps, lock, lock_count, pad
                   double bw, damping, lower, upper, u, phi, K1, K2; };
 struct DemodExt { PllState pll; double pll_snr, pll_cphase, foffset;                       // chan->pll.snr / .cphase, chan->sig.foffset (linear)
                   double g_s0, g_s1, old_pl_phase, tone_deviation;                         // Goertzel state, src/fm.c:60, chan->fm.tone_deviation
-                  int pll_rotations, pl_sample_count, tone_mute, pad; };
+                  int pll_rotations, pl_sample_count, tone_mute, pad;
+                  // hand-over between the passes of an FM channel whose PLL demodulator / PL-tone detector runs one channel per lane
+                  double fm_snr, fm_noise;                                                 // fm_front_k -> fm_pll_lanes, demod_linear_tail, fm_finish
+                  int fm_go, fm_stage; };                                                  // squelch open this block; 1 = waiting for the tone decision
 struct DemodState { double gain, am_dc, n0; int hangcount, squelch_state, squelch_open, pll_was_on;   // pll_was_on: chan->pll.was_on (FM, src/fm.c:178-184,209)
                     double pm_re, pm_im, deemph_state, foffset, pdeviation; };   // FM: phase_memory, de-emphasis state, chan->sig.foffset, chan->fm.pdeviation
 struct DemodStatus { int frame, mute, squelch_state, pll_lock; double output_power, gain, n0, snr, foffset, pdeviation;   // frame 0 = PCM present, 1 = silence
@@ -1390,6 +1393,8 @@ struct DemodParams {
   int ch0, nch, olen, pcm_stride;
   unsigned job;
   double blocktime, power_alpha;
+  int lin_pll, fm_pll, fm_tone;   // the bank has channels with a carrier PLL (linear) / the PLL demodulator (FM) / a PL-tone squelch (FM): which
+                             // of the lane-per-channel passes launch_demod adds; they need `mix`
   float2* mix;               // [cap][olen] or nullptr: the coherent modes' blocks after their PLL (written by pll_lanes, one CHANNEL PER LANE);
                              // nullptr: lane 0 of each channel's wavefront walks the block inside demod_linear_tail (round 2's way)
 };
@@ -1561,25 +1566,21 @@ __device__ inline double pll_run(PllState& q, double phase) {                   
 // demod_fm()'s per-block work (src/fm.c:19-345), one wavefront per channel, lane l owning SEG consecutive samples.  esh[] is
 // per-lane scratch (every lane reads only what it wrote) except around the two sequential stages -- the PLL demodulator
 // (:176-203) and the PL-tone detector (:264-311) -- which lane 0 runs over the whole block between wavefront syncs.
-__device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodChan& c, DemodState st, int ch, int lane, double* esh, float2* xs) {
-  const int N = p.olen;
-  const int SEG = (N + 63) >> 6;
-  const int n0 = lane * SEG;
-  const int cnt = n0 >= N ? 0 : (N - n0 < SEG ? N - n0 : SEG);
-  const float2* __restrict__ x = p.in + (size_t)ch * N;
-  unsigned char* __restrict__ o = p.pcm + (size_t)ch * p.pcm_stride;
+// ---- demod_fm() in pieces, so that the same statements serve the one-kernel path and the split one (PLL demodulator and PL-tone
+// detector at one channel per lane, below): every piece is the reference's own order of operations.
+struct FmFront { double fmsnr, noise; };
+// :55-155 noise smoothing, both SNR estimators, the squelch sequencer.  Advances st.n0 and st.squelch_state.
+__device__ __forceinline__ FmFront fm_front(const DemodParams& p, const DemodChan& c, DemodState& st, int ch, const float2* __restrict__ x,
+                                            int n0, int cnt, int N, double* esh) {
   const double bb_power = p.power[ch];
-  const double samprate = c.samprate, devmax = 5000.0, beta = 0.5;             // src/fm.c:43,103
-  const bool tone = c.tone_freq != 0, pll = c.pll_enable != 0;                  // wave-uniform
   const double est = p.n0[ch];
   if (st.n0 != st.n0) st.n0 = est;
   else { const double diff = est - st.n0; st.n0 += p.power_alpha * diff; }
-  const double alpha = -expm1(-p.blocktime / 1.0);                              // :55
-  const double noise = st.n0 * c.bandwidth;                                     // :101
-  const double snr = noise == 0 ? __builtin_huge_val() : (bb_power / noise) - 1.0;
-  double fmsnr;
+  FmFront f;
+  f.noise = st.n0 * c.bandwidth;                                                // :101
+  const double snr = f.noise == 0 ? __builtin_huge_val() : (bb_power / f.noise) - 1.0;
   if (c.snr_squelch || (st.squelch_state <= 0 && snr < c.squelch_close)) {
-    fmsnr = snr;
+    f.fmsnr = snr;
   } else {                                                                      // :110-129 amplitude variance
     double part = 0.0;
     for (int i = 0; i < cnt; i++) { const double a = (double)demod_cabsf(x[n0 + i]); esh[n0 + i] = a; part += a; }
@@ -1588,15 +1589,106 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
     for (int i = 0; i < cnt; i++) { const double dlt = esh[n0 + i] - avg; part += dlt * dlt; }
     const double var = wave_sum(part);
     const double s2 = fm_snr_dev(avg * avg * (N - 1) / var);
-    fmsnr = s2 > 0.0 ? s2 : 0.0;
+    f.fmsnr = s2 > 0.0 ? s2 : 0.0;
   }
   const int smax = c.squelch_tail + 5;                                          // :149-155
-  if (fmsnr >= c.squelch_open) st.squelch_state = smax;
-  else if (st.squelch_state > 0 && (fmsnr < c.squelch_close || st.squelch_state < smax)) st.squelch_state--;
+  if (f.fmsnr >= c.squelch_open) st.squelch_state = smax;
+  else if (st.squelch_state > 0 && (f.fmsnr < c.squelch_close || st.squelch_state < smax)) st.squelch_state--;
+  return f;
+}
+// one sample of the PLL demodulator (:185-201)
+__device__ __forceinline__ float fm_pll_sample(PllState& q, float2 v, double pdev, bool extend, double beta, double noise) {
+  double sn, cs; pll_nco(q.vco_phase, sn, cs);
+  const double br = v.x, bi = v.y;
+  const double sr = br * cs + bi * sn, si = bi * cs - br * sn;                  // buffer[n] * conj(vco)
+  double phase = M_1_PI * atan2(si, sr);
+  if (extend) {
+    if (fabs(phase) > pdev) phase = copysign(pdev, phase);
+    float a = v.x * v.x, b = v.y * v.y; CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
+    double pw = (double)(a + b);
+    if (pw > 0) { pw /= (pw + beta * noise); phase *= pw; }
+    else phase = 0;
+  }
+  return (float)(2 * pll_run(q, phase));
+}
+// the PL-tone detector's state and one sample of it (:264-304)
+struct FmTone { double s0, s1, old_phase, tdev; int count, tmute; };
+__device__ __forceinline__ void fm_tone_sample(FmTone& g, const DemodChan& c, double xin, int isamprate, int integrate) {
+  { const double t = xin + c.g_coeff * g.s0 - g.s1; g.s1 = g.s0; g.s0 = t; }   // update_goertzel
+  if (++g.count >= integrate) {
+    { const double t = 0.0 + c.g_coeff * g.s0 - g.s1; g.s1 = g.s0; g.s0 = t; } // output_goertzel: one zero sample
+    const double cre = g.s0 - c.g_cfr * g.s1, cim = -c.g_cfi * g.s1;
+    const double gm = sqrt(cre * cre + cim * cim) / g.count;
+    g.tdev = isamprate * gm;
+    const double ph = atan2(cim, cre) / (2 * M_PI);
+    g.old_phase += c.tone_freq * g.count / isamprate;
+    double ip;
+    double np = 2 * modf(ph - g.old_phase, &ip);
+    g.old_phase = ph;
+    np = np < -1 ? np + 2 : np > 1 ? np - 2 : np;
+    g.tmute = g.tdev < 250 || fabs(np) > .10;
+    g.s0 = 0.0; g.s1 = 0.0; g.count = 0;
+  }
+}
+// :312-334 de-emphasis (a scan of affine maps over the lanes' segments), gain, PCM, the status record.  esh[] holds the baseband
+// after DC removal.
+__device__ __forceinline__ void fm_deemph_output(const DemodParams& p, const DemodChan& c, DemodState& st, DemodStatus& r, int ch, int lane,
+                                                 double* esh, int n0, int cnt, int N) {
+  unsigned char* __restrict__ o = p.pcm + (size_t)ch * p.pcm_stride;
+  const bool pm = c.deemph_rate != 0;
+  double y_in = st.deemph_state;
+  if (pm) {
+    double A = 1.0, B = 0.0;
+    for (int i = 0; i < cnt; i++) {
+      const float b = (float)esh[n0 + i];
+      A *= (1.0 - c.deemph_rate); B = (1.0 - c.deemph_rate) * B + c.deemph_rate * (c.deemph_gain * (double)b);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const double Ap = __shfl_up(A, d), Bp = __shfl_up(B, d);
+      if (lane >= d) { B = A * Bp + B; A = A * Ap; }
+    }
+    const double Ae = __shfl_up(A, 1), Be = __shfl_up(B, 1);
+    y_in = lane == 0 ? st.deemph_state : Ae * st.deemph_state + Be;
+    st.deemph_state = __shfl(A, 63) * st.deemph_state + __shfl(B, 63);
+  }
+  const double gain = (2 * c.headroom * c.samprate) / c.bandwidth;              // :325
+  double part = 0.0;
+  {
+    double y = y_in;
+    for (int i = 0; i < cnt; i++) {
+      float b = (float)esh[n0 + i];
+      if (pm) { y += c.deemph_rate * (c.deemph_gain * (double)b - y); b = (float)y; }
+      const double sgn = gain * (double)b;
+      part += sgn * sgn;
+      demod_put(o, c.encoding, n0 + i, (float)sgn);
+    }
+  }
+  r.frame = 0; r.mute = 0; r.gain = gain; r.output_power = wave_sum(part) / N; r.foffset = st.foffset; r.pdeviation = st.pdeviation;
+  if (lane == 0) { demod_publish(p, ch, r); p.state[ch] = st; }
+}
+
+__device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodChan& c, DemodState st, int ch, int lane, double* esh, float2* xs) {
+  const int N = p.olen;
+  const int SEG = (N + 63) >> 6;
+  const int n0 = lane * SEG;
+  const int cnt = n0 >= N ? 0 : (N - n0 < SEG ? N - n0 : SEG);
+  const float2* __restrict__ x = p.in + (size_t)ch * N;
+  const double samprate = c.samprate, devmax = 5000.0, beta = 0.5;             // src/fm.c:43,103
+  const bool tone = c.tone_freq != 0, pll = c.pll_enable != 0;                  // wave-uniform
+  const bool pll_split = pll && p.mix != nullptr && p.fm_pll != 0;              // fm_front_k + fm_pll_lanes have run for this channel
+  const bool tone_split = tone && p.mix != nullptr && p.fm_tone != 0;           // fm_tone_lanes + fm_finish will
+  DemodExt* __restrict__ ext = p.ext + ch;                                      // touched only with pll / tone
+  float* __restrict__ mixf = reinterpret_cast<float*>(p.mix) + (size_t)ch * 2 * N;   // [N] PLL baseband, [N] the tone detector's input
+  const double alpha = -expm1(-p.blocktime / 1.0);                              // :55
+  FmFront f;
+  if (pll_split) { f.fmsnr = ext->fm_snr; f.noise = ext->fm_noise; }           // (st was advanced by fm_front_k)
+  else f = fm_front(p, c, st, ch, x, n0, cnt, N, esh);
+  const double fmsnr = f.fmsnr, noise = f.noise;
+  const int smax = c.squelch_tail + 5;
   DemodStatus r;
   r.pll_lock = 0; r.pll_snr = 0.0; r.pll_cphase = 0.0; r.pll_rotations = 0; r.tone_deviation = 0.0; r.tone_mute = 0;
   r.n0 = st.n0; r.snr = fmsnr; r.squelch_state = st.squelch_state; r.gain = 0.0;
-  DemodExt* __restrict__ ext = p.ext + ch;                                      // touched by lane 0 only, and only with pll / tone
   if (st.squelch_state <= 4) {                                                  // :157-173
     if (st.squelch_state >= 1) { st.pm_re = 0.0; st.pm_im = 0.0; }
     r.frame = 1; r.mute = st.squelch_state == 0; r.output_power = 0.0; r.foffset = st.foffset; r.pdeviation = st.pdeviation;
@@ -1610,7 +1702,10 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
     }
     return;
   }
-  if (pll) {
+  if (pll_split) {
+    for (int i = 0; i < cnt; i++) esh[n0 + i] = (double)mixf[n0 + i];          // fm_pll_lanes has walked the block
+    st.pll_was_on = 1;
+  } else if (pll) {
     // :176-203 PLL demodulator: the block goes to LDS, lane 0 walks it
     for (int i = 0; i < cnt; i++) xs[n0 + i] = x[n0 + i];
     CHZ_WAVE_SYNC();
@@ -1623,21 +1718,7 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
         pll_set_params(q, 500.0 / isamprate, M_SQRT1_2);
         q.lower = -pdev; q.upper = +pdev;
       }
-      for (int n = 0; n < N; n++) {
-        double sn, cs; pll_nco(q.vco_phase, sn, cs);
-        const float2 v = xs[n];
-        const double br = v.x, bi = v.y;
-        const double sr = br * cs + bi * sn, si = bi * cs - br * sn;            // buffer[n] * conj(vco)
-        double phase = M_1_PI * atan2(si, sr);
-        if (c.threshold_extend != 0) {
-          if (fabs(phase) > pdev) phase = copysign(pdev, phase);
-          float a = v.x * v.x, b = v.y * v.y; CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
-          double pw = (double)(a + b);
-          if (pw > 0) { pw /= (pw + beta * noise); phase *= pw; }
-          else phase = 0;
-        }
-        esh[n] = (double)(float)(2 * pll_run(q, phase));
-      }
+      for (int n = 0; n < N; n++) esh[n] = (double)fm_pll_sample(q, xs[n], pdev, c.threshold_extend != 0, beta, noise);
       ext->pll = q;
     }
     st.pll_was_on = 1;
@@ -1684,25 +1765,15 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
     ppos -= st.foffset; pneg -= st.foffset;
     st.pdeviation = ppos > -pneg ? ppos : -pneg;
   }
-  const bool pm = c.deemph_rate != 0;
-  const float dc = (float)(2 * st.foffset / samprate);                          // :258-263
-  const double deemph_before = st.deemph_state;
-  double y_in = st.deemph_state;
-  if (pm) {                                                                     // :312-320 as a scan of affine maps
-    double A = 1.0, B = 0.0;
-    for (int i = 0; i < cnt; i++) {
-      const float b = (float)esh[n0 + i] - dc;
-      esh[n0 + i] = (double)b;
-      A *= (1.0 - c.deemph_rate); B = (1.0 - c.deemph_rate) * B + c.deemph_rate * (c.deemph_gain * (double)b);
-    }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const double Ap = __shfl_up(A, d), Bp = __shfl_up(B, d);
-      if (lane >= d) { B = A * Bp + B; A = A * Ap; }
-    }
-    const double Ae = __shfl_up(A, 1), Be = __shfl_up(B, 1);
-    y_in = lane == 0 ? st.deemph_state : Ae * st.deemph_state + Be;
-    st.deemph_state = __shfl(A, 63) * st.deemph_state + __shfl(B, 63);
+  if (c.deemph_rate != 0) {                                                     // :258-263 DC removal (with the de-emphasis, :312-320)
+    const float dc = (float)(2 * st.foffset / samprate);
+    for (int i = 0; i < cnt; i++) { const float b = (float)esh[n0 + i] - dc; esh[n0 + i] = (double)b; }
+  }
+  if (tone_split) {
+    // the tone detector runs one channel per lane in fm_tone_lanes; fm_finish takes the block from there
+    for (int i = 0; i < cnt; i++) mixf[N + n0 + i] = (float)esh[n0 + i];
+    if (lane == 0) { ext->fm_snr = fmsnr; ext->fm_stage = 1; p.state[ch] = st; }
+    return;
   }
   if (tone) {
     // :264-311 PL / CTCSS tone squelch on the baseband after DC removal and before de-emphasis: a Goertzel detector integrated over
@@ -1711,53 +1782,23 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
     CHZ_WAVE_SYNC();
     int tmute = 0; double tdev = 0.0;
     if (lane == 0) {
-      double s0 = ext->g_s0, s1 = ext->g_s1, old_phase = ext->old_pl_phase;
-      int count = ext->pl_sample_count; tmute = ext->tone_mute; tdev = ext->tone_deviation;
+      FmTone g{ext->g_s0, ext->g_s1, ext->old_pl_phase, ext->tone_deviation, ext->pl_sample_count, ext->tone_mute};
       const int isamprate = (int)samprate;
       const int integrate = (int)rint(isamprate * 0.24);
-      for (int n = 0; n < N; n++) {
-        { const double t = esh[n] + c.g_coeff * s0 - s1; s1 = s0; s0 = t; }     // update_goertzel
-        if (++count >= integrate) {
-          { const double t = 0.0 + c.g_coeff * s0 - s1; s1 = s0; s0 = t; }      // output_goertzel: one zero sample
-          const double cre = s0 - c.g_cfr * s1, cim = -c.g_cfi * s1;
-          const double g = sqrt(cre * cre + cim * cim) / count;
-          tdev = isamprate * g;
-          const double ph = atan2(cim, cre) / (2 * M_PI);
-          old_phase += c.tone_freq * count / isamprate;
-          double ip;
-          double np = 2 * modf(ph - old_phase, &ip);
-          old_phase = ph;
-          np = np < -1 ? np + 2 : np > 1 ? np - 2 : np;
-          tmute = tdev < 250 || fabs(np) > .10;
-          s0 = 0.0; s1 = 0.0; count = 0;
-        }
-      }
-      ext->g_s0 = s0; ext->g_s1 = s1; ext->old_pl_phase = old_phase; ext->pl_sample_count = count;
-      ext->tone_mute = tmute; ext->tone_deviation = tdev;
+      for (int n = 0; n < N; n++) fm_tone_sample(g, c, esh[n], isamprate, integrate);
+      ext->g_s0 = g.s0; ext->g_s1 = g.s1; ext->old_pl_phase = g.old_phase; ext->pl_sample_count = g.count;
+      ext->tone_mute = g.tmute; ext->tone_deviation = g.tdev;
+      tmute = g.tmute; tdev = g.tdev;
     }
     tmute = __shfl(tmute, 0); tdev = __shfl(tdev, 0);
     r.tone_deviation = tdev; r.tone_mute = tmute;
     if (tmute) {                                                                // :305-309: muted before de-emphasis runs
-      st.deemph_state = deemph_before;
       r.frame = 1; r.mute = 1; r.output_power = 0.0; r.foffset = st.foffset; r.pdeviation = st.pdeviation;
       if (lane == 0) { demod_publish(p, ch, r); p.state[ch] = st; }
       return;
     }
   }
-  const double gain = (2 * c.headroom * samprate) / c.bandwidth;                // :325
-  double part = 0.0;
-  {
-    double y = y_in;
-    for (int i = 0; i < cnt; i++) {
-      float b = (float)esh[n0 + i];
-      if (pm) { y += c.deemph_rate * (c.deemph_gain * (double)b - y); b = (float)y; }
-      const double s = gain * (double)b;
-      part += s * s;
-      demod_put(o, c.encoding, n0 + i, (float)s);
-    }
-  }
-  r.frame = 0; r.mute = 0; r.gain = gain; r.output_power = wave_sum(part) / N; r.foffset = st.foffset; r.pdeviation = st.pdeviation;
-  if (lane == 0) { demod_publish(p, ch, r); p.state[ch] = st; }
+  fm_deemph_output(p, c, st, r, ch, lane, esh, n0, cnt, N);
 }
 
 // The carrier PLL of the coherent modes (src/linear.c:83-153, loop src/osc.c:75-205) at ONE CHANNEL PER LANE.  The loop is a
@@ -1845,6 +1886,143 @@ __global__ void __launch_bounds__(64, 2) pll_lanes(DemodParams p) {
   }
 }
 
+// ---- FM's two sample-by-sample recurrences at ONE CHANNEL PER LANE (src/fm.c:176-203 the PLL demodulator, :264-311 the PL-tone
+// detector).  Inside demod_fm_wave lane 0 walks the block while 63 lanes wait: 66 ns per channel with the PLL demodulator and 6.1 ns
+// with the tone detector, against 2.4 ns for plain FM (profiles/r03_fm_probe.jsonl).  demod_fm() is therefore cut where the loops sit:
+//   fm_front_k      (a wavefront per channel)  noise smoothing, SNR, squelch sequencer          -> ext.fm_go / fm_snr / fm_noise, state
+//   fm_pll_lanes    (a LANE per channel)       the PLL loop over the block                      -> mix[0..N) baseband, ext.pll
+//   demod_linear_tail                          everything between the loops                     -> mix[N..2N) tone input, ext.fm_stage
+//   fm_tone_lanes   (a LANE per channel)       the Goertzel detector and its decision           -> ext tone state
+//   fm_finish       (a wavefront per channel)  mute, or de-emphasis + gain + PCM + status
+// Only channels that use the PLL demodulator take the first two, only channels with a tone squelch the last two; the statements are
+// the ones demod_fm_wave runs (fm_front, fm_pll_sample, fm_tone_sample, fm_deemph_output), so the frames are bit-identical.
+__global__ void __launch_bounds__(64) fm_front_k(DemodParams p) {
+  HIP_DYNAMIC_SHARED(double, esh)                          // [N]
+  const int lane = (int)threadIdx.x;
+  const int ch = p.ch0 + (int)blockIdx.x;
+  const DemodChan* __restrict__ cp = p.chan + ch;
+  if (!cp->on || cp->kind != 1 || cp->pll_enable == 0) return;                // wave-uniform
+  const DemodChan c = *cp;
+  DemodState st = p.state[ch];
+  const int N = p.olen, SEG = (N + 63) >> 6, n0 = lane * SEG;
+  const int cnt = n0 >= N ? 0 : (N - n0 < SEG ? N - n0 : SEG);
+  const FmFront f = fm_front(p, c, st, ch, p.in + (size_t)ch * N, n0, cnt, N, esh);
+  if (lane == 0) {
+    DemodExt* __restrict__ ext = p.ext + ch;
+    ext->fm_snr = f.fmsnr; ext->fm_noise = f.noise; ext->fm_go = st.squelch_state > 4;
+    p.state[ch] = st;
+  }
+}
+
+#define FM_TILE 32
+__global__ void __launch_bounds__(64, 2) fm_pll_lanes(DemodParams p) {
+  HIP_DYNAMIC_SHARED(float2, tile)                         // [64][FM_TILE + 1]
+  const int lane = (int)threadIdx.x;
+  const int base = p.ch0 + (int)blockIdx.x * 64;
+  const int ch = base + lane;
+  const int N = p.olen;
+  DemodExt* __restrict__ ext = p.ext + ch;
+  const bool active = (int)blockIdx.x * 64 + lane < p.nch && p.chan[ch].on && p.chan[ch].kind == 1 && p.chan[ch].pll_enable != 0 && ext->fm_go != 0;
+  const unsigned long long act = __ballot(active);
+  if (act == 0ull) return;                                 // wave-uniform
+  PllState q; double pdev = 0.0, noise = 0.0; bool extend = false;
+  if (active) {
+    const DemodChan* __restrict__ c = p.chan + ch;
+    q = ext->pll;
+    const int isamprate = (int)c->samprate;
+    pdev = 5000.0 / isamprate; noise = ext->fm_noise; extend = c->threshold_extend != 0;
+    if (!p.state[ch].pll_was_on) {                         // (demod_linear_tail sets it behind us)
+      pll_init(q);
+      pll_set_params(q, 500.0 / isamprate, M_SQRT1_2);
+      q.lower = -pdev; q.upper = +pdev;
+    }
+  }
+  constexpr int LD = FM_TILE + 1;
+  float* __restrict__ mixf = reinterpret_cast<float*>(p.mix);
+  for (int t0 = 0; t0 < N; t0 += FM_TILE) {
+    const int tn = N - t0 < FM_TILE ? N - t0 : FM_TILE;
+    for (int r0 = 0; r0 < 64; r0 += 64 / FM_TILE) {
+      const int r = r0 + lane / FM_TILE, n = lane % FM_TILE;
+      if (((act >> r) & 1ull) && n < tn) tile[r * LD + n] = p.in[(size_t)(base + r) * N + t0 + n];
+    }
+    CHZ_WAVE_SYNC();
+    if (active)
+      for (int n = 0; n < tn; n++) tile[lane * LD + n].x = fm_pll_sample(q, tile[lane * LD + n], pdev, extend, 0.5, noise);
+    CHZ_WAVE_SYNC();
+    for (int r0 = 0; r0 < 64; r0 += 64 / FM_TILE) {
+      const int r = r0 + lane / FM_TILE, n = lane % FM_TILE;
+      if (((act >> r) & 1ull) && n < tn) mixf[(size_t)(base + r) * 2 * N + t0 + n] = tile[r * LD + n].x;
+    }
+    CHZ_WAVE_SYNC();
+  }
+  if (active) ext->pll = q;
+}
+
+__global__ void __launch_bounds__(64, 2) fm_tone_lanes(DemodParams p) {
+  HIP_DYNAMIC_SHARED(float, tilef)                         // [64][FM_TILE + 1]
+  const int lane = (int)threadIdx.x;
+  const int base = p.ch0 + (int)blockIdx.x * 64;
+  const int ch = base + lane;
+  const int N = p.olen;
+  DemodExt* __restrict__ ext = p.ext + ch;
+  const bool active = (int)blockIdx.x * 64 + lane < p.nch && p.chan[ch].on && p.chan[ch].kind == 1 && p.chan[ch].tone_freq != 0 && ext->fm_stage == 1;
+  const unsigned long long act = __ballot(active);
+  if (act == 0ull) return;                                 // wave-uniform
+  FmTone g{0.0, 0.0, 0.0, 0.0, 0, 0};
+  DemodChan c; c.g_coeff = 0.0; c.g_cfr = 0.0; c.g_cfi = 0.0; c.tone_freq = 0.0;      // (the four members fm_tone_sample reads)
+  int isamprate = 1, integrate = 1;
+  if (active) {
+    const DemodChan* __restrict__ cp = p.chan + ch;
+    c.g_coeff = cp->g_coeff; c.g_cfr = cp->g_cfr; c.g_cfi = cp->g_cfi; c.tone_freq = cp->tone_freq;
+    isamprate = (int)cp->samprate; integrate = (int)rint(isamprate * 0.24);
+    g = FmTone{ext->g_s0, ext->g_s1, ext->old_pl_phase, ext->tone_deviation, ext->pl_sample_count, ext->tone_mute};
+  }
+  constexpr int LD = FM_TILE + 1;
+  const float* __restrict__ mixf = reinterpret_cast<const float*>(p.mix);
+  for (int t0 = 0; t0 < N; t0 += FM_TILE) {
+    const int tn = N - t0 < FM_TILE ? N - t0 : FM_TILE;
+    for (int r0 = 0; r0 < 64; r0 += 64 / FM_TILE) {
+      const int r = r0 + lane / FM_TILE, n = lane % FM_TILE;
+      if (((act >> r) & 1ull) && n < tn) tilef[r * LD + n] = mixf[(size_t)(base + r) * 2 * N + N + t0 + n];
+    }
+    CHZ_WAVE_SYNC();
+    if (active)
+      for (int n = 0; n < tn; n++) fm_tone_sample(g, c, (double)tilef[lane * LD + n], isamprate, integrate);
+    CHZ_WAVE_SYNC();
+  }
+  if (active) {
+    ext->g_s0 = g.s0; ext->g_s1 = g.s1; ext->old_pl_phase = g.old_phase; ext->pl_sample_count = g.count;
+    ext->tone_mute = g.tmute; ext->tone_deviation = g.tdev;
+  }
+}
+
+__global__ void __launch_bounds__(64) fm_finish(DemodParams p) {
+  HIP_DYNAMIC_SHARED(double, esh)                          // [N]
+  const int lane = (int)threadIdx.x;
+  const int ch = p.ch0 + (int)blockIdx.x;
+  const DemodChan* __restrict__ cp = p.chan + ch;
+  DemodExt* __restrict__ ext = p.ext + ch;
+  if (!cp->on || cp->kind != 1 || cp->tone_freq == 0 || ext->fm_stage != 1) return;     // wave-uniform
+  const DemodChan c = *cp;
+  DemodState st = p.state[ch];
+  const int N = p.olen, SEG = (N + 63) >> 6, n0 = lane * SEG;
+  const int cnt = n0 >= N ? 0 : (N - n0 < SEG ? N - n0 : SEG);
+  const float* __restrict__ mixf = reinterpret_cast<const float*>(p.mix) + (size_t)ch * 2 * N + N;
+  for (int i = 0; i < cnt; i++) esh[n0 + i] = (double)mixf[n0 + i];
+  DemodStatus r;
+  r.pll_lock = 0; r.pll_snr = 0.0; r.pll_cphase = 0.0; r.pll_rotations = 0;
+  r.n0 = st.n0; r.snr = ext->fm_snr; r.squelch_state = st.squelch_state; r.gain = 0.0;
+  r.tone_deviation = ext->tone_deviation; r.tone_mute = ext->tone_mute;
+  CHZ_WAVE_SYNC();                                         // every lane has read the record before lane 0 marks it done
+  if (lane == 0) ext->fm_stage = 0;
+  if (r.tone_mute) {                                       // :305-309: muted before de-emphasis runs
+    r.frame = 1; r.mute = 1; r.output_power = 0.0; r.foffset = st.foffset; r.pdeviation = st.pdeviation;
+    if (lane == 0) { demod_publish(p, ch, r); p.state[ch] = st; }
+    return;
+  }
+  fm_deemph_output(p, c, st, r, ch, lane, esh, n0, cnt, N);
+}
+
 __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   HIP_DYNAMIC_SHARED(double, esh)                          // [N] per-sample energies (AGC slices), then [N] complex samples (PLL modes)
   const int lane = (int)threadIdx.x;
@@ -1871,7 +2049,7 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   // looks at it.  The block goes to LDS, lane 0 walks it, the mixed samples replace it there.
   const bool pll = c.pll_enable != 0;                      // wave-uniform
   double pll_snr = 0.0, pll_cph = 0.0, pll_foff = 0.0; int pll_lock = 0, pll_rot = 0;
-  if (pll && p.mix != nullptr) {
+  if (pll && p.mix != nullptr && p.lin_pll != 0) {
     // pll_lanes has run this channel's loop already (one channel per lane): the mixed block and the loop's results are in memory
     const DemodExt* __restrict__ ext = p.ext + ch;
     const float2* __restrict__ m = p.mix + (size_t)ch * N;

@@ -15,7 +15,7 @@ namespace chz {
 // per-kernel times measured in-process agree with the profiler.
 #define CHZ_LAUNCH(kern, grid, block, lds, s, ev0, ev1, p)                                              \
   do {                                                                                                  \
-    if (ev0 || ev1) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (unsigned)(lds), s, ev0, ev1, 0, p); \
+    if ((ev0) || (ev1)) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (unsigned)(lds), s, (ev0), (ev1), 0, p); \
     else hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, p);                                \
   } while (0)
 
@@ -133,18 +133,30 @@ inline int launch_demod(hipStream_t s, const DemodParams& p, hipEvent_t e0 = nul
     if (big < 0) big = big_lds_prepare(reinterpret_cast<const void*>(demod_linear_tail)) == 0 ? 1 : 0;
     if (big != 1) return -1;
   }
-  // the carrier PLLs of the coherent modes first, one channel per lane (only when the caller provided the scratch block: the
-  // engine does as soon as a channel of the bank asks for a PLL)
-  if (p.mix != nullptr) {
-    const size_t tl = sizeof(float2) * 64 * (PLL_TILE + 1);
-    if (e0) {                                   // timed together: the pair's first dispatch starts the clock, its second stops it
-      hipExtLaunchKernelGGL(pll_lanes, dim3((p.nch + 63) / 64), dim3(64), (unsigned)tl, s, e0, nullptr, 0, p);
-      hipExtLaunchKernelGGL(demod_linear_tail, dim3(p.nch), dim3(64), (unsigned)lds, s, nullptr, e1, 0, p);
-      return 0;
-    }
-    hipLaunchKernelGGL(pll_lanes, dim3((p.nch + 63) / 64), dim3(64), tl, s, p);
+  // The sample-by-sample recurrences run one channel per lane in passes of their own, around the wavefront-per-channel kernel (only
+  // when the caller provided the scratch block: the engine does as soon as a channel of the bank asks for one of them).  Timed
+  // together when instrumented: the first dispatch starts the clock, the last stops it.
+  const bool lanes = p.mix != nullptr;
+  const bool lin = lanes && p.lin_pll, fpll = lanes && p.fm_pll, ftone = lanes && p.fm_tone;
+  if ((fpll || ftone) && 8 * (size_t)p.olen > 64 * 1024) {
+    static int big2 = -1;
+    if (big2 < 0) big2 = (big_lds_prepare(reinterpret_cast<const void*>(fm_front_k)) == 0 && big_lds_prepare(reinterpret_cast<const void*>(fm_finish)) == 0) ? 1 : 0;
+    if (big2 != 1) return -1;
   }
-  CHZ_LAUNCH(demod_linear_tail, p.nch, 64, lds, s, e0, e1, p);
+  const size_t tl = sizeof(float2) * 64 * (PLL_TILE + 1);
+  const int groups = (p.nch + 63) / 64;
+  hipEvent_t first = e0;
+  auto ev0 = [&]() { hipEvent_t r = first; first = nullptr; return r; };
+  if (lin) { hipEvent_t a = ev0(); CHZ_LAUNCH(pll_lanes, groups, 64, tl, s, a, (hipEvent_t) nullptr, p); }
+  if (fpll) {
+    { hipEvent_t a = ev0(); CHZ_LAUNCH(fm_front_k, p.nch, 64, 8 * (size_t)p.olen, s, a, (hipEvent_t) nullptr, p); }
+    CHZ_LAUNCH(fm_pll_lanes, groups, 64, sizeof(float2) * 64 * (FM_TILE + 1), s, (hipEvent_t) nullptr, (hipEvent_t) nullptr, p);
+  }
+  { hipEvent_t a = ev0(); CHZ_LAUNCH(demod_linear_tail, p.nch, 64, lds, s, a, ftone ? (hipEvent_t) nullptr : e1, p); }
+  if (ftone) {
+    CHZ_LAUNCH(fm_tone_lanes, groups, 64, sizeof(float) * 64 * (FM_TILE + 1), s, (hipEvent_t) nullptr, (hipEvent_t) nullptr, p);
+    CHZ_LAUNCH(fm_finish, p.nch, 64, 8 * (size_t)p.olen, s, (hipEvent_t) nullptr, e1, p);
+  }
   return 0;
 }
 // host side of the coherent modes and the PL-tone squelch: what init_pll() (src/osc.c:130-136, called once when the demodulator

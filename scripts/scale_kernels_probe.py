@@ -28,7 +28,11 @@ for c0 in range(0, cap, tile):
 bank.enable_noise(129.6e6)
 bank.set_pcm_stride(2 * olen)
 mode = sys.argv[2] if len(sys.argv) > 2 else "linear"       # "pll": every channel in a coherent mode (carrier PLL, src/linear.c:83-153)
-q = ol.lin_params(pll=(mode == "pll"))
+if mode.startswith("fm"):       # "fm", "fmtone" (PL-tone squelch, src/fm.c:264-311), "fmpll" (PLL demodulator, :176-203); squelch held open
+    q = ol.fm_params(samprate=12000.0, bandwidth=6000.0, snr_squelch=True, squelch_open=-2.0, squelch_close=-3.0,
+                     tone_freq=(100.0 if mode == "fmtone" else 0.0), pll=(mode == "fmpll"))
+else:
+    q = ol.lin_params(pll=(mode == "pll"))
 one = pkg.engine.DemodParams(*[getattr(q, f) for f, _ in ol.LinParams._fields_])
 for c0 in range(0, cap, 65536):
     bank.set_demod(0, c0, [one] * min(65536, cap - c0), 0.02)

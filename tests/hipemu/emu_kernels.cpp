@@ -292,7 +292,14 @@ int emu_demod(const float* in, const double* power, const double* n0, const void
   // the coherent modes' PLLs run one channel per lane in a pass of their own when the scratch block exists (as in the engine);
   // EMU_PLL_LANE0=1 keeps round 2's path (lane 0 of the channel's wavefront) for the A/B test
   std::vector<float2> mix;
-  if (ext != nullptr && !getenv("EMU_PLL_LANE0")) { mix.assign((size_t)nch * olen, make_float2(0.f, 0.f)); d.mix = mix.data(); }
+  if (ext != nullptr && !getenv("EMU_PLL_LANE0")) {
+    mix.assign((size_t)nch * olen, make_float2(0.f, 0.f)); d.mix = mix.data();
+    for (int i = 0; i < nch; i++) {
+      const DemodChan& c = d.chan[i];
+      if (!c.on) continue;
+      d.lin_pll |= c.kind == 0 && c.pll_enable; d.fm_pll |= c.kind == 1 && c.pll_enable; d.fm_tone |= c.kind == 1 && c.tone_freq != 0;
+    }
+  }
   return launch_demod(nullptr, d);
 }
 int emu_demod_sizes(int* out3) { out3[0] = (int)sizeof(DemodChan); out3[1] = (int)sizeof(DemodState); out3[2] = (int)sizeof(DemodStatus); return 0; }

@@ -619,6 +619,52 @@ def test_coherent_modes_and_tone_squelch_on_the_device(pkg):
 
 
 @pytest.mark.gpu
+def test_fm_lane_passes_equal_the_one_kernel_path_on_the_device(pkg, monkeypatch):
+    """FM's PLL demodulator and PL-tone detector at one channel per lane (passes of their own around the demodulator kernel) against
+    the one-kernel path, where lane 0 of each channel's wavefront walks the block (CHZ_PLL_LANE0=1): both are the same statements
+    compiled twice, and every status record and PCM byte must agree -- 70 channels, two lane groups, squelch opening and closing."""
+    from test_kernels_emulated import FM2_CASES
+    L, M, fs_in = 25920, 6481, 1.296e6
+    N = L + M - 1
+    nblk, nch = 44, 70
+    rng = np.random.default_rng(321)
+    t = np.arange(nblk * L)
+    lvl = np.full(nblk * L, 0.05); lvl[:5 * L] = 0.0; lvl[34 * L:] = 0.0; lvl[30 * L:34 * L] = 0.05 * np.linspace(1, 0.02, 4 * L)
+    mod = (3000.0 / 1000.0) * np.cos(2 * np.pi * 1000.0 * t / fs_in)
+    fm_tone = lvl * np.cos(2 * np.pi * 200350.0 * t / fs_in - mod - (600.0 / 100.0) * np.cos(2 * np.pi * 100.0 * t / fs_in))
+    fm_plain = lvl * np.cos(2 * np.pi * 300350.0 * t / fs_in - mod)
+    x = (fm_tone + fm_plain + 4e-4 * rng.standard_normal(nblk * L)).astype(np.float32)
+    cases = [FM2_CASES[i % len(FM2_CASES)] for i in range(nch)]
+    fm = [ol.fm_params(**kw) for kw, _ in cases]
+    runs = []
+    for lane0 in ("1", None):
+        if lane0:
+            monkeypatch.setenv("CHZ_PLL_LANE0", lane0)
+        else:
+            monkeypatch.delenv("CHZ_PLL_LANE0", raising=False)
+        eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+        try:
+            B = eng.bank(600, 480, nch)
+            B.set_responses(0, np.stack([pkg.filterapi.design_response(600, 480, N, True, -8000 / 24000.0, 8000 / 24000.0, 11.0)] * nch))
+            B.set_tuning(0, 0, np.array([5000 if sent else 7500 for _, sent in cases], np.int32), np.zeros(nch))
+            B.set_active(nch); B.enable_noise(fs_in); B.set_pcm_stride(4 * 480)
+            B.set_demod(0, 0, [pkg.engine.DemodParams(*[getattr(p, f) for f, _ in ol.LinParams._fields_]) for p in fm], 0.02)
+            trace, frames = [], 0
+            for b in range(nblk):
+                eng.write(x[b * L:(b + 1) * L])
+                eng.step(b)
+                pcm, status = B.read_pcm(b % 4)
+                frames += sum(1 for st in status if st.frame == ol.FRAME_DATA)
+                trace.append((pcm.tobytes(), bytes(status)))
+            runs.append(trace)
+            assert frames > 200
+        finally:
+            eng.close()
+    for b in range(nblk):
+        assert runs[0][b] == runs[1][b], b
+
+
+@pytest.mark.gpu
 def test_filter2_between_channelizer_and_demodulator(pkg):
     """radiod with `filter2 = 1` (src/radio.c:1572-1594): channel block -> the channel's private second filter (chz_mini_*) -> the
     fine-tuning tail (radiod's own, here the restated one) -> demodulator.  On the device: a bank whose demodulators do NOT run

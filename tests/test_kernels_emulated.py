@@ -720,7 +720,8 @@ class _DemodExt(C.Structure):            # struct DemodExt, chz_kernels.h (PllSt
                 ("K1", C.c_double), ("K2", C.c_double),
                 ("pll_snr", C.c_double), ("pll_cphase", C.c_double), ("foffset", C.c_double),
                 ("g_s0", C.c_double), ("g_s1", C.c_double), ("old_pl_phase", C.c_double), ("tone_deviation", C.c_double),
-                ("pll_rotations", C.c_int), ("pl_sample_count", C.c_int), ("tone_mute", C.c_int), ("pad", C.c_int)]
+                ("pll_rotations", C.c_int), ("pl_sample_count", C.c_int), ("tone_mute", C.c_int), ("pad", C.c_int),
+                ("fm_snr", C.c_double), ("fm_noise", C.c_double), ("fm_go", C.c_int), ("fm_stage", C.c_int)]
 
 
 _CHAN_FIELDS = ("channels", "env", "agc", "encoding", "snr_squelch", "squelch_tail", "tuned", "kind", "samprate", "headroom", "threshold",
@@ -872,6 +873,48 @@ def test_fm_pll_and_tone_kernel(emu):
                 assert got.foffset == pytest.approx(st.foffset, rel=1e-6, abs=1e-6) and got.pdeviation == pytest.approx(st.pdeviation, rel=1e-6, abs=1e-3)
                 _check_pcm(p, pcm[i], want, N, 4e-6)
     assert data[0] > 5 and data[1] > 5 and data[2] > 5 and data[3] == 0 and data[4] == 0 and data[5] > 5
+
+
+def test_fm_loops_one_channel_per_lane_equal_one_lane_per_wavefront(emu, monkeypatch):
+    """FM's PLL demodulator and PL-tone detector in passes of their own, one channel per lane (fm_front_k, fm_pll_lanes, fm_tone_lanes,
+    fm_finish around demod_linear_tail), against the one-kernel path where lane 0 of the channel's wavefront walks the block: the
+    same statements, so status records, PCM and the loops' state must come out bit for bit the same -- 70 channels over two lane
+    groups, every FM2 case, some switched off, squelch opening and closing on the way."""
+    from test_oracle_vs_reference import _fm_case
+    nblk, N, fs, bt = 40, 480, 24000.0, 0.02
+    nch = 70
+    cases = [FM2_CASES[i % len(FM2_CASES)] for i in range(nch)]
+    sig = [_fm_case(np.random.default_rng(300 + k), nblk, N, fs, tone=FM2_CASES[k][1], last=30) for k in range(len(FM2_CASES))]
+    r = np.random.default_rng(5)
+    est = (2 * 2e-3 ** 2 / fs) * (1 + 0.1 * r.standard_normal((nch, nblk)))
+    keep = ("vco_phase", "vco_step", "wraps", "lock", "lock_count", "u", "phi", "g_s0", "g_s1", "old_pl_phase", "tone_deviation", "pl_sample_count", "tone_mute")
+    results = []
+    for lane0 in (True, False):
+        if lane0:
+            monkeypatch.setenv("EMU_PLL_LANE0", "1")
+        else:
+            monkeypatch.delenv("EMU_PLL_LANE0", raising=False)
+        chan = (_DemodChan * nch)(); state = (_DemodState * nch)(); status = (ol.LinStatus * nch)(); ext = (_DemodExt * nch)()
+        emu.emu_demod_ext_init(ext, nch)
+        for i, (kw, _) in enumerate(cases):
+            p = ol.fm_params(**kw)
+            c = chan[i]
+            for f in _CHAN_FIELDS:
+                setattr(c, f, getattr(p, f))
+            c.on = 0 if i % 19 == 7 else 1
+            emu.emu_demod_tone_consts(chan, i, p.tone_freq, p.samprate)
+            state[i].n0 = float("nan")
+        pcm = np.zeros((nch, N * 8), np.uint8)
+        trace = []
+        for b in range(nblk):
+            x = np.ascontiguousarray(np.stack([sig[i % len(FM2_CASES)][0][b] * np.float32(1 + 0.01 * (i % 5)) for i in range(nch)]).astype(np.complex64))
+            pw = np.array([sig[i % len(FM2_CASES)][1][b] * (1 + 0.01 * (i % 5)) ** 2 for i in range(nch)]); ne = np.ascontiguousarray(est[:, b])
+            assert emu.emu_demod(x.ctypes.data, pw.ctypes.data, ne.ctypes.data, chan, state, status, pcm.ctypes.data, nch, N, b, bt, ext) == 0
+            trace.append((bytes(status), bytes(state), pcm.tobytes(), [[getattr(ext[i], f) for f in keep] for i in range(nch)]))
+        results.append(trace)
+        assert any(status[i].frame == ol.FRAME_DATA for i in range(nch))
+    for b in range(nblk):
+        assert results[0][b] == results[1][b], b
 
 
 def random_demod_channels(seed=99, nblk=30, N=240, fs=12000.0):
