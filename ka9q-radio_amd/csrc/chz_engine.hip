@@ -196,6 +196,17 @@ struct chz_engine {
   long wpos = 0;                              // write position (floats)
   float2* spec[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};
   bool spec_owned[CHZ_ND] = {false, false, false, false};
+  // A master length outside the compiled axes runs as Bluestein's chirp-z over a planned complex transform of length Mz >= 2N - 1
+  // (chz_kernels.h: blue_pre / blue_mul / blue_post).  The twiddle tables and lane buffers below then belong to THAT transform
+  // (blue->zp); `plan` only carries the master's own numbers (N, bins, a natural-order spectrum layout).
+  struct Blue {
+    FwdPlan zp; long Mz = 0;
+    float2* chirp = nullptr;              // [N]  exp(-i pi n^2 / N)
+    float2* bf = nullptr;                 // [zp.spec_elems]  F(conj(chirp) wrapped), in zp's storage order
+    float2* za[CHZ_MAX_LANES] = {};       // [Mz] per lane: the transform's input, natural order
+    float2* zs[CHZ_MAX_LANES] = {};       // [zp.spec_elems] per lane: its output
+  };
+  Blue* blue = nullptr;
   float2 *tw_sub_a = nullptr, *tw_sub_b = nullptr, *tw_sub_c = nullptr;
   float2 *tw1_tile = nullptr, *tw1_col = nullptr, *tw2_tile = nullptr, *tw2_col = nullptr, *tw2_full = nullptr;
   // spur notches: device tables + the event chain that orders the recurrence across lanes
@@ -272,6 +283,7 @@ int chz_gather_descriptor(int in_type, int master_bins, int P, int shift, int ou
   return 0;
 }
 
+static int blue_setup(chz_engine* e);
 int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, const char* plan_spec, int ring_blocks) {
   if (!out) return fail(-1, "null out pointer");
   *out = nullptr;
@@ -293,8 +305,23 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   const char* envspec = getenv("CHZ_PLAN");
   if ((!plan_spec || !*plan_spec) && envspec && *envspec) plan_spec = envspec;
   if (!build_fwd_plan(N, in_type, plan_spec, e->plan)) {
-    return fail(-3, "no transform plan for N=%d (spec '%s'): N must factor into the compiled axis lengths", N, plan_spec ? plan_spec : "");
+    if (plan_spec && *plan_spec)
+      return fail(-3, "no transform plan for N=%d (spec '%s'): N must factor into the compiled axis lengths", N, plan_spec);
+    // any other length: chirp-z over the next planned complex length
+    chz_engine::Blue* bl = new chz_engine::Blue();
+    e->blue = bl;
+    for (long m = 2L * N - 1; m <= 4L * N + 4096 && m < (1L << 30); m++)
+      if (build_fwd_plan((int)m, CHZ_COMPLEX, nullptr, bl->zp)) { bl->Mz = m; break; }
+    if (!bl->Mz) return fail(-3, "no transform plan for N=%d, and no planned length above 2N-1 for the chirp-z form either", N);
+    FwdPlan& q = e->plan;
+    q = FwdPlan();
+    q.N = N; q.in_type = in_type; q.bins = bins; q.Na = 128; q.Nb = 1; q.Nc = (bins + 127) / 128;
+    q.spec_pitch = 128; q.spec_off = 0; q.spec_elems = (long)q.Nc * 128 + 16;
+    char d[256];
+    snprintf(d, sizeof d, "N=%d %s as chirp-z over [%s]", N, in_type == CHZ_REAL ? "real" : "complex", bl->zp.desc.c_str());
+    q.desc = d;
   }
+  const FwdPlan& tp = e->blue ? e->blue->zp : e->plan;         // the transform that is actually executed
   const int minblocks = (N + L - 1) / L + 1;
   if (ring_blocks < minblocks) ring_blocks = minblocks < 8 ? 8 : minblocks;
   e->ring_blocks = ring_blocks;
@@ -326,7 +353,7 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   for (int i = 0; i < e->nlanes; i++) {
     if (i == 0) e->lanes[i].s = e->stream;
     else HIPOK(hipStreamCreateWithFlags(&e->lanes[i].s, hipStreamNonBlocking));
-    HIPOK(hipMalloc((void**)&e->lanes[i].buf, sizeof(float2) * (size_t)e->plan.Ra * e->plan.inner));
+    HIPOK(hipMalloc((void**)&e->lanes[i].buf, sizeof(float2) * (size_t)tp.Ra * tp.inner));
   }
   HIPOK(hipMalloc((void**)&e->ring, sizeof(float) * (size_t)e->ring_len));
   HIPOK(hipMemset(e->ring, 0, sizeof(float) * (size_t)e->ring_len));       // src/filter.c:242,257
@@ -337,12 +364,13 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
     e->spec_owned[i] = true;
   }
   int r;
-  if ((r = upload(&e->tw_sub_a, e->plan.tw_sub_a)) || (r = upload(&e->tw_sub_b, e->plan.tw_sub_b)) ||
-      (r = upload(&e->tw_sub_c, e->plan.tw_sub_c)) || (r = upload(&e->tw1_tile, e->plan.tw1_tile)) ||
-      (r = upload(&e->tw1_col, e->plan.tw1_col)) || (r = upload(&e->tw2_tile, e->plan.tw2_tile)) ||
-      (r = upload(&e->tw2_col, e->plan.tw2_col)) || (r = upload(&e->tw2_full, e->plan.tw2_full)))
+  if ((r = upload(&e->tw_sub_a, tp.tw_sub_a)) || (r = upload(&e->tw_sub_b, tp.tw_sub_b)) ||
+      (r = upload(&e->tw_sub_c, tp.tw_sub_c)) || (r = upload(&e->tw1_tile, tp.tw1_tile)) ||
+      (r = upload(&e->tw1_col, tp.tw1_col)) || (r = upload(&e->tw2_tile, tp.tw2_tile)) ||
+      (r = upload(&e->tw2_col, tp.tw2_col)) || (r = upload(&e->tw2_full, tp.tw2_full)))
     return r;
   HIPOK(hipDeviceSynchronize());       // null-stream memsets vs the engine's non-blocking streams
+  if (e->blue) { r = blue_setup(e); if (r) return r; }
   guard.e = nullptr;
   *out = e;
   return 0;
@@ -382,6 +410,11 @@ void chz_engine_destroy(chz_engine* e) {
   hipFree(e->ring); hipFree(e->ring16); hipFree(e->energy_part); hipFree(e->clip_part);
   for (int i = 0; i < CHZ_ND; i++) if (e->spec_owned[i]) hipFree(e->spec[i]);
   for (int i = 0; i < CHZ_ND; i++) if (e->energy[i]) hipFree(e->energy[i]);
+  if (e->blue) {
+    hipFree(e->blue->chirp); hipFree(e->blue->bf);
+    for (int i = 0; i < CHZ_MAX_LANES; i++) { hipFree(e->blue->za[i]); hipFree(e->blue->zs[i]); }
+    delete e->blue;
+  }
   hipFree(e->tw_sub_a); hipFree(e->tw_sub_b); hipFree(e->tw_sub_c);
   hipFree(e->tw1_tile); hipFree(e->tw1_col); hipFree(e->tw2_tile); hipFree(e->tw2_col); hipFree(e->tw2_full);
   free_notches(e);
@@ -467,6 +500,7 @@ int chz_input_write_device(chz_engine* e, const float* dev, long n) {
 // the energy sum and the clip count happen where the first transform pass loads them.
 static int ring16_write(chz_engine* e, const short* src, long n, float scale, int randomize, hipMemcpyKind kind) {
   if (e->in_type != CHZ_REAL) return fail(-1, "int16 input is a real A/D stream");
+  if (e->blue) return fail(-3, "int16 input is converted inside the first pass of a directly planned master; N=%d runs as chirp-z: feed it float samples", e->N);
   if (n < 0 || n > e->ring_len) return fail(-1, "write of %ld samples does not fit the ring", n);
   HIPOK(hipSetDevice(e->device));
   if (!e->ring16) {
@@ -604,6 +638,80 @@ static int enqueue_notch(chz_engine* e, int slot, hipStream_t st, Instr* in, Not
   return rc;
 }
 
+// the planned complex transform of a chirp-z master: za (natural order) -> zs (zp's storage order), all on `st`
+static int blue_fft(chz_engine* e, const float2* za, float2* lbuf, float2* zs, hipStream_t st) {
+  const FwdPlan& p = e->blue->zp;
+  ColsParams a{};
+  a.in = za; a.in_len = 0; a.in_start = 0; a.out = lbuf; a.rows = 1; a.inner = p.inner; a.T = p.T1; a.padk = p.padk1;
+  a.tw_sub = e->tw_sub_a; a.tw_tile = e->tw1_tile; a.tw_col = e->tw1_col;
+  if (launch_cols(p.ra, p.grid1, p.block1, p.lds1, st, a)) return fail(-4, "no kernel for axis a");
+  if (p.Nb > 1) {
+    ColsParams b{};
+    b.in = lbuf; b.in_len = 0; b.in_start = 0; b.out = lbuf; b.rows = p.Ra; b.inner = p.Nc; b.T = p.T2;
+    b.padk = p.padk2; b.tw_sub = e->tw_sub_b; b.tw_tile = e->tw2_tile; b.tw_col = e->tw2_col; b.tw_full = e->tw2_full;
+    if (launch_cols(p.rb, p.grid2, p.block2, p.lds2, st, b)) return fail(-4, "no kernel for axis b");
+  }
+  RowsParams c{};
+  c.lay = SpecLayout{p.Na, p.spec_pitch, p.spec_off}; c.ka_shift = p.ka_shift;
+  c.buf = lbuf; c.spec = zs; c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3;
+  c.padg = p.padg3; c.N = p.N; c.mirror = false; c.tw_sub = e->tw_sub_c;
+  if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, st, c)) return fail(-4, "no kernel for axis c");
+  return 0;
+}
+static inline int blue_grid(long n) { const long g = (n + 255) / 256; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+// tables and buffers of a chirp-z master; Bf is made by the device's own transform
+static int blue_setup(chz_engine* e) {
+  chz_engine::Blue& b = *e->blue;
+  const int N = e->N; const long Mz = b.Mz;
+  std::vector<f2> c((size_t)N);
+  for (long n = 0; n < N; n++) c[(size_t)n] = root_of_unity((long long)((unsigned long long)n * (unsigned long long)n % (unsigned long long)(2L * N)), 2LL * N, -1);
+  int r = upload(&b.chirp, c);
+  if (r) return r;
+  for (int i = 0; i < e->nlanes; i++) {
+    HIPOK(hipMalloc((void**)&b.za[i], sizeof(float2) * (size_t)Mz));
+    HIPOK(hipMalloc((void**)&b.zs[i], sizeof(float2) * (size_t)b.zp.spec_elems));
+    HIPOK(hipMemset(b.zs[i], 0, sizeof(float2) * (size_t)b.zp.spec_elems));
+  }
+  HIPOK(hipMalloc((void**)&b.bf, sizeof(float2) * (size_t)b.zp.spec_elems));
+  std::vector<f2> bz((size_t)Mz, f2{0.f, 0.f});
+  for (long m = 0; m < N; m++) {
+    const f2 v{c[(size_t)m].x, -c[(size_t)m].y};
+    bz[(size_t)m] = v;
+    if (m) bz[(size_t)(Mz - m)] = v;
+  }
+  HIPOK(hipMemcpy(b.za[0], bz.data(), sizeof(f2) * (size_t)Mz, hipMemcpyHostToDevice));
+  HIPOK(hipDeviceSynchronize());
+  r = blue_fft(e, b.za[0], e->lanes[0].buf, b.zs[0], e->stream);
+  if (r) return r;
+  HIPOK(hipMemcpyAsync(b.bf, b.zs[0], sizeof(float2) * (size_t)b.zp.spec_elems, hipMemcpyDeviceToDevice, e->stream));
+  HIPOK(hipStreamSynchronize(e->stream));
+  HIPOK(hipGetLastError());
+  return 0;
+}
+static int enqueue_forward_blue(chz_engine* e, unsigned job, int ln, hipStream_t st, long start, Instr* in) {
+  chz_engine::Blue& b = *e->blue;
+  const int slot = job % CHZ_ND;
+  float2* lbuf = e->lanes[ln].buf;
+  const SpecLayout zlay{b.zp.Na, b.zp.spec_pitch, b.zp.spec_off};
+  mark(in, st, 0, true);
+  BluePreParams pre{e->ring, e->ring_len, start, e->per, b.chirp, b.za[ln], e->N, b.Mz};
+  CHZ_LAUNCH(blue_pre, blue_grid(b.Mz), 256, 0, st, IN_E0(in), IN_E1(in), pre);
+  mark(in, st, 0, false);
+  int r = blue_fft(e, b.za[ln], lbuf, b.zs[ln], st);
+  if (r) return r;
+  mark(in, st, 1, true);
+  BlueMulParams mul{b.zs[ln], b.bf, b.za[ln], zlay, b.Mz};
+  CHZ_LAUNCH(blue_mul, blue_grid(b.Mz), 256, 0, st, IN_E0(in), IN_E1(in), mul);
+  mark(in, st, 1, false);
+  r = blue_fft(e, b.za[ln], lbuf, b.zs[ln], st);
+  if (r) return r;
+  mark(in, st, 2, true);
+  BluePostParams post{b.zs[ln], b.chirp, e->spec[slot], zlay, SpecLayout{e->plan.Na, e->plan.spec_pitch, e->plan.spec_off}, e->bins, (float)(1.0 / (double)b.Mz)};
+  CHZ_LAUNCH(blue_post, blue_grid(e->bins), 256, 0, st, IN_E0(in), IN_E1(in), post);
+  mark(in, st, 2, false);
+  return 0;
+}
+
 static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* turn = nullptr, int seq = 0, bool capture_first = false, bool capturing = false) {
   const FwdPlan& p = e->plan;
   const int slot = job % CHZ_ND;
@@ -612,6 +720,10 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* tu
   float2* lbuf = e->lanes[ln].buf;
   if (ln != 0 && e->input_pending) HIPOK(hipStreamWaitEvent(st, e->input_ready, 0));
   const long start = (long)(((unsigned long long)job * (unsigned long long)e->L) % (unsigned long long)((long)e->ring_blocks * e->L)) * e->per;
+  if (e->blue) {
+    const int r = enqueue_forward_blue(e, job, ln, st, start, in);
+    return r ? r : enqueue_notch(e, slot, st, in, turn, seq, capture_first, capturing);
+  }
   if (e->in_type == CHZ_REAL) {
     FirstRealParams a{};
     a.ring = e->ring; a.ring_len = e->ring_len; a.start = start; a.buf = lbuf; a.inner = p.inner;

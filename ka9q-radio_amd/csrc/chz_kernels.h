@@ -1038,6 +1038,47 @@ __global__ void __launch_bounds__(256) chan_c2r(ChanParams p) {
 }
 
 // ------------------------------------------------------------------------------
+// Masters of ANY length (FFTW plans every N, src/filter.c:101-163,222-231; the compiled axes cover N = a x b x c from a menu).
+// Bluestein's identity  n k = (n^2 + k^2 - (k - n)^2) / 2  turns the N-point transform into a circular convolution of length
+// Mz >= 2N - 1, Mz a planned size:   X[k] = c[k] * sum_n (x[n] c[n]) conj(c)[k - n],   c[n] = exp(-i pi n^2 / N).
+// Three elementwise kernels around two runs of the complex forward transform of length Mz (the inverse as conj(F(conj(.))) / Mz):
+//   blue_pre   za[n] = x[n] c[n] (window read out of the sample ring), zero beyond N
+//   blue_mul   za[k] = conj(Z[k] * Bf[k])            Z = F(za) in the planned transform's own storage order, Bf = F(conj(c) wrapped)
+//   blue_post  X[k]  = c[k] * conj(Z'[k]) / Mz       the master's bins, in the master's spectrum layout
+// ------------------------------------------------------------------------------
+struct BluePreParams { const float* ring; long ring_len, start; int per; const float2* chirp; float2* za; int N; long Mz; };
+__global__ void __launch_bounds__(256) blue_pre(BluePreParams p) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.Mz; i += stride) {
+    float2 v = make_float2(0.f, 0.f);
+    if (i < p.N) {
+      long idx = p.start + i * p.per;
+      if (idx >= p.ring_len) idx -= p.ring_len;                      // (a window is never longer than the ring)
+      const float2 x = p.per == 1 ? make_float2(p.ring[idx], 0.f) : make_float2(p.ring[idx], p.ring[idx + 1]);
+      v = cmul(x, p.chirp[i]);
+    }
+    p.za[i] = v;
+  }
+}
+struct BlueMulParams { const float2* zs; const float2* bf; float2* za; SpecLayout lay; long Mz; };
+__global__ void __launch_bounds__(256) blue_mul(BlueMulParams p) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < p.Mz; k += stride) {
+    const long a = spec_addr(p.lay, k);
+    const float2 t = cmul(p.zs[a], p.bf[a]);
+    p.za[k] = make_float2(t.x, -t.y);
+  }
+}
+struct BluePostParams { const float2* zs; const float2* chirp; float2* spec; SpecLayout zlay, lay; int bins; float inv; };
+__global__ void __launch_bounds__(256) blue_post(BluePostParams p) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < p.bins; k += stride) {
+    const float2 y = p.zs[spec_addr(p.zlay, k)];
+    p.spec[spec_addr(p.lay, k)] = cmul(make_float2(y.x * p.inv, -y.y * p.inv), p.chirp[k]);
+  }
+}
+
+// ------------------------------------------------------------------------------
 // K5: estimate_noise() of src/radio.c:1783-1866, one workgroup per channel.
 // |X|^2 of nbins master bins around |shift| -> LDS, bitonic sort, the 0.10 quantile with linear
 // interpolation, mean of the energies <= 1.5 x quantile, times the truncated-exponential correction,

@@ -264,6 +264,51 @@ def test_channel_sizes_with_large_prime_factors(pkg, P, olen):
         fa.delete_filter_input(master)
 
 
+@pytest.mark.parametrize("L,M,kind", [(1800, 219, "real"), (5400, 1352, "real"), (1000, 10, "complex"), (4000, 201, "complex"), (25920, 6482, "real")])
+def test_master_lengths_outside_the_compiled_axes(pkg, L, M, kind):
+    # FFTW plans every N (src/filter.c:222-231): N = 2018 = 2 x 1009, 6751 (prime), 1009 (prime), 4200 (smooth, but its factor 7 is in
+    # none of the compiled axis lengths), 32401 = 3 x 10800 + 1 -- the engine runs them as Bluestein's chirp-z over the next planned
+    # complex length.  Spectrum against the restatement's float64 DFT, channels through it,
+    # blocks in sequence (the ring wraps), a notch on top.
+    in_type = ol.REAL if kind == "real" else ol.COMPLEX
+    N = L + M - 1
+    rng = np.random.default_rng(N)
+    eng = pkg.engine.Engine(L, M, in_type, ring_blocks=8)
+    try:
+        assert "chirp-z" in eng.plan
+        mk = (lambda: rng.standard_normal(L).astype(np.float32)) if kind == "real" else (lambda: (rng.standard_normal(L) + 1j * rng.standard_normal(L)).astype(np.complex64))
+        st = ol.Stream(L, M, in_type)
+        B = eng.bins
+        # the smallest channel this master can have: P / N = olen / L in integers
+        g = int(np.gcd(N, L))
+        olen, P = L // g, N // g
+        while P < 8:
+            olen, P = 2 * olen, 2 * P
+        if P > 8000:
+            P = None                                                  # (N and L coprime: the only "channel" is the whole band)
+        for job in range(11):
+            x = mk()
+            eng.write(x); eng.forward(job)
+            want = st.push(x, f64=True)
+            got = eng.spectrum(job % 4)
+            assert got.shape == want.shape
+            assert rel(got, want) <= 3 * SPEC_REL, (job, rel(got, want))
+        if P:
+            nch = 6
+            bank = eng.bank(P, olen, nch)
+            resp = (rng.standard_normal((nch, P)) + 1j * rng.standard_normal((nch, P))).astype(np.complex64) / P
+            shifts = np.array([0, 7, -9, B // 3, -(B // 3), B // 2 - 1], np.int32) if kind == "complex" else np.array([0, 7, -9, B // 3, -(B // 3), B - 1], np.int32)
+            bank.set_responses(0, resp); bank.set_shifts(0, shifts); bank.set_active(nch)
+            x = mk()
+            eng.write(x); eng.step(11)
+            spec64 = st.push(x, f64=True)
+            out = bank.read_slot(11 % 4)
+            for c in range(nch):
+                check_channel(out[c], ol.channel(spec64, in_type, P, olen, int(shifts[c]), resp[c]), floor=0.0)
+    finally:
+        eng.close()
+
+
 def test_channel_sizes_beyond_the_lds(pkg):
     # 768 kHz and 1.536 MHz channels of the full-rate master (P = 19200, 38400; share/*.conf has both): chan_any with its two
     # transform buffers in global scratch.  The restatement's gather + float64 inverse DFT on the DEVICE's own spectrum.
