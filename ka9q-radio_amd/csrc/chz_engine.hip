@@ -310,8 +310,17 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
     // any other length: chirp-z over the next planned complex length
     chz_engine::Blue* bl = new chz_engine::Blue();
     e->blue = bl;
-    for (long m = 2L * N - 1; m <= 4L * N + 4096 && m < (1L << 30); m++)
-      if (build_fwd_plan((int)m, CHZ_COMPLEX, nullptr, bl->zp)) { bl->Mz = m; break; }
+    // the cheapest planned length within 4 % above the first one that exists (the planner's cost model, scaled by the length)
+    double best = 1e300;
+    for (long m = 2L * N - 1; m <= 4L * N + 4096 && m < (1L << 30); m++) {
+      if (bl->Mz && (double)m > 1.04 * (double)bl->Mz + 64) break;
+      FwdPlan cand; double sc = 0.0;
+      if (!build_fwd_plan((int)m, CHZ_COMPLEX, nullptr, cand, &sc)) continue;
+      if (!bl->Mz) bl->Mz = m;                                   // (the first hit anchors the window)
+      sc *= (double)m;
+      if (sc < best) { best = sc; bl->zp = cand; }
+    }
+    if (bl->Mz) bl->Mz = bl->zp.N;
     if (!bl->Mz) return fail(-3, "no transform plan for N=%d, and no planned length above 2N-1 for the chirp-z form either", N);
     FwdPlan& q = e->plan;
     q = FwdPlan();

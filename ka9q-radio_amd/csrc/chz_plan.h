@@ -209,7 +209,7 @@ inline bool finish_fwd_plan(FwdPlan& p, int T1_over, int T2_over, int Ta_over) {
 }
 
 // spec: "" (automatic) or "NaxNbxNc[:T1,T2,Ta]" / "NaxNc[:T1,Ta]"
-inline bool build_fwd_plan(int N, int in_type, const char* spec, FwdPlan& out) {
+inline bool build_fwd_plan(int N, int in_type, const char* spec, FwdPlan& out, double* score_out = nullptr) {
   if (N < 4 || (in_type != CHZ_IN_REAL && in_type != CHZ_IN_COMPLEX)) return false;
   const bool real = in_type == CHZ_IN_REAL;
   int T1o = 0, T2o = 0, Tao = 0;
@@ -274,6 +274,7 @@ inline bool build_fwd_plan(int N, int in_type, const char* spec, FwdPlan& out) {
   }
   if (!found) return false;
   out = bestp;
+  if (score_out) *score_out = best;
   return true;
 }
 
