@@ -587,6 +587,15 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
     sc->bank = bi; sc->idx = b->n; sc->epoch = 1; sc->n0 = NAN;
     sc->shard = c->next_shard++ % c->wshards;
     b->slaves[b->n] = slave; b->shift[b->n] = 0;
+    /* the device row must hold the descriptor of the shift the host believes it holds: a channel that only ever asks for shift 0
+       (the centre channel of a complex front end) would otherwise never send one and read an empty row */
+    if (chz_bank_set_shifts(c->eng, b->id, b->n, 1, &b->shift[b->n]) != 0) {
+      stage_wrunlock(c);
+      pthread_mutex_unlock(&c->lock);
+      fprintf(stderr, "create_filter_output: %s\n", chz_last_error());
+      FREE(slave->fdomain); FREE(slave->output_buffer.c); FREE(slave->output_buffer.r); free(sc);
+      return -1;
+    }
     for (int s = 0; s < ND; s++) b->stage_epoch[s][b->n] = 0;
     b->n++;
     slave->rev_plan = (fftwf_plan)(void *)sc;

@@ -130,6 +130,27 @@ def test_dropin_radiod_style_small():
     plan[0] = (2500, 2600, 3, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4)            # retune at block 3
     plan[1] = (2501, 2501, 10 ** 6, 2, 0.004, 0.25, 11.0, -0.02, 0.02)         # new filter at block 2
     plan[2] = (-7000, 7000, 5, 4, -0.4, 0.4, 11.0, 0.1, 0.3)                   # both
+    plan[3] = (0, 0, 10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4)             # never asks for anything but shift 0 (round 3: it got an empty row)
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x)
+    _check(L, M, olen, P, plan, nblocks, out, spec, meta, x)
+
+
+@pytest.mark.gpu
+def test_dropin_master_and_slave_lengths_fftw_would_plan():
+    """create_filter_input / create_filter_output with lengths no compiled transform covers: N = 32402 = 2 x 17 x 953 (the master runs
+    as chirp-z over a planned length) and P = 16201 = 17 x 953 (the slaves run Bluestein inside chan_any) -- FFTW plans both
+    (src/filter.c:222-231,331-357), so the drop-in must not refuse them.  Through filter.h from C, against the restatement's float64 DFT."""
+    _build_lib(); ol.build()
+    L, M, olen = 25920, 6483, 12960
+    N = L + M - 1
+    P = N * olen // L
+    assert P * L == N * olen and P == 16201
+    nblocks = 4
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=3)
+    x = g.generate(nblocks * L)
+    plan = [(0, 0, 10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4), (4000, -4000, 2, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4),
+            (-8100, -8100, 10 ** 6, 1, 0.004, 0.25, 11.0, -0.02, 0.02)]
     with tempfile.TemporaryDirectory() as tmp:
         out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x)
     _check(L, M, olen, P, plan, nblocks, out, spec, meta, x)
