@@ -505,7 +505,7 @@ def main():
     ap.add_argument("--no-crt", action="store_true", help="skip the C_rt leg (one large bank, every block inside 20 ms)")
     ap.add_argument("--crt-channels", type=int, default=0, help="channels of the C_rt leg's bank (default 17.0 M at P=300, 8.4 M at P=600)")
     ap.add_argument("--crt-blocks", type=int, default=500)
-    ap.add_argument("--crt-ladder", default="", help="comma-separated channel counts (millions) of the C_rt ladder; default 17.0,19.0,20.0,20.5 at P=300 / 8.4,9.4,9.7,10.0 at P=600")
+    ap.add_argument("--crt-ladder", default="", help="comma-separated channel counts (millions) of the C_rt ladder; default 17.0,19.0,19.5,20.0,20.5 at P=300 / 8.4,9.4,9.7,10.0 at P=600")
     ap.add_argument("--no-dropin", action="store_true", help="skip the legs through the filter.h drop-in")
     ap.add_argument("--dropin-blocks", type=int, default=500)
     ap.add_argument("--no-crt-pcie", action="store_true", help="skip the C_rt probes with the host link in the loop")
@@ -714,7 +714,7 @@ def main():
         elif args.crt_channels:
             crt_n = [args.crt_channels]
         else:
-            crt_n = [17_000_000, 19_000_000, 20_000_000, 20_500_000] if P == 300 else [8_400_000, 9_400_000, 9_700_000, 10_000_000]
+            crt_n = [17_000_000, 19_000_000, 19_500_000, 20_000_000, 20_500_000] if P == 300 else [8_400_000, 9_400_000, 9_700_000, 10_000_000]
         if comm is not None:
             # the big bank's channels span the whole spectrum on every rank: whole-slot broadcast, whatever the headline leg moved
             def run_one(job):
