@@ -34,6 +34,7 @@ extern double filter_hip_noise(struct filter_out const *) __attribute__((weak));
 extern unsigned long filter_hip_skipped_blocks(struct filter_in const *) __attribute__((weak));
 extern int filter_hip_drain(struct filter_in *) __attribute__((weak));
 static double Noise_samprate; static double *Noise;   /* env HARNESS_NOISE=<front-end sample rate>: [Nblocks][Nch] device-side estimate_noise() */
+static int Ahead = 2;                                  /* env HARNESS_AHEAD: blocks the front end may run ahead of the slowest channel (the filter keeps ND = 4 blocks: 3 loses nothing) */
 static int Free_run;                                   /* env HARNESS_FREE_RUN=1: the front end does not wait for the channels (a real A/D never does); > 1: and takes that many microseconds per block */
 static unsigned char *Skipflag; static unsigned long Skips_seen;   /* [Nblocks]: the front end's block was skipped (drop mode) */
 static unsigned char *Dropped;                         /* [Nblocks][Nch]: the channel's block_drops went up in that call */
@@ -201,6 +202,7 @@ int main(int argc, char **argv) {
     Noise = calloc((size_t)Nblocks * Nch, sizeof *Noise);
   }
   if (getenv("HARNESS_FREE_RUN")) { Free_run = atoi(getenv("HARNESS_FREE_RUN")); Dropped = calloc((size_t)Nblocks * Nch, 1); Skipflag = calloc((size_t)Nblocks, 1); }
+  if (getenv("HARNESS_AHEAD")) { Ahead = atoi(getenv("HARNESS_AHEAD")); if (Ahead < 1) Ahead = 1; }
   if (getenv("HARNESS_RETUNE_MOD")) Retune_mod = atoi(getenv("HARNESS_RETUNE_MOD"));
   if (getenv("HARNESS_CHURN_MOD")) Churn_mod = atoi(getenv("HARNESS_CHURN_MOD"));
   pthread_t *th = calloc((size_t)Nch, sizeof *th), clk;
@@ -228,7 +230,7 @@ int main(int argc, char **argv) {
     for (;;) {   /* never run more than 2 blocks ahead of the slowest channel: no drops wanted here */
       int slow = Nblocks;
       for (int i = 0; i < Nch; i++) { int p = atomic_load(&Progress[i]); if (p < slow) slow = p; }
-      if (blk - slow < 2 || Free_run) break;
+      if (blk - slow < Ahead || Free_run) break;
       usleep(100);
     }
     int n = Chunk; if (pos + n > total) n = (int)(total - pos);
