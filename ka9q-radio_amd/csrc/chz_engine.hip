@@ -87,6 +87,7 @@ struct Bank {
   float2* dm_mix = nullptr;              // [cap][olen] the coherent modes' blocks after their PLL (pll_lanes); allocated with dm_ext
   int dm_pll_lin = 0;                    // channels of the linear demodulator with a carrier PLL
   int dm_fm_pll = 0, dm_fm_tone = 0;     // FM channels with the PLL demodulator / a PL-tone squelch
+  int dm_lin = 0, dm_fm = 0;             // channels of the linear / of the FM demodulator
   DemodStatus* dm_status = nullptr;      // [ND][cap]
   unsigned char* dm_flags = nullptr;     // [ND][cap] one status byte per channel and block
   unsigned char* dm_pcm = nullptr;       // [ND][cap][pcm_stride]
@@ -174,6 +175,7 @@ struct chz_engine {
   FwdPlan plan;
   float* energy[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // |X|^2 image of each slot for large banks' noise windows (spec_energy), made on first need
   int noise_energy = -1;            // -1: by launch size, 0 never, 1 always (env CHZ_NOISE_ENERGY)
+  bool demod_wave = false;          // env CHZ_DEMOD_WAVE=1: linear demodulators on the wavefront-per-channel kernel (A/B)
   int chan_stage = -1;              // output staging of chan_ifft: -1 by launch size, 0 never, 1 always (env CHZ_CHAN_STAGE)
   hipStream_t stream = nullptr;     // == lanes[0].s: input copies and anything not tied to a block
   bool own_stream = false;
@@ -245,7 +247,7 @@ static void free_bank(Bank& b) {
   hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); hipFree(b.any_scratch); b.any_scratch = nullptr;
   hipFree(b.fine); hipFree(b.power); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam);
   hipFree(b.dm_chan); hipFree(b.dm_state); hipFree(b.dm_ext); hipFree(b.dm_status); hipFree(b.dm_flags); hipFree(b.dm_pcm); hipFree(b.dm_mix);
-  b.dm_mix = nullptr; b.dm_pll_lin = 0; b.dm_fm_pll = 0; b.dm_fm_tone = 0;
+  b.dm_mix = nullptr; b.dm_pll_lin = 0; b.dm_fm_pll = 0; b.dm_fm_tone = 0; b.dm_lin = 0; b.dm_fm = 0;
   b.dm_chan = nullptr; b.dm_state = nullptr; b.dm_ext = nullptr; b.dm_status = nullptr; b.dm_flags = nullptr; b.dm_pcm = nullptr; b.dm_on = 0; b.dm_chan_h.clear(); b.dm_osc.clear();
   for (int s = 0; s < CHZ_ND; s++) {
     if (b.ev_bank[s]) (void)hipEventDestroy(b.ev_bank[s]);
@@ -339,6 +341,7 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   e->own_stream = true;
   if (const char* cs = getenv("CHZ_CHAN_STAGE")) e->chan_stage = atoi(cs) != 0;
   if (const char* cs = getenv("CHZ_NOISE_ENERGY")) e->noise_energy = atoi(cs) != 0;
+  if (const char* cs = getenv("CHZ_DEMOD_WAVE")) e->demod_wave = atoi(cs) != 0;
   const char* envl = getenv("CHZ_STREAMS");
   int nl = envl ? atoi(envl) : 4;
   e->nlanes = (nl >= 4) ? 4 : (nl >= 2) ? 2 : 1;             // must divide ND so slot and lane stay aligned
@@ -873,6 +876,12 @@ static int after_edit(chz_engine* e, Bank& b, int ch0, int n) {
   return 0;
 }
 
+// which kernels serve the bank's demodulators: the linear ones run one channel per lane (demod_lin_lanes; CHZ_DEMOD_WAVE=1 keeps the
+// wavefront-per-channel kernel for them), FM -- and a coherent-mode channel whose PLL has no scratch block -- the wavefront kernel
+static void demod_paths(const chz_engine* e, const Bank& b, DemodParams& d) {
+  d.lin_lanes = (b.dm_lin > 0 && !e->demod_wave) ? 1 : 0;
+  d.wave_any = (b.dm_fm > 0 || !d.lin_lanes || (b.dm_pll_lin > 0 && d.mix == nullptr)) ? 1 : 0;
+}
 static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch0 = 0, int n = -1) {
   Bank& b = e->banks[(size_t)bank];
   if (n < 0) n = b.active;
@@ -935,6 +944,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
     d.pcm_stride = b.pcm_stride; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;      // Power_alpha, src/radio.c:72
     d.lin_pll = b.dm_pll_lin > 0; d.fm_pll = b.dm_fm_pll > 0; d.fm_tone = b.dm_fm_tone > 0;
     d.mix = (d.lin_pll || d.fm_pll || d.fm_tone) ? b.dm_mix : nullptr;
+    demod_paths(e, b, d);
     mark(in, ts, 6, true);
     if (launch_demod(ts, d, IN_E0(in), IN_E1(in))) return fail(-4, "the demodulator kernel refuses blocks of %d samples", b.olen);
     mark(in, ts, 6, false);
@@ -1383,6 +1393,7 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
     c.channels = q.channels; c.env = q.env != 0; c.agc = q.agc != 0; c.encoding = q.encoding; c.snr_squelch = q.snr_squelch != 0;
     c.squelch_tail = q.squelch_tail; c.tuned = q.tuned != 0; c.on = 1;
     c.samprate = q.samprate; c.headroom = q.headroom; c.threshold = q.threshold; c.recovery_rate = q.recovery_rate; c.hangtime = q.hangtime;
+    c.recov_ps = std::pow(q.recovery_rate, 1.0 / q.samprate);
     c.dc_alpha = q.dc_alpha; c.bandwidth = q.bandwidth; c.squelch_open = q.squelch_open; c.squelch_close = q.squelch_close;
     if (q.kind == CHZ_DEMOD_FM) {                       // demod_fm()'s defaults for thresholds left unset (src/fm.c:38-41)
       if (!std::isfinite(c.squelch_open) || c.squelch_open == 0) c.squelch_open = 6.3;
@@ -1428,9 +1439,10 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
       init.push_back(st); init_ch.push_back(ch0 + i);
     }
   }
-  b.dm_pll_lin = 0; b.dm_fm_pll = 0; b.dm_fm_tone = 0;
+  b.dm_pll_lin = 0; b.dm_fm_pll = 0; b.dm_fm_tone = 0; b.dm_lin = 0; b.dm_fm = 0;
   for (const DemodChan& dc : b.dm_chan_h) {
     if (!dc.on) continue;
+    b.dm_lin += dc.kind == CHZ_DEMOD_LINEAR ? 1 : 0; b.dm_fm += dc.kind == CHZ_DEMOD_FM ? 1 : 0;
     b.dm_pll_lin += (dc.kind == CHZ_DEMOD_LINEAR && dc.pll_enable) ? 1 : 0;
     b.dm_fm_pll += (dc.kind == CHZ_DEMOD_FM && dc.pll_enable) ? 1 : 0;
     b.dm_fm_tone += (dc.kind == CHZ_DEMOD_FM && dc.tone_freq != 0) ? 1 : 0;
@@ -1480,6 +1492,7 @@ int chz_bank_demod(chz_engine* e, int bank, unsigned job, int slot) {
   d.pcm_stride = b.pcm_stride; d.job = job; d.blocktime = b.dm_blocktime; d.power_alpha = 0.10;
   d.lin_pll = b.dm_pll_lin > 0; d.fm_pll = b.dm_fm_pll > 0; d.fm_tone = b.dm_fm_tone > 0;
     d.mix = (d.lin_pll || d.fm_pll || d.fm_tone) ? b.dm_mix : nullptr;
+    demod_paths(e, b, d);
   if (b.pcm_copying[slot]) HIPOK(hipStreamWaitEvent(e->tail, b.ev_pcm[slot], 0));
   if (launch_demod(e->tail, d)) return fail(-4, "the demodulator kernel refuses blocks of %d samples", b.olen);
   HIPOK(hipGetLastError());

@@ -1407,6 +1407,7 @@ struct DemodChan {               // per channel, set by the host (names: the cha
   double pll_loop_bw;            // chan->pll.loop_bw, Hz
   double tone_freq;              // FM: chan->fm.tone_freq (0 = no PL tone squelch, src/fm.c:264-311)
   double g_coeff, g_cfr, g_cfi;  // init_goertzel(tone_freq / samprate) (src/iir.c:32-39), computed by the host
+  double recov_ps;               // pow(recovery_rate, 1 / samprate) (src/linear.c:231), computed by the host: a constant of the channel
 };
 // State of the coherent modes and of the PL-tone squelch; only channels that use them touch it (one lane, sequentially).
 struct PllState { unsigned vco_phase; int vco_step, wraps, lock, lock_count, pad;         // struct pll (src/osc.h:21-32) + chan->pll.lock / .lock_count
@@ -1434,6 +1435,9 @@ struct DemodParams {
   int ch0, nch, olen, pcm_stride;
   unsigned job;
   double blocktime, power_alpha;
+  double fm_alpha;           // -expm1(-blocktime / 1 s): the smoothing constant of FM's frequency-offset estimate (src/fm.c:55); filled in by launch_demod
+  int lin_lanes;             // the linear demodulator's channels are served by demod_lin_lanes (one channel per lane); set by launch_demod
+  int wave_any;              // the bank has channels demod_linear_tail must serve (FM; PLL channels without the scratch block)
   int lin_pll, fm_pll, fm_tone;   // the bank has channels with a carrier PLL (linear) / the PLL demodulator (FM) / a PL-tone squelch (FM): which
                              // of the lane-per-channel passes launch_demod adds; they need `mix`
   float2* mix;               // [cap][olen] or nullptr: the coherent modes' blocks after their PLL (written by pll_lanes, one CHANNEL PER LANE);
@@ -1721,7 +1725,7 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
   const bool tone_split = tone && p.mix != nullptr && p.fm_tone != 0;           // fm_tone_lanes + fm_finish will
   DemodExt* __restrict__ ext = p.ext + ch;                                      // touched only with pll / tone
   float* __restrict__ mixf = reinterpret_cast<float*>(p.mix) + (size_t)ch * 2 * N;   // [N] PLL baseband, [N] the tone detector's input
-  const double alpha = -expm1(-p.blocktime / 1.0);                              // :55
+  const double alpha = p.fm_alpha;                                              // -expm1(-blocktime / 1.0), :55 (launch_demod)
   FmFront f;
   if (pll_split) { f.fmsnr = ext->fm_snr; f.noise = ext->fm_noise; }           // (st was advanced by fm_front_k)
   else f = fm_front(p, c, st, ch, x, n0, cnt, N, esh);
@@ -1848,7 +1852,7 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
 // 64 channels' blocks are transposed through LDS, tile by tile, and the 64 lanes run their loops side by side; the mixed
 // blocks go back to memory (p.mix) the same way, the loop's results to DemodExt, and demod_linear_tail picks both up.
 // Statement for statement the loop of demod_linear_tail's lane-0 path: the results are bit-identical.
-#define PLL_TILE 32
+#define PLL_TILE 16
 __global__ void __launch_bounds__(64, 2) pll_lanes(DemodParams p) {
   HIP_DYNAMIC_SHARED(float2, tile)                         // [64][PLL_TILE + 1]
   const int lane = (int)threadIdx.x;
@@ -1872,14 +1876,31 @@ __global__ void __launch_bounds__(64, 2) pll_lanes(DemodParams p) {
     pll_foff = ext->foffset;
   }
   constexpr int LD = PLL_TILE + 1;
+  // in: row r = channel base + r, PLL_TILE consecutive samples per row, 64 / PLL_TILE rows per wavefront load.  A tile travels
+  // global -> registers -> LDS with all its loads issued back to back, and the NEXT tile's loads are issued before this one is
+  // walked (a load -> store round trip per row step otherwise: the wavefront then sits out the memory latency 240 times per block).
+  constexpr int RPS = 64 / PLL_TILE, STEPS = 64 / RPS;
+  float2 regs[STEPS];
+  auto fetch_tile = [&](int t0) {
+    const int tn = N - t0 < PLL_TILE ? N - t0 : PLL_TILE;
+    const int n = lane % PLL_TILE;
+#pragma unroll
+    for (int k = 0; k < STEPS; k++) {
+      const int r = k * RPS + lane / PLL_TILE;
+      regs[k] = make_float2(0.f, 0.f);
+      if (((act >> r) & 1ull) && n < tn) regs[k] = p.in[(size_t)(base + r) * N + t0 + n];
+    }
+  };
+  fetch_tile(0);
   for (int t0 = 0; t0 < N; t0 += PLL_TILE) {
     const int tn = N - t0 < PLL_TILE ? N - t0 : PLL_TILE;
-    // in: row r = channel base + r, PLL_TILE consecutive samples per row, two rows per wavefront load
-    for (int r0 = 0; r0 < 64; r0 += 64 / PLL_TILE) {
-      const int r = r0 + lane / PLL_TILE, n = lane % PLL_TILE;
-      if (((act >> r) & 1ull) && n < tn) tile[r * LD + n] = p.in[(size_t)(base + r) * N + t0 + n];
+    {
+      const int n = lane % PLL_TILE;
+#pragma unroll
+      for (int k = 0; k < STEPS; k++) tile[(k * RPS + lane / PLL_TILE) * LD + n] = regs[k];
     }
     CHZ_WAVE_SYNC();
+    if (t0 + PLL_TILE < N) fetch_tile(t0 + PLL_TILE);
     if (active) {
       for (int n = 0; n < tn; n++) {
         double sn, cs; pll_nco(q.vco_phase, sn, cs);
@@ -2064,6 +2085,248 @@ __global__ void __launch_bounds__(64) fm_finish(DemodParams p) {
   fm_deemph_output(p, c, st, r, ch, lane, esh, n0, cnt, N);
 }
 
+// ---- demod_linear() at ONE CHANNEL PER LANE.  A wavefront per channel spends ~800 vector instructions per channel and block, most
+// of them on what is the same in all 64 lanes (noise smoothing, the AGC's decisions with their square roots, divisions and pow(), the
+// squelch, the status record), for 3.75 samples per lane: 2.2 ns per channel at 1.5 M channels, the slowest stage of the chain.  Here a
+// workgroup of 64 lanes takes 64 channels; their blocks pass through LDS in tiles of 32 samples (coalesced rows in, one column per
+// lane out, as in pll_lanes), every lane walks ITS channel in the reference's own order -- slice energies and peak (src/linear.c:
+// 177-234), the gain ramp multiplied up sample by sample, the carrier filter as the recurrence it is, the power sum in sample order --
+// so nothing is re-associated: statement for statement chzo_lindemod_block / demod_linear().  The samples of the final pass go back
+// into the tile where the input stood and leave as packed PCM, whole rows at a time.  Serves every channel of the linear demodulator
+// (those in a coherent mode after pll_lanes has mixed their block down); demod_linear_tail then only sees the FM channels.
+#define LIN_TILE 16
+struct LinRow { unsigned char* o; int enc, channels, data; };
+__global__ void __launch_bounds__(64, 2) demod_lin_lanes(DemodParams p) {
+  HIP_DYNAMIC_SHARED(float2, tile)                         // [64][LIN_TILE + 1], then LinRow[64]
+  constexpr int LD = LIN_TILE + 1;
+  LinRow* rows = reinterpret_cast<LinRow*>(tile + 64 * LD);
+  const int lane = (int)threadIdx.x;
+  const int base = p.ch0 + (int)blockIdx.x * 64;
+  const int ch = base + lane;
+  const int N = p.olen;
+  bool active = false, pll = false;
+  if ((int)blockIdx.x * 64 + lane < p.nch) {
+    const DemodChan* __restrict__ cp = p.chan + ch;
+    pll = cp->pll_enable != 0;
+    active = cp->on && cp->kind == 0 && (!pll || (p.mix != nullptr && p.lin_pll != 0));
+  }
+  const unsigned long long act = __ballot(active);
+  if (act == 0ull) return;                                 // wave-uniform
+  const unsigned long long from_mix = __ballot(active && pll);      // rows whose block pll_lanes left in p.mix
+  // the channel's record, member by member (200 bytes per lane otherwise)
+  int channels = 1, env = 0, agc = 0, snr_squelch = 0, squelch_tail = 0, tuned = 1, enc = 0;
+  double samprate = 1.0, headroom = 0.0, threshold = 0.0, hangtime = 0.0, dc_alpha = 0.0, bandwidth = 1.0, sq_open = 0.0, sq_close = 0.0;
+  double osc_phase0 = 0.0, osc_freq = 0.0, recov_ps = 1.0;
+  unsigned osc_job0 = 0;
+  DemodState st; st.gain = 0.0; st.am_dc = 0.0; st.n0 = 0.0; st.hangcount = 0; st.squelch_state = 0; st.squelch_open = 0;
+  double bb_power = 0.0;
+  double pll_snr = 0.0, pll_cph = 0.0, pll_foff = 0.0; int pll_lock = 0, pll_rot = 0;
+  if (active) {
+    const DemodChan* __restrict__ c = p.chan + ch;
+    channels = c->channels; env = c->env; agc = c->agc; snr_squelch = c->snr_squelch; squelch_tail = c->squelch_tail; tuned = c->tuned; enc = c->encoding;
+    samprate = c->samprate; headroom = c->headroom; threshold = c->threshold; hangtime = c->hangtime; dc_alpha = c->dc_alpha;
+    bandwidth = c->bandwidth; sq_open = c->squelch_open; sq_close = c->squelch_close;
+    osc_phase0 = c->osc_phase0; osc_freq = c->osc_freq; osc_job0 = c->osc_job0; recov_ps = c->recov_ps;
+    st = p.state[ch];
+    bb_power = p.power[ch];
+    const double est = p.n0[ch];                           // src/radio.c:1466-1473
+    if (st.n0 != st.n0) st.n0 = est;
+    else { const double diff = est - st.n0; st.n0 += p.power_alpha * diff; }
+    if (pll) {
+      const DemodExt* __restrict__ ext = p.ext + ch;
+      pll_snr = ext->pll_snr; pll_cph = ext->pll_cphase; pll_foff = ext->foffset; pll_lock = ext->pll.lock; pll_rot = ext->pll_rotations;
+    }
+  }
+  // chan->shift (src/linear.c:168-172): the phasor at a tile's first sample from the closed form, stepped in double inside the tile
+  const bool rot = active && osc_freq != 0.0;
+  double c1 = 1.0, s1 = 0.0;
+  if (rot) sincospi(2.0 * osc_freq, &s1, &c1);
+  auto rot_at = [&](int n, double& cr, double& sr) {
+    const double g = (double)(p.job - osc_job0) * (double)N + (double)n;
+    double hi = g * osc_freq, lo = fma(g, osc_freq, -hi);
+    hi -= rint(hi);
+    sincospi(2.0 * (osc_phase0 + hi + lo), &sr, &cr);
+  };
+  // A tile travels global -> registers -> LDS: all of a tile's loads are issued back to back, and the NEXT tile's are issued before
+  // this one is worked on (32 dependent load -> store round trips per tile otherwise: the kernel then waits for memory 16 times per block)
+  constexpr int ROWS_PER_STEP = 64 / LIN_TILE, STEPS = 64 / ROWS_PER_STEP;
+  float2 regs[STEPS];
+  auto fetch_tile = [&](int t0) {
+    const int tn = N - t0 < LIN_TILE ? N - t0 : LIN_TILE;
+    const int n = lane % LIN_TILE;
+#pragma unroll
+    for (int k = 0; k < STEPS; k++) {
+      const int r = k * ROWS_PER_STEP + lane / LIN_TILE;
+      regs[k] = make_float2(0.f, 0.f);
+      if (((act >> r) & 1ull) && n < tn) {
+        const float2* __restrict__ src = ((from_mix >> r) & 1ull) ? p.mix : p.in;
+        regs[k] = src[(size_t)(base + r) * N + t0 + n];
+      }
+    }
+  };
+  auto place_tile = [&]() {
+    const int n = lane % LIN_TILE;
+#pragma unroll
+    for (int k = 0; k < STEPS; k++) tile[(k * ROWS_PER_STEP + lane / LIN_TILE) * LD + n] = regs[k];
+  };
+  // ---- AGC (src/linear.c:177-234): the largest slice energy of the block, slices in order
+  double gain_change = 1.0;
+  if (__ballot(active && agc) != 0ull) {                   // wave-uniform
+    int sps = (int)rint(N * .002 / p.blocktime);
+    sps = sps < 1 ? 1 : sps;
+    double peak = 0.0, energy = 0.0; int in_slice = 0;
+    fetch_tile(0);
+    for (int t0 = 0; t0 < N; t0 += LIN_TILE) {
+      const int tn = N - t0 < LIN_TILE ? N - t0 : LIN_TILE;
+      place_tile();
+      CHZ_WAVE_SYNC();
+      if (t0 + LIN_TILE < N) fetch_tile(t0 + LIN_TILE);
+      if (active && agc) {
+        double cr = 1.0, sr = 0.0;
+        if (rot) rot_at(t0, cr, sr);
+        for (int n = 0; n < tn; n++) {
+          float2 v = tile[lane * LD + n];
+          if (rot) {
+            const double xr = v.x, xi = v.y;
+            v = make_float2((float)(xr * cr - xi * sr), (float)(xr * sr + xi * cr));
+            const double nc = cr * c1 - sr * s1; sr = cr * s1 + sr * c1; cr = nc;
+          }
+          float a = v.x * v.x, b = v.y * v.y;
+          CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
+          energy += (double)(a + b);                       // cnrmf
+          if (++in_slice == sps) {
+            // `while (n + samples_per_slice < N)` (:199): a slice counts only if it ends before the block's last sample
+            if (t0 + n + 1 < N && energy > peak) peak = energy;
+            energy = 0.0; in_slice = 0;
+          }
+        }
+      }
+      CHZ_WAVE_SYNC();
+    }
+    if (active && agc) {
+      const double bn = sqrt(bandwidth * st.n0);
+      const double ampl = sqrt(bb_power);
+      const double peak_level = sqrt(peak / sps);
+      if (peak_level * st.gain > M_SQRT2 * headroom) {
+        st.gain = M_SQRT2 * headroom / peak_level;
+        gain_change = 1.0;
+        st.hangcount = (int)rint(0.08 * samprate);
+      } else if (ampl * st.gain > headroom) {
+        const double newgain = headroom / ampl;
+        if (newgain > 0) gain_change = pow(newgain / st.gain, 1.0 / N);
+        st.hangcount = (int)rint(hangtime * samprate);
+      } else if (bn * st.gain > threshold * headroom) {
+        const double newgain = threshold * headroom / bn;
+        if (newgain > 0) gain_change = pow(newgain / st.gain, 1.0 / N);
+      } else if (st.hangcount > 0) {
+        st.hangcount -= N;
+      } else {
+        gain_change = recov_ps;                            // pow(recovery_rate, 1 / samprate)
+      }
+    }
+  }
+  // ---- squelch sequencer (src/linear.c:313-352); it does not interact with the final pass, and knowing the frame type first
+  // saves packing PCM nobody will send
+  double snr = __builtin_huge_val();
+  if (snr_squelch) snr = (bb_power / (st.n0 * bandwidth)) - 1.0;
+  else if (pll) snr = pll_snr;                             // :317-318
+  const int smax = squelch_tail + 4;
+  if (!(snr_squelch || pll) || snr >= sq_open) st.squelch_state = smax;
+  else if (st.squelch_state > 0 && snr < sq_close) st.squelch_state--;
+  const bool data = active && st.squelch_state >= 4;
+  rows[lane] = LinRow{p.pcm + (size_t)ch * p.pcm_stride, enc, channels, data ? 1 : 0};
+  // ---- final pass (src/linear.c:236-311); the gain ramp and the carrier filter run whether or not the frame is sent
+  const double k_env = M_SQRT1_2;
+  const bool dcfilt = env && dc_alpha != 0;
+  double gain = st.gain, am_dc = st.am_dc, part = 0.0;
+  const unsigned long long any_data = __ballot(data);
+  fetch_tile(0);
+  for (int t0 = 0; t0 < N; t0 += LIN_TILE) {
+    const int tn = N - t0 < LIN_TILE ? N - t0 : LIN_TILE;
+    place_tile();
+    CHZ_WAVE_SYNC();
+    if (t0 + LIN_TILE < N) fetch_tile(t0 + LIN_TILE);
+    if (active) {
+      double cr = 1.0, sr = 0.0;
+      if (rot) rot_at(t0, cr, sr);
+      for (int n = 0; n < tn; n++) {
+        float2 v = tile[lane * LD + n];
+        if (rot) {
+          const double xr = v.x, xi = v.y;
+          v = make_float2((float)(xr * cr - xi * sr), (float)(xr * sr + xi * cr));
+          const double nc = cr * c1 - sr * s1; sr = cr * s1 + sr * c1; cr = nc;
+        }
+        float oa, ob = 0.f;
+        if (channels == 1) {
+          double sgn;
+          if (env) {
+            sgn = gain * k_env * (double)demod_cabsf(v);
+            gain *= gain_change;
+            part += sgn * sgn;
+            if (dcfilt) { am_dc += dc_alpha * (sgn - am_dc); sgn -= am_dc; }
+          } else {
+            sgn = gain * (double)v.x;
+            gain *= gain_change;
+            part += sgn * sgn;
+          }
+          oa = (float)sgn;
+        } else {
+          double a, b;
+          if (env) {
+            const double k = gain * k_env;
+            a = k * (double)v.x; b = k * (double)demod_cabsf(v);
+            gain *= gain_change;
+            part += a * a + b * b;
+            if (dcfilt) { am_dc += dc_alpha * (b - am_dc); b -= am_dc; }
+          } else {
+            a = gain * (double)v.x; b = gain * (double)v.y;
+            gain *= gain_change;
+            part += a * a + b * b;
+          }
+          oa = (float)a; ob = (float)b;
+        }
+        tile[lane * LD + n] = make_float2(oa, ob);
+      }
+    }
+    CHZ_WAVE_SYNC();
+    if (any_data != 0ull) {
+      for (int r0 = 0; r0 < 64; r0 += 64 / LIN_TILE) {
+        const int r = r0 + lane / LIN_TILE, n = lane % LIN_TILE;
+        if (((any_data >> r) & 1ull) && n < tn) {
+          const LinRow q = rows[r];
+          const float2 v = tile[r * LD + n];
+          if (q.channels == 1) demod_put(q.o, q.enc, t0 + n, v.x);
+          else { demod_put(q.o, q.enc, 2 * (t0 + n), v.x); demod_put(q.o, q.enc, 2 * (t0 + n) + 1, v.y); }
+        }
+      }
+    }
+    CHZ_WAVE_SYNC();
+  }
+  if (!active) return;
+  st.gain = gain; st.am_dc = am_dc;
+  double output_power = part / N;
+  if (channels == 1) output_power *= 2;
+  DemodStatus r;
+  r.gain = st.gain; r.n0 = st.n0; r.snr = snr; r.squelch_state = st.squelch_state;
+  r.output_power = output_power; r.foffset = pll_foff; r.pdeviation = 0.0;
+  r.pll_lock = pll_lock; r.pll_snr = pll_snr; r.pll_cphase = pll_cph; r.pll_rotations = pll_rot; r.tone_deviation = 0.0; r.tone_mute = 0;
+  if (!data) {
+    r.frame = 1; r.mute = st.squelch_state == 0;
+    if (st.squelch_state == 3 || st.squelch_state == 0) r.output_power = 0;
+  } else {
+    if (snr_squelch || pll) {
+      if (snr < sq_close) st.squelch_open = 0;
+      else if (!st.squelch_open && snr > sq_open) { st.squelch_open = 1; st.am_dc = 0; }
+    } else st.squelch_open = 1;
+    r.frame = 0;
+    r.mute = (output_power == 0 || !st.squelch_open || !tuned);
+  }
+  demod_publish(p, ch, r);
+  // (only the members this demodulator owns: the FM members of the record are not ours to touch)
+  DemodState* __restrict__ so = p.state + ch;
+  so->gain = st.gain; so->am_dc = st.am_dc; so->n0 = st.n0; so->hangcount = st.hangcount; so->squelch_state = st.squelch_state; so->squelch_open = st.squelch_open;
+}
+
 __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   HIP_DYNAMIC_SHARED(double, esh)                          // [N] per-sample energies (AGC slices), then [N] complex samples (PLL modes)
   const int lane = (int)threadIdx.x;
@@ -2075,6 +2338,7 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   DemodState st = p.state[ch];
   float2* xs = reinterpret_cast<float2*>(esh + p.olen);
   if (c.kind == 1) { demod_fm_wave(p, c, st, ch, lane, esh, xs); return; }     // wave-uniform
+  if (p.lin_lanes != 0 && (c.pll_enable == 0 || (p.mix != nullptr && p.lin_pll != 0))) return;   // demod_lin_lanes has served this channel
   const int N = p.olen;
   const int SEG = (N + 63) >> 6;
   const int n0 = lane * SEG;                               // first sample of this lane
@@ -2202,7 +2466,7 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
     } else if (st.hangcount > 0) {
       st.hangcount -= N;
     } else {
-      gain_change = pow(c.recovery_rate, 1.0 / c.samprate);
+      gain_change = c.recov_ps;                                               // pow(recovery_rate, 1 / samprate)
     }
   }
   // ---- squelch sequencer (src/linear.c:313-352).  It is advanced AFTER the final pass in the reference's program order, but
@@ -2217,7 +2481,13 @@ __global__ void __launch_bounds__(64) demod_linear_tail(DemodParams p) {
   // ---- final pass (src/linear.c:236-311); the gain ramp and the carrier filter run whether or not the frame is sent
   const double k_env = M_SQRT1_2;
   double gain = st.gain;
-  if (gain_change != 1.0 && n0 > 0) gain *= pow(gain_change, (double)(n0 < N ? n0 : N));
+  // this lane's first sample sees the gain after n0 steps of the ramp: gain_change^n0 by squaring over the bits of n0 (a dozen
+  // multiplications; libm's pow() is ~180 instructions, and every lane of every channel paid it)
+  if (gain_change != 1.0 && n0 > 0) {
+    double f = 1.0, b = gain_change;
+    for (unsigned e = (unsigned)(n0 < N ? n0 : N); e; e >>= 1) { if (e & 1u) f *= b; b *= b; }
+    gain *= f;
+  }
   // pass A (envelope modes with carrier removal only): this lane's samples as an affine map of the incoming filter state
   const bool dcfilt = c.env && c.dc_alpha != 0;
   double am_in = st.am_dc;

@@ -124,8 +124,10 @@ inline NotchTables notch_tables(const int* bins, int n, const SpecLayout& lay) {
   }
   return t;
 }
-inline int launch_demod(hipStream_t s, const DemodParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-  if (p.nch <= 0) return 0;
+inline int launch_demod(hipStream_t s, const DemodParams& p_in, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+  if (p_in.nch <= 0) return 0;
+  DemodParams p = p_in;
+  p.fm_alpha = -std::expm1(-p.blocktime / 1.0);
   const size_t lds = 16 * (size_t)p.olen;                                          // one wavefront per channel; LDS: N doubles + N complex
   if (lds > 160 * 1024) return -1;                                                 // blocks of more than 10240 samples do not fit a CU
   if (lds > 64 * 1024) {
@@ -138,6 +140,7 @@ inline int launch_demod(hipStream_t s, const DemodParams& p, hipEvent_t e0 = nul
   // together when instrumented: the first dispatch starts the clock, the last stops it.
   const bool lanes = p.mix != nullptr;
   const bool lin = lanes && p.lin_pll, fpll = lanes && p.fm_pll, ftone = lanes && p.fm_tone;
+  const bool linl = p.lin_lanes != 0, wave = p.wave_any != 0 || !linl;
   if ((fpll || ftone) && 8 * (size_t)p.olen > 64 * 1024) {
     static int big2 = -1;
     if (big2 < 0) big2 = (big_lds_prepare(reinterpret_cast<const void*>(fm_front_k)) == 0 && big_lds_prepare(reinterpret_cast<const void*>(fm_finish)) == 0) ? 1 : 0;
@@ -145,17 +148,23 @@ inline int launch_demod(hipStream_t s, const DemodParams& p, hipEvent_t e0 = nul
   }
   const size_t tl = sizeof(float2) * 64 * (PLL_TILE + 1);
   const int groups = (p.nch + 63) / 64;
-  hipEvent_t first = e0;
-  auto ev0 = [&]() { hipEvent_t r = first; first = nullptr; return r; };
-  if (lin) { hipEvent_t a = ev0(); CHZ_LAUNCH(pll_lanes, groups, 64, tl, s, a, (hipEvent_t) nullptr, p); }
-  if (fpll) {
-    { hipEvent_t a = ev0(); CHZ_LAUNCH(fm_front_k, p.nch, 64, 8 * (size_t)p.olen, s, a, (hipEvent_t) nullptr, p); }
-    CHZ_LAUNCH(fm_pll_lanes, groups, 64, sizeof(float2) * 64 * (FM_TILE + 1), s, (hipEvent_t) nullptr, (hipEvent_t) nullptr, p);
-  }
-  { hipEvent_t a = ev0(); CHZ_LAUNCH(demod_linear_tail, p.nch, 64, lds, s, a, ftone ? (hipEvent_t) nullptr : e1, p); }
-  if (ftone) {
-    CHZ_LAUNCH(fm_tone_lanes, groups, 64, sizeof(float) * 64 * (FM_TILE + 1), s, (hipEvent_t) nullptr, (hipEvent_t) nullptr, p);
-    CHZ_LAUNCH(fm_finish, p.nch, 64, 8 * (size_t)p.olen, s, (hipEvent_t) nullptr, e1, p);
+  // dispatches of this call, in order; the first one carries e0, the last one e1
+  const int total = (lin ? 1 : 0) + (linl ? 1 : 0) + (wave ? (fpll ? 2 : 0) + 1 + (ftone ? 2 : 0) : 0);
+  int k = 0;
+  auto E0 = [&]() { return k == 0 ? e0 : (hipEvent_t) nullptr; };
+  auto E1 = [&]() { return k == total - 1 ? e1 : (hipEvent_t) nullptr; };
+  if (lin) { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(pll_lanes, groups, 64, tl, s, a, b, p); k++; }
+  if (linl) { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(demod_lin_lanes, groups, 64, sizeof(float2) * 64 * (LIN_TILE + 1) + sizeof(LinRow) * 64, s, a, b, p); k++; }
+  if (wave) {
+    if (fpll) {
+      { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(fm_front_k, p.nch, 64, 8 * (size_t)p.olen, s, a, b, p); k++; }
+      { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(fm_pll_lanes, groups, 64, sizeof(float2) * 64 * (FM_TILE + 1), s, a, b, p); k++; }
+    }
+    { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(demod_linear_tail, p.nch, 64, lds, s, a, b, p); k++; }
+    if (ftone) {
+      { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(fm_tone_lanes, groups, 64, sizeof(float) * 64 * (FM_TILE + 1), s, a, b, p); k++; }
+      { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(fm_finish, p.nch, 64, 8 * (size_t)p.olen, s, a, b, p); k++; }
+    }
   }
   return 0;
 }

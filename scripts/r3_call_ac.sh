@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 3, call ac: demod_lin_lanes with register-staged, prefetched 16-sample tiles
+cd "$(dirname "$0")/.." || exit 1
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_pipeline.py tests/test_golden.py -m gpu -q -x -k "demod or coherent or linear or golden or filter2 or partial_rerun" -p no:cacheprovider 2>&1 | tail -2
+for m in linear pll; do
+  timeout 300 python scripts/scale_kernels_probe.py 1.5 $m 2>&1 | tail -1 | sed "s/^{/{\"tiles\": \"16, prefetched\", /" | tee -a gpurun_out/r3_demod_lanes.jsonl
+done

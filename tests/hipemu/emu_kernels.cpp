@@ -286,6 +286,8 @@ int emu_demod(const float* in, const double* power, const double* n0, const void
               int nch, int olen, unsigned job, double blocktime, void* ext) {
   DemodParams d{};
   d.in = reinterpret_cast<const float2*>(in); d.power = power; d.n0 = n0;
+  { DemodChan* cw = static_cast<DemodChan*>(const_cast<void*>(chan));      // the host-computed constant, as chz_bank_set_demod leaves it
+    for (int i = 0; i < nch; i++) cw[i].recov_ps = std::pow(cw[i].recovery_rate, 1.0 / cw[i].samprate); }
   d.chan = static_cast<const DemodChan*>(chan); d.state = static_cast<DemodState*>(state); d.status = static_cast<DemodStatus*>(status);
   d.ext = static_cast<DemodExt*>(ext); d.flags = nullptr;
   d.pcm = pcm; d.ch0 = 0; d.nch = nch; d.olen = olen; d.pcm_stride = olen * 8; d.job = job; d.blocktime = blocktime; d.power_alpha = 0.10;
@@ -300,6 +302,11 @@ int emu_demod(const float* in, const double* power, const double* n0, const void
       d.lin_pll |= c.kind == 0 && c.pll_enable; d.fm_pll |= c.kind == 1 && c.pll_enable; d.fm_tone |= c.kind == 1 && c.tone_freq != 0;
     }
   }
+  // the linear demodulators run one channel per lane (as in the engine); EMU_DEMOD_WAVE=1 keeps them on the wavefront kernel
+  { bool any_lin = false, any_fm = false, pll_lin = false;
+    for (int i = 0; i < nch; i++) { const DemodChan& c = d.chan[i]; if (!c.on) continue; any_lin |= c.kind == 0; any_fm |= c.kind == 1; pll_lin |= c.kind == 0 && c.pll_enable; }
+    d.lin_lanes = (any_lin && !getenv("EMU_DEMOD_WAVE")) ? 1 : 0;
+    d.wave_any = (any_fm || !d.lin_lanes || (pll_lin && d.mix == nullptr)) ? 1 : 0; }
   return launch_demod(nullptr, d);
 }
 int emu_demod_sizes(int* out3) { out3[0] = (int)sizeof(DemodChan); out3[1] = (int)sizeof(DemodState); out3[2] = (int)sizeof(DemodStatus); return 0; }

@@ -596,7 +596,7 @@ class _DemodChan(C.Structure):           # struct DemodChan, chz_kernels.h
                 ("squelch_close", C.c_double), ("osc_phase0", C.c_double), ("osc_freq", C.c_double), ("osc_job0", C.c_uint), ("kind", C.c_int),
                 ("deemph_rate", C.c_double), ("deemph_gain", C.c_double), ("threshold_extend", C.c_double),
                 ("pll_enable", C.c_int), ("pll_square", C.c_int), ("pll_loop_bw", C.c_double), ("tone_freq", C.c_double),
-                ("g_coeff", C.c_double), ("g_cfr", C.c_double), ("g_cfi", C.c_double)]
+                ("g_coeff", C.c_double), ("g_cfr", C.c_double), ("g_cfi", C.c_double), ("recov_ps", C.c_double)]
 
 
 class _DemodState(C.Structure):
@@ -611,7 +611,12 @@ DEMOD_CASES = [dict(), dict(channels=2, encoding=ol.PCM_F32LE), dict(env=True, d
                dict(encoding=ol.PCM_F16LE), dict(channels=2, env=True, dc_alpha=0.01, encoding=ol.PCM_F16BE)]
 
 
-def test_linear_demodulator_kernel(emu):
+@pytest.mark.parametrize("path", ["lanes", "wave"])      # demod_lin_lanes (one channel per lane) / demod_linear_tail (a wavefront per channel)
+def test_linear_demodulator_kernel(emu, monkeypatch, path):
+    if path == "wave":
+        monkeypatch.setenv("EMU_DEMOD_WAVE", "1")
+    else:
+        monkeypatch.delenv("EMU_DEMOD_WAVE", raising=False)
     """demod_linear_tail (one lane per channel, the reference's own loop order) against the restated demodulator over 40
     blocks of baseband that walks every AGC branch; all seven mode combinations side by side as seven channels."""
     sizes = (C.c_int * 3)()
@@ -747,7 +752,12 @@ PLL_CASES = [dict(pll=True), dict(pll=True, square=True, pll_bw=20.0, channels=2
              dict(pll=True, env=True, dc_alpha=0.002, pll_bw=50.0, squelch_tail=0, encoding=ol.PCM_S16LE), dict()]
 
 
-def test_linear_pll_kernel(emu):
+@pytest.mark.parametrize("path", ["lanes", "wave"])      # demod_lin_lanes (one channel per lane) / demod_linear_tail (a wavefront per channel)
+def test_linear_pll_kernel(emu, monkeypatch, path):
+    if path == "wave":
+        monkeypatch.setenv("EMU_DEMOD_WAVE", "1")
+    else:
+        monkeypatch.delenv("EMU_DEMOD_WAVE", raising=False)
     """The coherent modes of the demodulator kernel (src/linear.c:83-153: PLL on one lane, lock detector, PLL squelch) against the
     restated demodulator, which is pinned to the reference's linear.c / osc.c; a channel without the PLL rides along.
     The loop is a recurrence through a truncation to a 32-bit phase word: device and restatement may differ by an LSB of that
@@ -804,6 +814,7 @@ def test_pll_one_channel_per_lane_equals_one_lane_per_wavefront(emu, monkeypatch
     bb0, pw0 = _coherent_case(np.random.default_rng(3), nblk, N, False)
     bb1, pw1 = _coherent_case(np.random.default_rng(4), nblk, N, True)
     results = []
+    monkeypatch.setenv("EMU_DEMOD_WAVE", "1")      # both runs through the wavefront kernel: what differs is WHERE the PLL loop runs
     for lane0 in (True, False):
         if lane0:
             monkeypatch.setenv("EMU_PLL_LANE0", "1")
@@ -950,7 +961,12 @@ def random_demod_channels(seed=99, nblk=30, N=240, fs=12000.0):
     return params, oracles, bbs, powers, ests
 
 
-def test_demodulator_kernel_random_parameter_sweep(emu):
+@pytest.mark.parametrize("path", ["lanes", "wave"])      # demod_lin_lanes (one channel per lane) / demod_linear_tail (a wavefront per channel)
+def test_demodulator_kernel_random_parameter_sweep(emu, monkeypatch, path):
+    if path == "wave":
+        monkeypatch.setenv("EMU_DEMOD_WAVE", "1")
+    else:
+        monkeypatch.delenv("EMU_DEMOD_WAVE", raising=False)
     """Twenty-four channels with randomly drawn demodulator settings -- linear and FM side by side in ONE launch, every PCM encoding,
     AGC on and off, envelope / carrier removal, squelch variants, PLLs, tone squelch -- run for 30 blocks on the emulated kernel
     against the restated demodulators (which the same kind of sweep pins to the reference's own code)."""
