@@ -1977,8 +1977,9 @@ __global__ void __launch_bounds__(64) fm_front_k(DemodParams p) {
 }
 
 #define FM_TILE 32
+#define FMP_TILE 16
 __global__ void __launch_bounds__(64, 2) fm_pll_lanes(DemodParams p) {
-  HIP_DYNAMIC_SHARED(float2, tile)                         // [64][FM_TILE + 1]
+  HIP_DYNAMIC_SHARED(float2, tile)                         // [64][FMP_TILE + 1]
   const int lane = (int)threadIdx.x;
   const int base = p.ch0 + (int)blockIdx.x * 64;
   const int ch = base + lane;
@@ -1999,20 +2000,29 @@ __global__ void __launch_bounds__(64, 2) fm_pll_lanes(DemodParams p) {
       q.lower = -pdev; q.upper = +pdev;
     }
   }
-  constexpr int LD = FM_TILE + 1;
+  constexpr int LD = FMP_TILE + 1;
   float* __restrict__ mixf = reinterpret_cast<float*>(p.mix);
-  for (int t0 = 0; t0 < N; t0 += FM_TILE) {
-    const int tn = N - t0 < FM_TILE ? N - t0 : FM_TILE;
-    for (int r0 = 0; r0 < 64; r0 += 64 / FM_TILE) {
-      const int r = r0 + lane / FM_TILE, n = lane % FM_TILE;
-      if (((act >> r) & 1ull) && n < tn) tile[r * LD + n] = p.in[(size_t)(base + r) * N + t0 + n];
+  for (int t0 = 0; t0 < N; t0 += FMP_TILE) {
+    const int tn = N - t0 < FMP_TILE ? N - t0 : FMP_TILE;
+    {   // all of the tile's loads in flight at once, then into LDS (the loop's registers leave no room to hold the next tile as well)
+      constexpr int RPS = 64 / FMP_TILE, STEPS = 64 / RPS;
+      float2 regs[STEPS];
+      const int n = lane % FMP_TILE;
+#pragma unroll
+      for (int k = 0; k < STEPS; k++) {
+        const int r = k * RPS + lane / FMP_TILE;
+        regs[k] = make_float2(0.f, 0.f);
+        if (((act >> r) & 1ull) && n < tn) regs[k] = p.in[(size_t)(base + r) * N + t0 + n];
+      }
+#pragma unroll
+      for (int k = 0; k < STEPS; k++) tile[(k * RPS + lane / FMP_TILE) * LD + n] = regs[k];
     }
     CHZ_WAVE_SYNC();
     if (active)
       for (int n = 0; n < tn; n++) tile[lane * LD + n].x = fm_pll_sample(q, tile[lane * LD + n], pdev, extend, 0.5, noise);
     CHZ_WAVE_SYNC();
-    for (int r0 = 0; r0 < 64; r0 += 64 / FM_TILE) {
-      const int r = r0 + lane / FM_TILE, n = lane % FM_TILE;
+    for (int r0 = 0; r0 < 64; r0 += 64 / FMP_TILE) {
+      const int r = r0 + lane / FMP_TILE, n = lane % FMP_TILE;
       if (((act >> r) & 1ull) && n < tn) mixf[(size_t)(base + r) * 2 * N + t0 + n] = tile[r * LD + n].x;
     }
     CHZ_WAVE_SYNC();
@@ -2041,13 +2051,29 @@ __global__ void __launch_bounds__(64, 2) fm_tone_lanes(DemodParams p) {
   }
   constexpr int LD = FM_TILE + 1;
   const float* __restrict__ mixf = reinterpret_cast<const float*>(p.mix);
+  // (tiles staged through registers, the next one fetched while this one is walked: see pll_lanes)
+  constexpr int RPS = 64 / FM_TILE, STEPS = 64 / RPS;
+  float regs[STEPS];
+  auto fetch_tile = [&](int t0) {
+    const int tn = N - t0 < FM_TILE ? N - t0 : FM_TILE;
+    const int n = lane % FM_TILE;
+#pragma unroll
+    for (int k = 0; k < STEPS; k++) {
+      const int r = k * RPS + lane / FM_TILE;
+      regs[k] = 0.f;
+      if (((act >> r) & 1ull) && n < tn) regs[k] = mixf[(size_t)(base + r) * 2 * N + N + t0 + n];
+    }
+  };
+  fetch_tile(0);
   for (int t0 = 0; t0 < N; t0 += FM_TILE) {
     const int tn = N - t0 < FM_TILE ? N - t0 : FM_TILE;
-    for (int r0 = 0; r0 < 64; r0 += 64 / FM_TILE) {
-      const int r = r0 + lane / FM_TILE, n = lane % FM_TILE;
-      if (((act >> r) & 1ull) && n < tn) tilef[r * LD + n] = mixf[(size_t)(base + r) * 2 * N + N + t0 + n];
+    {
+      const int n = lane % FM_TILE;
+#pragma unroll
+      for (int k = 0; k < STEPS; k++) tilef[(k * RPS + lane / FM_TILE) * LD + n] = regs[k];
     }
     CHZ_WAVE_SYNC();
+    if (t0 + FM_TILE < N) fetch_tile(t0 + FM_TILE);
     if (active)
       for (int n = 0; n < tn; n++) fm_tone_sample(g, c, (double)tilef[lane * LD + n], isamprate, integrate);
     CHZ_WAVE_SYNC();

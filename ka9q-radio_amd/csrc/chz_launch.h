@@ -158,7 +158,7 @@ inline int launch_demod(hipStream_t s, const DemodParams& p_in, hipEvent_t e0 = 
   if (wave) {
     if (fpll) {
       { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(fm_front_k, p.nch, 64, 8 * (size_t)p.olen, s, a, b, p); k++; }
-      { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(fm_pll_lanes, groups, 64, sizeof(float2) * 64 * (FM_TILE + 1), s, a, b, p); k++; }
+      { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(fm_pll_lanes, groups, 64, sizeof(float2) * 64 * (FMP_TILE + 1), s, a, b, p); k++; }
     }
     { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(demod_linear_tail, p.nch, 64, lds, s, a, b, p); k++; }
     if (ftone) {
