@@ -46,7 +46,8 @@ def test_product_binding_refuses_the_emulated_library(emulated_engine):
 def test_engine_orchestration_on_the_emulator(emulated_engine):
     env = dict(os.environ, CHZ_LIB=emulated_engine, CHZ_ALLOW_EMULATED_ENGINE="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_pipeline.py"),
-                        os.path.join(ROOT, "tests", "test_golden.py"), "-m", "gpu", "-q", "-x", "--timeout", "180", "-p", "no:cacheprovider", "-k", "not (%s)" % SKIP],
+                        os.path.join(ROOT, "tests", "test_golden.py"), "-m", "gpu", "-q", "-x", "--timeout", "300", "-p", "no:cacheprovider", "-k", "not (%s)" % SKIP,
+                        "-n", str(max(1, min(6, (os.cpu_count() or 2) - 1)))],      # the tests are independent processes' worth of work: pytest-xdist
                        capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     assert r.returncode == 0, (tail, r.stdout[-3000:], r.stderr[-1500:])

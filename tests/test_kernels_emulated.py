@@ -350,6 +350,7 @@ def test_noise_estimate_kernel(emu, in_type, B, s_bins, lay):
     assert np.allclose(n0, want, rtol=1e-12, atol=0)
 
 
+@pytest.mark.skipif(os.environ.get("CHZ_TEST_TWSHUFFLE") != "1", reason="70 s for a rejected build variant (make twshuffle, profiles/r03_twiddle_ab.jsonl): set CHZ_TEST_TWSHUFFLE=1")
 def test_forward_with_lane_generated_twiddles(emu, tmp_path):
     """-DCHZ_TW_SHUFFLE=1: the first pass's column factors generated across each row of 16 lanes (base factor broadcast, powers
     handed on in four DPP steps) instead of read from the table -- the north star's "wavefront-shuffle twiddles", kept as a
