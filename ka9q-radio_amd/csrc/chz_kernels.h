@@ -1523,22 +1523,31 @@ __device__ __forceinline__ float demod_cabsf(float2 x) {
 // Against the restatement's strictly sequential loops these reorderings differ by a few ulp of a DOUBLE (1e-15 relative),
 // far below the float / int16 the samples are rounded to; everything decision-making (AGC branches, squelch sequencer,
 // packing) is the reference's statement for statement.
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+// wave-wide sum / max / min of doubles, the same value in every lane: DPP inside the rows of 16, v_readlane across them (no LDS round
+// trips); on the CPU test emulator plain shuffles
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_f64(v); }
+template <bool MAX> __device__ __forceinline__ double wave_ext_f64(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CHZ_DPP_F64_EXT(ctrl) { const unsigned long long u = (unsigned long long)__double_as_longlong(v); \
+    const unsigned lo = CHZ_DPP_U32((unsigned)u, ctrl), hi = CHZ_DPP_U32((unsigned)(u >> 32), ctrl); \
+    const double o = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); v = MAX ? (o > v ? o : v) : (o < v ? o : v); }
+  CHZ_DPP_F64_EXT(0xB1) CHZ_DPP_F64_EXT(0x4E) CHZ_DPP_F64_EXT(0x141) CHZ_DPP_F64_EXT(0x140)
+#undef CHZ_DPP_F64_EXT
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  double r = v;
+  for (int k = 0; k < 4; k++) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, 16 * k), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), 16 * k);
+    const double o = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    r = k == 0 ? o : (MAX ? (o > r ? o : r) : (o < r ? o : r));
+  }
+  return r;
+#else
+  for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(v, d); v = MAX ? (o > v ? o : v) : (o < v ? o : v); }
   return v;
+#endif
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(v, d); v = o > v ? o : v; }
-  return v;
-}
-
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { const double o = __shfl_xor(v, d); v = o < v ? o : v; }
-  return v;
-}
+__device__ __forceinline__ double wave_max(double v) { return wave_ext_f64<true>(v); }
+__device__ __forceinline__ double wave_min(double v) { return wave_ext_f64<false>(v); }
 // fm_snr() with its Bessel series (src/misc.c:414-468): amplitude mean^2/variance of a Rice process -> signal-to-noise ratio
 __device__ inline double fm_i0(double z) { double t = 0.25 * z * z, sum = 1 + t, term = t;
   for (int k = 2; k < 40; k++) { term *= t / (double)(k * k); sum += term; if (term < 1e-12 * sum) break; } return sum; }
