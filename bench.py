@@ -419,6 +419,55 @@ def crt_pcie_leg(pkg, wl, nch, blocks, demod, dev_index, pipelined=False):
         eng.close()
 
 
+def next_rows_leg(pkg, wl, nch, dev_index, mode="linear"):
+    """SURVEY 8f's rows at scale, I/O resident in HBM: one bank of `nch` channels with fine tuning, the device-side estimate_noise()
+    and a demodulator + PCM packer behind every channel; time per block with 4 blocks in flight, and each stage's own kernel time
+    (instrumented run, HIP events around every launch) per channel.  Never `value`: the callers' loops either side of the path."""
+    tile = 3072
+    nch -= nch % tile
+    P, olen = wl["P"], wl["olen"]
+    eng = pkg.engine.Engine(wl["L"], wl["M"], pkg.engine.REAL, device=dev_index, ring_blocks=RING_BLOCKS)
+    try:
+        x = (np.random.default_rng(1).standard_normal(RING_BLOCKS * wl["L"]) * 0.05).astype(np.float32)
+        eng.write(x[:RING_BLOCKS * wl["L"] - (wl["M"] - 1)]); eng.write(x[RING_BLOCKS * wl["L"] - (wl["M"] - 1):])
+        bank = eng.bank(P, olen, nch)
+        plan = channel_plan_config3(tile)
+        resp = np.stack([pkg.filterapi.design_response(P, olen, wl["N"], True, lo, hi, 11.0) for _, lo, hi in plan[:3]])
+        resp = np.ascontiguousarray(np.tile(resp, (tile // 3, 1)))
+        shifts = np.array([p[0] for p in plan], np.int32)
+        for c0 in range(0, nch, tile):
+            bank.set_responses(c0, resp)
+            bank.set_tuning(0, c0, shifts + (c0 // tile) % 7, np.full(tile, -3.3 / 12000.0))
+        bank.enable_noise(wl["fs"])
+        bank.set_pcm_stride(2 * olen)
+        v = lambda db: 10 ** (db / 20.0)                    # radiod's defaults for a linear mode (src/modes.c:40-60,224-246)
+        if mode == "fm":
+            one = pkg.engine.DemodParams(channels=1, env=0, agc=0, encoding=pkg.engine.PCM_S16BE, snr_squelch=1, squelch_tail=1, tuned=1, kind=1,
+                                         samprate=12000.0, headroom=v(-15.0), threshold=0.0, recovery_rate=0.0, hangtime=0.0, dc_alpha=0.0,
+                                         bandwidth=6000.0, shift=0.0, squelch_open=-2.0, squelch_close=-3.0, gain=1.0,
+                                         deemph_rate=float(-np.expm1(-1.0 / (530.5e-6 * 12000.0))), deemph_gain=v(12.0))
+        else:
+            one = pkg.engine.DemodParams(channels=1, env=0, agc=1, encoding=pkg.engine.PCM_S16BE, snr_squelch=0, squelch_tail=1, tuned=1, kind=0,
+                                         samprate=12000.0, headroom=v(-15.0), threshold=v(-15.0), recovery_rate=v(20.0), hangtime=1.1, dc_alpha=0.0,
+                                         bandwidth=2950.0, shift=0.0, squelch_open=10 ** 0.8, squelch_close=10 ** 0.7, gain=v(50.0),
+                                         pll_enable=1 if mode == "pll" else 0, pll_loop_bw=100.0 if mode == "pll" else 0.0)
+        for c0 in range(0, nch, 65536):
+            bank.set_demod(0, c0, [one] * min(65536, nch - c0), BLOCKTIME)
+        bank.set_active(nch)
+        eng.set_notches([0], 0.01)
+        eng.run_blocks(0, 8)
+        t = eng.run_blocks(8, 16)
+        it = eng.run_blocks(0, 16, instrument=True)
+        per = lambda ms, n: (ms / n * 1e6 / nch) if n else None
+        return {"channels": nch, "mode": mode, "P": P, "olen": olen,
+                "what": "fine tuning (downconvert() tail) inside chan_ifft, estimate_noise() on the device, %s demodulator + S16 PCM behind every channel; I/O in HBM" % mode,
+                "pipelined_ms_per_block": t.total_ms / 16, "fits_20ms": bool(t.total_ms / 16 <= BLOCKTIME * 1e3),
+                "ns_per_channel": {"chan_ifft_with_tuning_and_power": per(it.chan_ms, it.chan_n), "noise_est": per(it.notch_ms, it.notch_n),
+                                   "demodulator_and_pcm": per(it.demod_ms, it.demod_n)}}
+    finally:
+        eng.close()
+
+
 def dropin_leg(wl, ring_host, nthreads, nblocks, env, label):
     """The same workload THROUGH ka9q-radio's filter.h (libka9q_filter_hip.so), driven radiod-style from C by tests/c/dropin_harness.c:
     a front-end thread copying samples into the host ring and calling write_rfilter(), one pthread per channel looping
@@ -505,6 +554,8 @@ def main():
     ap.add_argument("--no-crt", action="store_true", help="skip the C_rt leg (one large bank, every block inside 20 ms)")
     ap.add_argument("--crt-channels", type=int, default=0, help="channels of the C_rt leg's bank (default 17.0 M at P=300, 8.4 M at P=600)")
     ap.add_argument("--crt-blocks", type=int, default=500)
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8f chain leg (tuning + noise estimate + demodulator behind 1.5 M channels)")
+    ap.add_argument("--next-rows-channels", type=int, default=1_500_000)
     ap.add_argument("--crt-ladder", default="", help="comma-separated channel counts (millions) of the C_rt ladder; default 17.0,19.0,19.5,20.0,20.5 at P=300 / 8.4,9.4,9.7,10.0 at P=600")
     ap.add_argument("--no-dropin", action="store_true", help="skip the legs through the filter.h drop-in")
     ap.add_argument("--dropin-blocks", type=int, default=500)
@@ -794,6 +845,14 @@ def main():
                 crt_pcie.append(crt_pcie_leg(pkg, wl, n, args.crt_pcie_blocks, dm, dev_index, pipe))
             except Exception as ex:
                 crt_pcie.append({"channels": n, "error": str(ex)[:200]})
+    next_rows = None
+    if rank == 0 and world == 1 and not args.no_next_rows and config == 3:
+        next_rows = []
+        for mode in ("linear", "pll", "fm"):
+            try:
+                next_rows.append(next_rows_leg(pkg, wl, args.next_rows_channels, dev_index, mode))
+            except Exception as ex:
+                next_rows.append({"mode": mode, "error": str(ex)[:200]})
     if rank == 0:
         def leg_obj(name, leg):
             el, ts, tm, rp, sg = leg
@@ -837,7 +896,7 @@ def main():
             "gpu_event_ms_per_step": timing.total_ms / timing.blocks,
             "host_enqueue_ms_per_step": timing.enqueue_ms / timing.blocks,
             "roofline": roof, "cpu_baseline": cpu, "c_rt": crt, "c_rt_shared_responses": crt_shared,
-            "dropin": dropin, "c_rt_pcie": crt_pcie,
+            "dropin": dropin, "c_rt_pcie": crt_pcie, "next_rows": next_rows,
             "rccl_ranks": rccl_ranks, "ranks": ranks_info,
         }
     if use_dist:

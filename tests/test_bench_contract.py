@@ -19,7 +19,7 @@ def test_bench_cli_parses_without_a_gpu():
 @pytest.mark.gpu
 def test_bench_emits_one_json_line_with_the_contract_keys():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "64", "--warmup", "8",
-                        "--crt-channels", "3000000", "--crt-blocks", "40", "--dropin-blocks", "60", "--crt-pcie-blocks", "30"],
+                        "--crt-channels", "3000000", "--crt-blocks", "40", "--dropin-blocks", "60", "--crt-pcie-blocks", "30", "--next-rows-channels", "300000"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.strip()]
@@ -58,6 +58,9 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
     assert len(pc) == 3 and all("error" not in x for x in pc), pc          # baseband, demodulated PCM, the same double-buffered
     assert pc[0]["d2h_bytes_per_channel"] == 1920 and pc[1]["d2h_bytes_per_channel"] == 481 and pc[2]["d2h_bytes_per_channel"] == 481
     assert "double-buffered" in pc[2]["loop"] and pc[2]["worst_latency_ms"] >= pc[2]["worst_block_ms"]
+    nr = j["next_rows"]                                        # SURVEY 8f's rows behind every channel of one large bank
+    assert [x["mode"] for x in nr] == ["linear", "pll", "fm"] and all("error" not in x for x in nr), nr
+    assert all(x["channels"] == 297984 and x["fits_20ms"] and all(v > 0 for v in x["ns_per_channel"].values()) for x in nr)
     assert all(x["blocks"] == 30 and x["d2h_bytes_per_block"] == x["channels"] * x["d2h_bytes_per_channel"] for x in pc)
 
 
@@ -69,7 +72,7 @@ def test_bench_other_configs_run_on_one_gpu(extra, cfg):
         env["BENCH_FORCE_DIST"] = "1"          # one rank, but through the process group and the RCCL exchange behind the C ABI
         env["MASTER_PORT"] = "29617"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-crt",
-                        "--no-cpu-baseline", "--min-seconds", "0.05", "--no-crt-pcie", "--dropin-blocks", "40"] + extra,
+                        "--no-cpu-baseline", "--min-seconds", "0.05", "--no-crt-pcie", "--no-next-rows", "--dropin-blocks", "40"] + extra,
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.strip()][-1])
