@@ -136,7 +136,8 @@ int chz_bank_set_row_responses(chz_engine *e, int bank, int row0, int n, const f
  * variant (tuning, ISB, beam, noise) drain the engine. */
 /* response[P] complex as set_filter leaves it (src/filter.c:968-1045) */
 int chz_bank_set_responses(chz_engine *e, int bank, int ch0, int n, const float *resp);
-/* `shift` of execute_filter_output(slave, shift) (src/filter.c:663) */
+/* `shift` of execute_filter_output(slave, shift) (src/filter.c:663).  A channel has NO gather descriptor until this (or
+ * chz_bank_set_tuning) has been called for it -- shift 0 included -- and produces zeros until then. */
 int chz_bank_set_shifts(chz_engine *e, int bank, int ch0, int n, const int *shifts);
 /* slave->isb (src/filter.c:895-909, filter2 of the linear demodulator in ISB mode): LSB and USB are unpacked to I and Q
  * after the gather.  One flag byte per channel, non-zero = on.  COMPLEX-output banks only. */
