@@ -175,7 +175,9 @@ struct chz_engine {
   FwdPlan plan;
   float* energy[CHZ_ND] = {nullptr, nullptr, nullptr, nullptr};   // |X|^2 image of each slot for large banks' noise windows (spec_energy), made on first need
   int noise_energy = -1;            // -1: by launch size, 0 never, 1 always (env CHZ_NOISE_ENERGY)
-  bool demod_wave = false;          // env CHZ_DEMOD_WAVE=1: linear demodulators on the wavefront-per-channel kernel (A/B)
+  int demod_wave = -1;              // linear demodulators: -1 by bank size (one channel per lane from 65536 channels up: its ~120 us of
+                                    // latency per launch is only worth paying for a bank that fills the chip), 1 always a wavefront per
+                                    // channel, 0 always a lane per channel (env CHZ_DEMOD_WAVE)
   int chan_stage = -1;              // output staging of chan_ifft: -1 by launch size, 0 never, 1 always (env CHZ_CHAN_STAGE)
   hipStream_t stream = nullptr;     // == lanes[0].s: input copies and anything not tied to a block
   bool own_stream = false;
@@ -341,7 +343,7 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   e->own_stream = true;
   if (const char* cs = getenv("CHZ_CHAN_STAGE")) e->chan_stage = atoi(cs) != 0;
   if (const char* cs = getenv("CHZ_NOISE_ENERGY")) e->noise_energy = atoi(cs) != 0;
-  if (const char* cs = getenv("CHZ_DEMOD_WAVE")) e->demod_wave = atoi(cs) != 0;
+  if (const char* cs = getenv("CHZ_DEMOD_WAVE")) e->demod_wave = atoi(cs) != 0 ? 1 : 0;
   const char* envl = getenv("CHZ_STREAMS");
   int nl = envl ? atoi(envl) : 4;
   e->nlanes = (nl >= 4) ? 4 : (nl >= 2) ? 2 : 1;             // must divide ND so slot and lane stay aligned
@@ -876,10 +878,11 @@ static int after_edit(chz_engine* e, Bank& b, int ch0, int n) {
   return 0;
 }
 
-// which kernels serve the bank's demodulators: the linear ones run one channel per lane (demod_lin_lanes; CHZ_DEMOD_WAVE=1 keeps the
-// wavefront-per-channel kernel for them), FM -- and a coherent-mode channel whose PLL has no scratch block -- the wavefront kernel
+// which kernels serve the bank's demodulators: the linear ones of a LARGE bank run one channel per lane (demod_lin_lanes: 1.2 against
+// 2.2 ns per channel, but ~120 us per launch however small the bank -- profiles/r03_demod_crossover.jsonl), those of a small bank,
+// FM, and a coherent-mode channel whose PLL has no scratch block the wavefront-per-channel kernel
 static void demod_paths(const chz_engine* e, const Bank& b, DemodParams& d) {
-  d.lin_lanes = (b.dm_lin > 0 && !e->demod_wave) ? 1 : 0;
+  d.lin_lanes = (b.dm_lin > 0 && (e->demod_wave == 0 || (e->demod_wave < 0 && b.dm_lin >= 65536))) ? 1 : 0;
   d.wave_any = (b.dm_fm > 0 || !d.lin_lanes || (b.dm_pll_lin > 0 && d.mix == nullptr)) ? 1 : 0;
 }
 static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch0 = 0, int n = -1) {

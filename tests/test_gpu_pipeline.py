@@ -362,7 +362,9 @@ def _demod_engine(pkg, ring, L, M, P, olen, cases, fs_out):
     return eng, bank, params
 
 
-def test_linear_demodulator_on_the_device(pkg):
+@pytest.mark.parametrize("lin_path", ["lanes", "wave"])     # demod_lin_lanes (what banks of >= 65536 channels get) / demod_linear_tail
+def test_linear_demodulator_on_the_device(pkg, monkeypatch, lin_path):
+    monkeypatch.setenv("CHZ_DEMOD_WAVE", "1" if lin_path == "wave" else "0")
     """chan_ifft (+ fine tuning, bb_power) -> noise_est -> demod_linear_tail, block after block through the C ABI.  The
     oracle's demodulator (pinned to the reference's linear.c) is fed exactly what the device stage was fed -- the channel
     outputs, bb_power and noise estimate read back from the same slot -- and must produce the same frames; then the same
@@ -532,7 +534,9 @@ def test_fm_demodulator_on_the_device(pkg):
 
 
 @pytest.mark.gpu
-def test_coherent_modes_and_tone_squelch_on_the_device(pkg):
+@pytest.mark.parametrize("lin_path", ["lanes", "wave"])     # demod_lin_lanes (what banks of >= 65536 channels get) / demod_linear_tail
+def test_coherent_modes_and_tone_squelch_on_the_device(pkg, monkeypatch, lin_path):
+    monkeypatch.setenv("CHZ_DEMOD_WAVE", "1" if lin_path == "wave" else "0")
     """The sequential stages of the demodulator kernel through the C ABI: the carrier-tracking PLL of the linear demodulator
     (plain and squaring loop) with its lock detector and squelch, FM's PLL demodulator and the PL-tone squelch (tone present /
     absent).  Two banks on one engine -- 12 kHz linear channels and 24 kHz FM channels -- share the demodulator stream.  The
@@ -818,7 +822,9 @@ def test_channels_sharing_response_rows(pkg):
 
 
 @pytest.mark.gpu
-def test_demodulators_random_parameter_sweep_on_the_device(pkg):
+@pytest.mark.parametrize("lin_path", ["lanes", "wave"])     # demod_lin_lanes (what banks of >= 65536 channels get) / demod_linear_tail
+def test_demodulators_random_parameter_sweep_on_the_device(pkg, monkeypatch, lin_path):
+    monkeypatch.setenv("CHZ_DEMOD_WAVE", "1" if lin_path == "wave" else "0")
     """The 24 randomly configured channels of tests/test_kernels_emulated.py::random_demod_channels (linear and FM mixed in one bank,
     all encodings, PLLs, tone squelch) on the device: blocks handed to the demodulator stage through chz_bank_write_block +
     chz_bank_demod, frames against the restated demodulators."""
