@@ -318,6 +318,9 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
     double best = 1e300;
     for (long m = 2L * N - 1; m <= 4L * N + 4096 && m < (1L << 30); m++) {
       if (bl->Mz && (double)m > 1.04 * (double)bl->Mz + 64) break;
+      { long r = m;                                              // the compiled axes only hold the primes 2, 3, 5, 13, 19
+        for (int q : {2, 3, 5, 13, 19}) while (r % q == 0) r /= q;
+        if (r != 1) continue; }
       FwdPlan cand; double sc = 0.0;
       if (!build_fwd_plan((int)m, CHZ_COMPLEX, nullptr, cand, &sc)) continue;
       if (!bl->Mz) bl->Mz = m;                                   // (the first hit anchors the window)
