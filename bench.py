@@ -442,7 +442,8 @@ def next_rows_leg(pkg, wl, nch, dev_index, mode="linear"):
         bank.set_pcm_stride(2 * olen)
         v = lambda db: 10 ** (db / 20.0)                    # radiod's defaults for a linear mode (src/modes.c:40-60,224-246)
         if mode == "fm":
-            one = pkg.engine.DemodParams(channels=1, env=0, agc=0, encoding=pkg.engine.PCM_S16BE, snr_squelch=1, squelch_tail=1, tuned=1, kind=1,
+            # NBFM with radiod's default SNR estimator for an open squelch (amplitude variance + fm_snr(), src/fm.c:110-129); thresholds that hold it open on noise
+            one = pkg.engine.DemodParams(channels=1, env=0, agc=0, encoding=pkg.engine.PCM_S16BE, snr_squelch=0, squelch_tail=1, tuned=1, kind=1,
                                          samprate=12000.0, headroom=v(-15.0), threshold=0.0, recovery_rate=0.0, hangtime=0.0, dc_alpha=0.0,
                                          bandwidth=6000.0, shift=0.0, squelch_open=-2.0, squelch_close=-3.0, gain=1.0,
                                          deemph_rate=float(-np.expm1(-1.0 / (530.5e-6 * 12000.0))), deemph_gain=v(12.0))

@@ -88,6 +88,7 @@ struct Bank {
   int dm_pll_lin = 0;                    // channels of the linear demodulator with a carrier PLL
   int dm_fm_pll = 0, dm_fm_tone = 0;     // FM channels with the PLL demodulator / a PL-tone squelch
   int dm_lin = 0, dm_fm = 0;             // channels of the linear / of the FM demodulator
+  int dm_fm_nopll = 0;                   // FM channels on the discriminator (not the PLL demodulator)
   DemodStatus* dm_status = nullptr;      // [ND][cap]
   unsigned char* dm_flags = nullptr;     // [ND][cap] one status byte per channel and block
   unsigned char* dm_pcm = nullptr;       // [ND][cap][pcm_stride]
@@ -249,7 +250,7 @@ static void free_bank(Bank& b) {
   hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); hipFree(b.any_scratch); b.any_scratch = nullptr;
   hipFree(b.fine); hipFree(b.power); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam);
   hipFree(b.dm_chan); hipFree(b.dm_state); hipFree(b.dm_ext); hipFree(b.dm_status); hipFree(b.dm_flags); hipFree(b.dm_pcm); hipFree(b.dm_mix);
-  b.dm_mix = nullptr; b.dm_pll_lin = 0; b.dm_fm_pll = 0; b.dm_fm_tone = 0; b.dm_lin = 0; b.dm_fm = 0;
+  b.dm_mix = nullptr; b.dm_pll_lin = 0; b.dm_fm_pll = 0; b.dm_fm_tone = 0; b.dm_lin = 0; b.dm_fm = 0; b.dm_fm_nopll = 0;
   b.dm_chan = nullptr; b.dm_state = nullptr; b.dm_ext = nullptr; b.dm_status = nullptr; b.dm_flags = nullptr; b.dm_pcm = nullptr; b.dm_on = 0; b.dm_chan_h.clear(); b.dm_osc.clear();
   for (int s = 0; s < CHZ_ND; s++) {
     if (b.ev_bank[s]) (void)hipEventDestroy(b.ev_bank[s]);
@@ -886,7 +887,12 @@ static int after_edit(chz_engine* e, Bank& b, int ch0, int n) {
 // FM, and a coherent-mode channel whose PLL has no scratch block the wavefront-per-channel kernel
 static void demod_paths(const chz_engine* e, const Bank& b, DemodParams& d) {
   d.lin_lanes = (b.dm_lin > 0 && (e->demod_wave == 0 || (e->demod_wave < 0 && b.dm_lin >= 65536))) ? 1 : 0;
-  d.wave_any = (b.dm_fm > 0 || !d.lin_lanes || (b.dm_pll_lin > 0 && d.mix == nullptr)) ? 1 : 0;
+  // FM on the discriminator likewise (demod_fm_lanes keeps the baseband in the bank's scratch block)
+  d.fm_lanes = (b.dm_fm_nopll > 0 && b.dm_mix != nullptr && (e->demod_wave == 0 || (e->demod_wave < 0 && b.dm_fm_nopll >= 65536))) ? 1 : 0;
+  if (d.fm_lanes) d.mix = b.dm_mix;
+  const bool fm_wave = b.dm_fm > 0 && (!d.fm_lanes || b.dm_fm > b.dm_fm_nopll);
+  const bool lin_wave = b.dm_lin > 0 && (!d.lin_lanes || (b.dm_pll_lin > 0 && d.mix == nullptr));
+  d.wave_any = (fm_wave || lin_wave) ? 1 : 0;
 }
 static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch0 = 0, int n = -1) {
   Bank& b = e->banks[(size_t)bank];
@@ -1339,7 +1345,7 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
     return fail(-1, "the demodulator needs the channel's bb_power and noise estimate: call chz_bank_set_tuning and chz_bank_enable_noise first");
   if (b.olen > 10240) return fail(-3, "the demodulator kernel keeps a block in LDS: at most 10240 samples per block (bank has %d)", b.olen);
   if (!b.pcm_stride) b.pcm_stride = b.olen * 8;
-  bool need_ext = false;
+  bool need_ext = false, need_fm_mix = false;
   for (int i = 0; i < n; i++) {
     const chz_demod_params& q = p[i];
     if (q.channels < 0 || q.channels > 2 || q.encoding < CHZ_PCM_S16BE || q.encoding > CHZ_PCM_F16BE) return fail(-1, "bad demodulator parameters for channel %d", ch0 + i);
@@ -1354,7 +1360,10 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
       return fail(-1, "channel %d: the PLL needs a loop bandwidth", ch0 + i);
     if (q.channels > 0 && !(q.tone_freq >= 0 && q.tone_freq < q.samprate / 2)) return fail(-1, "bad PL tone frequency for channel %d", ch0 + i);
     if (q.channels > 0 && (q.pll_enable || (q.kind == CHZ_DEMOD_FM && q.tone_freq != 0))) need_ext = true;
+    if (q.channels > 0 && q.kind == CHZ_DEMOD_FM && !q.pll_enable) need_fm_mix = true;
   }
+  // demod_fm_lanes keeps a block's baseband in the scratch block: only banks large enough to be served by it get one for that
+  need_fm_mix = need_fm_mix && (e->demod_wave == 0 || (e->demod_wave < 0 && b.cap >= 65536));
   HIPOK(hipSetDevice(e->device));
   if (!e->tail) HIPOK(hipStreamCreateWithFlags(&e->tail, hipStreamNonBlocking));
   if (!b.dm_chan) {
@@ -1383,11 +1392,12 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
     std::vector<DemodExt> fresh((size_t)b.cap, demod_ext_init());
     HIPOK(hipMalloc((void**)&b.dm_ext, sizeof(DemodExt) * (size_t)b.cap));
     HIPOK(hipMemcpy(b.dm_ext, fresh.data(), sizeof(DemodExt) * (size_t)b.cap, hipMemcpyHostToDevice));
-    if (!getenv("CHZ_PLL_LANE0")) {            // (A/B knob: round 2's one-lane-per-channel PLL inside the demodulator kernel)
-      HIPOK(hipMalloc((void**)&b.dm_mix, sizeof(float2) * (size_t)b.cap * b.olen));
-      HIPOK(hipMemset(b.dm_mix, 0, sizeof(float2) * (size_t)b.cap * b.olen));
-      HIPOK(hipDeviceSynchronize());
-    }
+    drop_graph(e);
+  }
+  if ((need_ext || need_fm_mix) && !b.dm_mix && !getenv("CHZ_PLL_LANE0")) {      // (A/B knob: round 2's one-lane-per-channel loops inside the demodulator kernel)
+    HIPOK(hipMalloc((void**)&b.dm_mix, sizeof(float2) * (size_t)b.cap * b.olen));
+    HIPOK(hipMemset(b.dm_mix, 0, sizeof(float2) * (size_t)b.cap * b.olen));
+    HIPOK(hipDeviceSynchronize());
     drop_graph(e);
   }
   std::vector<DemodState> init; std::vector<int> init_ch;
@@ -1445,10 +1455,11 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
       init.push_back(st); init_ch.push_back(ch0 + i);
     }
   }
-  b.dm_pll_lin = 0; b.dm_fm_pll = 0; b.dm_fm_tone = 0; b.dm_lin = 0; b.dm_fm = 0;
+  b.dm_pll_lin = 0; b.dm_fm_pll = 0; b.dm_fm_tone = 0; b.dm_lin = 0; b.dm_fm = 0; b.dm_fm_nopll = 0;
   for (const DemodChan& dc : b.dm_chan_h) {
     if (!dc.on) continue;
     b.dm_lin += dc.kind == CHZ_DEMOD_LINEAR ? 1 : 0; b.dm_fm += dc.kind == CHZ_DEMOD_FM ? 1 : 0;
+    b.dm_fm_nopll += (dc.kind == CHZ_DEMOD_FM && !dc.pll_enable) ? 1 : 0;
     b.dm_pll_lin += (dc.kind == CHZ_DEMOD_LINEAR && dc.pll_enable) ? 1 : 0;
     b.dm_fm_pll += (dc.kind == CHZ_DEMOD_FM && dc.pll_enable) ? 1 : 0;
     b.dm_fm_tone += (dc.kind == CHZ_DEMOD_FM && dc.tone_freq != 0) ? 1 : 0;

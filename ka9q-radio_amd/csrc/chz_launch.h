@@ -140,7 +140,7 @@ inline int launch_demod(hipStream_t s, const DemodParams& p_in, hipEvent_t e0 = 
   // together when instrumented: the first dispatch starts the clock, the last stops it.
   const bool lanes = p.mix != nullptr;
   const bool lin = lanes && p.lin_pll, fpll = lanes && p.fm_pll, ftone = lanes && p.fm_tone;
-  const bool linl = p.lin_lanes != 0, wave = p.wave_any != 0 || !linl;
+  const bool linl = p.lin_lanes != 0, fml = lanes && p.fm_lanes != 0, wave = p.wave_any != 0 || !(linl || fml);
   if ((fpll || ftone) && 8 * (size_t)p.olen > 64 * 1024) {
     static int big2 = -1;
     if (big2 < 0) big2 = (big_lds_prepare(reinterpret_cast<const void*>(fm_front_k)) == 0 && big_lds_prepare(reinterpret_cast<const void*>(fm_finish)) == 0) ? 1 : 0;
@@ -149,12 +149,13 @@ inline int launch_demod(hipStream_t s, const DemodParams& p_in, hipEvent_t e0 = 
   const size_t tl = sizeof(float2) * 64 * (PLL_TILE + 1);
   const int groups = (p.nch + 63) / 64;
   // dispatches of this call, in order; the first one carries e0, the last one e1
-  const int total = (lin ? 1 : 0) + (linl ? 1 : 0) + (wave ? (fpll ? 2 : 0) + 1 + (ftone ? 2 : 0) : 0);
+  const int total = (lin ? 1 : 0) + (linl ? 1 : 0) + (fml ? 1 : 0) + (wave ? (fpll ? 2 : 0) + 1 + (ftone ? 2 : 0) : 0);
   int k = 0;
   auto E0 = [&]() { return k == 0 ? e0 : (hipEvent_t) nullptr; };
   auto E1 = [&]() { return k == total - 1 ? e1 : (hipEvent_t) nullptr; };
   if (lin) { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(pll_lanes, groups, 64, tl, s, a, b, p); k++; }
   if (linl) { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(demod_lin_lanes, groups, 64, sizeof(float2) * 64 * (LIN_TILE + 1) + sizeof(LinRow) * 64, s, a, b, p); k++; }
+  if (fml) { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(demod_fm_lanes, groups, 64, sizeof(float2) * 64 * (LIN_TILE + 1) + sizeof(LinRow) * 64, s, a, b, p); k++; }
   if (wave) {
     if (fpll) {
       { hipEvent_t a = E0(), b = E1(); CHZ_LAUNCH(fm_front_k, p.nch, 64, 8 * (size_t)p.olen, s, a, b, p); k++; }

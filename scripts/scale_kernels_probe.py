@@ -29,7 +29,8 @@ bank.enable_noise(129.6e6)
 bank.set_pcm_stride(2 * olen)
 mode = sys.argv[2] if len(sys.argv) > 2 else "linear"       # "pll": every channel in a coherent mode (carrier PLL, src/linear.c:83-153)
 if mode.startswith("fm"):       # "fm", "fmtone" (PL-tone squelch, src/fm.c:264-311), "fmpll" (PLL demodulator, :176-203); squelch held open
-    q = ol.fm_params(samprate=12000.0, bandwidth=6000.0, snr_squelch=True, squelch_open=-2.0, squelch_close=-3.0,
+    # "fmvar": the amplitude-variance SNR estimator of an open NBFM squelch (src/fm.c:110-129), radiod's default, instead of the bb_power / N0 one
+    q = ol.fm_params(samprate=12000.0, bandwidth=6000.0, snr_squelch=(mode != "fmvar"), squelch_open=-2.0, squelch_close=-3.0,
                      tone_freq=(100.0 if mode == "fmtone" else 0.0), pll=(mode == "fmpll"))
 else:
     q = ol.lin_params(pll=(mode == "pll"))

@@ -303,10 +303,14 @@ int emu_demod(const float* in, const double* power, const double* n0, const void
     }
   }
   // the linear demodulators run one channel per lane (as in the engine); EMU_DEMOD_WAVE=1 keeps them on the wavefront kernel
-  { bool any_lin = false, any_fm = false, pll_lin = false;
-    for (int i = 0; i < nch; i++) { const DemodChan& c = d.chan[i]; if (!c.on) continue; any_lin |= c.kind == 0; any_fm |= c.kind == 1; pll_lin |= c.kind == 0 && c.pll_enable; }
-    d.lin_lanes = (any_lin && !getenv("EMU_DEMOD_WAVE")) ? 1 : 0;
-    d.wave_any = (any_fm || !d.lin_lanes || (pll_lin && d.mix == nullptr)) ? 1 : 0; }
+  { bool any_lin = false, fm_pll = false, fm_nopll = false, pll_lin = false;
+    for (int i = 0; i < nch; i++) { const DemodChan& c = d.chan[i]; if (!c.on) continue; any_lin |= c.kind == 0; fm_pll |= c.kind == 1 && c.pll_enable; fm_nopll |= c.kind == 1 && !c.pll_enable; pll_lin |= c.kind == 0 && c.pll_enable; }
+    const bool lanes_on = !getenv("EMU_DEMOD_WAVE");
+    std::vector<float2>* mp = &mix;
+    if (fm_nopll && lanes_on && mp->empty() && !getenv("EMU_PLL_LANE0")) { mp->assign((size_t)nch * olen, make_float2(0.f, 0.f)); d.mix = mp->data(); }
+    d.lin_lanes = (any_lin && lanes_on) ? 1 : 0;
+    d.fm_lanes = (fm_nopll && lanes_on && d.mix != nullptr) ? 1 : 0;
+    d.wave_any = (fm_pll || (fm_nopll && !d.fm_lanes) || (any_lin && !d.lin_lanes) || (pll_lin && d.mix == nullptr)) ? 1 : 0; }
   return launch_demod(nullptr, d);
 }
 int emu_demod_sizes(int* out3) { out3[0] = (int)sizeof(DemodChan); out3[1] = (int)sizeof(DemodState); out3[2] = (int)sizeof(DemodStatus); return 0; }

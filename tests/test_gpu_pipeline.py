@@ -476,7 +476,9 @@ def test_mini_master_of_8192_points(pkg):
         pool.close()
 
 
-def test_fm_demodulator_on_the_device(pkg):
+@pytest.mark.parametrize("fm_path", ["lanes", "wave"])      # demod_fm_lanes (what banks of >= 65536 channels get) / demod_linear_tail
+def test_fm_demodulator_on_the_device(pkg, monkeypatch, fm_path):
+    monkeypatch.setenv("CHZ_DEMOD_WAVE", "1" if fm_path == "wave" else "0")
     """24 kHz NBFM channels behind the channelizer: an FM carrier that comes up out of the noise, is modulated with an offset,
     and fades out through the squelch tail.  The oracle's demod_fm restatement (pinned to the reference's fm.c) gets exactly
     what the device stage got (channel outputs, bb_power, noise estimate read back) and must produce the same frames."""

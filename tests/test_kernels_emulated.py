@@ -672,7 +672,12 @@ FM_CASES = [dict(), dict(threshold_extend=True, encoding=ol.PCM_F32LE), dict(dee
             dict(snr_squelch=True, squelch_tail=3, encoding=ol.PCM_F32BE)]
 
 
-def test_fm_demodulator_kernel(emu):
+@pytest.mark.parametrize("path", ["lanes", "wave"])      # demod_fm_lanes (one channel per lane) / demod_linear_tail (a wavefront per channel)
+def test_fm_demodulator_kernel(emu, monkeypatch, path):
+    if path == "wave":
+        monkeypatch.setenv("EMU_DEMOD_WAVE", "1")
+    else:
+        monkeypatch.delenv("EMU_DEMOD_WAVE", raising=False)
     """The FM branch of the demodulator kernel (demod_fm, src/fm.c; PLL / PL tone: test_fm_pll_and_tone_kernel) against the restated demodulator:
     carrier coming up out of the noise, a modulated stretch with a frequency offset, fading out through the squelch tail."""
     from test_oracle_vs_reference import _fm_case
@@ -846,7 +851,12 @@ FM2_CASES = [(dict(pll=True, encoding=ol.PCM_F32LE), 0.0), (dict(pll=True, thres
              (dict(tone_freq=100.0, deemph_tc=0, encoding=ol.PCM_S16LE), 0.0), (dict(tone_freq=123.0, pll=True), 100.0), (dict(), 100.0)]
 
 
-def test_fm_pll_and_tone_kernel(emu):
+@pytest.mark.parametrize("path", ["lanes", "wave"])      # demod_fm_lanes (one channel per lane) / demod_linear_tail (a wavefront per channel)
+def test_fm_pll_and_tone_kernel(emu, monkeypatch, path):
+    if path == "wave":
+        monkeypatch.setenv("EMU_DEMOD_WAVE", "1")
+    else:
+        monkeypatch.delenv("EMU_DEMOD_WAVE", raising=False)
     """The PLL demodulator (src/fm.c:176-203) and the PL-tone squelch (:264-311) of the demodulator kernel against the restatement
     pinned to the reference's fm.c / osc.c / iir.c: the tone present, absent, the wrong one; a plain channel alongside."""
     from test_oracle_vs_reference import _fm_case
@@ -901,6 +911,7 @@ def test_fm_loops_one_channel_per_lane_equal_one_lane_per_wavefront(emu, monkeyp
     est = (2 * 2e-3 ** 2 / fs) * (1 + 0.1 * r.standard_normal((nch, nblk)))
     keep = ("vco_phase", "vco_step", "wraps", "lock", "lock_count", "u", "phi", "g_s0", "g_s1", "old_pl_phase", "tone_deviation", "pl_sample_count", "tone_mute")
     results = []
+    monkeypatch.setenv("EMU_DEMOD_WAVE", "1")      # both runs through the wavefront kernel: what differs is WHERE the two loops run
     for lane0 in (True, False):
         if lane0:
             monkeypatch.setenv("EMU_PLL_LANE0", "1")
