@@ -973,8 +973,9 @@ def random_demod_channels(seed=99, nblk=30, N=240, fs=12000.0):
     return params, oracles, bbs, powers, ests
 
 
+@pytest.mark.parametrize("N", [240, 250])                # 250: the lane kernels' last tile is a partial one (10 of 16 samples)
 @pytest.mark.parametrize("path", ["lanes", "wave"])      # demod_lin_lanes (one channel per lane) / demod_linear_tail (a wavefront per channel)
-def test_demodulator_kernel_random_parameter_sweep(emu, monkeypatch, path):
+def test_demodulator_kernel_random_parameter_sweep(emu, monkeypatch, path, N):
     if path == "wave":
         monkeypatch.setenv("EMU_DEMOD_WAVE", "1")
     else:
@@ -983,8 +984,8 @@ def test_demodulator_kernel_random_parameter_sweep(emu, monkeypatch, path):
     AGC on and off, envelope / carrier removal, squelch variants, PLLs, tone squelch -- run for 30 blocks on the emulated kernel
     against the restated demodulators (which the same kind of sweep pins to the reference's own code)."""
     from test_oracle_vs_reference import _cmp_pcm
-    nblk, N = 30, 240
-    params, oracles, bbs, powers, ests = random_demod_channels(99, nblk, N)
+    nblk = 30
+    params, oracles, bbs, powers, ests = random_demod_channels(99, nblk, N, fs=50.0 * N)
     nch = len(params)
     chan = (_DemodChan * nch)(); state = (_DemodState * nch)(); status = (ol.LinStatus * nch)(); ext = (_DemodExt * nch)()
     emu.emu_demod_ext_init(ext, nch)
