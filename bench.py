@@ -841,7 +841,7 @@ def main():
     crt_pcie = None
     if rank == 0 and world == 1 and not args.no_crt_pcie and config == 3:
         crt_pcie = []
-        for n, dm, pipe in ((460_800, False, False), (1_105_920, True, False), (1_428_480, True, True)):
+        for n, dm, pipe in ((460_800, False, False), (1_320_960, True, False), (1_428_480, True, True)):
             try:
                 crt_pcie.append(crt_pcie_leg(pkg, wl, n, args.crt_pcie_blocks, dm, dev_index, pipe))
             except Exception as ex:

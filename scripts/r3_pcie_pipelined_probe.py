@@ -8,6 +8,7 @@ import bench
 import __graft_entry__ as ge
 pkg = ge.load()
 wl = bench.workload_for(3, 0, 1, 0)
+pipelined = os.environ.get("PROBE_SYNC") != "1"          # PROBE_SYNC=1: the block-by-block loop (H2D -> kernels -> D2H -> sync)
 for n in sys.argv[1:]:
-    r = bench.crt_pcie_leg(pkg, wl, int(float(n)), 500, True, 0, True)
+    r = bench.crt_pcie_leg(pkg, wl, int(float(n)), 500, True, 0, pipelined)
     print(json.dumps({k: r[k] for k in ("channels", "blocks", "worst_block_ms", "mean_block_ms", "sustained", "d2h_GBps", "worst_latency_ms")}))
