@@ -153,7 +153,9 @@ int chz_bank_set_active(chz_engine *e, int bank, int n);                    /* c
 /* the bank runs on the spectrum of block `job` (slot job % 4); for a bank without tuning only the slot
  * matters, so passing a slot number 0..3 is equivalent */
 int chz_bank_execute(chz_engine *e, int bank, unsigned job);
-/* the same for channels [ch0, ch0+n) only: the slow path of one retuned channel */
+/* the same for channels [ch0, ch0+n) only: the slow path of one retuned channel.  ALWAYS a partial re-run of a block the bank has
+ * already seen -- whatever the range, including a bank of exactly one channel: the bank's demodulators are not stepped and the
+ * block's PCM is left alone (only chz_bank_execute / chz_step / chz_run_blocks are "the block") */
 int chz_bank_execute_range(chz_engine *e, int bank, unsigned job, int ch0, int n);
 
 /* SURVEY 8(f) rank 1 -- the tail of radiod's downconvert() fused into the channel kernel's epilogue

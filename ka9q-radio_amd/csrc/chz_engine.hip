@@ -226,6 +226,8 @@ struct chz_engine {
   unsigned notch_tickets = 0;                           // host: tickets handed out so far
   unsigned* notch_err = nullptr;                        // pinned host word the kernel raises when a ticket wait runs out
   NotchTables notch_tab; std::vector<double> notch_alpha_h;
+  NotchOwn* notch_own = nullptr;                        // device: who stores each listed bin inside fwd_rows
+  RowsNotch notch_fold{};                               // n > 0: the list rides inside fwd_rows (short lists, directly planned masters; env CHZ_NOTCH_FOLD=0 keeps the kernel)
   std::vector<Bank> banks;
   hipGraphExec_t graph = nullptr; unsigned graph_job0 = 0; int graph_blocks = 0;
   int capture_blocks = 0;           // blocks of the capture in progress (the last one moves the ticket base on)
@@ -400,8 +402,9 @@ static void drop_graph(chz_engine* e) {
 
 static void free_notches(chz_engine* e) {
   hipFree(e->notch_addr); hipFree(e->notch_next); hipFree(e->notch_head); hipFree(e->notch_alpha); hipFree(e->notch_state); hipFree(e->notch_ver);
+  hipFree(e->notch_own); e->notch_own = nullptr;
   e->notch_addr = e->notch_next = e->notch_head = nullptr; e->notch_alpha = nullptr; e->notch_state = nullptr; e->notch_ver = nullptr;
-  e->n_notch = 0; e->notch_have = false; e->notch_tickets = 0;
+  e->n_notch = 0; e->notch_have = false; e->notch_tickets = 0; e->notch_fold = RowsNotch{};
 }
 
 void chz_engine_destroy(chz_engine* e) {
@@ -778,6 +781,34 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* tu
   c.lay = SpecLayout{p.Na, p.spec_pitch, p.spec_off}; c.ka_shift = p.ka_shift;
   c.buf = lbuf; c.spec = e->spec[slot]; c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3;
   c.padg = p.padg3; c.N = p.N; c.mirror = e->in_type == CHZ_REAL; c.tw_sub = e->tw_sub_c;
+  // K2 inside this pass (short lists ordered by the device ticket): the launch is then what has to go out in block order
+  const bool by_event = e->notch_order == 1 || (capturing && e->graph_notch_event);
+  const bool fold = e->n_notch > 0 && e->notch_fold.n > 0 && !by_event && e->notch_order != 2;
+  if (fold) {
+    if (turn) {
+      while (turn->next.load(std::memory_order_acquire) != seq) {
+        if (turn->abort.load(std::memory_order_relaxed)) return fail(-6, "another issuing thread failed");
+        __builtin_ia32_pause();
+      }
+    }
+    c.nf = e->notch_fold;
+    c.nf.state = e->notch_state; c.nf.err = e->notch_err; c.nf.max_wait = e->notch_max_wait;
+    const bool ticket = e->nlanes > 1;
+    if (ticket && capturing) {
+      c.nf.ver = e->notch_ver; c.nf.seq_base = e->notch_ver + 2; c.nf.seq = (unsigned)seq;
+      c.nf.adv = seq == e->capture_blocks - 1 ? (unsigned)e->capture_blocks : 0u;
+    } else if (ticket) { c.nf.ver = e->notch_ver; c.nf.seq = e->notch_tickets; }
+    mark(in, st, 2, true);
+    const int lr = launch_rows(p.rc, p.grid3, p.block3, p.lds3, st, c, IN_E0(in), IN_E1(in));
+    mark(in, st, 2, false);
+    if (!lr && ticket && !capturing) e->notch_tickets++;           // taken only by a launch that went out
+    if (turn) {
+      if (lr) turn->abort.store(1, std::memory_order_relaxed);
+      turn->next.store(seq + 1, std::memory_order_release);
+    }
+    if (lr) return fail(-4, "no kernel for axis c");
+    return 0;
+  }
   mark(in, st, 2, true);
   if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis c");
   mark(in, st, 2, false);
@@ -894,7 +925,7 @@ static void demod_paths(const chz_engine* e, const Bank& b, DemodParams& d) {
   const bool lin_wave = b.dm_lin > 0 && (!d.lin_lanes || (b.dm_pll_lin > 0 && d.mix == nullptr));
   d.wave_any = (fm_wave || lin_wave) ? 1 : 0;
 }
-static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch0 = 0, int n = -1) {
+static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch0 = 0, int n = -1, bool partial = false) {
   Bank& b = e->banks[(size_t)bank];
   if (n < 0) n = b.active;
   if (n <= 0 || !b.resp) return 0;
@@ -904,7 +935,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   { int r = refresh_slot(e, b, slot, st); if (r) return r; }
   // Only a launch over the WHOLE bank is "the block": a partial re-run (the drop-in's miss path re-runs single channels of a
   // block that has already been demodulated) must neither step anybody's AGC / squelch / PLL a second time nor overwrite PCM.
-  const bool whole_bank = ch0 == 0 && n == b.active;
+  const bool whole_bank = !partial && ch0 == 0 && n == b.active;      // (a range call over a one-channel bank is still a re-run: the caller says so)
   // the demodulator of the block that used this slot last (4 blocks ago) still reads the output image
   if (b.tail_used[slot] && !(in && in->on)) HIPOK(hipStreamWaitEvent(st, b.ev_tail[slot], 0));
   const size_t so = (size_t)slot * b.cap;
@@ -999,6 +1030,17 @@ int chz_set_notches_alpha(chz_engine* e, const int* bins, const double* alpha, i
   e->notch_tab = t; e->notch_alpha_h.assign(alpha, alpha + n);
   e->notch_tickets = 0;
   e->n_notch = n;
+  e->notch_fold = RowsNotch{};
+  const char* nf = getenv("CHZ_NOTCH_FOLD");
+  if (!e->blue && !(nf && nf[0] == '0') && n <= CHZ_NOTCH_INLINE) {
+    std::vector<NotchOwn> own;
+    if (rows_notch_fill(e->notch_fold, own, e->plan, e->in_type == CHZ_REAL, bins, n)) {       // false leaves n = 0: the kernel serves the list
+      HIPOK(hipMalloc((void**)&e->notch_own, sizeof(NotchOwn) * own.size()));
+      HIPOK(hipMemcpy(e->notch_own, own.data(), sizeof(NotchOwn) * own.size(), hipMemcpyHostToDevice));
+      e->notch_fold.own = e->notch_own; e->notch_fold.addr = e->notch_addr; e->notch_fold.next = e->notch_next;
+      e->notch_fold.head = e->notch_head; e->notch_fold.alpha = e->notch_alpha;
+    }
+  }
   return 0;
 }
 int chz_set_notches(chz_engine* e, const int* bins, int n, double alpha) {
@@ -1537,6 +1579,9 @@ static int read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm
   if (!b.dm_chan) return fail(-1, "bank has no demodulator: call chz_bank_set_demod first");
   static_assert(sizeof(chz_demod_status) == sizeof(DemodStatus), "status layouts must agree");
   const size_t so = (size_t)slot * b.cap + ch0, stride = (size_t)b.pcm_stride;
+  // a read of the same slot on the copy stream (chz_bank_read_pcm_flags_async) may still be travelling: this record must not hide it
+  // from the next demodulator launch and from chz_bank_pcm_wait, so the tail stream takes it in first
+  if (b.pcm_copying[slot]) HIPOK(hipStreamWaitEvent(e->tail, b.ev_pcm[slot], 0));
   if (pcm) HIPOK(hipMemcpyAsync(pcm, b.dm_pcm + so * stride, stride * (size_t)n, hipMemcpyDeviceToHost, e->tail));
   if (status) HIPOK(hipMemcpyAsync(status, b.dm_status + so, sizeof(DemodStatus) * (size_t)n, hipMemcpyDeviceToHost, e->tail));
   HIPOK(hipEventRecord(b.ev_pcm[slot], e->tail));
@@ -1591,7 +1636,7 @@ int chz_bank_execute(chz_engine* e, int bank, unsigned job) {
 int chz_bank_execute_range(chz_engine* e, int bank, unsigned job, int ch0, int n) {
   BANK_CHECK(e, bank, ch0, n);
   HIPOK(hipSetDevice(e->device));
-  int r = enqueue_bank(e, bank, job, nullptr, ch0, n);
+  int r = enqueue_bank(e, bank, job, nullptr, ch0, n, true);
   if (r) return r;
   HIPOK(hipGetLastError());
   return 0;
@@ -1792,6 +1837,10 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
     }
     for (; done < nblocks; done++) if ((rc = enqueue_step(e, job0 + (unsigned)done, &in))) return rc;
     if (!in.on && (rc = lanes_join(e, join_ev))) return rc;
+  }
+  if (e->tail && !in.on) {          // the demodulators of the last blocks belong to the run (ev_join[0] is free: lanes join from 1 up)
+    HIPOK(hipEventRecord(join_ev[0], e->tail));
+    HIPOK(hipStreamWaitEvent(s0, join_ev[0], 0));
   }
   HIPOK(hipEventRecord(t1, s0));
   const double enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();

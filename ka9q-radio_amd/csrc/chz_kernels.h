@@ -2,7 +2,8 @@
 //
 // What the reference does on CPU threads with FFTW3 (src/filter.c):
 //   K1  forward transform of the N-sample window          src/filter.c:505-508,573-582
-//   K2  spur notches on a handful of bins                  src/filter.c:464-474 (notch_fix, ordered across blocks by events)
+//   K2  spur notches on a handful of bins                  src/filter.c:464-474 (ordered across blocks by a device ticket: folded into
+//                                                            fwd_rows for the usual short lists, the notch_fix kernel otherwise)
 //   K3  per-channel bin gather x frequency response        src/filter.c:728-911
 //   K4  per-channel small backward transform, keep olen    src/filter.c:914, :357
 // is done here by four kernels.  The large transform is a three-axis Cooley-Tukey
@@ -172,6 +173,34 @@ __device__ __forceinline__ int spec_index(int na_off, unsigned magic, int dpitch
   return k + (int)__umul24(q, (unsigned)dpitch) + na_off;
 }
 
+// K2 inside fwd_rows (apply_notch_filters, src/filter.c:464-474).  Every listed bin is stored by exactly ONE thread of ONE workgroup
+// of this pass, and that thread has the bin's value in a register: the host names it (workgroup, thread, output index K2 -- notch_owner()
+// in chz_launch.h restates the kernel's own index arithmetic), the thread takes the block's ticket, runs the recurrence on its register
+// and stores the notched value.  No kernel of its own (3.6 us of queue time per block on the 4-stream trace of round 3), no second
+// trip of the bin through memory.  Ticket / tombstone / error-word semantics are those of notch_fix (below); only lists that fit the
+// kernel arguments (CHZ_NOTCH_INLINE entries: radiod's DC-only or few-spur lists) ride here, ordered by the device ticket.
+#define CHZ_NOTCH_INLINE 8
+struct NotchOwn { int wg, tid, k2, pad; };   // who stores the entry's bin: workgroup (blockIdx.x), thread, second-layer output index
+struct RowsNotch {
+  int n;                            // list entries (0: nothing folded into this launch)
+  int nwg;                          // distinct owner workgroups: the last one to finish publishes the ticket
+  int wg[CHZ_NOTCH_INLINE];         // owner workgroup per entry, in the kernel arguments (read with compile-time indices only: every
+                                    // workgroup of the pass asks "is it me?" with eight scalar compares and no memory access)
+  // the rest of the list lives in device memory, touched by the owner workgroups only
+  const NotchOwn* own;              // [n]
+  const int* addr;                  // [n] storage index of the entry's bin: checked against what the thread is about to store
+  const int* next;                  // [n] next entry naming the same bin, or -1
+  const int* head;                  // [n] 1 if the entry is the first one naming its bin
+  const double* alpha;              // [n]
+  double* state;                    // [n][2] persists across blocks
+  unsigned* ver;                    // [4] ticket counter, tombstone, graph base, owner-workgroup count of the block in progress
+  unsigned seq;                     // this block's ticket (relative to *seq_base when that is set: captured launches)
+  unsigned* seq_base;
+  unsigned adv;                     // != 0: last block of a captured sequence: moves *seq_base on
+  unsigned* err;                    // host-visible error word
+  long long max_wait;               // ticket wait budget, ticks of the constant-rate counter
+};
+
 struct RowsParams {
   const float2* buf;      // [Ra][Nb][Nc]
   float2* spec;           // out: master spectrum in SpecLayout order
@@ -183,6 +212,7 @@ struct RowsParams {
   long N;                 // full transform length
   int mirror;             // 1: real master (bins N/2+1, conj-mirror store); 0: complex master
   const float2* tw_sub;   // [R2][R1] W_Nc^(j*k1)
+  RowsNotch nf;           // K2 folded into this pass (nf.n == 0: none; the notch_fix kernel follows instead, or there is no list)
 };
 
 // One channel's gather, precomputed on the host from `shift`
@@ -481,6 +511,77 @@ __global__ void fwd_cols(ColsParams p) {
   }
 }
 
+// K2 inside fwd_rows: the thread that is about to store a listed bin takes the block's ticket and runs the reference's recurrence
+//   state += alpha * (X[bin] - state);  X[bin] -= state        (src/filter.c:464-474; state double complex, X float complex)
+// over the head entry and every entry chained behind it (the same bin named again), in list order.  A wait that runs out, a
+// tombstone left by an earlier failure, or a bin that is not the one the host named (a planner/owner mismatch: never seen, checked
+// anyway) leave the value as it is, raise the host-visible error word and set the tombstone: a wrong recurrence is never published.
+__device__ __forceinline__ float2 rows_notch_apply(const RowsNotch& nf, int e, float2 x, int at, bool stored) {
+  if (at != nf.addr[e] || !stored) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nf.ver != nullptr) __hip_atomic_store(nf.ver + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nf.err != nullptr) __hip_atomic_store(nf.err, 0x80000000u | (unsigned)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    if (nf.err != nullptr) *nf.err = 0x80000000u | (unsigned)e;
+#endif
+    return x;
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (nf.ver != nullptr) {
+    if (__hip_atomic_load(nf.ver + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return x;
+    unsigned seq = nf.seq;
+    if (nf.seq_base != nullptr) seq += __hip_atomic_load(nf.seq_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned v = 0;
+    const long long t0 = wall_clock64();
+    for (;;) {
+      v = __hip_atomic_load(nf.ver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v == seq || wall_clock64() - t0 > nf.max_wait) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (v != seq) {
+      __hip_atomic_store(nf.ver + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(nf.err, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return x;
+    }
+  }
+#endif
+  for (int q = e; q >= 0; q = nf.next[q]) {
+    double sr = nf.state[2 * q], si = nf.state[2 * q + 1];
+    const double al = nf.alpha[q];
+    double dr = al * ((double)x.x - sr), di = al * ((double)x.y - si);   // rounded products, then the sums (no fma on x86-64)
+    CHZ_ROUNDED_F64(dr); CHZ_ROUNDED_F64(di);
+    sr += dr; si += di;
+    nf.state[2 * q] = sr; nf.state[2 * q + 1] = si;
+    x = make_float2((float)((double)x.x - sr), (float)((double)x.y - si));
+  }
+  return x;
+}
+// ... and once every owner workgroup of the block is through, the last of them hands the ticket on (release: the states and the
+// notched bins of this block are visible to whoever acquires seq + 1).  Called by ALL threads of an owner workgroup.
+__device__ __forceinline__ void rows_notch_publish(const RowsNotch& nf, int tid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (nf.ver == nullptr) return;
+  __syncthreads();                                     // this workgroup's state and bin writes precede the release
+  if (tid == 0) {
+    bool last = true;
+    if (nf.nwg > 1) {
+      const unsigned c = __hip_atomic_fetch_add(nf.ver + 3, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      last = c == (unsigned)nf.nwg;
+      if (last) __hip_atomic_store(nf.ver + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (last && __hip_atomic_load(nf.ver + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      unsigned seq = nf.seq;
+      if (nf.seq_base != nullptr) seq += __hip_atomic_load(nf.seq_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (nf.adv != 0u) __hip_atomic_store(nf.seq_base, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(nf.ver, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#else
+  (void)nf; (void)tid;
+#endif
+}
+
 // ------------------------------------------------------------------------------
 // K1c: last axis.  grid = Nb * ceil(Ra/Ta); tile = Ta consecutive ka at one kb.
 // ------------------------------------------------------------------------------
@@ -497,6 +598,13 @@ __global__ void fwd_rows(RowsParams p) {
 
   const float2* __restrict__ tws = p.tw_sub;
   const float2* __restrict__ gin = p.buf + (long)kb * NC;
+  bool nf_owner = false;                           // does this workgroup store a bin of the notch list?  (scalar compares on kernel arguments)
+  static_for<CHZ_NOTCH_INLINE>([&](auto ee) { constexpr int E = decltype(ee)::value; nf_owner = nf_owner || (E < p.nf.n && p.nf.wg[E] == (int)blockIdx.x); });
+  unsigned nf_mask = 0;                            // ... and which of this thread's second-layer outputs, if any (at most one: rows_notch_fill)
+  float2 nf_x = make_float2(0.f, 0.f); int nf_at = -1; bool nf_ok = false;
+  if (nf_owner)
+    for (int e = 0; e < p.nf.n; e++)
+      if (p.nf.head[e] != 0 && p.nf.own[e].wg == (int)blockIdx.x && p.nf.own[e].tid == tid) nf_mask |= 1u << p.nf.own[e].k2;
   if constexpr (R2 % 16 == 0) {
     // The first layer takes its points straight from global memory: with the lanes running along nc (j1 fastest),
     // the R2 lanes of one row read R2 consecutive complex values = whole 128-byte lines per load instruction, and
@@ -597,10 +705,21 @@ __global__ void fwd_rows(RowsParams p) {
         const int at = direct ? d0 + K2 * ds : m0 - K2 * ds;
         float2 x = u[K2];
         if (!direct) x.y = -x.y;
+        if (nf_mask >> K2 & 1u) { nf_x = x; nf_at = at; nf_ok = direct || !selfconj; }   // a listed bin: remember what goes where (one thread of the pass, as a rule)
         CHZ_STORE_IF(sdesc, sp, at, x, direct || !selfconj);
       });
+      // K2: the listed bin is stored once more, notched (same lane, same address, program order; nobody reads the slot before the
+      // kernel ends).  Done here, behind the store loop, so that the rare path does not cost the common one any registers.
+      if (nf_mask != 0u) {
+        for (int e = 0; e < p.nf.n; e++)
+          if (p.nf.head[e] != 0 && p.nf.own[e].wg == (int)blockIdx.x && p.nf.own[e].tid == tid) {
+            const float2 y = rows_notch_apply(p.nf, e, nf_x, nf_at, nf_ok);
+            CHZ_STORE_IF(sdesc, sp, nf_at, y, nf_ok);
+          }
+      }
     }
   }
+  if (nf_owner) rows_notch_publish(p.nf, tid);
 }
 
 // ------------------------------------------------------------------------------
@@ -619,7 +738,6 @@ __global__ void fwd_rows(RowsParams p) {
 // same lane in list order, exactly as the reference's sequential walk does.  Lists of up to CHZ_NOTCH_INLINE
 // entries (radiod's usual DC-only or few-spur lists) travel in the kernel arguments: no dependent table loads.
 // ------------------------------------------------------------------------------
-#define CHZ_NOTCH_INLINE 8
 struct NotchFixParams {
   float2* spec;           // this block's spectrum slot (SpecLayout order)
   const int* addr;        // [n] storage index of the entry's bin

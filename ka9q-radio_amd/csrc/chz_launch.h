@@ -124,6 +124,43 @@ inline NotchTables notch_tables(const int* bins, int n, const SpecLayout& lay) {
   }
   return t;
 }
+// K2 folded into fwd_rows: which thread of which workgroup stores listed bin `bin`, and as which second-layer output.  Restates the
+// pass's own index arithmetic (fwd_rows in chz_kernels.h): workgroup = at * Nb + kb holds ka in [at*Ta - ka_shift, ...) at one kb,
+// thread = k1 * Ta + r stores bins ka + Na * (kb + Nb * (k1 + R1 * K2)); for a real master the rows ka > Na/2 are never computed:
+// those bins leave as the conjugate mirror image of bin N - k, written by the thread that holds row Na - ka, column xrows - 1 - x.
+// Returns false for a bin nobody stores (cannot happen for bin < bins); the kernel checks the storage index again before it acts.
+inline bool notch_owner(const FwdPlan& p, bool real, int bin, int* wg, int* tid, int* k2) {
+  const int R1 = p.rc.r1, R2 = p.rc.r2;
+  const long xrows = (long)p.Nb * p.Nc;
+  long ka = bin % p.Na, x = bin / p.Na;
+  if (real && ka >= p.Ra) { ka = p.Na - ka; x = xrows - 1 - x; }        // the mirror image's owner
+  if (ka < 0 || ka >= p.Ra || x < 0 || x >= xrows) return false;
+  const long kb = x % p.Nb, kc = x / p.Nb;
+  const long k1 = kc % R1, K2 = kc / R1;
+  if (K2 >= R2) return false;
+  const long at = (ka + p.ka_shift) / p.Ta, r = (ka + p.ka_shift) % p.Ta;
+  *wg = (int)(at * p.Nb + kb); *tid = (int)(k1 * p.Ta + r); *k2 = (int)K2;
+  return *wg < p.grid3 && *tid < p.block3;
+}
+// the pass's notch block for the engine's list (n <= CHZ_NOTCH_INLINE entries): owner workgroups into the kernel arguments, the
+// per-entry owner records into `own` (uploaded by the caller); false: some bin has no owner (the notch_fix kernel keeps the list)
+inline bool rows_notch_fill(RowsNotch& nf, std::vector<NotchOwn>& own, const FwdPlan& p, bool real, const int* bins, int n) {
+  nf = RowsNotch{}; own.clear();
+  if (n < 1 || n > CHZ_NOTCH_INLINE) return false;
+  for (int i = 0; i < n; i++) {
+    int wg = 0, tid = 0, k2 = 0;
+    if (!notch_owner(p, real, bins[i], &wg, &tid, &k2) || k2 > 31) { nf = RowsNotch{}; own.clear(); return false; }
+    // one thread remembers ONE listed bin: two different bins stored by the same thread (Na*Nb*R1 bins apart) keep the kernel
+    for (int j = 0; j < i; j++) if (bins[j] != bins[i] && own[(size_t)j].wg == wg && own[(size_t)j].tid == tid) { nf = RowsNotch{}; own.clear(); return false; }
+    nf.wg[i] = wg;
+    own.push_back(NotchOwn{wg, tid, k2, 0});
+    bool seen = false;
+    for (int j = 0; j < i; j++) seen = seen || nf.wg[j] == wg;
+    if (!seen) nf.nwg++;
+  }
+  nf.n = n;
+  return true;
+}
 inline int launch_demod(hipStream_t s, const DemodParams& p_in, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   if (p_in.nch <= 0) return 0;
   DemodParams p = p_in;

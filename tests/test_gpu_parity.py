@@ -570,6 +570,77 @@ def test_notch_recurrence_is_ordered_across_streams(pkg):
     assert rel(got, want) <= SPEC_REL
 
 
+@pytest.mark.parametrize("in_type,L,M,plan", [(ol.REAL, 25920, 6481, ""), (ol.REAL, 11520, 2881, "16x25x36"), (ol.REAL, 25920, 6481, "225x144"),
+                                              (ol.COMPLEX, 11520, 2881, "16x25x36"), (ol.COMPLEX, 48000, 12001, "")])
+def test_notch_folded_into_the_last_pass(pkg, monkeypatch, in_type, L, M, plan):
+    """Round 4: lists of up to 8 entries are applied INSIDE fwd_rows by the thread that stores the listed bin (no notch_fix launch);
+    the host names that thread by restating the pass's index arithmetic (notch_owner, chz_launch.h).  Bins served by direct and by
+    conjugate-mirrored stores, the first and last bin, a bin named twice, two- and three-axis plans, REAL and COMPLEX masters:
+    identical to the separate kernel (CHZ_NOTCH_FOLD=0), equal to the reference's recurrence, and really folded (no fix launches)."""
+    N = L + M - 1
+    B = N // 2 + 1 if in_type == ol.REAL else N
+    # (a thread of the pass remembers ONE listed bin: DC together with the last bin can land on one thread -- such a list keeps the
+    #  notch_fix kernel, test_notch_list_that_cannot_be_folded_keeps_the_kernel)
+    bins = [125, B - 40, B // 2 + 17, 7, 125, B - 33, 1, 0]
+    rng = np.random.default_rng(L + in_type)
+    nblk = 22
+    if in_type == ol.REAL:
+        ring = (rng.standard_normal(8 * L) + 0.4).astype(np.float32)
+    else:
+        ring = (rng.standard_normal(8 * L) + 1j * rng.standard_normal(8 * L) + 0.4).astype(np.complex64)
+    got = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("CHZ_NOTCH_FOLD", fold)
+        eng = pkg.engine.Engine(L, M, in_type, plan=plan, ring_blocks=8)
+        try:
+            eng.set_notches(bins, 0.05)
+            eng.write(ring[:8 * L - (M - 1)]); eng.write(ring[8 * L - (M - 1):])
+            eng.run_blocks(0, nblk)
+            got[fold] = eng.spectrum((nblk - 1) % 4)
+            it = eng.run_blocks(nblk, 4, instrument=True)
+            assert it.rows_n == 4 and it.fix_n == (0 if fold == "1" else 4), (fold, it.fix_n)
+            eng.check()
+        finally:
+            eng.close()
+    assert np.array_equal(got["1"], got["0"])
+    st = ol.Stream(L, M, in_type)
+    st.push(ring[7 * L:8 * L])
+    state = np.zeros(2 * len(bins))
+    for j in range(nblk):
+        want = st.push(ring[(j % 8) * L:(j % 8 + 1) * L])
+        ol.notch(state, bins, 0.05, want)
+    for b in bins:
+        assert abs(got["1"][b] - want[b]) <= 5e-6 * abs(want[b]) + 5e-3, b
+    assert rel(got["1"], want) <= SPEC_REL
+
+
+def test_notch_list_that_cannot_be_folded_keeps_the_kernel(pkg):
+    # DC and the Nyquist bin of N = 32400 = 135 x 240 are stored by the same thread of fwd_rows (ka = 0, k1 = 0): the list stays with notch_fix
+    L, M = 25920, 6481
+    B = (L + M - 1) // 2 + 1
+    bins = [B - 1, 0]
+    rng = np.random.default_rng(9)
+    ring = (rng.standard_normal(8 * L) + 0.4).astype(np.float32)
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    try:
+        eng.set_notches(bins, 0.05)
+        eng.write(ring[:8 * L - (M - 1)]); eng.write(ring[8 * L - (M - 1):])
+        eng.run_blocks(0, 9)
+        got = eng.spectrum(0)
+        it = eng.run_blocks(9, 4, instrument=True)
+        assert it.fix_n == 4
+    finally:
+        eng.close()
+    st = ol.Stream(L, M, ol.REAL)
+    st.push(ring[7 * L:8 * L])
+    state = np.zeros(2 * len(bins))
+    for j in range(9):
+        want = st.push(ring[(j % 8) * L:(j % 8 + 1) * L])
+        ol.notch(state, bins, 0.05, want)
+    for b in bins:
+        assert abs(got[b] - want[b]) <= 5e-6 * abs(want[b]) + 5e-3, b
+
+
 def test_run_blocks_graph_equals_eager(pkg):
     # the hipGraph replay of a ring cycle must produce exactly what eager launches produce
     L, M = 25920, 6481

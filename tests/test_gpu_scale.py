@@ -1,0 +1,159 @@
+"""GPU parity at the bank sizes where the engine's size-selected code paths are the DEFAULT (no environment forcing).
+
+Round 3's review: demod_lin_lanes / demod_fm_lanes / pll_lanes serve banks of >= 65,536 channels, noise_est reads the |X|^2
+image and chan_ifft stages its stores from 16,384 -- and every oracle comparison of those paths forced them onto banks of a few
+channels.  Here one bank of 70,001 channels (not a multiple of 64, 12, 4 or 3) per demodulator family runs 12 blocks, four at
+a time pipelined over the engine's 4 HIP streams, and 200+ channels sampled across the bank (first, last, workgroup edges, the
+partially filled last groups, random) are compared with the oracle stage by stage:
+  chan_ifft + downconvert() tail   ol.channel + ol.Downconv on the device's own block spectrum     src/filter.c:663-921, src/radio.c:1476-1520
+  noise_est (energy image)         ol.estimate_noise, 1e-12                                       src/radio.c:1783-1866
+  demodulators, lane per channel   ol.LinDemod / ol.FmDemod fed what the device stage was fed     src/linear.c:56-375, src/fm.c:19-345
+then a second engine runs the same 12 blocks in ONE pipelined call and must leave the same PCM and status in every slot for
+EVERY channel of the bank.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import scale_check as sc
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+L, M, FS_IN = 25920, 6481, 1.296e6
+N = L + M - 1
+NCH = 70001
+NBLK = 12
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    p = load_pkg()
+    if p.engine.lib().chz_device_count() < 1:
+        pytest.fail("no HIP device visible: GPU tests cannot run (there is no CPU fallback)")
+    ol.build()
+    return p
+
+
+@pytest.fixture(autouse=True)
+def default_dispatch(monkeypatch):
+    for v in ("CHZ_DEMOD_WAVE", "CHZ_NOISE_ENERGY", "CHZ_CHAN_STAGE", "CHZ_PLL_LANE0", "CHZ_STREAMS", "CHZ_ENQ_THREADS"):
+        monkeypatch.delenv(v, raising=False)
+
+
+def _comb_ring(spacing_bins, ncar, kind, seed):
+    """8 blocks of input, periodic over the ring (every frequency is a multiple of 1/(8L) cycles per sample, so the cyclic
+    replay has no seam): carriers `spacing_bins` apart, every one with its own level, + white noise.
+      am   amplitude-modulated carriers with per-block level steps (walks the AGC branches)
+      cw   steady carriers with a little AM: something for the PLLs to hold on to
+      fm   frequency-modulated carriers (1 kHz tone, 3 kHz deviation), some fading in and out through the squelch"""
+    rng = np.random.default_rng(seed)
+    n = 8 * L
+    t = np.arange(n)
+    per_bin = n / N                                        # ring-periodic cycles per master bin: 6.4
+    x = 1e-4 * rng.standard_normal(n)
+    blk = t // L
+    for c in range(ncar):
+        k = int(round((spacing_bins * (c + 1) + 0.3) * per_bin))
+        f = k / n
+        a = 0.004 * (1 + c % 5)
+        if kind == "am":
+            steps = np.array([0.02, 0.02, 1.0, 1.0, 8.0 if c % 2 else 1.0, 1.0, 0.1, 0.1])[blk]
+            x += a * steps * (1 + 0.5 * np.sin(2 * np.pi * (66 + c) / n * t)) * np.cos(2 * np.pi * f * t + c)
+        elif kind == "cw":
+            x += a * (1 + 0.3 * np.sin(2 * np.pi * (64 + c) / n * t)) * np.cos(2 * np.pi * f * t + c)
+        else:
+            lvl = np.ones(n)
+            if c % 3 == 1:
+                lvl = np.array([0.0, 0.0, 1.0, 1.0, 1.0, 0.3, 0.02, 0.0])[blk]
+            x += 2 * a * lvl * np.cos(2 * np.pi * f * t - 3.0 * np.cos(2 * np.pi * 160 / n * t))
+    return x.astype(np.float32)
+
+
+def _bank_plan(spacing_bins, ncar, fs_out):
+    """channel i listens next to carrier i % ncar, a bin or two off, with its own fine-tuning remainder"""
+    hz = FS_IN / N
+    f_hz = np.array([(spacing_bins * (1 + i % ncar) + (i % 3) - 1) * hz + 3.7 + 0.013 * (i % 997) for i in range(NCH)])
+    shifts = np.zeros(NCH, np.int32); rems = np.zeros(NCH)
+    for i in range(NCH):
+        _, shifts[i], rems[i] = ol.compute_tuning(N, FS_IN, float(f_hz[i]))
+    return shifts, rems
+
+
+def _setup(pkg, ring, P, olen, fs_out, shifts, rems, kinds, params, stride):
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    eng.write(ring[:8 * L - (M - 1)]); eng.write(ring[8 * L - (M - 1):])
+    bank = eng.bank(P, olen, NCH)
+    resp = np.stack([pkg.filterapi.design_response(P, olen, N, True, lo, hi, 11.0) for lo, hi in kinds])
+    bank.set_responses(0, resp[np.arange(NCH) % len(kinds)])
+    bank.set_tuning(0, 0, shifts, -rems / fs_out)
+    bank.set_active(NCH)
+    bank.enable_noise(FS_IN)
+    bank.set_pcm_stride(stride)
+    dp = [pkg.engine.DemodParams(*[getattr(p, f) for f, _ in ol.LinParams._fields_]) for p in params]
+    for c0 in range(0, NCH, 16384):
+        bank.set_demod(0, c0, [dp[i % len(dp)] for i in range(c0, min(NCH, c0 + 16384))], 0.02)
+    eng.set_notches([0], 0.01)
+    return eng, bank, resp
+
+
+def _run_family(pkg, kind, P, olen, fs_out, spacing, ncar, kinds, params, stride, strict_pll=True):
+    ring = _comb_ring(spacing, ncar, kind, seed=P + ncar)
+    shifts, rems = _bank_plan(spacing, ncar, fs_out)
+    chans = sc.sample_channels(NCH, 208, seed=5)
+    assert len(chans) >= 200 and chans[0] == 0 and chans[-1] == NCH - 1
+    eng, bank, resp = _setup(pkg, ring, P, olen, fs_out, shifts, rems, kinds, params, stride)
+    chk = sc.ChainChecker(L, M, FS_IN, fs_out, P, olen, chans, shifts[chans], rems[chans], lambda c: resp[c % len(kinds)],
+                          [params[c % len(params)] for c in chans], strict_pll=strict_pll)
+    last = {}
+    try:
+        assert eng.lanes == 4
+        for g in range(NBLK // 4):
+            eng.run_blocks(4 * g, 4)                                   # four blocks in flight on four streams, two issuing threads
+            for s in range(4):
+                spec = eng.spectrum(s)
+                out = bank.read_slot(s); power = bank.read_power(s); noise = bank.read_noise(s)
+                pcm, status = bank.read_pcm(s)
+                chk.block(spec, {c: out[c] for c in chans}, {c: power[c] for c in chans}, {c: noise[c] for c in chans},
+                          {c: pcm[c] for c in chans}, {c: status[c] for c in chans})
+                if g == NBLK // 4 - 1:
+                    last[s] = (pcm.copy(), np.frombuffer(bytes(status), np.uint8).copy())
+    finally:
+        eng.close()
+    r = chk.result()
+    assert r["failed"] == [] and r["status_mismatches"] == 0 and r["pcm_mismatches"] == 0, r
+    assert r["max_rel_err"] < 2e-5 and r["noise_max_rel_err"] <= 1e-12, r
+    assert r["data_frames"] > len(chans) * NBLK // 3, r                   # the comparison was not vacuous (muted / silent frames)
+    # the same 12 blocks in ONE pipelined call: every channel of the bank, not just the sample
+    eng2, bank2, _ = _setup(pkg, ring, P, olen, fs_out, shifts, rems, kinds, params, stride)
+    try:
+        eng2.run_blocks(0, NBLK)
+        for s in range(4):
+            pcm, status = bank2.read_pcm(s)
+            st_bytes = np.frombuffer(bytes(status), np.uint8)
+            assert np.array_equal(pcm, last[s][0]), "PCM of slot %d differs between 3 x 4 and 1 x 12 pipelined blocks" % s
+            assert np.array_equal(st_bytes, last[s][1]), "status records of slot %d differ" % s
+    finally:
+        eng2.close()
+    return r
+
+
+def test_linear_bank_of_70001_channels_default_dispatch(pkg):
+    from test_kernels_emulated import DEMOD_CASES
+    params = [ol.lin_params(**kw) for kw in DEMOD_CASES]
+    kinds = [(-0.24, 0.24), (50 / 12000, 3000 / 12000), (-200 / 12000, 200 / 12000), (-5000 / 12000, 5000 / 12000), (-0.12, 0.12)]
+    _run_family(pkg, "am", 300, 240, 12000.0, 300, 50, kinds, params, 8 * 240)
+
+
+def test_coherent_bank_of_70001_channels_default_dispatch(pkg):
+    from test_kernels_emulated import PLL_CASES
+    params = [ol.lin_params(**kw) for kw in PLL_CASES]
+    kinds = [(-2950 / 12000.0, 2950 / 12000.0), (-0.2, 0.2)]
+    _run_family(pkg, "cw", 300, 240, 12000.0, 300, 50, kinds, params, 8 * 240)
+
+
+def test_fm_bank_of_70001_channels_default_dispatch(pkg):
+    from test_kernels_emulated import FM_CASES
+    params = [ol.fm_params(**kw) for kw in FM_CASES]
+    kinds = [(-8000 / 24000.0, 8000 / 24000.0), (-6000 / 24000.0, 6000 / 24000.0)]
+    _run_family(pkg, "fm", 600, 480, 24000.0, 600, 25, kinds, params, 4 * 480)
