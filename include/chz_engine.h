@@ -92,6 +92,21 @@ int chz_input_write_i16_device(chz_engine *e, const short *dev_samples, long n, 
 int chz_input_stats(chz_engine *e, int slot, unsigned long long *energy, unsigned *clips);
 /* direct access to the device ring for HBM-resident benchmarks */
 int chz_input_ring(chz_engine *e, float **dev_ring, long *ring_len_floats);
+/* Re-seat the input ring in front of block `job`: the next L samples written are that block's new samples and `history`
+ * (M-1 samples from host memory; NULL = zeros, the state create_filter_input leaves, src/filter.c:244,259) is what came
+ * before them.  A freshly created engine sits in front of job 0; a host that REPLACES an engine in mid-stream (the drop-in's
+ * recovery from a failed device-side check: the reference exits and lets systemd restart it, src/radio.c:398, src/main.c:202)
+ * continues its job numbering and its overlap history with this.  Drains the engine.  Float input only. */
+int chz_input_seek(chz_engine *e, unsigned job, const float *history);
+/* Fences for a producer that does not wait for blocks (the drop-in's KA9Q_HIP_INPUT_FULL=drop): chz_input_mark(e, k) records
+ * marker k (0..7) behind everything chz_input_write has enqueued so far, chz_input_mark_wait(e, k) blocks until the copies in
+ * front of marker k have read their host source (so that the host ring region may be overwritten); a marker never recorded
+ * is complete. */
+int chz_input_mark(chz_engine *e, int k);
+int chz_input_mark_wait(chz_engine *e, int k);
+/* by_event != 0: order the spur-notch recurrence by HIP events between the streams instead of the device ticket (what env
+ * CHZ_NOTCH_ORDER=event selects at creation): no device-side wait that could run out.  Drains the engine. */
+int chz_engine_notch_order(chz_engine *e, int by_event);
 
 /* replaces the body of execute_filter_input / run_fft (src/filter.c:485-651):
  * forward transform of the window of job `job` (window start = job*L in ring
@@ -239,7 +254,9 @@ int chz_spectrum_broadcast(chz_engine *e, chz_comm *c, int slot, int root);
  * one grouped ncclSend/ncclRecv */
 int chz_spectrum_exchange_rows(chz_engine *e, chz_comm *c, int slot, int root, const int *row_lo, const int *row_hi);
 /* BASELINE config 4 from a C host: per block the root transforms, the spectrum travels (mode 0 broadcast, 1 rows),
- * every rank runs its own banks; timed like chz_run_blocks */
+ * every rank runs its own banks; timed like chz_run_blocks.  mode 2 (SURVEY 8e's alternative): the block's L new samples
+ * travel from the root's input ring into every rank's ring (ncclBroadcast on the communicator's own stream: 10.4 MB instead of
+ * the 13.8 MB slot at 129.6 MS/s) and every rank runs the forward transform itself -- nobody waits for the root's transform */
 int chz_run_blocks_sharded(chz_engine *e, chz_comm *c, int root, int mode, const int *row_lo, const int *row_hi,
                            unsigned job0, int nblocks, chz_timing *timing);
 

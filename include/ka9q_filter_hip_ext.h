@@ -24,6 +24,12 @@ double filter_hip_noise(struct filter_out const *slave);
 int filter_hip_drain(struct filter_in *master);
 /* blocks skipped by the front end because the device was ND blocks behind (only with KA9Q_HIP_INPUT_FULL=drop) */
 unsigned long filter_hip_skipped_blocks(struct filter_in const *master);
+/* Failure policy.  A failed device-side check or a HIP error while a block is being enqueued makes the drop-in replace its engine
+   ONCE (every registered slave's response, shift, ISB / beam state, the notch list and the overlap history are carried over; the
+   blocks lost on the way are zeros + block_drops for every slave, like a lapped block, /root/reference/src/filter.c:690-701); a second
+   failure within 500 blocks, or a re-creation that fails, ends the process with EX_SOFTWARE so that the supervisor restarts it, which
+   is what the reference does on a fatal error (/root/reference/src/radio.c:398, src/main.c:202).  Returns the number of recoveries so far. */
+unsigned filter_hip_recoveries(struct filter_in const *master, unsigned *blocks_lost);
 #ifdef __cplusplus
 }
 #endif

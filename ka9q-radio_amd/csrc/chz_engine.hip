@@ -192,6 +192,8 @@ struct chz_engine {
   hipStream_t pcmcopy = nullptr;
   Lane lanes[CHZ_MAX_LANES];
   int nlanes = 1;
+#define CHZ_INPUT_MARKS 8
+  hipEvent_t input_mark[CHZ_INPUT_MARKS] = {};   // chz_input_mark / chz_input_mark_wait
   hipEvent_t input_ready = nullptr; // after the latest ring write
   bool input_pending = false;
   float* ring = nullptr; long ring_len = 0;   // floats
@@ -422,6 +424,7 @@ void chz_engine_destroy(chz_engine* e) {
     if (i > 0 && e->lanes[i].s) hipStreamDestroy(e->lanes[i].s);
   }
   if (e->input_ready) hipEventDestroy(e->input_ready);
+  for (auto ev : e->input_mark) if (ev) hipEventDestroy(ev);
   if (e->ev_t0) hipEventDestroy(e->ev_t0);
   if (e->ev_t1) hipEventDestroy(e->ev_t1);
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
@@ -566,6 +569,44 @@ int chz_input_stats(chz_engine* e, int slot, unsigned long long* energy, unsigne
   for (size_t i = 0; i < en.size(); i++) { se += en[i]; sc += cl[i]; }
   if (energy) *energy = se;
   if (clips) *clips = sc;
+  return 0;
+}
+int chz_input_seek(chz_engine* e, unsigned job, const float* history) {
+  if (!e) return fail(-1, "null engine");
+  if (e->ring16) return fail(-1, "chz_input_seek re-seats a float ring (this engine takes int16 input)");
+  HIPOK(hipSetDevice(e->device));
+  { int r = sync_all(e); if (r) return r; }
+  const long start = (long)(((unsigned long long)job * (unsigned long long)e->L) % (unsigned long long)((long)e->ring_blocks * e->L)) * e->per;
+  const long nh = (long)(e->M - 1) * e->per;                      // floats of history in front of the block's new samples
+  e->wpos = start;
+  if (history) { int r = ring_write(e, history, e->M - 1, hipMemcpyHostToDevice); if (r) return r; }
+  else {
+    const long first = (start + nh <= e->ring_len) ? nh : e->ring_len - start;
+    if (first > 0) HIPOK(hipMemsetAsync(e->ring + start, 0, sizeof(float) * (size_t)first, e->stream));
+    if (nh > first) HIPOK(hipMemsetAsync(e->ring, 0, sizeof(float) * (size_t)(nh - first), e->stream));
+    e->wpos = (start + nh) % e->ring_len;
+  }
+  HIPOK(hipStreamSynchronize(e->stream));                          // the caller's history buffer is free again
+  e->input_pending = false;
+  return 0;
+}
+int chz_input_mark(chz_engine* e, int k) {
+  if (!e || k < 0 || k >= CHZ_INPUT_MARKS) return fail(-1, "bad argument");
+  if (!e->input_mark[k]) HIPOK(hipEventCreateWithFlags(&e->input_mark[k], hipEventDisableTiming));
+  HIPOK(hipEventRecord(e->input_mark[k], e->stream));
+  return 0;
+}
+int chz_input_mark_wait(chz_engine* e, int k) {
+  if (!e || k < 0 || k >= CHZ_INPUT_MARKS) return fail(-1, "bad argument");
+  if (e->input_mark[k]) HIPOK(hipEventSynchronize(e->input_mark[k]));
+  return 0;
+}
+int chz_engine_notch_order(chz_engine* e, int by_event) {
+  if (!e) return fail(-1, "null engine");
+  { int r = sync_all(e); if (r) return r; }
+  drop_graph(e);
+  e->notch_order = by_event ? 1 : 0;
+  e->notch_have = false;
   return 0;
 }
 int chz_input_ring(chz_engine* e, float** dev_ring, long* ring_len_floats) {

@@ -516,8 +516,8 @@ __global__ void fwd_cols(ColsParams p) {
 // over the head entry and every entry chained behind it (the same bin named again), in list order.  A wait that runs out, a
 // tombstone left by an earlier failure, or a bin that is not the one the host named (a planner/owner mismatch: never seen, checked
 // anyway) leave the value as it is, raise the host-visible error word and set the tombstone: a wrong recurrence is never published.
-__device__ __forceinline__ float2 rows_notch_apply(const RowsNotch& nf, int e, float2 x, int at, bool stored) {
-  if (at != nf.addr[e] || !stored) {
+__device__ __forceinline__ float2 rows_notch_apply(const RowsNotch& nf, int e, int addr_e, double alpha_e, float2 x, int at, bool stored) {
+  if (at != addr_e || !stored) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (nf.ver != nullptr) __hip_atomic_store(nf.ver + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (nf.err != nullptr) __hip_atomic_store(nf.err, 0x80000000u | (unsigned)e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -548,13 +548,16 @@ __device__ __forceinline__ float2 rows_notch_apply(const RowsNotch& nf, int e, f
 #endif
   for (int q = e; q >= 0; q = nf.next[q]) {
     double sr = nf.state[2 * q], si = nf.state[2 * q + 1];
-    const double al = nf.alpha[q];
+    const double al = q == e ? alpha_e : nf.alpha[q];
     double dr = al * ((double)x.x - sr), di = al * ((double)x.y - si);   // rounded products, then the sums (no fma on x86-64)
     CHZ_ROUNDED_F64(dr); CHZ_ROUNDED_F64(di);
     sr += dr; si += di;
     nf.state[2 * q] = sr; nf.state[2 * q + 1] = si;
     x = make_float2((float)((double)x.x - sr), (float)((double)x.y - si));
   }
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the state stores have left this wave before the workgroup's barrier: the publisher's write-back covers them
+#endif
   return x;
 }
 // ... and once every owner workgroup of the block is through, the last of them hands the ticket on (release: the states and the
@@ -574,7 +577,12 @@ __device__ __forceinline__ void rows_notch_publish(const RowsNotch& nf, int tid)
       unsigned seq = nf.seq;
       if (nf.seq_base != nullptr) seq += __hip_atomic_load(nf.seq_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (nf.adv != 0u) __hip_atomic_store(nf.seq_base, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(nf.ver, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      // release, spelled out: the fence writes the XCD's dirty lines back (the states; the bins went out write-through), the explicit
+      // wait keeps the ticket from overtaking that write-back (ROCm 7.2 drops the wait behind buffer_wbl2 when it believes this wave's
+      // memory counter is empty -- it is, the stores were another wave's: MI355X_MICROARCH.md, "compiler hazard"), then a relaxed store
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(nf.ver, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 #else
@@ -602,9 +610,12 @@ __global__ void fwd_rows(RowsParams p) {
   static_for<CHZ_NOTCH_INLINE>([&](auto ee) { constexpr int E = decltype(ee)::value; nf_owner = nf_owner || (E < p.nf.n && p.nf.wg[E] == (int)blockIdx.x); });
   unsigned nf_mask = 0;                            // ... and which of this thread's second-layer outputs, if any (at most one: rows_notch_fill)
   float2 nf_x = make_float2(0.f, 0.f); int nf_at = -1; bool nf_ok = false;
+  int nf_e = -1, nf_addr = -1; double nf_alpha = 0.0;     // the entry, fetched now: only the ticket and the state are left for the tail
   if (nf_owner)
     for (int e = 0; e < p.nf.n; e++)
-      if (p.nf.head[e] != 0 && p.nf.own[e].wg == (int)blockIdx.x && p.nf.own[e].tid == tid) nf_mask |= 1u << p.nf.own[e].k2;
+      if (p.nf.head[e] != 0 && p.nf.own[e].wg == (int)blockIdx.x && p.nf.own[e].tid == tid) {
+        nf_mask |= 1u << p.nf.own[e].k2; nf_e = e; nf_addr = p.nf.addr[e]; nf_alpha = p.nf.alpha[e];
+      }
   if constexpr (R2 % 16 == 0) {
     // The first layer takes its points straight from global memory: with the lanes running along nc (j1 fastest),
     // the R2 lanes of one row read R2 consecutive complex values = whole 128-byte lines per load instruction, and
@@ -711,11 +722,8 @@ __global__ void fwd_rows(RowsParams p) {
       // K2: the listed bin is stored once more, notched (same lane, same address, program order; nobody reads the slot before the
       // kernel ends).  Done here, behind the store loop, so that the rare path does not cost the common one any registers.
       if (nf_mask != 0u) {
-        for (int e = 0; e < p.nf.n; e++)
-          if (p.nf.head[e] != 0 && p.nf.own[e].wg == (int)blockIdx.x && p.nf.own[e].tid == tid) {
-            const float2 y = rows_notch_apply(p.nf, e, nf_x, nf_at, nf_ok);
-            CHZ_STORE_IF(sdesc, sp, nf_at, y, nf_ok);
-          }
+        const float2 y = rows_notch_apply(p.nf, nf_e, nf_addr, nf_alpha, nf_x, nf_at, nf_ok);
+        CHZ_STORE_IF(sdesc, sp, nf_at, y, nf_ok);
       }
     }
   }
@@ -814,7 +822,9 @@ __global__ void __launch_bounds__(1024) notch_fix(NotchFixParams p) {
     __syncthreads();                                     // every lane's state and bin writes precede the release
     if (i == 0) {
       if (p.adv != 0u) __hip_atomic_store(p.seq_base, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the last block's ticket + 1 = base + blocks per replay
-      __hip_atomic_store(p.ver, seq + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // (spelled out as in rows_notch_publish: the wait must not be optimised away)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(p.ver, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 #endif

@@ -35,6 +35,7 @@
 #include <errno.h>
 #include <sys/mman.h>
 #include <sys/syscall.h>
+#include <sysexits.h>
 #include <linux/futex.h>
 #include "../../include/ka9q_filter_abi.h"
 #include "../../include/chz_engine.h"
@@ -116,7 +117,19 @@ struct mctx {
      completion record, spectrum, staged outputs and host-ring window belong to the enqueued job until the two agree. */
   unsigned enq_seq[ND];             /* blocks enqueued in the slot so far (producer only) */
   unsigned dev_seq[ND];             /* of which the completion callback has run (futex word the producer sleeps on) */
-  unsigned long n_skipped;
+  unsigned long n_skipped;          /* written under `lock`, read from other threads: atomic accesses */
+  int consecutive_skips;            /* drop mode: skips in a row (bounded: the device ring holds 8 blocks, see execute_filter_input) */
+  /* Failure policy (round 4).  The reference has none of its own -- a radiod whose front end or FFT dies exits and systemd
+     restarts it (src/radio.c:398, src/main.c:202).  Here a failed device-side check (chz_engine_check: a notch ticket that ran
+     out) or a HIP error while a block is being enqueued means the engine is gone: the blocks it still delivers are dropped
+     (zeros + block_drops for every slave, as for a lapped block, src/filter.c:690-701), the engine is re-created ONCE with
+     everything the slaves have registered (responses, shifts, ISB, beam weights, notch list, noise estimate) and the overlap
+     history re-seated from the host ring, and the stream continues.  A second failure within RECOVERY_GRACE blocks of a
+     recovery, or a re-creation that fails, ends the process with EX_SOFTWARE, like the reference, so the supervisor restarts it. */
+#define RECOVERY_GRACE 500
+  bool failed;                      /* set by the completion callback / the producer when the engine reports a failure (atomic) */
+  unsigned recoveries, failed_blocks;
+  unsigned last_recovery_job;
   double noise_samprate;            /* > 0: banks run the device's estimate_noise() (filter_hip_enable_noise) */
   /* wake-up of the channel threads: the completion callback wakes wake_first of them (0 = all), every woken thread wakes
      wake_fan more (KA9Q_HIP_WAKE="first,fan"; default "0,2") */
@@ -125,6 +138,9 @@ struct mctx {
   bool profile;
   struct timespec t_done[ND];       /* when the slot's completion callback ran */
   unsigned long long prof_blocks, prof_input_ns, prof_wait_ns, prof_consume_sum_ns, prof_consume_n, prof_consume_max_ns, prof_hits, prof_misses, prof_dev_max_ns;
+  unsigned long long prof_consume_max8_ns;   /* the same worst case over blocks 8.. only (the first blocks carry one-time costs: first touch of every
+                                                slave's buffers, thread start-up, the runtime's first launches) */
+  unsigned t_done_job[ND];
   /* channels whose staged result does not fit (retuned, new filter, just created) are re-run in batches: the first
      thread to miss becomes the leader and serves everybody who queued up meanwhile with one device round trip */
   pthread_mutex_t miss_lock;
@@ -290,7 +306,19 @@ static void block_done(void *arg) {
   struct timespec t1;
   clock_gettime(CLOCK_MONOTONIC, &t1);
   struct mctx *const c = n->ctx;
+  /* the engine has reported a failed device-side check: what it still delivers is not to be trusted (the notch recurrence of this
+     block and of every later one was not applied) -- the block is announced like a skipped one: zeros and a counted drop for everybody */
+  if (__atomic_load_n(&c->failed, __ATOMIC_ACQUIRE) || chz_engine_check(c->eng) != 0) {
+    __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE);
+    __atomic_fetch_add(&c->failed_blocks, 1u, __ATOMIC_RELAXED);
+    __atomic_store_n(&c->skipped[job % ND][(job / ND) % SKIP_RING], ((uint64_t)1 << 32) | job, __ATOMIC_RELEASE);
+    announce(c, (int)(job % ND), true);
+    __atomic_store_n(&c->dev_seq[job % ND], seq, __ATOMIC_RELEASE);
+    futex_wake_n(&c->dev_seq[job % ND], 1);
+    return;
+  }
   if (c->profile) {
+    c->t_done_job[job % ND] = job;
     c->t_done[job % ND] = t1;
     long long const d = (t1.tv_nsec - t0.tv_nsec) + 1000000000LL * (t1.tv_sec - t0.tv_sec);
     if (job >= 8 && (unsigned long long)d > c->prof_dev_max_ns) c->prof_dev_max_ns = (unsigned long long)d;   /* the first blocks carry one-time set-up */
@@ -514,10 +542,10 @@ int delete_filter_input(struct filter_in *master) {
     chz_sync(c->eng);
     if (c->profile && c->prof_blocks)
       fprintf(stderr, "filter_hip profile: blocks=%llu input_us=%.1f input_wait_us=%.1f consume_mean_us=%.1f consume_worst_us=%.1f reads=%llu "
-              "hits=%llu misses=%llu skipped=%lu dev_block_max_us_after_8=%.1f\n",
+              "hits=%llu misses=%llu skipped=%lu dev_block_max_us_after_8=%.1f consume_worst_after_8_us=%.1f recoveries=%u failed_blocks=%u\n",
               c->prof_blocks, c->prof_input_ns / 1e3 / c->prof_blocks, c->prof_wait_ns / 1e3 / c->prof_blocks,
               c->prof_consume_n ? c->prof_consume_sum_ns / 1e3 / c->prof_consume_n : 0.0, c->prof_consume_max_ns / 1e3, c->prof_consume_n,
-              c->prof_hits, c->prof_misses, c->n_skipped, c->prof_dev_max_ns / 1e3);
+              c->prof_hits, c->prof_misses, c->n_skipped, c->prof_dev_max_ns / 1e3, c->prof_consume_max8_ns / 1e3, c->recoveries, c->failed_blocks);
     if (c->ring_pinned) chz_host_unregister(master->input_buffer);
     chz_engine_destroy(c->eng);
     mctx_free(c);
@@ -659,6 +687,63 @@ static void sync_notches(struct mctx *c, struct filter_in *f) {
   c->notch_ptr = ns; c->notch_n = n;
 }
 
+/* Replace a failed engine (see struct mctx).  Caller holds c->lock; `job` is the block about to be enqueued, whose window starts at
+   the master's read pointer.  Ends the process if the engine cannot be replaced or has just been. */
+static void die_for_the_supervisor(const char *why) {
+  fprintf(stderr, "filter_hip: %s -- exiting (EX_SOFTWARE) so that the supervisor restarts the process, as the reference does on a fatal "
+                  "front-end or FFT error (src/radio.c:398, src/main.c:202)\n", why);
+  exit(EX_SOFTWARE);
+}
+static void recover_engine(struct mctx *c, struct filter_in *f, unsigned job) {
+  char why[200];
+  snprintf(why, sizeof why, "%s", chz_last_error());
+  if (c->recoveries > 0 && job - c->last_recovery_job < RECOVERY_GRACE) {
+    fprintf(stderr, "filter_hip: the device failed again %u blocks after a recovery (%s)\n", job - c->last_recovery_job, why);
+    die_for_the_supervisor("second device failure");
+  }
+  fprintf(stderr, "filter_hip: device-side failure at block %u (%s): re-creating the engine, in-flight blocks are counted as drops\n", job, why);
+  (void)chz_sync(c->eng);                    /* every completion callback of the old engine has run after this (each one dropped its block) */
+  stage_wrlock(c);
+  chz_engine_destroy(c->eng);
+  c->eng = NULL;
+  const char *dev = getenv("KA9Q_HIP_DEVICE");
+  if (chz_engine_create(&c->eng, f->ilen, f->impulse_length, f->in_type == REAL ? CHZ_REAL : CHZ_COMPLEX, dev ? atoi(dev) : 0, NULL, 0) != 0) {
+    fprintf(stderr, "filter_hip: %s\n", chz_last_error());
+    die_for_the_supervisor("the engine could not be re-created");
+  }
+  (void)chz_engine_notch_order(c->eng, 1);   /* what failed was a device-side wait: the new engine orders its notches by HIP events, which cannot run out */
+  for (int i = 0; i < c->nbanks; i++) {
+    struct hbank *b = &c->banks[i];
+    b->id = bank_create_dev(c, b, b->cap);
+    if (b->id < 0) { fprintf(stderr, "filter_hip: %s\n", chz_last_error()); die_for_the_supervisor("a channel bank could not be re-created"); }
+    for (int k = 0; k < b->n; k++) {
+      struct filter_out *sl = b->slaves[k];
+      pthread_mutex_lock(&sl->response_mutex);                     /* (see bank_for) */
+      if (sl->response) chz_bank_set_responses(c->eng, b->id, k, 1, (const float *)sl->response);
+      pthread_mutex_unlock(&sl->response_mutex);
+      b->beam_on[k] = 0;                                           /* re-uploaded by the block below if the slave is in beam mode */
+    }
+    if (b->n > 0) {
+      chz_bank_set_shifts(c->eng, b->id, 0, b->n, b->shift);
+      if (!b->real) chz_bank_set_isb(c->eng, b->id, 0, b->n, b->isb);
+    }
+    for (int s2 = 0; s2 < ND; s2++) {                              /* nothing staged survives */
+      b->stage_job[s2] = UINT_MAX; b->stage_n[s2] = 0;
+      for (int k = 0; k < b->cap; k++) b->stage_epoch[s2][k] = 0;
+    }
+  }
+  c->notch_ptr = NULL; c->notch_n = -1;                            /* sync_notches uploads the list again */
+  /* the overlap history in front of this block's new samples: the first M-1 samples of its window in the host ring */
+  const float *hist = f->in_type == COMPLEX ? (const float *)f->input_read_pointer.c : f->input_read_pointer.r;
+  if (chz_input_seek(c->eng, job, f->impulse_length > 1 ? hist : NULL) != 0) {
+    fprintf(stderr, "filter_hip: %s\n", chz_last_error());
+    die_for_the_supervisor("the input history could not be re-seated");
+  }
+  stage_wrunlock(c);
+  c->recoveries++; c->last_recovery_job = job;
+  __atomic_store_n(&c->failed, false, __ATOMIC_RELEASE);
+}
+
 int execute_filter_input(struct filter_in *const f) {
   if (f == NULL || f->fwd_plan == NULL) return -1;
   if (is_mini_master(f)) return mini_execute_input(f);
@@ -675,14 +760,27 @@ int execute_filter_input(struct filter_in *const f) {
     for (;;) {
       unsigned const done = __atomic_load_n(&c->dev_seq[nslot], __ATOMIC_ACQUIRE);
       if (done == c->enq_seq[nslot]) break;
-      if (c->drop_when_full) { skip = true; break; }
+      /* drop mode skips at most 3 blocks in a row: the samples of a skipped block still travel (below), and a 4th copy in a row
+         would overwrite the device-ring window of a forward transform that may not have run yet (8 blocks of ring: jobs r-3..r in
+         flight read regions r-4..r, the copy of job r+4 writes region r-4).  Then the producer waits like the default mode. */
+      if (c->drop_when_full && c->consecutive_skips < 3) { skip = true; break; }
       futex_wait_u32(&c->dev_seq[nslot], done);
     }
+  }
+  if (c->drop_when_full && f->next_jobnum >= ND) {
+    /* ... and the H2D copy of block job-4 reads the region of the HOST ring the front end starts to overwrite as soon as this call
+       returns (the ring holds ND windows): if the device's copy queue is THAT far behind, the producer has to wait for that copy --
+       not for the block.  (In wait mode block job-4 has completed altogether by now.) */
+    if (chz_input_mark_wait(c->eng, (int)((f->next_jobnum - ND) % 8)) != 0) fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
   }
   if (c->profile) clock_gettime(CLOCK_MONOTONIC, &tp1);
   pthread_mutex_lock(&c->lock);
   unsigned const job = __atomic_fetch_add(&f->next_jobnum, 1u, __ATOMIC_RELAXED);   /* src/filter.c:607; read lock-free by slaves being created */
   int const slot = (int)(job % ND);
+  if (__atomic_load_n(&c->failed, __ATOMIC_ACQUIRE) || chz_engine_check(c->eng) != 0) {
+    recover_engine(c, f, job);
+    skip = false;                                                   /* the new engine is idle */
+  }
   /* readers pick this up without a lock, possibly while a later lap overwrites it (as in the reference): tear-free accesses */
   __atomic_store_n(&f->samples_by_job[slot], f->sample_index, __ATOMIC_RELAXED);   /* src/filter.c:614-615 */
   f->sample_index += (uint64_t)f->ilen;
@@ -699,15 +797,18 @@ int execute_filter_input(struct filter_in *const f) {
       f->input_read_pointer.r += f->ilen;
       ring_wrap((void **)&f->input_read_pointer.r, f->input_buffer, f->input_buffer_size);
     }
+    if (rc == 0) rc = chz_input_mark(c->eng, (int)(job % 8));
     if (rc != 0) fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
     /* completed_jobs[slot] stays with the block still in flight there (publishing this one in it would lap that block away
        from every slave that has not fetched it yet): a skipped block is announced on its own */
     __atomic_store_n(&c->skipped[slot][(job / ND) % SKIP_RING], ((uint64_t)1 << 32) | job, __ATOMIC_RELEASE);
-    c->n_skipped++;
+    __atomic_fetch_add(&c->n_skipped, 1ul, __ATOMIC_RELAXED);
+    c->consecutive_skips++;
     pthread_mutex_unlock(&c->lock);
     announce(c, slot, true);
     return rc == 0 ? 0 : -1;
   }
+  c->consecutive_skips = 0;
   struct done_note *note = &c->note[slot];
   note->ctx = c; note->job = job;
   note->seq = ++c->enq_seq[slot];
@@ -728,7 +829,7 @@ int execute_filter_input(struct filter_in *const f) {
     f->input_read_pointer.r += f->ilen;
     ring_wrap((void **)&f->input_read_pointer.r, f->input_buffer, f->input_buffer_size);
   }
-  if (rc == 0) rc = chz_engine_check(c->eng);                      /* a failed device-side check makes every later block fail loudly */
+  if (rc == 0 && c->drop_when_full) rc = chz_input_mark(c->eng, (int)(job % 8));
   if (rc == 0) rc = chz_forward(c->eng, job);
   if (rc == 0 && c->host_spectrum) rc = chz_spectrum_read_async(c->eng, slot, (float *)f->fdomain[slot]);
   /* speculative batched channel launches: every slave with its last-known shift */
@@ -778,8 +879,14 @@ int execute_filter_input(struct filter_in *const f) {
   }
   if (rc == 0) rc = chz_host_callback(c->eng, slot, block_done, note);
   if (rc != 0) {
-    fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
-    c->enq_seq[slot]--;                                             /* no completion callback will come for this block */
+    /* no completion callback will come for this block: it is dropped here (zeros + a counted drop for every slave), and the next
+       call replaces the engine (ONE line of log, not one per block) */
+    fprintf(stderr, "execute_filter_input: block %u: %s\n", job, chz_last_error());
+    c->enq_seq[slot]--;
+    __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE);
+    __atomic_fetch_add(&c->failed_blocks, 1u, __ATOMIC_RELAXED);
+    __atomic_store_n(&c->skipped[slot][(job / ND) % SKIP_RING], ((uint64_t)1 << 32) | job, __ATOMIC_RELEASE);
+    announce(c, slot, true);
   }
   if (c->profile) {
     struct timespec tp2; clock_gettime(CLOCK_MONOTONIC, &tp2);
@@ -957,6 +1064,10 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
           __atomic_fetch_add(&c->prof_consume_n, 1ull, __ATOMIC_RELAXED);
           unsigned long long mx = __atomic_load_n(&c->prof_consume_max_ns, __ATOMIC_RELAXED);
           while ((unsigned long long)ns > mx && !__atomic_compare_exchange_n(&c->prof_consume_max_ns, &mx, (unsigned long long)ns, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+          if (job >= 8 && c->t_done_job[slot] == job) {
+            mx = __atomic_load_n(&c->prof_consume_max8_ns, __ATOMIC_RELAXED);
+            while ((unsigned long long)ns > mx && !__atomic_compare_exchange_n(&c->prof_consume_max8_ns, &mx, (unsigned long long)ns, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+          }
         }
       }
       __atomic_fetch_add(hit ? &c->prof_hits : &c->prof_misses, 1ull, __ATOMIC_RELAXED);
@@ -1025,12 +1136,23 @@ double filter_hip_noise(struct filter_out const *slave) {
 /* returns once the device has finished every block handed to it so far (an orderly shutdown reads its last results after this) */
 int filter_hip_drain(struct filter_in *master) {
   if (master == NULL || master->fwd_plan == NULL || is_mini_master(master)) return -1;
-  return chz_sync(MCTX(master)->eng) == 0 ? 0 : -1;
+  struct mctx *c = MCTX(master);
+  pthread_mutex_lock(&c->lock);              /* the producer and the miss leaders enqueue (and a recovery swaps the engine) under it */
+  int const rc = chz_sync(c->eng);
+  pthread_mutex_unlock(&c->lock);
+  return rc == 0 ? 0 : -1;
 }
 /* blocks the front end skipped because the device was ND blocks behind (KA9Q_HIP_INPUT_FULL=drop) */
 unsigned long filter_hip_skipped_blocks(struct filter_in const *master) {
   if (master == NULL || master->fwd_plan == NULL || is_mini_master(master)) return 0;
-  return ((struct mctx const *)(void const *)master->fwd_plan)->n_skipped;
+  return __atomic_load_n(&((struct mctx const *)(void const *)master->fwd_plan)->n_skipped, __ATOMIC_RELAXED);
+}
+/* how often the engine had to be replaced, and how many blocks were lost to it (each a counted drop for every slave) */
+unsigned filter_hip_recoveries(struct filter_in const *master, unsigned *blocks_lost) {
+  if (master == NULL || master->fwd_plan == NULL || is_mini_master(master)) return 0;
+  struct mctx const *c = (struct mctx const *)(void const *)master->fwd_plan;
+  if (blocks_lost) *blocks_lost = __atomic_load_n(&c->failed_blocks, __ATOMIC_RELAXED);
+  return c->recoveries;
 }
 
 int set_filter_weights(struct filter_out *out, double complex i_weight, double complex q_weight) {  /* src/filter.c:922-929 */

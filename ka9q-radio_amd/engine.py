@@ -61,7 +61,7 @@ SYMBOLS = [
     "chz_bank_set_tuning", "chz_bank_read_power", "chz_bank_read_power_async",
     "chz_input_write_i16", "chz_input_write_i16_device", "chz_input_stats",
     "chz_bank_enable_noise", "chz_bank_read_noise", "chz_bank_read_noise_async", "chz_bank_create_real", "chz_bank_set_isb", "chz_bank_set_beam",
-    "chz_set_notches_alpha", "chz_slot_sync", "chz_engine_check",
+    "chz_set_notches_alpha", "chz_slot_sync", "chz_engine_check", "chz_input_seek", "chz_input_mark", "chz_input_mark_wait", "chz_engine_notch_order",
     "chz_bank_set_demod", "chz_bank_pcm_stride", "chz_bank_set_pcm_stride", "chz_bank_read_pcm", "chz_bank_read_pcm_async",
     "chz_comm_unique_id", "chz_comm_create", "chz_comm_create_file", "chz_comm_destroy", "chz_comm_rank", "chz_comm_world",
     "chz_mini_create", "chz_mini_destroy", "chz_mini_capacity", "chz_mini_add", "chz_mini_release", "chz_mini_set_response", "chz_mini_execute",
@@ -255,11 +255,14 @@ class Engine:
     def slot_sync(self, slot):
         _check(lib().chz_slot_sync(self._h, slot))
 
-    def run_blocks_sharded(self, comm, job0, nblocks, root=0, rows=None):
+    def run_blocks_sharded(self, comm, job0, nblocks, root=0, rows=None, samples=False):
         """BASELINE config 4: the root transforms, the spectrum travels over RCCL (whole slot, or the row ranges
-        rows = (lo[world], hi[world])), every rank runs its own banks."""
+        rows = (lo[world], hi[world])), every rank runs its own banks.  samples=True: the block's new samples travel
+        instead and every rank transforms them itself (SURVEY 8e's alternative)."""
         t = ChzTiming()
-        if rows is None:
+        if samples:
+            _check(lib().chz_run_blocks_sharded(self._h, comm._h, root, 2, None, None, job0 & 0xFFFFFFFF, nblocks, C.byref(t)))
+        elif rows is None:
             _check(lib().chz_run_blocks_sharded(self._h, comm._h, root, 0, None, None, job0 & 0xFFFFFFFF, nblocks, C.byref(t)))
         else:
             lo = np.ascontiguousarray(rows[0], np.int32); hi = np.ascontiguousarray(rows[1], np.int32)

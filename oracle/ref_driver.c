@@ -237,6 +237,84 @@ double refchz_bench(void *mh, void **chans, const int *shifts, int nchan,
   return t1 - t0;
 }
 
+/* The same run with a clock on every block: stats[0] = worst and stats[1] = mean time between the completions of two consecutive
+   blocks (a block is complete when the LAST pool thread has run its channels on it), stats[2] = worst time from handing a block's
+   samples to write_?filter to its completion, all in ms, over blocks skip.. only (the first ones fill the pipeline).  This is the
+   CPU side of bench.py's C_rt definition: a channel count is sustained if EVERY block completes within 20 ms of the one before. */
+struct bench_pool_arg2 { struct bench_pool_arg a; double *done; };
+static void *bench_pool_thread2(void *v) {
+  struct bench_pool_arg2 *p = v;
+  for (int b = 0; b < p->a.blocks; b++) {
+    for (int i = p->a.first; i < p->a.last; i++)
+      execute_filter_output(&p->a.ch[i]->out, p->a.shift[i]);
+    p->done[b] = now_s();
+  }
+  return NULL;
+}
+/* pace_us > 0: the front end hands a block over every pace_us microseconds of WALL CLOCK (absolute deadlines) and never waits for a
+   channel, as a real A/D front end does (src/sig_gen.c:357-362, src/rx888.c): a channel that falls ND blocks behind is lapped and
+   counts a drop (src/filter.c:686-701); stats[3] = total block_drops of all channels over the run.  This is "sustained in real time"
+   exactly as radiod experiences it.  pace_us == 0: free-running with back-pressure (never more than ND-1 blocks ahead). */
+double refchz_bench_blocks(void *mh, void **chans, const int *shifts, int nchan, const float *ring, int ring_blocks, int blocks,
+                           int pool_threads, int skip, double *stats, int pace_us) {
+  struct refchz_master *m = mh;
+  int L = m->in.ilen;
+  int per = m->in.in_type == REAL ? 1 : 2;
+  if (pool_threads < 1) pool_threads = 1;
+  if (pool_threads > nchan) pool_threads = nchan > 0 ? nchan : 1;
+  pthread_t *th = calloc((size_t)pool_threads, sizeof *th);
+  struct bench_pool_arg2 *args = calloc((size_t)pool_threads, sizeof *args);
+  double *done = calloc((size_t)pool_threads * (size_t)blocks, sizeof *done), *in = calloc((size_t)blocks, sizeof *in);
+  for (int i = 0; i < nchan; i++)
+    ((struct refchz_chan *)chans[i])->out.next_jobnum = m->in.next_jobnum;
+  double t0 = now_s();
+  for (int t = 0; t < pool_threads; t++) {
+    args[t].a.ch = (struct refchz_chan **)chans; args[t].a.shift = shifts; args[t].a.blocks = blocks;
+    args[t].a.first = (int)((long)nchan * t / pool_threads);
+    args[t].a.last = (int)((long)nchan * (t + 1) / pool_threads);
+    args[t].done = done + (size_t)t * (size_t)blocks;
+    pthread_create(&th[t], NULL, bench_pool_thread2, &args[t]);
+  }
+  for (int b = 0; b < blocks; b++) {
+    const float *src = ring + (size_t)(b % ring_blocks) * (size_t)L * per;
+    if (pace_us > 0) {
+      double const due = t0 + (double)(b + 1) * (double)pace_us * 1e-6;        /* the block's last sample arrives now */
+      struct timespec d = {.tv_sec = (time_t)due, .tv_nsec = (long)((due - (double)(time_t)due) * 1e9)};
+      while (clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &d, NULL) != 0) { }
+    } else for (;;) {
+      unsigned slowest = m->in.next_jobnum;
+      for (int i = 0; i < nchan; i++) {
+        unsigned nj = *(volatile unsigned *)&((struct refchz_chan *)chans[i])->out.next_jobnum;
+        if ((int)(nj - slowest) < 0) slowest = nj;
+      }
+      if (nchan == 0 || (int)(m->in.next_jobnum - slowest) < ND - 1) break;
+      struct timespec ts = {0, 20000}; nanosleep(&ts, NULL);
+    }
+    in[b] = now_s();
+    if (m->in.in_type == REAL) write_rfilter(&m->in, src, L);
+    else write_cfilter(&m->in, (const float complex *)src, L);
+  }
+  for (int t = 0; t < pool_threads; t++) pthread_join(th[t], NULL);
+  double t1 = now_s();
+  double worst = 0, sum = 0, lat = 0, prev = 0; int n = 0;
+  for (int b = 0; b < blocks; b++) {
+    double d = 0;
+    for (int t = 0; t < pool_threads; t++) if (done[(size_t)t * (size_t)blocks + b] > d) d = done[(size_t)t * (size_t)blocks + b];
+    if (b >= skip && b > 0) {
+      double const iv = d - prev;
+      if (iv > worst) worst = iv;
+      sum += iv; n++;
+      if (d - in[b] > lat) lat = d - in[b];
+    }
+    prev = d;
+  }
+  unsigned long drops = 0;
+  for (int i = 0; i < nchan; i++) drops += ((struct refchz_chan *)chans[i])->out.block_drops;
+  if (stats) { stats[0] = worst * 1e3; stats[1] = n ? sum / n * 1e3 : 0; stats[2] = lat * 1e3; stats[3] = (double)drops; }
+  free(th); free(args); free(done); free(in);
+  return t1 - t0;
+}
+
 extern int64_t Min_fft_time, Max_fft_time, Avg_fft_time;
 void refchz_fft_times(long long *mn, long long *mx, long long *avg) { *mn = Min_fft_time; *mx = Max_fft_time; *avg = Avg_fft_time; }
 

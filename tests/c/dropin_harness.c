@@ -36,6 +36,12 @@ extern int filter_hip_drain(struct filter_in *) __attribute__((weak));
 static double Noise_samprate; static double *Noise;   /* env HARNESS_NOISE=<front-end sample rate>: [Nblocks][Nch] device-side estimate_noise() */
 static int Ahead = 2;                                  /* env HARNESS_AHEAD: blocks the front end may run ahead of the slowest channel (the filter keeps ND = 4 blocks: 3 loses nothing) */
 static int Free_run;                                   /* env HARNESS_FREE_RUN=1: the front end does not wait for the channels (a real A/D never does); > 1: and takes that many microseconds per block */
+static long Paced_us;                                  /* env HARNESS_PACED_US=20000: a front end on its own WALL CLOCK, as an A/D is (src/sig_gen.c:357-362 paces itself the same way):
+                                                          every chunk goes in at the instant its last sample would have arrived (absolute deadlines, no drift), the
+                                                          front end never waits for a channel, a late channel is a counted drop (src/filter.c:686-701) */
+static long long *T_in;                                /* [Nblocks] when write_?filter returned for the chunk that completed the block */
+static _Atomic long long *Last_out;                    /* [Nblocks] when the LAST slave left execute_filter_output with the block */
+static _Atomic int *N_out;                             /* [Nblocks] slaves served */
 static unsigned char *Skipflag; static unsigned long Skips_seen;   /* [Nblocks]: the front end's block was skipped (drop mode) */
 static unsigned char *Dropped;                         /* [Nblocks][Nch]: the channel's block_drops went up in that call */
 static struct filter_in Master;
@@ -44,6 +50,7 @@ static struct chanplan *Plan;
 static float complex *Result;          /* [Nblocks][Nch][Olen] */
 static unsigned *Drops;
 static _Atomic int *Progress;          /* blocks consumed per channel */
+static _Atomic int Done_count;         /* channel threads that have consumed their last block */
 static float *Input;
 
 struct chanarg { int idx; };
@@ -58,6 +65,7 @@ static int Retune_mod;
 static int Input_blocks, Keep = 1;
 static long long Fe_copy_ns, Fe_call_ns, Fe_wait_ns;          /* front end: copying samples in, inside write_?filter, waiting for the slowest channel */
 static long long Worst_gap_ns, Sum_gap_ns; static int N_gap;  /* block clock: time between consecutive blocks */
+static long long Pace_t0, Fe_late_worst_ns, Fe_call_worst_ns; /* paced front end: start instant, worst wake-up lateness, longest single write_?filter call (after 8 blocks) */
 static long long now_ns(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1000000000LL + t.tv_nsec; }
 /* env HARNESS_CHURN_MOD=m: channel i with i % m == 1 leaves half way (delete_filter_output while everybody else runs: the bank
    closes the gap by moving its last slave) and comes back as a NEW slave a little later (create_filter_output + set_filter into
@@ -91,6 +99,15 @@ static void *channel_thread(void *a) {
     unsigned const drops_before = out.block_drops;
     if (execute_filter_output(&out, shift) != 0) { fprintf(stderr, "execute_filter_output failed\n"); exit(2); }
     if (Dropped) Dropped[(size_t)b * Nch + i] = out.block_drops != drops_before;
+    if (Last_out) {                                     /* latency bookkeeping: the block just served is next_jobnum - 1 (slaves start at job 0) */
+      unsigned const jb = out.next_jobnum - 1u;
+      if (jb < (unsigned)Nblocks && out.block_drops == drops_before) {
+        long long const t = now_ns();
+        long long prev = atomic_load(&Last_out[jb]);
+        while (t > prev && !atomic_compare_exchange_weak(&Last_out[jb], &prev, t)) { }
+        atomic_fetch_add(&N_out[jb], 1);
+      }
+    }
     if (Noise && filter_hip_noise) Noise[(size_t)b * Nch + i] = filter_hip_noise(&out);
     if (F2_blocking > 0) {
       int r = write_cfilter(&f2in, out.output.c, Olen);          /* runs the input side once the block is full (src/radio.c:1508) */
@@ -116,6 +133,10 @@ static void *channel_thread(void *a) {
     }
   }
   Drops[i] += out.block_drops;
+  /* nobody tears its slave down while others are still fetching the last block: delete_filter_output takes the master's write locks
+     and talks to the device, and 1000 of those in front of the stragglers made the LAST block look 50 ms late (round 4, paced legs) */
+  atomic_fetch_add(&Done_count, 1);
+  while (atomic_load(&Done_count) < Nch) usleep(500);
   if (F2_blocking > 0) { delete_filter_output(&f2out); delete_filter_input(&f2in); }
   delete_filter_output(&out);
   return NULL;
@@ -202,6 +223,16 @@ int main(int argc, char **argv) {
     Noise = calloc((size_t)Nblocks * Nch, sizeof *Noise);
   }
   if (getenv("HARNESS_FREE_RUN")) { Free_run = atoi(getenv("HARNESS_FREE_RUN")); Dropped = calloc((size_t)Nblocks * Nch, 1); Skipflag = calloc((size_t)Nblocks, 1); }
+  if (getenv("HARNESS_RECORD_DROPS") && !Dropped) Dropped = calloc((size_t)Nblocks * Nch, 1);   /* per-call drop flags without a free-running front end */
+  if (getenv("HARNESS_PACED_US")) {
+    Paced_us = atol(getenv("HARNESS_PACED_US"));
+    if (Paced_us > 0) { Free_run = 1; if (!Dropped) Dropped = calloc((size_t)Nblocks * Nch, 1); if (!Skipflag) Skipflag = calloc((size_t)Nblocks, 1); }
+  }
+  if (Paced_us > 0 || getenv("HARNESS_LATENCY")) {
+    T_in = calloc((size_t)Nblocks, sizeof *T_in);
+    Last_out = calloc((size_t)Nblocks, sizeof *Last_out);
+    N_out = calloc((size_t)Nblocks, sizeof *N_out);
+  }
   if (getenv("HARNESS_AHEAD")) { Ahead = atoi(getenv("HARNESS_AHEAD")); if (Ahead < 1) Ahead = 1; }
   if (getenv("HARNESS_RETUNE_MOD")) Retune_mod = atoi(getenv("HARNESS_RETUNE_MOD"));
   if (getenv("HARNESS_CHURN_MOD")) Churn_mod = atoi(getenv("HARNESS_CHURN_MOD"));
@@ -222,6 +253,7 @@ int main(int argc, char **argv) {
   /* front end: write in place, then tell the filter how much arrived */
   struct timespec ts0, ts1;
   clock_gettime(CLOCK_MONOTONIC, &ts0);
+  Pace_t0 = now_ns();
   long total = (long)Nblocks * L, pos = 0;
   long const cyc = (long)Input_blocks * L;
   while (pos < total) {
@@ -236,6 +268,14 @@ int main(int argc, char **argv) {
     int n = Chunk; if (pos + n > total) n = (int)(total - pos);
     long const src = pos % cyc;
     if (src + n > cyc) n = (int)(cyc - src);                    /* a chunk does not straddle the replay seam */
+    if (pos / L != (pos + n - 1) / L) n = (int)(((pos / L) + 1) * L - pos);   /* ... nor a block boundary (so a block's completion has one instant) */
+    if (Paced_us > 0) {                                         /* the chunk's last sample arrives at t0 + (pos + n) / fs */
+      long long const due = Pace_t0 + (long long)((double)(pos + n) / (double)L * (double)Paced_us * 1000.0);
+      struct timespec d = {.tv_sec = due / 1000000000LL, .tv_nsec = due % 1000000000LL};
+      while (clock_nanosleep(CLOCK_MONOTONIC, TIMER_ABSTIME, &d, NULL) != 0) { }
+      long long const late = now_ns() - due;
+      if (pos / L >= 8 && late > Fe_late_worst_ns) Fe_late_worst_ns = late;      /* (the first blocks: 1000 threads touching their buffers for the first time) */
+    }
     long long const w1 = now_ns();
     long long w2;
     if (In_type == REAL) {
@@ -247,8 +287,11 @@ int main(int argc, char **argv) {
       w2 = now_ns();
       if (write_cfilter(&Master, NULL, n) < 0) { fprintf(stderr, "write_cfilter overrun\n"); return 4; }
     }
-    Fe_wait_ns += w1 - w0; Fe_copy_ns += w2 - w1; Fe_call_ns += now_ns() - w2;
+    long long const w3 = now_ns();
+    Fe_wait_ns += w1 - w0; Fe_copy_ns += w2 - w1; Fe_call_ns += w3 - w2;
+    { long long const c = w3 - w2; if (pos / L >= 8 && c > Fe_call_worst_ns) Fe_call_worst_ns = c; }
     pos += n;
+    if (T_in && pos % L == 0) T_in[pos / L - 1] = w3;          /* the block is in: its clock starts */
     if (Skipflag && filter_hip_skipped_blocks && pos / L != (pos - n) / L) {      /* a block has just gone in: was it skipped? */
       unsigned long const sk = filter_hip_skipped_blocks(&Master);
       Skipflag[(pos - n) / L] = sk != Skips_seen; Skips_seen = sk;
@@ -280,17 +323,27 @@ int main(int argc, char **argv) {
     snprintf(path, sizeof path, "%s/noise.bin", argv[1]);
     f = fopen(path, "wb"); fwrite(Noise, sizeof *Noise, (size_t)Nblocks * Nch, f); fclose(f);
   }
+  if (T_in) {                                             /* per block: ns from 'the block is in' to 'the last slave has it', and how many slaves got it */
+    snprintf(path, sizeof path, "%s/latency.bin", argv[1]);
+    f = fopen(path, "wb");
+    for (int b = 0; b < Nblocks; b++) {
+      long long const lo = atomic_load(&Last_out[b]);
+      long long rec[2] = {(lo && T_in[b]) ? lo - T_in[b] : -1, atomic_load(&N_out[b])};
+      fwrite(rec, sizeof rec, 1, f);
+    }
+    fclose(f);
+  }
   snprintf(path, sizeof path, "%s/spec.bin", argv[1]);   /* host-visible spectrum of the last block (estimate_noise reads it) */
   f = fopen(path, "wb"); fwrite(Master.fdomain[(Nblocks - 1) % ND], sizeof(float complex), (size_t)Master.bins, f); fclose(f);
   snprintf(path, sizeof path, "%s/meta.txt", argv[1]);
   f = fopen(path, "w");
   unsigned drops = 0; for (int i = 0; i < Nch; i++) drops += Drops[i];
   fprintf(f, "drops %u clock %d next_jobnum %u bins %d points %d sample_index %llu elapsed_s %.6f avg_block_ns %lld max_block_ns %lld "
-             "worst_gap_ns %lld mean_gap_ns %lld fe_copy_ns %lld fe_call_ns %lld fe_wait_ns %lld skipped %lu\n",
+             "worst_gap_ns %lld mean_gap_ns %lld fe_copy_ns %lld fe_call_ns %lld fe_wait_ns %lld skipped %lu fe_late_worst_ns %lld fe_call_worst_ns %lld\n",
           drops, atomic_load(&Clock_blocks), Master.next_jobnum, Master.bins, Master.points,
           (unsigned long long)Master.sample_index, elapsed, (long long)Avg_fft_time, (long long)Max_fft_time,
           Worst_gap_ns, N_gap ? Sum_gap_ns / N_gap : 0, Fe_copy_ns, Fe_call_ns, Fe_wait_ns,
-          filter_hip_skipped_blocks ? filter_hip_skipped_blocks(&Master) : 0ul);
+          filter_hip_skipped_blocks ? filter_hip_skipped_blocks(&Master) : 0ul, Fe_late_worst_ns, Fe_call_worst_ns);
   fclose(f);
   delete_filter_input(&Master);
   free(th); free(args); free(notch);      /* a clean exit for the leak checker of the sanitizer runs (the caller owns the notch list) */

@@ -58,6 +58,13 @@ def main(world, nblk):
             eng.run_blocks_sharded(comm, 0, nblk)                           # whole-slot broadcast
             out["broadcast"] = [bank.read_slot(s).copy() for s in range(4)]
             spec = eng.spectrum((nblk - 1) % 4).copy()
+            gate.wait()
+            # SURVEY 8e's alternative: the block's new samples travel, every rank transforms them itself (mode 2).  The peers' rings
+            # start empty, so their first window differs from the root's; from the second block on every rank sees the same samples
+            # (the notch recurrence keeps a memory of block 0, but bins 0 and 125 lie outside every channel and noise window here)
+            eng.run_blocks_sharded(comm, 0, nblk, samples=True)
+            out["samples"] = [bank.read_slot(s).copy() for s in range(4)]
+            out["samples_noise"] = [bank.read_noise(s).copy() for s in range(4)] if n else [np.zeros(0)] * 4
             comm.barrier()
             comm.close(); eng.close()
             results[rank] = (first, last, out, spec)
@@ -87,7 +94,7 @@ def main(world, nblk):
         np.testing.assert_array_equal(results[r][3], results[0][3])
     checked = 0
     for first, last, out, _ in results:
-        for mode in ("broadcast", "rows"):
+        for mode in ("broadcast", "rows", "samples"):
             for j in range(max(0, nblk - 4), nblk):
                 got = out[mode][j % 4]
                 for c in range(last - first):
@@ -98,6 +105,7 @@ def main(world, nblk):
             for c in range(last - first):
                 want = ol.estimate_noise(spectra[j], ol.REAL, P, int(shifts_all[first + c]), 50.0 * L)
                 assert abs(out["noise"][j % 4][c] - want) <= 1e-6 * want, (first + c, j, out["noise"][j % 4][c], want)
+                assert abs(out["samples_noise"][j % 4][c] - want) <= 1e-6 * want, (first + c, j, out["samples_noise"][j % 4][c], want)
         # and both hand-overs give the same samples
         for s in range(4):
             np.testing.assert_array_equal(out["rows"][s][:last - first], out["broadcast"][s][:last - first])

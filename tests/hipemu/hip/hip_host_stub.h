@@ -43,6 +43,7 @@ static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, void* = nullptr) { memset(p, v, n); return hipSuccess; }
 typedef void* hipDeviceptr_t;
 static inline hipError_t hipMemsetD32Async(hipDeviceptr_t p, int v, size_t count, void* = nullptr) { for (size_t i = 0; i < count; i++) static_cast<int*>(p)[i] = v; return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }

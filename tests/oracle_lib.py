@@ -108,6 +108,9 @@ def ref():
         L.refchz_i0.restype = _d; L.refchz_i0.argtypes = [_d]
         L.refchz_bench.restype = _d
         L.refchz_bench.argtypes = [_vp, _vp, _vp, _i, _vp, _i, _i, _i]
+        if hasattr(L, "refchz_bench_blocks"):
+            L.refchz_bench_blocks.restype = _d
+            L.refchz_bench_blocks.argtypes = [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i]
         L.refchz_fft_times.argtypes = [_vp, _vp, _vp]
         L.refsig_create.restype = _vp; L.refsig_create.argtypes = [_d, _d, _d, _d, _i, C.c_ulonglong]
         L.refsig_delete.argtypes = [_vp]

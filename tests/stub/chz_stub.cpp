@@ -47,6 +47,8 @@ struct chz_engine {
   Bank banks[MAX_BANKS];                   // contents touched by the worker only; a new one is published through nbanks
   std::atomic<int> nbanks{0};
   std::thread worker; std::mutex m; std::condition_variable cv, idle;
+  std::atomic<bool> failed{false}; int fail_job = -1;     // fault injection (CHZ_STUB_FAIL_JOB)
+  std::mutex mm; std::condition_variable mcv; unsigned long long mark_seq = 0, mark_want[8] = {}, mark_done[8] = {};   // chz_input_mark
   std::deque<std::function<void()>> q; bool busy = false, quit = false;
   void post(std::function<void()> f) { { std::lock_guard<std::mutex> lk(m); q.push_back(std::move(f)); } cv.notify_one(); }
   void drain() { std::unique_lock<std::mutex> lk(m); idle.wait(lk, [&] { return q.empty() && !busy; }); }
@@ -63,6 +65,8 @@ struct chz_engine {
   }
 };
 
+static std::atomic<int> g_instances{0};     // engines created by this process so far (fault injection below)
+
 extern "C" {
 
 const char* chz_last_error(void) { return g_err; }
@@ -77,6 +81,9 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int, const ch
   e->bins = chzo_stream_bins(e->stream);
   for (auto& s : e->spec) s.assign((size_t)2 * e->bins, 0.f);
   e->worker = std::thread([e] { e->loop(); });
+  { const int inst = g_instances.fetch_add(1);
+    const char* fj = getenv("CHZ_STUB_FAIL_JOB"); const char* fa = getenv("CHZ_STUB_FAIL_ALWAYS");
+    if (fj && (inst == 0 || (fa && fa[0] == '1'))) e->fail_job = atoi(fj) + (inst == 0 ? 0 : 4 * inst); }
   *out = e;
   return 0;
 }
@@ -91,7 +98,42 @@ void chz_engine_destroy(chz_engine* e) {
 }
 int chz_sync(chz_engine* e) { if (!e) return fail(-1, "null engine"); e->drain(); return 0; }
 int chz_slot_sync(chz_engine* e, int) { return chz_sync(e); }
-int chz_engine_check(const chz_engine* e) { return e ? 0 : fail(-1, "null engine"); }
+// fault injection for the drop-in's recovery path: env CHZ_STUB_FAIL_JOB=n makes the FIRST engine of the process (every engine
+// with CHZ_STUB_FAIL_ALWAYS=1) report a failed device-side check once it has been handed block n, as a notch ticket that ran out does
+int chz_engine_check(const chz_engine* e) {
+  if (!e) return fail(-1, "null engine");
+  if (e->failed.load(std::memory_order_acquire)) return fail(-8, "chz_stub: injected device-side failure");
+  return 0;
+}
+int chz_input_seek(chz_engine* e, unsigned job, const float* history) {
+  if (!e) return fail(-1, "null engine");
+  e->drain();
+  const size_t per = e->in_type == CHZ_REAL ? 1 : 2;
+  chzo_stream_delete(e->stream);
+  e->stream = chzo_stream_create(e->L, e->M, e->in_type);
+  e->pending.clear(); e->next_job = job;
+  if (history) {                       // run the history through the stream's overlap: blocks of zeros ending with the M-1 samples
+    const long nh = e->M - 1, nblk = (nh + e->L - 1) / e->L;
+    std::vector<float> buf((size_t)nblk * e->L * per, 0.f), scratch((size_t)2 * e->bins);
+    memcpy(buf.data() + ((size_t)nblk * e->L - (size_t)nh) * per, history, sizeof(float) * (size_t)nh * per);
+    for (long b = 0; b < nblk; b++) chzo_stream_push(e->stream, buf.data() + (size_t)b * e->L * per, scratch.data());
+  }
+  return 0;
+}
+int chz_input_mark(chz_engine* e, int k) {
+  if (!e || k < 0 || k >= 8) return fail(-1, "bad argument");
+  const unsigned long long t = ++e->mark_seq;
+  e->mark_want[k] = t;
+  e->post([e, k, t] { { std::lock_guard<std::mutex> lk(e->mm); e->mark_done[k] = t; } e->mcv.notify_all(); });
+  return 0;
+}
+int chz_input_mark_wait(chz_engine* e, int k) {
+  if (!e || k < 0 || k >= 8) return fail(-1, "bad argument");
+  std::unique_lock<std::mutex> lk(e->mm);
+  e->mcv.wait(lk, [&] { return e->mark_done[k] >= e->mark_want[k]; });
+  return 0;
+}
+int chz_engine_notch_order(chz_engine* e, int) { return e ? 0 : fail(-1, "null engine"); }
 
 int chz_input_write(chz_engine* e, const float* x, long n) {
   if (!e || !x || n < 0) return fail(-1, "bad argument");
@@ -101,6 +143,7 @@ int chz_input_write(chz_engine* e, const float* x, long n) {
 }
 int chz_forward(chz_engine* e, unsigned job) {
   if (!e) return fail(-1, "null engine");
+  if (e->fail_job >= 0 && (int)job >= e->fail_job) e->post([e] { e->failed.store(true, std::memory_order_release); });
   e->post([e, job] {
     static const int delay_ms = [] { const char* v = getenv("CHZ_STUB_FORWARD_DELAY_MS"); return v ? atoi(v) : 0; }();   // a slow device
     if (delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));

@@ -55,7 +55,7 @@ def test_dropin_exports_the_reference_symbol_set():
     # beyond filter.h: every function include/ka9q_filter_hip_ext.h declares
     ext_hdr = open(os.path.join(ROOT, "include", "ka9q_filter_hip_ext.h")).read()
     ext = set(re.findall(r"\b(filter_hip_\w+)\s*\(", ext_hdr))
-    assert ext == {"filter_hip_enable_noise", "filter_hip_noise", "filter_hip_drain", "filter_hip_skipped_blocks"} and ext <= mine, ext - mine
+    assert ext == {"filter_hip_enable_noise", "filter_hip_noise", "filter_hip_drain", "filter_hip_skipped_blocks", "filter_hip_recoveries"} and ext <= mine, ext - mine
     assert functions | data <= mine, (functions | data) - mine
     ref_obj = os.path.join(ROOT, "oracle", "_build", "ref_filter.o")
     if os.path.exists(ref_obj):   # the reference's own object, compiled in place by oracle/Makefile
@@ -483,3 +483,53 @@ def test_plan_helpers_forward_to_fftw_when_the_link_has_it(tmp_path):
     assert r.returncode == 0 and "forward-ok" in r.stdout, r.stderr[-1500:]
     r = subprocess.run([sys.executable, str(script), "-", drop], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "null-ok" in r.stdout, r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_dropin_recovers_when_a_notch_ticket_runs_out():
+    """Failure policy on the device (round 4): CHZ_NOTCH_WAIT_MS=0.0002 makes the first notch ticket that has to wait for its
+    predecessor run out -- the engine raises its host-visible error word and tombstones the chain, exactly what a wedged
+    predecessor would cause.  The drop-in must log ONE line, drop what the broken engine still delivers, replace the engine
+    (notches then ordered by HIP events), re-seat the overlap history from the host ring and carry on within 8 blocks: every
+    block it delivers is exact, every block it does not is zeros + a counted drop for every slave (src/filter.c:690-701)."""
+    _build_lib(); ol.build()
+    L, M, olen, P = 25920, 6481, 240, 300
+    N = L + M - 1
+    nblocks, nch = 40, 24
+    rng = np.random.default_rng(18)
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = [(int(rng.integers(500, 12000)) * (1 if i % 2 else -1),) * 2 + (10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4) for i in range(nch)]
+    with tempfile.TemporaryDirectory() as tmp:
+        exe = os.path.join(tmp, "harness")
+        _build_harness(exe)
+        open(os.path.join(tmp, "cfg.txt"), "w").write("%d %d %d %d %d %d %d\n" % (L, M, ol.REAL, olen, len(plan), nblocks, 4096))
+        with open(os.path.join(tmp, "plan.bin"), "wb") as f:
+            for p in plan:
+                f.write(struct.pack("iiiiddddd", *p))
+        x.tofile(os.path.join(tmp, "in.bin"))
+        env = dict(os.environ, CHZ_NOTCH_WAIT_MS="0.0002", HARNESS_RECORD_DROPS="1", HARNESS_AHEAD="3", KA9Q_HIP_PROFILE="1")
+        r = subprocess.run([exe, tmp], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+        out = np.fromfile(os.path.join(tmp, "out.bin"), np.complex64).reshape(nblocks, nch, olen)
+        dropped = np.fromfile(os.path.join(tmp, "dropped.bin"), np.uint8).reshape(nblocks, nch).astype(bool)
+        meta = open(os.path.join(tmp, "meta.txt")).read().split()
+        meta = dict(zip(meta[::2], meta[1::2]))
+    recovered = r.stderr.count("re-creating the engine")
+    if recovered == 0:
+        pytest.skip("no ticket had to wait in this run (blocks never overlapped): nothing ran out")
+    assert recovered == 1 and r.stderr.count("execute_filter_input:") <= 1, r.stderr[-2000:]
+    assert int(meta["clock"]) == nblocks and int(meta["next_jobnum"]) == nblocks
+    lost = np.flatnonzero(dropped.all(axis=1))
+    assert 1 <= len(lost) <= 8 and np.array_equal(lost, np.arange(lost[0], lost[0] + len(lost))), lost
+    assert int(meta["drops"]) == int(dropped.sum()) == len(lost) * nch
+    st = ol.Stream(L, M, ol.REAL)
+    for b in range(nblocks):
+        s64 = st.push(x[b * L:(b + 1) * L], f64=True)
+        if b in lost:
+            assert not out[b].any()
+            continue
+        for i, p in enumerate(plan):
+            want = ol.channel(s64, ol.REAL, P, olen, p[0], ol.set_filter(P, olen, N, True, p[4], p[5], p[6]))     # (channels away from the DC notch)
+            err = float(np.sqrt(np.mean(np.abs(out[b, i] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+            assert err <= 1e-5 * rms + 2e-8 * float(np.abs(s64).max()) * 4, (b, i, err, rms)

@@ -51,7 +51,8 @@ def _run(exe, tmp, L, M, olen, plan, nblocks, x, env=None):
         for p in plan:
             f.write(struct.pack("iiiiddddd", *p))
     x.tofile(os.path.join(tmp, "in.bin"))
-    e = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=67", **(env or {}))
+    e = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=67")
+    e.update(env or {})
     r = subprocess.run([exe, tmp], capture_output=True, text=True, timeout=int(os.environ.get("STUB_TIMEOUT", "300")), env=e)
     return r
 
@@ -235,3 +236,60 @@ def test_dropin_drop_mode_and_device_noise_under_sanitizers(tmp_path, san):
             assert noise[b, i] == pytest.approx(ol.estimate_noise(s32, ol.REAL, P, p[0], fs), rel=1e-6), (b, i)
             checked += 1
     assert checked >= nch
+
+
+def _recovery_run(tmp_path, san, env, nblocks=16, nch=20):
+    exe = _build(san, str(tmp_path / "build"))
+    L, M, olen = 25920, 6481, 240
+    rng = np.random.default_rng(77)
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = [(int(rng.integers(500, 12000)) * (1 if i % 2 else -1),) * 2 + (10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4) for i in range(nch)]
+    run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
+    r = _run(exe, run_dir, L, M, olen, plan, nblocks, x, dict(env, HARNESS_RECORD_DROPS="1"))
+    return r, run_dir, x, plan
+
+
+@pytest.mark.parametrize("san", ["thread", "address"])
+def test_dropin_replaces_a_failed_engine_and_carries_on(tmp_path, san):
+    """Failure policy (round 4): the engine reports a failed device-side check from block 5 on (injected into the stand-in engine, as a
+    notch ticket that ran out would).  The drop-in drops what that engine still delivers (zeros + block_drops for every slave),
+    replaces the engine ONCE -- responses, shifts, notch list re-registered, the overlap history re-seated from the host ring --
+    and the stream continues within 8 blocks, exact again from the first block of the new engine; one line of log, no error per block."""
+    if not _have("-fsanitize=" + san):
+        pytest.skip("no -fsanitize=%s runtime in this image" % san)
+    nblocks, nch = 16, 20
+    r, run_dir, x, plan = _recovery_run(tmp_path, san, {"CHZ_STUB_FAIL_JOB": "5"}, nblocks, nch)
+    assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-6000:]
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    assert r.stderr.count("re-creating the engine") == 1 and r.stderr.count("execute_filter_input:") <= 1, r.stderr[-2000:]
+    L, M, olen, P = 25920, 6481, 240, 300
+    N = L + M - 1
+    out = np.fromfile(os.path.join(run_dir, "out.bin"), np.complex64).reshape(nblocks, nch, olen)
+    dropped = np.fromfile(os.path.join(run_dir, "dropped.bin"), np.uint8).reshape(nblocks, nch).astype(bool)
+    meta = open(os.path.join(run_dir, "meta.txt")).read().split()
+    meta = dict(zip(meta[::2], meta[1::2]))
+    assert int(meta["clock"]) == nblocks and int(meta["next_jobnum"]) == nblocks
+    lost = np.flatnonzero(dropped.all(axis=1))
+    assert 1 <= len(lost) <= 8 and lost[0] >= 5 and np.array_equal(lost, np.arange(lost[0], lost[0] + len(lost))), lost   # one gap, recovered within 8 blocks
+    assert int(meta["drops"]) == int(dropped.sum()) == len(lost) * nch                                                    # every lost block is a counted drop
+    st = ol.Stream(L, M, ol.REAL)
+    for b in range(nblocks):
+        s64 = st.push(x[b * L:(b + 1) * L], f64=True)
+        if b in lost:
+            assert not out[b].any()
+            continue
+        for i, p in enumerate(plan):
+            want = ol.channel(s64, ol.REAL, P, olen, p[0], ol.set_filter(P, olen, N, True, p[4], p[5], p[6]))     # (channels away from the DC notch)
+            err = float(np.sqrt(np.mean(np.abs(out[b, i] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+            assert err <= 1e-5 * rms + 2e-8 * float(np.abs(s64).max()), (b, i, err, rms)
+
+
+def test_dropin_second_failure_exits_for_the_supervisor(tmp_path):
+    """... and if the replacement fails as well (within 500 blocks), the process ends with EX_SOFTWARE (70) -- the reference's own answer
+    to a fatal front-end / FFT error (src/radio.c:398, src/main.c:202): systemd restarts radiod."""
+    if not _have("-fsanitize=address"):
+        pytest.skip("no -fsanitize=address runtime in this image")
+    r, _, _, _ = _recovery_run(tmp_path, "address", {"CHZ_STUB_FAIL_JOB": "4", "CHZ_STUB_FAIL_ALWAYS": "1", "ASAN_OPTIONS": "detect_leaks=0"}, 24, 8)
+    assert r.returncode == 70, (r.returncode, r.stderr[-2000:])
+    assert "second device failure" in r.stderr and "supervisor" in r.stderr and r.stderr.count("re-creating the engine") == 1
