@@ -107,6 +107,8 @@ struct Bank {
   bool pcm_copying[CHZ_ND] = {false, false, false, false};             // a read on the copy stream is (or was) in flight for the slot
   bool tail_used[CHZ_ND] = {false, false, false, false};
   double* power = nullptr;      // [ND][cap] (tail of downconvert(), src/radio.c:1516-1520)
+  double* agc_peak = nullptr;   // [ND][cap] the block's largest 2 ms slice energy, left by chan_ifft for demod_lin_lanes (allocated with the demodulators of a large bank)
+  bool agc_peak_valid[CHZ_ND] = {false, false, false, false};   // the slot's image was written by this slot's latest whole-bank channel launch
   double* n0 = nullptr;         // [ND][cap] estimate_noise() (src/radio.c:1783-1866)
   double noise_samprate = 0.0;  // front-end sample rate; 0 = off
 };
@@ -252,7 +254,7 @@ template <class T> static int upload(T** dst, const std::vector<f2>& v) {
 
 static void free_bank(Bank& b) {
   hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); hipFree(b.any_scratch); b.any_scratch = nullptr;
-  hipFree(b.fine); hipFree(b.power); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam);
+  hipFree(b.fine); hipFree(b.power); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam); hipFree(b.agc_peak); b.agc_peak = nullptr;
   hipFree(b.dm_chan); hipFree(b.dm_state); hipFree(b.dm_ext); hipFree(b.dm_status); hipFree(b.dm_flags); hipFree(b.dm_pcm); hipFree(b.dm_mix);
   b.dm_mix = nullptr; b.dm_pll_lin = 0; b.dm_fm_pll = 0; b.dm_fm_tone = 0; b.dm_lin = 0; b.dm_fm = 0; b.dm_fm_nopll = 0;
   b.dm_chan = nullptr; b.dm_state = nullptr; b.dm_ext = nullptr; b.dm_status = nullptr; b.dm_flags = nullptr; b.dm_pcm = nullptr; b.dm_on = 0; b.dm_chan_h.clear(); b.dm_osc.clear();
@@ -814,14 +816,32 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* tu
     b.in = lbuf; b.in_len = 0; b.in_start = 0; b.out = lbuf; b.rows = p.Ra; b.inner = p.Nc; b.T = p.T2;
     b.padk = p.padk2; b.tw_sub = e->tw_sub_b; b.tw_tile = e->tw2_tile; b.tw_col = e->tw2_col;
     if (!getenv("CHZ_NO_TWFULL")) b.tw_full = e->tw2_full;
+    int grid2 = p.grid2;
+#if CHZ_XCD_AFFINE
+    // (experiment build: axis b of a three-axis plan only -- a complex master's first axis goes through launch_cols above, untouched... and
+    //  would be remapped too: this build serves REAL three-axis masters, which is what the experiment measures)
+    const int ncomp = (p.Ra + p.ka_shift + p.Ta - 1) / p.Ta;
+    if (ncomp > 8) return fail(-4, "the XCD-affine experiment build places at most 8 components (plan has %d)", ncomp);
+    b.xa = XcdAffine{CHZ_XCD_AFFINE, p.Ta, p.ka_shift, (int)((job * (unsigned)ncomp) & 7u), ncomp};
+    grid2 = 8 * p.Ta * (p.Nc / p.T2);
+#endif
     mark(in, st, 1, true);
-    if (launch_cols(p.rb, p.grid2, p.block2, p.lds2, st, b, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis b");
+    if (launch_cols(p.rb, grid2, p.block2, p.lds2, st, b, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis b");
     mark(in, st, 1, false);
   }
   RowsParams c{};
   c.lay = SpecLayout{p.Na, p.spec_pitch, p.spec_off}; c.ka_shift = p.ka_shift;
   c.buf = lbuf; c.spec = e->spec[slot]; c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3;
   c.padg = p.padg3; c.N = p.N; c.mirror = e->in_type == CHZ_REAL; c.tw_sub = e->tw_sub_c;
+  int grid3 = p.grid3;
+#if CHZ_XCD_AFFINE
+  {
+    const int ncomp = (p.Ra + p.ka_shift + p.Ta - 1) / p.Ta;
+    if (ncomp > 8 || p.Nb <= 1 || e->in_type != CHZ_REAL) return fail(-4, "the XCD-affine experiment build serves REAL three-axis masters with at most 8 a-tiles");
+    c.xa = XcdAffine{CHZ_XCD_AFFINE, p.Ta, p.ka_shift, (int)((job * (unsigned)ncomp) & 7u), ncomp};
+    grid3 = 8 * p.Nb;
+  }
+#endif
   // K2 inside this pass (short lists ordered by the device ticket): the launch is then what has to go out in block order
   const bool by_event = e->notch_order == 1 || (capturing && e->graph_notch_event);
   const bool fold = e->n_notch > 0 && e->notch_fold.n > 0 && !by_event && e->notch_order != 2;
@@ -840,7 +860,7 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* tu
       c.nf.adv = seq == e->capture_blocks - 1 ? (unsigned)e->capture_blocks : 0u;
     } else if (ticket) { c.nf.ver = e->notch_ver; c.nf.seq = e->notch_tickets; }
     mark(in, st, 2, true);
-    const int lr = launch_rows(p.rc, p.grid3, p.block3, p.lds3, st, c, IN_E0(in), IN_E1(in));
+    const int lr = launch_rows(p.rc, grid3, p.block3, p.lds3, st, c, IN_E0(in), IN_E1(in));
     mark(in, st, 2, false);
     if (!lr && ticket && !capturing) e->notch_tickets++;           // taken only by a launch that went out
     if (turn) {
@@ -851,7 +871,7 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* tu
     return 0;
   }
   mark(in, st, 2, true);
-  if (launch_rows(p.rc, p.grid3, p.block3, p.lds3, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis c");
+  if (launch_rows(p.rc, grid3, p.block3, p.lds3, st, c, IN_E0(in), IN_E1(in))) return fail(-4, "no kernel for axis c");
   mark(in, st, 2, false);
   return enqueue_notch(e, slot, st, in, turn, seq, capture_first, capturing);
 }
@@ -987,6 +1007,13 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   c.stage = e->chan_stage >= 0 ? e->chan_stage : (n >= 16384);
   c.isb = b.isb ? b.isb + so : nullptr; c.beam = b.beam ? b.beam + so : nullptr;
   c.fine = b.fine ? b.fine + so : nullptr; c.power = b.power ? b.power + so : nullptr; c.job = job;
+  // the AGC's first look at the block rides in the channel kernel's epilogue when the rows pass through LDS anyway (large launches) and the
+  // lane-per-channel demodulator follows (CHZ_AGC_PEAK=0: A/B knob, the demodulator then walks the block twice as before)
+  // (only when somebody will use them: linear channels outside the coherent modes, served by the lane-per-channel demodulator)
+  const bool peaks = b.agc_peak && whole_bank && c.stage && !b.g.any && !b.out_real && (c.fine || c.power) && b.dm_on > 0 && b.dm_auto &&
+                     b.dm_lin > b.dm_pll_lin && (e->demod_wave == 0 || (e->demod_wave < 0 && b.dm_lin >= 65536));
+  if (peaks) { c.agc_peak = b.agc_peak + so; int sps = (int)std::rint(b.olen * .002 / b.dm_blocktime); c.agc_sps = sps < 1 ? 1 : sps; }
+  if (whole_bank) b.agc_peak_valid[slot] = peaks;
   const int per_block = b.g.any ? 1 : b.g.wpb * b.g.cpw;
   const int grid = (n + per_block - 1) / per_block;
   mark(in, st, 4, true);
@@ -1029,6 +1056,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
     d.lin_pll = b.dm_pll_lin > 0; d.fm_pll = b.dm_fm_pll > 0; d.fm_tone = b.dm_fm_tone > 0;
     d.mix = (d.lin_pll || d.fm_pll || d.fm_tone) ? b.dm_mix : nullptr;
     demod_paths(e, b, d);
+    d.agc_peak = (b.agc_peak_valid[slot] && d.lin_lanes) ? b.agc_peak + so : nullptr;
     mark(in, ts, 6, true);
     if (launch_demod(ts, d, IN_E0(in), IN_E1(in))) return fail(-4, "the demodulator kernel refuses blocks of %d samples", b.olen);
     mark(in, ts, 6, false);
@@ -1475,6 +1503,12 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
     std::vector<DemodExt> fresh((size_t)b.cap, demod_ext_init());
     HIPOK(hipMalloc((void**)&b.dm_ext, sizeof(DemodExt) * (size_t)b.cap));
     HIPOK(hipMemcpy(b.dm_ext, fresh.data(), sizeof(DemodExt) * (size_t)b.cap, hipMemcpyHostToDevice));
+    drop_graph(e);
+  }
+  if (!b.agc_peak && (e->demod_wave == 0 || (e->demod_wave < 0 && b.cap >= 65536)) && !(getenv("CHZ_AGC_PEAK") && getenv("CHZ_AGC_PEAK")[0] == '0')) {
+    HIPOK(hipMalloc((void**)&b.agc_peak, sizeof(double) * (size_t)CHZ_ND * b.cap));
+    HIPOK(hipMemset(b.agc_peak, 0, sizeof(double) * (size_t)CHZ_ND * b.cap));
+    HIPOK(hipDeviceSynchronize());
     drop_graph(e);
   }
   if ((need_ext || need_fm_mix) && !b.dm_mix && !getenv("CHZ_PLL_LANE0")) {      // (A/B knob: round 2's one-lane-per-channel loops inside the demodulator kernel)

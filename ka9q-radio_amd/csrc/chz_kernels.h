@@ -141,6 +141,19 @@ template <int N_> __device__ __forceinline__ float row_shr16(float v) {
 #endif
 }
 
+// EXPERIMENT (round 4, build variant `make xcdaffine`, -DCHZ_XCD_AFFINE=1; the shipped library carries none of it).  The one
+// byte-saving idea left for the forward transform: make fwd_rows read what fwd_cols wrote out of the SAME XCD's L2.  fwd_rows'
+// workgroup (kb, a-tile) reads rows ka of its a-tile at one kb over all nc; fwd_cols' workgroup (ka, column tile) writes every kb of
+// its columns -- so producers and consumers form one connected component per a-tile (5 for config 3: ka in [16c - 12, 16c + 4)).
+// Placement: the dispatcher is observed to put block b on XCD b % 8 (MI355X_MICROARCH.md), so both passes launch 8 x (work per
+// component) blocks, block b serves component (b % 8 - rot) mod 8 and leaves at once if that component does not exist; `rot`
+// advances by ncomp per block so consecutive blocks in flight load different XCDs.  fwd_cols then stores PLAIN (the lines stay
+// in its XCD's L2; write-through stores drop them).  Decision record: DESIGN.md section 7, profiles/r04_xcd_affine.txt.
+#ifndef CHZ_XCD_AFFINE
+#define CHZ_XCD_AFFINE 0
+#endif
+struct XcdAffine { int on, Ta, shift, rot, ncomp; };
+
 struct ColsParams {
   const float2* in;       // in[(row*NP + n)*inner + col]  (+ ring wrap when in_len != 0)
   long in_len;            // 0, or ring length in float2 (input then starts at in_start)
@@ -155,6 +168,7 @@ struct ColsParams {
   const float2* tw_col;   // [NP][T]       W_(NP*inner)^(k * t)
   const float2* tw_full;  // [NP][inner] W_(NP*inner)^(k * col), or nullptr: one load and no product per output (axis b: the table
                           // is Nb*Nc entries and L2-resident; axis a of a complex master would need N entries and keeps the two factors)
+  XcdAffine xa;           // experiment build only (CHZ_XCD_AFFINE): XCD-affine placement of the axis-b pass
 };
 
 // Spectrum storage: bin k = ka + Na*x lives at  spec[x*pitch + off + ka].  pitch = Na, off = 0 is
@@ -212,6 +226,7 @@ struct RowsParams {
   long N;                 // full transform length
   int mirror;             // 1: real master (bins N/2+1, conj-mirror store); 0: complex master
   const float2* tw_sub;   // [R2][R1] W_Nc^(j*k1)
+  XcdAffine xa;           // experiment build only (CHZ_XCD_AFFINE)
   RowsNotch nf;           // K2 folded into this pass (nf.n == 0: none; the notch_fix kernel follows instead, or there is no list)
 };
 
@@ -246,6 +261,11 @@ struct ChanParams {
   const BeamDesc* beam;   // [nch] or nullptr: slave->beam with its weights (EPI variant only, COMPLEX masters)
   const FineDesc* fine;   // [nch] or nullptr: plain execute_filter_output semantics
   double* power;          // [nch] mean |sample|^2 of the block after rotation (chan->sig.bb_power, :1516-1520)
+  // demod_linear()'s AGC looks at the block once before it demodulates it: the largest energy of a 2 ms slice (src/linear.c:177-203).
+  // With the output rows staged through LDS (p.stage) that first look happens HERE, on the samples still in LDS, in the reference's
+  // own order -- and the lane-per-channel demodulator reads the baseband once instead of twice (1920 of 8.9 KB per 12 kHz channel).
+  double* agc_peak;       // [nch] or nullptr (EPI variant, stage mode only)
+  int agc_sps;            // samples per slice: rint(olen * .002 / blocktime), at least 1
   unsigned job;
   const float2* spec;     // master spectrum of this block (SpecLayout order)
   SpecLayout lay;
@@ -431,7 +451,19 @@ __global__ void fwd_cols(ColsParams p) {
   const int tid = threadIdx.x;
   const int T = p.T;
   const int tpr = p.inner / T;
+#if CHZ_XCD_AFFINE
+  int row, ct;
+  {
+    const int comp = (((int)blockIdx.x & 7) + 8 - p.xa.rot) & 7, idx = (int)blockIdx.x >> 3;
+    if (comp >= p.xa.ncomp) return;
+    const int r0 = comp * p.xa.Ta - p.xa.shift;
+    const int lo = r0 < 0 ? 0 : r0, hi = r0 + p.xa.Ta < p.rows ? r0 + p.xa.Ta : p.rows;
+    if (idx >= (hi - lo) * tpr) return;
+    row = lo + idx / tpr; ct = idx - (idx / tpr) * tpr;
+  }
+#else
   const int row = blockIdx.x / tpr, ct = blockIdx.x - row * tpr;
+#endif
   const int c0 = ct * T;
   const long base = (long)row * NP * p.inner + c0;
   const float2* __restrict__ gin = p.in;
@@ -504,10 +536,17 @@ __global__ void fwd_cols(ColsParams p) {
     CHZ_OUT_DESC(odesc, gout);
     const int o0 = (int)base + k1o * p.inner + to;       // element index into gout: the whole buffer is < 2^31 bytes
     const int ostep = R1 * p.inner;
+#if CHZ_XCD_AFFINE == 1        // plain stores: the lines stay in this XCD's L2 for fwd_rows (a COMPILE-time choice: an untaken run-time
+    static_for<R2>([&](auto k2) {  // branch around a second store flavour cost this pass 6 us, 5.7 -> 12.0)
+      constexpr int K2 = decltype(k2)::value;
+      gout[o0 + K2 * ostep] = cmul(u[K2], full ? wt[K2] : cmul(wt[K2], wc[K2]));
+    });
+#else
     static_for<R2>([&](auto k2) {
       constexpr int K2 = decltype(k2)::value;
       CHZ_STORE(odesc, gout, o0 + K2 * ostep, cmul(u[K2], full ? wt[K2] : cmul(wt[K2], wc[K2])));
     });
+#endif
   }
 }
 
@@ -599,7 +638,16 @@ __global__ void fwd_rows(RowsParams p) {
   HIP_DYNAMIC_SHARED(float2, lds)
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int Ta = p.Ta, ld = p.ld, padg = p.padg;
+#if CHZ_XCD_AFFINE
+  int kb, at;
+  {
+    const int comp = (((int)blockIdx.x & 7) + 8 - p.xa.rot) & 7, idx = (int)blockIdx.x >> 3;
+    if (comp >= p.xa.ncomp || idx >= p.Nb) return;
+    kb = idx; at = comp;
+  }
+#else
   const int kb = blockIdx.x % p.Nb, at = blockIdx.x / p.Nb;
+#endif
   const int a0 = at * Ta - p.ka_shift;           // may be negative for the first (ragged) tile
   const int rowstride = p.Nb * NC;               // all index math below is 32-bit: N < 2^31
   const int gstep = R2 * ld + padg;              // LDS distance between butterfly groups
@@ -1043,6 +1091,31 @@ __global__ void __launch_bounds__(256, (!EPI && R1 <= 15 && R2 <= 20) ? 6 : 1) c
   // global memory: stream it out of LDS as 16-byte stores in lane order (full 128-byte lines) instead of the
   // R1-sample pieces the butterfly leaves in each lane.  Worth 11 % at millions of channels (12 M channels: 12.8 ->
   // 11.4 ms per block), costs 0.6 us of latency on a 1024-channel launch: the engine picks per launch.
+  if constexpr (EPI) {
+    if (p.stage && p.agc_peak != nullptr) {                 // wave-uniform
+      // slice s = samples [s*sps, (s+1)*sps) of the channel's row in LDS; the channel's lanes take the slices in turn and sum each one in
+      // sample order exactly as demod_lin_lanes' first pass did (float squares rounded one by one, their float sum, accumulated in double);
+      // a slice counts if it ends before the block's last sample (`while (n + samples_per_slice < N)`, src/linear.c:199)
+      const int sps = p.agc_sps, N = p.olen;
+      double peak = 0.0;
+      if (live) {
+        for (int s0 = jl; (s0 + 1) * sps < N; s0 += LPC) {
+          double energy = 0.0;
+          for (int n = s0 * sps; n < (s0 + 1) * sps; n++) {
+            const float2 w = my[n];
+            float a = w.x * w.x, b = w.y * w.y;
+            CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
+            energy += (double)(a + b);
+          }
+          if (energy > peak) peak = energy;
+        }
+      }
+      double tot = 0.0;                                      // max over the channel's lanes (energies are >= 0: max of the lanes' maxima)
+#pragma unroll
+      for (int i = 0; i < LPC; i++) { const double o = __shfl(peak, (cw < CPW ? cw : 0) * LPC + i); tot = o > tot ? o : tot; }
+      if (live && jl == 0) p.agc_peak[ch] = tot;
+    }
+  }
   if (p.stage) {
     const int first_lc = (blockIdx.x * wpb + wave) * CPW;
     int nl = p.nch - first_lc; if (nl > CPW) nl = CPW;
@@ -1569,6 +1642,8 @@ struct DemodParams {
   int wave_any;              // the bank has channels demod_linear_tail must serve (FM; PLL channels without the scratch block)
   int lin_pll, fm_pll, fm_tone;   // the bank has channels with a carrier PLL (linear) / the PLL demodulator (FM) / a PL-tone squelch (FM): which
                              // of the lane-per-channel passes launch_demod adds; they need `mix`
+  const double* agc_peak;    // [cap] this slot, or nullptr: the block's largest slice energy as chan_ifft left it (the AGC's first look at the
+                             // block, src/linear.c:177-203); valid for channels without a post-detection shift and without a PLL
   float2* mix;               // [cap][olen] or nullptr: the coherent modes' blocks after their PLL (written by pll_lanes, one CHANNEL PER LANE);
                              // nullptr: lane 0 of each channel's wavefront walks the block inside demod_linear_tail (round 2's way)
 };
@@ -2335,17 +2410,22 @@ __global__ void __launch_bounds__(64, 2) demod_lin_lanes(DemodParams p) {
   };
   // ---- AGC (src/linear.c:177-234): the largest slice energy of the block, slices in order
   double gain_change = 1.0;
+  // the channel kernel has already looked at this block (its samples were still in LDS there): the first pass over the baseband is
+  // only walked by lanes whose block is not what that kernel wrote -- a post-detection shift rotates it first, a PLL replaced it
+  const bool have_peak = p.agc_peak != nullptr && !rot && !pll;
+  const bool walk1 = active && agc && !have_peak;
   if (__ballot(active && agc) != 0ull) {                   // wave-uniform
     int sps = (int)rint(N * .002 / p.blocktime);
     sps = sps < 1 ? 1 : sps;
     double peak = 0.0, energy = 0.0; int in_slice = 0;
-    fetch_tile(0);
-    for (int t0 = 0; t0 < N; t0 += LIN_TILE) {
+    const bool any_walk = __ballot(walk1) != 0ull;         // wave-uniform
+    if (any_walk) fetch_tile(0);
+    for (int t0 = 0; any_walk && t0 < N; t0 += LIN_TILE) {
       const int tn = N - t0 < LIN_TILE ? N - t0 : LIN_TILE;
       place_tile();
       CHZ_WAVE_SYNC();
       if (t0 + LIN_TILE < N) fetch_tile(t0 + LIN_TILE);
-      if (active && agc) {
+      if (walk1) {
         double cr = 1.0, sr = 0.0;
         if (rot) rot_at(t0, cr, sr);
         for (int n = 0; n < tn; n++) {
@@ -2368,6 +2448,7 @@ __global__ void __launch_bounds__(64, 2) demod_lin_lanes(DemodParams p) {
       CHZ_WAVE_SYNC();
     }
     if (active && agc) {
+      if (have_peak) peak = p.agc_peak[ch];
       const double bn = sqrt(bandwidth * st.n0);
       const double ampl = sqrt(bb_power);
       const double peak_level = sqrt(peak / sps);

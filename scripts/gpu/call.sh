@@ -26,6 +26,38 @@ case "$name" in
     $B --no-crt --no-next-rows --no-crt-pcie --no-cpu-baseline > "$out/bench_paced.json" 2> "$out/bench_paced.err"; echo "bench rc=$?" >> "$out/rc.txt"
     cat /sys/fs/cgroup/cpu.stat >> "$out/host.txt" 2>&1
     ;;
+  xcd)       # round 4 experiment: XCD-affine fwd_cols -> fwd_rows hand-over (build variants libchz_hip_xcd{1,2}.so), timing + L2 counters
+    X1="CHZ_LIB=$PWD/ka9q-radio_amd/libchz_hip_xcd1.so CHZ_NOTCH_FOLD=0"      # affine placement + plain hand-over stores
+    X2="CHZ_LIB=$PWD/ka9q-radio_amd/libchz_hip_xcd2.so CHZ_NOTCH_FOLD=0"      # affine placement, write-through stores kept
+    env $X1 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 300 -k "forward_matches_oracle and (2592000 or 1296000)" > "$out/parity_affine.txt" 2>&1; echo "parity rc=$?" >> "$out/rc.txt"
+    for rep in 1 2; do
+      CHZ_NOTCH_FOLD=0 $B --quick > "$out/base_$rep.json" 2>> "$out/err.txt"
+      env $X1 $B --quick > "$out/affine_plain_$rep.json" 2>> "$out/err.txt"
+      env $X2 $B --quick > "$out/affine_wt_$rep.json" 2>> "$out/err.txt"
+    done
+    for lanes in 1 2; do
+      CHZ_NOTCH_FOLD=0 CHZ_STREAMS=$lanes $B --quick > "$out/base_lanes$lanes.json" 2>> "$out/err.txt"
+      env $X1 CHZ_STREAMS=$lanes $B --quick > "$out/affine_plain_lanes$lanes.json" 2>> "$out/err.txt"
+    done
+    R=$PWD; cd /tmp
+    for v in base affine; do
+      E="CHZ_NOTCH_FOLD=0 CHZ_NOTCH_ORDER=event"; [ $v = affine ] && E="$X1 CHZ_NOTCH_ORDER=event"
+      for c in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+        n=$(echo $c | cut -d' ' -f1)
+        env $E timeout 240 rocprofv3 --pmc $c -f csv -d $R/$out/pmc_${v}_$n -o $n -- python $R/bench.py --steps 160 --warmup 16 --min-seconds 0.05 --quick > $R/$out/pmc_${v}_$n.log 2>&1
+      done
+    done
+    cd $R
+    python scripts/rocprof_summary.py $out/pmc_base_TCC_HIT_sum $out/pmc_affine_TCC_HIT_sum $out/pmc_base_FETCH_SIZE $out/pmc_affine_FETCH_SIZE $out/pmc_base_WRITE_SIZE $out/pmc_affine_WRITE_SIZE > "$out/pmc_summary.txt" 2>&1
+    rm -rf $out/pmc_*/ 2>/dev/null
+    ;;
+  agc)       # round 4: L2 hand-over microbenchmark; the AGC's first look in chan_ifft's epilogue, A/B at 1.5 M channels; demodulator tests
+    ./scripts/micro/xcd_l2_handover.bin > "$out/xcd_l2_handover.txt" 2>&1
+    NR="--no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline"
+    $B $NR > "$out/next_rows_peak.json" 2> "$out/err.txt"
+    CHZ_AGC_PEAK=0 $B $NR > "$out/next_rows_nopeak.json" 2>> "$out/err.txt"
+    timeout 1200 python -m pytest tests/test_gpu_scale.py tests/test_gpu_pipeline.py tests/test_golden.py -m gpu -x -q --timeout 600 -k "demod or scale or 70001 or golden or coherent or fm" > "$out/demod_tests.txt" 2>&1; echo "tests rc=$?" >> "$out/rc.txt"
+    ;;
   tests)     # the whole GPU suite, as the driver runs it
     timeout 2400 python -m pytest tests -m gpu -x -q --timeout 900 > "$out/gpu_suite.txt" 2>&1; echo "suite rc=$?" >> "$out/rc.txt"
     ;;

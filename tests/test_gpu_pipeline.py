@@ -362,9 +362,14 @@ def _demod_engine(pkg, ring, L, M, P, olen, cases, fs_out):
     return eng, bank, params
 
 
-@pytest.mark.parametrize("lin_path", ["lanes", "wave"])     # demod_lin_lanes (what banks of >= 65536 channels get) / demod_linear_tail
+# demod_lin_lanes (what banks of >= 65536 channels get) / demod_linear_tail / demod_lin_lanes behind a channel kernel that stages its rows
+# through LDS and leaves the AGC's slice-energy peak there (round 4: what banks of >= 65536 channels REALLY get -- the demodulator then reads
+# the baseband once; channel 4 of DEMOD_CASES has a post-detection shift and still walks it twice)
+@pytest.mark.parametrize("lin_path", ["lanes", "wave", "lanes_staged"])
 def test_linear_demodulator_on_the_device(pkg, monkeypatch, lin_path):
     monkeypatch.setenv("CHZ_DEMOD_WAVE", "1" if lin_path == "wave" else "0")
+    if lin_path == "lanes_staged":
+        monkeypatch.setenv("CHZ_CHAN_STAGE", "1")
     """chan_ifft (+ fine tuning, bb_power) -> noise_est -> demod_linear_tail, block after block through the C ABI.  The
     oracle's demodulator (pinned to the reference's linear.c) is fed exactly what the device stage was fed -- the channel
     outputs, bb_power and noise estimate read back from the same slot -- and must produce the same frames; then the same
