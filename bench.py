@@ -158,6 +158,22 @@ def siggen_ring(oracle_lib, fs=FS, seed=1, l=None, real=True):
     return g.generate(RING_BLOCKS * l)
 
 
+def kernel_sources_sha16():
+    """fingerprint of the forward kernels' sources (the same one scripts/rocprof_summary.py writes into the committed profiles)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("chz_kernels.h", "regfft.h", "chz_plan.h", "chz_launch.h"):
+        h.update(open(os.path.join(ROOT, "ka9q-radio_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_sha(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name))).get("kernel_sources_sha16")
+    except Exception:
+        return None
+
+
 def pmc_traffic_bytes():
     """HBM-side bytes per block of the forward kernels from the committed rocprofv3 PMC passes
     (profiles/pmc_forward.json, written by scripts/rocprof_summary.py --json from separate FETCH_SIZE and
@@ -960,6 +976,10 @@ def main():
             "traffic": traffic,
             "traffic_source": ("committed profile, not this run: profiles/pmc_forward.json (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate "
                                "passes over this same command, FETCH_SIZE doubled as the gfx950 guide prescribes)") if traffic else None,
+            # do the committed profiles belong to the kernels this run executes?  (same fingerprint of the kernel sources)
+            "profiles_match_this_tree": {"pmc_forward.json": profile_sha("pmc_forward.json") == kernel_sources_sha16() if traffic else None,
+                                         "rocprof_kernels.json": profile_sha("rocprof_kernels.json") == kernel_sources_sha16() if rp else None,
+                                         "kernel_sources_sha16": kernel_sources_sha16()},
             "rocprof": rp,
             "rocprof_frac": (fb / (rp["forward_us_1_stream"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if rp and rp.get("forward_us_1_stream") else None,
             "frac_of_measured_copy_rate": achieved / COPY_RATE_GBS,

@@ -58,6 +58,9 @@ case "$name" in
     CHZ_AGC_PEAK=0 $B $NR > "$out/next_rows_nopeak.json" 2>> "$out/err.txt"
     timeout 1200 python -m pytest tests/test_gpu_scale.py tests/test_gpu_pipeline.py tests/test_golden.py -m gpu -x -q --timeout 600 -k "demod or scale or 70001 or golden or coherent or fm" > "$out/demod_tests.txt" 2>&1; echo "tests rc=$?" >> "$out/rc.txt"
     ;;
+  profile)   # the round's profile: kernel trace (4 streams and 1), PMC passes, summaries for profiles/
+    GRAFT_REPO_ROOT=$PWD bash scripts/gpu_profile.sh r04 > "$out/profile.txt" 2>&1; echo "profile rc=$?" >> "$out/rc.txt"
+    ;;
   tests)     # the whole GPU suite, as the driver runs it
     timeout 2400 python -m pytest tests -m gpu -x -q --timeout 900 > "$out/gpu_suite.txt" 2>&1; echo "suite rc=$?" >> "$out/rc.txt"
     ;;

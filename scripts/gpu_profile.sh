@@ -5,13 +5,13 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-TAG=${1:-r03}
-FAST="--no-crt --no-cpu-baseline --no-dropin --no-crt-pcie --no-next-rows"
+TAG=${1:-r04}
+FAST="--quick"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_4streams -o t -- python $R/bench.py --steps 20 --warmup 5 $FAST > $R/gpurun_out/${TAG}_prof4.json 2> $R/gpurun_out/${TAG}_prof4.err
 CHZ_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_1stream -o t -- python $R/bench.py --steps 20 --warmup 5 $FAST > $R/gpurun_out/${TAG}_prof1.json 2> $R/gpurun_out/${TAG}_prof1.err
 cd $R
-[ "$SKIP_PMC" = 1 ] || timeout 1300 bash scripts/pmc_passes.sh $TAG --no-dropin --no-crt-pcie --no-next-rows
+[ "$SKIP_PMC" = 1 ] || timeout 1300 bash scripts/pmc_passes.sh $TAG
 {
   echo "## rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 $FAST   (default: 4 HIP streams)"
   python scripts/rocprof_summary.py gpurun_out/prof_${TAG}_4streams

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 # ticket) can then wait for something that is not allowed to start.  Under --pmc the recurrence is ordered by HIP events instead,
 # and every pass has its own time limit.
 export CHZ_NOTCH_ORDER=event
-run() { name=$1; shift; timeout 240 rocprofv3 --pmc "$@" -f csv -d $R/gpurun_out/pmc_$TAG/$name -o $name -- python $R/bench.py --steps 160 --warmup 16 --min-seconds 0.05 --no-crt --no-cpu-baseline $BENCH_ARGS > $R/gpurun_out/pmc_$TAG/$name.log 2>&1; }
+run() { name=$1; shift; timeout 240 rocprofv3 --pmc "$@" -f csv -d $R/gpurun_out/pmc_$TAG/$name -o $name -- python $R/bench.py --steps 160 --warmup 16 --min-seconds 0.05 --quick $BENCH_ARGS > $R/gpurun_out/pmc_$TAG/$name.log 2>&1; }
 mkdir -p $R/gpurun_out/pmc_$TAG
 BENCH_ARGS="$@"
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR

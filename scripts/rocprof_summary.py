@@ -4,6 +4,15 @@ into the small text tables committed under profiles/.   usage: rocprof_summary.p
 import csv, glob, os, sqlite3, sys
 from collections import defaultdict
 
+def tree_sha16():
+    """fingerprint of the kernel sources a profile was taken from (bench.py compares it with the tree it runs)"""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in ("chz_kernels.h", "regfft.h", "chz_plan.h", "chz_launch.h"):
+        h.update(open(os.path.join(root, "ka9q-radio_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
 def short(n):
     return n.replace("void chz::", "").replace("chz::", "").split("(")[0]
 
@@ -51,7 +60,7 @@ def pmc_json(fetch_dir, write_dir, out):
         b = (2.0 * fe[k] + wr.get(k, 0.0)) * 1024.0
         kern[k] = {"FETCH_SIZE_KiB": fe[k], "WRITE_SIZE_KiB": wr.get(k, 0.0), "bytes_corrected": b}
         total += b
-    json.dump({"forward_traffic_bytes_per_block": total, "kernels": kern,
+    json.dump({"forward_traffic_bytes_per_block": total, "kernels": kern, "kernel_sources_sha16": tree_sha16(),
                "note": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 wide reads)"},
               open(out, "w"), indent=1)
     print("wrote", out, total)
@@ -69,7 +78,7 @@ def kernels_json(dir4, dir1, out, tag):
     k4, k1 = avgs(dir4), avgs(dir1)
     fwd1 = sum(v["avg_us"] for k, v in k1.items() if k.startswith("fwd_"))
     fwd4 = sum(v["avg_us"] for k, v in k4.items() if k.startswith("fwd_"))
-    json.dump({"round": tag, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-crt --no-cpu-baseline --no-dropin --no-crt-pcie",
+    json.dump({"round": tag, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --quick", "kernel_sources_sha16": tree_sha16(),
                "forward_us_1_stream": fwd1, "forward_us_4_streams_sum_of_overlapping_kernels": fwd4,
                "kernels_1_stream": k1, "kernels_4_streams": k4,
                "note": "CHZ_STREAMS=1: one kernel at a time, comparable with roofline.kernels_us; profiled runs are about 10 % slower than unprofiled ones"},

@@ -104,12 +104,18 @@ def make_demod_rows(name):
             s = est[b] if np.isnan(s) else s + 0.10 * (est[b] - s)
             n0s[b] = s
         return n0s
+    # (round 4) lin_pllhold / lin_pllsqhold: the carrier is there from the first block (a wide loop left alone with noise can run off
+    # before it arrives) and STAYS: 150 blocks (3 s) of a loop that holds lock, every one of them compared strictly -- the 50-block
+    # window of the other two coherent cases ends where their carrier does
     lin = [("lin_usb", dict(), False), ("lin_am", dict(env=True, dc_alpha=0.002, encoding=ol.PCM_S16LE), False),
-           ("lin_pll", dict(pll=True), True), ("lin_pllsq", dict(pll=True, square=True, pll_bw=20.0, channels=2, encoding=ol.PCM_F32LE), True)]
+           ("lin_pll", dict(pll=True), True), ("lin_pllsq", dict(pll=True, square=True, pll_bw=20.0, channels=2, encoding=ol.PCM_F32LE), True),
+           ("lin_pllhold", dict(pll=True), "hold"), ("lin_pllsqhold", dict(pll=True, square=True, pll_bw=20.0, channels=2, encoding=ol.PCM_F32LE), "hold")]
     for key, kw, coh in lin:
-        nblk, N = (60, 240) if coh else (40, 240)
+        nblk, N = (150, 240) if coh == "hold" else (60, 240) if coh else (40, 240)
         r = np.random.default_rng(3)
-        if coh:                                  # the 90-block case of the pin test (seed 3 locks), its first 60 blocks
+        if coh == "hold":
+            bb, power = T._coherent_case(r, nblk, N, kw.get("square", False), last=10 ** 9, first=0)
+        elif coh:                                # the 90-block case of the pin test (seed 3 locks), its first 60 blocks
             bb, power = T._coherent_case(r, 90, N, kw.get("square", False))
             bb, power = bb[:nblk], power[:nblk]
         else:

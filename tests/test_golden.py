@@ -211,7 +211,12 @@ def test_hip_reproduces_noise_and_conversion_golden():
 # frames produced by the reference's own demod_linear() / demod_fm() (linear.c, fm.c, osc.c, iir.c, misc.c)
 # ------------------------------------------------------------------------------------------------
 DEMOD_FILE = os.path.join(GOLDEN, "demod_rows.npz")
-LIN_KEYS = ["lin_usb", "lin_am", "lin_pll", "lin_pllsq"]
+LIN_KEYS = ["lin_usb", "lin_am", "lin_pll", "lin_pllsq", "lin_pllhold", "lin_pllsqhold"]
+
+
+def _strict_blocks(key):
+    """how long a coherent case is compared strictly: while its carrier is there (round 4: the *hold cases keep it for all 150 blocks)"""
+    return 10 ** 9 if key.endswith("hold") else 50
 FM_KEYS = ["fm_plain", "fm_thr", "fm_pll", "fm_tone"]
 
 
@@ -299,14 +304,14 @@ def test_hip_reproduces_demodulator_golden():
                     if k.startswith("lin"):
                         assert got.gain == pytest.approx(g[k + "_gain"][b], rel=1e-6)
                         assert got.output_power == pytest.approx(g[k + "_opower"][b], rel=1e-5, abs=1e-300)
-                        if p.pll_enable and b < 50:
+                        if p.pll_enable and b < _strict_blocks(k):
                             snr, lock, cph, rot, foff = g[k + "_pll"][b]
                             assert got.pll_lock == int(lock) and got.pll_rotations == int(rot), (k, b)
                             assert got.pll_snr == pytest.approx(snr, rel=1e-5, abs=1e-9) and got.foffset == pytest.approx(foff, rel=1e-6, abs=1e-5)
                     else:
                         assert got.snr == pytest.approx(g[k + "_snr"][b], rel=1e-5, abs=1e-9)
                         assert got.tone_deviation == pytest.approx(g[k + "_tonedev"][b], rel=1e-5, abs=1e-5)
-                    if got.frame == ol.FRAME_DATA and (b < 50 or not p.pll_enable):
+                    if got.frame == ol.FRAME_DATA and (b < _strict_blocks(k) or not p.pll_enable):
                         ndata[i] += 1
                         assert _pcm_close(p, pcm[i], g[k + "_pcm"][b], olen * p.channels, 8e-6), (k, b)
             assert (ndata >= 5).all()

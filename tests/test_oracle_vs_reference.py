@@ -449,7 +449,7 @@ def test_pll_oscillator_matches_reference_osc_c(oracle_built):
         assert abs(s2.value - np.sin(th)) < 2e-9 and abs(c2.value - np.cos(th)) < 2e-9      # what the table + Taylor step is good for
 
 
-def _coherent_case(r, nblk, N, square):
+def _coherent_case(r, nblk, N, square, last=50, first=4):
     """A carrier 30 Hz off tune (5 Hz for the squaring loop, which false-locks near fs/4 when it is left to run on noise with a
     wide bandwidth) that comes up at block 4 and goes away at block 50; AM (or, for the squaring loop, BPSK) on it"""
     t = np.arange(nblk * N)
@@ -458,7 +458,7 @@ def _coherent_case(r, nblk, N, square):
         mod = np.sign(np.sin(2 * np.pi * 31.25 * t / fs + 0.3))                 # phase reversals: only a squaring loop locks
     else:
         mod = 1 + 0.5 * np.sin(2 * np.pi * 400 * t / fs)
-    lvl = np.where((t >= 4 * N) & (t < 50 * N), 0.02, 0.0)
+    lvl = np.where((t >= first * N) & (t < last * N), 0.02, 0.0)
     x = lvl * mod * np.exp(2j * np.pi * ((5.0 if square else 30.0) * t / fs) + 0.7j)
     x = x + (r.standard_normal(nblk * N) + 1j * r.standard_normal(nblk * N)) * 4e-4
     bb = x.astype(np.complex64).reshape(nblk, N)
