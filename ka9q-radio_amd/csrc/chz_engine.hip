@@ -524,16 +524,16 @@ int chz_input_write_device(chz_engine* e, const float* dev, long n) {
 // rx888.c's convert() + write_rfilter(.., NULL, n) (src/rx888.c:753-767,800-829): the samples stay int16
 // all the way into HBM (half the PCIe and half the first pass's read bytes); scaling, de-randomising,
 // the energy sum and the clip count happen where the first transform pass loads them.
+static inline int blue_grid(long n);
 static int ring16_write(chz_engine* e, const short* src, long n, float scale, int randomize, hipMemcpyKind kind) {
   if (e->in_type != CHZ_REAL) return fail(-1, "int16 input is a real A/D stream");
-  if (e->blue) return fail(-3, "int16 input is converted inside the first pass of a directly planned master; N=%d runs as chirp-z: feed it float samples", e->N);
   if (n < 0 || n > e->ring_len) return fail(-1, "write of %ld samples does not fit the ring", n);
   HIPOK(hipSetDevice(e->device));
   if (!e->ring16) {
     if (e->wpos != (long)(e->M - 1)) return fail(-1, "int16 and float input cannot be mixed on one engine");
     HIPOK(hipMalloc((void**)&e->ring16, sizeof(short) * (size_t)e->ring_len));
     HIPOK(hipMemset(e->ring16, 0, sizeof(short) * (size_t)e->ring_len));
-    e->stat_n = e->plan.grid1 * (e->plan.block1 / 64);
+    e->stat_n = e->blue ? blue_grid(e->blue->Mz) * 4 : e->plan.grid1 * (e->plan.block1 / 64);     // per-wave partials of the pass that loads the samples
     HIPOK(hipMalloc((void**)&e->energy_part, sizeof(unsigned long long) * (size_t)CHZ_ND * e->stat_n));
     HIPOK(hipMalloc((void**)&e->clip_part, sizeof(unsigned) * (size_t)CHZ_ND * e->stat_n));
     HIPOK(hipMemset(e->energy_part, 0, sizeof(unsigned long long) * (size_t)CHZ_ND * e->stat_n));
@@ -758,7 +758,11 @@ static int enqueue_forward_blue(chz_engine* e, unsigned job, int ln, hipStream_t
   float2* lbuf = e->lanes[ln].buf;
   const SpecLayout zlay{b.zp.Na, b.zp.spec_pitch, b.zp.spec_off};
   mark(in, st, 0, true);
-  BluePreParams pre{e->ring, e->ring_len, start, e->per, b.chirp, b.za[ln], e->N, b.Mz};
+  BluePreParams pre{e->ring, e->ring_len, start, e->per, b.chirp, b.za[ln], e->N, b.Mz, nullptr, 1.0f, 0, 0, nullptr, nullptr};
+  if (e->ring16) {
+    pre.ring16 = e->ring16; pre.scale16 = e->scale16; pre.derand = e->derand; pre.new_from = e->M - 1;
+    pre.energy_part = e->energy_part + (size_t)slot * e->stat_n; pre.clip_part = e->clip_part + (size_t)slot * e->stat_n;
+  }
   CHZ_LAUNCH(blue_pre, blue_grid(b.Mz), 256, 0, st, IN_E0(in), IN_E1(in), pre);
   mark(in, st, 0, false);
   int r = blue_fft(e, b.za[ln], lbuf, b.zs[ln], st);

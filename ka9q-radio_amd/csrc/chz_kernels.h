@@ -1247,18 +1247,40 @@ __global__ void __launch_bounds__(256) chan_c2r(ChanParams p) {
 //   blue_mul   za[k] = conj(Z[k] * Bf[k])            Z = F(za) in the planned transform's own storage order, Bf = F(conj(c) wrapped)
 //   blue_post  X[k]  = c[k] * conj(Z'[k]) / Mz       the master's bins, in the master's spectrum layout
 // ------------------------------------------------------------------------------
-struct BluePreParams { const float* ring; long ring_len, start; int per; const float2* chirp; float2* za; int N; long Mz; };
+struct BluePreParams {
+  const float* ring; long ring_len, start; int per; const float2* chirp; float2* za; int N; long Mz;
+  // SURVEY 8(f) rank 3 on a chirp-z master (round 4): raw A/D samples converted on load, as fwd_first_real does (src/rx888.c:753-767)
+  const short* ring16; float scale16; int derand, new_from;
+  unsigned long long* energy_part; unsigned* clip_part;              // [grid * waves] partials over the block's NEW samples, or nullptr
+};
 __global__ void __launch_bounds__(256) blue_pre(BluePreParams p) {
   const long stride = (long)gridDim.x * blockDim.x;
+  unsigned long long energy = 0; unsigned clips = 0;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.Mz; i += stride) {
     float2 v = make_float2(0.f, 0.f);
     if (i < p.N) {
       long idx = p.start + i * p.per;
       if (idx >= p.ring_len) idx -= p.ring_len;                      // (a window is never longer than the ring)
-      const float2 x = p.per == 1 ? make_float2(p.ring[idx], 0.f) : make_float2(p.ring[idx], p.ring[idx + 1]);
+      float2 x;
+      if (p.ring16 != nullptr) {                                     // REAL masters only (per == 1)
+        int a = (int)p.ring16[idx];
+        if (p.derand) { a ^= -(a & 1) & 0xfffe; a = (int)(short)a; }
+        float fa = (float)a * p.scale16;
+        CHZ_ROUNDED_F32(fa);
+        x = make_float2(fa, 0.f);
+        if (i >= p.new_from) { energy += (unsigned)(a * a); clips += (a > 32766 || a < -32766); }
+      } else x = p.per == 1 ? make_float2(p.ring[idx], 0.f) : make_float2(p.ring[idx], p.ring[idx + 1]);
       v = cmul(x, p.chirp[i]);
     }
     p.za[i] = v;
+  }
+  if (p.energy_part != nullptr) {                                    // uniform; every lane takes part in the shuffles
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { energy += __shfl_xor(energy, d); clips += __shfl_xor(clips, d); }
+    if ((threadIdx.x & 63) == 0) {
+      const int w = (int)blockIdx.x * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
+      p.energy_part[w] = energy; p.clip_part[w] = clips;
+    }
   }
 }
 struct BlueMulParams { const float2* zs; const float2* bf; float2* za; SpecLayout lay; long Mz; };

@@ -112,5 +112,37 @@ def main(world, nblk):
     print("fake-rccl ranks ok: world=%d blocks=%d channel-blocks checked=%d" % (world, nblk, checked))
 
 
+def rendezvous():
+    """chz_comm_create_file with a launch id (env CHZ_LAUNCH_ID): rank 1 comes up FIRST and finds the fresh left-over of another launch
+    (same path, another id) -- it must keep waiting for rank 0's file instead of joining a communicator that will never form."""
+    import tempfile
+    import time
+    pkg = load_pkg()
+    os.environ["CHZ_LAUNCH_ID"] = "launch-42"
+    path = os.path.join(tempfile.mkdtemp(), "chz_id")
+    open(path, "wb").write(b"\x55" * 128 + b"launch-41".ljust(64, b"\0"))          # a crashed launch's file, seconds old
+    done, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            c = pkg.engine.Comm(rank, 2, device=0, path=path, timeout_s=30.0)
+            c.barrier()
+            done[rank] = time.monotonic()
+            c.close()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    t1 = threading.Thread(target=rank_main, args=(1,)); t1.start()
+    time.sleep(1.0)
+    assert 1 not in done and not errors, ("rank 1 took the stale file", done, errors)
+    t0 = threading.Thread(target=rank_main, args=(0,)); t0.start()
+    t0.join(60); t1.join(60)
+    assert not errors and 0 in done and 1 in done, (errors, done)
+    print("rendezvous ok")
+
+
 if __name__ == "__main__":
-    main(int(sys.argv[1]), int(sys.argv[2]))
+    if sys.argv[1] == "rendezvous":
+        rendezvous()
+    else:
+        main(int(sys.argv[1]), int(sys.argv[2]))

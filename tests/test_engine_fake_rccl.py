@@ -32,3 +32,11 @@ def test_sharded_block_loop_with_several_ranks(emulated_engine, fake_rccl, world
                        capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "fake-rccl ranks ok: world=%d" % world in r.stdout
+
+
+def test_rendezvous_file_carries_the_launch_id(emulated_engine, fake_rccl):  # noqa: F811
+    """round 3 advisor: a restarted rank that comes up before rank 0 must not read the id a crashed launch left at the same path"""
+    env = dict(os.environ, CHZ_LIB=emulated_engine, CHZ_ALLOW_EMULATED_ENGINE="1", CHZ_RCCL_LIB=fake_rccl)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fake_rccl_ranks.py"), "rendezvous", "0"],
+                       capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode == 0 and "rendezvous ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

@@ -804,7 +804,8 @@ def test_tuned_bank_pipelined_over_streams(pkg):
 # ------------------------------------------------------------------------------
 # raw int16 A/D samples converted where the first pass loads them
 # ------------------------------------------------------------------------------
-@pytest.mark.parametrize("L,M,randomize", [(25920, 6481, False), (1296000, 324001, True), (2592000, 648001, False)])
+# (25920, 6483): N = 32402 = 2 x 17 x 953 runs as chirp-z -- round 4: raw A/D samples are converted where blue_pre loads them
+@pytest.mark.parametrize("L,M,randomize", [(25920, 6481, False), (1296000, 324001, True), (2592000, 648001, False), (25920, 6483, True)])
 def test_int16_input_matches_convert_then_float_path(pkg, L, M, randomize):
     rng = np.random.default_rng(L)
     scale = np.float32(ol.scale_ad(True, 16, 0.0, 0.0, 0.0))
