@@ -1102,6 +1102,9 @@ int chz_set_notches_alpha(chz_engine* e, const int* bins, const double* alpha, i
   HIPOK(hipDeviceSynchronize());
   e->notch_tab = t; e->notch_alpha_h.assign(alpha, alpha + n);
   e->notch_tickets = 0;
+  // fault injection for the hosts' recovery paths (tests/test_dropin.py): the host's tickets start one ahead of the device's counter, so
+  // the first notch waits for a turn that never comes, runs out of its budget and raises the error word -- what a wedged predecessor does
+  if (const char* fs = getenv("CHZ_FAULT_TICKET_SKEW")) e->notch_tickets = (unsigned)atoi(fs);
   e->n_notch = n;
   e->notch_fold = RowsNotch{};
   const char* nf = getenv("CHZ_NOTCH_FOLD");
