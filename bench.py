@@ -273,35 +273,45 @@ def cpu_baseline(oracle_lib, ring, wl, seconds=12.0, crt_blocks=500):
     # keeps up at all, so the reference's own criterion is the fair one.  Ascending ladder around the free-running estimate.
     crt_cpu = None
     if hasattr(R, "refchz_bench_blocks") and wl.get("real", True):
-        def ladder(workers, est):
-            probes, best = [], None
-            for frac in (0.7, 1.0, 1.3):
-                n = max(64, int(est * frac) // 64 * 64)
-                m = oracle_lib.RefMaster(wl["L"], wl["M"], oracle_lib.REAL, worker_threads=workers)
-                chans = []
-                for i in range(n):
-                    shift, low, high = plan[i % len(plan)]
-                    c = m.channel(olen, oracle_lib.COMPLEX); c.set_filter(low, high, 11.0); chans.append(c)
-                harr = (ctypes.c_void_p * n)(*[c.h for c in chans])
-                sh = np.array([plan[i % len(plan)][0] for i in range(n)], np.int32)
-                st = (ctypes.c_double * 4)()
-                R.refchz_bench_blocks(m.h, harr, sh.ctypes.data, n, ring.ctypes.data, RING_BLOCKS, crt_blocks + 8, pool, 8, st, int(BLOCKTIME * 1e6))
-                m.close()
-                pr = {"channels": n, "blocks": crt_blocks, "fft_workers": workers, "block_drops": int(st[3]), "worst_completion_interval_ms": st[0],
-                      "mean_completion_interval_ms": st[1], "worst_latency_ms": st[2],
-                      "sustained": bool(st[3] == 0 and st[2] <= 4 * BLOCKTIME * 1e3)}
-                probes.append(pr)
-                if not pr["sustained"]:
-                    break
+        def probe(m, chans, n, workers):
+            while len(chans) < n:
+                shift, low, high = plan[len(chans) % len(plan)]
+                c = m.channel(olen, oracle_lib.COMPLEX); c.set_filter(low, high, 11.0); chans.append(c)
+            harr = (ctypes.c_void_p * n)(*[c.h for c in chans[:n]])
+            sh = np.array([plan[i % len(plan)][0] for i in range(n)], np.int32)
+            st = (ctypes.c_double * 4)()
+            R.refchz_bench_blocks(m.h, harr, sh.ctypes.data, n, ring.ctypes.data, RING_BLOCKS, crt_blocks + 8, pool, 8, st, int(BLOCKTIME * 1e6))
+            return {"channels": n, "blocks": crt_blocks, "fft_workers": workers, "block_drops": int(st[3]), "worst_completion_interval_ms": st[0],
+                    "mean_completion_interval_ms": st[1], "worst_latency_ms": st[2],
+                    "sustained": bool(st[3] == 0 and st[2] <= 4 * BLOCKTIME * 1e3)}
+        # geometric ladder (x4 per rung from 1024: the channel side of the CPU path is cheap, the forward transform is what costs), then ONE
+        # bisection step between the last sustained and the first failed count; every rung is 500 paced blocks = 10 s of wall clock
+        m = oracle_lib.RefMaster(wl["L"], wl["M"], oracle_lib.REAL, worker_threads=2)
+        chans, probes, best, failed = [], [], None, None
+        n = 1024
+        while n <= 262144:
+            pr = probe(m, chans, n, 2)
+            probes.append(pr)
+            if not pr["sustained"]:
+                failed = pr
+                break
+            best = pr
+            n *= 4
+        if best and failed:
+            mid = int((best["channels"] * failed["channels"]) ** 0.5) // 64 * 64
+            pr = probe(m, chans, mid, 2)
+            probes.append(pr)
+            if pr["sustained"]:
                 best = pr
-            return best, probes
-        est2 = len(plan) * BLOCKTIME / per_block2
-        best, probes = ladder(2, est2)
-        crt_cpu = {"channels": best["channels"] if best else 0, "sustained": bool(best), "blocks_per_probe": crt_blocks, "fft_workers": 2, "cores": 2 + pool,
+        m.close()
+        crt_cpu = {"channels": best["channels"] if best else 0, "sustained": bool(best), "limit_above_ladder": bool(best and not failed), "blocks_per_probe": crt_blocks,
+                   "fft_workers": 2, "cores": 2 + pool,
                    "block_drops": best["block_drops"] if best else None, "worst_latency_ms": best["worst_latency_ms"] if best else None, "probes": probes,
-                   "definition": "front end paced at one block per 20 ms of wall clock, never waiting (as an A/D); the largest channel count of the ladder at which, "
+                   "definition": "front end paced at one block per 20 ms of wall clock, never waiting (as an A/D); the largest probed channel count at which, "
                                  "over %d blocks, no channel was lapped (block_drops = 0, src/filter.c:686-701) and no block took longer than 4 block times from arrival "
-                                 "to its last channel; 2 FFT worker threads (docs/ka9q-radio.md:232) + %d channel threads" % (crt_blocks, pool)}
+                                 "to its last channel; 2 FFT worker threads (docs/ka9q-radio.md:232) + a POOL of %d channel threads each looping over a static channel "
+                                 "subset (SURVEY 8d; radiod itself runs one thread per channel and stops at Nchannels = 2000, src/radio.h:356); ladder x4 from 1024 "
+                                 "+ one bisection step" % (crt_blocks, pool)}
     R.oracle_fft_set_precision(0)
     out = {
         "value": len(plan) * BLOCKTIME / per_block, "unit": "channels",

@@ -61,6 +61,9 @@ case "$name" in
   profile)   # the round's profile: kernel trace (4 streams and 1), PMC passes, summaries for profiles/
     GRAFT_REPO_ROOT=$PWD bash scripts/gpu_profile.sh r04 > "$out/profile.txt" 2>&1; echo "profile rc=$?" >> "$out/rc.txt"
     ;;
+  cpu)       # headline + the CPU baseline leg only
+    $B --no-crt --no-next-rows --no-dropin --no-dropin-paced --no-crt-pcie > "$out/bench_cpu.json" 2> "$out/err.txt"; echo "bench rc=$?" >> "$out/rc.txt"
+    ;;
   tests)     # the whole GPU suite, as the driver runs it
     timeout 2400 python -m pytest tests -m gpu -x -q --timeout 900 > "$out/gpu_suite.txt" 2>&1; echo "suite rc=$?" >> "$out/rc.txt"
     ;;
