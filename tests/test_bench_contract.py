@@ -62,6 +62,32 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
     assert [x["mode"] for x in nr] == ["linear", "pll", "fm"] and all("error" not in x for x in nr), nr
     assert all(x["channels"] == 297984 and x["fits_20ms"] and all(v > 0 for v in x["ns_per_channel"].values()) for x in nr)
     assert all(x["blocks"] == 30 and x["d2h_bytes_per_block"] == x["channels"] * x["d2h_bytes_per_channel"] for x in pc)
+    # round 4: every scale leg compares sampled channels (incl. the highest index) with the oracle after its timed blocks ...
+    assert crt["verified_channels"] >= 64 and crt["max_rel_err"] < 1e-5 and crt["highest_channel_checked"] >= crt["channels"] - 1024 - 3072
+    assert all(x["verified_channels"] >= 64 and x["max_rel_err"] < 1e-5 for x in pc) and pc[1]["pcm_mismatches"] == 0 and pc[2]["pcm_mismatches"] == 0
+    assert all(x["verified_channels"] >= 64 and x["max_rel_err"] < 1e-5 and x["pcm_mismatches"] == 0 and x["verification"]["status_mismatches"] == 0 for x in nr)
+    # ... the boundary runs at wall-clock pace ...
+    pl = j["dropin_paced"]
+    assert len(pl) == 2 and [x["threads"] for x in pl] == [1024, 2000]
+    for x in pl:
+        assert "error" not in x, x
+        pd = x["paced"]
+        assert pd["block_drops"] == 0 and pd["skipped_blocks"] == 0 and pd["blocks_served_to_every_channel"] == pd["blocks_measured"]
+        assert 0 < pd["latency_ms"]["p50"] < 20.0 and 19.0 < x["ms_per_block"] < 24.0          # one block per 20 ms on the front end's clock (+ start-up and tear-down spread over 60 blocks)
+    # ... the CPU leg is like for like, and the line says what each leg cost
+    cc = cpu["c_rt_cpu"]
+    assert cc["probes"] and "block_drops" in cc["probes"][0] and cpu["us_per_channel_block"] > 0 and cpu["fwd_fft_ms"] > 0
+    assert j["quick"] is False and set(j["leg_seconds"]) >= {"c_rt", "cpu_baseline", "dropin", "dropin_paced", "c_rt_pcie", "next_rows"}
+    assert roof["profiles_match_this_tree"]["kernel_sources_sha16"]
+
+
+@pytest.mark.gpu
+def test_bench_quick_mode_is_the_headline_only():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--quick"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.strip()][-1])
+    assert j["quick"] is True and j["value"] > 0 and j["roofline"]["frac"] > 0
+    assert j["c_rt"] is None and j["cpu_baseline"] is None and j["dropin"] is None and j["dropin_paced"] is None and j["c_rt_pcie"] is None and j["next_rows"] is None
 
 
 @pytest.mark.gpu
@@ -70,6 +96,7 @@ def test_bench_other_configs_run_on_one_gpu(extra, cfg):
     env = dict(os.environ)
     if cfg == 4:
         env["BENCH_FORCE_DIST"] = "1"          # one rank, but through the process group and the RCCL exchange behind the C ABI
+        env["BENCH_ALL_EXCHANGES"] = "1"       # ... every hand-over: spectrum rows, whole slot, and (round 4) the block's samples
         env["MASTER_PORT"] = "29617"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-crt",
                         "--no-cpu-baseline", "--min-seconds", "0.05", "--no-crt-pcie", "--no-next-rows", "--dropin-blocks", "40"] + extra,
@@ -84,6 +111,8 @@ def test_bench_other_configs_run_on_one_gpu(extra, cfg):
         assert len(j["dropin"]) == 3 and all("error" not in x for x in j["dropin"])
     if cfg == 4:
         assert "RCCL" in j["exchange"] and "replicate" in j["legs"]
+        assert {"samples", "subband", "broadcast", "replicate"} <= set(j["legs"]) | {"broadcast" if "whole spectrum slot" in j["exchange"] else "subband"}
+        assert all(v["value"] > 0 for v in j["legs"].values())
     if cfg == 5:
         assert "replicas only" in j["exchange"]
 

@@ -161,3 +161,57 @@ def test_two_rank_broadcast_pipeline_matches_single_process(oracle_built):
         want = np.stack([ol.channel(spec, ol.REAL, P, OLEN, shifts[c], resp[c]) for c in range(NCH)])
         got = np.concatenate([r[3][job] for r in results])
         np.testing.assert_array_equal(got, want)
+
+
+def _samples_worker(rank, world, port, q):
+    """SURVEY 8e's alternative hand-over (round 4, chz_run_blocks_sharded mode 2): the block's L new samples travel, every rank
+    keeps its own overlap history and runs the forward transform itself."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load_pkg()
+    x, shifts, resp = _inputs()
+    first, last = pkg.sharding.shard_channels(NCH, rank, world)
+    stream = ol.Stream(L, M, ol.REAL)                      # EVERY rank has a master: same zero history before the first block
+    blocks = [torch.zeros(L, dtype=torch.float32) for _ in range(4)]
+    outs = {}
+    spectra = {}
+
+    def forward(job):                                       # root only: the A/D delivers block `job` into the root's ring
+        blocks[job % 4].copy_(torch.from_numpy(x[job * L:(job + 1) * L]))
+
+    def broadcast(job):
+        return dist.broadcast(blocks[job % 4], src=0, async_op=True)
+
+    def channels(job):
+        spec = stream.push(blocks[job % 4].numpy())
+        spectra[job] = spec
+        outs[job] = [ol.channel(spec, ol.REAL, P, OLEN, shifts[c], resp[c]) for c in range(first, last)]
+
+    pkg.sharding.pipelined_blocks(range(NBLK), rank == 0, forward, broadcast, channels)
+    q.put((rank, first, last, {j: np.stack(v) if v else np.zeros((0, OLEN), np.complex64) for j, v in outs.items()}, spectra[NBLK - 1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sample_exchange_matches_single_process(oracle_built):
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_samples_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results.sort(key=lambda r: r[0])
+    x, shifts, resp = _inputs()
+    st = ol.Stream(L, M, ol.REAL)
+    for job in range(NBLK):
+        spec = st.push(x[job * L:(job + 1) * L])
+        want = np.stack([ol.channel(spec, ol.REAL, P, OLEN, shifts[c], resp[c]) for c in range(NCH)])
+        got = np.concatenate([r[3][job] for r in results])
+        np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(results[0][4], results[1][4])     # every rank computed the same spectrum from the same samples
