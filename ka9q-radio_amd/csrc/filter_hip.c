@@ -130,6 +130,7 @@ struct mctx {
   bool failed;                      /* set by the completion callback / the producer when the engine reports a failure (atomic) */
   unsigned recoveries, failed_blocks;
   unsigned last_recovery_job;
+  unsigned engine_first_job;        /* the first block the CURRENT engine was handed: the spectra of earlier blocks died with its predecessor (atomic) */
   double noise_samprate;            /* > 0: banks run the device's estimate_noise() (filter_hip_enable_noise) */
   /* wake-up of the channel threads: the completion callback wakes wake_first of them (0 = all), every woken thread wakes
      wake_fan more (KA9Q_HIP_WAKE="first,fan"; default "0,2") */
@@ -741,6 +742,7 @@ static void recover_engine(struct mctx *c, struct filter_in *f, unsigned job) {
   }
   stage_wrunlock(c);
   c->recoveries++; c->last_recovery_job = job;
+  __atomic_store_n(&c->engine_first_job, job, __ATOMIC_RELEASE);
   __atomic_store_n(&c->failed, false, __ATOMIC_RELEASE);
 }
 
@@ -948,13 +950,18 @@ static void serve_misses(struct mctx *c, struct miss_req *list) {
     if (rc == 0) rc = chz_bank_read_async(c->eng, b->id, r->slot, k, 1,
                                           (float *)((char *)b->stage[r->slot] + (size_t)k * b->olen * bank_sample_bytes(b)));
     if (rc == 0 && b->noise_on) rc = chz_bank_read_noise_async(c->eng, b->id, r->slot, k, 1, b->stage_n0[r->slot] + k);
-    if (rc != 0) fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
+    if (rc != 0) {
+      /* a broken engine (the producer replaces it at its next block): this channel's block is lost with it, once, quietly */
+      if (chz_engine_check(c->eng) != 0 || __atomic_load_n(&c->failed, __ATOMIC_ACQUIRE)) __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE);
+      else fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
+    }
     r->rc = rc;
     touched[r->slot] = true;
   }
   for (int s = 0; s < ND; s++)
     if (touched[s] && chz_slot_sync(c->eng, s) != 0) {
-      fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
+      if (chz_engine_check(c->eng) != 0) __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE);
+      else fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
       for (struct miss_req *r = list; r; r = r->next) if (r->slot == s) r->rc = -1;
     }
   /* the staged image now holds exactly what each requester asked for */
@@ -1073,6 +1080,13 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
       __atomic_fetch_add(hit ? &c->prof_hits : &c->prof_misses, 1ull, __ATOMIC_RELAXED);
     }
     if (hit) return 0;
+    /* a block the PREVIOUS engine completed, asked for after that engine was replaced: its staged results were invalidated and its
+       spectrum is gone -- re-running the channel on the new engine's slot would hand out garbage: zeros + a counted drop */
+    if (c->recoveries && (int)(job - __atomic_load_n(&c->engine_first_job, __ATOMIC_ACQUIRE)) < 0) {
+      slave->block_drops++;
+      memset(dst, 0, (real_out ? sizeof(float) : sizeof(float complex)) * (size_t)slave->olen);
+      return 0;
+    }
 
     /* retuned / new filter / newly created: queue this channel for a re-run on the block's spectrum */
     struct miss_req req = {.slave = slave, .shift = shift, .slot = slot, .job = job};
@@ -1095,7 +1109,14 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
       while (!req.done) pthread_cond_wait(&c->miss_cv, &c->miss_lock);
     }
     pthread_mutex_unlock(&c->miss_lock);
-    if (req.rc != 0) return -1;
+    if (req.rc != 0) {
+      if (__atomic_load_n(&c->failed, __ATOMIC_ACQUIRE)) {          /* the engine died under this block: zeros + a counted drop, like every block it lost */
+        slave->block_drops++;
+        memset(dst, 0, (real_out ? sizeof(float) : sizeof(float complex)) * (size_t)slave->olen);
+        return 0;
+      }
+      return -1;
+    }
   }
   /* the block's slot was re-used for a later block while this channel waited (it was being lapped) */
   fprintf(stderr, "execute_filter_output: block %u is gone from the device (the channel is more than %d blocks behind)\n", job, ND - 1);

@@ -519,12 +519,49 @@ def test_dropin_recovers_when_a_notch_ticket_runs_out():
     assert int(meta["clock"]) == nblocks and int(meta["next_jobnum"]) == nblocks
     lost = np.flatnonzero(dropped.all(axis=1))
     assert 1 <= len(lost) <= 8 and np.array_equal(lost, np.arange(lost[0], lost[0] + len(lost))), lost
-    assert int(meta["drops"]) == int(dropped.sum()) == len(lost) * nch
+    assert int(meta["drops"]) == int(dropped.sum()) and len(lost) * nch <= dropped.sum() <= (len(lost) + 3) * nch
     st = ol.Stream(L, M, ol.REAL)
     for b in range(nblocks):
         s64 = st.push(x[b * L:(b + 1) * L], f64=True)
         if b in lost:
             assert not out[b].any()
+            continue
+        for i, p in enumerate(plan):
+            if dropped[b, i]:
+                assert not out[b, i].any()
+                continue
+            want = ol.channel(s64, ol.REAL, P, olen, p[0], ol.set_filter(P, olen, N, True, p[4], p[5], p[6]))     # (channels away from the DC notch)
+            err = float(np.sqrt(np.mean(np.abs(out[b, i] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+            assert err <= 1e-5 * rms + 2e-8 * float(np.abs(s64).max()) * 4, (b, i, err, rms)
+
+
+@pytest.mark.gpu
+def test_dropin_at_wall_clock_pace():
+    """The boundary the way radiod runs it (src/sig_gen.c:357-362, src/filter.c:686-701): the front end on its own 20 ms
+    clock (absolute deadlines, chunks as an A/D delivers them), never waiting for a channel; 96 channel threads blocking in
+    execute_filter_output.  Nobody may be lapped, no block may be skipped, and from the ninth block on the LAST channel thread must have
+    its block well inside one period after the block's last sample was written; what they get is exact."""
+    _build_lib(); ol.build()
+    L, M, olen, P = 25920, 6481, 240, 300
+    N = L + M - 1
+    nblocks, nch = 60, 96
+    rng = np.random.default_rng(44)
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = [(int(rng.integers(500, 12000)) * (1 if i % 2 else -1),) * 2 + (10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4) for i in range(nch)]
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x, env={"HARNESS_PACED_US": "20000"})
+        lat = np.fromfile(os.path.join(tmp, "latency.bin"), np.int64).reshape(nblocks, 2)
+        skipped = np.fromfile(os.path.join(tmp, "skipped.bin"), np.uint8)
+    assert meta["drops"] == "0" and int(meta["skipped"]) == 0 and not skipped.any()
+    assert int(meta["clock"]) == nblocks and 1.15 < float(meta["elapsed_s"]) < 1.6           # 60 blocks of 20 ms, on the front end's clock
+    assert (lat[:, 1] == nch).all()                                                            # every block reached every channel
+    steady = lat[8:, 0] / 1e6
+    assert steady.max() < 20.0 and np.median(steady) < 5.0, (steady.max(), np.median(steady))
+    st = ol.Stream(L, M, ol.REAL)
+    for b in range(nblocks):
+        s64 = st.push(x[b * L:(b + 1) * L], f64=True)
+        if b % 7:
             continue
         for i, p in enumerate(plan):
             want = ol.channel(s64, ol.REAL, P, olen, p[0], ol.set_filter(P, olen, N, True, p[4], p[5], p[6]))     # (channels away from the DC notch)

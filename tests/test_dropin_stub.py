@@ -244,14 +244,18 @@ def _recovery_run(tmp_path, san, env, nblocks=16, nch=20):
     rng = np.random.default_rng(77)
     g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
     x = g.generate(nblocks * L)
-    plan = [(int(rng.integers(500, 12000)) * (1 if i % 2 else -1),) * 2 + (10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4) for i in range(nch)]
+    plan = []
+    for i in range(nch):
+        sh = int(rng.integers(500, 12000)) * (1 if i % 2 else -1)
+        plan.append((sh, sh + (37 if sh > 0 else -37), 10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4))     # (the second shift: HARNESS_RETUNE_MOD)
     run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
     r = _run(exe, run_dir, L, M, olen, plan, nblocks, x, dict(env, HARNESS_RECORD_DROPS="1"))
     return r, run_dir, x, plan
 
 
 @pytest.mark.parametrize("san", ["thread", "address"])
-def test_dropin_replaces_a_failed_engine_and_carries_on(tmp_path, san):
+@pytest.mark.parametrize("retune", [0, 2], ids=["steady", "channels_retuning_every_other_block"])
+def test_dropin_replaces_a_failed_engine_and_carries_on(tmp_path, san, retune):
     """Failure policy (round 4): the engine reports a failed device-side check from block 5 on (injected into the stand-in engine, as a
     notch ticket that ran out would).  The drop-in drops what that engine still delivers (zeros + block_drops for every slave),
     replaces the engine ONCE -- responses, shifts, notch list re-registered, the overlap history re-seated from the host ring --
@@ -259,7 +263,9 @@ def test_dropin_replaces_a_failed_engine_and_carries_on(tmp_path, san):
     if not _have("-fsanitize=" + san):
         pytest.skip("no -fsanitize=%s runtime in this image" % san)
     nblocks, nch = 16, 20
-    r, run_dir, x, plan = _recovery_run(tmp_path, san, {"CHZ_STUB_FAIL_JOB": "5"}, nblocks, nch)
+    # (retune: half of the channels change their shift every other block, so misses are being served while the engine dies: those become
+    #  drops of the lost blocks too, never an error return)
+    r, run_dir, x, plan = _recovery_run(tmp_path, san, dict({"CHZ_STUB_FAIL_JOB": "5"}, **({"HARNESS_RETUNE_MOD": str(retune)} if retune else {})), nblocks, nch)
     assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-6000:]
     assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
     assert r.stderr.count("re-creating the engine") == 1 and r.stderr.count("execute_filter_input:") <= 1, r.stderr[-2000:]
@@ -272,7 +278,8 @@ def test_dropin_replaces_a_failed_engine_and_carries_on(tmp_path, san):
     assert int(meta["clock"]) == nblocks and int(meta["next_jobnum"]) == nblocks
     lost = np.flatnonzero(dropped.all(axis=1))
     assert 1 <= len(lost) <= 8 and lost[0] >= 5 and np.array_equal(lost, np.arange(lost[0], lost[0] + len(lost))), lost   # one gap, recovered within 8 blocks
-    assert int(meta["drops"]) == int(dropped.sum()) == len(lost) * nch                                                    # every lost block is a counted drop
+    # every lost block is a counted drop for everybody; a slow channel may also lose (and count) up to 3 blocks the old engine had completed but it had not fetched yet
+    assert int(meta["drops"]) == int(dropped.sum()) and len(lost) * nch <= dropped.sum() <= (len(lost) + 3) * nch
     st = ol.Stream(L, M, ol.REAL)
     for b in range(nblocks):
         s64 = st.push(x[b * L:(b + 1) * L], f64=True)
@@ -280,7 +287,11 @@ def test_dropin_replaces_a_failed_engine_and_carries_on(tmp_path, san):
             assert not out[b].any()
             continue
         for i, p in enumerate(plan):
-            want = ol.channel(s64, ol.REAL, P, olen, p[0], ol.set_filter(P, olen, N, True, p[4], p[5], p[6]))     # (channels away from the DC notch)
+            if dropped[b, i]:
+                assert not out[b, i].any()
+                continue
+            shift = p[1] if (retune and ((b + i) // retune) & 1) else p[0]
+            want = ol.channel(s64, ol.REAL, P, olen, shift, ol.set_filter(P, olen, N, True, p[4], p[5], p[6]))     # (channels away from the DC notch)
             err = float(np.sqrt(np.mean(np.abs(out[b, i] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
             assert err <= 1e-5 * rms + 2e-8 * float(np.abs(s64).max()), (b, i, err, rms)
 
