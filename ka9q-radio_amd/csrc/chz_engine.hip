@@ -1060,7 +1060,9 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
     d.lin_pll = b.dm_pll_lin > 0; d.fm_pll = b.dm_fm_pll > 0; d.fm_tone = b.dm_fm_tone > 0;
     d.mix = (d.lin_pll || d.fm_pll || d.fm_tone) ? b.dm_mix : nullptr;
     demod_paths(e, b, d);
-    d.agc_peak = (b.agc_peak_valid[slot] && d.lin_lanes) ? b.agc_peak + so : nullptr;
+    if (b.agc_peak && d.lin_lanes) {       // the AGC's first look: left by the channel kernel and, for coherent-mode channels, by pll_lanes
+      d.agc_peak = b.agc_peak + so; d.peak_chan = b.agc_peak_valid[slot] ? 1 : 0; d.peak_pll = (d.lin_pll && d.mix != nullptr) ? 1 : 0;
+    }
     mark(in, ts, 6, true);
     if (launch_demod(ts, d, IN_E0(in), IN_E1(in))) return fail(-4, "the demodulator kernel refuses blocks of %d samples", b.olen);
     mark(in, ts, 6, false);
@@ -1634,6 +1636,7 @@ int chz_bank_demod(chz_engine* e, int bank, unsigned job, int slot) {
   d.lin_pll = b.dm_pll_lin > 0; d.fm_pll = b.dm_fm_pll > 0; d.fm_tone = b.dm_fm_tone > 0;
     d.mix = (d.lin_pll || d.fm_pll || d.fm_tone) ? b.dm_mix : nullptr;
     demod_paths(e, b, d);
+  if (b.agc_peak && d.lin_lanes) { d.agc_peak = b.agc_peak + so; d.peak_chan = 0; d.peak_pll = (d.lin_pll && d.mix != nullptr) ? 1 : 0; }
   if (b.pcm_copying[slot]) HIPOK(hipStreamWaitEvent(e->tail, b.ev_pcm[slot], 0));
   if (launch_demod(e->tail, d)) return fail(-4, "the demodulator kernel refuses blocks of %d samples", b.olen);
   HIPOK(hipGetLastError());

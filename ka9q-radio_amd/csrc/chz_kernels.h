@@ -1664,8 +1664,11 @@ struct DemodParams {
   int wave_any;              // the bank has channels demod_linear_tail must serve (FM; PLL channels without the scratch block)
   int lin_pll, fm_pll, fm_tone;   // the bank has channels with a carrier PLL (linear) / the PLL demodulator (FM) / a PL-tone squelch (FM): which
                              // of the lane-per-channel passes launch_demod adds; they need `mix`
-  const double* agc_peak;    // [cap] this slot, or nullptr: the block's largest slice energy as chan_ifft left it (the AGC's first look at the
-                             // block, src/linear.c:177-203); valid for channels without a post-detection shift and without a PLL
+  double* agc_peak;          // [cap] this slot, or nullptr: the block's largest 2 ms slice energy (the AGC's first look at the block,
+                             // src/linear.c:177-203), left by whoever had the block's samples in hand last: chan_ifft (peak_chan: channels outside the
+                             // coherent modes) or pll_lanes (peak_pll: the mixed block of a coherent-mode channel); not valid for a channel with a
+                             // post-detection shift, which rotates the block once more
+  int peak_chan, peak_pll;
   float2* mix;               // [cap][olen] or nullptr: the coherent modes' blocks after their PLL (written by pll_lanes, one CHANNEL PER LANE);
                              // nullptr: lane 0 of each channel's wavefront walks the block inside demod_linear_tail (round 2's way)
 };
@@ -2126,6 +2129,11 @@ __global__ void __launch_bounds__(64, 2) pll_lanes(DemodParams p) {
       if (((act >> r) & 1ull) && n < tn) regs[k] = p.in[(size_t)(base + r) * N + t0 + n];
     }
   };
+  // the AGC's first look at the block demod_linear() takes after the PLL (src/linear.c:177-203): the largest energy of a 2 ms slice of
+  // the MIXED block, slices in order -- this lane walks exactly those samples in exactly that order, so it keeps the sum (round 4)
+  int sps = (int)rint(N * .002 / p.blocktime);
+  sps = sps < 1 ? 1 : sps;
+  double peak = 0.0, energy = 0.0; int in_slice = 0;
   fetch_tile(0);
   for (int t0 = 0; t0 < N; t0 += PLL_TILE) {
     const int tn = N - t0 < PLL_TILE ? N - t0 : PLL_TILE;
@@ -2142,7 +2150,17 @@ __global__ void __launch_bounds__(64, 2) pll_lanes(DemodParams p) {
         const float2 v = tile[lane * LD + n];
         const double br = v.x, bi = v.y;
         const double sr = br * cs + bi * sn, si = bi * cs - br * sn;           // buffer[n] * conj(vco)
-        tile[lane * LD + n] = make_float2((float)sr, (float)si);
+        const float2 mixed = make_float2((float)sr, (float)si);
+        tile[lane * LD + n] = mixed;
+        {
+          float a = mixed.x * mixed.x, b = mixed.y * mixed.y;
+          CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
+          energy += (double)(a + b);                                          // cnrmf, as demod_lin_lanes' first pass summed it
+          if (++in_slice == sps) {
+            if (t0 + n + 1 < N && energy > peak) peak = energy;
+            energy = 0.0; in_slice = 0;
+          }
+        }
         double phase;
         if (q.lock) {
           if (!square) { const double mag = sqrt(sr * sr + si * si); phase = (mag > 0) ? si / mag : 0.0; }
@@ -2180,6 +2198,7 @@ __global__ void __launch_bounds__(64, 2) pll_lanes(DemodParams p) {
       }
     }
     ext->pll = q; ext->pll_snr = pll_snr; ext->pll_cphase = pll_cph; ext->foffset = pll_foff; ext->pll_rotations = pll_rot;
+    if (p.agc_peak != nullptr && p.peak_pll != 0) p.agc_peak[ch] = peak;
   }
 }
 
@@ -2432,9 +2451,10 @@ __global__ void __launch_bounds__(64, 2) demod_lin_lanes(DemodParams p) {
   };
   // ---- AGC (src/linear.c:177-234): the largest slice energy of the block, slices in order
   double gain_change = 1.0;
-  // the channel kernel has already looked at this block (its samples were still in LDS there): the first pass over the baseband is
-  // only walked by lanes whose block is not what that kernel wrote -- a post-detection shift rotates it first, a PLL replaced it
-  const bool have_peak = p.agc_peak != nullptr && !rot && !pll;
+  // whoever had the block's samples in hand last has already looked at it -- the channel kernel (rows in LDS), or pll_lanes for a
+  // coherent-mode channel (its lane walks the mixed block in order anyway): the first pass over the baseband is only walked by lanes
+  // with a post-detection shift, which rotates the block once more
+  const bool have_peak = p.agc_peak != nullptr && !rot && (pll ? p.peak_pll != 0 : p.peak_chan != 0);
   const bool walk1 = active && agc && !have_peak;
   if (__ballot(active && agc) != 0ull) {                   // wave-uniform
     int sps = (int)rint(N * .002 / p.blocktime);

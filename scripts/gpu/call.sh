@@ -64,6 +64,10 @@ case "$name" in
   cpu)       # headline + the CPU baseline leg only
     $B --no-crt --no-next-rows --no-dropin --no-dropin-paced --no-crt-pcie > "$out/bench_cpu.json" 2> "$out/err.txt"; echo "bench rc=$?" >> "$out/rc.txt"
     ;;
+  chain)     # the 8f chain legs only (1.5 M channels, verified) + the large-bank and demodulator tests
+    $B --no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline > "$out/next_rows.json" 2> "$out/err.txt"; echo "bench rc=$?" >> "$out/rc.txt"
+    timeout 1200 python -m pytest tests/test_gpu_scale.py tests/test_gpu_pipeline.py tests/test_golden.py -m gpu -x -q --timeout 600 -k "demod or scale or 70001 or golden or coherent or fm" > "$out/demod_tests.txt" 2>&1; echo "tests rc=$?" >> "$out/rc.txt"
+    ;;
   tests)     # the whole GPU suite, as the driver runs it
     timeout 2400 python -m pytest tests -m gpu -x -q --timeout 900 > "$out/gpu_suite.txt" 2>&1; echo "suite rc=$?" >> "$out/rc.txt"
     ;;
