@@ -2695,7 +2695,36 @@ __global__ void __launch_bounds__(64, 2) demod_fm_lanes(DemodParams p) {
 #pragma unroll
     for (int k = 0; k < STEPS; k++) tilef[(k * RPS + lane / LIN_TILE) * LD + n] = regs[k].x;
   };
-  // ---- SNR (:105-129)
+  // the discriminator (:204-231): phase of x[n] * conj(x[n-1]); the sample before the block is phase_memory.  One sample of it:
+  double psum = 0.0, pmax = 0.0, pmin = 0.0;
+  double pr = st.pm_re, pi = st.pm_im;
+  double p0 = pr * pr + pi * pi;                           // cnrm(phase_memory)
+  if (p0 > 0) p0 /= (p0 + beta * noise);
+  auto discriminate = [&](const float2 v) -> float {
+    const double br = v.x, bi = v.y;
+    const double sr = br * pr + bi * pi, si = bi * pr - br * pi;
+    double phase = M_1_PI * atan2(si, sr);
+    if (extend) {
+      if (fabs(phase) > devmax / samprate) phase = copysign(devmax / samprate, phase);
+      float a = v.x * v.x, b = v.y * v.y; CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
+      double p1 = (double)(a + b);
+      if (p1 > 0) p1 /= (p1 + beta * noise);
+      phase *= p0 * p1;
+      p0 = p1;
+    }
+    const float bbf = (float)phase;
+    const double bbv = (double)bbf;
+    psum += bbv;
+    if (bbv > pmax) pmax = bbv;
+    if (bbv < pmin) pmin = bbv;
+    pr = br; pi = bi;
+    return bbf;
+  };
+  // ---- SNR (:105-129).  The variance estimator walks the block twice (mean amplitude, then the variance around it); the second walk
+  // carries the discriminator along SPECULATIVELY (round 4): a channel that needs the estimator has its squelch open or opening, so
+  // the discriminator will almost always be wanted, and its pass over the baseband -- a third read of the block -- is saved.  Nothing
+  // of it is committed before the squelch sequencer below has decided (the sums and phase_memory are locals, the baseband goes to the
+  // channel's scratch block).
   double fmsnr = snr;
   const bool need_var = active && !(snr_squelch || (st.squelch_state <= 0 && snr < sq_close));
   const unsigned long long var_rows = __ballot(need_var);
@@ -2710,12 +2739,20 @@ __global__ void __launch_bounds__(64, 2) demod_fm_lanes(DemodParams p) {
         if (t0 + LIN_TILE < N) fetch_x(t0 + LIN_TILE, var_rows);
         if (need_var) {
           for (int n = 0; n < tn; n++) {
-            const double a = (double)demod_cabsf(tile[lane * LD + n]);
+            const float2 v = tile[lane * LD + n];
+            const double a = (double)demod_cabsf(v);
             if (pass == 0) avg += a;
-            else { const double dlt = a - avg; var += dlt * dlt; }
+            else { const double dlt = a - avg; var += dlt * dlt; tile[lane * LD + n].x = discriminate(v); }
           }
         }
         CHZ_WAVE_SYNC();
+        if (pass == 1) {
+          for (int r0 = 0; r0 < 64; r0 += RPS) {
+            const int rr = r0 + lane / LIN_TILE, n = lane % LIN_TILE;
+            if (((var_rows >> rr) & 1ull) && n < tn) mixf[(size_t)(base + rr) * 2 * N + t0 + n] = tile[rr * LD + n].x;
+          }
+          CHZ_WAVE_SYNC();
+        }
       }
       if (pass == 0) avg /= N;
     }
@@ -2746,50 +2783,28 @@ __global__ void __launch_bounds__(64, 2) demod_fm_lanes(DemodParams p) {
   }
   const unsigned long long go_rows = __ballot(go);
   if (go_rows == 0ull) return;                             // wave-uniform
-  // ---- pass 3: the discriminator (:204-231): phase of x[n] * conj(x[n-1]); the sample before the block is phase_memory
-  double psum = 0.0, pmax = 0.0, pmin = 0.0;
-  {
-    double pr = st.pm_re, pi = st.pm_im;
-    double p0 = pr * pr + pi * pi;                         // cnrm(phase_memory)
-    if (p0 > 0) p0 /= (p0 + beta * noise);
-    fetch_x(0, go_rows);
+  // ---- pass 3: the discriminator for the lanes that did not carry it through the variance pass (SNR squelch, or the squelch was shut
+  // and has just been told to open by the cheap estimator)
+  const bool late = go && !need_var;
+  const unsigned long long late_rows = __ballot(late);
+  if (late_rows != 0ull) {                                 // wave-uniform
+    fetch_x(0, late_rows);
     for (int t0 = 0; t0 < N; t0 += LIN_TILE) {
       const int tn = N - t0 < LIN_TILE ? N - t0 : LIN_TILE;
       place_x();
       CHZ_WAVE_SYNC();
-      if (t0 + LIN_TILE < N) fetch_x(t0 + LIN_TILE, go_rows);
-      if (go) {
-        for (int n = 0; n < tn; n++) {
-          const float2 v = tile[lane * LD + n];
-          const double br = v.x, bi = v.y;
-          const double sr = br * pr + bi * pi, si = bi * pr - br * pi;
-          double phase = M_1_PI * atan2(si, sr);
-          if (extend) {
-            if (fabs(phase) > devmax / samprate) phase = copysign(devmax / samprate, phase);
-            float a = v.x * v.x, b = v.y * v.y; CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
-            double p1 = (double)(a + b);
-            if (p1 > 0) p1 /= (p1 + beta * noise);
-            phase *= p0 * p1;
-            p0 = p1;
-          }
-          const float bbf = (float)phase;
-          const double bbv = (double)bbf;
-          psum += bbv;
-          if (bbv > pmax) pmax = bbv;
-          if (bbv < pmin) pmin = bbv;
-          tile[lane * LD + n].x = bbf;
-          pr = br; pi = bi;
-        }
-      }
+      if (t0 + LIN_TILE < N) fetch_x(t0 + LIN_TILE, late_rows);
+      if (late)
+        for (int n = 0; n < tn; n++) tile[lane * LD + n].x = discriminate(tile[lane * LD + n]);
       CHZ_WAVE_SYNC();
       for (int r0 = 0; r0 < 64; r0 += RPS) {
         const int rr = r0 + lane / LIN_TILE, n = lane % LIN_TILE;
-        if (((go_rows >> rr) & 1ull) && n < tn) mixf[(size_t)(base + rr) * 2 * N + t0 + n] = tile[rr * LD + n].x;
+        if (((late_rows >> rr) & 1ull) && n < tn) mixf[(size_t)(base + rr) * 2 * N + t0 + n] = tile[rr * LD + n].x;
       }
       CHZ_WAVE_SYNC();
     }
-    if (go) { st.pm_re = pr; st.pm_im = pi; }              // phase_memory = the block's last sample
   }
+  if (go) { st.pm_re = pr; st.pm_im = pi; }                // phase_memory = the block's last sample
   st.pll_was_on = 0;                                       // :209
   if (go && st.squelch_state == smax) {                    // :232-256
     const double foff = psum * (samprate * 0.5 / N);
