@@ -521,6 +521,7 @@ def crt_pcie_leg(pkg, wl, nch, blocks, demod, dev_index, pipelined=False):
         bank.set_active(nch)
         worst = tot = 0.0
         lat_worst = 0.0
+        times = []
         if not pipelined:
             for j in range(blocks + 8):
                 t0 = time.perf_counter()
@@ -533,7 +534,7 @@ def crt_pcie_leg(pkg, wl, nch, blocks, demod, dev_index, pipelined=False):
                 eng.sync()
                 dt = (time.perf_counter() - t0) * 1e3
                 if j >= 8:
-                    worst = max(worst, dt); tot += dt
+                    worst = max(worst, dt); tot += dt; times.append(dt)
         else:
             issued = {}
             last_done = None
@@ -554,7 +555,7 @@ def crt_pcie_leg(pkg, wl, nch, blocks, demod, dev_index, pipelined=False):
                     now = time.perf_counter()
                     if j - 1 >= 8:
                         period = (now - last_done) * 1e3
-                        worst = max(worst, period); tot += period
+                        worst = max(worst, period); tot += period; times.append(period)
                         lat_worst = max(lat_worst, (now - issued[j - 1]) * 1e3)
                     last_done = now
             eng.sync()
@@ -581,6 +582,8 @@ def crt_pcie_leg(pkg, wl, nch, blocks, demod, dev_index, pipelined=False):
             ver = verify_chain(pkg, eng, bank, wl, nch, tile, shifts, resp, one, j0, 6, 64, step)
         mean = tot / blocks
         return {"channels": nch, "blocks": blocks, "worst_block_ms": worst, "mean_block_ms": mean, "sustained": bool(worst <= BLOCKTIME * 1e3),
+                # (the host side of this leg is one Python thread on a shared box: how many blocks, if any, fell outside the slot, and the tail)
+                "blocks_over_20ms": int(sum(t > BLOCKTIME * 1e3 for t in times)), "p99_block_ms": float(np.percentile(times, 99)) if times else None,
                 "verified_channels": ver["verified_channels"], "max_rel_err": ver["max_rel_err"], "pcm_mismatches": ver.get("pcm_mismatches"),
                 "verification": ver,
                 "returns": "mono S16BE PCM + 1 status byte per channel (tuning, noise estimate, linear demodulator on the device)" if demod

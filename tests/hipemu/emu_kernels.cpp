@@ -118,6 +118,43 @@ long emu_spec_index_check(int na, int pitch, int off, long bins) {
     if ((long)spec_index(lay.off, c.magic, c.dpitch, (int)k) != spec_addr(lay, k)) return k;
   return -1;
 }
+// K2 inside fwd_rows (round 4): notch_owner() names the workgroup / thread / output index that stores a listed bin; here the pass's own
+// store arithmetic (fwd_rows in chz_kernels.h, restated line by line) says where THAT thread's K2-th output goes and whether the store
+// happens at all.  Walks bins 0, step, 2*step, ... and the last `tail` bins of the planned master; returns the first bin whose owner
+// would store somewhere else (or not at all), -1 if every probed bin is stored by exactly the named thread, -2 without a plan.
+long emu_notch_owner_check(int N, int in_type, const char* spec, int step, int tail) {
+  FwdPlan p;
+  if (!build_fwd_plan(N, in_type, spec ? spec : "", p)) return -2;
+  const bool real = in_type == CHZ_IN_REAL;
+  const SpecLayout lay{p.Na, p.spec_pitch, p.spec_off};
+  const int R1 = p.rc.r1;
+  const long xrows = (long)p.Nb * p.Nc, half = (long)p.N >> 1;
+  auto check = [&](long bin) -> bool {
+    int wg = 0, tid = 0, k2 = 0;
+    if (!notch_owner(p, real, (int)bin, &wg, &tid, &k2)) return false;
+    // the kernel's own indices for (wg, tid, k2)
+    const int kb = wg % p.Nb, at = wg / p.Nb;
+    const int a0 = at * p.Ta - p.ka_shift;
+    if (tid >= R1 * p.Ta) return false;
+    const int k1 = tid / p.Ta, r = tid - k1 * p.Ta;
+    const int ka = a0 + r;
+    if (ka < 0 || ka >= p.Ra) return false;
+    const bool selfconj = (ka == 0) || (2 * ka == p.Na);
+    const long x0 = kb + (long)p.Nb * k1, xs = (long)p.Nb * R1;
+    const long kk0 = ka + (long)p.Na * x0, kks = (long)p.Na * xs;
+    const long d0 = x0 * lay.pitch + lay.off + ka, ds = xs * lay.pitch;
+    const long m0 = (xrows - 1 - x0) * lay.pitch + lay.off + (p.Na - ka);
+    const bool direct = !real || kk0 + k2 * kks <= half;
+    const long addr = direct ? d0 + k2 * ds : m0 - k2 * ds;
+    const bool stored = direct || !selfconj;
+    return stored && addr == spec_addr(lay, bin);
+  };
+  const long bins = real ? p.N / 2 + 1 : p.N;
+  if (step < 1) step = 1;
+  for (long b = 0; b < bins; b += step) if (!check(b)) return b;
+  for (long b = bins - tail < 0 ? 0 : bins - tail; b < bins; b++) if (!check(b)) return b;
+  return -1;
+}
 int emu_chan_desc(int in_type, int m_bins, int P, int shift, int* out6) {
   ChanDescH d = make_chan_desc(in_type, m_bins, P, shift);
   out6[0] = d.t0; out6[1] = d.cnt; out6[2] = d.src0; out6[3] = d.dir; out6[4] = d.conj; out6[5] = d.wrap;

@@ -589,6 +589,34 @@ def test_planner_covers_the_front_ends_people_run(emu):
     assert not missing, missing
 
 
+def test_notch_owner_names_the_thread_that_stores_the_bin(emu):
+    """Round 4: spur notches of short lists are applied inside fwd_rows by the ONE thread that stores the listed bin, and the host names
+    that thread (notch_owner, chz_launch.h).  For every front-end geometry the planner serves -- REAL and COMPLEX masters, two- and
+    three-axis plans, pitched and natural spectrum layouts, both overlaps -- the pass's own store arithmetic must put that thread's
+    output exactly at the bin's storage address: every 7th bin of the master plus its last 600 (the mirrored stores of a real master
+    sit in the upper rows).  (The kernel checks the address again at run time and raises the engine's error word on a mismatch.)"""
+    emu.emu_notch_owner_check.restype = C.c_long
+    emu.emu_notch_owner_check.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int]
+    real = [129.6e6, 64.8e6, 65.536e6, 32.4e6, 130e6, 125e6, 100e6, 50e6, 25e6, 20e6, 1.296e6, 576e3]
+    cplx = [2.4e6, 2.048e6, 1.8e6, 1.92e6, 3.2e6, 2e6, 2.5e6, 3e6, 4e6, 5e6, 6e6, 8e6, 9.6e6, 10e6, 12.5e6, 20e6,
+            912e3, 921.6e3, 768e3, 384e3, 192e3, 250e3, 1.536e6, 576e3]
+    checked = 0
+    for typ, rates in ((ol.REAL, real), (ol.COMPLEX, cplx)):
+        for fs in rates:
+            L = int(round(fs * 0.02))
+            for M in (L // 4 + 1, L + 1):
+                r = emu.emu_notch_owner_check(L + M - 1, typ, b"", 7, 600)
+                assert r == -1, (fs, M, typ, r)
+                checked += 1
+    for spec in (b"16x25x36", b"81x400", b"225x144", b"144x100x225"):
+        N = {b"16x25x36": 14400, b"81x400": 32400, b"225x144": 32400, b"144x100x225": 3240000}[spec]
+        for typ in (ol.REAL, ol.COMPLEX):
+            r = emu.emu_notch_owner_check(N, typ, spec, 1 if N < 100000 else 5, 600)
+            assert r in (-1, -2), (spec, typ, r)
+            checked += r == -1
+    assert checked >= 70
+
+
 class _DemodChan(C.Structure):           # struct DemodChan, chz_kernels.h
     _fields_ = [("channels", C.c_int), ("env", C.c_int), ("agc", C.c_int), ("encoding", C.c_int), ("snr_squelch", C.c_int),
                 ("squelch_tail", C.c_int), ("tuned", C.c_int), ("on", C.c_int),
