@@ -73,7 +73,7 @@ def test_bench_emits_one_json_line_with_the_contract_keys():
         assert "error" not in x, x
         pd = x["paced"]
         assert pd["block_drops"] == 0 and pd["skipped_blocks"] == 0 and pd["blocks_served_to_every_channel"] == pd["blocks_measured"]
-        assert 0 < pd["latency_ms"]["p50"] < 20.0 and 19.0 < x["ms_per_block"] < 24.0          # one block per 20 ms on the front end's clock (+ start-up and tear-down spread over 60 blocks)
+        assert 0 < pd["latency_ms"]["p50"] < 20.0 and 19.0 < x["ms_per_block"] < 32.0          # one block per 20 ms on the front end's clock (+ start-up of 1000-2000 threads and tear-down, spread over only 60 blocks here)
     # ... the CPU leg is like for like, and the line says what each leg cost
     cc = cpu["c_rt_cpu"]
     assert cc["probes"] and "block_drops" in cc["probes"][0] and cpu["us_per_channel_block"] > 0 and cpu["fwd_fft_ms"] > 0
