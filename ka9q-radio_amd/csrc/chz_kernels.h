@@ -882,9 +882,12 @@ __global__ void __launch_bounds__(1024) notch_fix(NotchFixParams p) {
 // K3+K4: per-channel gather x response, P-point backward FFT, keep last olen.
 // LPC = max(R1,R2) lanes serve one channel, 64/LPC channels share a wavefront.
 // ------------------------------------------------------------------------------
-// EPI: compiled with the downconvert() epilogue (fine tuning + power); the plain variant carries none of it.
+// EPI: 0 = plain execute_filter_output; 1 = with the downconvert() epilogue (fine tuning, power, the AGC's slice-energy peak); 2 = that plus the
+// ISB unpack and beam mode.  Three instantiations because the rare paths cost the common ones registers: the full variant of the 12 kHz
+// kernel takes 150 VGPRs (3 wavefronts per SIMD) -- beam mode's double-precision products over R1 registers, the mirror bins, the ISB
+// partner values -- which every TUNED bank paid for although hardly any uses them (round 4).
 // (the small sizes are asked to fit 6 wavefronts per SIMD: without the hint the 12 kHz kernel takes 95 VGPRs and loses one)
-template <int R1, int R2, bool EPI>
+template <int R1, int R2, int EPI>
 __global__ void __launch_bounds__(256, (!EPI && R1 <= 15 && R2 <= 20) ? 6 : 1) chan_ifft(ChanParams p) {
   constexpr int P = R1 * R2;
   constexpr int LPC = R1 > R2 ? R1 : R2;
@@ -912,7 +915,7 @@ __global__ void __launch_bounds__(256, (!EPI && R1 <= 15 && R2 <= 20) ? 6 : 1) c
     // zeroed afterwards) so they overlap instead of costing one round trip per bin.
     float2 h[R1];
     bool ok[R1];
-    int srcs[EPI ? R1 : 1];                               // master bin of each register (beam mode needs its mirror)
+    int srcs[EPI == 2 ? R1 : 1];                          // master bin of each register (beam mode needs its mirror)
     // Index arithmetic is what this kernel spends most of its instructions on (at millions of channels it is bound by them, not by
     // memory): the +-1 direction is a sign trick, not a multiply; both range tests are one unsigned compare; bin -> storage index
     // is a multiply-high with a host-made reciprocal instead of a float estimate with fix-ups; the gather goes through a buffer
@@ -932,10 +935,10 @@ __global__ void __launch_bounds__(256, (!EPI && R1 <= 15 && R2 <= 20) ? 6 : 1) c
       if (!ok[Q]) src = 0;
       v[Q] = CHZ_LOAD2(xdesc, X, spec_index(p.lay.off, p.magic, p.dpitch, src));
       h[Q] = Hl[Q * R2];
-      if constexpr (EPI) srcs[Q] = src;
+      if constexpr (EPI == 2) srcs[Q] = src;
     });
     bool beamed = false;
-    if constexpr (EPI) {
+    if constexpr (EPI == 2) {
       if (p.beam != nullptr) {                             // wave-uniform
         const BeamDesc bd = p.beam[ch];
         if (bd.on && d.wrap > 0) {                         // COMPLEX masters only (wrap = master bins)
@@ -977,7 +980,7 @@ __global__ void __launch_bounds__(256, (!EPI && R1 <= 15 && R2 <= 20) ? 6 : 1) c
       });
     }
   }
-  if constexpr (EPI) {
+  if constexpr (EPI == 2) {
     // ISB mode (slave->isb, src/filter.c:895-909, filter2 of the linear demodulator): LSB and USB are unpacked to
     // I and Q -- Y[p] += conj(Y[P-p]), Y[P-p] -= conj(Y[p]) for 0 < p < P/2, Y[0] = 0.  Bin P-i of lane jl, register Q
     // sits in lane R2-jl, register R1-1-Q (lane 0: its own register R1-Q): one cross-lane fetch per register.

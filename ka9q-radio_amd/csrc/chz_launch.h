@@ -52,8 +52,9 @@ inline bool chan_layout(ChanParams& c, const SpecLayout& lay, long bins) {
 }
 inline int launch_chan(Radix2 r, int grid, int block, size_t lds, hipStream_t s, const ChanParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
 #define X(a, b) if (r.r1 == a && r.r2 == b) { \
-    if (p.fine || p.power || p.isb || p.beam) { CHZ_LAUNCH((chan_ifft<a, b, true>), grid, block, lds, s, e0, e1, p); } \
-    else { CHZ_LAUNCH((chan_ifft<a, b, false>), grid, block, lds, s, e0, e1, p); } \
+    if (p.isb || p.beam) { CHZ_LAUNCH((chan_ifft<a, b, 2>), grid, block, lds, s, e0, e1, p); } \
+    else if (p.fine || p.power) { CHZ_LAUNCH((chan_ifft<a, b, 1>), grid, block, lds, s, e0, e1, p); } \
+    else { CHZ_LAUNCH((chan_ifft<a, b, 0>), grid, block, lds, s, e0, e1, p); } \
     return 0; }
   CHZ_CHAN_MENU(X)
 #undef X
