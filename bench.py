@@ -793,6 +793,7 @@ def main():
     ap.add_argument("--crt-blocks", type=int, default=500)
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8f chain leg (tuning + noise estimate + demodulator behind 1.5 M channels)")
     ap.add_argument("--next-rows-channels", type=int, default=1_500_000)
+    ap.add_argument("--next-rows-modes", default="linear,pll,fm", help="which demodulators the 8f chain leg runs (profiling passes take one)")
     ap.add_argument("--crt-ladder", default="", help="comma-separated channel counts (millions) of the C_rt ladder; default 17.0,19.0,19.5,20.0,20.5 at P=300 / 8.4,9.4,9.7,10.0 at P=600")
     ap.add_argument("--no-dropin", action="store_true", help="skip the legs through the filter.h drop-in")
     ap.add_argument("--dropin-blocks", type=int, default=500)
@@ -1126,7 +1127,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_next_rows and config == 3:
         t_leg = time.perf_counter()
         next_rows = []
-        for mode in ("linear", "pll", "fm"):
+        for mode in [m for m in ("linear", "pll", "fm") if m in args.next_rows_modes.split(",")]:
             try:
                 next_rows.append(next_rows_leg(pkg, wl, args.next_rows_channels, dev_index, mode))
             except Exception as ex:

@@ -110,6 +110,7 @@ struct Bank {
   double* agc_peak = nullptr;   // [ND][cap] the block's largest 2 ms slice energy, left by chan_ifft for demod_lin_lanes (allocated with the demodulators of a large bank)
   bool agc_peak_valid[CHZ_ND] = {false, false, false, false};   // the slot's image was written by this slot's latest whole-bank channel launch
   double* n0 = nullptr;         // [ND][cap] estimate_noise() (src/radio.c:1783-1866)
+  unsigned* noise_hint = nullptr;   // [cap] the binade the channel's quantile fell into last time (noise_est: a guess it verifies, never a result)
   double noise_samprate = 0.0;  // front-end sample rate; 0 = off
 };
 
@@ -254,7 +255,7 @@ template <class T> static int upload(T** dst, const std::vector<f2>& v) {
 
 static void free_bank(Bank& b) {
   hipFree(b.resp); hipFree(b.desc); hipFree(b.out); hipFree(b.tw_sub); hipFree(b.any_scratch); b.any_scratch = nullptr;
-  hipFree(b.fine); hipFree(b.power); hipFree(b.n0); hipFree(b.isb); hipFree(b.beam); hipFree(b.agc_peak); b.agc_peak = nullptr;
+  hipFree(b.fine); hipFree(b.power); hipFree(b.n0); hipFree(b.noise_hint); b.noise_hint = nullptr; hipFree(b.isb); hipFree(b.beam); hipFree(b.agc_peak); b.agc_peak = nullptr;
   hipFree(b.dm_chan); hipFree(b.dm_state); hipFree(b.dm_ext); hipFree(b.dm_status); hipFree(b.dm_flags); hipFree(b.dm_pcm); hipFree(b.dm_mix);
   b.dm_mix = nullptr; b.dm_pll_lin = 0; b.dm_fm_pll = 0; b.dm_fm_tone = 0; b.dm_lin = 0; b.dm_fm = 0; b.dm_fm_nopll = 0;
   b.dm_chan = nullptr; b.dm_state = nullptr; b.dm_ext = nullptr; b.dm_status = nullptr; b.dm_flags = nullptr; b.dm_pcm = nullptr; b.dm_on = 0; b.dm_chan_h.clear(); b.dm_osc.clear();
@@ -1033,12 +1034,12 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   mark(in, st, 4, false);
   if (b.n0 && b.noise_samprate > 0.0) {
     NoiseParams q = noise_params(e->bins, e->in_type == CHZ_REAL, b.out_real ? b.P / 2 + 1 : b.P, b.noise_samprate);   // slave->bins
-    q.spec = e->spec[slot]; q.lay = c.lay; q.desc = b.desc + so; q.n0 = b.n0 + so; q.ch0 = ch0; q.nch = n; q.magic = c.magic; q.dpitch = c.dpitch;
+    q.spec = e->spec[slot]; q.lay = c.lay; q.desc = b.desc + so; q.n0 = b.n0 + so; q.ch0 = ch0; q.nch = n; q.magic = c.magic; q.dpitch = c.dpitch; q.hint = b.noise_hint;
     // a launch that reads every bin many times over takes |X|^2 once per bin first (16384 channels x 1000 bins = 10 x the spectrum)
     const bool en = e->energy[slot] && (e->noise_energy >= 0 ? e->noise_energy != 0 : n >= 16384);
     mark(in, st, 3, true);
     if (en) {
-      launch_spec_energy(e->spec[slot], e->energy[slot], e->plan.spec_elems & ~1L, st, IN_E0(in), nullptr);     // (timed together with the
+      launch_spec_energy(e->spec[slot], e->energy[slot], e->bins, c.lay, c.magic, c.dpitch, st, IN_E0(in), nullptr);     // (timed together with the
       q.energy = e->energy[slot];                                                                                 //  windows when instrumented)
     }
     if (launch_noise(n, st, q, en ? nullptr : IN_E0(in), IN_E1(in))) return fail(-4, "no noise kernel for a %d-bin window", q.nbins);
@@ -1375,10 +1376,14 @@ int chz_bank_enable_noise(chz_engine* e, int bank, double samprate) {
   if (!b.n0 && samprate > 0.0) {
     HIPOK(hipMalloc((void**)&b.n0, sizeof(double) * (size_t)CHZ_ND * b.cap));
     HIPOK(hipMemset(b.n0, 0, sizeof(double) * (size_t)CHZ_ND * b.cap));
+    if (!b.noise_hint && !(getenv("CHZ_NOISE_HINT") && getenv("CHZ_NOISE_HINT")[0] == '0')) {
+      HIPOK(hipMalloc((void**)&b.noise_hint, sizeof(unsigned) * (size_t)b.cap));
+      HIPOK(hipMemset(b.noise_hint, 0, sizeof(unsigned) * (size_t)b.cap));
+    }
     HIPOK(hipDeviceSynchronize());
   }
   if (samprate > 0.0 && !e->energy[0] && e->noise_energy != 0 && (b.cap >= 16384 || e->noise_energy == 1)) {
-    for (int i = 0; i < CHZ_ND; i++) HIPOK(hipMalloc((void**)&e->energy[i], sizeof(float) * (size_t)e->plan.spec_elems));
+    for (int i = 0; i < CHZ_ND; i++) HIPOK(hipMalloc((void**)&e->energy[i], sizeof(float) * spec_energy_floats(e->bins)));
     HIPOK(hipDeviceSynchronize());
   }
   b.noise_samprate = samprate;

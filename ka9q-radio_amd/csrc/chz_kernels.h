@@ -86,6 +86,10 @@ __device__ __forceinline__ float2 load_f2(__amdgpu_buffer_rsrc_t d, int elem) {
   return make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
 }
 #define CHZ_LOAD2(desc, base, elem) load_f2(desc, (int)(elem))
+__device__ __forceinline__ float load_f1(__amdgpu_buffer_rsrc_t d, int elem) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(d, elem * 4, 0, 0));
+}
+#define CHZ_LOAD1(desc, base, elem) load_f1(desc, (int)(elem))
 #define CHZ_STORE(desc, base, elem, value) store_wt(desc, (int)(elem), (value))
 // predicated store without a branch: a raw buffer access past num_records is dropped by the hardware
 #define CHZ_STORE_IF(desc, base, elem, value, cond) store_wt(desc, (cond) ? (int)(elem) : 0x10000000, (value))
@@ -93,6 +97,7 @@ __device__ __forceinline__ float2 load_f2(__amdgpu_buffer_rsrc_t d, int elem) {
 #define CHZ_OUT_DESC(name, base) const int name = 0; (void)name
 #define CHZ_IN_DESC(name, base) const int name = 0; (void)name
 #define CHZ_LOAD2(desc, base, elem) ((base)[(elem)])
+#define CHZ_LOAD1(desc, base, elem) ((base)[(elem)])
 #define CHZ_STORE(desc, base, elem, value) ((base)[(elem)] = (value))
 #define CHZ_STORE_IF(desc, base, elem, value, cond) do { if (cond) (base)[(elem)] = (value); } while (0)
 #endif
@@ -1329,20 +1334,30 @@ struct NoiseParams {
   unsigned magic; int dpitch;   // bin -> storage index without a division (chan_layout)
   double scale;           // correction / (master bins * front-end sample rate)   (:1840-1844,1863-1865)
   const float* energy;    // EN kernels: |X|^2 of every stored bin (spec_energy), same storage index as spec
+  unsigned* hint;         // [nch] or nullptr: exponent + 1 of the channel's last quantile (0: none yet).  A GUESS the kernel verifies with
+                          // the counts it needs anyway: a noise floor keeps its binade from block to block, and the search for it -- two
+                          // passes for the window's range, four bisection steps -- is half the kernel.  Never part of a result: blocks in
+                          // flight on other streams may read an older or a newer guess, and get the same answer either way.
 };
 
 // Large banks read every master bin hundreds of times (1.5 M channels x 1000-bin windows over 1.62 M bins): cnrmf() is then taken
 // ONCE per bin into an image of floats, and the windows read 4 bytes per bin instead of 8 -- the same float, bit for bit, since it is
-// the same three roundings.  One elementwise pass over the slot (13 MB in, 6.5 MB out), launched by the engine only when the bank is
-// large enough to pay for it.
-struct EnergyParams { const float2* spec; float* energy; long n; };
+// the same three roundings.  The image is in NATURAL bin order (energy[k] for bin k, not the spectrum's pitched storage) with the
+// first CHZ_ENERGY_TAIL bins repeated behind the last one: a window is then a plain run of floats from its first bin on, whether
+// it wraps around the end of a COMPLEX master or not, and the window kernel has no index arithmetic left per value (round 4: the
+// storage index -- a multiply-high, a multiply and three more operations per value -- was a third of noise_est's vector instructions).
+// One elementwise pass over the slot (13 MB in, 6.5 MB out), launched by the engine only when the bank is large enough to pay for it.
+#define CHZ_ENERGY_TAIL 2048           /* >= the longest window (nsort) */
+struct EnergyParams { const float2* spec; float* energy; int bins; int na_off; unsigned magic; int dpitch; };
 __global__ void __launch_bounds__(256) spec_energy(EnergyParams p) {
-  const long stride = (long)gridDim.x * blockDim.x * 2;
-  const float4* __restrict__ in = reinterpret_cast<const float4*>(p.spec);
-  float2* __restrict__ out = reinterpret_cast<float2*>(p.energy);
-  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2; i < p.n; i += stride) {       // n is even (the layout's pitch is)
-    const float4 x = in[i >> 1];
-    out[i >> 1] = make_float2(cnrm_unfused(make_float2(x.x, x.y)), cnrm_unfused(make_float2(x.z, x.w)));
+  const int stride = (int)(gridDim.x * blockDim.x);
+  const float2* __restrict__ sp = p.spec;
+  CHZ_IN_DESC(sdesc, sp);
+  float* __restrict__ out = p.energy;
+  for (int k = (int)(blockIdx.x * blockDim.x + threadIdx.x); k < p.bins; k += stride) {
+    const float en = cnrm_unfused(CHZ_LOAD2(sdesc, sp, spec_index(p.na_off, p.magic, p.dpitch, k)));
+    out[k] = en;
+    if (k < CHZ_ENERGY_TAIL) out[p.bins + k] = en;
   }
 }
 
@@ -1446,19 +1461,18 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
   // any is consumed: entries past n read the window's first bin and are replaced by +inf afterwards.
   // (the storage index of a bin without a division: one multiply-high by the layout's reciprocal, as in chan_ifft)
   if constexpr (EN) {
+    // the image is in bin order with the first bins repeated behind the last: the window is a run of floats from mbin on
+    // (entries past n read bins beyond the window -- inside the image -- and are replaced)
     const float* __restrict__ en = p.energy;
+    CHZ_IN_DESC(edesc, en);
     static_for<VPL>([&](auto rr) {
       constexpr int R = decltype(rr)::value;
-      int i = R * 64 + lane;
-      if (i >= n) i = 0;
-      int k = mbin + i;
-      if (wrap && k >= wrap) k -= wrap;
-      v[R] = en[spec_index(p.lay.off, p.magic, p.dpitch, k)];
+      v[R] = CHZ_LOAD1(edesc, en, mbin + lane + R * 64);
     });
     static_for<VPL>([&](auto rr) {
       constexpr int R = decltype(rr)::value;
       const unsigned u = __float_as_uint(v[R]);
-      mx = u > mx ? u : mx;                                           // (a padding entry holds the window's first bin here)
+      mx = u > mx ? u : mx;                                           // (an upper bound for the search is all this is: a padding entry may take part)
       if (R * 64 + lane >= n) v[R] = inf;
     });
   } else {
@@ -1497,26 +1511,49 @@ __global__ void __launch_bounds__(256) noise_est(NoiseParams p) {
   // The exponent first, by bisection over the exponents the window actually spans (white noise: some 15 binades, four steps instead
   // of the eight a bit-by-bit search of the field needs): the answer is the largest exponent E with no more than qi values below
   // E << 23, it is not below the smallest value's exponent (nothing lies below that) and not above the largest's.
-  unsigned mn = bits[0];
-  static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; mn = bits[R] < mn ? bits[R] : mn; });
-  int lo = (int)(wave_min_u32(mn) >> 23), hi = (int)(wave_max_u32(mx) >> 23);
-  if (lo > 255) lo = 255;                                            // (NaNs only: they sort above +inf)
-  if (hi > 255) hi = 255;
-  int below = 0;                                                     // values strictly below lo << 23 (wave-uniform)
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    const unsigned t = (unsigned)mid << 23;
-    int c = 0;
-    static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; c += __popcll(__ballot(bits[R] < t)); });
-    if (c <= qi) { lo = mid; below = c; } else hi = mid - 1;         // wave-uniform
+  int lo = 0, below = 0, mine = 0, total = 0;
+  bool guessed = false;
+  const unsigned hx = p.hint != nullptr ? (unsigned)__builtin_amdgcn_readfirstlane((int)p.hint[ch]) : 0u;
+  if (hx != 0u && hx <= 255u) {
+    // last time's binade [t0, t1): right again if no more than qi values lie below t0 and more than qi below t1 -- the counts the
+    // compaction needs anyway
+    const unsigned t0 = (hx - 1u) << 23, t1 = t0 + (1u << 23);
+    int c0 = 0, c1 = 0;
+    static_for<VPL>([&](auto rr) {
+      constexpr int R = decltype(rr)::value;
+      const bool a = bits[R] < t0, b = bits[R] < t1;
+      c0 += __popcll(__ballot(a)); c1 += __popcll(__ballot(b));
+      mine += (b && !a) ? 1 : 0;
+    });
+    if (c0 <= qi && c1 > qi) { guessed = true; lo = (int)hx - 1; below = c0; total = c1 - c0; }
+  }
+  if (!guessed) {
+    unsigned mn = bits[0];
+    static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; mn = bits[R] < mn ? bits[R] : mn; });
+    int hi = (int)(wave_max_u32(mx) >> 23);
+    lo = (int)(wave_min_u32(mn) >> 23);
+    if (lo > 255) lo = 255;                                            // (NaNs only: they sort above +inf)
+    if (hi > 255) hi = 255;
+    below = 0;                                                         // values strictly below lo << 23 (wave-uniform)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      const unsigned t = (unsigned)mid << 23;
+      int c = 0;
+      static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; c += __popcll(__ballot(bits[R] < t)); });
+      if (c <= qi) { lo = mid; below = c; } else hi = mid - 1;         // wave-uniform
+    }
   }
   unsigned ans = (unsigned)lo << 23;
   // the binade [ans, ans + 2^23): how many values, and each lane's share of them
   const unsigned top = ans + (1u << 23);                             // (ans has exponent < 255: +inf padding and NaNs sort above every finite value)
-  int mine = 0;
-  static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; mine += (bits[R] >= ans && bits[R] < top) ? 1 : 0; });
-  int total;
-  const int incl = wave_scan_i32(mine, lane, total);                 // inclusive scan over the lanes
+  if (!guessed) {
+    mine = 0;
+    static_for<VPL>([&](auto rr) { constexpr int R = decltype(rr)::value; mine += (bits[R] >= ans && bits[R] < top) ? 1 : 0; });
+  }
+  int scan_total;
+  const int incl = wave_scan_i32(mine, lane, scan_total);            // inclusive scan over the lanes
+  if (!guessed) total = scan_total;
+  if (p.hint != nullptr && !guessed && lane == 0) p.hint[ch] = (unsigned)lo + 1u;
   const int r = qi - below;                                          // rank of the answer inside the binade, 0 <= r < total
   unsigned cur = ans;
   int c_le;                                                          // values <= the answer, all of the window

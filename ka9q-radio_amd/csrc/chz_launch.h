@@ -220,10 +220,12 @@ inline void demod_tone_consts(double tone_freq, double samprate, DemodChan& c) {
   const double f = tone_freq / (double)(int)samprate;
   c.g_coeff = 2 * std::cos(2 * M_PI * f); c.g_cfr = std::cos(2 * M_PI * f); c.g_cfi = -std::sin(2 * M_PI * f);
 }
-// |X|^2 of every stored bin of a slot (n = the slot's element count): the input of the EN noise kernels
-inline void launch_spec_energy(const float2* spec, float* energy, long n, hipStream_t s, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-  EnergyParams q{spec, energy, n};
-  long grid = (n / 2 + 255) / 256; if (grid > 2048) grid = 2048;
+// |X|^2 of every bin of a slot in bin order (+ CHZ_ENERGY_TAIL repeated bins): the input of the EN noise kernels
+inline size_t spec_energy_floats(int bins) { return (size_t)bins + CHZ_ENERGY_TAIL + 64; }
+inline void launch_spec_energy(const float2* spec, float* energy, int bins, const SpecLayout& lay, unsigned magic, int dpitch, hipStream_t s,
+                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+  EnergyParams q{spec, energy, bins, lay.off, magic, dpitch};
+  long grid = ((long)bins + 255) / 256; if (grid > 2048) grid = 2048;
   CHZ_LAUNCH(spec_energy, (int)grid, 256, 0, s, e0, e1, q);
 }
 inline int launch_noise(int nch, hipStream_t s, const NoiseParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {

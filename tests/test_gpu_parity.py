@@ -872,6 +872,41 @@ def test_noise_estimate_matches_radio_c(pkg, L, M, P, olen, nch):
         eng.close()
 
 
+def test_noise_estimate_with_a_stale_binade_guess(pkg, monkeypatch):
+    # round 4: noise_est starts from the binade the channel's quantile fell into last time and verifies it with the counts it needs
+    # anyway.  A guess is never a result: a level that jumps by 40 dB up, 100 dB down and back between blocks (every guess wrong), a
+    # level that stays (every guess right) and the guess switched off give radio.c's estimate on the device's own spectrum, bit for bit
+    # the same in all three
+    L, M, P, olen, nch = 25920, 6481, 300, 240, 48
+    B = (L + M - 1) // 2 + 1
+    fs = 50.0 * L
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(L).astype(np.float32)
+    shifts = np.array([0, 3, B - 1, -(B - 1), 500, -499] + [900 + 263 * i for i in range(nch - 6)], np.int32)
+    gains = [1.0, 1.0, 100.0, 1e-3, 1e-3, 1.0, 1.0 + 2 ** -20, 7.0]
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CHZ_NOISE_HINT", mode)
+        eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+        try:
+            b = eng.bank(P, olen, nch)
+            b.set_responses(0, np.ones((nch, P), np.complex64) / P); b.set_shifts(0, shifts); b.set_active(nch)
+            b.enable_noise(fs)
+            rows = []
+            for job, g in enumerate(gains):
+                eng.write((x * np.float32(g)).astype(np.float32)); eng.step(job)
+                n0 = b.read_noise(job % 4).copy()
+                if mode == "1":
+                    spec = eng.spectrum(job % 4)
+                    want = np.array([ol.estimate_noise(spec, ol.REAL, P, int(s), fs) for s in shifts])
+                    assert np.all(want > 0) and np.allclose(n0, want, rtol=1e-12, atol=0), job
+                rows.append(n0)
+            got[mode] = np.stack(rows)
+        finally:
+            eng.close()
+    np.testing.assert_array_equal(got["1"], got["0"])
+
+
 @pytest.mark.parametrize("master", ["real", "complex"])
 def test_noise_windows_from_the_energy_image(pkg, monkeypatch, master):
     # large banks take |X|^2 once per bin (spec_energy) and their noise windows read that image instead of the spectrum: the same
