@@ -1012,6 +1012,7 @@ static int enqueue_bank(chz_engine* e, int bank, unsigned job, Instr* in, int ch
   c.stage = e->chan_stage >= 0 ? e->chan_stage : (n >= 16384);
   c.isb = b.isb ? b.isb + so : nullptr; c.beam = b.beam ? b.beam + so : nullptr;
   c.fine = b.fine ? b.fine + so : nullptr; c.power = b.power ? b.power + so : nullptr; c.job = job;
+  if (b.fine) fine_launch(c, 1 + e->L / (e->M - 1), job);
   // the AGC's first look at the block rides in the channel kernel's epilogue when the rows pass through LDS anyway (large launches) and the
   // lane-per-channel demodulator follows (CHZ_AGC_PEAK=0: A/B knob, the demodulator then walks the block twice as before)
   // (only when somebody will use them: linear channels outside the coherent modes, served by the lane-per-channel demodulator)
@@ -1337,13 +1338,14 @@ int chz_bank_set_tuning(chz_engine* e, int bank, unsigned job, int ch0, int n, c
   if (b.out_real) return fail(-1, "fine tuning applies to COMPLEX-output banks");
   if (e->M < 2) return fail(-1, "impulse length %d has no overlap factor", e->M);
   const int V = 1 + e->L / (e->M - 1);
+  if (V >= (1 << 26)) return fail(-1, "overlap factor %d: the block phase correction is exact up to 2^26", V);
   HIPOK(hipSetDevice(e->device));
   for (int i = 0; i < n; i++)
     if (!std::isfinite(freq[i]) || (rate && !std::isfinite(rate[i]))) return fail(-1, "non-finite tuning for channel %d", ch0 + i);
   if (!b.fine) {
     { int r = sync_all(e); if (r) return r; }     // the kernel variant changes: one-time switch
     b.fine_h.assign((size_t)b.cap, FineHost());
-    b.fine_dh.assign((size_t)b.cap, FineDesc{0.0, 0.0, 0.0, 0u, 0, 1, 0});
+    b.fine_dh.assign((size_t)b.cap, FineDesc{0.0, 0.0, 0.0, 0u, 0, 1, 0, 0, 0, 1.0, 0.0});
     HIPOK(hipMalloc((void**)&b.fine, sizeof(FineDesc) * (size_t)CHZ_ND * b.cap));
     HIPOK(hipMemset(b.fine, 0, sizeof(FineDesc) * (size_t)CHZ_ND * b.cap));
     HIPOK(hipMalloc((void**)&b.power, sizeof(double) * (size_t)CHZ_ND * b.cap));
@@ -1357,7 +1359,7 @@ int chz_bank_set_tuning(chz_engine* e, int bank, unsigned job, int ch0, int n, c
     d.t0 = h.t0; d.cnt = h.cnt; d.src0 = h.src0; d.dir = h.dir; d.conj = h.conj; d.wrap = h.wrap; d.shift = shifts[i];
     FineHost& fh = b.fine_h[(size_t)(ch0 + i)];
     fine_retune(fh, job, b.olen, V, shifts[i], freq[i], rate ? rate[i] : 0.0);
-    b.fine_dh[(size_t)(ch0 + i)] = fine_desc(fh, V);
+    b.fine_dh[(size_t)(ch0 + i)] = fine_desc(fh, V, b.g.any ? 0 : b.g.r.r1);
   }
   return after_edit(e, b, ch0, n);
 }

@@ -63,10 +63,18 @@ static inline void fine_retune(FineHost& h, unsigned job, int olen, int V, int s
   h.phase0 = frac1(phase); h.feff = feff; h.rate = cur_rate; h.job0 = job; h.adj_num = adj; h.on = true;
 }
 
-static inline FineDesc fine_desc(const FineHost& h, int V) {
+// stride: the register-tiled channel kernel's lanes hold every stride-th output sample (its R1); 0 for kernels that do not use the step
+static inline FineDesc fine_desc(const FineHost& h, int V, int stride = 0) {
   FineDesc d;
   d.phase0 = h.phase0; d.freq = h.feff; d.rate = h.rate; d.job0 = h.job0; d.adj_num = h.adj_num; d.V = V; d.on = h.on ? 1 : 0;
+  d.job0m = (int)(h.job0 % (unsigned)V); d.stride = stride;
+  const double a = 2.0 * M_PI * std::remainder((double)stride * h.feff, 1.0);
+  d.step_c = std::cos(a); d.step_s = std::sin(a);
   return d;
+}
+// the per-launch integers of the block phase correction (ChanParams::fine_*)
+static inline void fine_launch(ChanParams& c, int V, unsigned job) {
+  c.fine_V = V; c.fine_invV = 1.0 / (double)V; c.fine_jobm = (int)(job % (unsigned)V); c.fine_wrapm = (int)(4294967296ull % (unsigned long long)V);
 }
 
 }  // namespace chz

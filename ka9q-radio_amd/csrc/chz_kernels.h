@@ -254,7 +254,10 @@ struct ChanDesc { int t0, cnt, src0, dir, conj, wrap, row, shift; };
 //   freq/rate  = what set_osc() was given (cycles/sample, cycles/sample^2; src/osc.c:28-47, :60-70),
 //   adj_num/V  = the per-block phase_adjust = cispi(2*(shift % V)/V)   (src/radio.c:1493,1497),
 //   phase0     = everything accumulated before the base, including the shift-change kick (src/radio.c:1494).
-struct FineDesc { double phase0, freq, rate; unsigned job0; int adj_num, V, on; };
+struct FineDesc { double phase0, freq, rate; unsigned job0; int adj_num, V, on;
+                  // for the register-tiled channel kernel, computed by the host when the channel is (re)tuned: job0 mod V, and the rotator's
+                  // advance over `stride` samples (the kernel's lanes hold every stride-th sample: stride = its R1), e^{2 pi i stride freq}
+                  int job0m, stride; double step_c, step_s; };
 
 // slave->beam (src/filter.c:756-775): Y = (alpha X[rp] + beta conj(X[m_bins-rp])) H, weights as set_filter_weights stores them
 struct BeamDesc { double ar, ai, br, bi; int on; int pad; };
@@ -272,6 +275,9 @@ struct ChanParams {
   double* agc_peak;       // [nch] or nullptr (EPI variant, stage mode only)
   int agc_sps;            // samples per slice: rint(olen * .002 / blocktime), at least 1
   unsigned job;
+  // the block phase correction's integers without a division in the kernel (round 4): V = the master's overlap factor (the same for
+  // every channel), 1/V, job mod V and 2^32 mod V, by the host per launch
+  int fine_V; double fine_invV; int fine_jobm, fine_wrapm;
   const float2* spec;     // master spectrum of this block (SpecLayout order)
   SpecLayout lay;
   float inv_na;           // 1/na, for the bin -> (row, column) split
@@ -893,7 +899,7 @@ __global__ void __launch_bounds__(1024) notch_fix(NotchFixParams p) {
 // partner values -- which every TUNED bank paid for although hardly any uses them (round 4).
 // (the small sizes are asked to fit 6 wavefronts per SIMD: without the hint the 12 kHz kernel takes 95 VGPRs and loses one)
 template <int R1, int R2, int EPI>
-__global__ void __launch_bounds__(256, (!EPI && R1 <= 15 && R2 <= 20) ? 6 : 1) chan_ifft(ChanParams p) {
+__global__ void __launch_bounds__(256, (R1 <= 15 && R2 <= 20) ? (EPI == 0 ? 6 : (EPI == 1 ? 5 : 1)) : 1) chan_ifft(ChanParams p) {
   constexpr int P = R1 * R2;
   constexpr int LPC = R1 > R2 ? R1 : R2;
   constexpr int CPW = 64 / LPC;
@@ -1043,14 +1049,22 @@ __global__ void __launch_bounds__(256, (!EPI && R1 <= 15 && R2 <= 20) ? 6 : 1) c
         const double kb = (double)(p.job - f.job0);
         const int m0 = jl - drop;
         const double g0 = kb * (double)p.olen + (double)m0;
-        const unsigned r = (unsigned)(((unsigned long long)((p.job - f.job0) % (unsigned)f.V + 1u) * (unsigned)f.adj_num) % (unsigned)f.V);
-        const double base = f.phase0 + (double)r / (double)f.V;
+        // r = ((kb mod V) + 1) * adj_num mod V, the phase_adjust multiplications so far (src/radio.c:1493,1497), without an integer
+        // division: kb mod V from the two residues the host took (the block counter wraps at 2^32), the product's residue in double
+        // (exact: V < 2^26, chz_bank_set_tuning)
+        const int V = p.fine_V;
+        int kbm = p.fine_jobm - f.job0m + (p.job < f.job0 ? p.fine_wrapm : 0);
+        kbm += kbm < 0 ? V : 0; kbm -= kbm >= V ? V : 0;
+        const double x = (double)(kbm + 1) * (double)f.adj_num;
+        double r = fma(-floor(x * p.fine_invV), (double)V, x);
+        r += r < 0.0 ? (double)V : 0.0; r -= r >= (double)V ? (double)V : 0.0;
+        const double base = f.phase0 + r * p.fine_invV;
         if (f.rate == 0.0) {
           double hi = g0 * f.freq, lo = fma(g0, f.freq, -hi);          // exact product, reduced mod 1
           hi -= rint(hi);
           double s0, c0, s1, c1;
           sincospi(2.0 * (base + hi + lo), &s0, &c0);
-          sincospi(2.0 * ((double)R1 * f.freq), &s1, &c1);
+          c1 = f.step_c; s1 = f.step_s;                                  // e^{2 pi i R1 freq}, the host's (fine_desc(.., stride = R1))
           static_for<R2>([&](auto k2) {
             constexpr int K2 = decltype(k2)::value;
             const double xr = u[K2].x, xi = u[K2].y;
@@ -1118,9 +1132,10 @@ __global__ void __launch_bounds__(256, (!EPI && R1 <= 15 && R2 <= 20) ? 6 : 1) c
           if (energy > peak) peak = energy;
         }
       }
-      double tot = 0.0;                                      // max over the channel's lanes (energies are >= 0: max of the lanes' maxima)
+      // max over the channel's lanes (energies are >= 0: max of the lanes' maxima), a tree over the group: lane jl takes lane jl + d
+      double tot = peak;
 #pragma unroll
-      for (int i = 0; i < LPC; i++) { const double o = __shfl(peak, (cw < CPW ? cw : 0) * LPC + i); tot = o > tot ? o : tot; }
+      for (int d = 16; d >= 1; d >>= 1) if (d < LPC) { const double o = __shfl_down(tot, (unsigned)d); if (jl + d < LPC && o > tot) tot = o; }
       if (live && jl == 0) p.agc_peak[ch] = tot;
     }
   }
@@ -1142,9 +1157,9 @@ __global__ void __launch_bounds__(256, (!EPI && R1 <= 15 && R2 <= 20) ? 6 : 1) c
     }
   }
   if (EPI && p.power != nullptr) {     // wave-uniform: every lane takes part in the shuffles
-    double tot = 0.0;
+    double tot = part;                                       // (lanes outside the second layer hold 0)
 #pragma unroll
-    for (int i = 0; i < R1; i++) tot += __shfl(part, (cw < CPW ? cw : 0) * LPC + i);
+    for (int d = 16; d >= 1; d >>= 1) if (d < LPC) { const double o = __shfl_down(tot, (unsigned)d); if (jl + d < LPC) tot += o; }
     if (live && jl == 0) p.power[ch] = tot / (double)p.olen;
   }
 }

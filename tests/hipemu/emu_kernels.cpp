@@ -285,14 +285,14 @@ int emu_channels_tuned(const float* spec, int m_bins, int in_type, int P, int ol
   for (int i = 0; i < nch; i++) {
     ChanDescH h = make_chan_desc(in_type, m_bins, P, shifts[i]);
     desc[i] = ChanDesc{h.t0, h.cnt, h.src0, h.dir, h.conj, h.wrap, i, shifts[i]};
-    fd[(size_t)i] = fine_desc(fh[(size_t)i], V);
+    fd[(size_t)i] = fine_desc(fh[(size_t)i], V, g.r.r1);
   }
   ChanParams c{};
   c.spec = reinterpret_cast<const float2*>(spec); if (!chan_layout(c, lay, m_bins)) return -9;
   c.resp = reinterpret_cast<const float2*>(resp);
   c.desc = desc.data(); c.out = reinterpret_cast<float2*>(out); c.ch0 = 0; c.nch = nch; c.olen = olen;
   c.tw_sub = F2(g.tw_sub);
-  c.fine = fd.data(); c.power = power; c.job = job;
+  c.fine = fd.data(); c.power = power; c.job = job; fine_launch(c, V, job);
   c.stage = getenv("CHZ_CHAN_STAGE") ? atoi(getenv("CHZ_CHAN_STAGE")) : 0;
   const int per_block = g.wpb * g.cpw;
   const int grid = (nch + per_block - 1) / per_block;
