@@ -254,11 +254,15 @@ def test_fused_notch(emu, N, in_type, spec):
     np.testing.assert_allclose(st_a, st_b, rtol=1e-4, atol=1e-2)
 
 
-def test_tuned_channel_epilogue_follows_downconvert(emu):
+@pytest.mark.parametrize("L,M,olen", [(11520, 2881, 240), (11520, 5761, 200), (11520, 11521, 150)])   # overlap factors V = 5 (the real configurations), 3, 2
+def test_tuned_channel_epilogue_follows_downconvert(emu, L, M, olen):
     """Channel kernel + fine-tuning epilogue + host re-basing (chz_finetune.h) against the oracle's
     execute_filter_output followed by the restated downconvert() tail, over a tuning history with shift
-    changes, remainder changes, a frequency sweep, and a wrapped job counter."""
-    L, M, N, P, olen, fs = 11520, 2881, 14400, 300, 240, 12000.0     # V = 5 like the real configurations
+    changes, remainder changes, a frequency sweep, and a wrapped job counter (round 4: the block phase
+    correction's residues come from the host, 2^32 mod V included: V = 3 and 5 do not divide 2^32)."""
+    N, P = L + M - 1, 300
+    fs = olen / (L / 576000.0)
+    assert P == olen * N // L
     V = 1 + L // (M - 1)
     B = N // 2 + 1
     nch = 5
