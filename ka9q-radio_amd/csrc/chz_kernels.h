@@ -154,6 +154,16 @@ template <int N_> __device__ __forceinline__ float row_shr16(float v) {
 // component) blocks, block b serves component (b % 8 - rot) mod 8 and leaves at once if that component does not exist; `rot`
 // advances by ncomp per block so consecutive blocks in flight load different XCDs.  fwd_cols then stores PLAIN (the lines stay
 // in its XCD's L2; write-through stores drop them).  Decision record: DESIGN.md section 7, profiles/r04_xcd_affine.txt.
+// Wavefronts per SIMD the lane-per-channel passes are compiled for (the second __launch_bounds__ argument is HIP's minimum number of
+// wavefronts per execution unit).  Both want ~235 VGPRs; at 3 wavefronts the compiler gets 168 and spills the rest to scratch.  Measured
+// at 1.5 M channels (round 4): demod_fm_lanes 2.28 -> 2.07 ns per channel with 3 (its walks are latency-bound, the spills sit outside the
+// per-sample chains), pll_lanes 2.52 -> 3.02 ns (its spills land inside the loop): FM ships 3, the PLL pass stays at 2.
+#ifndef CHZ_PLL_WAVES
+#define CHZ_PLL_WAVES 2
+#endif
+#ifndef CHZ_FM_WAVES
+#define CHZ_FM_WAVES 3
+#endif
 #ifndef CHZ_XCD_AFFINE
 #define CHZ_XCD_AFFINE 0
 #endif
@@ -2146,7 +2156,7 @@ __device__ __forceinline__ void demod_fm_wave(const DemodParams& p, const DemodC
 // blocks go back to memory (p.mix) the same way, the loop's results to DemodExt, and demod_linear_tail picks both up.
 // Statement for statement the loop of demod_linear_tail's lane-0 path: the results are bit-identical.
 #define PLL_TILE 16
-__global__ void __launch_bounds__(64, 2) pll_lanes(DemodParams p) {
+__global__ void __launch_bounds__(64, CHZ_PLL_WAVES) pll_lanes(DemodParams p) {
   HIP_DYNAMIC_SHARED(float2, tile)                         // [64][PLL_TILE + 1]
   const int lane = (int)threadIdx.x;
   const int base = p.ch0 + (int)blockIdx.x * 64;           // first channel of this workgroup
@@ -2679,7 +2689,7 @@ __global__ void __launch_bounds__(64, 2) demod_lin_lanes(DemodParams p) {
 //   pass 4      PL-tone detector over the baseband after DC removal  (only when a lane has a tone squelch)
 //   pass 5      de-emphasis as the recurrence it is, gain, PCM
 // Nothing is re-associated: statement for statement chzo_fmdemod_block / demod_fm().
-__global__ void __launch_bounds__(64, 2) demod_fm_lanes(DemodParams p) {
+__global__ void __launch_bounds__(64, CHZ_FM_WAVES) demod_fm_lanes(DemodParams p) {
   HIP_DYNAMIC_SHARED(float2, tile)                         // [64][LIN_TILE + 1] float2 (passes 1-3) / floats (4, 5); then LinRow[64]
   constexpr int LD = LIN_TILE + 1;
   float* tilef = reinterpret_cast<float*>(tile);
