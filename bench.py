@@ -757,7 +757,9 @@ def dropin_leg(wl, ring_host, nthreads, nblocks, env, label, paced_us=0):
                              "callback_to_slave_has_its_block_us_worst_after_8_blocks": pv.get("consume_worst_after_8_us"),
                              "staged_hits": pv.get("hits"), "misses": pv.get("misses")},
             "host_cgroup": {"cpu.max": cg1.get("cpu.max"), "periods_throttled_during_the_leg": cg1.get("nr_throttled", 0) - cg0.get("nr_throttled", 0),
-                            "throttled_ms_during_the_leg": (cg1.get("throttled_usec", cg1.get("throttled_time", 0)) - cg0.get("throttled_usec", cg0.get("throttled_time", 0))) / 1e3},
+                            "throttled_ms_during_the_leg": (cg1.get("throttled_usec", cg1.get("throttled_time", 0)) - cg0.get("throttled_usec", cg0.get("throttled_time", 0))) / 1e3,
+                            # CPU seconds the container used per second of the leg (the quota is cpu.max's first number / its second)
+                            "cpus_used_mean": round((cg1.get("usage_usec", 0) - cg0.get("usage_usec", 0)) / 1e6 / wall, 2) if wall > 0 and "usage_usec" in cg1 else None},
             "process_wall_s": wall}
 
 
