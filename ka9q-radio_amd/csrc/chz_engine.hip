@@ -491,6 +491,9 @@ static int sync_all(chz_engine* e) {
   for (int i = 0; i < e->nlanes; i++) HIPOK(hipStreamSynchronize(e->lanes[i].s));
   if (e->tail) HIPOK(hipStreamSynchronize(e->tail));
   if (e->pcmcopy) HIPOK(hipStreamSynchronize(e->pcmcopy));
+  // nothing is travelling any more: the demodulator launches that follow (a graph capture among them: an eagerly recorded event is no
+  // business of a capture) need not wait for the copy stream's last read of their slot
+  for (auto& b : e->banks) for (int s = 0; s < CHZ_ND; s++) b.pcm_copying[s] = false;
   return check_device_errors(e);
 }
 int chz_sync(chz_engine* e) {
