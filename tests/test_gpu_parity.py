@@ -907,12 +907,13 @@ def test_noise_estimate_with_a_stale_binade_guess(pkg, monkeypatch):
     np.testing.assert_array_equal(got["1"], got["0"])
 
 
+@pytest.mark.parametrize("P,olen", [(300, 240), (1200, 960)])      # windows of 1000 bins (16 values per lane) and of 1200 (32 per lane)
 @pytest.mark.parametrize("master", ["real", "complex"])
-def test_noise_windows_from_the_energy_image(pkg, monkeypatch, master):
+def test_noise_windows_from_the_energy_image(pkg, monkeypatch, master, P, olen):
     # large banks take |X|^2 once per bin (spec_energy) and their noise windows read that image instead of the spectrum: the same
     # estimate bit for bit (forced on here for a small bank) -- windows clamped at both ends of a REAL master, an inverted channel,
     # windows that wrap or stop at the seam of a COMPLEX master -- and radio.c's arithmetic on the device's own spectrum
-    L, M, P, olen, nch = 25920, 6481, 300, 240, 40
+    L, M, nch = 25920, 6481, 40
     in_type = ol.REAL if master == "real" else ol.COMPLEX
     N = L + M - 1
     B = N // 2 + 1 if master == "real" else N
