@@ -30,6 +30,13 @@ unsigned long filter_hip_skipped_blocks(struct filter_in const *master);
    failure within 500 blocks, or a re-creation that fails, ends the process with EX_SOFTWARE so that the supervisor restarts it, which
    is what the reference does on a fatal error (/root/reference/src/radio.c:398, src/main.c:202).  Returns the number of recoveries so far. */
 unsigned filter_hip_recoveries(struct filter_in const *master, unsigned *blocks_lost);
+/* Sharding behind filter.h.  Env KA9Q_HIP_DEVICES="0,1,..." at create_filter_input time spreads the slaves of the master over the
+   listed devices (one engine each; every device takes the block's samples from the same pinned host ring and transforms them
+   itself; slaves are assigned in creation order, KA9Q_HIP_SHARD_CHANNELS -- default 1024 -- per device before the next one is
+   used; a block is complete when every device has delivered).  The reference runs a thread per channel inside one process against
+   one shared master (/root/reference/src/radio.c:996, src/filter.c:704-712); callers of filter.h see no difference.  Returns the
+   number of devices; counts (may be NULL) receives the slaves living on each. */
+int filter_hip_devices(struct filter_in const *master, int *counts, int max);
 #ifdef __cplusplus
 }
 #endif

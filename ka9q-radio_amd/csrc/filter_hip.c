@@ -21,6 +21,14 @@
  *   set_filter()       Kaiser design on the host in float64 as before (src/filter.c:968-1045),
  *                      response uploaded to the bank.
  *
+ *   KA9Q_HIP_DEVICES   "0,1,2,..." spreads the slaves of ONE master over the node's GPUs (north star: "channels shard
+ *                      naturally across the 8 GPUs"; thread per channel inside one process, src/radio.c:996, every slave
+ *                      reading one shared master, src/filter.c:704-712): one engine per listed device, every engine
+ *                      takes the block's L new samples from the same pinned host ring and transforms them itself (no
+ *                      collective in the data path; 518 MB/s of PCIe per device), slaves go to devices in creation
+ *                      order, KA9Q_HIP_SHARD_CHANNELS (default 1024) at a time; a block is complete when every
+ *                      device's completion callback has run.  filter.h callers see none of this.
+ *
  * There is no CPU signal path here: REAL-output slaves and transform sizes the device
  * kernels are not compiled for fail loudly with -1.
  */
@@ -74,11 +82,23 @@ struct hbank {
   bool noise_on;                    /* the device runs noise_est behind this bank's channel kernel */
 };
 
-struct done_note { struct mctx *ctx; unsigned job, seq; struct timespec t0; };
+struct done_note { struct mctx *ctx; unsigned job, seq; int shard; struct timespec t0; };
+
+/* one device's share of a master (KA9Q_HIP_DEVICES): its engine and the banks of the slaves assigned to it */
+#define MAX_SHARDS 16
+struct shard {
+  chz_engine *eng;
+  int device;
+  struct hbank *banks;
+  int nbanks;
+  int nslaves;                      /* slaves living on this device right now */
+};
 
 struct mctx {
   int kind;                         /* CTX_ENGINE; a small inline master carries a struct minictx instead (filter_hip_mini.h) */
-  chz_engine *eng;
+  struct shard sh[MAX_SHARDS];      /* sh[0] is the primary: master->fdomain[] comes from it */
+  int nsh;
+  int shard_channels;               /* slaves per device before the next device is used (KA9Q_HIP_SHARD_CHANNELS) */
   struct filter_in *master;
   pthread_mutex_t lock;             /* serialises engine calls and bank bookkeeping */
   /* staged outputs: ~1000 channel threads read after every block, the launcher / bank edits write now and then.  One
@@ -86,15 +106,14 @@ struct mctx {
      shard its slave hashes to, a writer takes them all. */
 #define STAGE_SHARDS 16
   struct { pthread_rwlock_t l; char pad[64 - sizeof(pthread_rwlock_t) % 64]; } stage_lock[STAGE_SHARDS];
-  struct hbank *banks;
-  int nbanks;
   bool ring_pinned;                 /* host ring registered with the HIP runtime */
   bool host_spectrum;               /* copy every block's spectrum into master->fdomain[] (KA9Q_HIP_FDOMAIN, default on) */
   struct notch_state *notch_ptr;    /* list last uploaded to the device */
   int notch_n;
   int notch_bins[64];
   double notch_alpha[64];
-  struct done_note note[ND];        /* one per job slot; execute_filter_input never has more than ND blocks in flight */
+  struct done_note note[ND][MAX_SHARDS];   /* one per job slot and device; execute_filter_input never has more than ND blocks in flight */
+  unsigned pending[ND];             /* completion callbacks of the slot's block still to come (atomic): the LAST one publishes the block */
   /* KA9Q_HIP_INPUT_FULL=drop: the reference's producer never waits (src/filter.c:639-649 only queues a job); with ND blocks
      still in flight on the device this block is then NOT transformed -- its samples still travel so the overlap history stays
      whole -- and every slave gets zeros and a counted drop for it (src/filter.c:690-701), instead of the front-end thread
@@ -128,16 +147,17 @@ struct mctx {
      recovery, or a re-creation that fails, ends the process with EX_SOFTWARE, like the reference, so the supervisor restarts it. */
 #define RECOVERY_GRACE 500
   bool failed;                      /* set by the completion callback / the producer when the engine reports a failure (atomic) */
-  unsigned recoveries, failed_blocks;
+  unsigned recoveries, failed_blocks;   /* (atomic accesses: read lock-free by the channel threads) */
   unsigned last_recovery_job;
   unsigned engine_first_job;        /* the first block the CURRENT engine was handed: the spectra of earlier blocks died with its predecessor (atomic) */
   double noise_samprate;            /* > 0: banks run the device's estimate_noise() (filter_hip_enable_noise) */
   /* wake-up of the channel threads: the completion callback wakes wake_first of them (0 = all), every woken thread wakes
      wake_fan more (KA9Q_HIP_WAKE="first,fan"; default "0,2") */
   int wake_first, wake_fan;
+  int bank_cap0;                    /* channels a new bank starts with (KA9Q_HIP_BANK_CHANNELS, default 64; banks double as they fill) */
   /* KA9Q_HIP_PROFILE=1: where a block's host time goes, printed by delete_filter_input */
   bool profile;
-  struct timespec t_done[ND];       /* when the slot's completion callback ran */
+  long long t_done_ns[ND];          /* when the slot's block was completed (CLOCK_MONOTONIC, ns; atomic) */
   unsigned long long prof_blocks, prof_input_ns, prof_wait_ns, prof_consume_sum_ns, prof_consume_n, prof_consume_max_ns, prof_hits, prof_misses, prof_dev_max_ns;
   unsigned long long prof_consume_max8_ns;   /* the same worst case over blocks 8.. only (the first blocks carry one-time costs: first touch of every
                                                 slave's buffers, thread start-up, the runtime's first launches) */
@@ -155,19 +175,27 @@ struct miss_req {
   int shift, slot;
   unsigned job;
   int rc;
-  bool done;
+  bool done, ranged;
   struct miss_req *next;
 };
 
 struct sctx {
-  int bank;                         /* index into mctx.banks */
+  int dev;                          /* index into mctx.sh: the device this slave lives on */
+  int bank;                         /* index into that shard's banks */
   int idx;                          /* channel index inside the bank */
   unsigned epoch;                   /* bumped whenever the response changes */
   double n0;                        /* the device's noise estimate of the block this slave consumed last (NaN: none) */
   int shard;                        /* which of the master's wake words this slave sleeps on */
+  /* The shift this slave will ask for, published by execute_filter_output BEFORE it waits for its block (atomic): the front-end
+     thread launches the block's batch with it.  The API hands the shift over only with the request for a block, so without this
+     the first block of every slave (and the first after every retune) was launched with the previous shift and had to be re-run:
+     2000 re-runs in block 0 of a 2000-channel radiod (round 4: 70 ms and 279 lapped slave-blocks on a fresh box). */
+  int want_shift;
+  unsigned char want_valid;
 };
 
 struct hbank;
+static void sync_notches(struct mctx *c, struct filter_in *f);
 static void bank_free_host(struct hbank *b);
 static void stage_wrlock(struct mctx *c);
 static void stage_wrunlock(struct mctx *c);
@@ -300,51 +328,59 @@ static void announce(struct mctx *c, int slot, bool everybody) {
 
 static void block_done(void *arg) {
   struct done_note *n = arg;
-  struct filter_in *f = n->ctx->master;
-  /* the record is read in full BEFORE the job is published: publishing releases the producer, which may reuse it */
-  unsigned const job = n->job, seq = n->seq;
-  struct timespec const t0 = n->t0;
+  struct mctx *const c = n->ctx;
+  struct filter_in *f = c->master;
+  unsigned const job = n->job;
+  int const slot = (int)(job % ND);
+  /* a device of this master has reported a failed check: what the engines still deliver is not to be trusted (the notch recurrence
+     of this block and of every later one was not applied) -- remembered here, acted on by whoever completes the block */
+  if (chz_engine_check(c->sh[n->shard].eng) != 0) __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE);
+  /* one callback per device; the block is complete when the last of them has run (it alone goes on: the records of the slot are
+     read in full BEFORE the job is published -- publishing releases the producer, which may reuse them) */
+  if (__atomic_sub_fetch(&c->pending[slot], 1u, __ATOMIC_ACQ_REL) != 0) return;
+  unsigned const seq = c->note[slot][0].seq;
+  struct timespec const t0 = c->note[slot][0].t0;
   struct timespec t1;
   clock_gettime(CLOCK_MONOTONIC, &t1);
-  struct mctx *const c = n->ctx;
-  /* the engine has reported a failed device-side check: what it still delivers is not to be trusted (the notch recurrence of this
-     block and of every later one was not applied) -- the block is announced like a skipped one: zeros and a counted drop for everybody */
-  if (__atomic_load_n(&c->failed, __ATOMIC_ACQUIRE) || chz_engine_check(c->eng) != 0) {
-    __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE);
+  if (__atomic_load_n(&c->failed, __ATOMIC_ACQUIRE)) {
+    /* the block is announced like a skipped one: zeros and a counted drop for everybody */
     __atomic_fetch_add(&c->failed_blocks, 1u, __ATOMIC_RELAXED);
-    __atomic_store_n(&c->skipped[job % ND][(job / ND) % SKIP_RING], ((uint64_t)1 << 32) | job, __ATOMIC_RELEASE);
-    announce(c, (int)(job % ND), true);
-    __atomic_store_n(&c->dev_seq[job % ND], seq, __ATOMIC_RELEASE);
-    futex_wake_n(&c->dev_seq[job % ND], 1);
+    __atomic_store_n(&c->skipped[slot][(job / ND) % SKIP_RING], ((uint64_t)1 << 32) | job, __ATOMIC_RELEASE);
+    announce(c, slot, true);
+    __atomic_store_n(&c->dev_seq[slot], seq, __ATOMIC_RELEASE);
+    futex_wake_n(&c->dev_seq[slot], 1);
     return;
   }
+  int64_t const ns = (t1.tv_nsec - t0.tv_nsec) + 1000000000LL * (t1.tv_sec - t0.tv_sec);
   if (c->profile) {
-    c->t_done_job[job % ND] = job;
-    c->t_done[job % ND] = t1;
-    long long const d = (t1.tv_nsec - t0.tv_nsec) + 1000000000LL * (t1.tv_sec - t0.tv_sec);
-    if (job >= 8 && (unsigned long long)d > c->prof_dev_max_ns) c->prof_dev_max_ns = (unsigned long long)d;   /* the first blocks carry one-time set-up */
+    /* (slaves of an older job on this slot may be reading these right now: tear-free, and before the block is announced) */
+    __atomic_store_n(&c->t_done_ns[slot], (long long)t1.tv_sec * 1000000000LL + t1.tv_nsec, __ATOMIC_RELAXED);
+    __atomic_store_n(&c->t_done_job[slot], job, __ATOMIC_RELAXED);
+    if (job >= 8 && (unsigned long long)ns > c->prof_dev_max_ns) c->prof_dev_max_ns = (unsigned long long)ns;   /* the first blocks carry one-time set-up */
   }
+  /* src/filter.c:544-552; before the block is announced: a caller that has seen its last block may read them (src/main.c:155-163) */
+  if (ns > __atomic_load_n(&Max_fft_time, __ATOMIC_RELAXED)) __atomic_store_n(&Max_fft_time, ns, __ATOMIC_RELAXED);
+  if (ns < __atomic_load_n(&Min_fft_time, __ATOMIC_RELAXED)) __atomic_store_n(&Min_fft_time, ns, __ATOMIC_RELAXED);
+  int64_t const avg = __atomic_load_n(&Avg_fft_time, __ATOMIC_RELAXED), dev = ns - avg;
+  __atomic_store_n(&Avg_fft_time, avg + (dev >> 4), __ATOMIC_RELAXED);
+  int64_t const md = __atomic_load_n(&Mean_dev, __ATOMIC_RELAXED);
+  __atomic_store_n(&Mean_dev, md + ((llabs(dev) - md) >> 4), __ATOMIC_RELAXED);
   pthread_mutex_lock(&f->filter_mutex);
   __atomic_store_n(&f->owner, pthread_self(), __ATOMIC_RELEASE);      /* read without the mutex by execute_filter_output */
-  __atomic_store_n(&f->completed_jobs[job % ND], job, __ATOMIC_RELEASE);   /* src/filter.c:526-529 */
+  __atomic_store_n(&f->completed_jobs[slot], job, __ATOMIC_RELEASE);   /* src/filter.c:526-529 */
   pthread_cond_broadcast(&f->filter_cond);              /* src/filter.c:532-535 (kept; nobody in this build waits on it) */
   pthread_mutex_unlock(&f->filter_mutex);
-  announce(c, (int)(job % ND), false);
-  __atomic_store_n(&c->dev_seq[job % ND], seq, __ATOMIC_RELEASE);      /* the slot is the producer's again */
-  futex_wake_n(&c->dev_seq[job % ND], 1);
-  int64_t ns = (t1.tv_nsec - t0.tv_nsec) + 1000000000LL * (t1.tv_sec - t0.tv_sec);
-  if (ns > Max_fft_time) Max_fft_time = ns;             /* src/filter.c:544-552 */
-  if (ns < Min_fft_time) Min_fft_time = ns;
-  int64_t dev = ns - Avg_fft_time;
-  Avg_fft_time += dev >> 4;
-  Mean_dev += (llabs(dev) - Mean_dev) >> 4;
+  announce(c, slot, false);
+  __atomic_store_n(&c->dev_seq[slot], seq, __ATOMIC_RELEASE);      /* the slot is the producer's again */
+  futex_wake_n(&c->dev_seq[slot], 1);
 }
+static void warm_done(void *arg) { __atomic_fetch_add((unsigned *)arg, 1u, __ATOMIC_RELEASE); }
 
 /* ------------------------------------------------------------------------- */
 /* banks                                                                        */
 /* ------------------------------------------------------------------------- */
 static size_t bank_sample_bytes(const struct hbank *b) { return b->real ? sizeof(float) : sizeof(float complex); }
-static int bank_create_dev(struct mctx *c, struct hbank *b, int cap);
+static int bank_create_dev(struct mctx *c, struct shard *sh, struct hbank *b, int cap);
 static void bank_free_host(struct hbank *b) {
   for (int s = 0; s < ND; s++) { chz_host_free(b->stage[s]); b->stage[s] = NULL; chz_host_free(b->stage_n0[s]); b->stage_n0[s] = NULL; FREE(b->stage_shift[s]); FREE(b->stage_epoch[s]); FREE(b->stage_isb[s]); }
   FREE(b->slaves); FREE(b->shift); FREE(b->isb); FREE(b->beam_ab); FREE(b->beam_on);
@@ -372,25 +408,39 @@ static int bank_alloc_host(struct hbank *b, int cap) {
   }
   return 0;
 }
-static int bank_create_dev(struct mctx *c, struct hbank *b, int cap) {
-  int const id = b->real ? chz_bank_create_real(c->eng, b->P, b->olen, cap) : chz_bank_create(c->eng, b->P, b->olen, cap);
+static int bank_create_dev(struct mctx *c, struct shard *sh, struct hbank *b, int cap) {
+  int const id = b->real ? chz_bank_create_real(sh->eng, b->P, b->olen, cap) : chz_bank_create(sh->eng, b->P, b->olen, cap);
   b->noise_on = false;
   /* estimate_noise() on the device (filter_hip_enable_noise): sizes the noise kernel is not compiled for keep NaN */
-  if (id >= 0 && c->noise_samprate > 0) b->noise_on = chz_bank_enable_noise(c->eng, id, c->noise_samprate) == 0;
+  if (id >= 0 && c->noise_samprate > 0) b->noise_on = chz_bank_enable_noise(sh->eng, id, c->noise_samprate) == 0;
   return id;
 }
-/* find (or create, or grow) the bank for (P, olen, output type); caller holds ctx->lock */
-static int bank_for(struct mctx *c, int P, int olen, bool real) {
-  for (int i = 0; i < c->nbanks; i++) {
-    struct hbank *b = &c->banks[i];
+/* A bank that has just been created (or re-created larger) runs its kernels once on every slot before a real block does: the
+   first launch of the channel kernel of its size (and of the noise kernel), the descriptor staging of every slot, and one
+   device-to-host copy into each of the staged-output images -- as the reference pays for planning inside create_filter_output
+   (src/filter.c:359), so that the first block a new slave sees is an ordinary block.  Caller holds c->lock; `b` has its host side. */
+static void bank_warm(struct shard *sh, struct hbank *b) {
+  if (b->n < 1 && b->cap < 1) return;
+  for (int s = 0; s < ND; s++) {
+    if (chz_bank_execute_range(sh->eng, b->id, (unsigned)s, 0, 1) != 0) return;
+    if (chz_bank_read_async(sh->eng, b->id, s, 0, 1, (float *)b->stage[s]) != 0) return;
+    if (b->noise_on && chz_bank_read_noise_async(sh->eng, b->id, s, 0, 1, b->stage_n0[s]) != 0) return;
+  }
+  for (int s = 0; s < ND; s++) (void)chz_slot_sync(sh->eng, s);
+  for (int s = 0; s < ND; s++) { memset(b->stage[s], 0, bank_sample_bytes(b) * (size_t)b->olen); b->stage_n0[s][0] = NAN; }
+}
+/* find (or create, or grow) the bank for (P, olen, output type) on one device; caller holds ctx->lock */
+static int bank_for(struct mctx *c, struct shard *sh, int P, int olen, bool real) {
+  for (int i = 0; i < sh->nbanks; i++) {
+    struct hbank *b = &sh->banks[i];
     if (b->P != P || b->olen != olen || b->real != real) continue;
     if (b->n < b->cap) return i;
     /* grow: a new, larger device bank; move responses and shifts over */
     struct hbank nb = {.P = P, .olen = olen, .n = b->n, .real = real};
-    nb.id = bank_create_dev(c, &nb, b->cap * 2);
+    nb.id = bank_create_dev(c, sh, &nb, b->cap * 2);
     if (nb.id < 0 || bank_alloc_host(&nb, b->cap * 2) != 0) {
       fprintf(stderr, "filter_hip: cannot grow bank: %s\n", chz_last_error());
-      if (nb.id >= 0) chz_bank_destroy(c->eng, nb.id);
+      if (nb.id >= 0) chz_bank_destroy(sh->eng, nb.id);
       bank_free_host(&nb);
       return -1;
     }
@@ -399,40 +449,91 @@ static int bank_for(struct mctx *c, int P, int olen, bool real) {
       nb.beam_on[k] = 0;                                  /* re-uploaded by the next execute_filter_input if the slave is in beam mode */
       /* the slave's own thread may be inside set_filter right now: its swap frees the old response */
       pthread_mutex_lock(&nb.slaves[k]->response_mutex);
-      if (nb.slaves[k]->response) chz_bank_set_responses(c->eng, nb.id, k, 1, (const float *)nb.slaves[k]->response);
+      if (nb.slaves[k]->response) chz_bank_set_responses(sh->eng, nb.id, k, 1, (const float *)nb.slaves[k]->response);
       pthread_mutex_unlock(&nb.slaves[k]->response_mutex);
     }
-    chz_bank_set_shifts(c->eng, nb.id, 0, nb.n, nb.shift);
-    if (!real) chz_bank_set_isb(c->eng, nb.id, 0, nb.n, nb.isb);
-    chz_bank_destroy(c->eng, b->id);
+    chz_bank_set_shifts(sh->eng, nb.id, 0, nb.n, nb.shift);
+    if (!real) chz_bank_set_isb(sh->eng, nb.id, 0, nb.n, nb.isb);
+    bank_warm(sh, &nb);
+    chz_bank_destroy(sh->eng, b->id);
     bank_free_host(b);
     *b = nb;
     return i;
   }
-  struct hbank *nbanks = realloc(c->banks, sizeof *nbanks * (size_t)(c->nbanks + 1));
+  struct hbank *nbanks = realloc(sh->banks, sizeof *nbanks * (size_t)(sh->nbanks + 1));
   if (!nbanks) return -1;
-  c->banks = nbanks;
-  struct hbank *b = &c->banks[c->nbanks];
+  sh->banks = nbanks;
+  struct hbank *b = &sh->banks[sh->nbanks];
   memset(b, 0, sizeof *b);
   b->P = P; b->olen = olen; b->real = real;
-  b->id = bank_create_dev(c, b, 64);
+  /* a master that will carry a thousand slaves doubles its way up from here; every doubling is a new device bank and new pinned images */
+  int const cap0 = c->bank_cap0 > 0 ? c->bank_cap0 : 64;
+  b->id = bank_create_dev(c, sh, b, cap0);
   if (b->id < 0) { fprintf(stderr, "filter_hip: %s\n", chz_last_error()); return -1; }
-  if (bank_alloc_host(b, 64) != 0) { chz_bank_destroy(c->eng, b->id); bank_free_host(b); return -1; }
-  return c->nbanks++;
+  if (bank_alloc_host(b, cap0) != 0) { chz_bank_destroy(sh->eng, b->id); bank_free_host(b); return -1; }
+  { int const zero = 0; (void)chz_bank_set_shifts(sh->eng, b->id, 0, 1, &zero); }
+  bank_warm(sh, b);
+  return sh->nbanks++;
 }
 
 /* ------------------------------------------------------------------------- */
 /* create / delete                                                               */
 /* ------------------------------------------------------------------------- */
-static void mctx_free(struct mctx *c) {          /* host side only; the engine is destroyed by the caller first */
-  for (int i = 0; i < c->nbanks; i++) bank_free_host(&c->banks[i]);
-  free(c->banks);
+static void mctx_free(struct mctx *c) {          /* host side only; the engines are destroyed by the caller first */
+  for (int g = 0; g < c->nsh; g++) {
+    for (int i = 0; i < c->sh[g].nbanks; i++) bank_free_host(&c->sh[g].banks[i]);
+    free(c->sh[g].banks);
+  }
   pthread_mutex_destroy(&c->lock);
   for (int i = 0; i < STAGE_SHARDS; i++) pthread_rwlock_destroy(&c->stage_lock[i].l);
   pthread_mutex_destroy(&c->miss_lock);
   pthread_cond_destroy(&c->miss_cv);
   free(c);
 }
+/* KA9Q_HIP_DEVICES="0,1,2" (or the older KA9Q_HIP_DEVICE=n): the devices this master's slaves are spread over.  An entry may
+   repeat ("0,0": two engines on one device -- how the sharded path is exercised on a one-GPU box). */
+static int device_list(struct mctx *c) {
+  const char *list = getenv("KA9Q_HIP_DEVICES");
+  int n = 0;
+  if (list && *list) {
+    const char *q = list;
+    while (*q && n < MAX_SHARDS) {
+      char *end = NULL;
+      long v = strtol(q, &end, 10);
+      if (end == q || v < 0 || v > 1023) { fprintf(stderr, "create_filter_input: KA9Q_HIP_DEVICES=\"%s\" is not a list of device numbers\n", list); return -1; }
+      c->sh[n++].device = (int)v;
+      q = end;
+      while (*q == ',' || *q == ' ') q++;
+    }
+    if (*q) { fprintf(stderr, "create_filter_input: KA9Q_HIP_DEVICES names more than %d devices\n", MAX_SHARDS); return -1; }
+  }
+  if (n == 0) { const char *dev = getenv("KA9Q_HIP_DEVICE"); c->sh[0].device = dev ? atoi(dev) : 0; n = 1; }
+  return n;
+}
+/* Everything a block does, once, on zeros, before create_filter_input returns: the first launches of the plan's kernels on every
+   lane, the first H2D copy out of the (pinned) host ring, the first D2H copies into fdomain[], the runtime's callback thread -- the
+   reference pays for planning inside create_filter_input (src/filter.c:248,263), so block 0 of the stream is an ordinary block.
+   The input ring is re-seated in front of job 0 afterwards (zero history, src/filter.c:244,259); the spectra of zeros are zeros. */
+static void engines_warm(struct mctx *c, struct filter_in *f) {
+  unsigned ran = 0, want = 0;
+  for (int g = 0; g < c->nsh; g++) {
+    chz_engine *e = c->sh[g].eng;
+    const float *src = (const float *)f->input_buffer;             /* zeros */
+    for (unsigned j = 0; j < ND; j++) {
+      if (chz_input_write(e, src, f->ilen) != 0 || chz_forward(e, j) != 0) break;
+      if (g == 0 && c->host_spectrum && chz_spectrum_read_async(e, (int)j, (float *)f->fdomain[j]) != 0) break;
+      if (chz_host_callback(e, (int)j, warm_done, &ran) != 0) break;
+      want++;
+    }
+  }
+  for (int g = 0; g < c->nsh; g++) {
+    if (chz_sync(c->sh[g].eng) != 0 || chz_input_seek(c->sh[g].eng, 0, NULL) != 0)
+      fprintf(stderr, "create_filter_input: warm-up on device %d: %s\n", c->sh[g].device, chz_last_error());
+  }
+  /* (a stream callback may still be returning on its runtime thread after the stream has drained) */
+  for (int spin = 0; spin < 2000 && __atomic_load_n(&ran, __ATOMIC_ACQUIRE) != want; spin++) usleep(100);
+}
+
 int create_filter_input(struct filter_in *master, int const L, int const M, enum filtertype const in_type) {
   if (master == NULL) return -1;
   if (master->init && master->ilen == L && master->impulse_length == M && in_type == master->in_type)
@@ -447,7 +548,7 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   if (master->init && master->fwd_plan) {                          /* re-create with new geometry */
     struct mctx *old = MCTX(master);
     if (old->ring_pinned) chz_host_unregister(master->input_buffer);
-    chz_engine_destroy(old->eng);
+    for (int g = 0; g < old->nsh; g++) chz_engine_destroy(old->sh[g].eng);
     mctx_free(old);
     master->fwd_plan = NULL;
     for (int i = 0; i < ND; i++) { chz_host_free(master->fdomain[i]); master->fdomain[i] = NULL; }
@@ -457,13 +558,19 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   struct mctx *c = calloc(1, sizeof *c);
   if (!c) return -1;
   c->kind = CTX_ENGINE;
-  const char *dev = getenv("KA9Q_HIP_DEVICE");
-  if (chz_engine_create(&c->eng, L, M, in_type == REAL ? CHZ_REAL : CHZ_COMPLEX, dev ? atoi(dev) : 0, NULL, 0) != 0) {
-    fprintf(stderr, "create_filter_input(L=%d M=%d): %s\n", L, M, chz_last_error());
-    free(c);
-    return -1;
-  }
+  c->nsh = device_list(c);
+  if (c->nsh < 1) { free(c); return -1; }
+  for (int g = 0; g < c->nsh; g++)
+    if (chz_engine_create(&c->sh[g].eng, L, M, in_type == REAL ? CHZ_REAL : CHZ_COMPLEX, c->sh[g].device, NULL, 0) != 0) {
+      fprintf(stderr, "create_filter_input(L=%d M=%d, device %d): %s\n", L, M, c->sh[g].device, chz_last_error());
+      for (int k = 0; k < g; k++) chz_engine_destroy(c->sh[k].eng);
+      free(c);
+      return -1;
+    }
   c->master = master;
+  c->shard_channels = 1024;                                       /* contiguous 1024-blocks */
+  { const char *sc = getenv("KA9Q_HIP_SHARD_CHANNELS"); if (sc && atoi(sc) > 0) c->shard_channels = atoi(sc); }
+  { const char *bc = getenv("KA9Q_HIP_BANK_CHANNELS"); if (bc && atoi(bc) > 0 && atoi(bc) <= 65536) c->bank_cap0 = atoi(bc); }
   /* master->fdomain[] is read by radiod's estimate_noise() (src/radio.c:1801) and by nothing else outside filter.c;
      a host that takes the noise estimate from the device (chz_bank_enable_noise) can switch the 13 MB per-block copy off */
   { const char *fd = getenv("KA9Q_HIP_FDOMAIN"); c->host_spectrum = !(fd && fd[0] == '0'); }
@@ -520,12 +627,13 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   master->wcnt = 0;
   master->next_jobnum = 0;
   master->fwd_plan = (fftwf_plan)(void *)c;
+  engines_warm(c, master);
   return 0;
 
 fail:
   for (int i = 0; i < ND; i++) chz_host_free(fd[i]);
   ring_unmap(&ring, ring_bytes);
-  chz_engine_destroy(c->eng);
+  for (int g = 0; g < c->nsh; g++) chz_engine_destroy(c->sh[g].eng);
   mctx_free(c);
   return -1;
 }
@@ -540,7 +648,7 @@ int delete_filter_input(struct filter_in *master) {
   }
   if (master->fwd_plan) {
     struct mctx *c = MCTX(master);
-    chz_sync(c->eng);
+    for (int g = 0; g < c->nsh; g++) chz_sync(c->sh[g].eng);
     if (c->profile && c->prof_blocks)
       fprintf(stderr, "filter_hip profile: blocks=%llu input_us=%.1f input_wait_us=%.1f consume_mean_us=%.1f consume_worst_us=%.1f reads=%llu "
               "hits=%llu misses=%llu skipped=%lu dev_block_max_us_after_8=%.1f consume_worst_after_8_us=%.1f recoveries=%u failed_blocks=%u\n",
@@ -548,7 +656,7 @@ int delete_filter_input(struct filter_in *master) {
               c->prof_consume_n ? c->prof_consume_sum_ns / 1e3 / c->prof_consume_n : 0.0, c->prof_consume_max_ns / 1e3, c->prof_consume_n,
               c->prof_hits, c->prof_misses, c->n_skipped, c->prof_dev_max_ns / 1e3, c->prof_consume_max8_ns / 1e3, c->recoveries, c->failed_blocks);
     if (c->ring_pinned) chz_host_unregister(master->input_buffer);
-    chz_engine_destroy(c->eng);
+    for (int g = 0; g < c->nsh; g++) chz_engine_destroy(c->sh[g].eng);
     mctx_free(c);
   }
   if (master->init) { pthread_mutex_destroy(&master->filter_mutex); pthread_cond_destroy(&master->filter_cond); }
@@ -604,7 +712,14 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
     if (!slave->fdomain || (!slave->output_buffer.c && !slave->output_buffer.r) || !sc) { FREE(slave->fdomain); FREE(slave->output_buffer.c); FREE(slave->output_buffer.r); free(sc); return -1; }
     pthread_mutex_lock(&c->lock);
     stage_wrlock(c);
-    int bi = bank_for(c, slave->points, len, real);
+    /* which device: the first one that still has room in its share of shard_channels slaves (creation order fills device 0, then 1, ...:
+       contiguous blocks); with every share full, the one with the fewest slaves */
+    int dv = 0;
+    for (int g = 0; g < c->nsh; g++) if (c->sh[g].nslaves < c->shard_channels) { dv = g; goto chosen; }
+    for (int g = 1; g < c->nsh; g++) if (c->sh[g].nslaves < c->sh[dv].nslaves) dv = g;
+  chosen:;
+    struct shard *const sh = &c->sh[dv];
+    int bi = bank_for(c, sh, slave->points, len, real);
     if (bi < 0) {
       stage_wrunlock(c);
       pthread_mutex_unlock(&c->lock);
@@ -612,13 +727,13 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
       FREE(slave->fdomain); FREE(slave->output_buffer.c); FREE(slave->output_buffer.r); free(sc);
       return -1;
     }
-    struct hbank *b = &c->banks[bi];
-    sc->bank = bi; sc->idx = b->n; sc->epoch = 1; sc->n0 = NAN;
+    struct hbank *b = &sh->banks[bi];
+    sc->dev = dv; sc->bank = bi; sc->idx = b->n; sc->epoch = 1; sc->n0 = NAN;
     sc->shard = c->next_shard++ % c->wshards;
     b->slaves[b->n] = slave; b->shift[b->n] = 0;
     /* the device row must hold the descriptor of the shift the host believes it holds: a channel that only ever asks for shift 0
        (the centre channel of a complex front end) would otherwise never send one and read an empty row */
-    if (chz_bank_set_shifts(c->eng, b->id, b->n, 1, &b->shift[b->n]) != 0) {
+    if (chz_bank_set_shifts(sh->eng, b->id, b->n, 1, &b->shift[b->n]) != 0) {
       stage_wrunlock(c);
       pthread_mutex_unlock(&c->lock);
       fprintf(stderr, "create_filter_output: %s\n", chz_last_error());
@@ -626,8 +741,9 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
       return -1;
     }
     for (int s = 0; s < ND; s++) b->stage_epoch[s][b->n] = 0;
-    b->n++;
+    b->n++; sh->nslaves++;
     slave->rev_plan = (fftwf_plan)(void *)sc;
+    sync_notches(c, master);               /* radio.c installs the list right after create_filter_input (src/radio.c:601-620): uploaded before block 0, not by it */
     stage_wrunlock(c);
     pthread_mutex_unlock(&c->lock);
   }
@@ -645,21 +761,22 @@ int delete_filter_output(struct filter_out *slave) {
     struct sctx *sc = SCTX(slave);
     pthread_mutex_lock(&c->lock);
     stage_wrlock(c);
-    struct hbank *b = &c->banks[sc->bank];
+    struct shard *const sh = &c->sh[sc->dev];
+    struct hbank *b = &sh->banks[sc->bank];
     int last = b->n - 1;
     if (sc->idx != last) {                 /* the last channel moves into the freed index */
       struct filter_out *mv = b->slaves[last];
       struct sctx *ms = SCTX(mv);
       b->slaves[sc->idx] = mv; ms->idx = sc->idx; ms->epoch++;
       b->shift[sc->idx] = b->shift[last];
-      if (!b->real && b->isb[sc->idx] != b->isb[last]) { b->isb[sc->idx] = b->isb[last]; chz_bank_set_isb(c->eng, b->id, sc->idx, 1, &b->isb[sc->idx]); }
+      if (!b->real && b->isb[sc->idx] != b->isb[last]) { b->isb[sc->idx] = b->isb[last]; chz_bank_set_isb(sh->eng, b->id, sc->idx, 1, &b->isb[sc->idx]); }
       pthread_mutex_lock(&mv->response_mutex);                     /* (see bank_for) */
-      if (mv->response) chz_bank_set_responses(c->eng, b->id, ms->idx, 1, (const float *)mv->response);
+      if (mv->response) chz_bank_set_responses(sh->eng, b->id, ms->idx, 1, (const float *)mv->response);
       pthread_mutex_unlock(&mv->response_mutex);
-      chz_bank_set_shifts(c->eng, b->id, ms->idx, 1, &b->shift[ms->idx]);
+      chz_bank_set_shifts(sh->eng, b->id, ms->idx, 1, &b->shift[ms->idx]);
       for (int s = 0; s < ND; s++) b->stage_epoch[s][ms->idx] = 0;
     }
-    b->slaves[last] = NULL; b->n--;
+    b->slaves[last] = NULL; b->n--; sh->nslaves--;
     stage_wrunlock(c);
     pthread_mutex_unlock(&c->lock);
     free(sc);
@@ -684,66 +801,86 @@ static void sync_notches(struct mctx *c, struct filter_in *f) {
   for (int i = 0; same && i < n; i++) same = (ns[i].bin == c->notch_bins[i] && ns[i].alpha == c->notch_alpha[i]);
   if (same) return;
   for (int i = 0; i < n; i++) { c->notch_bins[i] = ns[i].bin; c->notch_alpha[i] = ns[i].alpha; }
-  if (chz_set_notches_alpha(c->eng, c->notch_bins, c->notch_alpha, n) != 0) fprintf(stderr, "filter_hip: notches: %s\n", chz_last_error());
+  /* every device runs the recurrence itself on the same samples: the same states everywhere (src/filter.c:464-474) */
+  for (int g = 0; g < c->nsh; g++)
+    if (chz_set_notches_alpha(c->sh[g].eng, c->notch_bins, c->notch_alpha, n) != 0) fprintf(stderr, "filter_hip: notches: %s\n", chz_last_error());
   c->notch_ptr = ns; c->notch_n = n;
 }
 
-/* Replace a failed engine (see struct mctx).  Caller holds c->lock; `job` is the block about to be enqueued, whose window starts at
-   the master's read pointer.  Ends the process if the engine cannot be replaced or has just been. */
+/* Replace failed engines (see struct mctx).  Caller holds c->lock; `job` is the block about to be enqueued, whose window starts at
+   the master's read pointer.  Ends the process if an engine cannot be replaced or has just been. */
 static void die_for_the_supervisor(const char *why) {
   fprintf(stderr, "filter_hip: %s -- exiting (EX_SOFTWARE) so that the supervisor restarts the process, as the reference does on a fatal "
                   "front-end or FFT error (src/radio.c:398, src/main.c:202)\n", why);
-  exit(EX_SOFTWARE);
+  fflush(stderr);
+  /* _exit, as the reference's fatal path (src/main.c:202): this thread holds the master's locks, a thousand channel threads and the
+     runtime's callback thread are still running, and atexit handlers / static destructors of a runtime whose device has just been
+     declared broken may block for ever */
+  _exit(EX_SOFTWARE);
 }
 static void recover_engine(struct mctx *c, struct filter_in *f, unsigned job) {
-  char why[200];
-  snprintf(why, sizeof why, "%s", chz_last_error());
-  if (c->recoveries > 0 && job - c->last_recovery_job < RECOVERY_GRACE) {
+  char why[200] = "";
+  for (int g = 0; g < c->nsh && !why[0]; g++)                      /* (chz_last_error is per thread: ask again from this one) */
+    if (chz_engine_check(c->sh[g].eng) != 0) snprintf(why, sizeof why, "device %d: %s", c->sh[g].device, chz_last_error());
+  if (!why[0]) snprintf(why, sizeof why, "%s", chz_last_error()[0] ? chz_last_error() : "a block could not be enqueued");
+  unsigned const nrec = __atomic_load_n(&c->recoveries, __ATOMIC_RELAXED);
+  if (nrec > 0 && job - c->last_recovery_job < RECOVERY_GRACE) {
     fprintf(stderr, "filter_hip: the device failed again %u blocks after a recovery (%s)\n", job - c->last_recovery_job, why);
     die_for_the_supervisor("second device failure");
   }
   fprintf(stderr, "filter_hip: device-side failure at block %u (%s): re-creating the engine, in-flight blocks are counted as drops\n", job, why);
-  (void)chz_sync(c->eng);                    /* every completion callback of the old engine has run after this (each one dropped its block) */
+  for (int g = 0; g < c->nsh; g++) (void)chz_sync(c->sh[g].eng);   /* every completion callback of the old engines has run after this (each one dropped its block) */
   stage_wrlock(c);
-  chz_engine_destroy(c->eng);
-  c->eng = NULL;
-  const char *dev = getenv("KA9Q_HIP_DEVICE");
-  if (chz_engine_create(&c->eng, f->ilen, f->impulse_length, f->in_type == REAL ? CHZ_REAL : CHZ_COMPLEX, dev ? atoi(dev) : 0, NULL, 0) != 0) {
-    fprintf(stderr, "filter_hip: %s\n", chz_last_error());
-    die_for_the_supervisor("the engine could not be re-created");
-  }
-  (void)chz_engine_notch_order(c->eng, 1);   /* what failed was a device-side wait: the new engine orders its notches by HIP events, which cannot run out */
-  for (int i = 0; i < c->nbanks; i++) {
-    struct hbank *b = &c->banks[i];
-    b->id = bank_create_dev(c, b, b->cap);
-    if (b->id < 0) { fprintf(stderr, "filter_hip: %s\n", chz_last_error()); die_for_the_supervisor("a channel bank could not be re-created"); }
-    for (int k = 0; k < b->n; k++) {
-      struct filter_out *sl = b->slaves[k];
-      pthread_mutex_lock(&sl->response_mutex);                     /* (see bank_for) */
-      if (sl->response) chz_bank_set_responses(c->eng, b->id, k, 1, (const float *)sl->response);
-      pthread_mutex_unlock(&sl->response_mutex);
-      b->beam_on[k] = 0;                                           /* re-uploaded by the block below if the slave is in beam mode */
+  /* the overlap history in front of this block's new samples: the first M-1 samples of its window in the host ring */
+  const float *hist = f->in_type == COMPLEX ? (const float *)f->input_read_pointer.c : f->input_read_pointer.r;
+  for (int g = 0; g < c->nsh; g++) {
+    struct shard *sh = &c->sh[g];
+    chz_engine_destroy(sh->eng);
+    sh->eng = NULL;
+    if (chz_engine_create(&sh->eng, f->ilen, f->impulse_length, f->in_type == REAL ? CHZ_REAL : CHZ_COMPLEX, sh->device, NULL, 0) != 0) {
+      fprintf(stderr, "filter_hip: %s\n", chz_last_error());
+      die_for_the_supervisor("the engine could not be re-created");
     }
-    if (b->n > 0) {
-      chz_bank_set_shifts(c->eng, b->id, 0, b->n, b->shift);
-      if (!b->real) chz_bank_set_isb(c->eng, b->id, 0, b->n, b->isb);
+    (void)chz_engine_notch_order(sh->eng, 1);   /* what failed was a device-side wait: the new engine orders its notches by HIP events, which cannot run out */
+    for (int i = 0; i < sh->nbanks; i++) {
+      struct hbank *b = &sh->banks[i];
+      b->id = bank_create_dev(c, sh, b, b->cap);
+      if (b->id < 0) { fprintf(stderr, "filter_hip: %s\n", chz_last_error()); die_for_the_supervisor("a channel bank could not be re-created"); }
+      for (int k = 0; k < b->n; k++) {
+        struct filter_out *sl = b->slaves[k];
+        pthread_mutex_lock(&sl->response_mutex);                     /* (see bank_for) */
+        if (sl->response) chz_bank_set_responses(sh->eng, b->id, k, 1, (const float *)sl->response);
+        pthread_mutex_unlock(&sl->response_mutex);
+        b->beam_on[k] = 0;                                           /* re-uploaded by the block below if the slave is in beam mode */
+      }
+      if (b->n > 0) {
+        chz_bank_set_shifts(sh->eng, b->id, 0, b->n, b->shift);
+        if (!b->real) chz_bank_set_isb(sh->eng, b->id, 0, b->n, b->isb);
+      }
+      for (int s2 = 0; s2 < ND; s2++) {                              /* nothing staged survives */
+        b->stage_job[s2] = UINT_MAX; b->stage_n[s2] = 0;
+        for (int k = 0; k < b->cap; k++) b->stage_epoch[s2][k] = 0;
+      }
     }
-    for (int s2 = 0; s2 < ND; s2++) {                              /* nothing staged survives */
-      b->stage_job[s2] = UINT_MAX; b->stage_n[s2] = 0;
-      for (int k = 0; k < b->cap; k++) b->stage_epoch[s2][k] = 0;
+    if (chz_input_seek(sh->eng, job, f->impulse_length > 1 ? hist : NULL) != 0) {
+      fprintf(stderr, "filter_hip: %s\n", chz_last_error());
+      die_for_the_supervisor("the input history could not be re-seated");
     }
   }
   c->notch_ptr = NULL; c->notch_n = -1;                            /* sync_notches uploads the list again */
-  /* the overlap history in front of this block's new samples: the first M-1 samples of its window in the host ring */
-  const float *hist = f->in_type == COMPLEX ? (const float *)f->input_read_pointer.c : f->input_read_pointer.r;
-  if (chz_input_seek(c->eng, job, f->impulse_length > 1 ? hist : NULL) != 0) {
-    fprintf(stderr, "filter_hip: %s\n", chz_last_error());
-    die_for_the_supervisor("the input history could not be re-seated");
-  }
   stage_wrunlock(c);
-  c->recoveries++; c->last_recovery_job = job;
+  __atomic_fetch_add(&c->recoveries, 1u, __ATOMIC_RELAXED); c->last_recovery_job = job;
   __atomic_store_n(&c->engine_first_job, job, __ATOMIC_RELEASE);
   __atomic_store_n(&c->failed, false, __ATOMIC_RELEASE);
+}
+static bool any_engine_failed(struct mctx *c) {
+  if (__atomic_load_n(&c->failed, __ATOMIC_ACQUIRE)) return true;
+  for (int g = 0; g < c->nsh; g++) if (chz_engine_check(c->sh[g].eng) != 0) return true;
+  return false;
+}
+static int futex_wait_u32_ms(unsigned *addr, unsigned expected, long ms) {
+  struct timespec ts = {.tv_sec = ms / 1000, .tv_nsec = (ms % 1000) * 1000000L};
+  return (int)syscall(SYS_futex, addr, FUTEX_WAIT_PRIVATE, expected, &ts, NULL, 0);
 }
 
 int execute_filter_input(struct filter_in *const f) {
@@ -759,6 +896,7 @@ int execute_filter_input(struct filter_in *const f) {
   bool skip = false;
   {
     int const nslot = (int)(f->next_jobnum % ND);
+    int waited_ms = 0;
     for (;;) {
       unsigned const done = __atomic_load_n(&c->dev_seq[nslot], __ATOMIC_ACQUIRE);
       if (done == c->enq_seq[nslot]) break;
@@ -766,40 +904,68 @@ int execute_filter_input(struct filter_in *const f) {
          would overwrite the device-ring window of a forward transform that may not have run yet (8 blocks of ring: jobs r-3..r in
          flight read regions r-4..r, the copy of job r+4 writes region r-4).  Then the producer waits like the default mode. */
       if (c->drop_when_full && c->consecutive_skips < 3) { skip = true; break; }
-      futex_wait_u32(&c->dev_seq[nslot], done);
+      /* a watchdog of a few block times: after a sticky device error the runtime delivers no more stream callbacks, and a producer
+         asleep here for good would never reach the recovery below.  A failed check ends the wait (the recovery drains the old engines,
+         whose callbacks, if they still come, drop their blocks); a device that reports nothing and completes nothing for
+         WEDGED_MS is beyond recovery from in here */
+#define WATCHDOG_MS 250
+#define WEDGED_MS 10000
+      if (futex_wait_u32_ms(&c->dev_seq[nslot], done, WATCHDOG_MS) != 0 && errno == ETIMEDOUT) {
+        waited_ms += WATCHDOG_MS;
+        if (any_engine_failed(c)) { __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE); break; }
+        if (waited_ms >= WEDGED_MS) die_for_the_supervisor("the device has not completed a block for 10 s and reports no error");
+      }
     }
   }
   if (c->drop_when_full && f->next_jobnum >= ND) {
     /* ... and the H2D copy of block job-4 reads the region of the HOST ring the front end starts to overwrite as soon as this call
        returns (the ring holds ND windows): if the device's copy queue is THAT far behind, the producer has to wait for that copy --
        not for the block.  (In wait mode block job-4 has completed altogether by now.) */
-    if (chz_input_mark_wait(c->eng, (int)((f->next_jobnum - ND) % 8)) != 0) fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
+    for (int g = 0; g < c->nsh; g++)
+      if (chz_input_mark_wait(c->sh[g].eng, (int)((f->next_jobnum - ND) % 8)) != 0) fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
   }
   if (c->profile) clock_gettime(CLOCK_MONOTONIC, &tp1);
   pthread_mutex_lock(&c->lock);
   unsigned const job = __atomic_fetch_add(&f->next_jobnum, 1u, __ATOMIC_RELAXED);   /* src/filter.c:607; read lock-free by slaves being created */
   int const slot = (int)(job % ND);
-  if (__atomic_load_n(&c->failed, __ATOMIC_ACQUIRE) || chz_engine_check(c->eng) != 0) {
+  if (any_engine_failed(c)) {
+    __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE);
     recover_engine(c, f, job);
-    skip = false;                                                   /* the new engine is idle */
+    skip = false;                                                   /* the new engines are idle */
+    for (int s2 = 0; s2 < ND; s2++)
+      if (__atomic_load_n(&c->dev_seq[s2], __ATOMIC_ACQUIRE) != c->enq_seq[s2]) {
+        /* a block whose completion callback never came (after a sticky device error the runtime delivers none): the old engines are
+           gone, nobody else will tell its slaves -- zeros and a counted drop, like every block the failure cost */
+        unsigned const lost = c->note[s2][0].job;
+        __atomic_fetch_add(&c->failed_blocks, 1u, __ATOMIC_RELAXED);
+        __atomic_store_n(&c->skipped[s2][(lost / ND) % SKIP_RING], ((uint64_t)1 << 32) | lost, __ATOMIC_RELEASE);
+        announce(c, s2, true);
+        __atomic_store_n(&c->dev_seq[s2], c->enq_seq[s2], __ATOMIC_RELEASE);
+      }
   }
   /* readers pick this up without a lock, possibly while a later lap overwrites it (as in the reference): tear-free accesses */
   __atomic_store_n(&f->samples_by_job[slot], f->sample_index, __ATOMIC_RELAXED);   /* src/filter.c:614-615 */
   f->sample_index += (uint64_t)f->ilen;
+  /* the window is [read, read+N); its last L samples are the new ones (the mirror keeps them contiguous).  Advance the read
+     pointer by L (src/filter.c:626-636). */
+  const float *newsamples;
+  if (f->in_type == COMPLEX) {
+    newsamples = (const float *)(f->input_read_pointer.c + (f->impulse_length - 1));
+    f->input_read_pointer.c += f->ilen;
+    ring_wrap((void **)&f->input_read_pointer.c, f->input_buffer, f->input_buffer_size);
+  } else {
+    newsamples = f->input_read_pointer.r + (f->impulse_length - 1);
+    f->input_read_pointer.r += f->ilen;
+    ring_wrap((void **)&f->input_read_pointer.r, f->input_buffer, f->input_buffer_size);
+  }
   if (skip) {
-    /* the samples still go to the device ring (the next block's window starts with them); nothing is transformed, the
+    /* the samples still go to the device rings (the next block's window starts with them); nothing is transformed, the
        slot's records stay with the block that is still in flight, and the slaves are told at once */
     int rc = 0;
-    if (f->in_type == COMPLEX) {
-      rc = chz_input_write(c->eng, (const float *)(f->input_read_pointer.c + (f->impulse_length - 1)), f->ilen);
-      f->input_read_pointer.c += f->ilen;
-      ring_wrap((void **)&f->input_read_pointer.c, f->input_buffer, f->input_buffer_size);
-    } else {
-      rc = chz_input_write(c->eng, f->input_read_pointer.r + (f->impulse_length - 1), f->ilen);
-      f->input_read_pointer.r += f->ilen;
-      ring_wrap((void **)&f->input_read_pointer.r, f->input_buffer, f->input_buffer_size);
+    for (int g = 0; g < c->nsh && rc == 0; g++) {
+      rc = chz_input_write(c->sh[g].eng, newsamples, f->ilen);
+      if (rc == 0) rc = chz_input_mark(c->sh[g].eng, (int)(job % 8));
     }
-    if (rc == 0) rc = chz_input_mark(c->eng, (int)(job % 8));
     if (rc != 0) fprintf(stderr, "execute_filter_input: %s\n", chz_last_error());
     /* completed_jobs[slot] stays with the block still in flight there (publishing this one in it would lap that block away
        from every slave that has not fetched it yet): a skipped block is announced on its own */
@@ -811,84 +977,97 @@ int execute_filter_input(struct filter_in *const f) {
     return rc == 0 ? 0 : -1;
   }
   c->consecutive_skips = 0;
-  struct done_note *note = &c->note[slot];
-  note->ctx = c; note->job = job;
-  note->seq = ++c->enq_seq[slot];
-  clock_gettime(CLOCK_MONOTONIC, &note->t0);
+  unsigned const seq = ++c->enq_seq[slot];
+  struct timespec tq;
+  clock_gettime(CLOCK_MONOTONIC, &tq);
   sync_notches(c, f);
 
-  /* the window is [read, read+N); its last L samples are the new ones (the mirror keeps
-     them contiguous).  Advance the read pointer by L (src/filter.c:626-636). */
-  int rc = 0;
-  if (f->in_type == COMPLEX) {
-    float complex *win = f->input_read_pointer.c;
-    rc = chz_input_write(c->eng, (const float *)(win + (f->impulse_length - 1)), f->ilen);
-    f->input_read_pointer.c += f->ilen;
-    ring_wrap((void **)&f->input_read_pointer.c, f->input_buffer, f->input_buffer_size);
-  } else {
-    float *win = f->input_read_pointer.r;
-    rc = chz_input_write(c->eng, win + (f->impulse_length - 1), f->ilen);
-    f->input_read_pointer.r += f->ilen;
-    ring_wrap((void **)&f->input_read_pointer.r, f->input_buffer, f->input_buffer_size);
-  }
-  if (rc == 0 && c->drop_when_full) rc = chz_input_mark(c->eng, (int)(job % 8));
-  if (rc == 0) rc = chz_forward(c->eng, job);
-  if (rc == 0 && c->host_spectrum) rc = chz_spectrum_read_async(c->eng, slot, (float *)f->fdomain[slot]);
-  /* speculative batched channel launches: every slave with its last-known shift */
-  for (int i = 0; rc == 0 && i < c->nbanks; i++) {
-    struct hbank *b = &c->banks[i];
-    stage_wrlock(c);
-    if (!b->real) {                 /* callers flip slave->isb directly (src/radio.c:1586, src/radio_status.c:326) */
-      int lo = b->n, hi = 0;
-      for (int k = 0; k < b->n; k++) {
-        /* a caller-owned bool its own thread flips at will: a relaxed one-byte load */
-        unsigned char v = __atomic_load_n((unsigned char const *)&b->slaves[k]->isb, __ATOMIC_RELAXED) ? 1 : 0;
-        if (v != b->isb[k]) { b->isb[k] = v; if (k < lo) lo = k; hi = k + 1; }
-      }
-      if (hi > lo) chz_bank_set_isb(c->eng, b->id, lo, hi - lo, b->isb + lo);
-    }
-    b->stage_job[slot] = job; b->stage_n[slot] = b->n;
-    for (int k = 0; k < b->n; k++) {
-      b->stage_shift[slot][k] = b->shift[k];
-      b->stage_epoch[slot][k] = __atomic_load_n(&b->slaves[k]->response, __ATOMIC_ACQUIRE) ? SCTX(b->slaves[k])->epoch : 0;
-      b->stage_isb[slot][k] = b->isb[k];
-    }
-    stage_wrunlock(c);
-    if (b->n == 0) continue;
-    if (!b->real) {
-      if (f->in_type == COMPLEX) {   /* slave->beam and its weights (src/radio.c:938-940) */
+  int rc = 0, callbacks = 0;
+  __atomic_store_n(&c->pending[slot], (unsigned)c->nsh, __ATOMIC_RELEASE);
+  for (int g = 0; g < c->nsh && rc == 0; g++) {
+    struct shard *const sh = &c->sh[g];
+    struct done_note *note = &c->note[slot][g];
+    note->ctx = c; note->job = job; note->seq = seq; note->shard = g; note->t0 = tq;
+    rc = chz_input_write(sh->eng, newsamples, f->ilen);
+    if (rc == 0 && c->drop_when_full) rc = chz_input_mark(sh->eng, (int)(job % 8));
+    if (rc == 0) rc = chz_forward(sh->eng, job);
+    if (rc == 0 && g == 0 && c->host_spectrum) rc = chz_spectrum_read_async(sh->eng, slot, (float *)f->fdomain[slot]);
+    /* batched channel launches: every slave with the shift it has asked for (or, failing that, asked for last) */
+    for (int i = 0; rc == 0 && i < sh->nbanks; i++) {
+      struct hbank *b = &sh->banks[i];
+      stage_wrlock(c);
+      {
+        int lo = b->n, hi = 0, slo = b->n, shi = 0;
         for (int k = 0; k < b->n; k++) {
-          struct filter_out *s = b->slaves[k];
-          /* set_filter_weights() runs in the slave's own thread and writes two complex doubles: read them whole */
-          if (s->init) pthread_mutex_lock(&s->response_mutex);
-          double ab[4] = {creal(s->alpha), cimag(s->alpha), creal(s->beta), cimag(s->beta)};
-          if (s->init) pthread_mutex_unlock(&s->response_mutex);
-          unsigned char on = __atomic_load_n((unsigned char const *)&s->beam, __ATOMIC_RELAXED) ? 1 : 0;
-          if (on != b->beam_on[k] || (on && memcmp(ab, b->beam_ab + 4 * k, sizeof ab) != 0)) {
-            b->beam_on[k] = on; memcpy(b->beam_ab + 4 * k, ab, sizeof ab);
-            chz_bank_set_beam(c->eng, b->id, k, 1, ab, &on);
-            stage_wrlock(c);
-            for (int s2 = 0; s2 < ND; s2++) if (s2 != slot) b->stage_epoch[s2][k] = 0;   /* earlier staged results used other weights */
-            stage_wrunlock(c);
+          struct filter_out *const sl = b->slaves[k];
+          if (!b->real) {           /* callers flip slave->isb directly (src/radio.c:1586, src/radio_status.c:326) */
+            /* a caller-owned bool its own thread flips at will: a relaxed one-byte load */
+            unsigned char v = __atomic_load_n((unsigned char const *)&sl->isb, __ATOMIC_RELAXED) ? 1 : 0;
+            if (v != b->isb[k]) { b->isb[k] = v; if (k < lo) lo = k; hi = k + 1; }
+          }
+          /* the shift the slave published when it came for a block (see struct sctx) */
+          struct sctx *const sc = SCTX(sl);
+          if (__atomic_load_n(&sc->want_valid, __ATOMIC_ACQUIRE)) {
+            int const w = __atomic_load_n(&sc->want_shift, __ATOMIC_RELAXED);
+            if (w != b->shift[k]) {
+              b->shift[k] = w;
+              if (shi > 0 && k > shi + 64) { chz_bank_set_shifts(sh->eng, b->id, slo, shi - slo, b->shift + slo); slo = k; }   /* islands far apart: separate edits */
+              if (k < slo) slo = k;
+              shi = k + 1;
+            }
+          }
+        }
+        if (hi > lo) chz_bank_set_isb(sh->eng, b->id, lo, hi - lo, b->isb + lo);
+        if (shi > slo) chz_bank_set_shifts(sh->eng, b->id, slo, shi - slo, b->shift + slo);
+      }
+      b->stage_job[slot] = job; b->stage_n[slot] = b->n;
+      for (int k = 0; k < b->n; k++) {
+        b->stage_shift[slot][k] = b->shift[k];
+        b->stage_epoch[slot][k] = __atomic_load_n(&b->slaves[k]->response, __ATOMIC_ACQUIRE) ? SCTX(b->slaves[k])->epoch : 0;
+        b->stage_isb[slot][k] = b->isb[k];
+      }
+      stage_wrunlock(c);
+      if (b->n == 0) continue;
+      if (!b->real) {
+        if (f->in_type == COMPLEX) {   /* slave->beam and its weights (src/radio.c:938-940) */
+          for (int k = 0; k < b->n; k++) {
+            struct filter_out *sl = b->slaves[k];
+            /* set_filter_weights() runs in the slave's own thread and writes two complex doubles: read them whole */
+            if (sl->init) pthread_mutex_lock(&sl->response_mutex);
+            double ab[4] = {creal(sl->alpha), cimag(sl->alpha), creal(sl->beta), cimag(sl->beta)};
+            if (sl->init) pthread_mutex_unlock(&sl->response_mutex);
+            unsigned char on = __atomic_load_n((unsigned char const *)&sl->beam, __ATOMIC_RELAXED) ? 1 : 0;
+            if (on != b->beam_on[k] || (on && memcmp(ab, b->beam_ab + 4 * k, sizeof ab) != 0)) {
+              b->beam_on[k] = on; memcpy(b->beam_ab + 4 * k, ab, sizeof ab);
+              chz_bank_set_beam(sh->eng, b->id, k, 1, ab, &on);
+              stage_wrlock(c);
+              for (int s2 = 0; s2 < ND; s2++) if (s2 != slot) b->stage_epoch[s2][k] = 0;   /* earlier staged results used other weights */
+              stage_wrunlock(c);
+            }
           }
         }
       }
+      chz_bank_set_active(sh->eng, b->id, b->n);
+      rc = chz_bank_execute(sh->eng, b->id, slot);
+      if (rc == 0) rc = chz_bank_read_async(sh->eng, b->id, slot, 0, b->n, (float *)b->stage[slot]);
+      if (rc == 0 && b->noise_on) rc = chz_bank_read_noise_async(sh->eng, b->id, slot, 0, b->n, b->stage_n0[slot]);
     }
-    chz_bank_set_active(c->eng, b->id, b->n);
-    rc = chz_bank_execute(c->eng, b->id, slot);
-    if (rc == 0) rc = chz_bank_read_async(c->eng, b->id, slot, 0, b->n, (float *)b->stage[slot]);
-    if (rc == 0 && b->noise_on) rc = chz_bank_read_noise_async(c->eng, b->id, slot, 0, b->n, b->stage_n0[slot]);
+    if (rc == 0) rc = chz_host_callback(sh->eng, slot, block_done, note);
+    if (rc == 0) callbacks++;
   }
-  if (rc == 0) rc = chz_host_callback(c->eng, slot, block_done, note);
   if (rc != 0) {
-    /* no completion callback will come for this block: it is dropped here (zeros + a counted drop for every slave), and the next
-       call replaces the engine (ONE line of log, not one per block) */
+    /* the block is dropped here (zeros + a counted drop for every slave), and the next call replaces the engines (ONE line of log,
+       not one per block).  Devices that did take the block still call back: they see `failed` and the last of them announces the
+       block as dropped; if none did, nobody will -- it is announced from here */
     fprintf(stderr, "execute_filter_input: block %u: %s\n", job, chz_last_error());
-    c->enq_seq[slot]--;
     __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE);
-    __atomic_fetch_add(&c->failed_blocks, 1u, __ATOMIC_RELAXED);
-    __atomic_store_n(&c->skipped[slot][(job / ND) % SKIP_RING], ((uint64_t)1 << 32) | job, __ATOMIC_RELEASE);
-    announce(c, slot, true);
+    unsigned const missing = (unsigned)(c->nsh - callbacks);
+    if (missing && __atomic_sub_fetch(&c->pending[slot], missing, __ATOMIC_ACQ_REL) == 0) {
+      __atomic_fetch_add(&c->failed_blocks, 1u, __ATOMIC_RELAXED);
+      __atomic_store_n(&c->skipped[slot][(job / ND) % SKIP_RING], ((uint64_t)1 << 32) | job, __ATOMIC_RELEASE);
+      announce(c, slot, true);
+      __atomic_store_n(&c->dev_seq[slot], seq, __ATOMIC_RELEASE);
+    }
   }
   if (c->profile) {
     struct timespec tp2; clock_gettime(CLOCK_MONOTONIC, &tp2);
@@ -898,7 +1077,7 @@ int execute_filter_input(struct filter_in *const f) {
   }
   pthread_mutex_unlock(&c->lock);
   if (rc == 0 && f->perform_inline) {      /* inline masters hand the block over before returning (src/filter.c:562-600) */
-    chz_sync(c->eng);
+    for (int g = 0; g < c->nsh; g++) chz_sync(c->sh[g].eng);
     pthread_mutex_lock(&f->filter_mutex);
     __atomic_store_n(&f->owner, pthread_self(), __ATOMIC_RELEASE);      /* read without the mutex by execute_filter_output */
     pthread_mutex_unlock(&f->filter_mutex);
@@ -932,44 +1111,86 @@ int write_rfilter(struct filter_in *f, float const *buffer, int size) {         
 /* ------------------------------------------------------------------------- */
 /* output side                                                                   */
 /* ------------------------------------------------------------------------- */
-/* Serve every queued miss with one device round trip: per request refresh the channel's shift / ISB flag (host-side
-   edits, picked up in stream order), launch that one channel on the block's spectrum, read it into the channel's
-   place in the staged image; then ONE wait per spectrum slot touched.  Caller is the batch leader. */
+/* Serve every queued miss with one device round trip per device: per request refresh the channel's shift / ISB flag (host-side
+   edits, picked up in stream order); then, per bank and spectrum slot, a FEW requests are re-run and read back one channel at a time
+   into their places in the staged image, MANY (a master whose slaves have all just been retuned, or the first block of slaves that
+   arrived after it was launched) as ONE launch over the range of channels that covers them and one copy -- 2000 single-channel
+   launches and copies cost tens of milliseconds, the whole bank again costs tens of microseconds; then ONE wait per slot touched.
+   Caller is the batch leader. */
+#define MISS_BATCH 8
 static void serve_misses(struct mctx *c, struct miss_req *list) {
-  bool touched[ND] = {false, false, false, false};
   pthread_mutex_lock(&c->lock);
+  /* host-side edits first */
   for (struct miss_req *r = list; r; r = r->next) {
     struct sctx *sc = SCTX(r->slave);
-    struct hbank *b = &c->banks[sc->bank];
+    struct shard *sh = &c->sh[sc->dev];
+    struct hbank *b = &sh->banks[sc->bank];
     int const k = sc->idx;
     unsigned char const isb = r->slave->isb ? 1 : 0;
     int rc = 0;
-    if (b->shift[k] != r->shift) { b->shift[k] = r->shift; rc = chz_bank_set_shifts(c->eng, b->id, k, 1, &b->shift[k]); }
-    if (rc == 0 && !b->real && b->isb[k] != isb) { b->isb[k] = isb; rc = chz_bank_set_isb(c->eng, b->id, k, 1, &b->isb[k]); }
-    if (rc == 0) rc = chz_bank_execute_range(c->eng, b->id, (unsigned)r->slot, k, 1);
-    if (rc == 0) rc = chz_bank_read_async(c->eng, b->id, r->slot, k, 1,
-                                          (float *)((char *)b->stage[r->slot] + (size_t)k * b->olen * bank_sample_bytes(b)));
-    if (rc == 0 && b->noise_on) rc = chz_bank_read_noise_async(c->eng, b->id, r->slot, k, 1, b->stage_n0[r->slot] + k);
-    if (rc != 0) {
-      /* a broken engine (the producer replaces it at its next block): this channel's block is lost with it, once, quietly */
-      if (chz_engine_check(c->eng) != 0 || __atomic_load_n(&c->failed, __ATOMIC_ACQUIRE)) __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE);
-      else fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
-    }
-    r->rc = rc;
-    touched[r->slot] = true;
+    if (b->shift[k] != r->shift) { b->shift[k] = r->shift; rc = chz_bank_set_shifts(sh->eng, b->id, k, 1, &b->shift[k]); }
+    if (rc == 0 && !b->real && b->isb[k] != isb) { b->isb[k] = isb; rc = chz_bank_set_isb(sh->eng, b->id, k, 1, &b->isb[k]); }
+    r->rc = rc; r->ranged = false;
   }
-  for (int s = 0; s < ND; s++)
-    if (touched[s] && chz_slot_sync(c->eng, s) != 0) {
-      if (chz_engine_check(c->eng) != 0) __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE);
-      else fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
-      for (struct miss_req *r = list; r; r = r->next) if (r->slot == s) r->rc = -1;
+  bool wide = false;             /* a range re-run overwrites staged results of channels that did not ask: readers stay out meanwhile */
+  for (int g = 0; g < c->nsh; g++) {
+    struct shard *sh = &c->sh[g];
+    bool touched[ND] = {false, false, false, false};
+    for (int bi = 0; bi < sh->nbanks; bi++) for (int slot = 0; slot < ND; slot++) {
+      struct hbank *b = &sh->banks[bi];
+      int cnt = 0, lo = INT_MAX, hi = 0;
+      for (struct miss_req *r = list; r; r = r->next) {
+        struct sctx *sc = SCTX(r->slave);
+        if (sc->dev != g || sc->bank != bi || r->slot != slot || r->rc != 0) continue;
+        cnt++; if (sc->idx < lo) lo = sc->idx; if (sc->idx + 1 > hi) hi = sc->idx + 1;
+      }
+      if (cnt == 0) continue;
+      int rc = 0;
+      bool const ranged = cnt > MISS_BATCH && b->stage_job[slot] != UINT_MAX && hi <= b->stage_n[slot];
+      if (ranged) {
+        if (!wide) { stage_wrlock(c); wide = true; }
+        rc = chz_bank_execute_range(sh->eng, b->id, (unsigned)slot, lo, hi - lo);
+        if (rc == 0) rc = chz_bank_read_async(sh->eng, b->id, slot, lo, hi - lo, (float *)((char *)b->stage[slot] + (size_t)lo * b->olen * bank_sample_bytes(b)));
+        if (rc == 0 && b->noise_on) rc = chz_bank_read_noise_async(sh->eng, b->id, slot, lo, hi - lo, b->stage_n0[slot] + lo);
+        /* what the image now holds for EVERY channel of the range: computed with the bank's current shifts, ISB flags and responses */
+        for (int k = lo; rc == 0 && k < hi; k++) {
+          b->stage_shift[slot][k] = b->shift[k];
+          b->stage_isb[slot][k] = b->isb[k];
+          b->stage_epoch[slot][k] = __atomic_load_n(&b->slaves[k]->response, __ATOMIC_ACQUIRE) ? SCTX(b->slaves[k])->epoch : 0;
+        }
+      }
+      for (struct miss_req *r = list; r; r = r->next) {
+        struct sctx *sc = SCTX(r->slave);
+        if (sc->dev != g || sc->bank != bi || r->slot != slot || r->rc != 0) continue;
+        if (ranged) { r->rc = rc; r->ranged = true; }
+        else {
+          int const k = sc->idx;
+          rc = chz_bank_execute_range(sh->eng, b->id, (unsigned)slot, k, 1);
+          if (rc == 0) rc = chz_bank_read_async(sh->eng, b->id, slot, k, 1, (float *)((char *)b->stage[slot] + (size_t)k * b->olen * bank_sample_bytes(b)));
+          if (rc == 0 && b->noise_on) rc = chz_bank_read_noise_async(sh->eng, b->id, slot, k, 1, b->stage_n0[slot] + k);
+          r->rc = rc;
+        }
+        if (r->rc != 0) {
+          /* a broken engine (the producer replaces it at its next block): this channel's block is lost with it, once, quietly */
+          if (chz_engine_check(sh->eng) != 0 || __atomic_load_n(&c->failed, __ATOMIC_ACQUIRE)) __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE);
+          else fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
+        }
+      }
+      touched[slot] = true;
     }
+    for (int s2 = 0; s2 < ND; s2++)
+      if (touched[s2] && chz_slot_sync(sh->eng, s2) != 0) {
+        if (chz_engine_check(sh->eng) != 0) __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE);
+        else fprintf(stderr, "execute_filter_output: %s\n", chz_last_error());
+        for (struct miss_req *r = list; r; r = r->next) if (r->slot == s2 && SCTX(r->slave)->dev == g) r->rc = -1;
+      }
+  }
   /* the staged image now holds exactly what each requester asked for */
-  stage_wrlock(c);
+  if (!wide) stage_wrlock(c);
   for (struct miss_req *r = list; r; r = r->next) {
-    if (r->rc != 0) continue;
+    if (r->rc != 0 || r->ranged) continue;
     struct sctx *sc = SCTX(r->slave);
-    struct hbank *b = &c->banks[sc->bank];
+    struct hbank *b = &c->sh[sc->dev].banks[sc->bank];
     if (b->stage_job[r->slot] == r->job && sc->idx < b->stage_n[r->slot]) {
       b->stage_shift[r->slot][sc->idx] = r->shift;
       b->stage_epoch[r->slot][sc->idx] = sc->epoch;
@@ -996,6 +1217,11 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
      plus the pass-it-on below.) */
   struct mctx *const mc = (master->fwd_plan && !is_mini_master(master)) ? MCTX(master) : NULL;
   int const shard = (mc && slave->rev_plan) ? SCTX(slave)->shard : 0;
+  if (mc && slave->rev_plan) {            /* what this slave wants its next block computed with: read by the front end when it launches one */
+    struct sctx *const sc0 = SCTX(slave);
+    __atomic_store_n(&sc0->want_shift, shift, __ATOMIC_RELAXED);
+    __atomic_store_n(&sc0->want_valid, 1, __ATOMIC_RELEASE);
+  }
   unsigned *const wake = mc ? &mc->gen[slot][shard].v : &master->completed_jobs[slot];
   bool skipped = false;
   for (;;) {
@@ -1051,7 +1277,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
     bool hit = false;
     pthread_rwlock_t *const rl = stage_rdlock(c, slave);
     {
-      struct hbank *b = &c->banks[sc->bank];
+      struct hbank *b = &c->sh[sc->dev].banks[sc->bank];
       int const k = sc->idx;
       if (b->stage_job[slot] == job && k < b->stage_n[slot] && b->stage_shift[slot][k] == shift &&
           b->stage_epoch[slot][k] == sc->epoch && (b->real || b->stage_isb[slot][k] == (slave->isb ? 1 : 0))) {
@@ -1065,13 +1291,13 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
     if (c->profile) {
       if (hit && attempt == 0) {
         struct timespec tn; clock_gettime(CLOCK_MONOTONIC, &tn);
-        long long const ns = (tn.tv_sec - c->t_done[slot].tv_sec) * 1000000000LL + (tn.tv_nsec - c->t_done[slot].tv_nsec);
+        long long const ns = (long long)tn.tv_sec * 1000000000LL + tn.tv_nsec - __atomic_load_n(&c->t_done_ns[slot], __ATOMIC_RELAXED);
         if (ns >= 0 && ns < 1000000000LL) {
           __atomic_fetch_add(&c->prof_consume_sum_ns, (unsigned long long)ns, __ATOMIC_RELAXED);
           __atomic_fetch_add(&c->prof_consume_n, 1ull, __ATOMIC_RELAXED);
           unsigned long long mx = __atomic_load_n(&c->prof_consume_max_ns, __ATOMIC_RELAXED);
           while ((unsigned long long)ns > mx && !__atomic_compare_exchange_n(&c->prof_consume_max_ns, &mx, (unsigned long long)ns, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
-          if (job >= 8 && c->t_done_job[slot] == job) {
+          if (job >= 8 && __atomic_load_n(&c->t_done_job[slot], __ATOMIC_RELAXED) == job) {
             mx = __atomic_load_n(&c->prof_consume_max8_ns, __ATOMIC_RELAXED);
             while ((unsigned long long)ns > mx && !__atomic_compare_exchange_n(&c->prof_consume_max8_ns, &mx, (unsigned long long)ns, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
           }
@@ -1082,7 +1308,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
     if (hit) return 0;
     /* a block the PREVIOUS engine completed, asked for after that engine was replaced: its staged results were invalidated and its
        spectrum is gone -- re-running the channel on the new engine's slot would hand out garbage: zeros + a counted drop */
-    if (c->recoveries && (int)(job - __atomic_load_n(&c->engine_first_job, __ATOMIC_ACQUIRE)) < 0) {
+    if (__atomic_load_n(&c->recoveries, __ATOMIC_RELAXED) && (int)(job - __atomic_load_n(&c->engine_first_job, __ATOMIC_ACQUIRE)) < 0) {
       slave->block_drops++;
       memset(dst, 0, (real_out ? sizeof(float) : sizeof(float complex)) * (size_t)slave->olen);
       return 0;
@@ -1138,11 +1364,12 @@ int filter_hip_enable_noise(struct filter_in *master, double samprate) {
   pthread_mutex_lock(&c->lock);
   stage_wrlock(c);
   c->noise_samprate = samprate;
-  for (int i = 0; i < c->nbanks; i++) {
-    struct hbank *b = &c->banks[i];
-    b->noise_on = chz_bank_enable_noise(c->eng, b->id, samprate) == 0 && samprate > 0;
+  for (int g = 0; g < c->nsh; g++) for (int i = 0; i < c->sh[g].nbanks; i++) {
+    struct hbank *b = &c->sh[g].banks[i];
+    b->noise_on = chz_bank_enable_noise(c->sh[g].eng, b->id, samprate) == 0 && samprate > 0;
     if (samprate > 0 && !b->noise_on) rc = 1;                /* some channel size has no noise kernel: those slaves report NaN */
     for (int s = 0; s < ND; s++) for (int k = 0; k < b->cap; k++) b->stage_n0[s][k] = NAN;
+    if (b->noise_on && b->n > 0) bank_warm(&c->sh[g], b);   /* the noise kernel's first launch is not block 0's business */
   }
   stage_wrunlock(c);
   pthread_mutex_unlock(&c->lock);
@@ -1159,7 +1386,8 @@ int filter_hip_drain(struct filter_in *master) {
   if (master == NULL || master->fwd_plan == NULL || is_mini_master(master)) return -1;
   struct mctx *c = MCTX(master);
   pthread_mutex_lock(&c->lock);              /* the producer and the miss leaders enqueue (and a recovery swaps the engine) under it */
-  int const rc = chz_sync(c->eng);
+  int rc = 0;
+  for (int g = 0; g < c->nsh; g++) if (chz_sync(c->sh[g].eng) != 0) rc = -1;
   pthread_mutex_unlock(&c->lock);
   return rc == 0 ? 0 : -1;
 }
@@ -1173,7 +1401,18 @@ unsigned filter_hip_recoveries(struct filter_in const *master, unsigned *blocks_
   if (master == NULL || master->fwd_plan == NULL || is_mini_master(master)) return 0;
   struct mctx const *c = (struct mctx const *)(void const *)master->fwd_plan;
   if (blocks_lost) *blocks_lost = __atomic_load_n(&c->failed_blocks, __ATOMIC_RELAXED);
-  return c->recoveries;
+  return __atomic_load_n(&c->recoveries, __ATOMIC_RELAXED);
+}
+/* how many devices the master's slaves are spread over (KA9Q_HIP_DEVICES), and -- counts != NULL -- how many slaves live on each */
+int filter_hip_devices(struct filter_in const *master, int *counts, int max) {
+  if (master == NULL || master->fwd_plan == NULL || is_mini_master(master)) return 0;
+  struct mctx *c = (struct mctx *)(void *)master->fwd_plan;
+  if (counts) {
+    pthread_mutex_lock(&c->lock);
+    for (int g = 0; g < c->nsh && g < max; g++) counts[g] = c->sh[g].nslaves;
+    pthread_mutex_unlock(&c->lock);
+  }
+  return c->nsh;
 }
 
 int set_filter_weights(struct filter_out *out, double complex i_weight, double complex q_weight) {  /* src/filter.c:922-929 */
@@ -1233,7 +1472,7 @@ int set_filter(struct filter_out *const slave, double low, double high, double c
     stage_wrlock(c);
     sc->epoch++;
     stage_wrunlock(c);
-    int rc = chz_bank_set_responses(c->eng, c->banks[sc->bank].id, sc->idx, 1, (const float *)response);
+    int rc = chz_bank_set_responses(c->sh[sc->dev].eng, c->sh[sc->dev].banks[sc->bank].id, sc->idx, 1, (const float *)response);
     pthread_mutex_unlock(&c->lock);
     if (rc != 0) { fprintf(stderr, "set_filter: %s\n", chz_last_error()); return -1; }
   }

@@ -315,6 +315,11 @@ double refchz_bench_blocks(void *mh, void **chans, const int *shifts, int nchan,
   return t1 - t0;
 }
 
+/* between two paced probes: block_drops is a running total per slave (src/filter.c:700), the next probe counts from zero */
+void refchz_reset_drops(void **chans, int nchan) {
+  for (int i = 0; i < nchan; i++) ((struct refchz_chan *)chans[i])->out.block_drops = 0;
+}
+
 extern int64_t Min_fft_time, Max_fft_time, Avg_fft_time;
 void refchz_fft_times(long long *mn, long long *mx, long long *avg) { *mn = Min_fft_time; *mx = Max_fft_time; *avg = Avg_fft_time; }
 

@@ -33,6 +33,8 @@ extern int filter_hip_enable_noise(struct filter_in *, double) __attribute__((we
 extern double filter_hip_noise(struct filter_out const *) __attribute__((weak));
 extern unsigned long filter_hip_skipped_blocks(struct filter_in const *) __attribute__((weak));
 extern int filter_hip_drain(struct filter_in *) __attribute__((weak));
+extern int filter_hip_devices(struct filter_in const *, int *, int) __attribute__((weak));
+static int Devices = 1; static char Dev_counts[256] = "-";   /* KA9Q_HIP_DEVICES: devices behind the master and the slaves on each, once everybody has registered */
 static double Noise_samprate; static double *Noise;   /* env HARNESS_NOISE=<front-end sample rate>: [Nblocks][Nch] device-side estimate_noise() */
 static int Ahead = 2;                                  /* env HARNESS_AHEAD: blocks the front end may run ahead of the slowest channel (the filter keeps ND = 4 blocks: 3 loses nothing) */
 static int Free_run;                                   /* env HARNESS_FREE_RUN=1: the front end does not wait for the channels (a real A/D never does); > 1: and takes that many microseconds per block */
@@ -250,6 +252,12 @@ int main(int argc, char **argv) {
   while (!atomic_load(&Clock_ready) || (Real_on && !atomic_load(&Real_ready))) usleep(200);
 
   if (Noise && filter_hip_enable_noise(&Master, Noise_samprate) < 0) { fprintf(stderr, "filter_hip_enable_noise failed\n"); return 5; }
+  if (filter_hip_devices) {
+    int cnt[64] = {0};
+    Devices = filter_hip_devices(&Master, cnt, 64);
+    size_t o = 0;
+    for (int g = 0; g < Devices && g < 64 && o + 16 < sizeof Dev_counts; g++) o += (size_t)snprintf(Dev_counts + o, sizeof Dev_counts - o, "%s%d", g ? ":" : "", cnt[g]);
+  }
   /* front end: write in place, then tell the filter how much arrived */
   struct timespec ts0, ts1;
   clock_gettime(CLOCK_MONOTONIC, &ts0);
@@ -301,7 +309,7 @@ int main(int argc, char **argv) {
   for (int i = 0; i < Nch; i++) pthread_join(th[i], NULL);
   pthread_join(clk, NULL);
   if (Real_on) pthread_join(rth, NULL);
-  if (Free_run && filter_hip_drain) filter_hip_drain(&Master);   /* skipped blocks let the consumers finish before the device has */
+  if (filter_hip_drain) filter_hip_drain(&Master);   /* skipped blocks let the consumers finish before the device has; and the statistics below are the callback thread's */
   clock_gettime(CLOCK_MONOTONIC, &ts1);
   double elapsed = (ts1.tv_sec - ts0.tv_sec) + 1e-9 * (ts1.tv_nsec - ts0.tv_nsec);
 
@@ -339,11 +347,12 @@ int main(int argc, char **argv) {
   f = fopen(path, "w");
   unsigned drops = 0; for (int i = 0; i < Nch; i++) drops += Drops[i];
   fprintf(f, "drops %u clock %d next_jobnum %u bins %d points %d sample_index %llu elapsed_s %.6f avg_block_ns %lld max_block_ns %lld "
-             "worst_gap_ns %lld mean_gap_ns %lld fe_copy_ns %lld fe_call_ns %lld fe_wait_ns %lld skipped %lu fe_late_worst_ns %lld fe_call_worst_ns %lld\n",
+             "worst_gap_ns %lld mean_gap_ns %lld fe_copy_ns %lld fe_call_ns %lld fe_wait_ns %lld skipped %lu fe_late_worst_ns %lld fe_call_worst_ns %lld "
+             "devices %d dev_counts %s\n",
           drops, atomic_load(&Clock_blocks), Master.next_jobnum, Master.bins, Master.points,
           (unsigned long long)Master.sample_index, elapsed, (long long)Avg_fft_time, (long long)Max_fft_time,
           Worst_gap_ns, N_gap ? Sum_gap_ns / N_gap : 0, Fe_copy_ns, Fe_call_ns, Fe_wait_ns,
-          filter_hip_skipped_blocks ? filter_hip_skipped_blocks(&Master) : 0ul, Fe_late_worst_ns, Fe_call_worst_ns);
+          filter_hip_skipped_blocks ? filter_hip_skipped_blocks(&Master) : 0ul, Fe_late_worst_ns, Fe_call_worst_ns, Devices, Dev_counts);
   fclose(f);
   delete_filter_input(&Master);
   free(th); free(args); free(notch);      /* a clean exit for the leak checker of the sanitizer runs (the caller owns the notch list) */

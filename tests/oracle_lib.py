@@ -111,6 +111,9 @@ def ref():
         if hasattr(L, "refchz_bench_blocks"):
             L.refchz_bench_blocks.restype = _d
             L.refchz_bench_blocks.argtypes = [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i]
+        if hasattr(L, "refchz_reset_drops"):
+            L.refchz_reset_drops.restype = None
+            L.refchz_reset_drops.argtypes = [_vp, _i]
         L.refchz_fft_times.argtypes = [_vp, _vp, _vp]
         L.refsig_create.restype = _vp; L.refsig_create.argtypes = [_d, _d, _d, _d, _i, C.c_ulonglong]
         L.refsig_delete.argtypes = [_vp]

@@ -70,10 +70,12 @@ static std::atomic<int> g_instances{0};     // engines created by this process s
 extern "C" {
 
 const char* chz_last_error(void) { return g_err; }
-int chz_device_count(void) { return 1; }
+// CHZ_STUB_DEVICES=n: the stand-in reports n devices (the drop-in's KA9Q_HIP_DEVICES sharding runs over n independent engines)
+int chz_device_count(void) { const char* v = getenv("CHZ_STUB_DEVICES"); const int n = v ? atoi(v) : 1; return n > 0 ? n : 1; }
 
-int chz_engine_create(chz_engine** out, int L, int M, int in_type, int, const char*, int) {
+int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, const char*, int) {
   if (!out || L < 1 || M < 1 || (in_type != CHZ_REAL && in_type != CHZ_COMPLEX)) return fail(-1, "bad argument");
+  if (device < 0 || device >= chz_device_count()) return fail(-2, "device %d out of range (%d devices)", device, chz_device_count());
   chz_engine* e = new chz_engine;
   e->L = L; e->M = M; e->N = L + M - 1; e->in_type = in_type;
   e->stream = chzo_stream_create(L, M, in_type);

@@ -304,3 +304,105 @@ def test_dropin_second_failure_exits_for_the_supervisor(tmp_path):
     r, _, _, _ = _recovery_run(tmp_path, "address", {"CHZ_STUB_FAIL_JOB": "4", "CHZ_STUB_FAIL_ALWAYS": "1", "ASAN_OPTIONS": "detect_leaks=0"}, 24, 8)
     assert r.returncode == 70, (r.returncode, r.stderr[-2000:])
     assert "second device failure" in r.stderr and "supervisor" in r.stderr and r.stderr.count("re-creating the engine") == 1
+
+
+@pytest.mark.parametrize("ndev,san", [(2, "thread"), (3, "thread"), (3, "address")])
+def test_dropin_sharded_over_fake_devices(tmp_path, ndev, san):
+    """KA9Q_HIP_DEVICES: ONE master behind filter.h, its slaves spread over 2 and 3 (stand-in) devices -- BASELINE config 4's shape
+    scaled down (24 kHz channels, P = 600, a disjoint contiguous block of channels per device), driven by the radiod-style C harness.
+    Every device transforms the block's samples itself; a block is complete when the last device's callback has run; retunes, a new
+    filter and channels leaving / joining cross device boundaries.  Outputs of EVERY channel against the oracle, the host-visible
+    fdomain[] from device 0, zero drops, the slaves where SURVEY 8e puts them (creation order, KA9Q_HIP_SHARD_CHANNELS at a time);
+    ThreadSanitizer / AddressSanitizer silent."""
+    if not _have("-fsanitize=" + san):
+        pytest.skip("no -fsanitize=%s runtime in this image" % san)
+    exe = _build(san, str(tmp_path / "build"))
+    L, M, olen, P = 25920, 6481, 480, 600
+    nblocks, nch = 8, 24 * ndev
+    rng = np.random.default_rng(80 + ndev)
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = _plan(rng, nch)
+    env = {"CHZ_STUB_DEVICES": str(ndev), "KA9Q_HIP_DEVICES": ",".join(str(i) for i in range(ndev)), "KA9Q_HIP_SHARD_CHANNELS": "24"}
+    run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
+    r = _run(exe, run_dir, L, M, olen, plan, nblocks, x, env)
+    report = r.stderr
+    assert "WARNING: ThreadSanitizer" not in report and "ERROR: AddressSanitizer" not in report and "LeakSanitizer" not in report, report[-6000:]
+    assert r.returncode == 0, (r.returncode, report[-3000:])
+    out = np.fromfile(os.path.join(run_dir, "out.bin"), np.complex64).reshape(nblocks, len(plan), olen)
+    spec = np.fromfile(os.path.join(run_dir, "spec.bin"), np.complex64)
+    meta = open(os.path.join(run_dir, "meta.txt")).read().split()
+    meta = dict(zip(meta[::2], meta[1::2]))
+    assert int(meta["devices"]) == ndev and [int(v) for v in meta["dev_counts"].split(":")] == [24] * ndev
+    _check(L, M, olen, P, plan, nblocks, out, spec, meta, x)
+
+
+def test_dropin_sharded_refuses_a_device_that_is_not_there(tmp_path):
+    exe = _build("address", str(tmp_path / "build"))
+    L, M, olen = 25920, 6481, 240
+    x = np.zeros(2 * L, np.float32)
+    run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
+    r = _run(exe, run_dir, L, M, olen, _plan(np.random.default_rng(1), 4), 2, x, {"CHZ_STUB_DEVICES": "2", "KA9Q_HIP_DEVICES": "0,5"})
+    assert r.returncode == 3 and "device 5" in r.stderr                # create_filter_input fails loudly, nothing runs on fewer devices than asked
+
+
+def _build_plain(out_dir):
+    ol.build()
+    os.makedirs(out_dir, exist_ok=True)
+    subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", os.path.join(STUB, "chz_stub.cpp"), "-o", os.path.join(out_dir, "libchz_hip.so"),
+                    "-L", os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread"], check=True)
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-maybe-uninitialized",
+                    os.path.join(CSRC, "filter_hip.c"), "-o", os.path.join(out_dir, "libka9q_filter_hip.so"),
+                    "-L", out_dir, "-lchz_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"], check=True)
+    exe = os.path.join(out_dir, "harness")
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "dropin_harness.c"), "-o", exe,
+                    "-L", out_dir, "-lka9q_filter_hip", "-lchz_hip", "-Wl,-rpath," + out_dir, "-lpthread", "-lm"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("ndev,nch", [(3, 3840), (8, 8192)])
+def test_dropin_config4_channel_count_sharded(tmp_path, ndev, nch):
+    """BASELINE config 4's channel count behind filter.h: 8192 x 24 kHz channels (P = 600; the master scaled to 1.296 MS/s so that the CPU
+    stand-in finishes), ONE master, 8192 channel pthreads, slaves spread over 8 stand-in devices (and 3840 over 3).  With 8 devices every device
+    owns exactly one contiguous 1024-block of channels in creation order; with fewer the blocks fill up and the rest is
+    balanced.  256 sampled channels (the first and last of every device's share among them) x 3 blocks against the oracle, zero drops."""
+    exe = _build_plain(str(tmp_path / "build"))
+    L, M, olen, P = 25920, 6481, 480, 600
+    N = L + M - 1
+    nblocks = 3
+    rng = np.random.default_rng(4)
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = [(int(s), int(s), 10 ** 6, 10 ** 6, -10000 / 24000, 10000 / 24000, 11.0, -10000 / 24000, 10000 / 24000) for s in rng.integers(-15000, 15000, nch)]
+    env = {"CHZ_STUB_DEVICES": str(ndev), "KA9Q_HIP_DEVICES": ",".join(str(i) for i in range(ndev)), "STUB_TIMEOUT": "600"}
+    run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
+    os.environ["STUB_TIMEOUT"] = "600"
+    try:
+        r = _run(exe, run_dir, L, M, olen, plan, nblocks, x, env)
+    finally:
+        os.environ.pop("STUB_TIMEOUT", None)
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    out = np.fromfile(os.path.join(run_dir, "out.bin"), np.complex64).reshape(nblocks, nch, olen)
+    meta = open(os.path.join(run_dir, "meta.txt")).read().split()
+    meta = dict(zip(meta[::2], meta[1::2]))
+    counts = [int(v) for v in meta["dev_counts"].split(":")]
+    assert int(meta["devices"]) == ndev and sum(counts) == nch and meta["drops"] == "0" and int(meta["clock"]) == nblocks
+    if ndev == 8:
+        assert counts == [1024] * 8
+    else:
+        assert min(counts) >= 1024 and max(counts) - min(counts) <= 1
+    # (channel threads register in whatever order the scheduler starts them: WHICH slave sits where is not checked, every output is)
+    edges = [0, nch - 1] + [k * 1024 + d for k in range(1, nch // 1024) for d in (-1, 0)]
+    sample = sorted(set(edges) | set(int(v) for v in rng.choice(nch, 256 - len(edges), replace=False)))
+    st = ol.Stream(L, M, ol.REAL)
+    state = np.zeros(2)
+    resp = ol.set_filter(P, olen, N, True, -10000 / 24000, 10000 / 24000, 11.0)
+    for b in range(nblocks):
+        s64 = st.push(x[b * L:(b + 1) * L], f64=True)
+        dc = s64[:1].astype(np.complex64); ol.notch(state, [0], 0.01, dc); s64[0] = dc[0]
+        peak = float(np.abs(s64).max())
+        for i in sample:
+            want = ol.channel(s64, ol.REAL, P, olen, plan[i][0], resp)
+            err = float(np.sqrt(np.mean(np.abs(out[b, i] - want) ** 2)))
+            rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+            assert err <= 1e-5 * rms + 2e-8 * peak * float(np.linalg.norm(resp)), (b, i, err, rms)
