@@ -748,7 +748,7 @@ def next_rows_leg(pkg, wl, nch, dev_index, mode="linear"):
         eng.close()
 
 
-def dropin_leg(wl, ring_host, nthreads, nblocks, env, label, paced_us=0):
+def dropin_leg(wl, ring_host, nthreads, nblocks, env, label, paced_us=0, verify=0):
     """The same workload THROUGH ka9q-radio's filter.h (libka9q_filter_hip.so), driven radiod-style from C by tests/c/dropin_harness.c:
     a front-end thread copying samples into the host ring and calling write_rfilter(), one pthread per channel looping
     execute_filter_output() (src/radio.c:1460), a SPECTRUM block clock.  PCIe is in the loop (H2D samples, D2H outputs and --
@@ -804,6 +804,27 @@ def dropin_leg(wl, ring_host, nthreads, nblocks, env, label, paced_us=0):
         if os.path.exists(os.path.join(tmp, "latency.bin")):
             lat = np.fromfile(os.path.join(tmp, "latency.bin"), np.int64).reshape(-1, 2)
         dropped = np.fromfile(os.path.join(tmp, "dropped.bin"), np.uint8) if os.path.exists(os.path.join(tmp, "dropped.bin")) else None
+        ver = None
+        if verify:
+            # what the channel threads were handed for the LAST block against the oracle's execute_filter_output on the host-visible
+            # spectrum of that block (master->fdomain[], from the first device), sampled channels incl. both ends of every device's share
+            import oracle_lib as ol
+            res = np.fromfile(os.path.join(tmp, "out.bin"), np.complex64).reshape(-1, len(plan), wl["olen"])[-1]
+            spec = np.fromfile(os.path.join(tmp, "spec.bin"), np.complex64).astype(np.complex128)
+            rng = np.random.default_rng(len(plan))
+            pick = sorted(set([0, len(plan) - 1] + [k for k in range(1023, len(plan) - 1, 1024)] + [k for k in range(1024, len(plan), 1024)] +
+                              [int(v) for v in rng.choice(len(plan), min(verify, len(plan)), replace=False)]))
+            bad, worst = [], 0.0
+            peak = float(np.abs(spec).max())
+            for i in pick:
+                sh, lo, hi = plan[i]
+                resp = ol.set_filter(wl["P"], wl["olen"], wl["N"], wl.get("real", True), lo, hi, 11.0)
+                want = ol.channel(spec, ol.REAL if wl.get("real", True) else ol.COMPLEX, wl["P"], wl["olen"], sh, resp)
+                err = float(np.sqrt(np.mean(np.abs(res[i] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+                worst = max(worst, err / max(rms, 1e-30))
+                if not err <= 1e-5 * rms + 2e-8 * peak * float(np.linalg.norm(resp)):
+                    bad.append(i)
+            ver = {"verified_channels": len(pick), "mismatched_channels": len(bad), "max_rel_err": worst, "first_mismatches": bad[:8]}
     prof = [ln for ln in r.stderr.splitlines() if ln.startswith("filter_hip profile:")]
     pv = {}
     if prof:
@@ -839,7 +860,11 @@ def dropin_leg(wl, ring_host, nthreads, nblocks, env, label, paced_us=0):
                  "definition": "front end on its own wall clock (absolute deadlines, one 20 ms block per 20 ms, chunks as they would arrive from the A/D), never "
                                "waits for a channel; latency = last sample of the block handed to write_rfilter -> the last of the channel threads has the block; "
                                "gpu_busy = mean enqueue-to-callback time of a block (H2D + kernels + D2H) / period"}
+    dev_counts = [int(v) for v in m.get("dev_counts", "-").split(":")] if m.get("dev_counts", "-") != "-" else None
     return {"label": label, "threads": len(plan), "blocks": nblocks, "env": env, "paced": paced,
+            "devices": int(m.get("devices", 1)), "slaves_per_device": dev_counts,
+            "verified_channels": ver["verified_channels"] if ver else None, "mismatched_channels": ver["mismatched_channels"] if ver else None,
+            "verification": ver,
             "ms_per_block": el / nblocks * 1e3, "realtime_margin": BLOCKTIME / (el / nblocks),
             "worst_block_gap_ms": int(m["worst_gap_ns"]) / 1e6, "mean_block_gap_ms": int(m["mean_gap_ns"]) / 1e6,
             "drops": int(m["drops"]),
@@ -930,7 +955,8 @@ def headline(out, detail_path):
     many("dropin", lambda x: _pick(x, "threads", "ms_per_block", "drops"))
     many("dropin_paced", lambda x: dict(_pick(x, "threads", "drops"),
                                         **{k: (x.get("paced") or {}).get(k) for k in ("drops_first_8_blocks", "block0_ms", "max_first_8_blocks_ms", "p50_ms", "p99_ms", "max_ms")}))
-    many("dropin_sharded", lambda x: _pick(x, "threads", "devices", "ms_per_block", "drops", "mismatched_channels"))
+    many("dropin_sharded", lambda x: dict(_pick(x, "threads", "devices", "devices_distinct", "slaves_per_device", "drops", "verified_channels", "mismatched_channels"),
+                                          **{k: (x.get("paced") or {}).get(k) for k in ("drops_first_8_blocks", "block0_ms", "p99_ms", "max_ms")}))
     many("c_rt_pcie", lambda x: _pick(x, "channels", "sustained", "worst_block_ms", "d2h_bytes_per_channel", "pcm_mismatches"))
     many("next_rows", lambda x: dict(_pick(x, "mode", "channels", "pcm_mismatches", "verified_channels"), ms_per_block=x.get("pipelined_ms_per_block")))
     h.update(_pick(out, "leg_seconds", "rccl_ranks", "quick"))
@@ -1313,6 +1339,24 @@ def main():
             except Exception as ex:
                 dropin_paced.append({"label": label, "error": str(ex)[:600]})
         leg_seconds["dropin_paced"] = time.perf_counter() - t_leg
+    # ---- channels sharded over the node's GPUs BEHIND filter.h (KA9Q_HIP_DEVICES): config 4's shape, 1024 x 24 kHz channels per device,
+    # one master, one pthread per channel, the front end at wall-clock pace.  On a one-GPU run the two shards share the device ("0,0").
+    dropin_sharded = None
+    if rank == 0 and not args.no_dropin and not args.no_dropin_paced and config in (3, 4):
+        t_leg = time.perf_counter()
+        ndev = world if world > 1 else 2
+        devs = ",".join(str(i) for i in range(world)) if world > 1 else "%d,%d" % (dev_index, dev_index)
+        wl4 = workload_for(4, 0, 1, 1024 * ndev)
+        try:
+            res = dropin_leg(wl4, ring_host, 1024 * ndev, min(args.dropin_blocks, 250), {"KA9Q_HIP_DEVICES": devs}, "config 4's shape behind filter.h: %d x 24 kHz "
+                             "channels (P=600), one master, slaves sharded over KA9Q_HIP_DEVICES=%s (1024 per device), one pthread per channel, front end at "
+                             "wall-clock pace, spectrum copied back from the first device" % (1024 * ndev, devs), paced_us=BLOCKTIME * 1e6, verify=24)
+            res["devices_distinct"] = bool(world > 1)
+            res["hardware"] = "measured on %d MI355X" % world if world > 1 else "two shards on ONE MI355X (the box has one): the multi-device path itself is unmeasured on hardware"
+            dropin_sharded = [res]
+        except Exception as ex:
+            dropin_sharded = [{"error": str(ex)[:600]}]
+        leg_seconds["dropin_sharded"] = time.perf_counter() - t_leg
     crt_pcie = None
     if rank == 0 and world == 1 and not args.no_crt_pcie and config == 3:
         t_leg = time.perf_counter()
@@ -1378,7 +1422,7 @@ def main():
             "gpu_event_ms_per_step": timing.total_ms / timing.blocks,
             "host_enqueue_ms_per_step": timing.enqueue_ms / timing.blocks,
             "roofline": roof, "cpu_baseline": cpu, "c_rt": crt, "c_rt_shared_responses": crt_shared,
-            "dropin": dropin, "dropin_paced": dropin_paced, "c_rt_pcie": crt_pcie, "next_rows": next_rows,
+            "dropin": dropin, "dropin_paced": dropin_paced, "dropin_sharded": dropin_sharded, "c_rt_pcie": crt_pcie, "next_rows": next_rows,
             "leg_seconds": {k: round(v, 1) for k, v in leg_seconds.items()},
             "rccl_ranks": rccl_ranks, "ranks": ranks_info, "quick": bool(args.quick),
         }

@@ -256,7 +256,8 @@ int chz_spectrum_exchange_rows(chz_engine *e, chz_comm *c, int slot, int root, c
 /* BASELINE config 4 from a C host: per block the root transforms, the spectrum travels (mode 0 broadcast, 1 rows),
  * every rank runs its own banks; timed like chz_run_blocks.  mode 2 (SURVEY 8e's alternative): the block's L new samples
  * travel from the root's input ring into every rank's ring (ncclBroadcast on the communicator's own stream: 10.4 MB instead of
- * the 13.8 MB slot at 129.6 MS/s) and every rank runs the forward transform itself -- nobody waits for the root's transform */
+ * the 13.8 MB slot at 129.6 MS/s) and every rank runs the forward transform itself -- nobody waits for the root's transform; with the
+ * run's first block the M-1 samples of overlap history in front of it travel too, so every rank's spectra (and notch states) equal the root's */
 int chz_run_blocks_sharded(chz_engine *e, chz_comm *c, int root, int mode, const int *row_lo, const int *row_hi,
                            unsigned job0, int nblocks, chz_timing *timing);
 

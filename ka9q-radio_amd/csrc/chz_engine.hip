@@ -466,6 +466,7 @@ int chz_engine_info(const chz_engine* e, chz_info* info) {
 }
 
 int chz_engine_set_stream(chz_engine* e, void* hip_stream) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e) return fail(-1, "null engine");
   int r = sync_all(e);
   if (r) return r;
@@ -488,6 +489,7 @@ static int check_device_errors(const chz_engine* e) {
   return 0;
 }
 static int sync_all(chz_engine* e) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   for (int i = 0; i < e->nlanes; i++) HIPOK(hipStreamSynchronize(e->lanes[i].s));
   if (e->tail) HIPOK(hipStreamSynchronize(e->tail));
   if (e->pcmcopy) HIPOK(hipStreamSynchronize(e->pcmcopy));
@@ -507,6 +509,7 @@ int chz_engine_check(const chz_engine* e) {
 }
 
 static int ring_write(chz_engine* e, const float* src, long n, hipMemcpyKind kind) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (e->ring16) return fail(-1, "int16 and float input cannot be mixed on one engine");
   const long nf = n * e->per;
   if (nf < 0 || nf > e->ring_len) return fail(-1, "write of %ld samples does not fit the ring", n);
@@ -564,6 +567,7 @@ int chz_input_write_i16_device(chz_engine* e, const short* dev, long n, float sc
 }
 // sum of x^2 and number of clipped samples over the L new samples of the block last transformed into `slot`
 int chz_input_stats(chz_engine* e, int slot, unsigned long long* energy, unsigned* clips) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   if (!e->ring16) return fail(-1, "input statistics exist for int16 input only");
   std::vector<unsigned long long> en((size_t)e->stat_n); std::vector<unsigned> cl((size_t)e->stat_n);
@@ -597,12 +601,14 @@ int chz_input_seek(chz_engine* e, unsigned job, const float* history) {
   return 0;
 }
 int chz_input_mark(chz_engine* e, int k) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || k < 0 || k >= CHZ_INPUT_MARKS) return fail(-1, "bad argument");
   if (!e->input_mark[k]) HIPOK(hipEventCreateWithFlags(&e->input_mark[k], hipEventDisableTiming));
   HIPOK(hipEventRecord(e->input_mark[k], e->stream));
   return 0;
 }
 int chz_input_mark_wait(chz_engine* e, int k) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || k < 0 || k >= CHZ_INPUT_MARKS) return fail(-1, "bad argument");
   if (e->input_mark[k]) HIPOK(hipEventSynchronize(e->input_mark[k]));
   return 0;
@@ -1087,6 +1093,7 @@ int chz_forward(chz_engine* e, unsigned job) {
 
 // notch list as radio.c builds it (src/radio.c:601-620), one averager gain per entry (src/filter.c:468)
 int chz_set_notches_alpha(chz_engine* e, const int* bins, const double* alpha, int n) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e) return fail(-1, "null engine");
   { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
@@ -1111,10 +1118,17 @@ int chz_set_notches_alpha(chz_engine* e, const int* bins, const double* alpha, i
   e->notch_tickets = 0;
   // fault injection for the hosts' recovery paths (tests/test_dropin.py): the host's tickets start one ahead of the device's counter, so
   // the first notch waits for a turn that never comes, runs out of its budget and raises the error word -- what a wedged predecessor does
-  if (const char* fs = getenv("CHZ_FAULT_TICKET_SKEW")) e->notch_tickets = (unsigned)atoi(fs);
+  // (a test hook in a production library: it takes TWO variables to arm, so one that leaks into a deployment's environment does nothing)
+  if (const char* fs = getenv("CHZ_FAULT_TICKET_SKEW")) {
+    const char* allow = getenv("CHZ_ALLOW_FAULT_INJECTION");
+    if (allow && allow[0] == '1') e->notch_tickets = (unsigned)atoi(fs);
+  }
   e->n_notch = n;
   e->notch_fold = RowsNotch{};
   const char* nf = getenv("CHZ_NOTCH_FOLD");
+#if CHZ_XCD_AFFINE
+  nf = "0";        // the experiment builds remap blockIdx inside fwd_rows; the owner table of the folded notch is made for the default mapping
+#endif
   if (!e->blue && !(nf && nf[0] == '0') && n <= CHZ_NOTCH_INLINE) {
     std::vector<NotchOwn> own;
     if (rows_notch_fill(e->notch_fold, own, e->plan, e->in_type == CHZ_REAL, bins, n)) {       // false leaves n = 0: the kernel serves the list
@@ -1153,6 +1167,7 @@ static int copy_spectrum(chz_engine* e, int slot, float* host, hipStream_t st) {
 }
 
 int chz_spectrum_read(chz_engine* e, int slot, float* host) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || !host || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   hipStream_t st = slot_stream(e, slot);          // the lane that produced this slot
   int r = copy_spectrum(e, slot, host, st);
@@ -1409,6 +1424,7 @@ int chz_bank_read_noise(chz_engine* e, int bank, int slot, int ch0, int n, doubl
   return read_doubles(e, bank, e->banks[(size_t)bank].n0, slot, ch0, n, host, true, "noise estimation is off: call chz_bank_enable_noise first");
 }
 int chz_bank_read_noise_async(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, ch0, n);
   return read_doubles(e, bank, e->banks[(size_t)bank].n0, slot, ch0, n, host, false, "noise estimation is off: call chz_bank_enable_noise first");
 }
@@ -1418,6 +1434,7 @@ int chz_bank_read_power(chz_engine* e, int bank, int slot, int ch0, int n, doubl
   return read_doubles(e, bank, e->banks[(size_t)bank].power, slot, ch0, n, host, true, "bank has no tuning: call chz_bank_set_tuning first");
 }
 int chz_bank_read_power_async(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, ch0, n);
   return read_doubles(e, bank, e->banks[(size_t)bank].power, slot, ch0, n, host, false, "bank has no tuning: call chz_bank_set_tuning first");
 }
@@ -1660,6 +1677,7 @@ int chz_bank_pcm_stride(chz_engine* e, int bank) {
 // rows of exactly the size the bank's encodings need (480 B for 12 kHz mono S16) make the device-to-host copy of a block's
 // PCM one contiguous transfer of only the bytes that matter; before the first chz_bank_set_demod
 int chz_bank_set_pcm_stride(chz_engine* e, int bank, int bytes) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, 0, 0);
   Bank& b = e->banks[(size_t)bank];
   if (b.dm_chan) return fail(-1, "the PCM row size is fixed once demodulators exist");
@@ -1686,6 +1704,7 @@ static int read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm
 // the per-block essentials only: PCM + one flag byte per channel (the full status record is 96 bytes; a host that ships
 // audio reads it when somebody asks, not 50 times a second for every channel)
 int chz_bank_read_pcm_flags_async(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm, unsigned char* flags) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, ch0, n);
   if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
   Bank& b = e->banks[(size_t)bank];
@@ -1701,6 +1720,7 @@ int chz_bank_read_pcm_flags_async(chz_engine* e, int bank, int slot, int ch0, in
   return 0;
 }
 int chz_bank_pcm_wait(chz_engine* e, int bank, int slot) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, 0, 0);
   if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
   Bank& b = e->banks[(size_t)bank];
@@ -1712,6 +1732,7 @@ int chz_bank_read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* p
   return read_pcm(e, bank, slot, ch0, n, pcm, status, true);
 }
 int chz_bank_read_pcm_async(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm, chz_demod_status* status) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   return read_pcm(e, bank, slot, ch0, n, pcm, status, false);
 }
 int chz_bank_set_active(chz_engine* e, int bank, int n) {
@@ -1737,6 +1758,7 @@ int chz_bank_execute_range(chz_engine* e, int bank, unsigned job, int ch0, int n
   return 0;
 }
 int chz_bank_destroy(chz_engine* e, int bank) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, 0, 0);
   Bank& b = e->banks[(size_t)bank];
   { int r = sync_all(e); if (r) return r; }
@@ -1745,6 +1767,7 @@ int chz_bank_destroy(chz_engine* e, int bank) {
   return 0;
 }
 int chz_bank_read_async(chz_engine* e, int bank, int slot, int ch0, int n, float* host) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, ch0, n);
   if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
   Bank& b = e->banks[(size_t)bank];
@@ -1754,33 +1777,37 @@ int chz_bank_read_async(chz_engine* e, int bank, int slot, int ch0, int n, float
   return 0;
 }
 int chz_spectrum_read_async(chz_engine* e, int slot, float* host) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || !host || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   return copy_spectrum(e, slot, host, slot_stream(e, slot));
 }
 int chz_host_callback(chz_engine* e, int slot, void (*fn)(void*), void* arg) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || !fn || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   HIPOK(hipLaunchHostFunc(slot_stream(e, slot), fn, arg));
   return 0;
 }
 int chz_slot_sync(chz_engine* e, int slot) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   HIPOK(hipStreamSynchronize(slot_stream(e, slot)));
   return 0;
 }
 int chz_host_alloc(void** p, size_t bytes) {
   if (!p) return fail(-1, "null pointer");
-  HIPOK(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+  HIPOK(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocPortable));      // every device of the process DMAs out of / into it
   return 0;
 }
 void chz_host_free(void* p) { if (p) (void)hipHostFree(p); }
 int chz_host_register(void* p, size_t bytes) {
   if (!p || !bytes) return fail(-1, "bad argument");
-  hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
   if (e != hipSuccess) { (void)hipGetLastError(); return fail(-10, "hipHostRegister failed: %s", hipGetErrorString(e)); }
   return 0;
 }
 void chz_host_unregister(void* p) { if (p) (void)hipHostUnregister(p); }
 int chz_bank_read(chz_engine* e, int bank, int ch0, int n, float* host) {
+  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, ch0, n);
   Bank& b = e->banks[(size_t)bank];
   hipStream_t st = slot_stream(e, b.last_slot);

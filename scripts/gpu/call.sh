@@ -9,6 +9,15 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5a)       # round 5, first call: the drop-in's cold start + sharding on hardware, the compact bench line, the C_rt search
+    timeout 900 python -m pytest tests/test_dropin.py -m gpu -q --timeout 600 > "$out/dropin.txt" 2>&1; echo "dropin rc=$?" >> "$out/rc.txt"
+    tail -5 "$out/dropin.txt"
+    $B > "$out/bench_stdout.txt" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/rc.txt"
+    tail -n 1 "$out/bench_stdout.txt" > "$out/bench_headline.json"; cp gpurun_out/bench_detail.json "$out/bench_detail.json" 2>/dev/null
+    wc -c "$out/bench_headline.json"; tail -c 400 "$out/bench.err"
+    timeout 1200 python -m pytest tests/test_bench_contract.py -m gpu -q --timeout 900 -k "contract_keys or crt_search or quick" > "$out/contract.txt" 2>&1; echo "contract rc=$?" >> "$out/rc.txt"
+    tail -5 "$out/contract.txt"
+    ;;
   scale)     # round 4, first call: large-bank parity at default dispatch, the folded notch on hardware, headline A/B
     timeout 900 python -m pytest tests/test_gpu_scale.py -m gpu -x -q --timeout 600 > "$out/scale.txt" 2>&1; echo "scale rc=$?" >> "$out/rc.txt"
     timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_pipeline.py -m gpu -q --timeout 300 -k "notch" > "$out/notch.txt" 2>&1; echo "notch rc=$?" >> "$out/rc.txt"
