@@ -419,7 +419,7 @@ def crt_leg(pkg, eng, wl, counts, blocks, run_one, shared=False, verify=64, agre
                 break                            # one block outside the slot: the rung is lost, no need to sit through the rest
         n_run = j + 1
         worst, mean = agree(worst), agree(tot / n_run)
-        pr = {"channels": nch + wl["nch"], "blocks": n_run, "worst_block_ms": worst, "mean_block_ms": mean, "blocks_over_20ms": int(late),
+        pr = {"channels": nch + wl["nch"], "bank_channels": nch, "blocks": n_run, "worst_block_ms": worst, "mean_block_ms": mean, "blocks_over_20ms": int(late),
               "sustained": bool(full and worst <= BLOCKTIME * 1e3 and n_run == nblk)}
         if full and verify and pr["sustained"]:
             # the rung's LAST block (still in its slot): `verify` channels sampled across the active range -- first, last, workgroup
@@ -475,10 +475,12 @@ def crt_leg(pkg, eng, wl, counts, blocks, run_one, shared=False, verify=64, agre
                     lo = best = pr
                     break
                 hi = pr
-        if lo and hi and hi["channels"] - lo["channels"] >= step:            # one bisection step
-            pr = rung(grid((lo["channels"] + hi["channels"]) // 2 - wl["nch"], step // 2), blocks)
-            if pr["sustained"]:
-                best = pr
+        if lo and hi:                                                        # one bisection step, if the grid has a count in between
+            mid = grid((lo["bank_channels"] + hi["bank_channels"]) // 2 + step // 4, step // 2)
+            if lo["bank_channels"] < mid < hi["bank_channels"]:
+                pr = rung(mid, blocks)
+                if pr["sustained"]:
+                    best = pr
         search = ("two 24-block calibration runs -> mean_ms(n); first rung at 0.975 x the count whose MEAN block would take 20 ms, then %d-channel steps "
                   "up while sustained / down until sustained, then one bisection step; %d blocks per rung, a rung is left at its first late block" % (step, blocks))
     bank.set_active(0)

@@ -420,14 +420,16 @@ static int bank_create_dev(struct mctx *c, struct shard *sh, struct hbank *b, in
    device-to-host copy into each of the staged-output images -- as the reference pays for planning inside create_filter_output
    (src/filter.c:359), so that the first block a new slave sees is an ordinary block.  Caller holds c->lock; `b` has its host side. */
 static void bank_warm(struct shard *sh, struct hbank *b) {
-  if (b->n < 1 && b->cap < 1) return;
+  int const n = b->cap;              /* every row: the copies then walk the whole of each pinned image once (channels without a gather descriptor give zeros) */
+  if (n < 1) return;
   for (int s = 0; s < ND; s++) {
-    if (chz_bank_execute_range(sh->eng, b->id, (unsigned)s, 0, 1) != 0) return;
-    if (chz_bank_read_async(sh->eng, b->id, s, 0, 1, (float *)b->stage[s]) != 0) return;
-    if (b->noise_on && chz_bank_read_noise_async(sh->eng, b->id, s, 0, 1, b->stage_n0[s]) != 0) return;
+    if (chz_bank_execute_range(sh->eng, b->id, (unsigned)s, 0, n) != 0) return;
+    if (chz_bank_read_async(sh->eng, b->id, s, 0, n, (float *)b->stage[s]) != 0) return;
+    if (b->noise_on && chz_bank_read_noise_async(sh->eng, b->id, s, 0, n, b->stage_n0[s]) != 0) return;
   }
   for (int s = 0; s < ND; s++) (void)chz_slot_sync(sh->eng, s);
-  for (int s = 0; s < ND; s++) { memset(b->stage[s], 0, bank_sample_bytes(b) * (size_t)b->olen); b->stage_n0[s][0] = NAN; }
+  /* (a bank that already serves blocks -- filter_hip_enable_noise in mid-stream: what was staged is gone, its slaves re-run their block) */
+  for (int s = 0; s < ND; s++) { memset(b->stage[s], 0, bank_sample_bytes(b) * (size_t)n * b->olen); for (int k = 0; k < n; k++) { b->stage_n0[s][k] = NAN; b->stage_epoch[s][k] = 0; } }
 }
 /* find (or create, or grow) the bank for (P, olen, output type) on one device; caller holds ctx->lock */
 static int bank_for(struct mctx *c, struct shard *sh, int P, int olen, bool real) {

@@ -13,7 +13,7 @@
 enum hipError_t { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorNotSupported = 801 };
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipEventReleaseToDevice = 0x40000000, hipHostMallocDefault = 0, hipHostMallocMapped = 2,
-       hipHostRegisterDefault = 0, hipStreamCaptureModeThreadLocal = 1 };
+       hipHostRegisterDefault = 0, hipHostRegisterPortable = 1, hipHostMallocPortable = 1, hipStreamCaptureModeThreadLocal = 1 };
 enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 struct hipemu_event { double t_ms = 0.0; };

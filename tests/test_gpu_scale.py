@@ -11,6 +11,8 @@ partially filled last groups, random) are compared with the oracle stage by stag
 then a second engine runs the same 12 blocks in ONE pipelined call and must leave the same PCM and status in every slot for
 EVERY channel of the bank.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -22,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 L, M, FS_IN = 25920, 6481, 1.296e6
 N = L + M - 1
-NCH = 70001
+NCH = int(os.environ.get("CHZ_TEST_SCALE_NCH", "70001"))      # (the override lets the emulator walk the test's logic with a few hundred channels)
 NBLK = 12
 
 
@@ -157,3 +159,73 @@ def test_fm_bank_of_70001_channels_default_dispatch(pkg):
     params = [ol.fm_params(**kw) for kw in FM_CASES]
     kinds = [(-8000 / 24000.0, 8000 / 24000.0), (-6000 / 24000.0, 6000 / 24000.0)]
     _run_family(pkg, "fm", 600, 480, 24000.0, 600, 25, kinds, params, 4 * 480)
+
+
+def test_end_to_end_from_samples_at_70001_channels(pkg):
+    """The stage-wise checks above feed the oracle the DEVICE's own block spectrum (right for isolating a stage).  This one closes the
+    loop once at scale: the same SAMPLES go to the device (forward transform, notch, chan_ifft with fine tuning; 70,001-channel bank,
+    default dispatch, four blocks in flight) and to the reference's own filter.c compiled from /root/reference (oracle/_ref:
+    create_filter_input / write_rfilter / execute_filter_output, float64 DFT behind its FFTW calls) followed by the reference's own
+    osc.c in downconvert()'s tail (src/filter.c:663-921, src/radio.c:1476-1520); 64 sampled channels x 4 blocks, baseband and bb_power."""
+    P, olen, fs_out = 300, 240, 12000.0
+    ring = _comb_ring(300, 50, "cw", seed=991)
+    shifts, rems = _bank_plan(300, 50, fs_out)
+    kinds = [(-0.24, 0.24), (50 / 12000, 3000 / 12000), (-200 / 12000, 200 / 12000), (-5000 / 12000, 5000 / 12000)]
+    chans = sc.sample_channels(NCH, 64, seed=17)
+    assert chans[0] == 0 and chans[-1] == NCH - 1
+    eng = pkg.engine.Engine(L, M, ol.REAL, ring_blocks=8)
+    try:
+        eng.write(ring[:8 * L - (M - 1)]); eng.write(ring[8 * L - (M - 1):])
+        bank = eng.bank(P, olen, NCH)
+        resp = np.stack([pkg.filterapi.design_response(P, olen, N, True, lo, hi, 11.0) for lo, hi in kinds])
+        bank.set_responses(0, resp[np.arange(NCH) % len(kinds)])
+        bank.set_tuning(0, 0, shifts, -rems / fs_out)
+        bank.set_active(NCH)
+        eng.set_notches([0], 0.01)
+        eng.run_blocks(0, 4)
+        got = {s: (bank.read_slot(s), bank.read_power(s)) for s in range(4)}
+    finally:
+        eng.close()
+    use_ref = ol.have_ref()
+    # the device ring was filled to the brim before block 0, so block 0's overlap history is the END of the 8-block ring, not zeros:
+    # the reference master is brought to the same state by writing that history's block first (its output is not compared)
+    if use_ref:
+        m = ol.RefMaster(L, M, ol.REAL, worker_threads=0)
+        rc = []
+        for c in chans:
+            ch = m.channel(olen, ol.COMPLEX)
+            lo, hi = kinds[c % len(kinds)]
+            assert ch.set_filter(lo, hi, 11.0) == 0
+            rc.append(ch)
+        m.write(ring[7 * L:8 * L])
+        m.set_notches([0], 0.01)                              # (installed after the priming block: the device's recurrence starts at block 0)
+        for ch, c in zip(rc, chans):
+            ch.execute(int(shifts[c]))
+    else:
+        st = ol.Stream(L, M, ol.REAL); st.push(ring[7 * L:8 * L], f64=True)
+        nstate = np.zeros(2)
+    dcs = {c: ol.Downconv(L, M, fs_out, "ref" if use_ref else "oracle") for c in chans}
+    worst = 0.0
+    for b in range(4):
+        x = ring[b * L:(b + 1) * L]
+        if use_ref:
+            m.write(x)
+            peak = float(np.abs(m.spectrum()).max())
+        else:
+            s64 = st.push(x, f64=True)
+            dc = s64[:1].astype(np.complex64); ol.notch(nstate, [0], 0.01, dc); s64[0] = dc[0]
+            peak = float(np.abs(s64).max())
+        out, power = got[b % 4]
+        for k, c in enumerate(chans):
+            r = resp[c % len(kinds)]
+            base = rc[k].execute(int(shifts[c])) if use_ref else ol.channel(s64, ol.REAL, P, olen, int(shifts[c]), r)
+            want, pw = dcs[c].block(base, int(shifts[c]), float(rems[c]))
+            err = float(np.sqrt(np.mean(np.abs(out[c] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+            assert err <= 1e-5 * rms + 2e-8 * peak * float(np.linalg.norm(r)), (b, c, err, rms)
+            assert abs(power[c] - pw) <= 3e-5 * pw + 1e-30, (b, c, power[c], pw)
+            worst = max(worst, err / max(rms, 1e-30))
+    if use_ref:
+        m.close()
+    for d in dcs.values():
+        d.close()
+    assert worst < 1e-4
