@@ -242,6 +242,12 @@ typedef struct chz_comm chz_comm;
 int chz_comm_unique_id(void *id128);
 int chz_comm_create(chz_comm **out, int rank, int world, const void *id128, int device);
 int chz_comm_create_file(chz_comm **out, int rank, int world, const char *path, int device, double timeout_s);
+/* ONE process, several devices (the filter.h drop-in's KA9Q_HIP_DEVICES with KA9Q_HIP_EXCHANGE=broadcast): a clique of n communicators
+ * (ncclCommInitAll), out[i] on devices[i]; every device at most once.  chz_spectrum_broadcast_local sends slot `slot` of engines[root]
+ * into the same slot of the other engines -- engines[i] created on devices[i], comms from one chz_comm_create_local call -- as one
+ * grouped call, each part on its engine's slot stream.  Each communicator is released with chz_comm_destroy. */
+int chz_comm_create_local(chz_comm **out, int n, const int *devices);
+int chz_spectrum_broadcast_local(chz_engine *const *engines, chz_comm *const *comms, int n, int slot, int root);
 void chz_comm_destroy(chz_comm *c);
 int chz_comm_rank(const chz_comm *c);
 int chz_comm_world(const chz_comm *c);

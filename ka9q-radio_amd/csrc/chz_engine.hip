@@ -295,6 +295,27 @@ int chz_gather_descriptor(int in_type, int master_bins, int P, int shift, int ou
   return 0;
 }
 
+// EXPERIMENT knob (round 5): CHZ_TAIL_CUS=n gives the demodulator stream n of the 256 compute units to itself
+// (spread evenly over the XCDs) and the transform lanes the other 256 - n, through hipExtStreamCreateWithCUMask -- the question being
+// whether the latency-bound demodulator pass and the issue-bound channel kernel overlap better side by side than back to back.
+// Unset (the default): plain streams, the whole device for everybody.
+static int tail_cus() { static const int n = [] { const char* v = getenv("CHZ_TAIL_CUS"); const int k = v ? atoi(v) : 0; return (k > 0 && k < 256) ? k : 0; }(); return n; }
+static hipError_t stream_create_masked(hipStream_t* s, bool tail) {
+#ifndef HIPEMU
+  const int n = tail_cus();
+  if (n > 0) {
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 256; i++) {
+      const bool t = ((i + 1) * n) / 256 > (i * n) / 256;      // n of 256, evenly spread
+      if (t == tail) mask[i / 32] |= 1u << (i % 32);
+    }
+    return hipExtStreamCreateWithCUMask(s, 8, mask);
+  }
+#endif
+  (void)tail;
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 static int blue_setup(chz_engine* e);
 int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, const char* plan_spec, int ring_blocks) {
   if (!out) return fail(-1, "null out pointer");
@@ -350,7 +371,7 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   if (ring_blocks < minblocks) ring_blocks = minblocks < 8 ? 8 : minblocks;
   e->ring_blocks = ring_blocks;
   e->ring_len = (long)ring_blocks * L * e->per;
-  HIPOK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  HIPOK(stream_create_masked(&e->stream, false));
   e->own_stream = true;
   if (const char* cs = getenv("CHZ_CHAN_STAGE")) e->chan_stage = atoi(cs) != 0;
   if (const char* cs = getenv("CHZ_NOISE_ENERGY")) e->noise_energy = atoi(cs) != 0;
@@ -377,7 +398,7 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   *e->notch_err = 0;
   for (int i = 0; i < e->nlanes; i++) {
     if (i == 0) e->lanes[i].s = e->stream;
-    else HIPOK(hipStreamCreateWithFlags(&e->lanes[i].s, hipStreamNonBlocking));
+    else HIPOK(stream_create_masked(&e->lanes[i].s, false));
     HIPOK(hipMalloc((void**)&e->lanes[i].buf, sizeof(float2) * (size_t)tp.Ra * tp.inner));
   }
   HIPOK(hipMalloc((void**)&e->ring, sizeof(float) * (size_t)e->ring_len));
@@ -889,6 +910,36 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* tu
   mark(in, st, 2, false);
   return enqueue_notch(e, slot, st, in, turn, seq, capture_first, capturing);
 }
+
+#if CHZ_FWD_BATCH
+// EXPERIMENT (see chz_kernels.h): the forward transform of blocks job .. job+B-1 (B = 2 or 4, job a multiple of B) as three launches of
+// B x the grid, on `st`; block y uses lane (job + y) % 4's intermediate buffer and spectrum slot (job + y) % 4.  REAL three-axis masters,
+// float input, no notch list (timing only).
+static int enqueue_forward_batch(chz_engine* e, unsigned job, int B, hipStream_t st) {
+  const FwdPlan& p = e->plan;
+  if (e->blue || e->in_type != CHZ_REAL || p.Nb <= 1 || e->ring16 || e->n_notch > 0 || e->nlanes != 4) return fail(-4, "the batched-pass experiment serves REAL three-axis masters on 4 lanes without a notch list");
+  FirstRealParams a{};
+  a.ring = e->ring; a.ring_len = e->ring_len; a.inner = p.inner; a.T = p.T1; a.Ra = p.Ra; a.padk = p.padk1;
+  a.tw_sub = e->tw_sub_a; a.tw_tile = e->tw1_tile; a.tw_col = e->tw1_col; a.nbatch = B;
+  ColsParams b{};
+  b.in_len = 0; b.in_start = 0; b.rows = p.Ra; b.inner = p.Nc; b.T = p.T2; b.padk = p.padk2;
+  b.tw_sub = e->tw_sub_b; b.tw_tile = e->tw2_tile; b.tw_col = e->tw2_col; b.tw_full = e->tw2_full; b.nbatch = B;
+  RowsParams c{};
+  c.lay = SpecLayout{p.Na, p.spec_pitch, p.spec_off}; c.ka_shift = p.ka_shift;
+  c.Ra = p.Ra; c.Na = p.Na; c.Nb = p.Nb; c.Ta = p.Ta; c.ld = p.ld3; c.padg = p.padg3; c.N = p.N; c.mirror = 1; c.tw_sub = e->tw_sub_c; c.nbatch = B;
+  for (int y = 0; y < B; y++) {
+    const unsigned j = job + (unsigned)y;
+    a.bstart[y] = (long)(((unsigned long long)j * (unsigned long long)e->L) % (unsigned long long)((long)e->ring_blocks * e->L)) * e->per;
+    float2* lb = e->lanes[j % 4u].buf;
+    a.bbuf[y] = lb; b.bbuf[y] = lb; c.bbuf[y] = lb; c.bspec[y] = e->spec[j % CHZ_ND];
+  }
+  a.start = a.bstart[0]; a.buf = a.bbuf[0]; b.in = b.bbuf[0]; b.out = b.bbuf[0]; c.buf = c.bbuf[0]; c.spec = c.bspec[0];
+  if (launch_first_real(p.ra, dim3((unsigned)p.grid1, (unsigned)B), p.block1, p.lds1, st, a)) return fail(-4, "no kernel for axis a");
+  if (launch_cols(p.rb, dim3((unsigned)p.grid2, (unsigned)B), p.block2, p.lds2, st, b)) return fail(-4, "no kernel for axis b");
+  if (launch_rows(p.rc, dim3((unsigned)p.grid3, (unsigned)B), p.block3, p.lds3, st, c)) return fail(-4, "no kernel for axis c");
+  return 0;
+}
+#endif
 
 // output image of one slot; a sample is one float (REAL banks) or one float2
 static inline size_t bank_sample_bytes(const Bank& b) { return b.out_real ? sizeof(float) : sizeof(float2); }
@@ -1512,7 +1563,7 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
   // demod_fm_lanes keeps a block's baseband in the scratch block: only banks large enough to be served by it get one for that
   need_fm_mix = need_fm_mix && (e->demod_wave == 0 || (e->demod_wave < 0 && b.cap >= 65536));
   HIPOK(hipSetDevice(e->device));
-  if (!e->tail) HIPOK(hipStreamCreateWithFlags(&e->tail, hipStreamNonBlocking));
+  if (!e->tail) HIPOK(stream_create_masked(&e->tail, true));
   if (!b.dm_chan) {
     { int r = sync_all(e); if (r) return r; }        // one-time switch
     const size_t cap = (size_t)b.cap;
@@ -1929,11 +1980,24 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
   } else {
     HIPOK(hipEventRecord(t0, s0));
     if (!in.on && (rc = lanes_fork(e, fork_ev))) return rc;
+#if CHZ_FWD_BATCH
+    {   // EXPERIMENT: CHZ_FWD_BATCH_N = 2 or 4 blocks per launch (forward transform only: every bank must be idle); 4 / N batches in flight
+      static const int B = [] { const char* v = getenv("CHZ_FWD_BATCH_N"); const int k = v ? atoi(v) : 0; return (k == 2 || k == 4) ? k : 0; }();
+      bool idle = true;
+      for (const Bank& bk : e->banks) idle = idle && bk.active == 0;
+      if (B && idle && !in.on && job0 % (unsigned)B == 0) {
+        for (; done + B <= nblocks; done += B) {
+          const unsigned job = job0 + (unsigned)done;
+          if ((rc = enqueue_forward_batch(e, job, B, e->lanes[(job / (unsigned)B) % (unsigned)(4 / B)].s))) return rc;
+        }
+      }
+    }
+#endif
     // Blocks of different lanes are independent launch sequences.  A single host thread issues ~5 launches per block at
     // ~3 us each, which bounds the small configurations -- so the lanes are split over CHZ_ENQ_THREADS host threads
     // (default 2; 1 = issue from the caller only): the caller takes its share, persistent issuers take the rest.
     const int T = issue_threads();
-    if (T > 1 && !in.on && e->nlanes >= T && nblocks >= 2 * e->nlanes) {
+    if (T > 1 && !in.on && done == 0 && e->nlanes >= T && nblocks >= 2 * e->nlanes) {
       while ((int)e->issuers.size() < T - 1) {
         Issuer* is = new Issuer();
         const int dev = e->device;
@@ -1944,7 +2008,7 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
       std::vector<int> rcs((size_t)T, 0);
       std::vector<std::string> errs((size_t)T);
       auto work = [&](int t) {
-        for (int b = 0; b < nblocks && !rcs[(size_t)t]; b++) {
+        for (int b = done; b < nblocks && !rcs[(size_t)t]; b++) {
           const unsigned job = job0 + (unsigned)b;
           if ((int)(job % (unsigned)e->nlanes) % T != t) continue;
           if ((rcs[(size_t)t] = enqueue_step(e, job, nullptr, &turn, b))) { errs[(size_t)t] = g_err; turn.abort.store(1); }

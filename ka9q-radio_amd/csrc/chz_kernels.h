@@ -128,6 +128,9 @@ struct FirstRealParams {
   unsigned long long* energy_part;   // [grid * waves] or nullptr
   unsigned* clip_part;               // [grid * waves]
   int new_from;
+#if CHZ_FWD_BATCH
+  int nbatch; long bstart[4]; float2* bbuf[4];     // blockIdx.y picks the block's window start and intermediate buffer
+#endif
 };
 
 // A/B of the north star's "wavefront-shuffle twiddles" (build with -DCHZ_TW_SHUFFLE=1; tiles of T = 16 columns only): the epilogue's
@@ -161,11 +164,19 @@ template <int N_> __device__ __forceinline__ float row_shr16(float v) {
 #ifndef CHZ_PLL_WAVES
 #define CHZ_PLL_WAVES 2
 #endif
+#ifndef CHZ_LIN_PACKED_STORE
+#define CHZ_LIN_PACKED_STORE 1      // demod_lin_lanes: mono S16 rows leave as 8-byte words (A/B build: -DCHZ_LIN_PACKED_STORE=0)
+#endif
 #ifndef CHZ_FM_WAVES
 #define CHZ_FM_WAVES 3
 #endif
 #ifndef CHZ_XCD_AFFINE
 #define CHZ_XCD_AFFINE 0
+#endif
+// EXPERIMENT build (round 5, -DCHZ_FWD_BATCH=1, ../libchz_hip_batch.so): the three forward passes of 2 or 4 CONSECUTIVE blocks as one grid
+// each (blockIdx.y = the block within the batch): 4 x the wavefronts per launch, a third of the launches.  Decision record: DESIGN.md section 7.
+#ifndef CHZ_FWD_BATCH
+#define CHZ_FWD_BATCH 0
 #endif
 struct XcdAffine { int on, Ta, shift, rot, ncomp; };
 
@@ -184,6 +195,9 @@ struct ColsParams {
   const float2* tw_full;  // [NP][inner] W_(NP*inner)^(k * col), or nullptr: one load and no product per output (axis b: the table
                           // is Nb*Nc entries and L2-resident; axis a of a complex master would need N entries and keeps the two factors)
   XcdAffine xa;           // experiment build only (CHZ_XCD_AFFINE): XCD-affine placement of the axis-b pass
+#if CHZ_FWD_BATCH
+  int nbatch; float2* bbuf[4];
+#endif
 };
 
 // Spectrum storage: bin k = ka + Na*x lives at  spec[x*pitch + off + ka].  pitch = Na, off = 0 is
@@ -243,6 +257,9 @@ struct RowsParams {
   const float2* tw_sub;   // [R2][R1] W_Nc^(j*k1)
   XcdAffine xa;           // experiment build only (CHZ_XCD_AFFINE)
   RowsNotch nf;           // K2 folded into this pass (nf.n == 0: none; the notch_fix kernel follows instead, or there is no list)
+#if CHZ_FWD_BATCH
+  int nbatch; float2* bbuf[4]; float2* bspec[4];
+#endif
 };
 
 // One channel's gather, precomputed on the host from `shift`
@@ -305,6 +322,9 @@ struct ChanParams {
 // ------------------------------------------------------------------------------
 template <int R1, int R2>
 __global__ void fwd_first_real(FirstRealParams p) {
+#if CHZ_FWD_BATCH
+  if (p.nbatch > 1) { p.start = p.bstart[blockIdx.y]; p.buf = p.bbuf[blockIdx.y]; }
+#endif
   constexpr int NA = R1 * R2;
   constexpr int LA = R1 > R2 ? R1 : R2;
   // rows one lane walks in the split epilogue: ceil(Ra / rows-per-sweep), rows-per-sweep >= LA
@@ -467,6 +487,9 @@ __global__ void fwd_first_real(FirstRealParams p) {
 // ------------------------------------------------------------------------------
 template <int R1, int R2>
 __global__ void fwd_cols(ColsParams p) {
+#if CHZ_FWD_BATCH
+  if (p.nbatch > 1) { p.in = p.bbuf[blockIdx.y]; p.out = p.bbuf[blockIdx.y]; }
+#endif
   constexpr int NP = R1 * R2;
   HIP_DYNAMIC_SHARED(float2, lds)
   const int tid = threadIdx.x;
@@ -655,6 +678,9 @@ __device__ __forceinline__ void rows_notch_publish(const RowsNotch& nf, int tid)
 // ------------------------------------------------------------------------------
 template <int R1, int R2>
 __global__ void fwd_rows(RowsParams p) {
+#if CHZ_FWD_BATCH
+  if (p.nbatch > 1) { p.buf = p.bbuf[blockIdx.y]; p.spec = p.bspec[blockIdx.y]; }
+#endif
   constexpr int NC = R1 * R2;
   HIP_DYNAMIC_SHARED(float2, lds)
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -1779,6 +1805,15 @@ __device__ __forceinline__ unsigned short demod_f16_bits(float v) {
   return (unsigned short)(sign | hb);
 #endif
 }
+// export_s16_*() for one sample (src/import.h:90-94): what demod_put stores for the S16 encodings
+__device__ __forceinline__ unsigned short demod_s16(float v, bool big_endian) {
+  float t = ldexpf(v, 15);
+  t = t > 32767.0f ? 32767.0f : t < -32767.0f ? -32767.0f : t;
+  const int q = (int)rintf(t);                                         // lrintf: to nearest, ties to even
+  unsigned short u = (unsigned short)(short)q;
+  if (big_endian) u = (unsigned short)((u >> 8) | (u << 8));
+  return u;
+}
 __device__ __forceinline__ void demod_put(unsigned char* o, int enc, int idx, float v) {
   if (enc == CHZ_PCM_F16LE_K || enc == CHZ_PCM_F16BE_K) {
     unsigned short u = demod_f16_bits(v);
@@ -2592,6 +2627,9 @@ __global__ void __launch_bounds__(64, 2) demod_lin_lanes(DemodParams p) {
   const bool dcfilt = env && dc_alpha != 0;
   double gain = st.gain, am_dc = st.am_dc, part = 0.0;
   const unsigned long long any_data = __ballot(data);
+  // every row that sends is mono S16 and the PCM rows are 8-byte aligned (wave-uniform): the packed store below
+  const bool s16_mono = CHZ_LIN_PACKED_STORE && (p.pcm_stride & 7) == 0 &&
+                        __ballot(data && !(channels == 1 && (enc == CHZ_PCM_S16BE_K || enc == CHZ_PCM_S16LE_K))) == 0ull;
   fetch_tile(0);
   for (int t0 = 0; t0 < N; t0 += LIN_TILE) {
     const int tn = N - t0 < LIN_TILE ? N - t0 : LIN_TILE;
@@ -2642,6 +2680,21 @@ __global__ void __launch_bounds__(64, 2) demod_lin_lanes(DemodParams p) {
     }
     CHZ_WAVE_SYNC();
     if (any_data != 0ull) {
+      if (s16_mono && tn == LIN_TILE) {
+        // mono S16 (what a voice channel sends): a lane packs FOUR samples of a row and stores them as one 8-byte word -- 4 store
+        // instructions per tile, 16 rows each, instead of 16 of 4 rows with 2 bytes per lane; the values are demod_put's
+        static_assert(LIN_TILE == 16, "the packed store walks a tile as 4 x 4 samples");
+        for (int r0 = 0; r0 < 64; r0 += 16) {
+          const int r = r0 + (lane >> 2), n4 = (lane & 3) * 4;
+          if ((any_data >> r) & 1ull) {
+            const LinRow q = rows[r];
+            const bool be = q.enc == CHZ_PCM_S16BE_K;
+            const unsigned long long w = (unsigned long long)demod_s16(tile[r * LD + n4].x, be) | ((unsigned long long)demod_s16(tile[r * LD + n4 + 1].x, be) << 16) |
+                                         ((unsigned long long)demod_s16(tile[r * LD + n4 + 2].x, be) << 32) | ((unsigned long long)demod_s16(tile[r * LD + n4 + 3].x, be) << 48);
+            *reinterpret_cast<unsigned long long*>(q.o + 2 * (t0 + n4)) = w;
+          }
+        }
+      } else
       for (int r0 = 0; r0 < 64; r0 += 64 / LIN_TILE) {
         const int r = r0 + lane / LIN_TILE, n = lane % LIN_TILE;
         if (((any_data >> r) & 1ull) && n < tn) {

@@ -19,19 +19,19 @@ namespace chz {
     else hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, p);                                \
   } while (0)
 
-inline int launch_first_real(Radix2 r, int grid, int block, size_t lds, hipStream_t s, const FirstRealParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+inline int launch_first_real(Radix2 r, dim3 grid, int block, size_t lds, hipStream_t s, const FirstRealParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
 #define X(a, b) if (r.r1 == a && r.r2 == b) { CHZ_LAUNCH((fwd_first_real<a, b>), grid, block, lds, s, e0, e1, p); return 0; }
   CHZ_FWD_MENU(X)
 #undef X
   return -1;
 }
-inline int launch_cols(Radix2 r, int grid, int block, size_t lds, hipStream_t s, const ColsParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+inline int launch_cols(Radix2 r, dim3 grid, int block, size_t lds, hipStream_t s, const ColsParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
 #define X(a, b) if (r.r1 == a && r.r2 == b) { CHZ_LAUNCH((fwd_cols<a, b>), grid, block, lds, s, e0, e1, p); return 0; }
   CHZ_FWD_MENU(X)
 #undef X
   return -1;
 }
-inline int launch_rows(Radix2 r, int grid, int block, size_t lds, hipStream_t s, const RowsParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+inline int launch_rows(Radix2 r, dim3 grid, int block, size_t lds, hipStream_t s, const RowsParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
 #define X(a, b) if (r.r1 == a && r.r2 == b) { CHZ_LAUNCH((fwd_rows<a, b>), grid, block, lds, s, e0, e1, p); return 0; }
   CHZ_FWD_MENU(X)
 #undef X

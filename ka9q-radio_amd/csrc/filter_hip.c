@@ -99,6 +99,11 @@ struct mctx {
   struct shard sh[MAX_SHARDS];      /* sh[0] is the primary: master->fdomain[] comes from it */
   int nsh;
   int shard_channels;               /* slaves per device before the next device is used (KA9Q_HIP_SHARD_CHANNELS) */
+  /* how a block reaches the devices (KA9Q_HIP_EXCHANGE): "samples" (default) -- every device copies the L new samples out of the host
+     ring and transforms them itself, no collective; "broadcast" -- the first device transforms, the spectrum slot travels to the others
+     over xGMI as one in-process grouped ncclBroadcast on the slots' own streams (the north star's wording) */
+  bool bcast;
+  chz_comm *comm[MAX_SHARDS];
   struct filter_in *master;
   pthread_mutex_t lock;             /* serialises engine calls and bank bookkeeping */
   /* staged outputs: ~1000 channel threads read after every block, the launcher / bank edits write now and then.  One
@@ -481,7 +486,8 @@ static int bank_for(struct mctx *c, struct shard *sh, int P, int olen, bool real
 /* ------------------------------------------------------------------------- */
 /* create / delete                                                               */
 /* ------------------------------------------------------------------------- */
-static void mctx_free(struct mctx *c) {          /* host side only; the engines are destroyed by the caller first */
+static void mctx_free(struct mctx *c) {          /* host side (and the communicators); the engines are destroyed by the caller first */
+  for (int g = 0; g < c->nsh; g++) if (c->comm[g]) { chz_comm_destroy(c->comm[g]); c->comm[g] = NULL; }
   for (int g = 0; g < c->nsh; g++) {
     for (int i = 0; i < c->sh[g].nbanks; i++) bank_free_host(&c->sh[g].banks[i]);
     free(c->sh[g].banks);
@@ -522,11 +528,17 @@ static void engines_warm(struct mctx *c, struct filter_in *f) {
     chz_engine *e = c->sh[g].eng;
     const float *src = (const float *)f->input_buffer;             /* zeros */
     for (unsigned j = 0; j < ND; j++) {
-      if (chz_input_write(e, src, f->ilen) != 0 || chz_forward(e, j) != 0) break;
+      if ((g == 0 || !c->bcast) && (chz_input_write(e, src, f->ilen) != 0 || chz_forward(e, j) != 0)) break;
       if (g == 0 && c->host_spectrum && chz_spectrum_read_async(e, (int)j, (float *)f->fdomain[j]) != 0) break;
       if (chz_host_callback(e, (int)j, warm_done, &ran) != 0) break;
       want++;
     }
+  }
+  if (c->bcast) {                     /* the collective's first use (RCCL sets its channels up then) is not block 0's business either */
+    chz_engine *engs[MAX_SHARDS];
+    for (int g = 0; g < c->nsh; g++) engs[g] = c->sh[g].eng;
+    for (int j = 0; j < ND; j++)
+      if (chz_spectrum_broadcast_local(engs, c->comm, c->nsh, j, 0) != 0) { fprintf(stderr, "create_filter_input: warm-up broadcast: %s\n", chz_last_error()); break; }
   }
   for (int g = 0; g < c->nsh; g++) {
     if (chz_sync(c->sh[g].eng) != 0 || chz_input_seek(c->sh[g].eng, 0, NULL) != 0)
@@ -570,6 +582,19 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
       return -1;
     }
   c->master = master;
+  { const char *ex = getenv("KA9Q_HIP_EXCHANGE");
+    if (ex && strcmp(ex, "broadcast") == 0) c->bcast = true;
+    else if (ex && *ex && strcmp(ex, "samples") != 0) fprintf(stderr, "create_filter_input: KA9Q_HIP_EXCHANGE=%s is neither \"samples\" nor \"broadcast\": using samples\n", ex); }
+  if (c->bcast) {
+    int devs[MAX_SHARDS];
+    for (int g = 0; g < c->nsh; g++) devs[g] = c->sh[g].device;
+    if (chz_comm_create_local(c->comm, c->nsh, devs) != 0) {
+      fprintf(stderr, "create_filter_input: KA9Q_HIP_EXCHANGE=broadcast: %s\n", chz_last_error());
+      for (int g = 0; g < c->nsh; g++) chz_engine_destroy(c->sh[g].eng);
+      free(c);
+      return -1;
+    }
+  }
   c->shard_channels = 1024;                                       /* contiguous 1024-blocks */
   { const char *sc = getenv("KA9Q_HIP_SHARD_CHANNELS"); if (sc && atoi(sc) > 0) c->shard_channels = atoi(sc); }
   { const char *bc = getenv("KA9Q_HIP_BANK_CHANNELS"); if (bc && atoi(bc) > 0 && atoi(bc) <= 65536) c->bank_cap0 = atoi(bc); }
@@ -986,14 +1011,25 @@ int execute_filter_input(struct filter_in *const f) {
 
   int rc = 0, callbacks = 0;
   __atomic_store_n(&c->pending[slot], (unsigned)c->nsh, __ATOMIC_RELEASE);
+  /* the block reaches the devices: samples to everybody (each transforms), or samples to the first device and its spectrum to the rest */
   for (int g = 0; g < c->nsh && rc == 0; g++) {
     struct shard *const sh = &c->sh[g];
     struct done_note *note = &c->note[slot][g];
     note->ctx = c; note->job = job; note->seq = seq; note->shard = g; note->t0 = tq;
+    if (c->bcast && g > 0) continue;
     rc = chz_input_write(sh->eng, newsamples, f->ilen);
     if (rc == 0 && c->drop_when_full) rc = chz_input_mark(sh->eng, (int)(job % 8));
     if (rc == 0) rc = chz_forward(sh->eng, job);
     if (rc == 0 && g == 0 && c->host_spectrum) rc = chz_spectrum_read_async(sh->eng, slot, (float *)f->fdomain[slot]);
+  }
+  if (rc == 0 && c->bcast && c->nsh > 1) {
+    chz_engine *engs[MAX_SHARDS];
+    for (int g = 0; g < c->nsh; g++) engs[g] = c->sh[g].eng;
+    rc = chz_spectrum_broadcast_local(engs, c->comm, c->nsh, slot, 0);
+  }
+  for (int g = 0; g < c->nsh && rc == 0; g++) {
+    struct shard *const sh = &c->sh[g];
+    struct done_note *note = &c->note[slot][g];
     /* batched channel launches: every slave with the shift it has asked for (or, failing that, asked for last) */
     for (int i = 0; rc == 0 && i < sh->nbanks; i++) {
       struct hbank *b = &sh->banks[i];

@@ -66,6 +66,7 @@ SYMBOLS = [
     "chz_comm_unique_id", "chz_comm_create", "chz_comm_create_file", "chz_comm_destroy", "chz_comm_rank", "chz_comm_world",
     "chz_mini_create", "chz_mini_destroy", "chz_mini_capacity", "chz_mini_add", "chz_mini_release", "chz_mini_set_response", "chz_mini_execute",
     "chz_comm_barrier", "chz_comm_allreduce_max", "chz_spectrum_broadcast", "chz_spectrum_exchange_rows", "chz_run_blocks_sharded",
+    "chz_comm_create_local", "chz_spectrum_broadcast_local",
 ]
 
 _lib = None

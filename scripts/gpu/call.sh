@@ -9,6 +9,36 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5b)       # round 5, second call: profiles of the shipped kernels (folded notch), the CU-mask and batched-pass experiments, the packed PCM store
+    NR="--no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear"
+    for cus in 0 32 64 96; do      # (0 = unset: plain streams)
+      if [ $cus = 0 ]; then $B $NR --detail "$out/chain_cus0.json" > "$out/chain_cus0.head" 2>> "$out/err.txt"
+      else CHZ_TAIL_CUS=$cus $B $NR --detail "$out/chain_cus$cus.json" > "$out/chain_cus$cus.head" 2>> "$out/err.txt"; fi
+    done
+    $B --no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes pll,fm --detail "$out/chain_pllfm.json" > "$out/chain_pllfm.head" 2>> "$out/err.txt"
+    LIBB=$PWD/ka9q-radio_amd/libchz_hip_batch.so
+    for rep in 1 2; do
+      BENCH_NO_NOTCH=1 $B --quick --detail "$out/fwd_base_$rep.json" > /dev/null 2>> "$out/err.txt"
+      BENCH_NO_NOTCH=1 CHZ_LIB=$LIBB $B --quick --detail "$out/fwd_batchlib_n0_$rep.json" > /dev/null 2>> "$out/err.txt"
+      BENCH_NO_NOTCH=1 CHZ_LIB=$LIBB CHZ_FWD_BATCH_N=2 $B --quick --detail "$out/fwd_batch2_$rep.json" > /dev/null 2>> "$out/err.txt"
+      BENCH_NO_NOTCH=1 CHZ_LIB=$LIBB CHZ_FWD_BATCH_N=4 $B --quick --detail "$out/fwd_batch4_$rep.json" > /dev/null 2>> "$out/err.txt"
+    done
+    for n in 2 4; do CHZ_LIB=$LIBB CHZ_FWD_BATCH_N=$n timeout 300 python scripts/batch_check.py >> "$out/batch_parity.txt" 2>&1; done
+    python - "$out" <<'PY'
+import json, sys, glob, os
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/chain_*.json")):
+    j = json.load(open(f))
+    print(os.path.basename(f), [(x.get("mode"), round(x.get("pipelined_ms_per_block", 0), 3), x.get("pcm_mismatches"), {k: round(v, 3) for k, v in (x.get("ns_per_channel") or {}).items()}) if "error" not in x else x for x in (j.get("next_rows") or [])])
+for f in sorted(glob.glob(out + "/fwd_*.json")):
+    j = json.load(open(f)); r = j["roofline"]
+    print(os.path.basename(f), "ms_per_step", round(j["ms_per_step"] * 1e3, 2), "fwd_pipelined_us", round(r["pipelined"]["forward_us_per_block"], 2), "frac", round(r["pipelined"]["frac"], 4))
+PY
+    timeout 600 python -m pytest tests/test_dropin.py tests/test_gpu_scale.py -m gpu -q --timeout 400 -k "clique or two_shards or end_to_end" > "$out/newtests.txt" 2>&1; echo "newtests rc=$?" >> "$out/rc.txt"
+    tail -3 "$out/newtests.txt"
+    SKIP_PMC=0 timeout 1500 bash scripts/gpu_profile.sh r05 > "$out/profile.txt" 2>&1
+    tail -3 "$out/batch_parity.txt"
+    ;;
   r5a)       # round 5, first call: the drop-in's cold start + sharding on hardware, the compact bench line, the C_rt search
     timeout 900 python -m pytest tests/test_dropin.py -m gpu -q --timeout 600 > "$out/dropin.txt" 2>&1; echo "dropin rc=$?" >> "$out/rc.txt"
     tail -5 "$out/dropin.txt"

@@ -5,9 +5,11 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 # Counter collection serialises kernel dispatches: a kernel that waits on the device for a kernel of another stream (the notch
-# ticket) can then wait for something that is not allowed to start.  Under --pmc the recurrence is ordered by HIP events instead,
-# and every pass has its own time limit.
-export CHZ_NOTCH_ORDER=event
+# ticket) can then wait for something that is not allowed to start.  Rounds 2-4 ordered the recurrence by HIP events under --pmc,
+# which also UNFOLDS the notch from fwd_rows (a separate notch_fix launch): the counters were then not the shipped kernel's.  Round 5:
+# ONE lane instead (CHZ_STREAMS=1) -- no ticket is taken with one stream, the notch stays folded inside fwd_rows exactly as shipped,
+# and per-dispatch counters do not depend on how many streams the dispatches came from.  Every pass has its own time limit.
+export CHZ_STREAMS=1
 run() { name=$1; shift; timeout 240 rocprofv3 --pmc "$@" -f csv -d $R/gpurun_out/pmc_$TAG/$name -o $name -- python $R/bench.py --steps 160 --warmup 16 --min-seconds 0.05 --quick $BENCH_ARGS > $R/gpurun_out/pmc_$TAG/$name.log 2>&1; }
 mkdir -p $R/gpurun_out/pmc_$TAG
 BENCH_ARGS="$@"

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -190,6 +191,34 @@ int chz_host_callback(chz_engine* e, int, void (*fn)(void*), void* arg) {
   e->post([fn, arg] { fn(arg); });
   return 0;
 }
+// the in-process clique of the drop-in's KA9Q_HIP_EXCHANGE=broadcast: a communicator is just its rank here; the broadcast is a task on
+// the root's queue (behind its forward transform) that hands the slot to a task on every other engine's queue (in front of its banks)
+struct chz_comm { int rank, world, device; };
+int chz_comm_create_local(chz_comm** out, int n, const int* devices) {
+  if (!out || !devices || n < 1) return fail(-1, "bad argument");
+  for (int i = 0; i < n; i++) {
+    if (devices[i] < 0 || devices[i] >= chz_device_count()) return fail(-2, "device %d is not visible", devices[i]);
+    for (int k = 0; k < i; k++) if (devices[k] == devices[i]) return fail(-2, "device %d is listed twice: an RCCL clique needs one communicator per device", devices[i]);
+  }
+  for (int i = 0; i < n; i++) out[i] = new chz_comm{i, n, devices[i]};
+  return 0;
+}
+void chz_comm_destroy(chz_comm* c) { delete c; }
+int chz_spectrum_broadcast_local(chz_engine* const* engines, chz_comm* const* comms, int n, int slot, int root) {
+  if (!engines || !comms || n < 1 || slot < 0 || slot >= CHZ_ND || root < 0 || root >= n) return fail(-1, "bad argument");
+  for (int i = 0; i < n; i++) if (!engines[i] || !comms[i] || comms[i]->rank != i || comms[i]->world != n) return fail(-1, "not this clique");
+  struct Box { std::mutex m; std::condition_variable cv; bool ready = false; std::vector<float> data; };
+  auto box = std::make_shared<Box>();
+  chz_engine* r = engines[root];
+  r->post([r, slot, box] { { std::lock_guard<std::mutex> lk(box->m); box->data = r->spec[slot]; box->ready = true; } box->cv.notify_all(); });
+  for (int i = 0; i < n; i++) {
+    if (i == root) continue;
+    chz_engine* e = engines[i];
+    e->post([e, slot, box] { std::unique_lock<std::mutex> lk(box->m); box->cv.wait(lk, [&] { return box->ready; }); e->spec[slot] = box->data; });
+  }
+  return 0;
+}
+
 int chz_host_alloc(void** p, size_t bytes) { return posix_memalign(p, 64, bytes ? bytes : 64) == 0 ? 0 : fail(-2, "out of memory"); }
 void chz_host_free(void* p) { free(p); }
 int chz_host_register(void*, size_t) { return 0; }

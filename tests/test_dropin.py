@@ -657,3 +657,25 @@ def test_dropin_config4_shape_two_shards_full_rate():
     assert int(meta["devices"]) == 2 and meta["dev_counts"] == "1024:1024"
     sub = list(range(0, nch, 67)) + [1023, 1024, nch - 1]
     _check(L, M, olen, P, [plan[i] for i in sub], nblocks, out[:, sub], spec, meta, x)
+
+
+@pytest.mark.gpu
+def test_dropin_broadcast_exchange_clique_of_one():
+    """KA9Q_HIP_EXCHANGE=broadcast with the one device this box has: create_filter_input builds the in-process RCCL clique
+    (ncclCommInitAll, one communicator) and runs the grouped broadcast of every spectrum slot once as part of its warm-up -- the
+    collective's code path on real RCCL with G = 1; blocks then run as usual.  (Two engines on ONE device cannot form a clique:
+    that request must fail loudly at create time, not run on fewer devices.)"""
+    _build_lib(); ol.build()
+    L, M, olen, P = 25920, 6481, 240, 300
+    nblocks = 5
+    rng = np.random.default_rng(81)
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = [(int(s), int(s), 10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4) for s in rng.integers(-12000, 12000, 12)]
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x, env={"KA9Q_HIP_DEVICES": "0", "KA9Q_HIP_EXCHANGE": "broadcast"})
+        assert int(meta["devices"]) == 1
+        _check(L, M, olen, P, plan, nblocks, out, spec, meta, x)
+        exe = os.path.join(tmp, "harness")
+        r = subprocess.run([exe, tmp], capture_output=True, text=True, timeout=300, env=dict(os.environ, KA9Q_HIP_DEVICES="0,0", KA9Q_HIP_EXCHANGE="broadcast"))
+        assert r.returncode == 3 and "listed twice" in r.stderr, (r.returncode, r.stderr[-500:])

@@ -306,8 +306,9 @@ def test_dropin_second_failure_exits_for_the_supervisor(tmp_path):
     assert "second device failure" in r.stderr and "supervisor" in r.stderr and r.stderr.count("re-creating the engine") == 1
 
 
-@pytest.mark.parametrize("ndev,san", [(2, "thread"), (3, "thread"), (3, "address")])
-def test_dropin_sharded_over_fake_devices(tmp_path, ndev, san):
+@pytest.mark.parametrize("ndev,san,exchange", [(2, "thread", "samples"), (3, "thread", "samples"), (3, "address", "samples"),
+                                               (3, "thread", "broadcast"), (2, "address", "broadcast")])
+def test_dropin_sharded_over_fake_devices(tmp_path, ndev, san, exchange):
     """KA9Q_HIP_DEVICES: ONE master behind filter.h, its slaves spread over 2 and 3 (stand-in) devices -- BASELINE config 4's shape
     scaled down (24 kHz channels, P = 600, a disjoint contiguous block of channels per device), driven by the radiod-style C harness.
     Every device transforms the block's samples itself; a block is complete when the last device's callback has run; retunes, a new
@@ -323,7 +324,9 @@ def test_dropin_sharded_over_fake_devices(tmp_path, ndev, san):
     g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
     x = g.generate(nblocks * L)
     plan = _plan(rng, nch)
-    env = {"CHZ_STUB_DEVICES": str(ndev), "KA9Q_HIP_DEVICES": ",".join(str(i) for i in range(ndev)), "KA9Q_HIP_SHARD_CHANNELS": "24"}
+    # exchange: every device transforms the samples itself (default), or device 0 transforms and its spectrum slot is handed to the
+    # others (KA9Q_HIP_EXCHANGE=broadcast: in-process grouped ncclBroadcast on the device; a queue hand-over in the stand-in)
+    env = {"CHZ_STUB_DEVICES": str(ndev), "KA9Q_HIP_DEVICES": ",".join(str(i) for i in range(ndev)), "KA9Q_HIP_SHARD_CHANNELS": "24", "KA9Q_HIP_EXCHANGE": exchange}
     run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
     r = _run(exe, run_dir, L, M, olen, plan, nblocks, x, env)
     report = r.stderr
@@ -344,6 +347,8 @@ def test_dropin_sharded_refuses_a_device_that_is_not_there(tmp_path):
     run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
     r = _run(exe, run_dir, L, M, olen, _plan(np.random.default_rng(1), 4), 2, x, {"CHZ_STUB_DEVICES": "2", "KA9Q_HIP_DEVICES": "0,5"})
     assert r.returncode == 3 and "device 5" in r.stderr                # create_filter_input fails loudly, nothing runs on fewer devices than asked
+    r = _run(exe, run_dir, L, M, olen, _plan(np.random.default_rng(1), 4), 2, x, {"CHZ_STUB_DEVICES": "2", "KA9Q_HIP_DEVICES": "0,0", "KA9Q_HIP_EXCHANGE": "broadcast"})
+    assert r.returncode == 3 and "listed twice" in r.stderr            # an RCCL clique cannot hold one device twice
 
 
 def _build_plain(out_dir):

@@ -644,8 +644,15 @@ DEMOD_CASES = [dict(), dict(channels=2, encoding=ol.PCM_F32LE), dict(env=True, d
                dict(encoding=ol.PCM_F16LE), dict(channels=2, env=True, dc_alpha=0.01, encoding=ol.PCM_F16BE)]
 
 
-@pytest.mark.parametrize("path", ["lanes", "wave"])      # demod_lin_lanes (one channel per lane) / demod_linear_tail (a wavefront per channel)
-def test_linear_demodulator_kernel(emu, monkeypatch, path):
+# a bank whose every channel sends mono S16 (what voice channels send; big- and little-endian side by side): demod_lin_lanes then packs
+# four samples of a row into one 8-byte store -- 70 channels = one full wavefront of rows and a partly filled one
+S16_MONO_CASES = [dict(), dict(env=True, dc_alpha=0.002, encoding=ol.PCM_S16LE), dict(agc=False, gain_db=30.0, shift=500.0, encoding=ol.PCM_S16LE),
+                  dict(snr_squelch=True, squelch_tail=2), dict(tuned=False), dict(encoding=ol.PCM_S16LE), dict(hangtime=0.3)] * 10
+
+
+@pytest.mark.parametrize("path,cases", [("lanes", "mixed"), ("wave", "mixed"), ("lanes", "s16_mono")])      # demod_lin_lanes (one channel per lane) / demod_linear_tail (a wavefront per channel)
+def test_linear_demodulator_kernel(emu, monkeypatch, path, cases):
+    DEMOD_CASES = S16_MONO_CASES if cases == "s16_mono" else globals()["DEMOD_CASES"]
     if path == "wave":
         monkeypatch.setenv("EMU_DEMOD_WAVE", "1")
     else:
@@ -656,7 +663,7 @@ def test_linear_demodulator_kernel(emu, monkeypatch, path):
     emu.emu_demod_sizes(sizes)
     assert list(sizes) == [C.sizeof(_DemodChan), C.sizeof(_DemodState), C.sizeof(ol.LinStatus)]
     from test_oracle_vs_reference import _demod_case
-    nblk, N, bt = 40, 240, 0.02
+    nblk, N, bt = (12 if cases == "s16_mono" else 40), 240, 0.02
     nch = len(DEMOD_CASES)
     r = np.random.default_rng(99)
     bbs, powers, ests, params, oracles = [], [], [], [], []
