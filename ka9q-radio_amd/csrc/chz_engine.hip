@@ -299,7 +299,9 @@ int chz_gather_descriptor(int in_type, int master_bins, int P, int shift, int ou
 // (spread evenly over the XCDs) and the transform lanes the other 256 - n, through hipExtStreamCreateWithCUMask -- the question being
 // whether the latency-bound demodulator pass and the issue-bound channel kernel overlap better side by side than back to back.
 // Unset (the default): plain streams, the whole device for everybody.
-static int tail_cus() { static const int n = [] { const char* v = getenv("CHZ_TAIL_CUS"); const int k = v ? atoi(v) : 0; return (k > 0 && k < 256) ? k : 0; }(); return n; }
+// (CHZ_TAIL_CUS=256: every stream through hipExtStreamCreateWithCUMask with ALL units enabled -- the control of the experiment: same
+//  creation path, hence the same hardware-queue assignment, no partition)
+static int tail_cus() { static const int n = [] { const char* v = getenv("CHZ_TAIL_CUS"); const int k = v ? atoi(v) : 0; return (k > 0 && k <= 256) ? k : 0; }(); return n; }
 static hipError_t stream_create_masked(hipStream_t* s, bool tail) {
 #ifndef HIPEMU
   const int n = tail_cus();
@@ -307,7 +309,7 @@ static hipError_t stream_create_masked(hipStream_t* s, bool tail) {
     uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 256; i++) {
       const bool t = ((i + 1) * n) / 256 > (i * n) / 256;      // n of 256, evenly spread
-      if (t == tail) mask[i / 32] |= 1u << (i % 32);
+      if (t == tail || n == 256) mask[i / 32] |= 1u << (i % 32);
     }
     return hipExtStreamCreateWithCUMask(s, 8, mask);
   }

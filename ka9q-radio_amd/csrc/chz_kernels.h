@@ -178,6 +178,13 @@ template <int N_> __device__ __forceinline__ float row_shr16(float v) {
 #ifndef CHZ_FWD_BATCH
 #define CHZ_FWD_BATCH 0
 #endif
+// (the block's pointers are picked with compile-time indices: writing to the by-value parameter struct, or indexing its arrays with
+//  blockIdx.y, sends the whole struct through scratch memory -- measured: every pass 3.7 x slower, batched or not)
+#if CHZ_FWD_BATCH
+#define CHZ_BSEL(arr, dflt) (p.nbatch > 1 ? (blockIdx.y == 0 ? arr[0] : blockIdx.y == 1 ? arr[1] : blockIdx.y == 2 ? arr[2] : arr[3]) : (dflt))
+#else
+#define CHZ_BSEL(arr, dflt) (dflt)
+#endif
 struct XcdAffine { int on, Ta, shift, rot, ncomp; };
 
 struct ColsParams {
@@ -322,9 +329,6 @@ struct ChanParams {
 // ------------------------------------------------------------------------------
 template <int R1, int R2>
 __global__ void fwd_first_real(FirstRealParams p) {
-#if CHZ_FWD_BATCH
-  if (p.nbatch > 1) { p.start = p.bstart[blockIdx.y]; p.buf = p.bbuf[blockIdx.y]; }
-#endif
   constexpr int NA = R1 * R2;
   constexpr int LA = R1 > R2 ? R1 : R2;
   // rows one lane walks in the split epilogue: ceil(Ra / rows-per-sweep), rows-per-sweep >= LA
@@ -334,11 +338,11 @@ __global__ void fwd_first_real(FirstRealParams p) {
   const int T = p.T;
   const int c0 = tile * T;                       // first packed column of the tile
   const float2* __restrict__ ring2 = reinterpret_cast<const float2*>(p.ring);
-  const long ring2_len = p.ring_len >> 1, start2 = p.start >> 1, inner2 = p.inner >> 1;
+  const long ring2_len = p.ring_len >> 1, start2 = CHZ_BSEL(p.bstart, p.start) >> 1, inner2 = p.inner >> 1;
   const float2* __restrict__ tws = p.tw_sub;
   const float2* __restrict__ twt = p.tw_tile;
   const float2* __restrict__ twc = p.tw_col;
-  float2* __restrict__ gout = p.buf;
+  float2* __restrict__ gout = CHZ_BSEL(p.bbuf, p.buf);
   float2* zl = lds + NA * T + R1 * p.padk;         // second LDS region (see layer 2)
 
   // Epilogue geometry is known up front: one lane owns one PACKED column pc (= two adjacent real
@@ -487,9 +491,6 @@ __global__ void fwd_first_real(FirstRealParams p) {
 // ------------------------------------------------------------------------------
 template <int R1, int R2>
 __global__ void fwd_cols(ColsParams p) {
-#if CHZ_FWD_BATCH
-  if (p.nbatch > 1) { p.in = p.bbuf[blockIdx.y]; p.out = p.bbuf[blockIdx.y]; }
-#endif
   constexpr int NP = R1 * R2;
   HIP_DYNAMIC_SHARED(float2, lds)
   const int tid = threadIdx.x;
@@ -510,8 +511,8 @@ __global__ void fwd_cols(ColsParams p) {
 #endif
   const int c0 = ct * T;
   const long base = (long)row * NP * p.inner + c0;
-  const float2* __restrict__ gin = p.in;
-  float2* __restrict__ gout = p.out;
+  const float2* __restrict__ gin = CHZ_BSEL(p.bbuf, p.in);
+  float2* __restrict__ gout = CHZ_BSEL(p.bbuf, p.out);
   const float2* __restrict__ tws = p.tw_sub;
   const float2* __restrict__ twt = p.tw_tile;
   const float2* __restrict__ twc = p.tw_col;
@@ -678,9 +679,6 @@ __device__ __forceinline__ void rows_notch_publish(const RowsNotch& nf, int tid)
 // ------------------------------------------------------------------------------
 template <int R1, int R2>
 __global__ void fwd_rows(RowsParams p) {
-#if CHZ_FWD_BATCH
-  if (p.nbatch > 1) { p.buf = p.bbuf[blockIdx.y]; p.spec = p.bspec[blockIdx.y]; }
-#endif
   constexpr int NC = R1 * R2;
   HIP_DYNAMIC_SHARED(float2, lds)
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -700,7 +698,7 @@ __global__ void fwd_rows(RowsParams p) {
   const int gstep = R2 * ld + padg;              // LDS distance between butterfly groups
 
   const float2* __restrict__ tws = p.tw_sub;
-  const float2* __restrict__ gin = p.buf + (long)kb * NC;
+  const float2* __restrict__ gin = CHZ_BSEL(p.bbuf, p.buf) + (long)kb * NC;
   bool nf_owner = false;                           // does this workgroup store a bin of the notch list?  (scalar compares on kernel arguments)
   static_for<CHZ_NOTCH_INLINE>([&](auto ee) { constexpr int E = decltype(ee)::value; nf_owner = nf_owner || (E < p.nf.n && p.nf.wg[E] == (int)blockIdx.x); });
   unsigned nf_mask = 0;                            // ... and which of this thread's second-layer outputs, if any (at most one: rows_notch_fill)
@@ -801,7 +799,7 @@ __global__ void fwd_rows(RowsParams p) {
       const int kk0 = ka + p.Na * x0, kks = p.Na * xs;            // bin index k = kk0 + K2*kks
       const int d0 = x0 * p.lay.pitch + p.lay.off + ka, ds = xs * p.lay.pitch;
       const int m0 = (xrows - 1 - x0) * p.lay.pitch + p.lay.off + (p.Na - ka);
-      float2* __restrict__ sp = p.spec;
+      float2* __restrict__ sp = CHZ_BSEL(p.bspec, p.spec);
       CHZ_OUT_DESC(sdesc, sp);
       // one store per output, no branches: bins up to N/2 go out as they are, the rest conjugated to bin N-k; the
       // self-conjugate rows (ka = 0, Na/2) have no mirror image to write

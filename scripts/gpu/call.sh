@@ -9,6 +9,40 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5c)       # round 5, third call: is the CU-mask gain the partition or the hardware-queue assignment?  + the batched passes, fixed build
+    NR="--no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear"
+    run_chain() { tag=$1; shift; env "$@" $B $NR --detail "$out/chain_$tag.json" > "$out/chain_$tag.head" 2>> "$out/err.txt"; }
+    run_chain base1 X=1
+    run_chain q8_1 GPU_MAX_HW_QUEUES=8
+    run_chain cus256_1 CHZ_TAIL_CUS=256
+    run_chain cus96_1 CHZ_TAIL_CUS=96
+    run_chain cus128_1 CHZ_TAIL_CUS=128
+    run_chain base2 X=1
+    run_chain q8_2 GPU_MAX_HW_QUEUES=8
+    run_chain cus256_2 CHZ_TAIL_CUS=256
+    run_chain cus96_2 CHZ_TAIL_CUS=96
+    run_chain cus96q8 CHZ_TAIL_CUS=96 GPU_MAX_HW_QUEUES=8
+    LIBB=$PWD/ka9q-radio_amd/libchz_hip_batch.so
+    for rep in 1 2; do
+      BENCH_NO_NOTCH=1 $B --quick --detail "$out/fwd_base_$rep.json" > /dev/null 2>> "$out/err.txt"
+      BENCH_NO_NOTCH=1 GPU_MAX_HW_QUEUES=8 $B --quick --detail "$out/fwd_baseq8_$rep.json" > /dev/null 2>> "$out/err.txt"
+      BENCH_NO_NOTCH=1 CHZ_LIB=$LIBB $B --quick --detail "$out/fwd_batchlib_n0_$rep.json" > /dev/null 2>> "$out/err.txt"
+      BENCH_NO_NOTCH=1 CHZ_LIB=$LIBB CHZ_FWD_BATCH_N=2 $B --quick --detail "$out/fwd_batch2_$rep.json" > /dev/null 2>> "$out/err.txt"
+      BENCH_NO_NOTCH=1 CHZ_LIB=$LIBB CHZ_FWD_BATCH_N=4 $B --quick --detail "$out/fwd_batch4_$rep.json" > /dev/null 2>> "$out/err.txt"
+    done
+    for n in 2 4; do CHZ_LIB=$LIBB CHZ_FWD_BATCH_N=$n timeout 300 python scripts/batch_check.py >> "$out/batch_parity.txt" 2>&1; done
+    python - "$out" <<'PY'
+import json, sys, glob, os
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/chain_*.json")):
+    j = json.load(open(f))
+    print(os.path.basename(f), [(x.get("mode"), round(x.get("pipelined_ms_per_block", 0), 3), x.get("pcm_mismatches"), {k: round(v, 3) for k, v in (x.get("ns_per_channel") or {}).items()}) if "error" not in x else x for x in (j.get("next_rows") or [])], "headline us/step", round(j["ms_per_step"] * 1e3, 2))
+for f in sorted(glob.glob(out + "/fwd_*.json")):
+    j = json.load(open(f)); r = j["roofline"]
+    print(os.path.basename(f), "ms_per_step", round(j["ms_per_step"] * 1e3, 2), "fwd_pipelined_us", round(r["pipelined"]["forward_us_per_block"], 2), "frac", round(r["pipelined"]["frac"], 4))
+PY
+    cat "$out/batch_parity.txt"
+    ;;
   r5b)       # round 5, second call: profiles of the shipped kernels (folded notch), the CU-mask and batched-pass experiments, the packed PCM store
     NR="--no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear"
     for cus in 0 32 64 96; do      # (0 = unset: plain streams)
