@@ -295,23 +295,31 @@ int chz_gather_descriptor(int in_type, int master_bins, int P, int shift, int ou
   return 0;
 }
 
-// EXPERIMENT knob (round 5): CHZ_TAIL_CUS=n gives the demodulator stream n of the 256 compute units to itself
-// (spread evenly over the XCDs) and the transform lanes the other 256 - n, through hipExtStreamCreateWithCUMask -- the question being
-// whether the latency-bound demodulator pass and the issue-bound channel kernel overlap better side by side than back to back.
-// Unset (the default): plain streams, the whole device for everybody.
-// (CHZ_TAIL_CUS=256: every stream through hipExtStreamCreateWithCUMask with ALL units enabled -- the control of the experiment: same
-//  creation path, hence the same hardware-queue assignment, no partition)
-static int tail_cus() { static const int n = [] { const char* v = getenv("CHZ_TAIL_CUS"); const int k = v ? atoi(v) : 0; return (k > 0 && k <= 256) ? k : 0; }(); return n; }
+// Every stream the engine launches kernels on gets a HARDWARE QUEUE OF ITS OWN (round 5).  The runtime deals plain streams onto its
+// GPU_MAX_HW_QUEUES (4) hardware queues round-robin, so a fifth stream -- the demodulators' -- shares a queue with a transform lane and the
+// two take turns: measured at 1.5 M channels, the SURVEY 8f chain takes 4.40-4.61 ms per block that way and 4.12-4.15 ms when every
+// stream has its own queue (GPU_MAX_HW_QUEUES=8 in the environment: 4.12-4.23).  A library cannot set that variable (the runtime may be
+// up already); what it can do is create its streams through hipExtStreamCreateWithCUMask with EVERY compute unit enabled -- such a
+// stream is given a queue of its own.  CHZ_OWN_QUEUES=0 keeps plain streams.
+// EXPERIMENT knob on top: CHZ_TAIL_CUS=n gives the demodulator stream n of the compute units to itself (spread
+// evenly over the XCDs) and the transform lanes the others -- the partition itself buys nothing (4.20-4.33 ms), see the decision record.
+static int tail_cus() { static const int n = [] { const char* v = getenv("CHZ_TAIL_CUS"); const int k = v ? atoi(v) : 0; return (k > 0 && k < 256) ? k : 0; }(); return n; }
+static bool own_queues() { static const bool on = [] { const char* v = getenv("CHZ_OWN_QUEUES"); return !(v && v[0] == '0'); }(); return on; }
 static hipError_t stream_create_masked(hipStream_t* s, bool tail) {
 #ifndef HIPEMU
   const int n = tail_cus();
-  if (n > 0) {
-    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = 0; i < 256; i++) {
-      const bool t = ((i + 1) * n) / 256 > (i * n) / 256;      // n of 256, evenly spread
-      if (t == tail || n == 256) mask[i / 32] |= 1u << (i % 32);
+  if (n > 0 || own_queues()) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 && cus <= 1024) {
+      uint32_t mask[32] = {};
+      for (int i = 0; i < cus; i++) {
+        const bool t = n > 0 && (((i + 1) * n) / cus > (i * n) / cus);      // n of the units, evenly spread
+        if (n == 0 || t == tail) mask[i / 32] |= 1u << (i % 32);
+      }
+      const hipError_t r = hipExtStreamCreateWithCUMask(s, (uint32_t)((cus + 31) / 32), mask);
+      if (r == hipSuccess) return r;
+      (void)hipGetLastError();                       // a runtime without the extension: plain streams
     }
-    return hipExtStreamCreateWithCUMask(s, 8, mask);
   }
 #endif
   (void)tail;

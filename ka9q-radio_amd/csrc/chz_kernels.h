@@ -164,6 +164,9 @@ template <int N_> __device__ __forceinline__ float row_shr16(float v) {
 #ifndef CHZ_PLL_WAVES
 #define CHZ_PLL_WAVES 2
 #endif
+#ifndef CHZ_LIN_WAVES
+#define CHZ_LIN_WAVES 2             // demod_lin_lanes: the compiler takes 165 VGPRs with this bound = 3 wavefronts per SIMD (A/B build: -DCHZ_LIN_WAVES=4 caps it at 128)
+#endif
 #ifndef CHZ_LIN_PACKED_STORE
 #define CHZ_LIN_PACKED_STORE 1      // demod_lin_lanes: mono S16 rows leave as 8-byte words (A/B build: -DCHZ_LIN_PACKED_STORE=0)
 #endif
@@ -2474,7 +2477,7 @@ __global__ void __launch_bounds__(64) fm_finish(DemodParams p) {
 // (those in a coherent mode after pll_lanes has mixed their block down); demod_linear_tail then only sees the FM channels.
 #define LIN_TILE 16
 struct LinRow { unsigned char* o; int enc, channels, data; };
-__global__ void __launch_bounds__(64, 2) demod_lin_lanes(DemodParams p) {
+__global__ void __launch_bounds__(64, CHZ_LIN_WAVES) demod_lin_lanes(DemodParams p) {
   HIP_DYNAMIC_SHARED(float2, tile)                         // [64][LIN_TILE + 1], then LinRow[64]
   constexpr int LD = LIN_TILE + 1;
   LinRow* rows = reinterpret_cast<LinRow*>(tile + 64 * LD);

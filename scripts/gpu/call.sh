@@ -9,6 +9,31 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5d)       # round 5, fourth call: demod_lin_lanes at 4 wavefronts per SIMD (A/B build), then the whole GPU suite on the tree with own hardware queues
+    NR="--no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear"
+    LW4=$PWD/ka9q-radio_amd/libchz_hip_linw4.so
+    for rep in 1 2; do
+      $B $NR --detail "$out/chain_default_$rep.json" > /dev/null 2>> "$out/err.txt"
+      CHZ_LIB=$LW4 $B $NR --detail "$out/chain_linw4_$rep.json" > /dev/null 2>> "$out/err.txt"
+    done
+    CHZ_OWN_QUEUES=0 $B $NR --detail "$out/chain_plain_streams.json" > /dev/null 2>> "$out/err.txt"
+    python - "$out" <<'PY'
+import json, sys, glob, os
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/chain_*.json")):
+    j = json.load(open(f))
+    print(os.path.basename(f), [(x.get("mode"), round(x.get("pipelined_ms_per_block", 0), 3), x.get("pcm_mismatches"), {k: round(v, 3) for k, v in (x.get("ns_per_channel") or {}).items()}) if "error" not in x else x for x in (j.get("next_rows") or [])], "headline us/step", round(j["ms_per_step"] * 1e3, 2))
+PY
+    timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -x > "$out/gpu_suite.txt" 2>&1; echo "suite rc=$?" >> "$out/rc.txt"
+    tail -6 "$out/gpu_suite.txt"
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.txt" 2>&1; tail -1 "$out/smoke.txt"
+    ;;
+  r5e)       # round 5, last call: the driver's command on the final tree + its profiles
+    $B > "$out/bench_stdout.txt" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/rc.txt"
+    tail -n 1 "$out/bench_stdout.txt" > "$out/bench_headline.json"; cp gpurun_out/bench_detail.json "$out/bench_detail.json" 2>/dev/null
+    wc -c "$out/bench_headline.json"; cat "$out/bench_headline.json"
+    SKIP_PMC=0 timeout 1500 bash scripts/gpu_profile.sh r05 > "$out/profile.txt" 2>&1
+    ;;
   r5c)       # round 5, third call: is the CU-mask gain the partition or the hardware-queue assignment?  + the batched passes, fixed build
     NR="--no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear"
     run_chain() { tag=$1; shift; env "$@" $B $NR --detail "$out/chain_$tag.json" > "$out/chain_$tag.head" 2>> "$out/err.txt"; }

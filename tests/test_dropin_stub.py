@@ -182,9 +182,8 @@ def test_dropin_random_traffic_under_sanitizers(tmp_path, san, seed):
     that is being fed all the while.  It must end, every call must succeed, the sanitizers must stay silent."""
     if not _have("-fsanitize=" + san):
         pytest.skip("no -fsanitize=%s runtime in this image" % san)
-    out_dir = str(tmp_path / "build")
-    _build(san, out_dir)
-    exe = os.path.join(out_dir, "fuzz")
+    out_dir = os.path.dirname(_build(san, str(tmp_path / "build")))
+    exe = str(tmp_path / "fuzz")
     subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-fsanitize=" + san, "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "dropin_fuzz.c"),
                     "-o", exe, "-L", out_dir, "-lka9q_filter_hip", "-lchz_hip", "-Wl,-rpath," + out_dir, "-lpthread", "-lm"], check=True)
     e = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=67")
