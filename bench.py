@@ -1028,6 +1028,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)
 
+    t_start = time.perf_counter()
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
@@ -1147,6 +1148,9 @@ def main():
             job += reps * args.steps
         return statistics.median(times), times, last, reps, single
 
+    def progress(what):
+        if rank == 0:
+            print("bench.py [%6.1f s] %s" % (time.perf_counter() - t_start, what), file=sys.stderr, flush=True)
     legs = {}
     leg_seconds = {}                      # wall seconds of every leg of this run (rank 0): the time budget of the bench line
     t_leg = time.perf_counter()
@@ -1168,6 +1172,7 @@ def main():
     leg_seconds["headline_and_exchange_legs"] = time.perf_counter() - t_leg
     t_leg = time.perf_counter()
 
+    progress("roofline: per-kernel times")
     # ---- per-kernel durations with HIP events on the launch stream (eager, instrumented; >= 200 launches whatever K is)
     roof = None
     if rank == 0:
@@ -1227,6 +1232,7 @@ def main():
 
     leg_seconds["roofline_kernels"] = time.perf_counter() - t_leg
     t_leg = time.perf_counter()
+    progress("c_rt")
     # ---- C_rt leg: one bank of millions of channels of the workload's kind; every block on its own <= 20 ms
     crt = None
     if not args.no_crt and config in (3, 4):
@@ -1280,6 +1286,7 @@ def main():
         except Exception as ex:
             crt_shared = {"error": str(ex)[:600]}
 
+    progress("cpu_baseline")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         t_leg = time.perf_counter()
@@ -1297,6 +1304,7 @@ def main():
         dist.all_gather_object(allr, ranks_info[0])
         ranks_info = allr
 
+    progress("dropin (free-running)")
     # ---- the boundary itself: the same workload through filter.h (C harness, one pthread per channel), PCIe in the loop
     dropin = None
     if rank == 0 and world == 1 and not args.no_dropin and config in (1, 2, 3):
@@ -1314,6 +1322,7 @@ def main():
             except Exception as ex:
                 dropin.append({"label": label, "error": str(ex)[:600]})
         leg_seconds["dropin"] = time.perf_counter() - t_leg
+    progress("dropin_paced")
     # ---- the boundary the way radiod runs it: the front end on its own 20 ms clock, channel threads blocking in execute_filter_output
     dropin_paced = None
     if rank == 0 and world == 1 and not args.no_dropin_paced and config in (2, 3):
@@ -1341,6 +1350,7 @@ def main():
             except Exception as ex:
                 dropin_paced.append({"label": label, "error": str(ex)[:600]})
         leg_seconds["dropin_paced"] = time.perf_counter() - t_leg
+    progress("dropin_sharded")
     # ---- channels sharded over the node's GPUs BEHIND filter.h (KA9Q_HIP_DEVICES): config 4's shape, 1024 x 24 kHz channels per device,
     # one master, one pthread per channel, the front end at wall-clock pace.  On a one-GPU run the two shards share the device ("0,0").
     dropin_sharded = None
@@ -1359,21 +1369,25 @@ def main():
         except Exception as ex:
             dropin_sharded = [{"error": str(ex)[:600]}]
         leg_seconds["dropin_sharded"] = time.perf_counter() - t_leg
+    progress("c_rt_pcie")
     crt_pcie = None
     if rank == 0 and world == 1 and not args.no_crt_pcie and config == 3:
         t_leg = time.perf_counter()
         crt_pcie = []
         for n, dm, pipe in ((460_800, False, False), (1_320_960, True, False), (1_428_480, True, True)):
+            progress("c_rt_pcie %d channels demod=%s pipelined=%s" % (n, dm, pipe))
             try:
                 crt_pcie.append(crt_pcie_leg(pkg, wl, n, args.crt_pcie_blocks, dm, dev_index, pipe))
             except Exception as ex:
                 crt_pcie.append({"channels": n, "error": str(ex)[:600]})
         leg_seconds["c_rt_pcie"] = time.perf_counter() - t_leg
+    progress("next_rows")
     next_rows = None
     if rank == 0 and world == 1 and not args.no_next_rows and config == 3:
         t_leg = time.perf_counter()
         next_rows = []
         for mode in [m for m in ("linear", "pll", "fm") if m in args.next_rows_modes.split(",")]:
+            progress("next_rows " + mode)
             try:
                 next_rows.append(next_rows_leg(pkg, wl, args.next_rows_channels, dev_index, mode))
             except Exception as ex:

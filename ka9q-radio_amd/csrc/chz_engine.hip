@@ -295,20 +295,22 @@ int chz_gather_descriptor(int in_type, int master_bins, int P, int shift, int ou
   return 0;
 }
 
-// Every stream the engine launches kernels on gets a HARDWARE QUEUE OF ITS OWN (round 5).  The runtime deals plain streams onto its
+// The demodulator stream gets a HARDWARE QUEUE OF ITS OWN (round 5).  The runtime deals plain streams onto its
 // GPU_MAX_HW_QUEUES (4) hardware queues round-robin, so a fifth stream -- the demodulators' -- shares a queue with a transform lane and the
 // two take turns: measured at 1.5 M channels, the SURVEY 8f chain takes 4.40-4.61 ms per block that way and 4.12-4.15 ms when every
 // stream has its own queue (GPU_MAX_HW_QUEUES=8 in the environment: 4.12-4.23).  A library cannot set that variable (the runtime may be
 // up already); what it can do is create its streams through hipExtStreamCreateWithCUMask with EVERY compute unit enabled -- such a
-// stream is given a queue of its own.  CHZ_OWN_QUEUES=0 keeps plain streams.
+// stream is given a queue of its own.  The transform lanes keep plain streams: they are exactly the four the runtime has queues for.
 // EXPERIMENT knob on top: CHZ_TAIL_CUS=n gives the demodulator stream n of the compute units to itself (spread
 // evenly over the XCDs) and the transform lanes the others -- the partition itself buys nothing (4.20-4.33 ms), see the decision record.
 static int tail_cus() { static const int n = [] { const char* v = getenv("CHZ_TAIL_CUS"); const int k = v ? atoi(v) : 0; return (k > 0 && k < 256) ? k : 0; }(); return n; }
-static bool own_queues() { static const bool on = [] { const char* v = getenv("CHZ_OWN_QUEUES"); return !(v && v[0] == '0'); }(); return on; }
+// CHZ_OWN_QUEUES: 0 plain streams everywhere (rounds 1-4), 1 (default) the demodulator stream only -- the one stream beyond the runtime's
+// four queues --, 2 every stream the engine launches kernels on
+static int own_queues() { static const int m = [] { const char* v = getenv("CHZ_OWN_QUEUES"); const int k = v ? atoi(v) : 1; return (k >= 0 && k <= 2) ? k : 1; }(); return m; }
 static hipError_t stream_create_masked(hipStream_t* s, bool tail) {
 #ifndef HIPEMU
   const int n = tail_cus();
-  if (n > 0 || own_queues()) {
+  if (n > 0 || own_queues() == 2 || (own_queues() == 1 && tail)) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 && cus <= 1024) {
       uint32_t mask[32] = {};

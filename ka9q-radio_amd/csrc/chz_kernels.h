@@ -167,6 +167,9 @@ template <int N_> __device__ __forceinline__ float row_shr16(float v) {
 #ifndef CHZ_LIN_WAVES
 #define CHZ_LIN_WAVES 2             // demod_lin_lanes: the compiler takes 165 VGPRs with this bound = 3 wavefronts per SIMD (A/B build: -DCHZ_LIN_WAVES=4 caps it at 128)
 #endif
+#ifndef CHZ_LIN_UNROLL
+#define CHZ_LIN_UNROLL 1            // demod_lin_lanes' final pass: samples read / stepped / written per group (A/B builds: 4, 8)
+#endif
 #ifndef CHZ_LIN_PACKED_STORE
 #define CHZ_LIN_PACKED_STORE 1      // demod_lin_lanes: mono S16 rows leave as 8-byte words (A/B build: -DCHZ_LIN_PACKED_STORE=0)
 #endif
@@ -2640,8 +2643,8 @@ __global__ void __launch_bounds__(64, CHZ_LIN_WAVES) demod_lin_lanes(DemodParams
     if (active) {
       double cr = 1.0, sr = 0.0;
       if (rot) rot_at(t0, cr, sr);
-      for (int n = 0; n < tn; n++) {
-        float2 v = tile[lane * LD + n];
+      // one sample of the final pass, in the reference's order (the state -- gain, carrier filter, power sum, shift phasor -- lives in the captured variables)
+      auto final_step = [&](float2 v) -> float2 {
         if (rot) {
           const double xr = v.x, xi = v.y;
           v = make_float2((float)(xr * cr - xi * sr), (float)(xr * sr + xi * cr));
@@ -2676,8 +2679,23 @@ __global__ void __launch_bounds__(64, CHZ_LIN_WAVES) demod_lin_lanes(DemodParams
           }
           oa = (float)a; ob = (float)b;
         }
-        tile[lane * LD + n] = make_float2(oa, ob);
+        return make_float2(oa, ob);
+      };
+      int n = 0;
+#if CHZ_LIN_UNROLL > 1
+      // the walk is a chain of LDS round trips (read a sample, a few dependent double-precision operations, write it back): CHZ_LIN_UNROLL
+      // samples are read together, stepped in order, and written together -- the same operations in the same order, one LDS latency per group
+      for (; n + CHZ_LIN_UNROLL <= tn; n += CHZ_LIN_UNROLL) {
+        float2 v[CHZ_LIN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < CHZ_LIN_UNROLL; u++) v[u] = tile[lane * LD + n + u];
+#pragma unroll
+        for (int u = 0; u < CHZ_LIN_UNROLL; u++) v[u] = final_step(v[u]);
+#pragma unroll
+        for (int u = 0; u < CHZ_LIN_UNROLL; u++) tile[lane * LD + n + u] = v[u];
       }
+#endif
+      for (; n < tn; n++) tile[lane * LD + n] = final_step(tile[lane * LD + n]);
     }
     CHZ_WAVE_SYNC();
     if (any_data != 0ull) {

@@ -9,6 +9,27 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5f)       # round 5, fifth call: the driver's command with the demodulator stream alone on its own queue (bounded: r5d's run with EVERY stream masked hung in one of the legs), then A/Bs of the chain
+    timeout 420 $B > "$out/bench_stdout.txt" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/rc.txt"
+    tail -n 1 "$out/bench_stdout.txt" > "$out/bench_headline.json"; cp gpurun_out/bench_detail.json "$out/bench_detail.json" 2>/dev/null
+    grep "^bench.py \[" "$out/bench.err" | tail -20
+    NR="--no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear"
+    run_chain() { tag=$1; shift; env "$@" timeout 200 $B $NR --detail "$out/chain_$tag.json" > /dev/null 2>> "$out/err.txt"; }
+    run_chain q0 CHZ_OWN_QUEUES=0
+    run_chain q1 CHZ_OWN_QUEUES=1
+    run_chain q2 CHZ_OWN_QUEUES=2
+    run_chain linu4 CHZ_LIB=$PWD/ka9q-radio_amd/libchz_hip_linu4.so
+    run_chain linu8 CHZ_LIB=$PWD/ka9q-radio_amd/libchz_hip_linu8.so
+    run_chain q1b CHZ_OWN_QUEUES=1
+    python - "$out" <<'PY'
+import json, sys, glob, os
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/chain_*.json")):
+    j = json.load(open(f))
+    print(os.path.basename(f), [(x.get("mode"), round(x.get("pipelined_ms_per_block", 0), 3), x.get("pcm_mismatches"), {k: round(v, 3) for k, v in (x.get("ns_per_channel") or {}).items()}) if "error" not in x else x for x in (j.get("next_rows") or [])], "headline us/step", round(j["ms_per_step"] * 1e3, 2))
+PY
+    wc -c "$out/bench_headline.json"; head -c 1500 "$out/bench_headline.json"
+    ;;
   r5d)       # round 5, fourth call: demod_lin_lanes at 4 wavefronts per SIMD (A/B build), then the whole GPU suite on the tree with own hardware queues
     NR="--no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear"
     LW4=$PWD/ka9q-radio_amd/libchz_hip_linw4.so
