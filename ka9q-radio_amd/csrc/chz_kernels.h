@@ -168,7 +168,8 @@ template <int N_> __device__ __forceinline__ float row_shr16(float v) {
 #define CHZ_LIN_WAVES 2             // demod_lin_lanes: the compiler takes 165 VGPRs with this bound = 3 wavefronts per SIMD (A/B build: -DCHZ_LIN_WAVES=4 caps it at 128)
 #endif
 #ifndef CHZ_LIN_UNROLL
-#define CHZ_LIN_UNROLL 1            // demod_lin_lanes' final pass: samples read / stepped / written per group (A/B builds: 4, 8)
+#define CHZ_LIN_UNROLL 4            // demod_lin_lanes' final pass: samples read / stepped / written per group (1 = round 4's loop; measured at 1.5 M channels on one
+                                    // box, every stream on its own queue: 1 -> 4.28, 4 -> 4.07, 8 -> 4.06 ms per block, PCM bit-identical; A/B: make linu1 / linu8)
 #endif
 #ifndef CHZ_LIN_PACKED_STORE
 #define CHZ_LIN_PACKED_STORE 1      // demod_lin_lanes: mono S16 rows leave as 8-byte words (A/B build: -DCHZ_LIN_PACKED_STORE=0)

@@ -9,6 +9,15 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5g)       # round 5, final validation: the whole GPU suite + smoke, the driver's command, its profiles -- every step bounded
+    timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > "$out/gpu_suite.txt" 2>&1; echo "suite rc=$?" >> "$out/rc.txt"
+    tail -8 "$out/gpu_suite.txt"
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.txt" 2>&1; tail -1 "$out/smoke.txt"
+    timeout 480 $B > "$out/bench_stdout.txt" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/rc.txt"
+    tail -n 1 "$out/bench_stdout.txt" > "$out/bench_headline.json"; cp gpurun_out/bench_detail.json "$out/bench_detail.json" 2>/dev/null
+    wc -c "$out/bench_headline.json"; grep "^bench.py \[" "$out/bench.err" | tail -3
+    SKIP_PMC=0 timeout 900 bash scripts/gpu_profile.sh r05 > "$out/profile.txt" 2>&1
+    ;;
   r5f)       # round 5, fifth call: the driver's command with the demodulator stream alone on its own queue (bounded: r5d's run with EVERY stream masked hung in one of the legs), then A/Bs of the chain
     timeout 420 $B > "$out/bench_stdout.txt" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/rc.txt"
     tail -n 1 "$out/bench_stdout.txt" > "$out/bench_headline.json"; cp gpurun_out/bench_detail.json "$out/bench_detail.json" 2>/dev/null
