@@ -377,7 +377,7 @@ def crt_leg(pkg, eng, wl, counts, blocks, run_one, shared=False, verify=64, agre
     P, olen, tile = wl["P"], wl["olen"], 3072
     solo = agree is None
     agree = agree or (lambda x: x)
-    top = 21_000_000 if P == 300 else 10_500_000
+    top = 22_000_000 if P == 300 else 11_000_000          # the allocated bank (responses + 4 output images: 222 GB of the 288): the search must not be capped by it
     if counts:
         counts = sorted(set(int(c) - int(c) % tile for c in counts))
         nmax = counts[-1]

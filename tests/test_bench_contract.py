@@ -146,7 +146,7 @@ def test_bench_crt_search_reports_a_sustained_count_and_the_mean_crossing(tmp_pa
     h, j = _run_bench(["--steps", "20", "--warmup", "5", "--crt-blocks", "60", "--no-next-rows", "--no-dropin", "--no-dropin-paced", "--no-crt-pcie",
                        "--no-cpu-baseline"], tmp_path)
     c = j["c_rt"]
-    assert c["sustained"] is True and 10_000_000 < c["channels"] <= 21_001_024 and c["worst_block_ms"] <= 20.0 and c["verified_channels"] >= 64
+    assert c["sustained"] is True and 10_000_000 < c["channels"] <= 22_001_024 and c["worst_block_ms"] <= 20.0 and c["verified_channels"] >= 64
     assert len(c["calibration"]) == 2 and 1 <= c["rungs"] <= 12 and c["probes"][0]["channels"] > 0.8 * c["mean_crossing_channels"]
     assert 0.9 * c["channels"] < c["mean_crossing_channels"] < 1.25 * c["channels"]
     assert h["c_rt"]["channels"] == c["channels"] and h["c_rt"]["mean_crossing_channels"] > 0
