@@ -9,6 +9,12 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5h)       # round 5: the C_rt search with the 22 M-channel bank; why the all-streams-masked tree hung (stream callbacks on CU-masked streams?)
+    $B --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --no-next-rows --detail "$out/crt22.json" > "$out/crt22.head" 2> "$out/crt22.err"; echo "crt22 rc=$?" >> "$out/rc.txt"
+    python -c "import json; c=json.load(open('$out/crt22.json'))['c_rt']; print('c_rt', c.get('channels'), c.get('sustained'), c.get('worst_block_ms'), c.get('mean_crossing_channels'), [(p['channels'], p['blocks'], round(p['worst_block_ms'],2), p['sustained']) for p in c.get('probes', [])], c.get('error'))"
+    for q in 0 1 2; do CHZ_OWN_QUEUES=$q timeout 60 python scripts/hostfunc_on_masked_stream.py >> "$out/hostfunc.txt" 2>&1; echo "CHZ_OWN_QUEUES=$q rc=$?" >> "$out/hostfunc.txt"; done
+    cat "$out/hostfunc.txt"
+    ;;
   r5g)       # round 5, final validation: the whole GPU suite + smoke, the driver's command, its profiles -- every step bounded
     timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > "$out/gpu_suite.txt" 2>&1; echo "suite rc=$?" >> "$out/rc.txt"
     tail -8 "$out/gpu_suite.txt"
