@@ -929,6 +929,7 @@ def headline(out, detail_path):
                   "forward_us_per_block", "launches_timed", "kernels_us")
         r["kernel"] = "fwd_first_real + fwd_cols + fwd_rows" if "fwd_cols" in (roof.get("kernels_us") or {}) else "fwd_first_real + fwd_rows"
         r["pipelined"] = _pick(roof.get("pipelined"), "frac", "forward_us_per_block", "lanes")
+        r["streamed"] = _pick(roof.get("streamed"), "frac", "forward_us_per_block", "input_ring_MB", "error")
         m = roof.get("profiles_match_this_tree") or {}
         r["profiles_match_this_tree"] = None if m.get("pmc_forward.json") is None else bool(m.get("pmc_forward.json") and m.get("rocprof_kernels.json"))
         if roof.get("batched"):
@@ -1190,6 +1191,29 @@ def main():
         fo = eng.run_blocks(400, 2000)
         bank.set_active(nch)
         fwd_pipe_us = fo.total_ms / fo.blocks * 1e3
+        # ... and with the INPUT genuinely streamed from HBM: the 8-block ring above (83 MB) lives in the 256 MiB Infinity Cache, so the figures
+        # above are fabric rates; a second engine with a 48-block ring (498 MB of samples at 129.6 MS/s, read once per 48 blocks) cannot keep it there
+        streamed = None
+        if real and config in (3, 4, 5) and os.environ.get("BENCH_NO_STREAMED") != "1":
+            try:
+                sb = 48
+                e2 = pkg.engine.Engine(wl["L"], wl["M"], pkg.engine.REAL, device=dev_index, plan=args.plan, ring_blocks=sb)
+                try:
+                    for k in range(sb // RING_BLOCKS):
+                        e2.write(ring_host if k else ring_host[:RING_BLOCKS * wl["L"] - (wl["M"] - 1)])
+                    e2.write(ring_host[RING_BLOCKS * wl["L"] - (wl["M"] - 1):])
+                    if os.environ.get("BENCH_NO_NOTCH") != "1":
+                        e2.set_notches([0], 0.01)
+                    e2.run_blocks(0, 480)
+                    f2 = e2.run_blocks(480, 1920)
+                    us = f2.total_ms / f2.blocks * 1e3
+                    streamed = {"ring_blocks": sb, "input_ring_MB": sb * wl["L"] * 4 / 1e6, "blocks_timed": f2.blocks, "forward_us_per_block": us,
+                                "achieved": fwd_bytes(wl["N"], real) / (us * 1e-6) / 1e9, "frac": fwd_bytes(wl["N"], real) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                "note": "forward transform alone, four blocks in flight, the samples read from a ring larger than the Infinity Cache"}
+                finally:
+                    e2.close()
+            except Exception as ex:
+                streamed = {"error": str(ex)[:300]}
         Ra = eng.axes[0] // 2 + 1 if real else eng.axes[0]
         inner_bytes = Ra * eng.axes[1] * eng.axes[2] * 8
         own = {"fwd_first_real": (4 if real else 8) * wl["N"] + inner_bytes, "fwd_cols": 2 * inner_bytes,
@@ -1227,6 +1251,7 @@ def main():
                           "frac": fb / (fwd_pipe_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "lanes": eng.lanes, "blocks_timed": fo.blocks,
                           "traffic_GBps": (traffic / (fwd_pipe_us * 1e-6) / 1e9) if traffic else None,
                           "measured_copy_rate_GBps": COPY_RATE_GBS},
+            "streamed": streamed,
             "kernels_own_GBps": {k: own[k] / (kern[k] * 1e-6) / 1e9 for k in own if k in kern and kern[k] > 0},
         }
 

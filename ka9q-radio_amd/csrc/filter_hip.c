@@ -159,6 +159,7 @@ struct mctx {
   /* wake-up of the channel threads: the completion callback wakes wake_first of them (0 = all), every woken thread wakes
      wake_fan more (KA9Q_HIP_WAKE="first,fan"; default "0,2") */
   int wake_first, wake_fan;
+  int wedged_ms;                    /* how long the producer waits for a device that completes nothing and reports nothing before it gives up (KA9Q_HIP_WEDGED_MS) */
   int bank_cap0;                    /* channels a new bank starts with (KA9Q_HIP_BANK_CHANNELS, default 64; banks double as they fill) */
   /* KA9Q_HIP_PROFILE=1: where a block's host time goes, printed by delete_filter_input */
   bool profile;
@@ -597,6 +598,8 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   }
   c->shard_channels = 1024;                                       /* contiguous 1024-blocks */
   { const char *sc = getenv("KA9Q_HIP_SHARD_CHANNELS"); if (sc && atoi(sc) > 0) c->shard_channels = atoi(sc); }
+  c->wedged_ms = 10000;
+  { const char *wm = getenv("KA9Q_HIP_WEDGED_MS"); if (wm && atoi(wm) >= 500) c->wedged_ms = atoi(wm); }
   { const char *bc = getenv("KA9Q_HIP_BANK_CHANNELS"); if (bc && atoi(bc) > 0 && atoi(bc) <= 65536) c->bank_cap0 = atoi(bc); }
   /* master->fdomain[] is read by radiod's estimate_noise() (src/radio.c:1801) and by nothing else outside filter.c;
      a host that takes the noise estimate from the device (chz_bank_enable_noise) can switch the 13 MB per-block copy off */
@@ -934,13 +937,12 @@ int execute_filter_input(struct filter_in *const f) {
       /* a watchdog of a few block times: after a sticky device error the runtime delivers no more stream callbacks, and a producer
          asleep here for good would never reach the recovery below.  A failed check ends the wait (the recovery drains the old engines,
          whose callbacks, if they still come, drop their blocks); a device that reports nothing and completes nothing for
-         WEDGED_MS is beyond recovery from in here */
+         wedged_ms (KA9Q_HIP_WEDGED_MS, default 10000) is beyond recovery from in here */
 #define WATCHDOG_MS 250
-#define WEDGED_MS 10000
       if (futex_wait_u32_ms(&c->dev_seq[nslot], done, WATCHDOG_MS) != 0 && errno == ETIMEDOUT) {
         waited_ms += WATCHDOG_MS;
         if (any_engine_failed(c)) { __atomic_store_n(&c->failed, true, __ATOMIC_RELEASE); break; }
-        if (waited_ms >= WEDGED_MS) die_for_the_supervisor("the device has not completed a block for 10 s and reports no error");
+        if (waited_ms >= c->wedged_ms) die_for_the_supervisor("the device has not completed a block for a long time (KA9Q_HIP_WEDGED_MS, default 10 s) and reports no error");
       }
     }
   }

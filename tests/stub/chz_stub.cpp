@@ -148,6 +148,9 @@ int chz_forward(chz_engine* e, unsigned job) {
   if (!e) return fail(-1, "null engine");
   if (e->fail_job >= 0 && (int)job >= e->fail_job) e->post([e] { e->failed.store(true, std::memory_order_release); });
   e->post([e, job] {
+    // CHZ_STUB_WEDGE_JOB=n: from block n on the device neither completes anything nor reports anything (a wedged device)
+    static const int wedge = [] { const char* v = getenv("CHZ_STUB_WEDGE_JOB"); return v ? atoi(v) : -1; }();
+    if (wedge >= 0 && (int)job >= wedge) for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));
     static const int delay_ms = [] { const char* v = getenv("CHZ_STUB_FORWARD_DELAY_MS"); return v ? atoi(v) : 0; }();   // a slow device
     if (delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
     const size_t need = (size_t)e->L * (e->in_type == CHZ_REAL ? 1 : 2);
@@ -188,7 +191,9 @@ int chz_spectrum_read_async(chz_engine* e, int slot, float* host) {
 }
 int chz_host_callback(chz_engine* e, int, void (*fn)(void*), void* arg) {
   if (!e || !fn) return fail(-1, "bad argument");
-  e->post([fn, arg] { fn(arg); });
+  // CHZ_STUB_LOSE_CALLBACKS=1: once the engine has failed its stream callbacks are never delivered -- what the runtime does after a sticky device error
+  static const bool lose = [] { const char* v = getenv("CHZ_STUB_LOSE_CALLBACKS"); return v && v[0] == '1'; }();
+  e->post([e, fn, arg] { if (lose && e->failed.load(std::memory_order_acquire)) return; fn(arg); });
   return 0;
 }
 // the in-process clique of the drop-in's KA9Q_HIP_EXCHANGE=broadcast: a communicator is just its rank here; the broadcast is a task on

@@ -317,6 +317,67 @@ def test_dropin_second_failure_exits_for_the_supervisor(tmp_path):
     assert "second device failure" in r.stderr and "supervisor" in r.stderr and r.stderr.count("re-creating the engine") == 1
 
 
+def test_dropin_recovers_when_the_failed_device_delivers_no_more_callbacks(tmp_path):
+    """After a sticky device error the runtime delivers no more stream callbacks: the blocks in flight never complete, and a producer
+    asleep on their slot would never reach the recovery (round 4's advisor finding).  The stand-in fails at block 5 AND swallows every
+    callback from then on; the front end runs at its own pace and never waits for a channel.  The producer's watchdog (250 ms) must
+    notice the failed check, replace the engine once, announce the blocks whose callbacks never came as dropped (zeros + a counted drop
+    for every slave -- nobody is left asleep), and the stream must be exact again afterwards."""
+    if not _have("-fsanitize=thread"):
+        pytest.skip("no -fsanitize=thread runtime in this image")
+    nblocks, nch = 20, 12
+    r, run_dir, x, plan = _recovery_run(tmp_path, "thread", {"CHZ_STUB_FAIL_JOB": "5", "CHZ_STUB_LOSE_CALLBACKS": "1", "HARNESS_PACED_US": "20000",
+                                                            "CHZ_STUB_FORWARD_DELAY_MS": "60"}, nblocks, nch)       # (a device 3 x slower than the stream: the producer is asleep on a busy slot when the failure is raised)
+    assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    assert r.stderr.count("re-creating the engine") == 1, r.stderr[-2000:]
+    L, M, olen, P = 25920, 6481, 240, 300
+    N = L + M - 1
+    out = np.fromfile(os.path.join(run_dir, "out.bin"), np.complex64).reshape(nblocks, nch, olen)
+    dropped = np.fromfile(os.path.join(run_dir, "dropped.bin"), np.uint8).reshape(nblocks, nch).astype(bool)
+    meta = open(os.path.join(run_dir, "meta.txt")).read().split()
+    meta = dict(zip(meta[::2], meta[1::2]))
+    assert int(meta["clock"]) == nblocks and int(meta["next_jobnum"]) == nblocks       # everybody got to the end: nobody was left asleep on a lost block
+    # (a paced front end that never waits: WHICH call of a slave saw a drop is not the block number -- the counts and the delivered data are checked)
+    assert int(meta["drops"]) == int(dropped.sum()) and nch <= dropped.sum() <= 16 * nch, dropped.sum(axis=1)
+    st = ol.Stream(L, M, ol.REAL)
+    wants = []
+    for b in range(nblocks):
+        s64 = st.push(x[b * L:(b + 1) * L], f64=True)
+        wants.append([ol.channel(s64, ol.REAL, P, olen, p[0], ol.set_filter(P, olen, N, True, p[4], p[5], p[6])) for p in plan])
+    exact = 0
+    for i in range(nch):
+        # every call's output is either zeros (a counted drop) or EXACTLY some block of the stream, in order
+        b = 0
+        for call in range(nblocks):
+            if dropped[call, i]:
+                assert not out[call, i].any()
+                continue
+            while b < nblocks:
+                want = wants[b][i]
+                err = float(np.sqrt(np.mean(np.abs(out[call, i] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+                b += 1
+                if err <= 1e-5 * rms + 1e-9:
+                    exact += 1
+                    break
+            else:
+                raise AssertionError("channel %d call %d: output matches no later block of the stream" % (i, call))
+    assert exact >= nch * (nblocks - 16)
+
+
+def test_dropin_exits_when_the_device_is_wedged_without_an_error(tmp_path):
+    """... and a device that neither completes anything nor reports anything: no recovery is possible from inside the process --
+    after KA9Q_HIP_WEDGED_MS (default 10 s; 1.5 s here) the producer ends the process with EX_SOFTWARE through _exit, with its locks
+    held and a dozen channel threads asleep (the reference's fatal path, src/main.c:202)."""
+    exe = _build_plain(str(tmp_path / "build"))
+    L, M, olen = 25920, 6481, 240
+    x = np.zeros(12 * L, np.float32)
+    run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
+    r = _run(exe, run_dir, L, M, olen, _plan(np.random.default_rng(1), 12), 12, x, {"CHZ_STUB_WEDGE_JOB": "4", "KA9Q_HIP_WEDGED_MS": "1500", "HARNESS_PACED_US": "20000"})
+    assert r.returncode == 70, (r.returncode, r.stderr[-1500:])
+    assert "has not completed a block" in r.stderr and "supervisor" in r.stderr
+
+
 @pytest.mark.parametrize("ndev,san,exchange", [(3, "thread", "samples"), (2, "address", "samples"), (3, "thread", "broadcast"), (2, "address", "broadcast")])
 def test_dropin_sharded_over_fake_devices(tmp_path, ndev, san, exchange):
     """KA9Q_HIP_DEVICES: ONE master behind filter.h, its slaves spread over 2 and 3 (stand-in) devices -- BASELINE config 4's shape
