@@ -167,6 +167,9 @@ template <int N_> __device__ __forceinline__ float row_shr16(float v) {
 #ifndef CHZ_LIN_WAVES
 #define CHZ_LIN_WAVES 2             // demod_lin_lanes: the compiler takes 165 VGPRs with this bound = 3 wavefronts per SIMD (A/B build: -DCHZ_LIN_WAVES=4 caps it at 128)
 #endif
+#ifndef CHZ_PLL_UNROLL
+#define CHZ_PLL_UNROLL 1            // pll_lanes: samples read / stepped / written per group (A/B build: make pllu4)
+#endif
 #ifndef CHZ_LIN_UNROLL
 #define CHZ_LIN_UNROLL 4            // demod_lin_lanes' final pass: samples read / stepped / written per group (1 = round 4's loop; measured at 1.5 M channels on one
                                     // box, every stream on its own queue: 1 -> 4.28, 4 -> 4.07, 8 -> 4.06 ms per block, PCM bit-identical; A/B: make linu1 / linu8)
@@ -2250,13 +2253,12 @@ __global__ void __launch_bounds__(64, CHZ_PLL_WAVES) pll_lanes(DemodParams p) {
     CHZ_WAVE_SYNC();
     if (t0 + PLL_TILE < N) fetch_tile(t0 + PLL_TILE);
     if (active) {
-      for (int n = 0; n < tn; n++) {
+      // one sample of the loop (src/linear.c:83-153 with the loop filter of src/osc.c:75-205), in the reference's order
+      auto pll_step = [&](const float2 v, const int n) -> float2 {
         double sn, cs; pll_nco(q.vco_phase, sn, cs);
-        const float2 v = tile[lane * LD + n];
         const double br = v.x, bi = v.y;
         const double sr = br * cs + bi * sn, si = bi * cs - br * sn;           // buffer[n] * conj(vco)
         const float2 mixed = make_float2((float)sr, (float)si);
-        tile[lane * LD + n] = mixed;
         {
           float a = mixed.x * mixed.x, b = mixed.y * mixed.y;
           CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
@@ -2277,7 +2279,21 @@ __global__ void __launch_bounds__(64, CHZ_PLL_WAVES) pll_lanes(DemodParams p) {
         phase /= (2 * M_PI);
         pll_foff = isamprate * pll_run(q, phase);
         signal += sr * sr; noise += si * si;
+        return mixed;
+      };
+      int n = 0;
+#if CHZ_PLL_UNROLL > 1
+      for (; n + CHZ_PLL_UNROLL <= tn; n += CHZ_PLL_UNROLL) {      // (see demod_lin_lanes: one LDS round trip per group instead of per sample)
+        float2 v[CHZ_PLL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < CHZ_PLL_UNROLL; u++) v[u] = tile[lane * LD + n + u];
+#pragma unroll
+        for (int u = 0; u < CHZ_PLL_UNROLL; u++) v[u] = pll_step(v[u], n + u);
+#pragma unroll
+        for (int u = 0; u < CHZ_PLL_UNROLL; u++) tile[lane * LD + n + u] = v[u];
       }
+#endif
+      for (; n < tn; n++) tile[lane * LD + n] = pll_step(tile[lane * LD + n], n);
     }
     CHZ_WAVE_SYNC();
     for (int r0 = 0; r0 < 64; r0 += 64 / PLL_TILE) {

@@ -9,6 +9,23 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5i)       # round 5: the HBM-streamed forward figure; pll_lanes with 4 samples per LDS round trip (A/B build)
+    $B --quick --detail "$out/quick.json" > "$out/quick.head" 2> "$out/quick.err"; echo "quick rc=$?" >> "$out/rc.txt"
+    python -c "import json; r=json.load(open('$out/quick.json'))['roofline']; print('pipelined', r['pipelined']['forward_us_per_block'], r['pipelined']['frac'], 'streamed', r['streamed'])"
+    NR="--no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes pll"
+    P4=$PWD/ka9q-radio_amd/libchz_hip_pllu4.so
+    for rep in 1 2; do
+      timeout 200 $B $NR --detail "$out/pll_default_$rep.json" > /dev/null 2>> "$out/err.txt"
+      CHZ_LIB=$P4 timeout 200 $B $NR --detail "$out/pll_u4_$rep.json" > /dev/null 2>> "$out/err.txt"
+    done
+    python - "$out" <<'PY'
+import json, sys, glob, os
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/pll_*.json")):
+    j = json.load(open(f))
+    print(os.path.basename(f), [(x.get("mode"), round(x.get("pipelined_ms_per_block", 0), 3), x.get("pcm_mismatches"), {k: round(v, 3) for k, v in (x.get("ns_per_channel") or {}).items()}) if "error" not in x else x for x in (j.get("next_rows") or [])])
+PY
+    ;;
   r5h)       # round 5: the C_rt search with the 22 M-channel bank; why the all-streams-masked tree hung (stream callbacks on CU-masked streams?)
     $B --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --no-next-rows --detail "$out/crt22.json" > "$out/crt22.head" 2> "$out/crt22.err"; echo "crt22 rc=$?" >> "$out/rc.txt"
     python -c "import json; c=json.load(open('$out/crt22.json'))['c_rt']; print('c_rt', c.get('channels'), c.get('sustained'), c.get('worst_block_ms'), c.get('mean_crossing_channels'), [(p['channels'], p['blocks'], round(p['worst_block_ms'],2), p['sustained']) for p in c.get('probes', [])], c.get('error'))"
