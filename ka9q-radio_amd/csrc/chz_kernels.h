@@ -3008,21 +3008,48 @@ __global__ void __launch_bounds__(64, CHZ_FM_WAVES) demod_fm_lanes(DemodParams p
   rows[lane] = LinRow{p.pcm + (size_t)ch * p.pcm_stride, enc, 1, go ? 1 : 0};
   const double gain = (2 * headroom * samprate) / bandwidth;
   double y = st.deemph_state, part = 0.0;
+  // every row that sends is S16 and the PCM rows are 8-byte aligned (wave-uniform): the packed store below
+  const bool fm_s16 = CHZ_LIN_PACKED_STORE && LIN_TILE == 16 && (p.pcm_stride & 7) == 0 && __ballot(go && !(enc == CHZ_PCM_S16BE_K || enc == CHZ_PCM_S16LE_K)) == 0ull;
   fetch_b(0, out_rows);
   for (int t0 = 0; t0 < N; t0 += LIN_TILE) {
     const int tn = N - t0 < LIN_TILE ? N - t0 : LIN_TILE;
     place_b();
     CHZ_WAVE_SYNC();
     if (t0 + LIN_TILE < N) fetch_b(t0 + LIN_TILE, out_rows);
-    if (go)
-      for (int n = 0; n < tn; n++) {
-        float b = tilef[lane * LD + n];
+    if (go) {
+      auto out_step = [&](float b) -> float {              // de-emphasis as the recurrence it is, gain, power sum: in the reference's order
         if (pm) { b -= dc; y += deemph_rate * (deemph_gain * (double)b - y); b = (float)y; }
         const double sgn = gain * (double)b;
         part += sgn * sgn;
-        tilef[lane * LD + n] = (float)sgn;
+        return (float)sgn;
+      };
+      int n = 0;
+#if CHZ_LIN_UNROLL > 1
+      for (; n + CHZ_LIN_UNROLL <= tn; n += CHZ_LIN_UNROLL) {       // (see demod_lin_lanes: one LDS round trip per group instead of per sample)
+        float v[CHZ_LIN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < CHZ_LIN_UNROLL; u++) v[u] = tilef[lane * LD + n + u];
+#pragma unroll
+        for (int u = 0; u < CHZ_LIN_UNROLL; u++) v[u] = out_step(v[u]);
+#pragma unroll
+        for (int u = 0; u < CHZ_LIN_UNROLL; u++) tilef[lane * LD + n + u] = v[u];
       }
+#endif
+      for (; n < tn; n++) tilef[lane * LD + n] = out_step(tilef[lane * LD + n]);
+    }
     CHZ_WAVE_SYNC();
+    if (fm_s16 && tn == LIN_TILE) {                        // S16 rows leave as 8-byte words, four samples per lane (see demod_lin_lanes)
+      for (int r0 = 0; r0 < 64; r0 += 16) {
+        const int rr = r0 + (lane >> 2), n4 = (lane & 3) * 4;
+        if ((out_rows >> rr) & 1ull) {
+          const LinRow q = rows[rr];
+          const bool be = q.enc == CHZ_PCM_S16BE_K;
+          const unsigned long long w = (unsigned long long)demod_s16(tilef[rr * LD + n4], be) | ((unsigned long long)demod_s16(tilef[rr * LD + n4 + 1], be) << 16) |
+                                       ((unsigned long long)demod_s16(tilef[rr * LD + n4 + 2], be) << 32) | ((unsigned long long)demod_s16(tilef[rr * LD + n4 + 3], be) << 48);
+          *reinterpret_cast<unsigned long long*>(q.o + 2 * (t0 + n4)) = w;
+        }
+      }
+    } else
     for (int r0 = 0; r0 < 64; r0 += RPS) {
       const int rr = r0 + lane / LIN_TILE, n = lane % LIN_TILE;
       if (((out_rows >> rr) & 1ull) && n < tn) { const LinRow q = rows[rr]; demod_put(q.o, q.enc, t0 + n, tilef[rr * LD + n]); }

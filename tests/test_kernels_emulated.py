@@ -711,8 +711,14 @@ FM_CASES = [dict(), dict(threshold_extend=True, encoding=ol.PCM_F32LE), dict(dee
             dict(snr_squelch=True, squelch_tail=3, encoding=ol.PCM_F32BE)]
 
 
-@pytest.mark.parametrize("path", ["lanes", "wave"])      # demod_fm_lanes (one channel per lane) / demod_linear_tail (a wavefront per channel)
-def test_fm_demodulator_kernel(emu, monkeypatch, path):
+# every channel S16 (big- and little-endian side by side): demod_fm_lanes' last pass then packs four samples per 8-byte store (66 channels: a full wavefront of rows and a partly filled one)
+FM_S16_CASES = [dict(), dict(deemph_tc=0, encoding=ol.PCM_S16LE), dict(threshold_extend=True), dict(snr_squelch=True, squelch_tail=3, encoding=ol.PCM_S16LE),
+                dict(encoding=ol.PCM_S16LE), dict(threshold_extend=True, deemph_tc=0)] * 11
+
+
+@pytest.mark.parametrize("path,cases", [("lanes", "mixed"), ("wave", "mixed"), ("lanes", "s16")])      # demod_fm_lanes (one channel per lane) / demod_linear_tail (a wavefront per channel)
+def test_fm_demodulator_kernel(emu, monkeypatch, path, cases):
+    FM_CASES = FM_S16_CASES if cases == "s16" else globals()["FM_CASES"]
     if path == "wave":
         monkeypatch.setenv("EMU_DEMOD_WAVE", "1")
     else:
@@ -720,12 +726,12 @@ def test_fm_demodulator_kernel(emu, monkeypatch, path):
     """The FM branch of the demodulator kernel (demod_fm, src/fm.c; PLL / PL tone: test_fm_pll_and_tone_kernel) against the restated demodulator:
     carrier coming up out of the noise, a modulated stretch with a frequency offset, fading out through the squelch tail."""
     from test_oracle_vs_reference import _fm_case
-    nblk, N, fs, bt = 36, 480, 24000.0, 0.02
+    nblk, N, fs, bt = (18 if cases == "s16" else 36), 480, 24000.0, 0.02
     nch = len(FM_CASES)
     r = np.random.default_rng(5)
     bbs, powers, ests, params, oracles = [], [], [], [], []
     for i, kw in enumerate(FM_CASES):
-        bb, power = _fm_case(np.random.default_rng(200 + i), nblk, N, fs)
+        bb, power = _fm_case(np.random.default_rng(200 + i), nblk, N, fs, **({"last": 13} if cases == "s16" else {}))
         bbs.append(bb); powers.append(power); ests.append((2 * 2e-3 ** 2 / fs) * (1 + 0.1 * r.standard_normal(nblk)))
         p = ol.fm_params(**kw); params.append(p); oracles.append(ol.FmDemod(p))
     chan = (_DemodChan * nch)(); state = (_DemodState * nch)(); status = (ol.LinStatus * nch)()
