@@ -795,7 +795,8 @@ def dropin_leg(wl, ring_host, nthreads, nblocks, env, label, paced_us=0, verify=
             return out
         cg0 = cgroup_cpu()
         t0 = time.perf_counter()
-        r = subprocess.run([exe, tmp], capture_output=True, text=True, timeout=900, env=e)
+        # (a leg that hangs must cost this run minutes, not its line: 500 paced blocks take 10 s + the start of 2000 threads)
+        r = subprocess.run([exe, tmp], capture_output=True, text=True, timeout=max(180, int(3 * nblocks * BLOCKTIME) + 120), env=e)
         wall = time.perf_counter() - t0
         cg1 = cgroup_cpu()
         if r.returncode != 0:

@@ -9,6 +9,10 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5p)       # round 5: the profiles of the final tree once more (the first run's FETCH_SIZE pass died inside rocprofv3)
+    SKIP_PMC=0 timeout 900 bash scripts/gpu_profile.sh r05 > "$out/profile.txt" 2>&1
+    cat gpurun_out/r05_pmc_forward.json; cat gpurun_out/pmc_r05/retries.txt 2>/dev/null
+    ;;
   r5i)       # round 5: the HBM-streamed forward figure; pll_lanes with 4 samples per LDS round trip (A/B build)
     $B --quick --detail "$out/quick.json" > "$out/quick.head" 2> "$out/quick.err"; echo "quick rc=$?" >> "$out/rc.txt"
     python -c "import json; r=json.load(open('$out/quick.json'))['roofline']; print('pipelined', r['pipelined']['forward_us_per_block'], r['pipelined']['frac'], 'streamed', r['streamed'])"

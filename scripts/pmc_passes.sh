@@ -10,7 +10,15 @@ cd /tmp && export TMPDIR=/tmp
 # ONE lane instead (CHZ_STREAMS=1) -- no ticket is taken with one stream, the notch stays folded inside fwd_rows exactly as shipped,
 # and per-dispatch counters do not depend on how many streams the dispatches came from.  Every pass has its own time limit.
 export CHZ_STREAMS=1
-run() { name=$1; shift; timeout 240 rocprofv3 --pmc "$@" -f csv -d $R/gpurun_out/pmc_$TAG/$name -o $name -- python $R/bench.py --steps 160 --warmup 16 --min-seconds 0.05 --quick $BENCH_ARGS > $R/gpurun_out/pmc_$TAG/$name.log 2>&1; }
+# (rocprofv3 itself crashed once in a FETCH_SIZE pass of round 5 -- SIGSEGV inside its dispatch callback: a pass that fails is repeated once)
+run() {
+  name=$1; shift
+  for attempt in 1 2; do
+    rm -rf $R/gpurun_out/pmc_$TAG/$name
+    timeout 240 rocprofv3 --pmc "$@" -f csv -d $R/gpurun_out/pmc_$TAG/$name -o $name -- python $R/bench.py --steps 160 --warmup 16 --min-seconds 0.05 --quick $BENCH_ARGS > $R/gpurun_out/pmc_$TAG/$name.log 2>&1 && break
+    echo "pmc pass $name: attempt $attempt failed (rc $?)" >> $R/gpurun_out/pmc_$TAG/retries.txt
+  done
+}
 mkdir -p $R/gpurun_out/pmc_$TAG
 BENCH_ARGS="$@"
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
