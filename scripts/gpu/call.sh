@@ -9,6 +9,21 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5q)       # round 5: does the demodulator stream's own hardware queue cost the synchronous PCIe probes a late block now and then?  3 x 3 probes of 500 blocks per setting
+    PC="--no-crt --no-dropin --no-dropin-paced --no-cpu-baseline --no-next-rows"
+    for rep in 1 2 3; do
+      for q in 0 1; do
+        CHZ_OWN_QUEUES=$q BENCH_NO_STREAMED=1 timeout 200 $B $PC --detail "$out/pcie_q${q}_$rep.json" > /dev/null 2>> "$out/err.txt"
+      done
+    done
+    python - "$out" <<'PY'
+import json, sys, glob, os
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/pcie_*.json")):
+    d = json.load(open(f))
+    print(os.path.basename(f), [(x["channels"], round(x["worst_block_ms"], 2), round(x["mean_block_ms"], 2), x.get("blocks_over_20ms"), round(x.get("p99_block_ms") or 0, 2)) if "error" not in x else x for x in d["c_rt_pcie"]])
+PY
+    ;;
   r5p)       # round 5: the profiles of the final tree once more (the first run's FETCH_SIZE pass died inside rocprofv3)
     SKIP_PMC=0 timeout 900 bash scripts/gpu_profile.sh r05 > "$out/profile.txt" 2>&1
     cat gpurun_out/r05_pmc_forward.json; cat gpurun_out/pmc_r05/retries.txt 2>/dev/null
