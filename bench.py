@@ -1400,7 +1400,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_crt_pcie and config == 3:
         t_leg = time.perf_counter()
         crt_pcie = []
-        for n, dm, pipe in ((460_800, False, False), (1_320_960, True, False), (1_428_480, True, True)):
+        probes = ((460_800, False, False), (1_320_960, True, False), (1_428_480, True, True))
+        if os.environ.get("BENCH_PCIE_PROBES"):              # (scripts: only some of the probes, by index)
+            probes = tuple(probes[int(i)] for i in os.environ["BENCH_PCIE_PROBES"].split(","))
+        for n, dm, pipe in probes:
             progress("c_rt_pcie %d channels demod=%s pipelined=%s" % (n, dm, pipe))
             try:
                 crt_pcie.append(crt_pcie_leg(pkg, wl, n, args.crt_pcie_blocks, dm, dev_index, pipe))

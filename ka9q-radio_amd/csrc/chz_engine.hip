@@ -306,11 +306,12 @@ int chz_gather_descriptor(int in_type, int master_bins, int P, int shift, int ou
 static int tail_cus() { static const int n = [] { const char* v = getenv("CHZ_TAIL_CUS"); const int k = v ? atoi(v) : 0; return (k > 0 && k < 256) ? k : 0; }(); return n; }
 // CHZ_OWN_QUEUES: 0 plain streams everywhere (rounds 1-4), 1 (default) the demodulator stream only -- the one stream beyond the runtime's
 // four queues --, 2 every stream the engine launches kernels on
-static int own_queues() { static const int m = [] { const char* v = getenv("CHZ_OWN_QUEUES"); const int k = v ? atoi(v) : 1; return (k >= 0 && k <= 2) ? k : 1; }(); return m; }
+// (3: experiment -- the demodulator stream and the PCM copy stream)
+static int own_queues() { static const int m = [] { const char* v = getenv("CHZ_OWN_QUEUES"); const int k = v ? atoi(v) : 1; return (k >= 0 && k <= 3) ? k : 1; }(); return m; }
 static hipError_t stream_create_masked(hipStream_t* s, bool tail) {
 #ifndef HIPEMU
   const int n = tail_cus();
-  if (n > 0 || own_queues() == 2 || (own_queues() == 1 && tail)) {
+  if (n > 0 || own_queues() == 2 || (own_queues() == 1 && tail) || (own_queues() == 3 && tail)) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 && cus <= 1024) {
       uint32_t mask[32] = {};
@@ -1773,7 +1774,7 @@ int chz_bank_read_pcm_flags_async(chz_engine* e, int bank, int slot, int ch0, in
   Bank& b = e->banks[(size_t)bank];
   if (!b.dm_chan) return fail(-1, "bank has no demodulator: call chz_bank_set_demod first");
   const size_t so = (size_t)slot * b.cap + ch0, stride = (size_t)b.pcm_stride;
-  if (!e->pcmcopy) HIPOK(hipStreamCreateWithFlags(&e->pcmcopy, hipStreamNonBlocking));
+  if (!e->pcmcopy) { if (own_queues() == 3) HIPOK(stream_create_masked(&e->pcmcopy, true)); else HIPOK(hipStreamCreateWithFlags(&e->pcmcopy, hipStreamNonBlocking)); }
   HIPOK(hipEventRecord(b.ev_pcmgo[slot], e->tail));                 // behind the slot's demodulator kernel (and whatever else is queued there)
   HIPOK(hipStreamWaitEvent(e->pcmcopy, b.ev_pcmgo[slot], 0));
   if (pcm) HIPOK(hipMemcpyAsync(pcm, b.dm_pcm + so * stride, stride * (size_t)n, hipMemcpyDeviceToHost, e->pcmcopy));

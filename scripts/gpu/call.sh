@@ -9,6 +9,24 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5r)       # round 5: the double-buffered PCIe probe (mean period 13.3 ms with plain streams, 16.8 with the demodulator stream on its own queue) and the chain, per queue mode
+    PC="--no-crt --no-dropin --no-dropin-paced --no-cpu-baseline --no-next-rows"
+    NR="--no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear"
+    for q in 0 1 3 2; do
+      CHZ_OWN_QUEUES=$q BENCH_PCIE_PROBES=2 BENCH_NO_STREAMED=1 timeout 200 $B $PC --detail "$out/pcie_q${q}.json" > /dev/null 2>> "$out/err.txt"
+      CHZ_OWN_QUEUES=$q BENCH_NO_STREAMED=1 timeout 200 $B $NR --detail "$out/chain_q${q}.json" > /dev/null 2>> "$out/err.txt"
+    done
+    python - "$out" <<'PY'
+import json, sys, glob, os
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/pcie_*.json")):
+    d = json.load(open(f))
+    print(os.path.basename(f), [(x["channels"], round(x["worst_block_ms"], 2), round(x["mean_block_ms"], 2), x.get("blocks_over_20ms"), round(x.get("p99_block_ms") or 0, 2)) if "error" not in x else x for x in d["c_rt_pcie"]])
+for f in sorted(glob.glob(out + "/chain_*.json")):
+    j = json.load(open(f))
+    print(os.path.basename(f), [(x.get("mode"), round(x.get("pipelined_ms_per_block", 0), 3), x.get("pcm_mismatches")) if "error" not in x else x for x in (j.get("next_rows") or [])])
+PY
+    ;;
   r5q)       # round 5: does the demodulator stream's own hardware queue cost the synchronous PCIe probes a late block now and then?  3 x 3 probes of 500 blocks per setting
     PC="--no-crt --no-dropin --no-dropin-paced --no-cpu-baseline --no-next-rows"
     for rep in 1 2 3; do
