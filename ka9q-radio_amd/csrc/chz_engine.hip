@@ -295,23 +295,25 @@ int chz_gather_descriptor(int in_type, int master_bins, int P, int shift, int ou
   return 0;
 }
 
-// The demodulator stream gets a HARDWARE QUEUE OF ITS OWN (round 5).  The runtime deals plain streams onto its
-// GPU_MAX_HW_QUEUES (4) hardware queues round-robin, so a fifth stream -- the demodulators' -- shares a queue with a transform lane and the
-// two take turns: measured at 1.5 M channels, the SURVEY 8f chain takes 4.40-4.61 ms per block that way and 4.12-4.15 ms when every
-// stream has its own queue (GPU_MAX_HW_QUEUES=8 in the environment: 4.12-4.23).  A library cannot set that variable (the runtime may be
-// up already); what it can do is create its streams through hipExtStreamCreateWithCUMask with EVERY compute unit enabled -- such a
-// stream is given a queue of its own.  The transform lanes keep plain streams: they are exactly the four the runtime has queues for.
+// The demodulator stream and the PCM copy stream get HARDWARE QUEUES OF THEIR OWN (round 5).  The runtime deals plain streams onto its
+// GPU_MAX_HW_QUEUES (4) hardware queues round-robin, so the streams beyond the four transform lanes share a queue with a lane and take
+// turns with it.  Measured at 1.5 M channels (profiles/r05_chain_queues.txt): the SURVEY 8f chain 4.40-4.61 ms per block with plain
+// streams, 4.12-4.28 ms with the demodulator stream on its own queue; and with the host link in the loop (1.43 M channels of S16 PCM,
+// double-buffered host loop) the time between two completions 13.25 ms mean / 16.9 worst with plain streams, 17.0 / 17.9 with only the
+// demodulator stream moved (its copies then queue up behind a lane), 12.1 / 12.7 with the PCM copy stream moved as well.  A library
+// cannot set GPU_MAX_HW_QUEUES (the runtime may be up already); what it can do is create these streams through
+// hipExtStreamCreateWithCUMask with EVERY compute unit enabled -- such a stream is given a queue of its own.  The transform lanes keep
+// plain streams: they are exactly the four the runtime has queues for (with every stream masked one driver-command bench run hung).
 // EXPERIMENT knob on top: CHZ_TAIL_CUS=n gives the demodulator stream n of the compute units to itself (spread
 // evenly over the XCDs) and the transform lanes the others -- the partition itself buys nothing (4.20-4.33 ms), see the decision record.
 static int tail_cus() { static const int n = [] { const char* v = getenv("CHZ_TAIL_CUS"); const int k = v ? atoi(v) : 0; return (k > 0 && k < 256) ? k : 0; }(); return n; }
-// CHZ_OWN_QUEUES: 0 plain streams everywhere (rounds 1-4), 1 (default) the demodulator stream only -- the one stream beyond the runtime's
-// four queues --, 2 every stream the engine launches kernels on
-// (3: experiment -- the demodulator stream and the PCM copy stream)
-static int own_queues() { static const int m = [] { const char* v = getenv("CHZ_OWN_QUEUES"); const int k = v ? atoi(v) : 1; return (k >= 0 && k <= 3) ? k : 1; }(); return m; }
+// CHZ_OWN_QUEUES: 0 plain streams everywhere (rounds 1-4), 1 (default) the demodulator stream and the PCM copy stream, 2 every stream the
+// engine launches kernels on
+static int own_queues() { static const int m = [] { const char* v = getenv("CHZ_OWN_QUEUES"); const int k = v ? atoi(v) : 1; return (k >= 0 && k <= 2) ? k : 1; }(); return m; }
 static hipError_t stream_create_masked(hipStream_t* s, bool tail) {
 #ifndef HIPEMU
   const int n = tail_cus();
-  if (n > 0 || own_queues() == 2 || (own_queues() == 1 && tail) || (own_queues() == 3 && tail)) {
+  if (n > 0 || own_queues() == 2 || (own_queues() == 1 && tail)) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 && cus <= 1024) {
       uint32_t mask[32] = {};
@@ -1774,7 +1776,7 @@ int chz_bank_read_pcm_flags_async(chz_engine* e, int bank, int slot, int ch0, in
   Bank& b = e->banks[(size_t)bank];
   if (!b.dm_chan) return fail(-1, "bank has no demodulator: call chz_bank_set_demod first");
   const size_t so = (size_t)slot * b.cap + ch0, stride = (size_t)b.pcm_stride;
-  if (!e->pcmcopy) { if (own_queues() == 3) HIPOK(stream_create_masked(&e->pcmcopy, true)); else HIPOK(hipStreamCreateWithFlags(&e->pcmcopy, hipStreamNonBlocking)); }
+  if (!e->pcmcopy) HIPOK(stream_create_masked(&e->pcmcopy, true));      // (own hardware queue unless CHZ_OWN_QUEUES=0: see stream_create_masked)
   HIPOK(hipEventRecord(b.ev_pcmgo[slot], e->tail));                 // behind the slot's demodulator kernel (and whatever else is queued there)
   HIPOK(hipStreamWaitEvent(e->pcmcopy, b.ev_pcmgo[slot], 0));
   if (pcm) HIPOK(hipMemcpyAsync(pcm, b.dm_pcm + so * stride, stride * (size_t)n, hipMemcpyDeviceToHost, e->pcmcopy));

@@ -9,6 +9,14 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5s)       # round 5, last validation: the GPU suite + smoke and the driver's command on the final tree (demodulator + PCM copy streams on their own queues)
+    timeout 420 $B > "$out/bench_stdout.txt" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/rc.txt"
+    tail -n 1 "$out/bench_stdout.txt" > "$out/bench_headline.json"; cp gpurun_out/bench_detail.json "$out/bench_detail.json" 2>/dev/null
+    wc -c "$out/bench_headline.json"; grep "^bench.py \[" "$out/bench.err" | tail -2
+    timeout 600 python -m pytest tests -m gpu -q --timeout 400 > "$out/gpu_suite.txt" 2>&1; echo "suite rc=$?" >> "$out/rc.txt"
+    tail -4 "$out/gpu_suite.txt"
+    timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.txt" 2>&1; tail -1 "$out/smoke.txt"
+    ;;
   r5r)       # round 5: the double-buffered PCIe probe (mean period 13.3 ms with plain streams, 16.8 with the demodulator stream on its own queue) and the chain, per queue mode
     PC="--no-crt --no-dropin --no-dropin-paced --no-cpu-baseline --no-next-rows"
     NR="--no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear"
