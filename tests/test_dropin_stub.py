@@ -307,6 +307,39 @@ def test_dropin_replaces_a_failed_engine_and_carries_on(tmp_path, san, retune):
             assert err <= 1e-5 * rms + 2e-8 * float(np.abs(s64).max()), (b, i, err, rms)
 
 
+def test_dropin_sharded_master_replaces_its_engines_when_one_device_fails(tmp_path):
+    """KA9Q_HIP_DEVICES with a failure: one of the two (stand-in) devices reports a failed check from block 5 on.  The block is published
+    by the LAST device's callback, so the healthy device's results of a failed block must not be handed out: every slave -- on either
+    device -- gets zeros and a counted drop for the blocks the failure cost, BOTH engines are replaced once, and the stream is exact again."""
+    if not _have("-fsanitize=thread"):
+        pytest.skip("no -fsanitize=thread runtime in this image")
+    nblocks, nch = 16, 20
+    r, run_dir, x, plan = _recovery_run(tmp_path, "thread", {"CHZ_STUB_FAIL_JOB": "5", "CHZ_STUB_DEVICES": "2", "KA9Q_HIP_DEVICES": "0,1", "KA9Q_HIP_SHARD_CHANNELS": "10"}, nblocks, nch)
+    assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    assert r.stderr.count("re-creating the engine") == 1, r.stderr[-2000:]
+    L, M, olen, P = 25920, 6481, 240, 300
+    N = L + M - 1
+    out = np.fromfile(os.path.join(run_dir, "out.bin"), np.complex64).reshape(nblocks, nch, olen)
+    dropped = np.fromfile(os.path.join(run_dir, "dropped.bin"), np.uint8).reshape(nblocks, nch).astype(bool)
+    meta = open(os.path.join(run_dir, "meta.txt")).read().split()
+    meta = dict(zip(meta[::2], meta[1::2]))
+    assert int(meta["clock"]) == nblocks and int(meta["devices"]) == 2 and meta["dev_counts"] == "10:10"
+    lost = np.flatnonzero(dropped.all(axis=1))
+    assert 1 <= len(lost) <= 8 and lost[0] >= 5 and np.array_equal(lost, np.arange(lost[0], lost[0] + len(lost))), lost
+    assert int(meta["drops"]) == int(dropped.sum()) and len(lost) * nch <= dropped.sum() <= (len(lost) + 3) * nch
+    st = ol.Stream(L, M, ol.REAL)
+    for b in range(nblocks):
+        s64 = st.push(x[b * L:(b + 1) * L], f64=True)
+        for i, p in enumerate(plan):
+            if dropped[b, i]:
+                assert not out[b, i].any()
+                continue
+            want = ol.channel(s64, ol.REAL, P, olen, p[0], ol.set_filter(P, olen, N, True, p[4], p[5], p[6]))
+            err = float(np.sqrt(np.mean(np.abs(out[b, i] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+            assert err <= 1e-5 * rms + 2e-8 * float(np.abs(s64).max()), (b, i, err, rms)
+
+
 def test_dropin_second_failure_exits_for_the_supervisor(tmp_path):
     """... and if the replacement fails as well (within 500 blocks), the process ends with EX_SOFTWARE (70) -- the reference's own answer
     to a fatal front-end / FFT error (src/radio.c:398, src/main.c:202): systemd restarts radiod."""
