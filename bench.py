@@ -1400,7 +1400,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_crt_pcie and config == 3:
         t_leg = time.perf_counter()
         crt_pcie = []
-        probes = ((460_800, False, False), (1_320_960, True, False), (1_428_480, True, True))
+        nb = int(os.environ.get("BENCH_PCIE_PIPELINED_CHANNELS", "1428480"))     # (scripts: the double-buffered probe at another size)
+        probes = ((460_800, False, False), (1_320_960, True, False), (nb, True, True))
         if os.environ.get("BENCH_PCIE_PROBES"):              # (scripts: only some of the probes, by index)
             probes = tuple(probes[int(i)] for i in os.environ["BENCH_PCIE_PROBES"].split(","))
         for n, dm, pipe in probes:

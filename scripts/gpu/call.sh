@@ -9,6 +9,19 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r5t)       # round 5: how many channels the double-buffered PCIe probe carries now that its period is D2H-bound (12.1 ms at 1.43 M)
+    PC="--no-crt --no-dropin --no-dropin-paced --no-cpu-baseline --no-next-rows"
+    for n in 1800000 1950000 2050000; do
+      BENCH_PCIE_PROBES=2 BENCH_PCIE_PIPELINED_CHANNELS=$n BENCH_NO_STREAMED=1 timeout 200 $B $PC --detail "$out/pcie_$n.json" > /dev/null 2>> "$out/err.txt"
+    done
+    python - "$out" <<'PY'
+import json, sys, glob, os
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/pcie_*.json")):
+    d = json.load(open(f))
+    print(os.path.basename(f), [(x["channels"], round(x["worst_block_ms"], 2), round(x["mean_block_ms"], 2), x.get("blocks_over_20ms"), round(x.get("p99_block_ms") or 0, 2), round(x.get("worst_latency_ms") or 0, 1), x.get("pcm_mismatches"), round(x.get("d2h_GBps") or 0, 1)) if "error" not in x else x for x in d["c_rt_pcie"]])
+PY
+    ;;
   r5s)       # round 5, last validation: the GPU suite + smoke and the driver's command on the final tree (demodulator + PCM copy streams on their own queues)
     timeout 420 $B > "$out/bench_stdout.txt" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/rc.txt"
     tail -n 1 "$out/bench_stdout.txt" > "$out/bench_headline.json"; cp gpurun_out/bench_detail.json "$out/bench_detail.json" 2>/dev/null
