@@ -218,3 +218,54 @@ def test_bench_two_ranks_control_flow_on_one_gpu(args, port, tmp_path):
     assert abs(j["value"] - 2 * per_rank * 0.02 / (j["ms_per_step"] * 1e-3)) <= 1e-6 * j["value"]
     if "--no-crt" not in args:
         assert j["c_rt"]["gpus"] == 2 and j["c_rt"]["channels"] >= 2 * 1490000 and j["c_rt"]["blocks"] == 12
+
+
+class _FakeBank:
+    def __init__(self):
+        self.active = 0
+
+    def set_responses(self, c0, resp): pass
+    def set_shifts(self, c0, shifts): pass
+    def set_active(self, n): self.active = n
+    def destroy(self): pass
+
+
+class _FakeEng:
+    def __init__(self):
+        self.b = _FakeBank()
+
+    def bank(self, P, olen, n, shared_rows=0):
+        self.cap = n
+        return self.b
+
+
+@pytest.mark.parametrize("ns_per_channel,spike_at", [(0.93, None), (1.30, None), (0.93, 20_100_000), (2.4, None)])
+def test_crt_search_decisions_on_a_modelled_device(ns_per_channel, spike_at):
+    """bench.crt_leg's search (no GPU): a device whose block takes 0.4 ms + ns_per_channel x channels, optionally with one late block per
+    rung above a channel count.  The search must report the largest grid count whose every block stays inside 20 ms -- stepping UP from
+    its first rung on a fast device, DOWN on a slow one (never 'nothing sustained'), taking the bisection step -- and a mean-crossing
+    count within 1 % of the model's."""
+    import importlib.util
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    import __graft_entry__ as ge
+    pkg = ge.load()
+    eng = _FakeEng()
+    wl = b.workload_for(3, 0, 1, 0)
+    calls = {"n": 0}
+
+    def run_one(job):
+        calls["n"] += 1
+        n = eng.b.active + wl["nch"]
+        ms = 0.4 + ns_per_channel * 1e-6 * n
+        if spike_at and n > spike_at and calls["n"] % 97 == 0:
+            ms += 3.0
+        return ms
+    r = b.crt_leg(pkg, eng, wl, None, 120, run_one, verify=0)
+    true_cross = (20.0 - 0.4) / (ns_per_channel * 1e-6)
+    assert r["sustained"] is True and r["channels"] > 0 and r["worst_block_ms"] <= 20.0
+    assert abs(r["mean_crossing_channels"] - true_cross) <= 0.01 * true_cross
+    limit = min(true_cross, spike_at or 1e18, eng.cap + wl["nch"])
+    assert r["channels"] <= limit and r["channels"] >= limit - 270_000 - 3072, (r["channels"], limit)     # within one 0.25 M grid step of the truth
+    assert len(r["calibration"]) == 2 and 1 <= r["rungs"] <= 14
