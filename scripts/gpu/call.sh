@@ -279,7 +279,7 @@ PY
     ;;
   chainpmc)  # SQ counters for the 8f chain's kernels at 1.5 M channels (linear leg only: chan_ifft<EPI 1>, noise_est, demod_lin_lanes), one --pmc set per pass
     R=$PWD; cd /tmp
-    run() { n=$1; shift; CHZ_NOTCH_ORDER=event timeout 140 rocprofv3 --pmc "$@" -f csv -d $R/$out/$n -o $n -- python $R/bench.py --steps 5 --warmup 2 --min-seconds 0.02 --no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear > $R/$out/$n.log 2>&1; echo "$n rc=$?" >> $R/$out/rc.txt; }
+    run() { n=$1; shift; CHZ_NOTCH_ORDER=event timeout 400 rocprofv3 --pmc "$@" -f csv -d $R/$out/$n -o $n -- python $R/bench.py --steps 5 --warmup 2 --min-seconds 0.02 --no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear > $R/$out/$n.log 2>&1; echo "$n rc=$?" >> $R/$out/rc.txt; }
     run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
     run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU
     cd $R
