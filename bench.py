@@ -837,6 +837,7 @@ def dropin_leg(wl, ring_host, nthreads, nblocks, env, label, paced_us=0, verify=
                 pv[k] = float(v)
             except ValueError:
                 pass
+    first_blocks = [ln for ln in r.stderr.splitlines() if ln.startswith("filter_hip first blocks:")]
     el = float(m["elapsed_s"])
     paced = None
     if paced_us and lat is not None:
@@ -885,6 +886,8 @@ def dropin_leg(wl, ring_host, nthreads, nblocks, env, label, paced_us=0, verify=
                             "throttled_ms_during_the_leg": (cg1.get("throttled_usec", cg1.get("throttled_time", 0)) - cg0.get("throttled_usec", cg0.get("throttled_time", 0))) / 1e3,
                             # CPU seconds the container used per second of the leg (the quota is cpu.max's first number / its second)
                             "cpus_used_mean": round((cg1.get("usage_usec", 0) - cg0.get("usage_usec", 0)) / 1e6 / wall, 2) if wall > 0 and "usage_usec" in cg1 else None},
+            "first_blocks_profile": first_blocks[-1][len("filter_hip first blocks:"):].strip() if first_blocks else None,
+            "first_8_blocks_latency_ms": [round(float(v) / 1e6, 3) for v in lat[:8, 0]] if lat is not None else None,
             "process_wall_s": wall}
 
 

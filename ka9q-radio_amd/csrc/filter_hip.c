@@ -168,6 +168,8 @@ struct mctx {
   unsigned long long prof_consume_max8_ns;   /* the same worst case over blocks 8.. only (the first blocks carry one-time costs: first touch of every
                                                 slave's buffers, thread start-up, the runtime's first launches) */
   unsigned t_done_job[ND];
+  unsigned long long prof_first_dev_ns[8], prof_first_input_ns[8], prof_first_consume_ns[8];   /* blocks 0..7 one by one: enqueue -> callback; time inside execute_filter_input; the slowest slave's completion -> output in hand */
+  unsigned prof_first_hits[8], prof_first_misses[8];
   /* channels whose staged result does not fit (retuned, new filter, just created) are re-run in batches: the first
      thread to miss becomes the leader and serves everybody who queued up meanwhile with one device round trip */
   pthread_mutex_t miss_lock;
@@ -363,6 +365,7 @@ static void block_done(void *arg) {
     __atomic_store_n(&c->t_done_ns[slot], (long long)t1.tv_sec * 1000000000LL + t1.tv_nsec, __ATOMIC_RELAXED);
     __atomic_store_n(&c->t_done_job[slot], job, __ATOMIC_RELAXED);
     if (job >= 8 && (unsigned long long)ns > c->prof_dev_max_ns) c->prof_dev_max_ns = (unsigned long long)ns;   /* the first blocks carry one-time set-up */
+    if (job < 8) c->prof_first_dev_ns[job] = (unsigned long long)ns;
   }
   /* src/filter.c:544-552; before the block is announced: a caller that has seen its last block may read them (src/main.c:155-163) */
   if (ns > __atomic_load_n(&Max_fft_time, __ATOMIC_RELAXED)) __atomic_store_n(&Max_fft_time, ns, __ATOMIC_RELAXED);
@@ -685,6 +688,13 @@ int delete_filter_input(struct filter_in *master) {
               c->prof_blocks, c->prof_input_ns / 1e3 / c->prof_blocks, c->prof_wait_ns / 1e3 / c->prof_blocks,
               c->prof_consume_n ? c->prof_consume_sum_ns / 1e3 / c->prof_consume_n : 0.0, c->prof_consume_max_ns / 1e3, c->prof_consume_n,
               c->prof_hits, c->prof_misses, c->n_skipped, c->prof_dev_max_ns / 1e3, c->prof_consume_max8_ns / 1e3, c->recoveries, c->failed_blocks);
+    if (c->profile && c->prof_blocks) {
+      fprintf(stderr, "filter_hip first blocks:");
+      for (int j = 0; j < 8 && (unsigned long long)j < c->prof_blocks; j++)
+        fprintf(stderr, " [%d dev_us=%.0f input_us=%.0f consume_worst_us=%.0f hits=%u misses=%u]", j, c->prof_first_dev_ns[j] / 1e3, c->prof_first_input_ns[j] / 1e3,
+                c->prof_first_consume_ns[j] / 1e3, c->prof_first_hits[j], c->prof_first_misses[j]);
+      fprintf(stderr, "\n");
+    }
     if (c->ring_pinned) chz_host_unregister(master->input_buffer);
     for (int g = 0; g < c->nsh; g++) chz_engine_destroy(c->sh[g].eng);
     mctx_free(c);
@@ -1111,6 +1121,7 @@ int execute_filter_input(struct filter_in *const f) {
   }
   if (c->profile) {
     struct timespec tp2; clock_gettime(CLOCK_MONOTONIC, &tp2);
+    if (c->prof_blocks < 8) c->prof_first_input_ns[c->prof_blocks] = (unsigned long long)((tp2.tv_sec - tp0.tv_sec) * 1000000000LL + (tp2.tv_nsec - tp0.tv_nsec));
     c->prof_blocks++;
     c->prof_input_ns += (unsigned long long)((tp2.tv_sec - tp0.tv_sec) * 1000000000LL + (tp2.tv_nsec - tp0.tv_nsec));
     c->prof_wait_ns += (unsigned long long)((tp1.tv_sec - tp0.tv_sec) * 1000000000LL + (tp1.tv_nsec - tp0.tv_nsec));
@@ -1337,6 +1348,10 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
           __atomic_fetch_add(&c->prof_consume_n, 1ull, __ATOMIC_RELAXED);
           unsigned long long mx = __atomic_load_n(&c->prof_consume_max_ns, __ATOMIC_RELAXED);
           while ((unsigned long long)ns > mx && !__atomic_compare_exchange_n(&c->prof_consume_max_ns, &mx, (unsigned long long)ns, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+          if (job < 8 && __atomic_load_n(&c->t_done_job[slot], __ATOMIC_RELAXED) == job) {
+            mx = __atomic_load_n(&c->prof_first_consume_ns[job], __ATOMIC_RELAXED);
+            while ((unsigned long long)ns > mx && !__atomic_compare_exchange_n(&c->prof_first_consume_ns[job], &mx, (unsigned long long)ns, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
+          }
           if (job >= 8 && __atomic_load_n(&c->t_done_job[slot], __ATOMIC_RELAXED) == job) {
             mx = __atomic_load_n(&c->prof_consume_max8_ns, __ATOMIC_RELAXED);
             while ((unsigned long long)ns > mx && !__atomic_compare_exchange_n(&c->prof_consume_max8_ns, &mx, (unsigned long long)ns, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
@@ -1344,6 +1359,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
         }
       }
       __atomic_fetch_add(hit ? &c->prof_hits : &c->prof_misses, 1ull, __ATOMIC_RELAXED);
+      if (job < 8) __atomic_fetch_add(hit ? &c->prof_first_hits[job] : &c->prof_first_misses[job], 1u, __ATOMIC_RELAXED);
     }
     if (hit) return 0;
     /* a block the PREVIOUS engine completed, asked for after that engine was replaced: its staged results were invalidated and its

@@ -9,6 +9,15 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r6a)       # round 6, first call: block 0 of the FIRST drop-in process on a fresh box (before anything else touches the GPU); the reference's own
+             # callers on the drop-in (mini-radiod, tests/test_mini_radiod.py); is a CU-masked stream a blocking stream? (scripts/micro/masked_stream_blocking.hip)
+    timeout 300 python scripts/block0_probe.py 150 > "$out/block0_probe.jsonl" 2> "$out/block0_probe.err"; echo "block0 rc=$?" >> "$out/rc.txt"
+    cat "$out/block0_probe.jsonl"
+    timeout 600 python -m pytest tests/test_mini_radiod.py -m gpu -q -s --timeout 300 > "$out/mini_radiod.txt" 2>&1; echo "mini_radiod rc=$?" >> "$out/rc.txt"
+    tail -12 "$out/mini_radiod.txt"
+    timeout 60 ./scripts/micro/masked_stream_blocking.bin > "$out/masked_stream_blocking.txt" 2>&1; echo "masked rc=$?" >> "$out/rc.txt"
+    cat "$out/masked_stream_blocking.txt"; cat "$out/rc.txt"
+    ;;
   r5t)       # round 5: how many channels the double-buffered PCIe probe carries now that its period is D2H-bound (12.1 ms at 1.43 M)
     PC="--no-crt --no-dropin --no-dropin-paced --no-cpu-baseline --no-next-rows"
     for n in 1800000 1950000 2050000; do

@@ -1,0 +1,129 @@
+"""The reference's OWN callers -- radio.c (downconvert, set_channel_filter, demod_thread ...), linear.c (demod_linear), fm.c (demod_fm),
+compiled unmodified from /root/reference/src -- running on the drop-in, A/B against the same objects on the reference's filter.c.
+
+north_star: "drops in behind ka9q-radio's existing filter.h API ... so radiod, linear.c and fm.c are untouched".  tests/c/mini_radiod.c
+says what is the reference's and what is stubbed; tests/c/Makefile links it twice from ONE set of caller objects:
+    oracle/_ref/mini_radiod_ref        + the reference's filter.c (+ the oracle's float64 FFT provider)     -- the checker
+    tests/c/_prebuilt/mini_radiod_hip  + libka9q_filter_hip.so -> libchz_hip.so (the hand-written kernels)  -- the product
+Both are built by __graft_entry__.build() where /root/reference exists and travel to the GPU box.
+
+CPU tier: the checker link runs and the channel table does what it is meant to (squelch closed on empty channels, PL tone found, PLL
+locks, filter2 = 4 decimates the frame rate, commands land); the SAME callers on the drop-in's host code over the CPU stand-in engine
+(tests/stub/chz_stub.cpp) equal the reference link -- the drop-in's host logic under the reference's own call sequence, no GPU.
+GPU tier: the product link on the MI355X against the checker link, the bar of the round-5 review:
+frame kinds / mute flags / squelch / timestamps / bin shifts / block_drops identical, float PCM <= 1e-5 rel-L2, int16 PCM <= 1 LSB on
+<= 0.1 % of the samples, sig.n0 and bb_power within 1e-5."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import mini_radiod_lib as mr
+import oracle_lib as ol
+
+ROOT = mr.ROOT
+REF_SRC = "/root/reference/src"
+FS, L, M, NBLOCKS = 1.296e6, 25920, 6481, 30        # N = 32,400: 40 Hz bins, 20 ms blocks, overlap 5
+
+needs_ref_exe = pytest.mark.skipif(not os.path.exists(mr.REF_EXE), reason="oracle/_ref/mini_radiod_ref not built (needs /root/reference at build time)")
+
+
+def _kinds(frames):
+    return "".join("N" if f["isnull"] else "M" if f["mute"] else "D" for f in frames)
+
+
+def _reference_run(tmp, channels, x, nblocks=NBLOCKS):
+    return mr.run(mr.REF_EXE, os.path.join(tmp, "ref"), channels, x, FS, L, M, nblocks)
+
+
+@needs_ref_exe
+def test_reference_callers_on_the_reference_filter(tmp_path):
+    """the checker link on its own: every channel thread runs its lifetime down and cleans up through close_chan(), the front end is
+    shut down by the last one, and the channel table exercises what it claims to"""
+    ch = mr.standard_channels()
+    x = mr.synthesise(ch, FS, L, NBLOCKS)
+    fr, meta, _ = _reference_run(str(tmp_path), ch, x)
+    assert int(meta["channels"]) == 48 and int(meta["master_jobs"]) == NBLOCKS and int(meta["shutdowns"]) == 1 and int(meta["commands"]) == 5
+    by = {c.ssrc: c for c in ch}
+    for ssrc, F in fr.items():
+        c = by[ssrc]
+        assert all(f["block_drops"] == 0 for f in F)
+        assert len(F) == (NBLOCKS // 4 if c.preset in ("cwu", "cwl") else NBLOCKS), (ssrc, c.preset, len(F))      # filter2 = 4: one frame per 4 blocks
+        assert [f["next_jobnum"] for f in F] == ([4 * (i + 1) for i in range(len(F))] if c.preset in ("cwu", "cwl") else list(range(1, NBLOCKS + 1)))
+    assert _kinds(fr[142]) == "N" * NBLOCKS and _kinds(fr[107]) == "N" * NBLOCKS       # FM / PM on noise: squelch never opens
+    assert _kinds(fr[116]) == "N" * NBLOCKS and fr[116][-1]["pll_lock"] == 0           # SAM on noise: no lock
+    assert fr[104][-1]["pll_lock"] == 1 and _kinds(fr[104]).endswith("DDDDDDDDDD")     # SAM on a carrier: locked, open
+    assert fr[110][-1]["pll_lock"] == 1                                                  # AME
+    k = _kinds(fr[118]); assert k.startswith("NNNNNNNNNNNN") and k.endswith("DD")       # PL tone present: opens after the 240 ms integration
+    assert _kinds(fr[130]) == "N" * NBLOCKS                                             # PL tone absent: stays shut
+    assert fr[105][0]["channels"] == 2 and fr[105][0]["nfloat"] == 480                   # ISB: stereo frames out of filter2
+    a, b = fr[100][8], fr[100][10]
+    assert a["tune_freq"] != b["tune_freq"] and b["bin_shift"] == a["bin_shift"] + 3    # the retune moved 3 bins (+ 11 Hz of remainder)
+    assert fr[100][9]["remainder"] != fr[100][10]["remainder"]
+
+
+def _build_stub_link(out_dir):
+    """the drop-in's host code (filter_hip.c, unmodified) over the CPU stand-in for libchz_hip.so, and mini-radiod's caller objects on it"""
+    ol.build()
+    stub = os.path.join(ROOT, "tests", "stub")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", os.path.join(stub, "chz_stub.cpp"), "-o", os.path.join(out_dir, "libchz_hip.so"),
+                    "-L", os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread"], check=True)
+    subprocess.run(["gcc", "-O2", "-g", "-std=gnu11", "-fPIC", "-shared", os.path.join(ROOT, "ka9q-radio_amd", "csrc", "filter_hip.c"), "-o",
+                    os.path.join(out_dir, "libka9q_filter_hip.so"), "-L", out_dir, "-lchz_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"], check=True)
+    exe = os.path.join(out_dir, "mini_radiod_stub")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), "LIBDIR=" + out_dir, "OUT_HIP=" + exe, exe], check=True)
+    return exe
+
+
+@needs_ref_exe
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="/root/reference absent: the caller objects cannot be linked here")
+def test_reference_callers_on_the_dropin_host_code_over_the_cpu_stand_in(tmp_path):
+    exe = _build_stub_link(str(tmp_path))
+    ch = mr.standard_channels()
+    x = mr.synthesise(ch, FS, L, NBLOCKS)
+    A, _, _ = _reference_run(str(tmp_path), ch, x)
+    B, meta, _ = mr.run(exe, str(tmp_path / "got"), ch, x, FS, L, M, NBLOCKS)
+    assert int(meta["commands"]) == 5 and int(meta["shutdowns"]) == 1
+    s = mr.compare(A, B, float_tol=1e-6, n0_tol=1e-9)       # the stand-in computes with the oracle's float64 transforms: nothing but rounding order differs
+    assert s["data"] > 1000 and s["null"] > 100, s
+
+
+def _hip_exe():
+    assert os.path.exists(mr.HIP_EXE), "tests/c/_prebuilt/mini_radiod_hip missing: __graft_entry__.build() makes it where /root/reference exists"
+    assert os.path.exists(mr.REF_EXE), "oracle/_ref/mini_radiod_ref missing"
+    return mr.HIP_EXE
+
+
+@pytest.mark.gpu
+def test_reference_callers_on_the_mi355x_match_the_reference_filter():
+    """THE row-31 test: 48 channels (usb lsb cwu/cwl [filter2 = 4] am sam iq [one ISB] fm pm nfm dsb ame; S16BE and F32LE; SNR squelch,
+    PLL squelch, PL tone squelch; two retunes, three set_filter()s mid-stream), 30 blocks, real demod_linear() / demod_fm() threads"""
+    exe = _hip_exe()
+    ch = mr.standard_channels()
+    x = mr.synthesise(ch, FS, L, NBLOCKS)
+    with tempfile.TemporaryDirectory() as tmp:
+        A, _, _ = _reference_run(tmp, ch, x)
+        B, meta, err = mr.run(exe, os.path.join(tmp, "hip"), ch, x, FS, L, M, NBLOCKS)
+    assert int(meta["commands"]) == 5 and int(meta["shutdowns"]) == 1 and int(meta["master_jobs"]) == NBLOCKS
+    s = mr.compare(A, B)
+    print("mini-radiod A/B on the device:", s)
+    assert s["data"] > 1000 and s["null"] > 100
+
+
+@pytest.mark.gpu
+def test_reference_callers_on_the_mi355x_at_wall_clock_pace():
+    """the same channel table with the front end on its own 20 ms clock (never waiting, as hardware): no channel thread of the
+    reference's may be lapped, so the frames are those of the lock-step run"""
+    exe = _hip_exe()
+    ch = mr.standard_channels()
+    nb = 100
+    x = mr.synthesise(ch, FS, L, nb, seed=6)
+    with tempfile.TemporaryDirectory() as tmp:
+        A, _, _ = _reference_run(tmp, ch, x, nblocks=nb)
+        B, meta, err = mr.run(exe, os.path.join(tmp, "hip"), ch, x, FS, L, M, nb, paced=1)
+    assert all(f["block_drops"] == 0 for F in B.values() for f in F)
+    assert float(meta["seconds"]) < nb * 0.02 + 0.5
+    s = mr.compare(A, B)
+    print("mini-radiod paced A/B on the device:", s)
