@@ -796,7 +796,10 @@ def dropin_leg(wl, ring_host, nthreads, nblocks, env, label, paced_us=0, verify=
         cg0 = cgroup_cpu()
         t0 = time.perf_counter()
         # (a leg that hangs must cost this run minutes, not its line: 500 paced blocks take 10 s + the start of 2000 threads)
-        r = subprocess.run([exe, tmp], capture_output=True, text=True, timeout=max(180, int(3 * nblocks * BLOCKTIME) + 120), env=e)
+        # BENCH_DROPIN_WRAPPER="rocprofv3 --hip-trace -d DIR --": the harness under a tracer (scripts/gpu/call.sh r6c: which HIP call blocks in block 1?)
+        import shlex
+        r = subprocess.run(shlex.split(os.environ.get("BENCH_DROPIN_WRAPPER", "")) + [exe, tmp], capture_output=True, text=True,
+                           timeout=max(180, int(3 * nblocks * BLOCKTIME) + 120), env=e)
         wall = time.perf_counter() - t0
         cg1 = cgroup_cpu()
         if r.returncode != 0:

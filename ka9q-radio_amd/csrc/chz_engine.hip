@@ -994,7 +994,7 @@ static inline size_t stage_bytes_per_channel() { return sizeof(ChanDesc) + sizeo
 static int refresh_slot(chz_engine* e, Bank& b, int slot, hipStream_t st) {
   if (b.dirty[slot].empty()) return 0;
   const int chunk = b.cap < CHZ_STAGE_CAP ? b.cap : CHZ_STAGE_CAP;
-  const size_t half_bytes = stage_bytes_per_channel() * (size_t)chunk;
+  const size_t half_bytes = (stage_bytes_per_channel() * (size_t)chunk + 64 + 63) & ~(size_t)63;      // (+ the 8-byte rounding of each segment)
   if (!b.stage[slot]) {
     HIPOK(hipHostMalloc((void**)&b.stage[slot], 2 * half_bytes, hipHostMallocDefault));
     for (int h = 0; h < 2; h++) HIPOK(hipEventCreateWithFlags(&b.stage_ev[slot][h], hipEventDisableTiming));
@@ -1005,24 +1005,19 @@ static int refresh_slot(chz_engine* e, Bank& b, int slot, hipStream_t st) {
       const int n = hi - c0 < chunk ? hi - c0 : chunk;
       const int h = b.stage_next[slot]; b.stage_next[slot] ^= 1;
       if (b.stage_busy[slot][h]) HIPOK(hipEventSynchronize(b.stage_ev[slot][h]));   // the copy before last out of this half: long done
+      // (round 6) the staged descriptors travel by the desc_push kernel reading the pinned staging buffer, not by hipMemcpyAsync: see chz_kernels.h
       char* sp = b.stage[slot] + (size_t)h * half_bytes;
-      memcpy(sp, b.desc_h.data() + c0, sizeof(ChanDesc) * (size_t)n);
-      HIPOK(hipMemcpyAsync(b.desc + (size_t)slot * b.cap + c0, sp, sizeof(ChanDesc) * (size_t)n, hipMemcpyHostToDevice, st));
-      sp += sizeof(ChanDesc) * (size_t)n;
-      if (b.fine) {
-        memcpy(sp, b.fine_dh.data() + c0, sizeof(FineDesc) * (size_t)n);
-        HIPOK(hipMemcpyAsync(b.fine + (size_t)slot * b.cap + c0, sp, sizeof(FineDesc) * (size_t)n, hipMemcpyHostToDevice, st));
-        sp += sizeof(FineDesc) * (size_t)n;
-      }
-      if (b.beam) {
-        memcpy(sp, b.beam_h.data() + c0, sizeof(BeamDesc) * (size_t)n);
-        HIPOK(hipMemcpyAsync(b.beam + (size_t)slot * b.cap + c0, sp, sizeof(BeamDesc) * (size_t)n, hipMemcpyHostToDevice, st));
-        sp += sizeof(BeamDesc) * (size_t)n;
-      }
-      if (b.isb) {
-        memcpy(sp, b.isb_h.data() + c0, (size_t)n);
-        HIPOK(hipMemcpyAsync(b.isb + (size_t)slot * b.cap + c0, sp, (size_t)n, hipMemcpyHostToDevice, st));
-      }
+      PushParams pp{};
+      auto seg = [&](void* dst, const void* src, size_t bytes) {
+        memcpy(sp, src, bytes);
+        pp.seg[pp.nseg].dst = dst; pp.seg[pp.nseg].src = sp; pp.seg[pp.nseg].bytes = (unsigned)bytes; pp.nseg++;
+        sp += (bytes + 7) & ~(size_t)7;
+      };
+      seg(b.desc + (size_t)slot * b.cap + c0, b.desc_h.data() + c0, sizeof(ChanDesc) * (size_t)n);
+      if (b.fine) seg(b.fine + (size_t)slot * b.cap + c0, b.fine_dh.data() + c0, sizeof(FineDesc) * (size_t)n);
+      if (b.beam) seg(b.beam + (size_t)slot * b.cap + c0, b.beam_h.data() + c0, sizeof(BeamDesc) * (size_t)n);
+      if (b.isb) seg(b.isb + (size_t)slot * b.cap + c0, b.isb_h.data() + c0, (size_t)n);
+      launch_desc_push(pp, st);
       HIPOK(hipEventRecord(b.stage_ev[slot][h], st));
       b.stage_busy[slot][h] = true;
     }

@@ -1420,6 +1420,27 @@ __global__ void __launch_bounds__(256) spec_energy(EnergyParams p) {
   }
 }
 
+// Descriptor refresh (round 6): a slot's copy of the gather / fine-tuning / beam descriptors and ISB flags is brought up to the host copy by
+// THIS kernel, reading the engine's pinned staging buffer over the host link, in stream order on the slot's lane -- not by hipMemcpyAsync.
+// Why: a small host-to-device copy enqueued on a lane right behind the spectrum's device-to-host 2-D copy made the runtime stall the
+// CALLING thread for 8-9 ms the first time it happened on a second stream (rocprofv3 --hip-trace of the filter.h drop-in: block 1's
+// execute_filter_input took 8.2 ms, every process, profiles/r06_block1_stall.txt); a kernel launch has no such path.  At most 4 segments.
+struct PushSeg { void* dst; const void* src; unsigned bytes; unsigned pad; };
+struct PushParams { PushSeg seg[4]; int nseg; };
+__global__ void __launch_bounds__(256) desc_push(PushParams p) {
+  const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+  for (int g = 0; g < p.nseg; g++) {
+    const PushSeg sg = p.seg[g];
+    if ((((unsigned long long)sg.dst | (unsigned long long)sg.src | sg.bytes) & 3u) == 0) {
+      const unsigned* __restrict__ s = (const unsigned*)sg.src; unsigned* __restrict__ d = (unsigned*)sg.dst;
+      for (unsigned i = tid; i < sg.bytes / 4; i += nthr) d[i] = s[i];
+    } else {
+      const unsigned char* __restrict__ s = (const unsigned char*)sg.src; unsigned char* __restrict__ d = (unsigned char*)sg.dst;
+      for (unsigned i = tid; i < sg.bytes; i += nthr) d[i] = s[i];
+    }
+  }
+}
+
 // Reductions over the wavefront for wave-uniform results: DPP inside the rows of 16 lanes, then the four row results through
 // v_readlane into scalar registers (no LDS round trips as with ds_bpermute).  On the CPU test emulator: plain shuffles.
 #if defined(__HIP_DEVICE_COMPILE__)

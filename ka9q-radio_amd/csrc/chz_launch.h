@@ -228,6 +228,12 @@ inline void launch_spec_energy(const float2* spec, float* energy, int bins, cons
   long grid = ((long)bins + 255) / 256; if (grid > 2048) grid = 2048;
   CHZ_LAUNCH(spec_energy, (int)grid, 256, 0, s, e0, e1, q);
 }
+inline void launch_desc_push(const PushParams& p, hipStream_t s) {
+  size_t words = 0;
+  for (int g = 0; g < p.nseg; g++) words += (p.seg[g].bytes + 3) / 4;
+  long grid = ((long)words + 1023) / 1024; if (grid < 1) grid = 1; if (grid > 128) grid = 128;
+  CHZ_LAUNCH(desc_push, (int)grid, 256, 0, s, nullptr, nullptr, p);
+}
 inline int launch_noise(int nch, hipStream_t s, const NoiseParams& p, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
   const int grid = (nch + 3) / 4;          // four wavefronts = four channels per workgroup
   if (p.energy) {

@@ -170,6 +170,8 @@ struct mctx {
   unsigned t_done_job[ND];
   unsigned long long prof_first_dev_ns[8], prof_first_input_ns[8], prof_first_consume_ns[8];   /* blocks 0..7 one by one: enqueue -> callback; time inside execute_filter_input; the slowest slave's completion -> output in hand */
   unsigned prof_first_hits[8], prof_first_misses[8];
+#define PROF_STAGES 8                /* lock, h2d, forward, spectrum read, bank edits, bank launch, bank reads, callback */
+  unsigned long long prof_stage_ns[8][PROF_STAGES];
   /* channels whose staged result does not fit (retuned, new filter, just created) are re-run in batches: the first
      thread to miss becomes the leader and serves everybody who queued up meanwhile with one device round trip */
   pthread_mutex_t miss_lock;
@@ -691,8 +693,10 @@ int delete_filter_input(struct filter_in *master) {
     if (c->profile && c->prof_blocks) {
       fprintf(stderr, "filter_hip first blocks:");
       for (int j = 0; j < 8 && (unsigned long long)j < c->prof_blocks; j++)
-        fprintf(stderr, " [%d dev_us=%.0f input_us=%.0f consume_worst_us=%.0f hits=%u misses=%u]", j, c->prof_first_dev_ns[j] / 1e3, c->prof_first_input_ns[j] / 1e3,
-                c->prof_first_consume_ns[j] / 1e3, c->prof_first_hits[j], c->prof_first_misses[j]);
+        fprintf(stderr, " [%d dev_us=%.0f input_us=%.0f consume_worst_us=%.0f hits=%u misses=%u stages_us(lock,h2d,fwd,specread,edits,launch,reads,callback)=%.0f,%.0f,%.0f,%.0f,%.0f,%.0f,%.0f,%.0f]",
+                j, c->prof_first_dev_ns[j] / 1e3, c->prof_first_input_ns[j] / 1e3, c->prof_first_consume_ns[j] / 1e3, c->prof_first_hits[j], c->prof_first_misses[j],
+                c->prof_stage_ns[j][0] / 1e3, c->prof_stage_ns[j][1] / 1e3, c->prof_stage_ns[j][2] / 1e3, c->prof_stage_ns[j][3] / 1e3, c->prof_stage_ns[j][4] / 1e3,
+                c->prof_stage_ns[j][5] / 1e3, c->prof_stage_ns[j][6] / 1e3, c->prof_stage_ns[j][7] / 1e3);
       fprintf(stderr, "\n");
     }
     if (c->ring_pinned) chz_host_unregister(master->input_buffer);
@@ -923,6 +927,9 @@ static int futex_wait_u32_ms(unsigned *addr, unsigned expected, long ms) {
   return (int)syscall(SYS_futex, addr, FUTEX_WAIT_PRIVATE, expected, &ts, NULL, 0);
 }
 
+/* KA9Q_HIP_PROFILE=1, blocks 0..7 only: host time of each stage of execute_filter_input */
+#define PROF_STAGE(c, job, k, tref) do { if ((c)->profile && (job) < 8) { struct timespec t_; clock_gettime(CLOCK_MONOTONIC, &t_); \
+    (c)->prof_stage_ns[job][k] += (unsigned long long)((t_.tv_sec - (tref).tv_sec) * 1000000000LL + (t_.tv_nsec - (tref).tv_nsec)); (tref) = t_; } } while (0)
 int execute_filter_input(struct filter_in *const f) {
   if (f == NULL || f->fwd_plan == NULL) return -1;
   if (is_mini_master(f)) return mini_execute_input(f);
@@ -1019,7 +1026,9 @@ int execute_filter_input(struct filter_in *const f) {
   unsigned const seq = ++c->enq_seq[slot];
   struct timespec tq;
   clock_gettime(CLOCK_MONOTONIC, &tq);
+  struct timespec tst = tp1;
   sync_notches(c, f);
+  PROF_STAGE(c, job, 0, tst);
 
   int rc = 0, callbacks = 0;
   __atomic_store_n(&c->pending[slot], (unsigned)c->nsh, __ATOMIC_RELEASE);
@@ -1031,8 +1040,11 @@ int execute_filter_input(struct filter_in *const f) {
     if (c->bcast && g > 0) continue;
     rc = chz_input_write(sh->eng, newsamples, f->ilen);
     if (rc == 0 && c->drop_when_full) rc = chz_input_mark(sh->eng, (int)(job % 8));
+    PROF_STAGE(c, job, 1, tst);
     if (rc == 0) rc = chz_forward(sh->eng, job);
+    PROF_STAGE(c, job, 2, tst);
     if (rc == 0 && g == 0 && c->host_spectrum) rc = chz_spectrum_read_async(sh->eng, slot, (float *)f->fdomain[slot]);
+    PROF_STAGE(c, job, 3, tst);
   }
   if (rc == 0 && c->bcast && c->nsh > 1) {
     chz_engine *engs[MAX_SHARDS];
@@ -1098,11 +1110,15 @@ int execute_filter_input(struct filter_in *const f) {
         }
       }
       chz_bank_set_active(sh->eng, b->id, b->n);
+      PROF_STAGE(c, job, 4, tst);
       rc = chz_bank_execute(sh->eng, b->id, slot);
+      PROF_STAGE(c, job, 5, tst);
       if (rc == 0) rc = chz_bank_read_async(sh->eng, b->id, slot, 0, b->n, (float *)b->stage[slot]);
       if (rc == 0 && b->noise_on) rc = chz_bank_read_noise_async(sh->eng, b->id, slot, 0, b->n, b->stage_n0[slot]);
+      PROF_STAGE(c, job, 6, tst);
     }
     if (rc == 0) rc = chz_host_callback(sh->eng, slot, block_done, note);
+    PROF_STAGE(c, job, 7, tst);
     if (rc == 0) callbacks++;
   }
   if (rc != 0) {

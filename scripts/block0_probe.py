@@ -18,9 +18,13 @@ ol.build()
 wl = bench.workload_for(3, 0, 1, 1024)
 ring = bench.siggen_ring(ol, wl["fs"], l=wl["L"], real=wl.get("real", True))
 out = []
-for label, n, env in [("first process on the box, 1024 threads", 1024, {}), ("second process, 1024 threads", 1024, {}),
+only = os.environ.get("BLOCK0_ONLY", "")        # "1": only the BLOCK0_EXTRA configurations; "2": one default 1024-thread run
+base = [] if only == "1" else [("first process on the box, 1024 threads", 1024, {}), ("second process, 1024 threads", 1024, {}),
                       ("third process, 2000 threads, noise from the device", 2000, {"KA9Q_HIP_FDOMAIN": "0", "KA9Q_HIP_NOISE_SAMPRATE": "%.1f" % wl["fs"]}),
-                      ("fourth process, 1024 threads", 1024, {})] + [(l, n, dict(e)) for l, n, e in json.loads(os.environ.get("BLOCK0_EXTRA", "[]"))]:
+                      ("fourth process, 1024 threads", 1024, {})]
+if only == "2":
+    base = base[:1]
+for label, n, env in base + [(l, n, dict(e)) for l, n, e in json.loads(os.environ.get("BLOCK0_EXTRA", "[]"))]:
     r = bench.dropin_leg(wl, ring, n, blocks, env, label, paced_us=20000)
     p = r.get("paced") or {}
     rec = {"label": label, "threads": n, "drops": r.get("drops"), "block0_ms": p.get("block0_ms"), "first_8_ms": r.get("first_8_blocks_latency_ms"),

@@ -9,9 +9,38 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
-  r6a)       # round 6, first call: block 0 of the FIRST drop-in process on a fresh box (before anything else touches the GPU); the reference's own
+  r6e)       # round 6: descriptors refreshed by a kernel (desc_push) instead of hipMemcpyAsync: is block 1's 8 ms stall gone?  mini-radiod with fading signals
+    timeout 300 python scripts/block0_probe.py 60 > "$out/block0_probe.jsonl" 2> "$out/block0_probe.err"; echo "block0 rc=$?" >> "$out/rc.txt"
+    python -c "
+import json,sys
+for ln in open('$out/block0_probe.jsonl'):
+    r=json.loads(ln); print(r['label'], 'block0', r['block0_ms'], 'first8', r['first_8_ms'], 'p99', r['p99_ms'], 'max', r['max_ms'], 'drops', r['drops']); print('   ', (r['first_blocks_profile'] or '')[:1000])"
+    timeout 600 python -m pytest tests/test_mini_radiod.py -m gpu -q -s --timeout 300 > "$out/mini_radiod.txt" 2>&1; echo "mini_radiod rc=$?" >> "$out/rc.txt"
+    tail -5 "$out/mini_radiod.txt" | cut -c1-1800
+    timeout 120 python scripts/mini_radiod_ab.py --paced --blocks 100 --seed 6 --repeat 3 > "$out/mini_paced.txt" 2>&1; grep -v "^   call" "$out/mini_paced.txt" | cut -c1-700 | head
+    cat "$out/rc.txt"
+    ;;
+  r6d)       # round 6: the 9 ms hipMemcpyAsync of block 1 in context (rocprofv3 --hip-trace of the harness, 12 paced blocks)
+    cd /tmp && BLOCK0_ONLY=2 BENCH_DROPIN_WRAPPER="rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --output-format csv -d $OLDPWD/$out/trace --" timeout 300 python $OLDPWD/scripts/block0_probe.py 12 > "$OLDPWD/$out/block0_traced.jsonl" 2>> "$OLDPWD/$out/err.txt"; cd "$OLDPWD"
+    python scripts/slow_hip_calls.py "$out/trace" > "$out/slow_hip_calls.txt" 2>&1; grep -A 20 "^context" "$out/slow_hip_calls.txt" | head -120; grep -A 60 "^all copies" "$out/slow_hip_calls.txt" | head -70
+    rm -rf "$out/trace"
+    ;;
+  r6c)       # round 6: (1) the paced mini-radiod run, frames side by side where the gain differs; (2) block 1 of the drop-in blocks 8 ms inside chz_bank_execute
+             # with the spectrum copied back: which HIP call?  the harness under rocprofv3 --hip-trace; and the same leg with the spectrum copy off
+    timeout 120 python scripts/mini_radiod_ab.py --paced --blocks 100 --seed 6 --repeat 2 > "$out/mini_paced.txt" 2>&1; echo "paced rc=$?" >> "$out/rc.txt"
+    grep -v "^   call" "$out/mini_paced.txt" | cut -c1-600 | head -30
+    BLOCK0_ONLY=1 BLOCK0_EXTRA='[["1024 threads, no spectrum copy, no noise", 1024, {"KA9Q_HIP_FDOMAIN": "0"}], ["2000 threads, spectrum copied back", 2000, {}]]' timeout 200 python scripts/block0_probe.py 40 > "$out/block0_extra.jsonl" 2>> "$out/err.txt"
+    python -c "
+import json,sys
+for ln in open('$out/block0_extra.jsonl'):
+    r=json.loads(ln); print(r['label'], r['block0_ms'], r['first_8_ms']); print('   ', (r['first_blocks_profile'] or '')[:900])"
+    cd /tmp && BLOCK0_ONLY=2 BENCH_DROPIN_WRAPPER="rocprofv3 --hip-trace --kernel-trace --memory-copy-trace --output-format csv -d $OLDPWD/$out/trace --" timeout 300 python $OLDPWD/scripts/block0_probe.py 12 > "$OLDPWD/$out/block0_traced.jsonl" 2>> "$OLDPWD/$out/err.txt"; cd "$OLDPWD"
+    python scripts/slow_hip_calls.py "$out/trace" > "$out/slow_hip_calls.txt" 2>&1; head -60 "$out/slow_hip_calls.txt"
+    rm -rf "$out/trace"
+    ;;
+  r6b)       # round 6, first call: block 0 of the FIRST drop-in process on a fresh box (before anything else touches the GPU); the reference's own
              # callers on the drop-in (mini-radiod, tests/test_mini_radiod.py); is a CU-masked stream a blocking stream? (scripts/micro/masked_stream_blocking.hip)
-    timeout 300 python scripts/block0_probe.py 150 > "$out/block0_probe.jsonl" 2> "$out/block0_probe.err"; echo "block0 rc=$?" >> "$out/rc.txt"
+    timeout 300 python scripts/block0_probe.py 100 > "$out/block0_probe.jsonl" 2> "$out/block0_probe.err"; echo "block0 rc=$?" >> "$out/rc.txt"
     cat "$out/block0_probe.jsonl"
     timeout 600 python -m pytest tests/test_mini_radiod.py -m gpu -q -s --timeout 300 > "$out/mini_radiod.txt" 2>&1; echo "mini_radiod rc=$?" >> "$out/rc.txt"
     tail -12 "$out/mini_radiod.txt"

@@ -1,9 +1,9 @@
 // scripts/micro/masked_stream_blocking.hip -- reproducer for the round-5 hang (not product code).
 // Question: is a stream made by hipExtStreamCreateWithCUMask a BLOCKING stream (hipStreamDefault semantics: implicitly ordered with the
 // legacy null stream), although the engine treats its streams as hipStreamNonBlocking?  The call takes no flags argument.
-// Test per kind of stream: a kernel on the stream spins until the HOST sets a flag; meanwhile a 4-byte hipMemsetAsync goes to the null stream.
-//   non-blocking stream: the null-stream memset completes while the kernel still spins
-//   blocking stream:     the memset stays "not ready" until the flag is set (null-stream work waits for every blocking stream, and the
+// Test per kind of stream: a kernel on the stream spins until the HOST sets a flag; meanwhile a one-thread kernel goes to the null stream.
+//   non-blocking stream: the null-stream kernel runs while the other still spins
+//   blocking stream:     it does not run until the flag is set (null-stream work waits for every blocking stream, and the
 //                        next work on any blocking stream waits for the null stream) -- with a device-side ticket wait between two such
 //                        streams and ANY null-stream operation in between (the engine's synchronous hipMemcpy / hipMemset, torch's
 //                        default stream in bench.py) that is a deadlock: kernel A spins for kernel B, B queues behind the null-stream
@@ -32,15 +32,16 @@ static int full_mask_stream(hipStream_t* s) {
 }
 
 static int probe(const char* name, hipStream_t s, volatile int* hflag, int* dflag, int* scratch) {
-  *hflag = 0;
+  (void)scratch;
+  hflag[0] = 0; hflag[8] = 0;
   hipLaunchKernelGGL(spin_until, dim3(1), dim3(1), 0, s, (volatile int*)dflag, 1, 100000000LL * 5);     // <= 5 s at 100 MHz
-  CK(hipMemsetAsync(scratch, 0, 4, 0));                                                                   // legacy null stream
+  hipLaunchKernelGGL(set_flag, dim3(1), dim3(1), 0, 0, (volatile int*)(dflag + 8), 1);                    // legacy null stream: a kernel the host can SEE finishing
   std::this_thread::sleep_for(std::chrono::milliseconds(200));
-  const hipError_t q = hipStreamQuery(0);
+  const bool ran = hflag[8] == 1;                     // (hipStreamQuery(0) is no witness: on the null stream it reports on every stream of the device)
   unsigned flags = 99;
   (void)hipStreamGetFlags(s, &flags);
-  printf("%-42s null-stream memset after 200 ms: %-14s -> the stream is %s   (hipStreamGetFlags = %u, hipStreamNonBlocking = %u)\n", name,
-         q == hipSuccess ? "done" : "NOT READY", q == hipSuccess ? "non-blocking" : "BLOCKING", flags, (unsigned)hipStreamNonBlocking);
+  printf("%-44s null-stream kernel after 200 ms: %-8s -> the stream is %s   (hipStreamGetFlags = %u, hipStreamNonBlocking = %u)\n", name,
+         ran ? "ran" : "WAITING", ran ? "non-blocking" : "BLOCKING", flags, (unsigned)hipStreamNonBlocking);
   *hflag = 1;
   CK(hipStreamSynchronize(s));
   CK(hipDeviceSynchronize());
@@ -64,18 +65,24 @@ int main() {
   if (probe("hipExtStreamCreateWithCUMask(all CUs)", masked, hflag, dflag, scratch)) return 1;
   if (probe("hipStreamCreateWithPriority(NonBlocking,hi)", prio, hflag, dflag, scratch)) return 1;
 
-  // Part 2: the engine's shape.  Kernel A on masked lane 1 waits (device side, bounded 2 s) for a ticket that kernel B on masked lane 2
-  // publishes; between the two launches the host issues ONE null-stream operation.
-  for (int with_null_op = 0; with_null_op < 2; with_null_op++) {
-    *hflag = 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(spin_until, dim3(1), dim3(1), 0, masked, (volatile int*)dflag, 7, 100000000LL * 2);
-    if (with_null_op) CK(hipMemsetAsync(scratch, 0, 4, 0));
-    hipLaunchKernelGGL(set_flag, dim3(1), dim3(1), 0, masked2, (volatile int*)dflag, 7);
-    CK(hipDeviceSynchronize());
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    printf("ticket wait across two masked streams, %s null-stream operation in between: %.1f ms %s\n", with_null_op ? "ONE" : "no", ms,
-           ms > 1000 ? "= the waiter sat out its whole budget: DEADLOCK SHAPE (an unbounded wait hangs here)" : "= handed over at once");
+  // Part 2: the engine's shape.  Kernel A on lane 1 waits (device side, bounded 2 s) for a ticket that kernel B on lane 2 publishes;
+  // between the two launches the host issues ONE null-stream operation (what a synchronous hipMemcpy / hipMemset, or torch's default
+  // stream, amounts to).  With CU-masked lanes and with plain non-blocking lanes.
+  hipStream_t plain2;
+  CK(hipStreamCreateWithFlags(&plain2, hipStreamNonBlocking));
+  for (int kind = 0; kind < 2; kind++) {
+    hipStream_t l1 = kind ? plain : masked, l2 = kind ? plain2 : masked2;
+    for (int with_null_op = 0; with_null_op < 2; with_null_op++) {
+      *hflag = 0;
+      const auto t0 = std::chrono::steady_clock::now();
+      hipLaunchKernelGGL(spin_until, dim3(1), dim3(1), 0, l1, (volatile int*)dflag, 7, 100000000LL * 2);
+      if (with_null_op) CK(hipMemsetAsync(scratch, 0, 4, 0));
+      hipLaunchKernelGGL(set_flag, dim3(1), dim3(1), 0, l2, (volatile int*)dflag, 7);
+      CK(hipDeviceSynchronize());
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      printf("ticket wait across two %s streams, %s null-stream operation in between: %.1f ms %s\n", kind ? "plain non-blocking" : "CU-masked", with_null_op ? "ONE" : "no", ms,
+             ms > 1000 ? "= the waiter sat out its whole budget: DEADLOCK SHAPE (an unbounded wait hangs here)" : "= handed over at once");
+    }
   }
   return 0;
 }

@@ -45,9 +45,13 @@
 #include "misc.h"
 #include "filter.h"
 #include "radio.h"
+#include "osc.h"
 #include "import.h"
 
 int Verbose = 0;                       /* src/main.c */
+/* only in the checker link: the oracle's FFT provider can do its arithmetic in float32 (oracle/fftw_shim.c) -- MINI_RADIOD_FFT_F32=1 runs the
+   reference on a float32 transform, as it would on FFTW, to show how far two CORRECT transforms move the reference's own outputs */
+extern void oracle_fft_set_precision(int) __attribute__((weak));
 extern int Overlap;                    /* src/radio.c:128, not in radio.h */
 
 /* ---- never reached (see the header) ---- */
@@ -291,6 +295,11 @@ int main(int argc, char **argv) {
   if (!g || fread(FE.samples, sizeof(float) * FE.L, FE.nblocks, g) != (size_t)FE.nblocks) { perror(path); return 2; }
   fclose(g);
 
+  if (getenv("MINI_RADIOD_FFT_F32") && oracle_fft_set_precision) oracle_fft_set_precision(1);
+  /* src/osc.c:96-98: nco() fills its sine table on first use, and only the FIRST caller waits for that -- channel threads that start their
+     PLLs at the same moment read a half-filled table (a start-up transient in radiod; here it made one run in eight of the checker link differ
+     from the others on a coherent channel).  One call from the main thread before any channel exists makes every run the same. */
+  { double s_, c_; nco(0, &s_, &c_); }
   setup_hardware_like_radiod();
   Overlap = 1 + FE.L / (FE.M - 1);                       /* "overlap" of [global], src/radio.c:283; set_channel_filter reads it */
   set_defaults(&Template);                               /* src/radio.c:439 */

@@ -87,10 +87,16 @@ def synthesise(channels, fs, L, nblocks, seed=5, noise=0.002):
     t = np.arange(n) / fs
     rng = np.random.default_rng(seed)
     x = noise * rng.standard_normal(n)
-    for c in channels:
+    for i, c in enumerate(channels):
         a, k, f = c.signal.get("amp", 0.0), c.signal.get("kind", ""), c.freq
         if a == 0.0:
             continue
+        if k not in ("fm", "pm", "nfm"):
+            # slow fading, a different rate and phase per channel: with a STATIONARY signal the block AGC of src/linear.c:205-238 sits exactly
+            # on its own decision boundary (after an attack, amplitude x gain == headroom to the last bit, and the next block's "above or
+            # below?" is decided by rounding: 1 dB of gain per block either way) -- measured: the reference against itself on a float32
+            # transform then differs by 39 % in gain.  Real signals are never stationary to 1e-7; neither are these.
+            a = a * (1.0 + 0.35 * np.sin(2 * np.pi * (1.1 + 0.13 * (i % 7)) * t + 0.7 * i))
         if k in ("usb", "iq"):
             x += a * (np.cos(2 * np.pi * (f + 700.0) * t) + 0.6 * np.cos(2 * np.pi * (f + 1900.0) * t + 0.3))
         elif k == "ame":      # carrier + weak upper sideband: the lock detector takes sideband power in quadrature for noise
@@ -148,45 +154,108 @@ def parse(path):
 S16LE, S16BE, F32LE = 1, 2, 4       # src/rtp.h:27-41 enum encoding
 
 
-def compare(ref, got, float_tol=1e-5, n0_tol=1e-5, lsb_frac=1e-3):
-    """The A/B bar of the round-5 review: frame kinds, mute / squelch flags, timestamps, bin shifts, block_drops IDENTICAL; float PCM
-    within float_tol relative L2 per frame (+ a floor of 1e-7 of the channel's loudest frame); int16 PCM at most 1 LSB apart on at most
-    lsb_frac of a channel's samples; sig.n0 and bb_power within n0_tol relative.  Returns a summary dict."""
+DISCRETE = ("call", "next_jobnum", "block_drops", "frames", "channels", "mute", "isnull", "encoding", "bin_shift", "pll_lock",
+            "silent", "rtp_timestamp", "pcm_bytes", "nfloat", "olen")
+
+
+def diff(ref, got, upto=None):
+    """Frame by frame.  Everything discrete -- frame kinds, mute / squelch flags, PLL lock, RTP timestamps, bin shifts, block_drops, the
+    tuning -- is compared for equality: st["agree"] = the number of leading frames of the channel on which the two runs agree in all of
+    it (== st["frames"] when they never part), st["parted"] = (frame, field, value, value) where they first do not.  The continuous
+    outputs are measured over those leading frames (and at most upto[ssrc] of them): "float_rel" worst relative L2 of a frame's float PCM
+    (frames above 1e-3 of the channel's loudest), "n0_rel" / "bb_power_rel" / "gain_rel" worst relative differences, "lsb_frac" share of
+    the int16 PCM samples that differ, "lsb_max" by how many LSB at most."""
     assert sorted(ref) == sorted(got), (sorted(ref)[:5], sorted(got)[:5])
-    worst = {"float_rel_l2": 0.0, "n0_rel": 0.0, "bb_power_rel": 0.0, "lsb_frac": 0.0, "gain_rel": 0.0}
-    kinds = {"data": 0, "null": 0, "mute": 0}
+    out = {}
     for ssrc in sorted(ref):
         A, B = ref[ssrc], got[ssrc]
         assert len(A) == len(B), (ssrc, len(A), len(B))
         peak = max([float(np.sqrt(np.mean(a["pcm_f"].astype(np.float64) ** 2))) for a in A if a["pcm_f"] is not None] or [0.0])
+        st = {"float_rel": 0.0, "float_abs_over_peak": 0.0, "n0_rel": 0.0, "bb_power_rel": 0.0, "gain_rel": 0.0, "lsb_frac": 0.0, "lsb_max": 0, "frames": len(A),
+              "agree": len(A), "parted": None, "data": 0, "null": 0}
         nsamp = ndiff = 0
-        for a, b in zip(A, B):
-            for k in ("call", "next_jobnum", "block_drops", "frames", "channels", "mute", "isnull", "encoding", "bin_shift", "pll_lock",
-                      "silent", "rtp_timestamp", "pcm_bytes", "nfloat", "olen"):
-                assert a[k] == b[k], (ssrc, a["call"], k, a[k], b[k])
-            assert a["tune_freq"] == b["tune_freq"] and (a["remainder"] == b["remainder"] or (np.isnan(a["remainder"]) and np.isnan(b["remainder"])))
-            kinds["null" if a["isnull"] else "mute" if a["mute"] else "data"] += 1
-            for k, tol_key in (("n0", "n0_rel"), ("bb_power", "bb_power_rel"), ("gain", "gain_rel")):
-                if a[k] == 0 and b[k] == 0 or (np.isnan(a[k]) and np.isnan(b[k])):
+        for idx, (a, b) in enumerate(zip(A, B)):
+            if upto is not None and idx >= upto[ssrc]:
+                break
+            bad = [k for k in DISCRETE if a[k] != b[k]]
+            if not bad and not (a["tune_freq"] == b["tune_freq"] and (a["remainder"] == b["remainder"] or (np.isnan(a["remainder"]) and np.isnan(b["remainder"])))):
+                bad = ["tune_freq"]
+            if bad:
+                st["agree"] = idx; st["parted"] = (idx, bad[0], a[bad[0]], b[bad[0]])
+                break
+            for k in ("n0", "bb_power", "gain"):
+                if (a[k] == 0 and b[k] == 0) or (np.isnan(a[k]) and np.isnan(b[k])):
                     continue
-                rel = abs(a[k] - b[k]) / max(abs(a[k]), 1e-300)
-                worst[tol_key] = max(worst[tol_key], rel)
-                assert rel <= (n0_tol if k != "gain" else 10 * n0_tol), (ssrc, a["call"], k, a[k], b[k])
+                st[k + "_rel"] = max(st[k + "_rel"], abs(a[k] - b[k]) / max(abs(a[k]), 1e-300))
             if a["pcm_f"] is None:
+                st["null"] += 1
                 continue
+            st["data"] += 1
             fa, fb = a["pcm_f"].astype(np.float64), b["pcm_f"].astype(np.float64)
             err = float(np.sqrt(np.mean((fa - fb) ** 2))); rms = float(np.sqrt(np.mean(fa ** 2)))
-            assert err <= float_tol * rms + 1e-7 * peak, (ssrc, a["call"], err, rms, peak)
+            st["float_abs_over_peak"] = max(st["float_abs_over_peak"], err / max(peak, 1e-300))
             if rms > 1e-3 * peak:
-                worst["float_rel_l2"] = max(worst["float_rel_l2"], err / rms)
+                st["float_rel"] = max(st["float_rel"], err / rms)
             if a["encoding"] in (S16BE, S16LE):
                 dt = ">i2" if a["encoding"] == S16BE else "<i2"
-                ia, ib = a["pcm"].view(dt).astype(np.int32), b["pcm"].view(dt).astype(np.int32)
-                d = np.abs(ia - ib)
-                assert d.max(initial=0) <= 1, (ssrc, a["call"], int(d.max()))
+                d = np.abs(a["pcm"].view(dt).astype(np.int32) - b["pcm"].view(dt).astype(np.int32))
+                st["lsb_max"] = max(st["lsb_max"], int(d.max(initial=0)))
                 nsamp += d.size; ndiff += int((d != 0).sum())
-        if nsamp:
-            worst["lsb_frac"] = max(worst["lsb_frac"], ndiff / nsamp)
-            assert ndiff <= lsb_frac * nsamp + 1, (ssrc, ndiff, nsamp)
-    worst.update(kinds)
-    return worst
+        st["lsb_frac"] = ndiff / nsamp if nsamp else 0.0
+        out[ssrc] = st
+    return out
+
+
+def summary(d):
+    keys = ("float_rel", "float_abs_over_peak", "n0_rel", "bb_power_rel", "gain_rel", "lsb_frac", "lsb_max")
+    s = {k: max(v[k] for v in d.values()) for k in keys}
+    s.update({k + "_median": float(np.median([v[k] for v in d.values()])) for k in ("float_rel", "n0_rel", "bb_power_rel")})
+    s["data"] = sum(v["data"] for v in d.values()); s["null"] = sum(v["null"] for v in d.values())
+    s["frames"] = sum(v["frames"] for v in d.values()); s["frames_in_agreement"] = sum(v["agree"] for v in d.values())
+    s["parted"] = {k: v["parted"] for k, v in d.items() if v["parted"]}
+    return s
+
+
+def check(d, d_self=None, pll=(), float_tol=1e-5, n0_tol=1e-5, lsb_frac=1e-3, factor=4.0):
+    """The bar of the round-5 review -- float PCM within 1e-5 relative L2, int16 PCM at most 1 LSB apart on at most 0.1 % of the samples,
+    sig.n0 / bb_power within 1e-5 -- held wherever the REFERENCE ITSELF holds it.  d_self = diff(reference on a float64 transform,
+    reference on a float32 transform) over the same samples says where it does not (measured, tests/test_mini_radiod.py):
+      * estimate_noise() averages the bins under a threshold derived from a quantile (src/radio.c:1840-1864): one bin crossing that
+        threshold moves n0 by ~1/bins_averaged however small the rounding difference that pushed it (reference vs itself: up to 1.2e-3,
+        median 7e-7) -- n0 is held to `factor` x the reference's own worst spread, and its MEDIAN over the channels to n0_tol;
+      * a PLL that is still acquiring amplifies its input differences (the coherent presets sam / ame / dsb: reference vs itself up to
+        6.7e-4 in the first frames) -- channels in `pll` are held to `factor` x the reference's own worst spread on those channels;
+      * an int16 sample flips when the float error crosses a rounding boundary: a share of 2 x |error in LSB| of the samples, 0.1-0.2 % for
+        a full-scale signal at float32's 2.5e-7 (reference vs itself: 0.17 %) -- held to `factor` x the reference's own worst share;
+    everything else (float PCM of the other channels, bb_power, gain) to the review's figures."""
+    # Discrete outputs: the link under test must agree with the reference at least as long as the reference agrees with ITSELF on the other
+    # transform (a squelch or lock decision taken on a marginal SNR -- a PLL still acquiring -- flips with the rounding of its input in the
+    # reference too; from there on the two runs of that channel are different histories).  Without d_self: on every frame.
+    for ssrc, st in d.items():
+        need = d_self[ssrc]["agree"] if d_self else st["frames"]
+        assert st["agree"] >= need, (ssrc, "discrete outputs part at frame", st["parted"], "the reference agrees with itself up to frame", need)
+    if d_self:
+        held = sum(v["agree"] for v in d_self.values()); total = sum(v["frames"] for v in d_self.values())
+        assert held >= 0.95 * total, ("the reference itself is unstable on too much of this input to test with", held, total)
+    own = summary(d_self) if d_self else None
+    own_pll = max([d_self[s]["float_rel"] for s in pll] + [d_self[s]["float_abs_over_peak"] for s in pll] + [0.0]) if d_self else 0.0
+    lim_n0 = max(n0_tol, factor * own["n0_rel"]) if own else n0_tol
+    lim_lsb = max(lsb_frac, factor * own["lsb_frac"]) if own else lsb_frac
+    lim_gain = max(10 * n0_tol, factor * own["gain_rel"]) if own else 10 * n0_tol      # the AGC's threshold follows n0 (src/linear.c:196-204)
+    for ssrc, st in d.items():
+        lim_f = max(float_tol, factor * own_pll) if ssrc in pll else float_tol
+        assert st["float_rel"] <= lim_f, (ssrc, "float_rel", st["float_rel"], lim_f)
+        assert st["float_abs_over_peak"] <= lim_f, (ssrc, "float_abs_over_peak", st["float_abs_over_peak"], lim_f)
+        assert st["n0_rel"] <= lim_n0, (ssrc, "n0_rel", st["n0_rel"], lim_n0)
+        assert st["bb_power_rel"] <= n0_tol, (ssrc, "bb_power_rel", st["bb_power_rel"])
+        assert st["gain_rel"] <= lim_gain, (ssrc, "gain_rel", st["gain_rel"], lim_gain)
+        assert st["lsb_max"] <= 1, (ssrc, "lsb_max", st["lsb_max"])
+        assert st["lsb_frac"] <= lim_lsb, (ssrc, "lsb_frac", st["lsb_frac"], lim_lsb)
+    s = summary(d)
+    assert s["n0_rel_median"] <= n0_tol and s["float_rel_median"] <= float_tol, s
+    s["limits"] = {"float_rel": float_tol, "float_rel_pll_channels": max(float_tol, factor * own_pll), "n0_rel": lim_n0, "lsb_frac": lim_lsb, "gain_rel": lim_gain}
+    return s
+
+
+def compare(ref, got, **kw):
+    return check(diff(ref, got), None, **kw)
