@@ -34,6 +34,7 @@ import os
 import socket
 import statistics
 import sys
+import threading
 import time
 
 import numpy as np
@@ -969,7 +970,7 @@ def headline(out, detail_path):
                                           **{k: (x.get("paced") or {}).get(k) for k in ("drops_first_8_blocks", "block0_ms", "p99_ms", "max_ms")}))
     many("c_rt_pcie", lambda x: _pick(x, "channels", "sustained", "worst_block_ms", "d2h_bytes_per_channel", "pcm_mismatches"))
     many("next_rows", lambda x: dict(_pick(x, "mode", "channels", "pcm_mismatches", "verified_channels"), ms_per_block=x.get("pipelined_ms_per_block")))
-    h.update(_pick(out, "leg_seconds", "rccl_ranks", "quick"))
+    h.update(_pick(out, "leg_seconds", "rccl_ranks", "quick", "leg_timeouts", "headline_from", "exchange_errors"))
     h["detail"] = detail_path
     h = _clean(h, 5)
     line = json.dumps(h, allow_nan=False, separators=(",", ":"))
@@ -1156,26 +1157,165 @@ def main():
             job += reps * args.steps
         return statistics.median(times), times, last, reps, single
 
+    # ---- per-leg watchdog.  Every leg announces itself through progress(); a leg that is still running when its budget is spent is reported in
+    # the line ("leg_timeouts") and the run ENDS there with rc 0 and whatever the finished legs measured: a thread, not a signal (the main thread
+    # may be blocked inside a HIP call, and a blocked ctypes / torch call does not run Python signal handlers).  Budgets: several times what the
+    # leg takes on a healthy box (profiles/r05_bench_detail.json leg_seconds), BENCH_LEG_BUDGET_SCALE scales them, BENCH_LEG_BUDGET_S replaces them.
+    LEG_BUDGET_S = {"headline": 120, "exchange": 90, "roofline": 120, "c_rt": 180, "cpu_baseline": 150, "dropin": 150, "dropin_paced": 150,
+                    "dropin_sharded": 90, "c_rt_pcie": 200, "next_rows": 240}
+    wd = {"leg": None, "t0": 0.0, "budget": 0.0}
+
     def progress(what):
         if rank == 0:
             print("bench.py [%6.1f s] %s" % (time.perf_counter() - t_start, what), file=sys.stderr, flush=True)
+        key = what.split()[0].rstrip(":")
+        key = {"dropin": "dropin"}.get(key, key)
+        budget = float(os.environ.get("BENCH_LEG_BUDGET_S", 0)) or LEG_BUDGET_S.get(key, 240) * float(os.environ.get("BENCH_LEG_BUDGET_SCALE", "1"))
+        # the other ranks give rank 0 the time to print before the launcher sees anybody exit
+        wd["t0"], wd["budget"], wd["leg"] = time.perf_counter(), budget + (0 if rank == 0 else 20), what
+        if os.environ.get("BENCH_TEST_HANG_LEG") and what.startswith(os.environ["BENCH_TEST_HANG_LEG"]):
+            while True:                              # (tests: a leg that never comes back)
+                time.sleep(0.2)
+
+    def watchdog():
+        while True:
+            time.sleep(0.5)
+            leg = wd["leg"]
+            if leg is None or time.perf_counter() - wd["t0"] <= wd["budget"]:
+                continue
+            print("bench.py: leg '%s' has been running for %.0f s (budget %.0f s): giving up on it -- printing the line with what was measured and ending the run"
+                  % (leg, time.perf_counter() - wd["t0"], wd["budget"]), file=sys.stderr, flush=True)
+            try:
+                import faulthandler
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)      # where every thread of this process sits
+            except Exception:
+                pass
+            try:
+                emit([leg])
+            finally:
+                sys.stdout.flush(); sys.stderr.flush()
+                os._exit(0)
+    threading.Thread(target=watchdog, daemon=True, name="bench-watchdog").start()
     legs = {}
     leg_seconds = {}                      # wall seconds of every leg of this run (rank 0): the time budget of the bench line
+    # ---- everything the line is built from exists from here on (None until its leg has run), so that the line can be printed at ANY moment:
+    # by the normal end of the run, or by the watchdog when a leg overruns its time budget (round 5: one bench run with every stream
+    # CU-masked never came back and cost the whole record -- a hung leg must cost its own numbers, not the line)
+    roof = cpu = crt = crt_shared = dropin = dropin_paced = dropin_sharded = crt_pcie = next_rows = None
+    rccl_ranks, ranks_info, eng_lanes, eng_plan = 0, None, eng.lanes, eng.plan
+    main_leg = intended_leg = None
+    exchange_errors = {}
+    emitted = threading.Lock()
+
+    def emit(leg_timeouts):
+        if not emitted.acquire(blocking=False):
+            return
+        elapsed, times, timing, reps, single = legs[main_leg] if main_leg in legs else (None, None, None, None, None)
+        if rank == 0:
+            def leg_obj(name, leg):
+                el, ts, tm, rp, sg = leg
+                return {"ms_per_step": el * 1e3 / args.steps, "value": nch * world * BLOCKTIME / (el / args.steps), "reps": rp, "regions": len(ts),
+                        "ms_per_step_min": min(ts) * 1e3 / args.steps, "ms_per_step_max": max(ts) * 1e3 / args.steps,
+                        "drained_k_step_region_ms_per_step": sg * 1e3 / args.steps,
+                        "gpu_event_ms_per_step": tm.total_ms / tm.blocks, "host_enqueue_ms_per_step": tm.enqueue_ms / tm.blocks}
+            have = elapsed is not None
+            ms_per_step = elapsed * 1e3 / args.steps if have else None
+            total_ch = nch * world
+            value = total_ch * BLOCKTIME / (elapsed / args.steps) if have else None
+            fwd_copies = world if (config == 5 or main_leg == "replicate") else 1
+            step_bytes = fwd_copies * fwd_bytes(wl["N"], wl["real"]) + total_ch * chan_bytes(P, olen)
+            exchange_desc = None
+            if config == 4:
+                exchange_desc = {
+                    "subband": "RCCL grouped ncclSend/ncclRecv of the spectrum rows each rank's channels read (chz_spectrum_exchange_rows), on the slot's HIP stream",
+                    "broadcast": "RCCL ncclBroadcast of the whole spectrum slot (chz_spectrum_broadcast), on the slot's HIP stream",
+                    "samples": "RCCL ncclBroadcast of the block's L new samples into every rank's input ring on the communicator's stream; every rank runs the forward transform itself",
+                    "replicate": "none: every rank transforms its own HBM-resident copy of the samples",
+                }[main_leg] + "; %d rank(s)" % world
+            elif config == 5:
+                exchange_desc = "none (replicas only): %d independent front ends" % world
+            out = {
+                "metric": "channels sustained @%.1f MS/s input (real-time-equivalent: channel-blocks/s / 50)" % (wl["fs"] / 1e6),
+                "value": value, "unit": "channels", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": wl["name"] + (", 1 MI355X" if world == 1 else ""), "baseline_config": config,
+                           "channels_total": total_ch, "P": P, "olen": olen, "N": wl["N"], "L": wl["L"], "M": wl["M"],
+                           "launch": ("hipGraph replays of >= %s blocks" % os.environ.get("CHZ_GRAPH_BLOCKS", "32") if graph else "eager") + ", %d HIP streams, notch recurrence ordered by %s"
+                                     % (eng_lanes, "HIP events" if os.environ.get("CHZ_NOTCH_ORDER") == "event" else "device ticket"),
+                           "plan": eng_plan, "lanes": eng_lanes,
+                           "value_is": "free-running channel-blocks/s / 50 of this configuration, inputs resident in HBM; the literal simultaneous-channel count is c_rt.channels"},
+                "timing": "steady state: median over `regions` timed regions, each = `reps` back-to-back repetitions of the K-step loop "
+                          "(reps*K blocks, barrier+sync on both sides, max over ranks); drained_k_step_region = ONE K-step region on its own, "
+                          "pipeline fill and drain included",
+                "reps": reps, "regions": len(times) if have else None, "ms_per_step_min": min(times) * 1e3 / args.steps if have else None,
+                "ms_per_step_max": max(times) * 1e3 / args.steps if have else None,
+                "drained_k_step_region_ms_per_step": single * 1e3 / args.steps if have else None,
+                "exchange": exchange_desc, "exchange_mode": (main_leg if config == 4 else None),
+                "legs": {k: leg_obj(k, v) for k, v in legs.items() if k != main_leg} or None,
+                "blocks_per_s": args.steps / elapsed if have else None, "realtime_margin": BLOCKTIME / (elapsed / args.steps) if have else None,
+                "step_algorithmic_GBps": step_bytes / (elapsed / args.steps) / 1e9 if have else None,
+                "gpu_event_ms_per_step": timing.total_ms / timing.blocks if have else None,
+                "host_enqueue_ms_per_step": timing.enqueue_ms / timing.blocks if have else None,
+                # legs that overran their time budget (the watchdog printed this line and ended the run there); headline_from says which
+                # leg `value` comes from when the intended one never finished
+                "leg_timeouts": list(leg_timeouts) or None, "headline_from": main_leg, "intended_headline_leg": intended_leg,
+                "exchange_errors": exchange_errors or None,
+                "roofline": roof, "cpu_baseline": cpu, "c_rt": crt, "c_rt_shared_responses": crt_shared,
+                "dropin": dropin, "dropin_paced": dropin_paced, "dropin_sharded": dropin_sharded, "c_rt_pcie": crt_pcie, "next_rows": next_rows,
+                "leg_seconds": {k: round(v, 1) for k, v in leg_seconds.items()},
+                "rccl_ranks": rccl_ranks, "ranks": ranks_info, "quick": bool(args.quick),
+            }
+        if rank == 0:
+            # RCCL prints a banner through C stdio: flush it first so the JSON is the LAST line of stdout
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            # the detail (every probe, ladder, definition and note) goes to a side file; stdout's LAST line is the compact strict-JSON headline
+            detail_path = args.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+                with open(detail_path, "w") as f:
+                    json.dump(_clean(out, 0), f, allow_nan=False)
+                    f.write("\n")
+                shown = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT + os.sep) else detail_path
+            except OSError as ex:
+                print("bench.py: could not write the detail file %s: %s" % (detail_path, ex), file=sys.stderr)
+                shown = None
+            sys.stdout.write(headline(out, shown) + "\n")
+            sys.stdout.flush()
+
     t_leg = time.perf_counter()
     graph = bool(args.graph) and not use_dist
+    progress("headline")
+    intended_leg = None
     if comm is not None:
         def run_sharded(m):
             return lambda job0, k: eng.run_blocks_sharded(comm, job0, k, root=0, rows=(rows if m == "subband" else None), samples=(m == "samples"))
-        legs[mode] = measure(run_sharded(mode))
-        if world > 1 or os.environ.get("BENCH_ALL_EXCHANGES") == "1":
-            for other in ("subband", "broadcast", "samples"):        # the first real multi-GPU run A/Bs every hand-over
-                if other != mode:
-                    legs[other] = measure(run_sharded(other))
+        # the leg without a collective runs FIRST: if an exchange leg never comes back (the first real multi-GPU run: collectives of one communicator
+        # on four lane streams, a notch ticket spinning beside RCCL's kernels -- DESIGN.md section 6), the line still carries a measured value
+        # (headline_from = "replicate", leg_timeouts says which exchange hung) instead of nothing
+        intended_leg = mode
         legs["replicate"] = measure(lambda job0, k: eng.run_blocks(job0, k))
-        main_leg = mode
+        main_leg = "replicate"
+        # an exchange that FAILS (a HIP / RCCL error out of the engine) is reported and the next hand-over becomes the headline: the
+        # ladder is the intended one, then samples (one stream, no collective on the lane streams), then whichever is left
+        ladder = [mode] + [m for m in ("samples", "broadcast", "subband") if m != mode]
+        if not (world > 1 or os.environ.get("BENCH_ALL_EXCHANGES") == "1"):
+            ladder = ladder[:1]
+        for m in ladder:
+            progress("exchange " + m)
+            try:
+                legs[m] = measure(run_sharded(m))
+                if main_leg == "replicate":
+                    main_leg = m
+            except Exception as ex:                                  # every rank sees the same failure or the next barrier times the leg out
+                exchange_errors[m] = str(ex)[:300]
     else:
-        main_leg = "replicate" if config == 4 else "local"
-        legs[main_leg] = measure(lambda job0, k: eng.run_blocks(job0, k, graph=graph))
+        intended_leg = "replicate" if config == 4 else "local"
+        legs[intended_leg] = measure(lambda job0, k: eng.run_blocks(job0, k, graph=graph))
+        main_leg = intended_leg
     elapsed, times, timing, reps, single = legs[main_leg]
     leg_seconds["headline_and_exchange_legs"] = time.perf_counter() - t_leg
     t_leg = time.perf_counter()
@@ -1429,76 +1569,10 @@ def main():
             except Exception as ex:
                 next_rows.append({"mode": mode, "error": str(ex)[:600]})
         leg_seconds["next_rows"] = time.perf_counter() - t_leg
-    if rank == 0:
-        def leg_obj(name, leg):
-            el, ts, tm, rp, sg = leg
-            return {"ms_per_step": el * 1e3 / args.steps, "value": nch * world * BLOCKTIME / (el / args.steps), "reps": rp, "regions": len(ts),
-                    "ms_per_step_min": min(ts) * 1e3 / args.steps, "ms_per_step_max": max(ts) * 1e3 / args.steps,
-                    "drained_k_step_region_ms_per_step": sg * 1e3 / args.steps,
-                    "gpu_event_ms_per_step": tm.total_ms / tm.blocks, "host_enqueue_ms_per_step": tm.enqueue_ms / tm.blocks}
-        ms_per_step = elapsed * 1e3 / args.steps
-        total_ch = nch * world
-        value = total_ch * BLOCKTIME / (elapsed / args.steps)
-        fwd_copies = world if (config == 5 or main_leg == "replicate") else 1
-        step_bytes = fwd_copies * fwd_bytes(wl["N"], wl["real"]) + total_ch * chan_bytes(P, olen)
-        exchange_desc = None
-        if config == 4:
-            exchange_desc = {
-                "subband": "RCCL grouped ncclSend/ncclRecv of the spectrum rows each rank's channels read (chz_spectrum_exchange_rows), on the slot's HIP stream",
-                "broadcast": "RCCL ncclBroadcast of the whole spectrum slot (chz_spectrum_broadcast), on the slot's HIP stream",
-                "samples": "RCCL ncclBroadcast of the block's L new samples into every rank's input ring on the communicator's stream; every rank runs the forward transform itself",
-                "replicate": "none: every rank transforms its own HBM-resident copy of the samples",
-            }[main_leg] + "; %d rank(s)" % world
-        elif config == 5:
-            exchange_desc = "none (replicas only): %d independent front ends" % world
-        out = {
-            "metric": "channels sustained @%.1f MS/s input (real-time-equivalent: channel-blocks/s / 50)" % (wl["fs"] / 1e6),
-            "value": value, "unit": "channels", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": wl["name"] + (", 1 MI355X" if world == 1 else ""), "baseline_config": config,
-                       "channels_total": total_ch, "P": P, "olen": olen, "N": wl["N"], "L": wl["L"], "M": wl["M"],
-                       "launch": ("hipGraph replays of >= %s blocks" % os.environ.get("CHZ_GRAPH_BLOCKS", "32") if graph else "eager") + ", %d HIP streams, notch recurrence ordered by %s"
-                                 % (eng_lanes, "HIP events" if os.environ.get("CHZ_NOTCH_ORDER") == "event" else "device ticket"),
-                       "plan": eng_plan, "lanes": eng_lanes,
-                       "value_is": "free-running channel-blocks/s / 50 of this configuration, inputs resident in HBM; the literal simultaneous-channel count is c_rt.channels"},
-            "timing": "steady state: median over `regions` timed regions, each = `reps` back-to-back repetitions of the K-step loop "
-                      "(reps*K blocks, barrier+sync on both sides, max over ranks); drained_k_step_region = ONE K-step region on its own, "
-                      "pipeline fill and drain included",
-            "reps": reps, "regions": len(times), "ms_per_step_min": min(times) * 1e3 / args.steps, "ms_per_step_max": max(times) * 1e3 / args.steps,
-            "drained_k_step_region_ms_per_step": single * 1e3 / args.steps,
-            "exchange": exchange_desc, "exchange_mode": (main_leg if config == 4 else None),
-            "legs": {k: leg_obj(k, v) for k, v in legs.items() if k != main_leg} or None,
-            "blocks_per_s": args.steps / elapsed, "realtime_margin": BLOCKTIME / (elapsed / args.steps),
-            "step_algorithmic_GBps": step_bytes / (elapsed / args.steps) / 1e9,
-            "gpu_event_ms_per_step": timing.total_ms / timing.blocks,
-            "host_enqueue_ms_per_step": timing.enqueue_ms / timing.blocks,
-            "roofline": roof, "cpu_baseline": cpu, "c_rt": crt, "c_rt_shared_responses": crt_shared,
-            "dropin": dropin, "dropin_paced": dropin_paced, "dropin_sharded": dropin_sharded, "c_rt_pcie": crt_pcie, "next_rows": next_rows,
-            "leg_seconds": {k: round(v, 1) for k, v in leg_seconds.items()},
-            "rccl_ranks": rccl_ranks, "ranks": ranks_info, "quick": bool(args.quick),
-        }
+    wd["leg"] = None                          # nothing left to watch
     if use_dist:
         dist.destroy_process_group()
-    if rank == 0:
-        # RCCL prints a banner through C stdio: flush it first so the JSON is the LAST line of stdout
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        # the detail (every probe, ladder, definition and note) goes to a side file; stdout's LAST line is the compact strict-JSON headline
-        detail_path = args.detail or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
-        try:
-            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
-            with open(detail_path, "w") as f:
-                json.dump(_clean(out, 0), f, allow_nan=False)
-                f.write("\n")
-            shown = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT + os.sep) else detail_path
-        except OSError as ex:
-            print("bench.py: could not write the detail file %s: %s" % (detail_path, ex), file=sys.stderr)
-            shown = None
-        sys.stdout.write(headline(out, shown) + "\n")
-        sys.stdout.flush()
+    emit(())
 
 
 if __name__ == "__main__":

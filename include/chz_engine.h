@@ -57,6 +57,12 @@ typedef struct chz_timing {
 } chz_timing;
 
 const char *chz_last_error(void);
+/* Options (round 6): dispatch thresholds and test hooks, process-wide, read when an engine / communicator is CREATED.  The shipped
+ * library reads only the operator's environment variables; everything a test or an A/B script used to set
+ * through CHZ_* variables is set here instead.  value NULL or "" = back to the default.  Names: chan_stage, noise_energy, demod_wave
+ * (-1 auto / 0 / 1), enq_threads (1|2|4), graph_blocks, notch_fold (0|1), noise_hint (0|1), pll_lane0 (0|1), notch_wait_ms,
+ * fault_ticket_skew + allow_fault_injection (recovery-path tests), launch_id (chz_comm_create_file).  < 0: unknown name. */
+int chz_set_option(const char *name, const char *value);
 int chz_device_count(void);
 
 /* replaces create_filter_input (src/filter.c:186-269): allocates the device input

@@ -225,6 +225,7 @@ struct chz_engine {
   double* notch_alpha = nullptr; double* notch_state = nullptr;
   hipEvent_t notch_ev[CHZ_NOTCH_EVENTS] = {};
   unsigned notch_seq = 0; bool notch_have = false;      // notch_ev[(notch_seq-1) % 8] is the latest recorded one
+  bool opt_noise_hint = true, opt_pll_lane0 = false, opt_notch_fold = true;      // chz_set_option, read when the engine is created
   int notch_order = 0;                                  // 0: device ticket (default), 1: HIP events (env CHZ_NOTCH_ORDER=event)
   long long notch_max_wait = 0;                         // ticket wait budget, counter ticks (default 3 s; env CHZ_NOTCH_WAIT_MS)
   unsigned* notch_ver = nullptr;                        // device: tickets served so far
@@ -303,16 +304,80 @@ int chz_gather_descriptor(int in_type, int master_bins, int P, int shift, int ou
 // demodulator stream moved (its copies then queue up behind a lane), 12.1 / 12.7 with the PCM copy stream moved as well.  A library
 // cannot set GPU_MAX_HW_QUEUES (the runtime may be up already); what it can do is create these streams through
 // hipExtStreamCreateWithCUMask with EVERY compute unit enabled -- such a stream is given a queue of its own.  The transform lanes keep
-// plain streams: they are exactly the four the runtime has queues for (with every stream masked one driver-command bench run hung).
+// plain streams: they are exactly the four the runtime has queues for (with every stream masked one driver-command bench run hung: a CU-masked
+// stream is a BLOCKING stream, see chz_engine_create -- masked lanes are only to be had with the notch ordered by HIP events).
 // EXPERIMENT knob on top: CHZ_TAIL_CUS=n gives the demodulator stream n of the compute units to itself (spread
 // evenly over the XCDs) and the transform lanes the others -- the partition itself buys nothing (4.20-4.33 ms), see the decision record.
-static int tail_cus() { static const int n = [] { const char* v = getenv("CHZ_TAIL_CUS"); const int k = v ? atoi(v) : 0; return (k > 0 && k < 256) ? k : 0; }(); return n; }
+// ---- options (round 6).  Dispatch thresholds and test hooks are set through the C ABI -- chz_set_option(name, value) before the engine is
+// created -- not through the environment: the shipped libraries read the operator's variables only (CHZ_PLAN,
+// CHZ_STREAMS, CHZ_NOTCH_ORDER, CHZ_OWN_QUEUES, CHZ_RCCL_LIB, CHZ_COMM_TIMEOUT_S and the drop-in's KA9Q_HIP_*); the Python test mirror
+// (ka9q-radio_amd/engine.py) and the C test drivers translate the CHZ_* names the tests use into these calls.  A/B EXPERIMENT hooks
+// (CHZ_TAIL_CUS, CHZ_NO_TWFULL, CHZ_AGC_PEAK, CHZ_CHAN_WPB, CHZ_FWD_BATCH_N, CHZ_GRAPH_NOTCH ...) exist only in builds with -DCHZ_EXPERIMENTS
+// (the A/B targets of the Makefile): CHZ_XENV() is getenv() there and a null pointer in the shipped library.
+#ifdef CHZ_EXPERIMENTS
+#define CHZ_XENV(name) getenv(name)
+#else
+#define CHZ_XENV(name) ((const char*)nullptr)
+#endif
+struct ChzOptions {
+  int chan_stage = -1;        // chan_ifft rows staged through LDS: -1 auto (launches of >= 16384 channels), 0 never, 1 always
+  int noise_energy = -1;      // |X|^2 image for the noise windows: -1 auto, 0 never, 1 always
+  int demod_wave = -1;        // demodulators: -1 auto (lane-per-channel kernels from 65536 channels on), 0 lanes always, 1 wavefront-per-channel always
+  int enq_threads = 2;        // host threads issuing the lanes of chz_run_blocks (1, 2 or 4)
+  int graph_blocks = 32;      // least number of blocks a captured graph covers
+  int notch_fold = 1;         // short notch lists applied inside fwd_rows (0: always the notch_fix kernel)
+  int noise_hint = 1;         // the noise kernel's per-channel binade guess
+  int pll_lane0 = 0;          // 1: the coherent modes' PLL as round 2's one-lane loop inside the demodulator kernel (no scratch block)
+  double notch_wait_ms = 3000.0;  // budget of a device-side ticket wait
+  int fault_ticket_skew = 0;  // fault injection for the hosts' recovery paths: the host's tickets start this far ahead of the device's counter ...
+  int allow_fault_injection = 0;  // ... only with this set as well
+  char launch_id[64] = {0};   // chz_comm_create_file: the id of this launch (ranks of another launch's rendezvous file are refused)
+};
+static ChzOptions g_opt;
+static std::mutex g_opt_mu;
+extern "C" int chz_set_option(const char* name, const char* value) {
+  if (!name) return fail(-1, "null option name");
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  const ChzOptions def{};
+  const bool d = value == nullptr || value[0] == 0;            // null / empty: back to the default
+  const int iv = d ? 0 : atoi(value);
+  const std::string n(name);
+  if (n == "chan_stage") g_opt.chan_stage = d ? def.chan_stage : (iv != 0);
+  else if (n == "noise_energy") g_opt.noise_energy = d ? def.noise_energy : (iv != 0);
+  else if (n == "demod_wave") g_opt.demod_wave = d ? def.demod_wave : (iv != 0);
+  else if (n == "enq_threads") g_opt.enq_threads = d ? def.enq_threads : ((iv == 2 || iv == 4) ? iv : 1);
+  else if (n == "graph_blocks") g_opt.graph_blocks = (d || iv <= 0 || iv > 4096) ? def.graph_blocks : iv;
+  else if (n == "notch_fold") g_opt.notch_fold = d ? def.notch_fold : (value[0] != '0');
+  else if (n == "noise_hint") g_opt.noise_hint = d ? def.noise_hint : (value[0] != '0');
+  else if (n == "pll_lane0") g_opt.pll_lane0 = d ? def.pll_lane0 : 1;
+  else if (n == "notch_wait_ms") g_opt.notch_wait_ms = (d || !(atof(value) > 0)) ? def.notch_wait_ms : atof(value);
+  else if (n == "fault_ticket_skew") g_opt.fault_ticket_skew = d ? 0 : iv;
+  else if (n == "allow_fault_injection") g_opt.allow_fault_injection = d ? 0 : (value[0] == '1');
+  else if (n == "launch_id") snprintf(g_opt.launch_id, sizeof g_opt.launch_id, "%s", d ? "" : value);
+  else return fail(-1, "unknown option '%s'", name);
+  return 0;
+}
+static ChzOptions options() { std::lock_guard<std::mutex> lk(g_opt_mu); return g_opt; }
+
+static int tail_cus() { static const int n = [] { const char* v = CHZ_XENV("CHZ_TAIL_CUS"); const int k = v ? atoi(v) : 0; return (k > 0 && k < 256) ? k : 0; }(); return n; }
 // CHZ_OWN_QUEUES: 0 plain streams everywhere (rounds 1-4), 1 (default) the demodulator stream and the PCM copy stream, 2 every stream the
 // engine launches kernels on
-static int own_queues() { static const int m = [] { const char* v = getenv("CHZ_OWN_QUEUES"); const int k = v ? atoi(v) : 1; return (k >= 0 && k <= 2) ? k : 1; }(); return m; }
+static int own_queues() { static const int m = [] { const char* v = getenv("CHZ_OWN_QUEUES"); const int k = v ? atoi(v) : 1; return (k >= 0 && k <= 4) ? k : 1; }(); return m; }
 static hipError_t stream_create_masked(hipStream_t* s, bool tail) {
 #ifndef HIPEMU
   const int n = tail_cus();
+  // (round 6 A/B) 3 / 4: the demodulator and PCM copy streams as NON-BLOCKING streams of another priority (3 = highest, 4 = lowest): the runtime keeps
+  // a pool of hardware queues per priority, so such a stream does not share a queue with the four normal-priority lanes either -- and, unlike a
+  // CU-masked stream, it IS a hipStreamNonBlocking stream (scripts/micro/masked_stream_blocking.hip, profiles/r06_masked_stream_blocking.txt)
+  if (n == 0 && tail && own_queues() >= 3) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+      const hipError_t r = hipStreamCreateWithPriority(s, hipStreamNonBlocking, own_queues() == 3 ? hi : lo);
+      if (r == hipSuccess) return r;
+      (void)hipGetLastError();
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  }
   if (n > 0 || own_queues() == 2 || (own_queues() == 1 && tail)) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0 && cus <= 1024) {
@@ -388,9 +453,11 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   e->ring_len = (long)ring_blocks * L * e->per;
   HIPOK(stream_create_masked(&e->stream, false));
   e->own_stream = true;
-  if (const char* cs = getenv("CHZ_CHAN_STAGE")) e->chan_stage = atoi(cs) != 0;
-  if (const char* cs = getenv("CHZ_NOISE_ENERGY")) e->noise_energy = atoi(cs) != 0;
-  if (const char* cs = getenv("CHZ_DEMOD_WAVE")) e->demod_wave = atoi(cs) != 0 ? 1 : 0;
+  const ChzOptions opt = options();
+  e->opt_noise_hint = opt.noise_hint != 0; e->opt_pll_lane0 = opt.pll_lane0 != 0; e->opt_notch_fold = opt.notch_fold != 0;
+  if (opt.chan_stage >= 0) e->chan_stage = opt.chan_stage;
+  if (opt.noise_energy >= 0) e->noise_energy = opt.noise_energy;
+  if (opt.demod_wave >= 0) e->demod_wave = opt.demod_wave;
   const char* envl = getenv("CHZ_STREAMS");
   int nl = envl ? atoi(envl) : 4;
   e->nlanes = (nl >= 4) ? 4 : (nl >= 2) ? 2 : 1;             // must divide ND so slot and lane stay aligned
@@ -402,13 +469,18 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
   {
     int khz = 0;                                        // constant-rate counter, kHz (100 MHz on this family)
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, e->device) != hipSuccess || khz <= 0) khz = 100000;
-    double ms = 3000.0;
-    if (const char* w = getenv("CHZ_NOTCH_WAIT_MS")) { const double v = atof(w); if (v > 0) ms = v; }
+    const double ms = opt.notch_wait_ms;
     e->notch_max_wait = (long long)(ms * (double)khz);
   }
-  if (const char* gn = getenv("CHZ_GRAPH_NOTCH")) e->graph_notch_event = strcmp(gn, "event") == 0;
-  if (const char* gb = getenv("CHZ_GRAPH_BLOCKS")) { const int v = atoi(gb); if (v > 0 && v <= 4096) e->graph_min_blocks = v; }
+  if (const char* gn = CHZ_XENV("CHZ_GRAPH_NOTCH")) e->graph_notch_event = strcmp(gn, "event") == 0;
+  e->graph_min_blocks = opt.graph_blocks;
   if (const char* no = getenv("CHZ_NOTCH_ORDER")) e->notch_order = strcmp(no, "event") == 0 ? 1 : (strcmp(no, "unordered-timing-only") == 0 ? 2 : 0);
+  // (round 6) CU-masked LANES are blocking streams -- hipExtStreamCreateWithCUMask takes no flags and makes hipStreamDefault streams, ordered with the
+  // legacy null stream -- and a device-side ticket wait between two blocking streams deadlocks as soon as ANY null-stream operation (a synchronous
+  // hipMemcpy / hipMemset of this engine, torch's default stream in bench.py) lands between the two launches: the waiter spins for a kernel that
+  // queues behind the null-stream operation, which waits for the waiter.  That was round 5's bench run that never came back (reproducer:
+  // scripts/micro/masked_stream_blocking.hip, profiles/r06_masked_stream_blocking.txt).  Masked lanes therefore order the notch by HIP events, always.
+  if ((own_queues() == 2 || tail_cus() > 0) && e->notch_order == 0) e->notch_order = 1;
   HIPOK(hipHostMalloc((void**)&e->notch_err, sizeof(unsigned), hipHostMallocMapped));
   *e->notch_err = 0;
   for (int i = 0; i < e->nlanes; i++) {
@@ -865,7 +937,7 @@ static int enqueue_forward(chz_engine* e, unsigned job, Instr* in, NotchTurn* tu
     ColsParams b{};
     b.in = lbuf; b.in_len = 0; b.in_start = 0; b.out = lbuf; b.rows = p.Ra; b.inner = p.Nc; b.T = p.T2;
     b.padk = p.padk2; b.tw_sub = e->tw_sub_b; b.tw_tile = e->tw2_tile; b.tw_col = e->tw2_col;
-    if (!getenv("CHZ_NO_TWFULL")) b.tw_full = e->tw2_full;
+    if (!CHZ_XENV("CHZ_NO_TWFULL")) b.tw_full = e->tw2_full;
     int grid2 = p.grid2;
 #if CHZ_XCD_AFFINE
     // (experiment build: axis b of a three-axis plan only -- a complex master's first axis goes through launch_cols above, untouched... and
@@ -1180,13 +1252,10 @@ int chz_set_notches_alpha(chz_engine* e, const int* bins, const double* alpha, i
   // fault injection for the hosts' recovery paths (tests/test_dropin.py): the host's tickets start one ahead of the device's counter, so
   // the first notch waits for a turn that never comes, runs out of its budget and raises the error word -- what a wedged predecessor does
   // (a test hook in a production library: it takes TWO variables to arm, so one that leaks into a deployment's environment does nothing)
-  if (const char* fs = getenv("CHZ_FAULT_TICKET_SKEW")) {
-    const char* allow = getenv("CHZ_ALLOW_FAULT_INJECTION");
-    if (allow && allow[0] == '1') e->notch_tickets = (unsigned)atoi(fs);
-  }
+  { const ChzOptions o = options(); if (o.fault_ticket_skew && o.allow_fault_injection) e->notch_tickets = (unsigned)o.fault_ticket_skew; }
   e->n_notch = n;
   e->notch_fold = RowsNotch{};
-  const char* nf = getenv("CHZ_NOTCH_FOLD");
+  const char* nf = e->opt_notch_fold ? nullptr : "0";
 #if CHZ_XCD_AFFINE
   nf = "0";        // the experiment builds remap blockIdx inside fwd_rows; the owner table of the folded notch is made for the default mapping
 #endif
@@ -1457,7 +1526,7 @@ int chz_bank_enable_noise(chz_engine* e, int bank, double samprate) {
   if (!b.n0 && samprate > 0.0) {
     HIPOK(hipMalloc((void**)&b.n0, sizeof(double) * (size_t)CHZ_ND * b.cap));
     HIPOK(hipMemset(b.n0, 0, sizeof(double) * (size_t)CHZ_ND * b.cap));
-    if (!b.noise_hint && !(getenv("CHZ_NOISE_HINT") && getenv("CHZ_NOISE_HINT")[0] == '0')) {
+    if (!b.noise_hint && e->opt_noise_hint) {
       HIPOK(hipMalloc((void**)&b.noise_hint, sizeof(unsigned) * (size_t)b.cap));
       HIPOK(hipMemset(b.noise_hint, 0, sizeof(unsigned) * (size_t)b.cap));
     }
@@ -1602,13 +1671,13 @@ int chz_bank_set_demod(chz_engine* e, int bank, unsigned job, int ch0, int n, co
     HIPOK(hipMemcpy(b.dm_ext, fresh.data(), sizeof(DemodExt) * (size_t)b.cap, hipMemcpyHostToDevice));
     drop_graph(e);
   }
-  if (!b.agc_peak && (e->demod_wave == 0 || (e->demod_wave < 0 && b.cap >= 65536)) && !(getenv("CHZ_AGC_PEAK") && getenv("CHZ_AGC_PEAK")[0] == '0')) {
+  if (!b.agc_peak && (e->demod_wave == 0 || (e->demod_wave < 0 && b.cap >= 65536)) && !(CHZ_XENV("CHZ_AGC_PEAK") && CHZ_XENV("CHZ_AGC_PEAK")[0] == '0')) {
     HIPOK(hipMalloc((void**)&b.agc_peak, sizeof(double) * (size_t)CHZ_ND * b.cap));
     HIPOK(hipMemset(b.agc_peak, 0, sizeof(double) * (size_t)CHZ_ND * b.cap));
     HIPOK(hipDeviceSynchronize());
     drop_graph(e);
   }
-  if ((need_ext || need_fm_mix) && !b.dm_mix && !getenv("CHZ_PLL_LANE0")) {      // (A/B knob: round 2's one-lane-per-channel loops inside the demodulator kernel)
+  if ((need_ext || need_fm_mix) && !b.dm_mix && !e->opt_pll_lane0) {      // (A/B knob: round 2's one-lane-per-channel loops inside the demodulator kernel)
     HIPOK(hipMalloc((void**)&b.dm_mix, sizeof(float2) * (size_t)b.cap * b.olen));
     HIPOK(hipMemset(b.dm_mix, 0, sizeof(float2) * (size_t)b.cap * b.olen));
     HIPOK(hipDeviceSynchronize());
@@ -1928,8 +1997,7 @@ static int lanes_join(chz_engine* e, hipEvent_t* evs) {
 }
 
 static int issue_threads() {
-  static const int n = [] { const char* v = getenv("CHZ_ENQ_THREADS"); int k = v ? atoi(v) : 2; return k == 2 || k == 4 ? k : 1; }();
-  return n;
+  return options().enq_threads;
 }
 
 int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int instrument, chz_timing* timing) {
@@ -1992,7 +2060,7 @@ int chz_run_blocks(chz_engine* e, unsigned job0, int nblocks, int mode, int inst
     if (!in.on && (rc = lanes_fork(e, fork_ev))) return rc;
 #if CHZ_FWD_BATCH
     {   // EXPERIMENT: CHZ_FWD_BATCH_N = 2 or 4 blocks per launch (forward transform only: every bank must be idle); 4 / N batches in flight
-      static const int B = [] { const char* v = getenv("CHZ_FWD_BATCH_N"); const int k = v ? atoi(v) : 0; return (k == 2 || k == 4) ? k : 0; }();
+      static const int B = [] { const char* v = CHZ_XENV("CHZ_FWD_BATCH_N"); const int k = v ? atoi(v) : 0; return (k == 2 || k == 4) ? k : 0; }();
       bool idle = true;
       for (const Bank& bk : e->banks) idle = idle && bk.active == 0;
       if (B && idle && !in.on && job0 % (unsigned)B == 0) {

@@ -356,7 +356,9 @@ inline bool build_chan_geom(int P, ChanGeom& g) {
   g.lpc = g.r.r1 > g.r.r2 ? g.r.r1 : g.r.r2;
   g.cpw = 64 / g.lpc;
   g.wpb = 1;                                   // one wavefront per workgroup: most workgroups, no barrier partners
+#ifdef CHZ_EXPERIMENTS
   if (const char* w = getenv("CHZ_CHAN_WPB")) { int v = atoi(w); if (v == 2 || v == 4) g.wpb = v; }   // experiment knob
+#endif
   g.lds = sizeof(f2) * (size_t)g.wpb * g.cpw * g.r.r1 * (g.r.r2 + 1);
   g.tw_sub = make_tw_sub(g.r.r1, g.r.r2, +1);
   return true;

@@ -48,6 +48,14 @@
 #include "../../include/ka9q_filter_abi.h"
 #include "../../include/chz_engine.h"
 
+/* Environment: the shipped library reads the operator's variables only.  Tuning / A-B hooks of earlier rounds
+   (KA9Q_HIP_WAKE, KA9Q_HIP_WAKE_SHARDS, KA9Q_HIP_BANK_CHANNELS, KA9Q_HIP_MINI, KA9Q_HIP_MINI_POOL) exist in -DCHZ_EXPERIMENTS builds only. */
+#ifdef CHZ_EXPERIMENTS
+#define XENV(name) getenv(name)
+#else
+#define XENV(name) ((const char *)NULL)
+#endif
+
 /* ---- globals the rest of radiod sets or reads (src/filter.c:40-48,476-479) ---- */
 const char *Wisdom_file;
 char const *System_wisdom_file = "/etc/fftw/wisdomf";
@@ -595,26 +603,26 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
     int devs[MAX_SHARDS];
     for (int g = 0; g < c->nsh; g++) devs[g] = c->sh[g].device;
     if (chz_comm_create_local(c->comm, c->nsh, devs) != 0) {
-      fprintf(stderr, "create_filter_input: KA9Q_HIP_EXCHANGE=broadcast: %s\n", chz_last_error());
-      for (int g = 0; g < c->nsh; g++) chz_engine_destroy(c->sh[g].eng);
-      free(c);
-      return -1;
+      /* the ladder (round 6): no in-process RCCL clique -- RCCL missing, a device listed twice, a time-out -- is no reason to come up
+         without a front end: every device copies the samples and transforms them itself, as in the default mode (no collective) */
+      fprintf(stderr, "create_filter_input: KA9Q_HIP_EXCHANGE=broadcast: %s -- falling back to KA9Q_HIP_EXCHANGE=samples\n", chz_last_error());
+      c->bcast = false;
     }
   }
   c->shard_channels = 1024;                                       /* contiguous 1024-blocks */
   { const char *sc = getenv("KA9Q_HIP_SHARD_CHANNELS"); if (sc && atoi(sc) > 0) c->shard_channels = atoi(sc); }
   c->wedged_ms = 10000;
   { const char *wm = getenv("KA9Q_HIP_WEDGED_MS"); if (wm && atoi(wm) >= 500) c->wedged_ms = atoi(wm); }
-  { const char *bc = getenv("KA9Q_HIP_BANK_CHANNELS"); if (bc && atoi(bc) > 0 && atoi(bc) <= 65536) c->bank_cap0 = atoi(bc); }
+  { const char *bc = XENV("KA9Q_HIP_BANK_CHANNELS"); if (bc && atoi(bc) > 0 && atoi(bc) <= 65536) c->bank_cap0 = atoi(bc); }
   /* master->fdomain[] is read by radiod's estimate_noise() (src/radio.c:1801) and by nothing else outside filter.c;
      a host that takes the noise estimate from the device (chz_bank_enable_noise) can switch the 13 MB per-block copy off */
   { const char *fd = getenv("KA9Q_HIP_FDOMAIN"); c->host_spectrum = !(fd && fd[0] == '0'); }
   { const char *fu = getenv("KA9Q_HIP_INPUT_FULL"); c->drop_when_full = fu && strcmp(fu, "drop") == 0; }
   c->wake_first = 0; c->wake_fan = 2;
-  { const char *wk = getenv("KA9Q_HIP_WAKE"); int a = 0, b = 2; if (wk && sscanf(wk, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0) { c->wake_first = a; c->wake_fan = b; } }
+  { const char *wk = XENV("KA9Q_HIP_WAKE"); int a = 0, b = 2; if (wk && sscanf(wk, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0) { c->wake_first = a; c->wake_fan = b; } }
   { const char *pf = getenv("KA9Q_HIP_PROFILE"); c->profile = pf && pf[0] == '1'; }
   c->wshards = 32;
-  { const char *ws = getenv("KA9Q_HIP_WAKE_SHARDS"); if (ws) { int v = atoi(ws); if (v >= 1 && v <= WSHARDS_MAX) c->wshards = v; } }
+  { const char *ws = XENV("KA9Q_HIP_WAKE_SHARDS"); if (ws) { int v = atoi(ws); if (v >= 1 && v <= WSHARDS_MAX) c->wshards = v; } }
   { const char *ns = getenv("KA9Q_HIP_NOISE_SAMPRATE"); if (ns && atof(ns) > 0) c->noise_samprate = atof(ns); }
   pthread_mutex_init(&c->lock, NULL);
   for (int i = 0; i < STAGE_SHARDS; i++) pthread_rwlock_init(&c->stage_lock[i].l, NULL);
@@ -873,6 +881,11 @@ static void recover_engine(struct mctx *c, struct filter_in *f, unsigned job) {
     die_for_the_supervisor("second device failure");
   }
   fprintf(stderr, "filter_hip: device-side failure at block %u (%s): re-creating the engine, in-flight blocks are counted as drops\n", job, why);
+  if (c->bcast) {
+    /* second rung of the ladder: whatever failed, the replacement engines take the path without a collective (every device gets the samples) */
+    fprintf(stderr, "filter_hip: KA9Q_HIP_EXCHANGE=broadcast was in use: the new engines exchange samples instead\n");
+    c->bcast = false;
+  }
   for (int g = 0; g < c->nsh; g++) (void)chz_sync(c->sh[g].eng);   /* every completion callback of the old engines has run after this (each one dropped its block) */
   stage_wrlock(c);
   /* the overlap history in front of this block's new samples: the first M-1 samples of its window in the host ring */

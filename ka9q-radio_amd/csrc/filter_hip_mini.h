@@ -52,7 +52,7 @@ static struct minipool *Mini_pools;
 
 static bool smooth235(int n) { for (int p = 2; p <= 5; p++) while (p != 4 && n % p == 0) n /= p; return n == 1; }
 static bool mini_wanted(int L, int M, enum filtertype in_type) {
-  const char *e = getenv("KA9Q_HIP_MINI");
+  const char *e = XENV("KA9Q_HIP_MINI");
   if (e && e[0] == '0') return false;
   int const N = L + M - 1;
   return in_type == COMPLEX && N >= 8 && N <= 8192 && smooth235(N);
@@ -67,7 +67,7 @@ static struct minipool *mini_pool_for(int L, int M) {
   if (!p) {
     p = calloc(1, sizeof *p);
     if (p) {
-      const char *e = getenv("KA9Q_HIP_MINI_POOL");
+      const char *e = XENV("KA9Q_HIP_MINI_POOL");
       const char *dev = getenv("KA9Q_HIP_DEVICE");
       p->L = L; p->M = M; p->cap = e && atoi(e) > 0 ? atoi(e) : 1024;
       if (chz_mini_create(&p->h, L, M, p->cap, dev ? atoi(dev) : 0) != 0) {

@@ -66,8 +66,23 @@ SYMBOLS = [
     "chz_comm_unique_id", "chz_comm_create", "chz_comm_create_file", "chz_comm_destroy", "chz_comm_rank", "chz_comm_world",
     "chz_mini_create", "chz_mini_destroy", "chz_mini_capacity", "chz_mini_add", "chz_mini_release", "chz_mini_set_response", "chz_mini_execute",
     "chz_comm_barrier", "chz_comm_allreduce_max", "chz_spectrum_broadcast", "chz_spectrum_exchange_rows", "chz_run_blocks_sharded",
-    "chz_comm_create_local", "chz_spectrum_broadcast_local",
+    "chz_comm_create_local", "chz_spectrum_broadcast_local", "chz_set_option",
 ]
+
+# the CHZ_* variables tests and scripts have always used to force a code path or arm a test hook: the shipped library does not read
+# them (its options are set through chz_set_option, include/chz_engine.h) -- this mirror translates them whenever an engine, a pool
+# or a communicator is created, so that a variable set by a test (monkeypatch.setenv) means what it always meant
+ENV_OPTIONS = {"CHZ_CHAN_STAGE": "chan_stage", "CHZ_NOISE_ENERGY": "noise_energy", "CHZ_DEMOD_WAVE": "demod_wave", "CHZ_ENQ_THREADS": "enq_threads",
+               "CHZ_GRAPH_BLOCKS": "graph_blocks", "CHZ_NOTCH_FOLD": "notch_fold", "CHZ_NOISE_HINT": "noise_hint", "CHZ_PLL_LANE0": "pll_lane0",
+               "CHZ_NOTCH_WAIT_MS": "notch_wait_ms", "CHZ_FAULT_TICKET_SKEW": "fault_ticket_skew", "CHZ_ALLOW_FAULT_INJECTION": "allow_fault_injection",
+               "CHZ_LAUNCH_ID": "launch_id"}
+
+
+def apply_env_options():
+    L = lib()
+    for env, opt in ENV_OPTIONS.items():
+        v = os.environ.get(env)
+        _check(L.chz_set_option(opt.encode(), v.encode() if v is not None else None))
 
 _lib = None
 
@@ -86,6 +101,7 @@ def lib():
             raise RuntimeError("%s is a CPU-emulated TEST build of the engine: refusing to use it as the product "
                                "(there is no CPU fallback)" % LIB_PATH)
         L.chz_last_error.restype = C.c_char_p
+        L.chz_set_option.argtypes = [C.c_char_p, C.c_char_p]
         L.chz_device_count.restype = _i
         L.chz_engine_create.argtypes = [C.POINTER(_vp), _i, _i, _i, _i, C.c_char_p, _i]
         L.chz_engine_destroy.argtypes = [_vp]; L.chz_engine_destroy.restype = None
@@ -177,6 +193,7 @@ class Engine:
 
     def __init__(self, L, M, in_type, device=0, plan="", ring_blocks=0):
         self._h = _vp()
+        apply_env_options()
         _check(lib().chz_engine_create(C.byref(self._h), L, M, in_type, device,
                                        plan.encode() if plan else None, ring_blocks))
         info = ChzInfo()
@@ -493,6 +510,7 @@ class Comm:
     def __init__(self, rank, world, uid=None, device=0, path=None, timeout_s=120.0):
         self._h = _vp()
         if path is not None:
+            apply_env_options()
             _check(lib().chz_comm_create_file(C.byref(self._h), rank, world, path.encode(), device, float(timeout_s)))
         else:
             buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(uid)

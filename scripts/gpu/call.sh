@@ -9,6 +9,26 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r6f)       # round 6: the demodulator / PCM copy streams on a hardware queue of their own WITHOUT being blocking streams: priority streams (3 = high, 4 = low)
+             # against CU-masked (1, round 5's default) and plain (0): the 8f chain at 1.5 M channels and the double-buffered PCIe probe; the bench watchdog test
+    PC="--no-crt --no-dropin --no-dropin-paced --no-cpu-baseline --no-next-rows"
+    NR="--no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear"
+    for rep in 1 2; do for q in 0 1 3 4; do
+      CHZ_OWN_QUEUES=$q BENCH_NO_STREAMED=1 timeout 200 $B $NR --detail "$out/chain_q${q}_$rep.json" > /dev/null 2>> "$out/err.txt"
+      CHZ_OWN_QUEUES=$q BENCH_PCIE_PROBES=2 BENCH_NO_STREAMED=1 timeout 200 $B $PC --detail "$out/pcie_q${q}_$rep.json" > /dev/null 2>> "$out/err.txt"
+    done; done
+    python - "$out" <<'PY'
+import json, sys, glob, os
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/pcie_*.json")):
+    d = json.load(open(f))
+    print(os.path.basename(f), [(x["channels"], round(x["worst_block_ms"], 2), round(x["mean_block_ms"], 2), x.get("blocks_over_20ms"), round(x.get("p99_block_ms") or 0, 2)) if "error" not in x else x for x in d["c_rt_pcie"]])
+for f in sorted(glob.glob(out + "/chain_*.json")):
+    j = json.load(open(f))
+    print(os.path.basename(f), [(x.get("mode"), round(x.get("pipelined_ms_per_block", 0), 3), x.get("pcm_mismatches")) if "error" not in x else x for x in (j.get("next_rows") or [])], "headline us/step", round(j["ms_per_step"] * 1e3, 2))
+PY
+    timeout 400 python -m pytest tests/test_bench_contract.py -m gpu -q -k "never_comes_back" --timeout 300 2>&1 | tail -5
+    ;;
   r6e)       # round 6: descriptors refreshed by a kernel (desc_push) instead of hipMemcpyAsync: is block 1's 8 ms stall gone?  mini-radiod with fading signals
     timeout 300 python scripts/block0_probe.py 60 > "$out/block0_probe.jsonl" 2> "$out/block0_probe.err"; echo "block0 rc=$?" >> "$out/rc.txt"
     python -c "

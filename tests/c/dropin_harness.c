@@ -195,6 +195,15 @@ int main(int argc, char **argv) {
   f = fopen(path, "rb");
   if (!f || fread(Plan, sizeof *Plan, (size_t)Nch, f) != (size_t)Nch) { perror("plan"); return 1; }
   fclose(f);
+  /* the engine library does not read test variables from the environment (include/chz_engine.h: chz_set_option): the harness hands them over */
+  {
+    extern int chz_set_option(const char *, const char *);
+    static const char *const map[][2] = {{"CHZ_NOTCH_WAIT_MS", "notch_wait_ms"}, {"CHZ_FAULT_TICKET_SKEW", "fault_ticket_skew"},
+                                          {"CHZ_ALLOW_FAULT_INJECTION", "allow_fault_injection"}, {"CHZ_ENQ_THREADS", "enq_threads"},
+                                          {"CHZ_NOTCH_FOLD", "notch_fold"}, {"CHZ_CHAN_STAGE", "chan_stage"}};
+    for (size_t i = 0; i < sizeof map / sizeof map[0]; i++)
+      if (getenv(map[i][0])) chz_set_option(map[i][1], getenv(map[i][0]));
+  }
   if (getenv("HARNESS_INPUT_BLOCKS")) Input_blocks = atoi(getenv("HARNESS_INPUT_BLOCKS"));
   if (getenv("HARNESS_KEEP")) Keep = atoi(getenv("HARNESS_KEEP")) != 0;
   if (Input_blocks <= 0 || Input_blocks > Nblocks) Input_blocks = Nblocks;

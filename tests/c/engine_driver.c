@@ -30,6 +30,7 @@ static void *mini_thread(void *a) {
 int main(void) {
   chz_engine *e = NULL;
   int const L = 25920, M = 6481, P = 300, olen = 240, nch = 8;
+  if (getenv("CHZ_ENQ_THREADS")) OK(chz_set_option("enq_threads", getenv("CHZ_ENQ_THREADS")));      /* (options are an API, not environment variables) */
   OK(chz_engine_create(&e, L, M, CHZ_REAL, 0, NULL, 8));
   int const plain = chz_bank_create(e, P, olen, nch), tuned = chz_bank_create(e, P, olen, nch);
   if (plain < 0 || tuned < 0) { fprintf(stderr, "bank: %s\n", chz_last_error()); return 2; }

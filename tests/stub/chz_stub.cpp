@@ -71,6 +71,7 @@ static std::atomic<int> g_instances{0};     // engines created by this process s
 extern "C" {
 
 const char* chz_last_error(void) { return g_err; }
+int chz_set_option(const char*, const char*) { return 0; }      /* the stand-in has no dispatch to steer */
 // CHZ_STUB_DEVICES=n: the stand-in reports n devices (the drop-in's KA9Q_HIP_DEVICES sharding runs over n independent engines)
 int chz_device_count(void) { const char* v = getenv("CHZ_STUB_DEVICES"); const int n = v ? atoi(v) : 1; return n > 0 ? n : 1; }
 
@@ -199,8 +200,12 @@ int chz_host_callback(chz_engine* e, int, void (*fn)(void*), void* arg) {
 // the in-process clique of the drop-in's KA9Q_HIP_EXCHANGE=broadcast: a communicator is just its rank here; the broadcast is a task on
 // the root's queue (behind its forward transform) that hands the slot to a task on every other engine's queue (in front of its banks)
 struct chz_comm { int rank, world, device; };
+// fault injection for the drop-in's exchange ladder: CHZ_STUB_FAIL_COMM=1 -- no clique can be formed; CHZ_STUB_FAIL_BCAST_CALL=n -- the n-th
+// broadcast of the process reports an error (as an RCCL call that returns ncclSystemError would)
+static std::atomic<int> g_bcast_calls{0};
 int chz_comm_create_local(chz_comm** out, int n, const int* devices) {
   if (!out || !devices || n < 1) return fail(-1, "bad argument");
+  if (getenv("CHZ_STUB_FAIL_COMM")) return fail(-6, "chz_stub: injected communicator failure (ncclCommInitAll timed out)");
   for (int i = 0; i < n; i++) {
     if (devices[i] < 0 || devices[i] >= chz_device_count()) return fail(-2, "device %d is not visible", devices[i]);
     for (int k = 0; k < i; k++) if (devices[k] == devices[i]) return fail(-2, "device %d is listed twice: an RCCL clique needs one communicator per device", devices[i]);
@@ -212,6 +217,7 @@ void chz_comm_destroy(chz_comm* c) { delete c; }
 int chz_spectrum_broadcast_local(chz_engine* const* engines, chz_comm* const* comms, int n, int slot, int root) {
   if (!engines || !comms || n < 1 || slot < 0 || slot >= CHZ_ND || root < 0 || root >= n) return fail(-1, "bad argument");
   for (int i = 0; i < n; i++) if (!engines[i] || !comms[i] || comms[i]->rank != i || comms[i]->world != n) return fail(-1, "not this clique");
+  if (const char* fb = getenv("CHZ_STUB_FAIL_BCAST_CALL")) if (g_bcast_calls.fetch_add(1) + 1 == atoi(fb)) return fail(-6, "chz_stub: injected broadcast failure (ncclSystemError)");
   struct Box { std::mutex m; std::condition_variable cv; bool ready = false; std::vector<float> data; };
   auto box = std::make_shared<Box>();
   chz_engine* r = engines[root];

@@ -269,3 +269,18 @@ def test_crt_search_decisions_on_a_modelled_device(ns_per_channel, spike_at):
     limit = min(true_cross, spike_at or 1e18, eng.cap + wl["nch"])
     assert r["channels"] <= limit and r["channels"] >= limit - 270_000 - 3072, (r["channels"], limit)     # within one 0.25 M grid step of the truth
     assert len(r["calibration"]) == 2 and 1 <= r["rungs"] <= 14
+
+
+@pytest.mark.gpu
+def test_a_leg_that_never_comes_back_costs_its_own_numbers_not_the_line(tmp_path):
+    """round 5: one bench run (every engine stream CU-masked) never came back and cost the whole record.  Every leg now has a time budget
+    and a watchdog THREAD (the main thread may sit inside a HIP call): the leg that overruns is named in the line, the run ends with rc 0
+    and the legs that did finish are in it.  BENCH_TEST_HANG_LEG makes the named leg hang; the budget is cut to 4 s."""
+    env = dict(os.environ, BENCH_TEST_HANG_LEG="c_rt", BENCH_LEG_BUDGET_S="4")
+    h, j = _run_bench(["--quick", "--steps", "20", "--warmup", "5"], tmp_path, timeout=300, env=env)
+    assert h["leg_timeouts"] == ["c_rt"] and h["headline_from"] == "local"
+    assert h["value"] > 0 and h["roofline"]["frac"] > 0 and h["c_rt"] is None        # what ran before the hang is in the line
+    # ... and when the HEADLINE leg itself hangs there is still one strict line, with a null value, rc 0
+    env = dict(os.environ, BENCH_TEST_HANG_LEG="headline", BENCH_LEG_BUDGET_S="4")
+    h, j = _run_bench(["--quick", "--steps", "20", "--warmup", "5"], tmp_path, timeout=300, env=env)
+    assert h["leg_timeouts"] == ["headline"] and h["value"] is None and h["roofline"] is None

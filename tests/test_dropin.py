@@ -685,4 +685,6 @@ def test_dropin_broadcast_exchange_clique_of_one():
         _check(L, M, olen, P, plan, nblocks, out, spec, meta, x)
         exe = os.path.join(tmp, "harness")
         r = subprocess.run([exe, tmp], capture_output=True, text=True, timeout=300, env=dict(os.environ, KA9Q_HIP_DEVICES="0,0", KA9Q_HIP_EXCHANGE="broadcast"))
-        assert r.returncode == 3 and "listed twice" in r.stderr, (r.returncode, r.stderr[-500:])
+        # round 6, the ladder: no clique (RCCL refuses one device twice) is no reason to come up without a front end -- every shard copies the
+        # samples and transforms them itself, and the run completes
+        assert r.returncode == 0 and "listed twice" in r.stderr and "falling back to KA9Q_HIP_EXCHANGE=samples" in r.stderr, (r.returncode, r.stderr[-500:])

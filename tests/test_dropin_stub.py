@@ -49,7 +49,7 @@ def _build_once(san, out_dir):
     subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", flag, os.path.join(STUB, "chz_stub.cpp"), "-o", os.path.join(out_dir, "libchz_hip.so"),
                     "-L", os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread"], check=True)
     subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", "-fPIC", "-shared", flag, "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-maybe-uninitialized",
-                    os.path.join(CSRC, "filter_hip.c"), "-o", os.path.join(out_dir, "libka9q_filter_hip.so"),
+                    "-DCHZ_EXPERIMENTS=1", os.path.join(CSRC, "filter_hip.c"), "-o", os.path.join(out_dir, "libka9q_filter_hip.so"),
                     "-L", out_dir, "-lchz_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"], check=True)
     exe = os.path.join(out_dir, "harness")
     subprocess.run(["gcc", "-O1", "-g", "-std=gnu11", flag, "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "dropin_harness.c"), "-o", exe,
@@ -452,7 +452,52 @@ def test_dropin_sharded_refuses_a_device_that_is_not_there(tmp_path):
     r = _run(exe, run_dir, L, M, olen, _plan(np.random.default_rng(1), 4), 2, x, {"CHZ_STUB_DEVICES": "2", "KA9Q_HIP_DEVICES": "0,5"})
     assert r.returncode == 3 and "device 5" in r.stderr                # create_filter_input fails loudly, nothing runs on fewer devices than asked
     r = _run(exe, run_dir, L, M, olen, _plan(np.random.default_rng(1), 4), 2, x, {"CHZ_STUB_DEVICES": "2", "KA9Q_HIP_DEVICES": "0,0", "KA9Q_HIP_EXCHANGE": "broadcast"})
-    assert r.returncode == 3 and "listed twice" in r.stderr            # an RCCL clique cannot hold one device twice
+    # an RCCL clique cannot hold one device twice: round 6's ladder falls back to the sample exchange instead of refusing to start
+    assert r.returncode == 0 and "listed twice" in r.stderr and "falling back to KA9Q_HIP_EXCHANGE=samples" in r.stderr, (r.returncode, r.stderr[-800:])
+
+
+@pytest.mark.parametrize("fault", [{"CHZ_STUB_FAIL_COMM": "1"}, {"CHZ_STUB_FAIL_BCAST_CALL": "7"}], ids=["no_clique_at_start", "a_broadcast_fails_mid_stream"])
+def test_dropin_exchange_ladder_broadcast_to_samples(tmp_path, fault):
+    """SURVEY 8e behind filter.h, fail-safe (round 6): KA9Q_HIP_EXCHANGE=broadcast that cannot form its clique comes up with the sample
+    exchange; a broadcast that FAILS mid-stream (an RCCL error out of the engine) takes the recovery path -- engines re-created, the blocks
+    in flight counted as drops -- and the replacement engines exchange samples.  Three stand-in devices; every channel's output of the
+    blocks after the recovery against the oracle."""
+    exe = _build_plain(str(tmp_path / "build"))
+    L, M, olen, P = 25920, 6481, 480, 600
+    ndev, nblocks = 3, 16
+    nch = 24 * ndev
+    rng = np.random.default_rng(91)
+    g = ol.SigGen(100020.0 / 1.296e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = [(int(rng.integers(-12000, 12000)),) * 2 + (10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4) for _ in range(nch)]
+    env = {"CHZ_STUB_DEVICES": str(ndev), "KA9Q_HIP_DEVICES": "0,1,2", "KA9Q_HIP_SHARD_CHANNELS": "24", "KA9Q_HIP_EXCHANGE": "broadcast", "HARNESS_RECORD_DROPS": "1"}
+    env.update(fault)
+    run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
+    r = _run(exe, run_dir, L, M, olen, plan, nblocks, x, env)
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    out = np.fromfile(os.path.join(run_dir, "out.bin"), np.complex64).reshape(nblocks, nch, olen)
+    meta = open(os.path.join(run_dir, "meta.txt")).read().split()
+    meta = dict(zip(meta[::2], meta[1::2]))
+    if "CHZ_STUB_FAIL_COMM" in fault:
+        assert "falling back to KA9Q_HIP_EXCHANGE=samples" in r.stderr and meta["drops"] == "0"
+        first_good = 0
+    else:
+        assert "the new engines exchange samples instead" in r.stderr and int(meta["drops"]) > 0
+        first_good = 12                                     # the overlap history is re-seated from the host ring: exact again well before this
+    st = ol.Stream(L, M, ol.REAL)
+    state = np.zeros(2)
+    for b in range(nblocks):
+        s64 = st.push(x[b * L:(b + 1) * L], f64=True)
+        dc = s64[:1].astype(np.complex64); ol.notch(state, [0], 0.01, dc); s64[0] = dc[0]
+        if b < first_good:
+            continue
+        for i, pl in enumerate(plan):
+            if first_good and abs(pl[0]) <= P // 2 + 1:
+                continue                    # a channel over the DC bin: the spur notch's state (alpha 0.01, a 100-block memory) restarted with the new engines
+            resp = ol.set_filter(P, olen, L + M - 1, True, -0.4, 0.4, 11.0)
+            want = ol.channel(s64, ol.REAL, P, olen, pl[0], resp)
+            err = float(np.sqrt(np.mean(np.abs(out[b, i] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
+            assert err <= 1e-4 * rms + 1e-9, (b, i, err, rms)
 
 
 def _build_plain(out_dir):
@@ -469,7 +514,7 @@ def _build_plain_once(out_dir):
     subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", os.path.join(STUB, "chz_stub.cpp"), "-o", os.path.join(out_dir, "libchz_hip.so"),
                     "-L", os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread"], check=True)
     subprocess.run(["gcc", "-O2", "-std=gnu11", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-maybe-uninitialized",
-                    os.path.join(CSRC, "filter_hip.c"), "-o", os.path.join(out_dir, "libka9q_filter_hip.so"),
+                    "-DCHZ_EXPERIMENTS=1", os.path.join(CSRC, "filter_hip.c"), "-o", os.path.join(out_dir, "libka9q_filter_hip.so"),
                     "-L", out_dir, "-lchz_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"], check=True)
     exe = os.path.join(out_dir, "harness")
     subprocess.run(["gcc", "-O2", "-std=gnu11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "dropin_harness.c"), "-o", exe,

@@ -162,3 +162,26 @@ def test_compute_tuning_property(N, fs, f):
     # rem = f - shift*hz is formed in float64: it carries a few ulp of f (and of shift*hz), not of hz
     assert abs(rem) <= hz / 2 + 8 * np.finfo(np.float64).eps * max(abs(f), hz)
     assert (r != 0) == (abs(shift) >= N // 2)
+
+
+def test_the_shipped_libraries_read_the_operators_variables_only():
+    """round 5 shipped 39 getenv() knobs, most of them A/B and experiment hooks.  The libraries now read the operator's set
+     and nothing else: test hooks and dispatch thresholds go through chz_set_option (include/chz_engine.h),
+    experiment hooks are compiled in by -DCHZ_EXPERIMENTS only.  Counted in the built objects, not in the sources."""
+    import re
+    import subprocess
+    pkg = os.path.join(ROOT, "ka9q-radio_amd")
+    subprocess.run(["make", "-s", "-C", os.path.join(pkg, "csrc"), "all"], check=True)
+    seen = {}
+    for lib in ("libchz_hip.so", "libka9q_filter_hip.so"):
+        out = subprocess.run(["strings", os.path.join(pkg, lib)], capture_output=True, text=True, check=True).stdout
+        seen[lib] = sorted(set(re.findall(r"^(?:CHZ|KA9Q)_[A-Z0-9_]+$", out, re.M)))
+    assert seen["libchz_hip.so"] == ["CHZ_COMM_TIMEOUT_S", "CHZ_NOTCH_ORDER", "CHZ_OWN_QUEUES", "CHZ_PLAN", "CHZ_RCCL_LIB", "CHZ_STREAMS"], seen
+    assert seen["libka9q_filter_hip.so"] == ["KA9Q_HIP_DEVICE", "KA9Q_HIP_DEVICES", "KA9Q_HIP_EXCHANGE", "KA9Q_HIP_FDOMAIN", "KA9Q_HIP_INPUT_FULL",
+                                             "KA9Q_HIP_NOISE_SAMPRATE", "KA9Q_HIP_PROFILE", "KA9Q_HIP_SHARD_CHANNELS", "KA9Q_HIP_WEDGED_MS"], seen
+    assert sum(len(v) for v in seen.values()) <= 16
+    # ... and every one of them is in INTEGRATION.md's table
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for names in seen.values():
+        for n in names:
+            assert "`%s`" % n in doc, n
