@@ -180,6 +180,13 @@ template <int N_> __device__ __forceinline__ float row_shr16(float v) {
 #ifndef CHZ_FM_WAVES
 #define CHZ_FM_WAVES 3
 #endif
+#ifndef CHZ_FM_DISC_UNROLL
+#define CHZ_FM_DISC_UNROLL 1        // demod_fm_lanes: samples whose discriminator phases (double atan2) are computed side by side.  Measured at 1.5 M channels
+                                    // (round 6, profiles/r06_fm_disc_unroll.txt; A/B builds: make ../libchz_hip_fmd2.so, _fmd4.so, _fmd8.so): 1 -> 1.93-1.98 ns per
+                                    // channel, 2 -> 1.99-2.01, 4 -> 2.13-2.17, 8 -> 2.49-2.50 (4 at 2 wavefronts per SIMD, no spills: 1.91-1.93): the pass is
+                                    // bound by vector ISSUE (~300 instructions per sample, a third of them the atan2), not by the latency of its chains --
+                                    // overlapping the chains buys nothing and the extra live registers cost spills.  Ships 1 = round 5's loop.
+#endif
 #ifndef CHZ_XCD_AFFINE
 #define CHZ_XCD_AFFINE 0
 #endif
@@ -2875,10 +2882,16 @@ __global__ void __launch_bounds__(64, CHZ_FM_WAVES) demod_fm_lanes(DemodParams p
   double pr = st.pm_re, pi = st.pm_im;
   double p0 = pr * pr + pi * pi;                           // cnrm(phase_memory)
   if (p0 > 0) p0 /= (p0 + beta * noise);
-  auto discriminate = [&](const float2 v) -> float {
+  // (round 6) split in two: disc_phase() is the long part -- a double-precision atan2 -- and depends on nothing but the sample and its
+  // predecessor; disc_commit() is the reference's sequential part (threshold extension, sums, extremes, phase_memory).  The loops below take
+  // CHZ_FM_DISC_UNROLL samples at a time: their atan2 chains are independent and overlap, the commits then run in sample order -- the same
+  // operations on the same values as one sample at a time (bit-identical), the dependent-latency chain per sample a fraction of it.
+  auto disc_phase = [&](const float2 v, const double qr, const double qi) -> double {
     const double br = v.x, bi = v.y;
-    const double sr = br * pr + bi * pi, si = bi * pr - br * pi;
-    double phase = M_1_PI * atan2(si, sr);
+    const double sr = br * qr + bi * qi, si = bi * qr - br * qi;
+    return M_1_PI * atan2(si, sr);
+  };
+  auto disc_commit = [&](const float2 v, double phase) -> float {
     if (extend) {
       if (fabs(phase) > devmax / samprate) phase = copysign(devmax / samprate, phase);
       float a = v.x * v.x, b = v.y * v.y; CHZ_ROUNDED_F32(a); CHZ_ROUNDED_F32(b);
@@ -2892,9 +2905,10 @@ __global__ void __launch_bounds__(64, CHZ_FM_WAVES) demod_fm_lanes(DemodParams p
     psum += bbv;
     if (bbv > pmax) pmax = bbv;
     if (bbv < pmin) pmin = bbv;
-    pr = br; pi = bi;
+    pr = v.x; pi = v.y;
     return bbf;
   };
+  auto discriminate = [&](const float2 v) -> float { return disc_commit(v, disc_phase(v, pr, pi)); };
   // ---- SNR (:105-129).  The variance estimator walks the block twice (mean amplitude, then the variance around it); the second walk
   // carries the discriminator along SPECULATIVELY (round 4): a channel that needs the estimator has its squelch open or opening, so
   // the discriminator will almost always be wanted, and its pass over the baseband -- a third read of the block -- is saved.  Nothing
@@ -2913,7 +2927,24 @@ __global__ void __launch_bounds__(64, CHZ_FM_WAVES) demod_fm_lanes(DemodParams p
         CHZ_WAVE_SYNC();
         if (t0 + LIN_TILE < N) fetch_x(t0 + LIN_TILE, var_rows);
         if (need_var) {
-          for (int n = 0; n < tn; n++) {
+          int n = 0;
+#if CHZ_FM_DISC_UNROLL > 1
+          if (pass == 1)
+            for (; n + CHZ_FM_DISC_UNROLL <= tn; n += CHZ_FM_DISC_UNROLL) {
+              float2 v[CHZ_FM_DISC_UNROLL]; double ph[CHZ_FM_DISC_UNROLL];
+#pragma unroll
+              for (int u = 0; u < CHZ_FM_DISC_UNROLL; u++) v[u] = tile[lane * LD + n + u];
+#pragma unroll
+              for (int u = 0; u < CHZ_FM_DISC_UNROLL; u++) ph[u] = u ? disc_phase(v[u], (double)v[u - 1].x, (double)v[u - 1].y) : disc_phase(v[0], pr, pi);
+#pragma unroll
+              for (int u = 0; u < CHZ_FM_DISC_UNROLL; u++) {
+                const double a = (double)demod_cabsf(v[u]);
+                const double dlt = a - avg; var += dlt * dlt;
+                tile[lane * LD + n + u].x = disc_commit(v[u], ph[u]);
+              }
+            }
+#endif
+          for (; n < tn; n++) {
             const float2 v = tile[lane * LD + n];
             const double a = (double)demod_cabsf(v);
             if (pass == 0) avg += a;
@@ -2969,8 +3000,21 @@ __global__ void __launch_bounds__(64, CHZ_FM_WAVES) demod_fm_lanes(DemodParams p
       place_x();
       CHZ_WAVE_SYNC();
       if (t0 + LIN_TILE < N) fetch_x(t0 + LIN_TILE, late_rows);
-      if (late)
-        for (int n = 0; n < tn; n++) tile[lane * LD + n].x = discriminate(tile[lane * LD + n]);
+      if (late) {
+        int n = 0;
+#if CHZ_FM_DISC_UNROLL > 1
+        for (; n + CHZ_FM_DISC_UNROLL <= tn; n += CHZ_FM_DISC_UNROLL) {
+          float2 v[CHZ_FM_DISC_UNROLL]; double ph[CHZ_FM_DISC_UNROLL];
+#pragma unroll
+          for (int u = 0; u < CHZ_FM_DISC_UNROLL; u++) v[u] = tile[lane * LD + n + u];
+#pragma unroll
+          for (int u = 0; u < CHZ_FM_DISC_UNROLL; u++) ph[u] = u ? disc_phase(v[u], (double)v[u - 1].x, (double)v[u - 1].y) : disc_phase(v[0], pr, pi);
+#pragma unroll
+          for (int u = 0; u < CHZ_FM_DISC_UNROLL; u++) tile[lane * LD + n + u].x = disc_commit(v[u], ph[u]);
+        }
+#endif
+        for (; n < tn; n++) tile[lane * LD + n].x = discriminate(tile[lane * LD + n]);
+      }
       CHZ_WAVE_SYNC();
       for (int r0 = 0; r0 < 64; r0 += RPS) {
         const int rr = r0 + lane / LIN_TILE, n = lane % LIN_TILE;

@@ -9,6 +9,25 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r6h)       # round 6: demod_fm_lanes' discriminator phases 1 / 2 / 4 (shipped) / 8 samples side by side, and 2 wavefronts per SIMD: the FM chain at 1.5 M channels
+    for rep in 1 2; do for v in default fmd1 fmd2 fmd8 fmw2; do
+      L=""; [ $v != default ] && L=$PWD/ka9q-radio_amd/libchz_hip_$v.so
+      CHZ_LIB=$L timeout 200 python scripts/chain_profile.py fm 1500000 >> "$out/fm_$v.jsonl" 2>> "$out/err.txt"
+    done; done
+    for v in default fmd1 fmd2 fmd8 fmw2; do echo "$v: $(cat $out/fm_$v.jsonl | python -c "
+import sys, json
+for ln in sys.stdin:
+    r = json.loads(ln); print(round(r['pipelined_ms_per_block'], 3), round(r['ns_per_channel']['demodulator_and_pcm'], 3), r['pcm_mismatches'], end=' | ')
+")"; done
+    ;;
+  r6g)       # round 6: the whole GPU suite + smoke + the driver's command after the options / desc_push / watchdog changes
+    timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -x > "$out/gpu_suite.txt" 2>&1; echo "suite rc=$?" >> "$out/rc.txt"
+    tail -8 "$out/gpu_suite.txt"
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.txt" 2>&1; tail -1 "$out/smoke.txt"
+    timeout 600 $B > "$out/bench_stdout.txt" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/rc.txt"
+    tail -n 1 "$out/bench_stdout.txt" > "$out/bench_headline.json"; cp gpurun_out/bench_detail.json "$out/bench_detail.json" 2>/dev/null
+    wc -c "$out/bench_headline.json"; grep "^bench.py \[" "$out/bench.err" | tail -14; cat "$out/rc.txt"
+    ;;
   r6f)       # round 6: the demodulator / PCM copy streams on a hardware queue of their own WITHOUT being blocking streams: priority streams (3 = high, 4 = low)
              # against CU-masked (1, round 5's default) and plain (0): the 8f chain at 1.5 M channels and the double-buffered PCIe probe; the bench watchdog test
     PC="--no-crt --no-dropin --no-dropin-paced --no-cpu-baseline --no-next-rows"
@@ -335,14 +354,19 @@ PY
     $B --no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline > "$out/next_rows.json" 2> "$out/err.txt"; echo "bench rc=$?" >> "$out/rc.txt"
     timeout 1200 python -m pytest tests/test_gpu_scale.py tests/test_gpu_pipeline.py tests/test_golden.py -m gpu -x -q --timeout 600 -k "demod or scale or 70001 or golden or coherent or fm" > "$out/demod_tests.txt" 2>&1; echo "tests rc=$?" >> "$out/rc.txt"
     ;;
-  chainpmc)  # SQ counters for the 8f chain's kernels at 1.5 M channels (linear leg only: chan_ifft<EPI 1>, noise_est, demod_lin_lanes), one --pmc set per pass
+  chainpmc)  # SQ counters for the 8f chain's kernels (tuned chan_ifft, noise_est, demod_lin_lanes / pll_lanes / demod_fm_lanes), one --pmc set per pass and mode.
+             # round 6: scripts/chain_profile.py runs ONE mode's chain on 300,000 channels and nothing else (bench.py's leg sits behind the headline loops,
+             # tens of thousands of launches that a counter pass serialises: round 5's passes did not finish in 140 s); instruction counts per channel do not depend on the bank size
     R=$PWD; cd /tmp
-    run() { n=$1; shift; CHZ_NOTCH_ORDER=event timeout 400 rocprofv3 --pmc "$@" -f csv -d $R/$out/$n -o $n -- python $R/bench.py --steps 5 --warmup 2 --min-seconds 0.02 --no-crt --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --next-rows-modes linear > $R/$out/$n.log 2>&1; echo "$n rc=$?" >> $R/$out/rc.txt; }
-    run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
-    run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU
+    run() { n=$1; m=$2; shift; shift; CHZ_NOTCH_ORDER=event timeout 200 rocprofv3 --pmc "$@" -f csv -d $R/$out/$n -o $n -- python $R/scripts/chain_profile.py $m 300000 > $R/$out/$n.log 2>&1; echo "$n rc=$?" >> $R/$out/rc.txt; }
+    for m in linear pll fm; do
+      run sq1_$m $m SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
+      run sq2_$m $m SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU
+    done
     cd $R
-    python scripts/rocprof_summary.py $out/sq1 $out/sq2 > "$out/chain_pmc.txt" 2>&1
-    rm -rf $out/sq1 $out/sq2
+    for m in linear pll fm; do echo "## mode $m (300,000 channels)"; python scripts/rocprof_summary.py $out/sq1_$m $out/sq2_$m; done > "$out/chain_pmc.txt" 2>&1
+    rm -rf $out/sq1_* $out/sq2_*
+    cat $out/rc.txt; grep -c . $out/chain_pmc.txt
     ;;
   tests)     # the whole GPU suite, as the driver runs it
     timeout 2400 python -m pytest tests -m gpu -x -q --timeout 900 > "$out/gpu_suite.txt" 2>&1; echo "suite rc=$?" >> "$out/rc.txt"
