@@ -210,8 +210,8 @@ def cpu_baseline(oracle_lib, ring, wl, seconds=12.0, crt_blocks=500):
     plan, P, olen = wl["plan"], wl["P"], wl["olen"]
     sarr = np.array([p[0] for p in plan], np.int32)
 
-    def run(workers, budget):
-        m = oracle_lib.RefMaster(wl["L"], wl["M"], oracle_lib.REAL if wl.get("real", True) else oracle_lib.COMPLEX, worker_threads=workers)
+    def run(workers, budget, internal=1):
+        m = oracle_lib.RefMaster(wl["L"], wl["M"], oracle_lib.REAL if wl.get("real", True) else oracle_lib.COMPLEX, worker_threads=workers, internal_threads=internal)
         chans = []
         for shift, low, high in plan:
             c = m.channel(olen, oracle_lib.COMPLEX)
@@ -243,6 +243,7 @@ def cpu_baseline(oracle_lib, ring, wl, seconds=12.0, crt_blocks=500):
         calib = {"error": str(ex)[:120]}
     nblk, per_block, fft_ms = run(1, seconds * 0.6)
     nblk2, per_block2, fft_ms2 = run(2, seconds * 0.3)      # fft-threads = 2, the reference's advice for this rate (docs/ka9q-radio.md:232)
+    nblk4, per_block4, fft_ms4 = run(1, seconds * 0.2, internal=4)   # fft-internal-threads = 4: one worker, the transform itself on 4 threads (src/filter.c:131-133)
 
     # microseconds per channel-block on ONE core: an inline master (N_worker_threads = 0: the transform runs on the caller, src/filter.c:562-600),
     # then execute_filter_output() of every channel on this thread, timed as a whole
@@ -340,11 +341,13 @@ def cpu_baseline(oracle_lib, ring, wl, seconds=12.0, crt_blocks=500):
         "value": len(plan) * BLOCKTIME / per_block, "unit": "channels",
         "cores": 1 + pool, "kind": "reference",
         "sample": "%d blocks of the same workload (%d channels P=%d), reference filter.c with the project's "
-                  "portable float32 FFT provider (FFTW3 is not installed on this image), 1 FFT worker + %d channel threads"
+                  "float32 FFT provider (AVX2 four-step, one thread per transform; FFTW3 is not installed on this image), 1 FFT worker + %d channel threads"
                   % (nblk, len(plan), P, pool),
         "ms_per_block": per_block * 1e3, "fwd_fft_ms_avg": fft_ms, "host_cores": cores,
         "two_fft_workers": {"value": len(plan) * BLOCKTIME / per_block2, "cores": 2 + pool, "blocks": nblk2,
                             "ms_per_block": per_block2 * 1e3, "fwd_fft_ms_avg": fft_ms2},
+        "four_fft_internal_threads": {"value": len(plan) * BLOCKTIME / per_block4, "cores": 4 + pool, "blocks": nblk4,
+                                      "ms_per_block": per_block4 * 1e3, "fwd_fft_ms_avg": fft_ms4},
         # real time is a statement about EVERY block (c_rt_cpu below); these two say whether the MEAN block time of each leg is inside 20 ms
         "real_time": bool(crt_cpu["sustained"]) if crt_cpu else bool(min(per_block, per_block2) <= BLOCKTIME),
         "mean_block_inside_20ms": {"one_fft_worker": bool(per_block <= BLOCKTIME), "two_fft_workers": bool(per_block2 <= BLOCKTIME)},
@@ -352,13 +355,13 @@ def cpu_baseline(oracle_lib, ring, wl, seconds=12.0, crt_blocks=500):
         # what the channel side could carry if nothing but its own arithmetic limited it: the pool's cores (after the forward transform's
         # two), each doing one channel-block per us_per_channel_block, for 20 ms
         "throughput_bound_channels": int(pool * BLOCKTIME * 1e6 / us_per_chan) if us_per_chan else None,
-        # the forward transform is what bounds the CPU path at this rate: with a tuned FFT in place of the portable provider the
-        # block time would drop by about (fwd_fft_ms_avg - pocketfft time); FFTW with wisdom is typically somewhat faster still
+        # the forward transform is what bounds the CPU path at this rate; how the provider compares with a tuned library on this host
+        # (round 6: the provider's long transform runs 8 sub-transforms side by side in AVX2 lanes -- round 5's scalar one was 1.9 x slower than pocketfft)
         "fft_calibration": dict(calib or {}, portable_provider_fwd_fft_ms=fft_ms,
-                                note="forward N=%d real transform, float32: the project's portable provider inside reference filter.c vs "
+                                note="forward N=%d real transform, float32: the project's provider inside reference filter.c vs "
                                      "scipy's pocketfft (SIMD) on this host; FFTW3 itself is not installed" % wl["N"]),
     }
-    if calib and "pocketfft_f32_rfft_ms_workers_1" in calib:
+    if calib and "pocketfft_f32_rfft_ms_workers_1" in calib and calib["pocketfft_f32_rfft_ms_workers_1"] < fft_ms:
         pf = calib["pocketfft_f32_rfft_ms_workers_1"]
         out["with_tuned_fft_estimate"] = {
             "value": len(plan) * BLOCKTIME / max(per_block - (fft_ms - pf) * 1e-3, pf * 1e-3),

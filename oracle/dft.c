@@ -20,6 +20,8 @@
 #include "dft_core.h"
 #undef DFT_REAL
 #undef DFT_NAME
+#include <pthread.h>
+#include "dft_batch.h"
 
 /* Cache-friendly "four-step" path for the float32 CPU baseline: a long transform of length
    h = n1*n2 becomes n2 column transforms of length n1 (gathered 8 columns at a time so every cache
@@ -35,6 +37,7 @@ struct four_step {
 struct odft_plan {
   int n;
   int precision;
+  int threads;        /* float32 timing path only: threads of the long four-step transform (odft_set_threads) */
   struct four_step *fs;   /* for the length-n/2 complex transform behind the float32 r2c, when n is large */
   d64_plan *full64;   /* length n   (lazily built) */
   d64_plan *half64;   /* length n/2 (lazily built, even n only) */
@@ -59,17 +62,36 @@ static void four_step_destroy(struct four_step *fs) {
   if (!fs) return;
   f32_plan_destroy(fs->p1); f32_plan_destroy(fs->p2); free(fs->wstep); free(fs);
 }
-/* forward transform of h complex points, out-of-place */
-static void four_step_forward(const struct four_step *fs, const f32_cpx *in, f32_cpx *out) {
-  const int n1 = fs->n1, n2 = fs->n2, TB = 8;
-  f32_cpx *T = (f32_cpx *)malloc(sizeof(f32_cpx) * (size_t)fs->h);
-  f32_cpx *col = (f32_cpx *)malloc(sizeof(f32_cpx) * (size_t)TB * (n1 > n2 ? n1 : n2) * 2);
-  f32_cpx *res = col + (size_t)TB * (n1 > n2 ? n1 : n2);
-  /* columns: Y[k1][j2] = sum_j1 x[j1*n2 + j2] W_n1^(j1 k1), then times W_h^(j2 k1) */
-  for (int j0 = 0; j0 < n2; j0 += TB) {
-    const int tb = n2 - j0 < TB ? n2 - j0 : TB;
+/* ---- a few threads for the long float32 transform (round 6): FFTW runs a plan made after fftwf_plan_with_nthreads(n) on n threads
+   (the reference's fft-internal-threads, src/filter.c:131-133); the shim hands that n to the plan (odft_set_threads) and the two passes of
+   the four-step transform -- independent groups of columns, then of rows -- and the real-transform unpacking are split over that many. */
+struct par_job { void (*fn)(void *ctx, long lo, long hi); void *ctx; long lo, hi; };
+static void *par_thread(void *a) { struct par_job *j = (struct par_job *)a; j->fn(j->ctx, j->lo, j->hi); return NULL; }
+static void par_for(int threads, long n, void (*fn)(void *ctx, long lo, long hi), void *ctx) {
+  if (threads > 16) threads = 16;
+  if (threads < 2 || n < 2 * threads) { fn(ctx, 0, n); return; }
+  pthread_t th[16]; struct par_job jb[16];
+  for (int t = 0; t < threads; t++) {
+    jb[t].fn = fn; jb[t].ctx = ctx; jb[t].lo = n * t / threads; jb[t].hi = n * (t + 1) / threads;
+    if (t + 1 < threads) pthread_create(&th[t], NULL, par_thread, &jb[t]);
+  }
+  par_thread(&jb[threads - 1]);
+  for (int t = 0; t + 1 < threads; t++) pthread_join(th[t], NULL);
+}
+
+struct fs_ctx { const struct four_step *fs; const f32_cpx *in; f32_cpx *T; f32_cpx *out; int v8; };
+#define FS_TB 8
+/* columns: Y[k1][j2] = sum_j1 x[j1*n2 + j2] W_n1^(j1 k1), then times W_h^(j2 k1); groups [g0, g1) of 8 columns */
+static void fs_cols_scalar(void *vc, long g0, long g1) {
+  struct fs_ctx *c = (struct fs_ctx *)vc;
+  const struct four_step *fs = c->fs;
+  const int n1 = fs->n1, n2 = fs->n2, TB = FS_TB;
+  f32_cpx *col = (f32_cpx *)malloc(sizeof(f32_cpx) * (size_t)TB * n1 * 2);
+  f32_cpx *res = col + (size_t)TB * n1;
+  for (long g = g0; g < g1; g++) {
+    const int j0 = (int)g * TB, tb = n2 - j0 < TB ? n2 - j0 : TB;
     for (int j1 = 0; j1 < n1; j1++)
-      for (int t = 0; t < tb; t++) col[(size_t)t * n1 + j1] = in[(size_t)j1 * n2 + j0 + t];
+      for (int t = 0; t < tb; t++) col[(size_t)t * n1 + j1] = c->in[(size_t)j1 * n2 + j0 + t];
     for (int t = 0; t < tb; t++) {
       f32_execute(fs->p1, col + (size_t)t * n1, res + (size_t)t * n1, -1);
       /* twiddle by recurrence in double: w_{k1} = W_h^{(j0+t) k1} */
@@ -83,16 +105,93 @@ static void four_step_forward(const struct four_step *fs, const f32_cpx *in, f32
       }
     }
     for (int k1 = 0; k1 < n1; k1++)
-      for (int t = 0; t < tb; t++) T[(size_t)k1 * n2 + j0 + t] = res[(size_t)t * n1 + k1];
+      for (int t = 0; t < tb; t++) c->T[(size_t)k1 * n2 + j0 + t] = res[(size_t)t * n1 + k1];
   }
-  /* rows: Z[k1][k2] = sum_j2 T[k1][j2] W_n2^(j2 k2), out[k1 + n1*k2] */
-  for (int k0 = 0; k0 < n1; k0 += TB) {
-    const int tb = n1 - k0 < TB ? n1 - k0 : TB;
-    for (int t = 0; t < tb; t++) f32_execute(fs->p2, T + (size_t)(k0 + t) * n2, res + (size_t)t * n2, -1);
+  free(col);
+}
+/* rows: Z[k1][k2] = sum_j2 T[k1][j2] W_n2^(j2 k2), out[k1 + n1*k2]; groups of 8 rows */
+static void fs_rows_scalar(void *vc, long g0, long g1) {
+  struct fs_ctx *c = (struct fs_ctx *)vc;
+  const struct four_step *fs = c->fs;
+  const int n1 = fs->n1, n2 = fs->n2, TB = FS_TB;
+  f32_cpx *res = (f32_cpx *)malloc(sizeof(f32_cpx) * (size_t)TB * n2);
+  for (long g = g0; g < g1; g++) {
+    const int k0 = (int)g * TB, tb = n1 - k0 < TB ? n1 - k0 : TB;
+    for (int t = 0; t < tb; t++) f32_execute(fs->p2, c->T + (size_t)(k0 + t) * n2, res + (size_t)t * n2, -1);
     for (int k2 = 0; k2 < n2; k2++)
-      for (int t = 0; t < tb; t++) out[(size_t)k0 + t + (size_t)n1 * k2] = res[(size_t)t * n2 + k2];
+      for (int t = 0; t < tb; t++) c->out[(size_t)k0 + t + (size_t)n1 * k2] = res[(size_t)t * n2 + k2];
   }
-  free(T); free(col);
+  free(res);
+}
+/* the same two passes with the 8 transforms of a group side by side in the lanes of AVX2 vectors (dft_batch.h) */
+typedef float v4f __attribute__((vector_size(16)));
+V8_TARGET static void fs_cols_v8(void *vc, long g0, long g1) {
+  struct fs_ctx *c = (struct fs_ctx *)vc;
+  const struct four_step *fs = c->fs;
+  const int n1 = fs->n1, n2 = fs->n2;
+  v8c *col = NULL;
+  if (posix_memalign((void **)&col, 64, sizeof(v8c) * (size_t)n1 * 2) != 0) return;
+  v8c *res = col + n1;
+  for (long g = g0; g < g1; g++) {
+    const int j0 = (int)g * 8, tb = n2 - j0 < 8 ? n2 - j0 : 8;
+    for (int j1 = 0; j1 < n1; j1++) {
+      const f32_cpx *src = c->in + (size_t)j1 * n2 + j0;
+      v8f re = {0, 0, 0, 0, 0, 0, 0, 0}, im = re;
+      for (int t = 0; t < tb; t++) { re[t] = src[t].re; im[t] = src[t].im; }
+      col[j1].re = re; col[j1].im = im;
+    }
+    v8_rec(fs->p1, 0, n1, col, 1, res, -1);
+    /* twiddles W_h^{(j0+t) k1} by recurrence in double, one column per lane (two 4-wide double vectors) */
+    v4d sr[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, si[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, wr[2] = {{1, 1, 1, 1}, {1, 1, 1, 1}}, wi[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int q = 0; q < 2; q++)
+      for (int t = 0; t < 4; t++) {
+        const int j = j0 + 4 * q + t < n2 ? j0 + 4 * q + t : 0;
+        sr[q][t] = fs->wstep[2 * j]; si[q][t] = fs->wstep[2 * j + 1]; wr[q][t] = 1.0; wi[q][t] = 0.0;
+      }
+    for (int k1 = 0; k1 < n1; k1++) {
+      union { v8f v; v4f h[2]; } fr, fi;
+      fr.h[0] = __builtin_convertvector(wr[0], v4f); fr.h[1] = __builtin_convertvector(wr[1], v4f);
+      fi.h[0] = __builtin_convertvector(wi[0], v4f); fi.h[1] = __builtin_convertvector(wi[1], v4f);
+      const v8f a = res[k1].re, b = res[k1].im;
+      const v8f yr = a * fr.v - b * fi.v, yi = a * fi.v + b * fr.v;
+      f32_cpx *dst = c->T + (size_t)k1 * n2 + j0;
+      for (int t = 0; t < tb; t++) { dst[t].re = yr[t]; dst[t].im = yi[t]; }
+      for (int q = 0; q < 2; q++) { const v4d nr = wr[q] * sr[q] - wi[q] * si[q]; wi[q] = wr[q] * si[q] + wi[q] * sr[q]; wr[q] = nr; }
+    }
+  }
+  free(col);
+}
+V8_TARGET static void fs_rows_v8(void *vc, long g0, long g1) {
+  struct fs_ctx *c = (struct fs_ctx *)vc;
+  const struct four_step *fs = c->fs;
+  const int n1 = fs->n1, n2 = fs->n2;
+  v8c *col = NULL;
+  if (posix_memalign((void **)&col, 64, sizeof(v8c) * (size_t)n2 * 2) != 0) return;
+  v8c *res = col + n2;
+  for (long g = g0; g < g1; g++) {
+    const int k0 = (int)g * 8, tb = n1 - k0 < 8 ? n1 - k0 : 8;
+    /* 8 rows read side by side (8 sequential streams), one element of each per vector */
+    for (int j2 = 0; j2 < n2; j2++) {
+      v8f re = {0, 0, 0, 0, 0, 0, 0, 0}, im = re;
+      for (int t = 0; t < tb; t++) { const f32_cpx v = c->T[(size_t)(k0 + t) * n2 + j2]; re[t] = v.re; im[t] = v.im; }
+      col[j2].re = re; col[j2].im = im;
+    }
+    v8_rec(fs->p2, 0, n2, col, 1, res, -1);
+    for (int k2 = 0; k2 < n2; k2++) {
+      f32_cpx *dst = c->out + (size_t)k0 + (size_t)n1 * k2;
+      const v8f yr = res[k2].re, yi = res[k2].im;
+      for (int t = 0; t < tb; t++) { dst[t].re = yr[t]; dst[t].im = yi[t]; }
+    }
+  }
+  free(col);
+}
+/* forward transform of h complex points, out-of-place */
+static void four_step_forward(const struct four_step *fs, const f32_cpx *in, f32_cpx *out, int threads) {
+  struct fs_ctx c = {fs, in, NULL, out, v8_usable(fs->p1) && v8_usable(fs->p2)};
+  c.T = (f32_cpx *)malloc(sizeof(f32_cpx) * (size_t)fs->h);
+  par_for(threads, (fs->n2 + FS_TB - 1) / FS_TB, c.v8 ? fs_cols_v8 : fs_cols_scalar, &c);
+  par_for(threads, (fs->n1 + FS_TB - 1) / FS_TB, c.v8 ? fs_rows_v8 : fs_rows_scalar, &c);
+  free(c.T);
 }
 
 odft_plan *odft_create(int n, int precision) {
@@ -114,6 +213,7 @@ void odft_destroy(odft_plan *p) {
 }
 
 int odft_length(const odft_plan *p) { return p ? p->n : 0; }
+void odft_set_threads(odft_plan *p, int threads) { if (p) p->threads = threads < 1 ? 1 : threads; }
 
 /* Plans are built lazily; callers (the FFTW shim) create them under the
    reference's own planning mutex (src/filter.c:50-51), and the bench/test
@@ -219,6 +319,21 @@ void odft_r2c_f64(odft_plan *p, const double *in, double *out) {
   free(z);
 }
 
+struct unpack_ctx { const f32_cpx *z; const double *tw; float *out; int h; };
+static void unpack_range(void *vc, long lo, long hi) {
+  const struct unpack_ctx *u = (const struct unpack_ctx *)vc;
+  const f32_cpx *z = u->z; const double *tw = u->tw; float *out = u->out; const int h = u->h;
+  for (long k = lo; k < hi; k++) {
+    f32_cpx a = z[k == h ? 0 : k];
+    f32_cpx b = z[k == 0 ? 0 : h - k];
+    float er = 0.5f * (a.re + b.re), ei = 0.5f * (a.im - b.im);
+    float orr = 0.5f * (a.re - b.re), oi = 0.5f * (a.im + b.im);
+    float wr = (float)tw[2 * k], wi = (float)tw[2 * k + 1];
+    float tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
+    out[2 * k] = er + ti;
+    out[2 * k + 1] = ei - tr;
+  }
+}
 void odft_r2c(odft_plan *p, const float *in, float *out) {
   int n = p->n;
   int h = n / 2;
@@ -243,18 +358,10 @@ void odft_r2c(odft_plan *p, const float *in, float *out) {
   }
   const double *tw = need_rtw(p);
   f32_cpx *z = (f32_cpx *)malloc(sizeof(f32_cpx) * (size_t)h);
-  if (p->fs) four_step_forward(p->fs, (const f32_cpx *)in, z);
+  if (p->fs) four_step_forward(p->fs, (const f32_cpx *)in, z, p->threads);
   else f32_execute(need_half32(p), (const f32_cpx *)in, z, -1);
-  for (int k = 0; k <= h; k++) {
-    f32_cpx a = z[k == h ? 0 : k];
-    f32_cpx b = z[k == 0 ? 0 : h - k];
-    float er = 0.5f * (a.re + b.re), ei = 0.5f * (a.im - b.im);
-    float orr = 0.5f * (a.re - b.re), oi = 0.5f * (a.im + b.im);
-    float wr = (float)tw[2 * k], wi = (float)tw[2 * k + 1];
-    float tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
-    out[2 * k] = er + ti;
-    out[2 * k + 1] = ei - tr;
-  }
+  struct unpack_ctx u = {z, tw, out, h};
+  par_for(p->fs ? p->threads : 1, (long)h + 1, unpack_range, &u);
   free(z);
 }
 

@@ -21,6 +21,8 @@ typedef struct odft_plan odft_plan;
 odft_plan *odft_create(int n, int precision);
 void odft_destroy(odft_plan *p);
 int odft_length(const odft_plan *p);
+/* float32 timing path: run the long real transform on this many threads (what fftwf_plan_with_nthreads asks FFTW for) */
+void odft_set_threads(odft_plan *p, int threads);
 /* build the internal tables now, from one thread (real != 0: tables for r2c) */
 void odft_warm(odft_plan *p, int real);
 

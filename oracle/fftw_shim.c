@@ -26,6 +26,7 @@
 const char fftwf_version[] = "oracle-dft-shim (not FFTW; float64 mixed-radix DFT by definition)";
 
 static int Precision = ODFT_F64;
+static int Plan_threads;      /* fftwf_plan_with_nthreads, below */
 void oracle_fft_set_precision(int p) { Precision = p ? ODFT_F32 : ODFT_F64; }
 int oracle_fft_get_precision(void) { return Precision; }
 
@@ -46,6 +47,7 @@ static fftwf_plan mkplan(enum kind k, int n, int sign, void *in, void *out) {
   p->kind = k; p->n = n; p->sign = sign; p->in = in; p->out = out;
   p->dft = odft_create(n, Precision);
   if (!p->dft) { free(p); return NULL; }
+  odft_set_threads(p->dft, Plan_threads);
   odft_warm(p->dft, k != K_C2C && k != K_C2R);
   return p;
 }
@@ -84,7 +86,9 @@ void fftwf_destroy_plan(fftwf_plan p) {
   free(p);
 }
 int fftwf_init_threads(void) { return 1; }
-void fftwf_plan_with_nthreads(int nthreads) { (void)nthreads; }
+/* plans made after this call run on `nthreads` threads (FFTW's contract; the reference passes fft-internal-threads, src/filter.c:131-133):
+   honoured by the float32 timing path's long transform (oracle/dft.c), ignored by the float64 parity oracle */
+void fftwf_plan_with_nthreads(int nthreads) { Plan_threads = nthreads < 1 ? 1 : nthreads; }
 int fftwf_import_system_wisdom(void) { return 1; }
 int fftwf_import_wisdom_from_filename(const char *filename) { (void)filename; return 1; }
 void *fftwf_malloc(size_t n) { void *p = NULL; return posix_memalign(&p, 64, n ? n : 64) == 0 ? p : NULL; }

@@ -248,9 +248,11 @@ def compute_tuning(N, samprate, freq):
 # ----------------------------------------------------------------------------
 
 class RefMaster:
-    def __init__(self, L, M, in_type, worker_threads=0):
+    def __init__(self, L, M, in_type, worker_threads=0, internal_threads=1):
         self.lib = ref()
         self.L, self.M, self.in_type = L, M, in_type
+        # radiod's fft-internal-threads (src/radio.c:296): filter.c hands it to fftwf_plan_with_nthreads() when it plans (src/filter.c:131-133)
+        C.c_int.in_dll(self.lib, "N_internal_threads").value = int(internal_threads)
         self.h = self.lib.refchz_master_create(L, M, in_type, worker_threads)
         if not self.h:
             raise ValueError("create_filter_input failed")

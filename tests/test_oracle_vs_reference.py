@@ -729,3 +729,29 @@ def test_f16_packing_equals_the_references_import_h():
     bits = np.arange(0x7c00, dtype=np.uint16)
     ref.ref_import_f16(back.ctypes.data, bits.ctypes.data, bits.size, 0)
     assert np.array_equal(back, halfs)
+
+
+@pytest.mark.parametrize("n", [3240000, 134400, 2 * 65536 * 3])
+def test_float32_timing_provider_long_real_transform(n):
+    """oracle/dft.c's float32 path for long real transforms -- the CPU BASELINE's forward FFT, not the parity oracle: the four-step
+    transform with 8 sub-transforms side by side in AVX2 lanes (oracle/dft_batch.h) and the work split over fft-internal-threads
+    (odft_set_threads <- fftwf_plan_with_nthreads).  Against numpy's float64 rfft; the result does not depend on the thread count.
+    n = 3,240,000 is config 3's window (n1 = 1296, n2 = 1250: tail groups of 2 columns), 134,400 has a radix-7 level."""
+    import ctypes as C
+    lib = ol.oracle()
+    lib.odft_create.restype = C.c_void_p; lib.odft_create.argtypes = [C.c_int, C.c_int]
+    lib.odft_set_threads.argtypes = [C.c_void_p, C.c_int]; lib.odft_warm.argtypes = [C.c_void_p, C.c_int]
+    lib.odft_r2c.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]; lib.odft_destroy.argtypes = [C.c_void_p]
+    x = np.random.default_rng(n).standard_normal(n).astype(np.float32)
+    want = np.fft.rfft(x.astype(np.float64))
+    outs = []
+    for threads in (1, 3):
+        p = lib.odft_create(n, 1)
+        lib.odft_set_threads(p, threads); lib.odft_warm(p, 1)
+        out = np.zeros(n + 2, np.float32)
+        lib.odft_r2c(p, x.ctypes.data, out.ctypes.data)
+        lib.odft_destroy(p)
+        got = out.view(np.complex64)
+        assert np.linalg.norm(got - want) <= 5e-7 * np.linalg.norm(want)
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1])
