@@ -37,6 +37,12 @@ unsigned filter_hip_recoveries(struct filter_in const *master, unsigned *blocks_
    one shared master (/root/reference/src/radio.c:996, src/filter.c:704-712); callers of filter.h see no difference.  Returns the
    number of devices; counts (may be NULL) receives the slaves living on each. */
 int filter_hip_devices(struct filter_in const *master, int *counts, int max);
+/* round 6: what the process must still do before the drop-in ends it for the supervisor (a second device failure, a re-creation that
+ * fails, a device that completes nothing for KA9Q_HIP_WEDGED_MS).  The reference's fatal path shuts the front end down first
+ * (src/main.c:197-201: Frontend.shutdown -- bias tee off, streaming stopped); radiod registers the equivalent here, e.g.
+ *     static void hw_off(void) { if (Frontend.shutdown) Frontend.shutdown(&Frontend); }   ...   filter_hip_set_exit_hook(hw_off);
+ * Called once, from the failing thread, before stdio is flushed and _exit(EX_SOFTWARE).  NULL removes it. */
+void filter_hip_set_exit_hook(void (*hook)(void));
 #ifdef __cplusplus
 }
 #endif

@@ -176,6 +176,7 @@ struct mctx {
   unsigned long long prof_consume_max8_ns;   /* the same worst case over blocks 8.. only (the first blocks carry one-time costs: first touch of every
                                                 slave's buffers, thread start-up, the runtime's first launches) */
   unsigned t_done_job[ND];
+  unsigned warm_ran;                /* stream callbacks of create_filter_input's warm-up that have run (lives here, not on that call's stack: a late one must find it) */
   unsigned long long prof_first_dev_ns[8], prof_first_input_ns[8], prof_first_consume_ns[8];   /* blocks 0..7 one by one: enqueue -> callback; time inside execute_filter_input; the slowest slave's completion -> output in hand */
   unsigned prof_first_hits[8], prof_first_misses[8];
 #define PROF_STAGES 8                /* lock, h2d, forward, spectrum read, bank edits, bank launch, bank reads, callback */
@@ -441,10 +442,10 @@ static int bank_create_dev(struct mctx *c, struct shard *sh, struct hbank *b, in
 static void bank_warm(struct shard *sh, struct hbank *b) {
   int const n = b->cap;              /* every row: the copies then walk the whole of each pinned image once (channels without a gather descriptor give zeros) */
   if (n < 1) return;
-  for (int s = 0; s < ND; s++) {
-    if (chz_bank_execute_range(sh->eng, b->id, (unsigned)s, 0, n) != 0) return;
-    if (chz_bank_read_async(sh->eng, b->id, s, 0, n, (float *)b->stage[s]) != 0) return;
-    if (b->noise_on && chz_bank_read_noise_async(sh->eng, b->id, s, 0, n, b->stage_n0[s]) != 0) return;
+  for (int s = 0; s < ND; s++) {       /* (on an enqueue error: stop enqueueing, but never leave with copies into b->stage[] still in flight) */
+    if (chz_bank_execute_range(sh->eng, b->id, (unsigned)s, 0, n) != 0) break;
+    if (chz_bank_read_async(sh->eng, b->id, s, 0, n, (float *)b->stage[s]) != 0) break;
+    if (b->noise_on && chz_bank_read_noise_async(sh->eng, b->id, s, 0, n, b->stage_n0[s]) != 0) break;
   }
   for (int s = 0; s < ND; s++) (void)chz_slot_sync(sh->eng, s);
   /* (a bank that already serves blocks -- filter_hip_enable_noise in mid-stream: what was staged is gone, its slaves re-run their block) */
@@ -537,14 +538,16 @@ static int device_list(struct mctx *c) {
    reference pays for planning inside create_filter_input (src/filter.c:248,263), so block 0 of the stream is an ordinary block.
    The input ring is re-seated in front of job 0 afterwards (zero history, src/filter.c:244,259); the spectra of zeros are zeros. */
 static void engines_warm(struct mctx *c, struct filter_in *f) {
-  unsigned ran = 0, want = 0;
+  unsigned want = 0;
+  bool synced = true;
+  __atomic_store_n(&c->warm_ran, 0u, __ATOMIC_RELEASE);
   for (int g = 0; g < c->nsh; g++) {
     chz_engine *e = c->sh[g].eng;
     const float *src = (const float *)f->input_buffer;             /* zeros */
     for (unsigned j = 0; j < ND; j++) {
       if ((g == 0 || !c->bcast) && (chz_input_write(e, src, f->ilen) != 0 || chz_forward(e, j) != 0)) break;
       if (g == 0 && c->host_spectrum && chz_spectrum_read_async(e, (int)j, (float *)f->fdomain[j]) != 0) break;
-      if (chz_host_callback(e, (int)j, warm_done, &ran) != 0) break;
+      if (chz_host_callback(e, (int)j, warm_done, &c->warm_ran) != 0) break;
       want++;
     }
   }
@@ -555,11 +558,14 @@ static void engines_warm(struct mctx *c, struct filter_in *f) {
       if (chz_spectrum_broadcast_local(engs, c->comm, c->nsh, j, 0) != 0) { fprintf(stderr, "create_filter_input: warm-up broadcast: %s\n", chz_last_error()); break; }
   }
   for (int g = 0; g < c->nsh; g++) {
-    if (chz_sync(c->sh[g].eng) != 0 || chz_input_seek(c->sh[g].eng, 0, NULL) != 0)
+    if (chz_sync(c->sh[g].eng) != 0 || chz_input_seek(c->sh[g].eng, 0, NULL) != 0) {
       fprintf(stderr, "create_filter_input: warm-up on device %d: %s\n", c->sh[g].device, chz_last_error());
+      synced = false;
+    }
   }
-  /* (a stream callback may still be returning on its runtime thread after the stream has drained) */
-  for (int spin = 0; spin < 2000 && __atomic_load_n(&ran, __ATOMIC_ACQUIRE) != want; spin++) usleep(100);
+  /* (a stream callback may still be returning on its runtime thread after the stream has drained; after a FAILED sync nobody waits for
+     callbacks that may never come -- the counter lives in the context, a late one does no harm) */
+  for (int spin = 0; synced && spin < 2000 && __atomic_load_n(&c->warm_ran, __ATOMIC_ACQUIRE) != want; spin++) usleep(100);
 }
 
 int create_filter_input(struct filter_in *master, int const L, int const M, enum filtertype const in_type) {
@@ -861,10 +867,16 @@ static void sync_notches(struct mctx *c, struct filter_in *f) {
 
 /* Replace failed engines (see struct mctx).  Caller holds c->lock; `job` is the block about to be enqueued, whose window starts at
    the master's read pointer.  Ends the process if an engine cannot be replaced or has just been. */
+static void (*Exit_hook)(void);
+void filter_hip_set_exit_hook(void (*hook)(void)) { __atomic_store_n(&Exit_hook, hook, __ATOMIC_RELEASE); }
 static void die_for_the_supervisor(const char *why) {
   fprintf(stderr, "filter_hip: %s -- exiting (EX_SOFTWARE) so that the supervisor restarts the process, as the reference does on a fatal "
                   "front-end or FFT error (src/radio.c:398, src/main.c:202)\n", why);
-  fflush(stderr);
+  /* what the reference's fatal path does first (src/main.c:197-201): the host's hardware shut-down, if it registered one; then the host's
+     buffered output (this is not exit(): nobody else will flush it) */
+  void (*hook)(void) = __atomic_exchange_n(&Exit_hook, NULL, __ATOMIC_ACQ_REL);
+  if (hook) hook();
+  fflush(NULL);
   /* _exit, as the reference's fatal path (src/main.c:202): this thread holds the master's locks, a thousand channel threads and the
      runtime's callback thread are still running, and atexit handlers / static destructors of a runtime whose device has just been
      declared broken may block for ever */
@@ -1219,14 +1231,19 @@ static void serve_misses(struct mctx *c, struct miss_req *list) {
     for (int bi = 0; bi < sh->nbanks; bi++) for (int slot = 0; slot < ND; slot++) {
       struct hbank *b = &sh->banks[bi];
       int cnt = 0, lo = INT_MAX, hi = 0;
+      bool same_job = true;      /* every requester wants the block the slot's image was staged for (a lapped slot holds another block's spectrum) */
       for (struct miss_req *r = list; r; r = r->next) {
         struct sctx *sc = SCTX(r->slave);
         if (sc->dev != g || sc->bank != bi || r->slot != slot || r->rc != 0) continue;
         cnt++; if (sc->idx < lo) lo = sc->idx; if (sc->idx + 1 > hi) hi = sc->idx + 1;
+        if (r->job != b->stage_job[slot]) same_job = false;
       }
       if (cnt == 0) continue;
       int rc = 0;
-      bool const ranged = cnt > MISS_BATCH && b->stage_job[slot] != UINT_MAX && hi <= b->stage_n[slot];
+      /* the range launch rewrites the staged image AND its shift / ISB / epoch records for every channel of [lo, hi): only for the block
+         those records belong to (round 5's advisor: after a lap it relabelled another block's results; the single-channel path below
+         checks the job before it records anything) */
+      bool const ranged = cnt > MISS_BATCH && same_job && b->stage_job[slot] != UINT_MAX && hi <= b->stage_n[slot];
       if (ranged) {
         if (!wide) { stage_wrlock(c); wide = true; }
         rc = chz_bank_execute_range(sh->eng, b->id, (unsigned)slot, lo, hi - lo);

@@ -55,7 +55,7 @@ def test_dropin_exports_the_reference_symbol_set():
     # beyond filter.h: every function include/ka9q_filter_hip_ext.h declares
     ext_hdr = open(os.path.join(ROOT, "include", "ka9q_filter_hip_ext.h")).read()
     ext = set(re.findall(r"\b(filter_hip_\w+)\s*\(", ext_hdr))
-    assert ext == {"filter_hip_enable_noise", "filter_hip_noise", "filter_hip_drain", "filter_hip_skipped_blocks", "filter_hip_recoveries", "filter_hip_devices"} and ext <= mine, ext - mine
+    assert ext == {"filter_hip_enable_noise", "filter_hip_noise", "filter_hip_drain", "filter_hip_skipped_blocks", "filter_hip_recoveries", "filter_hip_devices", "filter_hip_set_exit_hook"} and ext <= mine, ext - mine
     assert functions | data <= mine, (functions | data) - mine
     ref_obj = os.path.join(ROOT, "oracle", "_build", "ref_filter.o")
     if os.path.exists(ref_obj):   # the reference's own object, compiled in place by oracle/Makefile
