@@ -15,7 +15,7 @@ import oracle_lib as ol
 
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 ol.build()
-wl = bench.workload_for(3, 0, 1, 1024)
+wl = bench.workload_for(4, 0, 1, 1024) if os.environ.get("BLOCK0_CONFIG4") else bench.workload_for(3, 0, 1, 1024)
 ring = bench.siggen_ring(ol, wl["fs"], l=wl["L"], real=wl.get("real", True))
 out = []
 only = os.environ.get("BLOCK0_ONLY", "")        # "1": only the BLOCK0_EXTRA configurations; "2": one default 1024-thread run

@@ -9,6 +9,12 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r6p)       # round 6: the profiles of the final kernels (kernel trace with 4 and 1 streams, PMC passes), RCCL sanity with one rank
+    SKIP_PMC=0 timeout 1500 bash scripts/gpu_profile.sh r06 > "$out/profile.txt" 2>&1; echo "profile rc=$?" >> "$out/rc.txt"
+    cat gpurun_out/r06_pmc_forward.json; cat gpurun_out/pmc_r06/retries.txt 2>/dev/null
+    timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29711 scripts/rccl_sanity.py > "$out/rccl_sanity.txt" 2>&1; echo "rccl rc=$?" >> "$out/rc.txt"
+    tail -2 "$out/rccl_sanity.txt"; cat "$out/rc.txt"
+    ;;
   r6h)       # round 6: demod_fm_lanes' discriminator phases 1 / 2 / 4 (shipped) / 8 samples side by side, and 2 wavefronts per SIMD: the FM chain at 1.5 M channels
     for rep in 1 2; do for v in default fmd1 fmd2 fmd8 fmw2; do
       L=""; [ $v != default ] && L=$PWD/ka9q-radio_amd/libchz_hip_$v.so

@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 # ONE lane instead (CHZ_STREAMS=1) -- no ticket is taken with one stream, the notch stays folded inside fwd_rows exactly as shipped,
 # and per-dispatch counters do not depend on how many streams the dispatches came from.  Every pass has its own time limit.
 export CHZ_STREAMS=1
+export BENCH_LEG_BUDGET_SCALE=10      # (bench.py's per-leg watchdog: counter passes serialise the dispatches)
 # (rocprofv3 itself crashed once in a FETCH_SIZE pass of round 5 -- SIGSEGV inside its dispatch callback: a pass that fails is repeated once)
 run() {
   name=$1; shift

@@ -239,23 +239,84 @@ def check(d, d_self=None, pll=(), float_tol=1e-5, n0_tol=1e-5, lsb_frac=1e-3, fa
         assert held >= 0.95 * total, ("the reference itself is unstable on too much of this input to test with", held, total)
     own = summary(d_self) if d_self else None
     own_pll = max([d_self[s]["float_rel"] for s in pll] + [d_self[s]["float_abs_over_peak"] for s in pll] + [0.0]) if d_self else 0.0
+    # the other channels: 1e-5 at the small geometry; at BASELINE's full rates (N = 1.62 M / 3.24 M, a hundred strong lines in the window) a float32
+    # transform's error floor in a quiet channel is set by the strongest line of the WINDOW, not by what the channel holds --
+    # the reference on a float32 transform shows it too (config 3: up to 8.7e-5, median 4e-6), and that spread is the yardstick
+    own_plain = max([max(v["float_rel"], v["float_abs_over_peak"]) for k, v in d_self.items() if k not in pll] + [0.0]) if d_self else 0.0
     lim_n0 = max(n0_tol, factor * own["n0_rel"]) if own else n0_tol
+    lim_bb = max(n0_tol, factor * own["bb_power_rel"]) if own else n0_tol
     lim_lsb = max(lsb_frac, factor * own["lsb_frac"]) if own else lsb_frac
     lim_gain = max(10 * n0_tol, factor * own["gain_rel"]) if own else 10 * n0_tol      # the AGC's threshold follows n0 (src/linear.c:196-204)
     for ssrc, st in d.items():
-        lim_f = max(float_tol, factor * own_pll) if ssrc in pll else float_tol
+        lim_f = max(float_tol, factor * own_pll) if ssrc in pll else max(float_tol, factor * own_plain)
         assert st["float_rel"] <= lim_f, (ssrc, "float_rel", st["float_rel"], lim_f)
         assert st["float_abs_over_peak"] <= lim_f, (ssrc, "float_abs_over_peak", st["float_abs_over_peak"], lim_f)
         assert st["n0_rel"] <= lim_n0, (ssrc, "n0_rel", st["n0_rel"], lim_n0)
-        assert st["bb_power_rel"] <= n0_tol, (ssrc, "bb_power_rel", st["bb_power_rel"])
+        assert st["bb_power_rel"] <= lim_bb, (ssrc, "bb_power_rel", st["bb_power_rel"], lim_bb)
         assert st["gain_rel"] <= lim_gain, (ssrc, "gain_rel", st["gain_rel"], lim_gain)
         assert st["lsb_max"] <= 1, (ssrc, "lsb_max", st["lsb_max"])
         assert st["lsb_frac"] <= lim_lsb, (ssrc, "lsb_frac", st["lsb_frac"], lim_lsb)
     s = summary(d)
-    assert s["n0_rel_median"] <= n0_tol and s["float_rel_median"] <= float_tol, s
-    s["limits"] = {"float_rel": float_tol, "float_rel_pll_channels": max(float_tol, factor * own_pll), "n0_rel": lim_n0, "lsb_frac": lim_lsb, "gain_rel": lim_gain}
+    assert s["n0_rel_median"] <= max(n0_tol, 2 * own["n0_rel_median"] if own else 0) and s["float_rel_median"] <= max(float_tol, 2 * own["float_rel_median"] if own else 0), s
+    s["limits"] = {"float_rel": max(float_tol, factor * own_plain), "float_rel_pll_channels": max(float_tol, factor * own_pll), "n0_rel": lim_n0, "bb_power_rel": lim_bb,
+                   "lsb_frac": lim_lsb, "gain_rel": lim_gain}
     return s
 
 
 def compare(ref, got, **kw):
     return check(diff(ref, got), None, **kw)
+
+
+# ---- BASELINE.json's own configurations through the reference's callers (config 2: 64.8 MS/s, 256 NBFM channels; config 3: 129.6 MS/s,
+# 1024 mixed usb / cw / iq channels) -- the channel rasters of bench.py's workloads
+def spectral_synth(lines, fs, n, noise, seed):
+    """n real samples = white noise + the spectral lines [(Hz, amplitude, phase)], every frequency rounded to a bin of the whole run (one
+    inverse transform instead of one cosine of n samples per line: 10^3 lines over 4 x 10^7 samples)."""
+    S = np.zeros(n // 2 + 1, np.complex128)
+    for f, a, ph in lines:
+        k = int(round(f * n / fs))
+        if 0 < k < n // 2:
+            S[k] += 0.5 * a * n * np.exp(1j * ph)
+    x = np.fft.irfft(S, n)
+    del S
+    rng = np.random.default_rng(seed)
+    x += noise * rng.standard_normal(n)
+    return x.astype(np.float32)
+
+
+def config3_channels(nch=1024, every=8):
+    """bench.py's channel_plan_config3 raster (1 MHz + i x 60 kHz + (i mod 40) Hz; thirds usb / cw / iq) as radiod channels: the usb and iq
+    presets, and the cwu preset (filter2 = 4, +500 Hz shift) for the CW third; S16BE and F32LE; a signal on every `every`-th channel
+    (two tones with slow fading sidebands -- see synthesise() on why nothing here is stationary), noise on the others."""
+    ch, lines = [], []
+    for i in range(nch):
+        f = 1e6 + (i % 1040) * 60e3 + (i % 40)
+        k = ("usb", "cwu", "iq")[i % 3]
+        extra = "encoding=f32le" if i % 5 == 1 else ""
+        ch.append(Channel(1000 + i, f, k, extra, {"kind": k}))
+        if i % every == 0:
+            a = 0.004 + 0.001 * (i % 3)
+            tones = {"usb": [(700.0, 1.0), (1900.0, 0.6)], "cwu": [(0.0, 1.0)], "iq": [(-1300.0, 1.0), (2100.0, 0.7)]}[k]
+            for df, rel in tones:
+                ph = 0.37 * i + df * 1e-3
+                lines.append((f + df, a * rel, ph))
+                lines.append((f + df + 3.0 + 0.2 * (i % 5), 0.17 * a * rel, ph + 1.0))      # +- a few Hz: a slow beat = fading
+                lines.append((f + df - 3.0 - 0.2 * (i % 5), 0.17 * a * rel, ph - 0.4))
+    return ch, lines
+
+
+def config2_channels(nch=256, every=4):
+    """bench.py's channel_plan_config2 raster (10 MHz + i x 12.5 kHz) as 12 kHz NBFM channels (the fm preset at samprate 12 k, +-5 kHz);
+    every `every`-th carries a carrier frequency-modulated by a 1 kHz tone (beta 1.5: the Bessel lines n = -7..7), the others noise."""
+    from scipy.special import jv
+    ch, lines = [], []
+    fm12 = "samprate=12000 low=-5000 high=5000"
+    for i in range(nch):
+        f = 10e6 + i * 12.5e3
+        k = "pm" if i % 3 == 2 else "fm"
+        ch.append(Channel(2000 + i, f, k, fm12 + (" encoding=f32le" if i % 5 == 1 else "") + (" threshold-extend=yes" if i % 2 else ""), {"kind": k}))
+        if i % every == 0:
+            a, beta, fmod = 0.01, 1.5, 1000.0 + 10.0 * (i % 7)
+            for n in range(-7, 8):
+                lines.append((f + n * fmod, a * float(jv(n, beta)), 0.3 * i + (0.0 if n >= 0 or n % 2 == 0 else np.pi) * 0 + 0.0))
+    return ch, lines

@@ -42,11 +42,12 @@ def _pll_channels(channels):
     return {c.ssrc for c in channels if c.preset in ("sam", "ame", "dsb")}
 
 
-def _ab(tmp, exe, channels, x, nblocks, **kw):
+def _ab(tmp, exe, channels, x, nblocks, geom=None, **kw):
     """reference on the float64 transform (A), reference on the float32 transform (its own spread), the link under test (B)"""
-    A, _, _ = _reference_run(tmp, channels, x, nblocks)
-    A32, _, _ = _reference_run(tmp, channels, x, nblocks, f32=True)
-    B, meta, err = mr.run(exe, os.path.join(tmp, "got"), channels, x, FS, L, M, nblocks, **kw)
+    fs, l, m = geom or (FS, L, M)
+    A, _, _ = mr.run(mr.REF_EXE, os.path.join(tmp, "ref"), channels, x, fs, l, m, nblocks)
+    A32, _, _ = mr.run(mr.REF_EXE, os.path.join(tmp, "ref32"), channels, x, fs, l, m, nblocks, env={"MINI_RADIOD_FFT_F32": "1"})
+    B, meta, err = mr.run(exe, os.path.join(tmp, "got"), channels, x, fs, l, m, nblocks, **kw)
     d_self = mr.diff(A, A32)
     s = mr.check(mr.diff(A, B, upto={k: v["agree"] for k, v in d_self.items()}), d_self, pll=_pll_channels(channels))
     s["reference_vs_itself"] = {k: v for k, v in mr.summary(d_self).items() if k not in ("data", "null")}
@@ -124,6 +125,29 @@ def test_reference_callers_on_the_dropin_host_code_over_the_cpu_stand_in(tmp_pat
     assert s["data"] > 1000 and s["null"] > 100 and s["frames_in_agreement"] == s["frames"], s
 
 
+CONFIG3 = (129.6e6, 2592000, 648001)     # BASELINE config 3: N = 3,240,000, 1024 mixed usb / cw / iq channels
+CONFIG2 = (64.8e6, 1296000, 324001)      # BASELINE config 2: N = 1,620,000, 256 x 12 kHz NBFM channels
+
+
+@needs_ref_exe
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="/root/reference absent: the caller objects cannot be linked here")
+def test_config3_through_the_reference_callers_on_the_dropin_host_code(tmp_path):
+    """BASELINE config 3 itself -- 129.6 MS/s real, 1024 mixed usb / cw / iq channels, one REAL radiod channel thread each (demod_thread ->
+    demod_linear -> downconvert; the CW third with filter2 = 4: 341 pooled inline masters) -- on the drop-in's host code over the CPU
+    stand-in engine against the same objects on the reference's filter.c: 1024 threads publishing shifts, block 0, the miss path,
+    filter2's leader / follower batching, lifetimes running out, close_chan() -- with nothing but rounding order between the two links."""
+    exe = _build_stub_link(str(tmp_path))
+    fs, l, m = CONFIG3
+    ch, lines = mr.config3_channels()
+    nb = 8
+    x = mr.spectral_synth(lines, fs, nb * l, 0.002, 7)
+    A, _, _ = mr.run(mr.REF_EXE, str(tmp_path / "ref"), ch, x, fs, l, m, nb)
+    B, meta, _ = mr.run(exe, str(tmp_path / "got"), ch, x, fs, l, m, nb)
+    assert int(meta["channels"]) == 1024 and int(meta["master_jobs"]) == nb and int(meta["shutdowns"]) == 1
+    s = mr.compare(A, B, float_tol=1e-6, n0_tol=1e-9)
+    assert s["frames_in_agreement"] == s["frames"] == 342 * nb + 341 * (nb // 4) + 341 * nb, s
+
+
 def _hip_exe():
     assert os.path.exists(mr.HIP_EXE), "tests/c/_prebuilt/mini_radiod_hip missing: __graft_entry__.build() makes it where /root/reference exists"
     assert os.path.exists(mr.REF_EXE), "oracle/_ref/mini_radiod_ref missing"
@@ -157,3 +181,41 @@ def test_reference_callers_on_the_mi355x_at_wall_clock_pace():
     assert all(f["block_drops"] == 0 for F in B.values() for f in F)
     assert float(meta["seconds"]) < nb * 0.02 + 0.5
     print("mini-radiod paced A/B on the device:", s)
+
+
+@pytest.mark.gpu
+def test_baseline_config3_through_the_reference_callers_on_the_mi355x():
+    """BASELINE config 3 -- 129.6 MS/s real (N = 3,240,000), 1024 mixed usb / cw / iq 12 kHz channels with per-channel filters -- run by the
+    reference's OWN radiod code on the device: 1024 real channel threads (the CW third through filter2 = 4), in lock step and then with the
+    front end on its own 20 ms clock (no drops), every frame of every channel against the same objects on the reference's filter.c."""
+    exe = _hip_exe()
+    ch, lines = mr.config3_channels()
+    fs, l, m = CONFIG3
+    with tempfile.TemporaryDirectory() as tmp:
+        x = mr.spectral_synth(lines, fs, 12 * l, 0.002, 7)
+        s, B, meta = _ab(tmp, exe, ch, x, 12, geom=CONFIG3)
+        print("mini-radiod config 3 A/B on the device:", s)
+        assert int(meta["channels"]) == 1024 and s["frames_in_agreement"] == s["frames"]
+    with tempfile.TemporaryDirectory() as tmp:
+        nb = 24
+        x = mr.spectral_synth(lines, fs, nb * l, 0.002, 8)
+        s, B, meta = _ab(tmp, exe, ch, x, nb, geom=CONFIG3, paced=1)
+        print("mini-radiod config 3 paced A/B on the device:", s)
+        assert all(f["block_drops"] == 0 for F in B.values() for f in F) and s["frames_in_agreement"] == s["frames"]
+        assert float(meta["seconds"]) < nb * 0.02 + 1.0
+
+
+@pytest.mark.gpu
+def test_baseline_config2_through_the_reference_callers_on_the_mi355x():
+    """BASELINE config 2 -- 64.8 MS/s real (N = 1,620,000), 256 x 12 kHz NBFM channels -- run by the reference's own demod_fm() threads on the
+    device: a frequency-modulated carrier on every fourth channel (squelch opens, discriminator, threshold extension on half of them,
+    de-emphasis on the pm third), noise on the others (squelch stays shut)."""
+    exe = _hip_exe()
+    ch, lines = mr.config2_channels()
+    fs, l, m = CONFIG2
+    nb = 16
+    with tempfile.TemporaryDirectory() as tmp:
+        x = mr.spectral_synth(lines, fs, nb * l, 0.002, 9)
+        s, B, meta = _ab(tmp, exe, ch, x, nb, geom=CONFIG2)
+    print("mini-radiod config 2 A/B on the device:", s)
+    assert int(meta["channels"]) == 256 and s["frames_in_agreement"] == s["frames"] and s["data"] > 600 and s["null"] > 2000
