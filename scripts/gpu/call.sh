@@ -9,6 +9,12 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r6q)       # round 6: mini-radiod at BASELINE config 2 / config 3 scale on the device; block 0 inside 10 ms (tightened cold-start test)
+    timeout 900 python -m pytest tests/test_mini_radiod.py -m gpu -q -s --timeout 600 > "$out/mini_radiod.txt" 2>&1; echo "mini_radiod rc=$?" >> "$out/rc.txt"
+    grep -E "A/B on the device|passed|failed|Error" "$out/mini_radiod.txt" | cut -c1-2500
+    timeout 600 python -m pytest tests/test_dropin.py -m gpu -q --timeout 600 -k "cold_start or wall_clock" > "$out/dropin_cold.txt" 2>&1; echo "cold rc=$?" >> "$out/rc.txt"
+    tail -5 "$out/dropin_cold.txt"; cat "$out/rc.txt"
+    ;;
   r6p)       # round 6: the profiles of the final kernels (kernel trace with 4 and 1 streams, PMC passes), RCCL sanity with one rank
     SKIP_PMC=0 timeout 1500 bash scripts/gpu_profile.sh r06 > "$out/profile.txt" 2>&1; echo "profile rc=$?" >> "$out/rc.txt"
     cat gpurun_out/r06_pmc_forward.json; cat gpurun_out/pmc_r06/retries.txt 2>/dev/null

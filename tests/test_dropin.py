@@ -602,9 +602,22 @@ def test_dropin_cold_start_at_full_rate(nthreads):
             for p in plan:
                 f.write(struct.pack("iiiiddddd", *p))
         x.tofile(os.path.join(tmp, "in.bin"))
-        # (a fresh process per attempt: every attempt IS a cold start.  One repeat is allowed: the box is shared, and its container's CPU
-        #  quota stops every thread of this test for tens of milliseconds now and then -- bench.py's paced legs repeat for the same reason)
+        # (a fresh process per attempt: every attempt IS a cold start.  Round 6: block 0 and the seven after it inside 10 ms -- half a block time;
+        #  measured 3.3-5.0 ms at 1024 threads, 4.6-6.3 ms at 2000 on four fresh boxes -- and NO free repeat: one is allowed only when the
+        #  container's CPU quota demonstrably stopped the process during the attempt (cpu.stat's nr_throttled moved: every thread of the test,
+        #  the front end included, then stands still for tens of milliseconds -- that says nothing about the boundary))
+        def throttled():
+            for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+                try:
+                    for ln in open(path):
+                        if ln.startswith("nr_throttled"):
+                            return int(ln.split()[1])
+                except OSError:
+                    continue
+            return 0
+        LIMIT_MS = 10.0
         for attempt in (1, 2):
+            th0 = throttled()
             r = subprocess.run([exe, tmp], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
             assert r.returncode == 0, r.stderr[-2000:]
             meta = open(os.path.join(tmp, "meta.txt")).read().split()
@@ -613,12 +626,12 @@ def test_dropin_cold_start_at_full_rate(nthreads):
             dropped = np.fromfile(os.path.join(tmp, "dropped.bin"), np.uint8).reshape(nblocks, nthreads)
             first = lat[:8, 0] / 1e6
             ok = (meta["drops"] == "0" and int(meta["skipped"]) == 0 and not dropped.any() and (lat[:, 1] == nthreads).all()
-                  and 0 <= first[0] < 20.0 and first.max() < 20.0)
-            if ok:
+                  and 0 <= first[0] < LIMIT_MS and first.max() < LIMIT_MS)
+            if ok or throttled() == th0:
                 break
     assert meta["drops"] == "0" and int(meta["skipped"]) == 0 and not dropped.any(), (meta["drops"], dropped[:8].sum(axis=1), first)
     assert (lat[:, 1] == nthreads).all(), np.flatnonzero(lat[:, 1] != nthreads)[:8]
-    assert 0 <= first[0] < 20.0 and first.max() < 20.0, first
+    assert 0 <= first[0] < LIMIT_MS and first.max() < LIMIT_MS, first
 
 
 @pytest.mark.gpu
