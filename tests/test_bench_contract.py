@@ -42,7 +42,7 @@ def test_headline_of_the_committed_full_run_is_compact_and_strict():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
-    for name in ("r05_bench_detail.json", "r04_bench.json"):
+    for name in ("r06_bench_detail.json", "r05_bench_detail.json", "r04_bench.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             break
