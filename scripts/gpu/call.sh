@@ -9,6 +9,13 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r6r)       # round 6: mini-radiod config 1 (complex front end) and config 4 shape (2000 channels, two shards) on the device; the null-stream soak in three queue modes
+    timeout 900 python -m pytest tests/test_mini_radiod.py -m gpu -q -s --timeout 600 -k "config1 or config4" > "$out/mini_radiod.txt" 2>&1; echo "mini_radiod rc=$?" >> "$out/rc.txt"
+    grep -E "A/B on the device|passed|failed|Error" "$out/mini_radiod.txt" | cut -c1-1500
+    timeout 1300 python -m pytest tests/test_gpu_pipeline.py -m gpu -q --timeout 450 -k "null_stream" > "$out/null_stream.txt" 2>&1; echo "null_stream rc=$?" >> "$out/rc.txt"
+    tail -5 "$out/null_stream.txt"
+    for q in 1 2 4; do CHZ_OWN_QUEUES=$q timeout 400 python scripts/null_stream_soak.py 2>/dev/null | tail -1; done > "$out/null_stream_soak.jsonl"; cat "$out/null_stream_soak.jsonl"; cat "$out/rc.txt"
+    ;;
   r6q)       # round 6: mini-radiod at BASELINE config 2 / config 3 scale on the device; block 0 inside 10 ms (tightened cold-start test)
     timeout 900 python -m pytest tests/test_mini_radiod.py -m gpu -q -s --timeout 600 > "$out/mini_radiod.txt" 2>&1; echo "mini_radiod rc=$?" >> "$out/rc.txt"
     grep -E "A/B on the device|passed|failed|Error" "$out/mini_radiod.txt" | cut -c1-2500

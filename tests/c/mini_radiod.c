@@ -168,9 +168,9 @@ int send_radio_status(struct sockaddr const *sock, struct frontend const *fronte
 
 /* ---- the front end "driver" ---- */
 static struct {
-  int L, M, nblocks, paced, slack;
+  int L, M, nblocks, paced, slack, isreal;
   double samprate;
-  float *samples;                      /* [nblocks][L] */
+  float *samples;                      /* [nblocks][L] real, or [nblocks][L] complex (interleaved) for a complex front end */
   pthread_t thread;
   atomic_int go, done;
   double worst_wait_ms;
@@ -199,10 +199,17 @@ static void *fe_thread(void *arg) {
     } else if (b >= FE.slack) {
       while (!all_channels_took((uint32_t)(b - FE.slack + 1))) usleep(100);
     }
-    float *wptr = fe->in.input_write_pointer.r;                      /* src/rx888.c:730-800: convert in place, then hand over */
-    memcpy(wptr, FE.samples + (size_t)b * FE.L, sizeof(float) * (size_t)FE.L);
+    int r;
+    if (FE.isreal) {
+      float *wptr = fe->in.input_write_pointer.r;                    /* src/rx888.c:730-800: convert in place, then hand over */
+      memcpy(wptr, FE.samples + (size_t)b * FE.L, sizeof(float) * (size_t)FE.L);
+      r = write_rfilter(&fe->in, NULL, FE.L);
+    } else {
+      float complex *wptr = fe->in.input_write_pointer.c;            /* src/sig_gen.c:300-330, src/airspy.c: complex front ends */
+      memcpy(wptr, FE.samples + (size_t)2 * b * FE.L, sizeof(float complex) * (size_t)FE.L);
+      r = write_cfilter(&fe->in, NULL, FE.L);
+    }
     fe->samples += FE.L;
-    int r = write_rfilter(&fe->in, NULL, FE.L);
     if (r != 1) { fprintf(stderr, "mini_radiod: write_rfilter returned %d at block %d\n", r, b); abort(); }
   }
   atomic_store(&FE.done, 1);
@@ -215,14 +222,15 @@ static int fe_shutdown(struct frontend *fe) { (void)fe; atomic_fetch_add(&Shutdo
 /* what src/radio.c:502-623 setup_hardware() does after the driver's setup() has filled in the rates */
 static void setup_hardware_like_radiod(void) {
   Frontend.start = fe_start; Frontend.shutdown = fe_shutdown;
-  Frontend.samprate = FE.samprate; Frontend.isreal = true; Frontend.bitspersample = 16; Frontend.frequency = 0; Frontend.calibrate = 0;
-  Frontend.min_IF = 0; Frontend.max_IF = 0.47 * FE.samprate;        /* src/rx888.c:343-345 */
+  Frontend.samprate = FE.samprate; Frontend.isreal = FE.isreal != 0; Frontend.bitspersample = 16; Frontend.frequency = 0; Frontend.calibrate = 0;
+  if (FE.isreal) { Frontend.min_IF = 0; Frontend.max_IF = 0.47 * FE.samprate; }                          /* src/rx888.c:343-345 */
+  else { Frontend.min_IF = -0.47 * FE.samprate; Frontend.max_IF = 0.47 * FE.samprate; }                  /* src/sig_gen.c:170-172 */
   Frontend.rf_gain = 0; Frontend.rf_atten = 0; Frontend.rf_level_cal = 0;
   strlcpy(Frontend.description, "mini-radiod", sizeof Frontend.description);
   Frontend.L = FE.L; Frontend.M = FE.M;
   Blocktime = Frontend.L / Frontend.samprate;                       /* src/radio.c:584 */
   int const N = Frontend.M + Frontend.L - 1;
-  if (create_filter_input(&Frontend.in, Frontend.L, Frontend.M, REAL) != 0) { fprintf(stderr, "mini_radiod: create_filter_input failed\n"); exit(3); }
+  if (create_filter_input(&Frontend.in, Frontend.L, Frontend.M, FE.isreal ? REAL : COMPLEX) != 0) { fprintf(stderr, "mini_radiod: create_filter_input failed\n"); exit(3); }
   Frontend.in.notches = calloc(NSPURS + 1, sizeof(struct notch_state));            /* src/radio.c:600-621 */
   struct notch_state *notch = Frontend.in.notches;
   for (int i = 0; i < NSPURS; i++) {
@@ -288,11 +296,14 @@ int main(int argc, char **argv) {
   if (!f) { perror(path); return 2; }
   int nchan = 0;
   if (fscanf(f, "%lf %d %d %d %d %d %d", &FE.samprate, &FE.L, &FE.M, &FE.nblocks, &nchan, &FE.paced, &FE.slack) != 7) { fprintf(stderr, "bad cfg\n"); return 2; }
+  FE.isreal = 1;
+  { int c = fgetc(f); while (c == ' ') c = fgetc(f); if (c == 'c') FE.isreal = 0; else if (c != EOF) ungetc(c, f); }      /* an 8th token "complex": a complex front end */
   if (nchan > Nchannels || FE.slack < 1 || FE.slack > 3) { fprintf(stderr, "bad cfg\n"); return 2; }
-  FE.samples = malloc(sizeof(float) * (size_t)FE.L * FE.nblocks);
+  size_t const per = FE.isreal ? 1 : 2;
+  FE.samples = malloc(sizeof(float) * per * (size_t)FE.L * FE.nblocks);
   snprintf(path, sizeof path, "%s/in.f32", argv[1]);
   FILE *g = fopen(path, "rb");
-  if (!g || fread(FE.samples, sizeof(float) * FE.L, FE.nblocks, g) != (size_t)FE.nblocks) { perror(path); return 2; }
+  if (!g || fread(FE.samples, sizeof(float) * per * FE.L, FE.nblocks, g) != (size_t)FE.nblocks) { perror(path); return 2; }
   fclose(g);
 
   if (getenv("MINI_RADIOD_FFT_F32") && oracle_fft_set_precision) oracle_fft_set_precision(1);

@@ -121,9 +121,10 @@ def synthesise(channels, fs, L, nblocks, seed=5, noise=0.002):
 
 
 def run(exe, workdir, channels, x, fs, L, M, nblocks, paced=0, slack=2, env=None, timeout=900):
+    """x: float32 samples of a real front end, or complex64 of a complex one"""
     os.makedirs(workdir, exist_ok=True)
     with open(os.path.join(workdir, "cfg.txt"), "w") as f:
-        f.write("%.1f %d %d %d %d %d %d\n" % (fs, L, M, nblocks, len(channels), paced, slack))
+        f.write("%.1f %d %d %d %d %d %d%s\n" % (fs, L, M, nblocks, len(channels), paced, slack, " complex" if np.iscomplexobj(x) else ""))
         for c in channels:
             f.write(c.line() + "\n")
     x.tofile(os.path.join(workdir, "in.f32"))
@@ -319,4 +320,42 @@ def config2_channels(nch=256, every=4):
             a, beta, fmod = 0.01, 1.5, 1000.0 + 10.0 * (i % 7)
             for n in range(-7, 8):
                 lines.append((f + n * fmod, a * float(jv(n, beta)), 0.3 * i + (0.0 if n >= 0 or n % 2 == 0 else np.pi) * 0 + 0.0))
+    return ch, lines
+
+
+def config1_channels():
+    """BASELINE config 1: sig_gen complex 2.4 MS/s, ONE IQ-mode channel (the reference's own CPU-runnable plumbing case; bench.py's
+    workload_for(1): the channel at 100 kHz) -- plus one on the negative side of the complex spectrum, which a real front end cannot have."""
+    ch = [Channel(3000, 100e3 + 3.7, "iq", "", {"kind": "iq"}), Channel(3001, -412e3 - 11.3, "usb", "encoding=f32le", {"kind": "usb"})]
+    lines = [(100e3 + 3.7 - 1300.0, 0.02, 0.3), (100e3 + 3.7 + 2100.0, 0.014, 1.1), (100e3 + 3.7 + 2103.0, 0.004, 0.2),
+             (-412e3 - 11.3 + 700.0, 0.02, 0.5), (-412e3 - 11.3 + 1900.0, 0.012, 2.0), (-412e3 - 11.3 + 1903.5, 0.003, 0.9)]
+    return ch, lines
+
+
+def complex_synth(lines, fs, n, noise, seed):
+    """n complex samples: lines [(Hz, amplitude, phase)] as complex exponentials (negative frequencies allowed) + complex white noise"""
+    S = np.zeros(n, np.complex128)
+    for f, a, ph in lines:
+        S[int(round(f * n / fs)) % n] += a * n * np.exp(1j * ph)
+    x = np.fft.ifft(S)
+    rng = np.random.default_rng(seed)
+    x += noise * (rng.standard_normal(n) + 1j * rng.standard_normal(n)) / np.sqrt(2)
+    return x.astype(np.complex64)
+
+
+def config4_channels(nch=2000, every=10):
+    """BASELINE config 4's shape on what one radiod can hold: 24 kHz channels (P = 600) on bench.py's channel_plan_config4 raster
+    (0.5 MHz + i x 7.8 kHz), Nchannels = 2000 of them (src/radio.h:356) -- behind ONE master whose slaves the drop-in shards over
+    KA9Q_HIP_DEVICES 1024 at a time.  iq preset at 24 kHz (stereo frames), +-10 kHz; a two-tone signal on every `every`-th channel."""
+    ch, lines = [], []
+    for i in range(nch):
+        f = 0.5e6 + i * 7.8e3
+        # (channels on noise alone run with a fixed gain: stationary noise parks the block AGC on its own decision boundary -- see synthesise() --
+        #  and the reference then differs from ITSELF by tens of per cent in gain on a float32 transform, which says nothing about anybody's filter)
+        ch.append(Channel(4000 + i, f, "iq", "samprate=24000 low=-10000 high=10000" + (" encoding=f32le" if i % 5 == 1 else "") + ("" if i % every == 0 else " agc=no gain=40"), {"kind": "iq"}))
+        if i % every == 0:
+            a = 0.004
+            for df, rel in ((-2600.0, 1.0), (4100.0, 0.7)):
+                ph = 0.21 * i + df * 1e-3
+                lines.append((f + df, a * rel, ph)); lines.append((f + df + 3.1, 0.2 * a * rel, ph + 1.0)); lines.append((f + df - 2.7, 0.2 * a * rel, ph - 0.5))
     return ch, lines

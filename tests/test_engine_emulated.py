@@ -23,7 +23,7 @@ LIB = os.path.join(EMU, "libchz_hip_emu.so")
 # wait on the device-side ticket, and the two long demodulator scenarios (run by scripts/engine_emulated.sh)
 SKIP = ("full_size or config3 or config2 or 2592000 or 1296000 or soak or rccl or comm_rendezvous or graph or runs_out or config4 or "
         "noise_and_conversion or beyond_the_lds or 400000 or 2600000 or 2500000 or coherent_modes or linear_demodulator_on_the_device or "
-        "random_operations_on_the_device or "
+        "random_operations_on_the_device or null_stream or "
         # 75 s on the emulator for what tests/test_kernels_emulated.py::test_fm_loops_one_channel_per_lane_equal_one_lane_per_wavefront
         # pins at kernel level in 10 s (the engine-level comparison stays a GPU test)
         "fm_lane_passes_equal")

@@ -876,3 +876,18 @@ def test_engine_random_operations_on_the_device(seed):
     env.pop("CHZ_LIB", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "engine_fuzz_child.py"), str(seed), "300"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "FUZZ ok" in r.stdout, (r.stdout[-500:], r.stderr[-2500:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("queues", ["1", "2", "4"])
+def test_stream_set_up_survives_null_stream_traffic(queues):
+    """scripts/null_stream_soak.py: what bench.py runs in one process (free-running lanes with the ticketed notch, staged descriptor
+    refreshes, response swaps, the 8f chain of all three modes with its demodulator and PCM copy streams), twice, while another thread
+    hammers the legacy null stream through torch.  CHZ_OWN_QUEUES=1 (shipped: the two tail streams CU-masked = BLOCKING streams),
+    =2 (every lane masked: round 5's run that never came back -- the notch is now ordered by HIP events there, always) and =4 (priority
+    streams, non-blocking).  A deadlock shows up as the time-out."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "null_stream_soak.py")], capture_output=True, text=True, timeout=420,
+                       env=dict(os.environ, CHZ_OWN_QUEUES=queues))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(out["rounds"]) == 2 and out["null_stream_ops"] > 100, out

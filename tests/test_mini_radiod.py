@@ -148,6 +148,29 @@ def test_config3_through_the_reference_callers_on_the_dropin_host_code(tmp_path)
     assert s["frames_in_agreement"] == s["frames"] == 342 * nb + 341 * (nb // 4) + 341 * nb, s
 
 
+@needs_ref_exe
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="/root/reference absent: the caller objects cannot be linked here")
+def test_complex_front_end_and_sharded_master_on_the_dropin_host_code(tmp_path):
+    """the two remaining shapes of BASELINE.json through the reference's callers on the drop-in's host code (stand-in engine): config 1 -- a
+    COMPLEX 2.4 MS/s front end (write_cfilter), one IQ channel and one at a negative frequency --, and config 4's shape -- 2000 x 24 kHz
+    channels (Nchannels) behind ONE master whose slaves are sharded over two stand-in devices (KA9Q_HIP_DEVICES=0,1)"""
+    exe = _build_stub_link(str(tmp_path))
+    ch, lines = mr.config1_channels()
+    fs, l, m = 2.4e6, 48000, 12001
+    x = mr.complex_synth(lines, fs, 40 * l, 0.002, 3)
+    A, _, _ = mr.run(mr.REF_EXE, str(tmp_path / "ref1"), ch, x, fs, l, m, 40)
+    B, meta, _ = mr.run(exe, str(tmp_path / "got1"), ch, x, fs, l, m, 40)
+    s = mr.compare(A, B, float_tol=1e-6, n0_tol=1e-9)
+    assert s["frames_in_agreement"] == s["frames"] == 80 and A[3001][-1]["bin_shift"] < 0
+    ch, lines = mr.config4_channels()
+    fs, l, m = CONFIG3
+    x = mr.spectral_synth(lines, fs, 6 * l, 0.002, 11)
+    A, _, _ = mr.run(mr.REF_EXE, str(tmp_path / "ref4"), ch, x, fs, l, m, 6)
+    B, meta, _ = mr.run(exe, str(tmp_path / "got4"), ch, x, fs, l, m, 6, env={"CHZ_STUB_DEVICES": "2", "KA9Q_HIP_DEVICES": "0,1"})
+    s = mr.compare(A, B, float_tol=1e-6, n0_tol=1e-9)
+    assert s["frames_in_agreement"] == s["frames"] == 12000
+
+
 def _hip_exe():
     assert os.path.exists(mr.HIP_EXE), "tests/c/_prebuilt/mini_radiod_hip missing: __graft_entry__.build() makes it where /root/reference exists"
     assert os.path.exists(mr.REF_EXE), "oracle/_ref/mini_radiod_ref missing"
@@ -219,3 +242,39 @@ def test_baseline_config2_through_the_reference_callers_on_the_mi355x():
         s, B, meta = _ab(tmp, exe, ch, x, nb, geom=CONFIG2)
     print("mini-radiod config 2 A/B on the device:", s)
     assert int(meta["channels"]) == 256 and s["frames_in_agreement"] == s["frames"] and s["data"] > 600 and s["null"] > 2000
+
+
+@pytest.mark.gpu
+def test_baseline_config1_complex_front_end_through_the_reference_callers():
+    """BASELINE config 1 -- sig_gen COMPLEX 2.4 MS/s (N = 60,000), one IQ-mode channel -- and a channel on the negative side of the complex
+    spectrum: write_cfilter() front end, COMPLEX master, the reference's callers on the device against the same objects on the reference's filter.c."""
+    exe = _hip_exe()
+    ch, lines = mr.config1_channels()
+    geom = (2.4e6, 48000, 12001)
+    nb = 40
+    with tempfile.TemporaryDirectory() as tmp:
+        x = mr.complex_synth(lines, geom[0], nb * geom[1], 0.002, 3)
+        s, B, meta = _ab(tmp, exe, ch, x, nb, geom=geom)
+    print("mini-radiod config 1 (complex front end) A/B on the device:", s)
+    assert s["frames_in_agreement"] == s["frames"] == 2 * nb and s["data"] == 2 * nb
+
+
+@pytest.mark.gpu
+def test_config4_shape_sharded_behind_one_master_through_the_reference_callers():
+    """BASELINE config 4's shape as far as ONE radiod reaches: 2000 x 24 kHz channels (P = 600; Nchannels = 2000, src/radio.h:356) at 129.6 MS/s,
+    2000 real channel threads, the slaves of the ONE master sharded by the drop-in over KA9Q_HIP_DEVICES=0,0 (1024 per shard; two engines on the
+    one device of this box: distinct devices are unmeasured), in lock step and at wall-clock pace."""
+    exe = _hip_exe()
+    ch, lines = mr.config4_channels()
+    env = {"KA9Q_HIP_DEVICES": "0,0"}
+    with tempfile.TemporaryDirectory() as tmp:
+        x = mr.spectral_synth(lines, CONFIG3[0], 8 * CONFIG3[1], 0.002, 11)
+        s, B, meta = _ab(tmp, exe, ch, x, 8, geom=CONFIG3, env=env)
+        print("mini-radiod config 4 shape, two shards, A/B on the device:", s)
+        assert int(meta["channels"]) == 2000 and s["frames_in_agreement"] == s["frames"] == 2000 * 8
+    with tempfile.TemporaryDirectory() as tmp:
+        nb = 20
+        x = mr.spectral_synth(lines, CONFIG3[0], nb * CONFIG3[1], 0.002, 12)
+        s, B, meta = _ab(tmp, exe, ch, x, nb, geom=CONFIG3, env=env, paced=1)
+        print("mini-radiod config 4 shape, two shards, paced A/B on the device:", s)
+        assert all(f["block_drops"] == 0 for F in B.values() for f in F) and s["frames_in_agreement"] == s["frames"]
