@@ -284,18 +284,30 @@ def cpu_baseline(oracle_lib, ring, wl, seconds=12.0, crt_blocks=500):
                 c = m.channel(olen, oracle_lib.COMPLEX); c.set_filter(low, high, 11.0); chans.append(c)
             harr = (ctypes.c_void_p * n)(*[c.h for c in chans[:n]])
             sh = np.array([plan[i % len(plan)][0] for i in range(n)], np.int32)
-            reps = []
-            for _ in range(REPEATS):
+            reps, hiccups = [], []
+
+            def one():
                 st = (ctypes.c_double * 4)()
                 if hasattr(R, "refchz_reset_drops"):
                     R.refchz_reset_drops(harr, n)
                 R.refchz_bench_blocks(m.h, harr, sh.ctypes.data, n, ring.ctypes.data, RING_BLOCKS, per_rep + 8, pool, 8, st, int(BLOCKTIME * 1e6))
-                reps.append({"block_drops": int(st[3]), "mean_completion_interval_ms": st[1], "worst_completion_interval_ms": st[0], "worst_latency_ms": st[2]})
-                if st[3] > 0:
-                    break                                 # lapped once: not sustained, the other repeats would say nothing new
+                return {"block_drops": int(st[3]), "mean_completion_interval_ms": st[1], "worst_completion_interval_ms": st[0], "worst_latency_ms": st[2]}
+            for _ in range(REPEATS):
+                r = one()
+                # ONE stall of the shared host (> 4 block times: every channel still waiting is lapped once) is not overload: the backlog did not
+                # grow (mean completion interval inside 1 %) and only a few per cent of the channel-blocks were lapped.  Round 5 / 6: exactly
+                # that made the figure flip between two rungs from run to run (65,536 channels need 6.7 of the quota's 16 CPUs).  Such a
+                # repeat is run again, at most twice per rung; a rung that laps again is not sustained.  Overload looks different (131,072:
+                # a third of all channel-blocks lapped, mean interval 22 ms) and fails at once.
+                while (r["block_drops"] > 0 and r["block_drops"] < 0.05 * n * per_rep and r["mean_completion_interval_ms"] <= 1.01 * BLOCKTIME * 1e3 and len(hiccups) < 2):
+                    hiccups.append(r)
+                    r = one()
+                reps.append(r)
+                if r["block_drops"] > 0:
+                    break                                 # lapped: not sustained, the other repeats would say nothing new
             ok = len(reps) == REPEATS and all(r["block_drops"] == 0 and r["mean_completion_interval_ms"] <= 1.01 * BLOCKTIME * 1e3 for r in reps)
-            return {"channels": n, "repeats": reps, "fft_workers": workers, "block_drops": sum(r["block_drops"] for r in reps),
-                    "worst_latency_ms": max(r["worst_latency_ms"] for r in reps), "sustained": bool(ok)}
+            return {"channels": n, "repeats": reps, "repeats_run_again_after_a_host_stall": hiccups or None, "fft_workers": workers,
+                    "block_drops": sum(r["block_drops"] for r in reps), "worst_latency_ms": max(r["worst_latency_ms"] for r in reps), "sustained": bool(ok)}
         # x4 ladder from 4096 (down to 1024 / 256 if that already fails), then ONE bisection step between the last sustained and the
         # first failed count; a rung = 3 repeats of crt_blocks/3 paced blocks, sustained only if NO repeat lapped a channel
         m = oracle_lib.RefMaster(wl["L"], wl["M"], oracle_lib.REAL, worker_threads=2)
@@ -332,7 +344,8 @@ def cpu_baseline(oracle_lib, ring, wl, seconds=12.0, crt_blocks=500):
                    "worst_latency_ms": best["worst_latency_ms"] if best else None, "probes": probes,
                    "definition": "front end paced at one block per 20 ms of wall clock, never waiting (as an A/D); a channel count is sustained if in EACH of %d "
                                  "repeats of %d blocks no channel was lapped (block_drops = 0, src/filter.c:686-701) and the mean completion interval stayed "
-                                 "within 1 %% of 20 ms (no growing backlog); the worst arrival-to-last-channel latency is reported, not judged (scheduler noise "
+                                 "within 1 %% of 20 ms (no growing backlog) -- a repeat that lapped < 5 %% of its channel-blocks with the mean interval intact (ONE stall of the "
+                                 "shared host) is run again, at most twice per rung; the worst arrival-to-last-channel latency is reported, not judged (scheduler noise "
                                  "of a shared host decided round 4's figure); 2 FFT worker threads (docs/ka9q-radio.md:232) + a POOL of %d channel threads each "
                                  "looping over a static channel subset (SURVEY 8d; radiod itself runs one thread per channel and stops at Nchannels = 2000, "
                                  "src/radio.h:356); ladder x4 from 4096 + one bisection step.  NOT the GPU's criterion: c_rt (GPU) demands every single block complete "

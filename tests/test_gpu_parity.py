@@ -448,13 +448,14 @@ def test_siggen_scaled_down_vs_reference(pkg):
 
 
 def test_siggen_config2_halfrate_256_channels(pkg):
-    # BASELINE config 2: 64.8 MS/s real, 256 x 12 kHz channels (P = 300)
-    _siggen_run(pkg, 1296000, 324001, 64.8e6, 256, 300, 240, 2, ref_check=8)
+    # BASELINE config 2: 64.8 MS/s real, 256 x 12 kHz channels (P = 300); round 6: EVERY channel also against the reference's own filter.c
+    _siggen_run(pkg, 1296000, 324001, 64.8e6, 256, 300, 240, 2, ref_check=256)
 
 
 def test_siggen_config3_fullrate_1024_channels(pkg):
-    # BASELINE config 3: 129.6 MS/s real, 1024 mixed usb/cw/iq channels (P = 300)
-    _siggen_run(pkg, 2592000, 648001, 129.6e6, 1024, 300, 240, 2, ref_check=8)
+    # BASELINE config 3: 129.6 MS/s real, 1024 mixed usb/cw/iq channels (P = 300); round 6: EVERY channel also against the reference's own
+    # filter.c (rounds 2-5 compared the first 8: the reference side costs 0.2 s per block, not minutes)
+    _siggen_run(pkg, 2592000, 648001, 129.6e6, 1024, 300, 240, 2, ref_check=1024)
 
 
 def test_config4_style_p600(pkg):
