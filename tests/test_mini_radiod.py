@@ -172,6 +172,8 @@ def test_complex_front_end_and_sharded_master_on_the_dropin_host_code(tmp_path):
 
 
 def _hip_exe():
+    if os.path.isdir(REF_SRC):          # (this container: rebuild if the sources or the libraries changed; the GPU box runs what travelled)
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), "all"], check=True)
     assert os.path.exists(mr.HIP_EXE), "tests/c/_prebuilt/mini_radiod_hip missing: __graft_entry__.build() makes it where /root/reference exists"
     assert os.path.exists(mr.REF_EXE), "oracle/_ref/mini_radiod_ref missing"
     return mr.HIP_EXE
