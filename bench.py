@@ -1064,12 +1064,59 @@ def main():
         self_spawn(args)
 
     t_start = time.perf_counter()
+    rank = int(os.environ.get("RANK", "0"))
+    emit_box = {}                         # the function that prints the line, once it exists (defined below, after the engine is up)
+    # ---- per-leg watchdog.  Every leg announces itself through progress(); a leg that is still running when its budget is spent is reported in
+    # the line ("leg_timeouts") and the run ENDS there with rc 0 and whatever the finished legs measured: a thread, not a signal (the main thread
+    # may be blocked inside a HIP call, and a blocked ctypes / torch call does not run Python signal handlers).  Budgets: several times what the
+    # leg takes on a healthy box (profiles/r05_bench_detail.json leg_seconds), BENCH_LEG_BUDGET_SCALE scales them, BENCH_LEG_BUDGET_S replaces them.
+    LEG_BUDGET_S = {"startup": 420, "headline": 120, "exchange": 90, "roofline": 120, "c_rt": 180, "cpu_baseline": 150, "dropin": 150, "dropin_paced": 150,
+                    "dropin_sharded": 90, "c_rt_pcie": 200, "next_rows": 240}
+    wd = {"leg": None, "t0": 0.0, "budget": 0.0}
+
+    def progress(what):
+        if rank == 0:
+            print("bench.py [%6.1f s] %s" % (time.perf_counter() - t_start, what), file=sys.stderr, flush=True)
+        key = what.split()[0].rstrip(":")
+        key = {"dropin": "dropin"}.get(key, key)
+        budget = float(os.environ.get("BENCH_LEG_BUDGET_S", 0)) or LEG_BUDGET_S.get(key, 240) * float(os.environ.get("BENCH_LEG_BUDGET_SCALE", "1"))
+        # the other ranks give rank 0 the time to print before the launcher sees anybody exit
+        wd["t0"], wd["budget"], wd["leg"] = time.perf_counter(), budget + (0 if rank == 0 else 20), what
+        if os.environ.get("BENCH_TEST_HANG_LEG") and what.startswith(os.environ["BENCH_TEST_HANG_LEG"]):
+            while True:                              # (tests: a leg that never comes back)
+                time.sleep(0.2)
+
+    def watchdog():
+        while True:
+            time.sleep(0.5)
+            leg = wd["leg"]
+            if leg is None or time.perf_counter() - wd["t0"] <= wd["budget"]:
+                continue
+            print("bench.py: leg '%s' has been running for %.0f s (budget %.0f s): giving up on it -- printing the line with what was measured and ending the run"
+                  % (leg, time.perf_counter() - wd["t0"], wd["budget"]), file=sys.stderr, flush=True)
+            try:
+                import faulthandler
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)      # where every thread of this process sits
+            except Exception:
+                pass
+            try:
+                if emit_box.get("fn"):
+                    emit_box["fn"]([leg])
+                elif rank == 0:                      # nothing has been measured yet (the runtime / the engine never came up): still ONE strict line, rc 0
+                    print(json.dumps({"metric": "channels sustained @129.6 MS/s input (real-time-equivalent: channel-blocks/s / 50)", "value": None, "unit": "channels",
+                                      "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                                      "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "not reached"}, "roofline": None, "cpu_baseline": None,
+                                      "leg_timeouts": [leg], "headline_from": None}))
+            finally:
+                sys.stdout.flush(); sys.stderr.flush()
+                os._exit(0)
+    threading.Thread(target=watchdog, daemon=True, name="bench-watchdog").start()
+    progress("startup")                   # importing torch on a fresh box, the process group, the engine and its bank, the input ring
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
     import oracle_lib
 
-    rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -1183,45 +1230,6 @@ def main():
             job += reps * args.steps
         return statistics.median(times), times, last, reps, single
 
-    # ---- per-leg watchdog.  Every leg announces itself through progress(); a leg that is still running when its budget is spent is reported in
-    # the line ("leg_timeouts") and the run ENDS there with rc 0 and whatever the finished legs measured: a thread, not a signal (the main thread
-    # may be blocked inside a HIP call, and a blocked ctypes / torch call does not run Python signal handlers).  Budgets: several times what the
-    # leg takes on a healthy box (profiles/r05_bench_detail.json leg_seconds), BENCH_LEG_BUDGET_SCALE scales them, BENCH_LEG_BUDGET_S replaces them.
-    LEG_BUDGET_S = {"headline": 120, "exchange": 90, "roofline": 120, "c_rt": 180, "cpu_baseline": 150, "dropin": 150, "dropin_paced": 150,
-                    "dropin_sharded": 90, "c_rt_pcie": 200, "next_rows": 240}
-    wd = {"leg": None, "t0": 0.0, "budget": 0.0}
-
-    def progress(what):
-        if rank == 0:
-            print("bench.py [%6.1f s] %s" % (time.perf_counter() - t_start, what), file=sys.stderr, flush=True)
-        key = what.split()[0].rstrip(":")
-        key = {"dropin": "dropin"}.get(key, key)
-        budget = float(os.environ.get("BENCH_LEG_BUDGET_S", 0)) or LEG_BUDGET_S.get(key, 240) * float(os.environ.get("BENCH_LEG_BUDGET_SCALE", "1"))
-        # the other ranks give rank 0 the time to print before the launcher sees anybody exit
-        wd["t0"], wd["budget"], wd["leg"] = time.perf_counter(), budget + (0 if rank == 0 else 20), what
-        if os.environ.get("BENCH_TEST_HANG_LEG") and what.startswith(os.environ["BENCH_TEST_HANG_LEG"]):
-            while True:                              # (tests: a leg that never comes back)
-                time.sleep(0.2)
-
-    def watchdog():
-        while True:
-            time.sleep(0.5)
-            leg = wd["leg"]
-            if leg is None or time.perf_counter() - wd["t0"] <= wd["budget"]:
-                continue
-            print("bench.py: leg '%s' has been running for %.0f s (budget %.0f s): giving up on it -- printing the line with what was measured and ending the run"
-                  % (leg, time.perf_counter() - wd["t0"], wd["budget"]), file=sys.stderr, flush=True)
-            try:
-                import faulthandler
-                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)      # where every thread of this process sits
-            except Exception:
-                pass
-            try:
-                emit([leg])
-            finally:
-                sys.stdout.flush(); sys.stderr.flush()
-                os._exit(0)
-    threading.Thread(target=watchdog, daemon=True, name="bench-watchdog").start()
     legs = {}
     leg_seconds = {}                      # wall seconds of every leg of this run (rank 0): the time budget of the bench line
     # ---- everything the line is built from exists from here on (None until its leg has run), so that the line can be printed at ANY moment:
@@ -1314,6 +1322,7 @@ def main():
 
     t_leg = time.perf_counter()
     graph = bool(args.graph) and not use_dist
+    emit_box["fn"] = emit
     progress("headline")
     intended_leg = None
     if comm is not None:

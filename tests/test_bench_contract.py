@@ -284,3 +284,19 @@ def test_a_leg_that_never_comes_back_costs_its_own_numbers_not_the_line(tmp_path
     env = dict(os.environ, BENCH_TEST_HANG_LEG="headline", BENCH_LEG_BUDGET_S="4")
     h, j = _run_bench(["--quick", "--steps", "20", "--warmup", "5"], tmp_path, timeout=300, env=env)
     assert h["leg_timeouts"] == ["headline"] and h["value"] is None and h["roofline"] is None
+    # ... and when nothing ever comes up (the runtime, the engine): the start-up has a budget too
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--quick"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, BENCH_TEST_HANG_LEG="startup", BENCH_LEG_BUDGET_S="3"))
+    assert r.returncode == 0, r.stderr[-1000:]
+    h = _strict(r.stdout.strip().splitlines()[-1])
+    assert h["leg_timeouts"] == ["startup"] and h["value"] is None and h["metric"].startswith("channels sustained")
+
+
+def test_bench_startup_has_a_time_budget_too():
+    """no GPU needed: the watchdog runs from the first line of main() -- a process that never gets as far as its first measurement (the
+    runtime or the engine never coming up) still prints ONE strict line with a null value and rc 0 after the start-up budget"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--quick"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, BENCH_TEST_HANG_LEG="startup", BENCH_LEG_BUDGET_S="2"))
+    assert r.returncode == 0, r.stderr[-1000:]
+    h = _strict(r.stdout.strip().splitlines()[-1])
+    assert h["leg_timeouts"] == ["startup"] and h["value"] is None and h["n_gpus"] == 1 and "giving up on it" in r.stderr
