@@ -65,9 +65,18 @@ def pmc_json(fetch_dir, write_dir, out):
               open(out, "w"), indent=1)
     print("wrote", out, total)
 
-def kernels_json(dir4, dir1, out, tag):
-    """average kernel durations of the bench command under rocprofv3 --kernel-trace --stats (4 streams and 1 stream)"""
+def kernels_json(dir4, dir1, out, tag, plain=""):
+    """average kernel durations of the bench command under rocprofv3 --kernel-trace --stats (4 streams and 1 stream); `plain` = the detail file of
+    the SAME command run unprofiled on the SAME box right before (round 6: boxes differ by 10 %, so a trace from one box and HIP-event
+    durations from another do not say whether the two methods agree)"""
     import json
+    same_box = None
+    if plain and os.path.exists(plain):
+        try:
+            r = json.load(open(plain))["roofline"]
+            same_box = {"hip_event_kernels_us": r["kernels_us"], "hip_event_forward_us": r["forward_us_per_block"], "frac": r["frac"]}
+        except Exception as ex:
+            same_box = {"error": str(ex)[:200]}
     def avgs(d):
         r = {}
         for db in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
@@ -81,12 +90,14 @@ def kernels_json(dir4, dir1, out, tag):
     json.dump({"round": tag, "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --quick", "kernel_sources_sha16": tree_sha16(),
                "forward_us_1_stream": fwd1, "forward_us_4_streams_sum_of_overlapping_kernels": fwd4,
                "kernels_1_stream": k1, "kernels_4_streams": k4,
+               "same_box_unprofiled": same_box,
+               "rocprof_over_hip_events": (fwd1 / same_box["hip_event_forward_us"]) if same_box and same_box.get("hip_event_forward_us") else None,
                "note": "CHZ_STREAMS=1: one kernel at a time, comparable with roofline.kernels_us; profiled runs are about 10 % slower than unprofiled ones"},
               open(out, "w"), indent=1)
     print("wrote", out, "forward 1 stream %.2f us" % fwd1)
 
 if len(sys.argv) > 1 and sys.argv[1] == "--kernels-json":
-    kernels_json(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else ""); sys.exit(0)
+    kernels_json(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "", sys.argv[6] if len(sys.argv) > 6 else ""); sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "--json":
     pmc_json(sys.argv[2], sys.argv[3], sys.argv[4]); sys.exit(0)
 
