@@ -68,9 +68,14 @@ struct capture {
   unsigned char *buf; size_t len, cap;
   struct event ev[MAXEV]; int nev;
   atomic_int status_calls; int commands;
+  int start, life;                  /* joins when `start` blocks have been written (0: before the front end starts); lives for `life` blocks (0: to the end of the run) */
+  int slot;                         /* its Channel_list[] entry */
+  double freq; chan_t *tmpl;        /* what it is created from (late joiners: by the front-end thread) */
 };
-static struct capture Cap[Nchannels];  /* indexed like Channel_list[] */
-static int Nchan;                      /* channels this run started */
+static struct capture Cap[2 * Nchannels];  /* in creation order */
+static int SlotCap[Nchannels];         /* Channel_list[] slot -> Cap[] index of the channel that lives there now (a slot is reused after close_chan()) */
+static int Nchan;                      /* channels this run has started so far */
+#define CAP_OF(chan) (&Cap[SlotCap[(chan) - Channel_list]])
 
 struct frame_hdr {                     /* one per send_output() call; tests/test_mini_radiod.py reads this layout */
   uint32_t ssrc, call, next_jobnum, block_drops;
@@ -90,7 +95,7 @@ static void cap_append(struct capture *c, const void *p, size_t n) {
 
 /* src/audio.c:41 send_output(): the demodulators call it once per block (src/linear.c:340,344,366; src/fm.c:172,307,335) */
 int send_output(chan_t *restrict const chan, float const *restrict buffer, int frames, bool const mute) {
-  struct capture *c = &Cap[chan - Channel_list];
+  struct capture *c = CAP_OF(chan);
   if (chan == NULL || frames <= 0 || chan->output.channels == 0 || chan->output.samprate == 0) return 0;      /* src/audio.c:43-44 */
   struct frame_hdr h;
   memset(&h, 0, sizeof h);
@@ -146,7 +151,7 @@ int send_output(chan_t *restrict const chan, float const *restrict buffer, int f
 bool decode_radio_commands(chan_t *chan, uint8_t const *buffer, int length) {
   if (length != (int)sizeof(struct event)) return false;
   struct event e; memcpy(&e, buffer, sizeof e);
-  struct capture *c = &Cap[chan - Channel_list];
+  struct capture *c = CAP_OF(chan);
   c->commands++;
   chan->status.packets_in++;
   /* NOT mirrored: "chan->lifetime = chan->lifestart" (src/radio_status.c:141) -- the lifetime counter is this test's block budget */
@@ -162,7 +167,7 @@ bool decode_radio_commands(chan_t *chan, uint8_t const *buffer, int length) {
 }
 int send_radio_status(struct sockaddr const *sock, struct frontend const *frontend, chan_t *chan) {
   (void)sock; (void)frontend;
-  atomic_fetch_add(&Cap[chan - Channel_list].status_calls, 1);
+  atomic_fetch_add(&CAP_OF(chan)->status_calls, 1);
   return 0;
 }
 
@@ -176,8 +181,10 @@ static struct {
   double worst_wait_ms;
 } FE;
 
+static int Ncfg;                       /* channels of the configuration file */
+static int create_channel(int ci);
 static bool all_channels_took(uint32_t job) {        /* every running channel has next_jobnum >= job */
-  for (int i = 0; i < Nchan; i++) {
+  for (int i = 0; i < Nchannels; i++) {
     chan_t *ch = &Channel_list[i];
     if (ch->state != CHANNEL_RUNNING || ch->filter.out.master != &Frontend.in) continue;
     if ((int32_t)(*(volatile unsigned int *)&ch->filter.out.next_jobnum - job) < 0) return false;
@@ -199,6 +206,13 @@ static void *fe_thread(void *arg) {
     } else if (b >= FE.slack) {
       while (!all_channels_took((uint32_t)(b - FE.slack + 1))) usleep(100);
     }
+    /* dynamic channels: created while the stream runs, as radiod creates one when a client asks for an unknown ssrc (src/radio_status.c:60-96);
+       the test wants both links to attach the newcomer at the SAME block, so the front end waits until it is in its loop */
+    for (int i = 0; i < Ncfg; i++)
+      if (Cap[i].start == b && b > 0) {
+        if (create_channel(i) != 0) abort();
+        for (int spins = 0; atomic_load(&Cap[i].status_calls) == 0; spins++) { if (spins > 300000) { fprintf(stderr, "mini_radiod: late channel %u never came up\n", Cap[i].ssrc); abort(); } usleep(100); }
+      }
     int r;
     if (FE.isreal) {
       float *wptr = fe->in.input_write_pointer.r;                    /* src/rx888.c:730-800: convert in place, then hand over */
@@ -215,7 +229,11 @@ static void *fe_thread(void *arg) {
   atomic_store(&FE.done, 1);
   return NULL;
 }
-static int fe_start(struct frontend *fe) { return pthread_create(&FE.thread, NULL, fe_thread, fe); }   /* called by lookup_or_create_chan() for the first channel, src/radio.c:898-904 */
+static int fe_start(struct frontend *fe) {     /* (again whenever the channel count comes up from zero: the sample thread is started once) */
+  static atomic_int started;
+  if (atomic_exchange(&started, 1)) return 0;
+  return pthread_create(&FE.thread, NULL, fe_thread, fe);
+}   /* called by lookup_or_create_chan() for the first channel, src/radio.c:898-904 */
 static atomic_int Shutdowns;
 static int fe_shutdown(struct frontend *fe) { (void)fe; atomic_fetch_add(&Shutdowns, 1); return 0; }  /* called by close_chan() of the last channel, src/radio.c:1088-1091 */
 
@@ -278,6 +296,8 @@ static int apply_kv(chan_t *chan, struct capture *c, char const *k, char const *
   else if (!strcmp(k, "tone")) chan->fm.tone_freq = fabs(x);
   else if (!strcmp(k, "update")) chan->status.output_interval = abs((int)x);
   else if (!strcmp(k, "filter2")) chan->filter2.blocking = abs((int)x);
+  else if (!strcmp(k, "start")) c->start = (int)x;         /* this test's own: the channel is created when `start` blocks have been written ... */
+  else if (!strcmp(k, "life")) c->life = (int)x;           /* ... and its "lifetime" (src/modes.c:329-330) runs out after `life` blocks */
   /* this test's own keys: a command for the channel's own command queue at a given frame */
   else if (!strcmp(k, "retune") || !strcmp(k, "edges")) {
     if (c->nev >= MAXEV) return -1;
@@ -285,6 +305,27 @@ static int apply_kv(chan_t *chan, struct capture *c, char const *k, char const *
     e->kind = k[0] == 'r' ? 'F' : 'W';
     if (sscanf(v, "%d:%lf:%lf", &e->frame, &e->a, &e->b) < 2) return -1;
   } else return -1;
+  return 0;
+}
+
+/* src/radio.c:807-834: what process_section() does per frequency (and what radio_status.c does for a dynamic channel: src/radio_status.c:60-96) */
+static int create_channel(int ci) {
+  struct capture *c = &Cap[ci];
+  chan_t *tmpl = c->tmpl;
+  if (c->life > 0) tmpl->lifestart = tmpl->lifetime = c->life + 1;
+  else if (c->start > 0) tmpl->lifestart = tmpl->lifetime = FE.nblocks - c->start + 1;
+  chan_t *chan = lookup_or_create_chan(c->ssrc, tmpl);
+  if (chan == NULL || chan->state != CHANNEL_STARTING) { fprintf(stderr, "mini_radiod: ssrc %u\n", c->ssrc); return -1; }
+  c->slot = (int)(chan - Channel_list);
+  SlotCap[c->slot] = ci;
+  snprintf(chan->name, sizeof chan->name, "%s %u", demod_name_from_type(chan->demod_type), chan->output.rtp.ssrc);
+  set_freq(chan, c->freq);
+  pthread_mutex_unlock(&chan->status.lock);
+  pthread_mutex_lock(&Channel_list_mutex);
+  chan->state = CHANNEL_RUNNING;
+  pthread_mutex_unlock(&Channel_list_mutex);
+  Nchan++;
+  start_demod(chan);
   return 0;
 }
 
@@ -298,7 +339,7 @@ int main(int argc, char **argv) {
   if (fscanf(f, "%lf %d %d %d %d %d %d", &FE.samprate, &FE.L, &FE.M, &FE.nblocks, &nchan, &FE.paced, &FE.slack) != 7) { fprintf(stderr, "bad cfg\n"); return 2; }
   FE.isreal = 1;
   { int c = fgetc(f); while (c == ' ') c = fgetc(f); if (c == 'c') FE.isreal = 0; else if (c != EOF) ungetc(c, f); }      /* an 8th token "complex": a complex front end */
-  if (nchan > Nchannels || FE.slack < 1 || FE.slack > 3) { fprintf(stderr, "bad cfg\n"); return 2; }
+  if (nchan > 2 * Nchannels || FE.slack < 1 || FE.slack > 3) { fprintf(stderr, "bad cfg\n"); return 2; }
   size_t const per = FE.isreal ? 1 : 2;
   FE.samples = malloc(sizeof(float) * per * (size_t)FE.L * FE.nblocks);
   snprintf(path, sizeof path, "%s/in.f32", argv[1]);
@@ -306,6 +347,7 @@ int main(int argc, char **argv) {
   if (!g || fread(FE.samples, sizeof(float) * per * FE.L, FE.nblocks, g) != (size_t)FE.nblocks) { perror(path); return 2; }
   fclose(g);
 
+  if (getenv("MINI_RADIOD_VERBOSE")) Verbose = atoi(getenv("MINI_RADIOD_VERBOSE"));
   if (getenv("MINI_RADIOD_FFT_F32") && oracle_fft_set_precision) oracle_fft_set_precision(1);
   /* src/osc.c:96-98: nco() fills its sine table on first use, and only the FIRST caller waits for that -- channel threads that start their
      PLLs at the same moment read a half-filled table (a start-up transient in radiod; here it made one run in eight of the checker link differ
@@ -338,19 +380,10 @@ int main(int argc, char **argv) {
     }
     if (tmpl.filter.min_IF > tmpl.filter.max_IF) { double t = tmpl.filter.min_IF; tmpl.filter.min_IF = tmpl.filter.max_IF; tmpl.filter.max_IF = t; }   /* src/modes.c:372-377 */
     tmpl.output.rtp.type = pt_from_info(tmpl.output.samprate, tmpl.output.channels, tmpl.output.encoding);                                                /* :355-362 */
-    chan_t *chan = lookup_or_create_chan(ssrc, &tmpl);
-    if (chan == NULL || chan->state != CHANNEL_STARTING) { fprintf(stderr, "mini_radiod: ssrc %u\n", ssrc); return 3; }
-    struct capture *c = &Cap[chan - Channel_list];
-    *c = cfg; c->ssrc = ssrc;
-    if ((int)(chan - Channel_list) != i) { fprintf(stderr, "mini_radiod: channel table order\n"); return 3; }
-    snprintf(chan->name, sizeof chan->name, "%s %u", demod_name_from_type(chan->demod_type), chan->output.rtp.ssrc);
-    set_freq(chan, freq);
-    pthread_mutex_unlock(&chan->status.lock);
-    pthread_mutex_lock(&Channel_list_mutex);
-    chan->state = CHANNEL_RUNNING;
-    pthread_mutex_unlock(&Channel_list_mutex);
-    Nchan = i + 1;
-    start_demod(chan);
+    int const ci = Ncfg++;
+    Cap[ci] = cfg; Cap[ci].ssrc = ssrc; Cap[ci].freq = freq;
+    Cap[ci].tmpl = malloc(sizeof tmpl); *Cap[ci].tmpl = tmpl;
+    if (Cap[ci].start == 0 && create_channel(ci) != 0) return 3;
   }
   fclose(f);
 
@@ -359,19 +392,20 @@ int main(int argc, char **argv) {
    * barrier (channels that join later start at the master's current block); the test wants every channel to see block 0 */
   for (int spins = 0;; spins++) {
     int ready = 0;
-    for (int i = 0; i < Nchan; i++) ready += atomic_load(&Cap[i].status_calls) > 0;
-    if (ready == Nchan) break;
-    if (spins > 600000) { fprintf(stderr, "mini_radiod: %d of %d channels in their loops after 60 s\n", ready, Nchan); return 4; }
+    int want = 0;
+    for (int i = 0; i < Ncfg; i++) if (Cap[i].start == 0) { want++; ready += atomic_load(&Cap[i].status_calls) > 0; }
+    if (ready == want) break;
+    if (spins > 600000) { fprintf(stderr, "mini_radiod: %d of %d channels in their loops after 60 s\n", ready, want); return 4; }
     usleep(100);
   }
   struct timespec t0, t1; clock_gettime(CLOCK_MONOTONIC, &t0);
   atomic_store(&FE.go, 1);
   /* channels run down their lifetime (downconvert() returns -1, src/radio.c:1424-1431), demod_thread() cleans up, close_chan() marks the entry idle */
   for (int spins = 0;; spins++) {
-    int idle = 0;
-    for (int i = 0; i < Nchan; i++) idle += Channel_list[i].state == CHANNEL_IDLE;
-    if (idle == Nchan) break;
-    if (spins > 6000000) { fprintf(stderr, "mini_radiod: %d of %d channels finished after 10 min\n", idle, Nchan); return 5; }
+    int idle = 0;                    /* (a slot may have been taken over by a later channel: idle = created and its slot idle or no longer its own) */
+    for (int i = 0; i < Ncfg; i++) idle += atomic_load(&Cap[i].status_calls) > 0 && (SlotCap[Cap[i].slot] != i || Channel_list[Cap[i].slot].state == CHANNEL_IDLE);
+    if (idle == Ncfg && atomic_load(&FE.done)) break;
+    if (spins > 6000000) { fprintf(stderr, "mini_radiod: %d of %d channels finished after 10 min\n", idle, Ncfg); return 5; }
     usleep(100);
   }
   clock_gettime(CLOCK_MONOTONIC, &t1);
@@ -382,7 +416,8 @@ int main(int argc, char **argv) {
   snprintf(path, sizeof path, "%s/frames.bin", argv[1]);
   g = fopen(path, "wb");
   long total_calls = 0, commands = 0, status = 0;
-  for (int i = 0; i < Nchan; i++) {
+  for (int i = 0; i < Ncfg; i++) {
+    if (getenv("MINI_RADIOD_DEBUG")) fprintf(stderr, "chan %d ssrc %u slot %d start %d life %d calls %d status %d len %zu\n", i, Cap[i].ssrc, Cap[i].slot, Cap[i].start, Cap[i].life, Cap[i].calls, atomic_load(&Cap[i].status_calls), Cap[i].len);
     fwrite(Cap[i].buf, 1, Cap[i].len, g);
     total_calls += Cap[i].calls; commands += Cap[i].commands; status += atomic_load(&Cap[i].status_calls);
   }

@@ -359,3 +359,20 @@ def config4_channels(nch=2000, every=10):
                 ph = 0.21 * i + df * 1e-3
                 lines.append((f + df, a * rel, ph)); lines.append((f + df + 3.1, 0.2 * a * rel, ph + 1.0)); lines.append((f + df - 2.7, 0.2 * a * rel, ph - 0.5))
     return ch, lines
+
+
+def churn_channels():
+    """the standard 48-channel table with channels LEAVING mid-stream (their lifetime runs out: downconvert() returns -1, demod_thread()
+    cleans up, close_chan() frees the Channel_list slot -- delete_filter_output while the others run) and channels JOINING mid-stream
+    (lookup_or_create_chan() / start_demod() from the front-end thread, as radiod creates a dynamic channel: create_filter_output on a
+    running master, a bank that grows and is warmed while blocks flow; the newcomers take over the slots the leavers freed)."""
+    ch = standard_channels()
+    for i, life in ((1, 6), (8, 9), (13, 9), (20, 14), (27, 4), (33, 17), (40, 11), (46, 22)):
+        ch[i].extra = (ch[i].extra + " life=%d" % life).strip()
+    # the newcomers tune to where the leavers (and two stayers) are: the front end covers 0 ... 609 kHz (0.47 x fs) and the table fills it;
+    # they listen to the signal that is already there (no signal of their own: amp 0), 13 Hz off so that their fine oscillators turn
+    spots = [ch[i].freq for i in (27, 1, 8, 13, 20, 33, 40, 46, 4, 22)]
+    for j, (start, kind) in enumerate(((7, "usb"), (7, "fm"), (10, "iq"), (12, "cwu"), (15, "am"), (15, "nfm"), (19, "lsb"), (24, "sam"), (24, "pm"), (26, "usb"))):
+        c = Channel(300 + j, spots[j] + 13.0, kind, ("start=%d" % start) + (" encoding=f32le" if j % 3 == 0 else ""), {"kind": kind, "amp": 0.0})
+        ch.append(c)
+    return ch

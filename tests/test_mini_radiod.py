@@ -171,6 +171,35 @@ def test_complex_front_end_and_sharded_master_on_the_dropin_host_code(tmp_path):
     assert s["frames_in_agreement"] == s["frames"] == 12000
 
 
+def _check_churn(fr, nblocks):
+    by = {c.ssrc: c for c in mr.churn_channels()}
+    assert sorted(fr) == sorted(by), sorted(set(by) - set(fr))           # every channel, the late ones included, produced frames
+    for ssrc, F in fr.items():
+        c = by[ssrc]
+        kv = dict(t.split("=", 1) for t in c.extra.split() if "=" in t)
+        start, life = int(kv.get("start", 0)), int(kv.get("life", 0))
+        blocks = life if life else nblocks - start
+        per = 4 if c.preset in ("cwu", "cwl") else 1
+        assert len(F) == blocks // per, (ssrc, c.preset, start, life, len(F))
+        assert F[0]["next_jobnum"] == start + per and all(f["block_drops"] == 0 for f in F), (ssrc, F[0]["next_jobnum"], start)
+
+
+@needs_ref_exe
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="/root/reference absent: the caller objects cannot be linked here")
+def test_channels_joining_and_leaving_on_the_dropin_host_code(tmp_path):
+    """radiod's dynamic channels through the reference's own lifecycle code on the drop-in's host code (stand-in engine): eight channels run
+    out of lifetime mid-stream (close_chan -> delete_filter_output while 50 others run), ten join mid-stream (create_filter_output on a
+    running master from another thread, the bank grows, the newcomers reuse the freed Channel_list slots)"""
+    exe = _build_stub_link(str(tmp_path))
+    ch = mr.churn_channels()
+    x = mr.synthesise(ch, FS, L, NBLOCKS, seed=21)
+    A, _, _ = _reference_run(str(tmp_path), ch, x)
+    B, meta, _ = mr.run(exe, str(tmp_path / "got"), ch, x, FS, L, M, NBLOCKS)
+    _check_churn(A, NBLOCKS)
+    s = mr.compare(A, B, float_tol=1e-6, n0_tol=1e-9)
+    assert int(meta["channels"]) == 58 and s["frames_in_agreement"] == s["frames"], s
+
+
 def _hip_exe():
     if os.path.isdir(REF_SRC):          # (this container: rebuild if the sources or the libraries changed; the GPU box runs what travelled)
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), "all"], check=True)
@@ -280,3 +309,18 @@ def test_config4_shape_sharded_behind_one_master_through_the_reference_callers()
         s, B, meta = _ab(tmp, exe, ch, x, nb, geom=CONFIG3, env=env, paced=1)
         print("mini-radiod config 4 shape, two shards, paced A/B on the device:", s)
         assert all(f["block_drops"] == 0 for F in B.values() for f in F) and s["frames_in_agreement"] == s["frames"]
+
+
+@pytest.mark.gpu
+def test_channels_joining_and_leaving_on_the_mi355x():
+    """radiod's dynamic channels on the device: eight channels' lifetimes run out mid-stream (the reference's close_chan() ->
+    delete_filter_output while 50 others run), ten are created mid-stream by another thread (create_filter_output on a running master: the
+    drop-in registers the slave, grows and warms the bank between two blocks), every frame against the reference link"""
+    exe = _hip_exe()
+    ch = mr.churn_channels()
+    x = mr.synthesise(ch, FS, L, NBLOCKS, seed=21)
+    with tempfile.TemporaryDirectory() as tmp:
+        s, B, meta = _ab(tmp, exe, ch, x, NBLOCKS)
+    _check_churn(B, NBLOCKS)
+    print("mini-radiod joining / leaving A/B on the device:", s)
+    assert int(meta["channels"]) == 58 and s["frames_in_agreement"] == s["frames"]
