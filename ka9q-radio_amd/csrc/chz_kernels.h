@@ -79,6 +79,24 @@ __device__ __forceinline__ void store_wt(__amdgpu_buffer_rsrc_t d, int elem, flo
 __device__ __forceinline__ void store_wt(__amdgpu_buffer_rsrc_t d, int elem, float4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(chz_u4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, d, elem * 16, 0, 16);
 }
+// (round 6) chan_ifft's STAGED output rows -- launches of >= 16384 channels: at C_rt 33 GB per block that nobody on the device reads again soon -- leave as
+// NON-TEMPORAL stores (CHZ_CHAN_NT bit 1, shipped).  Measured at 20.0 M channels (profiles/r06_chan_nt.txt): mean block 19.20-19.41 -> 18.77-18.78 ms, the
+// C_rt search 19.75 M -> 20.50 / 20.75 M sustained on the same box, the 8f chain at 1.5 M channels 4.20-4.26 -> 4.15-4.16 ms; PCM / outputs bit-identical.
+// Bit 0 -- the response rows (41 GB per block, read once) as non-temporal LOADS -- changes nothing (19.23-19.34 ms) and stays off; both together 18.82-18.88.
+// Small launches keep plain stores (their outputs are read back or demodulated out of the caches).  A/B builds: make ../libchz_hip_cnt0.so | _cnt1.so | _cnt3.so.
+#ifndef CHZ_CHAN_NT
+#define CHZ_CHAN_NT 2
+#endif
+typedef float chz_f2v __attribute__((ext_vector_type(2)));
+typedef float chz_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float2 load_resp(const float2* p) {
+  if constexpr ((CHZ_CHAN_NT & 1) != 0) { const chz_f2v r = __builtin_nontemporal_load(reinterpret_cast<const chz_f2v*>(p)); return make_float2(r.x, r.y); }
+  else return *p;
+}
+__device__ __forceinline__ void store_out4(float4* p, float4 v) {
+  if constexpr ((CHZ_CHAN_NT & 2) != 0) { const chz_f4v r = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(r, reinterpret_cast<chz_f4v*>(p)); }
+  else *p = v;
+}
 // gathers through a buffer descriptor: a 32-bit element offset from a wave-uniform base instead of a 64-bit address per lane
 #define CHZ_IN_DESC(name, base) const __amdgpu_buffer_rsrc_t name = __builtin_amdgcn_make_buffer_rsrc((void*)(base), 0, 0x7ffffffc, 0x00020000)
 __device__ __forceinline__ float2 load_f2(__amdgpu_buffer_rsrc_t d, int elem) {
@@ -93,9 +111,13 @@ __device__ __forceinline__ float load_f1(__amdgpu_buffer_rsrc_t d, int elem) {
 #define CHZ_STORE(desc, base, elem, value) store_wt(desc, (int)(elem), (value))
 // predicated store without a branch: a raw buffer access past num_records is dropped by the hardware
 #define CHZ_STORE_IF(desc, base, elem, value, cond) store_wt(desc, (cond) ? (int)(elem) : 0x10000000, (value))
+#define CHZ_LOAD_RESP(ptr) load_resp(ptr)
+#define CHZ_STORE_OUT4(ptr, value) store_out4((ptr), (value))
 #else
 #define CHZ_OUT_DESC(name, base) const int name = 0; (void)name
 #define CHZ_IN_DESC(name, base) const int name = 0; (void)name
+#define CHZ_LOAD_RESP(ptr) (*(ptr))
+#define CHZ_STORE_OUT4(ptr, value) (*(ptr) = (value))
 #define CHZ_LOAD2(desc, base, elem) ((base)[(elem)])
 #define CHZ_LOAD1(desc, base, elem) ((base)[(elem)])
 #define CHZ_STORE(desc, base, elem, value) ((base)[(elem)] = (value))
@@ -996,7 +1018,7 @@ __global__ void __launch_bounds__(256, (R1 <= 15 && R2 <= 20) ? (EPI == 0 ? 6 : 
       if (d.wrap && src >= d.wrap) src -= d.wrap;
       if (!ok[Q]) src = 0;
       v[Q] = CHZ_LOAD2(xdesc, X, spec_index(p.lay.off, p.magic, p.dpitch, src));
-      h[Q] = Hl[Q * R2];
+      h[Q] = CHZ_LOAD_RESP(Hl + Q * R2);
       if constexpr (EPI == 2) srcs[Q] = src;
     });
     bool beamed = false;
@@ -1203,7 +1225,7 @@ __global__ void __launch_bounds__(256, (R1 <= 15 && R2 <= 20) ? (EPI == 0 ? 6 : 
       float4* __restrict__ oc = og + (long)c * half;
       for (int e = lane; e < half; e += 64) {
         const float2 a = wc[2 * e], b = wc[2 * e + 1];
-        oc[e] = make_float4(a.x, a.y, b.x, b.y);
+        CHZ_STORE_OUT4(oc + e, make_float4(a.x, a.y, b.x, b.y));
       }
     }
   }

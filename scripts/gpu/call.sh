@@ -9,6 +9,35 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r6t)       # round 6: non-temporal output stores in chan_ifft's staged path (cnt2) against the shipped build: the C_rt search, the 8f chain, the PCIe probes
+    for rep in 1 2; do for v in default cnt2; do
+      L=""; [ $v != default ] && L=$PWD/ka9q-radio_amd/libchz_hip_$v.so
+      CHZ_LIB=$L BENCH_NO_STREAMED=1 timeout 400 $B --no-dropin --no-dropin-paced --no-cpu-baseline --next-rows-modes linear,fm --detail "$out/full_${v}_$rep.json" > /dev/null 2>> "$out/err.txt"
+    done; done
+    python - "$out" <<'PY'
+import json, sys, glob, os
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/full_*.json")):
+    j = json.load(open(f)); c = j["c_rt"]
+    print(os.path.basename(f), "c_rt", c.get("channels"), c.get("worst_block_ms"), c.get("mean_block_ms"), c.get("mean_crossing_channels"), [(p["channels"], p["sustained"], round(p["mean_block_ms"], 2)) for p in c.get("probes", [])],
+          "pcie", [(x["channels"], x["sustained"], round(x["worst_block_ms"], 2), round(x["mean_block_ms"], 2)) for x in (j.get("c_rt_pcie") or []) if "error" not in x],
+          "chain", [(x["mode"], round(x["pipelined_ms_per_block"], 3), x["pcm_mismatches"]) for x in (j.get("next_rows") or []) if "error" not in x], "us/step", round(j["ms_per_step"] * 1e3, 2))
+PY
+    ;;
+  r6s)       # round 6: chan_ifft's response rows / staged output rows as non-temporal accesses (A/B builds cnt1 / cnt2 / cnt3): mean block time of a 20 M-channel bank
+    cp gpurun_out/hbm_stream.txt "$out/" 2>/dev/null
+    for rep in 1 2; do for v in default cnt1 cnt2 cnt3; do
+      L=""; [ $v != default ] && L=$PWD/ka9q-radio_amd/libchz_hip_$v.so
+      CHZ_LIB=$L BENCH_NO_STREAMED=1 timeout 300 $B --crt-channels 20000000 --crt-blocks 80 --no-dropin --no-dropin-paced --no-crt-pcie --no-cpu-baseline --no-next-rows --detail "$out/crt_${v}_$rep.json" > /dev/null 2>> "$out/err.txt"
+    done; done
+    python - "$out" <<'PY'
+import json, sys, glob, os
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/crt_*.json")):
+    c = json.load(open(f))["c_rt"]
+    print(os.path.basename(f), [(p["channels"], p["blocks"], round(p["mean_block_ms"], 3), round(p["worst_block_ms"], 3), p.get("max_rel_err")) for p in c.get("probes", [])], c.get("error"))
+PY
+    ;;
   r6r)       # round 6: mini-radiod config 1 (complex front end) and config 4 shape (2000 channels, two shards) on the device; the null-stream soak in three queue modes
     timeout 900 python -m pytest tests/test_mini_radiod.py -m gpu -q -s --timeout 600 -k "config1 or config4" > "$out/mini_radiod.txt" 2>&1; echo "mini_radiod rc=$?" >> "$out/rc.txt"
     grep -E "A/B on the device|passed|failed|Error" "$out/mini_radiod.txt" | cut -c1-1500
