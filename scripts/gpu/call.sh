@@ -9,6 +9,14 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r6u)       # round 6: do the non-temporal output stores hurt MID-SIZE banks whose outputs the demodulator reads back out of the Infinity Cache?  the linear chain at 20 k ... 1.5 M channels, shipped (NT) against cnt0 (plain)
+    for n in 20000 40000 70000 130000 300000 1500000; do for v in default cnt0; do
+      L=""; [ $v != default ] && L=$PWD/ka9q-radio_amd/libchz_hip_$v.so
+      for rep in 1 2; do CHZ_LIB=$L timeout 200 python scripts/chain_profile.py linear $n 2>> "$out/err.txt" | tail -1 | python -c "
+import sys, json
+r = json.loads(sys.stdin.read()); print('$v', r['channels'], round(r['pipelined_ms_per_block'], 4), {k: round(v, 3) for k, v in r['ns_per_channel'].items()}, r['pcm_mismatches'])"; done
+    done; done | tee "$out/chain_sizes.txt"
+    ;;
   r6t)       # round 6: non-temporal output stores in chan_ifft's staged path (cnt2) against the shipped build: the C_rt search, the 8f chain, the PCIe probes
     for rep in 1 2; do for v in default cnt2; do
       L=""; [ $v != default ] && L=$PWD/ka9q-radio_amd/libchz_hip_$v.so
