@@ -9,6 +9,10 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r6v)       # round 6: src/spectrum.c's demod_spectrum() joins the mini-radiod (narrowband analysers: any-length COMPLEX slaves + plan_complex; a wideband one: a SPECTRUM slave); the hip link now carries an FFTW provider
+    timeout 1200 python -m pytest tests/test_mini_radiod.py -m gpu -q --timeout 600 -s > "$out/mini_radiod.txt" 2>&1; echo "rc=$?" >> "$out/rc.txt"
+    grep -a "mini-radiod\|passed\|failed\|Error\|assert" "$out/mini_radiod.txt" | cut -c1-1500 | tail -30; cat "$out/rc.txt"
+    ;;
   r6u)       # round 6: do the non-temporal output stores hurt MID-SIZE banks whose outputs the demodulator reads back out of the Infinity Cache?  the linear chain at 20 k ... 1.5 M channels, shipped (NT) against cnt0 (plain)
     for n in 20000 40000 70000 130000 300000 1500000; do for v in default cnt0; do
       L=""; [ $v != default ] && L=$PWD/ka9q-radio_amd/libchz_hip_$v.so

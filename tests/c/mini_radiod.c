@@ -1,7 +1,7 @@
 /* tests/c/mini_radiod.c -- TEST INFRASTRUCTURE.  The reference's OWN callers on a filter.h implementation of the linker's choice.
  *
  * north_star: "drops in behind ka9q-radio's existing filter.h API ... so radiod, linear.c and fm.c are untouched".  This program is the
- * evidence: it is linked from the reference's radio.c, linear.c, fm.c, modes.c, osc.c, misc.c, iir.c, rtp.c, sched.c, sincospi.c,
+ * evidence: it is linked from the reference's radio.c, linear.c, fm.c, spectrum.c, modes.c, osc.c, misc.c, iir.c, rtp.c, sched.c, sincospi.c,
  * window.c, compiled UNMODIFIED from where they lie (tests/c/Makefile; never copied), plus this one translation unit, TWICE:
  *     oracle/_ref/mini_radiod_ref        + the reference's own filter.c on the oracle's FFT provider  (the checker)
  *     tests/c/_prebuilt/mini_radiod_hip  + libka9q_filter_hip.so                                      (the product under test)
@@ -22,7 +22,11 @@
  *     that does what src/radio_status.c:241 (RADIO_FREQUENCY) and :640-659 (new filter edges) do, with the reference's set_freq() /
  *     set_channel_filter(); the commands are queued on chan->commands[] under chan->status.lock exactly where radiod's status
  *     thread queues them, but by the channel's own thread at a chosen frame so that both links see them at the same block;
- *   - demod_wfm / demod_spectrum / opus_encoder_destroy: referenced by demod_thread()'s switch and clean-up, never reached (abort).
+ *   - demod_wfm / opus_encoder_destroy: referenced by demod_thread()'s switch and clean-up, never reached (abort).
+ * Round 6 also links the reference's spectrum.c: demod_spectrum() in narrowband mode (a COMPLEX slave of whatever block size its rbw / bin count
+ * ask for, set_filter(), downconvert(), its own analysis transform through plan_complex()) and in wideband mode (a SPECTRUM slave as block clock,
+ * the raw A/D ring read through input_write_pointer); a poll command every block (as `control` polls), the bin data captured where the status
+ * packet would carry it.
  * Determinism: the front end thread writes block b only when every channel has taken block b-2 (no drops by construction, in either
  * link), or -- "paced 1" -- on its own wall clock at Blocktime intervals without ever waiting, as hardware does.
  *
@@ -49,14 +53,14 @@
 #include "import.h"
 
 int Verbose = 0;                       /* src/main.c */
-/* only in the checker link: the oracle's FFT provider can do its arithmetic in float32 (oracle/fftw_shim.c) -- MINI_RADIOD_FFT_F32=1 runs the
+/* the oracle's FFT provider (the checker link's transform; in the product link only spectrum.c's analysis FFTs reach it, through the drop-in's
+   plan_complex() forwarding to the process's fftwf_* as it would to libfftw3f) can do its arithmetic in float32 (oracle/fftw_shim.c) -- MINI_RADIOD_FFT_F32=1 runs the
    reference on a float32 transform, as it would on FFTW, to show how far two CORRECT transforms move the reference's own outputs */
 extern void oracle_fft_set_precision(int) __attribute__((weak));
 extern int Overlap;                    /* src/radio.c:128, not in radio.h */
 
 /* ---- never reached (see the header) ---- */
 int demod_wfm(void *p) { (void)p; fprintf(stderr, "mini_radiod: demod_wfm is outside this test\n"); abort(); }
-int demod_spectrum(void *p) { (void)p; fprintf(stderr, "mini_radiod: demod_spectrum is outside this test\n"); abort(); }
 void opus_encoder_destroy(OpusEncoder *e) { (void)e; fprintf(stderr, "mini_radiod: no Opus in this image\n"); abort(); }
 
 /* ---- per-channel capture ---- */
@@ -68,6 +72,7 @@ struct capture {
   unsigned char *buf; size_t len, cap;
   struct event ev[MAXEV]; int nev;
   atomic_int status_calls; int commands;
+  int poll;                         /* a spectrum channel: a poll command every block */
   int start, life;                  /* joins when `start` blocks have been written (0: before the front end starts); lives for `life` blocks (0: to the end of the run) */
   int slot;                         /* its Channel_list[] entry */
   double freq; chan_t *tmpl;        /* what it is created from (late joiners: by the front-end thread) */
@@ -155,7 +160,18 @@ bool decode_radio_commands(chan_t *chan, uint8_t const *buffer, int length) {
   c->commands++;
   chan->status.packets_in++;
   /* NOT mirrored: "chan->lifetime = chan->lifestart" (src/radio_status.c:141) -- the lifetime counter is this test's block budget */
-  if (e.kind == 'F') {
+  if (e.kind == 'P') {
+    /* a spectrum poll (what `control` sends every update): the reply carries the bin data demod_spectrum() computes after this block's
+       downconvert() -- and the next poll is already waiting: queued on the OTHER slot (the caller frees this one when we return), so
+       that exactly one poll is answered per block, in both links alike */
+    for (int q = 0; q < CQLEN; q++) {
+      if (chan->commands[q].buffer == (uint8_t *)buffer || chan->commands[q].buffer != NULL) continue;
+      struct event *n = malloc(sizeof *n);
+      *n = e;
+      chan->commands[q].buffer = (uint8_t *)n; chan->commands[q].length = sizeof *n;
+      break;
+    }
+  } else if (e.kind == 'F') {
     set_freq(chan, e.a);                                   /* src/radio_status.c:241 */
   } else if (e.kind == 'W') {
     chan->filter.min_IF = e.a; chan->filter.max_IF = e.b;  /* src/radio_status.c:262-281 */
@@ -167,7 +183,20 @@ bool decode_radio_commands(chan_t *chan, uint8_t const *buffer, int length) {
 }
 int send_radio_status(struct sockaddr const *sock, struct frontend const *frontend, chan_t *chan) {
   (void)sock; (void)frontend;
-  atomic_fetch_add(&CAP_OF(chan)->status_calls, 1);
+  struct capture *c = CAP_OF(chan);
+  if ((chan->demod_type == SPECT_DEMOD || chan->demod_type == SPECT2_DEMOD) && chan->spectrum.bin_data != NULL && chan->spectrum.bin_count > 0) {
+    /* src/radio_status.c:880-905 packs chan->spectrum.bin_data into the status packet: captured as a frame of bin_count floats */
+    struct frame_hdr h;
+    memset(&h, 0, sizeof h);
+    h.ssrc = chan->output.rtp.ssrc; h.call = (uint32_t)c->calls++; h.next_jobnum = chan->filter.out.next_jobnum; h.block_drops = chan->filter.out.block_drops;
+    h.frames = chan->spectrum.bin_count; h.channels = 1; h.bin_shift = chan->filter.bin_shift; h.olen = (uint32_t)chan->filter.out.olen;
+    h.nfloat = (uint32_t)chan->spectrum.bin_count; h.encoding = 0;
+    h.n0 = chan->sig.n0; h.bb_power = chan->sig.bb_power; h.gain = (double)chan->spectrum.fft_n; h.out_power = (double)chan->output.samprate;
+    h.remainder = chan->filter.remainder; h.tune_freq = chan->tune.freq;
+    cap_append(c, &h, sizeof h);
+    cap_append(c, chan->spectrum.bin_data, sizeof(float) * h.nfloat);
+  }
+  atomic_fetch_add(&c->status_calls, 1);
   return 0;
 }
 
@@ -296,6 +325,10 @@ static int apply_kv(chan_t *chan, struct capture *c, char const *k, char const *
   else if (!strcmp(k, "tone")) chan->fm.tone_freq = fabs(x);
   else if (!strcmp(k, "update")) chan->status.output_interval = abs((int)x);
   else if (!strcmp(k, "filter2")) chan->filter2.blocking = abs((int)x);
+  else if (!strcmp(k, "rbw")) chan->spectrum.rbw = x;                          /* RESOLUTION_BW / BIN_COUNT / SPECTRUM_AVG of a `control` command (src/radio_status.c:420-470) */
+  else if (!strcmp(k, "bins")) chan->spectrum.bin_count = (int)x;
+  else if (!strcmp(k, "fft-avg")) chan->spectrum.fft_avg = (int)x;
+  else if (!strcmp(k, "poll")) c->poll = truth(v);
   else if (!strcmp(k, "start")) c->start = (int)x;         /* this test's own: the channel is created when `start` blocks have been written ... */
   else if (!strcmp(k, "life")) c->life = (int)x;           /* ... and its "lifetime" (src/modes.c:329-330) runs out after `life` blocks */
   /* this test's own keys: a command for the channel's own command queue at a given frame */
@@ -320,6 +353,11 @@ static int create_channel(int ci) {
   SlotCap[c->slot] = ci;
   snprintf(chan->name, sizeof chan->name, "%s %u", demod_name_from_type(chan->demod_type), chan->output.rtp.ssrc);
   set_freq(chan, c->freq);
+  if (c->poll) {                                         /* the first poll is waiting when the thread starts; each one queues the next */
+    struct event *e = calloc(1, sizeof *e);
+    e->kind = 'P';
+    chan->commands[0].buffer = (uint8_t *)e; chan->commands[0].length = sizeof *e;
+  }
   pthread_mutex_unlock(&chan->status.lock);
   pthread_mutex_lock(&Channel_list_mutex);
   chan->state = CHANNEL_RUNNING;

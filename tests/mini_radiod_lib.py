@@ -376,3 +376,34 @@ def churn_channels():
         c = Channel(300 + j, spots[j] + 13.0, kind, ("start=%d" % start) + (" encoding=f32le" if j % 3 == 0 else ""), {"kind": kind, "amp": 0.0})
         ch.append(c)
     return ch
+
+
+def spectrum_channels():
+    """demod_spectrum() (src/spectrum.c) next to a few ordinary channels: narrowband analysers (rbw <= 200 Hz: a COMPLEX slave whose block
+    size follows from rbw and the bin count -- sizes no other caller asks for --, set_filter(), downconvert(), the analysis transform through
+    plan_complex()) and one wideband analyser (rbw > 200 Hz: a SPECTRUM slave as block clock; its bin data come from an ASYNCHRONOUS read of
+    the A/D ring and are not compared).  One poll per block; every reply's bin data is a frame."""
+    ch = standard_channels()[:12]
+    spec = "demod=spectrum poll=1"
+    ch.append(Channel(500, 200000.0 + 3.0, "usb", spec + " rbw=50 bins=200 fft-avg=2", {"kind": "spectrum"}))          # fft_n 216 -> samprate 10.8 kHz, P = 270
+    ch.append(Channel(501, 352000.0 - 7.0, "usb", spec + " rbw=100 bins=256 fft-avg=1", {"kind": "spectrum"}))         # fft_n 260/264.. whatever the search gives
+    ch.append(Channel(502, 120000.0, "usb", spec + " rbw=25 bins=100 fft-avg=3", {"kind": "spectrum"}))
+    ch.append(Channel(503, 300000.0, "usb", spec + " rbw=2000 bins=128 fft-avg=2", {"kind": "spectrum_wide"}))
+    return ch
+
+
+def spectrum_signal(channels, fs, l, nblocks, seed=31):
+    """the standard synthetic band plus, around every analyser's centre, two fading lines for the bins to show"""
+    x = synthesise(channels, fs, l, nblocks, seed=seed)
+    t = np.arange(nblocks * l) / fs
+    for c in channels:
+        if str(c.signal.get("kind", "")).startswith("spectrum"):
+            f0 = round(c.freq, -3)
+            x += (0.01 * np.cos(2 * np.pi * (f0 + 1234.0) * t) * (1 + 0.3 * np.sin(2 * np.pi * 2.3 * t)) + 0.004 * np.cos(2 * np.pi * (f0 - 2345.0) * t + 1.0)).astype(np.float32)
+    return x
+
+
+def split_wideband(frames, channels):
+    """(frames without the wideband analysers, the wideband analysers' frames)"""
+    wide = {c.ssrc for c in channels if c.signal.get("kind") == "spectrum_wide"}
+    return {k: v for k, v in frames.items() if k not in wide}, {k: v for k, v in frames.items() if k in wide}

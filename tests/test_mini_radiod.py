@@ -200,6 +200,39 @@ def test_channels_joining_and_leaving_on_the_dropin_host_code(tmp_path):
     assert int(meta["channels"]) == 58 and s["frames_in_agreement"] == s["frames"], s
 
 
+def _check_spectrum(fr, wide, nblocks):
+    """every analyser answered every poll; the narrowband ones with the bin counts asked for out of the block sizes spectrum.c derives"""
+    assert sorted(wide) == [503] and len(wide[503]) == nblocks and all(f["nfloat"] == 128 for f in wide[503])
+    for ssrc, bins in ((500, 200), (501, 256), (502, 100)):
+        F = fr[ssrc]
+        assert len(F) == nblocks and all(f["nfloat"] == bins and f["block_drops"] == 0 for f in F), (ssrc, len(F))
+        assert [f["next_jobnum"] for f in F] == list(range(1, nblocks + 1))
+        p = np.asarray(F[-1]["pcm_f"], dtype=np.float64)
+        assert np.max(p) > 30 * np.median(p), ssrc             # the two lines stand out of the noise floor
+    assert (fr[500][0]["olen"], fr[501][0]["olen"], fr[502][0]["olen"]) == (208, 520, 60)      # 10.4 / 26 / 3 kHz slaves: P = 261, 651, 76
+
+
+@needs_ref_exe
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="/root/reference absent: the caller objects cannot be linked here")
+def test_spectrum_analysers_on_the_dropin_host_code(tmp_path):
+    """src/spectrum.c's demod_spectrum() on the drop-in's host code (stand-in engine): three narrowband analysers -- COMPLEX slaves of 208, 520 and
+    60 samples per block, sizes no demodulator asks for; set_filter() with a Kaiser beta of its own; the analysis transform planned through
+    the drop-in's plan_complex() -- and one wideband analyser (a SPECTRUM slave as block clock), polled once per block next to 12 ordinary
+    channels.  The narrowband bin data equal the reference link's; the wideband bins come from an asynchronous read of the A/D ring
+    (src/spectrum.c wideband_poll) and are only counted."""
+    exe = _build_stub_link(str(tmp_path))
+    ch = mr.spectrum_channels()
+    x = mr.spectrum_signal(ch, FS, L, NBLOCKS)
+    A, _, _ = _reference_run(str(tmp_path), ch, x)
+    B, meta, _ = mr.run(exe, str(tmp_path / "got"), ch, x, FS, L, M, NBLOCKS)
+    A, Aw = mr.split_wideband(A, ch)
+    B, Bw = mr.split_wideband(B, ch)
+    _check_spectrum(A, Aw, NBLOCKS)
+    _check_spectrum(B, Bw, NBLOCKS)
+    s = mr.compare(A, B, float_tol=1e-6, n0_tol=1e-9)
+    assert int(meta["channels"]) == 16 and s["frames_in_agreement"] == s["frames"], s
+
+
 def _hip_exe():
     if os.path.isdir(REF_SRC):          # (this container: rebuild if the sources or the libraries changed; the GPU box runs what travelled)
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), "all"], check=True)
@@ -324,3 +357,23 @@ def test_channels_joining_and_leaving_on_the_mi355x():
     _check_churn(B, NBLOCKS)
     print("mini-radiod joining / leaving A/B on the device:", s)
     assert int(meta["channels"]) == 58 and s["frames_in_agreement"] == s["frames"]
+
+
+@pytest.mark.gpu
+def test_spectrum_analysers_on_the_mi355x():
+    """the reference's demod_spectrum() threads on the device: narrowband analysers whose slaves have 208, 520 and 60 samples per block (P = 261, 651
+    and 76 bins: the any-length channel kernel), polled once per block, bin data against the reference link; a wideband analyser rides along
+    (SPECTRUM slave: a block clock without a transform)"""
+    exe = _hip_exe()
+    ch = mr.spectrum_channels()
+    x = mr.spectrum_signal(ch, FS, L, NBLOCKS)
+    with tempfile.TemporaryDirectory() as tmp:
+        A, _, _ = mr.run(mr.REF_EXE, os.path.join(tmp, "ref"), ch, x, FS, L, M, NBLOCKS)
+        A32, _, _ = mr.run(mr.REF_EXE, os.path.join(tmp, "ref32"), ch, x, FS, L, M, NBLOCKS, env={"MINI_RADIOD_FFT_F32": "1"})
+        B, meta, _ = mr.run(exe, os.path.join(tmp, "got"), ch, x, FS, L, M, NBLOCKS)
+    (A, _), (A32, _), (B, Bw) = mr.split_wideband(A, ch), mr.split_wideband(A32, ch), mr.split_wideband(B, ch)
+    _check_spectrum(B, Bw, NBLOCKS)
+    d_self = mr.diff(A, A32)
+    s = mr.check(mr.diff(A, B, upto={k: v["agree"] for k, v in d_self.items()}), d_self, pll=_pll_channels(ch))
+    print("mini-radiod spectrum analysers A/B on the device:", s, {k: v["float_rel"] for k, v in mr.diff(A, B).items() if k >= 500})
+    assert int(meta["channels"]) == 16 and s["frames_in_agreement"] == s["frames"]
