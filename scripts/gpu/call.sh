@@ -9,6 +9,10 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r6w)       # round 6: src/wfm.c's demod_wfm() joins the mini-radiod: a P = 9600 slave + a REAL inline master (N = 15,360) with REAL / shifted COMPLEX slaves per WFM channel
+    KA9Q_HIP_PROFILE=1 timeout 600 python -m pytest tests/test_mini_radiod.py -m gpu -q --timeout 300 -s -k "wfm or spectrum" > "$out/mini_radiod.txt" 2>&1; echo "rc=$?" >> "$out/rc.txt"
+    grep -a "mini-radiod\|passed\|failed\|Error\|assert\|filter_hip" "$out/mini_radiod.txt" | cut -c1-1800 | tail -30; cat "$out/rc.txt"
+    ;;
   r6v)       # round 6: src/spectrum.c's demod_spectrum() joins the mini-radiod (narrowband analysers: any-length COMPLEX slaves + plan_complex; a wideband one: a SPECTRUM slave); the hip link now carries an FFTW provider
     timeout 1200 python -m pytest tests/test_mini_radiod.py -m gpu -q --timeout 600 -s > "$out/mini_radiod.txt" 2>&1; echo "rc=$?" >> "$out/rc.txt"
     grep -a "mini-radiod\|passed\|failed\|Error\|assert" "$out/mini_radiod.txt" | cut -c1-1500 | tail -30; cat "$out/rc.txt"

@@ -22,11 +22,12 @@
  *     that does what src/radio_status.c:241 (RADIO_FREQUENCY) and :640-659 (new filter edges) do, with the reference's set_freq() /
  *     set_channel_filter(); the commands are queued on chan->commands[] under chan->status.lock exactly where radiod's status
  *     thread queues them, but by the channel's own thread at a chosen frame so that both links see them at the same block;
- *   - demod_wfm / opus_encoder_destroy: referenced by demod_thread()'s switch and clean-up, never reached (abort).
+ *   - opus_encoder_destroy: referenced by demod_thread()'s clean-up, never reached (abort).
  * Round 6 also links the reference's spectrum.c: demod_spectrum() in narrowband mode (a COMPLEX slave of whatever block size its rbw / bin count
  * ask for, set_filter(), downconvert(), its own analysis transform through plan_complex()) and in wideband mode (a SPECTRUM slave as block clock,
  * the raw A/D ring read through input_write_pointer); a poll command every block (as `control` polls), the bin data captured where the status
- * packet would carry it.
+ * packet would carry it.  And wfm.c: demod_wfm() takes a 384 kHz COMPLEX slave off the front end and owns a REAL inline master of its own (the FM
+ * composite, 2:1 overlap) with three slaves -- mono (REAL), pilot and L-R (COMPLEX, spun down by 19 / 38 kHz through their shifts).
  * Determinism: the front end thread writes block b only when every channel has taken block b-2 (no drops by construction, in either
  * link), or -- "paced 1" -- on its own wall clock at Blocktime intervals without ever waiting, as hardware does.
  *
@@ -60,7 +61,6 @@ extern void oracle_fft_set_precision(int) __attribute__((weak));
 extern int Overlap;                    /* src/radio.c:128, not in radio.h */
 
 /* ---- never reached (see the header) ---- */
-int demod_wfm(void *p) { (void)p; fprintf(stderr, "mini_radiod: demod_wfm is outside this test\n"); abort(); }
 void opus_encoder_destroy(OpusEncoder *e) { (void)e; fprintf(stderr, "mini_radiod: no Opus in this image\n"); abort(); }
 
 /* ---- per-channel capture ---- */
