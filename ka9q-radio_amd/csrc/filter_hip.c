@@ -199,6 +199,7 @@ struct miss_req {
 };
 
 struct sctx {
+  int kind;                         /* CTX_SLAVE: delete_filter_output must know what hangs off rev_plan when the master is already gone */
   int dev;                          /* index into mctx.sh: the device this slave lives on */
   int bank;                         /* index into that shard's banks */
   int idx;                          /* channel index inside the bank */
@@ -760,6 +761,7 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
     slave->bins = real ? slave->points / 2 + 1 : slave->points;    /* src/filter.c:346,374 */
     slave->fdomain = lmalloc(sizeof(float complex) * (size_t)slave->bins);
     struct sctx *sc = calloc(1, sizeof *sc);
+    if (sc) sc->kind = CTX_SLAVE;
     if (real) {
       slave->output_buffer.r = lmalloc(sizeof(float) * (size_t)slave->points);
       if (slave->output_buffer.r) { memset(slave->output_buffer.r, 0, sizeof(float) * (size_t)slave->points); slave->output.r = slave->output_buffer.r + slave->points - len; }   /* src/filter.c:385 */
@@ -813,7 +815,14 @@ done:;
 
 int delete_filter_output(struct filter_out *slave) {
   if (slave == NULL) return -1;
-  if (slave->rev_plan && is_mini_master(slave->master)) mini_delete_output(slave);
+  /* src/wfm.c:290-293 deletes its composite MASTER first and the three slaves after it (the reference's delete_filter_output never looks at the
+     master, src/filter.c:943-957): what hangs off rev_plan says what it is by itself */
+  int const kind = slave->rev_plan ? *(const int *)(const void *)slave->rev_plan : 0;
+  if (kind == CTX_MSLAVE) mini_delete_output(slave);
+  else if (kind == CTX_SLAVE && !(slave->master && slave->master->fwd_plan && !is_mini_master(slave->master))) {
+    free(SCTX(slave));                     /* the master went first and took the banks' book-keeping (and the engines) with it */
+    slave->rev_plan = NULL;
+  }
   if (slave->rev_plan && slave->master && slave->master->fwd_plan) {
     struct mctx *c = MCTX(slave->master);
     struct sctx *sc = SCTX(slave);

@@ -16,6 +16,8 @@
  * REAL-output slave. */
 #define CTX_ENGINE 0x454e47
 #define CTX_MINI   0x4d494e
+#define CTX_SLAVE  0x534c56         /* struct sctx: a slave of an engine master */
+#define CTX_MSLAVE 0x4d534c         /* struct msctx: a slave of a mini master */
 
 struct mini_req {
   int inst, shift;
@@ -43,6 +45,7 @@ struct minictx {                    /* hangs off master->fwd_plan */
   const void *job_win[ND];          /* start of the N-sample window of the job in each slot */
 };
 struct msctx {                      /* hangs off slave->rev_plan */
+  int kind;                         /* CTX_MSLAVE */
   struct minipool *pool;
   int inst;
 };
@@ -142,7 +145,7 @@ static int mini_create_output(struct filter_out *slave, struct filter_in *master
     free(sc); free(buf); free(fdom);
     return -1;
   }
-  sc->pool = p; sc->inst = inst;
+  sc->kind = CTX_MSLAVE; sc->pool = p; sc->inst = inst;
   memset(buf, 0, sizeof(float complex) * (size_t)master->points);
   slave->bins = master->points;                                    /* src/filter.c:346 */
   slave->fdomain = fdom;

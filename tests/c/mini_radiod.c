@@ -449,7 +449,9 @@ int main(int argc, char **argv) {
   clock_gettime(CLOCK_MONOTONIC, &t1);
   pthread_join(FE.thread, NULL);
   unsigned const master_jobs = Frontend.in.next_jobnum;
+  struct notch_state *const notch_list = Frontend.in.notches;        /* the caller's (src/radio.c:600; radiod never frees it): delete_filter_input() zeroes the struct */
   delete_filter_input(&Frontend.in);
+  free(notch_list);
 
   snprintf(path, sizeof path, "%s/frames.bin", argv[1]);
   g = fopen(path, "wb");

@@ -99,16 +99,18 @@ def test_the_reference_is_not_1e_5_stable_against_its_own_transform(tmp_path):
     assert s["bb_power_rel"] <= 1e-5 and s["lsb_max"] <= 1
 
 
-def _build_stub_link(out_dir):
-    """the drop-in's host code (filter_hip.c, unmodified) over the CPU stand-in for libchz_hip.so, and mini-radiod's caller objects on it"""
+def _build_stub_link(out_dir, sanitize=None):
+    """the drop-in's host code (filter_hip.c, unmodified) over the CPU stand-in for libchz_hip.so, and mini-radiod's caller objects on it
+    (sanitize="address": the drop-in and the stand-in instrumented, the reference's objects as they are)"""
     ol.build()
     stub = os.path.join(ROOT, "tests", "stub")
-    subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", os.path.join(stub, "chz_stub.cpp"), "-o", os.path.join(out_dir, "libchz_hip.so"),
+    san = ["-fsanitize=" + sanitize, "-O1"] if sanitize else ["-O2"]
+    subprocess.run(["g++", "-std=c++17", "-g", "-fPIC", "-shared"] + san + [os.path.join(stub, "chz_stub.cpp"), "-o", os.path.join(out_dir, "libchz_hip.so"),
                     "-L", os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread"], check=True)
-    subprocess.run(["gcc", "-O2", "-g", "-std=gnu11", "-fPIC", "-shared", os.path.join(ROOT, "ka9q-radio_amd", "csrc", "filter_hip.c"), "-o",
+    subprocess.run(["gcc", "-g", "-std=gnu11", "-fPIC", "-shared"] + san + [os.path.join(ROOT, "ka9q-radio_amd", "csrc", "filter_hip.c"), "-o",
                     os.path.join(out_dir, "libka9q_filter_hip.so"), "-L", out_dir, "-lchz_hip", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"], check=True)
     exe = os.path.join(out_dir, "mini_radiod_stub")
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), "LIBDIR=" + out_dir, "OUT_HIP=" + exe, exe], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), "LIBDIR=" + out_dir, "OUT_HIP=" + exe, exe] + (["LINK_EXTRA=-fsanitize=" + sanitize] if sanitize else []), check=True)
     return exe
 
 
@@ -262,6 +264,25 @@ def test_wfm_stereo_decoder_on_the_dropin_host_code(tmp_path):
     _check_wfm(A, NBLOCKS)
     s = mr.check(mr.diff(A, B, settle=WFM_SETTLE), None, float_tol=1e-6, n0_tol=1e-9)
     assert int(meta["channels"]) == 12 and s["frames_in_agreement"] == s["frames"], s
+
+
+@needs_ref_exe
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="/root/reference absent: the caller objects cannot be linked here")
+def test_wfm_deletes_its_master_before_its_slaves_without_leaks(tmp_path):
+    """src/wfm.c:290-293 ends with delete_filter_input(&composite) FIRST and the three delete_filter_output() after it; the reference's
+    delete_filter_output never looks at the master (src/filter.c:943-957).  The drop-in's host code under AddressSanitizer + LeakSanitizer through the whole
+    life of four WFM channels: no invalid access, and nothing of the slaves left behind (round 6: their contexts were, found by this run)."""
+    probe = subprocess.run(["gcc", "-fsanitize=address", "-x", "c", "-", "-o", str(tmp_path / "probe")], input="int main(void){return 0;}", text=True, capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("no -fsanitize=address runtime in this image")
+    exe = _build_stub_link(str(tmp_path), sanitize="address")
+    ch = mr.wfm_channels()
+    fs, l, m = mr.WFM_GEOM
+    nb = 12
+    x = mr.synthesise(ch, fs, l, nb, seed=41)
+    B, meta, err = mr.run(exe, str(tmp_path / "got"), ch, x, fs, l, m, nb, env={"ASAN_OPTIONS": "detect_leaks=1"})
+    assert int(meta["channels"]) == 12 and "AddressSanitizer" not in err and "LeakSanitizer" not in err, err[-3000:]
+    _check_wfm(B, nb)
 
 
 def _hip_exe():
