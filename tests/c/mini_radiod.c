@@ -447,6 +447,8 @@ int main(int argc, char **argv) {
     usleep(100);
   }
   clock_gettime(CLOCK_MONOTONIC, &t1);
+  pthread_mutex_lock(&Channel_list_mutex);        /* close_chan() marks the entry idle under this mutex (src/radio.c:1084-1092): taking it once orders everything the */
+  pthread_mutex_unlock(&Channel_list_mutex);      /* channel threads did before this thread's reads of their captures (and lets ThreadSanitizer see that) */
   pthread_join(FE.thread, NULL);
   unsigned const master_jobs = Frontend.in.next_jobnum;
   struct notch_state *const notch_list = Frontend.in.notches;        /* the caller's (src/radio.c:600; radiod never frees it): delete_filter_input() zeroes the struct */

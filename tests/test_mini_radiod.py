@@ -285,6 +285,24 @@ def test_wfm_deletes_its_master_before_its_slaves_without_leaks(tmp_path):
     _check_wfm(B, nb)
 
 
+@needs_ref_exe
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="/root/reference absent: the caller objects cannot be linked here")
+def test_reference_callers_on_the_dropin_host_code_under_thread_sanitizer(tmp_path):
+    """the drop-in's host code and the stand-in engine compiled with -fsanitize=thread under the reference's own threads (pthread calls of the
+    uninstrumented caller objects are intercepted all the same): channels joining and leaving a running master, and WFM channels creating and
+    deleting engines of their own from their threads -- no report"""
+    probe = subprocess.run(["gcc", "-fsanitize=thread", "-x", "c", "-", "-o", str(tmp_path / "probe")], input="int main(void){return 0;}", text=True, capture_output=True)
+    if probe.returncode != 0:
+        pytest.skip("no -fsanitize=thread runtime in this image")
+    exe = _build_stub_link(str(tmp_path), sanitize="thread")
+    env = {"TSAN_OPTIONS": "halt_on_error=0 report_signal_unsafe=0 exitcode=0"}
+    for name, ch, (fs, l, m), seed in (("churn", mr.churn_channels(), (FS, L, M), 21), ("wfm", mr.wfm_channels(), mr.WFM_GEOM, 41)):
+        x = mr.synthesise(ch, fs, l, NBLOCKS, seed=seed)        # (the churn table's last channel joins at block 26)
+        B, meta, err = mr.run(exe, str(tmp_path / name), ch, x, fs, l, m, NBLOCKS, env=env, timeout=600)
+        assert "ThreadSanitizer" not in err, (name, err[-4000:])
+        assert int(meta["shutdowns"]) == 1
+
+
 def _hip_exe():
     if os.path.isdir(REF_SRC):          # (this container: rebuild if the sources or the libraries changed; the GPU box runs what travelled)
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), "all"], check=True)
