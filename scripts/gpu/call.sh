@@ -9,6 +9,10 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r6x)       # round 6, final tree: the GPU tier three times in a row on one box (flakiness of the new mini-radiod tables), then the mini-radiod file five more times
+    for i in 1 2 3; do timeout 900 python -m pytest tests -m gpu -q --timeout 600 -x -p no:cacheprovider > "$out/suite_$i.txt" 2>&1; echo "suite $i rc=$? $(tail -1 $out/suite_$i.txt)" | tee -a "$out/rc.txt"; done
+    for i in 1 2 3 4 5; do timeout 300 python -m pytest tests/test_mini_radiod.py -m gpu -q --timeout 200 -x -p no:cacheprovider > "$out/mr_$i.txt" 2>&1; echo "mini-radiod $i rc=$? $(tail -1 $out/mr_$i.txt)" | tee -a "$out/rc.txt"; done
+    ;;
   r6w)       # round 6: src/wfm.c's demod_wfm() joins the mini-radiod: a P = 9600 slave + a REAL inline master (N = 15,360) with REAL / shifted COMPLEX slaves per WFM channel
     KA9Q_HIP_PROFILE=1 timeout 600 python -m pytest tests/test_mini_radiod.py -m gpu -q --timeout 300 -s -k "wfm or spectrum" > "$out/mini_radiod.txt" 2>&1; echo "rc=$?" >> "$out/rc.txt"
     grep -a "mini-radiod\|passed\|failed\|Error\|assert\|filter_hip" "$out/mini_radiod.txt" | cut -c1-1800 | tail -30; cat "$out/rc.txt"
