@@ -3528,7 +3528,7 @@ __global__ void __launch_bounds__(256) mini_ovs(MiniParams p) {
 // unpacking, Nyquist bin zeroed -- the same rules as chan_ifft / chan_c2r, bin by bin), the backward transform is the
 // Stockham stage loop of mini_ovs, the last olen samples leave with the optional downconvert() epilogue.
 // ------------------------------------------------------------------------------
-// BIG: P beyond what two buffers in LDS hold (10240 < P <= 65536: 768 kHz ... 1.5 MHz channels): the two buffers live in a
+// BIG: P beyond what two buffers in LDS hold (10240 < P <= CHZ_ANY_MAX_P = 2^20: 768 kHz channels and wider): the two buffers live in a
 // per-workgroup piece of global scratch instead, which the L2 keeps; everything else is the same code.  (Within a workgroup
 // a barrier orders global memory as it orders LDS: the wavefronts of a workgroup share their CU's vector cache.)
 // Bluestein (P with a prime factor above 13): m describes the M-point transform (M = 2^k >= 2P - 1); m.tw holds W_M [M], then the chirp

@@ -284,7 +284,7 @@ inline bool build_fwd_plan(int N, int in_type, const char* spec, FwdPlan& out, d
 #endif
 inline bool mini_factor(int N, int* radix, int* nstages);
 #define CHZ_ANY_LDS_P 10240                     // two P-point complex buffers in the 160 KB of LDS
-#define CHZ_ANY_MAX_P 65536                     // beyond CHZ_ANY_LDS_P the two buffers are global scratch (L2)
+#define CHZ_ANY_MAX_P (1 << 20)                 // beyond CHZ_ANY_LDS_P the two buffers are global scratch (the L2 keeps them up to ~100 k points; beyond that they stream)
 struct ChanGeom {
   int P = 0; Radix2 r{}; int lpc = 0, cpw = 0, wpb = 1;
   size_t lds = 0;
@@ -326,7 +326,7 @@ inline bool build_chan_geom(int P, ChanGeom& g) {
     if (!mini_factor(P, g.radix, &g.nstages)) {                 // a prime factor above 13: Bluestein over M = 2^k >= 2P - 1
       int M = 16;
       while (M < 2 * P - 1) M <<= 1;
-      if (!mini_factor(M, g.radix, &g.nstages)) return false;
+      if (M > CHZ_ANY_MAX_P || !mini_factor(M, g.radix, &g.nstages)) return false;      // (chirp-z needs M >= 2P - 1 points per buffer)
       g.blue_M = M;
       g.tw_any.resize((size_t)M + (size_t)P + (size_t)M);
       for (int k = 0; k < M; k++) g.tw_any[(size_t)k] = root_of_unity(k, M, -1);

@@ -247,6 +247,23 @@ def test_dropin_wfm_sized_slaves():
 
 
 @pytest.mark.gpu
+def test_dropin_channels_wider_than_65536_points():
+    """[r6] a 3.84 MHz channel of a 12.96 MS/s front end: olen = 76800, P = 96000 -- beyond round 5's 65536-point limit of the any-size channel kernel
+    (the reference plans any size, src/filter.c:331-357); through filter.h from C with a retune and a new filter on the way"""
+    _build_lib(); ol.build()
+    L, M, olen, P = 259200, 64801, 76800, 96000
+    nblocks = 4
+    g = ol.SigGen(1000020.0 / 12.96e6, 0.1, 0.01, ol.scale_ad(True, 1), True, seed=1)
+    x = g.generate(nblocks * L)
+    plan = [(25000, 25000, 10 ** 6, 10 ** 6, -0.3, 0.3, 3.0, -0.3, 0.3),
+            (-60000, 61000, 2, 10 ** 6, -0.26, 0.26, 3.0, -0.26, 0.26),         # retune at block 2
+            (100000, 100000, 10 ** 6, 2, -0.3, 0.3, 3.0, -0.1, 0.2)]            # new filter at block 2
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x)
+    _check(L, M, olen, P, plan, nblocks, out, spec, meta, x)
+
+
+@pytest.mark.gpu
 def test_dropin_radiod_style_config3():
     # BASELINE config 3 through the unmodified-caller interface: 129.6 MS/s, 1024 channel threads
     _build_lib(); ol.build()

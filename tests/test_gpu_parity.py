@@ -320,7 +320,8 @@ def test_channel_sizes_beyond_the_lds(pkg):
         eng.forward(0)
         spec = eng.spectrum(0).astype(np.complex128)
         B = spec.shape[0]
-        for P, olen in ((19200, 15360), (38400, 30720)):
+        # [r6] ... and beyond round 5's 65536-point limit: a 3.072 MHz and a 9.6 MHz channel, one whose size has a prime factor above 13 (chirp-z over 2^18 points), and a million-point one (40 MHz wide)
+        for P, olen in ((19200, 15360), (38400, 30720), (76800, 61440), (240000, 192000), (85000, 68000), (1000000, 800000)):
             shifts = np.array([250000, -(B - P // 4), B - 9000], np.int32)
             bank = eng.bank(P, olen, len(shifts))
             resp = (rng.standard_normal((len(shifts), P)) + 1j * rng.standard_normal((len(shifts), P))).astype(np.complex64) / P
