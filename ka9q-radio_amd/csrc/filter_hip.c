@@ -168,6 +168,7 @@ struct mctx {
      wake_fan more (KA9Q_HIP_WAKE="first,fan"; default "0,2") */
   int wake_first, wake_fan;
   int wedged_ms;                    /* how long the producer waits for a device that completes nothing and reports nothing before it gives up (KA9Q_HIP_WEDGED_MS) */
+  void *retired_mini;               /* an undecided small master became this engine in place: its old context (see create_input_impl) */
   int bank_cap0;                    /* channels a new bank starts with (KA9Q_HIP_BANK_CHANNELS, default 64; banks double as they fill) */
   /* KA9Q_HIP_PROFILE=1: where a block's host time goes, printed by delete_filter_input */
   bool profile;
@@ -508,6 +509,7 @@ static void mctx_free(struct mctx *c) {          /* host side (and the communica
     for (int i = 0; i < c->sh[g].nbanks; i++) bank_free_host(&c->sh[g].banks[i]);
     free(c->sh[g].banks);
   }
+  free(c->retired_mini);
   pthread_mutex_destroy(&c->lock);
   for (int i = 0; i < STAGE_SHARDS; i++) pthread_rwlock_destroy(&c->stage_lock[i].l);
   pthread_mutex_destroy(&c->miss_lock);
@@ -538,13 +540,13 @@ static int device_list(struct mctx *c) {
    lane, the first H2D copy out of the (pinned) host ring, the first D2H copies into fdomain[], the runtime's callback thread -- the
    reference pays for planning inside create_filter_input (src/filter.c:248,263), so block 0 of the stream is an ordinary block.
    The input ring is re-seated in front of job 0 afterwards (zero history, src/filter.c:244,259); the spectra of zeros are zeros. */
-static void engines_warm(struct mctx *c, struct filter_in *f) {
+static void engines_warm(struct mctx *c, struct filter_in *f, const float *zeros) {
   unsigned want = 0;
   bool synced = true;
   __atomic_store_n(&c->warm_ran, 0u, __ATOMIC_RELEASE);
   for (int g = 0; g < c->nsh; g++) {
     chz_engine *e = c->sh[g].eng;
-    const float *src = (const float *)f->input_buffer;             /* zeros */
+    const float *src = zeros ? zeros : (const float *)f->input_buffer;     /* zeros (a fresh ring is; a master promoted in place brings a block of them) */
     for (unsigned j = 0; j < ND; j++) {
       if ((g == 0 || !c->bcast) && (chz_input_write(e, src, f->ilen) != 0 || chz_forward(e, j) != 0)) break;
       if (g == 0 && c->host_spectrum && chz_spectrum_read_async(e, (int)j, (float *)f->fdomain[j]) != 0) break;
@@ -569,9 +571,16 @@ static void engines_warm(struct mctx *c, struct filter_in *f) {
   for (int spin = 0; synced && spin < 2000 && __atomic_load_n(&c->warm_ran, __ATOMIC_ACQUIRE) != want; spin++) usleep(100);
 }
 
+static int create_input_impl(struct filter_in *master, int L, int M, enum filtertype in_type, bool force_engine);
 int create_filter_input(struct filter_in *master, int const L, int const M, enum filtertype const in_type) {
+  return create_input_impl(master, L, M, in_type, false);
+}
+/* force_engine: an UNDECIDED small COMPLEX master (filter_hip_mini.h: mini_wanted) becomes a full engine IN PLACE -- the caller's struct keeps its ring (the
+   front end may already have written block 0 into it), its pointers, counters and flags; only what hangs off fwd_plan and the fdomain[] buffers change.
+   Called with master->filter_mutex held, at job 0 (an undecided master has not run). */
+static int create_input_impl(struct filter_in *master, int const L, int const M, enum filtertype const in_type, bool const force_engine) {
   if (master == NULL) return -1;
-  if (master->init && master->ilen == L && master->impulse_length == M && in_type == master->in_type)
+  if (!force_engine && master->init && master->ilen == L && master->impulse_length == M && in_type == master->in_type)
     return 0;                                                      /* src/filter.c:191-192 */
   if (in_type != REAL && in_type != COMPLEX) return -1;            /* src/filter.c:228-234 */
   if (L <= 0 || M <= 0) return -1;
@@ -579,8 +588,8 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   int const bins = (in_type == COMPLEX) ? N : (N / 2 + 1);
   if (bins < 2) return -1;                                         /* src/filter.c:198-199 */
 
-  if (master->init && master->fwd_plan && is_mini_master(master)) mini_free_input(master);
-  if (master->init && master->fwd_plan) {                          /* re-create with new geometry */
+  if (!force_engine && master->init && master->fwd_plan && is_mini_master(master)) mini_free_input(master);
+  if (!force_engine && master->init && master->fwd_plan) {         /* re-create with new geometry */
     struct mctx *old = MCTX(master);
     if (old->ring_pinned) chz_host_unregister(master->input_buffer);
     for (int g = 0; g < old->nsh; g++) chz_engine_destroy(old->sh[g].eng);
@@ -589,7 +598,7 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
     for (int i = 0; i < ND; i++) { chz_host_free(master->fdomain[i]); master->fdomain[i] = NULL; }
     ring_unmap(&master->input_buffer, master->input_buffer_size);
   }
-  if (mini_wanted(L, M, in_type)) return mini_create_input(master, L, M);   /* radiod's filter2 and its like */
+  if (!force_engine && mini_wanted(L, M, in_type)) return mini_create_input(master, L, M);   /* radiod's filter2 and its like */
   struct mctx *c = calloc(1, sizeof *c);
   if (!c) return -1;
   c->kind = CTX_ENGINE;
@@ -641,31 +650,41 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
   void *fd[ND] = {NULL, NULL, NULL, NULL};
   for (int i = 0; i < ND; i++)
     if (chz_host_alloc(&fd[i], sizeof(float complex) * (size_t)bins) != 0) { fprintf(stderr, "create_filter_input: %s\n", chz_last_error()); goto fail; }
-  ring = ring_map(ring_bytes);
+  float *zeros = NULL;
+  if (force_engine) {
+    if (master->input_buffer == NULL || master->input_buffer_size != ring_bytes || (zeros = calloc((size_t)L, ssz)) == NULL) goto fail;
+    ring = master->input_buffer;
+  } else ring = ring_map(ring_bytes);
   if (!ring) { perror("create_filter_input: ring"); goto fail; }
 
   /* nothing below can fail: only now is the caller's struct touched */
-  master->points = N;
-  master->perform_inline = (N_worker_threads == 0);               /* src/filter.c:205 */
+  struct minictx *const old_mini = force_engine ? (struct minictx *)(void *)master->fwd_plan : NULL;
+  void *old_fd[ND] = {NULL, NULL, NULL, NULL};
+  if (!force_engine) { master->points = N; master->perform_inline = (N_worker_threads == 0); }   /* src/filter.c:205 */
   for (int i = 0; i < ND; i++) {
-    master->fdomain[i] = fd[i];                                    /* pinned: the device copies spectra here */
+    if (force_engine) old_fd[i] = master->fdomain[i];
     memset(fd[i], 0, sizeof(float complex) * (size_t)bins);
-    master->completed_jobs[i] = UINT_MAX;                         /* src/filter.c:214 */
+    master->fdomain[i] = fd[i];                                    /* pinned: the device copies spectra here */
+    if (!force_engine) master->completed_jobs[i] = UINT_MAX;      /* src/filter.c:214 */
   }
-  master->bins = bins; master->ilen = L; master->impulse_length = M;
+  if (!force_engine) { master->bins = bins; master->ilen = L; master->impulse_length = M; }     /* (in place: the same values, which other threads are reading) */
   if (!master->init) {
     pthread_mutex_init(&master->filter_mutex, NULL);
     pthread_cond_init(&master->filter_cond, NULL);
     master->init = true;
   }
-  master->owner = pthread_self();
-  master->in_type = in_type;
-  master->input_buffer_size = ring_bytes;
-  master->input_buffer = ring;
-  memset(master->input_buffer, 0, master->input_buffer_size);
+  if (!force_engine) {
+    master->owner = pthread_self();
+    master->in_type = in_type;
+    master->input_buffer_size = ring_bytes;
+    master->input_buffer = ring;
+    memset(master->input_buffer, 0, master->input_buffer_size);
+  }
   /* both mappings of the ring, so a window that runs into the mirror is still DMA-able */
   c->ring_pinned = chz_host_register(master->input_buffer, 2 * master->input_buffer_size) == 0;
-  if (in_type == COMPLEX) {                                        /* src/filter.c:243-246 */
+  if (force_engine) {
+    /* (pointers, wcnt, next_jobnum = 0, sample_index, perform_inline, notches: the caller's, untouched) */
+  } else if (in_type == COMPLEX) {                                 /* src/filter.c:243-246 */
     master->input_read_pointer.c = master->input_buffer;
     master->input_write_pointer.c = master->input_read_pointer.c + (M - 1);
     master->input_read_pointer.r = NULL; master->input_write_pointer.r = NULL;
@@ -674,15 +693,20 @@ int create_filter_input(struct filter_in *master, int const L, int const M, enum
     master->input_write_pointer.r = master->input_read_pointer.r + (M - 1);
     master->input_read_pointer.c = NULL; master->input_write_pointer.c = NULL;
   }
-  master->wcnt = 0;
-  master->next_jobnum = 0;
-  master->fwd_plan = (fftwf_plan)(void *)c;
-  engines_warm(c, master);
+  if (!force_engine) { master->wcnt = 0; master->next_jobnum = 0; }
+  engines_warm(c, master, zeros);                                  /* (before the context is published: the warm-up blocks use the engines directly) */
+  __atomic_store_n((void **)(void *)&master->fwd_plan, (void *)c, __ATOMIC_RELEASE);
+  if (force_engine) {
+    free(zeros);
+    c->retired_mini = old_mini;            /* another thread may be looking at its kind word this instant (is_mini_master): it goes with the context, at delete */
+    for (int i = 0; i < ND; i++) { free(old_fd[i]); futex_wake_all(&master->completed_jobs[i]); }      /* block clocks asleep on the old words look again */
+  }
   return 0;
 
 fail:
   for (int i = 0; i < ND; i++) chz_host_free(fd[i]);
-  ring_unmap(&ring, ring_bytes);
+  free(zeros);
+  if (!force_engine) ring_unmap(&ring, ring_bytes);
   for (int g = 0; g < c->nsh; g++) chz_engine_destroy(c->sh[g].eng);
   mctx_free(c);
   return -1;
@@ -753,9 +777,14 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
   slave->out_type = out_type;
   set_filter_weights(slave, 1.0, 0.0);
   if (is_mini_master(master)) {
-    int r = mini_create_output(slave, master, len, out_type);
+    pthread_mutex_lock(&master->filter_mutex);         /* what an undecided master becomes is settled under its mutex (see execute_filter_input) */
+    int r = is_mini_master(master) ? mini_create_output(slave, master, len, out_type) : 0;
+    if (r == 2)                            /* a slave no pooled instance serves, on a master still undecided: it becomes a full engine, in place */
+      r = create_input_impl(master, master->ilen, master->impulse_length, master->in_type, true);
+    pthread_mutex_unlock(&master->filter_mutex);
     if (r < 0) { slave->init = false; slave->master = NULL; return -1; }
-  } else if (out_type == COMPLEX || out_type == REAL) {
+  }
+  if (!is_mini_master(master) && (out_type == COMPLEX || out_type == REAL)) {
     struct mctx *c = MCTX(master);
     bool const real = out_type == REAL;
     slave->bins = real ? slave->points / 2 + 1 : slave->points;    /* src/filter.c:346,374 */
@@ -966,7 +995,19 @@ static int futex_wait_u32_ms(unsigned *addr, unsigned expected, long ms) {
     (c)->prof_stage_ns[job][k] += (unsigned long long)((t_.tv_sec - (tref).tv_sec) * 1000000000LL + (t_.tv_nsec - (tref).tv_nsec)); (tref) = t_; } } while (0)
 int execute_filter_input(struct filter_in *const f) {
   if (f == NULL || f->fwd_plan == NULL) return -1;
-  if (is_mini_master(f)) return mini_execute_input(f);
+  if (is_mini_master(f)) {
+    if (!__atomic_load_n(&((struct minictx *)(void *)f->fwd_plan)->decided, __ATOMIC_ACQUIRE)) {
+      /* a block arrives at a small COMPLEX master nobody has created a same-size slave on: not a filter2 (which creates its slave right behind its
+         master) but a small front end streaming before its channels exist -- a full engine from here on (filter_hip_mini.h: mini_wanted) */
+      pthread_mutex_lock(&f->filter_mutex);
+      int r = 0;
+      if (is_mini_master(f) && !((struct minictx *)(void *)f->fwd_plan)->decided)
+        r = create_input_impl(f, f->ilen, f->impulse_length, f->in_type, true);
+      pthread_mutex_unlock(&f->filter_mutex);
+      if (r != 0) return -1;
+    }
+    if (is_mini_master(f)) return mini_execute_input(f);
+  }
   struct mctx *c = MCTX(f);
   /* Everything below is asynchronous, so the producer must not run more than ND blocks ahead of the device: block
      job-ND owns this job's completion record, spectrum slot, staged outputs and host-ring window until its callback has
@@ -1321,16 +1362,17 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
   /* (Measured and rejected: sleeping on 16 sharded wake words per slot with a small initial fan-out -- the tree's depth
      times the scheduler's wake latency cost 10 ms per block at 1024 threads, against 3 ms for one FUTEX_WAKE of everybody
      plus the pass-it-on below.) */
-  struct mctx *const mc = (master->fwd_plan && !is_mini_master(master)) ? MCTX(master) : NULL;
-  int const shard = (mc && slave->rev_plan) ? SCTX(slave)->shard : 0;
-  if (mc && slave->rev_plan) {            /* what this slave wants its next block computed with: read by the front end when it launches one */
+  if (master->fwd_plan && !is_mini_master(master) && slave->rev_plan) {   /* what this slave wants its next block computed with: read by the front end when it launches one */
     struct sctx *const sc0 = SCTX(slave);
     __atomic_store_n(&sc0->want_shift, shift, __ATOMIC_RELAXED);
     __atomic_store_n(&sc0->want_valid, 1, __ATOMIC_RELEASE);
   }
-  unsigned *const wake = mc ? &mc->gen[slot][shard].v : &master->completed_jobs[slot];
   bool skipped = false;
   for (;;) {
+    /* (looked up every time round: an undecided small master may become an engine while a block clock sleeps on it -- it is woken then) */
+    struct mctx *const mc = (master->fwd_plan && !is_mini_master(master)) ? MCTX(master) : NULL;
+    int const shard = (mc && slave->rev_plan) ? SCTX(slave)->shard : 0;
+    unsigned *const wake = mc ? &mc->gen[slot][shard].v : &master->completed_jobs[slot];
     unsigned const g = mc ? __atomic_load_n(wake, __ATOMIC_ACQUIRE) : 0u;          /* before looking at what it announces */
     unsigned done = __atomic_load_n(&master->completed_jobs[slot], __ATOMIC_ACQUIRE);
     if ((int)(job - done) <= 0) {

@@ -12,8 +12,9 @@
  *                          arrive here within microseconds of each other (they were released together), so the first one
  *                          becomes the batch leader and ONE kernel launch (one workgroup per instance) and ONE round trip
  *                          serve everybody who queued up meanwhile.
- * What a mini cannot do fails loudly at create_filter_output: a slave whose block size differs from its master's, or a
- * REAL-output slave. */
+ * What a pooled instance cannot do -- a slave whose block size differs from its master's, or a REAL-output slave -- turns a
+ * master that is still undecided (mini_wanted) into a full engine at that create_filter_output (round 6); on a master that
+ * already serves a same-size slave it fails loudly. */
 #define CTX_ENGINE 0x454e47
 #define CTX_MINI   0x4d494e
 #define CTX_SLAVE  0x534c56         /* struct sctx: a slave of an engine master */
@@ -41,6 +42,8 @@ struct minipool {
 
 struct minictx {                    /* hangs off master->fwd_plan */
   int kind;                         /* CTX_MINI */
+  int nslaves;                      /* slaves created on this master and not yet deleted */
+  bool decided;                     /* a same-size COMPLEX slave has been created: this master IS a pooled inline master (see mini_wanted) */
   struct filter_in *master;
   const void *job_win[ND];          /* start of the N-sample window of the job in each slot */
 };
@@ -54,13 +57,22 @@ static pthread_mutex_t Mini_registry_lock = PTHREAD_MUTEX_INITIALIZER;
 static struct minipool *Mini_pools;
 
 static bool smooth235(int n) { for (int p = 2; p <= 5; p++) while (p != 4 && n % p == 0) n /= p; return n == 1; }
+/* A small COMPLEX master MAY be radiod's filter2 -- or the front end of a Funcube dongle (192 kHz: N = 4800) or an Airspy HF+ at its low rates.
+   create_filter_input cannot tell, so such a master starts UNDECIDED (host state only): the first same-size COMPLEX create_filter_output makes it a
+   pooled inline master (filter2 creates its slave right behind its master, src/radio.c:1583-1585); any other kind of slave, or a first block
+   arriving while it has no slave at all (a front end streams before its channels exist), makes it a full engine -- in place: ring, pointers and
+   job counter stay (round 6; rounds 2-5 refused every decimating slave of such a front end). */
 static bool mini_wanted(int L, int M, enum filtertype in_type) {
   const char *e = XENV("KA9Q_HIP_MINI");
   if (e && e[0] == '0') return false;
   int const N = L + M - 1;
   return in_type == COMPLEX && N >= 8 && N <= 8192 && smooth235(N);
 }
-static bool is_mini_master(const struct filter_in *m) { return m && m->fwd_plan && *(const int *)(const void *)m->fwd_plan == CTX_MINI; }
+static bool is_mini_master(const struct filter_in *m) {
+  if (!m) return false;
+  const void *const ctx = __atomic_load_n((void *const *)(void *)&m->fwd_plan, __ATOMIC_ACQUIRE);      /* (swapped once, when an undecided master becomes an engine) */
+  return ctx && *(const int *)ctx == CTX_MINI;
+}
 
 /* a pool of this geometry with a free instance (created on demand) */
 static struct minipool *mini_pool_for(int L, int M) {
@@ -129,8 +141,12 @@ static void mini_free_input(struct filter_in *master) {           /* the ctx and
 static int mini_create_output(struct filter_out *slave, struct filter_in *master, int len, enum filtertype out_type) {
   if (out_type == SPECTRUM) return 1;                              /* a block clock needs nothing: let the common path set it up */
   if (out_type != COMPLEX || len != master->ilen) {
-    fprintf(stderr, "create_filter_output: a %d-point inline master serves same-size COMPLEX slaves only (asked: olen %d, type %d); "
-                    "set KA9Q_HIP_MINI=0 to run this master as a full engine\n", master->points, len, (int)out_type);
+    /* not what a pooled instance does (a decimating or REAL-output slave).  A master that has not run yet and has no slaves -- the usual
+       order: create_filter_input, then its create_filter_output()s -- is simply re-made as a full engine by the caller (returns 2) */
+    struct minictx const *mc = (struct minictx const *)(void const *)master->fwd_plan;
+    if (!mc->decided && mc->nslaves == 0) return 2;
+    fprintf(stderr, "create_filter_output: a %d-point inline master that already serves a same-size slave takes same-size COMPLEX slaves only (asked: olen %d, type %d)\n",
+            master->points, len, (int)out_type);
     return -1;
   }
   struct minipool *p = mini_pool_for(master->ilen, master->impulse_length);
@@ -146,6 +162,8 @@ static int mini_create_output(struct filter_out *slave, struct filter_in *master
     return -1;
   }
   sc->kind = CTX_MSLAVE; sc->pool = p; sc->inst = inst;
+  ((struct minictx *)(void *)master->fwd_plan)->nslaves++;
+  ((struct minictx *)(void *)master->fwd_plan)->decided = true;
   memset(buf, 0, sizeof(float complex) * (size_t)master->points);
   slave->bins = master->points;                                    /* src/filter.c:346 */
   slave->fdomain = fdom;
@@ -160,6 +178,7 @@ static void mini_delete_output(struct filter_out *slave) {
   if (!sc) return;
   chz_mini_release(sc->pool->h, sc->inst);
   pthread_mutex_lock(&Mini_registry_lock); sc->pool->used--; pthread_mutex_unlock(&Mini_registry_lock);
+  if (is_mini_master(slave->master)) ((struct minictx *)(void *)slave->master->fwd_plan)->nslaves--;       /* (a master deleted first is all zeros) */
   free(sc);
   slave->rev_plan = NULL;
 }

@@ -134,22 +134,20 @@ def test_dropin_other_paths_are_sanitizer_clean(tmp_path, san, env):
         assert meta["drops"] == "0"
 
 
-@pytest.mark.parametrize("san", ["thread", "address"])
-def test_dropin_complex_master_under_sanitizers(tmp_path, san):
-    """BASELINE config 1's geometry (2.4 MS/s complex front end: L = 48000, M = 12001, one IQ-mode channel among others) through the
-    drop-in's host code with write_cfilter, under the sanitizers; outputs against the oracle."""
+def _complex_front_end(tmp_path, san, L, M, fs, nblocks=6, nch=24, env=None):
     if not _have("-fsanitize=" + san):
         pytest.skip("no -fsanitize=%s runtime in this image" % san)
     exe = _build(san, str(tmp_path / "build"))
-    L, M, olen, P = 48000, 12001, 240, 300
+    olen = 240
     N = L + M - 1
-    nblocks, nch = 6, 24
+    P = olen * N // L                                             # 300 at overlap 5, 480 at overlap 2
     rng = np.random.default_rng(12)
     g = ol.SigGen(100020.0 / 2.4e6, 0.1, 0.01, ol.scale_ad(False, 1), False, seed=1)
     x = g.generate(nblocks * L)                                   # complex64
-    plan = [(int(rng.integers(-25000, 25000)),) * 2 + (10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4) for _ in range(nch)]
+    reach = N // 2 - 400
+    plan = [(int(rng.integers(-reach, reach)),) * 2 + (10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4) for _ in range(nch)]
     plan[0] = (0, 0, 10 ** 6, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4)               # the IQ channel at DC
-    plan[1] = (29990, -29990, 3, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4)            # across the +-Nyquist seam, retuned at block 3
+    plan[1] = (N // 2 - 10, -(N // 2 - 10), 3, 10 ** 6, -0.4, 0.4, 11.0, -0.4, 0.4)   # across the +-Nyquist seam, retuned at block 3
     run_dir = str(tmp_path / "run"); os.makedirs(run_dir)
     open(os.path.join(run_dir, "cfg.txt"), "w").write("%d %d %d %d %d %d %d\n" % (L, M, ol.COMPLEX, olen, len(plan), nblocks, 4096))
     with open(os.path.join(run_dir, "plan.bin"), "wb") as f:
@@ -157,10 +155,14 @@ def test_dropin_complex_master_under_sanitizers(tmp_path, san):
             f.write(struct.pack("iiiiddddd", *p))
     np.ascontiguousarray(x, np.complex64).tofile(os.path.join(run_dir, "in.bin"))
     e = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=67")
+    e.update(env or {})
     r = subprocess.run([exe, run_dir], capture_output=True, text=True, timeout=int(os.environ.get("STUB_TIMEOUT", "300")), env=e)
     assert "WARNING: ThreadSanitizer" not in r.stderr and "ERROR: AddressSanitizer" not in r.stderr and "LeakSanitizer" not in r.stderr, r.stderr[-5000:]
     assert r.returncode == 0, r.stderr[-2000:]
     out = np.fromfile(os.path.join(run_dir, "out.bin"), np.complex64).reshape(nblocks, nch, olen)
+    meta = open(os.path.join(run_dir, "meta.txt")).read().split()
+    meta = dict(zip(meta[::2], meta[1::2]))
+    assert meta["drops"] == "0" and int(meta["next_jobnum"]) == nblocks and int(meta["points"]) == N
     st = ol.Stream(L, M, ol.COMPLEX)
     state = np.zeros(2)
     for b in range(nblocks):
@@ -172,6 +174,23 @@ def test_dropin_complex_master_under_sanitizers(tmp_path, san):
             want = ol.channel(s64, ol.COMPLEX, P, olen, shift, resp)
             err = float(np.sqrt(np.mean(np.abs(out[b, i] - want) ** 2))); rms = float(np.sqrt(np.mean(np.abs(want) ** 2)))
             assert err <= 1e-5 * rms + 2e-8 * float(np.abs(s64).max()) * float(np.linalg.norm(resp)), (b, i, err, rms)
+
+
+@pytest.mark.parametrize("san", ["thread", "address"])
+def test_dropin_complex_master_under_sanitizers(tmp_path, san):
+    """BASELINE config 1's geometry (2.4 MS/s complex front end: L = 48000, M = 12001, one IQ-mode channel among others) through the
+    drop-in's host code with write_cfilter, under the sanitizers; outputs against the oracle."""
+    _complex_front_end(tmp_path, san, 48000, 12001, 2.4e6)
+
+
+@pytest.mark.parametrize("san", ["thread", "address"])
+@pytest.mark.parametrize("geom", [(3840, 961), (5120, 1281), (3840, 3841)], ids=["funcube_192k", "airspyhf_256k", "funcube_overlap2"])
+def test_dropin_small_complex_front_end_under_sanitizers(tmp_path, san, geom):
+    """[r6] a COMPLEX front end small enough to look like radiod's filter2 (N <= 8192: a Funcube dongle at 192 kHz is N = 4800, an Airspy HF+ at 256 kHz
+    N = 6400; at overlap 2 even M = L + 1 as filter2 has it): create_filter_input cannot tell, the master starts undecided and becomes a full engine IN
+    PLACE when its first 12 kHz slave is created or its first block arrives, whichever of the front-end thread and the 24 channel threads comes first
+    (rounds 2-5 refused every channel of such a front end).  Under the sanitizers, outputs against the oracle from block 0 on."""
+    _complex_front_end(tmp_path, san, geom[0], geom[1], 192e3)
 
 
 @pytest.mark.parametrize("san", ["thread", "address"])
