@@ -431,3 +431,23 @@ def wfm_channels():
     ch.append(Channel(602, 740000.0, "wfm", "stereo=yes", {"kind": "wfm", "amp": 0.04, "stereo": 0.0}))
     ch.append(Channel(603, 1080000.0, "wfm", "stereo=yes", {"kind": "none"}))
     return ch
+
+
+FUNCUBE_GEOM = (192e3, 3840, 961)        # a Funcube dongle's COMPLEX 192 kHz front end: N = 4800 -- small enough to look like radiod's filter2 to create_filter_input
+
+
+def funcube_channels():
+    """six channels of a 192 kHz COMPLEX front end (N = 4800 <= 8192: the drop-in's undecided small master, which the first decimating slave turns into an
+    engine), one of them a CW channel whose filter2 = 4 is a real pooled inline master next to it; slowly beating two-tone signals (no AGC knife-edge)"""
+    spec = [(4000, 30e3 + 2.1, "usb", ""), (4001, -45e3 - 7.7, "lsb", "encoding=f32le"), (4002, 12e3 + 0.9, "cwu", ""), (4003, -70e3 + 5.3, "iq", ""),
+            (4004, 60e3 - 3.3, "am", ""), (4005, -20e3 + 1.7, "fm", "")]
+    ch, lines = [], []
+    for k, (ssrc, f, preset, extra) in enumerate(spec):
+        ch.append(Channel(ssrc, f, preset, extra, {"kind": preset}))
+        if preset == "fm":
+            continue                                   # noise only: the squelch stays shut
+        off = {"usb": 900.0, "lsb": -1100.0, "cwu": 0.0, "iq": 1500.0, "am": 0.0}[preset]
+        lines += [(f + off, 0.02 + 0.002 * k, 0.3 + k), (f + off + 3.0 + 0.5 * k, 0.006, 1.1 * k)]
+        if preset == "am":
+            lines += [(f + 1000.0, 0.005, 0.2), (f - 1000.0, 0.005, 0.9)]
+    return ch, lines

@@ -303,6 +303,23 @@ def test_reference_callers_on_the_dropin_host_code_under_thread_sanitizer(tmp_pa
         assert int(meta["shutdowns"]) == 1
 
 
+@needs_ref_exe
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="/root/reference absent: the caller objects cannot be linked here")
+def test_small_complex_front_end_on_the_dropin_host_code(tmp_path):
+    """a Funcube dongle's front end (192 kHz COMPLEX, N = 4800) under the reference's callers on the drop-in's host code: to create_filter_input such a master
+    looks like radiod's filter2; the first channel's decimating slave turns it into an engine in place, while the CW channel's filter2 = 4 next to it IS a
+    pooled inline master"""
+    exe = _build_stub_link(str(tmp_path))
+    ch, lines = mr.funcube_channels()
+    fs, l, m = mr.FUNCUBE_GEOM
+    nb = 40
+    x = mr.complex_synth(lines, fs, nb * l, 0.002, 5)
+    A, _, _ = mr.run(mr.REF_EXE, str(tmp_path / "ref"), ch, x, fs, l, m, nb)
+    B, meta, _ = mr.run(exe, str(tmp_path / "got"), ch, x, fs, l, m, nb)
+    s = mr.compare(A, B, float_tol=1e-6, n0_tol=1e-9)
+    assert int(meta["channels"]) == 6 and s["frames_in_agreement"] == s["frames"] == 5 * nb + nb // 4 and s["data"] == 4 * nb + nb // 4, s
+
+
 def _hip_exe():
     if os.path.isdir(REF_SRC):          # (this container: rebuild if the sources or the libraries changed; the GPU box runs what travelled)
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), "all"], check=True)
@@ -485,3 +502,20 @@ def test_wfm_stereo_decoder_on_the_mi355x():
     print("mini-radiod WFM stereo paced on the device:", {k: (v["agree"], v["frames"], v["float_rel"]) for k, v in d.items() if k >= 600}, "seconds", meta["seconds"])
     assert all(f["block_drops"] == 0 for F in B.values() for f in F) and all(v["agree"] == v["frames"] for v in d.values())
     assert max(v["float_rel"] for k, v in d.items() if k >= 600) < 1e-5 and float(meta["seconds"]) < nb * 0.02 + 0.5
+
+
+@pytest.mark.gpu
+def test_small_complex_front_end_through_the_reference_callers():
+    """a 192 kHz COMPLEX front end (a Funcube dongle: N = 4800, small enough to be taken for a filter2 at create_filter_input) with six channels of the reference's
+    own threads on the device, in lock step and at wall-clock pace: the front-end master becomes an engine in place with its first slave, the CW channel's
+    filter2 = 4 stays a pooled inline master"""
+    exe = _hip_exe()
+    ch, lines = mr.funcube_channels()
+    geom = mr.FUNCUBE_GEOM
+    for nb, paced in ((40, 0), (100, 1)):
+        x = mr.complex_synth(lines, geom[0], nb * geom[1], 0.002, 5 + paced)
+        with tempfile.TemporaryDirectory() as tmp:
+            s, B, meta = _ab(tmp, exe, ch, x, nb, geom=geom, paced=paced)
+        print("mini-radiod small complex front end%s A/B on the device:" % (" paced" if paced else ""), s)
+        assert int(meta["channels"]) == 6 and s["frames_in_agreement"] == s["frames"] == 5 * nb + nb // 4
+        assert all(f["block_drops"] == 0 for F in B.values() for f in F)
