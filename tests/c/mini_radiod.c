@@ -64,13 +64,14 @@ extern int Overlap;                    /* src/radio.c:128, not in radio.h */
 void opus_encoder_destroy(OpusEncoder *e) { (void)e; fprintf(stderr, "mini_radiod: no Opus in this image\n"); abort(); }
 
 /* ---- per-channel capture ---- */
-struct event { int frame; int kind; double a, b; };      /* kind 'F': retune to a Hz; 'W': filter edges a..b Hz */
+struct event { int frame; int kind; double a, b; };      /* kind 'F': retune to a Hz; 'W': filter edges a..b Hz; 'M': the preset change sw[(int)a]; 'P': spectrum poll */
 #define MAXEV 4
 struct capture {
   uint32_t ssrc;
   int calls;                        /* send_output calls so far */
   unsigned char *buf; size_t len, cap;
   struct event ev[MAXEV]; int nev;
+  char *sw[MAXEV]; int nsw;         /* "key~value,key~value,...": what a PRESET / OUTPUT_SAMPRATE / DEMOD_TYPE command changes (kind 'M') */
   atomic_int status_calls; int commands;
   int poll;                         /* a spectrum channel: a poll command every block */
   int start, life;                  /* joins when `start` blocks have been written (0: before the front end starts); lives for `life` blocks (0: to the end of the run) */
@@ -78,6 +79,7 @@ struct capture {
   double freq; chan_t *tmpl;        /* what it is created from (late joiners: by the front-end thread) */
 };
 static struct capture Cap[2 * Nchannels];  /* in creation order */
+static int FE_is_paced(void), FE_slack(void), FE_is_done(void);
 static int SlotCap[Nchannels];         /* Channel_list[] slot -> Cap[] index of the channel that lives there now (a slot is reused after close_chan()) */
 static int Nchan;                      /* channels this run has started so far */
 #define CAP_OF(chan) (&Cap[SlotCap[(chan) - Channel_list]])
@@ -152,7 +154,8 @@ int send_output(chan_t *restrict const chan, float const *restrict buffer, int f
   return frames;
 }
 
-/* src/radio_status.c:133 decode_radio_commands(): the two commands this test sends */
+static int apply_kv(chan_t *chan, struct capture *c, char const *k, char const *v);
+/* src/radio_status.c:133 decode_radio_commands(): the commands this test sends */
 bool decode_radio_commands(chan_t *chan, uint8_t const *buffer, int length) {
   if (length != (int)sizeof(struct event)) return false;
   struct event e; memcpy(&e, buffer, sizeof e);
@@ -171,6 +174,39 @@ bool decode_radio_commands(chan_t *chan, uint8_t const *buffer, int length) {
       chan->commands[q].buffer = (uint8_t *)n; chan->commands[q].length = sizeof *n;
       break;
     }
+  } else if (e.kind == 'M') {
+    /* a PRESET (src/radio_status.c:168-181: loadpreset()) / OUTPUT_SAMPRATE (:215-230) / DEMOD_TYPE (:310-319) command, and what the decoder does about it
+       afterwards (:613-660): a new sample rate or demodulator asks for a RESTART -- the demodulator returns, demod_thread() deletes the channel's
+       filter output and starts the (new) demodulator, which creates one of the new size (src/radio.c:940-985) --, new edges for new filters */
+    int const old_rate = chan->output.samprate, old_demod = chan->demod_type, old_blocking = chan->filter2.blocking;
+    double const old_lo = chan->filter.min_IF, old_hi = chan->filter.max_IF, old_beta = chan->filter.kaiser_beta;
+    char *list = strdup(c->sw[(int)e.a]);
+    char *save = NULL;                     /* (strtok_r: channel threads decode their commands side by side) */
+    for (char *tok = strtok_r(list, ",", &save); tok != NULL; tok = strtok_r(NULL, ",", &save)) {
+      char *sep = strchr(tok, '~');
+      if (sep == NULL) continue;
+      *sep = 0;
+      if (apply_kv(chan, c, tok, sep + 1) != 0) { fprintf(stderr, "mini_radiod: switch %s~%s\n", tok, sep + 1); abort(); }
+    }
+    free(list);
+    if (chan->output.samprate != old_rate || (int)chan->demod_type != old_demod) {
+      /* RESTART.  The new filter output will start at the master's job counter of that moment (src/filter.c:413), i.e. it skips what the front end has written
+         meanwhile.  For two links to skip the SAME blocks, the lock-step front end is let run as far ahead as it may (it stops `slack` blocks ahead of the slowest
+         channel, which this one now is) before the demodulator returns, and it does not move while a running channel has no filter output (all_channels_took).
+         The skipped blocks come off this test's block budget (the "lifetime"), so that the channel still ends with the input. */
+      unsigned const mine = chan->filter.out.next_jobnum;
+      while (!FE_is_paced() && (int)(*(volatile unsigned *)&Frontend.in.next_jobnum - (mine + FE_slack())) < 0 && !FE_is_done()) usleep(50);
+      int const skipped = (int)(*(volatile unsigned *)&Frontend.in.next_jobnum - mine);
+      if (skipped > 0 && chan->lifetime > skipped) chan->lifetime -= skipped;
+      return true;
+    }
+    if (chan->filter.min_IF != old_lo || chan->filter.max_IF != old_hi || chan->filter.kaiser_beta != old_beta || chan->filter2.blocking != old_blocking) {
+      set_channel_filter(chan);
+      set_freq(chan, chan->tune.freq);
+      chan->filter.remainder = NAN;
+    }
+    int const pt = pt_from_info(chan->output.samprate, chan->output.channels, chan->output.encoding);      /* :663-677 */
+    if (pt != -1) chan->output.rtp.type = pt;
   } else if (e.kind == 'F') {
     set_freq(chan, e.a);                                   /* src/radio_status.c:241 */
   } else if (e.kind == 'W') {
@@ -210,12 +246,17 @@ static struct {
   double worst_wait_ms;
 } FE;
 
+static int FE_is_paced(void) { return FE.paced; }
+static int FE_slack(void) { return FE.slack; }
+static int FE_is_done(void) { return atomic_load(&FE.done); }
 static int Ncfg;                       /* channels of the configuration file */
 static int create_channel(int ci);
 static bool all_channels_took(uint32_t job) {        /* every running channel has next_jobnum >= job */
   for (int i = 0; i < Nchannels; i++) {
     chan_t *ch = &Channel_list[i];
-    if (ch->state != CHANNEL_RUNNING || ch->filter.out.master != &Frontend.in) continue;
+    if (ch->state != CHANNEL_RUNNING) continue;
+    if (ch->filter.out.master == NULL) return false;              /* between delete_filter_output and create_filter_output of a restart (decode_radio_commands 'M') */
+    if (ch->filter.out.master != &Frontend.in) continue;
     if ((int32_t)(*(volatile unsigned int *)&ch->filter.out.next_jobnum - job) < 0) return false;
   }
   return true;
@@ -337,6 +378,13 @@ static int apply_kv(chan_t *chan, struct capture *c, char const *k, char const *
     struct event *e = &c->ev[c->nev++];
     e->kind = k[0] == 'r' ? 'F' : 'W';
     if (sscanf(v, "%d:%lf:%lf", &e->frame, &e->a, &e->b) < 2) return -1;
+  } else if (!strcmp(k, "switch")) {                         /* switch=frame:key~value,key~value,... */
+    if (c->nev >= MAXEV || c->nsw >= MAXEV) return -1;
+    char const *colon = strchr(v, ':');
+    if (colon == NULL) return -1;
+    struct event *e = &c->ev[c->nev++];
+    e->kind = 'M'; e->frame = atoi(v); e->a = c->nsw; e->b = 0;
+    c->sw[c->nsw++] = strdup(colon + 1);
   } else return -1;
   return 0;
 }

@@ -451,3 +451,23 @@ def funcube_channels():
         if preset == "am":
             lines += [(f + 1000.0, 0.005, 0.2), (f - 1000.0, 0.005, 0.9)]
     return ch, lines
+
+
+def _as_switch(frame, kv):
+    """a preset's key=value list as the switch=frame:key~value,... command of tests/c/mini_radiod.c"""
+    return "switch=%d:%s" % (frame, ",".join(t.replace("=", "~") for t in kv.split()))
+
+
+def switch_channels():
+    """what `control` does to a running channel (src/radio_status.c:168-181 PRESET, :215-230 OUTPUT_SAMPRATE, :310-319 DEMOD_TYPE): the decoder asks for a RESTART when
+    the sample rate or the demodulator changed -- the channel's filter output is deleted and created again at the new size on the running master, by the same
+    thread on the same struct -- and for new filters otherwise (a CW preset on a USB channel: filter2 appears mid-stream)"""
+    base = [c for c in standard_channels() if c.preset in ("usb", "lsb", "am", "iq")][:6]
+    ch = []
+    for i, c in enumerate(base):
+        ch.append(Channel(700 + i, c.freq, c.preset, c.extra.replace("snr-squelch=yes", "").strip(), dict(c.signal)))
+    ch[0].extra = (ch[0].extra + " " + _as_switch(8, "samprate=24000")).strip()                       # usb at 12 kHz -> 24 kHz: P 300 -> 600
+    ch[1].extra = (ch[1].extra + " " + _as_switch(10, PRESETS["fm"])).strip()                          # lsb -> the fm preset: another demodulator, another size
+    ch[2].extra = (ch[2].extra + " " + _as_switch(12, PRESETS["cwu"])).strip()                         # -> cwu: same rate and demodulator, new edges + filter2 = 4 appears
+    ch[3].extra = (ch[3].extra + " " + _as_switch(9, PRESETS["usb"]) + " " + _as_switch(21, "samprate=8000")).strip()     # twice: preset, then 8 kHz (P = 200)
+    return ch
