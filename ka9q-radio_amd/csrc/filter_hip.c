@@ -829,6 +829,16 @@ int create_filter_output(struct filter_out *slave, struct filter_in *master, int
       FREE(slave->fdomain); FREE(slave->output_buffer.c); FREE(slave->output_buffer.r); free(sc);
       return -1;
     }
+    if (!real && master->in_type == COMPLEX) {
+      /* likewise the beam form at this index (a reused index may still hold an earlier occupant's; radio.c sets out.beam BEFORE the demodulator creates
+         the filter output, src/radio.c:938-940, and create_filter_output has just reset the weights, src/filter.c:341) */
+      unsigned char const on = slave->beam ? 1 : 0;
+      if (b->beam_on[b->n] != on || on) {
+        double const ab[4] = {creal(slave->alpha), cimag(slave->alpha), creal(slave->beta), cimag(slave->beta)};
+        b->beam_on[b->n] = on; memcpy(b->beam_ab + 4 * b->n, ab, sizeof ab);
+        chz_bank_set_beam(sh->eng, b->id, b->n, 1, ab, &on);
+      }
+    }
     for (int s = 0; s < ND; s++) b->stage_epoch[s][b->n] = 0;
     b->n++; sh->nslaves++;
     slave->rev_plan = (fftwf_plan)(void *)sc;
@@ -868,10 +878,20 @@ int delete_filter_output(struct filter_out *slave) {
       if (!b->real && b->isb[sc->idx] != b->isb[last]) { b->isb[sc->idx] = b->isb[last]; chz_bank_set_isb(sh->eng, b->id, sc->idx, 1, &b->isb[sc->idx]); }
       pthread_mutex_lock(&mv->response_mutex);                     /* (see bank_for) */
       if (mv->response) chz_bank_set_responses(sh->eng, b->id, ms->idx, 1, (const float *)mv->response);
+      double const mv_ab[4] = {creal(mv->alpha), cimag(mv->alpha), creal(mv->beta), cimag(mv->beta)};
       pthread_mutex_unlock(&mv->response_mutex);
+      if (!b->real && slave->master->in_type == COMPLEX) {
+        /* ... and its beam form: the device holds the DELETED slave's flag and weights at this index, and the moved slave's block of this very moment may be
+           re-run there by the miss path before the next execute_filter_input looks at the flags (round 6, found by the reference's own callers: a beam
+           channel leaving handed its beam form to the plain channel that took its index) */
+        unsigned char mv_on = __atomic_load_n((unsigned char const *)&mv->beam, __ATOMIC_RELAXED) ? 1 : 0;
+        b->beam_on[sc->idx] = mv_on; memcpy(b->beam_ab + 4 * sc->idx, mv_ab, sizeof mv_ab);
+        chz_bank_set_beam(sh->eng, b->id, sc->idx, 1, mv_ab, &mv_on);
+      }
       chz_bank_set_shifts(sh->eng, b->id, ms->idx, 1, &b->shift[ms->idx]);
       for (int s = 0; s < ND; s++) b->stage_epoch[s][ms->idx] = 0;
     }
+    b->beam_on[last] = 0xFF;               /* whatever the device holds at the vacated index: "unknown" makes the block that first sees a newcomer there upload its flag */
     b->slaves[last] = NULL; b->n--; sh->nslaves--;
     stage_wrunlock(c);
     pthread_mutex_unlock(&c->lock);

@@ -366,6 +366,11 @@ static int apply_kv(chan_t *chan, struct capture *c, char const *k, char const *
   else if (!strcmp(k, "tone")) chan->fm.tone_freq = fabs(x);
   else if (!strcmp(k, "update")) chan->status.output_interval = abs((int)x);
   else if (!strcmp(k, "filter2")) chan->filter2.blocking = abs((int)x);
+  else if (!strcmp(k, "beam")) chan->filter.beam = truth(v);                                                           /* :547-556: two antennas on I and Q */
+  else if (!strcmp(k, "a-amp")) chan->filter.a_weight = x * (cabs(chan->filter.a_weight) > 0 ? chan->filter.a_weight / cabs(chan->filter.a_weight) : 1.0);
+  else if (!strcmp(k, "a-phase")) chan->filter.a_weight = (cabs(chan->filter.a_weight) > 0 ? cabs(chan->filter.a_weight) : 1.0) * csincospi(x / 180.);
+  else if (!strcmp(k, "b-amp")) chan->filter.b_weight = x * (cabs(chan->filter.b_weight) > 0 ? chan->filter.b_weight / cabs(chan->filter.b_weight) : 1.0);
+  else if (!strcmp(k, "b-phase")) chan->filter.b_weight = (cabs(chan->filter.b_weight) > 0 ? cabs(chan->filter.b_weight) : 1.0) * csincospi(x / 180.);
   else if (!strcmp(k, "rbw")) chan->spectrum.rbw = x;                          /* RESOLUTION_BW / BIN_COUNT / SPECTRUM_AVG of a `control` command (src/radio_status.c:420-470) */
   else if (!strcmp(k, "bins")) chan->spectrum.bin_count = (int)x;
   else if (!strcmp(k, "fft-avg")) chan->spectrum.fft_avg = (int)x;

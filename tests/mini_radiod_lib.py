@@ -437,10 +437,14 @@ FUNCUBE_GEOM = (192e3, 3840, 961)        # a Funcube dongle's COMPLEX 192 kHz fr
 
 
 def funcube_channels():
-    """six channels of a 192 kHz COMPLEX front end (N = 4800 <= 8192: the drop-in's undecided small master, which the first decimating slave turns into an
+    """seven channels of a 192 kHz COMPLEX front end (N = 4800 <= 8192: the drop-in's undecided small master, which the first decimating slave turns into an
     engine), one of them a CW channel whose filter2 = 4 is a real pooled inline master next to it; slowly beating two-tone signals (no AGC knife-edge)"""
     spec = [(4000, 30e3 + 2.1, "usb", ""), (4001, -45e3 - 7.7, "lsb", "encoding=f32le"), (4002, 12e3 + 0.9, "cwu", ""), (4003, -70e3 + 5.3, "iq", ""),
-            (4004, 60e3 - 3.3, "am", ""), (4005, -20e3 + 1.7, "fm", "")]
+            (4004, 60e3 - 3.3, "am", ""), (4005, -20e3 + 1.7, "fm", ""),
+            # two antennas on I and Q (src/modes.c:547-556 -> src/radio.c:938-940 -> the beam form of the gather, src/filter.c:756-775).  NB: demod_thread() sets the weights
+            # BEFORE the demodulator creates the filter output, and create_filter_output() resets them to (1, 0) (src/filter.c:341): what runs is "A input only" with
+            # out.beam set -- in both links alike, which is the point
+            (4006, 45e3 + 4.4, "usb", "beam=yes a-amp=1.0 a-phase=0 b-amp=0.7 b-phase=90")]
     ch, lines = [], []
     for k, (ssrc, f, preset, extra) in enumerate(spec):
         ch.append(Channel(ssrc, f, preset, extra, {"kind": preset}))
@@ -471,3 +475,15 @@ def switch_channels():
     ch[2].extra = (ch[2].extra + " " + _as_switch(12, PRESETS["cwu"])).strip()                         # -> cwu: same rate and demodulator, new edges + filter2 = 4 appears
     ch[3].extra = (ch[3].extra + " " + _as_switch(9, PRESETS["usb"]) + " " + _as_switch(21, "samprate=8000")).strip()     # twice: preset, then 8 kHz (P = 200)
     return ch
+
+
+def beam_handover_channels():
+    """the funcube table with its beam channel created mid-stream (so it is the LAST of its bank), one more plain channel created behind it, and the beam channel
+    leaving before the end: delete_filter_output moves the last slave into the freed index -- where the device still holds the leaver's beam flag and weights
+    (round 6: the plain channel inherited them until the host's record of what is uploaded there was invalidated)"""
+    ch, lines = funcube_channels()
+    beam = ch[-1]
+    beam.extra += " start=3 life=10"
+    ch.append(Channel(4007, -33e3 + 2.2, "usb", "start=6", {"kind": "usb"}))
+    lines += [(-33e3 + 2.2 + 900.0, 0.02, 0.4), (-33e3 + 2.2 + 904.5, 0.006, 1.9)]
+    return ch, lines

@@ -320,7 +320,7 @@ def test_small_complex_front_end_on_the_dropin_host_code(tmp_path):
     A, _, _ = mr.run(mr.REF_EXE, str(tmp_path / "ref"), ch, x, fs, l, m, nb)
     B, meta, _ = mr.run(exe, str(tmp_path / "got"), ch, x, fs, l, m, nb)
     s = mr.compare(A, B, float_tol=1e-6, n0_tol=1e-9)
-    assert int(meta["channels"]) == 6 and s["frames_in_agreement"] == s["frames"] == 5 * nb + nb // 4 and s["data"] == 4 * nb + nb // 4, s
+    assert int(meta["channels"]) == 7 and s["frames_in_agreement"] == s["frames"] == 6 * nb + nb // 4 and s["data"] == 5 * nb + nb // 4, s
 
 
 def _check_switches(fr, nblocks):
@@ -348,6 +348,23 @@ def test_presets_and_sample_rates_changed_on_running_channels_on_the_dropin_host
     _check_switches(A, NBLOCKS)
     s = mr.compare(A, B, float_tol=1e-6, n0_tol=1e-9)
     assert int(meta["commands"]) == 8 and s["frames_in_agreement"] == s["frames"] == 161, s
+
+
+@needs_ref_exe
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="/root/reference absent: the caller objects cannot be linked here")
+def test_a_leaving_beam_channel_does_not_hand_its_beam_form_to_the_slave_that_takes_its_index(tmp_path):
+    """round 6, found by running the reference's callers: when a slave in beam mode (src/radio.c:938-940) was deleted, the slave that took over its bank index was
+    computed with the leaver's beam weights from then on -- the host's record of what is uploaded at that index was stale"""
+    exe = _build_stub_link(str(tmp_path))
+    ch, lines = mr.beam_handover_channels()
+    fs, l, m = mr.FUNCUBE_GEOM
+    nb = 32
+    x = mr.complex_synth(lines, fs, nb * l, 0.002, 5)
+    A, _, _ = mr.run(mr.REF_EXE, str(tmp_path / "ref"), ch, x, fs, l, m, nb)
+    B, meta, _ = mr.run(exe, str(tmp_path / "got"), ch, x, fs, l, m, nb)
+    assert len(A[4006]) == 10 and len(A[4007]) == nb - 6
+    s = mr.compare(A, B, float_tol=1e-6, n0_tol=1e-9)
+    assert int(meta["channels"]) == 8 and s["frames_in_agreement"] == s["frames"], s
 
 
 def _hip_exe():
@@ -547,8 +564,14 @@ def test_small_complex_front_end_through_the_reference_callers():
         with tempfile.TemporaryDirectory() as tmp:
             s, B, meta = _ab(tmp, exe, ch, x, nb, geom=geom, paced=paced)
         print("mini-radiod small complex front end%s A/B on the device:" % (" paced" if paced else ""), s)
-        assert int(meta["channels"]) == 6 and s["frames_in_agreement"] == s["frames"] == 5 * nb + nb // 4
+        assert int(meta["channels"]) == 7 and s["frames_in_agreement"] == s["frames"] == 6 * nb + nb // 4
         assert all(f["block_drops"] == 0 for F in B.values() for f in F)
+    ch, lines = mr.beam_handover_channels()             # the beam channel leaves mid-stream and a plain channel takes its bank index
+    x = mr.complex_synth(lines, geom[0], 32 * geom[1], 0.002, 5)
+    with tempfile.TemporaryDirectory() as tmp:
+        s, B, meta = _ab(tmp, exe, ch, x, 32, geom=geom)
+    print("mini-radiod beam channel leaving A/B on the device:", s)
+    assert int(meta["channels"]) == 8 and s["frames_in_agreement"] == s["frames"] and len(B[4006]) == 10
 
 
 @pytest.mark.gpu
