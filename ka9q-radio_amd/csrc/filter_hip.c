@@ -518,7 +518,9 @@ static void mctx_free(struct mctx *c) {          /* host side (and the communica
 }
 /* KA9Q_HIP_DEVICES="0,1,2" (or the older KA9Q_HIP_DEVICE=n): the devices this master's slaves are spread over.  An entry may
    repeat ("0,0": two engines on one device -- how the sharded path is exercised on a one-GPU box). */
-static int device_list(struct mctx *c) {
+#define SHARD_MIN_POINTS 16384         /* a master of at most this many points -- a demodulator's private sub-filter (wfm's composite: 15,360), a small front end -- is not worth
+                                          spreading: every listed device would copy and transform its every block for a handful of slaves.  It lives on the first device. */
+static int device_list(struct mctx *c, int points) {
   const char *list = getenv("KA9Q_HIP_DEVICES");
   int n = 0;
   if (list && *list) {
@@ -534,6 +536,7 @@ static int device_list(struct mctx *c) {
     if (*q) { fprintf(stderr, "create_filter_input: KA9Q_HIP_DEVICES names more than %d devices\n", MAX_SHARDS); return -1; }
   }
   if (n == 0) { const char *dev = getenv("KA9Q_HIP_DEVICE"); c->sh[0].device = dev ? atoi(dev) : 0; n = 1; }
+  if (n > 1 && points <= SHARD_MIN_POINTS) n = 1;
   return n;
 }
 /* Everything a block does, once, on zeros, before create_filter_input returns: the first launches of the plan's kernels on every
@@ -602,7 +605,7 @@ static int create_input_impl(struct filter_in *master, int const L, int const M,
   struct mctx *c = calloc(1, sizeof *c);
   if (!c) return -1;
   c->kind = CTX_ENGINE;
-  c->nsh = device_list(c);
+  c->nsh = device_list(c, N);
   if (c->nsh < 1) { free(c); return -1; }
   for (int g = 0; g < c->nsh; g++)
     if (chz_engine_create(&c->sh[g].eng, L, M, in_type == REAL ? CHZ_REAL : CHZ_COMPLEX, c->sh[g].device, NULL, 0) != 0) {
@@ -725,10 +728,10 @@ int delete_filter_input(struct filter_in *master) {
     for (int g = 0; g < c->nsh; g++) chz_sync(c->sh[g].eng);
     if (c->profile && c->prof_blocks)
       fprintf(stderr, "filter_hip profile: blocks=%llu input_us=%.1f input_wait_us=%.1f consume_mean_us=%.1f consume_worst_us=%.1f reads=%llu "
-              "hits=%llu misses=%llu skipped=%lu dev_block_max_us_after_8=%.1f consume_worst_after_8_us=%.1f recoveries=%u failed_blocks=%u\n",
+              "hits=%llu misses=%llu skipped=%lu dev_block_max_us_after_8=%.1f consume_worst_after_8_us=%.1f recoveries=%u failed_blocks=%u points=%d devices=%d\n",
               c->prof_blocks, c->prof_input_ns / 1e3 / c->prof_blocks, c->prof_wait_ns / 1e3 / c->prof_blocks,
               c->prof_consume_n ? c->prof_consume_sum_ns / 1e3 / c->prof_consume_n : 0.0, c->prof_consume_max_ns / 1e3, c->prof_consume_n,
-              c->prof_hits, c->prof_misses, c->n_skipped, c->prof_dev_max_ns / 1e3, c->prof_consume_max8_ns / 1e3, c->recoveries, c->failed_blocks);
+              c->prof_hits, c->prof_misses, c->n_skipped, c->prof_dev_max_ns / 1e3, c->prof_consume_max8_ns / 1e3, c->recoveries, c->failed_blocks, master->points, c->nsh);
     if (c->profile && c->prof_blocks) {
       fprintf(stderr, "filter_hip first blocks:");
       for (int j = 0; j < 8 && (unsigned long long)j < c->prof_blocks; j++)

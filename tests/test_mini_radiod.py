@@ -267,6 +267,13 @@ def test_wfm_stereo_decoder_on_the_dropin_host_code(tmp_path):
     _check_wfm(A, NBLOCKS)
     s = mr.check(mr.diff(A, B, settle=WFM_SETTLE), None, float_tol=1e-6, n0_tol=1e-9)
     assert int(meta["channels"]) == 12 and s["frames_in_agreement"] == s["frames"], s
+    # with the master's slaves spread over two (stand-in) devices: the front-end master is, the WFM channels' private composite masters (15,360 points, three
+    # slaves each) are not -- every listed device would copy and transform their every block for nothing (filter_hip.c: SHARD_MIN_POINTS)
+    B, meta, err = mr.run(exe, str(tmp_path / "got2"), ch, x, fs, l, m, NBLOCKS, env={"CHZ_STUB_DEVICES": "2", "KA9Q_HIP_DEVICES": "0,1", "KA9Q_HIP_PROFILE": "1"})
+    prof = [dict(t.split("=") for t in ln.split() if "=" in t) for ln in err.splitlines() if ln.startswith("filter_hip profile:")]
+    assert sorted((int(p["points"]), int(p["devices"])) for p in prof) == [(15360, 1)] * 3 + [(64800, 2)], prof     # (the empty WFM channel never opens its squelch: its composite master never runs a block and prints nothing)
+    s = mr.check(mr.diff(A, B, settle=WFM_SETTLE), None, float_tol=1e-6, n0_tol=1e-9)
+    assert s["frames_in_agreement"] == s["frames"], s
 
 
 @needs_ref_exe
