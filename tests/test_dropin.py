@@ -35,7 +35,7 @@ def _build_harness(out, ref_header=False):
     cmd = ["gcc", "-O2", "-std=gnu11", "-Wall", os.path.join(ROOT, "tests", "c", "dropin_harness.c"), "-o", out,
            "-L", LIBDIR, "-lka9q_filter_hip", "-lchz_hip", "-Wl,-rpath," + LIBDIR, "-lpthread", "-lm"]
     if ref_header:
-        cmd[4:4] = ["-DKA9Q_FILTER_HEADER=\"filter.h\"", "-D_GNU_SOURCE=1", "-I", os.path.join(ROOT, "oracle", "shims"), "-iquote", REF_SRC]
+        cmd[4:4] = ["-DKA9Q_FILTER_HEADER=\"filter.h\"", "-DHARNESS_REF_HEADER=1", "-D_GNU_SOURCE=1", "-I", os.path.join(ROOT, "oracle", "shims"), "-iquote", REF_SRC]
     else:
         cmd[4:4] = ["-I", os.path.join(ROOT, "include")]
     subprocess.run(cmd, check=True)
@@ -196,6 +196,11 @@ def test_dropin_runs_a_caller_built_against_the_reference_header():
                                        env={"HARNESS_REAL": "40 0.0 0.3 5.0", "HARNESS_ISB": "5"})
     plan_chk = [p for i, p in enumerate(plan) if i != 5]                       # (channel 5 is the ISB one: checked in its own test)
     _check(L, M, olen, P, plan_chk, nblocks, np.delete(out, 5, axis=1), spec, meta, x)
+    # [r6] the same caller feeding its samples through the reference header's own inline put_rfilter() (src/filter.h:133-145: sample by sample through the
+    # struct's write pointer and counter, then execute_filter_input() directly -- how ctcss.c, packetd.c, rdsd.c and stereod.c feed their filters)
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 4096, x, exe=exe, env={"HARNESS_PUT": "1"})
+    _check(L, M, olen, P, plan, nblocks, out, spec, meta, x)
 
 
 @pytest.mark.gpu
