@@ -293,6 +293,11 @@ def test_wfm_deletes_its_master_before_its_slaves_without_leaks(tmp_path):
     B, meta, err = mr.run(exe, str(tmp_path / "got"), ch, x, fs, l, m, nb, env={"ASAN_OPTIONS": "detect_leaks=1"})
     assert int(meta["channels"]) == 12 and "AddressSanitizer" not in err and "LeakSanitizer" not in err, err[-3000:]
     _check_wfm(B, nb)
+    # ... and through restarts (a filter output deleted and created again at another size by its own thread) and an undecided small master becoming an engine
+    for name, ch, (fs, l, m), xx in (("switch", mr.switch_channels(), (FS, L, M), None), ("funcube",) + (lambda cl: (cl[0], mr.FUNCUBE_GEOM, cl[1]))(mr.beam_handover_channels())):
+        x = mr.complex_synth(xx, fs, NBLOCKS * l, 0.002, 5) if name == "funcube" else mr.synthesise(ch, fs, l, NBLOCKS, seed=51)
+        B, meta, err = mr.run(exe, str(tmp_path / name), ch, x, fs, l, m, NBLOCKS, env={"ASAN_OPTIONS": "detect_leaks=1"}, timeout=300)
+        assert "AddressSanitizer" not in err and "LeakSanitizer" not in err, (name, err[-3000:])
 
 
 @needs_ref_exe
@@ -306,8 +311,10 @@ def test_reference_callers_on_the_dropin_host_code_under_thread_sanitizer(tmp_pa
         pytest.skip("no -fsanitize=thread runtime in this image")
     exe = _build_stub_link(str(tmp_path), sanitize="thread")
     env = {"TSAN_OPTIONS": "halt_on_error=0 report_signal_unsafe=0 exitcode=0"}
-    for name, ch, (fs, l, m), seed in (("churn", mr.churn_channels(), (FS, L, M), 21), ("wfm", mr.wfm_channels(), mr.WFM_GEOM, 41)):
-        x = mr.synthesise(ch, fs, l, NBLOCKS, seed=seed)        # (the churn table's last channel joins at block 26)
+    fc, fc_lines = mr.beam_handover_channels()
+    for name, ch, (fs, l, m), seed in (("churn", mr.churn_channels(), (FS, L, M), 21), ("wfm", mr.wfm_channels(), mr.WFM_GEOM, 41),
+                                       ("switch", mr.switch_channels(), (FS, L, M), 51), ("funcube", fc, mr.FUNCUBE_GEOM, 5)):
+        x = mr.complex_synth(fc_lines, fs, NBLOCKS * l, 0.002, seed) if name == "funcube" else mr.synthesise(ch, fs, l, NBLOCKS, seed=seed)        # (the churn table's last channel joins at block 26)
         B, meta, err = mr.run(exe, str(tmp_path / name), ch, x, fs, l, m, NBLOCKS, env=env, timeout=600)
         assert "ThreadSanitizer" not in err, (name, err[-4000:])
         assert int(meta["shutdowns"]) == 1
