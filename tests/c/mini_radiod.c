@@ -178,7 +178,8 @@ bool decode_radio_commands(chan_t *chan, uint8_t const *buffer, int length) {
     /* a PRESET (src/radio_status.c:168-181: loadpreset()) / OUTPUT_SAMPRATE (:215-230) / DEMOD_TYPE (:310-319) command, and what the decoder does about it
        afterwards (:613-660): a new sample rate or demodulator asks for a RESTART -- the demodulator returns, demod_thread() deletes the channel's
        filter output and starts the (new) demodulator, which creates one of the new size (src/radio.c:940-985) --, new edges for new filters */
-    int const old_rate = chan->output.samprate, old_demod = chan->demod_type, old_blocking = chan->filter2.blocking;
+    int const old_rate = chan->output.samprate, old_demod = chan->demod_type, old_blocking = chan->filter2.blocking, old_channels = chan->output.channels;
+    bool const old_isb = chan->filter2.out.isb;
     double const old_lo = chan->filter.min_IF, old_hi = chan->filter.max_IF, old_beta = chan->filter.kaiser_beta;
     char *list = strdup(c->sw[(int)e.a]);
     char *save = NULL;                     /* (strtok_r: channel threads decode their commands side by side) */
@@ -189,6 +190,10 @@ bool decode_radio_commands(chan_t *chan, uint8_t const *buffer, int length) {
       if (apply_kv(chan, c, tok, sep + 1) != 0) { fprintf(stderr, "mini_radiod: switch %s~%s\n", tok, sep + 1); abort(); }
     }
     free(list);
+    if (chan->filter2.out.isb && !old_isb) {               /* ISB being turned on (:636-646): stereo output, filter2 forced on */
+      if (old_channels != 2) chan->output.channels = 2;
+      if (chan->filter2.blocking == 0) chan->filter2.blocking = 1;
+    }
     if (chan->output.samprate != old_rate || (int)chan->demod_type != old_demod) {
       /* RESTART.  The new filter output will start at the master's job counter of that moment (src/filter.c:413), i.e. it skips what the front end has written
          meanwhile.  For two links to skip the SAME blocks, the lock-step front end is let run as far ahead as it may (it stops `slack` blocks ahead of the slowest

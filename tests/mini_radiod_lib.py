@@ -474,6 +474,7 @@ def switch_channels():
     ch[1].extra = (ch[1].extra + " " + _as_switch(10, PRESETS["fm"])).strip()                          # lsb -> the fm preset: another demodulator, another size
     ch[2].extra = (ch[2].extra + " " + _as_switch(12, PRESETS["cwu"])).strip()                         # -> cwu: same rate and demodulator, new edges + filter2 = 4 appears
     ch[3].extra = (ch[3].extra + " " + _as_switch(9, PRESETS["usb"]) + " " + _as_switch(21, "samprate=8000")).strip()     # twice: preset, then 8 kHz (P = 200)
+    ch[4].extra = (ch[4].extra + " " + _as_switch(7, "conj=yes")).strip()                               # INDEPENDENT_SIDEBAND on a running usb channel: stereo, filter2 forced on (a pooled inline master appears)
     return ch
 
 

@@ -346,6 +346,7 @@ def _check_switches(fr, nblocks):
     assert all(b["next_jobnum"] - a["next_jobnum"] == 4 for a, b in zip(fr[702][13:], fr[702][14:]))
     assert fr[703][9]["channels"] == 2 and fr[703][10]["channels"] == 1 and fr[703][-1]["olen"] == 160 and len(fr[703]) == nblocks - 2   # iq -> usb (no restart), then 8 kHz
     assert len(fr[704]) == len(fr[705]) == nblocks and all(f["block_drops"] == 0 for F in fr.values() for f in F)
+    assert [f["channels"] for f in fr[704]][6:9] == [1, 1, 2] and fr[704][-1]["nfloat"] == 480                                           # ISB switched on after call 7: stereo out of a filter2 that appears then
 
 
 @needs_ref_exe
@@ -361,7 +362,7 @@ def test_presets_and_sample_rates_changed_on_running_channels_on_the_dropin_host
     B, meta, _ = mr.run(exe, str(tmp_path / "got"), ch, x, FS, L, M, NBLOCKS)
     _check_switches(A, NBLOCKS)
     s = mr.compare(A, B, float_tol=1e-6, n0_tol=1e-9)
-    assert int(meta["commands"]) == 8 and s["frames_in_agreement"] == s["frames"] == 161, s
+    assert int(meta["commands"]) == 9 and s["frames_in_agreement"] == s["frames"] == 161, s
 
 
 @needs_ref_exe
@@ -608,4 +609,4 @@ def test_presets_and_sample_rates_changed_on_running_channels_on_the_mi355x():
         s, B, meta = _ab(tmp, exe, ch, x, NBLOCKS)
     _check_switches(B, NBLOCKS)
     print("mini-radiod preset / sample-rate changes A/B on the device:", s)
-    assert int(meta["commands"]) == 8 and s["frames_in_agreement"] == s["frames"] == 161
+    assert int(meta["commands"]) == 9 and s["frames_in_agreement"] == s["frames"] == 161
