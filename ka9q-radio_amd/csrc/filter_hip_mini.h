@@ -163,7 +163,7 @@ static int mini_create_output(struct filter_out *slave, struct filter_in *master
   }
   sc->kind = CTX_MSLAVE; sc->pool = p; sc->inst = inst;
   ((struct minictx *)(void *)master->fwd_plan)->nslaves++;
-  ((struct minictx *)(void *)master->fwd_plan)->decided = true;
+  __atomic_store_n(&((struct minictx *)(void *)master->fwd_plan)->decided, true, __ATOMIC_RELEASE);      /* (read without the mutex by execute_filter_input) */
   memset(buf, 0, sizeof(float complex) * (size_t)master->points);
   slave->bins = master->points;                                    /* src/filter.c:346 */
   slave->fdomain = fdom;
