@@ -57,6 +57,9 @@ typedef struct chz_timing {
 } chz_timing;
 
 const char *chz_last_error(void);
+/* 1 once the process has begun to exit (exit() called: radiod's closedown(), src/main.c): the library has stopped issuing work to the HIP runtime, whose own exit
+ * handlers are about to tear it down, and every call reports -98 from then on -- not a device failure, nothing to recover (round 6) */
+int chz_process_exiting(void);
 /* Options (round 6): dispatch thresholds and test hooks, process-wide, read when an engine / communicator is CREATED.  The shipped
  * library reads only the operator's environment variables; everything a test or an A/B script used to set
  * through CHZ_* variables is set here instead.  value NULL or "" = back to the default.  Names: chan_stage, noise_energy, demod_wave

@@ -26,6 +26,28 @@
 #include <vector>
 #include <thread>
 #include <cmath>
+#include <unistd.h>
+// ---- the process is exiting ---------------------------------------------------------------------------------------------------------------------
+// radiod ends through exit() from a signal handler's closedown() (src/main.c) without deleting a single filter: its front-end thread is still handing over
+// blocks, and channel threads still ask for re-runs, while the HIP runtime's own exit handlers tear it down -- a kernel launched into that dies inside
+// libamdhip64 (round 6: a segmentation fault at every shutdown, tests/c/exit_midstream.c).  chz_exit::at_exit is registered (atexit) by the first engine, i.e.
+// AFTER the runtime has registered whatever it runs at exit, so it runs BEFORE: it raises `exiting` and waits (bounded) for the runtime calls in flight to
+// return; from then on every runtime call and kernel launch of this library is skipped and its API reports -98.
+namespace chz_exit {
+static std::atomic<int> exiting{0};
+static std::atomic<long> inflight{0};
+struct Scope {
+  bool ok;
+  Scope() { inflight.fetch_add(1, std::memory_order_seq_cst); ok = exiting.load(std::memory_order_seq_cst) == 0; }
+  ~Scope() { inflight.fetch_sub(1, std::memory_order_release); }
+};
+static void at_exit() {
+  exiting.store(1, std::memory_order_seq_cst);
+  for (int i = 0; i < 20000 && inflight.load(std::memory_order_acquire) > 0; i++) usleep(100);      // <= 2 s
+}
+static void arm() { static std::once_flag once; std::call_once(once, [] { std::atexit(at_exit); }); }
+}  // namespace chz_exit
+#define CHZ_EXIT_SCOPE(name) chz_exit::Scope name
 #include "chz_launch.h"
 #include "chz_finetune.h"
 #include "../../include/chz_engine.h"
@@ -37,7 +59,7 @@ static int fail(int code, const char* fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
   return code;
 }
-#define HIPOK(call) do { hipError_t _e = (call); if (_e != hipSuccess) \
+#define HIPOK(call) do { chz_exit::Scope _xs; if (!_xs.ok) return fail(-98, "the process is exiting"); hipError_t _e = (call); if (_e != hipSuccess) \
   return fail(-10, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
 
 #define CHZ_MAX_LANES 4
@@ -282,6 +304,7 @@ static void free_bank(Bank& b) {
 
 extern "C" {
 
+int chz_process_exiting(void) { return chz_exit::exiting.load(std::memory_order_acquire); }
 const char* chz_last_error(void) { return g_err; }
 
 int chz_device_count(void) {
@@ -407,6 +430,8 @@ int chz_engine_create(chz_engine** out, int L, int M, int in_type, int device, c
     return fail(-2, "no HIP device: the channelizer engine has no CPU fallback");
   if (device < 0 || device >= ndev) return fail(-2, "device %d out of range (%d devices)", device, ndev);
   HIPOK(hipSetDevice(device));
+  { void* probe = nullptr; HIPOK(hipMalloc(&probe, 256)); HIPOK(hipFree(probe)); }      // (the runtime is fully up -- and has registered its own exit handlers -- ...)
+  chz_exit::arm();                                          // ... before this library registers the one that must run ahead of them
   const int N = L + M - 1;                                  // src/filter.c:196
   const int bins = in_type == CHZ_COMPLEX ? N : N / 2 + 1;  // src/filter.c:197
   if (bins < 2) return fail(-1, "transform too small");     // src/filter.c:198-199
@@ -574,7 +599,7 @@ int chz_engine_info(const chz_engine* e, chz_info* info) {
 }
 
 int chz_engine_set_stream(chz_engine* e, void* hip_stream) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e) return fail(-1, "null engine");
   int r = sync_all(e);
   if (r) return r;
@@ -597,7 +622,7 @@ static int check_device_errors(const chz_engine* e) {
   return 0;
 }
 static int sync_all(chz_engine* e) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   for (int i = 0; i < e->nlanes; i++) HIPOK(hipStreamSynchronize(e->lanes[i].s));
   if (e->tail) HIPOK(hipStreamSynchronize(e->tail));
   if (e->pcmcopy) HIPOK(hipStreamSynchronize(e->pcmcopy));
@@ -617,7 +642,7 @@ int chz_engine_check(const chz_engine* e) {
 }
 
 static int ring_write(chz_engine* e, const float* src, long n, hipMemcpyKind kind) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (e->ring16) return fail(-1, "int16 and float input cannot be mixed on one engine");
   const long nf = n * e->per;
   if (nf < 0 || nf > e->ring_len) return fail(-1, "write of %ld samples does not fit the ring", n);
@@ -675,7 +700,7 @@ int chz_input_write_i16_device(chz_engine* e, const short* dev, long n, float sc
 }
 // sum of x^2 and number of clipped samples over the L new samples of the block last transformed into `slot`
 int chz_input_stats(chz_engine* e, int slot, unsigned long long* energy, unsigned* clips) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   if (!e->ring16) return fail(-1, "input statistics exist for int16 input only");
   std::vector<unsigned long long> en((size_t)e->stat_n); std::vector<unsigned> cl((size_t)e->stat_n);
@@ -709,14 +734,14 @@ int chz_input_seek(chz_engine* e, unsigned job, const float* history) {
   return 0;
 }
 int chz_input_mark(chz_engine* e, int k) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || k < 0 || k >= CHZ_INPUT_MARKS) return fail(-1, "bad argument");
   if (!e->input_mark[k]) HIPOK(hipEventCreateWithFlags(&e->input_mark[k], hipEventDisableTiming));
   HIPOK(hipEventRecord(e->input_mark[k], e->stream));
   return 0;
 }
 int chz_input_mark_wait(chz_engine* e, int k) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || k < 0 || k >= CHZ_INPUT_MARKS) return fail(-1, "bad argument");
   if (e->input_mark[k]) HIPOK(hipEventSynchronize(e->input_mark[k]));
   return 0;
@@ -1226,7 +1251,7 @@ int chz_forward(chz_engine* e, unsigned job) {
 
 // notch list as radio.c builds it (src/radio.c:601-620), one averager gain per entry (src/filter.c:468)
 int chz_set_notches_alpha(chz_engine* e, const int* bins, const double* alpha, int n) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e) return fail(-1, "null engine");
   { int r = sync_all(e); if (r) return r; }
   drop_graph(e);
@@ -1297,7 +1322,7 @@ static int copy_spectrum(chz_engine* e, int slot, float* host, hipStream_t st) {
 }
 
 int chz_spectrum_read(chz_engine* e, int slot, float* host) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || !host || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   hipStream_t st = slot_stream(e, slot);          // the lane that produced this slot
   int r = copy_spectrum(e, slot, host, st);
@@ -1554,7 +1579,7 @@ int chz_bank_read_noise(chz_engine* e, int bank, int slot, int ch0, int n, doubl
   return read_doubles(e, bank, e->banks[(size_t)bank].n0, slot, ch0, n, host, true, "noise estimation is off: call chz_bank_enable_noise first");
 }
 int chz_bank_read_noise_async(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, ch0, n);
   return read_doubles(e, bank, e->banks[(size_t)bank].n0, slot, ch0, n, host, false, "noise estimation is off: call chz_bank_enable_noise first");
 }
@@ -1564,7 +1589,7 @@ int chz_bank_read_power(chz_engine* e, int bank, int slot, int ch0, int n, doubl
   return read_doubles(e, bank, e->banks[(size_t)bank].power, slot, ch0, n, host, true, "bank has no tuning: call chz_bank_set_tuning first");
 }
 int chz_bank_read_power_async(chz_engine* e, int bank, int slot, int ch0, int n, double* host) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, ch0, n);
   return read_doubles(e, bank, e->banks[(size_t)bank].power, slot, ch0, n, host, false, "bank has no tuning: call chz_bank_set_tuning first");
 }
@@ -1807,7 +1832,7 @@ int chz_bank_pcm_stride(chz_engine* e, int bank) {
 // rows of exactly the size the bank's encodings need (480 B for 12 kHz mono S16) make the device-to-host copy of a block's
 // PCM one contiguous transfer of only the bytes that matter; before the first chz_bank_set_demod
 int chz_bank_set_pcm_stride(chz_engine* e, int bank, int bytes) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, 0, 0);
   Bank& b = e->banks[(size_t)bank];
   if (b.dm_chan) return fail(-1, "the PCM row size is fixed once demodulators exist");
@@ -1834,7 +1859,7 @@ static int read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm
 // the per-block essentials only: PCM + one flag byte per channel (the full status record is 96 bytes; a host that ships
 // audio reads it when somebody asks, not 50 times a second for every channel)
 int chz_bank_read_pcm_flags_async(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm, unsigned char* flags) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, ch0, n);
   if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
   Bank& b = e->banks[(size_t)bank];
@@ -1850,7 +1875,7 @@ int chz_bank_read_pcm_flags_async(chz_engine* e, int bank, int slot, int ch0, in
   return 0;
 }
 int chz_bank_pcm_wait(chz_engine* e, int bank, int slot) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, 0, 0);
   if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
   Bank& b = e->banks[(size_t)bank];
@@ -1862,7 +1887,7 @@ int chz_bank_read_pcm(chz_engine* e, int bank, int slot, int ch0, int n, void* p
   return read_pcm(e, bank, slot, ch0, n, pcm, status, true);
 }
 int chz_bank_read_pcm_async(chz_engine* e, int bank, int slot, int ch0, int n, void* pcm, chz_demod_status* status) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   return read_pcm(e, bank, slot, ch0, n, pcm, status, false);
 }
 int chz_bank_set_active(chz_engine* e, int bank, int n) {
@@ -1888,7 +1913,7 @@ int chz_bank_execute_range(chz_engine* e, int bank, unsigned job, int ch0, int n
   return 0;
 }
 int chz_bank_destroy(chz_engine* e, int bank) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, 0, 0);
   Bank& b = e->banks[(size_t)bank];
   { int r = sync_all(e); if (r) return r; }
@@ -1897,7 +1922,7 @@ int chz_bank_destroy(chz_engine* e, int bank) {
   return 0;
 }
 int chz_bank_read_async(chz_engine* e, int bank, int slot, int ch0, int n, float* host) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, ch0, n);
   if (slot < 0 || slot >= CHZ_ND) return fail(-1, "bad slot");
   Bank& b = e->banks[(size_t)bank];
@@ -1907,18 +1932,18 @@ int chz_bank_read_async(chz_engine* e, int bank, int slot, int ch0, int n, float
   return 0;
 }
 int chz_spectrum_read_async(chz_engine* e, int slot, float* host) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || !host || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   return copy_spectrum(e, slot, host, slot_stream(e, slot));
 }
 int chz_host_callback(chz_engine* e, int slot, void (*fn)(void*), void* arg) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || !fn || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   HIPOK(hipLaunchHostFunc(slot_stream(e, slot), fn, arg));
   return 0;
 }
 int chz_slot_sync(chz_engine* e, int slot) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   if (!e || slot < 0 || slot >= CHZ_ND) return fail(-1, "bad argument");
   HIPOK(hipStreamSynchronize(slot_stream(e, slot)));
   return 0;
@@ -1937,7 +1962,7 @@ int chz_host_register(void* p, size_t bytes) {
 }
 void chz_host_unregister(void* p) { if (p) (void)hipHostUnregister(p); }
 int chz_bank_read(chz_engine* e, int bank, int ch0, int n, float* host) {
-  if (e) (void)hipSetDevice(e->device);        // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
+  if (e) { chz_exit::Scope _xd; if (_xd.ok) (void)hipSetDevice(e->device); }       // several engines of one process may sit on different devices (KA9Q_HIP_DEVICES)
   BANK_CHECK(e, bank, ch0, n);
   Bank& b = e->banks[(size_t)bank];
   hipStream_t st = slot_stream(e, b.last_slot);

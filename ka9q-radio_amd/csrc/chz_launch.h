@@ -13,8 +13,15 @@ namespace chz {
 // Plain launch, or -- when an event pair is supplied -- hipExtLaunchKernelGGL, whose events carry
 // the dispatch packet's own begin/end timestamps (the same clock rocprofv3 --kernel-trace reads), so
 // per-kernel times measured in-process agree with the profiler.
+// CHZ_EXIT_SCOPE: the engine library (chz_engine.hip) stops issuing work to the runtime once the process has begun to exit -- see chz_exit there.
+// Other includers (the CPU emulation of the tests) launch unconditionally.
+#ifndef CHZ_EXIT_SCOPE
+#define CHZ_EXIT_SCOPE(name) struct { bool ok; } name = {true}
+#endif
 #define CHZ_LAUNCH(kern, grid, block, lds, s, ev0, ev1, p)                                              \
   do {                                                                                                  \
+    CHZ_EXIT_SCOPE(_xs);                                                                                \
+    if (!_xs.ok) break;                                                                                 \
     if ((ev0) || (ev1)) hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (unsigned)(lds), s, (ev0), (ev1), 0, p); \
     else hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, s, p);                                \
   } while (0)

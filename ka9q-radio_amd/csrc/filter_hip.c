@@ -944,6 +944,7 @@ static void die_for_the_supervisor(const char *why) {
   _exit(EX_SOFTWARE);
 }
 static void recover_engine(struct mctx *c, struct filter_in *f, unsigned job) {
+  if (chz_process_exiting()) return;       /* not a device failure: the library has stopped working because the process is on its way out */
   char why[200] = "";
   for (int g = 0; g < c->nsh && !why[0]; g++)                      /* (chz_last_error is per thread: ask again from this one) */
     if (chz_engine_check(c->sh[g].eng) != 0) snprintf(why, sizeof why, "device %d: %s", c->sh[g].device, chz_last_error());
@@ -1031,6 +1032,9 @@ int execute_filter_input(struct filter_in *const f) {
     }
     if (is_mini_master(f)) return mini_execute_input(f);
   }
+  /* radiod ends through exit() with its front-end thread still running (src/main.c: closedown()): once the process has begun to exit the engine library issues
+     nothing more to the runtime -- this block is nobody's any more (chz_process_exiting, include/chz_engine.h) */
+  if (chz_process_exiting()) return 0;
   struct mctx *c = MCTX(f);
   /* Everything below is asynchronous, so the producer must not run more than ND blocks ahead of the device: block
      job-ND owns this job's completion record, spectrum slot, staged outputs and host-ring window until its callback has
@@ -1432,6 +1436,7 @@ int execute_filter_output(struct filter_out *const slave, int const shift) {
   }
 
   if (slave->out_type == SPECTRUM || slave->rev_plan == NULL) return 0;   /* block clock only */
+  if (chz_process_exiting()) return 0;                                    /* (see execute_filter_input) */
   pthread_mutex_lock(&slave->response_mutex);
   bool const real_out = slave->out_type == REAL;
   void *const dst = real_out ? (void *)slave->output.r : (void *)slave->output.c;

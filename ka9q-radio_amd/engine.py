@@ -51,7 +51,7 @@ PCM_S16BE, PCM_S16LE, PCM_F32LE, PCM_F32BE, PCM_MULAW, PCM_ALAW, PCM_F16LE, PCM_
 
 # every symbol include/chz_engine.h declares (checked by tests/test_host_logic.py and __graft_entry__.build())
 SYMBOLS = [
-    "chz_last_error", "chz_device_count", "chz_engine_create", "chz_engine_destroy", "chz_engine_info",
+    "chz_last_error", "chz_process_exiting", "chz_device_count", "chz_engine_create", "chz_engine_destroy", "chz_engine_info",
     "chz_engine_set_stream", "chz_sync", "chz_input_write", "chz_input_write_device", "chz_input_ring",
     "chz_forward", "chz_slot_stream", "chz_set_notches", "chz_spectrum_read", "chz_spectrum_device", "chz_spectrum_attach",
     "chz_bank_create", "chz_bank_create_shared", "chz_bank_set_rows", "chz_bank_set_row_responses", "chz_bank_set_responses", "chz_bank_set_shifts", "chz_bank_set_active",

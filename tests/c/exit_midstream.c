@@ -3,6 +3,8 @@
  * under it must let that happen: no hang in a destructor, no crash.  This program does exactly that on the drop-in: a front-end thread at wall-clock pace, `nch`
  * channel threads, exit(0) from the main thread after `ms` milliseconds.      usage: exit_midstream [nch] [ms] */
 #include <complex.h>
+#include <execinfo.h>
+#include <signal.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -14,6 +16,7 @@
 static struct filter_in Master;
 enum { L = 259200, M = 64801 };                 /* 12.96 MS/s real, 20 ms blocks */
 
+static void on_segv(int sig) { void *bt[48]; int n = backtrace(bt, 48); fprintf(stderr, "exit_midstream: signal %d\n", sig); backtrace_symbols_fd(bt, n, 2); _exit(70); }
 static void *front_end(void *arg) {
   (void)arg;
   unsigned seed = 1;
@@ -36,6 +39,7 @@ static void *channel(void *arg) {
 }
 int main(int argc, char **argv) {
   int const nch = argc > 1 ? atoi(argv[1]) : 256, ms = argc > 2 ? atoi(argv[2]) : 500;
+  signal(SIGSEGV, on_segv); signal(SIGABRT, on_segv);
   if (create_filter_input(&Master, L, M, REAL) != 0) { fprintf(stderr, "create_filter_input failed\n"); return 2; }
   pthread_t t;
   for (long k = 0; k < nch; k++) pthread_create(&t, NULL, channel, (void *)k);

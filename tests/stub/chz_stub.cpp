@@ -71,6 +71,7 @@ static std::atomic<int> g_instances{0};     // engines created by this process s
 extern "C" {
 
 const char* chz_last_error(void) { return g_err; }
+int chz_process_exiting(void) { return 0; }
 int chz_set_option(const char*, const char*) { return 0; }      /* the stand-in has no dispatch to steer */
 // CHZ_STUB_DEVICES=n: the stand-in reports n devices (the drop-in's KA9Q_HIP_DEVICES sharding runs over n independent engines)
 int chz_device_count(void) { const char* v = getenv("CHZ_STUB_DEVICES"); const int n = v ? atoi(v) : 1; return n > 0 ? n : 1; }

@@ -687,6 +687,23 @@ def test_dropin_cold_start_at_full_rate(nthreads):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nch,ms", [(64, 300), (1024, 500)])
+def test_dropin_survives_exit_with_everything_running(nch, ms, tmp_path):
+    """radiod ends through exit() from its signal handler's closedown() (src/main.c) without deleting a filter: the front-end thread is still handing over blocks
+    and the channel threads sit in execute_filter_output() while the exit handlers run.  Round 6: the HIP runtime's own exit handlers tore it down under the
+    engine's next kernel launch -- a segmentation fault inside libamdhip64 at every shutdown.  The engine library now registers an exit handler AFTER the runtime's
+    (so it runs before), stops issuing work and waits for the calls in flight (chz_engine.hip: chz_exit; include/chz_engine.h: chz_process_exiting)."""
+    _build_lib()
+    exe = str(tmp_path / "exit_midstream")
+    subprocess.run(["gcc", "-O1", "-g", "-rdynamic", "-std=gnu11", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "exit_midstream.c"), "-o", exe,
+                    "-L", LIBDIR, "-lka9q_filter_hip", "-lchz_hip", "-Wl,-rpath," + LIBDIR, "-lpthread", "-lm"], check=True)
+    for attempt in range(3):                       # (where in a block the exit lands is a matter of timing: three tries at it)
+        r = subprocess.run([exe, str(nch), str(ms + 7 * attempt)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "signal" not in r.stderr and "device-side failure" not in r.stderr, (r.returncode, r.stderr[-1500:])
+        assert "leaving through exit()" in r.stderr
+
+
+@pytest.mark.gpu
 def test_dropin_two_shards_on_one_device():
     """KA9Q_HIP_DEVICES=0,0: the sharded drop-in on the one GPU of this box -- two engines, every block's samples copied to and
     transformed by both, the 24 slaves split 12 / 12 in creation order, a block complete when both engines have called back.
