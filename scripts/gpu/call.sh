@@ -9,6 +9,12 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 B="python bench.py --steps 20 --warmup 5"
 case "$name" in
+  r6y)       # round 6: the driver's bench command alone (the committed record: profiles re-collected on the final kernel sources first)
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$out/smoke.txt" 2>&1; tail -1 "$out/smoke.txt"
+    timeout 600 $B > "$out/bench_stdout.txt" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/rc.txt"
+    tail -n 1 "$out/bench_stdout.txt" > "$out/bench_headline.json"; cp gpurun_out/bench_detail.json "$out/bench_detail.json" 2>/dev/null
+    wc -c "$out/bench_headline.json"; cat "$out/rc.txt"
+    ;;
   r6x)       # round 6, final tree: the GPU tier three times in a row on one box (flakiness of the new mini-radiod tables), then the mini-radiod file five more times
     for i in 1 2 3; do timeout 900 python -m pytest tests -m gpu -q --timeout 600 -x -p no:cacheprovider > "$out/suite_$i.txt" 2>&1; echo "suite $i rc=$? $(tail -1 $out/suite_$i.txt)" | tee -a "$out/rc.txt"; done
     for i in 1 2 3 4 5; do timeout 300 python -m pytest tests/test_mini_radiod.py -m gpu -q --timeout 200 -x -p no:cacheprovider > "$out/mr_$i.txt" 2>&1; echo "mini-radiod $i rc=$? $(tail -1 $out/mr_$i.txt)" | tee -a "$out/rc.txt"; done
