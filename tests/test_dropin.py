@@ -204,6 +204,30 @@ def test_dropin_runs_a_caller_built_against_the_reference_header():
 
 
 @pytest.mark.gpu
+def test_dropin_packetd_style_analytic_filter():
+    """the shape packetd.c gives its AFSK decoder (src/packetd.c:52-53,492-497): a small REAL master (L = 960, M = 961: N = 1920) with ONE COMPLEX slave of the SAME
+    block size (P = N: an analytic, band-limited signal at the full rate -- the upper half of the slave's bins lies beyond the real master's Nyquist bin and is
+    zero-filled), fed sample by sample through the reference header's put_rfilter(); stereod.c / rdsd.c / ctcss.c use the same producer on their own small
+    masters.  The caller is compiled against the reference's OWN filter.h."""
+    _build_lib(); ol.build()
+    exe = PREBUILT_REF_HARNESS
+    if os.path.isdir(REF_SRC):
+        build_ref_header_harness()
+    if not os.path.exists(exe):
+        pytest.fail("tests/c/_prebuilt/harness_refhdr is missing: __graft_entry__.build() makes it where /root/reference exists")
+    L, M, olen = 960, 961, 960
+    N = L + M - 1
+    nblocks = 12
+    rng = np.random.default_rng(17)
+    x = (0.2 * rng.standard_normal(nblocks * L)).astype(np.float32)
+    lo, hi = (1200.0 - 300.0) / 48000.0, (2200.0 + 300.0) / 48000.0               # packetd's pass band: mark / space tones -+ a quarter of the bit rate
+    plan = [(0, 0, 10 ** 6, 10 ** 6, lo, hi, 3.0, lo, hi), (0, 0, 10 ** 6, 10 ** 6, -0.3, 0.3, 3.0, -0.3, 0.3), (40, -40, 5, 10 ** 6, lo, hi, 3.0, lo, hi)]
+    with tempfile.TemporaryDirectory() as tmp:
+        out, spec, meta = _run_harness(tmp, L, M, ol.REAL, olen, plan, nblocks, 960, x, exe=exe, env={"HARNESS_PUT": "1"})
+    _check(L, M, olen, N, plan, nblocks, out, spec, meta, x)
+
+
+@pytest.mark.gpu
 def test_dropin_device_noise_estimate_and_no_spectrum_copy():
     """include/ka9q_filter_hip_ext.h: with KA9Q_HIP_FDOMAIN=0 nothing is copied to master->fdomain[], and what estimate_noise()
     (src/radio.c:1783-1866) would have computed from it on the host comes from the device per channel and block -- equal to the
