@@ -382,6 +382,26 @@ def test_a_leaving_beam_channel_does_not_hand_its_beam_form_to_the_slave_that_ta
     assert int(meta["channels"]) == 8 and s["frames_in_agreement"] == s["frames"], s
 
 
+@needs_ref_exe
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="/root/reference absent: the caller objects cannot be linked here")
+def test_a_device_failure_under_the_reference_callers(tmp_path):
+    """the stand-in engine reports a failed device-side check at block 10 (CHZ_STUB_FAIL_JOB) while 48 channel threads of the reference's own code run: the drop-in
+    replaces its engine, the blocks in flight are counted drops (zeros, src/filter.c:690-701), every thread keeps its frame count and carries on -- no hang,
+    no crash, and the stateless channels are back on the reference link's samples a few blocks later"""
+    exe = _build_stub_link(str(tmp_path))
+    ch = mr.standard_channels()
+    x = mr.synthesise(ch, FS, L, NBLOCKS)
+    A, _, _ = _reference_run(str(tmp_path), ch, x)
+    B, meta, err = mr.run(exe, str(tmp_path / "got"), ch, x, FS, L, M, NBLOCKS, env={"CHZ_STUB_FAIL_JOB": "10"}, timeout=300)
+    assert "re-creating the engine" in err and int(meta["shutdowns"]) == 1
+    assert sorted(B) == sorted(A) and all(len(B[k]) == len(A[k]) for k in A)
+    drops = {F[-1]["block_drops"] for F in B.values()}
+    assert drops <= {1, 2, 3} and 2 in drops, drops
+    # an FM channel on noise and a squelched channel carry no state across the gap: identical frames again by block 20
+    for k in (142, 107):
+        assert all(a["isnull"] == b["isnull"] and a["mute"] == b["mute"] for a, b in zip(A[k][20:], B[k][20:]))
+
+
 def _hip_exe():
     if os.path.isdir(REF_SRC):          # (this container: rebuild if the sources or the libraries changed; the GPU box runs what travelled)
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), "all"], check=True)
