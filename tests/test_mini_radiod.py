@@ -402,6 +402,23 @@ def test_a_device_failure_under_the_reference_callers(tmp_path):
         assert all(a["isnull"] == b["isnull"] and a["mute"] == b["mute"] for a, b in zip(A[k][20:], B[k][20:]))
 
 
+@needs_ref_exe
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="/root/reference absent: the caller objects cannot be linked here")
+@pytest.mark.parametrize("env", [{"CHZ_STUB_DEVICES": "2", "KA9Q_HIP_DEVICES": "0,1", "KA9Q_HIP_SHARD_CHANNELS": "7"},
+                                 {"CHZ_STUB_DEVICES": "3", "KA9Q_HIP_DEVICES": "0,1,2", "KA9Q_HIP_SHARD_CHANNELS": "5", "KA9Q_HIP_EXCHANGE": "broadcast"}], ids=["two_devices_samples", "three_devices_broadcast"])
+def test_sharded_master_under_the_reference_callers(tmp_path, env):
+    """the front-end master's slaves spread over two / three stand-in devices a handful at a time (so that joiners, leavers and restarted channels land on every
+    device and "where the fewest live" decides), both exchanges: channels joining and leaving, presets and sample rates changed on running channels, the 48-channel
+    table -- every frame the reference link's"""
+    exe = _build_stub_link(str(tmp_path))
+    for name, ch, seed in (("churn", mr.churn_channels(), 21), ("switch", mr.switch_channels(), 51), ("standard", mr.standard_channels(), 5)):
+        x = mr.synthesise(ch, FS, L, NBLOCKS, seed=seed)
+        A, _, _ = mr.run(mr.REF_EXE, str(tmp_path / ("ref_" + name)), ch, x, FS, L, M, NBLOCKS)
+        B, meta, _ = mr.run(exe, str(tmp_path / ("got_" + name)), ch, x, FS, L, M, NBLOCKS, env=env)
+        s = mr.compare(A, B, float_tol=1e-6, n0_tol=1e-9)
+        assert s["frames_in_agreement"] == s["frames"], (name, s)
+
+
 def _hip_exe():
     if os.path.isdir(REF_SRC):          # (this container: rebuild if the sources or the libraries changed; the GPU box runs what travelled)
         subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "c"), "all"], check=True)
