@@ -647,3 +647,16 @@ def test_presets_and_sample_rates_changed_on_running_channels_on_the_mi355x():
     _check_switches(B, NBLOCKS)
     print("mini-radiod preset / sample-rate changes A/B on the device:", s)
     assert int(meta["commands"]) == 9 and s["frames_in_agreement"] == s["frames"] == 161
+
+
+@pytest.mark.gpu
+def test_sharded_master_under_churn_and_preset_changes_on_the_mi355x():
+    """KA9Q_HIP_DEVICES=0,0 with seven slaves per shard at a time: joiners, leavers and restarted channels land on both engines of the one device while the reference's
+    own threads run -- channels joining / leaving, presets and sample rates changed on running channels, the 48-channel table: every frame against the reference link"""
+    exe = _hip_exe()
+    env = {"KA9Q_HIP_DEVICES": "0,0", "KA9Q_HIP_SHARD_CHANNELS": "7"}
+    for name, ch, seed in (("churn", mr.churn_channels(), 21), ("switch", mr.switch_channels(), 51), ("standard", mr.standard_channels(), 5)):
+        x = mr.synthesise(ch, FS, L, NBLOCKS, seed=seed)
+        with tempfile.TemporaryDirectory() as tmp:
+            s, B, meta = _ab(tmp, exe, ch, x, NBLOCKS, env=env)
+        assert s["frames_in_agreement"] == s["frames"], (name, s)
